@@ -1,0 +1,132 @@
+/*
+ * mods_hip.h — C ABI of libmodsgpu.so, the MI355X (gfx950) implementation of the
+ * detect -> describe -> match -> verify hot path of MODS (ducha-aiki/mods-light-zmq).
+ *
+ * Plain pointers and sizes only.  Every entry point names the reference interface it
+ * replaces (file:line relative to the reference root); INTEGRATION.md shows the binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - images: row-major fp32, single channel, `stride` in elements (the reference passes
+ *     contiguous CV_32FC1 cv::Mat, imagerepresentation.cpp:293-302).
+ *   - all functions return 0 on success, a negative MODS_E_* code otherwise; nothing is
+ *     computed on the CPU when the GPU is missing (MODS_E_NODEVICE).
+ *   - `*_dev` variants take device pointers (HBM resident inputs/outputs); the others take
+ *     host pointers and stage through the context's pinned buffers.
+ */
+#ifndef MODS_HIP_H
+#define MODS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MODS_OK 0
+#define MODS_E_NODEVICE (-1)   /* no HIP device / extension unusable: never falls back to CPU */
+#define MODS_E_ARG (-2)
+#define MODS_E_CAPACITY (-3)   /* an output or internal list overflowed its capacity */
+#define MODS_E_HIP (-4)        /* a HIP runtime call failed; see mods_last_error() */
+
+typedef struct mods_ctx mods_ctx;
+
+/* [HessianAffine] keys of the .ini (io_mods.cpp:167-207) = PyramidParams + AffineShapeParams
+ * (detectors/structures.hpp:114-150, detectors/affinedetectors/affine.h:26-68). */
+typedef struct mods_hessaff_params {
+  int numberOfScales;          /* 3 */
+  float initialSigma;          /* 1.6 */
+  float threshold;             /* 5.33 */
+  float edgeEigenValueRatio;   /* 10 */
+  int border;                  /* 5 */
+  int maxIterations;           /* max_iter = 16 */
+  float convergenceThreshold;  /* 0.05 */
+  int smmWindowSize;           /* 19 */
+  int doBaumberg;              /* 1 */
+} mods_hessaff_params;
+
+/* AffineKeypoint (detectors/structures.hpp:185-195) + provenance of the pyramid hit. */
+typedef struct mods_affkey {
+  double x, y, s, a11, a12, a21, a22, response;
+  int sub_type;                /* 0 dark, 1 bright, 2 saddle (pyramid.h:33-36) */
+  int octave, level, r0, c0;   /* NMS cell that produced the point */
+  int pad;
+} mods_affkey;
+
+/* pyramid localisation result before affine adaptation (pyramid.cpp:281-403) */
+typedef struct mods_candidate {
+  int octave, level, r0, c0, r, c;
+  float x, y, s, pixelDistance, response;
+  int type;
+} mods_candidate;
+
+/* AffineRegion subset that travels through orientation/description/matching
+ * (detectors/structures.hpp:214-229): det_kp == reproj_kp for the identity view. */
+typedef struct mods_region {
+  double x, y, s, a11, a12, a21, a22, response;
+  int sub_type;
+  int id, parent;
+  int pad;
+  uint8_t desc[128];           /* RootSIFT, integer valued 0..255 (siftdesc.cpp:199-222) */
+} mods_region;
+
+/* TentativeCorrespExt subset (matching/matching.hpp:39-51) */
+typedef struct mods_tentative {
+  int q, t;                    /* first / second: indices into the query and train lists */
+  int t_bad, t_2nd;            /* secondbad / secondbadby2ndcl */
+  float d1, d2, d2nd;          /* squared L2 distances */
+  float pad;
+  double ratio;                /* sqrt(d1/d2) */
+} mods_tentative;
+
+/* ---- context ------------------------------------------------------------------------ */
+const char *mods_last_error(void);
+int mods_device_count(void);
+/* One context = one GPU, one stream set, one pool of HBM scratch sized for images up to
+ * max_w x max_h and `batch` images per call. */
+int mods_ctx_create(int device, int max_w, int max_h, int batch, mods_ctx **out);
+void mods_ctx_destroy(mods_ctx *ctx);
+int mods_ctx_sync(mods_ctx *ctx);
+void *mods_ctx_stream(mods_ctx *ctx);            /* hipStream_t the kernels run on */
+
+/* per-kernel HIP-event timing (bench.py roofline leg).  When enabled every launch of the
+ * named stage is bracketed by events on the context's stream. */
+enum { MODS_STAGE_BLUR = 0, MODS_STAGE_RESPONSE, MODS_STAGE_RESIZE, MODS_STAGE_NMS, MODS_STAGE_LOCALIZE,
+       MODS_STAGE_BAUMBERG, MODS_STAGE_SORT, MODS_STAGE_ORIENT, MODS_STAGE_DESCRIBE, MODS_STAGE_MATCH,
+       MODS_STAGE_RANSAC_SCORE, MODS_STAGE_COUNT };
+int mods_ctx_timing_enable(mods_ctx *ctx, int stage_mask);
+/* sums since the last reset; resolves pending events (synchronises the stream) */
+int mods_ctx_timing_read(mods_ctx *ctx, int stage, double *total_ms, int *launches, double *bytes);
+int mods_ctx_timing_reset(mods_ctx *ctx);
+
+/* ---- B2: detector --------------------------------------------------------------------
+ * Replaces  int DetectAffineKeypoints(cv::Mat &input, vector<AffineKeypoint> &out,
+ *           ScaleSpaceDetectorParams, ScalePyramid&, double tilt, double zoom)
+ * (detectors/affinedetectors/scale-space-detector.cpp:13-32) followed by the
+ * s*=sqrt|det A| / rectifyTransformation loop of DetectAffineRegions<>
+ * (synth-detection.hpp:79-112).  FIXED_TH mode.  Output sorted by |response| descending. */
+int mods_detect_hessian_affine(mods_ctx *ctx, const float *img, int w, int h, int stride,
+                               const mods_hessaff_params *par, mods_affkey *out, int max_out, int *n_out);
+/* batch of `n_img` same-size device-resident images; out[i*max_out ...], n_out[i] */
+int mods_detect_hessian_affine_dev(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, int stride,
+                                   const mods_hessaff_params *par, mods_affkey *out_host, int max_out,
+                                   int *n_out_host);
+
+/* Introspection used by the parity tests (no reference counterpart): planes of the last
+ * pyramid built by the context. kind 0 = blur, 1 = response. */
+int mods_pyramid_octaves(mods_ctx *ctx);
+int mods_pyramid_dims(mods_ctx *ctx, int octave, int *w, int *h);
+int mods_pyramid_plane(mods_ctx *ctx, int img, int octave, int level, int kind, float *dst_host);
+int mods_pyramid_candidates(mods_ctx *ctx, int img, mods_candidate *out, int max_out, int *n_out);
+
+/* single primitives (parity tests / building blocks; references: helpers.cpp:717-731,
+ * pyramid.cpp:196-254, pyramid.cpp:476, helpers.cpp:551-626) */
+int mods_gauss_blur(mods_ctx *ctx, const float *src, int w, int h, float sigma, float *dst);
+int mods_hessian_response(mods_ctx *ctx, const float *src, int w, int h, float norm, float *dst);
+int mods_resize_half(mods_ctx *ctx, const float *src, int w, int h, float *dst, int *dw, int *dh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODS_HIP_H */

@@ -1,0 +1,179 @@
+"""ctypes binding of libmodsgpu.so (include/mods_hip.h): the MI355X implementation of the MODS
+detect -> describe -> match -> verify hot path.
+
+The directory name carries a hyphen (repository contract), so load it with
+`import importlib.util` (see `__graft_entry__.load_package()`), not with `import`.
+
+There is no CPU path: every call fails loudly when the shared library or a HIP device is
+missing."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libmodsgpu.so")
+
+MODS_OK = 0
+STAGES = ["blur", "response", "resize", "nms", "localize", "baumberg", "sort", "orient", "describe", "match",
+          "ransac_score"]
+
+
+class ModsError(RuntimeError):
+    pass
+
+
+class HessAffParams(C.Structure):
+    """[HessianAffine] section of the reference .ini (io_mods.cpp:167-207)."""
+    _fields_ = [("numberOfScales", C.c_int), ("initialSigma", C.c_float), ("threshold", C.c_float),
+                ("edgeEigenValueRatio", C.c_float), ("border", C.c_int), ("maxIterations", C.c_int),
+                ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int)]
+
+    @staticmethod
+    def default():
+        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1)   # build/config_affori_classic.ini
+
+
+AFFKEY_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("s", "f8"), ("a11", "f8"), ("a12", "f8"), ("a21", "f8"),
+                         ("a22", "f8"), ("response", "f8"), ("sub_type", "i4"), ("octave", "i4"),
+                         ("level", "i4"), ("r0", "i4"), ("c0", "i4"), ("pad", "i4")])
+CAND_DTYPE = np.dtype([("octave", "i4"), ("level", "i4"), ("r0", "i4"), ("c0", "i4"), ("r", "i4"), ("c", "i4"),
+                       ("x", "f4"), ("y", "f4"), ("s", "f4"), ("pixelDistance", "f4"), ("response", "f4"),
+                       ("type", "i4")])
+
+_lib = None
+
+
+def build():
+    """Compile every HIP source for gfx950 into libmodsgpu.so (in-tree)."""
+    subprocess.check_call(["make", "-s", "-j4", "-C", PKG_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ModsError("libmodsgpu.so is not built (run __graft_entry__.build()); there is no CPU path")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7.  Two HIP runtimes in one process do not
+        # share devices, so when torch is used for device memory / torch.distributed it must be
+        # loaded first: libmodsgpu's NEEDED libamdhip64.so.7 then binds to the copy already mapped.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mods_last_error.restype = C.c_char_p
+        _lib.mods_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+def _check(rc):
+    if rc != MODS_OK:
+        raise ModsError("libmodsgpu error %d: %s" % (rc, lib().mods_last_error().decode()))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Context:
+    def __init__(self, device=0, max_w=1920, max_h=1080, batch=1):
+        self.h = C.c_void_p()
+        _check(lib().mods_ctx_create(device, max_w, max_h, batch, C.byref(self.h)))
+        self.batch = batch
+
+    def close(self):
+        if self.h:
+            lib().mods_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(lib().mods_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return lib().mods_ctx_stream(self.h)
+
+    # ---- timing
+    def timing_enable(self, stages):
+        mask = 0
+        for s in stages:
+            mask |= 1 << STAGES.index(s)
+        _check(lib().mods_ctx_timing_enable(self.h, mask))
+
+    def timing_read(self, stage):
+        ms, n, by = C.c_double(), C.c_int(), C.c_double()
+        _check(lib().mods_ctx_timing_read(self.h, STAGES.index(stage), C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value
+
+    def timing_reset(self):
+        _check(lib().mods_ctx_timing_reset(self.h))
+
+    # ---- primitives (host arrays)
+    def gauss_blur(self, img, sigma):
+        a = np.ascontiguousarray(img, np.float32)
+        out = np.empty_like(a)
+        _check(lib().mods_gauss_blur(self.h, _fp(a), a.shape[1], a.shape[0], C.c_float(sigma), _fp(out)))
+        return out
+
+    def hessian_response(self, img, norm):
+        a = np.ascontiguousarray(img, np.float32)
+        out = np.empty_like(a)
+        _check(lib().mods_hessian_response(self.h, _fp(a), a.shape[1], a.shape[0], C.c_float(norm), _fp(out)))
+        return out
+
+    def resize_half(self, img):
+        a = np.ascontiguousarray(img, np.float32)
+        out = np.empty(((a.shape[0] + 1) // 2 + 1, (a.shape[1] + 1) // 2 + 1), np.float32).ravel()
+        dw, dh = C.c_int(), C.c_int()
+        _check(lib().mods_resize_half(self.h, _fp(a), a.shape[1], a.shape[0], _fp(out), C.byref(dw), C.byref(dh)))
+        return out[:dw.value * dh.value].reshape(dh.value, dw.value).copy()
+
+    # ---- detector
+    def detect_hessian_affine(self, img, params=None, max_out=1 << 18):
+        params = params or HessAffParams.default()
+        a = np.ascontiguousarray(img, np.float32)
+        out = np.zeros(max_out, AFFKEY_DTYPE)
+        n = C.c_int()
+        _check(lib().mods_detect_hessian_affine(self.h, _fp(a), a.shape[1], a.shape[0], a.shape[1], C.byref(params),
+                                                out.ctypes.data_as(C.c_void_p), max_out, C.byref(n)))
+        return out[:n.value].copy()
+
+    def detect_hessian_affine_dev(self, dev_ptr, n_img, w, h, params=None, max_out=1 << 18, fetch=True):
+        """dev_ptr: device address of [n_img][h][w] fp32 (e.g. torch tensor .data_ptr())."""
+        params = params or HessAffParams.default()
+        counts = (C.c_int * n_img)()
+        out = np.zeros((n_img, max_out), AFFKEY_DTYPE) if fetch else None
+        _check(lib().mods_detect_hessian_affine_dev(self.h, C.c_void_p(dev_ptr), n_img, w, h, w, C.byref(params),
+                                                    out.ctypes.data_as(C.c_void_p) if fetch else None, max_out, counts))
+        if fetch:
+            return [out[i, :counts[i]].copy() for i in range(n_img)]
+        return list(counts)
+
+    # ---- introspection for parity tests
+    def pyramid_octaves(self):
+        return lib().mods_pyramid_octaves(self.h)
+
+    def pyramid_dims(self, o):
+        w, h = C.c_int(), C.c_int()
+        _check(lib().mods_pyramid_dims(self.h, o, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def pyramid_plane(self, img, o, level, kind):
+        w, h = self.pyramid_dims(o)
+        out = np.empty((h, w), np.float32)
+        _check(lib().mods_pyramid_plane(self.h, img, o, level, kind, _fp(out)))
+        return out
+
+    def pyramid_candidates(self, img=0, max_out=1 << 20):
+        out = np.zeros(max_out, CAND_DTYPE)
+        n = C.c_int()
+        _check(lib().mods_pyramid_candidates(self.h, img, out.ctypes.data_as(C.c_void_p), max_out, C.byref(n)))
+        return out[:n.value].copy()

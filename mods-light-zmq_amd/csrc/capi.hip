@@ -1,0 +1,248 @@
+// extern "C" surface of libmodsgpu.so (include/mods_hip.h): context management, timing,
+// detector entry points and introspection for the parity tests.
+#include "common.hpp"
+#include "detmath.hpp"
+#include <cstdarg>
+#include <algorithm>
+
+namespace mods {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+StageScope::StageScope(mods_ctx *c, int s, double bytes) : ctx(c), stage(s) {
+  on = (c->timing_mask >> s) & 1;
+  if (!on) return;
+  StageTimer &t = c->timers[s];
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!t.pool.empty()) { e = t.pool.back(); t.pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+  };
+  e0 = get(); e1 = get();
+  t.bytes += bytes;
+  (void)hipEventRecord(e0, c->stream);
+}
+StageScope::~StageScope() {
+  if (!on) return;
+  (void)hipEventRecord(e1, ctx->stream);
+  ctx->timers[stage].pending.emplace_back(e0, e1);
+}
+
+}  // namespace mods
+
+using namespace mods;
+
+extern "C" {
+
+const char *mods_last_error(void) { return g_err; }
+
+int mods_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mods_ctx_create(int device, int max_w, int max_h, int batch, mods_ctx **out) {
+  if (!out || max_w <= 0 || max_h <= 0 || batch <= 0) { set_error("mods_ctx_create: bad arguments"); return MODS_E_ARG; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) {
+    set_error("no HIP device available (count=%d, requested %d): libmodsgpu has no CPU path", n, device);
+    return MODS_E_NODEVICE;
+  }
+  MODS_HIP_CHECK(hipSetDevice(device));
+  mods_ctx *c = new mods_ctx();
+  c->device = device; c->max_w = max_w; c->max_h = max_h; c->batch = batch;
+  MODS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  const size_t px = (size_t)max_w * max_h;
+  size_t mc = px / 8;
+  mc = std::max<size_t>(mc, 1u << 16);
+  mc = std::min<size_t>(mc, 1u << 22);
+  c->max_cand = (int)mc;
+  MODS_HIP_CHECK(hipMalloc(&c->pyr_dev, sizeof(PyramidDev)));
+  MODS_HIP_CHECK(hipMalloc(&c->input_dev, px * batch * sizeof(float)));
+  MODS_HIP_CHECK(hipMalloc(&c->tmp_dev, px * batch * sizeof(float)));
+  MODS_HIP_CHECK(hipMalloc(&c->gauss_taps_dev, 16 * 64 * sizeof(float)));
+  MODS_HIP_CHECK(hipMalloc(&c->smm_mask_dev, 32 * 32 * sizeof(float)));
+  MODS_HIP_CHECK(hipMalloc(&c->cand, sizeof(CandDev) * mc * batch));
+  MODS_HIP_CHECK(hipMalloc(&c->cand_count, sizeof(int) * 3 * batch));
+  MODS_HIP_CHECK(hipMalloc(&c->keys_dev, sizeof(mods_affkey) * mc * batch));
+  MODS_HIP_CHECK(hipMalloc(&c->sort_keys, sizeof(unsigned long long) * mc * batch));
+  MODS_HIP_CHECK(hipMalloc(&c->sort_idx, sizeof(int) * 2 * mc * batch));
+  MODS_HIP_CHECK(hipHostMalloc(&c->host_counts, sizeof(int) * 3 * batch));
+  *out = c;
+  return MODS_OK;
+}
+
+void mods_ctx_destroy(mods_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &t : c->timers) {
+    for (auto &p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &e : t.pool) (void)hipEventDestroy(e);
+  }
+  (void)hipFree(c->pyr_dev); (void)hipFree(c->plane_pool); (void)hipFree(c->omap_pool); (void)hipFree(c->input_dev);
+  (void)hipFree(c->tmp_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
+  (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx);
+  (void)hipHostFree(c->host_counts);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int mods_ctx_sync(mods_ctx *c) { MODS_HIP_CHECK(hipStreamSynchronize(c->stream)); return MODS_OK; }
+void *mods_ctx_stream(mods_ctx *c) { return (void *)c->stream; }
+
+int mods_ctx_timing_enable(mods_ctx *c, int stage_mask) { c->timing_mask = stage_mask; return MODS_OK; }
+
+static int resolve_timers(mods_ctx *c) {
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (auto &t : c->timers) {
+    for (auto &p : t.pending) {
+      float ms = 0;
+      MODS_HIP_CHECK(hipEventElapsedTime(&ms, p.first, p.second));
+      t.total_ms += ms;
+      t.launches++;
+      t.pool.push_back(p.first); t.pool.push_back(p.second);
+    }
+    t.pending.clear();
+  }
+  return MODS_OK;
+}
+
+int mods_ctx_timing_read(mods_ctx *c, int stage, double *total_ms, int *launches, double *bytes) {
+  if (stage < 0 || stage >= MODS_STAGE_COUNT) return MODS_E_ARG;
+  int rc = resolve_timers(c);
+  if (rc) return rc;
+  if (total_ms) *total_ms = c->timers[stage].total_ms;
+  if (launches) *launches = c->timers[stage].launches;
+  if (bytes) *bytes = c->timers[stage].bytes;
+  return MODS_OK;
+}
+
+int mods_ctx_timing_reset(mods_ctx *c) {
+  int rc = resolve_timers(c);
+  if (rc) return rc;
+  for (auto &t : c->timers) { t.total_ms = 0; t.launches = 0; t.bytes = 0; }
+  return MODS_OK;
+}
+
+// ---- detector -----------------------------------------------------------------------------
+static int detect_common(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride,
+                         const mods_hessaff_params *par, mods_affkey *out_host, int max_out, int *n_out_host) {
+  if (!c || !img_dev || !par || !n_out_host) { set_error("detect: null argument"); return MODS_E_ARG; }
+  if (w > c->max_w * 1 && (size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image larger than the context"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = pyramid_configure(c, w, h, n_img, par))) return rc;
+  if ((rc = pyramid_build(c, img_dev, stride))) return rc;
+  if ((rc = detect_run(c))) return rc;
+  MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (int b = 0; b < n_img; b++) {
+    if (c->host_counts[b] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", c->host_counts[b], c->max_cand); return MODS_E_CAPACITY; }
+    const int n = c->host_counts[2 * c->batch + b];
+    n_out_host[b] = n;
+    if (out_host) {
+      if (n > max_out) { set_error("keypoint output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
+      MODS_HIP_CHECK(hipMemcpy(out_host + (size_t)b * max_out, c->keys_dev + (size_t)b * c->max_cand, sizeof(mods_affkey) * n, hipMemcpyDeviceToHost));
+    }
+  }
+  return MODS_OK;
+}
+
+int mods_detect_hessian_affine_dev(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride,
+                                   const mods_hessaff_params *par, mods_affkey *out_host, int max_out, int *n_out_host) {
+  return detect_common(c, img_dev, n_img, w, h, stride, par, out_host, max_out, n_out_host);
+}
+
+int mods_detect_hessian_affine(mods_ctx *c, const float *img, int w, int h, int stride, const mods_hessaff_params *par,
+                               mods_affkey *out, int max_out, int *n_out) {
+  if (!c || !img) { set_error("detect: null argument"); return MODS_E_ARG; }
+  if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image larger than the context"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(hipMemcpy2DAsync(c->input_dev, sizeof(float) * w, img, sizeof(float) * stride, sizeof(float) * w, h,
+                                  hipMemcpyHostToDevice, c->stream));
+  return detect_common(c, c->input_dev, 1, w, h, w, par, out, max_out, n_out);
+}
+
+int mods_pyramid_octaves(mods_ctx *c) { return c->pyr.n_oct; }
+int mods_pyramid_dims(mods_ctx *c, int o, int *w, int *h) {
+  if (o < 0 || o >= c->pyr.n_oct) return MODS_E_ARG;
+  *w = c->pyr.oct[o].w; *h = c->pyr.oct[o].h;
+  return MODS_OK;
+}
+int mods_pyramid_plane(mods_ctx *c, int img, int o, int level, int kind, float *dst) {
+  if (o < 0 || o >= c->pyr.n_oct || level < 0 || level >= c->pyr.n_levels || img < 0 || img >= c->last_n_img) return MODS_E_ARG;
+  const OctaveDev &oc = c->pyr.oct[o];
+  const float *p = (kind ? oc.resp[level] : oc.blur[level]) + (size_t)oc.w * oc.h * img;
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(hipMemcpy(dst, p, sizeof(float) * (size_t)oc.w * oc.h, hipMemcpyDeviceToHost));
+  return MODS_OK;
+}
+// accepted (post-dedup) localisation records of image `img`, in list (arbitrary) order
+int mods_pyramid_candidates(mods_ctx *c, int img, mods_candidate *out, int max_out, int *n_out) {
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  int count = 0;
+  MODS_HIP_CHECK(hipMemcpy(&count, c->cand_count + img, sizeof(int), hipMemcpyDeviceToHost));
+  int n = std::min(count, c->max_cand);
+  std::vector<CandDev> v(n);
+  MODS_HIP_CHECK(hipMemcpy(v.data(), c->cand + (size_t)img * c->max_cand, sizeof(CandDev) * n, hipMemcpyDeviceToHost));
+  // state: 2 accepted (claimed its octaveMap cell), 3 Baumberg converged, 4 Baumberg rejected
+  int m = 0;
+  for (auto &cd : v) {
+    if (!(cd.state == 2 || cd.state == 3 || cd.state == 4)) continue;
+    if (m < max_out) {
+      mods_candidate &o = out[m];
+      o.octave = cd.octave; o.level = cd.level; o.r0 = cd.r0; o.c0 = cd.c0; o.r = cd.r; o.c = cd.c;
+      o.x = cd.x; o.y = cd.y; o.s = cd.s; o.pixelDistance = cd.pixelDistance; o.response = cd.response; o.type = cd.type;
+    }
+    m++;
+  }
+  *n_out = m;
+  return m > max_out ? MODS_E_CAPACITY : MODS_OK;
+}
+
+// ---- single primitives -------------------------------------------------------------------
+int mods_gauss_blur(mods_ctx *c, const float *src, int w, int h, float sigma, float *dst) {
+  if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image larger than the context"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev, src, sizeof(float) * (size_t)w * h, hipMemcpyHostToDevice, c->stream));
+  int rc = launch_gauss_blur(c, c->input_dev, c->tmp_dev, w, h, 1, sigma);
+  if (rc) return rc;
+  MODS_HIP_CHECK(hipMemcpyAsync(dst, c->tmp_dev, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return MODS_OK;
+}
+
+int mods_hessian_response(mods_ctx *c, const float *src, int w, int h, float norm, float *dst) {
+  if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image larger than the context"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev, src, sizeof(float) * (size_t)w * h, hipMemcpyHostToDevice, c->stream));
+  int rc = launch_hessian_response(c, c->input_dev, c->tmp_dev, w, h, 1, norm);
+  if (rc) return rc;
+  MODS_HIP_CHECK(hipMemcpyAsync(dst, c->tmp_dev, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return MODS_OK;
+}
+
+int mods_resize_half(mods_ctx *c, const float *src, int w, int h, float *dst, int *dw, int *dh) {
+  if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image larger than the context"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  resize_half_dims(w, h, dw, dh);
+  MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev, src, sizeof(float) * (size_t)w * h, hipMemcpyHostToDevice, c->stream));
+  int rc = launch_resize_half(c, c->input_dev, c->tmp_dev, w, h, *dw, *dh, 1);
+  if (rc) return rc;
+  MODS_HIP_CHECK(hipMemcpyAsync(dst, c->tmp_dev, sizeof(float) * (size_t)(*dw) * (*dh), hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return MODS_OK;
+}
+
+}  // extern "C"

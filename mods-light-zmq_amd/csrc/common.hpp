@@ -1,0 +1,120 @@
+// Internal declarations of libmodsgpu (context, device buffers, launch helpers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/mods_hip.h"
+
+namespace mods {
+
+void set_error(const char *fmt, ...);
+
+#define MODS_HIP_CHECK(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      mods::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return MODS_E_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+constexpr int kMaxOctaves = 16;
+constexpr int kMaxLevels = 8;        // numberOfScales + 2 <= 8
+constexpr int kMaxBlurRadius = 16;   // fused separable blur: ksize <= 33
+
+// One octave of the scale space for a batch of images: plane(b) = base + b * w * h.
+struct OctaveDev {
+  int w, h;
+  float pixelDistance;
+  float sigma[kMaxLevels];
+  float *blur[kMaxLevels];
+  float *resp[kMaxLevels];
+  unsigned int *omap;                // dedup map (pyramid.cpp octaveMap), one u32 per pixel
+};
+
+struct PyramidDev {
+  int n_oct;
+  int n_levels;                      // numberOfScales + 2
+  OctaveDev oct[kMaxOctaves];
+};
+
+// raw NMS hit / localisation record, device side (AoS, 64 B)
+struct CandDev {
+  int octave, level, r0, c0;
+  int r, c;
+  float x, y, s, pixelDistance, response;
+  int type;
+  int state;                         // 0 rejected, 1 passed tests (pending dedup), 2 accepted
+  float a11, a12, a21, a22;          // Baumberg result
+};
+
+struct StageTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<hipEvent_t> pool;
+  double total_ms = 0;
+  int launches = 0;
+  double bytes = 0;
+};
+
+}  // namespace mods
+
+struct mods_ctx {
+  int device = 0;
+  int max_w = 0, max_h = 0, batch = 1;
+  hipStream_t stream = nullptr;
+  // scale space
+  mods::PyramidDev pyr;              // host copy of the descriptor table
+  mods::PyramidDev *pyr_dev = nullptr;
+  float *plane_pool = nullptr;       // all blur/response planes
+  size_t plane_pool_elems = 0;
+  unsigned int *omap_pool = nullptr;
+  size_t omap_pool_elems = 0;
+  float *input_dev = nullptr;        // staging for host-pointer entry points
+  float *tmp_dev = nullptr;
+  float *gauss_taps_dev = nullptr;   // [16 slots][64] Gaussian taps
+  float taps_sigma[16] = {0};        // sigma currently held by each slot (0 = empty)
+  float *smm_mask_dev = nullptr;     // computeGaussMask(smmWindowSize)
+  int smm_mask_size = 0;
+  // candidates
+  int max_cand = 0;                  // per image
+  mods::CandDev *cand = nullptr;     // [batch][max_cand]
+  int *cand_count = nullptr;         // [batch] raw NMS hits
+  mods_affkey *keys_dev = nullptr;   // [batch][max_cand] sorted output
+  unsigned long long *sort_keys = nullptr;
+  int *sort_idx = nullptr;
+  int *key_count = nullptr;          // [batch]
+  int *host_counts = nullptr;        // pinned
+  mods_hessaff_params par;
+  int last_w = 0, last_h = 0, last_n_img = 0;
+  // timing
+  int timing_mask = 0;
+  mods::StageTimer timers[MODS_STAGE_COUNT];
+};
+
+namespace mods {
+
+struct StageScope {                  // brackets launches of one stage with events when enabled
+  mods_ctx *ctx; int stage; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
+  StageScope(mods_ctx *c, int s, double bytes = 0);
+  ~StageScope();
+};
+
+// pyramid.hip
+int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff_params *par);
+int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride);
+int launch_gauss_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, float sigma);
+int launch_hessian_response(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, float norm);
+int launch_resize_half(mods_ctx *ctx, const float *src, float *dst, int w, int h, int dw, int dh, int n_img);
+void resize_half_dims(int w, int h, int *dw, int *dh);
+int gauss_ksize(float sigma);
+void gauss_kernel_host(int n, double sigma, float *out);
+void gauss_mask_host(int size, float *out);
+void circular_gauss_mask_host(int size, float sigma, float *out);
+
+// detect.hip
+int detect_run(mods_ctx *ctx);       // NMS -> localise -> dedup -> Baumberg -> sort, for the configured batch
+
+}  // namespace mods

@@ -1,0 +1,496 @@
+// Keypoint extraction on the scale space: 3x3x3 NMS, sub-pixel/scale localisation, octaveMap
+// de-duplication, Baumberg affine-shape iteration, |response| ordering and export.
+//
+// Reference behaviour (file:line relative to the reference root):
+//   findLevelKeypoints / isMax / isMin   detectors/affinedetectors/pyramid.cpp:405-425, 41-63
+//   localizeKeypoint                     pyramid.cpp:281-403   (thresholds: pyramid.h:46-66)
+//   findAffineShape (SMM branch)         detectors/affinedetectors/affine.cpp:26-158
+//   interpolate / computeGradient / invSqrt / getEigenvalues / solveLinear3x3
+//                                        detectors/helpers.cpp:551-626, 779-797, 463-515, 309-368
+//   exportKeypoints + DetectAffineRegions scale-space-detector.hpp:89-131, synth-detection.hpp:79-112
+//
+// The reference walks NMS hits in raster order per level and lets the first accepted point
+// claim its octaveMap cell.  Here all hits are processed in parallel and the claim is resolved
+// with an atomicMin over the processing-order key (level, r0, c0) of the points that pass
+// every other test: the winner is exactly the reference's first claimant.  The output order
+// (|response| descending, ties in processing order) is produced by a rank sort at the end, so
+// nothing upstream depends on the order hits were appended in.
+#include "common.hpp"
+#include "detmath.hpp"
+
+namespace mods {
+
+constexpr int ORDER_POS_BITS = 25;   // r0*w+c0 < 2^25 per octave
+
+struct DetectConst {
+  int border;
+  int n_scales;
+  float pos_th, neg_th, final_th;
+  double edge_th;
+  int max_cand;
+  int smm;                // smmWindowSize
+  int max_iter;
+  float conv_th;
+  float initial_sigma;
+  int do_baumberg;
+};
+
+// ---------------------------------------------------------------------------------------
+// NMS: one thread per pixel of the detection level; hits appended with one atomic per wave.
+// grid = (ceil((w-2b)/64), ceil((h-2b)/4), n_img), block = 256
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__ P, int oi, int lv, DetectConst k,
+                                                  CandDev *__restrict__ cand, int *__restrict__ cand_count) {
+  const OctaveDev &o = P->oct[oi];
+  const int w = o.w, h = o.h;
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const int c = k.border + blockIdx.x * 64 + lane;
+  const int r = k.border + blockIdx.y * 4 + (threadIdx.x >> 6);
+  bool hit = false;
+  if (r < h - k.border && c < w - k.border) {
+    const size_t plane = (size_t)w * h * b;
+    const float *cur = o.resp[lv] + plane;
+    const float val = cur[(size_t)r * w + c];
+    if (val > k.pos_th) {
+      const float *low = o.resp[lv - 1] + plane, *high = o.resp[lv + 1] + plane;
+      hit = true;
+      for (int dr = -1; dr <= 1 && hit; dr++) {
+        const size_t off = (size_t)(r + dr) * w + c;
+        for (int dc = -1; dc <= 1; dc++)
+          if (cur[off + dc] > val || low[off + dc] > val || high[off + dc] > val) hit = false;
+      }
+    } else if (val < k.neg_th) {
+      const float *low = o.resp[lv - 1] + plane, *high = o.resp[lv + 1] + plane;
+      hit = true;
+      for (int dr = -1; dr <= 1 && hit; dr++) {
+        const size_t off = (size_t)(r + dr) * w + c;
+        for (int dc = -1; dc <= 1; dc++)
+          if (cur[off + dc] < val || low[off + dc] < val || high[off + dc] < val) hit = false;
+      }
+    }
+  }
+  const unsigned long long m = __ballot(hit);
+  if (m == 0) return;
+  int base = 0;
+  const int leader = __ffsll((long long)m) - 1;
+  if (lane == leader) base = atomicAdd(&cand_count[b], __popcll(m));
+  base = __shfl(base, leader);
+  if (hit) {
+    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (slot < k.max_cand) {
+      CandDev &cd = cand[(size_t)b * k.max_cand + slot];
+      cd.octave = oi; cd.level = lv; cd.r0 = r; cd.c0 = c; cd.state = 0;
+    }
+  }
+}
+
+__device__ __forceinline__ void swapf(float &a, float &b) { float t = a; a = b; b = t; }
+
+// solveLinear3x3, helpers.cpp:309-368 (partial pivoting, fp32)
+__device__ void solve_linear_3x3(float *A, float *b) {
+  int i = 0;
+  int pr = 0;
+  float vp = fabsf(A[0]);
+  float tmp = fabsf(A[3]);
+  if (tmp > vp) { pr = 3; i = 1; vp = tmp; }
+  if (fabsf(A[6]) > vp) { pr = 6; i = 2; }
+  if (pr != 0) {
+    swapf(A[pr], A[0]); swapf(A[pr + 1], A[1]); swapf(A[pr + 2], A[2]); swapf(b[i], b[0]);
+  }
+  vp = A[3] / A[0];
+  A[4] -= vp * A[1]; A[5] -= vp * A[2]; b[1] -= vp * b[0];
+  vp = A[6] / A[0];
+  A[7] -= vp * A[1]; A[8] -= vp * A[2]; b[2] -= vp * b[0];
+  if (fabsf(A[4]) < fabsf(A[7])) { swapf(A[7], A[4]); swapf(A[8], A[5]); swapf(b[2], b[1]); }
+  vp = A[7] / A[4];
+  A[8] -= vp * A[5];
+  b[2] -= vp * b[1];
+  b[2] = (b[2]) / A[8];
+  b[1] = (b[1] - A[5] * b[2]) / A[4];
+  b[0] = (b[0] - A[2] * b[2] - A[1] * b[1]) / A[0];
+}
+
+// localizeKeypoint (pyramid.cpp:281-403): one thread per NMS hit, grid-stride over the hit list.
+// Points that pass every test claim their cell with atomicMin(order key).
+__global__ __launch_bounds__(256) void localize_kernel(const PyramidDev *__restrict__ P, DetectConst k,
+                                                       CandDev *__restrict__ cand, const int *__restrict__ cand_count) {
+  const int b = blockIdx.y;
+  int n = cand_count[b];
+  if (n > k.max_cand) n = k.max_cand;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    CandDev &cd = cand[(size_t)b * k.max_cand + i];
+    const OctaveDev &o = P->oct[cd.octave];
+    const int cols = o.w, rows = o.h;
+    const size_t plane = (size_t)cols * rows * b;
+    const float *low = o.resp[cd.level - 1] + plane;
+    const float *cur = o.resp[cd.level] + plane;
+    const float *high = o.resp[cd.level + 1] + plane;
+    int r = cd.r0, c = cd.c0;
+    float bb[3] = {0, 0, 0};
+    float val = 0;
+    int nr = r, nc = c;
+    bool ok = true;
+    for (int iter = 0; iter < 5; iter++) {
+      r = nr; c = nc;
+      const float *cur0 = cur + (size_t)(r - 1) * cols, *cur1 = cur0 + cols, *cur2 = cur1 + cols;
+      const float *low0 = low + (size_t)(r - 1) * cols, *low1 = low0 + cols, *low2 = low1 + cols;
+      const float *high0 = high + (size_t)(r - 1) * cols, *high1 = high0 + cols, *high2 = high1 + cols;
+      float dxx = cur1[c - 1] - 2.0f * cur1[c] + cur1[c + 1];
+      float dyy = cur0[c] - 2.0f * cur1[c] + cur2[c];
+      float dss = low1[c] - 2.0f * cur1[c] + high1[c];
+      float dxy = 0.25f * (cur2[c + 1] - cur2[c - 1] - cur0[c + 1] + cur0[c - 1]);
+      if (0 == iter) {
+        float edgeScore = (dxx + dyy) * (dxx + dyy) / (dxx * dyy - dxy * dxy);
+        if ((double)edgeScore >= k.edge_th || edgeScore < 0) { ok = false; break; }
+      }
+      float dxs = 0.25f * (high1[c + 1] - high1[c - 1] - low1[c + 1] + low1[c - 1]);
+      float dys = 0.25f * (high2[c] - high0[c] - low2[c] + low0[c]);
+      float A[9] = {dxx, dxy, dxs, dxy, dyy, dys, dxs, dys, dss};
+      float dx = 0.5f * (cur1[c + 1] - cur1[c - 1]);
+      float dy = 0.5f * (cur2[c] - cur0[c]);
+      float ds = 0.5f * (high1[c] - low1[c]);
+      bb[0] = -dx; bb[1] = -dy; bb[2] = -ds;
+      solve_linear_3x3(A, bb);
+      if (isnan(bb[0]) || isnan(bb[1]) || isnan(bb[2])) { ok = false; break; }
+      val = cur1[c] + 0.5f * (dx * bb[0] + dy * bb[1] + ds * bb[2]);
+      // MAX_SUBPIXEL_SHIFT is the double 0.6; POINT_SAFETY_BORDER 3
+      if ((double)bb[0] > 0.6) { if (c < cols - 3) nc++; else { ok = false; break; } }
+      if ((double)bb[1] > 0.6) { if (r < rows - 3) nr++; else { ok = false; break; } }
+      if ((double)bb[0] < -0.6) { if (c > 3) nc--; else { ok = false; break; } }
+      if ((double)bb[1] < -0.6) { if (r > 3) nr--; else { ok = false; break; } }
+      if (nr == r && nc == c) break;
+    }
+    if (ok && (fabsf(bb[0]) > 1.5f || fabsf(bb[1]) > 1.5f || fabsf(bb[2]) > 1.5f || fabsf(val) < k.final_th)) ok = false;
+    if (!ok) { cd.state = 0; continue; }
+    const float scale = o.sigma[cd.level] * det_pow2f(bb[2] / k.n_scales);
+    int type;
+    if (val < 0) type = 2;
+    else {
+      const float *ptr = o.blur[cd.level] + plane + (size_t)r * cols + c;
+      float Lxx = (ptr[-1] - 2 * ptr[0] + ptr[1]);
+      type = (Lxx < 0) ? 0 : 1;
+    }
+    cd.r = r; cd.c = c;
+    cd.x = o.pixelDistance * (c + bb[0]);
+    cd.y = o.pixelDistance * (r + bb[1]);
+    cd.s = o.pixelDistance * scale;
+    cd.pixelDistance = o.pixelDistance;
+    cd.type = type;
+    cd.response = val;
+    cd.state = 1;
+    const unsigned int key = ((unsigned int)cd.level << ORDER_POS_BITS) | (unsigned int)(cd.r0 * cols + cd.c0);
+    atomicMin(&o.omap[plane + (size_t)r * cols + c], key);
+  }
+}
+
+// Second half of the octaveMap rule: a point survives iff it is the first claimant of its cell.
+// Survivors are appended to the accepted list (order irrelevant).
+__global__ __launch_bounds__(256) void accept_kernel(const PyramidDev *__restrict__ P, DetectConst k,
+                                                     CandDev *__restrict__ cand, const int *__restrict__ cand_count,
+                                                     int *__restrict__ acc_list, int *__restrict__ acc_count) {
+  const int b = blockIdx.y;
+  int n = cand_count[b];
+  if (n > k.max_cand) n = k.max_cand;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    CandDev &cd = cand[(size_t)b * k.max_cand + i];
+    if (cd.state != 1) continue;
+    const OctaveDev &o = P->oct[cd.octave];
+    const size_t plane = (size_t)o.w * o.h * b;
+    const unsigned int key = ((unsigned int)cd.level << ORDER_POS_BITS) | (unsigned int)(cd.r0 * o.w + cd.c0);
+    if (o.omap[plane + (size_t)cd.r * o.w + cd.c] == key) {
+      cd.state = 2;
+      const int slot = atomicAdd(&acc_count[b], 1);
+      acc_list[(size_t)b * k.max_cand + slot] = i;
+    } else cd.state = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Baumberg iteration: one wave per accepted point.
+// ---------------------------------------------------------------------------------------
+// interpolateCheckBorders, helpers.cpp:527-549
+__device__ __forceinline__ bool check_borders(int img_w, int img_h, float ofsx, float ofsy, float a11, float a12,
+                                              float a21, float a22, int res_w, int res_h) {
+  const int width = img_w - 2, height = img_h - 2;
+  const float halfWidth = (float)ceil((double)((float)res_w) / 2.0);
+  const float halfHeight = (float)ceil((double)((float)res_h) / 2.0);
+  const float xs[4] = {-halfWidth, -halfWidth, +halfWidth, +halfWidth};
+  const float ys[4] = {-halfHeight, +halfHeight, -halfHeight, +halfHeight};
+  bool touch = false;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float imx = ofsx + xs[i] * a11 + ys[i] * a12;
+    float imy = ofsy + xs[i] * a21 + ys[i] * a22;
+    if (floorf(imx) <= 0 || floorf(imy) <= 0 || ceilf(imx) >= width || ceilf(imy) >= height) touch = true;
+  }
+  return touch;
+}
+
+// One bilinear tap of helpers.cpp:551-626 (both branches).
+__device__ __forceinline__ float bilinear_tap(const float *__restrict__ im, int w, int h, float WX, float WY, bool touch) {
+  if (!touch) {
+    const int x = (int)WX, y = (int)WY;
+    const float wx = WX - (float)x;
+    const float *Row0 = im + (size_t)y * w, *Row1 = Row0 + w;
+    const float I1 = wx * (Row0[x + 1] - Row0[x]) + Row0[x];
+    return (WY - y) * (wx * (Row1[x + 1] - Row1[x]) + Row1[x] - I1) + I1;
+  }
+  const int x = (int)floorf(WX), y = (int)floorf(WY);
+  if (WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1) {
+    const float wx = WX - x;
+    const float *Row0 = im + (size_t)y * w, *Row1 = Row0 + w;
+    const float I1 = wx * (Row0[x + 1] - Row0[x]) + Row0[x];
+    return (WY - y) * (wx * (Row1[x + 1] - Row1[x]) + Row1[x] - I1) + I1;
+  }
+  return 0.f;
+}
+
+// invSqrt, helpers.cpp:463-502 (double inside)
+__device__ void inv_sqrt(float &a, float &b, float &c, float &l1, float &l2) {
+  double t, r;
+  if (b != 0) {
+    r = double(c - a) / (2 * b);
+    if (r >= 0) t = 1.0 / (r + sqrt(1 + r * r));
+    else t = -1.0 / (-r + sqrt(1 + r * r));
+    r = 1.0 / sqrt(1 + t * t);
+    t = t * r;
+  } else { r = 1; t = 0; }
+  double x, z, d;
+  x = 1.0 / sqrt(r * r * a - 2 * r * t * b + t * t * c);
+  z = 1.0 / sqrt(t * t * a + 2 * r * t * b + r * r * c);
+  d = sqrt(x * z);
+  x /= d;
+  z /= d;
+  if (x < z) { l1 = float(z); l2 = float(x); }
+  else { l1 = float(x); l2 = float(z); }
+  a = float(r * r * x + t * t * z);
+  b = float(-r * t * x + t * r * z);
+  c = float(t * t * x + r * r * z);
+}
+
+// grid = (N, n_img) grid-stride over the accepted list; block = 64 (one wave).
+// dynamic LDS: 7 * W*W floats (+3)
+__global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restrict__ P, DetectConst k,
+                                                      CandDev *__restrict__ cand, const int *__restrict__ acc_list,
+                                                      const int *__restrict__ acc_count, const float *__restrict__ mask,
+                                                      unsigned long long *__restrict__ sort_keys, int *__restrict__ sort_idx,
+                                                      int *__restrict__ key_count) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int W = k.smm, WW = W * W;
+  float *s_cx = smem, *s_cy = s_cx + WW, *s_img = s_cy + WW, *s_pa = s_img + WW, *s_pb = s_pa + WW,
+        *s_pc = s_pb + WW, *s_mask = s_pc + WW, *s_sum = s_mask + WW;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.y;
+  const int half = W / 2;
+  for (int p = lane; p < WW; p += 64) s_mask[p] = mask[p];
+  const int n_acc = acc_count[b];
+  for (int slot = blockIdx.x; slot < n_acc; slot += gridDim.x) {
+    const int ci = acc_list[(size_t)b * k.max_cand + slot];
+    CandDev &cd = cand[(size_t)b * k.max_cand + ci];
+    const OctaveDev &o = P->oct[cd.octave];
+    const int iw = o.w, ih = o.h;
+    const float *im = o.blur[cd.level - 1] + (size_t)iw * ih * b;   // prevBlur, pyramid.cpp:402
+    const float pd = cd.pixelDistance;
+    float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
+    float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
+    const float lx = cd.x / pd, ly = cd.y / pd;
+    const float ratio = cd.s / (k.initial_sigma * pd);
+    bool converged = false;
+    if (!k.do_baumberg) converged = true;
+    else
+      for (int l = 0; l < k.max_iter; l++) {
+        const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
+        const bool touch = check_borders(iw, ih, lx, ly, a11, a12, a21, a22, W, W);
+        __syncthreads();   // previous iteration's readers are done with the tiles
+        // sample coordinates: lane j owns patch row j; rx/ry and WX/WY are sequential fp32 sums
+        if (lane < W) {
+          float rx = lx - (float)half * a12;
+          float ry = ly - (float)half * a22;
+          for (int q = 0; q < lane; q++) { rx += a12; ry += a22; }
+          float WX = rx - (float)half * a11;
+          float WY = ry - (float)half * a21;
+          for (int i = 0; i < W; i++) {
+            s_cx[lane * W + i] = WX;
+            s_cy[lane * W + i] = WY;
+            WX += a11;
+            WY += a21;
+          }
+        }
+        __syncthreads();
+        for (int p = lane; p < WW; p += 64) s_img[p] = bilinear_tap(im, iw, ih, s_cx[p], s_cy[p], touch);
+        __syncthreads();
+        // computeGradient (helpers.cpp:779-797) and the three SMM products
+        for (int p = lane; p < WW; p += 64) {
+          const int r = p / W, c = p - r * W;
+          float xgrad, ygrad;
+          if (c == 0) xgrad = s_img[p + 1] - s_img[p];
+          else if (c == W - 1) xgrad = s_img[p] - s_img[p - 1];
+          else xgrad = s_img[p + 1] - s_img[p - 1];
+          if (r == 0) ygrad = s_img[p + W] - s_img[p];
+          else if (r == W - 1) ygrad = s_img[p] - s_img[p - W];
+          else ygrad = s_img[p + W] - s_img[p - W];
+          const float v = s_mask[p];
+          const float gxy = xgrad * ygrad;
+          s_pa[p] = xgrad * xgrad * v;
+          s_pb[p] = gxy * v;
+          s_pc[p] = ygrad * ygrad * v;
+        }
+        __syncthreads();
+        // ordered accumulation (raster order, fp32): three lanes, one sum each
+        if (lane < 3) {
+          const float *arr = lane == 0 ? s_pa : (lane == 1 ? s_pb : s_pc);
+          float acc = 0;
+          for (int i = 0; i < WW; i++) acc += arr[i];
+          s_sum[lane] = acc;
+        }
+        __syncthreads();
+        float a = s_sum[0], bq = s_sum[1], c = s_sum[2];
+        a /= WW; bq /= WW; c /= WW;
+        inv_sqrt(a, bq, c, l1, l2);
+        if ((a != a) || (bq != bq) || (c != c)) break;
+        eigen_ratio_bef = eigen_ratio_act;
+        eigen_ratio_act = (float)(1.0 - l2 / l1);
+        const float u11t = u11, u12t = u12;
+        u11 = a * u11t + bq * u21;
+        u12 = a * u12t + bq * u22;
+        u21 = bq * u11t + c * u21;
+        u22 = bq * u12t + c * u22;
+        // getEigenvalues, helpers.cpp:504-515
+        const float trace = u11 + u22;
+        const float delta1 = (trace * trace - 4 * (u11 * u22 - u12 * u21));
+        if (delta1 < 0) break;
+        const float delta = sqrtf(delta1);
+        l1 = (trace + delta) / 2.0f;
+        l2 = (trace - delta) / 2.0f;
+        if ((l1 / l2 > 6) || (l2 / l1 > 6)) break;
+        if (eigen_ratio_act < k.conv_th && eigen_ratio_bef < k.conv_th) { converged = true; break; }
+      }
+    if (lane == 0) {
+      if (converged) {
+        cd.a11 = u11; cd.a12 = u12; cd.a21 = u21; cd.a22 = u22;
+        cd.state = 3;
+        // sort key: |response| descending, then processing order (octave, level, r0, c0)
+        const unsigned int absbits = __float_as_uint(fabsf(cd.response));
+        const unsigned int order = ((unsigned int)cd.octave << 28) | ((unsigned int)cd.level << ORDER_POS_BITS) |
+                                   (unsigned int)(cd.r0 * iw + cd.c0);
+        const int sl = atomicAdd(&key_count[b], 1);
+        sort_keys[(size_t)b * k.max_cand + sl] = ((unsigned long long)(~absbits) << 32) | order;
+        sort_idx[(size_t)b * k.max_cand + sl] = ci;
+      } else cd.state = 4;   // accepted by the pyramid, dropped by the affine adaptation
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Rank sort + export.  Keys are unique, so rank = #{j : key_j < key_i}.
+// grid = (ceil(max/256) capped, n_img), block = 256, LDS tile of 1024 keys.
+// Export applies DetectAffineRegions: s *= sqrt|det A|, rectifyTransformation (fp64).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rank_export_kernel(DetectConst k, const CandDev *__restrict__ cand,
+                                                          const unsigned long long *__restrict__ sort_keys,
+                                                          const int *__restrict__ sort_idx,
+                                                          const int *__restrict__ key_count,
+                                                          mods_affkey *__restrict__ out) {
+  __shared__ unsigned long long tile[1024];
+  const int b = blockIdx.y;
+  const int n = key_count[b];
+  const unsigned long long *keys = sort_keys + (size_t)b * k.max_cand;
+  const int nblk = (n + 255) / 256;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int i = blk * 256 + threadIdx.x;
+    const unsigned long long mine = (i < n) ? keys[i] : ~0ull;
+    int rank = 0;
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+      __syncthreads();
+      for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (t0 + q < n) ? keys[t0 + q] : ~0ull;
+      __syncthreads();
+      const int lim = min(1024, n - t0);
+      for (int q = 0; q < lim; q++) rank += (tile[q] < mine) ? 1 : 0;
+    }
+    if (i < n) {
+      const CandDev &cd = cand[(size_t)b * k.max_cand + sort_idx[(size_t)b * k.max_cand + i]];
+      mods_affkey o;
+      double a = cd.a11, bb = cd.a12, c = cd.a21, d = cd.a22;
+      o.x = cd.x; o.y = cd.y;
+      o.s = (double)cd.s * sqrt(fabs(a * d - bb * c));
+      const double det = sqrt(fabs(a * d - bb * c));
+      const double b2a2 = sqrt(bb * bb + a * a);
+      o.a11 = b2a2 / det;
+      o.a12 = 0;
+      o.a21 = (d * bb + c * a) / (b2a2 * det);
+      o.a22 = det / b2a2;
+      o.response = cd.response;
+      o.sub_type = cd.type;
+      o.octave = cd.octave; o.level = cd.level; o.r0 = cd.r0; o.c0 = cd.c0; o.pad = 0;
+      out[(size_t)b * k.max_cand + rank] = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+int detect_run(mods_ctx *ctx) {
+  const PyramidDev &P = ctx->pyr;
+  const mods_hessaff_params &par = ctx->par;
+  const int n_img = ctx->last_n_img;
+  DetectConst k;
+  k.border = par.border;
+  k.n_scales = par.numberOfScales;
+  // ScaleSpaceDetector ctor (pyramid.h:46-66): positive = 0.8*threshold (un-squared), final = threshold^2
+  const double er = (double)par.edgeEigenValueRatio;
+  k.edge_th = (er + 1.0f) * (er + 1.0f) / er;
+  k.pos_th = (float)(0.8 * par.threshold);
+  k.neg_th = -k.pos_th;
+  k.final_th = par.threshold * par.threshold;
+  k.max_cand = ctx->max_cand;
+  k.smm = par.smmWindowSize;
+  k.max_iter = par.maxIterations;
+  k.conv_th = par.convergenceThreshold;
+  k.initial_sigma = par.initialSigma;
+  k.do_baumberg = par.doBaumberg;
+  for (int oi = 0; oi < P.n_oct; oi++)
+    if ((size_t)P.oct[oi].w * P.oct[oi].h >= (1u << ORDER_POS_BITS)) { set_error("octave too large for the order key"); return MODS_E_ARG; }
+
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->cand_count, 0, sizeof(int) * 3 * ctx->batch, ctx->stream));   // cand/acc/key counts
+  size_t omap_elems = 0;
+  for (int oi = 0; oi < P.n_oct; oi++) omap_elems += (size_t)P.oct[oi].w * P.oct[oi].h * n_img;
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->omap_pool, 0xFF, omap_elems * sizeof(unsigned int), ctx->stream));
+  int *acc_count = ctx->cand_count + ctx->batch;
+  int *key_count = ctx->cand_count + 2 * ctx->batch;
+  {
+    StageScope ts(ctx, MODS_STAGE_NMS);
+    for (int oi = 0; oi < P.n_oct; oi++) {
+      const OctaveDev &o = P.oct[oi];
+      const int iw = o.w - 2 * par.border, ih = o.h - 2 * par.border;
+      if (iw <= 0 || ih <= 0) continue;
+      dim3 grid((iw + 63) / 64, (ih + 3) / 4, n_img);
+      for (int lv = 1; lv <= par.numberOfScales; lv++)
+        hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, ctx->stream, ctx->pyr_dev, oi, lv, k, ctx->cand, ctx->cand_count);
+    }
+    MODS_HIP_CHECK(hipGetLastError());
+  }
+  {
+    StageScope ts(ctx, MODS_STAGE_LOCALIZE);
+    hipLaunchKernelGGL(localize_kernel, dim3(256, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, k, ctx->cand, ctx->cand_count);
+    hipLaunchKernelGGL(accept_kernel, dim3(256, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, k, ctx->cand, ctx->cand_count,
+                       ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count);
+    MODS_HIP_CHECK(hipGetLastError());
+  }
+  {
+    StageScope ts(ctx, MODS_STAGE_BAUMBERG);
+    const size_t lds = sizeof(float) * (7 * (size_t)par.smmWindowSize * par.smmWindowSize + 4);
+    hipLaunchKernelGGL(baumberg_kernel, dim3(8192, n_img), dim3(64), lds, ctx->stream, ctx->pyr_dev, k, ctx->cand,
+                       ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->smm_mask_dev, ctx->sort_keys,
+                       ctx->sort_idx, key_count);
+    MODS_HIP_CHECK(hipGetLastError());
+  }
+  {
+    StageScope ts(ctx, MODS_STAGE_SORT);
+    hipLaunchKernelGGL(rank_export_kernel, dim3(512, n_img), dim3(256), 0, ctx->stream, k, ctx->cand, ctx->sort_keys,
+                       ctx->sort_idx, key_count, ctx->keys_dev);
+    MODS_HIP_CHECK(hipGetLastError());
+  }
+  return MODS_OK;
+}
+
+}  // namespace mods

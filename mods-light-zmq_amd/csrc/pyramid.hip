@@ -1,0 +1,377 @@
+// Hessian scale-space pyramid on gfx950: separable Gaussian blur (row + column pass fused
+// through an LDS tile), 3x3 Hessian response, 2x decimation.
+//
+// Reference behaviour (file:line relative to the reference root):
+//   gaussianBlur / gaussianBlurInplace   detectors/helpers.cpp:717-731 (cv::GaussianBlur, REPLICATE)
+//   HessianResponse                      detectors/affinedetectors/pyramid.cpp:196-254
+//   octave loop, sigma schedule          pyramid.cpp:428-529
+//   cv::resize(.., 0.5, 0.5, LINEAR)     pyramid.cpp:476
+// Arithmetic contract (shared with the CPU oracle): fp32, one rounding per operation
+// (-ffp-contract=off), row pass accumulates taps left to right, column pass centre tap first
+// then symmetric pairs k[r+j]*(T[y+j]+T[y-j]) for j = 1..r.
+#include "common.hpp"
+#include "detmath.hpp"
+#include <algorithm>
+#include <cmath>
+
+namespace mods {
+
+// ---------------------------------------------------------------------------------------
+// host-side table builders
+// ---------------------------------------------------------------------------------------
+int gauss_ksize(float sigma) {                    // helpers.cpp:720-721
+  int size = (int)(2.0 * 3.0 * sigma + 1.0);
+  if (size % 2 == 0) size++;
+  return size;
+}
+
+// OpenCV getGaussianKernel(n, sigma, CV_32F): double exp, float taps, normalised by the double
+// sum of the float taps.
+void gauss_kernel_host(int n, double sigma, float *out) {
+  double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+  double scale2X = -0.5 / (sigmaX * sigmaX);
+  double sum = 0;
+  for (int i = 0; i < n; i++) {
+    double x = i - (n - 1) * 0.5;
+    out[i] = (float)det_exp(scale2X * x * x);
+    sum += out[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; i++) out[i] = (float)(out[i] * sum);
+}
+
+void gauss_mask_host(int size, float *mask) {     // computeGaussMask, helpers.cpp:411-440
+  int halfSize = size >> 1;
+  float scale = float(halfSize) / 3.0f;
+  float scale2 = -2.0f * scale * scale;
+  std::vector<float> tmp(halfSize + 1);
+  for (int i = 0; i <= halfSize; i++) tmp[i] = det_expf(float(i * i) / scale2);
+  int endSize = int(ceil(scale * 5.0f) - halfSize);
+  for (int i = 1; i < endSize; i++)
+    tmp[halfSize - i] += det_expf(float((i + halfSize) * (i + halfSize)) / scale2);
+  for (int i = 0; i <= halfSize; i++)
+    for (int j = 0; j <= halfSize; j++) {
+      float v = tmp[i] * tmp[j];
+      mask[(i + halfSize) * size + (-j + halfSize)] = v;
+      mask[(-i + halfSize) * size + (j + halfSize)] = v;
+      mask[(i + halfSize) * size + (j + halfSize)] = v;
+      mask[(-i + halfSize) * size + (-j + halfSize)] = v;
+    }
+}
+
+void circular_gauss_mask_host(int size, float sigma, float *mask) {   // helpers.cpp:442-461
+  int halfSize = size >> 1;
+  float r2 = float(halfSize * halfSize);
+  float sigma2 = (sigma == 0) ? 0.9f * r2 : 2 * sigma * sigma;
+  for (int i = 0; i < size; i++)
+    for (int j = 0; j < size; j++) {
+      float disq = float((i - halfSize) * (i - halfSize) + (j - halfSize) * (j - halfSize));
+      mask[i * size + j] = (disq < r2) ? det_expf(-disq / sigma2) : 0;
+    }
+}
+
+void resize_half_dims(int w, int h, int *dw, int *dh) {   // cvRound(size * 0.5): half to even
+  auto rnd = [](double v) {
+    double fl = floor(v), d = v - fl;
+    if (d > 0.5) return (int)fl + 1;
+    if (d < 0.5) return (int)fl;
+    return (((long long)fl) & 1LL) ? (int)fl + 1 : (int)fl;
+  };
+  *dw = rnd(w * 0.5);
+  *dh = rnd(h * 0.5);
+}
+
+// ---------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------
+constexpr int BLUR_TW = 64;   // output tile width  (one wave-wide row)
+constexpr int BLUR_TH = 32;   // output tile height
+
+// Fused separable blur.  grid = (ceil(w/64), ceil(h/32), n_img), block = 256.
+// LDS: input tile (TH+2r) x (TW+2r), row-pass tile (TH+2r) x TW, taps.
+__global__ __launch_bounds__(256) void gauss_blur_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                         int w, int h, const float *__restrict__ taps, int n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int r = n >> 1;
+  const int IW = BLUR_TW + 2 * r;
+  const int IH = BLUR_TH + 2 * r;
+  float *s_in = smem;
+  float *s_row = smem + IH * IW;
+  float *s_tap = s_row + IH * BLUR_TW;
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)w * h;
+  src += plane * blockIdx.z;
+  dst += plane * blockIdx.z;
+  const int x0 = blockIdx.x * BLUR_TW;
+  const int y0 = blockIdx.y * BLUR_TH;
+
+  if (tid < n) s_tap[tid] = taps[tid];
+  // stage the input tile, BORDER_REPLICATE = clamp
+  for (int ly = tid / 64; ly < IH; ly += 4) {
+    int gy = y0 - r + ly;
+    gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+    const float *row = src + (size_t)gy * w;
+    for (int lx = tid & 63; lx < IW; lx += 64) {
+      int gx = x0 - r + lx;
+      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+      s_in[ly * IW + lx] = row[gx];
+    }
+  }
+  __syncthreads();
+  // row pass: lane = column, taps left to right
+  {
+    const int lx = tid & 63;
+    for (int ly = tid / 64; ly < IH; ly += 4) {
+      const float *p = s_in + ly * IW + lx;
+      float s = s_tap[0] * p[0];
+      for (int j = 1; j < n; j++) s += s_tap[j] * p[j];
+      s_row[ly * BLUR_TW + lx] = s;
+    }
+  }
+  __syncthreads();
+  // column pass: lane = column, each thread walks 8 rows
+  {
+    const int lx = tid & 63;
+    const int gx = x0 + lx;
+    const int ty = tid / 64;
+    if (gx < w) {
+      for (int k = 0; k < BLUR_TH / 4; k++) {
+        const int ly = ty * (BLUR_TH / 4) + k;
+        const int gy = y0 + ly;
+        if (gy >= h) break;
+        const float *p = s_row + (ly + r) * BLUR_TW + lx;
+        float s = s_tap[r] * p[0];
+        for (int j = 1; j <= r; j++) s += s_tap[r + j] * (p[j * BLUR_TW] + p[-j * BLUR_TW]);
+        dst[(size_t)gy * w + gx] = s;
+      }
+    }
+  }
+}
+
+// 3x3 Hessian determinant response.  grid = (ceil(w/64), ceil(h/4), n_img), block = 256.
+__global__ __launch_bounds__(256) void hessian_response_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                               int w, int h, float norm2) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const size_t plane = (size_t)w * h;
+  src += plane * blockIdx.z;
+  dst += plane * blockIdx.z;
+  float out = 0.f;   // the reference leaves the 1-px frame undefined; it is never read
+  if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+    const float *p0 = src + (size_t)(y - 1) * w + x;
+    const float *p1 = p0 + w;
+    const float *p2 = p1 + w;
+    const float v11 = p0[-1], v12 = p0[0], v13 = p0[1];
+    const float v21 = p1[-1], v22 = p1[0], v23 = p1[1];
+    const float v31 = p2[-1], v32 = p2[0], v33 = p2[1];
+    float Lxx = (v21 - 2 * v22 + v23);
+    float Lyy = (v12 - 2 * v22 + v32);
+    float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
+    out = (Lxx * Lyy - Lxy * Lxy) * norm2;
+  }
+  dst[(size_t)y * w + x] = out;
+}
+
+// cv::resize 0.5x: full 2x2 blocks ((a+b)+(c+d))*0.25f, edge blocks running sum / count.
+__global__ __launch_bounds__(256) void resize_half_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                          int w, int h, int dw, int dh) {
+  const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dx >= dw || dy >= dh) return;
+  src += (size_t)w * h * blockIdx.z;
+  dst += (size_t)dw * dh * blockIdx.z;
+  const int sy0 = dy * 2, sx0 = dx * 2;
+  float out;
+  if (sy0 >= h) out = 0.f;
+  else {
+    const int wfull = (sy0 + 2 <= h) ? (w / 2) : 0;
+    if (dx < wfull) {
+      const float *S0 = src + (size_t)sy0 * w + sx0;
+      const float *S1 = S0 + w;
+      out = ((S0[0] + S0[1]) + (S1[0] + S1[1])) * 0.25f;
+    } else if (sx0 >= w) out = 0.f;
+    else {
+      float sum = 0; int count = 0;
+      for (int sy = 0; sy < 2; sy++) {
+        if (sy0 + sy >= h) break;
+        for (int sx = 0; sx < 2; sx++) {
+          if (sx0 + sx >= w) break;
+          sum += src[(size_t)(sy0 + sy) * w + sx0 + sx];
+          count++;
+        }
+      }
+      out = sum / (float)count;
+    }
+  }
+  dst[(size_t)dy * dw + dx] = out;
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+// Tap tables live in 16 device slots of 64 floats; a slot is re-uploaded (synchronously, so
+// the host buffer is never read late) only when its sigma changes: steady state = no copies.
+static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
+  const int n = gauss_ksize(sigma);
+  if (n / 2 > kMaxBlurRadius) { set_error("gaussian kernel too wide: sigma=%g ksize=%d", (double)sigma, n); return MODS_E_ARG; }
+  *n_out = n;
+  if (ctx->taps_sigma[slot] == sigma) return MODS_OK;
+  float taps[2 * kMaxBlurRadius + 1];
+  gauss_kernel_host(n, (double)sigma, taps);
+  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // earlier launches may still read the slot
+  MODS_HIP_CHECK(hipMemcpy(ctx->gauss_taps_dev + slot * 64, taps, sizeof(float) * n, hipMemcpyHostToDevice));
+  ctx->taps_sigma[slot] = sigma;
+  return MODS_OK;
+}
+
+static int blur_with_slot(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, int slot, int n) {
+  const int r = n / 2;
+  const size_t lds = sizeof(float) * ((size_t)(BLUR_TH + 2 * r) * (BLUR_TW + 2 * r) + (size_t)(BLUR_TH + 2 * r) * BLUR_TW + 64);
+  dim3 grid((w + BLUR_TW - 1) / BLUR_TW, (h + BLUR_TH - 1) / BLUR_TH, n_img);
+  StageScope ts(ctx, MODS_STAGE_BLUR, 8.0 * w * h * n_img);
+  hipLaunchKernelGGL(gauss_blur_kernel, grid, dim3(256), lds, ctx->stream, src, dst, w, h, ctx->gauss_taps_dev + slot * 64, n);
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
+int launch_gauss_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, float sigma) {
+  int n;
+  int rc = upload_taps(ctx, 15, sigma, &n);
+  if (rc) return rc;
+  return blur_with_slot(ctx, src, dst, w, h, n_img, 15, n);
+}
+
+int launch_hessian_response(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, float norm) {
+  dim3 grid((w + 63) / 64, (h + 3) / 4, n_img);
+  StageScope ts(ctx, MODS_STAGE_RESPONSE, 8.0 * w * h * n_img);
+  hipLaunchKernelGGL(hessian_response_kernel, grid, dim3(256), 0, ctx->stream, src, dst, w, h, norm * norm);
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
+int launch_resize_half(mods_ctx *ctx, const float *src, float *dst, int w, int h, int dw, int dh, int n_img) {
+  dim3 grid((dw + 63) / 64, (dh + 3) / 4, n_img);
+  StageScope ts(ctx, MODS_STAGE_RESIZE, 5.0 * w * h * n_img);
+  hipLaunchKernelGGL(resize_half_kernel, grid, dim3(256), 0, ctx->stream, src, dst, w, h, dw, dh);
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// scale-space layout + build
+// ---------------------------------------------------------------------------------------
+// Computes the octave ladder (pyramid.cpp:520-528) and carves the planes out of the pools.
+int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff_params *par) {
+  if (w <= 0 || h <= 0 || n_img <= 0 || n_img > ctx->batch) { set_error("bad image batch %dx%d x%d (ctx batch %d)", w, h, n_img, ctx->batch); return MODS_E_ARG; }
+  const int n_levels = par->numberOfScales + 2;
+  if (par->numberOfScales < 1 || n_levels > kMaxLevels) { set_error("numberOfScales %d unsupported", par->numberOfScales); return MODS_E_ARG; }
+  if (par->border < 2) { set_error("border must be >= 2"); return MODS_E_ARG; }
+  PyramidDev &P = ctx->pyr;
+  P.n_levels = n_levels;
+  P.n_oct = 0;
+  const int minSize = 2 * par->border + 2;
+  int cw = w, ch = h;
+  float pd = 1.0f;
+  size_t plane_elems = 0, omap_elems = 0;
+  const float sigmaStep = det_pow2f(1.0f / (float)par->numberOfScales);
+  while (ch > minSize && cw > minSize) {
+    if (P.n_oct >= kMaxOctaves) break;
+    OctaveDev &o = P.oct[P.n_oct++];
+    o.w = cw; o.h = ch; o.pixelDistance = pd;
+    float cur = par->initialSigma;
+    for (int l = 0; l < n_levels; l++) { o.sigma[l] = cur; cur *= sigmaStep; }
+    plane_elems += (size_t)cw * ch * n_img * 2 * n_levels;
+    omap_elems += (size_t)cw * ch * n_img;
+    int nw, nh;
+    resize_half_dims(cw, ch, &nw, &nh);
+    cw = nw; ch = nh;
+    pd *= 2.0f;
+  }
+  if (plane_elems > ctx->plane_pool_elems) {
+    if (ctx->plane_pool) MODS_HIP_CHECK(hipFree(ctx->plane_pool));
+    ctx->plane_pool = nullptr;
+    MODS_HIP_CHECK(hipMalloc(&ctx->plane_pool, plane_elems * sizeof(float)));
+    ctx->plane_pool_elems = plane_elems;
+  }
+  if (omap_elems > ctx->omap_pool_elems) {
+    if (ctx->omap_pool) MODS_HIP_CHECK(hipFree(ctx->omap_pool));
+    ctx->omap_pool = nullptr;
+    MODS_HIP_CHECK(hipMalloc(&ctx->omap_pool, omap_elems * sizeof(unsigned int)));
+    ctx->omap_pool_elems = omap_elems;
+  }
+  float *pp = ctx->plane_pool;
+  unsigned int *mp = ctx->omap_pool;
+  for (int oi = 0; oi < P.n_oct; oi++) {
+    OctaveDev &o = P.oct[oi];
+    const size_t n = (size_t)o.w * o.h * n_img;
+    for (int l = 0; l < n_levels; l++) { o.blur[l] = pp; pp += n; o.resp[l] = pp; pp += n; }
+    o.omap = mp; mp += n;
+  }
+  MODS_HIP_CHECK(hipMemcpyAsync(ctx->pyr_dev, &P, sizeof(PyramidDev), hipMemcpyHostToDevice, ctx->stream));
+  ctx->par = *par;
+  ctx->last_w = w; ctx->last_h = h; ctx->last_n_img = n_img;
+  // SMM mask for Baumberg
+  if (ctx->smm_mask_size != par->smmWindowSize) {
+    if (par->smmWindowSize < 3 || par->smmWindowSize > 31 || !(par->smmWindowSize & 1)) { set_error("smmWindowSize %d unsupported", par->smmWindowSize); return MODS_E_ARG; }
+    std::vector<float> m((size_t)par->smmWindowSize * par->smmWindowSize);
+    gauss_mask_host(par->smmWindowSize, m.data());
+    MODS_HIP_CHECK(hipMemcpy(ctx->smm_mask_dev, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->smm_mask_size = par->smmWindowSize;
+  }
+  return MODS_OK;
+}
+
+// detectPyramidKeypoints / detectOctaveKeypoints (pyramid.cpp:496-529, 428-494): every blur and
+// response plane of every octave, for the whole batch.  `img_dev`: [n_img][h][stride].
+int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
+  PyramidDev &P = ctx->pyr;
+  const mods_hessaff_params &par = ctx->par;
+  const int n_img = ctx->last_n_img, w = ctx->last_w, h = ctx->last_h;
+  const int S = par.numberOfScales;
+  if (P.n_oct == 0) return MODS_OK;
+  int rc;
+  // tap tables: slot 0 = initial blur, slot l = increment to level l
+  int ntap[kMaxLevels + 1];
+  const float sigmaStep = det_pow2f(1.0f / (float)S);
+  const float curSigma0 = 0.5f;
+  bool initial_blur = par.initialSigma > curSigma0;
+  if (initial_blur) {
+    float sigma = sqrtf(par.initialSigma * par.initialSigma - curSigma0 * curSigma0);
+    if ((rc = upload_taps(ctx, 0, sigma, &ntap[0]))) return rc;
+  }
+  for (int l = 1; l < P.n_levels; l++) {
+    float sigma = P.oct[0].sigma[l - 1] * sqrtf(sigmaStep * sigmaStep - 1.0f);
+    if ((rc = upload_taps(ctx, l, sigma, &ntap[l]))) return rc;
+  }
+  // first level of octave 0
+  const float *src0 = img_dev;
+  float *packed = nullptr;
+  if (stride != w) {   // repack to contiguous planes
+    packed = ctx->tmp_dev;
+    MODS_HIP_CHECK(hipMemcpy2DAsync(packed, sizeof(float) * w, img_dev, sizeof(float) * stride, sizeof(float) * w,
+                                    (size_t)h * n_img, hipMemcpyDeviceToDevice, ctx->stream));
+    src0 = packed;
+  }
+  if (initial_blur) {
+    if ((rc = blur_with_slot(ctx, src0, P.oct[0].blur[0], w, h, n_img, 0, ntap[0]))) return rc;
+  } else {
+    MODS_HIP_CHECK(hipMemcpyAsync(P.oct[0].blur[0], src0, sizeof(float) * (size_t)w * h * n_img, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  for (int oi = 0; oi < P.n_oct; oi++) {
+    OctaveDev &o = P.oct[oi];
+    if ((rc = launch_hessian_response(ctx, o.blur[0], o.resp[0], o.w, o.h, n_img, o.sigma[0] * o.sigma[0]))) return rc;
+    for (int l = 1; l < P.n_levels; l++) {
+      if ((rc = blur_with_slot(ctx, o.blur[l - 1], o.blur[l], o.w, o.h, n_img, l, ntap[l]))) return rc;
+      const float sigma = o.sigma[l - 1] * sigmaStep;   // pyramid.cpp:455-458
+      if ((rc = launch_hessian_response(ctx, o.blur[l], o.resp[l], o.w, o.h, n_img, sigma * sigma))) return rc;
+      if (l == S && oi + 1 < P.n_oct) {
+        OctaveDev &nx = P.oct[oi + 1];
+        if ((rc = launch_resize_half(ctx, o.blur[l], nx.blur[0], o.w, o.h, nx.w, nx.h, n_img))) return rc;
+      }
+    }
+  }
+  return MODS_OK;
+}
+
+}  // namespace mods

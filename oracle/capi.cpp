@@ -1,0 +1,142 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Plain-C entry points of the CPU restatement for the
+// python tests (ctypes), smoke() and bench.py's cpu_baseline leg.  Never linked into the
+// product library.
+#include "orc.h"
+#include "detmath.h"
+#include <cstring>
+
+using namespace orc;
+
+extern "C" {
+
+struct orc_hessaff_params {     // mirrors include/mods_hip.h: mods_hessaff_params
+  int numberOfScales;
+  float initialSigma;
+  float threshold;
+  float edgeEigenValueRatio;
+  int border;
+  int maxIterations;
+  float convergenceThreshold;
+  int smmWindowSize;
+  int doBaumberg;
+};
+
+struct orc_candidate { int octave, level, r0, c0, r, c; float x, y, s, pixelDistance, response; int type; };
+struct orc_affkey { double x, y, s, a11, a12, a21, a22, response; int sub_type, octave, level, r0, c0, pad; };
+
+static HessAffParams cvt(const orc_hessaff_params *p) {
+  HessAffParams q;
+  if (p) {
+    q.numberOfScales = p->numberOfScales; q.initialSigma = p->initialSigma; q.threshold = p->threshold;
+    q.edgeEigenValueRatio = p->edgeEigenValueRatio; q.border = p->border; q.maxIterations = p->maxIterations;
+    q.convergenceThreshold = p->convergenceThreshold; q.smmWindowSize = p->smmWindowSize; q.doBaumberg = p->doBaumberg;
+  }
+  return q;
+}
+static Img wrap(const float *src, int w, int h) {
+  Img im(w, h);
+  std::memcpy(im.d.data(), src, sizeof(float) * (size_t)w * h);
+  return im;
+}
+
+int orc_gauss_ksize(float sigma) { return gauss_ksize(sigma); }
+void orc_gauss_kernel(int n, double sigma, float *out) {
+  std::vector<float> k = gauss_kernel(n, sigma);
+  std::memcpy(out, k.data(), sizeof(float) * n);
+}
+void orc_gauss_blur(const float *src, int w, int h, float sigma, float *dst) {
+  Img a = wrap(src, w, h), b;
+  gauss_blur(a, b, sigma);
+  std::memcpy(dst, b.d.data(), sizeof(float) * (size_t)w * h);
+}
+void orc_hessian_response(const float *src, int w, int h, float norm, float *dst) {
+  Img a = wrap(src, w, h), b;
+  hessian_response(a, b, norm);
+  std::memcpy(dst, b.d.data(), sizeof(float) * (size_t)w * h);
+}
+void orc_resize_half_dims(int w, int h, int *dw, int *dh) {
+  Img a(w, h), b;
+  resize_half(a, b);
+  *dw = b.w; *dh = b.h;
+}
+void orc_resize_half(const float *src, int w, int h, float *dst) {
+  Img a = wrap(src, w, h), b;
+  resize_half(a, b);
+  std::memcpy(dst, b.d.data(), sizeof(float) * (size_t)b.w * b.h);
+}
+int orc_interpolate(const float *src, int w, int h, float ofsx, float ofsy, float a11, float a12, float a21,
+                    float a22, int rw, int rh, float *dst) {
+  Img a = wrap(src, w, h), r(rw, rh);
+  bool t = interpolate(a, ofsx, ofsy, a11, a12, a21, a22, r);
+  std::memcpy(dst, r.d.data(), sizeof(float) * (size_t)rw * rh);
+  return t ? 1 : 0;
+}
+void orc_gauss_mask(int size, float *dst) {
+  Img m(size, size); compute_gauss_mask(m);
+  std::memcpy(dst, m.d.data(), sizeof(float) * (size_t)size * size);
+}
+void orc_circular_gauss_mask(int size, float sigma, float *dst) {
+  Img m(size, size); compute_circular_gauss_mask(m, sigma);
+  std::memcpy(dst, m.d.data(), sizeof(float) * (size_t)size * size);
+}
+float orc_det_pow2f(float x) { return det_pow2f(x); }
+float orc_det_expf(float x) { return det_expf(x); }
+void orc_det_sincos(double a, double *s, double *c) { det_sincos(a, s, c); }
+float orc_atan2_lut(float y, float x) { return atan2_lut_ff(y, x); }
+
+// ---- pyramid handle ----------------------------------------------------------------------
+void *orc_pyramid_build(const float *img, int w, int h, const orc_hessaff_params *p) {
+  Pyramid *pyr = new Pyramid();
+  build_pyramid(wrap(img, w, h), cvt(p), *pyr);
+  return pyr;
+}
+void orc_pyramid_free(void *h) { delete (Pyramid *)h; }
+int orc_pyramid_octaves(void *h) { return (int)((Pyramid *)h)->oct.size(); }
+void orc_pyramid_dims(void *h, int o, int *w, int *hh) { *w = ((Pyramid *)h)->oct[o].w; *hh = ((Pyramid *)h)->oct[o].h; }
+// kind 0 = blur, 1 = response
+void orc_pyramid_plane(void *h, int o, int level, int kind, float *dst) {
+  const Pyramid::Oct &oc = ((Pyramid *)h)->oct[o];
+  const Img &im = kind ? oc.resp[level] : oc.blur[level];
+  std::memcpy(dst, im.d.data(), sizeof(float) * (size_t)im.w * im.h);
+}
+int orc_pyramid_candidates(void *h, const orc_hessaff_params *p, orc_candidate *out, int max_out,
+                           int *nms_raw, int max_raw, int *n_raw) {
+  std::vector<Candidate> c;
+  std::vector<int> raw;
+  find_candidates(*(Pyramid *)h, cvt(p), c, &raw);
+  int n = (int)c.size();
+  for (int i = 0; i < n && i < max_out; i++) {
+    orc_candidate &o = out[i];
+    o.octave = c[i].octave; o.level = c[i].level; o.r0 = c[i].r0; o.c0 = c[i].c0; o.r = c[i].r; o.c = c[i].c;
+    o.x = c[i].x; o.y = c[i].y; o.s = c[i].s; o.pixelDistance = c[i].pixelDistance; o.response = c[i].response;
+    o.type = c[i].type;
+  }
+  int nr = (int)raw.size() / 4;
+  if (n_raw) *n_raw = nr;
+  if (nms_raw) for (int i = 0; i < nr * 4 && i < max_raw * 4; i++) nms_raw[i] = raw[i];
+  return n;
+}
+// Baumberg for one keypoint on plane (octave, level) of the pyramid.
+int orc_affine_shape(void *h, int o, int level, float x, float y, float s, float pixelDistance,
+                     const orc_hessaff_params *p, float *a4, int *iters) {
+  HessAffParams q = cvt(p);
+  Img mask(q.smmWindowSize, q.smmWindowSize);
+  compute_gauss_mask(mask);
+  return find_affine_shape(((Pyramid *)h)->oct[o].blur[level], x, y, s, pixelDistance, q, mask, a4, iters) ? 1 : 0;
+}
+
+int orc_detect_hessian_affine(const float *img, int w, int h, const orc_hessaff_params *p, orc_affkey *out,
+                              int max_out) {
+  std::vector<AffKey> k;
+  detect_hessian_affine(wrap(img, w, h), cvt(p), k);
+  int n = (int)k.size();
+  for (int i = 0; i < n && i < max_out; i++) {
+    orc_affkey &o = out[i];
+    o.x = k[i].x; o.y = k[i].y; o.s = k[i].s; o.a11 = k[i].a11; o.a12 = k[i].a12; o.a21 = k[i].a21; o.a22 = k[i].a22;
+    o.response = k[i].response; o.sub_type = k[i].sub_type; o.octave = k[i].octave; o.level = k[i].level;
+    o.r0 = k[i].r0; o.c0 = k[i].c0; o.pad = 0;
+  }
+  return n;
+}
+
+}  // extern "C"

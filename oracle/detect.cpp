@@ -1,0 +1,280 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Hessian scale-space pyramid, 3x3x3 NMS, sub-pixel
+// localisation and Baumberg affine-shape iteration, restated from
+// detectors/affinedetectors/{pyramid.h,pyramid.cpp,affine.cpp,scale-space-detector.hpp}.
+#include "orc.h"
+#include "detmath.h"
+#include <algorithm>
+#include <cmath>
+
+namespace orc {
+
+// detectPyramidKeypoints + detectOctaveKeypoints (pyramid.cpp:496-529, 428-494), blur /
+// response planes only.  upscaleInputImage = 0 (structures.hpp:137).
+void build_pyramid(const Img &image, const HessAffParams &p, Pyramid &pyr) {
+  pyr.oct.clear();
+  float curSigma0 = 0.5f;
+  float pixelDistance = 1.0f;
+  Img first = image;
+  if (p.initialSigma > curSigma0) {
+    float sigma = std::sqrt(p.initialSigma * p.initialSigma - curSigma0 * curSigma0);
+    gauss_blur(first, first, sigma);
+  }
+  const int minSize = 2 * p.border + 2;
+  while (first.h > minSize && first.w > minSize) {
+    Pyramid::Oct o;
+    o.w = first.w; o.h = first.h; o.pixelDistance = pixelDistance;
+    float sigmaStep = det_pow2f(1.0f / (float)p.numberOfScales);   // pow(2.0f, 1/nScales)
+    float curSigma = p.initialSigma;
+    o.blur.push_back(first);
+    o.sigma.push_back(curSigma);
+    Img r;
+    hessian_response(first, r, curSigma * curSigma);
+    o.resp.push_back(r);
+    Img next;
+    for (int i = 1; i < p.numberOfScales + 2; i++) {
+      float sigma = curSigma * std::sqrt(sigmaStep * sigmaStep - 1.0f);
+      Img nb;
+      gauss_blur(o.blur.back(), nb, sigma);
+      sigma = curSigma * sigmaStep;
+      Img rr;
+      hessian_response(nb, rr, sigma * sigma);
+      if (i == p.numberOfScales) resize_half(nb, next);
+      o.blur.push_back(nb);
+      o.resp.push_back(rr);
+      curSigma *= sigmaStep;
+      o.sigma.push_back(curSigma);
+    }
+    pyr.oct.push_back(o);
+    pixelDistance *= 2.0f;
+    first = next;
+  }
+}
+
+static bool is_max(float val, const Img &pix, int row, int col) {   // pyramid.cpp:41-51
+  for (int r = row - 1; r <= row + 1; r++) {
+    const float *p = pix.row(r);
+    for (int c = col - 1; c <= col + 1; c++)
+      if (p[c] > val) return false;
+  }
+  return true;
+}
+static bool is_min(float val, const Img &pix, int row, int col) {   // pyramid.cpp:53-63
+  for (int r = row - 1; r <= row + 1; r++) {
+    const float *p = pix.row(r);
+    for (int c = col - 1; c <= col + 1; c++)
+      if (p[c] < val) return false;
+  }
+  return true;
+}
+
+// ScaleSpaceDetector ctor thresholds, pyramid.h:46-66 (FIXED_TH, DET_HESSIAN): members are
+// initialised in declaration order edgeScoreThreshold, finalThreshold, positiveThreshold,
+// negativeThreshold => positive = 0.8 * threshold (un-squared), final = threshold^2.
+struct Thresholds {
+  double edgeScoreThreshold;
+  float finalThreshold, positiveThreshold, negativeThreshold;
+  explicit Thresholds(const HessAffParams &p) {
+    edgeScoreThreshold = (p.edgeEigenValueRatio + 1.0f) * (p.edgeEigenValueRatio + 1.0f) / p.edgeEigenValueRatio;
+    finalThreshold = p.threshold;
+    positiveThreshold = (float)(0.8 * finalThreshold);
+    negativeThreshold = -positiveThreshold;
+    finalThreshold = p.threshold * p.threshold;
+  }
+};
+
+// localizeKeypoint, pyramid.cpp:281-403.  Returns true and fills `out` when the point is
+// accepted; octaveMap handling stays with the caller's processing order.
+static bool localize(const Img &low, const Img &cur, const Img &high, const Img &blur,
+                     std::vector<unsigned char> &octaveMap, int r, int c, float curScale,
+                     float pixelDistance, const HessAffParams &p, const Thresholds &th, Candidate &out) {
+  const int cols = cur.w, rows = cur.h;
+  float b[3] = {0, 0, 0};
+  float val = 0;
+  int nr = r, nc = c;
+  for (int iter = 0; iter < 5; iter++) {
+    r = nr; c = nc;
+    const float *cur0 = cur.row(r - 1), *cur1 = cur.row(r), *cur2 = cur.row(r + 1);
+    const float *low0 = low.row(r - 1), *low1 = low.row(r), *low2 = low.row(r + 1);
+    const float *high0 = high.row(r - 1), *high1 = high.row(r), *high2 = high.row(r + 1);
+    float dxx = cur1[c - 1] - 2.0f * cur1[c] + cur1[c + 1];
+    float dyy = cur0[c] - 2.0f * cur1[c] + cur2[c];
+    float dss = low1[c] - 2.0f * cur1[c] + high1[c];
+    float dxy = 0.25f * (cur2[c + 1] - cur2[c - 1] - cur0[c + 1] + cur0[c - 1]);
+    if (0 == iter) {
+      float edgeScore = (dxx + dyy) * (dxx + dyy) / (dxx * dyy - dxy * dxy);
+      if (edgeScore >= th.edgeScoreThreshold || edgeScore < 0) return false;
+    }
+    float dxs = 0.25f * (high1[c + 1] - high1[c - 1] - low1[c + 1] + low1[c - 1]);
+    float dys = 0.25f * (high2[c] - high0[c] - low2[c] + low0[c]);
+    float A[9] = {dxx, dxy, dxs, dxy, dyy, dys, dxs, dys, dss};
+    float dx = 0.5f * (cur1[c + 1] - cur1[c - 1]);
+    float dy = 0.5f * (cur2[c] - cur0[c]);
+    float ds = 0.5f * (high1[c] - low1[c]);
+    b[0] = -dx; b[1] = -dy; b[2] = -ds;
+    solve_linear_3x3(A, b);
+    if (std::isnan(b[0]) || std::isnan(b[1]) || std::isnan(b[2])) return false;
+    val = cur1[c] + 0.5f * (dx * b[0] + dy * b[1] + ds * b[2]);
+    // MAX_SUBPIXEL_SHIFT 0.6 and POINT_SAFETY_BORDER 3 (pyramid.cpp:26,29); 0.6 is a double.
+    if (b[0] > 0.6) { if (c < cols - 3) nc++; else return false; }
+    if (b[1] > 0.6) { if (r < rows - 3) nr++; else return false; }
+    if (b[0] < -0.6) { if (c > 3) nc--; else return false; }
+    if (b[1] < -0.6) { if (r > 3) nr--; else return false; }
+    if (nr == r && nc == c) break;
+  }
+  if (std::fabs(b[0]) > 1.5 || std::fabs(b[1]) > 1.5 || std::fabs(b[2]) > 1.5 ||
+      std::fabs(val) < th.finalThreshold || octaveMap[(size_t)r * cols + c] > 0)
+    return false;
+  octaveMap[(size_t)r * cols + c] = 1;
+  float scale = curScale * det_pow2f(b[2] / p.numberOfScales);
+  // getPointType, pyramid.cpp:65-82 (HESSIAN_DARK 0, BRIGHT 1, SADDLE 2)
+  int type;
+  if (val < 0) type = 2;
+  else {
+    const float *ptr = blur.row(r) + c;
+    float Lxx = (ptr[-1] - 2 * ptr[0] + ptr[1]);
+    type = (Lxx < 0) ? 0 : 1;
+  }
+  out.r = r; out.c = c;
+  out.x = pixelDistance * (c + b[0]);
+  out.y = pixelDistance * (r + b[1]);
+  out.s = pixelDistance * scale;
+  out.pixelDistance = pixelDistance;
+  out.type = type;
+  out.response = val;
+  return true;
+}
+
+// findLevelKeypoints (pyramid.cpp:405-425) for the three detection levels of every octave in
+// the reference's processing order: octave, then level 1..S, then raster.
+// nms_raw (optional) receives (octave, level, r, c) of every NMS hit before localisation.
+void find_candidates(const Pyramid &pyr, const HessAffParams &p, std::vector<Candidate> &out,
+                     std::vector<int> *nms_raw) {
+  Thresholds th(p);
+  out.clear();
+  for (size_t oi = 0; oi < pyr.oct.size(); oi++) {
+    const Pyramid::Oct &o = pyr.oct[oi];
+    std::vector<unsigned char> octaveMap((size_t)o.w * o.h, 0);
+    for (int lv = 1; lv <= p.numberOfScales; lv++) {
+      const Img &low = o.resp[lv - 1], &cur = o.resp[lv], &high = o.resp[lv + 1];
+      const Img &blur = o.blur[lv];
+      const float curSigma = o.sigma[lv];
+      for (int r = p.border; r < (o.h - p.border); r++) {
+        const float *curPtr = cur.row(r);
+        for (int c = p.border; c < (o.w - p.border); c++) {
+          const float val = curPtr[c];
+          if ((val > th.positiveThreshold && (is_max(val, cur, r, c) && is_max(val, low, r, c) && is_max(val, high, r, c))) ||
+              (val < th.negativeThreshold && (is_min(val, cur, r, c) && is_min(val, low, r, c) && is_min(val, high, r, c)))) {
+            if (nms_raw) { nms_raw->push_back((int)oi); nms_raw->push_back(lv); nms_raw->push_back(r); nms_raw->push_back(c); }
+            Candidate cd;
+            cd.octave = (int)oi; cd.level = lv; cd.r0 = r; cd.c0 = c;
+            if (localize(low, cur, high, blur, octaveMap, r, c, curSigma, o.pixelDistance, p, th, cd))
+              out.push_back(cd);
+          }
+        }
+      }
+    }
+  }
+}
+
+// AffineShape::findAffineShape, SMM branch (affine.cpp:26-158).
+bool find_affine_shape(const Img &blur, float x, float y, float s, float pixelDistance,
+                       const HessAffParams &p, const Img &mask, float a_out[4], int *iters) {
+  float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
+  float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
+  float lx = x / pixelDistance, ly = y / pixelDistance;
+  float ratio = s / (p.initialSigma * pixelDistance);
+  const int W = p.smmWindowSize;
+  if (!p.doBaumberg) {
+    a_out[0] = u11; a_out[1] = u12; a_out[2] = u21; a_out[3] = u22;
+    if (iters) *iters = 0;
+    return true;
+  }
+  const int maskPixels = W * W;
+  Img img(W, W), fx(W, W), fy(W, W);
+  for (int l = 0; l < p.maxIterations; l++) {
+    float a = 0, b = 0, c = 0;
+    interpolate(blur, lx, ly, u11 * ratio, u12 * ratio, u21 * ratio, u22 * ratio, img);
+    compute_gradient(img, fx, fy);
+    const float *maskptr = mask.d.data();
+    const float *pfx = fx.d.data(), *pfy = fy.d.data();
+    for (int i = 0; i < maskPixels; ++i) {
+      const float v = maskptr[i];
+      const float gxx = pfx[i];
+      const float gyy = pfy[i];
+      const float gxy = gxx * gyy;
+      a += gxx * gxx * v;
+      b += gxy * v;
+      c += gyy * gyy * v;
+    }
+    a /= maskPixels;
+    b /= maskPixels;
+    c /= maskPixels;
+    inv_sqrt(a, b, c, l1, l2);
+    if ((a != a) || (b != b) || (c != c)) break;
+    eigen_ratio_bef = eigen_ratio_act;
+    eigen_ratio_act = (float)(1.0 - l2 / l1);
+    float u11t = u11, u12t = u12;
+    u11 = a * u11t + b * u21;
+    u12 = a * u12t + b * u22;
+    u21 = b * u11t + c * u21;
+    u22 = b * u12t + c * u22;
+    if (!get_eigenvalues(u11, u12, u21, u22, l1, l2)) break;
+    if ((l1 / l2 > 6) || (l2 / l1 > 6)) break;
+    if (eigen_ratio_act < p.convergenceThreshold && eigen_ratio_bef < p.convergenceThreshold) {
+      a_out[0] = u11; a_out[1] = u12; a_out[2] = u21; a_out[3] = u22;
+      if (iters) *iters = l;
+      return true;
+    }
+  }
+  return false;
+}
+
+// synth-detection.cpp:134-143
+static void rectify_transformation(double &a11, double &a12, double &a21, double &a22) {
+  double a = a11, b = a12, c = a21, d = a22;
+  double det = std::sqrt(std::fabs(a * d - b * c));
+  double b2a2 = std::sqrt(b * b + a * a);
+  a11 = b2a2 / det;
+  a12 = 0;
+  a21 = (d * b + c * a) / (b2a2 * det);
+  a22 = det / b2a2;
+}
+
+// DetectAffineKeypoints (scale-space-detector.cpp:13-32) -> onKeypointDetected ->
+// findAffineShape on prevBlur (= blur level-1 of the detection level, pyramid.cpp:402,478) ->
+// exportKeypoints: sort by |response| descending (scale-space-detector.hpp:120-131; std::sort is
+// unstable on ties, fixed here as processing order) -> DetectAffineRegions
+// (synth-detection.hpp:79-112): s *= sqrt|det A|, A -> lower-triangular det 1.  FIXED_TH mode.
+void detect_hessian_affine(const Img &image, const HessAffParams &p, std::vector<AffKey> &out) {
+  Pyramid pyr;
+  build_pyramid(image, p, pyr);
+  std::vector<Candidate> cand;
+  find_candidates(pyr, p, cand);
+  Img mask(p.smmWindowSize, p.smmWindowSize);
+  compute_gauss_mask(mask);
+  std::vector<AffKey> keys;
+  for (size_t i = 0; i < cand.size(); i++) {
+    const Candidate &cd = cand[i];
+    const Img &prevBlur = pyr.oct[cd.octave].blur[cd.level - 1];
+    float a[4]; int it;
+    if (!find_affine_shape(prevBlur, cd.x, cd.y, cd.s, cd.pixelDistance, p, mask, a, &it)) continue;
+    AffKey k;
+    k.x = cd.x; k.y = cd.y; k.s = cd.s;
+    k.a11 = a[0]; k.a12 = a[1]; k.a21 = a[2]; k.a22 = a[3];
+    k.response = cd.response; k.sub_type = cd.type;
+    k.octave = cd.octave; k.level = cd.level; k.r0 = cd.r0; k.c0 = cd.c0;
+    keys.push_back(k);
+  }
+  std::stable_sort(keys.begin(), keys.end(),
+                   [](const AffKey &k1, const AffKey &k2) { return std::fabs(k1.response) > std::fabs(k2.response); });
+  out.clear();
+  out.reserve(keys.size());
+  for (size_t i = 0; i < keys.size(); i++) {
+    AffKey k = keys[i];
+    k.s = k.s * std::sqrt(std::fabs(k.a11 * k.a22 - k.a12 * k.a21));
+    rectify_transformation(k.a11, k.a12, k.a21, k.a22);
+    out.push_back(k);
+  }
+}
+
+}  // namespace orc

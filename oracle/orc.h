@@ -1,0 +1,117 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see detmath.h).  CPU restatement of the reference's
+// detect -> describe -> match -> verify path.  Every function cites the reference
+// file:line it follows (paths relative to the reference root).
+//
+// Parity status: the degensac part (RANSAC) is pinned against the reference's own C code
+// compiled from /root/reference (oracle/_ref, see Makefile).  The OpenCV-dependent parts
+// (GaussianBlur, resize, FLANN linear search) are restated from OpenCV's documented
+// algorithms with a fixed summation order; OpenCV is not in the image and the reference
+// pins no version => for those stages: "parity unpinned" (see DESIGN.md).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace orc {
+
+struct Img {
+  int w = 0, h = 0;
+  std::vector<float> d;
+  Img() {}
+  Img(int w_, int h_) : w(w_), h(h_), d((size_t)w_ * h_, 0.f) {}
+  float *row(int y) { return d.data() + (size_t)y * w; }
+  const float *row(int y) const { return d.data() + (size_t)y * w; }
+  float &at(int y, int x) { return d[(size_t)y * w + x]; }
+  float at(int y, int x) const { return d[(size_t)y * w + x]; }
+};
+
+// ---- image primitives (image_ops.cpp) -------------------------------------------------
+int gauss_ksize(float sigma);                                  // detectors/helpers.cpp:720-721
+std::vector<float> gauss_kernel(int n, double sigma);          // OpenCV getGaussianKernel, CV_32F
+void gauss_blur(const Img &src, Img &dst, float sigma);        // detectors/helpers.cpp:717-731
+void resize_half(const Img &src, Img &dst);                    // pyramid.cpp:476 (cv::resize 0.5)
+void hessian_response(const Img &in, Img &out, float norm);    // pyramid.cpp:196-254
+bool interpolate_check_borders(int img_w, int img_h, float ofsx, float ofsy, float a11,
+                               float a12, float a21, float a22, int res_w, int res_h);
+bool interpolate(const Img &im, float ofsx, float ofsy, float a11, float a12, float a21,
+                 float a22, Img &res);                         // detectors/helpers.cpp:551-626
+void compute_gauss_mask(Img &mask);                            // detectors/helpers.cpp:411-440
+void compute_circular_gauss_mask(Img &mask, float sigma);      // detectors/helpers.cpp:442-461
+void compute_gradient(const Img &img, Img &gx, Img &gy);       // detectors/helpers.cpp:779-797
+void solve_linear_3x3(float *A, float *b);                     // detectors/helpers.cpp:309-368
+void inv_sqrt(float &a, float &b, float &c, float &l1, float &l2);   // helpers.cpp:463-502
+bool get_eigenvalues(float a, float b, float c, float d, float &l1, float &l2);  // :504-515
+void photometrically_normalize(Img &image, const Img &mask, float &sum, float &var);  // :666-715
+
+// ---- detector (detect.cpp) ------------------------------------------------------------
+struct HessAffParams {          // PyramidParams + AffineShapeParams, detectors/structures.hpp:114-150,
+  int numberOfScales = 3;       // affine.h:26-68; defaults = build/config_affori_classic.ini
+  float initialSigma = 1.6f;
+  float threshold = 5.33f;
+  double edgeEigenValueRatio = 10.0;
+  int border = 5;
+  int maxIterations = 16;
+  float convergenceThreshold = 0.05f;
+  int smmWindowSize = 19;
+  int doBaumberg = 1;
+};
+
+struct Candidate {              // one accepted pyramid keypoint before affine adaptation
+  int octave, level, r0, c0;    // NMS position that spawned it (processing order key)
+  int r, c;                     // final integer position after localisation
+  float x, y, s, pixelDistance, response;
+  int type;
+};
+
+struct AffKey {                 // AffineKeypoint subset, detectors/structures.hpp:185-195
+  double x, y, s, a11, a12, a21, a22, response;
+  int sub_type;
+  int octave, level, r0, c0;    // provenance (not in the reference struct; for parity tests)
+};
+
+struct Pyramid {
+  struct Oct { int w, h; float pixelDistance; std::vector<Img> blur, resp; std::vector<float> sigma; };
+  std::vector<Oct> oct;
+};
+
+void build_pyramid(const Img &image, const HessAffParams &p, Pyramid &pyr);
+void find_candidates(const Pyramid &pyr, const HessAffParams &p, std::vector<Candidate> &out,
+                     std::vector<int> *nms_raw = nullptr);
+bool find_affine_shape(const Img &blur, float x, float y, float s, float pixelDistance,
+                       const HessAffParams &p, const Img &mask, float a[4], int *iters);
+// Full DetectAffineKeypoints + DetectAffineRegions (scale-space-detector.cpp:13-32,
+// synth-detection.hpp:79-112): sorted by |response| desc, s*=sqrt|det|, A rectified.
+void detect_hessian_affine(const Img &image, const HessAffParams &p, std::vector<AffKey> &out);
+
+// ---- orientation + descriptor (describe.cpp) -------------------------------------------
+struct Region {                 // AffineRegion subset: det_kp == reproj_kp for the identity view
+  double x, y, s, a11, a12, a21, a22, response;
+  int sub_type;
+  int id, parent;
+  uint8_t desc[128];
+};
+// ReprojectRegionsAndRemoveTouchBoundary(dontRemove=true) for H=I: keep centres inside.
+void filter_centres_inside(std::vector<Region> &r, int w, int h);           // synth-detection.cpp:151-190
+int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, const Img &img,
+                       double mrSize, int patchSize, int maxAngles, double th);   // :1039-1149
+void filter_touch_boundary(std::vector<Region> &r, int w, int h);           // ReprojectRegions :631-706
+void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize,
+                       bool photoNorm);                                     // synth-detection.hpp:170-263
+void sift_patch_to_desc(const Img &patch41, uint8_t out[128], bool rootsift);   // matching/siftdesc.cpp
+void extract_desc_patch(const Region &r, const Img &img, double mrSize, int patchSize, bool photoNorm,
+                        Img &patch);
+bool dominant_angle(const Img &patch, double th, float *angle);              // :836-929 (maxAngles=1)
+
+// ---- matching (match.cpp) ------------------------------------------------------------------
+struct Tentative {
+  int q, t;            // first (query idx in list1), second (train idx in list2)
+  int t_bad, t_2nd;    // secondbad, secondbadby2ndcl
+  float d1, d2, d2nd;  // squared L2 (integer valued)
+  double ratio;        // sqrt(d1/d2)
+};
+int match_fginn(const std::vector<Region> &q, const std::vector<Region> &t, std::vector<Tentative> &out,
+                double ratio, double contradDist, int nn);                   // matching.cpp:356-460
+void duplicate_filter(std::vector<Tentative> &tc, const std::vector<Region> &q,
+                      const std::vector<Region> &t, double r, int mode);      // matching.cpp:2615-2679
+
+}  // namespace orc

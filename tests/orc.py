@@ -1,0 +1,171 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_lib = None
+
+
+class HessAffParams(C.Structure):
+    _fields_ = [("numberOfScales", C.c_int), ("initialSigma", C.c_float), ("threshold", C.c_float),
+                ("edgeEigenValueRatio", C.c_float), ("border", C.c_int), ("maxIterations", C.c_int),
+                ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int)]
+
+    @staticmethod
+    def default():
+        # build/config_affori_classic.ini [HessianAffine]
+        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1)
+
+
+class Candidate(C.Structure):
+    _fields_ = [("octave", C.c_int), ("level", C.c_int), ("r0", C.c_int), ("c0", C.c_int), ("r", C.c_int),
+                ("c", C.c_int), ("x", C.c_float), ("y", C.c_float), ("s", C.c_float),
+                ("pixelDistance", C.c_float), ("response", C.c_float), ("type", C.c_int)]
+
+
+class AffKey(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("s", C.c_double), ("a11", C.c_double),
+                ("a12", C.c_double), ("a21", C.c_double), ("a22", C.c_double), ("response", C.c_double),
+                ("sub_type", C.c_int), ("octave", C.c_int), ("level", C.c_int), ("r0", C.c_int),
+                ("c0", C.c_int), ("pad", C.c_int)]
+
+
+CAND_DTYPE = np.dtype([("octave", "i4"), ("level", "i4"), ("r0", "i4"), ("c0", "i4"), ("r", "i4"), ("c", "i4"),
+                       ("x", "f4"), ("y", "f4"), ("s", "f4"), ("pixelDistance", "f4"), ("response", "f4"),
+                       ("type", "i4")])
+AFFKEY_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("s", "f8"), ("a11", "f8"), ("a12", "f8"), ("a21", "f8"),
+                         ("a22", "f8"), ("response", "f8"), ("sub_type", "i4"), ("octave", "i4"),
+                         ("level", "i4"), ("r0", "i4"), ("c0", "i4"), ("pad", "i4")])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        _lib.orc_pyramid_build.restype = C.c_void_p
+        _lib.orc_det_pow2f.restype = C.c_float
+        _lib.orc_det_expf.restype = C.c_float
+        _lib.orc_atan2_lut.restype = C.c_float
+        _lib.orc_det_pow2f.argtypes = [C.c_float]
+        _lib.orc_det_expf.argtypes = [C.c_float]
+        _lib.orc_atan2_lut.argtypes = [C.c_float, C.c_float]
+        _lib.orc_det_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def gauss_ksize(sigma):
+    return lib().orc_gauss_ksize(C.c_float(sigma))
+
+
+def gauss_kernel(n, sigma):
+    out = np.zeros(n, np.float32)
+    lib().orc_gauss_kernel(n, C.c_double(sigma), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def gauss_blur(img, sigma):
+    a, p = _f(img)
+    out = np.empty_like(a)
+    lib().orc_gauss_blur(p, a.shape[1], a.shape[0], C.c_float(sigma), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def hessian_response(img, norm):
+    a, p = _f(img)
+    out = np.empty_like(a)
+    lib().orc_hessian_response(p, a.shape[1], a.shape[0], C.c_float(norm), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def resize_half(img):
+    a, p = _f(img)
+    dw, dh = C.c_int(), C.c_int()
+    lib().orc_resize_half_dims(a.shape[1], a.shape[0], C.byref(dw), C.byref(dh))
+    out = np.empty((dh.value, dw.value), np.float32)
+    lib().orc_resize_half(p, a.shape[1], a.shape[0], out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def interpolate(img, ofsx, ofsy, a11, a12, a21, a22, rw, rh):
+    a, p = _f(img)
+    out = np.empty((rh, rw), np.float32)
+    t = lib().orc_interpolate(p, a.shape[1], a.shape[0], C.c_float(ofsx), C.c_float(ofsy), C.c_float(a11),
+                              C.c_float(a12), C.c_float(a21), C.c_float(a22), rw, rh,
+                              out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out, bool(t)
+
+
+def gauss_mask(size):
+    out = np.empty((size, size), np.float32)
+    lib().orc_gauss_mask(size, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def circular_gauss_mask(size, sigma):
+    out = np.empty((size, size), np.float32)
+    lib().orc_circular_gauss_mask(size, C.c_float(sigma), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+class Pyramid:
+    def __init__(self, img, params=None):
+        self.params = params or HessAffParams.default()
+        a, p = _f(img)
+        self.h = C.c_void_p(lib().orc_pyramid_build(p, a.shape[1], a.shape[0], C.byref(self.params)))
+        self.n_oct = lib().orc_pyramid_octaves(self.h)
+
+    def dims(self, o):
+        w, h = C.c_int(), C.c_int()
+        lib().orc_pyramid_dims(self.h, o, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def plane(self, o, level, kind):
+        w, h = self.dims(o)
+        out = np.empty((h, w), np.float32)
+        lib().orc_pyramid_plane(self.h, o, level, kind, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def candidates(self, max_out=1 << 20):
+        out = np.zeros(max_out, CAND_DTYPE)
+        raw = np.zeros((max_out, 4), np.int32)
+        nraw = C.c_int()
+        n = lib().orc_pyramid_candidates(self.h, C.byref(self.params), out.ctypes.data_as(C.POINTER(Candidate)),
+                                         max_out, raw.ctypes.data_as(C.POINTER(C.c_int)), max_out, C.byref(nraw))
+        return out[:n].copy(), raw[:nraw.value].copy()
+
+    def affine_shape(self, o, level, x, y, s, pd):
+        a4 = (C.c_float * 4)()
+        it = C.c_int()
+        ok = lib().orc_affine_shape(self.h, o, level, C.c_float(x), C.c_float(y), C.c_float(s), C.c_float(pd),
+                                    C.byref(self.params), a4, C.byref(it))
+        return bool(ok), np.array(list(a4), np.float32), it.value
+
+    def __del__(self):
+        try:
+            lib().orc_pyramid_free(self.h)
+        except Exception:
+            pass
+
+
+def detect_hessian_affine(img, params=None, max_out=1 << 20):
+    params = params or HessAffParams.default()
+    a, p = _f(img)
+    out = np.zeros(max_out, AFFKEY_DTYPE)
+    n = lib().orc_detect_hessian_affine(p, a.shape[1], a.shape[0], C.byref(params),
+                                        out.ctypes.data_as(C.POINTER(AffKey)), max_out)
+    return out[:n].copy()

@@ -1,0 +1,86 @@
+"""Seeded synthetic inputs: blob texture + value noise, and pairs related
+by a random homography.  Pure numpy; used by tests, smoke() and bench.py."""
+import numpy as np
+
+
+def _value_noise(rng, w, h, octaves=6):
+    out = np.zeros((h, w), np.float32)
+    amp = 1.0
+    for o in range(octaves):
+        cell = max(2, 2 ** (octaves - o + 1))
+        gw, gh = w // cell + 2, h // cell + 2
+        g = rng.standard_normal((gh, gw)).astype(np.float32)
+        ys = (np.arange(h, dtype=np.float32) / cell)
+        xs = (np.arange(w, dtype=np.float32) / cell)
+        y0 = ys.astype(np.int32); x0 = xs.astype(np.int32)
+        fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+        a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+        out += amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
+        amp *= 0.6
+    return out
+
+
+def texture(w, h, seed=0, blobs=None):
+    """uint8-valued float32 image, mean ~128: Gaussian blobs + multi-octave value noise + 2% uniform noise."""
+    rng = np.random.default_rng(seed)
+    if blobs is None:
+        blobs = max(40, int(6000 * (w * h) / (1920.0 * 1080.0)))   # ~10k HessianAffine keypoints at 1080p
+    img = np.full((h, w), 128.0, np.float32)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    for _ in range(blobs):
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        s = rng.uniform(1.5, 12.0) if rng.uniform() < 0.3 else rng.uniform(1.5, 4.0)
+        amp = rng.uniform(20, 90) * rng.choice([-1.0, 1.0])
+        r = int(4 * s) + 1
+        x0, x1 = max(0, int(cx) - r), min(w, int(cx) + r + 1)
+        y0, y1 = max(0, int(cy) - r), min(h, int(cy) + r + 1)
+        if x1 <= x0 or y1 <= y0:
+            continue
+        d2 = (xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2
+        img[y0:y1, x0:x1] += (amp * np.exp(-d2 / (2 * s * s))).astype(np.float32)
+    img += 12.0 * _value_noise(rng, w, h)
+    img += rng.uniform(-2.5, 2.5, (h, w)).astype(np.float32)
+    return np.clip(np.rint(img), 0, 255).astype(np.float32)
+
+
+def random_homography(rng, w, h):
+    ang = np.deg2rad(rng.uniform(-25, 25))
+    sc = rng.uniform(0.7, 1.4)
+    c, s = np.cos(ang) * sc, np.sin(ang) * sc
+    cx, cy = w / 2.0, h / 2.0
+    T = np.array([[1, 0, -cx], [0, 1, -cy], [0, 0, 1.0]])
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    Tb = np.array([[1, 0, cx + rng.uniform(-0.1, 0.1) * w], [0, 1, cy + rng.uniform(-0.1, 0.1) * h], [0, 0, 1.0]])
+    P = np.eye(3)
+    P[2, 0] = rng.uniform(-2e-4, 2e-4)
+    P[2, 1] = rng.uniform(-2e-4, 2e-4)
+    H = Tb @ P @ R @ T
+    return H / H[2, 2]
+
+
+def warp(img, H, noise_sigma=2.0, seed=0):
+    """img2(x') = img(H^-1 x'), bilinear, out-of-image = 128, plus independent noise."""
+    h, w = img.shape
+    Hi = np.linalg.inv(H)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    den = Hi[2, 0] * xx + Hi[2, 1] * yy + Hi[2, 2]
+    sx = (Hi[0, 0] * xx + Hi[0, 1] * yy + Hi[0, 2]) / den
+    sy = (Hi[1, 0] * xx + Hi[1, 1] * yy + Hi[1, 2]) / den
+    x0 = np.floor(sx).astype(np.int64); y0 = np.floor(sy).astype(np.int64)
+    fx = (sx - x0).astype(np.float32); fy = (sy - y0).astype(np.float32)
+    valid = (x0 >= 0) & (y0 >= 0) & (x0 < w - 1) & (y0 < h - 1)
+    x0c = np.clip(x0, 0, w - 2); y0c = np.clip(y0, 0, h - 2)
+    a = img[y0c, x0c]; b = img[y0c, x0c + 1]; c = img[y0c + 1, x0c]; d = img[y0c + 1, x0c + 1]
+    out = (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+    out = np.where(valid, out, 128.0).astype(np.float32)
+    rng = np.random.default_rng(seed + 7919)
+    out += rng.normal(0, noise_sigma, out.shape).astype(np.float32)
+    return np.clip(np.rint(out), 0, 255).astype(np.float32)
+
+
+def pair(w, h, seed=0):
+    """(img1, img2, H) with img2 = img1 warped by H (img1 -> img2)."""
+    img1 = texture(w, h, seed)
+    rng = np.random.default_rng(seed + 104729)
+    H = random_homography(rng, w, h)
+    return img1, warp(img1, H, seed=seed), H

@@ -1,0 +1,87 @@
+"""-m gpu parity tests: HIP detector (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("x", "y", "s", "a11", "a12", "a21", "a22", "response", "sub_type", "octave", "level", "r0", "c0")
+
+
+def _assert_keys_equal(got, want):
+    assert len(got) == len(want)
+    for f in FIELDS:
+        assert np.array_equal(got[f], want[f]), "field %s differs" % f
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (135, 67), (257, 130), (33, 200), (640, 480)])
+@pytest.mark.parametrize("sigma", [0.8, 1.2263, 1.5199, 2.4525, 4.9])
+def test_gauss_blur_bitexact(gpu_ctx, w, h, sigma):
+    img = synth.texture(w, h, seed=w * 7 + h)
+    assert np.array_equal(gpu_ctx.gauss_blur(img, sigma), orc.gauss_blur(img, sigma))
+
+
+@pytest.mark.parametrize("w,h", [(3, 3), (64, 48), (135, 67), (1000, 37)])
+def test_hessian_response_bitexact(gpu_ctx, w, h):
+    img = synth.texture(max(w, 8), max(h, 8), seed=3)[:h, :w].copy()
+    assert np.array_equal(gpu_ctx.hessian_response(img, 2.56), orc.hessian_response(img, 2.56))
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (135, 67), (17, 30), (240, 135), (31, 33), (2, 2)])
+def test_resize_half_bitexact(gpu_ctx, w, h):
+    img = synth.texture(max(w, 8), max(h, 8), seed=5)[:h, :w].copy()
+    got, want = gpu_ctx.resize_half(img), orc.resize_half(img)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("w,h,seed", [(320, 240, 7), (515, 389, 11), (800, 640, 3)])
+def test_pyramid_and_candidates(gpu_ctx, w, h, seed):
+    img = synth.texture(w, h, seed=seed)
+    got = gpu_ctx.detect_hessian_affine(img)
+    pyr = orc.Pyramid(img)
+    assert gpu_ctx.pyramid_octaves() == pyr.n_oct
+    for o in range(pyr.n_oct):
+        assert gpu_ctx.pyramid_dims(o) == pyr.dims(o)
+        for lv in range(5):
+            for kind in (0, 1):
+                assert np.array_equal(gpu_ctx.pyramid_plane(0, o, lv, kind), pyr.plane(o, lv, kind)), (o, lv, kind)
+    cand_want, _ = pyr.candidates()
+    cand_got = gpu_ctx.pyramid_candidates(0)
+    order = np.lexsort((cand_got["c0"], cand_got["r0"], cand_got["level"], cand_got["octave"]))
+    cand_got = cand_got[order]
+    assert len(cand_got) == len(cand_want)
+    for f in cand_want.dtype.names:
+        assert np.array_equal(cand_got[f], cand_want[f]), f
+    _assert_keys_equal(got, orc.detect_hessian_affine(img))
+
+
+def test_detect_graf(gpu_ctx):
+    from PIL import Image
+    import os
+    p = os.path.join(os.path.dirname(__file__), "golden", "graf1.png")
+    im = np.asarray(Image.open(p)).astype(np.float32)
+    g = (((im[..., 2] + im[..., 1]) + im[..., 0]) / np.float32(3.0)).astype(np.float32)
+    _assert_keys_equal(gpu_ctx.detect_hessian_affine(g), orc.detect_hessian_affine(g))
+
+
+def test_detect_1080p_and_batch(gpu_ctx, pkg):
+    import torch
+    a = synth.texture(1920, 1080, seed=21)
+    b = synth.texture(1920, 1080, seed=22)
+    wa, wb = orc.detect_hessian_affine(a), orc.detect_hessian_affine(b)
+    assert len(wa) > 5000
+    _assert_keys_equal(gpu_ctx.detect_hessian_affine(a), wa)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    ga, gb = gpu_ctx.detect_hessian_affine_dev(t.data_ptr(), 2, 1920, 1080)
+    _assert_keys_equal(ga, wa)
+    _assert_keys_equal(gb, wb)
+
+
+def test_empty_image(gpu_ctx):
+    img = np.full((100, 120), 77.0, np.float32)
+    assert len(gpu_ctx.detect_hessian_affine(img)) == 0
+    tiny = synth.texture(12, 12, seed=1)          # below 2*border+2: no octave at all
+    assert len(gpu_ctx.detect_hessian_affine(tiny)) == 0
