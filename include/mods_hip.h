@@ -126,6 +126,41 @@ int mods_gauss_blur(mods_ctx *ctx, const float *src, int w, int h, float sigma, 
 int mods_hessian_response(mods_ctx *ctx, const float *src, int w, int h, float norm, float *dst);
 int mods_resize_half(mods_ctx *ctx, const float *src, int w, int h, float *dst, int *dw, int *dh);
 
+/* ---- B3: orientation + description ---------------------------------------------------------
+ * [DominantOrientation] and [SIFTDescriptor] keys (io_mods.cpp:731-740, 423-436). */
+typedef struct mods_describe_params {
+  double ori_mrSize;       /* 5.1962 */
+  int ori_patchSize;       /* 32 */
+  int ori_maxAngles;       /* 1 (only 0/1 supported: the shipped configs use 1) */
+  double ori_threshold;    /* (double)(float)0.8 */
+  double desc_mrSize;      /* 5.1962 */
+  int desc_patchSize;      /* 41 */
+  int photoNorm;           /* 1 */
+  int rootSift;            /* 1 = RootSIFT, 0 = SIFT */
+  double maxBinValue;      /* 0.2 */
+} mods_describe_params;
+
+/* Replaces, for one identity view (H = I), the chain of imagerepresentation.cpp:867-968:
+ *   ReprojectRegionsAndRemoveTouchBoundary(dontRemove)  synth-detection.cpp:151-190
+ *   DetectOrientation(...)                               synth-detection.cpp:1039-1149
+ *   ReprojectRegions(...)                                synth-detection.cpp:631-706
+ *   DescribeRegions<SIFTDescriptor>(...)                 synth-detection.hpp:170-263, matching/siftdesc.cpp
+ * Input: keypoints as produced by mods_detect_hessian_affine; output: oriented, described
+ * regions in input order (dropped ones removed). */
+int mods_orient_describe(mods_ctx *ctx, const float *img, int w, int h, int stride, const mods_affkey *keys,
+                         int n_keys, const mods_describe_params *par, mods_region *out, int max_out, int *n_out);
+
+/* detect + orient + describe for a batch of device-resident images; regions stay in HBM for the
+ * matcher (mods_regions_fetch copies them out).  n_regions_host[i] = regions of image i. */
+int mods_detect_describe_dev(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, int stride,
+                             const mods_hessaff_params *det, const mods_describe_params *desc,
+                             int *n_detected_host, int *n_regions_host);
+int mods_regions_fetch(mods_ctx *ctx, int img, mods_region *out, int max_out, int *n_out);
+
+/* parity-test building blocks: one 32x32 orientation patch / one 41x41 descriptor patch */
+int mods_dominant_angle(mods_ctx *ctx, const float *patch, int ps, double th, float *angle, int *found);
+int mods_sift_patch(mods_ctx *ctx, const float *patch, int ps, int rootsift, double maxBinValue, uint8_t *out128);
+
 #ifdef __cplusplus
 }
 #endif

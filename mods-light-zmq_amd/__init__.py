@@ -42,6 +42,23 @@ CAND_DTYPE = np.dtype([("octave", "i4"), ("level", "i4"), ("r0", "i4"), ("c0", "
                        ("x", "f4"), ("y", "f4"), ("s", "f4"), ("pixelDistance", "f4"), ("response", "f4"),
                        ("type", "i4")])
 
+REGION_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("s", "f8"), ("a11", "f8"), ("a12", "f8"), ("a21", "f8"),
+                         ("a22", "f8"), ("response", "f8"), ("sub_type", "i4"), ("id", "i4"), ("parent", "i4"),
+                         ("pad", "i4"), ("desc", "u1", (128,))])
+
+
+class DescribeParams(C.Structure):
+    """[DominantOrientation] + [SIFTDescriptor] (io_mods.cpp:731-740, 423-436)."""
+    _fields_ = [("ori_mrSize", C.c_double), ("ori_patchSize", C.c_int), ("ori_maxAngles", C.c_int),
+                ("ori_threshold", C.c_double), ("desc_mrSize", C.c_double), ("desc_patchSize", C.c_int),
+                ("photoNorm", C.c_int), ("rootSift", C.c_int), ("maxBinValue", C.c_double)]
+
+    @staticmethod
+    def default():
+        # config_affori_classic.ini; threshold is parsed into a float member (descriptors_parameters.hpp:10)
+        return DescribeParams(5.1962, 32, 1, float(np.float32(0.8)), 5.1962, 41, 1, 1, 0.2)
+
+
 _lib = None
 
 
@@ -177,3 +194,42 @@ class Context:
         n = C.c_int()
         _check(lib().mods_pyramid_candidates(self.h, img, out.ctypes.data_as(C.c_void_p), max_out, C.byref(n)))
         return out[:n.value].copy()
+
+    # ---- orientation + description
+    def orient_describe(self, img, keys, params=None, max_out=None):
+        params = params or DescribeParams.default()
+        a = np.ascontiguousarray(img, np.float32)
+        k = np.ascontiguousarray(keys)
+        max_out = max_out or len(k) + 1
+        out = np.zeros(max_out, REGION_DTYPE)
+        n = C.c_int()
+        _check(lib().mods_orient_describe(self.h, _fp(a), a.shape[1], a.shape[0], a.shape[1], k.ctypes.data_as(C.c_void_p),
+                                          len(k), C.byref(params), out.ctypes.data_as(C.c_void_p), max_out, C.byref(n)))
+        return out[:n.value].copy()
+
+    def detect_describe_dev(self, dev_ptr, n_img, w, h, det=None, desc=None):
+        det = det or HessAffParams.default()
+        desc = desc or DescribeParams.default()
+        nd, nr = (C.c_int * n_img)(), (C.c_int * n_img)()
+        _check(lib().mods_detect_describe_dev(self.h, C.c_void_p(dev_ptr), n_img, w, h, w, C.byref(det), C.byref(desc), nd, nr))
+        return list(nd), list(nr)
+
+    def regions_fetch(self, img, max_out=1 << 18):
+        n = C.c_int()
+        _check(lib().mods_regions_fetch(self.h, img, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), REGION_DTYPE)
+        _check(lib().mods_regions_fetch(self.h, img, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def dominant_angle(self, patch, th=float(np.float32(0.8))):
+        a = np.ascontiguousarray(patch, np.float32)
+        ang, found = C.c_float(), C.c_int()
+        _check(lib().mods_dominant_angle(self.h, _fp(a), a.shape[0], C.c_double(th), C.byref(ang), C.byref(found)))
+        return bool(found.value), ang.value
+
+    def sift_patch(self, patch, rootsift=True, max_bin=0.2):
+        a = np.ascontiguousarray(patch, np.float32)
+        out = np.zeros(128, np.uint8)
+        _check(lib().mods_sift_patch(self.h, _fp(a), a.shape[0], int(rootsift), C.c_double(max_bin),
+                                     out.ctypes.data_as(C.c_void_p)))
+        return out

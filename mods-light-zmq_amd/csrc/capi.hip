@@ -76,7 +76,10 @@ int mods_ctx_create(int device, int max_w, int max_h, int batch, mods_ctx **out)
   MODS_HIP_CHECK(hipMalloc(&c->keys_dev, sizeof(mods_affkey) * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->sort_keys, sizeof(unsigned long long) * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->sort_idx, sizeof(int) * 2 * mc * batch));
-  MODS_HIP_CHECK(hipHostMalloc(&c->host_counts, sizeof(int) * 3 * batch));
+  MODS_HIP_CHECK(hipHostMalloc(&c->host_counts, sizeof(int) * 4 * batch));
+  MODS_HIP_CHECK(hipMalloc(&c->ori_dev, 48 * mc * batch));
+  MODS_HIP_CHECK(hipMalloc(&c->regions_dev, sizeof(mods_region) * mc * batch));
+  MODS_HIP_CHECK(hipMalloc(&c->region_count, sizeof(int) * batch));
   *out = c;
   return MODS_OK;
 }
@@ -93,6 +96,8 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->tmp_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx);
   (void)hipHostFree(c->host_counts);
+  (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->region_count); (void)hipFree(c->desc_tables_dev);
+  (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -208,6 +213,99 @@ int mods_pyramid_candidates(mods_ctx *c, int img, mods_candidate *out, int max_o
   }
   *n_out = m;
   return m > max_out ? MODS_E_CAPACITY : MODS_OK;
+}
+
+// ---- orientation + description ----------------------------------------------------------------
+static int check_desc_err(mods_ctx *c) {
+  int e = 0;
+  MODS_HIP_CHECK(hipMemcpy(&e, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost));
+  if (e) {
+    MODS_HIP_CHECK(hipMemset(c->desc_err_dev, 0, sizeof(int)));
+    set_error("measurement region larger than the descriptor scratch (P2 > 3*max(w,h) or > 4096 blur taps)");
+    return MODS_E_CAPACITY;
+  }
+  return MODS_OK;
+}
+
+int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride,
+                             const mods_hessaff_params *det, const mods_describe_params *desc, int *n_detected_host,
+                             int *n_regions_host) {
+  if (!c || !img_dev || !det || !desc) { set_error("detect_describe: null argument"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = pyramid_configure(c, w, h, n_img, det))) return rc;
+  if ((rc = pyramid_build(c, img_dev, stride))) return rc;
+  if ((rc = detect_run(c))) return rc;
+  const float *planes = img_dev;
+  if (stride != w) planes = c->tmp_dev;   // pyramid_build repacked the batch there
+  if ((rc = describe_run(c, planes, n_img, w, h, desc))) return rc;
+  MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (int b = 0; b < n_img; b++) {
+    if (c->host_counts[b] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", c->host_counts[b], c->max_cand); return MODS_E_CAPACITY; }
+    if (n_detected_host) n_detected_host[b] = c->host_counts[2 * c->batch + b];
+    if (n_regions_host) n_regions_host[b] = c->host_counts[3 * c->batch + b];
+  }
+  return check_desc_err(c);
+}
+
+int mods_regions_fetch(mods_ctx *c, int img, mods_region *out, int max_out, int *n_out) {
+  if (!c || img < 0 || img >= c->batch || !n_out) return MODS_E_ARG;
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  int n = 0;
+  MODS_HIP_CHECK(hipMemcpy(&n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
+  *n_out = n;
+  if (out) {
+    if (n > max_out) { set_error("region output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
+    MODS_HIP_CHECK(hipMemcpy(out, c->regions_dev + (size_t)img * c->max_cand, sizeof(mods_region) * n, hipMemcpyDeviceToHost));
+  }
+  return MODS_OK;
+}
+
+int mods_orient_describe(mods_ctx *c, const float *img, int w, int h, int stride, const mods_affkey *keys, int n_keys,
+                         const mods_describe_params *par, mods_region *out, int max_out, int *n_out) {
+  if (!c || !img || !par || !n_out || (n_keys > 0 && !keys)) { set_error("orient_describe: null argument"); return MODS_E_ARG; }
+  if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image larger than the context"); return MODS_E_ARG; }
+  if (n_keys > c->max_cand) { set_error("too many keypoints for the context: %d > %d", n_keys, c->max_cand); return MODS_E_CAPACITY; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(hipMemcpy2DAsync(c->input_dev, sizeof(float) * w, img, sizeof(float) * stride, sizeof(float) * w, h,
+                                  hipMemcpyHostToDevice, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(c->keys_dev, keys, sizeof(mods_affkey) * n_keys, hipMemcpyHostToDevice, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(c->cand_count + 2 * c->batch, &n_keys, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));   // n_keys is a stack variable
+  int rc = describe_run(c, c->input_dev, 1, w, h, par);
+  if (rc) return rc;
+  if ((rc = mods_regions_fetch(c, 0, out, max_out, n_out))) return rc;
+  return check_desc_err(c);
+}
+
+int mods_dominant_angle(mods_ctx *c, const float *patch, int ps, double th, float *angle, int *found) {
+  mods_describe_params dp = {5.1962, ps, 1, th, 5.1962, c->desc_ps ? c->desc_ps : 41, 1, 1, 0.2};
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc = describe_configure(c, &dp);
+  if (rc) return rc;
+  MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev, patch, sizeof(float) * ps * ps, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_dominant_angle_test(c, c->input_dev, ps, th, c->tmp_dev))) return rc;
+  float res[2];
+  MODS_HIP_CHECK(hipMemcpyAsync(res, c->tmp_dev, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  *found = res[0] != 0.f;
+  *angle = res[1];
+  return MODS_OK;
+}
+
+int mods_sift_patch(mods_ctx *c, const float *patch, int ps, int rootsift, double maxBinValue, uint8_t *out128) {
+  mods_describe_params dp = {5.1962, c->desc_ori_ps ? c->desc_ori_ps : 32, 1, 0.8, 5.1962, ps, 1, rootsift, maxBinValue};
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc = describe_configure(c, &dp);
+  if (rc) return rc;
+  MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev, patch, sizeof(float) * ps * ps, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_sift_patch_test(c, c->input_dev, ps, rootsift, maxBinValue, (uint8_t *)c->tmp_dev))) return rc;
+  MODS_HIP_CHECK(hipMemcpyAsync(out128, c->tmp_dev, 128, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return MODS_OK;
 }
 
 // ---- single primitives -------------------------------------------------------------------

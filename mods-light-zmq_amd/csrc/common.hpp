@@ -89,6 +89,16 @@ struct mods_ctx {
   int *host_counts = nullptr;        // pinned
   mods_hessaff_params par;
   int last_w = 0, last_h = 0, last_n_img = 0;
+  // orientation + description
+  float *desc_tables_dev = nullptr;  // [orimask 64x64][desc mask 64x64][SiftTab]
+  int *desc_err_dev = nullptr;
+  int desc_ori_ps = 0, desc_ps = 0;
+  void *ori_dev = nullptr;           // [batch][max_cand] OriOut
+  mods_region *regions_dev = nullptr;  // [batch][max_cand]
+  int *region_count = nullptr;       // [batch]
+  float *desc_scratch = nullptr;
+  size_t desc_scratch_elems = 0;
+  const float *last_img_dev = nullptr;
   // timing
   int timing_mask = 0;
   mods::StageTimer timers[MODS_STAGE_COUNT];
@@ -116,5 +126,11 @@ void circular_gauss_mask_host(int size, float sigma, float *out);
 
 // detect.hip
 int detect_run(mods_ctx *ctx);       // NMS -> localise -> dedup -> Baumberg -> sort, for the configured batch
+
+// describe.hip
+int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par);
+int describe_configure(mods_ctx *ctx, const mods_describe_params *par);
+int launch_dominant_angle_test(mods_ctx *ctx, const float *patch_dev, int ps, double th, float *out_dev);
+int launch_sift_patch_test(mods_ctx *ctx, const float *patch_dev, int ps, int root, double max_bin, uint8_t *out_dev);
 
 }  // namespace mods

@@ -17,6 +17,7 @@
 // nothing upstream depends on the order hits were appended in.
 #include "common.hpp"
 #include "detmath.hpp"
+#include "device_util.hpp"
 
 namespace mods {
 
@@ -209,43 +210,6 @@ __global__ __launch_bounds__(256) void accept_kernel(const PyramidDev *__restric
 // ---------------------------------------------------------------------------------------
 // Baumberg iteration: one wave per accepted point.
 // ---------------------------------------------------------------------------------------
-// interpolateCheckBorders, helpers.cpp:527-549
-__device__ __forceinline__ bool check_borders(int img_w, int img_h, float ofsx, float ofsy, float a11, float a12,
-                                              float a21, float a22, int res_w, int res_h) {
-  const int width = img_w - 2, height = img_h - 2;
-  const float halfWidth = (float)ceil((double)((float)res_w) / 2.0);
-  const float halfHeight = (float)ceil((double)((float)res_h) / 2.0);
-  const float xs[4] = {-halfWidth, -halfWidth, +halfWidth, +halfWidth};
-  const float ys[4] = {-halfHeight, +halfHeight, -halfHeight, +halfHeight};
-  bool touch = false;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    float imx = ofsx + xs[i] * a11 + ys[i] * a12;
-    float imy = ofsy + xs[i] * a21 + ys[i] * a22;
-    if (floorf(imx) <= 0 || floorf(imy) <= 0 || ceilf(imx) >= width || ceilf(imy) >= height) touch = true;
-  }
-  return touch;
-}
-
-// One bilinear tap of helpers.cpp:551-626 (both branches).
-__device__ __forceinline__ float bilinear_tap(const float *__restrict__ im, int w, int h, float WX, float WY, bool touch) {
-  if (!touch) {
-    const int x = (int)WX, y = (int)WY;
-    const float wx = WX - (float)x;
-    const float *Row0 = im + (size_t)y * w, *Row1 = Row0 + w;
-    const float I1 = wx * (Row0[x + 1] - Row0[x]) + Row0[x];
-    return (WY - y) * (wx * (Row1[x + 1] - Row1[x]) + Row1[x] - I1) + I1;
-  }
-  const int x = (int)floorf(WX), y = (int)floorf(WY);
-  if (WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1) {
-    const float wx = WX - x;
-    const float *Row0 = im + (size_t)y * w, *Row1 = Row0 + w;
-    const float I1 = wx * (Row0[x + 1] - Row0[x]) + Row0[x];
-    return (WY - y) * (wx * (Row1[x + 1] - Row1[x]) + Row1[x] - I1) + I1;
-  }
-  return 0.f;
-}
-
 // invSqrt, helpers.cpp:463-502 (double inside)
 __device__ void inv_sqrt(float &a, float &b, float &c, float &l1, float &l2) {
   double t, r;

@@ -1,0 +1,75 @@
+// Device-side restatements of the small pixel primitives of detectors/helpers.cpp that
+// several kernels share.  fp32, one rounding per operation (-ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "atan_lut_data.h"
+
+namespace mods {
+
+// interpolateCheckBorders, helpers.cpp:527-549
+__device__ __forceinline__ bool check_borders(int img_w, int img_h, float ofsx, float ofsy, float a11, float a12,
+                                              float a21, float a22, int res_w, int res_h) {
+  const int width = img_w - 2, height = img_h - 2;
+  const float halfWidth = (float)ceil((double)((float)res_w) / 2.0);
+  const float halfHeight = (float)ceil((double)((float)res_h) / 2.0);
+  const float xs[4] = {-halfWidth, -halfWidth, +halfWidth, +halfWidth};
+  const float ys[4] = {-halfHeight, +halfHeight, -halfHeight, +halfHeight};
+  bool touch = false;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float imx = ofsx + xs[i] * a11 + ys[i] * a12;
+    float imy = ofsy + xs[i] * a21 + ys[i] * a22;
+    if (floorf(imx) <= 0 || floorf(imy) <= 0 || ceilf(imx) >= width || ceilf(imy) >= height) touch = true;
+  }
+  return touch;
+}
+
+// One bilinear tap of interpolate(), helpers.cpp:551-626: `touch` selects the unchecked
+// (int-cast) branch or the per-pixel checked (floor, zero fill) branch.
+__device__ __forceinline__ float bilinear_tap(const float *__restrict__ im, int w, int h, float WX, float WY, bool touch) {
+  if (!touch) {
+    const int x = (int)WX, y = (int)WY;
+    const float wx = WX - (float)x;
+    const float *Row0 = im + (size_t)y * w, *Row1 = Row0 + w;
+    const float I1 = wx * (Row0[x + 1] - Row0[x]) + Row0[x];
+    return (WY - y) * (wx * (Row1[x + 1] - Row1[x]) + Row1[x] - I1) + I1;
+  }
+  const int x = (int)floorf(WX), y = (int)floorf(WY);
+  if (WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1) {
+    const float wx = WX - x;
+    const float *Row0 = im + (size_t)y * w, *Row1 = Row0 + w;
+    const float I1 = wx * (Row0[x + 1] - Row0[x]) + Row0[x];
+    return (WY - y) * (wx * (Row1[x + 1] - Row1[x]) + Row1[x] - I1) + I1;
+  }
+  return 0.f;
+}
+
+// atan2LUTff, helpers.cpp:160-207.  The octant constants are float, the table double: each
+// +/- is a double operation rounded to float on return.
+__device__ const double g_atan_lut[256] = MODS_ATAN_LUT_INIT;
+
+__device__ __forceinline__ float atan2_lut_ff(float y, float x) {
+  const float PI_2f = 1.57079632679489661923f;
+  const float PIf = 3.14159265358979323846f;
+  if (x > 0.f) {
+    if (y > 0.f) {
+      if (x > y) return (float)g_atan_lut[(int)(255.f * y / x)];
+      return (float)((double)PI_2f - g_atan_lut[(int)(255 * x / y)]);
+    } else {
+      float absy = fabsf(y);
+      if (x > absy) return (float)(-g_atan_lut[(int)(255.f * absy / x)]);
+      return (float)((double)(-PI_2f) + g_atan_lut[(int)(255.f * x / absy)]);
+    }
+  } else if (y > 0.f) {
+    float absx = fabsf(x);
+    if (absx > y) return (float)((double)PIf - g_atan_lut[(int)(255.f * y / absx)]);
+    return (float)((double)PI_2f + g_atan_lut[(int)(255.f * absx / y)]);
+  } else {
+    float absx = fabsf(x), absy = fabsf(y);
+    if (absx > absy) return (float)((double)(-PIf) + g_atan_lut[(int)(255.f * absy / absx)]);
+    if (x == 0.f) return 0.f;
+    return (float)((double)(-PI_2f) - g_atan_lut[(int)(255.f * absx / absy)]);
+  }
+}
+
+}  // namespace mods

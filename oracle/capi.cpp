@@ -139,4 +139,90 @@ int orc_detect_hessian_affine(const float *img, int w, int h, const orc_hessaff_
   return n;
 }
 
+// ---- orientation + description -------------------------------------------------------------
+struct orc_region {            // mirrors include/mods_hip.h: mods_region
+  double x, y, s, a11, a12, a21, a22, response;
+  int sub_type, id, parent, pad;
+  uint8_t desc[128];
+};
+
+static void to_regions(const orc_region *in, int n, std::vector<Region> &v) {
+  v.resize(n);
+  for (int i = 0; i < n; i++) {
+    Region &r = v[i]; const orc_region &o = in[i];
+    r.x = o.x; r.y = o.y; r.s = o.s; r.a11 = o.a11; r.a12 = o.a12; r.a21 = o.a21; r.a22 = o.a22; r.response = o.response;
+    r.sub_type = o.sub_type; r.id = o.id; r.parent = o.parent;
+    std::memcpy(r.desc, o.desc, 128);
+  }
+}
+static int from_regions(const std::vector<Region> &v, orc_region *out, int max_out) {
+  int n = (int)v.size();
+  for (int i = 0; i < n && i < max_out; i++) {
+    const Region &r = v[i]; orc_region &o = out[i];
+    o.x = r.x; o.y = r.y; o.s = r.s; o.a11 = r.a11; o.a12 = r.a12; o.a21 = r.a21; o.a22 = r.a22; o.response = r.response;
+    o.sub_type = r.sub_type; o.id = r.id; o.parent = r.parent; o.pad = 0;
+    std::memcpy(o.desc, r.desc, 128);
+  }
+  return n;
+}
+
+int orc_dominant_angle(const float *patch, int ps, double th, float *angle) {
+  return dominant_angle(wrap(patch, ps, ps), th, angle) ? 1 : 0;
+}
+void orc_sift_desc(const float *patch, int ps, int rootsift, double maxBinValue, uint8_t *out128) {
+  sift_patch_to_desc(wrap(patch, ps, ps), out128, rootsift != 0, maxBinValue);
+}
+void orc_extract_desc_patch(const float *img, int w, int h, const orc_region *r, double mrSize, int patchSize,
+                            int photoNorm, float *patch_out) {
+  std::vector<Region> v; to_regions(r, 1, v);
+  Img patch(patchSize, patchSize);
+  extract_desc_patch(v[0], wrap(img, w, h), mrSize, patchSize, photoNorm != 0, patch);
+  std::memcpy(patch_out, patch.d.data(), sizeof(float) * (size_t)patchSize * patchSize);
+}
+int orc_detect_orientation(const float *img, int w, int h, const orc_region *in, int n, double mrSize, int patchSize,
+                           int maxAngles, double th, orc_region *out, int max_out) {
+  std::vector<Region> v, o; to_regions(in, n, v);
+  detect_orientation(v, o, wrap(img, w, h), mrSize, patchSize, maxAngles, th);
+  return from_regions(o, out, max_out);
+}
+int orc_filter_centres_inside(orc_region *r, int n, int w, int h) {
+  std::vector<Region> v; to_regions(r, n, v);
+  filter_centres_inside(v, w, h);
+  return from_regions(v, r, n);
+}
+int orc_filter_touch_boundary(orc_region *r, int n, int w, int h) {
+  std::vector<Region> v; to_regions(r, n, v);
+  filter_touch_boundary(v, w, h);
+  return from_regions(v, r, n);
+}
+void orc_describe_rootsift(const float *img, int w, int h, orc_region *r, int n, double mrSize, int patchSize, int photoNorm) {
+  std::vector<Region> v; to_regions(r, n, v);
+  describe_rootsift(v, wrap(img, w, h), mrSize, patchSize, photoNorm != 0);
+  from_regions(v, r, n);
+}
+
+// SynthDetectDescribeKeypoints for one identity view, HessianAffine + RootSIFT
+// (imagerepresentation.cpp:686-1104): detect -> centres inside -> orientation -> touch-boundary
+// filter -> RootSIFT.
+int orc_detect_describe(const float *img, int w, int h, const orc_hessaff_params *p, double ori_mrSize,
+                        int ori_patchSize, int maxAngles, double ori_th, double desc_mrSize, int desc_patchSize,
+                        int photoNorm, orc_region *out, int max_out, int *n_detected) {
+  Img im = wrap(img, w, h);
+  std::vector<AffKey> k;
+  detect_hessian_affine(im, cvt(p), k);
+  if (n_detected) *n_detected = (int)k.size();
+  std::vector<Region> v(k.size()), o;
+  for (size_t i = 0; i < k.size(); i++) {
+    Region &r = v[i];
+    r.x = k[i].x; r.y = k[i].y; r.s = k[i].s; r.a11 = k[i].a11; r.a12 = k[i].a12; r.a21 = k[i].a21; r.a22 = k[i].a22;
+    r.response = k[i].response; r.sub_type = k[i].sub_type; r.id = (int)i; r.parent = (int)i;
+    std::memset(r.desc, 0, 128);
+  }
+  filter_centres_inside(v, w, h);
+  detect_orientation(v, o, im, ori_mrSize, ori_patchSize, maxAngles, ori_th);
+  filter_touch_boundary(o, w, h);
+  describe_rootsift(o, im, desc_mrSize, desc_patchSize, photoNorm != 0);
+  return from_regions(o, out, max_out);
+}
+
 }  // extern "C"

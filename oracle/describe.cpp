@@ -1,0 +1,280 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Dominant orientation, patch extraction and
+// SIFT / RootSIFT description restated from synth-detection.{hpp,cpp} and
+// matching/siftdesc.cpp for the identity view (H = I, reproj_kp == det_kp).
+#include "orc.h"
+#include "detmath.h"
+#include <algorithm>
+#include <cmath>
+
+namespace orc {
+
+// synth-detection.cpp:21  const double k_sigma = 2 * 3.0 * sqrt(3.0)
+static double k_sigma_synth() { return 2 * 3.0 * std::sqrt(3.0); }
+
+// ReprojectRegionsAndRemoveTouchBoundary(..., dontRemove = true), synth-detection.cpp:151-190,
+// as called at imagerepresentation.cpp:867: with H = I only the centre test remains.
+void filter_centres_inside(std::vector<Region> &r, int w, int h) {
+  std::vector<Region> keep;
+  keep.reserve(r.size());
+  for (size_t i = 0; i < r.size(); i++)
+    if ((r[i].x < w) && (r[i].y < h) && (r[i].x > 0) && (r[i].y > 0)) keep.push_back(r[i]);
+  r.swap(keep);
+}
+
+// ReprojectRegions, synth-detection.cpp:631-706 with H = I.
+void filter_touch_boundary(std::vector<Region> &r, int w, int h) {
+  const double ks = k_sigma_synth();
+  std::vector<Region> keep;
+  keep.reserve(r.size());
+  for (size_t i = 0; i < r.size(); i++) {
+    const Region &p = r[i];
+    if ((p.x < w) && (p.y < h) && (p.x > 0) && (p.y > 0)) {
+      if (!interpolate_check_borders(w, h, (float)p.x, (float)p.y, (float)p.a11, (float)p.a12, (float)p.a21,
+                                     (float)p.a22, (int)(ks * p.s), (int)(ks * p.s)))
+        keep.push_back(p);
+    }
+  }
+  r.swap(keep);
+}
+
+// smoothCircularBuffer<36>, synth-detection.cpp:811-822
+static void smooth_circular(float *hist, int bins) {
+  float first = hist[0], prev = hist[bins - 1];
+  for (int i = 0; i < bins - 1; i++) {
+    float cur = hist[i];
+    hist[i] = prev + cur + hist[i + 1];
+    prev = cur;
+  }
+  hist[bins - 1] = prev + hist[bins - 1] + first;
+}
+
+// EstimateDominantAnglesFunctor::operator() for maxAngles = 1, doHalfSIFT = 0
+// (synth-detection.cpp:836-929): first local maximum >= 0.8*max in bin order 0..35, with
+// parabolic refinement.  Returns false when the histogram has no such peak.
+bool dominant_angle(const Img &img, double max_th, float *angle_out) {
+  const int pS = img.w;
+  const int bins = 36;
+  const float PIf = float(M_PI);
+  static thread_local Img orimask;
+  if (orimask.w != pS) { orimask = Img(pS, pS); compute_circular_gauss_mask(orimask, pS / 3.0f); }
+  Img gmag(pS, pS), gori(pS, pS);
+  // computeGradientMagnitudeAndOrientation, helpers.cpp:840-862 (interior only)
+  for (int r = 1; r < pS - 1; ++r)
+    for (int c = 1; c < pS - 1; ++c) {
+      float xgrad = img.at(r, c + 1) - img.at(r, c - 1);
+      float ygrad = img.at(r + 1, c) - img.at(r - 1, c);
+      gmag.at(r, c) = std::sqrt(xgrad * xgrad + ygrad * ygrad);
+      gori.at(r, c) = atan2_lut_ff(ygrad, xgrad);
+    }
+  float hist[bins + 1];
+  for (int i = 0; i < bins; i++) hist[i] = 0.0f;
+  hist[bins] = 0.0f;   // the reference leaves hist[36] uninitialised; it is write-only
+  const float *maskptr = orimask.row(1);
+  const float *pmag = gmag.row(1), *pori = gori.row(1);
+  const int maskPixels = pS * (pS - 2);
+  for (int i = 0; i < maskPixels; ++i) {
+    if (maskptr[i] > 0 && pmag[i] > 1.0) {
+      int bin = (int)(bins * (pori[i] / PIf + 1.0f) / 2.0f);
+      hist[bin] += pmag[i] * maskptr[i];
+    }
+  }
+  for (int i = 0; i < 6; i++) smooth_circular(hist, bins);
+  float thresh = 0.0;
+  for (int i = 0; i < bins; i++)
+    if (hist[i] > thresh) thresh = hist[i];
+  thresh = (float)(thresh * max_th);
+  for (int k = 0; k < bins; k++) {
+    int b = k, a = (k == 0) ? bins - 1 : k - 1, c = (k == bins - 1) ? 0 : k + 1;
+    if (hist[b] >= thresh && hist[b] > hist[a] && hist[b] > hist[c]) {
+      float pp = (hist[a] - hist[c]) / (hist[a] - 2.0f * hist[b] + hist[c]) / 2.0f;
+      *angle_out = 2.0f * PIf * (b + 0.5f + pp) / bins - PIf;
+      return true;
+    }
+  }
+  return false;
+}
+
+// DetectOrientation, synth-detection.cpp:1039-1149 (maxAngNum = 1, addUpRight = false).
+int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, const Img &img, double mrSize,
+                       int patchSize, int maxAngles, double th) {
+  const double ks = k_sigma_synth();
+  std::vector<Region> tmp;
+  tmp.reserve(in.size());
+  const int patchImageSize = 2 * int(mrSize) + 1;
+  const double imageToPatchScale = double(patchImageSize) / (double)patchSize;
+  Img patch(patchSize, patchSize);
+  for (size_t i = 0; i < in.size(); i++) {
+    const Region &k = in[i];
+    float curr_sc = (float)(imageToPatchScale * k.s);
+    if (interpolate_check_borders(img.w, img.h, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12, (float)k.a21,
+                                  (float)k.a22, (int)(ks * k.s), (int)(ks * k.s)))
+      continue;
+    if (maxAngles > 0) {
+      interpolate(img, (float)k.x, (float)k.y, (float)k.a11 * curr_sc, (float)k.a12 * curr_sc,
+                  (float)k.a21 * curr_sc, (float)k.a22 * curr_sc, patch);
+      float ang;
+      if (!dominant_angle(patch, th, &ang)) continue;
+      double si, ci;
+      det_sincos(-(double)ang, &si, &ci);
+      Region t = k;
+      t.a11 = k.a11 * ci - k.a12 * si;
+      t.a12 = k.a11 * si + k.a12 * ci;
+      t.a21 = k.a21 * ci - k.a22 * si;
+      t.a22 = k.a21 * si + k.a22 * ci;
+      t.parent = (int)i;
+      tmp.push_back(t);
+    }
+  }
+  out.swap(tmp);
+  return (int)out.size();
+}
+
+// ---------------------------------------------------------------------------------------
+// SIFT (matching/siftdesc.cpp), patchSize 41, spatialBins 4, orientationBins 8, maxBinValue 0.2
+// ---------------------------------------------------------------------------------------
+struct SiftTables {
+  int ps;
+  Img mask;
+  std::vector<int> bin0, bin1;
+  std::vector<double> w0, w1;
+  explicit SiftTables(int patchSize) : ps(patchSize), mask(patchSize, patchSize) {
+    compute_circular_gauss_mask(mask, 0);
+    // precomputeBinsAndWeights, siftdesc.cpp:22-71
+    const int spatialBins = 4, orientationBins = 8;
+    int halfSize = ps >> 1;
+    float step = float(spatialBins + 1) / (2 * halfSize);
+    bin0.resize(ps); bin1.resize(ps); w0.resize(ps); w1.resize(ps);
+    for (int i = 0; i < ps; i++) {
+      float x = step * i;
+      int xi = (int)(x);
+      bin0[i] = xi - 1;
+      bin1[i] = xi;
+      w1[i] = x - xi;
+      w0[i] = 1.0f - w1[i];
+      if (bin0[i] < 0) { bin0[i] = 0; w0[i] = 0; }
+      if (bin0[i] >= spatialBins) { bin0[i] = spatialBins - 1; w0[i] = 0; }
+      if (bin1[i] < 0) { bin1[i] = 0; w1[i] = 0; }
+      if (bin1[i] >= spatialBins) { bin1[i] = spatialBins - 1; w1[i] = 0; }
+      bin0[i] *= orientationBins;
+      bin1[i] *= orientationBins;
+    }
+  }
+};
+
+static double normalize_d(std::vector<double> &v) {   // siftdesc.cpp:133-158 (size % 4 == 0)
+  double len = 0.0;
+  for (size_t i = 0; i < v.size(); i += 4) {
+    const double sq0 = v[i] * v[i], sq1 = v[i + 1] * v[i + 1], sq2 = v[i + 2] * v[i + 2], sq3 = v[i + 3] * v[i + 3];
+    len += sq0 + sq1 + sq2 + sq3;
+  }
+  len = std::sqrt(len);
+  const double fac = 1.0 / len;
+  for (size_t i = 0; i < v.size(); i++) v[i] *= fac;
+  return len;
+}
+
+// computeRootSiftDescriptor / computeSiftDescriptor + (Root)SIFTnorm(double),
+// siftdesc.cpp:346-400, 288-345, 73-131, 199-222, 248-263.
+void sift_patch_to_desc(const Img &patch, uint8_t out[128], bool rootsift, double maxBinValue) {
+  const int ps = patch.w;
+  static thread_local SiftTables *T = nullptr;
+  if (!T || T->ps != ps) { delete T; T = new SiftTables(ps); }
+  const int spatialBins = 4, orientationBins = 8;
+  Img grad(ps, ps), ori(ps, ps);
+  for (int r = 0; r < ps; ++r)
+    for (int c = 0; c < ps; ++c) {
+      float xgrad, ygrad;
+      if (c == 0) xgrad = patch.at(r, c + 1) - patch.at(r, c);
+      else if (c == ps - 1) xgrad = patch.at(r, c) - patch.at(r, c - 1);
+      else xgrad = patch.at(r, c + 1) - patch.at(r, c - 1);
+      if (r == 0) ygrad = patch.at(r + 1, c) - patch.at(r, c);
+      else if (r == ps - 1) ygrad = patch.at(r, c) - patch.at(r - 1, c);
+      else ygrad = patch.at(r + 1, c) - patch.at(r - 1, c);
+      grad.at(r, c) = std::sqrt(xgrad * xgrad + ygrad * ygrad);
+      ori.at(r, c) = atan2_lut_ff(ygrad, xgrad);
+    }
+  std::vector<double> vec(spatialBins * spatialBins * orientationBins, 0.0);
+  // samplePatch, siftdesc.cpp:73-131 (magnLess = false)
+  const double M_PI_DOUBLED = 6.28318530718;
+  for (int r = 0; r < ps; ++r) {
+    const int br0 = spatialBins * T->bin0[r];
+    const float wr0 = (float)T->w0[r];
+    const int br1 = spatialBins * T->bin1[r];
+    const float wr1 = (float)T->w1[r];
+    for (int c = 0; c < ps; ++c) {
+      float val = (float)(float(false) * 1.0 + (1.0 - float(false)) * T->mask.at(r, c) * grad.at(r, c));
+      const int bc0 = T->bin0[c];
+      const float wc0 = (float)(T->w0[c] * val);
+      const int bc1 = T->bin1[c];
+      const float wc1 = (float)(T->w1[c] * val);
+      const float o = (float)(float(orientationBins) * (ori.at(r, c) + M_PI_DOUBLED) / M_PI_DOUBLED);
+      int bo0 = (int)o;
+      const float wo1 = o - bo0;
+      bo0 %= orientationBins;
+      int bo1 = (bo0 + 1) % orientationBins;
+      const float wo0 = 1.0f - wo1;
+      val = wr0 * wc0;
+      if (val > 0) { vec[br0 + bc0 + bo0] += val * wo0; vec[br0 + bc0 + bo1] += val * wo1; }
+      val = wr0 * wc1;
+      if (val > 0) { vec[br0 + bc1 + bo0] += val * wo0; vec[br0 + bc1 + bo1] += val * wo1; }
+      val = wr1 * wc0;
+      if (val > 0) { vec[br1 + bc0 + bo0] += val * wo0; vec[br1 + bc0 + bo1] += val * wo1; }
+      val = wr1 * wc1;
+      if (val > 0) { vec[br1 + bc1 + bo0] += val * wo0; vec[br1 + bc1 + bo1] += val * wo1; }
+    }
+  }
+  normalize_d(vec);
+  bool changed = false;
+  for (size_t i = 0; i < vec.size(); i++)
+    if (vec[i] > maxBinValue) { vec[i] = maxBinValue; changed = true; }
+  if (changed) normalize_d(vec);
+  if (rootsift) {
+    double sum = 0.;
+    for (size_t i = 0; i < vec.size(); i++) sum += std::fabs(vec[i]);
+    for (size_t i = 0; i < vec.size(); i++) vec[i] = std::sqrt(vec[i] / sum);
+    for (size_t i = 0; i < vec.size(); i++) {
+      int b = std::max(0, std::min((int)(512.0 * vec[i] + 0.5), 255));
+      out[i] = (uint8_t)b;
+    }
+  } else {
+    for (size_t i = 0; i < vec.size(); i++) {
+      int b = std::max(0, std::min((int)(512.0f * vec[i] + 0.5), 255));
+      out[i] = (uint8_t)b;
+    }
+  }
+}
+
+// Non-fast branch of DescribeRegions<>, synth-detection.hpp:186-231.
+void extract_desc_patch(const Region &k, const Img &img, double mrSize, int patchSize, bool photoNorm, Img &patch) {
+  static thread_local Img mask;
+  if (mask.w != patchSize) { mask = Img(patchSize, patchSize); compute_circular_gauss_mask(mask, 0); }
+  if (patch.w != patchSize || patch.h != patchSize) patch = Img(patchSize, patchSize);
+  float mrScale = (float)std::ceil(k.s * mrSize);
+  int patchImageSize = 2 * int(mrScale) + 1;
+  float imageToPatchScale = float(patchImageSize) / float(patchSize);
+  if (imageToPatchScale > 0.4) {
+    patchImageSize += 2;
+    Img smoothed(patchImageSize, patchImageSize);
+    interpolate(img, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12, (float)k.a21, (float)k.a22, smoothed);
+    gauss_blur(smoothed, smoothed, 1.5f * imageToPatchScale);
+    interpolate(smoothed, (float)(patchImageSize >> 1), (float)(patchImageSize >> 1), imageToPatchScale, 0, 0,
+                imageToPatchScale, patch);
+  } else {
+    interpolate(img, (float)k.x, (float)k.y, (float)k.a11 * imageToPatchScale, (float)k.a12 * imageToPatchScale,
+                (float)k.a21 * imageToPatchScale, (float)k.a22 * imageToPatchScale, patch);
+  }
+  if (photoNorm) {
+    float mean, var;
+    photometrically_normalize(patch, mask, mean, var);
+  }
+}
+
+void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize, bool photoNorm) {
+  Img patch(patchSize, patchSize);
+  for (size_t i = 0; i < r.size(); i++) {
+    extract_desc_patch(r[i], img, mrSize, patchSize, photoNorm, patch);
+    sift_patch_to_desc(patch, r[i].desc, true, 0.2);   // [SIFTDescriptor] maxBinValue = 0.2 (io_mods.cpp:427)
+  }
+}
+
+}  // namespace orc

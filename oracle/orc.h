@@ -97,7 +97,7 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
 void filter_touch_boundary(std::vector<Region> &r, int w, int h);           // ReprojectRegions :631-706
 void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize,
                        bool photoNorm);                                     // synth-detection.hpp:170-263
-void sift_patch_to_desc(const Img &patch41, uint8_t out[128], bool rootsift);   // matching/siftdesc.cpp
+void sift_patch_to_desc(const Img &patch41, uint8_t out[128], bool rootsift, double maxBinValue = 0.2);   // matching/siftdesc.cpp
 void extract_desc_patch(const Region &r, const Img &img, double mrSize, int patchSize, bool photoNorm,
                         Img &patch);
 bool dominant_angle(const Img &patch, double th, float *angle);              // :836-929 (maxAngles=1)

@@ -169,3 +169,87 @@ def detect_hessian_affine(img, params=None, max_out=1 << 20):
     n = lib().orc_detect_hessian_affine(p, a.shape[1], a.shape[0], C.byref(params),
                                         out.ctypes.data_as(C.POINTER(AffKey)), max_out)
     return out[:n].copy()
+
+
+# ---- orientation + description ---------------------------------------------------------------
+REGION_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("s", "f8"), ("a11", "f8"), ("a12", "f8"), ("a21", "f8"),
+                         ("a22", "f8"), ("response", "f8"), ("sub_type", "i4"), ("id", "i4"), ("parent", "i4"),
+                         ("pad", "i4"), ("desc", "u1", (128,))])
+
+# build/config_affori_classic.ini: [DominantOrientation] / [SIFTDescriptor]
+ORI_MRSIZE, ORI_PATCH, ORI_MAXANG, ORI_TH = 5.1962, 32, 1, float(np.float32(0.8))
+DESC_MRSIZE, DESC_PATCH = 5.1962, 41
+
+
+def regions_from_keys(keys):
+    r = np.zeros(len(keys), REGION_DTYPE)
+    for f in ("x", "y", "s", "a11", "a12", "a21", "a22", "response", "sub_type"):
+        r[f] = keys[f]
+    r["id"] = np.arange(len(keys))
+    r["parent"] = r["id"]
+    return r
+
+
+def dominant_angle(patch, th=ORI_TH):
+    a, p = _f(patch)
+    ang = C.c_float()
+    ok = lib().orc_dominant_angle(p, a.shape[0], C.c_double(th), C.byref(ang))
+    return bool(ok), ang.value
+
+
+def sift_desc(patch, rootsift=True, max_bin=0.2):
+    a, p = _f(patch)
+    out = np.zeros(128, np.uint8)
+    lib().orc_sift_desc(p, a.shape[0], int(rootsift), C.c_double(max_bin), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def extract_desc_patch(img, region, mrsize=DESC_MRSIZE, ps=DESC_PATCH, photonorm=True):
+    a, p = _f(img)
+    r = np.ascontiguousarray(np.atleast_1d(region)[:1])
+    out = np.empty((ps, ps), np.float32)
+    lib().orc_extract_desc_patch(p, a.shape[1], a.shape[0], r.ctypes.data_as(C.c_void_p), C.c_double(mrsize), ps,
+                                 int(photonorm), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def detect_orientation(img, regions, mrsize=ORI_MRSIZE, ps=ORI_PATCH, max_angles=ORI_MAXANG, th=ORI_TH):
+    a, p = _f(img)
+    r = np.ascontiguousarray(regions)
+    out = np.zeros(len(r) + 1, REGION_DTYPE)
+    n = lib().orc_detect_orientation(p, a.shape[1], a.shape[0], r.ctypes.data_as(C.c_void_p), len(r),
+                                     C.c_double(mrsize), ps, max_angles, C.c_double(th),
+                                     out.ctypes.data_as(C.c_void_p), len(out))
+    return out[:n].copy()
+
+
+def filter_centres_inside(regions, w, h):
+    r = np.ascontiguousarray(regions).copy()
+    n = lib().orc_filter_centres_inside(r.ctypes.data_as(C.c_void_p), len(r), w, h)
+    return r[:n].copy()
+
+
+def filter_touch_boundary(regions, w, h):
+    r = np.ascontiguousarray(regions).copy()
+    n = lib().orc_filter_touch_boundary(r.ctypes.data_as(C.c_void_p), len(r), w, h)
+    return r[:n].copy()
+
+
+def describe_rootsift(img, regions, mrsize=DESC_MRSIZE, ps=DESC_PATCH, photonorm=True):
+    a, p = _f(img)
+    r = np.ascontiguousarray(regions).copy()
+    lib().orc_describe_rootsift(p, a.shape[1], a.shape[0], r.ctypes.data_as(C.c_void_p), len(r), C.c_double(mrsize), ps,
+                                int(photonorm))
+    return r
+
+
+def detect_describe(img, params=None, max_out=1 << 18):
+    """HessianAffine + RootSIFT for one identity view; returns (regions, n_detected)."""
+    params = params or HessAffParams.default()
+    a, p = _f(img)
+    out = np.zeros(max_out, REGION_DTYPE)
+    ndet = C.c_int()
+    n = lib().orc_detect_describe(p, a.shape[1], a.shape[0], C.byref(params), C.c_double(ORI_MRSIZE), ORI_PATCH,
+                                  ORI_MAXANG, C.c_double(ORI_TH), C.c_double(DESC_MRSIZE), DESC_PATCH, 1,
+                                  out.ctypes.data_as(C.c_void_p), max_out, C.byref(ndet))
+    return out[:n].copy(), ndet.value
