@@ -161,6 +161,26 @@ int mods_regions_fetch(mods_ctx *ctx, int img, mods_region *out, int max_out, in
 int mods_dominant_angle(mods_ctx *ctx, const float *patch, int ps, double th, float *angle, int *found);
 int mods_sift_patch(mods_ctx *ctx, const float *patch, int ps, int rootsift, double maxBinValue, uint8_t *out128);
 
+/* ---- B4: matching ------------------------------------------------------------------------------
+ * Replaces  int MatchFlannFGINN(const AffineRegionList &q, const AffineRegionList &t,
+ *           TentativeCorrespListExt &out, const MatchPars &par, const int nn = 50)
+ * (matching/matching.hpp:261-262, matching.cpp:356-460) for vector_matcher = linear, vector_dist = L2:
+ * exact brute-force squared-L2 search (ties: lower train index first), FGINN walk over nn neighbours.
+ * ratio = par.currMatchRatio (FGINNThreshold of the iters .ini), contradDist = [Matching] contradDist.
+ * Tentatives come out in query order.  u6_out (optional, 6 doubles per tentative) receives the
+ * correspondences as LORANSACFiltering lays them out for degensac: x1 y1 1 x2 y2 1. */
+int mods_match_fginn(mods_ctx *ctx, const mods_region *q, int n_q, const mods_region *t, int n_t, double ratio,
+                     double contradDist, int nn, mods_tentative *out, double *u6_out, int max_out, int *n_out);
+/* same, on the HBM-resident region lists of images img_q / img_t left by mods_detect_describe_dev */
+int mods_match_dev(mods_ctx *ctx, int img_q, int img_t, double ratio, double contradDist, int nn, mods_tentative *out,
+                   double *u6_out, int max_out, int *n_out);
+
+/* Replaces  void DuplicateFiltering(TentativeCorrespListExt &in, const double r, const int mode)
+ * (matching.cpp:2615-2679).  Host-side, in place on (tent, u6); mode 0 = keep order (MODE_RANDOM),
+ * 1 = best FGINN ratio first, 2 = best distance first (configuration.hpp:31-34); equal keys keep
+ * list order.  Sequential greedy by definition; it is control logic, not a kernel. */
+int mods_duplicate_filter(mods_tentative *tent, double *u6, int n, double r, int mode, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

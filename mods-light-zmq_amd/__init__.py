@@ -233,3 +233,37 @@ class Context:
         _check(lib().mods_sift_patch(self.h, _fp(a), a.shape[0], int(rootsift), C.c_double(max_bin),
                                      out.ctypes.data_as(C.c_void_p)))
         return out
+
+    # ---- matching
+    def match_fginn(self, q, t, ratio=0.8, contrad=10.0, nn=50):
+        q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+        cap = max(len(q), 1)
+        out = np.zeros(cap, TENT_DTYPE)
+        u6 = np.zeros((cap, 6), np.float64)
+        n = C.c_int()
+        _check(lib().mods_match_fginn(self.h, q.ctypes.data_as(C.c_void_p), len(q), t.ctypes.data_as(C.c_void_p), len(t),
+                                      C.c_double(ratio), C.c_double(contrad), nn, out.ctypes.data_as(C.c_void_p),
+                                      u6.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy(), u6[:n.value].copy()
+
+    def match_dev(self, img_q, img_t, ratio=0.8, contrad=10.0, nn=50, cap=1 << 18):
+        out = np.zeros(cap, TENT_DTYPE)
+        u6 = np.zeros((cap, 6), np.float64)
+        n = C.c_int()
+        _check(lib().mods_match_dev(self.h, img_q, img_t, C.c_double(ratio), C.c_double(contrad), nn,
+                                    out.ctypes.data_as(C.c_void_p), u6.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy(), u6[:n.value].copy()
+
+
+TENT_DTYPE = np.dtype([("q", "i4"), ("t", "i4"), ("t_bad", "i4"), ("t_2nd", "i4"), ("d1", "f4"), ("d2", "f4"),
+                       ("d2nd", "f4"), ("pad", "f4"), ("ratio", "f8")])
+
+
+def duplicate_filter(tent, u6, r=2.0, mode=1):
+    """Host-side DuplicateFiltering (matching.cpp:2615-2679) on (tentatives, correspondences)."""
+    tent = np.ascontiguousarray(tent).copy()
+    u6 = np.ascontiguousarray(u6, np.float64).copy()
+    n = C.c_int()
+    _check(lib().mods_duplicate_filter(tent.ctypes.data_as(C.c_void_p), u6.ctypes.data_as(C.c_void_p), len(tent),
+                                       C.c_double(r), mode, C.byref(n)))
+    return tent[:n.value].copy(), u6[:n.value].copy()

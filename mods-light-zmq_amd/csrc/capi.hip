@@ -4,6 +4,7 @@
 #include "detmath.hpp"
 #include <cstdarg>
 #include <algorithm>
+#include <cmath>
 
 namespace mods {
 
@@ -60,7 +61,7 @@ int mods_ctx_create(int device, int max_w, int max_h, int batch, mods_ctx **out)
   MODS_HIP_CHECK(hipSetDevice(device));
   mods_ctx *c = new mods_ctx();
   c->device = device; c->max_w = max_w; c->max_h = max_h; c->batch = batch;
-  MODS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  MODS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamDefault));
   const size_t px = (size_t)max_w * max_h;
   size_t mc = px / 8;
   mc = std::max<size_t>(mc, 1u << 16);
@@ -220,7 +221,7 @@ static int check_desc_err(mods_ctx *c) {
   int e = 0;
   MODS_HIP_CHECK(hipMemcpy(&e, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost));
   if (e) {
-    MODS_HIP_CHECK(hipMemset(c->desc_err_dev, 0, sizeof(int)));
+    MODS_HIP_CHECK(hipMemsetAsync(c->desc_err_dev, 0, sizeof(int), c->stream));
     set_error("measurement region larger than the descriptor scratch (P2 > 3*max(w,h) or > 4096 blur taps)");
     return MODS_E_CAPACITY;
   }
@@ -247,6 +248,7 @@ int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w
     if (n_detected_host) n_detected_host[b] = c->host_counts[2 * c->batch + b];
     if (n_regions_host) n_regions_host[b] = c->host_counts[3 * c->batch + b];
   }
+  c->last_region_counts.assign(c->host_counts + 3 * c->batch, c->host_counts + 3 * c->batch + n_img);
   return check_desc_err(c);
 }
 
@@ -305,6 +307,88 @@ int mods_sift_patch(mods_ctx *c, const float *patch, int ps, int rootsift, doubl
   if ((rc = launch_sift_patch_test(c, c->input_dev, ps, rootsift, maxBinValue, (uint8_t *)c->tmp_dev))) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(out128, c->tmp_dev, 128, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return MODS_OK;
+}
+
+// ---- matching ----------------------------------------------------------------------------------
+static int match_fetch(mods_ctx *c, mods_tentative *out, double *u6_out, int max_out, int *n_out) {
+  int n = 0;
+  MODS_HIP_CHECK(hipMemcpyAsync(&n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  *n_out = n;
+  if (n > max_out) { set_error("tentative output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
+  if (n > 0 && out) MODS_HIP_CHECK(hipMemcpy(out, c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost));
+  if (n > 0 && u6_out) MODS_HIP_CHECK(hipMemcpy(u6_out, c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost));
+  return MODS_OK;
+}
+
+int mods_match_fginn(mods_ctx *c, const mods_region *q, int n_q, const mods_region *t, int n_t, double ratio,
+                     double contradDist, int nn, mods_tentative *out, double *u6_out, int max_out, int *n_out) {
+  if (!c || !n_out || (n_q > 0 && !q) || (n_t > 0 && !t)) { set_error("match: null argument"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc = match_ensure_buffers(c);
+  if (rc) return rc;
+  if (n_q > c->max_cand || n_t > c->max_cand) { set_error("match: list larger than the context capacity"); return MODS_E_CAPACITY; }
+  MODS_HIP_CHECK(hipMemcpyAsync(c->m_regs, q, sizeof(mods_region) * n_q, hipMemcpyHostToDevice, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(c->m_regs + c->max_cand, t, sizeof(mods_region) * n_t, hipMemcpyHostToDevice, c->stream));
+  if ((rc = match_run(c, c->m_regs, n_q, c->m_regs + c->max_cand, n_t, ratio, contradDist, nn))) return rc;
+  return match_fetch(c, out, u6_out, max_out, n_out);
+}
+
+int mods_match_dev(mods_ctx *c, int img_q, int img_t, double ratio, double contradDist, int nn, mods_tentative *out,
+                   double *u6_out, int max_out, int *n_out) {
+  if (!c || !n_out) { set_error("match: null argument"); return MODS_E_ARG; }
+  const int nb = (int)c->last_region_counts.size();
+  if (img_q < 0 || img_q >= nb || img_t < 0 || img_t >= nb) { set_error("match: image index outside the last described batch"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc = match_run(c, c->regions_dev + (size_t)img_q * c->max_cand, c->last_region_counts[img_q],
+                     c->regions_dev + (size_t)img_t * c->max_cand, c->last_region_counts[img_t], ratio, contradDist, nn);
+  if (rc) return rc;
+  return match_fetch(c, out, u6_out, max_out, n_out);
+}
+
+// DuplicateFiltering, matching.cpp:2615-2679: optional stable sort, then the first correspondence
+// (in list order) of every group whose two endpoints lie within r of each other survives.  A uniform
+// grid over the first-image points (cell = r) bounds the candidates to the 3x3 neighbourhood; the
+// accept/reject sequence is the reference's.
+int mods_duplicate_filter(mods_tentative *tent, double *u6, int n, double r, int mode, int *n_out) {
+  if (!n_out || (n > 0 && (!tent || !u6))) { set_error("duplicate_filter: null argument"); return MODS_E_ARG; }
+  *n_out = n;
+  if (r <= 0 || n <= 0) return MODS_OK;
+  std::vector<int> order(n);
+  for (int i = 0; i < n; i++) order[i] = i;
+  if (mode == 1) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(tent[a].ratio) < std::fabs(tent[b].ratio); });
+  else if (mode == 2) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs((double)tent[a].d1) < std::fabs((double)tent[b].d1); });
+  std::vector<mods_tentative> ts(n);
+  std::vector<double> us((size_t)n * 6);
+  for (int i = 0; i < n; i++) { ts[i] = tent[order[i]]; memcpy(&us[(size_t)i * 6], &u6[(size_t)order[i] * 6], 6 * sizeof(double)); }
+  const double r_sq = r * r;
+  // hash grid of the kept correspondences, keyed by the first-image cell
+  struct Cell { long long key; int idx; };
+  std::vector<std::vector<int>> buckets(1 << 14);
+  auto cell_of = [&](double v) { return (long long)std::floor(v / r); };
+  auto hash = [&](long long cx, long long cy) { return (size_t)(((unsigned long long)cx * 73856093ull) ^ ((unsigned long long)cy * 19349663ull)) & ((1 << 14) - 1); };
+  std::vector<char> keep(n, 0);
+  int m = 0;
+  for (int j = 0; j < n; j++) {
+    const double x1 = us[(size_t)j * 6], y1 = us[(size_t)j * 6 + 1], x2 = us[(size_t)j * 6 + 3], y2 = us[(size_t)j * 6 + 4];
+    const long long cx = cell_of(x1), cy = cell_of(y1);
+    bool dup = false;
+    for (long long dy = -1; dy <= 1 && !dup; dy++)
+      for (long long dx = -1; dx <= 1 && !dup; dx++) {
+        const std::vector<int> &bk = buckets[hash(cx + dx, cy + dy)];
+        for (int i : bk) {
+          double ex = us[(size_t)i * 6] - x1, ey = us[(size_t)i * 6 + 1] - y1;
+          if (ex * ex + ey * ey > r_sq) continue;
+          ex = us[(size_t)i * 6 + 3] - x2; ey = us[(size_t)i * 6 + 4] - y2;
+          if (ex * ex + ey * ey <= r_sq) { dup = true; break; }
+        }
+      }
+    if (!dup) { keep[j] = 1; buckets[hash(cx, cy)].push_back(j); }
+  }
+  for (int j = 0; j < n; j++)
+    if (keep[j]) { tent[m] = ts[j]; memcpy(&u6[(size_t)m * 6], &us[(size_t)j * 6], 6 * sizeof(double)); m++; }
+  *n_out = m;
   return MODS_OK;
 }
 

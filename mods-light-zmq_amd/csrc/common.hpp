@@ -99,6 +99,18 @@ struct mods_ctx {
   float *desc_scratch = nullptr;
   size_t desc_scratch_elems = 0;
   const float *last_img_dev = nullptr;
+  std::vector<int> last_region_counts;
+  // matching
+  int8_t *m_desc = nullptr;          // [2][pad][128] int8 descriptors (query list, train list)
+  int *m_c = nullptr;                // [2][pad] precombined norms
+  void *m_xy = nullptr;              // [2][pad] double2 centres
+  unsigned long long *m_u64 = nullptr;
+  int *m_int = nullptr;
+  void *m_mid = nullptr;
+  mods_tentative *m_tent = nullptr;
+  double *m_u6 = nullptr;            // [pad][6] correspondences (x1 y1 1 x2 y2 1)
+  int *m_count = nullptr;
+  mods_region *m_regs = nullptr;     // [2][max_cand] staging for host-side lists
   // timing
   int timing_mask = 0;
   mods::StageTimer timers[MODS_STAGE_COUNT];
@@ -126,6 +138,11 @@ void circular_gauss_mask_host(int size, float sigma, float *out);
 
 // detect.hip
 int detect_run(mods_ctx *ctx);       // NMS -> localise -> dedup -> Baumberg -> sort, for the configured batch
+
+// match.hip
+int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double ratio,
+              double contradDist, int nn);
+int match_ensure_buffers(mods_ctx *ctx);
 
 // describe.hip
 int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par);

@@ -604,7 +604,7 @@ int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
   if (!ctx->desc_tables_dev) {
     MODS_HIP_CHECK(hipMalloc(&ctx->desc_tables_dev, sizeof(float) * (64 * 64 * 2) + sizeof(SiftTab)));
     MODS_HIP_CHECK(hipMalloc(&ctx->desc_err_dev, sizeof(int)));
-    MODS_HIP_CHECK(hipMemset(ctx->desc_err_dev, 0, sizeof(int)));
+    MODS_HIP_CHECK(hipMemsetAsync(ctx->desc_err_dev, 0, sizeof(int), ctx->stream));
   }
   if (ctx->desc_ori_ps != par->ori_patchSize || ctx->desc_ps != par->desc_patchSize) {
     std::vector<float> m1((size_t)64 * 64, 0.f), m2((size_t)64 * 64, 0.f);

@@ -1,0 +1,317 @@
+// Brute-force 128-D nearest-neighbour matching with the first-geometrically-inconsistent
+// (FGINN) ratio test on the gfx950 matrix cores.
+//
+// Reference behaviour: MatchFlannFGINN, matching/matching.cpp:356-460, with the exact linear
+// index ([Matching] vector_matcher = linear, io_mods.cpp:389-390): for every query descriptor
+// the k = 50 nearest train descriptors (squared L2, ties by lower index) are walked in order;
+// neighbour j is accepted when d0/dj <= ratio^2, the walk stops at the first neighbour further
+// than contradDist from the nearest one.
+//
+// The walk is restated as reductions that a tiled distance GEMM can fold into its epilogue
+// (no N x M matrix, no top-k lists).  With (d0, i0) the nearest neighbour and D* the smallest
+// integer distance whose ratio test passes (fl32(d0/d) <= ratio^2; the quotient is monotone):
+//   reject  <=> some train t != i0 has d_t < D* and lies > contradDist from i0
+//   else accept the first train in (d, t) order with d_t >= D*, provided at most nn-2 trains
+//   (all consistent, all with d_t < D*) precede it.
+// Pass 1 finds (d0, i0); pass 2 accumulates {any inconsistent below D*, count below D*,
+// min key at/above D*, min key below D*} per query.
+//
+// Distances are exact integers: descriptors are offset to int8 (v - 128), the contraction runs
+// on v_mfma_i32_32x32x32_i8 (i32 accumulate) and d = cq + ct - 2*dot with precombined norms.
+// Trains are the MFMA rows (streamed), queries the columns (resident in registers), so every
+// lane reduces its 16 results per tile into per-query running values.
+#include "common.hpp"
+
+namespace mods {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct MatchConst {
+  int n_q, n_t;
+  int nn;
+  double sqminratio, contr_sq;
+  int tiles_per_split;
+};
+
+// Packs one region list for the matcher: int8 descriptors (v-128), c = sum v^2 - 256*sum(v-128),
+// centre coordinates.  grid = ceil(n/4), block = 256 (one wave per region).
+__global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__restrict__ reg, const int *__restrict__ count_ptr,
+                                                         int count_fixed, int8_t *__restrict__ desc, int *__restrict__ cvec,
+                                                         double2 *__restrict__ xy, int max_n) {
+  int n = count_ptr ? *count_ptr : count_fixed;
+  if (n > max_n) n = max_n;
+  const int lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+    const uint8_t *d = reg[i].desc;
+    const int v0 = d[lane * 2], v1 = d[lane * 2 + 1];
+    desc[(size_t)i * 128 + lane * 2] = (int8_t)(v0 - 128);
+    desc[(size_t)i * 128 + lane * 2 + 1] = (int8_t)(v1 - 128);
+    int n2 = v0 * v0 + v1 * v1;
+    int s1 = (v0 - 128) + (v1 - 128);
+    for (int off = 32; off > 0; off >>= 1) { n2 += __shfl_xor(n2, off); s1 += __shfl_xor(s1, off); }
+    if (lane == 0) {
+      cvec[i] = n2 - 256 * s1;
+      xy[i] = make_double2(reg[i].x, reg[i].y);
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+  unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
+  lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// One 32-train x 32-query tile: returns the 16 integer distances of this lane (rows
+// (reg&3) + 8*(reg>>2) + 4*(lane>>5) of the tile, column lane&31).
+__device__ __forceinline__ void tile_distances(const int8_t *__restrict__ tdesc, const int *__restrict__ tc, int tbase,
+                                               const v4i bq[4], int cq, int lane, int d[16]) {
+  const int g = lane >> 5;
+  const int8_t *arow = tdesc + (size_t)(tbase + (lane & 31)) * 128 + g * 16;
+  v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    const v4i a = *(const v4i *)(arow + ks * 32);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[ks], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int4 ct = *(const int4 *)(tc + tbase + 8 * q + 4 * g);
+    d[4 * q + 0] = cq + ct.x - 2 * acc[4 * q + 0];
+    d[4 * q + 1] = cq + ct.y - 2 * acc[4 * q + 1];
+    d[4 * q + 2] = cq + ct.z - 2 * acc[4 * q + 2];
+    d[4 * q + 3] = cq + ct.w - 2 * acc[4 * q + 3];
+  }
+}
+
+// Pass 1: nearest neighbour key (d << 32 | t) per query.  grid = (ceil(n_q/128), splits), block 256.
+__global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
+                                                        const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
+                                                        unsigned long long *__restrict__ best) {
+  const int lane = threadIdx.x & 63, g = lane >> 5;
+  const int j = blockIdx.x * 128 + (threadIdx.x >> 6) * 32 + (lane & 31);
+  const int jc = j < k.n_q ? j : k.n_q - 1;
+  v4i bq[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) bq[ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
+  const int cq = qc[jc] - 4194304;
+  const int n_tiles = (k.n_t + 31) / 32;
+  const int t0 = blockIdx.y * k.tiles_per_split;
+  const int t1 = min(n_tiles, t0 + k.tiles_per_split);
+  unsigned long long mine = ~0ull;
+  for (int tt = t0; tt < t1; tt++) {
+    int d[16];
+    tile_distances(tdesc, tc, tt * 32, bq, cq, lane, d);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int t = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      const unsigned long long key = ((unsigned long long)(unsigned int)d[r] << 32) | (unsigned int)t;
+      if (t < k.n_t && key < mine) mine = key;
+    }
+  }
+  const unsigned long long other = shfl_xor_u64(mine, 32);
+  if (other < mine) mine = other;
+  if (g == 0 && j < k.n_q && mine != ~0ull) atomicMin(&best[j], mine);
+}
+
+struct QueryMid {        // per query state between the passes
+  int i0, d0, dstar, pad;
+  double x0, y0;
+};
+
+// fl32(d0/d) <= ratio^2, evaluated as the reference does (float quotient promoted to double)
+__device__ __forceinline__ bool ratio_ok(int d0, int d, double sqmin) {
+  const double ratio = (double)((float)d0 / (float)d);
+  return ratio <= sqmin;
+}
+
+// grid = ceil(n_q/256), block 256.  Also clears the pass-2 accumulators.
+__global__ __launch_bounds__(256) void match_mid_kernel(MatchConst k, const unsigned long long *__restrict__ best,
+                                                        const double2 *__restrict__ txy, QueryMid *__restrict__ mid,
+                                                        unsigned long long *__restrict__ key_ge, unsigned long long *__restrict__ key_lt,
+                                                        int *__restrict__ n_lt, int *__restrict__ bad) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= k.n_q) return;
+  const unsigned long long b = best[j];
+  QueryMid m;
+  m.i0 = (int)(unsigned int)b;
+  m.d0 = (int)(b >> 32);
+  m.pad = 0;
+  int ds;
+  if (m.d0 == 0) ds = 1;
+  else {
+    double e = ceil((double)m.d0 / k.sqminratio);
+    if (e > 2.0e9) e = 2.0e9;
+    ds = (int)e - 2;
+    if (ds < 1) ds = 1;
+    while (!ratio_ok(m.d0, ds, k.sqminratio) && ds < 2000000000) ds++;
+    while (ds > 1 && ratio_ok(m.d0, ds - 1, k.sqminratio)) ds--;
+  }
+  m.dstar = ds;
+  const double2 p = txy[m.i0];
+  m.x0 = p.x; m.y0 = p.y;
+  mid[j] = m;
+  key_ge[j] = ~0ull; key_lt[j] = ~0ull; n_lt[j] = 0; bad[j] = 0;
+}
+
+// Pass 2: FGINN reductions.  Same tiling as pass 1.
+__global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
+                                                          const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
+                                                          const double2 *__restrict__ txy, const QueryMid *__restrict__ mid,
+                                                          unsigned long long *__restrict__ key_ge, unsigned long long *__restrict__ key_lt,
+                                                          int *__restrict__ n_lt, int *__restrict__ bad) {
+  const int lane = threadIdx.x & 63, g = lane >> 5;
+  const int j = blockIdx.x * 128 + (threadIdx.x >> 6) * 32 + (lane & 31);
+  const int jc = j < k.n_q ? j : k.n_q - 1;
+  v4i bq[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) bq[ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
+  const int cq = qc[jc] - 4194304;
+  const QueryMid m = mid[jc];
+  const int n_tiles = (k.n_t + 31) / 32;
+  const int t0 = blockIdx.y * k.tiles_per_split;
+  const int t1 = min(n_tiles, t0 + k.tiles_per_split);
+  unsigned long long kge = ~0ull, klt = ~0ull;
+  int cnt = 0, isbad = 0;
+  for (int tt = t0; tt < t1; tt++) {
+    int d[16];
+    tile_distances(tdesc, tc, tt * 32, bq, cq, lane, d);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int t = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (t >= k.n_t || t == m.i0) continue;
+      const unsigned long long key = ((unsigned long long)(unsigned int)d[r] << 32) | (unsigned int)t;
+      if (d[r] >= m.dstar) {
+        if (key < kge) kge = key;
+      } else {
+        cnt++;
+        if (key < klt) klt = key;
+        const double2 p = txy[t];
+        const double dx = m.x0 - p.x, dy = m.y0 - p.y;
+        if (dx * dx + dy * dy > k.contr_sq) isbad = 1;
+      }
+    }
+  }
+  unsigned long long o = shfl_xor_u64(kge, 32); if (o < kge) kge = o;
+  o = shfl_xor_u64(klt, 32); if (o < klt) klt = o;
+  cnt += __shfl_xor(cnt, 32);
+  isbad |= __shfl_xor(isbad, 32);
+  if (g == 0 && j < k.n_q) {
+    if (kge != ~0ull) atomicMin(&key_ge[j], kge);
+    if (klt != ~0ull) atomicMin(&key_lt[j], klt);
+    if (cnt) atomicAdd(&n_lt[j], cnt);
+    if (isbad) atomicOr(&bad[j], 1);
+  }
+}
+
+// Decision + order-preserving compaction into the tentative list.  grid = 1, block = 1024.
+__global__ __launch_bounds__(1024) void match_emit_kernel(MatchConst k, const QueryMid *__restrict__ mid,
+                                                          const unsigned long long *__restrict__ key_ge,
+                                                          const unsigned long long *__restrict__ key_lt, const int *__restrict__ n_lt,
+                                                          const int *__restrict__ bad, const double2 *__restrict__ qxy,
+                                                          const double2 *__restrict__ txy, mods_tentative *__restrict__ out,
+                                                          double *__restrict__ u6, int *__restrict__ out_count, int max_out) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const int K = min(k.nn, k.n_t);
+  for (int base = 0; base < k.n_q; base += 1024) {
+    const int j = base + tid;
+    bool emit = false;
+    mods_tentative tc;
+    if (j < k.n_q) {
+      const unsigned long long kg = key_ge[j];
+      const int c = n_lt[j];
+      if (!bad[j] && kg != ~0ull && c + 1 <= K - 1) {
+        const QueryMid m = mid[j];
+        const unsigned long long k2 = c > 0 ? key_lt[j] : kg;
+        const int d2 = (int)(kg >> 32);
+        tc.q = j; tc.t = m.i0; tc.t_bad = (int)(unsigned int)kg; tc.t_2nd = (int)(unsigned int)k2;
+        tc.d1 = (float)m.d0; tc.d2 = (float)d2; tc.d2nd = (float)(int)(k2 >> 32); tc.pad = 0;
+        tc.ratio = sqrt((double)((float)m.d0 / (float)d2));
+        emit = true;
+      }
+    }
+    const unsigned long long mm = __ballot(emit);
+    if (lane == 0) s_wave[wv] = __popcll(mm);
+    __syncthreads();
+    int off = s_base;
+    for (int q = 0; q < wv; q++) off += s_wave[q];
+    if (emit) {
+      const int slot = off + __popcll(mm & ((1ull << lane) - 1ull));
+      if (slot < max_out) {
+        out[slot] = tc;
+        // correspondence in the layout LORANSACFiltering hands to degensac (matching.cpp:691-713)
+        const double2 a = qxy[tc.q], bpt = txy[tc.t];
+        double *u = u6 + (size_t)slot * 6;
+        u[0] = a.x; u[1] = a.y; u[2] = 1.; u[3] = bpt.x; u[4] = bpt.y; u[5] = 1.;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int q = 0; q < 16; q++) t += s_wave[q]; s_base += t; }
+    __syncthreads();
+  }
+  if (tid == 0) *out_count = s_base;
+}
+
+// ---------------------------------------------------------------------------------------
+static size_t match_pad(const mods_ctx *ctx) { return ((size_t)ctx->max_cand + 127) & ~(size_t)63; }   // list stride, tile tail included
+
+int match_ensure_buffers(mods_ctx *ctx) {
+  if (ctx->m_desc) return MODS_OK;
+  const size_t n = match_pad(ctx);
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_desc, 2 * n * 128));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_c, 2 * n * sizeof(int)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_u6, n * 6 * sizeof(double)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_regs, 2 * (size_t)ctx->max_cand * sizeof(mods_region)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_xy, 2 * n * sizeof(double2)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_u64, 3 * n * sizeof(unsigned long long)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_int, 2 * n * sizeof(int)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_mid, n * sizeof(QueryMid)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, n * sizeof(mods_tentative)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_count, sizeof(int)));
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_desc, 0, 2 * n * 128, ctx->stream));
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_c, 0, 2 * n * sizeof(int), ctx->stream));
+  return MODS_OK;
+}
+
+// queries / trains: device region lists with host-known sizes n_q, n_t.
+int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double ratio,
+              double contradDist, int nn) {
+  int rc = match_ensure_buffers(ctx);
+  if (rc) return rc;
+  if (n_q > ctx->max_cand || n_t > ctx->max_cand) { set_error("match: list larger than the context capacity"); return MODS_E_CAPACITY; }
+  MatchConst k;
+  k.n_q = n_q; k.n_t = n_t; k.nn = nn;
+  k.sqminratio = ratio * ratio;
+  k.contr_sq = contradDist * contradDist;
+  if (!(k.sqminratio < 1.0)) { set_error("FGINN ratio >= 1 (all-neighbours mode) is not supported"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_count, 0, sizeof(int), ctx->stream));
+  if (n_q == 0 || n_t == 0) return MODS_OK;
+  const size_t n = match_pad(ctx);
+  int8_t *qd = ctx->m_desc, *td = ctx->m_desc + n * 128;
+  int *qc = ctx->m_c, *tc = ctx->m_c + n;
+  double2 *qxy = (double2 *)ctx->m_xy, *txy = (double2 *)ctx->m_xy + n;
+  unsigned long long *best = ctx->m_u64, *key_ge = ctx->m_u64 + n, *key_lt = ctx->m_u64 + 2 * n;
+  int *n_lt = ctx->m_int, *bad = ctx->m_int + n;
+  StageScope ts(ctx, MODS_STAGE_MATCH);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qxy, ctx->max_cand);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, txy, ctx->max_cand);
+  MODS_HIP_CHECK(hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * n_q, ctx->stream));
+  const int n_tiles = (n_t + 31) / 32;
+  const int qblocks = (n_q + 127) / 128;
+  int splits = std::max(1, std::min(n_tiles, 2048 / std::max(1, qblocks)));
+  k.tiles_per_split = (n_tiles + splits - 1) / splits;
+  splits = (n_tiles + k.tiles_per_split - 1) / k.tiles_per_split;
+  hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, best);
+  hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best, txy, (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
+  hipLaunchKernelGGL(match_fginn_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, txy, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(1), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, ctx->m_tent, ctx->m_u6, ctx->m_count, ctx->max_cand);
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
+}  // namespace mods

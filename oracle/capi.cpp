@@ -225,4 +225,36 @@ int orc_detect_describe(const float *img, int w, int h, const orc_hessaff_params
   return from_regions(o, out, max_out);
 }
 
+// ---- matching -----------------------------------------------------------------------------------
+struct orc_tentative { int q, t, t_bad, t_2nd; float d1, d2, d2nd, pad; double ratio; };   // mirrors mods_tentative
+
+int orc_match_fginn(const orc_region *q, int nq, const orc_region *t, int nt, double ratio, double contradDist, int nn,
+                    orc_tentative *out, int max_out) {
+  std::vector<Region> a, b; to_regions(q, nq, a); to_regions(t, nt, b);
+  std::vector<Tentative> tc;
+  match_fginn(a, b, tc, ratio, contradDist, nn);
+  for (size_t i = 0; i < tc.size() && (int)i < max_out; i++) {
+    orc_tentative &o = out[i];
+    o.q = tc[i].q; o.t = tc[i].t; o.t_bad = tc[i].t_bad; o.t_2nd = tc[i].t_2nd; o.d1 = tc[i].d1; o.d2 = tc[i].d2;
+    o.d2nd = tc[i].d2nd; o.pad = 0; o.ratio = tc[i].ratio;
+  }
+  return (int)tc.size();
+}
+int orc_duplicate_filter(orc_tentative *tcs, int n, const orc_region *q, int nq, const orc_region *t, int nt, double r,
+                         int mode) {
+  std::vector<Region> a, b; to_regions(q, nq, a); to_regions(t, nt, b);
+  std::vector<Tentative> tc(n);
+  for (int i = 0; i < n; i++) {
+    tc[i].q = tcs[i].q; tc[i].t = tcs[i].t; tc[i].t_bad = tcs[i].t_bad; tc[i].t_2nd = tcs[i].t_2nd; tc[i].d1 = tcs[i].d1;
+    tc[i].d2 = tcs[i].d2; tc[i].d2nd = tcs[i].d2nd; tc[i].ratio = tcs[i].ratio;
+  }
+  duplicate_filter(tc, a, b, r, mode);
+  for (size_t i = 0; i < tc.size(); i++) {
+    orc_tentative &o = tcs[i];
+    o.q = tc[i].q; o.t = tc[i].t; o.t_bad = tc[i].t_bad; o.t_2nd = tc[i].t_2nd; o.d1 = tc[i].d1; o.d2 = tc[i].d2;
+    o.d2nd = tc[i].d2nd; o.pad = 0; o.ratio = tc[i].ratio;
+  }
+  return (int)tc.size();
+}
+
 }  // extern "C"

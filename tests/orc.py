@@ -253,3 +253,24 @@ def detect_describe(img, params=None, max_out=1 << 18):
                                   ORI_MAXANG, C.c_double(ORI_TH), C.c_double(DESC_MRSIZE), DESC_PATCH, 1,
                                   out.ctypes.data_as(C.c_void_p), max_out, C.byref(ndet))
     return out[:n].copy(), ndet.value
+
+
+# ---- matching ------------------------------------------------------------------------------------
+TENT_DTYPE = np.dtype([("q", "i4"), ("t", "i4"), ("t_bad", "i4"), ("t_2nd", "i4"), ("d1", "f4"), ("d2", "f4"),
+                       ("d2nd", "f4"), ("pad", "f4"), ("ratio", "f8")])
+
+
+def match_fginn(q, t, ratio=0.8, contrad=10.0, nn=50):
+    q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+    out = np.zeros(len(q) + 1, TENT_DTYPE)
+    n = lib().orc_match_fginn(q.ctypes.data_as(C.c_void_p), len(q), t.ctypes.data_as(C.c_void_p), len(t),
+                              C.c_double(ratio), C.c_double(contrad), nn, out.ctypes.data_as(C.c_void_p), len(out))
+    return out[:n].copy()
+
+
+def duplicate_filter(tc, q, t, r=2.0, mode=1):
+    q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+    tc = np.ascontiguousarray(tc).copy()
+    n = lib().orc_duplicate_filter(tc.ctypes.data_as(C.c_void_p), len(tc), q.ctypes.data_as(C.c_void_p), len(q),
+                                   t.ctypes.data_as(C.c_void_p), len(t), C.c_double(r), mode)
+    return tc[:n].copy()

@@ -1,0 +1,87 @@
+"""-m gpu parity tests: MFMA brute-force FGINN matcher vs the CPU oracle (exact)."""
+import numpy as np
+import pytest
+
+import orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+TF = ("q", "t", "t_bad", "t_2nd", "d1", "d2", "d2nd", "ratio")
+
+
+def _rand_regions(n, seed, w=800, h=600, clusters=0):
+    rng = np.random.default_rng(seed)
+    r = np.zeros(n, orc.REGION_DTYPE)
+    r["x"] = rng.uniform(1, w - 1, n).astype(np.float32)
+    r["y"] = rng.uniform(1, h - 1, n).astype(np.float32)
+    if clusters:
+        # many near-duplicates within contradDist of each other (same place, similar descriptors)
+        c = rng.integers(0, clusters, n)
+        cx = rng.uniform(20, w - 20, clusters); cy = rng.uniform(20, h - 20, clusters)
+        r["x"] = (cx[c] + rng.uniform(-3, 3, n)).astype(np.float32)
+        r["y"] = (cy[c] + rng.uniform(-3, 3, n)).astype(np.float32)
+    r["s"] = 2.0; r["a11"] = 1.0; r["a22"] = 1.0
+    v = rng.gamma(0.6, 40.0, (n, 128))
+    if clusters:
+        base = rng.gamma(0.6, 40.0, (clusters, 128))
+        v = base[c] + rng.normal(0, 6.0, (n, 128))
+    r["desc"] = np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    return r
+
+
+def _assert_tents_equal(got, want):
+    assert len(got) == len(want)
+    for f in TF:
+        assert np.array_equal(got[f], want[f]), f
+
+
+@pytest.mark.parametrize("nq,nt,seed", [(1, 1, 1), (1, 2, 2), (5, 3, 3), (33, 31, 4), (300, 257, 5), (1000, 1500, 6)])
+def test_match_random(gpu_ctx, nq, nt, seed):
+    q, t = _rand_regions(nq, seed), _rand_regions(nt, seed + 100)
+    t["desc"][: min(nq, nt) // 2] = q["desc"][: min(nq, nt) // 2]      # exact matches: d0 = 0
+    t["desc"][-1] = t["desc"][0]                                       # exact ties between trains
+    for ratio in (0.8, 0.95):
+        got, u6 = gpu_ctx.match_fginn(q, t, ratio)
+        want = orc.match_fginn(q, t, ratio)
+        _assert_tents_equal(got, want)
+        assert np.array_equal(u6[:, 0], q["x"][got["q"]]) and np.array_equal(u6[:, 4], t["y"][got["t"]])
+        assert np.all(u6[:, 2] == 1) and np.all(u6[:, 5] == 1)
+
+
+def test_match_clusters_rank_cap(gpu_ctx):
+    """Near-duplicate clusters: more than nn consistent neighbours below the ratio threshold."""
+    q = _rand_regions(400, 11, clusters=4)
+    t = _rand_regions(600, 12, clusters=4)
+    for nn in (50, 8, 3):
+        got, _ = gpu_ctx.match_fginn(q, t, 0.97, 10.0, nn)
+        want = orc.match_fginn(q, t, 0.97, 10.0, nn)
+        _assert_tents_equal(got, want)
+
+
+def test_match_empty(gpu_ctx):
+    q, t = _rand_regions(10, 1), _rand_regions(0, 2)
+    assert len(gpu_ctx.match_fginn(q, t)[0]) == 0
+    assert len(gpu_ctx.match_fginn(t, q)[0]) == 0
+
+
+def test_match_pair_and_dupfilter(gpu_ctx, pkg):
+    import torch
+    a, b, H = synth.pair(1280, 960, seed=5)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    ctx2 = pkg.Context(0, 1280, 960, 2)
+    nd, nr = ctx2.detect_describe_dev(t.data_ptr(), 2, 1280, 960)
+    ra, rb = ctx2.regions_fetch(0), ctx2.regions_fetch(1)
+    got, u6 = ctx2.match_dev(0, 1)
+    want = orc.match_fginn(ra, rb)
+    assert len(want) > 100
+    _assert_tents_equal(got, want)
+    fw = orc.duplicate_filter(want, ra, rb, 2.0, 1)
+    fg, fu = pkg.duplicate_filter(got, u6, 2.0, 1)
+    _assert_tents_equal(fg, fw)
+    assert np.array_equal(fu[:, 0], ra["x"][fg["q"]]) and np.array_equal(fu[:, 3], rb["x"][fg["t"]])
+    # most tentatives agree with the generating homography
+    p = np.c_[fu[:, 0], fu[:, 1], np.ones(len(fu))] @ H.T
+    err = np.hypot(p[:, 0] / p[:, 2] - fu[:, 3], p[:, 1] / p[:, 2] - fu[:, 4])
+    assert (err < 3).mean() > 0.5
+    ctx2.close()
