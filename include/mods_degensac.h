@@ -1,0 +1,46 @@
+/*
+ * mods_degensac.h — the degensac C ABI exported by libmodsgpu.so with the reference's exact
+ * signatures, so that the reference's own matching/matching.cpp links against it unchanged.
+ *
+ * Replaces (reference root relative):
+ *   degensac/exp_ranH.h:32-36   Score exp_ransacHcustom(...)
+ *   degensac/Htools.h           HDs, HDsSym, HDsSymMax, HDsi, HDsiSym, HDsiSymMax, HDsidx, HDsSymidx, HDsSymidxMax
+ *   degensac/rtools.h:14-21     struct Score
+ * Behaviour: same sampling sequence (bit-exact glibc srand/rand/random), same decisions; every
+ * hypothesis is scored over all correspondences on the GPU.  th is in squared pixels
+ * (matching.cpp:731).  *resids is malloc'ed here and freed by the caller (matching.cpp:732).
+ * Unlike the reference (global HASH_TABLE, libc generator state) the entry points are re-entrant.
+ */
+#ifndef MODS_DEGENSAC_H
+#define MODS_DEGENSAC_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  unsigned I;   /* number of inliers */
+  double J;     /* MSAC score */
+} Score;
+
+typedef void (*HDsPtr)(const double *, const double *, const double *, double *, int);
+typedef void (*HDsiPtr)(const double *, const double *, const double *, double *, int, int *, int);
+typedef void (*HDsidxPtr)(const double *, const double *, const double *, double *, int, int *, int);
+
+Score exp_ransacHcustom(double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
+                        int iter_type, int *data_out, int oriented_constraint, unsigned inlLimit, double **resids,
+                        HDsPtr HDS1, HDsiPtr HDSi1, HDsidxPtr HDSidx1, int doSymCheck);
+
+void HDs(const double *lin, const double *u, const double *H, double *p, int len);
+void HDsSym(const double *lin, const double *u, const double *H, double *p, int len);
+void HDsSymMax(const double *lin, const double *u, const double *H, double *p, int len);
+void HDsi(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni);
+void HDsiSym(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni);
+void HDsiSymMax(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni);
+void HDsidx(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz);
+void HDsSymidx(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz);
+void HDsSymidxMax(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -168,18 +168,50 @@ int mods_sift_patch(mods_ctx *ctx, const float *patch, int ps, int rootsift, dou
  * exact brute-force squared-L2 search (ties: lower train index first), FGINN walk over nn neighbours.
  * ratio = par.currMatchRatio (FGINNThreshold of the iters .ini), contradDist = [Matching] contradDist.
  * Tentatives come out in query order.  u6_out (optional, 6 doubles per tentative) receives the
- * correspondences as LORANSACFiltering lays them out for degensac: x1 y1 1 x2 y2 1. */
+ * correspondences as LORANSACFiltering lays them out for degensac: x1 y1 1 x2 y2 1; laf_out (optional,
+ * 14 doubles per tentative) the two local affine frames x y a11 a12 a21 a22 s used by the LAF checks. */
 int mods_match_fginn(mods_ctx *ctx, const mods_region *q, int n_q, const mods_region *t, int n_t, double ratio,
-                     double contradDist, int nn, mods_tentative *out, double *u6_out, int max_out, int *n_out);
+                     double contradDist, int nn, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out);
 /* same, on the HBM-resident region lists of images img_q / img_t left by mods_detect_describe_dev */
 int mods_match_dev(mods_ctx *ctx, int img_q, int img_t, double ratio, double contradDist, int nn, mods_tentative *out,
-                   double *u6_out, int max_out, int *n_out);
+                   double *u6_out, double *laf_out, int max_out, int *n_out);
 
 /* Replaces  void DuplicateFiltering(TentativeCorrespListExt &in, const double r, const int mode)
  * (matching.cpp:2615-2679).  Host-side, in place on (tent, u6); mode 0 = keep order (MODE_RANDOM),
  * 1 = best FGINN ratio first, 2 = best distance first (configuration.hpp:31-34); equal keys keep
  * list order.  Sequential greedy by definition; it is control logic, not a kernel. */
-int mods_duplicate_filter(mods_tentative *tent, double *u6, int n, double r, int mode, int *n_out);
+int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, double r, int mode, int *n_out);
+
+/* ---- B1: verification ---------------------------------------------------------------------------
+ * The degensac C ABI itself is exported with the reference's exact signatures (degensac/exp_ranH.h:32-36,
+ * degensac/Htools.h): exp_ransacHcustom, HDs, HDsSym, HDsSymMax, HDsi, HDsiSym, HDsiSymMax, HDsidx,
+ * HDsSymidx, HDsSymidxMax - see include/mods_degensac.h.  Hypotheses are scored on the GPU.
+ *
+ * [RANSAC] keys (io_mods.cpp:437-455).  errorType: 0 Sampson, 1 SymmMax, 2 SymmSum. */
+typedef struct mods_ransac_params {
+  double err_threshold;     /* 4.0 px */
+  double confidence;        /* 0.99 */
+  int max_samples;          /* 1000000 */
+  int localOptimization;    /* 1 */
+  double LAFCoef;           /* 2 (F branch) */
+  double HLAFCoef;          /* 12 */
+  int errorType;            /* 0 */
+  int doSymmCheck;          /* 1 */
+} mods_ransac_params;
+
+/* Replaces  int LORANSACFiltering(TentativeCorrespListExt &in, TentativeCorrespListExt &out, double *H,
+ *           const RANSACPars pars)  (matching/matching.hpp:267-269, matching.cpp:637-805) for useF = 0.
+ * u6: n x 6 correspondences, laf: n x 14 frames (may be NULL: LAF check skipped).  mask[i] = 1 for the
+ * correspondences kept after RANSAC + NaiveHCheck + H_LAF_check; H_out row-major img1 -> img2
+ * (all -1 when no model).  stats3 (optional) = {samples drawn, LO runs, orientation rejects}. */
+int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask,
+                    double *H_out, int *n_inliers, int *stats3);
+/* GPU used by the degensac entry points of the calling thread (default 0). */
+int mods_ransac_set_device(int device);
+/* The reference seeds with srand(time(NULL)) (exp_ranH.c:823).  seed >= 0 makes every call behave as if
+ * time(NULL) returned `seed`; seed < 0 restores the wall clock.  MODS_RANSAC_SEED in the environment
+ * has the same effect when no seed is pinned. */
+void mods_ransac_pin_seed(long seed);
 
 #ifdef __cplusplus
 }

@@ -240,18 +240,23 @@ class Context:
         cap = max(len(q), 1)
         out = np.zeros(cap, TENT_DTYPE)
         u6 = np.zeros((cap, 6), np.float64)
+        laf = np.zeros((cap, 14), np.float64)
         n = C.c_int()
         _check(lib().mods_match_fginn(self.h, q.ctypes.data_as(C.c_void_p), len(q), t.ctypes.data_as(C.c_void_p), len(t),
                                       C.c_double(ratio), C.c_double(contrad), nn, out.ctypes.data_as(C.c_void_p),
-                                      u6.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+                                      u6.ctypes.data_as(C.c_void_p), laf.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        self.last_laf = laf[:n.value].copy()
         return out[:n.value].copy(), u6[:n.value].copy()
 
     def match_dev(self, img_q, img_t, ratio=0.8, contrad=10.0, nn=50, cap=1 << 18):
         out = np.zeros(cap, TENT_DTYPE)
         u6 = np.zeros((cap, 6), np.float64)
+        laf = np.zeros((cap, 14), np.float64)
         n = C.c_int()
         _check(lib().mods_match_dev(self.h, img_q, img_t, C.c_double(ratio), C.c_double(contrad), nn,
-                                    out.ctypes.data_as(C.c_void_p), u6.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+                                    out.ctypes.data_as(C.c_void_p), u6.ctypes.data_as(C.c_void_p),
+                                    laf.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        self.last_laf = laf[:n.value].copy()
         return out[:n.value].copy(), u6[:n.value].copy()
 
 
@@ -259,11 +264,76 @@ TENT_DTYPE = np.dtype([("q", "i4"), ("t", "i4"), ("t_bad", "i4"), ("t_2nd", "i4"
                        ("d2nd", "f4"), ("pad", "f4"), ("ratio", "f8")])
 
 
-def duplicate_filter(tent, u6, r=2.0, mode=1):
-    """Host-side DuplicateFiltering (matching.cpp:2615-2679) on (tentatives, correspondences)."""
+def duplicate_filter(tent, u6, r=2.0, mode=1, laf=None):
+    """Host-side DuplicateFiltering (matching.cpp:2615-2679) on (tentatives, correspondences[, frames])."""
     tent = np.ascontiguousarray(tent).copy()
     u6 = np.ascontiguousarray(u6, np.float64).copy()
+    lf = np.ascontiguousarray(laf, np.float64).copy() if laf is not None else None
     n = C.c_int()
-    _check(lib().mods_duplicate_filter(tent.ctypes.data_as(C.c_void_p), u6.ctypes.data_as(C.c_void_p), len(tent),
+    _check(lib().mods_duplicate_filter(tent.ctypes.data_as(C.c_void_p), u6.ctypes.data_as(C.c_void_p),
+                                       lf.ctypes.data_as(C.c_void_p) if lf is not None else None, len(tent),
                                        C.c_double(r), mode, C.byref(n)))
+    if lf is not None:
+        return tent[:n.value].copy(), u6[:n.value].copy(), lf[:n.value].copy()
     return tent[:n.value].copy(), u6[:n.value].copy()
+
+
+# ---- verification (degensac C ABI + LORANSACFiltering) ---------------------------------------------
+class Score(C.Structure):
+    _fields_ = [("I", C.c_uint), ("J", C.c_double)]
+
+
+class RansacParams(C.Structure):
+    """[RANSAC] section (io_mods.cpp:437-455).  errorType 0 Sampson, 1 SymmMax, 2 SymmSum."""
+    _fields_ = [("err_threshold", C.c_double), ("confidence", C.c_double), ("max_samples", C.c_int),
+                ("localOptimization", C.c_int), ("LAFCoef", C.c_double), ("HLAFCoef", C.c_double),
+                ("errorType", C.c_int), ("doSymmCheck", C.c_int)]
+
+    @staticmethod
+    def default():
+        return RansacParams(4.0, 0.99, 1000000, 1, 2.0, 12.0, 0, 1)   # config_affori_classic.ini
+
+
+_ERR = {"sampson": ("HDs", "HDsi", "HDsidx"), "symm_max": ("HDsSymMax", "HDsiSymMax", "HDsSymidxMax"),
+        "symm_sum": ("HDsSym", "HDsiSym", "HDsSymidx")}
+
+
+def ransac_pin_seed(seed):
+    lib().mods_ransac_pin_seed.argtypes = [C.c_long]
+    lib().mods_ransac_pin_seed(seed)
+
+
+def ransac_h(u6, th_sq, conf=0.99, max_sam=1000000, err="sampson", sym_check=1, seed_time=12345):
+    """exp_ransacHcustom exactly as LORANSACFiltering calls it (matching.cpp:731)."""
+    L = lib()
+    L.exp_ransacHcustom.restype = Score
+    ransac_pin_seed(seed_time)
+    u = np.ascontiguousarray(u6, np.float64).copy()
+    n = len(u)
+    H = np.zeros(9, np.float64)
+    inl = np.zeros(max(n, 1), np.uint8)
+    data_out = np.zeros(max(18 * n, 8), np.int32)
+    resids = C.POINTER(C.c_double)()
+    f = [C.cast(getattr(L, name), C.c_void_p) for name in _ERR[err]]
+    S = L.exp_ransacHcustom(u.ctypes.data_as(C.c_void_p), n, C.c_double(th_sq), C.c_double(conf), max_sam,
+                            H.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p), 4,
+                            data_out.ctypes.data_as(C.c_void_p), 1, C.c_uint(0), C.byref(resids), f[0], f[1], f[2],
+                            sym_check)
+    C.CDLL(None).free(resids)
+    return dict(I=S.I, J=S.J, H=H, inl=inl[:n], samples=int(data_out[0]), lo=int(data_out[1]), rej=int(data_out[2]))
+
+
+def loransac_h(u6, laf, params=None, seed_time=12345):
+    params = params or RansacParams.default()
+    ransac_pin_seed(seed_time)
+    u = np.ascontiguousarray(u6, np.float64)
+    n = len(u)
+    lf = np.ascontiguousarray(laf, np.float64) if laf is not None else None
+    mask = np.zeros(max(n, 1), np.uint8)
+    H = np.zeros(9, np.float64)
+    ninl = C.c_int()
+    stats = (C.c_int * 3)()
+    _check(lib().mods_loransac_h(u.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p) if lf is not None else None,
+                                 n, C.byref(params), mask.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
+                                 C.byref(ninl), stats))
+    return mask[:n].astype(bool), H.reshape(3, 3), ninl.value, list(stats)

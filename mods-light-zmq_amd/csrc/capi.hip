@@ -311,7 +311,7 @@ int mods_sift_patch(mods_ctx *c, const float *patch, int ps, int rootsift, doubl
 }
 
 // ---- matching ----------------------------------------------------------------------------------
-static int match_fetch(mods_ctx *c, mods_tentative *out, double *u6_out, int max_out, int *n_out) {
+static int match_fetch(mods_ctx *c, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out) {
   int n = 0;
   MODS_HIP_CHECK(hipMemcpyAsync(&n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -319,11 +319,12 @@ static int match_fetch(mods_ctx *c, mods_tentative *out, double *u6_out, int max
   if (n > max_out) { set_error("tentative output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
   if (n > 0 && out) MODS_HIP_CHECK(hipMemcpy(out, c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost));
   if (n > 0 && u6_out) MODS_HIP_CHECK(hipMemcpy(u6_out, c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost));
+  if (n > 0 && laf_out) MODS_HIP_CHECK(hipMemcpy(laf_out, c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost));
   return MODS_OK;
 }
 
 int mods_match_fginn(mods_ctx *c, const mods_region *q, int n_q, const mods_region *t, int n_t, double ratio,
-                     double contradDist, int nn, mods_tentative *out, double *u6_out, int max_out, int *n_out) {
+                     double contradDist, int nn, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out) {
   if (!c || !n_out || (n_q > 0 && !q) || (n_t > 0 && !t)) { set_error("match: null argument"); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   int rc = match_ensure_buffers(c);
@@ -332,11 +333,11 @@ int mods_match_fginn(mods_ctx *c, const mods_region *q, int n_q, const mods_regi
   MODS_HIP_CHECK(hipMemcpyAsync(c->m_regs, q, sizeof(mods_region) * n_q, hipMemcpyHostToDevice, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(c->m_regs + c->max_cand, t, sizeof(mods_region) * n_t, hipMemcpyHostToDevice, c->stream));
   if ((rc = match_run(c, c->m_regs, n_q, c->m_regs + c->max_cand, n_t, ratio, contradDist, nn))) return rc;
-  return match_fetch(c, out, u6_out, max_out, n_out);
+  return match_fetch(c, out, u6_out, laf_out, max_out, n_out);
 }
 
 int mods_match_dev(mods_ctx *c, int img_q, int img_t, double ratio, double contradDist, int nn, mods_tentative *out,
-                   double *u6_out, int max_out, int *n_out) {
+                   double *u6_out, double *laf_out, int max_out, int *n_out) {
   if (!c || !n_out) { set_error("match: null argument"); return MODS_E_ARG; }
   const int nb = (int)c->last_region_counts.size();
   if (img_q < 0 || img_q >= nb || img_t < 0 || img_t >= nb) { set_error("match: image index outside the last described batch"); return MODS_E_ARG; }
@@ -344,14 +345,14 @@ int mods_match_dev(mods_ctx *c, int img_q, int img_t, double ratio, double contr
   int rc = match_run(c, c->regions_dev + (size_t)img_q * c->max_cand, c->last_region_counts[img_q],
                      c->regions_dev + (size_t)img_t * c->max_cand, c->last_region_counts[img_t], ratio, contradDist, nn);
   if (rc) return rc;
-  return match_fetch(c, out, u6_out, max_out, n_out);
+  return match_fetch(c, out, u6_out, laf_out, max_out, n_out);
 }
 
 // DuplicateFiltering, matching.cpp:2615-2679: optional stable sort, then the first correspondence
 // (in list order) of every group whose two endpoints lie within r of each other survives.  A uniform
 // grid over the first-image points (cell = r) bounds the candidates to the 3x3 neighbourhood; the
 // accept/reject sequence is the reference's.
-int mods_duplicate_filter(mods_tentative *tent, double *u6, int n, double r, int mode, int *n_out) {
+int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, double r, int mode, int *n_out) {
   if (!n_out || (n > 0 && (!tent || !u6))) { set_error("duplicate_filter: null argument"); return MODS_E_ARG; }
   *n_out = n;
   if (r <= 0 || n <= 0) return MODS_OK;
@@ -360,8 +361,12 @@ int mods_duplicate_filter(mods_tentative *tent, double *u6, int n, double r, int
   if (mode == 1) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(tent[a].ratio) < std::fabs(tent[b].ratio); });
   else if (mode == 2) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs((double)tent[a].d1) < std::fabs((double)tent[b].d1); });
   std::vector<mods_tentative> ts(n);
-  std::vector<double> us((size_t)n * 6);
-  for (int i = 0; i < n; i++) { ts[i] = tent[order[i]]; memcpy(&us[(size_t)i * 6], &u6[(size_t)order[i] * 6], 6 * sizeof(double)); }
+  std::vector<double> us((size_t)n * 6), ls(laf ? (size_t)n * 14 : 0);
+  for (int i = 0; i < n; i++) {
+    ts[i] = tent[order[i]];
+    memcpy(&us[(size_t)i * 6], &u6[(size_t)order[i] * 6], 6 * sizeof(double));
+    if (laf) memcpy(&ls[(size_t)i * 14], &laf[(size_t)order[i] * 14], 14 * sizeof(double));
+  }
   const double r_sq = r * r;
   // hash grid of the kept correspondences, keyed by the first-image cell
   struct Cell { long long key; int idx; };
@@ -387,8 +392,134 @@ int mods_duplicate_filter(mods_tentative *tent, double *u6, int n, double r, int
     if (!dup) { keep[j] = 1; buckets[hash(cx, cy)].push_back(j); }
   }
   for (int j = 0; j < n; j++)
-    if (keep[j]) { tent[m] = ts[j]; memcpy(&u6[(size_t)m * 6], &us[(size_t)j * 6], 6 * sizeof(double)); m++; }
+    if (keep[j]) {
+      tent[m] = ts[j];
+      memcpy(&u6[(size_t)m * 6], &us[(size_t)j * 6], 6 * sizeof(double));
+      if (laf) memcpy(&laf[(size_t)m * 14], &ls[(size_t)j * 14], 14 * sizeof(double));
+      m++;
+    }
   *n_out = m;
+  return MODS_OK;
+}
+
+// ---- verification ----------------------------------------------------------------------------------
+extern "C" {
+typedef struct { unsigned I; double J; } mods_score;
+mods_score exp_ransacHcustom(double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl, int iter_type,
+                             int *data_out, int oriented_constraint, unsigned inlLimit, double **resids,
+                             void (*HDS1)(const double *, const double *, const double *, double *, int),
+                             void (*HDSi1)(const double *, const double *, const double *, double *, int, int *, int),
+                             void (*HDSidx1)(const double *, const double *, const double *, double *, int, int *, int), int doSymCheck);
+void HDs(const double *, const double *, const double *, double *, int);
+void HDsSym(const double *, const double *, const double *, double *, int);
+void HDsSymMax(const double *, const double *, const double *, double *, int);
+void HDsi(const double *, const double *, const double *, double *, int, int *, int);
+void HDsiSym(const double *, const double *, const double *, double *, int, int *, int);
+void HDsiSymMax(const double *, const double *, const double *, double *, int, int *, int);
+void HDsidx(const double *, const double *, const double *, double *, int, int *, int);
+void HDsSymidx(const double *, const double *, const double *, double *, int, int *, int);
+void HDsSymidxMax(const double *, const double *, const double *, double *, int, int *, int);
+}
+
+// cv::invert(3x3, DECOMP_LU) as OpenCV evaluates small matrices: determinant and cofactors in
+// double (OpenCV is not in the image: closed form assumed; result 0 when the determinant is 0).
+static bool invert3(const double *S, double *t) {
+  double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+  if (d == 0) { for (int i = 0; i < 9; i++) t[i] = 0; return false; }
+  d = 1. / d;
+  t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+  t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+  t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+  t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+  t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+  t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+  t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+  t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+  t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+  return true;
+}
+
+// LORANSACFiltering for the homography branch (useF = 0), matching.cpp:637-805: degensac LO-RANSAC,
+// H -> row-major img1->img2 by inv(H^T), NaiveHCheck (10 px, :1014-1043), H_LAF_check (:250-308).
+// mask[i] = 1 for the correspondences that survive every check.
+int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask, double *H_out,
+                    int *n_inliers, int *stats3) {
+  if (!par || !mask || !H_out || !n_inliers || (n > 0 && !u6)) { set_error("loransac_h: null argument"); return MODS_E_ARG; }
+  *n_inliers = 0;
+  for (int i = 0; i < 9; i++) H_out[i] = -1;   // TentativeCorrespListExt(): H[i] = -1 (matching.hpp:92-99)
+  for (int i = 0; i < n; i++) mask[i] = 0;
+  if (stats3) { stats3[0] = stats3[1] = stats3[2] = 0; }
+  const int MIN_POINTS = 8;
+  if (n < MIN_POINTS) return MODS_OK;
+  int max_samples = par->max_samples;
+  if (n <= 20) max_samples = 1000;
+  std::vector<double> u2(u6, u6 + (size_t)n * 6);
+  std::vector<unsigned char> inl2(n);
+  std::vector<int> data_out((size_t)n * 18);
+  double Hloran[9];
+  double *resids = nullptr;
+  void (*f0)(const double *, const double *, const double *, double *, int);
+  void (*f1)(const double *, const double *, const double *, double *, int, int *, int);
+  void (*f2)(const double *, const double *, const double *, double *, int, int *, int);
+  if (par->errorType == 0) { f0 = &HDs; f1 = &HDsi; f2 = &HDsidx; }
+  else if (par->errorType == 1) { f0 = &HDsSymMax; f1 = &HDsiSymMax; f2 = &HDsSymidxMax; }
+  else { f0 = &HDsSym; f1 = &HDsiSym; f2 = &HDsSymidx; }
+  exp_ransacHcustom(u2.data(), n, par->err_threshold * par->err_threshold, par->confidence, max_samples, Hloran, inl2.data(), 4,
+                    data_out.data(), 1, 0, &resids, f0, f1, f2, par->doSymmCheck);
+  free(resids);
+  if (stats3) { stats3[0] = data_out[0]; stats3[1] = data_out[1]; stats3[2] = data_out[2]; }
+  // H: inv(Hloran^T); reading the column-major h as a row-major matrix is H^T, its transpose is h read column-wise
+  const double Ht[9] = {Hloran[0], Hloran[3], Hloran[6], Hloran[1], Hloran[4], Hloran[7], Hloran[2], Hloran[5], Hloran[8]};
+  double Hinv[9];
+  invert3(Ht, Hinv);
+  bool nonzero = false;
+  for (int i = 0; i < 9; i++) nonzero = nonzero || (Hinv[i] != 0.0);
+  if (!nonzero) return MODS_OK;
+  for (int i = 0; i < 9; i++) H_out[i] = Hinv[i];
+  std::vector<int> cur;
+  for (int i = 0; i < n; i++) if (inl2[i]) cur.push_back(i);
+  // NaiveHCheck over the RANSAC inliers
+  {
+    const double err_sq = 10.0 * 10.0;
+    double Hi[9];
+    invert3(Hinv, Hi);
+    int ok = 0;
+    for (int i : cur) {
+      const double *p = u6 + (size_t)i * 6;
+      const double *Hm = Hinv;
+      double xa = (Hm[0] * p[0] + Hm[1] * p[1] + Hm[2]) / (Hm[6] * p[0] + Hm[7] * p[1] + Hm[8]);
+      double ya = (Hm[3] * p[0] + Hm[4] * p[1] + Hm[5]) / (Hm[6] * p[0] + Hm[7] * p[1] + Hm[8]);
+      const double d1 = (p[3] - xa) * (p[3] - xa) + (p[4] - ya) * (p[4] - ya);
+      xa = (Hi[0] * p[3] + Hi[1] * p[4] + Hi[2]) / (Hi[6] * p[3] + Hi[7] * p[4] + Hi[8]);
+      ya = (Hi[3] * p[3] + Hi[4] * p[4] + Hi[5]) / (Hi[6] * p[3] + Hi[7] * p[4] + Hi[8]);
+      const double d2 = (p[0] - xa) * (p[0] - xa) + (p[1] - ya) * (p[1] - ya);
+      if ((d1 <= err_sq) && (d2 <= err_sq)) ok++;
+    }
+    if (ok < MIN_POINTS) cur.clear();
+  }
+  // H_LAF_check with HDsSymMax on the three frame points
+  const double affineFerror = 3.0 * par->HLAFCoef * par->err_threshold;
+  if (affineFerror > 0 && laf) {
+    std::vector<int> good;
+    const double ks = 3.0;   // matching.cpp:171
+    for (int i : cur) {
+      const double *f = laf + (size_t)i * 14;
+      double u[18], err[3];
+      u[0] = f[0]; u[1] = f[1]; u[2] = 1.0;
+      u[3] = f[7]; u[4] = f[8]; u[5] = 1.0;
+      u[6] = u[0] + ks * f[3] * f[6]; u[7] = u[1] + ks * f[5] * f[6]; u[8] = 1.0;
+      u[9] = u[3] + ks * f[10] * f[13]; u[10] = u[4] + ks * f[12] * f[13]; u[11] = 1.0;
+      u[12] = u[0] + ks * f[2] * f[6]; u[13] = u[1] + ks * f[4] * f[6]; u[14] = 1.0;
+      u[15] = u[3] + ks * f[9] * f[13]; u[16] = u[4] + ks * f[11] * f[13]; u[17] = 1.0;
+      HDsSymMax(nullptr, u, Hloran, err, 3);
+      const double sumErr = std::sqrt(err[0] + err[1] + err[2]);
+      if (!(sumErr > affineFerror)) good.push_back(i);
+    }
+    cur.swap(good);
+  }
+  if ((int)cur.size() < MIN_POINTS) cur.clear();
+  for (int i : cur) mask[i] = 1;
+  *n_inliers = (int)cur.size();
   return MODS_OK;
 }
 

@@ -109,6 +109,7 @@ struct mods_ctx {
   void *m_mid = nullptr;
   mods_tentative *m_tent = nullptr;
   double *m_u6 = nullptr;            // [pad][6] correspondences (x1 y1 1 x2 y2 1)
+  double *m_laf = nullptr;           // [pad][14] frames (x y a11 a12 a21 a22 s) of both regions
   int *m_count = nullptr;
   mods_region *m_regs = nullptr;     // [2][max_cand] staging for host-side lists
   // timing

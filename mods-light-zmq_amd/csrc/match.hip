@@ -210,8 +210,10 @@ __global__ __launch_bounds__(1024) void match_emit_kernel(MatchConst k, const Qu
                                                           const unsigned long long *__restrict__ key_ge,
                                                           const unsigned long long *__restrict__ key_lt, const int *__restrict__ n_lt,
                                                           const int *__restrict__ bad, const double2 *__restrict__ qxy,
-                                                          const double2 *__restrict__ txy, mods_tentative *__restrict__ out,
-                                                          double *__restrict__ u6, int *__restrict__ out_count, int max_out) {
+                                                          const double2 *__restrict__ txy, const mods_region *__restrict__ qreg,
+                                                          const mods_region *__restrict__ treg, mods_tentative *__restrict__ out,
+                                                          double *__restrict__ u6, double *__restrict__ laf, int *__restrict__ out_count,
+                                                          int max_out) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -248,6 +250,11 @@ __global__ __launch_bounds__(1024) void match_emit_kernel(MatchConst k, const Qu
         const double2 a = qxy[tc.q], bpt = txy[tc.t];
         double *u = u6 + (size_t)slot * 6;
         u[0] = a.x; u[1] = a.y; u[2] = 1.; u[3] = bpt.x; u[4] = bpt.y; u[5] = 1.;
+        // local affine frames of both regions for the LAF checks (matching.cpp:192-308)
+        double *f = laf + (size_t)slot * 14;
+        const mods_region &r1 = qreg[tc.q], &r2 = treg[tc.t];
+        f[0] = r1.x; f[1] = r1.y; f[2] = r1.a11; f[3] = r1.a12; f[4] = r1.a21; f[5] = r1.a22; f[6] = r1.s;
+        f[7] = r2.x; f[8] = r2.y; f[9] = r2.a11; f[10] = r2.a12; f[11] = r2.a21; f[12] = r2.a22; f[13] = r2.s;
       }
     }
     __syncthreads();
@@ -266,6 +273,7 @@ int match_ensure_buffers(mods_ctx *ctx) {
   MODS_HIP_CHECK(hipMalloc(&ctx->m_desc, 2 * n * 128));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_c, 2 * n * sizeof(int)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_u6, n * 6 * sizeof(double)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_laf, n * 14 * sizeof(double)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_regs, 2 * (size_t)ctx->max_cand * sizeof(mods_region)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_xy, 2 * n * sizeof(double2)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_u64, 3 * n * sizeof(unsigned long long)));
@@ -309,7 +317,7 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, best);
   hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best, txy, (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
   hipLaunchKernelGGL(match_fginn_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, txy, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
-  hipLaunchKernelGGL(match_emit_kernel, dim3(1), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, ctx->m_tent, ctx->m_u6, ctx->m_count, ctx->max_cand);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(1), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, ctx->m_tent, ctx->m_u6, ctx->m_laf, ctx->m_count, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }

@@ -1,0 +1,643 @@
+// LO-RANSAC homography verification: GPU hypothesis scoring + host control loop.
+//
+// Reference behaviour: exp_ransacHcustom, degensac/exp_ranH.c:796-1236 (LO: exp_inHranicustom
+// :741-793, exp_iterHcustom :617-737), called from LORANSACFiltering, matching/matching.cpp:637-823.
+//
+// Structure.  The reference draws one 4-point sample per iteration from a libc generator that
+// is re-seeded every iteration (srand(seed); 4 x random(); seed = rand(), exp_ranH.c:861-863), so
+// the whole sample sequence is a function of the first seed only and never depends on scores.
+// It is therefore generated ahead of time on the host (bit-exact glibc generator), minimal
+// solutions are solved on the host (9x9 Gauss-Jordan, ~1 us each) and a batch of hypotheses is
+// scored over all correspondences on the GPU in one launch pair:
+//   score kernel : thread (correspondence i, hypothesis k): error d, symmetric-check error,
+//                  truncated-quadratic gain; inlier counts by wave ballots + one atomic per wave
+//   gain kernel  : lane k adds the gains of hypothesis k in correspondence order (the MSAC
+//                  score J is a sequential fp64 sum in the reference; same order here)
+// The host then replays the reference's decision sequence over the batch in order (best-so-far,
+// symmetric check, LO trigger, adaptive stopping); hypotheses scored beyond the stopping point
+// are discarded.  Local optimisation (least squares on inliers, iterated re-estimation) stays on
+// the host: it is a chain of data-dependent small solves.
+#include "common.hpp"
+#include "ransac_host.hpp"
+#include <ctime>
+#include <cstdlib>
+#include <mutex>
+
+namespace mods {
+
+using rs::Score;
+
+enum { ERR_SAMPSON = 0, ERR_SYMSUM = 1, ERR_SYMMAX = 2 };
+
+struct HypDev {            // one scored hypothesis
+  double h[9];
+  double Hinv[9], H1[9];   // symmetric-error operands (Hinv = h^T as stored, H1 = minv(Hinv))
+};
+
+__device__ __forceinline__ void pinvJ_dev(double a, double b, double c, double d, double e, double *pJ) {
+  const double a2 = a * a, b2 = b * b, c2 = c * c, d2 = d * d, e2 = e * e;
+  const double c2pd2 = c2 + d2, ab = a * b, de = d * e;
+  const double Q = c * (c2pd2 + e2);
+  pJ[0] = -b * de + a * (c2 + e2);
+  pJ[1] = b * c2pd2 - a * de;
+  pJ[2] = Q;
+  pJ[3] = -c * (a * d + b * e);
+  pJ[4] = d * (b2 + c2) - ab * e;
+  pJ[5] = -ab * d + e * (a2 + c2);
+  pJ[6] = pJ[3];
+  pJ[7] = c * (a2 + b2 + c2);
+  const double N = a * pJ[0] + b * pJ[1] + c * pJ[2];
+#pragma unroll
+  for (int i = 0; i < 8; i++) pJ[i] /= N;
+}
+
+__device__ __forceinline__ double hds_dev(const double *u, const double *H) {   // HDs, Htools.c:160-199
+  const double z0[9] = {u[3], 0, -u[0] * u[3], u[4], 0, -u[0] * u[4], u[5], 0, -u[0] * u[5]};
+  const double z1[9] = {0, u[3], -u[1] * u[3], 0, u[4], -u[1] * u[4], 0, u[5], -u[1] * u[5]};
+  double r1 = 0, r2 = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) { r1 += H[j] * z0[j]; r2 += H[j] * z1[j]; }
+  double a = H[0] - H[2] * u[0];
+  const double b = H[3] - H[5] * u[0];
+  const double c = -H[8] - H[2] * u[3] - H[5] * u[4];
+  const double d = H[1] - H[2] * u[1];
+  const double e = H[4] - H[5] * u[1];
+  double pJ[8];
+  pinvJ_dev(a, b, c, d, e, pJ);
+  double p = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    a = pJ[j] * r1 + pJ[j + 4] * r2;
+    p += a * a;
+  }
+  return p;
+}
+
+__device__ __forceinline__ void hsym_dev(const double *u, const double *Hinv, const double *H1, double *d1, double *d2) {
+  const double a = H1[6] * u[0] + H1[7] * u[1] + H1[8];
+  const double b = Hinv[6] * u[3] + Hinv[7] * u[4] + Hinv[8];
+  double xa = (H1[0] * u[0] + H1[1] * u[1] + H1[2]) / a;
+  double ya = (H1[3] * u[0] + H1[4] * u[1] + H1[5]) / a;
+  double xdiff = u[3] - xa, ydiff = u[4] - ya;
+  *d1 = xdiff * xdiff + ydiff * ydiff;
+  xa = (Hinv[0] * u[3] + Hinv[1] * u[4] + Hinv[2]) / b;
+  ya = (Hinv[3] * u[3] + Hinv[4] * u[4] + Hinv[5]) / b;
+  xdiff = u[0] - xa; ydiff = u[1] - ya;
+  *d2 = xdiff * xdiff + ydiff * ydiff;
+}
+
+__device__ __forceinline__ double trunc_quad_dev(double epsilon, double thr) {
+  if (thr == 0) return 0;
+  if (epsilon >= thr * 9 / 4) return 0;
+  return 1 - (epsilon / (thr * 9 / 4));
+}
+
+// grid = (ceil(len/256), n_hyp), block 256.  d[k][i], gain[i][kstride], counts[k] = {I, Isym}.
+__global__ __launch_bounds__(256) void ransac_score_kernel(const double *__restrict__ u, int len, const HypDev *__restrict__ hyp,
+                                                           int err_type, int do_sym, double th, double th_check,
+                                                           double *__restrict__ d_out, double *__restrict__ gain, int kstride,
+                                                           int *__restrict__ counts) {
+  __shared__ HypDev sh;
+  const int k = blockIdx.y;
+  for (int q = threadIdx.x; q < (int)(sizeof(HypDev) / sizeof(double)); q += 256) ((double *)&sh)[q] = ((const double *)&hyp[k])[q];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool inl = false, inls = false;
+  if (i < len) {
+    double uu[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) uu[q] = u[(size_t)i * 6 + q];
+    double d, d1 = 0, d2 = 0;
+    if (err_type != ERR_SAMPSON || do_sym) hsym_dev(uu, sh.Hinv, sh.H1, &d1, &d2);
+    if (err_type == ERR_SAMPSON) d = hds_dev(uu, sh.h);
+    else if (err_type == ERR_SYMSUM) d = d1 + d2;
+    else d = d1 > d2 ? d1 : d2;     // MAX(d1,d2), Htools.c:12,281
+    d_out[(size_t)k * len + i] = d;
+    gain[(size_t)i * kstride + k] = trunc_quad_dev(d, th);
+    inl = d <= th;
+    inls = do_sym && (d1 + d2) <= th_check;
+  }
+  const unsigned long long m1 = __ballot(inl), m2 = __ballot(inls);
+  if ((threadIdx.x & 63) == 0) {
+    if (m1) atomicAdd(&counts[2 * k], __popcll(m1));
+    if (m2) atomicAdd(&counts[2 * k + 1], __popcll(m2));
+  }
+}
+
+// grid = ceil(n_hyp/64), block 64: lane k sums gain[i][k] for i = 0..len-1 in order.
+__global__ __launch_bounds__(64) void ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride,
+                                                         double *__restrict__ J) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n_hyp) return;
+  double s = 0;
+  for (int i = 0; i < len; i++) s += gain[(size_t)i * kstride + k];
+  J[k] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-thread GPU workspace (the C entry point carries no context argument)
+// ---------------------------------------------------------------------------------------
+struct RansacGpu {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  double *u_dev = nullptr; size_t u_cap = 0;
+  HypDev *hyp_dev = nullptr; HypDev *hyp_host = nullptr; int hyp_cap = 0;
+  double *d_dev = nullptr; double *gain_dev = nullptr; size_t dg_cap = 0;
+  int *counts_dev = nullptr; double *J_dev = nullptr;
+  int *counts_host = nullptr; double *J_host = nullptr;
+  double *row_host = nullptr; size_t row_cap = 0;
+  double score_ms = 0; long launches = 0;
+  ~RansacGpu() {
+    if (device < 0) return;
+    (void)hipSetDevice(device);
+    (void)hipFree(u_dev); (void)hipFree(hyp_dev); (void)hipHostFree(hyp_host); (void)hipFree(d_dev); (void)hipFree(gain_dev);
+    (void)hipFree(counts_dev); (void)hipFree(J_dev); (void)hipHostFree(counts_host); (void)hipHostFree(J_host);
+    (void)hipHostFree(row_host);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+static int g_ransac_device = 0;
+static long g_pinned_seed = -1;
+static std::mutex g_cfg_mutex;
+
+static RansacGpu *ransac_gpu() {
+  static thread_local RansacGpu ws;
+  if (ws.device < 0) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device: RANSAC scoring has no CPU path"); return nullptr; }
+    int dev;
+    { std::lock_guard<std::mutex> lk(g_cfg_mutex); dev = g_ransac_device; }
+    if (hipSetDevice(dev) != hipSuccess) { set_error("hipSetDevice(%d) failed", dev); return nullptr; }
+    if (hipStreamCreateWithFlags(&ws.stream, hipStreamDefault) != hipSuccess) { set_error("stream creation failed"); return nullptr; }
+    ws.device = dev;
+  }
+  (void)hipSetDevice(ws.device);
+  return &ws;
+}
+
+#define RS_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return false; } } while (0)
+
+static bool ws_reserve(RansacGpu *ws, int len, int n_hyp) {
+  if ((size_t)len * 6 > ws->u_cap) {
+    if (ws->u_dev) RS_CHECK(hipFree(ws->u_dev));
+    ws->u_cap = (size_t)len * 6 * 2;
+    RS_CHECK(hipMalloc(&ws->u_dev, ws->u_cap * sizeof(double)));
+  }
+  if (n_hyp > ws->hyp_cap) {
+    if (ws->hyp_dev) { RS_CHECK(hipFree(ws->hyp_dev)); RS_CHECK(hipHostFree(ws->hyp_host)); RS_CHECK(hipFree(ws->counts_dev));
+                       RS_CHECK(hipFree(ws->J_dev)); RS_CHECK(hipHostFree(ws->counts_host)); RS_CHECK(hipHostFree(ws->J_host)); }
+    ws->hyp_cap = n_hyp;
+    RS_CHECK(hipMalloc(&ws->hyp_dev, sizeof(HypDev) * n_hyp));
+    RS_CHECK(hipHostMalloc(&ws->hyp_host, sizeof(HypDev) * n_hyp));
+    RS_CHECK(hipMalloc(&ws->counts_dev, sizeof(int) * 2 * n_hyp));
+    RS_CHECK(hipMalloc(&ws->J_dev, sizeof(double) * n_hyp));
+    RS_CHECK(hipHostMalloc(&ws->counts_host, sizeof(int) * 2 * n_hyp));
+    RS_CHECK(hipHostMalloc(&ws->J_host, sizeof(double) * n_hyp));
+    ws->dg_cap = 0;
+  }
+  const size_t need = (size_t)len * ws->hyp_cap;
+  if (need > ws->dg_cap) {
+    if (ws->d_dev) { RS_CHECK(hipFree(ws->d_dev)); RS_CHECK(hipFree(ws->gain_dev)); }
+    ws->dg_cap = need;
+    RS_CHECK(hipMalloc(&ws->d_dev, need * sizeof(double)));
+    RS_CHECK(hipMalloc(&ws->gain_dev, need * sizeof(double)));
+  }
+  if ((size_t)len > ws->row_cap) {
+    if (ws->row_host) RS_CHECK(hipHostFree(ws->row_host));
+    ws->row_cap = (size_t)len * 2;
+    RS_CHECK(hipHostMalloc(&ws->row_host, ws->row_cap * sizeof(double)));
+  }
+  return true;
+}
+
+// scores hyp_host[0..n) over all correspondences; fills counts_host / J_host
+static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, double th, double th_check) {
+  RS_CHECK(hipMemcpyAsync(ws->hyp_dev, ws->hyp_host, sizeof(HypDev) * n, hipMemcpyHostToDevice, ws->stream));
+  RS_CHECK(hipMemsetAsync(ws->counts_dev, 0, sizeof(int) * 2 * n, ws->stream));
+  hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, ws->hyp_dev, err_type,
+                     do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
+  hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(64), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
+  RS_CHECK(hipGetLastError());
+  RS_CHECK(hipMemcpyAsync(ws->counts_host, ws->counts_dev, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
+  RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ws->stream));
+  RS_CHECK(hipStreamSynchronize(ws->stream));
+  ws->launches += 2;
+  return true;
+}
+
+static bool gpu_fetch_row(RansacGpu *ws, int len, int k, double *dst) {
+  RS_CHECK(hipMemcpyAsync(ws->row_host, ws->d_dev + (size_t)k * len, sizeof(double) * len, hipMemcpyDeviceToHost, ws->stream));
+  RS_CHECK(hipStreamSynchronize(ws->stream));
+  memcpy(dst, ws->row_host, sizeof(double) * len);
+  return true;
+}
+
+}  // namespace mods
+
+using namespace mods;
+
+extern "C" {
+
+typedef void (*HDsPtr)(const double *, const double *, const double *, double *, int);
+typedef void (*HDsiPtr)(const double *, const double *, const double *, double *, int, int *, int);
+typedef void (*HDsidxPtr)(const double *, const double *, const double *, double *, int, int *, int);
+
+// Error functions with the reference's signatures (Htools.h).  `lin` is ignored: the design-matrix
+// rows are rebuilt from u (same values).  Host-side; used by LO and by the LAF checks.
+void HDs(const double *lin, const double *u, const double *H, double *p, int len) {
+  (void)lin;
+  for (int i = 0; i < len; i++) p[i] = rs::hds_point(u + 6 * i, H);
+}
+void HDsSym(const double *lin, const double *u, const double *H, double *p, int len) {
+  (void)lin;
+  rs::SymH s; rs::sym_prepare(H, &s);
+  for (int i = 0; i < len; i++) { double d1, d2; rs::hsym_point(u + 6 * i, &s, &d1, &d2); p[i] = d1 + d2; }
+}
+void HDsSymMax(const double *lin, const double *u, const double *H, double *p, int len) {
+  (void)lin;
+  rs::SymH s; rs::sym_prepare(H, &s);
+  for (int i = 0; i < len; i++) { double d1, d2; rs::hsym_point(u + 6 * i, &s, &d1, &d2); p[i] = d1 > d2 ? d1 : d2; }
+}
+void HDsi(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni) {
+  (void)lin; (void)len;
+  for (int i = 0; i < ni; i++) p[i] = rs::hds_point(u6 + 6 * pts[i], H);
+}
+void HDsiSym(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni) {
+  (void)lin; (void)len;
+  rs::SymH s; rs::sym_prepare(H, &s);
+  for (int i = 0; i < ni; i++) { double d1, d2; rs::hsym_point(u6 + 6 * pts[i], &s, &d1, &d2); p[i] = d1 + d2; }
+}
+void HDsiSymMax(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni) {
+  (void)lin; (void)len;
+  rs::SymH s; rs::sym_prepare(H, &s);
+  for (int i = 0; i < ni; i++) { double d1, d2; rs::hsym_point(u6 + 6 * pts[i], &s, &d1, &d2); p[i] = d1 > d2 ? d1 : d2; }
+}
+// HDsidx / HDsSymidx / HDsSymidxMax are passed through LORANSACFiltering but never invoked on the
+// live path (exp_ranH.c uses them only under __LSBL_MCE__); exported for link compatibility.
+void HDsidx(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz) { HDsi(lin, mu, H, p, len, idx, siz); }
+void HDsSymidx(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz) { HDsiSym(lin, mu, H, p, len, idx, siz); }
+void HDsSymidxMax(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz) { HDsiSymMax(lin, mu, H, p, len, idx, siz); }
+
+int mods_ransac_set_device(int device) { std::lock_guard<std::mutex> lk(g_cfg_mutex); g_ransac_device = device; return MODS_OK; }
+// seed >= 0: every call behaves as if time(NULL) returned `seed`; < 0: back to the wall clock
+void mods_ransac_pin_seed(long seed) { std::lock_guard<std::mutex> lk(g_cfg_mutex); g_pinned_seed = seed; }
+
+}  // extern "C"
+
+namespace mods {
+
+struct ErrFn {   // host-side error function of the run (LO path)
+  int type; HDsPtr custom;
+  void operator()(const double *u, const double *H, double *d, int len) const {
+    if (custom) { custom(nullptr, u, H, d, len); return; }
+    if (type == ERR_SAMPSON) HDs(nullptr, u, H, d, len);
+    else if (type == ERR_SYMSUM) HDsSym(nullptr, u, H, d, len);
+    else HDsSymMax(nullptr, u, H, d, len);
+  }
+};
+
+struct LoState {
+  const double *u; int len; double th;
+  double *errs[5];
+  double *buffer;
+  rs::GlibcRand *rng;
+  rs::HashTable *ht;
+  unsigned inlLimit;
+  ErrFn errfn;
+};
+
+// exp_iterHcustom, exp_ranH.c:617-737 (__D3__ with inlLimit = 1e6 => least squares on all
+// inliers; __HASHING__ on)
+static Score lo_iter(LoState &L, int *inliers, double th, double ths, int steps, double *H, int iterID, double *resids) {
+  const int len = L.len;
+  double *d = L.errs[1];
+  double h[9];
+  Score maxS = {0, 0}, S = {0, 0}, Ss;
+  const double dth = (ths - th) / (steps);
+  auto lsq = [&](const Score &Sc) {
+    unsigned detached = (unsigned)(int)(Sc.I * 1);
+    if (detached > L.inlLimit) detached = L.inlLimit;
+    if (detached < 4) detached = 4;
+    if (detached >= Sc.I) rs::u2h(L.u, inliers, (int)Sc.I, h, L.buffer);
+    else {
+      int *sub = rs::randsubset(*L.rng, inliers, (int)Sc.I, (int)detached);
+      rs::u2h(L.u, sub, (int)detached, h, L.buffer);
+    }
+  };
+  maxS = rs::inlidxs(L.errs[4], len, th, inliers);
+  if (maxS.I < 4) return S;
+  S = rs::inlidxs(L.errs[4], len, th * 2, inliers);   // th*MWM, MWM = (9/4) = 2 (rtools.h:33)
+  lsq(S);
+  for (int it = 0; it < steps; it++) {
+    L.errfn(L.u, h, d, len);
+    memcpy(resids + (size_t)it * len, d, len * sizeof(double));
+    Ss = rs::inlidxs(d, len, th, inliers);
+    const uint32_t hash = rs::super_fast_hash((const char *)inliers, (int)(Ss.I * sizeof(*inliers)));
+    const int ret = L.ht->contains(hash, (int)Ss.I, iterID);
+    if (ret != -1 && ret != iterID) { S.I = 0; S.J = 0; return S; }
+    if (ret == -1) L.ht->insert(hash, (int)Ss.I, iterID);
+    S = rs::inlidxs(d, len, ths * 2, inliers);
+    if (rs::score_less(maxS, Ss)) {
+      maxS = Ss;
+      L.errs[1] = L.errs[0];
+      L.errs[0] = d;
+      d = L.errs[1];
+      memcpy(H, h, 9 * sizeof(double));
+    }
+    if (S.I < 4) return maxS;
+    lsq(S);
+    ths -= dth;
+  }
+  L.errfn(L.u, h, d, len);
+  memcpy(resids + (size_t)4 * len, d, len * sizeof(double));
+  S = rs::inlidxs(d, len, th, inliers);
+  if (rs::score_less(maxS, S)) {
+    maxS = S;
+    L.errs[1] = L.errs[0];
+    L.errs[0] = d;
+    memcpy(H, h, 9 * sizeof(double));
+  }
+  return maxS;
+}
+
+// exp_inHranicustom, exp_ranH.c:741-793 (RAN_REP = 10, ILSQ_ITERS = 4, TC = 4)
+static Score lo_inner(LoState &L, int *inliers, int ninl, double th, double *H, int rep, int *iterID, double *resids) {
+  const int len = L.len;
+  Score S, maxS = {0, 0};
+  double *d, h[9];
+  std::vector<int> intbuff(len);
+  if (ninl < 8) {
+    memset(resids, 0xFF, (size_t)(62 - 2) * len * sizeof(double));   // RESIDS_M - 2
+    return maxS;
+  }
+  int ssiz = ninl / 2;
+  if (ssiz > 12) ssiz = 12;
+  d = L.errs[2]; L.errs[2] = L.errs[0]; L.errs[0] = d;
+  for (int i = 0; i < rep; i++) {
+    int *sample = rs::randsubset(*L.rng, inliers, ninl, ssiz);
+    rs::u2h(L.u, sample, ssiz, h, L.buffer);
+    L.errfn(L.u, h, L.errs[0], len);
+    memcpy(resids + (size_t)i * 6 * len, L.errs[0], len * sizeof(double));
+    L.errs[4] = L.errs[0];
+    S = lo_iter(L, intbuff.data(), th, 4 * th, 4, h, ++*iterID, resids + (size_t)i * 6 * len + len);
+    if (rs::score_less(maxS, S)) {
+      maxS = S;
+      d = L.errs[2]; L.errs[2] = L.errs[0]; L.errs[0] = d;
+      memcpy(H, h, 9 * sizeof(double));
+    }
+  }
+  d = L.errs[2]; L.errs[2] = L.errs[0]; L.errs[0] = d;
+  return maxS;
+}
+
+static double h_tol3(const double *h) {   // exp_ranH.c:877-885
+  double tol = h[8];
+  if (tol == 0) {
+    for (int i = 0; i < 9; ++i) tol += h[i] * h[i];
+    tol = std::sqrt(tol);
+    tol *= 0.001;
+  }
+  return tol * tol * tol;
+}
+
+}  // namespace mods
+
+extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
+                                    int iter_type, int *data_out, int oriented_constraint, unsigned inlLimit, double **resids,
+                                    HDsPtr HDS1, HDsiPtr HDSi1, HDsidxPtr HDSidx1, int doSymCheck) {
+  (void)HDSi1; (void)HDSidx1;
+  Score maxS = {0, 0}, maxSs = {0, 0}, S = {0, 0};
+  const int RESIDS_M = 2 + 10 * (1 + 4 + 1);
+  if (resids) *resids = (double *)malloc(0 * sizeof(double) + 8);
+  if (len < 4 || !u || !H || !inl || !data_out) { if (data_out) { data_out[0] = 0; data_out[1] = 0; data_out[2] = 0; } return maxS; }
+  RansacGpu *ws = ransac_gpu();
+  if (!ws) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }   // no CPU fallback
+  int err_type; HDsPtr custom = nullptr;
+  if (HDS1 == &HDs || HDS1 == nullptr) err_type = ERR_SAMPSON;
+  else if (HDS1 == &HDsSym) err_type = ERR_SYMSUM;
+  else if (HDS1 == &HDsSymMax) err_type = ERR_SYMMAX;
+  else { err_type = -1; custom = HDS1; }   // foreign error function: evaluated where it lives, on the host
+  if (inlLimit == 0) inlLimit = 1000000;
+
+  long pinned;
+  { std::lock_guard<std::mutex> lk(g_cfg_mutex); pinned = g_pinned_seed; }
+  if (pinned < 0) { const char *e = getenv("MODS_RANSAC_SEED"); if (e) pinned = atol(e); }
+  rs::GlibcRand rng;
+  rng.seed((unsigned)(pinned >= 0 ? (time_t)pinned : time(NULL)));   // srand(time(NULL)), exp_ranH.c:823
+  rs::HashTable ht;
+
+  std::vector<int> pool(len), inliers(len);
+  for (int i = 0; i < len; i++) pool[i] = i;
+  std::vector<double> buffer((size_t)len * 18), err((size_t)len * 4), d_check(len);
+  double *errs[5];
+  for (int i = 0; i < 4; i++) errs[i] = err.data() + (size_t)i * len;
+  errs[4] = errs[3];
+  int no_sam = 0, iter_cnt = 0, no_rej = 0, iterID = 0;
+  unsigned seed = (unsigned)rng.next();   // seed = rand()
+  double h[9];
+  const double CHECK_COEF = 9.0;
+  const unsigned MIN_GOOD_SYM_PTS = 5;
+  const double th_check = CHECK_COEF * th;
+  ErrFn errfn = {err_type, custom};
+  LoState L = {u, len, th, {errs[0], errs[1], errs[2], errs[3], errs[4]}, buffer.data(), &rng, &ht, inlLimit, errfn};
+
+  if (!ws_reserve(ws, len, 64)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+  if (hipMemcpyAsync(ws->u_dev, u, sizeof(double) * 6 * len, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
+      hipStreamSynchronize(ws->stream) != hipSuccess) { fprintf(stderr, "libmodsgpu: upload failed\n"); abort(); }
+
+  // sym check of a host-side model (LO results); the per-sample check comes from the GPU counts
+  auto sym_bad = [&](const double *hh) -> bool {
+    HDsSym(nullptr, u, hh, d_check.data(), len);
+    unsigned c = 0;
+    for (int j = 0; j < len; j++) if (d_check[j] <= th_check) c++;
+    return c <= MIN_GOOD_SYM_PTS;
+  };
+  // LO block of the main loop, exp_ranH.c:961-1074 (iter_type 4 = inner RANSAC + iterated LSQ; other
+  // types follow the same switch)
+  auto run_lo = [&](bool *new_max) {
+    iter_cnt++;
+    *resids = (double *)realloc(*resids, (size_t)iter_cnt * RESIDS_M * len * sizeof(double));
+    double *rbase = *resids + (size_t)RESIDS_M * (iter_cnt - 1) * len;
+    double *d;
+    switch (iter_type) {
+      case 0: break;
+      case 1:
+        S = rs::inlidxs(L.errs[4], len, 4 * th, inliers.data());
+        rs::u2h(u, inliers.data(), (int)S.I, h, buffer.data());
+        d = L.errs[0];
+        errfn(u, h, d, len);
+        S.I = 0; S.J = 0;
+        for (int j = 0; j < len; j++) { if (d[j] <= th) S.I++; S.J += rs::trunc_quad(d[j], th); }
+        break;
+      case 2:
+        S = lo_iter(L, inliers.data(), th, 4 * th, 4, h, ++iterID, rbase + 2 * len);
+        break;
+      case 3:
+        d = L.errs[0];
+        S = rs::inlidxs(L.errs[4], len, 4 * th, inliers.data());
+        rs::u2h(u, inliers.data(), (int)S.I, h, buffer.data());
+        errfn(u, h, d, len);
+        S = rs::inlidxs(d, len, th, inliers.data());
+        break;
+      default: {
+        memcpy(rbase, L.errs[4], len * sizeof(double));
+        d = L.errs[0];
+        S = rs::inlidxs(L.errs[4], len, 4 * th * 2, inliers.data());   // TC*th*MWM
+        rs::u2h(u, inliers.data(), (int)S.I, h, buffer.data());
+        errfn(u, h, d, len);
+        S = rs::inlidxs(d, len, th, inliers.data());
+        memcpy(rbase + len, d, len * sizeof(double));
+        S = lo_inner(L, inliers.data(), (int)S.I, th, h, 10, &iterID, rbase + 2 * len);
+        break;
+      }
+    }
+    const double tol = h_tol3(h);
+    if (rs::score_less(maxS, S) && (std::fabs(rs::det3(h) / tol) > 10e-2)) {
+      bool bad_model = false;
+      if (doSymCheck) bad_model = sym_bad(h);
+      if (!bad_model) {
+        double *dd = L.errs[0]; L.errs[0] = L.errs[3]; L.errs[3] = dd;
+        maxS = S;
+        *new_max = true;
+        memcpy(H, h, 9 * sizeof(double));
+      }
+    }
+  };
+
+  // ---- main loop, batched ---------------------------------------------------------------------------
+  struct Sample { unsigned seed_before; int idx[4]; int valid; double h[9]; };
+  std::vector<Sample> batch;
+  std::vector<double> Z((size_t)len * 18);
+  rs::lin_hg(u, Z.data(), pool.data(), len);
+  int batch_size = 64;
+  bool bad_model = false;
+  while (no_sam < max_sam) {
+    int want = batch_size;
+    if (want > max_sam - no_sam) want = max_sam - no_sam;
+    batch.resize(want);
+    if (!ws_reserve(ws, len, want)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+    int n_valid = 0;
+    for (int b = 0; b < want; b++) {
+      Sample &sm = batch[b];
+      sm.seed_before = seed;
+      rng.seed(seed);                               // srand(seed)
+      double M[9 * 9];
+      for (int i = 0; i < 4; i++) {                 // multirsampleT(Z, 9, 2, pool, 4, len, M), rtools.c:127-151
+        const int s = rng.next() % (len - i);
+        const int j = len - i - 1;
+        const int q = pool[s];
+        pool[s] = pool[j];
+        pool[j] = q;
+        for (int c = 0; c < 9; c++) {
+          M[(2 * i) * 9 + c] = Z[(size_t)c * 2 * len + 2 * q];
+          M[(2 * i + 1) * 9 + c] = Z[(size_t)c * 2 * len + 2 * q + 1];
+        }
+      }
+      seed = (unsigned)rng.next();                  // seed = rand()
+      for (int i = 0; i < 4; i++) sm.idx[i] = pool[len - 4 + i];
+      sm.valid = 0;
+      if (oriented_constraint && !rs::all_Hori_valid(u, sm.idx)) { sm.valid = -1; continue; }   // counts as no_rej
+      for (int i = 9 * 8; i < 9 * 9; ++i) M[i] = 0.0;
+      double sol[9 * 9];
+      int nb[18];
+      memset(sol, 0, sizeof(sol));
+      if (rs::nullspace(M, sol, 9, nb) != 1) continue;
+      const double v = rs::det3(sol);
+      const double tol = h_tol3(sol);
+      if (std::fabs(v / tol) < 10e-2) continue;     // close to singular
+      memcpy(sm.h, sol, sizeof(sm.h));
+      sm.valid = 1;
+      HypDev &hd = ws->hyp_host[n_valid];
+      memcpy(hd.h, sol, sizeof(hd.h));
+      rs::SymH sh; rs::sym_prepare(sol, &sh);
+      memcpy(hd.Hinv, sh.Hinv, sizeof(hd.Hinv)); memcpy(hd.H1, sh.H1, sizeof(hd.H1));
+      sm.valid = 1 + n_valid;                       // 1-based slot in the scored batch
+      n_valid++;
+    }
+    std::vector<double> custom_d;
+    if (n_valid > 0) {
+      if (custom) {
+        // foreign error function: scores come from the caller's code, on the host
+        custom_d.resize((size_t)n_valid * len);
+        for (int kq = 0; kq < n_valid; kq++) {
+          double *dd = custom_d.data() + (size_t)kq * len;
+          custom(nullptr, u, ws->hyp_host[kq].h, dd, len);
+          unsigned I = 0, Is = 0; double J = 0;
+          for (int j = 0; j < len; j++) { if (dd[j] <= th) I++; J += rs::trunc_quad(dd[j], th); }
+          if (doSymCheck) { HDsSym(nullptr, u, ws->hyp_host[kq].h, d_check.data(), len); for (int j = 0; j < len; j++) if (d_check[j] <= th_check) Is++; }
+          ws->counts_host[2 * kq] = (int)I; ws->counts_host[2 * kq + 1] = (int)Is; ws->J_host[kq] = J;
+        }
+      } else if (!gpu_score(ws, len, n_valid, err_type, doSymCheck, th, th_check)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+    }
+    auto fetch_row = [&](int slot, double *dst) {
+      if (custom) memcpy(dst, custom_d.data() + (size_t)slot * len, sizeof(double) * len);
+      else if (!gpu_fetch_row(ws, len, slot, dst)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+    };
+    // replay the reference's per-iteration decisions in order (exp_ranH.c:858-1083)
+    int b = 0;
+    for (; b < want && no_sam < max_sam; b++) {
+      const Sample &sm = batch[b];
+      no_sam++;
+      if (sm.valid == -1) { no_rej++; continue; }
+      if (sm.valid == 0) continue;
+      const int slot = sm.valid - 1;
+      bool new_max = false;
+      S.I = (unsigned)ws->counts_host[2 * slot];
+      S.J = ws->J_host[slot];
+      double *d = L.errs[0];
+      bool have_d = false;
+      if (rs::score_less(maxS, S)) {
+        if (doSymCheck) bad_model = (unsigned)ws->counts_host[2 * slot + 1] <= MIN_GOOD_SYM_PTS;
+        if (bad_model) continue;
+        fetch_row(slot, d); have_d = true;
+        L.errs[0] = L.errs[3];
+        L.errs[3] = d;
+        maxS = S;
+        new_max = true;
+        memcpy(H, sm.h, 9 * sizeof(double));
+      }
+      bool do_iterate;
+      if (rs::score_less(maxSs, S)) {
+        do_iterate = no_sam > 50;                   // ITER_SAM
+        maxSs = S;
+        if (!have_d) { fetch_row(slot, d); have_d = true; }
+        L.errs[4] = d;
+      } else do_iterate = false;
+      if ((no_sam >= 50) && (iter_cnt == 0) && (maxSs.I > 4)) do_iterate = true;
+      if (do_iterate) {
+        // generator state as the reference has it here: srand(seed_k); 4 x random(); rand()
+        rng.seed(sm.seed_before);
+        for (int i = 0; i < 5; i++) (void)rng.next();
+        memcpy(h, sm.h, sizeof(h));
+        run_lo(&new_max);
+      }
+      if (new_max) {
+        const int new_sam = rs::nsamples((int)maxS.I + 1, len, 4, conf);
+        if (new_sam < max_sam) max_sam = new_sam;
+      }
+    }
+    if (b < want) {
+      // stopped inside the batch: the generator continues from the last executed iteration
+      const Sample &last = batch[b - 1];
+      rng.seed(last.seed_before);
+      for (int i = 0; i < 5; i++) (void)rng.next();
+      break;
+    }
+    if (batch_size < 1024) batch_size *= 2;
+  }
+  // "If there were no LOs, do at least one NOW!", exp_ranH.c:1085-1197
+  if (iter_cnt == 0 && iter_type != 0) {
+    bool nm = false;
+    memset(h, 0, sizeof(h));
+    run_lo(&nm);
+  }
+  {
+    const double *d = L.errs[3];
+    for (int j = 0; j < len; j++) inl[j] = d[j] <= th ? 1 : 0;
+  }
+  data_out[0] = no_sam;
+  data_out[1] = iter_type == 0 ? 0 : iter_cnt;
+  data_out[2] = no_rej;
+  return maxS;
+}
