@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image pairs / second, end to end (detect + describe + match + RANSAC) on
+synthetic 1920x1080 pairs, HessianAffine + RootSIFT, one identity view per image
+(BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step = one image pair through the whole hot path (mods_match_pair_dev) with both images already
+resident in HBM.  N > 1 is launched by torch.distributed.run, one rank per GPU; pairs are independent
+units, so every rank works on its own pairs (weak scaling, no data-path collective) and the reported
+value is all pairs / max-over-ranks time.
+
+Rank 0 prints one JSON line.  Besides the contract fields it carries
+  roofline     - the Gaussian-blur kernel of the Hessian pyramid (largest share of the HBM-bound
+                 pyramid time): algorithmic bytes (8 B/px per blur launch) / mean launch time
+                 measured with HIP events on the context's stream during the timed steps
+  cpu_baseline - the CPU oracle (oracle/) timed on this host on one pair of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 1920, 1080
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(img1, img2, seed):
+    """Oracle chain on one pair, single thread.  Returns (pairs_per_s, seconds, inliers)."""
+    import pipeline_oracle as po
+    import refdeg
+    t0 = time.time()
+    if refdeg.available():
+        r = po.match_pair(img1, img2, seed_time=seed)
+        ninl = r["n_inliers"]
+    else:   # GPU box without oracle/_ref: everything up to the tentatives (RANSAC is <1% of the CPU time)
+        import orc
+        ra, _ = orc.detect_describe(img1)
+        rb, _ = orc.detect_describe(img2)
+        tc = orc.match_fginn(ra, rb, 0.8)
+        ninl = len(orc.duplicate_filter(tc, ra, rb, 2.0, 1))
+    dt = time.time() - t0
+    return 1.0 / dt, dt, ninl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs cycled through the steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    pkg = ge.load_package()
+    if pkg.lib().mods_device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: libmodsgpu has no CPU path")
+
+    # synthetic inputs: seed = 1000*config + pair index (config 2 = the 1080p pair), distinct per rank
+    pairs_host = [synth.pair(W, H, seed=2000 + rank * 100 + i) for i in range(args.pairs)]
+    pairs_dev = [torch.from_numpy(np.stack([a, b])).cuda(device) for a, b, _ in pairs_host]
+    torch.cuda.synchronize()
+
+    ctx = pkg.Context(device, W, H, 2)
+    pkg.lib().mods_ransac_set_device(device)
+    params = pkg.PairParams.default()
+    pkg.ransac_pin_seed(12345)
+
+    def step(i):
+        res, _ = pkg.match_pair_dev(ctx, pairs_dev[i % len(pairs_dev)].data_ptr(), W, H, params)
+        return res
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.timing_enable(["blur"])
+    ctx.timing_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inl = 0
+    stage_ms = [0.0, 0.0, 0.0, 0.0]
+    for i in range(args.steps):
+        r = step(i)
+        inl += r.n_inliers
+        for q, f in enumerate(("ms_detect_describe", "ms_match", "ms_duplicates", "ms_ransac")):
+            stage_ms[q] += getattr(r, f)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    blur_ms, blur_n, blur_bytes = ctx.timing_read("blur")
+    ctx.timing_enable([])
+    last = step(0)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        value = world * args.steps / dt
+        achieved = (blur_bytes / blur_n) / (blur_ms / blur_n * 1e-3) / 1e9 if blur_n else 0.0
+        out = {
+            "metric": "image_pairs_per_sec_end_to_end", "value": round(value, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "single 1920x1080 pair, HessianAffine+RootSIFT, 1 synth iteration (BASELINE configs[1])",
+                       "pairs_per_step": 1, "image": "1920x1080", "matcher": "linear (exact), FGINN 0.8",
+                       "verification": "LO-RANSAC homography, Sampson, th 4 px", "parallelism": "pairs sharded, %d rank(s)" % world,
+                       "keypoints_per_image": list(last.n_described), "tentatives": last.n_tentatives,
+                       "inliers_last_pair": last.n_inliers, "mean_inliers": round(inl / args.steps, 1),
+                       "ransac_samples_last_pair": last.ransac_samples, "ransac_lo_last_pair": last.ransac_lo,
+                       "stage_ms_per_pair": {"detect_describe": round(stage_ms[0] / args.steps, 3), "match": round(stage_ms[1] / args.steps, 3),
+                                             "duplicates": round(stage_ms[2] / args.steps, 3), "ransac": round(stage_ms[3] / args.steps, 3)}},
+            "roofline": {"kernel": "gauss_blur_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches": blur_n, "mean_launch_us": round(blur_ms / max(blur_n, 1) * 1e3, 3),
+                         "algorithmic_bytes_per_launch": round(blur_bytes / max(blur_n, 1), 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            a, b, _ = pairs_host[0]
+            v, secs, ninl = cpu_baseline(a, b, 12345)
+            out["cpu_baseline"] = {"value": round(v, 5), "unit": "pairs/s", "cores": 1, "kind": "port",
+                                   "sample": "1 of the benchmark's 1920x1080 pairs through the CPU oracle (oracle/), %.1f s, %d inliers" % (secs, ninl)}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

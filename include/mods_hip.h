@@ -213,6 +213,39 @@ int mods_ransac_set_device(int device);
  * has the same effect when no seed is pinned. */
 void mods_ransac_pin_seed(long seed);
 
+/* ---- whole hot path for one image pair ---------------------------------------------------------
+ * The step loop body of mods.cpp:202-383 for one step of HessianAffine + RootSIFT on identity views:
+ *   SynthDetectDescribeKeypoints x2 (mods.cpp:234-251) -> MatchImgReps (:270) -> DuplicateFiltering
+ *   (:283) -> LORANSACFiltering (:325). */
+typedef struct mods_pair_params {
+  mods_hessaff_params det;
+  mods_describe_params desc;
+  double fginn_ratio;        /* iters .ini: FGINNThreshold = 0.8 */
+  double contradDist;        /* [Matching] contradDist = 10 */
+  int nn;                    /* 50 */
+  int dup_before_ransac;     /* [DuplicateFiltering] doBeforeRANSAC = 1 */
+  double dup_dist;           /* duplicateDist = 2.0 */
+  int dup_mode;              /* whichCorrespondenceRemains = bestFGINN -> 1 */
+  mods_ransac_params ransac;
+} mods_pair_params;
+
+typedef struct mods_pair_result {
+  int n_detected[2];         /* regions per image after affine adaptation */
+  int n_described[2];        /* descriptors per image */
+  int n_tentatives;          /* after FGINN matching */
+  int n_unique;              /* after duplicate filtering */
+  int n_inliers;             /* after RANSAC + NaiveHCheck + H_LAF_check */
+  int ransac_samples, ransac_lo, ransac_rejects;
+  double H[9];               /* row-major img1 -> img2, all -1 when verification failed */
+  /* wall-clock per stage in ms, the reference's TimeLog buckets (detectors/structures.hpp:33-56) */
+  double ms_detect_describe, ms_match, ms_duplicates, ms_ransac;
+} mods_pair_result;
+
+/* img_dev: [2][h][stride] fp32 in HBM (image 1, image 2).  matches_out (optional): up to max_matches
+ * rows x1 y1 x2 y2 of the verified correspondences (matchings.txt layout, matching.cpp:2610-2611). */
+int mods_match_pair_dev(mods_ctx *ctx, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
+                        mods_pair_result *res, double *matches_out, int max_matches);
+
 #ifdef __cplusplus
 }
 #endif

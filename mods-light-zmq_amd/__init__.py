@@ -337,3 +337,33 @@ def loransac_h(u6, laf, params=None, seed_time=12345):
                                  n, C.byref(params), mask.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
                                  C.byref(ninl), stats))
     return mask[:n].astype(bool), H.reshape(3, 3), ninl.value, list(stats)
+
+
+# ---- one pair end to end ------------------------------------------------------------------------------
+class PairParams(C.Structure):
+    _fields_ = [("det", HessAffParams), ("desc", DescribeParams), ("fginn_ratio", C.c_double),
+                ("contradDist", C.c_double), ("nn", C.c_int), ("dup_before_ransac", C.c_int),
+                ("dup_dist", C.c_double), ("dup_mode", C.c_int), ("ransac", RansacParams)]
+
+    @staticmethod
+    def default():
+        """build/config_affori_classic.ini + build/iters_HessianSIFT.ini with vector_matcher = linear."""
+        return PairParams(HessAffParams.default(), DescribeParams.default(), 0.8, 10.0, 50, 1, 2.0, 1,
+                          RansacParams.default())
+
+
+class PairResult(C.Structure):
+    _fields_ = [("n_detected", C.c_int * 2), ("n_described", C.c_int * 2), ("n_tentatives", C.c_int),
+                ("n_unique", C.c_int), ("n_inliers", C.c_int), ("ransac_samples", C.c_int), ("ransac_lo", C.c_int),
+                ("ransac_rejects", C.c_int), ("H", C.c_double * 9), ("ms_detect_describe", C.c_double),
+                ("ms_match", C.c_double), ("ms_duplicates", C.c_double), ("ms_ransac", C.c_double)]
+
+
+def match_pair_dev(ctx, dev_ptr, w, h, params=None, max_matches=0):
+    """Whole hot path on [2][h][w] fp32 images resident in HBM; returns (PairResult, matches[n,4])."""
+    params = params or PairParams.default()
+    res = PairResult()
+    m = np.zeros((max(max_matches, 1), 4), np.float64)
+    _check(lib().mods_match_pair_dev(ctx.h, C.c_void_p(dev_ptr), w, h, w, C.byref(params), C.byref(res),
+                                     m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
+    return res, m[:min(res.n_inliers, max_matches)]

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 
 namespace mods {
 
@@ -80,7 +81,7 @@ int mods_ctx_create(int device, int max_w, int max_h, int batch, mods_ctx **out)
   MODS_HIP_CHECK(hipHostMalloc(&c->host_counts, sizeof(int) * 4 * batch));
   MODS_HIP_CHECK(hipMalloc(&c->ori_dev, 48 * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->regions_dev, sizeof(mods_region) * mc * batch));
-  MODS_HIP_CHECK(hipMalloc(&c->region_count, sizeof(int) * batch));
+  MODS_HIP_CHECK(hipMalloc(&c->region_count, sizeof(int) * 3 * batch));   // regions, then 2 tier counts per image
   *out = c;
   return MODS_OK;
 }
@@ -246,6 +247,7 @@ int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w
   for (int b = 0; b < n_img; b++) {
     if (c->host_counts[b] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", c->host_counts[b], c->max_cand); return MODS_E_CAPACITY; }
     if (n_detected_host) n_detected_host[b] = c->host_counts[2 * c->batch + b];
+    if (c->host_counts[3 * c->batch + b] > std::min(c->max_cand, 1 << 17)) { set_error("region list overflow: %d", c->host_counts[3 * c->batch + b]); return MODS_E_CAPACITY; }
     if (n_regions_host) n_regions_host[b] = c->host_counts[3 * c->batch + b];
   }
   c->last_region_counts.assign(c->host_counts + 3 * c->batch, c->host_counts + 3 * c->batch + n_img);
@@ -520,6 +522,58 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
   if ((int)cur.size() < MIN_POINTS) cur.clear();
   for (int i : cur) mask[i] = 1;
   *n_inliers = (int)cur.size();
+  return MODS_OK;
+}
+
+// ---- one pair end to end -------------------------------------------------------------------------------
+int mods_match_pair_dev(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
+                        mods_pair_result *res, double *matches_out, int max_matches) {
+  if (!c || !img_dev || !par || !res) { set_error("match_pair: null argument"); return MODS_E_ARG; }
+  if (c->batch < 2) { set_error("match_pair needs a context created with batch >= 2"); return MODS_E_ARG; }
+  memset(res, 0, sizeof(*res));
+  for (int i = 0; i < 9; i++) res->H[i] = -1;
+  int rc;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now();
+  if ((rc = mods_detect_describe_dev(c, img_dev, 2, w, h, stride, &par->det, &par->desc, res->n_detected, res->n_described))) return rc;
+  double t1 = now();
+  res->ms_detect_describe = t1 - t0;
+  if ((rc = match_run(c, c->regions_dev, res->n_described[0], c->regions_dev + c->max_cand, res->n_described[1],
+                      par->fginn_ratio, par->contradDist, par->nn))) return rc;
+  int n = 0;
+  MODS_HIP_CHECK(hipMemcpyAsync(&n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  res->n_tentatives = n;
+  if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
+  c->h_tent.resize(n); c->h_u6.resize((size_t)n * 6); c->h_laf.resize((size_t)n * 14); c->h_mask.resize(n);
+  if (n > 0) {
+    MODS_HIP_CHECK(hipMemcpyAsync(c->h_tent.data(), c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipMemcpyAsync(c->h_u6.data(), c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipMemcpyAsync(c->h_laf.data(), c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  }
+  double t2 = now();
+  res->ms_match = t2 - t1;
+  int nu = n;
+  if (par->dup_before_ransac && n > 0)
+    if ((rc = mods_duplicate_filter(c->h_tent.data(), c->h_u6.data(), c->h_laf.data(), n, par->dup_dist, par->dup_mode, &nu))) return rc;
+  res->n_unique = nu;
+  double t3 = now();
+  res->ms_duplicates = t3 - t2;
+  int stats[3] = {0, 0, 0};
+  mods_ransac_set_device(c->device);
+  if ((rc = mods_loransac_h(c->h_u6.data(), c->h_laf.data(), nu, &par->ransac, c->h_mask.data(), res->H, &res->n_inliers, stats))) return rc;
+  res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
+  res->ms_ransac = now() - t3;
+  if (matches_out) {
+    int m = 0;
+    for (int i = 0; i < nu && m < max_matches; i++)
+      if (c->h_mask[i]) {
+        const double *p = &c->h_u6[(size_t)i * 6];
+        matches_out[4 * m] = p[0]; matches_out[4 * m + 1] = p[1]; matches_out[4 * m + 2] = p[3]; matches_out[4 * m + 3] = p[4];
+        m++;
+      }
+  }
   return MODS_OK;
 }
 

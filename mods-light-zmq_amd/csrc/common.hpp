@@ -112,6 +112,9 @@ struct mods_ctx {
   double *m_laf = nullptr;           // [pad][14] frames (x y a11 a12 a21 a22 s) of both regions
   int *m_count = nullptr;
   mods_region *m_regs = nullptr;     // [2][max_cand] staging for host-side lists
+  std::vector<mods_tentative> h_tent;  // host copies for the sequential stages
+  std::vector<double> h_u6, h_laf;
+  std::vector<unsigned char> h_mask;
   // timing
   int timing_mask = 0;
   mods::StageTimer timers[MODS_STAGE_COUNT];
@@ -150,5 +153,6 @@ int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, c
 int describe_configure(mods_ctx *ctx, const mods_describe_params *par);
 int launch_dominant_angle_test(mods_ctx *ctx, const float *patch_dev, int ps, double th, float *out_dev);
 int launch_sift_patch_test(mods_ctx *ctx, const float *patch_dev, int ps, int root, double max_bin, uint8_t *out_dev);
+
 
 }  // namespace mods

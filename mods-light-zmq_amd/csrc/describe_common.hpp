@@ -1,0 +1,34 @@
+// Shared declarations of the orientation / description stage (describe.hip, sift.hip).
+#pragma once
+#include "common.hpp"
+
+namespace mods {
+
+struct DescConst {
+  int w, h;
+  int max_cand, max_reg;   // strides of the key / region lists
+  int reg_cap;             // regions that can be described per image (patch store capacity)
+  double ks;               // synth-detection.cpp:21  k_sigma = 2*3*sqrt(3)
+  int ori_ps;
+  double ori_i2p;          // imageToPatchScale of DetectOrientation = (2*int(mrSize)+1)/patchSize
+  int max_angles;
+  double ori_th;
+  double desc_mr;
+  int desc_ps;
+  int photo, root;
+  double max_bin;
+  int p2_lo, p2_hi;        // size tier handled by a launch: p2_lo < P2 <= p2_hi (P2 = 0: direct branch)
+  size_t scratch_stride;   // floats per block
+  int tap_cap;
+};
+
+struct SiftTab {           // precomputeBinsAndWeights, siftdesc.cpp:22-71 (host built, patchSize <= 64)
+  int bin0[64], bin1[64];  // already multiplied by orientationBins
+  float w0[64], w1[64];    // stored as double in the reference but float valued
+};
+
+// sift.hip
+int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, DescConst k, const float *dmask, const SiftTab *tab);
+int launch_sift_patch_test(mods_ctx *ctx, const float *patch_dev, int ps, int root, double max_bin, uint8_t *out_dev);
+
+}  // namespace mods

@@ -1,0 +1,654 @@
+// Measurement-region extraction (DescribeRegions<>, non-fast branch) and SIFT / RootSIFT.
+//
+// Reference behaviour (file:line relative to the reference root):
+//   DescribeRegions<SIFTDescriptor>           synth-detection.hpp:170-263
+//   interpolate / gaussianBlurInplace         detectors/helpers.cpp:551-626, 726-731
+//   photometricallyNormalize                  detectors/helpers.cpp:666-715
+//   SIFTDescriptor                            matching/siftdesc.cpp:22-131, 133-158, 199-263, 346-400
+//
+// Two kernels per batch:
+//   extract : one workgroup per region -> the ps x ps patch (before photometric normalisation),
+//             written to HBM.  The reference samples a P2 x P2 region (P2 = 2*ceil(s*mrSize)+3), blurs
+//             all of it and resamples 41 x 41 points on an axis-aligned grid.  Only the blurred values
+//             at the <= 2ps grid rows x 2ps grid columns are ever read, so the row pass runs on every row
+//             but only the needed columns and the column pass only on the needed (row, column) pairs -
+//             each value computed exactly as the full blur would.  Regions with P2 <= 80 keep the
+//             sampled region and the row-pass strip in LDS; larger ones use an HBM slab per workgroup.
+//   sift    : one workgroup per region: photometric normalisation, gradients, 4x4x8 histogram,
+//             normalisation, quantisation.
+// Every floating-point accumulation the reference performs sequentially keeps its order: sample
+// coordinates (each thread replays the additions up to its first sample), histogram bins (one lane per
+// bin, pixels in raster order), photometric sums and descriptor norms (one lane).
+#include "describe_common.hpp"
+#include "detmath.hpp"
+#include "device_util.hpp"
+
+namespace mods {
+
+constexpr int SMALL_CAP = 80;   // P2 limit of the LDS-resident extraction tier
+
+struct RegionGeom {             // per-region constants of DescribeRegions
+  int P2;                       // 0: direct branch (imageToPatchScale <= 0.4)
+  float scale;                  // imageToPatchScale
+  float fx, fy, f11, f12, f21, f22;
+};
+
+__device__ __forceinline__ RegionGeom region_geom(const mods_region &r, double desc_mr, int ps) {
+  RegionGeom g;
+  const float mrScale = (float)ceil(r.s * desc_mr);
+  const int P = 2 * int(mrScale) + 1;
+  g.scale = float(P) / float(ps);
+  g.P2 = ((double)g.scale > 0.4) ? P + 2 : 0;
+  g.fx = (float)r.x; g.fy = (float)r.y;
+  g.f11 = (float)r.a11; g.f12 = (float)r.a12; g.f21 = (float)r.a21; g.f22 = (float)r.a22;
+  return g;
+}
+
+// interpolate(img, x, y, A) -> dst (n x n, row-major), helpers.cpp:551-626.  All 256 threads take a
+// contiguous run of samples in raster order; the running coordinates of a run are rebuilt by
+// replaying the reference's fp32 additions (row steps, then column steps) up to its first sample.
+__device__ void sample_region(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12, float a21,
+                              float a22, int n, float *dst) {
+  const bool touch = check_borders(w, h, fx, fy, a11, a12, a21, a22, n, n);
+  const int half = n / 2;
+  const int total = n * n;
+  const int L = (total + 255) / 256;
+  int idx = threadIdx.x * L;
+  if (idx >= total) return;
+  int row = idx / n, col = idx - row * n;
+  float rx = fx - (float)half * a12;
+  float ry = fy - (float)half * a22;
+  for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
+  float WX = rx - (float)half * a11;
+  float WY = ry - (float)half * a21;
+  for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
+  const int end = min(total, idx + L);
+  for (; idx < end; idx++) {
+    dst[idx] = bilinear_tap(img, w, h, WX, WY, touch);
+    if (++col == n) {
+      col = 0;
+      rx += a12; ry += a22;
+      WX = rx - (float)half * a11;
+      WY = ry - (float)half * a21;
+    } else { WX += a11; WY += a21; }
+  }
+}
+
+// Gaussian taps for sigma (getGaussianKernel CV_32F) into s_tap; resampling sequence X_i (= Y_i) of
+// interpolate(smoothed, c0, c0, scale, 0, 0, scale) into s_seq and the two source indices of every
+// grid line into s_cidx.  Needs 2 doubles of scratch (s_red).  Ends with a barrier.
+__device__ void blur_setup(int P2, float scale, int ps, int n_tap, float *s_tap, float *s_seq, int *s_cidx, double *s_red) {
+  const int tid = threadIdx.x;
+  const double sig = (double)(1.5f * scale);
+  const double scale2X = -0.5 / (sig * sig);
+  for (int i = tid; i < n_tap; i += 256) {
+    const double x = i - (n_tap - 1) * 0.5;
+    s_tap[i] = (float)det_exp(scale2X * x * x);
+  }
+  if (tid == 64) {   // a different wave than the tap normalisation below
+    const float c0 = (float)(P2 >> 1);
+    float v = c0 - (float)(ps / 2) * scale;
+    for (int i = 0; i < ps; i++) {
+      s_seq[i] = v;
+      const int fl = (int)floorf(v);
+      int i0 = fl, i1 = fl + 1;
+      i0 = i0 < 0 ? 0 : (i0 > P2 - 1 ? P2 - 1 : i0);
+      i1 = i1 < 0 ? 0 : (i1 > P2 - 1 ? P2 - 1 : i1);
+      s_cidx[2 * i] = i0;
+      s_cidx[2 * i + 1] = i1;
+      v += scale;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double sum = 0;
+    for (int i = 0; i < n_tap; i++) sum += s_tap[i];
+    s_red[0] = 1. / sum;
+  }
+  __syncthreads();
+  for (int i = tid; i < n_tap; i += 256) s_tap[i] = (float)(s_tap[i] * s_red[0]);
+  __syncthreads();
+}
+
+// row pass of the separable blur at the needed columns: T[y][q] = sum_j tap[j] * S[y][clamp(cidx[q]-r+j)]
+__device__ __forceinline__ void row_pass(const float *S, float *T, int rows, int P2, int ps2, int n_tap, const float *s_tap,
+                                         const int *s_cidx) {
+  const int r_tap = n_tap >> 1;
+  for (int e = threadIdx.x; e < rows * ps2; e += 256) {
+    const int y = e / ps2, q = e - y * ps2;
+    const int x = s_cidx[q];
+    const float *row = S + (size_t)y * P2;
+    float s;
+    if (x - r_tap >= 0 && x + r_tap <= P2 - 1) {   // interior: no clamping, loads batched four at a time
+      const float *p = row + x - r_tap;
+      s = s_tap[0] * p[0];
+      int j = 1;
+      for (; j + 3 < n_tap; j += 4) {
+        const float v0 = p[j], v1 = p[j + 1], v2 = p[j + 2], v3 = p[j + 3];
+        s += s_tap[j] * v0; s += s_tap[j + 1] * v1; s += s_tap[j + 2] * v2; s += s_tap[j + 3] * v3;
+      }
+      for (; j < n_tap; j++) s += s_tap[j] * p[j];
+    } else {
+      int x0 = x - r_tap; x0 = x0 < 0 ? 0 : x0;
+      s = s_tap[0] * row[x0];
+      for (int j = 1; j < n_tap; j++) {
+        int xx = x - r_tap + j;
+        xx = xx < 0 ? 0 : (xx > P2 - 1 ? P2 - 1 : xx);
+        s += s_tap[j] * row[xx];
+      }
+    }
+    T[e] = s;
+  }
+}
+
+// column pass value at (needed row y, strip column q): centre tap first, symmetric pairs
+__device__ __forceinline__ float col_value(const float *T, int P2, int ps2, int y, int q, int r_tap, const float *s_tap) {
+  float s = s_tap[r_tap] * T[(size_t)y * ps2 + q];
+  if (y - r_tap >= 0 && y + r_tap <= P2 - 1) {
+    const float *c = T + (size_t)y * ps2 + q;
+    int j = 1;
+    for (; j + 1 <= r_tap; j += 2) {
+      const float p0 = c[(size_t)j * ps2], m0 = c[-(ptrdiff_t)j * ps2];
+      const float p1 = c[(size_t)(j + 1) * ps2], m1 = c[-(ptrdiff_t)(j + 1) * ps2];
+      s += s_tap[r_tap + j] * (p0 + m0);
+      s += s_tap[r_tap + j + 1] * (p1 + m1);
+    }
+    for (; j <= r_tap; j++) s += s_tap[r_tap + j] * (c[(size_t)j * ps2] + c[-(ptrdiff_t)j * ps2]);
+  } else {
+    for (int j = 1; j <= r_tap; j++) {
+      int yp = y + j; yp = yp > P2 - 1 ? P2 - 1 : yp;
+      int ym = y - j; ym = ym < 0 ? 0 : ym;
+      s += s_tap[r_tap + j] * (T[(size_t)yp * ps2 + q] + T[(size_t)ym * ps2 + q]);
+    }
+  }
+  return s;
+}
+
+// column pass fused with interpolate(smoothed, c0, c0, scale, 0, 0, scale): every blurred value is
+// used by exactly one output pixel, so it is produced where it is consumed.
+__device__ __forceinline__ void col_resample(const float *T, int P2, int ps, int n_tap, float scale, const float *s_tap,
+                                             const float *s_seq, const int *s_cidx, float *patch_out) {
+  const int ps2 = 2 * ps, r_tap = n_tap >> 1;
+  const float c0 = (float)(P2 >> 1);
+  const bool touch2 = check_borders(P2, P2, c0, c0, scale, 0.f, 0.f, scale, ps, ps);
+  for (int p = threadIdx.x; p < ps * ps; p += 256) {
+    const int j = p / ps, i = p - j * ps;
+    const float WX = s_seq[i], WY = s_seq[j];
+    const int x = touch2 ? (int)floorf(WX) : (int)WX;
+    const int y = touch2 ? (int)floorf(WY) : (int)WY;
+    float v = 0.f;
+    if (!touch2 || (WX >= 0 && WY >= 0 && x < P2 - 1 && y < P2 - 1)) {
+      const int y0 = s_cidx[2 * j], y1 = s_cidx[2 * j + 1];
+      const float r00 = col_value(T, P2, ps2, y0, 2 * i, r_tap, s_tap);
+      const float r01 = col_value(T, P2, ps2, y0, 2 * i + 1, r_tap, s_tap);
+      const float r10 = col_value(T, P2, ps2, y1, 2 * i, r_tap, s_tap);
+      const float r11 = col_value(T, P2, ps2, y1, 2 * i + 1, r_tap, s_tap);
+      const float wx = WX - (float)x;
+      const float I1 = wx * (r01 - r00) + r00;
+      v = (WY - y) * (wx * (r11 - r10) + r10 - I1) + I1;
+    }
+    patch_out[p] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// extract, LDS tier: direct branch and P2 <= SMALL_CAP.  grid = (N, n_img), block = 256.
+// dynamic LDS: S cap*cap | T cap*2ps | cx,cy aliases S | seq 2ps | cidx 2ps | taps 32 | red 2 doubles
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void extract_small_kernel(const float *__restrict__ img_all, DescConst k,
+                                                            const mods_region *__restrict__ reg_all, const int *__restrict__ reg_count,
+                                                            float *__restrict__ patches) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ps = k.desc_ps, pp = ps * ps, ps2 = 2 * ps;
+  float *s_S = smem;
+  float *s_T = s_S + SMALL_CAP * SMALL_CAP;
+  float *s_seq = s_T + SMALL_CAP * ps2;
+  int *s_cidx = (int *)(s_seq + ps2);
+  float *s_tap = (float *)(s_cidx + ps2);
+  double *s_red = (double *)(((uintptr_t)(s_tap + 32) + 7) & ~(uintptr_t)7);
+  const int b = blockIdx.y;
+  const float *img = img_all + (size_t)k.w * k.h * b;
+  const mods_region *reg = reg_all + (size_t)b * k.max_reg;
+  int n = reg_count[b];
+  if (n > k.reg_cap) n = k.reg_cap;
+  for (int ri = blockIdx.x; ri < n; ri += gridDim.x) {
+    const RegionGeom g = region_geom(reg[ri], k.desc_mr, ps);
+    if (g.P2 > SMALL_CAP) continue;
+    float *out = patches + ((size_t)b * k.reg_cap + ri) * pp;
+    __syncthreads();
+    if (g.P2 > 0) {
+      const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
+      sample_region(img, k.w, k.h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, g.P2, s_S);
+      blur_setup(g.P2, g.scale, ps, n_tap, s_tap, s_seq, s_cidx, s_red);
+      row_pass(s_S, s_T, g.P2, g.P2, ps2, n_tap, s_tap, s_cidx);
+      __syncthreads();
+      col_resample(s_T, g.P2, ps, n_tap, g.scale, s_tap, s_seq, s_cidx, out);
+    } else {
+      // direct branch: interpolate(img, x, y, A*scale) -> ps x ps
+      sample_region(img, k.w, k.h, g.fx, g.fy, g.f11 * g.scale, g.f12 * g.scale, g.f21 * g.scale, g.f22 * g.scale, ps, out);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// extract, HBM tier (P2 > SMALL_CAP): phase kernels over a device-built work list, so that a large
+// region is spread over many workgroups.  Per region a slab is reserved in the pool:
+//   header (taps n_tap | seq ps | cidx 2ps ints, padded to HDR floats) | S (P2 x P2) | T (P2 x 2ps)
+// ---------------------------------------------------------------------------------------
+constexpr int BIG_RC = 32;            // sample / row-pass rows per work item
+struct BigRegion { int img, ri, P2, n_tap; unsigned long long slab; float scale; int pad; };   // slab: float offset in the pool
+struct BigLists {                     // device-resident bookkeeping, zeroed before every batch
+  int n_regions, n_items;
+  unsigned long long pool_used;
+};
+
+__device__ __forceinline__ int big_hdr_floats(int n_tap, int ps) { return (n_tap + 3 * ps + 8 + 3) & ~3; }
+
+// grid = (ceil(reg_cap/256), n_img), block 256: reserve slabs, emit (region, row chunk) work items
+__global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mods_region *__restrict__ reg_all,
+                                                           const int *__restrict__ reg_count, BigLists *__restrict__ bl,
+                                                           BigRegion *__restrict__ regions, int2 *__restrict__ items, int max_regions,
+                                                           int max_items, unsigned long long pool_elems, int *__restrict__ err_flag) {
+  const int b = blockIdx.y;
+  int n = reg_count[b];
+  if (n > k.reg_cap) n = k.reg_cap;
+  const int ri = blockIdx.x * 256 + threadIdx.x;
+  if (ri >= n) return;
+  const RegionGeom g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps);
+  if (g.P2 <= SMALL_CAP) return;
+  const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
+  const unsigned long long need = (unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + (unsigned long long)g.P2 * g.P2 +
+                                  (unsigned long long)g.P2 * 2 * k.desc_ps;
+  const int li = atomicAdd(&bl->n_regions, 1);
+  const int chunks = (g.P2 + BIG_RC - 1) / BIG_RC;
+  const unsigned long long off = atomicAdd(&bl->pool_used, need);
+  const int it0 = atomicAdd(&bl->n_items, chunks);
+  if (li >= max_regions || off + need > pool_elems || it0 + chunks > max_items) { atomicExch(err_flag, 1); return; }
+  BigRegion br;
+  br.img = b; br.ri = ri; br.P2 = g.P2; br.n_tap = n_tap; br.slab = off; br.scale = g.scale; br.pad = 0;
+  regions[li] = br;
+  for (int c = 0; c < chunks; c++) items[it0 + c] = make_int2(li, c * BIG_RC);
+}
+
+// grid-stride over the big regions, block 256: taps / resampling sequence into the slab header
+__global__ __launch_bounds__(256) void big_setup_kernel(DescConst k, const BigLists *__restrict__ bl, const BigRegion *__restrict__ regions,
+                                                        int max_regions, float *__restrict__ pool) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // taps tap_cap | seq ps | cidx 2ps | red
+  const int ps = k.desc_ps, ps2 = 2 * ps;
+  float *s_tap = smem;
+  float *s_seq = s_tap + k.tap_cap;
+  int *s_cidx = (int *)(s_seq + ps2);
+  double *s_red = (double *)(((uintptr_t)(s_cidx + ps2) + 7) & ~(uintptr_t)7);
+  const int n = min(bl->n_regions, max_regions);
+  for (int li = blockIdx.x; li < n; li += gridDim.x) {
+    const BigRegion br = regions[li];
+    if (br.n_tap > k.tap_cap) continue;   // flagged by the host-visible error path in the sample kernel
+    __syncthreads();
+    blur_setup(br.P2, br.scale, ps, br.n_tap, s_tap, s_seq, s_cidx, s_red);
+    float *hdr = pool + br.slab;
+    for (int i = threadIdx.x; i < br.n_tap; i += 256) hdr[i] = s_tap[i];
+    for (int i = threadIdx.x; i < ps; i += 256) hdr[br.n_tap + i] = s_seq[i];
+    for (int i = threadIdx.x; i < ps2; i += 256) ((int *)(hdr + br.n_tap + ps))[i] = s_cidx[i];
+  }
+}
+
+// grid-stride over the work items, block 256: rows [r0, r0+BIG_RC) of S = interpolate(img, x, y, A)
+__global__ __launch_bounds__(256) void big_sample_kernel(const float *__restrict__ img_all, DescConst k, const BigLists *__restrict__ bl,
+                                                         const BigRegion *__restrict__ regions, const int2 *__restrict__ items,
+                                                         int max_items, const mods_region *__restrict__ reg_all,
+                                                         float *__restrict__ pool, int *__restrict__ err_flag) {
+  const int n_items = min(bl->n_items, max_items);
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int2 item = items[it];
+    const BigRegion br = regions[item.x];
+    if (br.n_tap > k.tap_cap) { if (threadIdx.x == 0) atomicExch(err_flag, 1); continue; }
+    const RegionGeom g = region_geom(reg_all[(size_t)br.img * k.max_reg + br.ri], k.desc_mr, k.desc_ps);
+    const float *img = img_all + (size_t)k.w * k.h * br.img;
+    float *S = pool + br.slab + big_hdr_floats(br.n_tap, k.desc_ps);
+    const int P2 = br.P2;
+    const int r0 = item.y, r1 = min(P2, r0 + BIG_RC);
+    const bool touch = check_borders(k.w, k.h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, P2, P2);
+    const int half = P2 / 2;
+    const int total = (r1 - r0) * P2;
+    const int L = (total + 255) / 256;
+    int idx = threadIdx.x * L;
+    if (idx >= total) continue;
+    int row = r0 + idx / P2, col = idx % P2;
+    float rx = g.fx - (float)half * g.f12;
+    float ry = g.fy - (float)half * g.f22;
+    for (int q = 0; q < row; q++) { rx += g.f12; ry += g.f22; }
+    float WX = rx - (float)half * g.f11;
+    float WY = ry - (float)half * g.f21;
+    for (int q = 0; q < col; q++) { WX += g.f11; WY += g.f21; }
+    const int end = min(total, idx + L);
+    float *dst = S + (size_t)r0 * P2;
+    for (; idx < end; idx++) {
+      dst[idx] = bilinear_tap(img, k.w, k.h, WX, WY, touch);
+      if (++col == P2) {
+        col = 0;
+        rx += g.f12; ry += g.f22;
+        WX = rx - (float)half * g.f11;
+        WY = ry - (float)half * g.f21;
+      } else { WX += g.f11; WY += g.f21; }
+    }
+  }
+}
+
+// grid-stride over the work items, block 256: rows [r0, r0+BIG_RC) of the row-pass strip T
+__global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const BigLists *__restrict__ bl, const BigRegion *__restrict__ regions,
+                                                          const int2 *__restrict__ items, int max_items, float *__restrict__ pool) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // taps tap_cap | cidx 2ps
+  const int ps = k.desc_ps, ps2 = 2 * ps;
+  float *s_tap = smem;
+  int *s_cidx = (int *)(s_tap + k.tap_cap);
+  const int n_items = min(bl->n_items, max_items);
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int2 item = items[it];
+    const BigRegion br = regions[item.x];
+    if (br.n_tap > k.tap_cap) continue;
+    const float *hdr = pool + br.slab;
+    __syncthreads();
+    for (int i = threadIdx.x; i < br.n_tap; i += 256) s_tap[i] = hdr[i];
+    for (int i = threadIdx.x; i < ps2; i += 256) s_cidx[i] = ((const int *)(hdr + br.n_tap + ps))[i];
+    __syncthreads();
+    const int P2 = br.P2;
+    const float *S = hdr + big_hdr_floats(br.n_tap, ps);
+    float *T = (float *)S + (size_t)P2 * P2;
+    const int r0 = item.y, r1 = min(P2, r0 + BIG_RC);
+    row_pass(S + (size_t)r0 * P2, T + (size_t)r0 * ps2, r1 - r0, P2, ps2, br.n_tap, s_tap, s_cidx);
+  }
+}
+
+// grid-stride over the big regions, block 256: column pass + resampling -> patch
+__global__ __launch_bounds__(256) void big_colres_kernel(DescConst k, const BigLists *__restrict__ bl, const BigRegion *__restrict__ regions,
+                                                         int max_regions, const float *__restrict__ pool, float *__restrict__ patches) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // taps tap_cap | seq ps | cidx 2ps
+  const int ps = k.desc_ps, ps2 = 2 * ps, pp = ps * ps;
+  float *s_tap = smem;
+  float *s_seq = s_tap + k.tap_cap;
+  int *s_cidx = (int *)(s_seq + ps2);
+  const int n = min(bl->n_regions, max_regions);
+  for (int li = blockIdx.x; li < n; li += gridDim.x) {
+    const BigRegion br = regions[li];
+    if (br.n_tap > k.tap_cap) continue;
+    const float *hdr = pool + br.slab;
+    __syncthreads();
+    for (int i = threadIdx.x; i < br.n_tap; i += 256) s_tap[i] = hdr[i];
+    for (int i = threadIdx.x; i < ps; i += 256) s_seq[i] = hdr[br.n_tap + i];
+    for (int i = threadIdx.x; i < ps2; i += 256) s_cidx[i] = ((const int *)(hdr + br.n_tap + ps))[i];
+    __syncthreads();
+    const float *T = hdr + big_hdr_floats(br.n_tap, ps) + (size_t)br.P2 * br.P2;
+    col_resample(T, br.P2, ps, br.n_tap, br.scale, s_tap, s_seq, s_cidx, patches + ((size_t)br.img * k.reg_cap + br.ri) * pp);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// photometric normalisation + SIFT on a patch held in LDS (block = 256)
+// ---------------------------------------------------------------------------------------
+// one lane: sequential fp32 sum of n contiguous LDS floats, loads batched eight at a time
+__device__ __forceinline__ float ordered_sum(const float *v, int n) {
+  float s = 0;
+  int q = 0;
+  for (; q + 7 < n; q += 8) {
+    const float4 a = *(const float4 *)(v + q), b = *(const float4 *)(v + q + 4);
+    s += a.x; s += a.y; s += a.z; s += a.w; s += b.x; s += b.y; s += b.z; s += b.w;
+  }
+  for (; q < n; q++) s += v[q];
+  return s;
+}
+
+// photometricallyNormalize, helpers.cpp:666-715.  s_midx: masked pixels in raster order; s_g: scratch
+// (16-byte aligned, >= n_mask floats).
+__device__ void photonorm_patch(float *s_patch, const unsigned short *s_midx, int n_mask, float *s_g, int pp, float *s_red) {
+  const int tid = threadIdx.x;
+  for (int q = tid; q < n_mask; q += 256) s_g[q] = s_patch[s_midx[q]];
+  __syncthreads();
+  if (tid == 0) s_red[0] = ordered_sum(s_g, n_mask) / (float)n_mask;   // gsum counts the masked pixels exactly
+  __syncthreads();
+  const float sum = s_red[0];
+  for (int q = tid; q < n_mask; q += 256) { const float d = sum - s_g[q]; s_g[q] = d * d; }
+  __syncthreads();
+  if (tid == 0) s_red[1] = sqrtf(ordered_sum(s_g, n_mask) / (float)n_mask);
+  __syncthreads();
+  const float var = s_red[1];
+  if (!((double)var < 0.0001)) {
+    const float fac = 50.0f / var;
+    for (int p = tid; p < pp; p += 256) {
+      float v = 128 + fac * (s_patch[p] - sum);
+      if (v > 255) v = 255;
+      if (v < 0) v = 0;
+      s_patch[p] = v;
+    }
+  }
+  __syncthreads();
+}
+
+// computeRootSiftDescriptor / computeSiftDescriptor + norms.  s_px: {mask*grad, wo1} per pixel,
+// s_bo: first orientation bin per pixel, s_wr / s_wc: per spatial bin effective row / column weights
+// [4][ps] (built per workgroup by sift_tables), s_vec: 128 doubles, s_red: 2 doubles.
+__device__ void sift_tables(const SiftTab *__restrict__ tab, int ps, float *s_wr) {
+  // weight of pixel line i for spatial bin b: the reference visits (bin0, w0) and (bin1, w1); when
+  // both name the same bin one of the weights is 0 (clamped), so the sum is the surviving weight.
+  for (int e = threadIdx.x; e < 4 * ps; e += 256) {
+    const int b8 = (e / ps) * 8, i = e - (e / ps) * ps;
+    float w = 0.f;
+    if (tab->bin0[i] == b8) w += tab->w0[i];
+    if (tab->bin1[i] == b8) w += tab->w1[i];
+    s_wr[e] = w;
+  }
+}
+
+__device__ void sift_from_patch(const float *s_patch, const float *__restrict__ mask, const float *s_w, int ps, bool rootsift,
+                                double max_bin, float2 *s_px, unsigned char *s_bo, double *s_vec, double *s_red, uint8_t *out) {
+  const int tid = threadIdx.x;
+  const int pp = ps * ps;
+  const double M_PI_DOUBLED = 6.28318530718;
+  for (int p = tid; p < pp; p += 256) {
+    const int r = p / ps, c = p - r * ps;
+    float xgrad, ygrad;
+    if (c == 0) xgrad = s_patch[p + 1] - s_patch[p];
+    else if (c == ps - 1) xgrad = s_patch[p] - s_patch[p - 1];
+    else xgrad = s_patch[p + 1] - s_patch[p - 1];
+    if (r == 0) ygrad = s_patch[p + ps] - s_patch[p];
+    else if (r == ps - 1) ygrad = s_patch[p] - s_patch[p - ps];
+    else ygrad = s_patch[p + ps] - s_patch[p - ps];
+    const float grad = sqrtf(xgrad * xgrad + ygrad * ygrad);
+    const float ori = atan2_lut_ff(ygrad, xgrad);
+    const float o = (float)(8.0f * ((double)ori + M_PI_DOUBLED) / M_PI_DOUBLED);
+    const int bo0 = (int)o;
+    s_px[p] = make_float2(mask[p] * grad, o - bo0);
+    s_bo[p] = (unsigned char)(bo0 % 8);
+  }
+  __syncthreads();
+  // samplePatch (siftdesc.cpp:73-131): thread t < 128 owns vec[t], t = br*32 + bc*8 + bo, and visits
+  // its block of pixels in raster order.  Per pixel exactly one (row weight, column weight) pair is
+  // non-zero for this bin; pixels whose two orientation bins miss `bo` add +0.0 (no effect).
+  if (tid < 128) {
+    const int br = tid >> 5, bc = (tid >> 3) & 3, bo = tid & 7;
+    const float *wr = s_w + br * ps, *wc = s_w + bc * ps;
+    int rlo = ps, rhi = 0, clo = ps, chi = 0;
+    for (int i = 0; i < ps; i++) {
+      if (wr[i] > 0) { rlo = min(rlo, i); rhi = i + 1; }
+      if (wc[i] > 0) { clo = min(clo, i); chi = i + 1; }
+    }
+    double acc = 0.0;
+    for (int r = rlo; r < rhi; r++) {
+      const float wrr = wr[r];
+      const float2 *px = s_px + r * ps;
+      const unsigned char *bop = s_bo + r * ps;
+      for (int c = clo; c < chi; c++) {
+        const float2 pv = px[c];
+        const int bo0 = bop[c];
+        const float wcc = (float)((double)wc[c] * pv.x);
+        const float val = wrr * wcc;
+        const float wo1 = pv.y, wo0 = 1.0f - wo1;
+        const bool m0 = bo0 == bo, m1 = ((bo0 + 1) & 7) == bo;
+        const float wo = m0 ? wo0 : wo1;
+        const float contrib = ((m0 || m1) && val > 0) ? val * wo : 0.0f;
+        acc += (double)contrib;
+      }
+    }
+    s_vec[tid] = acc;
+  }
+  __syncthreads();
+  // normalize (siftdesc.cpp:133-158) / clip / renormalise (:199-210, :248-257)
+  for (int pass = 0; pass < 2; pass++) {
+    if (tid == 0) {
+      double len = 0.0;
+      for (int i = 0; i < 128; i += 4) {
+        const double sq0 = s_vec[i] * s_vec[i], sq1 = s_vec[i + 1] * s_vec[i + 1];
+        const double sq2 = s_vec[i + 2] * s_vec[i + 2], sq3 = s_vec[i + 3] * s_vec[i + 3];
+        len += sq0 + sq1 + sq2 + sq3;
+      }
+      len = sqrt(len);
+      s_red[0] = 1.0 / len;
+    }
+    __syncthreads();
+    bool changed = false;
+    if (tid < 128) {
+      double v = s_vec[tid] * s_red[0];
+      if (pass == 0 && v > max_bin) { v = max_bin; changed = true; }
+      s_vec[tid] = v;
+    }
+    const int any = __syncthreads_or(changed ? 1 : 0);
+    if (!any) break;
+  }
+  if (rootsift) {
+    if (tid == 0) {
+      double sum = 0.;
+      for (int i = 0; i < 128; i++) sum += fabs(s_vec[i]);
+      s_red[1] = sum;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const double v = sqrt(s_vec[tid] / s_red[1]);
+      int bq = (int)(512.0 * v + 0.5);
+      bq = bq < 255 ? bq : 255;
+      bq = bq > 0 ? bq : 0;
+      out[tid] = (uint8_t)bq;
+    }
+  } else if (tid < 128) {
+    int bq = (int)(512.0 * s_vec[tid] + 0.5);
+    bq = bq < 255 ? bq : 255;
+    bq = bq > 0 ? bq : 0;
+    out[tid] = (uint8_t)bq;
+  }
+  __syncthreads();
+}
+
+struct SiftLds {   // carve of the dynamic LDS of the SIFT kernels
+  float *patch, *g, *w; float2 *px; unsigned char *bo; unsigned short *midx; double *vec, *red; float *redf;
+  __device__ SiftLds(float *base, int ps) {
+    const int pp = ps * ps, ppa = (pp + 3) & ~3;
+    patch = base;
+    g = patch + ppa;
+    px = (float2 *)(g + ppa);
+    w = (float *)(px + ppa);
+    vec = (double *)(((uintptr_t)(w + 4 * ps) + 7) & ~(uintptr_t)7);
+    red = vec + 128;
+    redf = (float *)(red + 2);
+    midx = (unsigned short *)(redf + 4);
+    bo = (unsigned char *)(midx + ppa);
+  }
+};
+static size_t sift_lds_bytes(int ps) {
+  const size_t ppa = ((size_t)ps * ps + 3) & ~(size_t)3;
+  return sizeof(float) * (2 * ppa + 2 * ppa + 4 * ps + 4) + sizeof(double) * 130 + sizeof(unsigned short) * ppa + ppa + 32;
+}
+
+// grid = (N, n_img), block = 256: patches -> descriptors
+__global__ __launch_bounds__(256) void sift_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
+                                                   const int *__restrict__ reg_count, const float *__restrict__ mask,
+                                                   const SiftTab *__restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ps = k.desc_ps, pp = ps * ps;
+  SiftLds L(smem, ps);
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  sift_tables(tab, ps, L.w);
+  if (tid < 64) {   // raster-ordered list of the masked pixels, one wave, ballot compaction
+    int c = 0;
+    for (int base = 0; base < pp; base += 64) {
+      const int p = base + tid;
+      const bool m = p < pp && mask[p] > 0;
+      const unsigned long long bm = __ballot(m);
+      if (m) L.midx[c + __popcll(bm & ((1ull << tid) - 1ull))] = (unsigned short)p;
+      c += __popcll(bm);
+    }
+    if (tid == 0) ((int *)L.redf)[2] = c;
+  }
+  __syncthreads();
+  const int n_mask = ((int *)L.redf)[2];
+  mods_region *reg = reg_all + (size_t)b * k.max_reg;
+  int n = reg_count[b];
+  if (n > k.reg_cap) n = k.reg_cap;
+  for (int ri = blockIdx.x; ri < n; ri += gridDim.x) {
+    const float *src = patches + ((size_t)b * k.reg_cap + ri) * pp;
+    __syncthreads();
+    for (int p = tid; p < pp; p += 256) L.patch[p] = src[p];
+    __syncthreads();
+    if (k.photo) photonorm_patch(L.patch, L.midx, n_mask, L.g, pp, L.redf);
+    sift_from_patch(L.patch, mask, L.w, ps, k.root != 0, k.max_bin, L.px, L.bo, L.vec, L.red, reg[ri].desc);
+  }
+}
+
+__global__ __launch_bounds__(256) void sift_patch_test_kernel(const float *__restrict__ patch, int ps, int root, double max_bin,
+                                                              const float *__restrict__ mask, const SiftTab *__restrict__ tab,
+                                                              uint8_t *out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  SiftLds L(smem, ps);
+  sift_tables(tab, ps, L.w);
+  for (int p = threadIdx.x; p < ps * ps; p += 256) L.patch[p] = patch[p];
+  __syncthreads();
+  sift_from_patch(L.patch, mask, L.w, ps, root != 0, max_bin, L.px, L.bo, L.vec, L.red, out);
+}
+
+// ---------------------------------------------------------------------------------------
+int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, DescConst k, const float *dmask, const SiftTab *tab) {
+  StageScope ts(ctx, MODS_STAGE_DESCRIBE);
+  const int ps = k.desc_ps, ps2 = 2 * ps, pp = ps * ps;
+  // HBM layout of the description scratch: patch store [n_img][reg_cap][ps*ps] | big-tier bookkeeping | slab pool
+  const size_t patch_elems = (size_t)n_img * k.reg_cap * pp;
+  const int max_big = 1 << 16, max_items = 1 << 19;
+  const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + sizeof(int2) * max_items + 15) / 4;
+  const unsigned long long pool_elems = 768ull << 20;   // 3 GiB of slabs
+  const size_t need = patch_elems + book_elems + pool_elems;
+  if (need > ctx->desc_scratch_elems) {
+    MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->desc_scratch) MODS_HIP_CHECK(hipFree(ctx->desc_scratch));
+    ctx->desc_scratch = nullptr;
+    MODS_HIP_CHECK(hipMalloc(&ctx->desc_scratch, need * sizeof(float)));
+    ctx->desc_scratch_elems = need;
+  }
+  float *patches = ctx->desc_scratch;
+  BigLists *bl = (BigLists *)(ctx->desc_scratch + patch_elems);
+  BigRegion *bregs = (BigRegion *)(bl + 1);
+  int2 *items = (int2 *)(bregs + max_big);
+  float *pool = ctx->desc_scratch + patch_elems + book_elems;
+  MODS_HIP_CHECK(hipMemsetAsync(bl, 0, sizeof(BigLists), ctx->stream));
+  k.tap_cap = 4096;
+  const size_t ldsS = sizeof(float) * ((size_t)SMALL_CAP * SMALL_CAP + (size_t)SMALL_CAP * ps2 + 2 * ps2 + 32) + 32;
+  hipLaunchKernelGGL(extract_small_kernel, dim3(2048, n_img), dim3(256), ldsS, ctx->stream, img_dev, k, ctx->regions_dev,
+                     ctx->region_count, patches);
+  hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
+                     ctx->region_count, bl, bregs, items, max_big, max_items, pool_elems, ctx->desc_err_dev);
+  const size_t ldsH = sizeof(float) * (k.tap_cap + 4 * ps2) + 32;
+  hipLaunchKernelGGL(big_setup_kernel, dim3(1024), dim3(256), ldsH, ctx->stream, k, bl, bregs, max_big, pool);
+  hipLaunchKernelGGL(big_sample_kernel, dim3(4096), dim3(256), 0, ctx->stream, img_dev, k, bl, bregs, items, max_items,
+                     ctx->regions_dev, pool, ctx->desc_err_dev);
+  hipLaunchKernelGGL(big_rowpass_kernel, dim3(4096), dim3(256), ldsH, ctx->stream, k, bl, bregs, items, max_items, pool);
+  hipLaunchKernelGGL(big_colres_kernel, dim3(2048), dim3(256), ldsH, ctx->stream, k, bl, bregs, max_big, pool, patches);
+  hipLaunchKernelGGL(sift_kernel, dim3(2048, n_img), dim3(256), sift_lds_bytes(ps), ctx->stream, k, patches, ctx->regions_dev,
+                     ctx->region_count, dmask, tab);
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
+int launch_sift_patch_test(mods_ctx *ctx, const float *patch_dev, int ps, int root, double max_bin, uint8_t *out_dev) {
+  hipLaunchKernelGGL(sift_patch_test_kernel, dim3(1), dim3(256), sift_lds_bytes(ps), ctx->stream, patch_dev, ps, root, max_bin,
+                     ctx->desc_tables_dev + 4096, (const SiftTab *)(ctx->desc_tables_dev + 8192), out_dev);
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
+}  // namespace mods

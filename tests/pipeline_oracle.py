@@ -1,0 +1,106 @@
+"""CPU oracle for the whole pair path (test infrastructure): restated detect/describe/match/duplicate
+filter + RANSAC from the reference's own degensac (oracle/_ref) when it is built."""
+import numpy as np
+
+import orc
+import refdeg
+
+
+def laf_of(ra, rb, tc):
+    a, b = ra[tc["q"]], rb[tc["t"]]
+    cols = []
+    for r in (a, b):
+        cols += [r["x"], r["y"], r["a11"], r["a12"], r["a21"], r["a22"], r["s"]]
+    return np.stack(cols, axis=1) if len(tc) else np.zeros((0, 14))
+
+
+def u6_of(ra, rb, tc):
+    n = len(tc)
+    return np.c_[ra["x"][tc["q"]], ra["y"][tc["q"]], np.ones(n), rb["x"][tc["t"]], rb["y"][tc["t"]], np.ones(n)]
+
+
+def _invert3(S):
+    S = S.ravel()
+    d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6])
+    if d == 0:
+        return np.zeros(9)
+    d = 1. / d
+    return np.array([(S[4] * S[8] - S[5] * S[7]) * d, (S[2] * S[7] - S[1] * S[8]) * d, (S[1] * S[5] - S[2] * S[4]) * d,
+                     (S[5] * S[6] - S[3] * S[8]) * d, (S[0] * S[8] - S[2] * S[6]) * d, (S[2] * S[3] - S[0] * S[5]) * d,
+                     (S[3] * S[7] - S[4] * S[6]) * d, (S[1] * S[6] - S[0] * S[7]) * d, (S[0] * S[4] - S[1] * S[3]) * d])
+
+
+def hds_sym_max(u, Hcol):
+    """HDsSymMax (Htools.c:243-283) on rows of u[n,6]; Hcol = degensac's column-major h."""
+    Hinv = np.array([Hcol[0], Hcol[3], Hcol[6], Hcol[1], Hcol[4], Hcol[7], Hcol[2], Hcol[5], Hcol[8]])
+    H1 = np.linalg.inv(Hinv.reshape(3, 3)).ravel()
+    out = []
+    for p in u:
+        a = H1[6] * p[0] + H1[7] * p[1] + H1[8]
+        b = Hinv[6] * p[3] + Hinv[7] * p[4] + Hinv[8]
+        xa = (H1[0] * p[0] + H1[1] * p[1] + H1[2]) / a
+        ya = (H1[3] * p[0] + H1[4] * p[1] + H1[5]) / a
+        d1 = (p[3] - xa) ** 2 + (p[4] - ya) ** 2
+        xa = (Hinv[0] * p[3] + Hinv[1] * p[4] + Hinv[2]) / b
+        ya = (Hinv[3] * p[3] + Hinv[4] * p[4] + Hinv[5]) / b
+        d2 = (p[0] - xa) ** 2 + (p[1] - ya) ** 2
+        out.append(max(d1, d2))
+    return np.array(out)
+
+
+def loransac_h(u6, laf, err_threshold=4.0, conf=0.99, max_samples=1000000, hlaf=12.0, sym=1, seed_time=12345):
+    """LORANSACFiltering, matching.cpp:637-805 (useF = 0), on top of the reference's exp_ransacHcustom."""
+    n = len(u6)
+    H = -np.ones(9)
+    mask = np.zeros(n, bool)
+    if n < 8:
+        return mask, H.reshape(3, 3), 0, [0, 0, 0]
+    ms = 1000 if n <= 20 else max_samples
+    r = refdeg.ransac_h(u6, err_threshold ** 2, conf, ms, "sampson", sym, seed_time)
+    stats = [r["samples"], r["lo"], r["rej"]]
+    Hl = r["H"]
+    Ht = np.array([Hl[0], Hl[3], Hl[6], Hl[1], Hl[4], Hl[7], Hl[2], Hl[5], Hl[8]])
+    Hinv = _invert3(Ht)
+    if not np.any(Hinv != 0):
+        return mask, H.reshape(3, 3), 0, stats
+    H = Hinv
+    cur = np.nonzero(r["inl"])[0]
+    Hi = _invert3(Hinv)
+    ok = 0
+    for i in cur:
+        p = u6[i]
+        xa = (Hinv[0] * p[0] + Hinv[1] * p[1] + Hinv[2]) / (Hinv[6] * p[0] + Hinv[7] * p[1] + Hinv[8])
+        ya = (Hinv[3] * p[0] + Hinv[4] * p[1] + Hinv[5]) / (Hinv[6] * p[0] + Hinv[7] * p[1] + Hinv[8])
+        d1 = (p[3] - xa) ** 2 + (p[4] - ya) ** 2
+        xa = (Hi[0] * p[3] + Hi[1] * p[4] + Hi[2]) / (Hi[6] * p[3] + Hi[7] * p[4] + Hi[8])
+        ya = (Hi[3] * p[3] + Hi[4] * p[4] + Hi[5]) / (Hi[6] * p[3] + Hi[7] * p[4] + Hi[8])
+        d2 = (p[0] - xa) ** 2 + (p[1] - ya) ** 2
+        ok += (d1 <= 100.0) and (d2 <= 100.0)
+    if ok < 8:
+        cur = cur[:0]
+    thr = 3.0 * hlaf * err_threshold
+    good = []
+    for i in cur:
+        f = laf[i]
+        u = np.zeros((3, 6))
+        u[0] = [f[0], f[1], 1, f[7], f[8], 1]
+        u[1] = [f[0] + 3.0 * f[3] * f[6], f[1] + 3.0 * f[5] * f[6], 1, f[7] + 3.0 * f[10] * f[13], f[8] + 3.0 * f[12] * f[13], 1]
+        u[2] = [f[0] + 3.0 * f[2] * f[6], f[1] + 3.0 * f[4] * f[6], 1, f[7] + 3.0 * f[9] * f[13], f[8] + 3.0 * f[11] * f[13], 1]
+        e = hds_sym_max(u, Hl)
+        if not (np.sqrt(e[0] + e[1] + e[2]) > thr):
+            good.append(i)
+    if len(good) < 8:
+        good = []
+    mask[good] = True
+    return mask, H.reshape(3, 3), len(good), stats
+
+
+def match_pair(img1, img2, seed_time=12345, ratio=0.8):
+    ra, nd1 = orc.detect_describe(img1)
+    rb, nd2 = orc.detect_describe(img2)
+    tc = orc.match_fginn(ra, rb, ratio)
+    un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
+    u6, laf = u6_of(ra, rb, un), laf_of(ra, rb, un)
+    mask, H, ninl, stats = loransac_h(u6, laf, seed_time=seed_time)
+    return dict(n_detected=[nd1, nd2], n_described=[len(ra), len(rb)], n_tentatives=len(tc), n_unique=len(un),
+                n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6)
