@@ -212,6 +212,8 @@ int mods_ransac_set_device(int device);
  * time(NULL) returned `seed`; seed < 0 restores the wall clock.  MODS_RANSAC_SEED in the environment
  * has the same effect when no seed is pinned. */
 void mods_ransac_pin_seed(long seed);
+/* self-test hook: first n values of srand(seed); rand(); ... from the restated glibc generator */
+void mods_test_glibc_rand(unsigned seed, int n, int *out);
 
 /* ---- whole hot path for one image pair ---------------------------------------------------------
  * The step loop body of mods.cpp:202-383 for one step of HessianAffine + RootSIFT on identity views:

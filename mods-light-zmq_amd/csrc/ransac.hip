@@ -279,6 +279,14 @@ void HDsidx(const double *lin, const double *mu, const double *H, double *p, int
 void HDsSymidx(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz) { HDsiSym(lin, mu, H, p, len, idx, siz); }
 void HDsSymidxMax(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz) { HDsiSymMax(lin, mu, H, p, len, idx, siz); }
 
+// first n outputs of srand(seed); rand() as the sampler sees them (host-only self-test hook: lets the
+// CPU test-suite compare the restated generator with the libc of the machine it runs on)
+void mods_test_glibc_rand(unsigned seed, int n, int *out) {
+  rs::GlibcRand g;
+  g.seed(seed);
+  for (int i = 0; i < n; i++) out[i] = g.next();
+}
+
 int mods_ransac_set_device(int device) { std::lock_guard<std::mutex> lk(g_cfg_mutex); g_ransac_device = device; return MODS_OK; }
 // seed >= 0: every call behaves as if time(NULL) returned `seed`; < 0: back to the wall clock
 void mods_ransac_pin_seed(long seed) { std::lock_guard<std::mutex> lk(g_cfg_mutex); g_pinned_seed = seed; }

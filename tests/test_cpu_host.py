@@ -1,0 +1,90 @@
+"""CPU tests (no GPU): the C ABI library loads and exports every declared symbol; host-side logic of
+libmodsgpu (restated glibc generator, duplicate filter, argument / no-device error paths)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef\s+struct\s*\w*\s*\{.*?\}\s*\w+;", "", src, flags=re.S)
+    src = re.sub(r"typedef[^;{}]*;", "", src, flags=re.S)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+    names = re.findall(r"\b([A-Za-z_]\w*)\s*\([^;{}]*\)\s*;", src)
+    return sorted(set(n for n in names if n not in ("defined",) and not n.endswith("Ptr")))
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    lib = pkg.lib()
+    names = _declared_functions("mods_hip.h") + _declared_functions("mods_degensac.h")
+    assert "mods_match_pair_dev" in names and "exp_ransacHcustom" in names and len(names) > 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_device_fails_loudly(pkg):
+    lib = pkg.lib()
+    if lib.mods_device_count() > 0:
+        return   # GPU box: covered by the -m gpu tests
+    h = C.c_void_p()
+    rc = lib.mods_ctx_create(0, 640, 480, 1, C.byref(h))
+    assert rc == -1 and b"no CPU path" in lib.mods_last_error()
+
+
+def test_glibc_generator_is_bit_exact(pkg):
+    lib = pkg.lib()
+    libc = C.CDLL(None)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "glibc_rand.npz"))
+    for seed in (1, 42, 12345, 0, 2 ** 31 + 5, 4294967295):
+        out = (C.c_int * 1000)()
+        lib.mods_test_glibc_rand(C.c_uint(seed), 1000, out)
+        libc.srand(C.c_uint(seed))
+        want = [libc.rand() for _ in range(1000)]
+        assert list(out) == want
+        if "s%d" % seed in g:
+            assert list(out) == list(g["s%d" % seed])
+
+
+def test_duplicate_filter_matches_oracle(pkg):
+    rng = np.random.default_rng(3)
+    n = 1500
+    q = np.zeros(n, orc.REGION_DTYPE); t = np.zeros(n, orc.REGION_DTYPE)
+    cl = rng.integers(0, 300, n)                                # 300 clusters of near-identical correspondences
+    cx, cy = rng.uniform(0, 800, 300), rng.uniform(0, 600, 300)
+    q["x"] = cx[cl] + rng.uniform(-1.2, 1.2, n); q["y"] = cy[cl] + rng.uniform(-1.2, 1.2, n)
+    t["x"] = 0.9 * cx[cl] + 30 + rng.uniform(-1.2, 1.2, n); t["y"] = 1.1 * cy[cl] - 10 + rng.uniform(-1.2, 1.2, n)
+    tc = np.zeros(n, orc.TENT_DTYPE)
+    tc["q"] = np.arange(n); tc["t"] = np.arange(n)
+    perm = rng.permutation(n)
+    tc = tc[perm]
+    tc["ratio"] = np.round(rng.uniform(0.2, 0.8, n), 2)        # many equal keys: stable order matters
+    tc["d1"] = rng.integers(100, 9000, n)
+    u6 = np.c_[q["x"][tc["q"]], q["y"][tc["q"]], np.ones(n), t["x"][tc["t"]], t["y"][tc["t"]], np.ones(n)]
+    for mode in (0, 1, 2):
+        for r in (2.0, 0.5, 7.0):
+            want = orc.duplicate_filter(tc, q, t, r, mode)
+            got, gu = pkg.duplicate_filter(tc, u6, r, mode)
+            assert len(got) == len(want) < n
+            for f in ("q", "t", "ratio", "d1"):
+                assert np.array_equal(got[f], want[f])
+            assert np.array_equal(gu[:, 0], q["x"][got["q"]])
+    got, _ = pkg.duplicate_filter(tc, u6, 0.0, 1)
+    assert len(got) == n                                        # r <= 0: no filtering (matching.cpp:2617)
+
+
+def test_loransac_rejects_small_sets_without_a_gpu(pkg):
+    u = np.random.default_rng(0).uniform(0, 100, (7, 6))
+    mask, H, ninl, stats = pkg.loransac_h(u, None)
+    assert ninl == 0 and not mask.any() and np.all(H == -1)     # tent_size < MIN_POINTS (matching.cpp:682-688)
+
+
+def test_struct_layouts(pkg):
+    assert pkg.REGION_DTYPE.itemsize == 208 and pkg.AFFKEY_DTYPE.itemsize == 88 and pkg.TENT_DTYPE.itemsize == 40
+    assert orc.REGION_DTYPE == pkg.REGION_DTYPE and orc.TENT_DTYPE == pkg.TENT_DTYPE

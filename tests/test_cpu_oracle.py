@@ -1,0 +1,135 @@
+"""CPU tests (no GPU): the oracle against the reference's known answers and the committed golden
+fixtures; properties of the restated primitives."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import refdeg
+import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _gray(name):
+    from PIL import Image
+    im = np.asarray(Image.open(os.path.join(GOLD, name))).astype(np.float32)
+    return (((im[..., 2] + im[..., 1]) + im[..., 0]) / np.float32(3.0)).astype(np.float32)
+
+
+def test_graf_counts_match_reference_readme():
+    """README.md:91-108 of the reference (graf1 <-> graf6, classic config): 2665 -> 2331 and 3287 -> 2912
+    regions -> descriptors.  The only known answer the reference publishes for this path; OpenCV/libm
+    builds differ in the last bit, so +-2 regions is the pin."""
+    for name, nreg, ndesc in (("graf1.png", 2665, 2331), ("graf6.png", 3287, 2912)):
+        regs, nd = orc.detect_describe(_gray(name))
+        assert abs(nd - nreg) <= 2, (name, nd)
+        assert abs(len(regs) - ndesc) <= 2, (name, len(regs))
+        norms = (regs["desc"].astype(np.int64) ** 2).sum(1)
+        assert np.all(np.abs(norms - 512 * 512) < 4000)      # RootSIFT is normalised to length 512
+
+
+def test_graf_matching_finds_the_homography():
+    ra, _ = orc.detect_describe(_gray("graf1.png"))
+    rb, _ = orc.detect_describe(_gray("graf6.png"))
+    tc = orc.match_fginn(ra, rb)
+    un = orc.duplicate_filter(tc, ra, rb)
+    assert 40 <= len(un) <= len(tc) <= 120      # reference (approximate kd-tree): 76 -> 74
+    if refdeg.available():
+        import pipeline_oracle as po
+        mask, H, ninl, _ = po.loransac_h(po.u6_of(ra, rb, un), po.laf_of(ra, rb, un), seed_time=1)
+        assert ninl >= 15                       # reference: 21; minMatches = 15 (iters_HessianSIFT.ini)
+        Hgt = np.array([[0.42, -0.66, 453.6], [0.44, 1.01, -46.5], [5.2e-4, -8e-5, 1.0]])   # graf H1to6 (Oxford)
+        Hn = H / H[2, 2]
+        assert np.max(np.abs(Hn - Hgt) / np.array([[1, 1, 100], [1, 1, 100], [1e-3, 1e-3, 1]])) < 0.3
+
+
+def test_stage_fixtures():
+    g = np.load(os.path.join(GOLD, "stages.npz"))
+    img = g["img"].astype(np.float32)
+    assert np.array_equal(orc.gauss_blur(img, 1.2263), g["blur_1p2263"])
+    assert np.array_equal(orc.hessian_response(img, 2.56), g["resp"])
+    assert np.array_equal(orc.resize_half(img[:67, :95]), g["half"])
+    big = g["big"].astype(np.float32)
+    keys = orc.detect_hessian_affine(big)
+    assert np.array_equal(keys, g["keys"])
+    regs, _ = orc.detect_describe(big)
+    assert np.array_equal(regs, g["regions"])
+    ra, _ = orc.detect_describe(g["pair_a"].astype(np.float32))
+    rb, _ = orc.detect_describe(g["pair_b"].astype(np.float32))
+    tc = orc.match_fginn(ra, rb)
+    assert np.array_equal(tc, g["tent"])
+    assert np.array_equal(orc.duplicate_filter(tc, ra, rb), g["tent_unique"])
+
+
+@pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_reference_degensac_reproduces_its_fixtures():
+    g = np.load(os.path.join(GOLD, "ransac_h.npz"))
+    for key in g["keys"][::5]:
+        ci, err, sym, seed = str(key).rsplit("_", 3)[0], None, None, None
+        parts = str(key).split("_")
+        ci = int(parts[0]); seed = int(parts[-1]); sym = int(parts[-2]); err = "_".join(parts[1:-2])
+        u = g["u_%d" % ci]
+        ms = 1000 if len(u) <= 20 else 20000
+        r = refdeg.ransac_h(u, 16.0, max_sam=ms, err=err, sym_check=sym, seed_time=seed)
+        assert np.array_equal(r["inl"], g["inl_" + str(key)])
+        assert [r["I"], r["samples"], r["lo"], r["rej"]] == list(g["stat_" + str(key)])
+
+
+def test_resize_dims_follow_half_to_even():
+    for (w, h), (dw, dh) in {(1920, 1080): (960, 540), (240, 135): (120, 68), (30, 17): (15, 8), (135, 67): (68, 34)}.items():
+        out = orc.resize_half(np.zeros((h, w), np.float32))
+        assert out.shape == (dh, dw)
+
+
+def test_octave_ladder_1080p():
+    p = orc.Pyramid(synth.texture(1920, 1080, seed=1))
+    assert [p.dims(o) for o in range(p.n_oct)] == [(1920, 1080), (960, 540), (480, 270), (240, 135), (120, 68), (60, 34), (30, 17)]
+
+
+def test_gauss_kernel_properties():
+    for sigma in (0.8, 1.2263, 1.5199, 2.4525, 7.3):
+        n = orc.gauss_ksize(sigma)
+        assert n % 2 == 1 and n == (int(6 * np.float32(sigma) + 1) | 1)
+        k = orc.gauss_kernel(n, float(np.float32(sigma)))
+        assert abs(k.sum() - 1) < 1e-6 and np.array_equal(k, k[::-1]) and k.argmax() == n // 2
+    img = np.full((40, 50), 93.0, np.float32)
+    assert np.allclose(orc.gauss_blur(img, 1.6), 93.0, atol=1e-4)
+
+
+def test_deterministic_math_is_close_to_libm():
+    L = orc.lib()
+    xs = np.linspace(-0.5, 0.5, 2001, dtype=np.float32)
+    got = np.array([L.orc_det_pow2f(float(x)) for x in xs], np.float32)
+    assert np.max(np.abs(got - np.exp2(xs.astype(np.float64))) / np.exp2(xs.astype(np.float64))) < 1.2e-7
+    assert np.mean(got == np.exp2(xs.astype(np.float64)).astype(np.float32)) > 0.999
+    import ctypes as C
+    s, c = C.c_double(), C.c_double()
+    for a in np.linspace(-3.2, 3.2, 999):
+        L.orc_det_sincos(float(a), C.byref(s), C.byref(c))
+        assert abs(s.value - np.sin(a)) < 1e-15 and abs(c.value - np.cos(a)) < 1e-15
+
+
+def test_atan2_lut_matches_atan2_within_table_resolution():
+    rng = np.random.default_rng(0)
+    L = orc.lib()
+    for y, x in rng.normal(0, 10, (2000, 2)).astype(np.float32):
+        a = L.orc_atan2_lut(float(y), float(x))
+        d = abs(a - np.arctan2(y, x))
+        assert min(d, 2 * np.pi - d) < 0.0045
+
+
+def test_interpolate_identity_and_border():
+    img = synth.texture(64, 48, seed=2)
+    out, touch = orc.interpolate(img, 30.0, 20.0, 1.0, 0.0, 0.0, 1.0, 9, 9)
+    assert not touch and np.array_equal(out, img[16:25, 26:35])
+    out, touch = orc.interpolate(img, 2.0, 2.0, 1.0, 0.0, 0.0, 1.0, 9, 9)
+    assert touch and out[0, 0] == 0.0
+
+
+def test_empty_and_tiny_inputs():
+    assert len(orc.detect_hessian_affine(np.full((100, 120), 7.0, np.float32))) == 0
+    assert len(orc.detect_hessian_affine(synth.texture(12, 12, seed=1))) == 0
+    z = np.zeros(0, orc.REGION_DTYPE)
+    assert len(orc.match_fginn(z, z)) == 0
