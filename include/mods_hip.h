@@ -86,6 +86,9 @@ int mods_device_count(void);
 /* One context = one GPU, one stream set, one pool of HBM scratch sized for images up to
  * max_w x max_h and `batch` images per call. */
 int mods_ctx_create(int device, int max_w, int max_h, int batch, mods_ctx **out);
+/* flags bit 0: non-blocking stream (no implicit ordering after the default stream: inputs must be complete
+ * when a call is made); lets several contexts overlap on one GPU */
+int mods_ctx_create_ex(int device, int max_w, int max_h, int batch, int flags, mods_ctx **out);
 void mods_ctx_destroy(mods_ctx *ctx);
 int mods_ctx_sync(mods_ctx *ctx);
 void *mods_ctx_stream(mods_ctx *ctx);            /* hipStream_t the kernels run on */
@@ -247,6 +250,18 @@ typedef struct mods_pair_result {
  * rows x1 y1 x2 y2 of the verified correspondences (matchings.txt layout, matching.cpp:2610-2611). */
 int mods_match_pair_dev(mods_ctx *ctx, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
                         mods_pair_result *res, double *matches_out, int max_matches);
+
+/* ---- pair pipeline ----------------------------------------------------------------------------------
+ * Throughput form of the same path: `gpu_workers` threads (one context each) run detect/describe/match
+ * while `verify_workers` threads run duplicate filtering + LO-RANSAC of earlier pairs (mods.cpp overlaps
+ * its two images with OpenMP tasks, mods.cpp:234-251; here the overlap is across pairs).  Results are
+ * returned in submission order and are identical to mods_match_pair_dev's. */
+typedef struct mods_pipeline mods_pipeline;
+int mods_pipeline_create(int device, int w, int h, const mods_pair_params *par, int gpu_workers, int verify_workers,
+                         mods_pipeline **out);
+int mods_pipeline_submit(mods_pipeline *p, const float *img_dev, long tag);
+int mods_pipeline_next(mods_pipeline *p, mods_pair_result *res, long *tag);
+void mods_pipeline_destroy(mods_pipeline *p);
 
 #ifdef __cplusplus
 }

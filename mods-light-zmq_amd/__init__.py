@@ -367,3 +367,33 @@ def match_pair_dev(ctx, dev_ptr, w, h, params=None, max_matches=0):
     _check(lib().mods_match_pair_dev(ctx.h, C.c_void_p(dev_ptr), w, h, w, C.byref(params), C.byref(res),
                                      m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
     return res, m[:min(res.n_inliers, max_matches)]
+
+
+class Pipeline:
+    """mods_pipeline_*: GPU workers (detect/describe/match) overlapped with verify workers (duplicate
+    filter + LO-RANSAC) across pairs; results in submission order."""
+
+    def __init__(self, device, w, h, params=None, gpu_workers=1, verify_workers=1):
+        self.params = params or PairParams.default()
+        self.h = C.c_void_p()
+        _check(lib().mods_pipeline_create(device, w, h, C.byref(self.params), gpu_workers, verify_workers, C.byref(self.h)))
+        self.capacity = 2 * (gpu_workers + verify_workers)
+
+    def submit(self, dev_ptr, tag=0):
+        _check(lib().mods_pipeline_submit(self.h, C.c_void_p(dev_ptr), C.c_long(tag)))
+
+    def next(self):
+        res, tag = PairResult(), C.c_long()
+        _check(lib().mods_pipeline_next(self.h, C.byref(res), C.byref(tag)))
+        return res, tag.value
+
+    def close(self):
+        if self.h:
+            lib().mods_pipeline_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

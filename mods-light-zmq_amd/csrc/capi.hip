@@ -52,7 +52,21 @@ int mods_device_count(void) {
   return n;
 }
 
+static int ctx_create_impl(int device, int max_w, int max_h, int batch, unsigned stream_flags, mods_ctx **out);
+
 int mods_ctx_create(int device, int max_w, int max_h, int batch, mods_ctx **out) {
+  // default: a stream that orders itself after the legacy default stream, so that images produced by
+  // another library on the default stream (e.g. a torch .cuda() copy) are complete when kernels read them
+  return ctx_create_impl(device, max_w, max_h, batch, hipStreamDefault, out);
+}
+
+// flags bit 0: non-blocking stream (no implicit ordering with the default stream; the caller guarantees
+// that inputs are complete).  Needed for several contexts to overlap on one GPU.
+int mods_ctx_create_ex(int device, int max_w, int max_h, int batch, int flags, mods_ctx **out) {
+  return ctx_create_impl(device, max_w, max_h, batch, (flags & 1) ? hipStreamNonBlocking : hipStreamDefault, out);
+}
+
+static int ctx_create_impl(int device, int max_w, int max_h, int batch, unsigned stream_flags, mods_ctx **out) {
   if (!out || max_w <= 0 || max_h <= 0 || batch <= 0) { set_error("mods_ctx_create: bad arguments"); return MODS_E_ARG; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) {
@@ -62,7 +76,7 @@ int mods_ctx_create(int device, int max_w, int max_h, int batch, mods_ctx **out)
   MODS_HIP_CHECK(hipSetDevice(device));
   mods_ctx *c = new mods_ctx();
   c->device = device; c->max_w = max_w; c->max_h = max_h; c->batch = batch;
-  MODS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamDefault));
+  MODS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, stream_flags));
   const size_t px = (size_t)max_w * max_h;
   size_t mc = px / 8;
   mc = std::max<size_t>(mc, 1u << 16);
@@ -220,7 +234,8 @@ int mods_pyramid_candidates(mods_ctx *c, int img, mods_candidate *out, int max_o
 // ---- orientation + description ----------------------------------------------------------------
 static int check_desc_err(mods_ctx *c) {
   int e = 0;
-  MODS_HIP_CHECK(hipMemcpy(&e, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost));
+  MODS_HIP_CHECK(hipMemcpyAsync(&e, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (e) {
     MODS_HIP_CHECK(hipMemsetAsync(c->desc_err_dev, 0, sizeof(int), c->stream));
     set_error("measurement region larger than the descriptor scratch (P2 > 3*max(w,h) or > 4096 blur taps)");
@@ -526,17 +541,19 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
 }
 
 // ---- one pair end to end -------------------------------------------------------------------------------
-int mods_match_pair_dev(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
-                        mods_pair_result *res, double *matches_out, int max_matches) {
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// GPU half of a pair: detect + describe both images, match, bring the tentatives to the host.
+int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
+                        mods_pair_result *res, std::vector<mods_tentative> *tent, std::vector<double> *u6, std::vector<double> *laf) {
   if (!c || !img_dev || !par || !res) { set_error("match_pair: null argument"); return MODS_E_ARG; }
   if (c->batch < 2) { set_error("match_pair needs a context created with batch >= 2"); return MODS_E_ARG; }
   memset(res, 0, sizeof(*res));
   for (int i = 0; i < 9; i++) res->H[i] = -1;
   int rc;
-  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t0 = now();
+  const double t0 = now_ms();
   if ((rc = mods_detect_describe_dev(c, img_dev, 2, w, h, stride, &par->det, &par->desc, res->n_detected, res->n_described))) return rc;
-  double t1 = now();
+  const double t1 = now_ms();
   res->ms_detect_describe = t1 - t0;
   if ((rc = match_run(c, c->regions_dev, res->n_described[0], c->regions_dev + c->max_cand, res->n_described[1],
                       par->fginn_ratio, par->contradDist, par->nn))) return rc;
@@ -545,36 +562,53 @@ int mods_match_pair_dev(mods_ctx *c, const float *img_dev, int w, int h, int str
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
   res->n_tentatives = n;
   if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
-  c->h_tent.resize(n); c->h_u6.resize((size_t)n * 6); c->h_laf.resize((size_t)n * 14); c->h_mask.resize(n);
+  tent->resize(n); u6->resize((size_t)n * 6); laf->resize((size_t)n * 14);
   if (n > 0) {
-    MODS_HIP_CHECK(hipMemcpyAsync(c->h_tent.data(), c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipMemcpyAsync(c->h_u6.data(), c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipMemcpyAsync(c->h_laf.data(), c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipMemcpyAsync(tent->data(), c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipMemcpyAsync(u6->data(), c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipMemcpyAsync(laf->data(), c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost, c->stream));
     MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
   }
-  double t2 = now();
-  res->ms_match = t2 - t1;
+  res->ms_match = now_ms() - t1;
+  return MODS_OK;
+}
+
+// Host-driven half: duplicate filtering + LO-RANSAC (hypotheses scored on `device`) + checks.
+int mods_pair_verify_stage(int device, const mods_pair_params *par, mods_pair_result *res, std::vector<mods_tentative> *tent,
+                           std::vector<double> *u6, std::vector<double> *laf, double *matches_out, int max_matches) {
+  int rc;
+  const double t2 = now_ms();
+  const int n = (int)tent->size();
   int nu = n;
   if (par->dup_before_ransac && n > 0)
-    if ((rc = mods_duplicate_filter(c->h_tent.data(), c->h_u6.data(), c->h_laf.data(), n, par->dup_dist, par->dup_mode, &nu))) return rc;
+    if ((rc = mods_duplicate_filter(tent->data(), u6->data(), laf->data(), n, par->dup_dist, par->dup_mode, &nu))) return rc;
   res->n_unique = nu;
-  double t3 = now();
+  const double t3 = now_ms();
   res->ms_duplicates = t3 - t2;
   int stats[3] = {0, 0, 0};
-  mods_ransac_set_device(c->device);
-  if ((rc = mods_loransac_h(c->h_u6.data(), c->h_laf.data(), nu, &par->ransac, c->h_mask.data(), res->H, &res->n_inliers, stats))) return rc;
+  mods_ransac_set_device(device);
+  std::vector<unsigned char> mask(nu > 0 ? nu : 1);
+  if ((rc = mods_loransac_h(u6->data(), laf->data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats))) return rc;
   res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
-  res->ms_ransac = now() - t3;
+  res->ms_ransac = now_ms() - t3;
   if (matches_out) {
     int m = 0;
     for (int i = 0; i < nu && m < max_matches; i++)
-      if (c->h_mask[i]) {
-        const double *p = &c->h_u6[(size_t)i * 6];
+      if (mask[i]) {
+        const double *p = &(*u6)[(size_t)i * 6];
         matches_out[4 * m] = p[0]; matches_out[4 * m + 1] = p[1]; matches_out[4 * m + 2] = p[3]; matches_out[4 * m + 3] = p[4];
         m++;
       }
   }
   return MODS_OK;
+}
+
+int mods_match_pair_dev(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
+                        mods_pair_result *res, double *matches_out, int max_matches) {
+  if (!c) { set_error("match_pair: null context"); return MODS_E_ARG; }
+  int rc = mods_pair_gpu_stage(c, img_dev, w, h, stride, par, res, &c->h_tent, &c->h_u6, &c->h_laf);
+  if (rc) return rc;
+  return mods_pair_verify_stage(c->device, par, res, &c->h_tent, &c->h_u6, &c->h_laf, matches_out, max_matches);
 }
 
 // ---- single primitives -------------------------------------------------------------------

@@ -48,6 +48,31 @@ __device__ __forceinline__ float bilinear_tap(const float *__restrict__ im, int 
 // +/- is a double operation rounded to float on return.
 __device__ const double g_atan_lut[256] = MODS_ATAN_LUT_INIT;
 
+// table pointer variant (e.g. an LDS copy of the table)
+__device__ __forceinline__ float atan2_lut_ff_t(float y, float x, const double *__restrict__ L) {
+  const float PI_2f = 1.57079632679489661923f;
+  const float PIf = 3.14159265358979323846f;
+  if (x > 0.f) {
+    if (y > 0.f) {
+      if (x > y) return (float)L[(int)(255.f * y / x)];
+      return (float)((double)PI_2f - L[(int)(255 * x / y)]);
+    } else {
+      float absy = fabsf(y);
+      if (x > absy) return (float)(-L[(int)(255.f * absy / x)]);
+      return (float)((double)(-PI_2f) + L[(int)(255.f * x / absy)]);
+    }
+  } else if (y > 0.f) {
+    float absx = fabsf(x);
+    if (absx > y) return (float)((double)PIf - L[(int)(255.f * y / absx)]);
+    return (float)((double)PI_2f + L[(int)(255.f * absx / y)]);
+  } else {
+    float absx = fabsf(x), absy = fabsf(y);
+    if (absx > absy) return (float)((double)(-PIf) + L[(int)(255.f * absy / absx)]);
+    if (x == 0.f) return 0.f;
+    return (float)((double)(-PI_2f) - L[(int)(255.f * absx / absy)]);
+  }
+}
+
 __device__ __forceinline__ float atan2_lut_ff(float y, float x) {
   const float PI_2f = 1.57079632679489661923f;
   const float PIf = 3.14159265358979323846f;

@@ -130,7 +130,15 @@ __global__ __launch_bounds__(64) void ransac_gain_kernel(const double *__restric
   const int k = blockIdx.x * 64 + threadIdx.x;
   if (k >= n_hyp) return;
   double s = 0;
-  for (int i = 0; i < len; i++) s += gain[(size_t)i * kstride + k];
+  int i = 0;
+  for (; i + 15 < len; i += 16) {   // loads batched, additions in correspondence order
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = gain[(size_t)(i + q) * kstride + k];
+#pragma unroll
+    for (int q = 0; q < 16; q++) s += v[q];
+  }
+  for (; i < len; i++) s += gain[(size_t)i * kstride + k];
   J[k] = s;
 }
 
@@ -169,7 +177,7 @@ static RansacGpu *ransac_gpu() {
     int dev;
     { std::lock_guard<std::mutex> lk(g_cfg_mutex); dev = g_ransac_device; }
     if (hipSetDevice(dev) != hipSuccess) { set_error("hipSetDevice(%d) failed", dev); return nullptr; }
-    if (hipStreamCreateWithFlags(&ws.stream, hipStreamDefault) != hipSuccess) { set_error("stream creation failed"); return nullptr; }
+    if (hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking) != hipSuccess) { set_error("stream creation failed"); return nullptr; }
     ws.device = dev;
   }
   (void)hipSetDevice(ws.device);

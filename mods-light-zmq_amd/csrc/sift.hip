@@ -389,9 +389,17 @@ __global__ __launch_bounds__(256) void big_colres_kernel(DescConst k, const BigL
 __device__ __forceinline__ float ordered_sum(const float *v, int n) {
   float s = 0;
   int q = 0;
-  for (; q + 7 < n; q += 8) {
-    const float4 a = *(const float4 *)(v + q), b = *(const float4 *)(v + q + 4);
+  if (n >= 16) {
+    float4 a = *(const float4 *)(v), b = *(const float4 *)(v + 4), c = *(const float4 *)(v + 8), d = *(const float4 *)(v + 12);
+    for (q = 16; q + 15 < n; q += 16) {   // the next 16 values are in flight while these 16 are added
+      const float4 na = *(const float4 *)(v + q), nb = *(const float4 *)(v + q + 4);
+      const float4 nc = *(const float4 *)(v + q + 8), nd = *(const float4 *)(v + q + 12);
+      s += a.x; s += a.y; s += a.z; s += a.w; s += b.x; s += b.y; s += b.z; s += b.w;
+      s += c.x; s += c.y; s += c.z; s += c.w; s += d.x; s += d.y; s += d.z; s += d.w;
+      a = na; b = nb; c = nc; d = nd;
+    }
     s += a.x; s += a.y; s += a.z; s += a.w; s += b.x; s += b.y; s += b.z; s += b.w;
+    s += c.x; s += c.y; s += c.z; s += c.w; s += d.x; s += d.y; s += d.z; s += d.w;
   }
   for (; q < n; q++) s += v[q];
   return s;
@@ -438,8 +446,9 @@ __device__ void sift_tables(const SiftTab *__restrict__ tab, int ps, float *s_wr
   }
 }
 
-__device__ void sift_from_patch(const float *s_patch, const float *__restrict__ mask, const float *s_w, int ps, bool rootsift,
-                                double max_bin, float2 *s_px, unsigned char *s_bo, double *s_vec, double *s_red, uint8_t *out) {
+__device__ void sift_from_patch(const float *s_patch, const float *__restrict__ mask, const float *s_w, const double *s_lut, int ps,
+                                bool rootsift, double max_bin, float2 *s_px, unsigned char *s_bo, double *s_vec, double *s_red,
+                                uint8_t *out) {
   const int tid = threadIdx.x;
   const int pp = ps * ps;
   const double M_PI_DOUBLED = 6.28318530718;
@@ -453,7 +462,7 @@ __device__ void sift_from_patch(const float *s_patch, const float *__restrict__ 
     else if (r == ps - 1) ygrad = s_patch[p] - s_patch[p - ps];
     else ygrad = s_patch[p + ps] - s_patch[p - ps];
     const float grad = sqrtf(xgrad * xgrad + ygrad * ygrad);
-    const float ori = atan2_lut_ff(ygrad, xgrad);
+    const float ori = atan2_lut_ff_t(ygrad, xgrad, s_lut);
     const float o = (float)(8.0f * ((double)ori + M_PI_DOUBLED) / M_PI_DOUBLED);
     const int bo0 = (int)o;
     s_px[p] = make_float2(mask[p] * grad, o - bo0);
@@ -463,27 +472,36 @@ __device__ void sift_from_patch(const float *s_patch, const float *__restrict__ 
   // samplePatch (siftdesc.cpp:73-131): thread t < 128 owns vec[t], t = br*32 + bc*8 + bo, and visits
   // its block of pixels in raster order.  Per pixel exactly one (row weight, column weight) pair is
   // non-zero for this bin; pixels whose two orientation bins miss `bo` add +0.0 (no effect).
+  // fl32(w (double) * v) of the reference = the fp32 product: the exact product of two floats fits a
+  // double, so both round the same real number once.
   if (tid < 128) {
     const int br = tid >> 5, bc = (tid >> 3) & 3, bo = tid & 7;
     const float *wr = s_w + br * ps, *wc = s_w + bc * ps;
-    int rlo = ps, rhi = 0, clo = ps, chi = 0;
+    int rlo = ps, rhi = 0, clo = ps;
     for (int i = 0; i < ps; i++) {
       if (wr[i] > 0) { rlo = min(rlo, i); rhi = i + 1; }
-      if (wc[i] > 0) { clo = min(clo, i); chi = i + 1; }
+      if (wc[i] > 0) clo = min(clo, i);
     }
+    // column weights of this bin in registers (spatial bins span <= 18 pixel columns for ps <= 45;
+    // trailing entries are 0 and contribute +0.0)
+    constexpr int CW = 18;
+    float wcr[CW];
+#pragma unroll
+    for (int q = 0; q < CW; q++) wcr[q] = (clo + q < ps) ? wc[clo + q] : 0.f;
     double acc = 0.0;
     for (int r = rlo; r < rhi; r++) {
       const float wrr = wr[r];
-      const float2 *px = s_px + r * ps;
-      const unsigned char *bop = s_bo + r * ps;
-      for (int c = clo; c < chi; c++) {
-        const float2 pv = px[c];
-        const int bo0 = bop[c];
-        const float wcc = (float)((double)wc[c] * pv.x);
-        const float val = wrr * wcc;
-        const float wo1 = pv.y, wo0 = 1.0f - wo1;
+      const float2 *px = s_px + r * ps + clo;
+      const unsigned char *bop = s_bo + r * ps + clo;
+      // always the full unrolled window: entries past the bin's columns carry weight 0 (the loads may
+      // run into the next row / the following LDS words: their value is irrelevant, 0-weight => +0.0)
+#pragma unroll
+      for (int q = 0; q < CW; q++) {
+        const float2 pv = px[q];
+        const int bo0 = bop[q];
+        const float val = wrr * (wcr[q] * pv.x);
         const bool m0 = bo0 == bo, m1 = ((bo0 + 1) & 7) == bo;
-        const float wo = m0 ? wo0 : wo1;
+        const float wo = m0 ? (1.0f - pv.y) : pv.y;
         const float contrib = ((m0 || m1) && val > 0) ? val * wo : 0.0f;
         acc += (double)contrib;
       }
@@ -537,7 +555,7 @@ __device__ void sift_from_patch(const float *s_patch, const float *__restrict__ 
 }
 
 struct SiftLds {   // carve of the dynamic LDS of the SIFT kernels
-  float *patch, *g, *w; float2 *px; unsigned char *bo; unsigned short *midx; double *vec, *red; float *redf;
+  float *patch, *g, *w; float2 *px; unsigned char *bo; unsigned short *midx; double *vec, *red, *lut; float *redf;
   __device__ SiftLds(float *base, int ps) {
     const int pp = ps * ps, ppa = (pp + 3) & ~3;
     patch = base;
@@ -546,14 +564,15 @@ struct SiftLds {   // carve of the dynamic LDS of the SIFT kernels
     w = (float *)(px + ppa);
     vec = (double *)(((uintptr_t)(w + 4 * ps) + 7) & ~(uintptr_t)7);
     red = vec + 128;
-    redf = (float *)(red + 2);
+    lut = red + 2;
+    redf = (float *)(lut + 256);
     midx = (unsigned short *)(redf + 4);
     bo = (unsigned char *)(midx + ppa);
   }
 };
 static size_t sift_lds_bytes(int ps) {
   const size_t ppa = ((size_t)ps * ps + 3) & ~(size_t)3;
-  return sizeof(float) * (2 * ppa + 2 * ppa + 4 * ps + 4) + sizeof(double) * 130 + sizeof(unsigned short) * ppa + ppa + 32;
+  return sizeof(float) * (2 * ppa + 2 * ppa + 4 * ps + 4) + sizeof(double) * (130 + 256) + sizeof(unsigned short) * ppa + ppa + 32;
 }
 
 // grid = (N, n_img), block = 256: patches -> descriptors
@@ -566,6 +585,7 @@ __global__ __launch_bounds__(256) void sift_kernel(DescConst k, const float *__r
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   sift_tables(tab, ps, L.w);
+  for (int i = tid; i < 256; i += 256) L.lut[i] = g_atan_lut[i];
   if (tid < 64) {   // raster-ordered list of the masked pixels, one wave, ballot compaction
     int c = 0;
     for (int base = 0; base < pp; base += 64) {
@@ -588,7 +608,7 @@ __global__ __launch_bounds__(256) void sift_kernel(DescConst k, const float *__r
     for (int p = tid; p < pp; p += 256) L.patch[p] = src[p];
     __syncthreads();
     if (k.photo) photonorm_patch(L.patch, L.midx, n_mask, L.g, pp, L.redf);
-    sift_from_patch(L.patch, mask, L.w, ps, k.root != 0, k.max_bin, L.px, L.bo, L.vec, L.red, reg[ri].desc);
+    sift_from_patch(L.patch, mask, L.w, L.lut, ps, k.root != 0, k.max_bin, L.px, L.bo, L.vec, L.red, reg[ri].desc);
   }
 }
 
@@ -598,9 +618,10 @@ __global__ __launch_bounds__(256) void sift_patch_test_kernel(const float *__res
   extern __shared__ __attribute__((aligned(16))) float smem[];
   SiftLds L(smem, ps);
   sift_tables(tab, ps, L.w);
+  for (int i = threadIdx.x; i < 256; i += 256) L.lut[i] = g_atan_lut[i];
   for (int p = threadIdx.x; p < ps * ps; p += 256) L.patch[p] = patch[p];
   __syncthreads();
-  sift_from_patch(L.patch, mask, L.w, ps, root != 0, max_bin, L.px, L.bo, L.vec, L.red, out);
+  sift_from_patch(L.patch, mask, L.w, L.lut, ps, root != 0, max_bin, L.px, L.bo, L.vec, L.red, out);
 }
 
 // ---------------------------------------------------------------------------------------
