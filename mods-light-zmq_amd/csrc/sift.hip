@@ -389,17 +389,14 @@ __global__ __launch_bounds__(256) void big_colres_kernel(DescConst k, const BigL
 __device__ __forceinline__ float ordered_sum(const float *v, int n) {
   float s = 0;
   int q = 0;
-  if (n >= 16) {
-    float4 a = *(const float4 *)(v), b = *(const float4 *)(v + 4), c = *(const float4 *)(v + 8), d = *(const float4 *)(v + 12);
-    for (q = 16; q + 15 < n; q += 16) {   // the next 16 values are in flight while these 16 are added
+  if (n >= 8) {
+    float4 a = *(const float4 *)(v), b = *(const float4 *)(v + 4);
+    for (q = 8; q + 7 < n; q += 8) {   // the next 8 values are in flight while these 8 are added
       const float4 na = *(const float4 *)(v + q), nb = *(const float4 *)(v + q + 4);
-      const float4 nc = *(const float4 *)(v + q + 8), nd = *(const float4 *)(v + q + 12);
       s += a.x; s += a.y; s += a.z; s += a.w; s += b.x; s += b.y; s += b.z; s += b.w;
-      s += c.x; s += c.y; s += c.z; s += c.w; s += d.x; s += d.y; s += d.z; s += d.w;
-      a = na; b = nb; c = nc; d = nd;
+      a = na; b = nb;
     }
     s += a.x; s += a.y; s += a.z; s += a.w; s += b.x; s += b.y; s += b.z; s += b.w;
-    s += c.x; s += c.y; s += c.z; s += c.w; s += d.x; s += d.y; s += d.z; s += d.w;
   }
   for (; q < n; q++) s += v[q];
   return s;
@@ -446,12 +443,14 @@ __device__ void sift_tables(const SiftTab *__restrict__ tab, int ps, float *s_wr
   }
 }
 
-__device__ void sift_from_patch(const float *s_patch, const float *__restrict__ mask, const float *s_w, const double *s_lut, int ps,
+__device__ void sift_from_patch(float *s_patch, const float *__restrict__ mask, const float *s_w, const double *s_lut, int ps,
                                 bool rootsift, double max_bin, float2 *s_px, unsigned char *s_bo, double *s_vec, double *s_red,
                                 uint8_t *out) {
+  double *s_sq = (double *)(((uintptr_t)s_patch + 7) & ~(uintptr_t)7);   // the patch is dead once the gradients are taken
   const int tid = threadIdx.x;
   const int pp = ps * ps;
   const double M_PI_DOUBLED = 6.28318530718;
+#pragma unroll 1
   for (int p = tid; p < pp; p += 256) {
     const int r = p / ps, c = p - r * ps;
     float xgrad, ygrad;
@@ -482,24 +481,21 @@ __device__ void sift_from_patch(const float *s_patch, const float *__restrict__ 
       if (wr[i] > 0) { rlo = min(rlo, i); rhi = i + 1; }
       if (wc[i] > 0) clo = min(clo, i);
     }
-    // column weights of this bin in registers (spatial bins span <= 18 pixel columns for ps <= 45;
-    // trailing entries are 0 and contribute +0.0)
+    // fixed 18-pixel window per row (spatial bins span <= 18 pixel columns for ps <= 45): entries past
+    // the bin's columns carry weight 0 and add +0.0; their loads may run into the next row / the
+    // following LDS words, whose value is irrelevant.  s_wpad: the bin's column weights, zero padded.
     constexpr int CW = 18;
-    float wcr[CW];
-#pragma unroll
-    for (int q = 0; q < CW; q++) wcr[q] = (clo + q < ps) ? wc[clo + q] : 0.f;
     double acc = 0.0;
     for (int r = rlo; r < rhi; r++) {
       const float wrr = wr[r];
       const float2 *px = s_px + r * ps + clo;
       const unsigned char *bop = s_bo + r * ps + clo;
-      // always the full unrolled window: entries past the bin's columns carry weight 0 (the loads may
-      // run into the next row / the following LDS words: their value is irrelevant, 0-weight => +0.0)
-#pragma unroll
+#pragma unroll 6
       for (int q = 0; q < CW; q++) {
         const float2 pv = px[q];
         const int bo0 = bop[q];
-        const float val = wrr * (wcr[q] * pv.x);
+        const float wcq = (clo + q < ps) ? wc[clo + q] : 0.f;
+        const float val = wrr * (wcq * pv.x);
         const bool m0 = bo0 == bo, m1 = ((bo0 + 1) & 7) == bo;
         const float wo = m0 ? (1.0f - pv.y) : pv.y;
         const float contrib = ((m0 || m1) && val > 0) ? val * wo : 0.0f;
@@ -511,12 +507,19 @@ __device__ void sift_from_patch(const float *s_patch, const float *__restrict__ 
   __syncthreads();
   // normalize (siftdesc.cpp:133-158) / clip / renormalise (:199-210, :248-257)
   for (int pass = 0; pass < 2; pass++) {
+    // squares in parallel (into s_red[2..129] would alias nothing: use the idle patch buffer instead)
+    if (tid < 128) ((double *)s_sq)[tid] = s_vec[tid] * s_vec[tid];
+    __syncthreads();
     if (tid == 0) {
+      const double *sq = (const double *)s_sq;
       double len = 0.0;
-      for (int i = 0; i < 128; i += 4) {
-        const double sq0 = s_vec[i] * s_vec[i], sq1 = s_vec[i + 1] * s_vec[i + 1];
-        const double sq2 = s_vec[i + 2] * s_vec[i + 2], sq3 = s_vec[i + 3] * s_vec[i + 3];
-        len += sq0 + sq1 + sq2 + sq3;
+#pragma unroll 1
+      for (int i = 0; i < 128; i += 16) {   // 16 loads in flight, then the reference's 4-term groups in order
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = sq[i + q];
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) len += v[q] + v[q + 1] + v[q + 2] + v[q + 3];
       }
       len = sqrt(len);
       s_red[0] = 1.0 / len;
@@ -534,7 +537,14 @@ __device__ void sift_from_patch(const float *s_patch, const float *__restrict__ 
   if (rootsift) {
     if (tid == 0) {
       double sum = 0.;
-      for (int i = 0; i < 128; i++) sum += fabs(s_vec[i]);
+#pragma unroll 1
+      for (int i = 0; i < 128; i += 16) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = s_vec[i + q];
+#pragma unroll
+        for (int q = 0; q < 16; q++) sum += fabs(v[q]);
+      }
       s_red[1] = sum;
     }
     __syncthreads();
@@ -576,7 +586,7 @@ static size_t sift_lds_bytes(int ps) {
 }
 
 // grid = (N, n_img), block = 256: patches -> descriptors
-__global__ __launch_bounds__(256) void sift_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
+__global__ __launch_bounds__(256, 4) void sift_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
                                                    const int *__restrict__ reg_count, const float *__restrict__ mask,
                                                    const SiftTab *__restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
