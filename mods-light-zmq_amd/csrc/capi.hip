@@ -92,6 +92,9 @@ static int ctx_create_impl(int device, int max_w, int max_h, int batch, unsigned
   MODS_HIP_CHECK(hipMalloc(&c->keys_dev, sizeof(mods_affkey) * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->sort_keys, sizeof(unsigned long long) * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->sort_idx, sizeof(int) * 2 * mc * batch));
+  MODS_HIP_CHECK(hipMalloc(&c->rank_dev, sizeof(int) * mc * batch));
+  c->nms_mask_words = (px / 64 + (size_t)max_h + 64) * kMaxLevels * batch;
+  MODS_HIP_CHECK(hipMalloc(&c->nms_mask, sizeof(unsigned long long) * c->nms_mask_words));
   MODS_HIP_CHECK(hipHostMalloc(&c->host_counts, sizeof(int) * 4 * batch));
   MODS_HIP_CHECK(hipMalloc(&c->ori_dev, 48 * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->regions_dev, sizeof(mods_region) * mc * batch));
@@ -110,7 +113,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   }
   (void)hipFree(c->pyr_dev); (void)hipFree(c->plane_pool); (void)hipFree(c->omap_pool); (void)hipFree(c->input_dev);
   (void)hipFree(c->tmp_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
-  (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx);
+  (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
   (void)hipHostFree(c->host_counts);
   (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->region_count); (void)hipFree(c->desc_tables_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);

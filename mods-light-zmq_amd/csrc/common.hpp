@@ -85,6 +85,9 @@ struct mods_ctx {
   mods_affkey *keys_dev = nullptr;   // [batch][max_cand] sorted output
   unsigned long long *sort_keys = nullptr;
   int *sort_idx = nullptr;
+  int *rank_dev = nullptr;           // [batch][max_cand]
+  unsigned long long *nms_mask = nullptr;   // ballot words of one octave's NMS
+  size_t nms_mask_words = 0;
   int *key_count = nullptr;          // [batch]
   int *host_counts = nullptr;        // pinned
   mods_hessaff_params par;

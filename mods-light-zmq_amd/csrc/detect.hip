@@ -37,52 +37,120 @@ struct DetectConst {
 };
 
 // ---------------------------------------------------------------------------------------
-// NMS: one thread per pixel of the detection level; hits appended with one atomic per wave.
-// grid = (ceil((w-2b)/64), ceil((h-2b)/4), n_img), block = 256
+// NMS for all detection levels of one octave: a thread walks NMS_ROWS rows of one pixel column and, per
+// pixel, the S levels.  Hits are appended with one atomic per wave (order is irrelevant, see header).
+// grid = (ceil((w-2b)/64), ceil((h-2b)/(4*NMS_ROWS)), n_img), block = 256
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__ P, int oi, int lv, DetectConst k,
-                                                  CandDev *__restrict__ cand, int *__restrict__ cand_count) {
+constexpr int NMS_ROWS = 8;
+
+// low/high planes of a pixel that already is an in-plane extremum above the gate: all 18 loads issued
+// together (no short-circuit chain of dependent loads)
+__device__ __forceinline__ bool nms_other_planes(const float *__restrict__ low, const float *__restrict__ high, int w, int r, int c,
+                                                 float val, bool want_max) {
+  float v[18];
+#pragma unroll
+  for (int dr = -1; dr <= 1; dr++) {
+    const size_t off = (size_t)(r + dr) * w + c;
+#pragma unroll
+    for (int dc = -1; dc <= 1; dc++) { v[(dr + 1) * 6 + (dc + 1) * 2] = low[off + dc]; v[(dr + 1) * 6 + (dc + 1) * 2 + 1] = high[off + dc]; }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < 18; q++) ok = ok && !(want_max ? (v[q] > val) : (v[q] < val));
+  return ok;
+}
+
+// Hits are written as ballot words (one u64 per wave-row per level: no atomics); nms_compact_kernel
+// turns the words into the hit list with one atomic per block.
+// mask layout per octave: [n_img][S][h - 2*border][words], words = ceil((w - 2*border) / 64)
+__global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__ P, int oi, DetectConst k,
+                                                  unsigned long long *__restrict__ mask) {
   const OctaveDev &o = P->oct[oi];
   const int w = o.w, h = o.h;
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63;
   const int c = k.border + blockIdx.x * 64 + lane;
-  const int r = k.border + blockIdx.y * 4 + (threadIdx.x >> 6);
-  bool hit = false;
-  if (r < h - k.border && c < w - k.border) {
-    const size_t plane = (size_t)w * h * b;
+  const int r_base = k.border + (blockIdx.y * 4 + (threadIdx.x >> 6)) * NMS_ROWS;
+  const size_t plane = (size_t)w * h * b;
+  const bool col_ok = c < w - k.border;
+  const int cc = col_ok ? c : k.border;      // idle lanes read a valid column
+  if (r_base >= h - k.border) return;
+  const int ih = h - 2 * k.border, words = gridDim.x;
+  for (int lv = 1; lv <= k.n_scales; lv++) {
     const float *cur = o.resp[lv] + plane;
-    const float val = cur[(size_t)r * w + c];
-    if (val > k.pos_th) {
-      const float *low = o.resp[lv - 1] + plane, *high = o.resp[lv + 1] + plane;
-      hit = true;
-      for (int dr = -1; dr <= 1 && hit; dr++) {
-        const size_t off = (size_t)(r + dr) * w + c;
-        for (int dc = -1; dc <= 1; dc++)
-          if (cur[off + dc] > val || low[off + dc] > val || high[off + dc] > val) hit = false;
-      }
-    } else if (val < k.neg_th) {
-      const float *low = o.resp[lv - 1] + plane, *high = o.resp[lv + 1] + plane;
-      hit = true;
-      for (int dr = -1; dr <= 1 && hit; dr++) {
-        const size_t off = (size_t)(r + dr) * w + c;
-        for (int dc = -1; dc <= 1; dc++)
-          if (cur[off + dc] < val || low[off + dc] < val || high[off + dc] < val) hit = false;
-      }
+    // the whole (NMS_ROWS+2) x 3 window of this thread is loaded up front: 30 independent loads in
+    // flight instead of a load -> compare chain per row
+    float win[NMS_ROWS + 2][3];
+#pragma unroll
+    for (int rr = 0; rr < NMS_ROWS + 2; rr++) {
+      int r = r_base - 1 + rr;
+      r = r < h - 1 ? r : h - 1;             // rows past the image are never used (clamped to stay in bounds)
+      const float *p = cur + (size_t)r * w + cc;
+      win[rr][0] = p[-1]; win[rr][1] = p[0]; win[rr][2] = p[1];
+    }
+    unsigned long long *mrow = mask + (((size_t)b * k.n_scales + (lv - 1)) * ih + (r_base - k.border)) * words + blockIdx.x;
+#pragma unroll
+    for (int rr = 0; rr < NMS_ROWS; rr++) {
+      const int r = r_base + rr;
+      const bool row_ok = r < h - k.border;  // uniform per wave
+      const float val = win[rr + 1][1];
+      // isMax / isMin on the level's own plane (pyramid.cpp:41-63: a neighbour strictly beyond val rejects)
+      bool mx = true, mn = true;
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+          if (q == 1 && e == 1) continue;
+          mx = mx && !(win[rr + q][e] > val);
+          mn = mn && !(win[rr + q][e] < val);
+        }
+      bool hit = false;
+      if (row_ok && col_ok && val > k.pos_th && mx) hit = nms_other_planes(o.resp[lv - 1] + plane, o.resp[lv + 1] + plane, w, r, c, val, true);
+      else if (row_ok && col_ok && val < k.neg_th && mn) hit = nms_other_planes(o.resp[lv - 1] + plane, o.resp[lv + 1] + plane, w, r, c, val, false);
+      const unsigned long long m = __ballot(hit);
+      if (row_ok && lane == 0) mrow[(size_t)rr * words] = m;
     }
   }
-  const unsigned long long m = __ballot(hit);
-  if (m == 0) return;
-  int base = 0;
-  const int leader = __ffsll((long long)m) - 1;
-  if (lane == leader) base = atomicAdd(&cand_count[b], __popcll(m));
-  base = __shfl(base, leader);
-  if (hit) {
-    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// grid = (ceil(total_words/256), n_img), block 256: ballot words -> hit records
+__global__ __launch_bounds__(256) void nms_compact_kernel(int oi, int w, int h, DetectConst k, const unsigned long long *__restrict__ mask,
+                                                          int words, CandDev *__restrict__ cand, int *__restrict__ cand_count) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int b = blockIdx.y;
+  const int ih = h - 2 * k.border;
+  const int total = k.n_scales * ih * words;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long m = 0;
+  if (idx < total) m = mask[(size_t)b * total + idx];
+  const int cnt = __popcll(m);
+  // block-wide exclusive prefix of cnt
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = cnt;
+  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+  if (lane == 63) s_wave[wv] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = tot ? atomicAdd(&cand_count[b], tot) : 0;
+  }
+  __syncthreads();
+  if (cnt == 0) return;
+  int slot = s_base + inc - cnt;
+  for (int q = 0; q < wv; q++) slot += s_wave[q];
+  const int lv = idx / (ih * words) + 1;
+  const int rem = idx - (lv - 1) * ih * words;
+  const int r = k.border + rem / words;
+  const int c0 = k.border + (rem % words) * 64;
+  while (m) {
+    const int bit = __ffsll((long long)m) - 1;
+    m &= m - 1;
     if (slot < k.max_cand) {
       CandDev &cd = cand[(size_t)b * k.max_cand + slot];
-      cd.octave = oi; cd.level = lv; cd.r0 = r; cd.c0 = c; cd.state = 0;
+      cd.octave = oi; cd.level = lv; cd.r0 = r; cd.c0 = c0 + bit; cd.state = 0;
     }
+    slot++;
   }
 }
 
@@ -348,47 +416,55 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
 
 // ---------------------------------------------------------------------------------------
 // Rank sort + export.  Keys are unique, so rank = #{j : key_j < key_i}.
-// grid = (ceil(max/256) capped, n_img), block = 256, LDS tile of 1024 keys.
-// Export applies DetectAffineRegions: s *= sqrt|det A|, rectifyTransformation (fp64).
+// rank_count_kernel: grid = (blocks over i, splits over j, n_img): partial counts added atomically.
+// export_kernel    : applies DetectAffineRegions: s *= sqrt|det A|, rectifyTransformation (fp64).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rank_export_kernel(DetectConst k, const CandDev *__restrict__ cand,
-                                                          const unsigned long long *__restrict__ sort_keys,
-                                                          const int *__restrict__ sort_idx,
-                                                          const int *__restrict__ key_count,
-                                                          mods_affkey *__restrict__ out) {
+__global__ __launch_bounds__(256) void rank_count_kernel(DetectConst k, const unsigned long long *__restrict__ sort_keys,
+                                                         const int *__restrict__ key_count, int *__restrict__ rank) {
   __shared__ unsigned long long tile[1024];
-  const int b = blockIdx.y;
+  const int b = blockIdx.z;
   const int n = key_count[b];
   const unsigned long long *keys = sort_keys + (size_t)b * k.max_cand;
   const int nblk = (n + 255) / 256;
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int i = blk * 256 + threadIdx.x;
-    const unsigned long long mine = (i < n) ? keys[i] : ~0ull;
-    int rank = 0;
-    for (int t0 = 0; t0 < n; t0 += 1024) {
-      __syncthreads();
-      for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (t0 + q < n) ? keys[t0 + q] : ~0ull;
-      __syncthreads();
-      const int lim = min(1024, n - t0);
-      for (int q = 0; q < lim; q++) rank += (tile[q] < mine) ? 1 : 0;
+  const int ntile = (n + 1023) / 1024;
+  for (int t = blockIdx.y; t < ntile; t += gridDim.y) {
+    const int t0 = t * 1024;
+    __syncthreads();
+    for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (t0 + q < n) ? keys[t0 + q] : ~0ull;
+    __syncthreads();
+    const int lim = min(1024, n - t0);
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+      const int i = blk * 256 + threadIdx.x;
+      if (i >= n) continue;
+      const unsigned long long mine = keys[i];
+      int cnt = 0;
+      for (int q = 0; q < lim; q++) cnt += (tile[q] < mine) ? 1 : 0;
+      if (cnt) atomicAdd(&rank[(size_t)b * k.max_cand + i], cnt);
     }
-    if (i < n) {
-      const CandDev &cd = cand[(size_t)b * k.max_cand + sort_idx[(size_t)b * k.max_cand + i]];
-      mods_affkey o;
-      double a = cd.a11, bb = cd.a12, c = cd.a21, d = cd.a22;
-      o.x = cd.x; o.y = cd.y;
-      o.s = (double)cd.s * sqrt(fabs(a * d - bb * c));
-      const double det = sqrt(fabs(a * d - bb * c));
-      const double b2a2 = sqrt(bb * bb + a * a);
-      o.a11 = b2a2 / det;
-      o.a12 = 0;
-      o.a21 = (d * bb + c * a) / (b2a2 * det);
-      o.a22 = det / b2a2;
-      o.response = cd.response;
-      o.sub_type = cd.type;
-      o.octave = cd.octave; o.level = cd.level; o.r0 = cd.r0; o.c0 = cd.c0; o.pad = 0;
-      out[(size_t)b * k.max_cand + rank] = o;
-    }
+  }
+}
+
+__global__ __launch_bounds__(256) void export_kernel(DetectConst k, const CandDev *__restrict__ cand, const int *__restrict__ sort_idx,
+                                                     const int *__restrict__ key_count, const int *__restrict__ rank,
+                                                     mods_affkey *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int n = key_count[b];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const CandDev &cd = cand[(size_t)b * k.max_cand + sort_idx[(size_t)b * k.max_cand + i]];
+    mods_affkey o;
+    double a = cd.a11, bb = cd.a12, c = cd.a21, d = cd.a22;
+    o.x = cd.x; o.y = cd.y;
+    o.s = (double)cd.s * sqrt(fabs(a * d - bb * c));
+    const double det = sqrt(fabs(a * d - bb * c));
+    const double b2a2 = sqrt(bb * bb + a * a);
+    o.a11 = b2a2 / det;
+    o.a12 = 0;
+    o.a21 = (d * bb + c * a) / (b2a2 * det);
+    o.a22 = det / b2a2;
+    o.response = cd.response;
+    o.sub_type = cd.type;
+    o.octave = cd.octave; o.level = cd.level; o.r0 = cd.r0; o.c0 = cd.c0; o.pad = 0;
+    out[(size_t)b * k.max_cand + rank[(size_t)b * k.max_cand + i]] = o;
   }
 }
 
@@ -427,9 +503,16 @@ int detect_run(mods_ctx *ctx) {
       const OctaveDev &o = P.oct[oi];
       const int iw = o.w - 2 * par.border, ih = o.h - 2 * par.border;
       if (iw <= 0 || ih <= 0) continue;
-      dim3 grid((iw + 63) / 64, (ih + 3) / 4, n_img);
-      for (int lv = 1; lv <= par.numberOfScales; lv++)
-        hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, ctx->stream, ctx->pyr_dev, oi, lv, k, ctx->cand, ctx->cand_count);
+      const int words = (iw + 63) / 64;
+      dim3 grid(words, (ih + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), n_img);
+      // the ballot words of this octave live at the start of the (not yet used) accept-list half of sort_idx
+      unsigned long long *mask = (unsigned long long *)ctx->nms_mask;
+      const size_t need_words = (size_t)n_img * par.numberOfScales * ih * words;
+      if (need_words > ctx->nms_mask_words) { set_error("nms mask buffer too small"); return MODS_E_CAPACITY; }
+      hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, ctx->stream, ctx->pyr_dev, oi, k, mask);
+      const int total = par.numberOfScales * ih * words;
+      hipLaunchKernelGGL(nms_compact_kernel, dim3((total + 255) / 256, n_img), dim3(256), 0, ctx->stream, oi, o.w, o.h, k, mask, words,
+                         ctx->cand, ctx->cand_count);
     }
     MODS_HIP_CHECK(hipGetLastError());
   }
@@ -450,8 +533,11 @@ int detect_run(mods_ctx *ctx) {
   }
   {
     StageScope ts(ctx, MODS_STAGE_SORT);
-    hipLaunchKernelGGL(rank_export_kernel, dim3(512, n_img), dim3(256), 0, ctx->stream, k, ctx->cand, ctx->sort_keys,
-                       ctx->sort_idx, key_count, ctx->keys_dev);
+    // rank array: the raw-hit half of sort_idx's accept list is dead by now; use the dedicated buffer
+    MODS_HIP_CHECK(hipMemsetAsync(ctx->rank_dev, 0, sizeof(int) * (size_t)ctx->max_cand * n_img, ctx->stream));
+    hipLaunchKernelGGL(rank_count_kernel, dim3(64, 32, n_img), dim3(256), 0, ctx->stream, k, ctx->sort_keys, key_count, ctx->rank_dev);
+    hipLaunchKernelGGL(export_kernel, dim3(256, n_img), dim3(256), 0, ctx->stream, k, ctx->cand, ctx->sort_idx, key_count,
+                       ctx->rank_dev, ctx->keys_dev);
     MODS_HIP_CHECK(hipGetLastError());
   }
   return MODS_OK;
