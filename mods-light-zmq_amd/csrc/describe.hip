@@ -25,37 +25,48 @@ struct OriOut { double a11, a12, a21, a22; int alive; int pad; };
 // Block = 64 lanes.  s_val/s_bin: ps*(ps-2) entries, s_hist: 40 floats.  Returns found/angle
 // (uniform across lanes).
 // ---------------------------------------------------------------------------------------
-__device__ bool dominant_angle_wave(const float *s_patch, const float *__restrict__ orimask, int ps, double th,
+__device__ bool dominant_angle_wave(const float *s_patch, const float *__restrict__ orimask, const double *s_lut, int ps, double th,
                                     float *s_val, int *s_bin, float *s_hist, float *angle_out) {
   const int lane = threadIdx.x;
   const int bins = 36;
   const float PIf = 3.14159265358979323846f;
   const int n = ps * (ps - 2);
-  for (int p = lane; p < n; p += 64) {
-    const int r = 1 + p / ps, c = p - (r - 1) * ps;
-    float mag = 0.f, ori = 0.f;
-    if (c >= 1 && c < ps - 1) {
-      const float xgrad = s_patch[r * ps + c + 1] - s_patch[r * ps + c - 1];
-      const float ygrad = s_patch[(r + 1) * ps + c] - s_patch[(r - 1) * ps + c];
-      mag = sqrtf(xgrad * xgrad + ygrad * ygrad);
-      ori = atan2_lut_ff(ygrad, xgrad);
-    }
-    const float m = orimask[r * ps + c];
+  const int n4 = (n + 3) & ~3;
+  for (int p = lane; p < n4; p += 64) {
     int bin = -1;
     float v = 0.f;
-    if (m > 0 && (double)mag > 1.0) {
-      bin = (int)(bins * (ori / PIf + 1.0f) / 2.0f);
-      v = mag * m;
+    if (p < n) {
+      const int r = 1 + p / ps, c = p - (r - 1) * ps;
+      float mag = 0.f, ori = 0.f;
+      if (c >= 1 && c < ps - 1) {
+        const float xgrad = s_patch[r * ps + c + 1] - s_patch[r * ps + c - 1];
+        const float ygrad = s_patch[(r + 1) * ps + c] - s_patch[(r - 1) * ps + c];
+        mag = sqrtf(xgrad * xgrad + ygrad * ygrad);
+        ori = atan2_lut_ff_t(ygrad, xgrad, s_lut);
+      }
+      const float m = orimask[r * ps + c];
+      if (m > 0 && (double)mag > 1.0) {
+        bin = (int)(bins * (ori / PIf + 1.0f) / 2.0f);
+        v = mag * m;
+      }
     }
     s_val[p] = v;
     s_bin[p] = bin;
   }
   __syncthreads();
-  // one lane per bin, pixels in raster order (bin 36 is write-only in the reference)
+  // one lane per bin, votes in raster order (bin 36 is write-only in the reference).  Votes of other
+  // bins add +0.0f, which leaves the non-negative running sum unchanged, so the scan is branch-free
+  // and reads four votes per LDS access.
   if (lane < bins) {
     float acc = 0.f;
-    for (int p = 0; p < n; p++)
-      if (s_bin[p] == lane) acc += s_val[p];
+    for (int p = 0; p < n4; p += 4) {
+      const int4 b4 = *(const int4 *)(s_bin + p);
+      const float4 v4 = *(const float4 *)(s_val + p);
+      acc += (b4.x == lane) ? v4.x : 0.f;
+      acc += (b4.y == lane) ? v4.y : 0.f;
+      acc += (b4.z == lane) ? v4.z : 0.f;
+      acc += (b4.w == lane) ? v4.w : 0.f;
+    }
     s_hist[lane] = acc;
   }
   __syncthreads();
@@ -90,17 +101,19 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
 }
 
 // grid = (N, n_img), block = 64.  One wave per detected keypoint.
-// dynamic LDS: ps*ps*(2 coords + patch) + ps*(ps-2)*(val + bin) + 40
+// dynamic LDS: lut 256 doubles | patch ps*ps | val, bin ps*(ps-2) (padded to 4) | hist 40
 __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ img_all, DescConst k,
                                                     const mods_affkey *__restrict__ keys_all,
                                                     const int *__restrict__ key_count, const float *__restrict__ orimask,
                                                     OriOut *__restrict__ ori_all) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ps = k.ori_ps, pp2 = ps * ps;
-  const int cst = ps + 1;   // padded row stride of the coordinate tiles (bank-conflict free column writes)
-  float *s_cx = smem, *s_cy = s_cx + ps * cst, *s_patch = s_cy + ps * cst, *s_val = s_patch + pp2;
-  int *s_bin = (int *)(s_val + ps * (ps - 2));
-  float *s_hist = (float *)(s_bin + ps * (ps - 2));
+  const int nv = (ps * (ps - 2) + 3) & ~3;
+  double *s_lut = (double *)smem;
+  float *s_patch = (float *)(s_lut + 256);
+  float *s_val = s_patch + ((pp2 + 3) & ~3);
+  int *s_bin = (int *)(s_val + nv);
+  float *s_hist = (float *)(s_bin + nv);
   const int lane = threadIdx.x;
   const int b = blockIdx.y;
   const float *img = img_all + (size_t)k.w * k.h * b;
@@ -109,6 +122,7 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
   int n = key_count[b];
   if (n > k.max_cand) n = k.max_cand;
   const int half = ps / 2;
+  for (int q = lane; q < 256; q += 64) s_lut[q] = g_atan_lut[q];
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const mods_affkey kp = keys[i];
     bool alive = (kp.x < k.w) && (kp.y < k.h) && (kp.x > 0) && (kp.y > 0);
@@ -123,27 +137,34 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
       const float a11 = f11 * curr_sc, a12 = f12 * curr_sc, a21 = f21 * curr_sc, a22 = f22 * curr_sc;
       const bool touch = check_borders(k.w, k.h, fx, fy, a11, a12, a21, a22, ps, ps);
       __syncthreads();
-      if (lane < ps) {
-        float rx = fx - (float)half * a12;
-        float ry = fy - (float)half * a22;
-        for (int q = 0; q < lane; q++) { rx += a12; ry += a22; }
-        float WX = rx - (float)half * a11;
-        float WY = ry - (float)half * a21;
-        for (int c = 0; c < ps; c++) {
-          s_cx[lane * cst + c] = WX;
-          s_cy[lane * cst + c] = WY;
-          WX += a11;
-          WY += a21;
+      // every lane samples a contiguous run of the ps x ps patch; the run's first coordinates are rebuilt
+      // by replaying the reference's fp32 additions (row steps, then column steps)
+      {
+        const int L = (pp2 + 63) / 64;
+        int idx = lane * L;
+        if (idx < pp2) {
+          int row = idx / ps, col = idx - row * ps;
+          float rx = fx - (float)half * a12;
+          float ry = fy - (float)half * a22;
+          for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
+          float WX = rx - (float)half * a11;
+          float WY = ry - (float)half * a21;
+          for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
+          const int end = min(pp2, idx + L);
+          for (; idx < end; idx++) {
+            s_patch[idx] = bilinear_tap(img, k.w, k.h, WX, WY, touch);
+            if (++col == ps) {
+              col = 0;
+              rx += a12; ry += a22;
+              WX = rx - (float)half * a11;
+              WY = ry - (float)half * a21;
+            } else { WX += a11; WY += a21; }
+          }
         }
       }
       __syncthreads();
-      for (int p = lane; p < pp2; p += 64) {
-        const int q = (p / ps) * cst + (p % ps);
-        s_patch[p] = bilinear_tap(img, k.w, k.h, s_cx[q], s_cy[q], touch);
-      }
-      __syncthreads();
       float ang = 0.f;
-      const bool found = dominant_angle_wave(s_patch, orimask, ps, k.ori_th, s_val, s_bin, s_hist, &ang);
+      const bool found = dominant_angle_wave(s_patch, orimask, s_lut, ps, k.ori_th, s_val, s_bin, s_hist, &ang);
       if (!found) alive = false;
       else {
         double si, ci;
@@ -212,14 +233,23 @@ __global__ __launch_bounds__(1024) void compact_regions_kernel(DescConst k, cons
 __global__ __launch_bounds__(64) void dominant_angle_test_kernel(const float *__restrict__ patch, int ps, double th,
                                                                  const float *__restrict__ orimask, float *out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *s_patch = smem, *s_val = s_patch + ps * ps;
-  int *s_bin = (int *)(s_val + ps * (ps - 2));
-  float *s_hist = (float *)(s_bin + ps * (ps - 2));
+  const int nv = (ps * (ps - 2) + 3) & ~3;
+  double *s_lut = (double *)smem;
+  float *s_patch = (float *)(s_lut + 256);
+  float *s_val = s_patch + ((ps * ps + 3) & ~3);
+  int *s_bin = (int *)(s_val + nv);
+  float *s_hist = (float *)(s_bin + nv);
+  for (int q = threadIdx.x; q < 256; q += 64) s_lut[q] = g_atan_lut[q];
   for (int p = threadIdx.x; p < ps * ps; p += 64) s_patch[p] = patch[p];
   __syncthreads();
   float ang = 0.f;
-  const bool f = dominant_angle_wave(s_patch, orimask, ps, th, s_val, s_bin, s_hist, &ang);
+  const bool f = dominant_angle_wave(s_patch, orimask, s_lut, ps, th, s_val, s_bin, s_hist, &ang);
   if (threadIdx.x == 0) { out[0] = f ? 1.f : 0.f; out[1] = ang; }
+}
+
+static size_t orient_lds_bytes(int ps) {
+  const size_t nv = ((size_t)ps * (ps - 2) + 3) & ~(size_t)3;
+  return sizeof(double) * 256 + sizeof(float) * ((((size_t)ps * ps + 3) & ~(size_t)3) + 2 * nv + 48);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -289,8 +319,7 @@ int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, c
   const SiftTab *tab = (const SiftTab *)(ctx->desc_tables_dev + 8192);
   {
     StageScope ts(ctx, MODS_STAGE_ORIENT);
-    const int ps = k.ori_ps;
-    const size_t lds = sizeof(float) * (2 * (size_t)ps * (ps + 1) + (size_t)ps * ps + 2 * (size_t)ps * (ps - 2) + 48);
+    const size_t lds = orient_lds_bytes(k.ori_ps);
     hipLaunchKernelGGL(orient_kernel, dim3(8192, n_img), dim3(64), lds, ctx->stream, img_dev, k, ctx->keys_dev, key_count,
                        orimask, (OriOut *)ctx->ori_dev);
     hipLaunchKernelGGL(compact_regions_kernel, dim3(1, n_img), dim3(1024), 0, ctx->stream, k, ctx->keys_dev, key_count,
@@ -301,7 +330,7 @@ int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, c
 }
 
 int launch_dominant_angle_test(mods_ctx *ctx, const float *patch_dev, int ps, double th, float *out_dev) {
-  const size_t lds = sizeof(float) * ((size_t)ps * ps + 2 * (size_t)ps * (ps - 2) + 48);
+  const size_t lds = orient_lds_bytes(ps);
   hipLaunchKernelGGL(dominant_angle_test_kernel, dim3(1), dim3(64), lds, ctx->stream, patch_dev, ps, th,
                      ctx->desc_tables_dev, out_dev);
   MODS_HIP_CHECK(hipGetLastError());

@@ -309,9 +309,8 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
                                                       unsigned long long *__restrict__ sort_keys, int *__restrict__ sort_idx,
                                                       int *__restrict__ key_count) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int W = k.smm, WW = W * W;
-  float *s_cx = smem, *s_cy = s_cx + WW, *s_img = s_cy + WW, *s_pa = s_img + WW, *s_pb = s_pa + WW,
-        *s_pc = s_pb + WW, *s_mask = s_pc + WW, *s_sum = s_mask + WW;
+  const int W = k.smm, WW = W * W, WP = (WW + 3) & ~3;
+  float *s_img = smem, *s_pa = s_img + WP, *s_pb = s_pa + WP, *s_pc = s_pb + WP, *s_mask = s_pc + WP, *s_sum = s_mask + WP;
   const int lane = threadIdx.x;
   const int b = blockIdx.y;
   const int half = W / 2;
@@ -335,22 +334,31 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
         const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
         const bool touch = check_borders(iw, ih, lx, ly, a11, a12, a21, a22, W, W);
         __syncthreads();   // previous iteration's readers are done with the tiles
-        // sample coordinates: lane j owns patch row j; rx/ry and WX/WY are sequential fp32 sums
-        if (lane < W) {
-          float rx = lx - (float)half * a12;
-          float ry = ly - (float)half * a22;
-          for (int q = 0; q < lane; q++) { rx += a12; ry += a22; }
-          float WX = rx - (float)half * a11;
-          float WY = ry - (float)half * a21;
-          for (int i = 0; i < W; i++) {
-            s_cx[lane * W + i] = WX;
-            s_cy[lane * W + i] = WY;
-            WX += a11;
-            WY += a21;
+        // every lane samples a contiguous run of the W x W window; its first coordinates are rebuilt by
+        // replaying the reference's sequential fp32 additions (row steps, then column steps)
+        {
+          const int L = (WW + 63) / 64;
+          int idx = lane * L;
+          if (idx < WW) {
+            int row = idx / W, col = idx - row * W;
+            float rx = lx - (float)half * a12;
+            float ry = ly - (float)half * a22;
+            for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
+            float WX = rx - (float)half * a11;
+            float WY = ry - (float)half * a21;
+            for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
+            const int end = min(WW, idx + L);
+            for (; idx < end; idx++) {
+              s_img[idx] = bilinear_tap(im, iw, ih, WX, WY, touch);
+              if (++col == W) {
+                col = 0;
+                rx += a12; ry += a22;
+                WX = rx - (float)half * a11;
+                WY = ry - (float)half * a21;
+              } else { WX += a11; WY += a21; }
+            }
           }
         }
-        __syncthreads();
-        for (int p = lane; p < WW; p += 64) s_img[p] = bilinear_tap(im, iw, ih, s_cx[p], s_cy[p], touch);
         __syncthreads();
         // computeGradient (helpers.cpp:779-797) and the three SMM products
         for (int p = lane; p < WW; p += 64) {
@@ -369,11 +377,16 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
           s_pc[p] = ygrad * ygrad * v;
         }
         __syncthreads();
-        // ordered accumulation (raster order, fp32): three lanes, one sum each
+        // ordered accumulation (raster order, fp32): three lanes, one sum each, four terms per LDS read
         if (lane < 3) {
           const float *arr = lane == 0 ? s_pa : (lane == 1 ? s_pb : s_pc);
           float acc = 0;
-          for (int i = 0; i < WW; i++) acc += arr[i];
+          int i = 0;
+          for (; i + 3 < WW; i += 4) {
+            const float4 v4 = *(const float4 *)(arr + i);
+            acc += v4.x; acc += v4.y; acc += v4.z; acc += v4.w;
+          }
+          for (; i < WW; i++) acc += arr[i];
           s_sum[lane] = acc;
         }
         __syncthreads();
@@ -525,7 +538,7 @@ int detect_run(mods_ctx *ctx) {
   }
   {
     StageScope ts(ctx, MODS_STAGE_BAUMBERG);
-    const size_t lds = sizeof(float) * (7 * (size_t)par.smmWindowSize * par.smmWindowSize + 4);
+    const size_t lds = sizeof(float) * (5 * ((((size_t)par.smmWindowSize * par.smmWindowSize) + 3) & ~(size_t)3) + 4);
     hipLaunchKernelGGL(baumberg_kernel, dim3(8192, n_img), dim3(64), lds, ctx->stream, ctx->pyr_dev, k, ctx->cand,
                        ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->smm_mask_dev, ctx->sort_keys,
                        ctx->sort_idx, key_count);

@@ -44,6 +44,28 @@ __device__ __forceinline__ float bilinear_tap(const float *__restrict__ im, int 
   return 0.f;
 }
 
+// The four pixels of one bilinear tap, loaded without combining them (lets a caller issue the loads
+// of several taps before the first use).  valid = false: the tap is 0 (checked branch, outside).
+struct TapLoads { float r00, r01, r10, r11, wx, wy; bool valid; };
+__device__ __forceinline__ TapLoads tap_load(const float *__restrict__ im, int w, int h, float WX, float WY, bool touch) {
+  TapLoads t;
+  int x, y;
+  if (!touch) { x = (int)WX; y = (int)WY; t.valid = true; }
+  else { x = (int)floorf(WX); y = (int)floorf(WY); t.valid = WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1; }
+  t.wx = WX - (float)x;
+  t.wy = WY - (float)y;
+  if (t.valid) {
+    const float *Row0 = im + (size_t)y * w + x;
+    t.r00 = Row0[0]; t.r01 = Row0[1]; t.r10 = Row0[w]; t.r11 = Row0[w + 1];
+  } else { t.r00 = t.r01 = t.r10 = t.r11 = 0.f; }
+  return t;
+}
+__device__ __forceinline__ float tap_combine(const TapLoads &t) {
+  if (!t.valid) return 0.f;
+  const float I1 = t.wx * (t.r01 - t.r00) + t.r00;
+  return t.wy * (t.wx * (t.r11 - t.r10) + t.r10 - I1) + I1;
+}
+
 // atan2LUTff, helpers.cpp:160-207.  The octant constants are float, the table double: each
 // +/- is a double operation rounded to float on return.
 __device__ const double g_atan_lut[256] = MODS_ATAN_LUT_INIT;

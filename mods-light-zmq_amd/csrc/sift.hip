@@ -63,14 +63,27 @@ __device__ void sample_region(const float *__restrict__ img, int w, int h, float
   float WY = ry - (float)half * a21;
   for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
   const int end = min(total, idx + L);
-  for (; idx < end; idx++) {
-    dst[idx] = bilinear_tap(img, w, h, WX, WY, touch);
-    if (++col == n) {
-      col = 0;
-      rx += a12; ry += a22;
-      WX = rx - (float)half * a11;
-      WY = ry - (float)half * a21;
-    } else { WX += a11; WY += a21; }
+  // four taps per step: coordinates first (sequential fp32 additions), then 16 loads, then the lerps
+  while (idx < end) {
+    TapLoads t[4];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (idx + u < end) {
+        t[u] = tap_load(img, w, h, WX, WY, touch);
+        cnt++;
+        if (++col == n) {
+          col = 0;
+          rx += a12; ry += a22;
+          WX = rx - (float)half * a11;
+          WY = ry - (float)half * a21;
+        } else { WX += a11; WY += a21; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (u < cnt) dst[idx + u] = tap_combine(t[u]);
+    idx += cnt;
   }
 }
 
@@ -110,34 +123,52 @@ __device__ void blur_setup(int P2, float scale, int ps, int n_tap, float *s_tap,
   __syncthreads();
 }
 
-// row pass of the separable blur at the needed columns: T[y][q] = sum_j tap[j] * S[y][clamp(cidx[q]-r+j)]
+// row pass of the separable blur at the needed columns: T[y][q] = sum_j tap[j] * S[y][clamp(cidx[q]-r+j)],
+// taps left to right.  The needed columns come in pairs (x, x+1) whose windows overlap in all but one
+// sample: one thread produces both and loads every sample once.
 __device__ __forceinline__ void row_pass(const float *S, float *T, int rows, int P2, int ps2, int n_tap, const float *s_tap,
                                          const int *s_cidx) {
   const int r_tap = n_tap >> 1;
-  for (int e = threadIdx.x; e < rows * ps2; e += 256) {
-    const int y = e / ps2, q = e - y * ps2;
-    const int x = s_cidx[q];
+  const int pairs = ps2 >> 1;
+  for (int e = threadIdx.x; e < rows * pairs; e += 256) {
+    const int y = e / pairs, pi = e - y * pairs;
+    const int x0 = s_cidx[2 * pi], x1 = s_cidx[2 * pi + 1];
     const float *row = S + (size_t)y * P2;
-    float s;
-    if (x - r_tap >= 0 && x + r_tap <= P2 - 1) {   // interior: no clamping, loads batched four at a time
-      const float *p = row + x - r_tap;
-      s = s_tap[0] * p[0];
+    float s0, s1;
+    if (x1 == x0 + 1 && x0 - r_tap >= 0 && x1 + r_tap <= P2 - 1) {
+      const float *p = row + x0 - r_tap;
+      float prev = p[1];
+      s0 = s_tap[0] * p[0];
+      s1 = s_tap[0] * prev;
       int j = 1;
       for (; j + 3 < n_tap; j += 4) {
-        const float v0 = p[j], v1 = p[j + 1], v2 = p[j + 2], v3 = p[j + 3];
-        s += s_tap[j] * v0; s += s_tap[j + 1] * v1; s += s_tap[j + 2] * v2; s += s_tap[j + 3] * v3;
+        const float c0 = p[j + 1], c1 = p[j + 2], c2 = p[j + 3], c3 = p[j + 4];
+        const float t0 = s_tap[j], t1 = s_tap[j + 1], t2 = s_tap[j + 2], t3 = s_tap[j + 3];
+        s0 += t0 * prev; s1 += t0 * c0;
+        s0 += t1 * c0;   s1 += t1 * c1;
+        s0 += t2 * c1;   s1 += t2 * c2;
+        s0 += t3 * c2;   s1 += t3 * c3;
+        prev = c3;
       }
-      for (; j < n_tap; j++) s += s_tap[j] * p[j];
+      for (; j < n_tap; j++) {
+        const float c = p[j + 1];
+        s0 += s_tap[j] * prev; s1 += s_tap[j] * c;
+        prev = c;
+      }
     } else {
-      int x0 = x - r_tap; x0 = x0 < 0 ? 0 : x0;
-      s = s_tap[0] * row[x0];
+      int xa = x0 - r_tap; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+      int xb = x1 - r_tap; xb = xb < 0 ? 0 : (xb > P2 - 1 ? P2 - 1 : xb);
+      s0 = s_tap[0] * row[xa];
+      s1 = s_tap[0] * row[xb];
       for (int j = 1; j < n_tap; j++) {
-        int xx = x - r_tap + j;
-        xx = xx < 0 ? 0 : (xx > P2 - 1 ? P2 - 1 : xx);
-        s += s_tap[j] * row[xx];
+        xa = x0 - r_tap + j; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+        xb = x1 - r_tap + j; xb = xb < 0 ? 0 : (xb > P2 - 1 ? P2 - 1 : xb);
+        s0 += s_tap[j] * row[xa];
+        s1 += s_tap[j] * row[xb];
       }
     }
-    T[e] = s;
+    T[(size_t)y * ps2 + 2 * pi] = s0;
+    T[(size_t)y * ps2 + 2 * pi + 1] = s1;
   }
 }
 
@@ -179,10 +210,31 @@ __device__ __forceinline__ void col_resample(const float *T, int P2, int ps, int
     float v = 0.f;
     if (!touch2 || (WX >= 0 && WY >= 0 && x < P2 - 1 && y < P2 - 1)) {
       const int y0 = s_cidx[2 * j], y1 = s_cidx[2 * j + 1];
-      const float r00 = col_value(T, P2, ps2, y0, 2 * i, r_tap, s_tap);
-      const float r01 = col_value(T, P2, ps2, y0, 2 * i + 1, r_tap, s_tap);
-      const float r10 = col_value(T, P2, ps2, y1, 2 * i, r_tap, s_tap);
-      const float r11 = col_value(T, P2, ps2, y1, 2 * i + 1, r_tap, s_tap);
+      float r00, r01, r10, r11;
+      if (y1 == y0 + 1 && y0 - r_tap >= 0 && y1 + r_tap <= P2 - 1) {
+        // the four blurred values of this pixel share their column windows: rows y0-r .. y0+1+r of the
+        // column pair (2i, 2i+1) are loaded once (float2) and feed all four sums, each in tap order
+        const float2 *c = (const float2 *)(T + (size_t)y0 * ps2 + 2 * i);
+        const int st = ps2 >> 1;                       // row stride in float2
+        const float2 m0 = c[0], m1 = c[st];
+        const float tc = s_tap[r_tap];
+        r00 = tc * m0.x; r01 = tc * m0.y; r10 = tc * m1.x; r11 = tc * m1.y;
+        float2 up = m1;                                 // row y0 + jj       (jj = 1)
+        float2 dn_prev = m0;                            // row y0 + 1 - jj   (jj = 1)
+        for (int jj = 1; jj <= r_tap; jj++) {
+          const float2 up1 = c[(ptrdiff_t)(jj + 1) * st];   // row y0 + 1 + jj
+          const float2 dn = c[-(ptrdiff_t)jj * st];         // row y0 - jj
+          const float t = s_tap[r_tap + jj];
+          r00 += t * (up.x + dn.x);        r01 += t * (up.y + dn.y);
+          r10 += t * (up1.x + dn_prev.x);  r11 += t * (up1.y + dn_prev.y);
+          up = up1; dn_prev = dn;
+        }
+      } else {
+        r00 = col_value(T, P2, ps2, y0, 2 * i, r_tap, s_tap);
+        r01 = col_value(T, P2, ps2, y0, 2 * i + 1, r_tap, s_tap);
+        r10 = col_value(T, P2, ps2, y1, 2 * i, r_tap, s_tap);
+        r11 = col_value(T, P2, ps2, y1, 2 * i + 1, r_tap, s_tap);
+      }
       const float wx = WX - (float)x;
       const float I1 = wx * (r01 - r00) + r00;
       v = (WY - y) * (wx * (r11 - r10) + r10 - I1) + I1;
@@ -243,6 +295,7 @@ struct BigLists {                     // device-resident bookkeeping, zeroed bef
 };
 
 __device__ __forceinline__ int big_hdr_floats(int n_tap, int ps) { return (n_tap + 3 * ps + 8 + 3) & ~3; }
+__device__ __forceinline__ unsigned long long big_s_floats(int P2) { return ((unsigned long long)P2 * P2 + 1ull) & ~1ull; }   // keeps T 8-byte aligned
 
 // grid = (ceil(reg_cap/256), n_img), block 256: reserve slabs, emit (region, row chunk) work items
 __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mods_region *__restrict__ reg_all,
@@ -257,8 +310,8 @@ __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mo
   const RegionGeom g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps);
   if (g.P2 <= SMALL_CAP) return;
   const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
-  const unsigned long long need = (unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + (unsigned long long)g.P2 * g.P2 +
-                                  (unsigned long long)g.P2 * 2 * k.desc_ps;
+  const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2) +
+                                   (unsigned long long)g.P2 * 2 * k.desc_ps + 3ull) & ~3ull;
   const int li = atomicAdd(&bl->n_regions, 1);
   const int chunks = (g.P2 + BIG_RC - 1) / BIG_RC;
   const unsigned long long off = atomicAdd(&bl->pool_used, need);
@@ -322,14 +375,26 @@ __global__ __launch_bounds__(256) void big_sample_kernel(const float *__restrict
     for (int q = 0; q < col; q++) { WX += g.f11; WY += g.f21; }
     const int end = min(total, idx + L);
     float *dst = S + (size_t)r0 * P2;
-    for (; idx < end; idx++) {
-      dst[idx] = bilinear_tap(img, k.w, k.h, WX, WY, touch);
-      if (++col == P2) {
-        col = 0;
-        rx += g.f12; ry += g.f22;
-        WX = rx - (float)half * g.f11;
-        WY = ry - (float)half * g.f21;
-      } else { WX += g.f11; WY += g.f21; }
+    while (idx < end) {
+      TapLoads t[4];
+      int cnt = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (idx + u < end) {
+          t[u] = tap_load(img, k.w, k.h, WX, WY, touch);
+          cnt++;
+          if (++col == P2) {
+            col = 0;
+            rx += g.f12; ry += g.f22;
+            WX = rx - (float)half * g.f11;
+            WY = ry - (float)half * g.f21;
+          } else { WX += g.f11; WY += g.f21; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (u < cnt) dst[idx + u] = tap_combine(t[u]);
+      idx += cnt;
     }
   }
 }
@@ -353,7 +418,7 @@ __global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const Big
     __syncthreads();
     const int P2 = br.P2;
     const float *S = hdr + big_hdr_floats(br.n_tap, ps);
-    float *T = (float *)S + (size_t)P2 * P2;
+    float *T = (float *)S + big_s_floats(P2);
     const int r0 = item.y, r1 = min(P2, r0 + BIG_RC);
     row_pass(S + (size_t)r0 * P2, T + (size_t)r0 * ps2, r1 - r0, P2, ps2, br.n_tap, s_tap, s_cidx);
   }
@@ -377,7 +442,7 @@ __global__ __launch_bounds__(256) void big_colres_kernel(DescConst k, const BigL
     for (int i = threadIdx.x; i < ps; i += 256) s_seq[i] = hdr[br.n_tap + i];
     for (int i = threadIdx.x; i < ps2; i += 256) s_cidx[i] = ((const int *)(hdr + br.n_tap + ps))[i];
     __syncthreads();
-    const float *T = hdr + big_hdr_floats(br.n_tap, ps) + (size_t)br.P2 * br.P2;
+    const float *T = hdr + big_hdr_floats(br.n_tap, ps) + big_s_floats(br.P2);
     col_resample(T, br.P2, ps, br.n_tap, br.scale, s_tap, s_seq, s_cidx, patches + ((size_t)br.img * k.reg_cap + br.ri) * pp);
   }
 }
