@@ -76,6 +76,8 @@ struct mods_ctx {
   float *tmp_dev = nullptr;
   float *gauss_taps_dev = nullptr;   // [16 slots][64] Gaussian taps
   float taps_sigma[16] = {0};        // sigma currently held by each slot (0 = empty)
+  float taps_host[16][2 * mods::kMaxBlurRadius + 1] = {{0}};
+  int taps_host_n[16] = {0};
   float *smm_mask_dev = nullptr;     // computeGaussMask(smmWindowSize)
   int smm_mask_size = 0;
   // candidates

@@ -148,6 +148,90 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float *__restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Register-blocked blur for radii 1..8 (every blur of the pyramid: ksize 9..15).  Tile = 128 x 64
+// outputs per 256-thread block.  Row pass: a thread produces 4 adjacent outputs from a window of
+// aligned float4 global loads held in registers (taps are kernel arguments -> SGPRs, loops fully
+// unrolled), results go to LDS as float4.  Column pass: float4 LDS reads, centre tap then symmetric
+// pairs.  Same arithmetic order as gauss_blur_kernel.
+// ---------------------------------------------------------------------------------------
+struct BlurTaps { float t[17]; };
+constexpr int FB_TW = 128;   // tile width; the tile height is a template parameter (64: large planes, 16: small planes,
+                             // where a short per-thread row chain matters more than halo reuse)
+
+template <int R, int FB_TH>
+__global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+                                                              BlurTaps taps) {
+  constexpr int N = 2 * R + 1;
+  constexpr int R4 = (R + 3) / 4;            // float4s on each side of the 4 outputs
+  constexpr int NV = 2 * R4 + 1;             // float4s in the register window
+  constexpr int D = 4 * R4 - R;              // window offset of tap 0 for output 0
+  constexpr int ROWS = FB_TH + 2 * R;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // ROWS x FB_TW row-pass results
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)w * h;
+  src += plane * blockIdx.z;
+  dst += plane * blockIdx.z;
+  const int x0 = blockIdx.x * FB_TW, y0 = blockIdx.y * FB_TH;
+  const int tc = tid & 31;                    // 4-pixel column group
+  const int x4 = x0 + 4 * tc;
+  const bool fast_x = (x4 - 4 * R4 >= 0) && (x4 + 4 * R4 + 3 <= w - 1);   // whole window inside the row
+  for (int ly = tid >> 5; ly < ROWS; ly += 8) {
+    int gy = y0 - R + ly;
+    gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+    const float *row = src + (size_t)gy * w;
+    float win[4 * NV];
+    if (fast_x) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        const float4 q = *(const float4 *)(row + x4 - 4 * R4 + 4 * v);
+        win[4 * v] = q.x; win[4 * v + 1] = q.y; win[4 * v + 2] = q.z; win[4 * v + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4 * NV; e++) {
+        int gx = x4 - 4 * R4 + e;
+        gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+        win[e] = row[gx];
+      }
+    }
+    float o[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      float s = taps.t[0] * win[D + u];
+#pragma unroll
+      for (int j = 1; j < N; j++) s += taps.t[j] * win[D + u + j];
+      o[u] = s;
+    }
+    *(float4 *)(smem + ly * FB_TW + 4 * tc) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  __syncthreads();
+  if (x4 < w) {
+    for (int k = 0; k < FB_TH / 8; k++) {
+      const int ly = (tid >> 5) * (FB_TH / 8) + k;
+      const int gy = y0 + ly;
+      if (gy >= h) break;
+      const float *p = smem + (ly + R) * FB_TW + 4 * tc;
+      const float4 c = *(const float4 *)p;
+      float4 s = make_float4(taps.t[R] * c.x, taps.t[R] * c.y, taps.t[R] * c.z, taps.t[R] * c.w);
+#pragma unroll
+      for (int j = 1; j <= R; j++) {
+        const float4 a = *(const float4 *)(p + j * FB_TW), b = *(const float4 *)(p - j * FB_TW);
+        const float t = taps.t[R + j];
+        s.x += t * (a.x + b.x); s.y += t * (a.y + b.y); s.z += t * (a.z + b.z); s.w += t * (a.w + b.w);
+      }
+      float *d = dst + (size_t)gy * w + x4;
+      if (x4 + 3 < w && ((w & 3) == 0)) *(float4 *)d = s;
+      else {
+        d[0] = s.x;
+        if (x4 + 1 < w) d[1] = s.y;
+        if (x4 + 2 < w) d[2] = s.z;
+        if (x4 + 3 < w) d[3] = s.w;
+      }
+    }
+  }
+}
+
 // 3x3 Hessian determinant response.  grid = (ceil(w/64), ceil(h/4), n_img), block = 256.
 __global__ __launch_bounds__(256) void hessian_response_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                                int w, int h, float norm2) {
@@ -219,14 +303,45 @@ static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
   if (ctx->taps_sigma[slot] == sigma) return MODS_OK;
   float taps[2 * kMaxBlurRadius + 1];
   gauss_kernel_host(n, (double)sigma, taps);
+  for (int i = 0; i < n; i++) ctx->taps_host[slot][i] = taps[i];
+  ctx->taps_host_n[slot] = n;
   MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // earlier launches may still read the slot
   MODS_HIP_CHECK(hipMemcpy(ctx->gauss_taps_dev + slot * 64, taps, sizeof(float) * n, hipMemcpyHostToDevice));
   ctx->taps_sigma[slot] = sigma;
   return MODS_OK;
 }
 
+template <int R>
+static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, const BlurTaps &taps) {
+  const int tiles64 = ((w + FB_TW - 1) / FB_TW) * ((h + 63) / 64) * n_img;
+  if (tiles64 >= 1024) {
+    dim3 grid((w + FB_TW - 1) / FB_TW, (h + 63) / 64, n_img);
+    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 64>), grid, dim3(256), sizeof(float) * (size_t)(64 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
+  } else {
+    dim3 grid((w + FB_TW - 1) / FB_TW, (h + 15) / 16, n_img);
+    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16>), grid, dim3(256), sizeof(float) * (size_t)(16 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
+  }
+}
+
 static int blur_with_slot(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, int slot, int n) {
   const int r = n / 2;
+  if (r >= 1 && r <= 8 && (w & 3) == 0 && ctx->taps_host_n[slot] == n) {
+    BlurTaps taps;
+    for (int i = 0; i < 17; i++) taps.t[i] = i < n ? ctx->taps_host[slot][i] : 0.f;
+    StageScope ts(ctx, MODS_STAGE_BLUR, 8.0 * w * h * n_img);
+    switch (r) {
+      case 1: launch_fast_blur<1>(ctx, src, dst, w, h, n_img, taps); break;
+      case 2: launch_fast_blur<2>(ctx, src, dst, w, h, n_img, taps); break;
+      case 3: launch_fast_blur<3>(ctx, src, dst, w, h, n_img, taps); break;
+      case 4: launch_fast_blur<4>(ctx, src, dst, w, h, n_img, taps); break;
+      case 5: launch_fast_blur<5>(ctx, src, dst, w, h, n_img, taps); break;
+      case 6: launch_fast_blur<6>(ctx, src, dst, w, h, n_img, taps); break;
+      case 7: launch_fast_blur<7>(ctx, src, dst, w, h, n_img, taps); break;
+      default: launch_fast_blur<8>(ctx, src, dst, w, h, n_img, taps); break;
+    }
+    MODS_HIP_CHECK(hipGetLastError());
+    return MODS_OK;
+  }
   const size_t lds = sizeof(float) * ((size_t)(BLUR_TH + 2 * r) * (BLUR_TW + 2 * r) + (size_t)(BLUR_TH + 2 * r) * BLUR_TW + 64);
   dim3 grid((w + BLUR_TW - 1) / BLUR_TW, (h + BLUR_TH - 1) / BLUR_TH, n_img);
   StageScope ts(ctx, MODS_STAGE_BLUR, 8.0 * w * h * n_img);
