@@ -170,17 +170,27 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
   extern __shared__ __attribute__((aligned(16))) float smem[];   // ROWS x FB_TW row-pass results
   const int tid = threadIdx.x;
   const size_t plane = (size_t)w * h;
-  src += plane * blockIdx.z;
-  dst += plane * blockIdx.z;
-  const int x0 = blockIdx.x * FB_TW, y0 = blockIdx.y * FB_TH;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2), so every XCD gets a
+  // contiguous band of tiles in (image, tile row, tile column) order and the halo rows shared by
+  // vertically adjacent tiles are served by one L2 instead of being fetched by two.
+  const int tiles_x = (w + FB_TW - 1) / FB_TW, tiles_y = (h + FB_TH - 1) / FB_TH;
+  const int nwg = gridDim.x;
+  const int q8 = nwg / 8, r8 = nwg % 8;
+  const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int img = wg / (tiles_x * tiles_y);
+  const int trem = wg - img * tiles_x * tiles_y;
+  const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+  src += plane * img;
+  dst += plane * img;
+  const int x0 = txi * FB_TW, y0 = tyi * FB_TH;
   const int tc = tid & 31;                    // 4-pixel column group
   const int x4 = x0 + 4 * tc;
   const bool fast_x = (x4 - 4 * R4 >= 0) && (x4 + 4 * R4 + 3 <= w - 1);   // whole window inside the row
-  for (int ly = tid >> 5; ly < ROWS; ly += 8) {
+  auto load_window = [&](int ly, float *win) {
     int gy = y0 - R + ly;
     gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
     const float *row = src + (size_t)gy * w;
-    float win[4 * NV];
     if (fast_x) {
 #pragma unroll
       for (int v = 0; v < NV; v++) {
@@ -195,6 +205,13 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
         win[e] = row[gx];
       }
     }
+  };
+  float win[4 * NV], nxt[4 * NV];
+  int ly = tid >> 5;
+  if (ly < ROWS) load_window(ly, win);
+  for (; ly < ROWS; ly += 8) {
+    const bool more = ly + 8 < ROWS;
+    if (more) load_window(ly + 8, nxt);     // in flight while this row is reduced
     float o[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -204,6 +221,10 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
       o[u] = s;
     }
     *(float4 *)(smem + ly * FB_TW + 4 * tc) = make_float4(o[0], o[1], o[2], o[3]);
+    if (more) {
+#pragma unroll
+      for (int e = 0; e < 4 * NV; e++) win[e] = nxt[e];
+    }
   }
   __syncthreads();
   if (x4 < w) {
@@ -314,12 +335,11 @@ static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
 template <int R>
 static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, const BlurTaps &taps) {
   const int tiles64 = ((w + FB_TW - 1) / FB_TW) * ((h + 63) / 64) * n_img;
-  if (tiles64 >= 1024) {
-    dim3 grid((w + FB_TW - 1) / FB_TW, (h + 63) / 64, n_img);
-    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 64>), grid, dim3(256), sizeof(float) * (size_t)(64 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
-  } else {
-    dim3 grid((w + FB_TW - 1) / FB_TW, (h + 15) / 16, n_img);
-    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16>), grid, dim3(256), sizeof(float) * (size_t)(16 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
+  if (tiles64 >= 384) {   // at least ~1.5 tiles per CU: tall tiles (halo overhead (64+2R)/64)
+    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 64>), dim3(tiles64), dim3(256), sizeof(float) * (size_t)(64 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
+  } else {                // small planes: short tiles, more workgroups, shorter per-thread row chains
+    const int tiles16 = ((w + FB_TW - 1) / FB_TW) * ((h + 15) / 16) * n_img;
+    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16>), dim3(tiles16), dim3(256), sizeof(float) * (size_t)(16 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
   }
 }
 
