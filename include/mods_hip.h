@@ -217,6 +217,19 @@ int mods_ransac_set_device(int device);
 void mods_ransac_pin_seed(long seed);
 /* self-test hook: first n values of srand(seed); rand(); ... from the restated glibc generator */
 void mods_test_glibc_rand(unsigned seed, int n, int *out);
+/* self-test hooks of the host-side pieces of the F-matrix path (no device needed; they let the CPU
+ * test-suite compare the restated solvers with the reference's own degensac build, oracle/_ref):
+ *   seven_point : u7 = 7 correspondences (7 x 6) -> up to 3 matrices in F27, returns their number
+ *                 (-1: null space not two-dimensional)           [exp_ranF.c:884-911]
+ *   u2f         : least-squares F of n >= 8 correspondences idx[] of u, optional weights w[len]   [Ftools.c:302-405]
+ *   checksample : plane-degeneracy test of a 7-point sample      [DegUtils.c:42-82]
+ *   inner_h     : homography LO of the degenerate branch, generator seeded with `seed`   [DegUtils.c:699-735]
+ *   rfth        : plane-and-parallax search, generator seeded with `seed`, candidates counted on the host  [DegUtils.c:233-444] */
+int mods_test_seven_point(const double *u7, double *F27);
+void mods_test_u2f(const double *u, const int *idx, int n, const double *w, double *F);
+int mods_test_checksample(const double *F, const double *u7, double th, double *H);
+unsigned mods_test_inner_h(unsigned seed, double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl);
+unsigned mods_test_rfth(unsigned seed, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F);
 
 /* ---- whole hot path for one image pair ---------------------------------------------------------
  * The step loop body of mods.cpp:202-383 for one step of HessianAffine + RootSIFT on identity views:

@@ -19,6 +19,7 @@
 // the host: it is a chain of data-dependent small solves.
 #include "common.hpp"
 #include "ransac_host.hpp"
+#include "ransac_gpu.hpp"
 #include <ctime>
 #include <cstdlib>
 #include <mutex>
@@ -33,6 +34,7 @@ struct HypDev {            // one scored hypothesis
   double h[9];
   double Hinv[9], H1[9];   // symmetric-error operands (Hinv = h^T as stored, H1 = minv(Hinv))
 };
+static_assert(sizeof(HypDev) <= HYP_SLOT_BYTES, "hypothesis slot too small");
 
 __device__ __forceinline__ void pinvJ_dev(double a, double b, double c, double d, double e, double *pJ) {
   const double a2 = a * a, b2 = b * b, c2 = c * c, d2 = d * d, e2 = e * e;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double *__restr
 }
 
 // grid = ceil(n_hyp/64), block 64: lane k sums gain[i][k] for i = 0..len-1 in order.
-__global__ __launch_bounds__(64) void ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride,
+__global__ void __launch_bounds__(64) ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride,
                                                          double *__restrict__ J) {
   const int k = blockIdx.x * 64 + threadIdx.x;
   if (k >= n_hyp) return;
@@ -142,34 +144,28 @@ __global__ __launch_bounds__(64) void ransac_gain_kernel(const double *__restric
   J[k] = s;
 }
 
-// ---------------------------------------------------------------------------------------
-// per-thread GPU workspace (the C entry point carries no context argument)
-// ---------------------------------------------------------------------------------------
-struct RansacGpu {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  double *u_dev = nullptr; size_t u_cap = 0;
-  HypDev *hyp_dev = nullptr; HypDev *hyp_host = nullptr; int hyp_cap = 0;
-  double *d_dev = nullptr; double *gain_dev = nullptr; size_t dg_cap = 0;
-  int *counts_dev = nullptr; double *J_dev = nullptr;
-  int *counts_host = nullptr; double *J_host = nullptr;
-  double *row_host = nullptr; size_t row_cap = 0;
-  double score_ms = 0; long launches = 0;
-  ~RansacGpu() {
-    if (device < 0) return;
-    (void)hipSetDevice(device);
-    (void)hipFree(u_dev); (void)hipFree(hyp_dev); (void)hipHostFree(hyp_host); (void)hipFree(d_dev); (void)hipFree(gain_dev);
-    (void)hipFree(counts_dev); (void)hipFree(J_dev); (void)hipHostFree(counts_host); (void)hipHostFree(J_host);
-    (void)hipHostFree(row_host);
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-};
+RansacGpu::~RansacGpu() {
+  if (device < 0) return;
+  (void)hipSetDevice(device);
+  (void)hipFree(u_dev); (void)hipFree(hyp_dev); (void)hipHostFree(hyp_host); (void)hipFree(d_dev); (void)hipFree(gain_dev);
+  (void)hipFree(counts_dev); (void)hipFree(J_dev); (void)hipHostFree(counts_host); (void)hipHostFree(J_host);
+  (void)hipHostFree(row_host); (void)hipFree(aux_dev);
+  (void)hipFree(cand_dev); (void)hipHostFree(cand_host); (void)hipFree(candc_dev); (void)hipHostFree(candc_host);
+  if (stream) (void)hipStreamDestroy(stream);
+}
 
 static int g_ransac_device = 0;
 static long g_pinned_seed = -1;
 static std::mutex g_cfg_mutex;
 
-static RansacGpu *ransac_gpu() {
+long ransac_pinned_seed() {
+  long pinned;
+  { std::lock_guard<std::mutex> lk(g_cfg_mutex); pinned = g_pinned_seed; }
+  if (pinned < 0) { const char *e = getenv("MODS_RANSAC_SEED"); if (e) pinned = atol(e); }
+  return pinned;
+}
+
+RansacGpu *ransac_gpu() {
   static thread_local RansacGpu ws;
   if (ws.device < 0) {
     int n = 0;
@@ -184,9 +180,7 @@ static RansacGpu *ransac_gpu() {
   return &ws;
 }
 
-#define RS_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return false; } } while (0)
-
-static bool ws_reserve(RansacGpu *ws, int len, int n_hyp) {
+bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
   if ((size_t)len * 6 > ws->u_cap) {
     if (ws->u_dev) RS_CHECK(hipFree(ws->u_dev));
     ws->u_cap = (size_t)len * 6 * 2;
@@ -196,8 +190,8 @@ static bool ws_reserve(RansacGpu *ws, int len, int n_hyp) {
     if (ws->hyp_dev) { RS_CHECK(hipFree(ws->hyp_dev)); RS_CHECK(hipHostFree(ws->hyp_host)); RS_CHECK(hipFree(ws->counts_dev));
                        RS_CHECK(hipFree(ws->J_dev)); RS_CHECK(hipHostFree(ws->counts_host)); RS_CHECK(hipHostFree(ws->J_host)); }
     ws->hyp_cap = n_hyp;
-    RS_CHECK(hipMalloc(&ws->hyp_dev, sizeof(HypDev) * n_hyp));
-    RS_CHECK(hipHostMalloc(&ws->hyp_host, sizeof(HypDev) * n_hyp));
+    RS_CHECK(hipMalloc(&ws->hyp_dev, (size_t)HYP_SLOT_BYTES * n_hyp));
+    RS_CHECK(hipHostMalloc(&ws->hyp_host, (size_t)HYP_SLOT_BYTES * n_hyp));
     RS_CHECK(hipMalloc(&ws->counts_dev, sizeof(int) * 2 * n_hyp));
     RS_CHECK(hipMalloc(&ws->J_dev, sizeof(double) * n_hyp));
     RS_CHECK(hipHostMalloc(&ws->counts_host, sizeof(int) * 2 * n_hyp));
@@ -223,7 +217,7 @@ static bool ws_reserve(RansacGpu *ws, int len, int n_hyp) {
 static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, double th, double th_check) {
   RS_CHECK(hipMemcpyAsync(ws->hyp_dev, ws->hyp_host, sizeof(HypDev) * n, hipMemcpyHostToDevice, ws->stream));
   RS_CHECK(hipMemsetAsync(ws->counts_dev, 0, sizeof(int) * 2 * n, ws->stream));
-  hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, ws->hyp_dev, err_type,
+  hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, (const HypDev *)ws->hyp_dev, err_type,
                      do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
   hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(64), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
   RS_CHECK(hipGetLastError());
@@ -234,7 +228,7 @@ static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, d
   return true;
 }
 
-static bool gpu_fetch_row(RansacGpu *ws, int len, int k, double *dst) {
+bool ransac_fetch_row(RansacGpu *ws, int len, int k, double *dst) {
   RS_CHECK(hipMemcpyAsync(ws->row_host, ws->d_dev + (size_t)k * len, sizeof(double) * len, hipMemcpyDeviceToHost, ws->stream));
   RS_CHECK(hipStreamSynchronize(ws->stream));
   memcpy(dst, ws->row_host, sizeof(double) * len);
@@ -436,9 +430,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
   else { err_type = -1; custom = HDS1; }   // foreign error function: evaluated where it lives, on the host
   if (inlLimit == 0) inlLimit = 1000000;
 
-  long pinned;
-  { std::lock_guard<std::mutex> lk(g_cfg_mutex); pinned = g_pinned_seed; }
-  if (pinned < 0) { const char *e = getenv("MODS_RANSAC_SEED"); if (e) pinned = atol(e); }
+  const long pinned = ransac_pinned_seed();
   rs::GlibcRand rng;
   rng.seed((unsigned)(pinned >= 0 ? (time_t)pinned : time(NULL)));   // srand(time(NULL)), exp_ranH.c:823
   rs::HashTable ht;
@@ -458,7 +450,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
   ErrFn errfn = {err_type, custom};
   LoState L = {u, len, th, {errs[0], errs[1], errs[2], errs[3], errs[4]}, buffer.data(), &rng, &ht, inlLimit, errfn};
 
-  if (!ws_reserve(ws, len, 64)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+  if (!ransac_ws_reserve(ws, len, 64)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
   if (hipMemcpyAsync(ws->u_dev, u, sizeof(double) * 6 * len, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
       hipStreamSynchronize(ws->stream) != hipSuccess) { fprintf(stderr, "libmodsgpu: upload failed\n"); abort(); }
 
@@ -532,7 +524,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
     int want = batch_size;
     if (want > max_sam - no_sam) want = max_sam - no_sam;
     batch.resize(want);
-    if (!ws_reserve(ws, len, want)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+    if (!ransac_ws_reserve(ws, len, want)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
     int n_valid = 0;
     for (int b = 0; b < want; b++) {
       Sample &sm = batch[b];
@@ -564,7 +556,8 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
       if (std::fabs(v / tol) < 10e-2) continue;     // close to singular
       memcpy(sm.h, sol, sizeof(sm.h));
       sm.valid = 1;
-      HypDev &hd = ws->hyp_host[n_valid];
+      HypDev *hyp_host = (HypDev *)ws->hyp_host;
+      HypDev &hd = hyp_host[n_valid];
       memcpy(hd.h, sol, sizeof(hd.h));
       rs::SymH sh; rs::sym_prepare(sol, &sh);
       memcpy(hd.Hinv, sh.Hinv, sizeof(hd.Hinv)); memcpy(hd.H1, sh.H1, sizeof(hd.H1));
@@ -578,17 +571,17 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
         custom_d.resize((size_t)n_valid * len);
         for (int kq = 0; kq < n_valid; kq++) {
           double *dd = custom_d.data() + (size_t)kq * len;
-          custom(nullptr, u, ws->hyp_host[kq].h, dd, len);
+          custom(nullptr, u, ((HypDev *)ws->hyp_host)[kq].h, dd, len);
           unsigned I = 0, Is = 0; double J = 0;
           for (int j = 0; j < len; j++) { if (dd[j] <= th) I++; J += rs::trunc_quad(dd[j], th); }
-          if (doSymCheck) { HDsSym(nullptr, u, ws->hyp_host[kq].h, d_check.data(), len); for (int j = 0; j < len; j++) if (d_check[j] <= th_check) Is++; }
+          if (doSymCheck) { HDsSym(nullptr, u, ((HypDev *)ws->hyp_host)[kq].h, d_check.data(), len); for (int j = 0; j < len; j++) if (d_check[j] <= th_check) Is++; }
           ws->counts_host[2 * kq] = (int)I; ws->counts_host[2 * kq + 1] = (int)Is; ws->J_host[kq] = J;
         }
       } else if (!gpu_score(ws, len, n_valid, err_type, doSymCheck, th, th_check)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
     }
     auto fetch_row = [&](int slot, double *dst) {
       if (custom) memcpy(dst, custom_d.data() + (size_t)slot * len, sizeof(double) * len);
-      else if (!gpu_fetch_row(ws, len, slot, dst)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+      else if (!ransac_fetch_row(ws, len, slot, dst)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
     };
     // replay the reference's per-iteration decisions in order (exp_ranH.c:858-1083)
     int b = 0;

@@ -1,0 +1,589 @@
+// DEGENSAC fundamental-matrix verification: GPU hypothesis scoring + host control loop.
+//
+// Reference behaviour: exp_ransacFcustom, degensac/exp_ranF.c:805-1202 (LO: exp_inFranicustom
+// :748-800, exp_iterFcustom :622-745; degeneracy handling: DegUtils.c), called from the useF branch
+// of LORANSACFiltering, matching/matching.cpp:714-726.
+//
+// Structure (same idea as ransac.hip).  One 7-point sample per iteration comes from a libc
+// generator that is re-seeded every iteration (srand(seed); 7 x random(); seed = rand(),
+// exp_ranF.c:884-891), so the sample sequence is a function of the first seed only.  It is generated
+// ahead of time on the host together with the 1..3 real solutions of each sample (9x9 null space +
+// cubic), and a batch of candidate matrices is scored over all correspondences on the GPU:
+//   score kernel : thread (correspondence i, candidate k): error d (Sampson or symmetric epipolar),
+//                  truncated-quadratic gain, symmetric-check vote; counts by wave ballots
+//   gain kernel  : MSAC score J_k = sum_i gain[i][k] in correspondence order (ransac.hip)
+// The host replays the reference's decisions per sample and per root in order.  The rare branches
+// stay on the host because they are chains of small data-dependent solves: the plane-degeneracy
+// test of a new best sample, the homography LO, the local optimisation of F.  The one O(N * 10^4)
+// piece of the degenerate branch, the plane-and-parallax search (rFtH), counts its two-point
+// candidates on the GPU in blocks.
+#include "common.hpp"
+#include "ransac_f_host.hpp"
+#include "ransac_gpu.hpp"
+#include <ctime>
+#include <cstdlib>
+
+namespace mods {
+
+using rs::Score;
+
+enum { FERR_SAMPSON = 0, FERR_SYM = 1 };
+
+struct HypF { double f[9]; };
+static_assert(sizeof(HypF) <= HYP_SLOT_BYTES, "hypothesis slot too small");
+
+struct FTerms { double r, a, b; };
+__device__ __forceinline__ FTerms f_terms(const double *u, const double *F) {   // common part of FDs / FDsSym, Ftools.c:94-135
+  const double rxc = F[0] * u[3] + F[3] * u[4] + F[6];
+  const double ryc = F[1] * u[3] + F[4] * u[4] + F[7];
+  const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
+  const double r = (u[0] * rxc + u[1] * ryc + rwc);
+  const double rx = F[0] * u[0] + F[1] * u[1] + F[2];
+  const double ry = F[3] * u[0] + F[4] * u[1] + F[5];
+  FTerms t;
+  t.r = r;
+  t.a = rxc * rxc + ryc * ryc;
+  t.b = rx * rx + ry * ry;
+  return t;
+}
+__device__ __forceinline__ double fds_from(const double *u, const double *F) {
+  const double rxc = F[0] * u[3] + F[3] * u[4] + F[6];
+  const double ryc = F[1] * u[3] + F[4] * u[4] + F[7];
+  const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
+  const double r = (u[0] * rxc + u[1] * ryc + rwc);
+  const double rx = F[0] * u[0] + F[1] * u[1] + F[2];
+  const double ry = F[3] * u[0] + F[4] * u[1] + F[5];
+  return r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+}
+__device__ __forceinline__ double trunc_quad_f(double epsilon, double thr) {
+  if (thr == 0) return 0;
+  if (epsilon >= thr * 9 / 4) return 0;
+  return 1 - (epsilon / (thr * 9 / 4));
+}
+
+// grid = (ceil(len/256), n_hyp), block 256.  d[k][i], gain[i][kstride], counts[k] = {I, Isym}.
+__global__ void __launch_bounds__(256) ransacf_score_kernel(const double *__restrict__ u, int len, const HypF *__restrict__ hyp, int err_type,
+                                                            int do_sym, double th, double th_check, double *__restrict__ d_out,
+                                                            double *__restrict__ gain, int kstride, int *__restrict__ counts) {
+  __shared__ double F[9];
+  const int k = blockIdx.y;
+  if (threadIdx.x < 9) F[threadIdx.x] = hyp[k].f[threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool inl = false, inls = false;
+  if (i < len) {
+    double uu[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) uu[q] = u[(size_t)i * 6 + q];
+    double d, ds = 0;
+    if (err_type == FERR_SYM || do_sym) {
+      const FTerms t = f_terms(uu, F);
+      ds = t.r * t.r * (t.a + t.b) / (t.a * t.b);
+    }
+    d = err_type == FERR_SYM ? ds : fds_from(uu, F);
+    d_out[(size_t)k * len + i] = d;
+    gain[(size_t)i * kstride + k] = trunc_quad_f(d, th);
+    inl = d <= th;
+    inls = do_sym && ds <= th_check;
+  }
+  const unsigned long long m1 = __ballot(inl), m2 = __ballot(inls);
+  if ((threadIdx.x & 63) == 0) {
+    if (m1) atomicAdd(&counts[2 * k], __popcll(m1));
+    if (m2) atomicAdd(&counts[2 * k + 1], __popcll(m2));
+  }
+}
+
+// plane-and-parallax candidates: counts[k] = #{i < n : FDs(uN_i, F_k) < limit}.  grid = (ceil(n/256), k)
+__global__ void __launch_bounds__(256) ransacf_count_kernel(const double *__restrict__ uN, int n, const double *__restrict__ Fs, double limit,
+                                                            int *__restrict__ counts) {
+  __shared__ double F[9];
+  const int k = blockIdx.y;
+  if (threadIdx.x < 9) F[threadIdx.x] = Fs[(size_t)k * 9 + threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool in = false;
+  if (i < n) {
+    double uu[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) uu[q] = uN[(size_t)i * 6 + q];
+    in = fds_from(uu, F) < limit;
+  }
+  const unsigned long long m = __ballot(in);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[k], __popcll(m));
+}
+
+static bool gpu_score_f(RansacGpu *ws, int len, int n, int err_type, int do_sym, double th, double th_check) {
+  RS_CHECK(hipMemcpyAsync(ws->hyp_dev, ws->hyp_host, sizeof(HypF) * n, hipMemcpyHostToDevice, ws->stream));
+  RS_CHECK(hipMemsetAsync(ws->counts_dev, 0, sizeof(int) * 2 * n, ws->stream));
+  hipLaunchKernelGGL(ransacf_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, (const HypF *)ws->hyp_dev,
+                     err_type, do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
+  hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(64), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
+  RS_CHECK(hipGetLastError());
+  RS_CHECK(hipMemcpyAsync(ws->counts_host, ws->counts_dev, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
+  RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ws->stream));
+  RS_CHECK(hipStreamSynchronize(ws->stream));
+  ws->launches += 2;
+  return true;
+}
+
+// off-plane set of rFtH -> aux_dev
+static bool gpu_upload_aux(RansacGpu *ws, const double *uN, unsigned n) {
+  if ((size_t)n * 6 > ws->aux_cap) {
+    if (ws->aux_dev) RS_CHECK(hipFree(ws->aux_dev));
+    ws->aux_cap = (size_t)n * 6 * 2;
+    RS_CHECK(hipMalloc(&ws->aux_dev, ws->aux_cap * sizeof(double)));
+  }
+  RS_CHECK(hipMemcpyAsync(ws->aux_dev, uN, sizeof(double) * 6 * n, hipMemcpyHostToDevice, ws->stream));
+  RS_CHECK(hipStreamSynchronize(ws->stream));
+  return true;
+}
+// counts k candidates (host array Fs, k x 9) over the n off-plane correspondences in aux_dev
+static bool gpu_count_pairs(RansacGpu *ws, unsigned n, const double *Fs, int k, double limit, unsigned *counts) {
+  if (k > ws->cand_cap) {
+    if (ws->cand_dev) { RS_CHECK(hipFree(ws->cand_dev)); RS_CHECK(hipHostFree(ws->cand_host)); RS_CHECK(hipFree(ws->candc_dev)); RS_CHECK(hipHostFree(ws->candc_host)); }
+    ws->cand_cap = k;
+    RS_CHECK(hipMalloc(&ws->cand_dev, sizeof(double) * 9 * k));
+    RS_CHECK(hipHostMalloc(&ws->cand_host, sizeof(double) * 9 * k));
+    RS_CHECK(hipMalloc(&ws->candc_dev, sizeof(int) * k));
+    RS_CHECK(hipHostMalloc(&ws->candc_host, sizeof(int) * k));
+  }
+  memcpy(ws->cand_host, Fs, sizeof(double) * 9 * k);
+  RS_CHECK(hipMemcpyAsync(ws->cand_dev, ws->cand_host, sizeof(double) * 9 * k, hipMemcpyHostToDevice, ws->stream));
+  RS_CHECK(hipMemsetAsync(ws->candc_dev, 0, sizeof(int) * k, ws->stream));
+  hipLaunchKernelGGL(ransacf_count_kernel, dim3((n + 255) / 256, k), dim3(256), 0, ws->stream, ws->aux_dev, (int)n, ws->cand_dev, limit, ws->candc_dev);
+  RS_CHECK(hipGetLastError());
+  RS_CHECK(hipMemcpyAsync(ws->candc_host, ws->candc_dev, sizeof(int) * k, hipMemcpyDeviceToHost, ws->stream));
+  RS_CHECK(hipStreamSynchronize(ws->stream));
+  for (int i = 0; i < k; i++) counts[i] = (unsigned)ws->candc_host[i];
+  ws->launches += 1;
+  return true;
+}
+
+}  // namespace mods
+
+using namespace mods;
+
+extern "C" {
+
+typedef void (*FDsPtr)(const double *, const double *, double *, int);
+typedef void (*exFDsPtr)(const double *, const double *, double *, double *, int);
+
+// Error functions with the reference's signatures (Ftools.h, matching.cpp:44-70).  Host-side; used by
+// the local optimisation and by the LAF check.
+void FDs(const double *u, const double *F, double *p, int len) { rs::FDs_all(u, F, p, len); }
+void FDsSym(const double *u, const double *F, double *p, int len) { rs::FDsSym_all(u, F, p, len); }
+void FDsfull(const double *u, const double *F, double *p, int len) { rs::FDsSym_all(u, F, p, len); }   // SYMMETRIC_ERROR_CHECK is defined, Ftools.c:11
+void exFDs(const double *u, const double *F, double *p, double *w, int len) { rs::exFDs_all(u, F, p, w, len); }
+void exFDsSym(const double *u, const double *F, double *p, double *w, int len) { rs::exFDsSym_all(u, F, p, w, len); }
+
+// ---- host-only self-test hooks (include/mods_hip.h) ----------------------------------------------------
+int mods_test_seven_point(const double *u7, double *F27) {
+  int id[7] = {0, 1, 2, 3, 4, 5, 6};
+  double Z[9 * 7], A[9 * 9], sol[9 * 9], poly[4], roots[3];
+  int nb[18];
+  rs::lin_fm(u7, Z, id, 7);
+  for (int i = 0; i < 7; i++)
+    for (int c = 0; c < 9; c++) A[i * 9 + c] = Z[c * 7 + i];
+  for (int i = 7 * 9; i < 9 * 9; ++i) A[i] = 0.0;
+  memset(sol, 0, sizeof(sol));
+  if (rs::nullspace(A, sol, 9, nb) != 2) return -1;
+  rs::slcm(sol, sol + 9, poly);
+  const int nsol = rs::rroots3(poly, roots);
+  for (int i = 0; i < nsol; i++)
+    for (int j = 0; j < 9; j++) F27[9 * i + j] = sol[j] * roots[i] + sol[9 + j] * (1 - roots[i]);
+  return nsol;
+}
+void mods_test_u2f(const double *u, const int *idx, int n, const double *w, double *F) {
+  std::vector<double> buffer((size_t)9 * n + 96);
+  rs::u2fw(u, idx, w, n, F, buffer.data());
+}
+int mods_test_checksample(const double *F, const double *u7, double th, double *H) { return rs::checksample(F, u7, th, H); }
+unsigned mods_test_inner_h(unsigned seed, double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl) {
+  rs::GlibcRand g;
+  g.seed(seed);
+  std::vector<double> buffer((size_t)18 * len + 96);
+  return rs::innerH(H, u, len, th, iters, inl, g, buffer.data());
+}
+unsigned mods_test_rfth(unsigned seed, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F) {
+  rs::GlibcRand g;
+  g.seed(seed);
+  return rs::rFtH(g, u, hinl, th, H, len, F, nullptr, rs::PairCounter());
+}
+
+}  // extern "C"
+
+namespace mods {
+
+struct FLo {
+  const double *u; int len;
+  double *errs[5];
+  double *buffer;
+  rs::GlibcRand *rng;
+  rs::HashTable *ht;
+  unsigned inlLimit;
+  FDsPtr fds; exFDsPtr exfds;
+};
+
+// least squares on (a subset of) the inliers, exp_ranF.c:647-668 / 706-727 (__D3__: D3_F_RATIO 1, D3_F_MIN 0)
+static void lo_lsq(FLo &L, int *inliers, unsigned n, const double *w, double *f) {
+  unsigned detached = (unsigned)(int)(n * 1);
+  if (detached > L.inlLimit) detached = L.inlLimit;
+  if (detached < 8) detached = 8;
+  if (detached >= n) rs::u2fw(L.u, inliers, w, (int)n, f, L.buffer);
+  else {
+    int *sub = rs::randsubset(*L.rng, inliers, (int)n, (int)detached);
+    rs::u2fw(L.u, sub, w, (int)detached, f, L.buffer);
+  }
+}
+
+// exp_iterFcustom, exp_ranF.c:622-745
+static Score lo_iter_f(FLo &L, int *inliers, double th, double ths, int iters, double *F, int iterID, double *resids) {
+  const int len = L.len;
+  double *d = L.errs[1];
+  double f[9];
+  Score S = {0, 0}, Ss, maxS;
+  std::vector<double> w(len);
+  const double dth = (ths - th) / 4;   // ILSQ_ITERS
+  maxS = rs::inlidxs(L.errs[4], len, th, inliers);
+  if (maxS.I < 8) return S;
+  S = rs::inlidxs(L.errs[4], len, th * 2, inliers);   // th*MWM
+  lo_lsq(L, inliers, S.I, nullptr, f);
+  for (int it = 0; it < iters; it++) {
+    L.exfds(L.u, f, d, w.data(), len);
+    memcpy(resids + (size_t)it * len, d, len * sizeof(double));
+    S = rs::inlidxs(d, len, th, inliers);
+    const uint32_t hash = rs::super_fast_hash((const char *)inliers, (int)(S.I * sizeof(*inliers)));
+    const int ret = L.ht->contains(hash, (int)S.I, iterID);
+    if (ret != -1 && ret != iterID) { S.I = 0; S.J = 0; return S; }
+    if (ret == -1) L.ht->insert(hash, (int)S.I, iterID);
+    if (rs::score_less(maxS, S)) {
+      maxS = S;
+      L.errs[1] = L.errs[0];
+      L.errs[0] = d;
+      d = L.errs[1];
+      memcpy(F, f, 9 * sizeof(double));
+    }
+    // the reference takes the next LSQ support from `d` AFTER the exchange above, i.e. from the buffer
+    // that has just become the scratch one (exp_ranF.c:700) - kept as is
+    Ss = rs::inlidxs(d, len, ths * 2, inliers);
+    if (Ss.I < 8) return maxS;
+    lo_lsq(L, inliers, Ss.I, w.data(), f);
+    ths -= dth;
+  }
+  L.fds(L.u, f, d, len);
+  memcpy(resids + (size_t)4 * len, d, len * sizeof(double));
+  S = rs::inlidxs(d, len, th, inliers);
+  if (rs::score_less(maxS, S)) {
+    maxS = S;
+    L.errs[1] = L.errs[0];
+    L.errs[0] = d;
+    memcpy(F, f, 9 * sizeof(double));
+  }
+  return maxS;
+}
+
+// exp_inFranicustom, exp_ranF.c:748-800 (RAN_REP 10, ILSQ_ITERS 4, TC 4)
+static Score lo_inner_f(FLo &L, int *inliers, int ninl, double th, double *F, int *iterID, double *resids) {
+  const int len = L.len;
+  Score S = {0, 0}, maxS = {0, 0};
+  double *d, f[9];
+  std::vector<int> intbuff(len);
+  if (ninl < 16) {
+    memset(resids, 0, (size_t)(62 - 2) * len * sizeof(double));   // RESIDS_M - 2
+    return maxS;
+  }
+  int ssiz = ninl / 2;
+  if (ssiz > 14) ssiz = 14;
+  d = L.errs[2]; L.errs[2] = L.errs[0]; L.errs[0] = d;
+  for (int i = 0; i < 10; i++) {
+    int *sample = rs::randsubset(*L.rng, inliers, ninl, ssiz);
+    rs::u2f(L.u, sample, ssiz, f, L.buffer);
+    L.fds(L.u, f, L.errs[0], len);
+    memcpy(resids + (size_t)i * 6 * len, L.errs[0], len * sizeof(double));
+    L.errs[4] = L.errs[0];
+    S = lo_iter_f(L, intbuff.data(), th, 4 * th, 4, f, ++*iterID, resids + (size_t)i * 6 * len + len);
+    if (rs::score_less(maxS, S)) {
+      maxS = S;
+      d = L.errs[2]; L.errs[2] = L.errs[0]; L.errs[0] = d;
+      memcpy(F, f, 9 * sizeof(double));
+    }
+  }
+  d = L.errs[2]; L.errs[2] = L.errs[0]; L.errs[0] = d;
+  return maxS;
+}
+
+}  // namespace mods
+
+#define F_FATAL() do { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); } while (0)
+
+extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
+                                  int do_lo, unsigned inlLimit, double **resids, double *H_best, int *Ih, exFDsPtr EXFDS1, FDsPtr FDS1,
+                                  int doSymCheck) {
+  (void)H_best;   // the reference copies zero elements into it (exp_ranF.c:1199)
+  const int RESIDS_M = 2 + 10 * (1 + 4 + 1);
+  const int ITER_SAM = 50;
+  const double CHECK_COEF = 16.0, SYMM_COEF = 0.6;
+  if (resids) *resids = (double *)malloc(8);
+  if (Ih) *Ih = 0;
+  if (len < 7 || !u || !F || !inl || !data_out || !resids) { if (data_out) { data_out[0] = 0; data_out[1] = 0; } return 0; }
+  RansacGpu *ws = ransac_gpu();
+  if (!ws) F_FATAL();   // no CPU fallback
+  if (!FDS1) FDS1 = &FDs;
+  if (!EXFDS1) EXFDS1 = FDS1 == &FDsSym ? &exFDsSym : &exFDs;
+  int err_type = FDS1 == &FDs ? FERR_SAMPSON : FDS1 == &FDsSym ? FERR_SYM : -1;   // -1: foreign error function, evaluated on the host
+
+  const long pinned = ransac_pinned_seed();
+  rs::GlibcRand rng, gen;
+  rng.seed((unsigned)(pinned >= 0 ? (time_t)pinned : time(NULL)));   // srand(time(NULL)), exp_ranF.c:832
+  rs::HashTable ht;
+
+  std::vector<int> pool(len), inliers(len), bufferP(len);
+  for (int i = 0; i < len; i++) pool[i] = i;
+  std::vector<double> Z((size_t)len * 9), buffer((size_t)len * 18 + 96), err((size_t)len * 4), errorsBest(len), HDsv(len), d_check(len);
+  rs::lin_fm(u, Z.data(), pool.data(), len);
+  FLo L;
+  L.u = u; L.len = len; L.buffer = buffer.data(); L.rng = &rng; L.ht = &ht; L.inlLimit = inlLimit; L.fds = FDS1; L.exfds = EXFDS1;
+  for (int i = 0; i < 4; i++) L.errs[i] = err.data() + (size_t)i * len;
+  L.errs[4] = L.errs[3];
+  double **errs = L.errs;
+
+  Score maxS = {8, 0}, maxSs = {8, 0}, S = {0, 0};
+  int no_sam = 0, iter_cnt = 0, degen_cnt = 0, iterID = 0, Ihmax = 0;
+  unsigned non_degen_samples_count = 0;
+  int samidxBest[7] = {0, 0, 0, 0, 0, 0, 0};
+  double FBest[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Hbest[9], H[9], f[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  (void)Hbest;
+  bool bad_model = false;
+  const double th_check = CHECK_COEF * th;
+  unsigned seed = (unsigned)rng.next();   // seed = rand()
+
+  if (!ransac_ws_reserve(ws, len, 96)) F_FATAL();
+  if (hipMemcpyAsync(ws->u_dev, u, sizeof(double) * 6 * len, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
+      hipStreamSynchronize(ws->stream) != hipSuccess) { set_error("upload of the correspondences failed"); F_FATAL(); }
+
+  // plane-and-parallax search with its two-point candidates counted on the GPU
+  unsigned aux_n = 0;
+  auto upload_offplane = [&](const double *uN, unsigned n) { aux_n = n; if (!gpu_upload_aux(ws, uN, n)) F_FATAL(); };
+  rs::PairCounter count_pairs = [&](const double *Fs, int k, unsigned *counts) {
+    if (!gpu_count_pairs(ws, aux_n, Fs, k, th * 2, counts)) F_FATAL();
+  };
+
+  // LO block of the main loop, exp_ranF.c:1032-1070 (__LSQ_BEFORE_LO__); `source` = errs[4] in the loop,
+  // errorsBest in the closing "ALO" run
+  auto run_lo = [&](const double *source, bool *new_max) {
+    iter_cnt++;
+    *resids = (double *)realloc(*resids, (size_t)iter_cnt * RESIDS_M * len * sizeof(double));
+    double *rbase = *resids + (size_t)RESIDS_M * (iter_cnt - 1) * len;
+    memcpy(rbase, errs[4], len * sizeof(double));
+    double *d = errs[0];
+    S = rs::inlidxs(source, len, 4 * th * 2, inliers.data());   // TC*th*MWM
+    rs::u2f(u, inliers.data(), (int)S.I, f, buffer.data());
+    FDS1(u, f, d, len);
+    S = rs::inlidxs(d, len, th, inliers.data());
+    memcpy(rbase + len, d, len * sizeof(double));
+    S = lo_inner_f(L, inliers.data(), (int)S.I, th, f, &iterID, rbase + 2 * len);
+    if (rs::score_less(maxS, S)) {
+      d = errs[0]; errs[0] = errs[3]; errs[3] = d;
+      maxS = S;
+      memcpy(F, f, 9 * sizeof(double));
+      *new_max = true;
+    }
+  };
+
+  struct Sample {
+    unsigned seed_before;
+    int idx[7];        // samidx[0..6] = pool[len-7 .. len-1]
+    int nsol;          // -1: null space not two-dimensional (iteration skipped)
+    double f[3][9];
+    int slot[3];       // scored slot, -1 = rejected by the orientation constraint
+  };
+  std::vector<Sample> batch;
+  int batch_size = 32;
+  int tag[4] = {-1, -1, -1, -1};   // per error buffer: batch slot of the candidate last evaluated into it (-1: content is on the host)
+  bool rng_live = true;          // does `rng` hold the generator state the reference has at this point?
+  unsigned live_seed = 0;
+  auto ensure_rng = [&]() {
+    if (rng_live) return;
+    rng.seed(live_seed);                       // srand(seed); 7 x random(); seed = rand()
+    for (int i = 0; i < 8; i++) (void)rng.next();
+    rng_live = true;
+  };
+
+  while (no_sam < max_sam) {
+    int want = batch_size;
+    if (want > max_sam - no_sam) want = max_sam - no_sam;
+    batch.resize(want);
+    if (!ransac_ws_reserve(ws, len, 3 * want)) F_FATAL();
+    HypF *hyp_host = (HypF *)ws->hyp_host;
+    int n_hyp = 0;
+    for (int b = 0; b < want; b++) {
+      Sample &sm = batch[b];
+      sm.seed_before = seed;
+      gen.seed(seed);
+      double A[9 * 9], sol[9 * 9];
+      int nb[18];
+      for (int i = 0; i < 7; i++) {                 // rsampleT(Z, 9, pool, 7, len, A), rtools.c:12-23, 83-101
+        const int s = gen.next() % (len - i);
+        const int j = len - i - 1;
+        const int q = pool[s];
+        pool[s] = pool[j];
+        pool[j] = q;
+        for (int c = 0; c < 9; c++) A[i * 9 + c] = Z[(size_t)c * len + q];
+      }
+      seed = (unsigned)gen.next();
+      for (int i = 0; i < 7; i++) sm.idx[i] = pool[len - 7 + i];
+      for (int i = 7 * 9; i < 9 * 9; ++i) A[i] = 0.0;
+      memset(sol, 0, sizeof(sol));
+      sm.nsol = -1;
+      if (rs::nullspace(A, sol, 9, nb) != 2) continue;
+      double poly[4], roots[3];
+      double *f1 = sol, *f2 = sol + 9;
+      rs::slcm(f1, f2, poly);
+      sm.nsol = rs::rroots3(poly, roots);
+      for (int i = 0; i < sm.nsol; i++) {
+        for (int j = 0; j < 9; j++) sm.f[i][j] = f1[j] * roots[i] + f2[j] * (1 - roots[i]);
+        sm.slot[i] = -1;
+        if (!rs::all_ori_valid(sm.f[i], u, sm.idx, 7)) continue;
+        memcpy(hyp_host[n_hyp].f, sm.f[i], sizeof(sm.f[i]));
+        sm.slot[i] = n_hyp++;
+      }
+    }
+    std::vector<double> host_d;
+    if (n_hyp > 0) {
+      if (err_type < 0) {
+        host_d.resize((size_t)n_hyp * len);
+        for (int kq = 0; kq < n_hyp; kq++) {
+          double *dd = host_d.data() + (size_t)kq * len;
+          FDS1(u, hyp_host[kq].f, dd, len);
+          unsigned I = 0, Is = 0; double J = 0;
+          for (int j = 0; j < len; j++) { if (dd[j] <= th) I++; J += rs::trunc_quad(dd[j], th); }
+          if (doSymCheck) { FDsSym(u, hyp_host[kq].f, d_check.data(), len); for (int j = 0; j < len; j++) if (d_check[j] <= th_check) Is++; }
+          ws->counts_host[2 * kq] = (int)I; ws->counts_host[2 * kq + 1] = (int)Is; ws->J_host[kq] = J;
+        }
+      } else if (!gpu_score_f(ws, len, n_hyp, err_type, doSymCheck, th, th_check)) F_FATAL();
+    }
+    std::vector<int> cnt(ws->counts_host, ws->counts_host + 2 * n_hyp);
+    std::vector<double> Jv(ws->J_host, ws->J_host + n_hyp);
+    auto fetch_row = [&](int slot, double *dst) {
+      if (err_type < 0) memcpy(dst, host_d.data() + (size_t)slot * len, sizeof(double) * len);
+      else if (!ransac_fetch_row(ws, len, slot, dst)) F_FATAL();
+    };
+    // The reference evaluates every candidate straight into errs[i] (exp_ranF.c:920-921), so a buffer
+    // that an older pointer still refers to (errs[4] after its buffer has rotated out of errs[3]) holds
+    // the errors of whichever candidate was written there LAST.  The rows stay on the GPU; each of the
+    // four buffers carries the slot of its last writer and is filled in when somebody reads it.
+    auto buf_of = [&](const double *p) { return (int)((p - err.data()) / len); };
+    auto materialise = [&](double *p) {
+      const int bi = buf_of(p);
+      if (tag[bi] >= 0) { fetch_row(tag[bi], p); tag[bi] = -1; }
+    };
+    auto materialise_all = [&]() { for (int q = 0; q < 4; q++) materialise(err.data() + (size_t)q * len); };
+
+    // replay of the reference's per-iteration decisions (exp_ranF.c:880-1079)
+    int b = 0;
+    for (; b < want && no_sam < max_sam; b++) {
+      const Sample &sm = batch[b];
+      no_sam++;
+      rng_live = false; live_seed = sm.seed_before;
+      if (sm.nsol < 0) continue;
+      double u7[6 * 7];
+      for (int i = 0; i < 7; i++) memcpy(u7 + 6 * i, u + 6 * sm.idx[i], 6 * sizeof(double));
+      bool new_max = false, do_iterate = false;
+      int LmaxI = 0;
+      for (int i = 0; i < sm.nsol; i++) {
+        memcpy(f, sm.f[i], sizeof(f));
+        if (sm.slot[i] < 0) continue;
+        const int slot = sm.slot[i];
+        double *d = errs[i];
+        tag[buf_of(d)] = slot;
+        S.I = (unsigned)cnt[2 * slot];
+        S.J = Jv[slot];
+        if ((int)S.I > LmaxI) LmaxI = (int)S.I;
+        if (rs::score_less(maxS, S)) {
+          if (doSymCheck) {
+            const int SI_min = (int)std::floor(SYMM_COEF * S.I);
+            bad_model = cnt[2 * slot + 1] <= SI_min;
+          }
+          if (bad_model) continue;
+          materialise(d);
+          errs[i] = errs[3];
+          errs[3] = d;
+          maxS = S;
+          memcpy(F, f, 9 * sizeof(double));
+          new_max = true;
+        }
+        if (rs::score_less(maxSs, S)) {
+          maxSs = S;
+          if (rs::checksample(f, u7, 3 * th, H)) {
+            rs::dHDs(H, u, (unsigned)len, HDsv.data());
+            unsigned I = 0;
+            for (int j = 0; j < len; ++j) if (HDsv[j] < th * 3) ++I;
+            if (I < 8) break;
+            ensure_rng();
+            I = rs::innerH(H, u, (unsigned)len, 16 * th, 10, inl, rng, buffer.data());
+            if ((int)I > Ihmax) { Ihmax = (int)I; memcpy(Hbest, H, sizeof(Hbest)); }
+            if (I > 6) {
+              materialise_all();
+              I = rs::rFtH(rng, u, inl, th, H, (unsigned)len, f, upload_offplane, count_pairs);
+              if (I > maxS.I) {
+                FDS1(u, f, errs[3], len);
+                maxS.I = I;                       // maxS.J follows below
+                memcpy(F, f, 9 * sizeof(double));
+                new_max = true;
+                d = errs[3];
+              } else {
+                FDS1(u, f, errs[i], len);
+                d = errs[i];
+              }
+              double jj = 0;
+              for (int j = 0; j < len; j++) jj += rs::trunc_quad(d[j], th);
+              if (new_max) maxS.J = jj;
+              ++degen_cnt;
+            }
+          } else {
+            do_iterate = (do_lo > 0 && (no_sam > ITER_SAM));
+            materialise(d);
+            errs[4] = d;
+            non_degen_samples_count++;
+            memcpy(samidxBest, sm.idx, sizeof(samidxBest));
+            memcpy(errorsBest.data(), d, len * sizeof(double));
+            memcpy(FBest, f, sizeof(FBest));
+          }
+        }
+      }
+      data_out[LmaxI + 2]++;
+      if (do_lo > 0 && (no_sam == ITER_SAM) && non_degen_samples_count) do_iterate = true;
+      if (do_iterate) {
+        ensure_rng();
+        materialise_all();
+        run_lo(errs[4], &new_max);
+      }
+      if (new_max) {
+        const int new_sam = rs::nsamples((int)maxS.I + 1, len, 7, conf);
+        if (new_sam < max_sam) max_sam = new_sam;
+      }
+    }
+    materialise_all();          // the rows of this batch are about to be overwritten
+    if (b < want) break;        // stopped inside the batch
+    if (batch_size < 512) batch_size *= 2;
+  }
+
+  // "If there were no LOs, do at least one NOW!", exp_ranF.c:1082-1163.  The sample kept in
+  // samidxBest/FBest is one that checksample() has already classified as non-degenerate (it is
+  // recorded only in that branch, :1023-1029) and the test is deterministic, so the degenerate arm of
+  // the reference's closing block cannot be taken; only its LO arm exists here.
+  if (do_lo && (!iter_cnt && !degen_cnt) && non_degen_samples_count) {
+    ensure_rng();
+    bool nm = false;
+    run_lo(errorsBest.data(), &nm);
+  }
+
+  {
+    const double *d = errs[3];
+    for (int j = 0; j < len; j++) inl[j] = d[j] <= th ? 1 : 0;
+  }
+  data_out[0] = no_sam;
+  data_out[1] = iter_cnt;
+  if (Ih) *Ih = Ihmax;
+  return (int)maxS.I;
+}

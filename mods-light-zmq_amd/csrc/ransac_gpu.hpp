@@ -1,0 +1,36 @@
+// Per-thread GPU workspace shared by the homography and the fundamental-matrix verification
+// (the reference's C entry points carry no context argument, so the workspace is thread-local).
+#pragma once
+#include "common.hpp"
+#include <mutex>
+
+namespace mods {
+
+struct RansacGpu {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  double *u_dev = nullptr; size_t u_cap = 0;
+  void *hyp_dev = nullptr; void *hyp_host = nullptr; int hyp_cap = 0;   // hyp_cap slots of HYP_SLOT_BYTES
+  double *d_dev = nullptr; double *gain_dev = nullptr; size_t dg_cap = 0;
+  int *counts_dev = nullptr; double *J_dev = nullptr;
+  int *counts_host = nullptr; double *J_host = nullptr;
+  double *row_host = nullptr; size_t row_cap = 0;
+  double *aux_dev = nullptr; size_t aux_cap = 0;        // second point set (off-plane correspondences of rFtH)
+  double *cand_dev = nullptr, *cand_host = nullptr;     // two-point candidates of rFtH (9 doubles each) and their counts
+  int *candc_dev = nullptr, *candc_host = nullptr; int cand_cap = 0;
+  double score_ms = 0; long launches = 0;
+  ~RansacGpu();
+};
+enum { HYP_SLOT_BYTES = 27 * 8 };   // largest hypothesis record (homography + its two symmetric operands)
+
+RansacGpu *ransac_gpu();                                  // nullptr + mods_last_error when no device
+bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp);
+bool ransac_fetch_row(RansacGpu *ws, int len, int k, double *dst);
+long ransac_pinned_seed();                                // >= 0: pinned (mods_ransac_pin_seed / MODS_RANSAC_SEED)
+
+// lane k adds gain[i][k], i = 0..len-1, in correspondence order (the MSAC score is a sequential sum)
+__global__ void ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride, double *__restrict__ J);
+
+#define RS_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return false; } } while (0)
+
+}  // namespace mods
