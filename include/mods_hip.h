@@ -200,6 +200,7 @@ typedef struct mods_ransac_params {
   double HLAFCoef;          /* 12 */
   int errorType;            /* 0 */
   int doSymmCheck;          /* 1 */
+  int useF;                 /* 0: homography (ver_type "Homog"), 1: epipolar geometry (DEGENSAC, ver_type "Epipolar") */
 } mods_ransac_params;
 
 /* Replaces  int LORANSACFiltering(TentativeCorrespListExt &in, TentativeCorrespListExt &out, double *H,
@@ -209,6 +210,13 @@ typedef struct mods_ransac_params {
  * (all -1 when no model).  stats3 (optional) = {samples drawn, LO runs, orientation rejects}. */
 int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask,
                     double *H_out, int *n_inliers, int *stats3);
+/* The useF = 1 branch of the same function (matching.cpp:711-726, 804-816): exp_ransacFcustom (inlLimit 0,
+ * error functions by errorType: 0 FDs/exFDs, otherwise FDsSym/exFDsSym) followed by F_LAF_check
+ * (matching.cpp:192-249, bound LAFCoef * err_threshold).  F_out = the matrix as degensac stores it
+ * (x2^T F x1 = 0, F_out[3*c + r] = entry (r, c)), as ransac_corresp.H receives it; all -1 when n < 8.
+ * stats3 = {samples drawn, LO runs, plane consensus *Ih}. */
+int mods_loransac_f(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask,
+                    double *F_out, int *n_inliers, int *stats3);
 /* GPU used by the degensac entry points of the calling thread (default 0). */
 int mods_ransac_set_device(int device);
 /* The reference seeds with srand(time(NULL)) (exp_ranH.c:823).  seed >= 0 makes every call behave as if
@@ -254,7 +262,7 @@ typedef struct mods_pair_result {
   int n_unique;              /* after duplicate filtering */
   int n_inliers;             /* after RANSAC + NaiveHCheck + H_LAF_check */
   int ransac_samples, ransac_lo, ransac_rejects;
-  double H[9];               /* row-major img1 -> img2, all -1 when verification failed */
+  double H[9];               /* row-major img1 -> img2, all -1 when verification failed; with ransac.useF: F as degensac stores it */
   /* wall-clock per stage in ms, the reference's TimeLog buckets (detectors/structures.hpp:33-56) */
   double ms_detect_describe, ms_match, ms_duplicates, ms_ransac;
 } mods_pair_result;

@@ -287,11 +287,11 @@ class RansacParams(C.Structure):
     """[RANSAC] section (io_mods.cpp:437-455).  errorType 0 Sampson, 1 SymmMax, 2 SymmSum."""
     _fields_ = [("err_threshold", C.c_double), ("confidence", C.c_double), ("max_samples", C.c_int),
                 ("localOptimization", C.c_int), ("LAFCoef", C.c_double), ("HLAFCoef", C.c_double),
-                ("errorType", C.c_int), ("doSymmCheck", C.c_int)]
+                ("errorType", C.c_int), ("doSymmCheck", C.c_int), ("useF", C.c_int)]
 
     @staticmethod
-    def default():
-        return RansacParams(4.0, 0.99, 1000000, 1, 2.0, 12.0, 0, 1)   # config_affori_classic.ini
+    def default(useF=0):
+        return RansacParams(4.0, 0.99, 1000000, 1, 2.0, 12.0, 0, 1, useF)   # config_affori_classic.ini
 
 
 _ERR = {"sampson": ("HDs", "HDsi", "HDsidx"), "symm_max": ("HDsSymMax", "HDsiSymMax", "HDsSymidxMax"),
@@ -362,6 +362,23 @@ def loransac_h(u6, laf, params=None, seed_time=12345):
                                  n, C.byref(params), mask.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
                                  C.byref(ninl), stats))
     return mask[:n].astype(bool), H.reshape(3, 3), ninl.value, list(stats)
+
+
+def loransac_f(u6, laf, params=None, seed_time=12345):
+    """useF branch of LORANSACFiltering: DEGENSAC + F_LAF_check.  Returns (mask, F as stored, n, stats)."""
+    params = params or RansacParams.default(useF=1)
+    ransac_pin_seed(seed_time)
+    u = np.ascontiguousarray(u6, np.float64)
+    n = len(u)
+    lf = np.ascontiguousarray(laf, np.float64) if laf is not None else None
+    mask = np.zeros(max(n, 1), np.uint8)
+    F = np.zeros(9, np.float64)
+    ninl = C.c_int()
+    stats = (C.c_int * 3)()
+    _check(lib().mods_loransac_f(u.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p) if lf is not None else None,
+                                 n, C.byref(params), mask.ctypes.data_as(C.c_void_p), F.ctypes.data_as(C.c_void_p),
+                                 C.byref(ninl), stats))
+    return mask[:n].astype(bool), F, ninl.value, list(stats)
 
 
 # ---- one pair end to end ------------------------------------------------------------------------------

@@ -430,6 +430,14 @@ mods_score exp_ransacHcustom(double *u, int len, double th, double conf, int max
                              void (*HDS1)(const double *, const double *, const double *, double *, int),
                              void (*HDSi1)(const double *, const double *, const double *, double *, int, int *, int),
                              void (*HDSidx1)(const double *, const double *, const double *, double *, int, int *, int), int doSymCheck);
+int exp_ransacFcustom(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out, int do_lo,
+                      unsigned inlLimit, double **resids, double *H_best, int *Ih,
+                      void (*EXFDS1)(const double *, const double *, double *, double *, int),
+                      void (*FDS1)(const double *, const double *, double *, int), int doSymCheck);
+void FDs(const double *, const double *, double *, int);
+void FDsSym(const double *, const double *, double *, int);
+void exFDs(const double *, const double *, double *, double *, int);
+void exFDsSym(const double *, const double *, double *, double *, int);
 void HDs(const double *, const double *, const double *, double *, int);
 void HDsSym(const double *, const double *, const double *, double *, int);
 void HDsSymMax(const double *, const double *, const double *, double *, int);
@@ -543,6 +551,56 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
   return MODS_OK;
 }
 
+// useF branch of LORANSACFiltering (matching.cpp:711-726, 804-816): DEGENSAC + F_LAF_check (:192-249)
+int mods_loransac_f(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask, double *F_out,
+                    int *n_inliers, int *stats3) {
+  if (!par || !mask || !F_out || !n_inliers || (n > 0 && !u6)) { set_error("loransac_f: null argument"); return MODS_E_ARG; }
+  *n_inliers = 0;
+  for (int i = 0; i < 9; i++) F_out[i] = -1;
+  for (int i = 0; i < n; i++) mask[i] = 0;
+  if (stats3) { stats3[0] = stats3[1] = stats3[2] = 0; }
+  const int MIN_POINTS = 8;
+  if (n < MIN_POINTS) return MODS_OK;
+  std::vector<double> u2(u6, u6 + (size_t)n * 6);
+  std::vector<unsigned char> inl2(n);
+  std::vector<int> data_out((size_t)n * 18, 0);
+  double Floran[9], HinF[9];
+  double *resids = nullptr;
+  int I_H = 0;
+  void (*fds)(const double *, const double *, double *, int) = par->errorType == 0 ? &FDs : &FDsSym;
+  void (*exfds)(const double *, const double *, double *, double *, int) = par->errorType == 0 ? &exFDs : &exFDsSym;
+  exp_ransacFcustom(u2.data(), n, par->err_threshold * par->err_threshold, par->confidence, par->max_samples, Floran, inl2.data(),
+                    data_out.data(), par->localOptimization, 0, &resids, HinF, &I_H, exfds, fds, par->doSymmCheck);
+  free(resids);
+  if (stats3) { stats3[0] = data_out[0]; stats3[1] = data_out[1]; stats3[2] = I_H; }
+  std::vector<int> cur;
+  for (int i = 0; i < n; i++) if (inl2[i]) cur.push_back(i);
+  const double affineFerror = par->LAFCoef * par->err_threshold;
+  if (affineFerror > 0 && laf) {
+    std::vector<int> good;
+    const double ks = 3.0;   // k_sigma, matching.cpp:171
+    for (int i : cur) {
+      const double *f = laf + (size_t)i * 14;
+      double u[18], err[3];
+      u[0] = f[0]; u[1] = f[1]; u[2] = 1.0;
+      u[3] = f[7]; u[4] = f[8]; u[5] = 1.0;
+      u[6] = u[0] + ks * f[3] * f[6]; u[7] = u[1] + ks * f[5] * f[6]; u[8] = 1.0;
+      u[9] = u[3] + ks * f[10] * f[13]; u[10] = u[4] + ks * f[12] * f[13]; u[11] = 1.0;
+      u[12] = u[0] + ks * f[2] * f[6]; u[13] = u[1] + ks * f[4] * f[6]; u[14] = 1.0;
+      u[15] = u[3] + ks * f[9] * f[13]; u[16] = u[4] + ks * f[11] * f[13]; u[17] = 1.0;
+      fds(u, Floran, err, 3);
+      const double sumErr = std::sqrt(err[0]) + std::sqrt(err[1]) + std::sqrt(err[2]);
+      if (!(sumErr > affineFerror)) good.push_back(i);
+    }
+    cur.swap(good);
+  }
+  if ((int)cur.size() < MIN_POINTS) cur.clear();
+  for (int i : cur) mask[i] = 1;
+  *n_inliers = (int)cur.size();
+  for (int i = 0; i < 9; i++) F_out[i] = Floran[i];     // ransac_corresp.H[i] = Hloran[i], matching.cpp:814-815
+  return MODS_OK;
+}
+
 // ---- one pair end to end -------------------------------------------------------------------------------
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -591,7 +649,9 @@ int mods_pair_verify_stage(int device, const mods_pair_params *par, mods_pair_re
   int stats[3] = {0, 0, 0};
   mods_ransac_set_device(device);
   std::vector<unsigned char> mask(nu > 0 ? nu : 1);
-  if ((rc = mods_loransac_h(u6->data(), laf->data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats))) return rc;
+  if (par->ransac.useF) rc = mods_loransac_f(u6->data(), laf->data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats);
+  else rc = mods_loransac_h(u6->data(), laf->data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats);
+  if (rc) return rc;
   res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
   res->ms_ransac = now_ms() - t3;
   if (matches_out) {

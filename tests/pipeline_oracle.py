@@ -95,12 +95,53 @@ def loransac_h(u6, laf, err_threshold=4.0, conf=0.99, max_samples=1000000, hlaf=
     return mask, H.reshape(3, 3), len(good), stats
 
 
-def match_pair(img1, img2, seed_time=12345, ratio=0.8):
+def fds(u, F):
+    """FDs (Ftools.c:94-112) on rows of u[n,6]; F as degensac stores it."""
+    rxc = F[0] * u[:, 3] + F[3] * u[:, 4] + F[6]
+    ryc = F[1] * u[:, 3] + F[4] * u[:, 4] + F[7]
+    rwc = F[2] * u[:, 3] + F[5] * u[:, 4] + F[8]
+    r = u[:, 0] * rxc + u[:, 1] * ryc + rwc
+    rx = F[0] * u[:, 0] + F[1] * u[:, 1] + F[2]
+    ry = F[3] * u[:, 0] + F[4] * u[:, 1] + F[5]
+    return r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry)
+
+
+def loransac_f(u6, laf, err_threshold=4.0, conf=0.99, max_samples=1000000, laf_coef=2.0, sym=1, do_lo=1, seed_time=12345):
+    """LORANSACFiltering, matching.cpp:711-726 + 804-816 (useF = 1), on top of the reference's exp_ransacFcustom."""
+    n = len(u6)
+    mask = np.zeros(n, bool)
+    if n < 8:
+        return mask, -np.ones(9), 0, [0, 0, 0]
+    r = refdeg.ransac_f(u6, err_threshold ** 2, conf, max_samples, "sampson", sym, do_lo, 0, seed_time)
+    stats = [r["samples"], r["lo"], r["Ih"]]
+    F = r["F"]
+    cur = np.nonzero(r["inl"])[0]
+    thr = laf_coef * err_threshold
+    good = []
+    for i in cur:
+        f = laf[i]
+        u = np.zeros((3, 6))
+        u[0] = [f[0], f[1], 1, f[7], f[8], 1]
+        u[1] = [f[0] + 3.0 * f[3] * f[6], f[1] + 3.0 * f[5] * f[6], 1, f[7] + 3.0 * f[10] * f[13], f[8] + 3.0 * f[12] * f[13], 1]
+        u[2] = [f[0] + 3.0 * f[2] * f[6], f[1] + 3.0 * f[4] * f[6], 1, f[7] + 3.0 * f[9] * f[13], f[8] + 3.0 * f[11] * f[13], 1]
+        e = fds(u, F)
+        if not (np.sqrt(e[0]) + np.sqrt(e[1]) + np.sqrt(e[2]) > thr):
+            good.append(i)
+    if len(good) < 8:
+        good = []
+    mask[good] = True
+    return mask, F, len(good), stats
+
+
+def match_pair(img1, img2, seed_time=12345, ratio=0.8, use_f=False):
     ra, nd1 = orc.detect_describe(img1)
     rb, nd2 = orc.detect_describe(img2)
     tc = orc.match_fginn(ra, rb, ratio)
     un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
     u6, laf = u6_of(ra, rb, un), laf_of(ra, rb, un)
-    mask, H, ninl, stats = loransac_h(u6, laf, seed_time=seed_time)
+    if use_f:
+        mask, H, ninl, stats = loransac_f(u6, laf, seed_time=seed_time)
+    else:
+        mask, H, ninl, stats = loransac_h(u6, laf, seed_time=seed_time)
     return dict(n_detected=[nd1, nd2], n_described=[len(ra), len(rb)], n_tentatives=len(tc), n_unique=len(un),
                 n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6)

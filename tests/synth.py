@@ -84,3 +84,45 @@ def pair(w, h, seed=0):
     rng = np.random.default_rng(seed + 104729)
     H = random_homography(rng, w, h)
     return img1, warp(img1, H, seed=seed), H
+
+
+def _warp_src(H, xx, yy):
+    Hi = np.linalg.inv(H)
+    den = Hi[2, 0] * xx + Hi[2, 1] * yy + Hi[2, 2]
+    return (Hi[0, 0] * xx + Hi[0, 1] * yy + Hi[0, 2]) / den, (Hi[1, 0] * xx + Hi[1, 1] * yy + Hi[1, 2]) / den
+
+
+def pair_two_planes(w, h, seed=0, noise_sigma=2.0):
+    """(img1, img2, F, HA, HB): a scene of two planes seen from two viewpoints.  Image 1 is split by a slanted
+    line; the two halves move with homographies HA and HB = HA + e a^T (same epipole e), so that all
+    true correspondences satisfy x2^T F x1 = 0 with F = [e]x HA, and no single homography explains them."""
+    img1 = texture(w, h, seed)
+    rng = np.random.default_rng(seed + 15485863)
+    HA = random_homography(rng, w, h)
+    e = np.array([w * rng.uniform(2.5, 4.0) * rng.choice([-1, 1]), h * rng.uniform(-1.0, 2.0), 1.0])
+    a = np.array([rng.uniform(-1, 1) * 6e-6, rng.uniform(-1, 1) * 6e-6, rng.uniform(0.012, 0.02) * rng.choice([-1, 1])])
+    HB = HA + np.outer(e, a)
+    HB = HB / HB[2, 2]
+    # region A: left of a slanted line through the image centre
+    nx, ny = np.cos(np.deg2rad(rng.uniform(-30, 30))), np.sin(np.deg2rad(rng.uniform(-30, 30)))
+    side = lambda x, y: (x - w / 2.0) * nx + (y - h / 2.0) * ny < 0
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    sxa, sya = _warp_src(HA, xx, yy)
+    sxb, syb = _warp_src(HB, xx, yy)
+    use_a = side(sxa, sya) & (sxa >= 0) & (sya >= 0) & (sxa < w - 1) & (sya < h - 1)
+    use_b = ~use_a & ~side(sxb, syb) & (sxb >= 0) & (syb >= 0) & (sxb < w - 1) & (syb < h - 1)
+    sx = np.where(use_a, sxa, sxb)
+    sy = np.where(use_a, sya, syb)
+    valid = use_a | use_b
+    x0 = np.clip(np.floor(sx).astype(np.int64), 0, w - 2)
+    y0 = np.clip(np.floor(sy).astype(np.int64), 0, h - 2)
+    fx = (sx - x0).astype(np.float32)
+    fy = (sy - y0).astype(np.float32)
+    p, q, r, t = img1[y0, x0], img1[y0, x0 + 1], img1[y0 + 1, x0], img1[y0 + 1, x0 + 1]
+    out = (p * (1 - fx) + q * fx) * (1 - fy) + (r * (1 - fx) + t * fx) * fy
+    out = np.where(valid, out, 128.0).astype(np.float32)
+    out += np.random.default_rng(seed + 7919).normal(0, noise_sigma, out.shape).astype(np.float32)
+    img2 = np.clip(np.rint(out), 0, 255).astype(np.float32)
+    ex = np.array([[0, -e[2], e[1]], [e[2], 0, -e[0]], [-e[1], e[0], 0]])
+    F = ex @ HA
+    return img1, img2, F / np.linalg.norm(F), HA, HB

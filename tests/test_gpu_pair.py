@@ -44,3 +44,52 @@ def test_pair_no_overlap(pkg):
     res, _ = pkg.match_pair_dev(ctx, t.data_ptr(), 640, 480)
     assert res.n_inliers == 0
     ctx.close()
+
+
+def _f_residual(F_stored, pts):
+    """max |x2^T F x1| / (|F| |x1| |x2|) over rows x1 y1 x2 y2; F_stored[3*c + r] = entry (r, c)."""
+    F = np.array(F_stored).reshape(3, 3).T
+    x1 = np.c_[pts[:, 0], pts[:, 1], np.ones(len(pts))]
+    x2 = np.c_[pts[:, 2], pts[:, 3], np.ones(len(pts))]
+    return np.abs(np.einsum("ij,jk,ik->i", x2, F, x1))
+
+
+@pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("planar", [False, True])
+def test_pair_end_to_end_epipolar(pkg, planar):
+    """ver_type Epipolar: the whole path with DEGENSAC + F_LAF_check on a two-plane scene (and on a single
+    plane, where every good sample is H-degenerate and the plane-and-parallax branch runs)."""
+    import torch
+    import pipeline_oracle as po
+    w, h = 800, 600
+    if planar:
+        a, b, _ = synth.pair(w, h, seed=4)
+    else:
+        a, b, Ftrue, HA, HB = synth.pair_two_planes(w, h, seed=4)
+    want = po.match_pair(a, b, seed_time=99, use_f=True)
+    ctx = pkg.Context(0, w, h, 2)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    par.ransac.useF = 1
+    pkg.ransac_pin_seed(99)
+    res, m = pkg.match_pair_dev(ctx, t.data_ptr(), w, h, par, max_matches=100000)
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] and res.n_inliers > 50
+    wm = want["u6"][want["mask"]][:, [0, 1, 3, 4]]
+    assert np.array_equal(m, wm)                                   # identical inlier set, same order
+    Fg, Fw = np.array(res.H), np.asarray(want["H"])
+    Fg, Fw = Fg / np.linalg.norm(Fg), Fw / np.linalg.norm(Fw)
+    if np.dot(Fg, Fw) < 0:
+        Fg = -Fg
+    assert np.max(np.abs(Fg - Fw)) < 1e-6
+    if not planar:
+        # inliers come from both planes and agree with the generating epipolar geometry
+        x1 = np.c_[m[:, 0], m[:, 1], np.ones(len(m))]
+        pa, pb = x1 @ HA.T, x1 @ HB.T
+        da = np.hypot(pa[:, 0] / pa[:, 2] - m[:, 2], pa[:, 1] / pa[:, 2] - m[:, 3])
+        db = np.hypot(pb[:, 0] / pb[:, 2] - m[:, 2], pb[:, 1] / pb[:, 2] - m[:, 3])
+        assert (da < 3).sum() > 20 and (db < 3).sum() > 20
+        assert ((da < 3) | (db < 3)).mean() > 0.9
+    ctx.close()
