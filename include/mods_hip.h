@@ -97,7 +97,7 @@ void *mods_ctx_stream(mods_ctx *ctx);            /* hipStream_t the kernels run 
  * named stage is bracketed by events on the context's stream. */
 enum { MODS_STAGE_BLUR = 0, MODS_STAGE_RESPONSE, MODS_STAGE_RESIZE, MODS_STAGE_NMS, MODS_STAGE_LOCALIZE,
        MODS_STAGE_BAUMBERG, MODS_STAGE_SORT, MODS_STAGE_ORIENT, MODS_STAGE_DESCRIBE, MODS_STAGE_MATCH,
-       MODS_STAGE_RANSAC_SCORE, MODS_STAGE_COUNT };
+       MODS_STAGE_RANSAC_SCORE, MODS_STAGE_SYNTH, MODS_STAGE_COUNT };
 int mods_ctx_timing_enable(mods_ctx *ctx, int stage_mask);
 /* sums since the last reset; resolves pending events (synchronises the stream) */
 int mods_ctx_timing_read(mods_ctx *ctx, int stage, double *total_ms, int *launches, double *bytes);
@@ -163,6 +163,41 @@ int mods_regions_fetch(mods_ctx *ctx, int img, mods_region *out, int max_out, in
 /* parity-test building blocks: one 32x32 orientation patch / one 41x41 descriptor patch */
 int mods_dominant_angle(mods_ctx *ctx, const float *patch, int ps, double th, float *angle, int *found);
 int mods_sift_patch(mods_ctx *ctx, const float *patch, int ps, int rootsift, double maxBinValue, uint8_t *out128);
+
+/* ---- view synthesis ---------------------------------------------------------------------------
+ * Replaces GenerateSynthImageCorr (synth-detection.cpp:324-518; the caller hands over a grey float image,
+ * i.e. the state after the (B+G+R)/3 conversion of :343-354) and the per-view body of
+ * ImageRepresentation::SynthDetectDescribeKeypoints (imagerepresentation.cpp:704-1099) for
+ * HessianAffine + RootSIFT.  tilt < 0 = vertical tilt, phi in radians, as in ViewSynthParameters. */
+typedef struct mods_view_geom {
+  int identity;              /* 1: the original image is the view (tilt ~ 1, phi ~ 0, zoom ~ 1) */
+  int w_rot, h_rot;          /* size after the rotation */
+  int w_new, h_new;          /* size of the view */
+  int ksize_x, ksize_y, pad; /* anti-aliasing Gaussian */
+  double rotation, tilt, zoom;   /* SynthImage fields: degrees, |tilt|, zoom */
+  double sigma_x, sigma_y;
+  double H[9];               /* original -> view (SynthImage::H), row-major */
+  double warpRot[6], warpTilt[6];   /* the two cv::warpAffine matrices (src -> dst) */
+} mods_view_geom;
+
+int mods_view_geometry(int w, int h, double tilt, double phi, double zoom, double initSigma, mods_view_geom *out);
+/* src_dev: w x h floats in HBM (row stride `stride` floats); dst_dev: out->w_new x out->h_new, dense.
+ * The context must hold the rotated intermediate: w_rot * h_rot <= max_w * max_h * batch
+ * (max_w = max_h = ceil(hypot(w, h)) is always enough). */
+int mods_synth_view_dev(mods_ctx *ctx, const float *src_dev, int w, int h, int stride, const mods_view_geom *geom, int doBlur,
+                        float *dst_dev);
+/* synthesise + detect + orient + reproject + describe one view; regions (reproj_kp, original frame, with
+ * descriptors) stay in the context: mods_regions_fetch(ctx, 0, ...) or mods_regions_dev(ctx, 0). */
+int mods_detect_describe_view_dev(mods_ctx *ctx, const float *src_dev, int w, int h, int stride, double tilt, double phi,
+                                  double zoom, double initSigma, int doBlur, const mods_hessaff_params *det,
+                                  const mods_describe_params *desc, mods_view_geom *geom_out, int *n_detected, int *n_regions);
+const mods_region *mods_regions_dev(mods_ctx *ctx, int img);     /* device pointer of the region list of image `img` */
+const float *mods_view_pixels_dev(mods_ctx *ctx);                /* pixels of the last synthesised view (w_new x h_new) */
+int mods_view_fetch(mods_ctx *ctx, const mods_view_geom *geom, float *dst_host);   /* host copy of those pixels */
+/* host-buffer primitives (parity tests): cv::warpAffine(LINEAR, BORDER_CONSTANT cval), M maps src -> dst;
+ * cv::GaussianBlur(Size(kx,ky), sx, sy, BORDER_REFLECT_101) */
+int mods_warp_affine(mods_ctx *ctx, const float *src, int w, int h, const double *M, int dw, int dh, float cval, float *dst);
+int mods_gauss_blur_xy(mods_ctx *ctx, const float *src, int w, int h, int kx, int ky, double sx, double sy, float *dst);
 
 /* ---- B4: matching ------------------------------------------------------------------------------
  * Replaces  int MatchFlannFGINN(const AffineRegionList &q, const AffineRegionList &t,

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmodsgpu.so")
 
 MODS_OK = 0
 STAGES = ["blur", "response", "resize", "nms", "localize", "baumberg", "sort", "orient", "describe", "match",
-          "ransac_score"]
+          "ransac_score", "synth"]
 
 
 class ModsError(RuntimeError):
@@ -92,6 +92,26 @@ def _check(rc):
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class ViewGeom(C.Structure):
+    """mods_view_geom: what GenerateSynthImageCorr derives before touching pixels."""
+    _fields_ = [("identity", C.c_int), ("w_rot", C.c_int), ("h_rot", C.c_int), ("w_new", C.c_int), ("h_new", C.c_int),
+                ("ksize_x", C.c_int), ("ksize_y", C.c_int), ("pad", C.c_int),
+                ("rotation", C.c_double), ("tilt", C.c_double), ("zoom", C.c_double), ("sigma_x", C.c_double),
+                ("sigma_y", C.c_double), ("H", C.c_double * 9), ("warpRot", C.c_double * 6), ("warpTilt", C.c_double * 6)]
+
+
+def view_geometry(w, h, tilt, phi, zoom=1.0, init_sigma=0.2):
+    g = ViewGeom()
+    _check(lib().mods_view_geometry(w, h, C.c_double(tilt), C.c_double(phi), C.c_double(zoom), C.c_double(init_sigma), C.byref(g)))
+    return g
+
+
+def view_ctx_dims(w, h):
+    """Context size that holds every rotated intermediate of a w x h image."""
+    d = int(np.ceil(np.hypot(w, h))) + 2
+    return d, d
 
 
 class Context:
@@ -232,6 +252,42 @@ class Context:
         out = np.zeros(128, np.uint8)
         _check(lib().mods_sift_patch(self.h, _fp(a), a.shape[0], int(rootsift), C.c_double(max_bin),
                                      out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- view synthesis
+    def warp_affine(self, img, M, dw, dh, cval=128.0):
+        a = np.ascontiguousarray(img, np.float32)
+        Mc = np.ascontiguousarray(M, np.float64).ravel()
+        out = np.empty((dh, dw), np.float32)
+        _check(lib().mods_warp_affine(self.h, _fp(a), a.shape[1], a.shape[0], Mc.ctypes.data_as(C.c_void_p), dw, dh,
+                                      C.c_float(cval), _fp(out)))
+        return out
+
+    def gauss_blur_xy(self, img, kx, ky, sx, sy):
+        a = np.ascontiguousarray(img, np.float32)
+        out = np.empty_like(a)
+        _check(lib().mods_gauss_blur_xy(self.h, _fp(a), a.shape[1], a.shape[0], kx, ky, C.c_double(sx), C.c_double(sy), _fp(out)))
+        return out
+
+    def synth_view_dev(self, src_ptr, w, h, geom, dst_ptr, do_blur=1):
+        _check(lib().mods_synth_view_dev(self.h, C.c_void_p(src_ptr), w, h, w, C.byref(geom), do_blur, C.c_void_p(dst_ptr)))
+
+    def detect_describe_view_dev(self, src_ptr, w, h, tilt, phi, zoom=1.0, init_sigma=0.2, do_blur=1, det=None, desc=None):
+        """One synthesised view of the w x h image at src_ptr (HBM): returns (geom, n_detected, n_regions); the
+        regions (original frame) stay in the context (regions_fetch(0))."""
+        det = det or HessAffParams.default()
+        desc = desc or DescribeParams.default()
+        g = ViewGeom()
+        nd, nr = C.c_int(), C.c_int()
+        _check(lib().mods_detect_describe_view_dev(self.h, C.c_void_p(src_ptr), w, h, w, C.c_double(tilt), C.c_double(phi),
+                                                   C.c_double(zoom), C.c_double(init_sigma), do_blur, C.byref(det),
+                                                   C.byref(desc), C.byref(g), C.byref(nd), C.byref(nr)))
+        return g, nd.value, nr.value
+
+    def view_pixels(self, geom):
+        """Host copy of the last synthesised view."""
+        out = np.empty((geom.h_new, geom.w_new), np.float32)
+        _check(lib().mods_view_fetch(self.h, C.byref(geom), _fp(out)))
         return out
 
     # ---- matching

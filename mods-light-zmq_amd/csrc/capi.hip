@@ -112,7 +112,7 @@ void mods_ctx_destroy(mods_ctx *c) {
     for (auto &e : t.pool) (void)hipEventDestroy(e);
   }
   (void)hipFree(c->pyr_dev); (void)hipFree(c->plane_pool); (void)hipFree(c->omap_pool); (void)hipFree(c->input_dev);
-  (void)hipFree(c->tmp_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
+  (void)hipFree(c->tmp_dev); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
   (void)hipHostFree(c->host_counts);
   (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->region_count); (void)hipFree(c->desc_tables_dev);

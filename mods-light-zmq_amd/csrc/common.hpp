@@ -74,6 +74,7 @@ struct mods_ctx {
   size_t omap_pool_elems = 0;
   float *input_dev = nullptr;        // staging for host-pointer entry points
   float *tmp_dev = nullptr;
+  float *view_dev = nullptr;         // pixels of the current synthesised view (allocated on first use)
   float *gauss_taps_dev = nullptr;   // [16 slots][64] Gaussian taps
   float taps_sigma[16] = {0};        // sigma currently held by each slot (0 = empty)
   float taps_host[16][2 * mods::kMaxBlurRadius + 1] = {{0}};
@@ -155,6 +156,8 @@ int match_ensure_buffers(mods_ctx *ctx);
 
 // describe.hip
 int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par);
+int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par, const double *H,
+                      int orig_w, int orig_h, mods_region *det_copy_dev);
 int describe_configure(mods_ctx *ctx, const mods_describe_params *par);
 int launch_dominant_angle_test(mods_ctx *ctx, const float *patch_dev, int ps, double th, float *out_dev);
 int launch_sift_patch_test(mods_ctx *ctx, const float *patch_dev, int ps, int root, double max_bin, uint8_t *out_dev);

@@ -125,7 +125,13 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
   for (int q = lane; q < 256; q += 64) s_lut[q] = g_atan_lut[q];
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const mods_affkey kp = keys[i];
-    bool alive = (kp.x < k.w) && (kp.y < k.h) && (kp.x > 0) && (kp.y > 0);
+    // ReprojectRegionsAndRemoveTouchBoundary(dontRemove): centre, in the original frame, strictly inside
+    bool alive;
+    if (k.view) {
+      const double rx = (k.Hinv[0] * kp.x + k.Hinv[1] * kp.y + k.Hinv[2]);
+      const double ry = (k.Hinv[3] * kp.x + k.Hinv[4] * kp.y + k.Hinv[5]);
+      alive = (rx < k.ow) && (ry < k.oh) && (rx > 0) && (ry > 0);
+    } else alive = (kp.x < k.w) && (kp.y < k.h) && (kp.x > 0) && (kp.y > 0);
     const float fx = (float)kp.x, fy = (float)kp.y;
     const float f11 = (float)kp.a11, f12 = (float)kp.a12, f21 = (float)kp.a21, f22 = (float)kp.a22;
     const int box = (int)(k.ks * kp.s);
@@ -173,8 +179,18 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
         n12 = kp.a11 * si + kp.a12 * ci;
         n21 = kp.a21 * ci - kp.a22 * si;
         n22 = kp.a21 * si + kp.a22 * ci;
-        // ReprojectRegions (H = I): same centre, rotated frame
-        if (check_borders(k.w, k.h, fx, fy, (float)n11, (float)n12, (float)n21, (float)n22, box, box)) alive = false;
+        if (k.view) {
+          // ReprojectRegions: ReprojectByH (synth-detection.cpp:578-587) then the centre and box tests in the original frame
+          const double rx = (k.Hinv[0] * kp.x + k.Hinv[1] * kp.y + k.Hinv[2]);
+          const double ry = (k.Hinv[3] * kp.x + k.Hinv[4] * kp.y + k.Hinv[5]);
+          const double r11 = (k.Hinv[0] * n11 + k.Hinv[1] * n21), r12 = (k.Hinv[0] * n12 + k.Hinv[1] * n22);
+          const double r21 = (k.Hinv[3] * n11 + k.Hinv[4] * n21), r22 = (k.Hinv[3] * n12 + k.Hinv[4] * n22);
+          if (!((rx < k.ow) && (ry < k.oh) && (rx > 0) && (ry > 0))) alive = false;
+          else if (check_borders(k.ow, k.oh, (float)rx, (float)ry, (float)r11, (float)r12, (float)r21, (float)r22, box, box)) alive = false;
+        } else {
+          // ReprojectRegions (H = I): same centre, rotated frame
+          if (check_borders(k.w, k.h, fx, fy, (float)n11, (float)n12, (float)n21, (float)n22, box, box)) alive = false;
+        }
       }
     }
     if (lane == 0) {
@@ -227,6 +243,23 @@ __global__ __launch_bounds__(1024) void compact_regions_kernel(DescConst k, cons
     __syncthreads();
   }
   if (tid == 0) reg_count[b] = s_base;
+}
+
+// det_kp -> reproj_kp of the described regions of a synthesised view, in place (ReprojectByH: centre and
+// frame through the affine part of inv(H); s, response, descriptor unchanged).  grid-stride, image 0 only.
+__global__ __launch_bounds__(256) void reproject_regions_kernel(DescConst k, mods_region *__restrict__ reg, const int *__restrict__ reg_count) {
+  int n = reg_count[0];
+  if (n > k.max_reg) n = k.max_reg;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    mods_region *r = reg + i;
+    const double x = r->x, y = r->y, a11 = r->a11, a12 = r->a12, a21 = r->a21, a22 = r->a22;
+    r->x = (k.Hinv[0] * x + k.Hinv[1] * y + k.Hinv[2]);
+    r->y = (k.Hinv[3] * x + k.Hinv[4] * y + k.Hinv[5]);
+    r->a11 = (k.Hinv[0] * a11 + k.Hinv[1] * a21);
+    r->a12 = (k.Hinv[0] * a12 + k.Hinv[1] * a22);
+    r->a21 = (k.Hinv[3] * a11 + k.Hinv[4] * a21);
+    r->a22 = (k.Hinv[3] * a12 + k.Hinv[4] * a22);
+  }
 }
 
 // single-patch entry points for the parity tests
@@ -302,9 +335,41 @@ int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
 // Orientation + compaction + description of the keypoints in ctx->keys_dev (as left by detect_run
 // or uploaded by mods_orient_describe) for images `img_dev` [n_img][h][w].
 int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par) {
+  return describe_run_view(ctx, img_dev, n_img, w, h, par, nullptr, 0, 0, nullptr);
+}
+
+// cv::invert(H, Hinv, DECOMP_LU) for 3x3 doubles: OpenCV's closed form (all zeros when singular)
+static void invert3_cv(const double *S, double *t) {
+  double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+  if (d == 0.) { for (int i = 0; i < 9; i++) t[i] = 0; return; }
+  d = 1. / d;
+  t[0] = (S[4] * S[8] - S[5] * S[7]) * d; t[1] = (S[2] * S[7] - S[1] * S[8]) * d; t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+  t[3] = (S[5] * S[6] - S[3] * S[8]) * d; t[4] = (S[0] * S[8] - S[2] * S[6]) * d; t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+  t[6] = (S[3] * S[7] - S[4] * S[6]) * d; t[7] = (S[1] * S[6] - S[0] * S[7]) * d; t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+}
+
+// The same for a synthesised view: H (original -> view, 9 doubles) and the original image size; the
+// regions come out in the original frame (reproj_kp).  H == nullptr or HIsEye(H) (synth-detection.cpp:
+// 144-149): identity view.  det_copy_dev (optional): receives the described regions in the view frame.
+int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par, const double *H,
+                      int orig_w, int orig_h, mods_region *det_copy_dev) {
   int rc = describe_configure(ctx, par);
   if (rc) return rc;
   DescConst k;
+  k.view = 0; k.ow = w; k.oh = h;
+  for (int i = 0; i < 6; i++) k.Hinv[i] = (i == 0 || i == 4) ? 1.0 : 0.0;
+  if (H) {
+    const bool eye = (std::fabs(H[0] - 1.0) + std::fabs(H[1]) + std::fabs(H[2]) + std::fabs(H[3]) + std::fabs(H[4] - 1.0) + std::fabs(H[5]) +
+                      std::fabs(H[6]) + std::fabs(H[7]) + std::fabs(H[8] - 1.0) < 0.01);
+    if (n_img != 1 && !eye) { set_error("a synthesised view is described one image at a time"); return MODS_E_ARG; }
+    k.ow = orig_w; k.oh = orig_h;
+    if (!eye) {
+      double Hi[9];
+      invert3_cv(H, Hi);
+      k.view = 1;
+      for (int i = 0; i < 6; i++) k.Hinv[i] = Hi[i];
+    } else if (orig_w != w || orig_h != h) k.view = 1;   // identity map onto a different canvas: the tests still use (ow, oh)
+  }
   k.w = w; k.h = h; k.max_cand = ctx->max_cand; k.max_reg = ctx->max_cand;
   k.reg_cap = std::min(ctx->max_cand, 1 << 17);
   k.ks = 2 * 3.0 * sqrt(3.0);
@@ -326,7 +391,15 @@ int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, c
                        (const OriOut *)ctx->ori_dev, ctx->regions_dev, ctx->region_count);
     MODS_HIP_CHECK(hipGetLastError());
   }
-  return launch_extract_and_sift(ctx, img_dev, n_img, k, dmask, tab);
+  rc = launch_extract_and_sift(ctx, img_dev, n_img, k, dmask, tab);
+  if (rc) return rc;
+  if (det_copy_dev)
+    MODS_HIP_CHECK(hipMemcpyAsync(det_copy_dev, ctx->regions_dev, sizeof(mods_region) * (size_t)ctx->max_cand, hipMemcpyDeviceToDevice, ctx->stream));
+  if (k.view) {
+    hipLaunchKernelGGL(reproject_regions_kernel, dim3(256), dim3(256), 0, ctx->stream, k, ctx->regions_dev, ctx->region_count);
+    MODS_HIP_CHECK(hipGetLastError());
+  }
+  return MODS_OK;
 }
 
 int launch_dominant_angle_test(mods_ctx *ctx, const float *patch_dev, int ps, double th, float *out_dev) {

@@ -20,6 +20,11 @@ struct DescConst {
   int p2_lo, p2_hi;        // size tier handled by a launch: p2_lo < P2 <= p2_hi (P2 = 0: direct branch)
   size_t scratch_stride;   // floats per block
   int tap_cap;
+  // synthesised view (H != I): keypoints live in the view frame; the inside / touch-boundary tests of
+  // ReprojectRegions* run on their reprojection into the original image (ow x oh) through Hinv
+  int view;                // 0: identity view (reproj_kp == det_kp)
+  int ow, oh;
+  double Hinv[6];          // affine part of inv(H), row-major 2x3
 };
 
 struct SiftTab {           // precomputeBinsAndWeights, siftdesc.cpp:22-71 (host built, patchSize <= 64)

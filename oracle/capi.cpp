@@ -225,6 +225,73 @@ int orc_detect_describe(const float *img, int w, int h, const orc_hessaff_params
   return from_regions(o, out, max_out);
 }
 
+// ---- view synthesis -------------------------------------------------------------------------------
+struct orc_view_geom {          // mirrors include/mods_hip.h: mods_view_geom
+  int identity, w_rot, h_rot, w_new, h_new, ksize_x, ksize_y, pad;
+  double rotation, tilt, zoom, sigma_x, sigma_y;
+  double H[9], warpRot[6], warpTilt[6];
+};
+static void cvt_geom(const ViewGeom &g, orc_view_geom *o) {
+  o->identity = g.identity ? 1 : 0; o->w_rot = g.w_rot; o->h_rot = g.h_rot; o->w_new = g.w_new; o->h_new = g.h_new;
+  o->ksize_x = g.identity ? 0 : g.ksize_x; o->ksize_y = g.identity ? 0 : g.ksize_y; o->pad = 0;
+  o->rotation = g.rotation; o->tilt = g.tilt; o->zoom = g.zoom;
+  o->sigma_x = g.identity ? 0 : g.sigma_x; o->sigma_y = g.identity ? 0 : g.sigma_y;
+  for (int i = 0; i < 9; i++) o->H[i] = g.H[i];
+  for (int i = 0; i < 6; i++) { o->warpRot[i] = g.identity ? 0 : g.warpRot[i]; o->warpTilt[i] = g.identity ? 0 : g.warpTilt[i]; }
+}
+void orc_view_geometry(int w, int h, double tilt, double phi, double zoom, double initSigma, orc_view_geom *out) {
+  ViewGeom g;
+  view_geometry(w, h, tilt, phi, zoom, initSigma, &g);
+  cvt_geom(g, out);
+}
+void orc_warp_affine(const float *src, int w, int h, const double *M, int dw, int dh, float cval, float *dst) {
+  Img o;
+  warp_affine(wrap(src, w, h), M, dw, dh, cval, o);
+  std::memcpy(dst, o.d.data(), sizeof(float) * (size_t)dw * dh);
+}
+void orc_gauss_blur_xy(const float *src, int w, int h, int kx, int ky, double sx, double sy, float *dst) {
+  Img o;
+  gauss_blur_xy(wrap(src, w, h), o, kx, ky, sx, sy);
+  std::memcpy(dst, o.d.data(), sizeof(float) * (size_t)w * h);
+}
+// dst must hold w_new*h_new floats of orc_view_geometry for the same arguments
+void orc_synth_view(const float *src, int w, int h, double tilt, double phi, double zoom, double initSigma, int doBlur,
+                    float *dst, orc_view_geom *geom) {
+  ViewGeom g;
+  Img o;
+  generate_synth_view(wrap(src, w, h), tilt, phi, zoom, initSigma, doBlur, o, &g);
+  std::memcpy(dst, o.d.data(), sizeof(float) * o.d.size());
+  if (geom) cvt_geom(g, geom);
+}
+
+// SynthDetectDescribeKeypoints for one synthesised view (imagerepresentation.cpp:704-1099), HessianAffine +
+// RootSIFT: detect on the view -> centres (in the original frame) inside -> orientation on the view ->
+// ReprojectRegions -> RootSIFT on the view.  `out` carries reproj_kp (original frame) + descriptor;
+// `out_det` (optional) the matching det_kp (view frame).
+int orc_detect_describe_view(const float *view, int vw, int vh, const double *H, int orig_w, int orig_h,
+                             const orc_hessaff_params *p, double ori_mrSize, int ori_patchSize, int maxAngles, double ori_th,
+                             double desc_mrSize, int desc_patchSize, int photoNorm, orc_region *out, orc_region *out_det,
+                             int max_out, int *n_detected) {
+  Img im = wrap(view, vw, vh);
+  std::vector<AffKey> k;
+  detect_hessian_affine(im, cvt(p), k);
+  if (n_detected) *n_detected = (int)k.size();
+  std::vector<Region> v(k.size()), o, rep;
+  for (size_t i = 0; i < k.size(); i++) {
+    Region &r = v[i];
+    r.x = k[i].x; r.y = k[i].y; r.s = k[i].s; r.a11 = k[i].a11; r.a12 = k[i].a12; r.a21 = k[i].a21; r.a22 = k[i].a22;
+    r.response = k[i].response; r.sub_type = k[i].sub_type; r.id = (int)i; r.parent = (int)i;
+    std::memset(r.desc, 0, 128);
+  }
+  filter_centres_inside_view(v, H, orig_w, orig_h);
+  detect_orientation(v, o, im, ori_mrSize, ori_patchSize, maxAngles, ori_th);
+  reproject_regions_view(o, rep, H, orig_w, orig_h);
+  describe_rootsift(o, im, desc_mrSize, desc_patchSize, photoNorm != 0);
+  for (size_t i = 0; i < o.size(); i++) std::memcpy(rep[i].desc, o[i].desc, 128);
+  if (out_det) from_regions(o, out_det, max_out);
+  return from_regions(rep, out, max_out);
+}
+
 // ---- matching -----------------------------------------------------------------------------------
 struct orc_tentative { int q, t, t_bad, t_2nd; float d1, d2, d2nd, pad; double ratio; };   // mirrors mods_tentative
 

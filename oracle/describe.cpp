@@ -37,6 +37,74 @@ void filter_touch_boundary(std::vector<Region> &r, int w, int h) {
   r.swap(keep);
 }
 
+// cv::invert(H, Hinv, DECOMP_LU) for a 3x3 CV_64F matrix: OpenCV's closed form (determinant by the first
+// row, cofactors times 1/det; all zeros when det == 0).  Parity unpinned, benign.
+void invert3(const double *S, double *t) {
+  double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+  if (d == 0.) { for (int i = 0; i < 9; i++) t[i] = 0; return; }
+  d = 1. / d;
+  t[0] = (S[4] * S[8] - S[5] * S[7]) * d; t[1] = (S[2] * S[7] - S[1] * S[8]) * d; t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+  t[3] = (S[5] * S[6] - S[3] * S[8]) * d; t[4] = (S[0] * S[8] - S[2] * S[6]) * d; t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+  t[6] = (S[3] * S[7] - S[4] * S[6]) * d; t[7] = (S[1] * S[6] - S[0] * S[7]) * d; t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+}
+
+// HIsEye, synth-detection.cpp:144-149 (eps1 = 0.01, :22)
+bool h_is_eye(const double *H) {
+  return (std::fabs(H[0] - 1.0) + std::fabs(H[1]) + std::fabs(H[2]) + std::fabs(H[3]) + std::fabs(H[4] - 1.0) + std::fabs(H[5]) +
+          std::fabs(H[6]) + std::fabs(H[7]) + std::fabs(H[8] - 1.0) < 0.01);
+}
+
+// ReprojectByH, synth-detection.cpp:578-587: centre and frame through the affine part of Hinv; s is kept
+static Region reproject_by_h(const Region &in, const double *H) {
+  Region o = in;
+  o.x = (H[0] * in.x + H[1] * in.y + H[2]);
+  o.y = (H[3] * in.x + H[4] * in.y + H[5]);
+  o.a11 = (H[0] * in.a11 + H[1] * in.a21);
+  o.a12 = (H[0] * in.a12 + H[1] * in.a22);
+  o.a21 = (H[3] * in.a11 + H[4] * in.a21);
+  o.a22 = (H[3] * in.a12 + H[4] * in.a22);
+  return o;
+}
+
+// ReprojectRegionsAndRemoveTouchBoundary(kps, H, orig_w, orig_h, mrSize, dontRemove = true),
+// synth-detection.cpp:151-190, for a synthesised view: H maps original -> view; a region stays when its
+// centre, taken back to the original image, lies strictly inside it.
+void filter_centres_inside_view(std::vector<Region> &det, const double *H, int orig_w, int orig_h) {
+  double Hinv[9];
+  invert3(H, Hinv);
+  const bool eye = h_is_eye(H);
+  std::vector<Region> keep;
+  keep.reserve(det.size());
+  for (size_t i = 0; i < det.size(); i++) {
+    const Region rp = eye ? det[i] : reproject_by_h(det[i], Hinv);
+    if ((rp.x < orig_w) && (rp.y < orig_h) && (rp.x > 0) && (rp.y > 0)) keep.push_back(det[i]);
+  }
+  det.swap(keep);
+}
+
+// ReprojectRegions(kps, H, orig_w, orig_h), synth-detection.cpp:631-706: det (view frame) and rep (original
+// frame) of the regions whose reprojected measurement box stays inside the original image.
+void reproject_regions_view(std::vector<Region> &det, std::vector<Region> &rep, const double *H, int orig_w, int orig_h) {
+  const double ks = k_sigma_synth();
+  double Hinv[9];
+  invert3(H, Hinv);
+  const bool eye = h_is_eye(H);
+  std::vector<Region> kd, kr;
+  kd.reserve(det.size()); kr.reserve(det.size());
+  for (size_t i = 0; i < det.size(); i++) {
+    const Region p = eye ? det[i] : reproject_by_h(det[i], Hinv);
+    if ((p.x < orig_w) && (p.y < orig_h) && (p.x > 0) && (p.y > 0)) {
+      if (!interpolate_check_borders(orig_w, orig_h, (float)p.x, (float)p.y, (float)p.a11, (float)p.a12, (float)p.a21,
+                                     (float)p.a22, (int)(ks * p.s), (int)(ks * p.s))) {
+        kd.push_back(det[i]);
+        kr.push_back(p);
+      }
+    }
+  }
+  det.swap(kd);
+  rep.swap(kr);
+}
+
 // smoothCircularBuffer<36>, synth-detection.cpp:811-822
 static void smooth_circular(float *hist, int bins) {
   float first = hist[0], prev = hist[bins - 1];

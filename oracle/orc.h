@@ -43,6 +43,22 @@ void inv_sqrt(float &a, float &b, float &c, float &l1, float &l2);   // helpers.
 bool get_eigenvalues(float a, float b, float c, float d, float &l1, float &l2);  // :504-515
 void photometrically_normalize(Img &image, const Img &mask, float &sum, float &var);  // :666-715
 
+// ---- view synthesis (synth_view.cpp) ---------------------------------------------------
+struct ViewGeom {               // what GenerateSynthImageCorr derives before touching pixels, synth-detection.cpp:336-469
+  bool identity;
+  double rotation, tilt, zoom;  // SynthImage fields (degrees, |tilt|, zoom)
+  double H[9];                  // original -> view
+  int w_rot, h_rot, w_new, h_new;
+  double warpRot[6], warpTilt[6];
+  double sigma_x, sigma_y;
+  int ksize_x, ksize_y;
+};
+bool view_geometry(int w, int h, double tilt, double phi, double zoom, double InitSigma, ViewGeom *g);
+void warp_affine(const Img &src, const double M[6], int dw, int dh, float cval, Img &dst);   // cv::warpAffine LINEAR/CONSTANT
+void gauss_blur_xy(const Img &src, Img &dst, int kx, int ky, double sx, double sy);          // cv::GaussianBlur, REFLECT_101
+void generate_synth_view(const Img &in, double tilt, double phi, double zoom, double InitSigma, int doBlur, Img &out,
+                         ViewGeom *g);                                                      // synth-detection.cpp:324-518
+
 // ---- detector (detect.cpp) ------------------------------------------------------------
 struct HessAffParams {          // PyramidParams + AffineShapeParams, detectors/structures.hpp:114-150,
   int numberOfScales = 3;       // affine.h:26-68; defaults = build/config_affori_classic.ini
@@ -95,6 +111,11 @@ void filter_centres_inside(std::vector<Region> &r, int w, int h);           // s
 int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, const Img &img,
                        double mrSize, int patchSize, int maxAngles, double th);   // :1039-1149
 void filter_touch_boundary(std::vector<Region> &r, int w, int h);           // ReprojectRegions :631-706
+// the same two steps for a synthesised view (H: original -> view); det = view frame, rep = original frame
+void invert3(const double *S, double *t);                                   // cv::invert 3x3
+bool h_is_eye(const double *H);                                             // synth-detection.cpp:144-149
+void filter_centres_inside_view(std::vector<Region> &det, const double *H, int orig_w, int orig_h);
+void reproject_regions_view(std::vector<Region> &det, std::vector<Region> &rep, const double *H, int orig_w, int orig_h);
 void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize,
                        bool photoNorm);                                     // synth-detection.hpp:170-263
 void sift_patch_to_desc(const Img &patch41, uint8_t out[128], bool rootsift, double maxBinValue = 0.2);   // matching/siftdesc.cpp

@@ -255,6 +255,62 @@ def detect_describe(img, params=None, max_out=1 << 18):
     return out[:n].copy(), ndet.value
 
 
+# ---- view synthesis ------------------------------------------------------------------------------
+class ViewGeom(C.Structure):
+    _fields_ = [("identity", C.c_int), ("w_rot", C.c_int), ("h_rot", C.c_int), ("w_new", C.c_int), ("h_new", C.c_int),
+                ("ksize_x", C.c_int), ("ksize_y", C.c_int), ("pad", C.c_int),
+                ("rotation", C.c_double), ("tilt", C.c_double), ("zoom", C.c_double), ("sigma_x", C.c_double),
+                ("sigma_y", C.c_double), ("H", C.c_double * 9), ("warpRot", C.c_double * 6), ("warpTilt", C.c_double * 6)]
+
+
+def view_geometry(w, h, tilt, phi, zoom=1.0, init_sigma=0.2):
+    g = ViewGeom()
+    lib().orc_view_geometry(w, h, C.c_double(tilt), C.c_double(phi), C.c_double(zoom), C.c_double(init_sigma), C.byref(g))
+    return g
+
+
+def warp_affine(img, M, dw, dh, cval=128.0):
+    a, p = _f(img)
+    M = np.ascontiguousarray(M, np.float64)
+    out = np.zeros((dh, dw), np.float32)
+    lib().orc_warp_affine(p, a.shape[1], a.shape[0], M.ctypes.data_as(C.c_void_p), dw, dh, C.c_float(cval),
+                          out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def gauss_blur_xy(img, kx, ky, sx, sy):
+    a, p = _f(img)
+    out = np.zeros_like(a)
+    lib().orc_gauss_blur_xy(p, a.shape[1], a.shape[0], kx, ky, C.c_double(sx), C.c_double(sy), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def synth_view(img, tilt, phi, zoom=1.0, init_sigma=0.2, do_blur=1):
+    """GenerateSynthImageCorr on a grey float image; returns (view, ViewGeom)."""
+    a, p = _f(img)
+    g = view_geometry(a.shape[1], a.shape[0], tilt, phi, zoom, init_sigma)
+    out = np.zeros((g.h_new, g.w_new), np.float32)
+    lib().orc_synth_view(p, a.shape[1], a.shape[0], C.c_double(tilt), C.c_double(phi), C.c_double(zoom),
+                         C.c_double(init_sigma), do_blur, out.ctypes.data_as(C.c_void_p), C.byref(g))
+    return out, g
+
+
+def detect_describe_view(view, H, orig_w, orig_h, params=None, max_out=1 << 18):
+    """One synthesised view through detect/orient/reproject/describe; returns (regions in the original frame,
+    the same regions in the view frame, n_detected)."""
+    params = params or HessAffParams.default()
+    a, p = _f(view)
+    Hc = np.ascontiguousarray(H, np.float64).ravel()
+    out = np.zeros(max_out, REGION_DTYPE)
+    det = np.zeros(max_out, REGION_DTYPE)
+    ndet = C.c_int()
+    n = lib().orc_detect_describe_view(p, a.shape[1], a.shape[0], Hc.ctypes.data_as(C.c_void_p), orig_w, orig_h,
+                                       C.byref(params), C.c_double(ORI_MRSIZE), ORI_PATCH, ORI_MAXANG, C.c_double(ORI_TH),
+                                       C.c_double(DESC_MRSIZE), DESC_PATCH, 1, out.ctypes.data_as(C.c_void_p),
+                                       det.ctypes.data_as(C.c_void_p), max_out, C.byref(ndet))
+    return out[:n].copy(), det[:n].copy(), ndet.value
+
+
 # ---- matching ------------------------------------------------------------------------------------
 TENT_DTYPE = np.dtype([("q", "i4"), ("t", "i4"), ("t_bad", "i4"), ("t_2nd", "i4"), ("d1", "f4"), ("d2", "f4"),
                        ("d2nd", "f4"), ("pad", "f4"), ("ratio", "f8")])
