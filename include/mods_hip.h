@@ -307,6 +307,52 @@ typedef struct mods_pair_result {
 int mods_match_pair_dev(mods_ctx *ctx, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
                         mods_pair_result *res, double *matches_out, int max_matches);
 
+/* ---- multi-view representation and the MODS step loop ---------------------------------------------------
+ * mods_view_schedule   = SetVSPars for one detector (synth-detection.cpp:191-322): views of a step that no
+ *                        earlier step produced; `prev`/`n_prev` is the history, extended in place.
+ * mods_imgrep          = the accumulated (HessianAffine, RootSIFT) regions of one image,
+ *                        ImageRepresentation::AddRegions (imagerepresentation.cpp:637-684); HBM resident.
+ * mods_match_reps      = CorrespondenceBank::MatchImgReps, separate-detector branch (correspondencebank.cpp:288-340)
+ *                        for a slice of the queries (the slice is what a rank of the multi-GPU path owns).
+ * mods_match_ladder_dev= the step loop of mods.cpp:202-383 on one GPU: per step, new views of both images ->
+ *                        match all accumulated regions -> duplicate filter -> LO-RANSAC; stops at min_matches. */
+typedef struct mods_view_par { double zoom, tilt, phi; } mods_view_par;      /* ViewSynthParameters subset */
+typedef struct mods_imgrep mods_imgrep;
+typedef struct mods_ladder_step {     /* one [HessianAffine<i>] section of the iterations .ini (io_mods.cpp:457-492) */
+  double scale_set[8]; int n_scales;  /* ScaleSet */
+  double tilt_set[8]; int n_tilts;    /* TiltSet */
+  double phi;                         /* Phi: rotation density in degrees */
+  double initSigma;                   /* initSigma */
+  int doBlur;                         /* 1 (io_mods.cpp:475) */
+  double fginn_ratio;                 /* FGINNThreshold of RootSIFT */
+} mods_ladder_step;
+typedef struct mods_ladder_result {
+  int steps_done, n_views;            /* steps executed; views synthesised (both images) */
+  int n_detected[2], n_described[2];  /* summed over views / accumulated regions per image */
+  int n_tentatives, n_unique, n_inliers;   /* of the last step */
+  int ransac_samples, ransac_lo, ransac_rejects;
+  double H[9];
+  double ms_detect_describe, ms_match, ms_duplicates, ms_ransac;
+} mods_ladder_result;
+
+int mods_view_schedule(const double *scale_set, int n_scales, const double *tilt_set, int n_tilts, double phi_base,
+                       mods_view_par *prev, int *n_prev, int prev_cap, mods_view_par *out, int max_out);
+int mods_imgrep_create(mods_ctx *ctx, int capacity, mods_imgrep **out);
+void mods_imgrep_destroy(mods_imgrep *rep);
+int mods_imgrep_clear(mods_imgrep *rep);
+int mods_imgrep_count(const mods_imgrep *rep);
+const mods_region *mods_imgrep_regions_dev(const mods_imgrep *rep);
+int mods_imgrep_append_ctx(mods_imgrep *rep, mods_ctx *ctx, int img);      /* regions the context holds for image slot img */
+int mods_imgrep_append_dev(mods_imgrep *rep, const mods_region *src_dev, int n);
+int mods_imgrep_append_host(mods_imgrep *rep, const mods_region *src, int n);
+int mods_imgrep_fetch(mods_imgrep *rep, int begin, int count, mods_region *out);
+int mods_match_reps(mods_ctx *ctx, const mods_imgrep *q, int q_begin, int q_end, const mods_imgrep *t, double ratio,
+                    double contradDist, int nn, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out);
+/* img_dev: [2][h][w] fp32 in HBM; the context needs max_w = max_h >= ceil(hypot(w, h)) and batch >= 1. */
+int mods_match_ladder_dev(mods_ctx *ctx, const float *img_dev, int w, int h, const mods_ladder_step *steps, int n_steps,
+                          int min_matches, const mods_pair_params *par, mods_imgrep *rep1, mods_imgrep *rep2,
+                          mods_ladder_result *res, double *matches_out, int max_matches);
+
 /* ---- pair pipeline ----------------------------------------------------------------------------------
  * Throughput form of the same path: `gpu_workers` threads (one context each) run detect/describe/match
  * while `verify_workers` threads run duplicate filtering + LO-RANSAC of earlier pairs (mods.cpp overlaps

@@ -437,6 +437,127 @@ def loransac_f(u6, laf, params=None, seed_time=12345):
     return mask[:n].astype(bool), F, ninl.value, list(stats)
 
 
+# ---- multi-view representation and the MODS step loop --------------------------------------------------------
+class ViewPar(C.Structure):
+    _fields_ = [("zoom", C.c_double), ("tilt", C.c_double), ("phi", C.c_double)]
+
+
+class LadderStep(C.Structure):
+    """One [HessianAffine<i>] section of an iterations .ini (io_mods.cpp:457-492)."""
+    _fields_ = [("scale_set", C.c_double * 8), ("n_scales", C.c_int), ("tilt_set", C.c_double * 8), ("n_tilts", C.c_int),
+                ("phi", C.c_double), ("initSigma", C.c_double), ("doBlur", C.c_int), ("fginn_ratio", C.c_double)]
+
+    @staticmethod
+    def make(tilts, phi, scales=(1.0,), init_sigma=0.2, do_blur=1, fginn=0.8):
+        s = LadderStep()
+        for i, v in enumerate(scales):
+            s.scale_set[i] = v
+        for i, v in enumerate(tilts):
+            s.tilt_set[i] = v
+        s.n_scales, s.n_tilts, s.phi, s.initSigma, s.doBlur, s.fginn_ratio = len(scales), len(tilts), phi, init_sigma, do_blur, fginn
+        return s
+
+
+def iters_mods_steps():
+    """[HessianAffine2] and [HessianAffine3] of build/iters_MODS.ini (the HessianAffine steps of the MODS ladder)."""
+    return [LadderStep.make((1, 2, 4, 6, 8), 360.0), LadderStep.make((1, 2, 4, 6, 8), 120.0)]
+
+
+class LadderResult(C.Structure):
+    _fields_ = [("steps_done", C.c_int), ("n_views", C.c_int), ("n_detected", C.c_int * 2), ("n_described", C.c_int * 2),
+                ("n_tentatives", C.c_int), ("n_unique", C.c_int), ("n_inliers", C.c_int),
+                ("ransac_samples", C.c_int), ("ransac_lo", C.c_int), ("ransac_rejects", C.c_int), ("H", C.c_double * 9),
+                ("ms_detect_describe", C.c_double), ("ms_match", C.c_double), ("ms_duplicates", C.c_double),
+                ("ms_ransac", C.c_double)]
+
+
+def view_schedule(step, history):
+    """SetVSPars for one step; `history` (list of (zoom, tilt, phi)) is extended in place.  Returns the new views."""
+    prev = (ViewPar * 1024)()
+    for i, v in enumerate(history):
+        prev[i] = ViewPar(*v)
+    n_prev = C.c_int(len(history))
+    out = (ViewPar * 256)()
+    n = lib().mods_view_schedule(step.scale_set, step.n_scales, step.tilt_set, step.n_tilts, C.c_double(step.phi), prev,
+                                 C.byref(n_prev), 1024, out, 256)
+    _check(min(n, 0))
+    views = [(out[i].zoom, out[i].tilt, out[i].phi) for i in range(n)]
+    history.extend(views)
+    return views
+
+
+class ImgRep:
+    """Accumulated regions of one image in HBM (ImageRepresentation::AddRegions)."""
+
+    def __init__(self, ctx, capacity=1 << 19):
+        self.h = C.c_void_p()
+        self.ctx = ctx
+        _check(lib().mods_imgrep_create(ctx.h, capacity, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().mods_imgrep_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        _check(lib().mods_imgrep_clear(self.h))
+
+    def __len__(self):
+        return lib().mods_imgrep_count(self.h)
+
+    @property
+    def dev_ptr(self):
+        lib().mods_imgrep_regions_dev.restype = C.c_void_p
+        return lib().mods_imgrep_regions_dev(self.h)
+
+    def append_ctx(self, img=0):
+        _check(lib().mods_imgrep_append_ctx(self.h, self.ctx.h, img))
+
+    def append_dev(self, dev_ptr, n):
+        _check(lib().mods_imgrep_append_dev(self.h, C.c_void_p(dev_ptr), n))
+
+    def append_host(self, regions):
+        r = np.ascontiguousarray(regions)
+        _check(lib().mods_imgrep_append_host(self.h, r.ctypes.data_as(C.c_void_p), len(r)))
+
+    def fetch(self, begin=0, count=None):
+        count = len(self) - begin if count is None else count
+        out = np.zeros(max(count, 1), REGION_DTYPE)
+        _check(lib().mods_imgrep_fetch(self.h, begin, count, out.ctypes.data_as(C.c_void_p)))
+        return out[:count].copy()
+
+
+def match_reps(ctx, q, t, q_begin=0, q_end=None, ratio=0.8, contrad=10.0, nn=50):
+    """MatchImgReps for the query slice [q_begin, q_end) of ImgRep q against all of ImgRep t."""
+    q_end = len(q) if q_end is None else q_end
+    cap = max(q_end - q_begin, 1)
+    out = np.zeros(cap, TENT_DTYPE)
+    u6 = np.zeros((cap, 6), np.float64)
+    laf = np.zeros((cap, 14), np.float64)
+    n = C.c_int()
+    _check(lib().mods_match_reps(ctx.h, q.h, q_begin, q_end, t.h, C.c_double(ratio), C.c_double(contrad), nn,
+                                 out.ctypes.data_as(C.c_void_p), u6.ctypes.data_as(C.c_void_p), laf.ctypes.data_as(C.c_void_p),
+                                 cap, C.byref(n)))
+    return out[:n.value].copy(), u6[:n.value].copy(), laf[:n.value].copy()
+
+
+def match_ladder_dev(ctx, img_ptr, w, h, steps, rep1, rep2, params=None, min_matches=15, max_matches=0):
+    """The step loop of mods.cpp:202-383 on one GPU; img_ptr: [2][h][w] fp32 in HBM."""
+    params = params or PairParams.default()
+    arr = (LadderStep * len(steps))(*steps)
+    res = LadderResult()
+    m = np.zeros((max(max_matches, 1), 4), np.float64)
+    _check(lib().mods_match_ladder_dev(ctx.h, C.c_void_p(img_ptr), w, h, arr, len(steps), min_matches, C.byref(params), rep1.h, rep2.h,
+                                       C.byref(res), m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
+    return res, m[:min(res.n_inliers, max_matches)]
+
+
 # ---- one pair end to end ------------------------------------------------------------------------------
 class PairParams(C.Structure):
     _fields_ = [("det", HessAffParams), ("desc", DescribeParams), ("fginn_ratio", C.c_double),

@@ -331,7 +331,7 @@ int mods_sift_patch(mods_ctx *c, const float *patch, int ps, int rootsift, doubl
 }
 
 // ---- matching ----------------------------------------------------------------------------------
-static int match_fetch(mods_ctx *c, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out) {
+int mods_match_fetch_internal(mods_ctx *c, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out) {
   int n = 0;
   MODS_HIP_CHECK(hipMemcpyAsync(&n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -353,7 +353,7 @@ int mods_match_fginn(mods_ctx *c, const mods_region *q, int n_q, const mods_regi
   MODS_HIP_CHECK(hipMemcpyAsync(c->m_regs, q, sizeof(mods_region) * n_q, hipMemcpyHostToDevice, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(c->m_regs + c->max_cand, t, sizeof(mods_region) * n_t, hipMemcpyHostToDevice, c->stream));
   if ((rc = match_run(c, c->m_regs, n_q, c->m_regs + c->max_cand, n_t, ratio, contradDist, nn))) return rc;
-  return match_fetch(c, out, u6_out, laf_out, max_out, n_out);
+  return mods_match_fetch_internal(c, out, u6_out, laf_out, max_out, n_out);
 }
 
 int mods_match_dev(mods_ctx *c, int img_q, int img_t, double ratio, double contradDist, int nn, mods_tentative *out,
@@ -365,7 +365,7 @@ int mods_match_dev(mods_ctx *c, int img_q, int img_t, double ratio, double contr
   int rc = match_run(c, c->regions_dev + (size_t)img_q * c->max_cand, c->last_region_counts[img_q],
                      c->regions_dev + (size_t)img_t * c->max_cand, c->last_region_counts[img_t], ratio, contradDist, nn);
   if (rc) return rc;
-  return match_fetch(c, out, u6_out, laf_out, max_out, n_out);
+  return mods_match_fetch_internal(c, out, u6_out, laf_out, max_out, n_out);
 }
 
 // DuplicateFiltering, matching.cpp:2615-2679: optional stable sort, then the first correspondence

@@ -1,0 +1,264 @@
+// Multi-view image representation and the MODS step loop for one image pair.
+//
+// Reference behaviour:
+//   SetVSPars                        synth-detection.cpp:191-322   view list of one step, minus the views of earlier steps
+//   ImageRepresentation::AddRegions / AddRegionsToList   imagerepresentation.cpp:637-684   regions of all views, appended
+//                                    in view order, ids shifted by the list size
+//   ImageRepresentation::SynthDetectDescribeKeypoints    imagerepresentation.cpp:686-1104  per-view chain (synth_view.hip)
+//   CorrespondenceBank::MatchImgReps (separate detector / descriptor branch)   correspondencebank.cpp:288-340
+//                                    all accumulated queries against all accumulated trains, every step
+//   main step loop                   mods.cpp:202-383   stop when the verified matches reach minMatches
+// One detector (HessianAffine) and one descriptor (RootSIFT): the part of iters_MODS.ini inside the hot
+// path (steps [HessianAffine2], [HessianAffine3]).
+//
+// The accumulated regions live in HBM (208 B each; 31 views of a 1080p image are ~3*10^5 regions = 60 MB),
+// so the matcher reads them in place and, for the multi-GPU path, the all-gather moves one dense buffer.
+#include "common.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+struct mods_imgrep {
+  int device = 0;
+  hipStream_t stream = nullptr;     // the owning context's stream
+  mods_region *reg = nullptr;
+  int cap = 0, n = 0;
+};
+
+namespace mods {
+
+// AddRegionsToList: id and parent_id are shifted by the size of the list they are appended to
+__global__ void __launch_bounds__(256) shift_ids_kernel(mods_region *reg, int n, int shift) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { reg[i].id += shift; reg[i].parent += shift; }
+}
+
+static double now_ms2() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace mods
+
+using namespace mods;
+
+extern "C" {
+
+int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask, double *H_out,
+                    int *n_inliers, int *stats3);
+int mods_loransac_f(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask, double *F_out,
+                    int *n_inliers, int *stats3);
+int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, double r, int mode, int *n_out);
+int mods_ransac_set_device(int device);
+int mods_match_fetch_internal(mods_ctx *c, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out);   // capi.hip
+
+// ---- view schedule -------------------------------------------------------------------------------------
+// SetVSPars for one detector: the (zoom, tilt, phi) triples of a step that no earlier step has produced.
+// `prev` (capacity prev_cap, *n_prev entries) is the history; the new views are appended to it.
+// Returns the number of views written to `out`, or a negative error.
+int mods_view_schedule(const double *scale_set, int n_scales, const double *tilt_set, int n_tilts, double phi_base,
+                       mods_view_par *prev, int *n_prev, int prev_cap, mods_view_par *out, int max_out) {
+  if (!n_prev || (*n_prev > 0 && !prev) || !out) { set_error("view_schedule: null argument"); return MODS_E_ARG; }
+  const double eps1 = 0.01;   // synth-detection.cpp:22
+  std::vector<mods_view_par> tmp;
+  if (n_scales == 0 || n_tilts == 0) { mods_view_par v = {0, 0, 0}; tmp.push_back(v); }
+  for (int sc = 0; sc < n_scales; sc++)
+    for (int t = 0; t < n_tilts; t++) {
+      if (std::fabs(tilt_set[t] - 1) > eps1) {
+        int n_rot1 = (int)std::floor(180.0 * tilt_set[t] / phi_base);
+        double delta_phi = M_PI / n_rot1;
+        if (n_rot1 < 0) {            // negative density: no rotations, one vertically tilted view as well
+          n_rot1 = 1;
+          delta_phi = 0;
+          mods_view_par v = {scale_set[sc], -tilt_set[t], 0.0};
+          tmp.push_back(v);
+        }
+        for (int r = 0; r < n_rot1; r++) {
+          mods_view_par v = {scale_set[sc], tilt_set[t], delta_phi * r};
+          tmp.push_back(v);
+        }
+      } else {
+        mods_view_par v = {scale_set[sc], tilt_set[t], 0.0};
+        tmp.push_back(v);
+      }
+    }
+  int n_out = 0;
+  const int n_hist = *n_prev;
+  for (size_t i = 0; i < tmp.size(); i++) {
+    bool unique = true;
+    for (int j = 0; j < n_hist; j++)
+      if ((std::fabs(tmp[i].zoom - prev[j].zoom) <= eps1) && (std::fabs(tmp[i].tilt - prev[j].tilt) <= eps1) &&
+          (std::fabs(tmp[i].phi - prev[j].phi) <= eps1)) { unique = false; break; }
+    if (!unique) continue;
+    if (n_out >= max_out) { set_error("view_schedule: more than %d views", max_out); return MODS_E_CAPACITY; }
+    out[n_out++] = tmp[i];
+  }
+  if (prev) {
+    if (*n_prev + n_out > prev_cap) { set_error("view_schedule: history overflow"); return MODS_E_CAPACITY; }
+    for (int i = 0; i < n_out; i++) prev[(*n_prev)++] = out[i];
+  }
+  return n_out;
+}
+
+// ---- accumulated regions of one image -----------------------------------------------------------------------
+int mods_imgrep_create(mods_ctx *c, int capacity, mods_imgrep **out) {
+  if (!c || !out || capacity <= 0) { set_error("imgrep_create: bad arguments"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  mods_imgrep *r = new mods_imgrep();
+  r->device = c->device; r->stream = c->stream; r->cap = capacity;
+  MODS_HIP_CHECK(hipMalloc(&r->reg, sizeof(mods_region) * (size_t)capacity));
+  *out = r;
+  return MODS_OK;
+}
+void mods_imgrep_destroy(mods_imgrep *r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  (void)hipStreamSynchronize(r->stream);
+  (void)hipFree(r->reg);
+  delete r;
+}
+int mods_imgrep_clear(mods_imgrep *r) { if (!r) return MODS_E_ARG; r->n = 0; return MODS_OK; }
+int mods_imgrep_count(const mods_imgrep *r) { return r ? r->n : 0; }
+const mods_region *mods_imgrep_regions_dev(const mods_imgrep *r) { return r ? r->reg : nullptr; }
+
+// AddRegions: the regions the context holds for image slot `img` (after mods_detect_describe[_view]_dev)
+int mods_imgrep_append_ctx(mods_imgrep *r, mods_ctx *c, int img) {
+  if (!r || !c || img < 0 || img >= (int)c->last_region_counts.size()) { set_error("imgrep_append: nothing described in that slot"); return MODS_E_ARG; }
+  const int n = c->last_region_counts[img];
+  if (r->n + n > r->cap) { set_error("imgrep: capacity %d exceeded (%d + %d)", r->cap, r->n, n); return MODS_E_CAPACITY; }
+  if (n == 0) return MODS_OK;
+  MODS_HIP_CHECK(hipSetDevice(r->device));
+  MODS_HIP_CHECK(hipMemcpyAsync(r->reg + r->n, c->regions_dev + (size_t)img * c->max_cand, sizeof(mods_region) * (size_t)n,
+                                hipMemcpyDeviceToDevice, c->stream));
+  if (r->n > 0) hipLaunchKernelGGL(shift_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, r->reg + r->n, n, r->n);
+  MODS_HIP_CHECK(hipGetLastError());
+  r->n += n;
+  return MODS_OK;
+}
+// the same from a device buffer (e.g. the slice of an all-gather) or a host array
+int mods_imgrep_append_dev(mods_imgrep *r, const mods_region *src_dev, int n) {
+  if (!r || (n > 0 && !src_dev)) { set_error("imgrep_append_dev: null argument"); return MODS_E_ARG; }
+  if (r->n + n > r->cap) { set_error("imgrep: capacity %d exceeded (%d + %d)", r->cap, r->n, n); return MODS_E_CAPACITY; }
+  if (n == 0) return MODS_OK;
+  MODS_HIP_CHECK(hipSetDevice(r->device));
+  MODS_HIP_CHECK(hipMemcpyAsync(r->reg + r->n, src_dev, sizeof(mods_region) * (size_t)n, hipMemcpyDeviceToDevice, r->stream));
+  if (r->n > 0) hipLaunchKernelGGL(shift_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, r->stream, r->reg + r->n, n, r->n);
+  MODS_HIP_CHECK(hipGetLastError());
+  r->n += n;
+  return MODS_OK;
+}
+int mods_imgrep_append_host(mods_imgrep *r, const mods_region *src, int n) {
+  if (!r || (n > 0 && !src)) { set_error("imgrep_append_host: null argument"); return MODS_E_ARG; }
+  if (r->n + n > r->cap) { set_error("imgrep: capacity %d exceeded (%d + %d)", r->cap, r->n, n); return MODS_E_CAPACITY; }
+  if (n == 0) return MODS_OK;
+  MODS_HIP_CHECK(hipSetDevice(r->device));
+  MODS_HIP_CHECK(hipMemcpyAsync(r->reg + r->n, src, sizeof(mods_region) * (size_t)n, hipMemcpyHostToDevice, r->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(r->stream));
+  if (r->n > 0) hipLaunchKernelGGL(shift_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, r->stream, r->reg + r->n, n, r->n);
+  MODS_HIP_CHECK(hipGetLastError());
+  r->n += n;
+  return MODS_OK;
+}
+int mods_imgrep_fetch(mods_imgrep *r, int begin, int count, mods_region *out) {
+  if (!r || begin < 0 || count < 0 || begin + count > r->n || (count > 0 && !out)) { set_error("imgrep_fetch: bad range"); return MODS_E_ARG; }
+  if (count == 0) return MODS_OK;
+  MODS_HIP_CHECK(hipSetDevice(r->device));
+  MODS_HIP_CHECK(hipMemcpyAsync(out, r->reg + begin, sizeof(mods_region) * (size_t)count, hipMemcpyDeviceToHost, r->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(r->stream));
+  return MODS_OK;
+}
+
+// MatchImgReps for (HessianAffine, RootSIFT): queries [q_begin, q_end) of rep `q` against every region of
+// rep `t` (MatchFlannFGINN, exact search).  Tentative indices refer to the full lists.
+int mods_match_reps(mods_ctx *c, const mods_imgrep *q, int q_begin, int q_end, const mods_imgrep *t, double ratio, double contradDist,
+                    int nn, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out) {
+  if (!c || !q || !t || !n_out) { set_error("match_reps: null argument"); return MODS_E_ARG; }
+  if (q_begin < 0 || q_end > q->n || q_begin > q_end) { set_error("match_reps: bad query range"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc = match_run(c, q->reg + q_begin, q_end - q_begin, t->reg, t->n, ratio, contradDist, nn);
+  if (rc) return rc;
+  rc = mods_match_fetch_internal(c, out, u6_out, laf_out, max_out, n_out);
+  if (rc) return rc;
+  if (out && q_begin)
+    for (int i = 0; i < *n_out; i++) out[i].q += q_begin;
+  return MODS_OK;
+}
+
+// ---- the step loop of mods.cpp:202-383 on one GPU ---------------------------------------------------------------
+// img_dev: [2][h][w] fp32 in HBM.  Every step adds the step's new views of both images to the two region
+// banks, matches bank 1 against bank 2, filters duplicates, verifies, and stops once the verified
+// matches reach min_matches.
+int mods_match_ladder_dev(mods_ctx *c, const float *img_dev, int w, int h, const mods_ladder_step *steps, int n_steps, int min_matches,
+                          const mods_pair_params *par, mods_imgrep *rep1, mods_imgrep *rep2, mods_ladder_result *res, double *matches_out,
+                          int max_matches) {
+  if (!c || !img_dev || !steps || !par || !rep1 || !rep2 || !res) { set_error("match_ladder: null argument"); return MODS_E_ARG; }
+  memset(res, 0, sizeof(*res));
+  for (int i = 0; i < 9; i++) res->H[i] = -1;
+  mods_imgrep_clear(rep1); mods_imgrep_clear(rep2);
+  std::vector<mods_view_par> hist(1024), views(256);
+  int n_hist = 0, rc;
+  int curr_matches = 0;
+  const size_t plane = (size_t)w * h;
+  std::vector<unsigned char> mask;
+  for (int step = 0; step < n_steps && curr_matches < min_matches; step++) {
+    const mods_ladder_step &st = steps[step];
+    const int nv = mods_view_schedule(st.scale_set, st.n_scales, st.tilt_set, st.n_tilts, st.phi, hist.data(), &n_hist, (int)hist.size(),
+                                      views.data(), (int)views.size());
+    if (nv < 0) return nv;
+    const double t0 = now_ms2();
+    for (int im = 0; im < 2; im++) {
+      mods_imgrep *rep = im ? rep2 : rep1;
+      for (int v = 0; v < nv; v++) {
+        int nd = 0, nr = 0;
+        if ((rc = mods_detect_describe_view_dev(c, img_dev + plane * im, w, h, w, views[v].tilt, views[v].phi, views[v].zoom, st.initSigma,
+                                                st.doBlur, &par->det, &par->desc, nullptr, &nd, &nr))) return rc;
+        if ((rc = mods_imgrep_append_ctx(rep, c, 0))) return rc;
+        res->n_views++;
+        res->n_detected[im] += nd;
+      }
+    }
+    res->n_described[0] = rep1->n; res->n_described[1] = rep2->n;
+    const double t1 = now_ms2();
+    res->ms_detect_describe += t1 - t0;
+    int n = 0;
+    if ((rc = match_run(c, rep1->reg, rep1->n, rep2->reg, rep2->n, st.fginn_ratio, par->contradDist, par->nn))) return rc;
+    MODS_HIP_CHECK(hipMemcpyAsync(&n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
+    c->h_tent.resize(n); c->h_u6.resize((size_t)n * 6); c->h_laf.resize((size_t)n * 14);
+    if (n > 0) {
+      MODS_HIP_CHECK(hipMemcpyAsync(c->h_tent.data(), c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(hipMemcpyAsync(c->h_u6.data(), c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(hipMemcpyAsync(c->h_laf.data(), c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    const double t2 = now_ms2();
+    res->ms_match += t2 - t1;
+    res->n_tentatives = n;
+    int nu = n;
+    if (par->dup_before_ransac && n > 0)
+      if ((rc = mods_duplicate_filter(c->h_tent.data(), c->h_u6.data(), c->h_laf.data(), n, par->dup_dist, par->dup_mode, &nu))) return rc;
+    res->n_unique = nu;
+    const double t3 = now_ms2();
+    res->ms_duplicates += t3 - t2;
+    int stats[3] = {0, 0, 0};
+    mods_ransac_set_device(c->device);
+    mask.assign(nu > 0 ? nu : 1, 0);
+    if (par->ransac.useF) rc = mods_loransac_f(c->h_u6.data(), c->h_laf.data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats);
+    else rc = mods_loransac_h(c->h_u6.data(), c->h_laf.data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats);
+    if (rc) return rc;
+    res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
+    res->ms_ransac += now_ms2() - t3;
+    curr_matches = res->n_inliers;
+    res->steps_done = step + 1;
+  }
+  if (matches_out) {
+    int m = 0;
+    for (int i = 0; i < res->n_unique && m < max_matches; i++)
+      if (mask[i]) {
+        const double *p = &c->h_u6[(size_t)i * 6];
+        matches_out[4 * m] = p[0]; matches_out[4 * m + 1] = p[1]; matches_out[4 * m + 2] = p[3]; matches_out[4 * m + 3] = p[4];
+        m++;
+      }
+  }
+  return MODS_OK;
+}
+
+}  // extern "C"

@@ -145,3 +145,55 @@ def match_pair(img1, img2, seed_time=12345, ratio=0.8, use_f=False):
         mask, H, ninl, stats = loransac_h(u6, laf, seed_time=seed_time)
     return dict(n_detected=[nd1, nd2], n_described=[len(ra), len(rb)], n_tentatives=len(tc), n_unique=len(un),
                 n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6)
+
+
+def view_schedule(tilts, phi_base, history, scales=(1.0,)):
+    """SetVSPars (synth-detection.cpp:191-322) for one step; history is extended in place."""
+    import math
+    eps1 = 0.01
+    tmp = []
+    for sc in scales:
+        for t in tilts:
+            if abs(t - 1) > eps1:
+                n_rot = int(math.floor(180.0 * t / phi_base))
+                dphi = math.pi / n_rot
+                if n_rot < 0:
+                    n_rot, dphi = 1, 0.0
+                    tmp.append((sc, -t, 0.0))
+                for r in range(n_rot):
+                    tmp.append((sc, t, dphi * r))
+            else:
+                tmp.append((sc, t, 0.0))
+    new = [v for v in tmp if not any(abs(v[0] - p[0]) <= eps1 and abs(v[1] - p[1]) <= eps1 and abs(v[2] - p[2]) <= eps1
+                                     for p in history)]
+    history.extend(new)
+    return new
+
+
+def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=0.2, ratio=0.8):
+    """mods.cpp:202-383 for HessianAffine + RootSIFT: steps = [(tilts, phi_base), ...]."""
+    h, w = img1.shape
+    banks = [[], []]
+    history = []
+    out = None
+    n_views = 0
+    for si, (tilts, phi_base) in enumerate(steps):
+        views = view_schedule(tilts, phi_base, history)
+        for im, img in enumerate((img1, img2)):
+            for (zoom, tilt, phi) in views:
+                px, g = orc.synth_view(img, tilt, phi, zoom, init_sigma, 1)
+                n_views += 1
+                if g.w_new < 16 or g.h_new < 16:
+                    continue
+                reg, _, _ = orc.detect_describe_view(px, np.array(g.H), w, h)
+                banks[im].append(reg)
+        ra, rb = np.concatenate(banks[0]), np.concatenate(banks[1])
+        tc = orc.match_fginn(ra, rb, ratio)
+        un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
+        u6, laf = u6_of(ra, rb, un), laf_of(ra, rb, un)
+        mask, H, ninl, stats = loransac_h(u6, laf, seed_time=seed_time)
+        out = dict(steps_done=si + 1, n_views=n_views, n_described=[len(ra), len(rb)], n_tentatives=len(tc), n_unique=len(un),
+                   n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6, regions=(ra, rb))
+        if ninl >= min_matches:
+            break
+    return out

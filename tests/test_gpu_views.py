@@ -84,3 +84,70 @@ def test_view_detect_describe_matches_oracle(pkg, img, tilt, phi):
         # regions are expressed in the original frame
         assert got["x"].min() > 0 and got["x"].max() < w and got["y"].min() > 0 and got["y"].max() < h
     ctx.close()
+
+
+def _hard_pair(w, h, seed):
+    """Image 2 = image 1 seen under a strong tilt (an affine map with anisotropy ~4.5 at 35 degrees)."""
+    a = synth.texture(w, h, seed)
+    ang = np.deg2rad(35.0)
+    R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+    A = R @ np.diag([1.0, 1.0 / 4.5]) @ R.T @ np.array([[np.cos(0.3), -np.sin(0.3)], [np.sin(0.3), np.cos(0.3)]])
+    c = np.array([w / 2.0, h / 2.0])
+    H = np.eye(3)
+    H[:2, :2] = A
+    H[:2, 2] = c - A @ c
+    return a, synth.warp(a, H, seed=seed), H
+
+
+def test_view_schedule_counts(pkg):
+    hist = []
+    steps = pkg.iters_mods_steps()
+    assert len(pkg.view_schedule(steps[0], hist)) == 11      # SURVEY 8: 11 + 20 new views per image
+    assert len(pkg.view_schedule(steps[1], hist)) == 20
+    import pipeline_oracle as po
+    h2 = []
+    assert po.view_schedule((1, 2, 4, 6, 8), 360.0, h2) == hist[:11]
+    assert po.view_schedule((1, 2, 4, 6, 8), 120.0, h2) == hist[11:]
+
+
+def test_ladder_matches_oracle(pkg):
+    """The step loop on a pair that the identity view alone cannot match: same views, same accumulated regions,
+    same tentatives, same inlier set as the CPU oracle chain."""
+    import torch
+    import pipeline_oracle as po
+    import refdeg
+    if not refdeg.available():
+        pytest.skip("oracle/_ref not built")
+    w, h = 480, 360
+    a, b, Htrue = _hard_pair(w, h, seed=21)
+    steps_spec = [((1,), 360.0), ((1, 2, 4), 360.0), ((1, 2, 4), 120.0)]
+    want = po.match_ladder(a, b, steps_spec, seed_time=31)
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    rep1, rep2 = pkg.ImgRep(ctx), pkg.ImgRep(ctx)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(31)
+    steps = [pkg.LadderStep.make(tl, ph) for tl, ph in steps_spec]
+    res, m = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2, max_matches=100000)
+    assert res.steps_done == want["steps_done"] and res.steps_done >= 2      # the identity view alone must fail
+    assert res.n_views == want["n_views"]
+    assert list(res.n_described) == want["n_described"] == [len(rep1), len(rep2)]
+    ra, rb = rep1.fetch(), rep2.fetch()
+    for got, exp in ((ra, want["regions"][0]), (rb, want["regions"][1])):
+        for f in ("x", "y", "s", "a11", "a12", "a21", "a22"):
+            assert np.array_equal(got[f], exp[f]), f
+        assert np.array_equal(got["desc"], exp["desc"])
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] >= 15
+    assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
+    # the verified matches follow the generating map (a handful of inliers: compare transfer, not coefficients)
+    p = np.c_[m[:, 0], m[:, 1], np.ones(len(m))] @ Htrue.T
+    assert np.median(np.hypot(p[:, 0] / p[:, 2] - m[:, 2], p[:, 1] / p[:, 2] - m[:, 3])) < 3.0
+    # query slices reproduce the full match (what each rank of the multi-GPU path computes)
+    full, _, _ = pkg.match_reps(ctx, rep1, rep2)
+    n = len(rep1)
+    parts = [pkg.match_reps(ctx, rep1, rep2, q0, q1)[0] for q0, q1 in ((0, n // 3), (n // 3, n // 2), (n // 2, n))]
+    assert np.array_equal(np.concatenate(parts), full)
+    rep1.close(); rep2.close(); ctx.close()
