@@ -192,6 +192,7 @@ int mods_detect_describe_view_dev(mods_ctx *ctx, const float *src_dev, int w, in
                                   double zoom, double initSigma, int doBlur, const mods_hessaff_params *det,
                                   const mods_describe_params *desc, mods_view_geom *geom_out, int *n_detected, int *n_regions);
 const mods_region *mods_regions_dev(mods_ctx *ctx, int img);     /* device pointer of the region list of image `img` */
+int mods_regions_copy_dev(mods_ctx *ctx, int img, mods_region *dst_dev, int n);   /* D2D copy of its first n entries */
 const float *mods_view_pixels_dev(mods_ctx *ctx);                /* pixels of the last synthesised view (w_new x h_new) */
 int mods_view_fetch(mods_ctx *ctx, const mods_view_geom *geom, float *dst_host);   /* host copy of those pixels */
 /* host-buffer primitives (parity tests): cv::warpAffine(LINEAR, BORDER_CONSTANT cval), M maps src -> dst;

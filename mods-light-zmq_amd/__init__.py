@@ -241,6 +241,10 @@ class Context:
         _check(lib().mods_regions_fetch(self.h, img, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
         return out[:n.value].copy()
 
+    def regions_copy_dev(self, img, dst_ptr, n):
+        """Device-to-device copy of the first n regions of image slot img (e.g. into a torch tensor)."""
+        _check(lib().mods_regions_copy_dev(self.h, img, C.c_void_p(dst_ptr), n))
+
     def dominant_angle(self, patch, th=float(np.float32(0.8))):
         a = np.ascontiguousarray(patch, np.float32)
         ang, found = C.c_float(), C.c_int()

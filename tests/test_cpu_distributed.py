@@ -45,6 +45,20 @@ WORKER = textwrap.dedent('''
     assert int(t.item()) == int(chk[0])
     views = shard.largest_first_views([100, 12, 50, 50, 12, 25], world)
     assert sorted(sum(views, [])) == list(range(6)) and abs(sum([100, 12, 50, 50, 12, 25][i] for i in views[0]) - 124.5) <= 12.5
+    # 3. the exchange step of the view-sharded ladder: every job computed by one rank, every rank ends up with all
+    #    blocks in job order (counts differ, one padded all-gather)
+    import torch
+    n_jobs = 7
+    owners = shard.largest_first_views([9, 1, 4, 4, 2, 7, 3], world)
+    def block(j):
+        k = (j * 5) %% 4 + (1 if j != 3 else 0)      # job 3 has no regions at all
+        g = np.random.default_rng(100 + j).integers(0, 256, k * shard.REGION_BYTES, dtype=np.uint8)
+        return torch.from_numpy(g)
+    local = {j: block(j) for j in owners[rank]}
+    blocks, counts = shard.exchange_blocks(local, n_jobs, dist)
+    for j in range(n_jobs):
+        assert torch.equal(blocks[j], block(j)), j
+        assert counts[j] == block(j).numel() // shard.REGION_BYTES
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok")
 ''') % (ROOT, ROOT, ROOT)
