@@ -158,6 +158,7 @@ int mods_orient_describe(mods_ctx *ctx, const float *img, int w, int h, int stri
 int mods_detect_describe_dev(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, int stride,
                              const mods_hessaff_params *det, const mods_describe_params *desc,
                              int *n_detected_host, int *n_regions_host);
+int mods_unoriented_count(mods_ctx *ctx, int img);   /* |"None" region list| of slot img after the last describe call */
 int mods_regions_fetch(mods_ctx *ctx, int img, mods_region *out, int max_out, int *n_out);
 
 /* parity-test building blocks: one 32x32 orientation patch / one 41x41 descriptor patch */
@@ -330,6 +331,7 @@ typedef struct mods_ladder_step {     /* one [HessianAffine<i>] section of the i
 typedef struct mods_ladder_result {
   int steps_done, n_views;            /* steps executed; views synthesised (both images) */
   int n_detected[2], n_described[2];  /* summed over views / accumulated regions per image */
+  int n_unoriented[2];                /* detections inside the image, summed over views (log: UnorientedReg) */
   int n_tentatives, n_unique, n_inliers;   /* of the last step */
   int ransac_samples, ransac_lo, ransac_rejects;
   double H[9];
@@ -349,10 +351,15 @@ int mods_imgrep_append_host(mods_imgrep *rep, const mods_region *src, int n);
 int mods_imgrep_fetch(mods_imgrep *rep, int begin, int count, mods_region *out);
 int mods_match_reps(mods_ctx *ctx, const mods_imgrep *q, int q_begin, int q_end, const mods_imgrep *t, double ratio,
                     double contradDist, int nn, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out);
-/* img_dev: [2][h][w] fp32 in HBM; the context needs max_w = max_h >= ceil(hypot(w, h)) and batch >= 1. */
-int mods_match_ladder_dev(mods_ctx *ctx, const float *img_dev, int w, int h, const mods_ladder_step *steps, int n_steps,
-                          int min_matches, const mods_pair_params *par, mods_imgrep *rep1, mods_imgrep *rep2,
-                          mods_ladder_result *res, double *matches_out, int max_matches);
+/* img1_dev, img2_dev: dense fp32 images in HBM; the context needs max_w = max_h >= ceil(hypot(w, h)) of the larger image. */
+int mods_match_ladder_dev(mods_ctx *ctx, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
+                          const mods_ladder_step *steps, int n_steps, int min_matches, const mods_pair_params *par,
+                          mods_imgrep *rep1, mods_imgrep *rep2, mods_ladder_result *res, double *matches_out, int max_matches);
+/* plain device-memory helpers for callers that do not link a HIP runtime themselves (the mods CLI) */
+int mods_dev_alloc(size_t bytes, void **out);
+int mods_dev_free(void *p);
+int mods_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
+int mods_dev_download(void *dst_host, const void *src_dev, size_t bytes);
 
 /* ---- pair pipeline ----------------------------------------------------------------------------------
  * Throughput form of the same path: `gpu_workers` threads (one context each) run detect/describe/match

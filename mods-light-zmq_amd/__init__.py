@@ -469,7 +469,7 @@ def iters_mods_steps():
 
 class LadderResult(C.Structure):
     _fields_ = [("steps_done", C.c_int), ("n_views", C.c_int), ("n_detected", C.c_int * 2), ("n_described", C.c_int * 2),
-                ("n_tentatives", C.c_int), ("n_unique", C.c_int), ("n_inliers", C.c_int),
+                ("n_unoriented", C.c_int * 2), ("n_tentatives", C.c_int), ("n_unique", C.c_int), ("n_inliers", C.c_int),
                 ("ransac_samples", C.c_int), ("ransac_lo", C.c_int), ("ransac_rejects", C.c_int), ("H", C.c_double * 9),
                 ("ms_detect_describe", C.c_double), ("ms_match", C.c_double), ("ms_duplicates", C.c_double),
                 ("ms_ransac", C.c_double)]
@@ -551,13 +551,16 @@ def match_reps(ctx, q, t, q_begin=0, q_end=None, ratio=0.8, contrad=10.0, nn=50)
     return out[:n.value].copy(), u6[:n.value].copy(), laf[:n.value].copy()
 
 
-def match_ladder_dev(ctx, img_ptr, w, h, steps, rep1, rep2, params=None, min_matches=15, max_matches=0):
-    """The step loop of mods.cpp:202-383 on one GPU; img_ptr: [2][h][w] fp32 in HBM."""
+def match_ladder_dev(ctx, img_ptr, w, h, steps, rep1, rep2, params=None, min_matches=15, max_matches=0, img2_ptr=None, w2=None, h2=None):
+    """The step loop of mods.cpp:202-383 on one GPU; img_ptr: [2][h][w] fp32 in HBM (or two separate images)."""
+    if img2_ptr is None:
+        img2_ptr, w2, h2 = img_ptr + 4 * w * h, w, h
     params = params or PairParams.default()
     arr = (LadderStep * len(steps))(*steps)
     res = LadderResult()
     m = np.zeros((max(max_matches, 1), 4), np.float64)
-    _check(lib().mods_match_ladder_dev(ctx.h, C.c_void_p(img_ptr), w, h, arr, len(steps), min_matches, C.byref(params), rep1.h, rep2.h,
+    _check(lib().mods_match_ladder_dev(ctx.h, C.c_void_p(img_ptr), w, h, C.c_void_p(img2_ptr), w2, h2, arr, len(steps), min_matches,
+                                       C.byref(params), rep1.h, rep2.h,
                                        C.byref(res), m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
     return res, m[:min(res.n_inliers, max_matches)]
 

@@ -1,0 +1,310 @@
+// mods - command-line front end of the MI355X matcher, argument- and file-compatible with the reference's
+// `mods` binary for the part of the system that is in scope (HessianAffine + RootSIFT steps, LO-RANSAC
+// homography or DEGENSAC epipolar verification).
+//
+// Reference behaviour:
+//   argv layout        getCLIparam, io_mods.cpp:558-603 (Tmin = 9, io_mods.h:13):
+//       mods img1 img2 out1 out2 k1 k2 matchings log [logOnly] [ver_type] [H/F file] [config.ini] [iters.ini]
+//            [read_pre_extracted] [match_one_to_many]
+//       ver_type 0 = LO-RANSAC homography, 2 = LO-RANSAC epipolar (1 = ground truth, 3 = ORSA: not built)
+//   configuration      the [HessianAffine], [DominantOrientation], [SIFTDescriptor], [Matching], [DuplicateFiltering],
+//                      [RANSAC], [TextOutput], [Computing] keys of io_mods.cpp:160-207, 423-455, 605-740 and the
+//                      [Iterations] / [HessianAffine<i>] sections of the iterations file (:457-492)
+//   step loop          mods.cpp:202-383 (mods_match_ladder_dev)
+//   outputs            matchings "x1 y1 x2 y2" (matching.cpp:2596-2613), log line (io_mods.cpp:10-66),
+//                      keypoint files (imagerepresentation.cpp:198-204, 1219-1255), H/F file (matching.cpp:2681-2686),
+//                      time.log (io_mods.cpp:67-99, mods.cpp:528-540); exit code 0 / 1
+// Not built (outside the hot path): MSER/DoG/Harris/ORB steps of an iterations file are skipped with a
+// warning, match images (out1/out2) are not drawn, pre-extracted input and ground-truth verification are
+// refused.  The vector matcher is always the exact (linear) search.
+#include "../../include/mods_hip.h"
+#include "image_io.hpp"
+#include "ini_reader.hpp"
+#include <chrono>
+#include <cmath>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+using modscli::GreyImage;
+using modscli::IniReader;
+
+namespace {
+
+const int Tmin = 9;
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+bool ends_with(const std::string &s, const std::string &suffix) {
+  return s.size() >= suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0;
+}
+
+struct Config {
+  mods_pair_params pair;
+  std::vector<mods_ladder_step> steps;
+  int max_steps = 4, min_matches = 15;
+  int load_color = 1;
+  int verbose = 0, time_log = 1, write_keypoints = 1, write_matches = 1, output_h = 0;
+};
+
+int read_config(const std::string &config_fn, const std::string &iters_fn, int ver_type, Config *cfg) {
+  IniReader ini(config_fn);
+  if (ini.ParseError() < 0) { std::cerr << "Can't load " << config_fn << std::endl; return 1; }
+  IniReader it(iters_fn);
+  if (it.ParseError() < 0) { std::cerr << "Can't load  " << iters_fn << std::endl; return 1; }
+  mods_pair_params &p = cfg->pair;
+  // [HessianAffine], io_mods.cpp:160-207; defaults = PyramidParams / AffineShapeParams constructors
+  mods_hessaff_params &d = p.det;
+  d.threshold = (float)ini.GetDouble("HessianAffine", "threshold", 16.0 / 3.0);
+  d.border = (int)ini.GetInteger("HessianAffine", "border", 5);
+  d.numberOfScales = (int)ini.GetInteger("HessianAffine", "numberOfScales", 3);
+  d.initialSigma = (float)ini.GetDouble("HessianAffine", "initialSigma", 1.6);
+  d.edgeEigenValueRatio = (float)ini.GetDouble("HessianAffine", "edgeEigenValueRatio", 10.0);
+  d.maxIterations = (int)ini.GetInteger("HessianAffine", "max_iter", 16);
+  d.smmWindowSize = (int)ini.GetInteger("HessianAffine", "smmWindowSize", 19);
+  d.convergenceThreshold = (float)ini.GetDouble("HessianAffine", "convergenceThreshold", 0.05);
+  d.doBaumberg = (int)ini.GetInteger("HessianAffine", "doBaumberg", 1);
+  const std::string mode = ini.GetStringVector("HessianAffine", "mode")[0];
+  if (!mode.empty() && mode != "FixedTh") std::cerr << "Warning: [HessianAffine] mode=" << mode << " is not supported, FixedTh is used" << std::endl;
+  if (ini.GetInteger("HessianAffine", "affBmbrgMethod", 0) != 0) std::cerr << "Warning: affBmbrgMethod != 0 (Hessian Baumberg) is not supported, SMM is used" << std::endl;
+  if (ini.GetBoolean("AffineAdaptation", "useZMQ", false) || ini.GetBoolean("DominantOrientation", "useZMQ", false))
+    std::cerr << "Warning: external (ZMQ) affine shape / orientation estimators are not supported, the built-in ones are used" << std::endl;
+  // [DominantOrientation] :731-740 and [SIFTDescriptor] :423-436
+  mods_describe_params &q = p.desc;
+  q.ori_mrSize = ini.GetDouble("DominantOrientation", "mrSize", 3.0 * std::sqrt(3.0));
+  q.ori_patchSize = (int)ini.GetInteger("DominantOrientation", "patchSize", 32);
+  q.ori_maxAngles = (int)ini.GetInteger("DominantOrientation", "maxAngles", 1);
+  q.ori_threshold = (double)(float)ini.GetDouble("DominantOrientation", "threshold", 0.8);
+  q.desc_mrSize = ini.GetDouble("SIFTDescriptor", "mrSize", 3.0 * std::sqrt(3.0));
+  q.desc_patchSize = (int)ini.GetInteger("SIFTDescriptor", "patchSize", 41);
+  q.photoNorm = ini.GetBoolean("SIFTDescriptor", "photoNorm", true) ? 1 : 0;
+  q.rootSift = 1;
+  q.maxBinValue = ini.GetDouble("SIFTDescriptor", "maxBinValue", 0.2);
+  if (ini.GetBoolean("SIFTDescriptor", "FastPatchExtraction", false)) std::cerr << "Warning: FastPatchExtraction is not supported, the exact extraction is used" << std::endl;
+  if (ini.GetInteger("SIFTDescriptor", "spatialBins", 4) != 4 || ini.GetInteger("SIFTDescriptor", "orientationBins", 8) != 8) {
+    std::cerr << "Only 4x4x8 SIFT is supported" << std::endl;
+    return 1;
+  }
+  // [Matching]
+  p.fginn_ratio = 0.8;
+  p.contradDist = ini.GetDouble("Matching", "contradDist", 10.0);
+  p.nn = 50;
+  const std::string vm = ini.GetString("Matching", "vector_matcher", "");
+  if (!vm.empty() && vm != "linear" && cfg->verbose) std::cerr << "Note: vector_matcher=" << vm << ": this build always searches exactly (linear)" << std::endl;
+  // [DuplicateFiltering] :665-679
+  p.dup_dist = ini.GetDouble("DuplicateFiltering", "duplicateDist", 3.0);
+  p.dup_before_ransac = (int)ini.GetDouble("DuplicateFiltering", "doBeforeRANSAC", 1);
+  const std::string fm = ini.GetString("DuplicateFiltering", "whichCorrespondenceRemains", "random");
+  p.dup_mode = fm == "bestFGINN" ? 1 : fm == "bestDistance" ? 2 : fm == "biggerRegion" ? 3 : 0;
+  if (p.dup_mode == 3) { std::cerr << "Warning: whichCorrespondenceRemains=biggerRegion is not supported, list order is used" << std::endl; p.dup_mode = 0; }
+  // [RANSAC] :437-455
+  mods_ransac_params &r = p.ransac;
+  r.err_threshold = ini.GetDouble("RANSAC", "err_threshold", 2.0);
+  r.confidence = ini.GetDouble("RANSAC", "confidence", 0.99);
+  r.max_samples = (int)ini.GetInteger("RANSAC", "max_samples", 100000);
+  r.localOptimization = (int)ini.GetInteger("RANSAC", "localOptimization", 1);
+  r.LAFCoef = (double)ini.GetInteger("RANSAC", "LAFcoef", ini.GetInteger("Matching", "LAFcoef", 0));
+  r.HLAFCoef = (double)ini.GetInteger("RANSAC", "HLAFcoef", 10);
+  r.doSymmCheck = (int)ini.GetInteger("RANSAC", "doSymmCheck", 0);
+  const std::string et = ini.GetStringVector("RANSAC", "ErrorType")[0];
+  r.errorType = et == "Sampson" ? 0 : et == "SymmMax" ? 1 : 2;
+  r.useF = ver_type == 2 ? 1 : 0;
+  // [TextOutput], [Computing]
+  cfg->verbose = (int)ini.GetInteger("TextOutput", "verbose", 0);
+  cfg->time_log = (int)ini.GetInteger("TextOutput", "timeLog", 0);
+  cfg->write_keypoints = (int)ini.GetInteger("TextOutput", "writeKeypoints", 1);
+  cfg->write_matches = (int)ini.GetInteger("TextOutput", "writeMatches", 1);
+  cfg->output_h = (int)ini.GetInteger("TextOutput", "outputEstimatedHorF", 0);
+  if (ini.GetInteger("TextOutput", "outputAllTentatives", 0)) std::cerr << "Warning: outputAllTentatives is not supported, only verified matches are written" << std::endl;
+  cfg->load_color = (int)ini.GetInteger("Computing", "LoadColor", 1);
+  // iterations file :457-492
+  cfg->max_steps = (int)it.GetInteger("Iterations", "Steps", 4);
+  cfg->min_matches = (int)it.GetInteger("Iterations", "minMatches", 15);
+  static const char *other_detectors[] = {"MSER", "DoG", "HarrisAffine", "ORB", "FAST", "ReadAffs", "STAR", "BRISK", "SURF", "SIFT", "TILDE", "FOCI"};
+  for (int i = 0; i < cfg->max_steps; i++) {
+    const std::string sec = "HessianAffine" + std::to_string(i);
+    for (const char *od : other_detectors)
+      if (it.Has(od + std::to_string(i), "TiltSet") || it.Has(od + std::to_string(i), "ScaleSet"))
+        std::cerr << "Warning: step " << i << ": detector " << od << " is outside this build, its views are skipped" << std::endl;
+    mods_ladder_step st;
+    memset(&st, 0, sizeof(st));
+    st.phi = it.GetDouble(sec, "Phi", 360);
+    st.initSigma = it.GetDouble(sec, "initSigma", 0.5);
+    st.doBlur = 1;
+    st.fginn_ratio = 0.0;
+    if (it.Has(sec, "TiltSet") && it.Has(sec, "ScaleSet")) {
+      const std::vector<double> tilts = it.GetDoubleVector(sec, "TiltSet"), scales = it.GetDoubleVector(sec, "ScaleSet");
+      if (tilts.size() > 8 || scales.size() > 8) { std::cerr << sec << ": at most 8 tilts and 8 scales per step" << std::endl; return 1; }
+      st.n_tilts = (int)tilts.size(); st.n_scales = (int)scales.size();
+      for (size_t k = 0; k < tilts.size(); k++) st.tilt_set[k] = tilts[k];
+      for (size_t k = 0; k < scales.size(); k++) st.scale_set[k] = scales[k];
+      const std::vector<std::string> descs = it.GetStringVector(sec, "Descriptors");
+      const std::vector<double> fginn = it.GetDoubleVector(sec, "FGINNThreshold");
+      bool has_root = false;
+      for (size_t k = 0; k < descs.size(); k++) {
+        std::string name = descs[k];
+        name.erase(0, name.find_first_not_of(" \t"));
+        name.erase(name.find_last_not_of(" \t") + 1);
+        if (name == "RootSIFT") { has_root = true; st.fginn_ratio = k < fginn.size() ? fginn[k] : 0.0; }
+        else if (!name.empty()) std::cerr << "Warning: " << sec << ": descriptor " << name << " is outside this build" << std::endl;
+      }
+      if (!has_root) { std::cerr << "Warning: " << sec << " does not ask for RootSIFT; the step is skipped" << std::endl; st.n_tilts = st.n_scales = -1; }
+      else if (!(st.fginn_ratio > 0 && st.fginn_ratio < 1)) { std::cerr << sec << ": FGINNThreshold of RootSIFT must lie in (0, 1)" << std::endl; return 1; }
+    } else st.n_tilts = st.n_scales = -1;      // no views of this detector in this step
+    cfg->steps.push_back(st);
+  }
+  return 0;
+}
+
+int usage() {
+  std::cerr << " ************************************************************************** " << std::endl
+            << " **** mods: two-view matching with view synthesis, MI355X build        **** " << std::endl
+            << " ************************************************************************** " << std::endl
+            << "Usage: mods img1 img2 out1 out2 k1 k2 matchings log [logOnly=1] [ver_type=0] [H/F file] [config.ini] [iters.ini]" << std::endl
+            << "  img1, img2   PNG or binary PGM/PPM" << std::endl
+            << "  out1, out2   accepted for compatibility (match images are not drawn)" << std::endl
+            << "  k1, k2       keypoint + descriptor files (text)" << std::endl
+            << "  matchings    verified correspondences, x1 y1 x2 y2 per line" << std::endl
+            << "  log          one line: time matches tentatives inlier% regions1 regions2 steps" << std::endl
+            << "  ver_type     0 LO-RANSAC homography, 2 LO-RANSAC (DEGENSAC) epipolar geometry" << std::endl;
+  return 1;
+}
+
+bool load_grey(const std::string &fn, int load_color, GreyImage *img) {
+  std::string err;
+  if (!modscli::read_image(fn, load_color != 0, img, &err)) { std::cerr << err << std::endl; return false; }
+  return true;
+}
+
+void write_regions(const std::string &fn, mods_imgrep *rep) {
+  std::ofstream kp(fn);
+  if (!kp.is_open()) { std::cerr << "Cannot open file " << fn << " to save keypoints" << std::endl; return; }
+  const int n = mods_imgrep_count(rep);
+  std::vector<mods_region> regs((size_t)std::max(n, 1));
+  if (n > 0 && mods_imgrep_fetch(rep, 0, n, regs.data())) { std::cerr << mods_last_error() << std::endl; return; }
+  kp << 1 << std::endl;
+  kp << "HessianAffine " << 1 << std::endl;
+  kp << "RootSIFT " << n << std::endl;
+  if (n > 0) kp << 128 << std::endl;
+  for (int i = 0; i < n; i++) {
+    const mods_region &r = regs[i];
+    kp << r.x << " " << r.y << " " << r.s << " " << r.a11 << " " << r.a12 << " " << r.a21 << " " << r.a22;
+    kp << " " << 128 << " ";
+    for (int j = 0; j < 128; j++) kp << (float)r.desc[j] << " ";
+    kp << std::endl;
+  }
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < Tmin) return usage();
+  const double c_start = now_s();
+  const std::string img1_fn = argv[1], img2_fn = argv[2], k1_fn = argv[5], k2_fn = argv[6], match_fn = argv[7], log_fn = argv[8];
+  int log_only = 1, ver_type = 0;
+  std::string config_fn = "config_iter.ini", iters_fn = "iters.ini";
+  if (argc >= Tmin + 1) log_only = atoi(argv[Tmin]);
+  if (argc >= Tmin + 2) {
+    ver_type = atoi(argv[Tmin + 1]);
+    if (ver_type != 0 && ver_type != 2) {
+      std::cerr << ver_type << " is wrong correspondence verification type." << std::endl
+                << "Try 0 for LO-RANSAC(homography) or 2 for LO-RANSAC(epipolar) (1, ground truth, and 3, ORSA, are not part of this build)" << std::endl;
+      return 1;
+    }
+  }
+  if (argc >= Tmin + 4) config_fn = argv[Tmin + 3];
+  if (argc >= Tmin + 5) iters_fn = argv[Tmin + 4];
+  if (argc >= Tmin + 6 && atoi(argv[Tmin + 5]) > 0) { std::cerr << "read_pre_extracted is not part of this build" << std::endl; return 1; }
+  Config cfg;
+  memset(&cfg.pair, 0, sizeof(cfg.pair));
+  if (read_config(config_fn, iters_fn, ver_type, &cfg)) return 1;
+
+  GreyImage img1, img2;
+  if (!load_grey(img1_fn, cfg.load_color, &img1)) { std::cerr << "Cannot read image " << img1_fn << std::endl; return 1; }
+  if (!load_grey(img2_fn, cfg.load_color, &img2)) { std::cerr << "Cannot read image " << img2_fn << std::endl; return 1; }
+  if (cfg.verbose) std::cerr << "Image1: " << img1.w << "x" << img1.h << ", Image2: " << img2.w << "x" << img2.h << std::endl;
+
+  if (mods_device_count() <= 0) { std::cerr << "mods: no MI355X / HIP device available (" << mods_last_error() << "); this build has no CPU path" << std::endl; return 1; }
+  const int device = getenv("MODS_DEVICE") ? atoi(getenv("MODS_DEVICE")) : 0;
+  const double diag = std::ceil(std::max(std::hypot((double)img1.w, (double)img1.h), std::hypot((double)img2.w, (double)img2.h))) + 2;
+  mods_ctx *ctx = nullptr;
+  mods_imgrep *rep1 = nullptr, *rep2 = nullptr;
+  void *d1 = nullptr, *d2 = nullptr;
+  auto fail = [&](const char *what) { std::cerr << "mods: " << what << ": " << mods_last_error() << std::endl; return 1; };
+  if (mods_ctx_create(device, (int)diag, (int)diag, 1, &ctx)) return fail("context");
+  if (mods_imgrep_create(ctx, 1 << 20, &rep1) || mods_imgrep_create(ctx, 1 << 20, &rep2)) return fail("region banks");
+  if (mods_dev_alloc(sizeof(float) * img1.px.size(), &d1) || mods_dev_alloc(sizeof(float) * img2.px.size(), &d2)) return fail("device memory");
+  if (mods_dev_upload(d1, img1.px.data(), sizeof(float) * img1.px.size()) || mods_dev_upload(d2, img2.px.data(), sizeof(float) * img2.px.size())) return fail("upload");
+
+  // steps without HessianAffine views are dropped from the ladder but still count as steps of the loop
+  std::vector<mods_ladder_step> steps;
+  std::vector<int> step_index;
+  for (size_t i = 0; i < cfg.steps.size(); i++)
+    if (cfg.steps[i].n_tilts >= 0) { steps.push_back(cfg.steps[i]); step_index.push_back((int)i); }
+  if (steps.empty()) { std::cerr << "The iterations file has no HessianAffine step with RootSIFT; nothing to do" << std::endl; return 1; }
+  if (cfg.verbose) std::cerr << steps.size() << " HessianAffine step(s) of " << cfg.steps.size() << " will be run, minMatches = " << cfg.min_matches << std::endl;
+
+  mods_ladder_result res;
+  std::vector<double> matches((size_t)4 << 20);
+  if (mods_match_ladder_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, steps.data(), (int)steps.size(),
+                            cfg.min_matches, &cfg.pair, rep1, rep2, &res, matches.data(), 1 << 20))
+    return fail("matching");
+  const double final_time = now_s() - c_start;
+  const int final_step = res.steps_done > 0 ? step_index[res.steps_done - 1] + 1 : 0;
+  if (cfg.verbose) {
+    std::cerr << res.n_views << " views synthesised, " << res.n_tentatives << " tentatives found." << std::endl;
+    std::cerr << res.n_unique << " unique tentatives left" << std::endl;
+    std::cerr << (cfg.pair.ransac.useF ? "LO-RANSAC(epipolar)" : "LO-RANSAC(homography)") << " verification is used..." << std::endl;
+    std::cerr << res.n_inliers << " RANSAC correspondences got" << std::endl;
+  }
+  std::cerr << "Done in " << final_step << " iterations" << std::endl << "*********************" << std::endl;
+
+  {   // WriteLog, io_mods.cpp:10-66
+    std::ofstream lf(log_fn);
+    if (lf.is_open()) {
+      const double ratio = res.n_unique > 0 ? (double)res.n_inliers / (double)res.n_unique : std::nan("");
+      lf << std::setprecision(3) << final_time << " " << res.n_inliers << " " << res.n_unique << " " << ratio * 100 << " ";
+      if (cfg.pair.ransac.useF) lf << res.n_described[0] << " " << res.n_described[1] << " ";
+      else lf << res.n_unoriented[0] << " " << res.n_unoriented[1] << " ";
+      lf << final_step << " " << std::endl;
+    }
+  }
+  if (cfg.output_h && argc >= Tmin + 3) {   // WriteH
+    std::ofstream hf(argv[Tmin + 2]);
+    if (hf.is_open())
+      hf << res.H[0] << " " << res.H[1] << " " << res.H[2] << std::endl << res.H[3] << " " << res.H[4] << " " << res.H[5] << std::endl
+         << res.H[6] << " " << res.H[7] << " " << res.H[8] << std::endl;
+  }
+  if (!log_only) {
+    if (cfg.write_matches) {
+      std::ofstream mf(match_fn);
+      if (mf.is_open())
+        for (int i = 0; i < res.n_inliers; i++)
+          mf << matches[4 * (size_t)i] << " " << matches[4 * (size_t)i + 1] << " " << matches[4 * (size_t)i + 2] << " " << matches[4 * (size_t)i + 3] << std::endl;
+    }
+    if (cfg.write_keypoints) {
+      if (ends_with(k1_fn, ".npz") || ends_with(k2_fn, ".npz")) std::cerr << "Warning: .npz keypoint output is not part of this build; text is written" << std::endl;
+      write_regions(k1_fn, rep1);
+      write_regions(k2_fn, rep2);
+    }
+  }
+  std::cerr << "Image1: regions descriptors | Image2: regions descriptors " << std::endl;
+  std::cerr << res.n_unoriented[0] << " " << res.n_described[0] << " | " << res.n_unoriented[1] << " " << res.n_described[1] << std::endl << std::endl;
+  std::cerr << "True matches | unique tentatives" << std::endl;
+  if (res.n_unique > 0) std::cerr << res.n_inliers << " | " << res.n_unique << " | " << std::setprecision(3) << 100.0 * res.n_inliers / res.n_unique << "%  1st geom inc" << std::endl;
+  else std::cerr << res.n_inliers << " | " << res.n_unique << " |  -  1st geom inc" << std::endl;
+  const double total = now_s() - c_start;
+  std::cerr << std::endl << "Main matching | All Time: " << std::endl << final_time << " | " << total << " seconds" << std::endl;
+  if (cfg.time_log) {   // WriteTimeLog(TimingLog, file, 0, 1, 0): Synth Detect Orient Desc Match RANSAC MISC Total (seconds)
+    const double dd = res.ms_detect_describe / 1000, mt = res.ms_match / 1000, rs = (res.ms_duplicates + res.ms_ransac) / 1000;
+    std::ofstream tf("time.log");
+    if (tf.is_open()) tf << 0.0 << " " << dd << " " << 0.0 << " " << 0.0 << " " << mt << " " << rs << " " << total - (dd + mt + rs) << " " << total << std::endl;
+    std::cerr << "Timings: (sec) " << std::endl << "Synth+Detect+Orient+Desc|Match|RANSAC|MISC|Total " << std::endl
+              << dd << " " << mt << " " << rs << " " << total - (dd + mt + rs) << " " << total << std::endl;
+  }
+  mods_imgrep_destroy(rep1); mods_imgrep_destroy(rep2);
+  mods_dev_free(d1); mods_dev_free(d2);
+  mods_ctx_destroy(ctx);
+  return 0;
+}

@@ -99,6 +99,8 @@ static int ctx_create_impl(int device, int max_w, int max_h, int batch, unsigned
   MODS_HIP_CHECK(hipMalloc(&c->ori_dev, 48 * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->regions_dev, sizeof(mods_region) * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->region_count, sizeof(int) * 3 * batch));   // regions, then 2 tier counts per image
+  MODS_HIP_CHECK(hipMalloc(&c->inside_count, sizeof(int) * batch));
+  MODS_HIP_CHECK(hipMemset(c->inside_count, 0, sizeof(int) * batch));
   *out = c;
   return MODS_OK;
 }
@@ -115,7 +117,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->tmp_dev); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
   (void)hipHostFree(c->host_counts);
-  (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->region_count); (void)hipFree(c->desc_tables_dev);
+  (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -269,7 +271,16 @@ int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w
     if (n_regions_host) n_regions_host[b] = c->host_counts[3 * c->batch + b];
   }
   c->last_region_counts.assign(c->host_counts + 3 * c->batch, c->host_counts + 3 * c->batch + n_img);
+  c->last_inside_counts.resize(n_img);
+  MODS_HIP_CHECK(hipMemcpy(c->last_inside_counts.data(), c->inside_count, sizeof(int) * n_img, hipMemcpyDeviceToHost));
   return check_desc_err(c);
+}
+
+// size of the reference's unoriented ("None") region list of image slot img after the last describe call:
+// detections whose centre, in the original frame, lies inside the image (imagerepresentation.cpp:867, 939)
+int mods_unoriented_count(mods_ctx *c, int img) {
+  if (!c || img < 0 || img >= (int)c->last_inside_counts.size()) return 0;
+  return c->last_inside_counts[img];
 }
 
 int mods_regions_fetch(mods_ctx *c, int img, mods_region *out, int max_out, int *n_out) {

@@ -102,6 +102,8 @@ struct mods_ctx {
   void *ori_dev = nullptr;           // [batch][max_cand] OriOut
   mods_region *regions_dev = nullptr;  // [batch][max_cand]
   int *region_count = nullptr;       // [batch]
+  int *inside_count = nullptr;       // [batch] keypoints that pass the centre test (the reference's unoriented list)
+  std::vector<int> last_inside_counts;
   float *desc_scratch = nullptr;
   size_t desc_scratch_elems = 0;
   const float *last_img_dev = nullptr;

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
       const double ry = (k.Hinv[3] * kp.x + k.Hinv[4] * kp.y + k.Hinv[5]);
       alive = (rx < k.ow) && (ry < k.oh) && (rx > 0) && (ry > 0);
     } else alive = (kp.x < k.w) && (kp.y < k.h) && (kp.x > 0) && (kp.y > 0);
+    const bool inside = alive;   // member of the unoriented ("None") region list of the reference
     const float fx = (float)kp.x, fy = (float)kp.y;
     const float f11 = (float)kp.a11, f12 = (float)kp.a12, f21 = (float)kp.a21, f22 = (float)kp.a22;
     const int box = (int)(k.ks * kp.s);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
     }
     if (lane == 0) {
       OriOut o;
-      o.a11 = n11; o.a12 = n12; o.a21 = n21; o.a22 = n22; o.alive = alive ? 1 : 0; o.pad = 0;
+      o.a11 = n11; o.a12 = n12; o.a21 = n21; o.a22 = n22; o.alive = alive ? 1 : 0; o.pad = inside ? 1 : 0;
       ori[i] = o;
     }
   }
@@ -206,9 +207,11 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
 __global__ __launch_bounds__(1024) void compact_regions_kernel(DescConst k, const mods_affkey *__restrict__ keys_all,
                                                                const int *__restrict__ key_count,
                                                                const OriOut *__restrict__ ori_all,
-                                                               mods_region *__restrict__ reg_all, int *__restrict__ reg_count) {
+                                                               mods_region *__restrict__ reg_all, int *__restrict__ reg_count,
+                                                               int *__restrict__ inside_count) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
+  __shared__ int s_inside;
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const mods_affkey *keys = keys_all + (size_t)b * k.max_cand;
@@ -216,13 +219,14 @@ __global__ __launch_bounds__(1024) void compact_regions_kernel(DescConst k, cons
   mods_region *reg = reg_all + (size_t)b * k.max_reg;
   int n = key_count[b];
   if (n > k.max_cand) n = k.max_cand;
-  if (tid == 0) s_base = 0;
+  if (tid == 0) { s_base = 0; s_inside = 0; }
   __syncthreads();
   for (int base = 0; base < n; base += 1024) {
     const int i = base + tid;
     const bool alive = i < n && ori[i].alive;
     const unsigned long long m = __ballot(alive);
-    if (lane == 0) s_wave[wv] = __popcll(m);
+    const unsigned long long mi = __ballot(i < n && ori[i].pad);
+    if (lane == 0) { s_wave[wv] = __popcll(m); if (mi) atomicAdd(&s_inside, __popcll(mi)); }
     __syncthreads();
     int off = s_base;
     for (int q = 0; q < wv; q++) off += s_wave[q];
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(1024) void compact_regions_kernel(DescConst k, cons
     if (tid == 0) { int t = 0; for (int q = 0; q < 16; q++) t += s_wave[q]; s_base += t; }
     __syncthreads();
   }
-  if (tid == 0) reg_count[b] = s_base;
+  if (tid == 0) { reg_count[b] = s_base; inside_count[b] = s_inside; }
 }
 
 // det_kp -> reproj_kp of the described regions of a synthesised view, in place (ReprojectByH: centre and
@@ -388,7 +392,7 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
     hipLaunchKernelGGL(orient_kernel, dim3(8192, n_img), dim3(64), lds, ctx->stream, img_dev, k, ctx->keys_dev, key_count,
                        orimask, (OriOut *)ctx->ori_dev);
     hipLaunchKernelGGL(compact_regions_kernel, dim3(1, n_img), dim3(1024), 0, ctx->stream, k, ctx->keys_dev, key_count,
-                       (const OriOut *)ctx->ori_dev, ctx->regions_dev, ctx->region_count);
+                       (const OriOut *)ctx->ori_dev, ctx->regions_dev, ctx->region_count, ctx->inside_count);
     MODS_HIP_CHECK(hipGetLastError());
   }
   rc = launch_extract_and_sift(ctx, img_dev, n_img, k, dmask, tab);

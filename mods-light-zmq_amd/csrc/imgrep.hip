@@ -47,7 +47,13 @@ int mods_loransac_f(const double *u6, const double *laf, int n, const mods_ransa
                     int *n_inliers, int *stats3);
 int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, double r, int mode, int *n_out);
 int mods_ransac_set_device(int device);
+int mods_unoriented_count(mods_ctx *c, int img);
 int mods_match_fetch_internal(mods_ctx *c, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out);   // capi.hip
+
+int mods_dev_alloc(size_t bytes, void **out) { if (!out) return MODS_E_ARG; MODS_HIP_CHECK(hipMalloc(out, bytes ? bytes : 4)); return MODS_OK; }
+int mods_dev_free(void *p) { MODS_HIP_CHECK(hipFree(p)); return MODS_OK; }
+int mods_dev_upload(void *dst_dev, const void *src_host, size_t bytes) { MODS_HIP_CHECK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return MODS_OK; }
+int mods_dev_download(void *dst_host, const void *src_dev, size_t bytes) { MODS_HIP_CHECK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return MODS_OK; }
 
 // ---- view schedule -------------------------------------------------------------------------------------
 // SetVSPars for one detector: the (zoom, tilt, phi) triples of a step that no earlier step has produced.
@@ -182,21 +188,21 @@ int mods_match_reps(mods_ctx *c, const mods_imgrep *q, int q_begin, int q_end, c
 }
 
 // ---- the step loop of mods.cpp:202-383 on one GPU ---------------------------------------------------------------
-// img_dev: [2][h][w] fp32 in HBM.  Every step adds the step's new views of both images to the two region
+// img1_dev / img2_dev: dense fp32 images in HBM (the two images may differ in size).  Every step adds the step's new views of both images to the two region
 // banks, matches bank 1 against bank 2, filters duplicates, verifies, and stops once the verified
 // matches reach min_matches.
-int mods_match_ladder_dev(mods_ctx *c, const float *img_dev, int w, int h, const mods_ladder_step *steps, int n_steps, int min_matches,
+int mods_match_ladder_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
+                          const mods_ladder_step *steps, int n_steps, int min_matches,
                           const mods_pair_params *par, mods_imgrep *rep1, mods_imgrep *rep2, mods_ladder_result *res, double *matches_out,
                           int max_matches) {
-  if (!c || !img_dev || !steps || !par || !rep1 || !rep2 || !res) { set_error("match_ladder: null argument"); return MODS_E_ARG; }
+  if (!c || !img1_dev || !img2_dev || !steps || !par || !rep1 || !rep2 || !res) { set_error("match_ladder: null argument"); return MODS_E_ARG; }
   memset(res, 0, sizeof(*res));
   for (int i = 0; i < 9; i++) res->H[i] = -1;
   mods_imgrep_clear(rep1); mods_imgrep_clear(rep2);
   std::vector<mods_view_par> hist(1024), views(256);
   int n_hist = 0, rc;
   int curr_matches = 0;
-  const size_t plane = (size_t)w * h;
-  std::vector<unsigned char> mask;
+  std::vector<unsigned char> mask(1, 0);
   for (int step = 0; step < n_steps && curr_matches < min_matches; step++) {
     const mods_ladder_step &st = steps[step];
     const int nv = mods_view_schedule(st.scale_set, st.n_scales, st.tilt_set, st.n_tilts, st.phi, hist.data(), &n_hist, (int)hist.size(),
@@ -207,11 +213,14 @@ int mods_match_ladder_dev(mods_ctx *c, const float *img_dev, int w, int h, const
       mods_imgrep *rep = im ? rep2 : rep1;
       for (int v = 0; v < nv; v++) {
         int nd = 0, nr = 0;
-        if ((rc = mods_detect_describe_view_dev(c, img_dev + plane * im, w, h, w, views[v].tilt, views[v].phi, views[v].zoom, st.initSigma,
+        const float *img = im ? img2_dev : img1_dev;
+        const int w = im ? w2 : w1, h = im ? h2 : h1;
+        if ((rc = mods_detect_describe_view_dev(c, img, w, h, w, views[v].tilt, views[v].phi, views[v].zoom, st.initSigma,
                                                 st.doBlur, &par->det, &par->desc, nullptr, &nd, &nr))) return rc;
         if ((rc = mods_imgrep_append_ctx(rep, c, 0))) return rc;
         res->n_views++;
         res->n_detected[im] += nd;
+        res->n_unoriented[im] += mods_unoriented_count(c, 0);
       }
     }
     res->n_described[0] = rep1->n; res->n_described[1] = rep2->n;

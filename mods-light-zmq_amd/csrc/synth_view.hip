@@ -279,6 +279,7 @@ int mods_detect_describe_view_dev(mods_ctx *c, const float *src_dev, int w, int 
     if (n_regions) *n_regions = 0;
     MODS_HIP_CHECK(hipMemsetAsync(c->region_count, 0, sizeof(int), c->stream));
     c->last_region_counts.assign(1, 0);
+    c->last_inside_counts.assign(1, 0);
     return MODS_OK;
   }
   if (!c->view_dev) MODS_HIP_CHECK(hipMalloc(&c->view_dev, sizeof(float) * (size_t)c->max_w * c->max_h));
@@ -296,6 +297,8 @@ int mods_detect_describe_view_dev(mods_ctx *c, const float *src_dev, int w, int 
   if (nr > (c->max_cand < (1 << 17) ? c->max_cand : (1 << 17))) { set_error("region list overflow: %d", nr); return MODS_E_CAPACITY; }
   if (n_regions) *n_regions = nr;
   c->last_region_counts.assign(1, nr);
+  c->last_inside_counts.assign(1, 0);
+  MODS_HIP_CHECK(hipMemcpy(c->last_inside_counts.data(), c->inside_count, sizeof(int), hipMemcpyDeviceToHost));
   int e = 0;
   MODS_HIP_CHECK(hipMemcpyAsync(&e, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -1,0 +1,88 @@
+"""-m gpu: the mods command line end to end on graf1/graf6 (PNG in, matchings / log / keypoints / H out) against
+the same run through the library API, and against the reference README's known answers for this pair."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODS = os.path.join(ROOT, "mods-light-zmq_amd", "mods")
+CFG = os.path.join(ROOT, "tests", "configs")
+G1, G6 = (os.path.join(ROOT, "tests", "golden", n) for n in ("graf1.png", "graf6.png"))
+
+
+def _grey(fn):
+    a = np.asarray(Image.open(fn).convert("RGB"), np.float32)
+    return ((a[:, :, 2] + a[:, :, 1]) + a[:, :, 0]) / np.float32(3.0)     # (B + G + R) / 3
+
+
+def _run(tmp_path, iters, ver_type="0"):
+    env = dict(os.environ, MODS_RANSAC_SEED="4242")
+    args = [MODS, G1, G6, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", ver_type, "H.txt",
+            os.path.join(CFG, "classic.ini"), os.path.join(CFG, iters)]
+    p = subprocess.run(args, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stderr.decode()
+
+
+def _library_run(pkg, steps, use_f=0):
+    import torch
+    a, b = _grey(G1), _grey(G6)
+    h, w = a.shape
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    par.ransac.useF = use_f
+    pkg.ransac_pin_seed(4242)
+    res, m = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2, par, max_matches=1 << 20)
+    regs = (rep1.fetch(), rep2.fetch())
+    pkg.ransac_pin_seed(-1)
+    rep1.close(); rep2.close(); ctx.close()
+    return res, m, regs
+
+
+def test_cli_one_view_matches_library_and_readme(pkg, tmp_path):
+    err = _run(tmp_path, "iters_one_view.ini")
+    res, m, regs = _library_run(pkg, [pkg.LadderStep.make((1,), 360.0)])
+    got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    assert len(got) == res.n_inliers > 15
+    assert np.allclose(got, m, rtol=1e-5, atol=1e-3)                 # text output carries 6 significant digits
+    log = (tmp_path / "log.txt").read_text().split()
+    assert len(log) == 7
+    assert [int(log[1]), int(log[2]), int(log[4]), int(log[5]), int(log[6])] == [res.n_inliers, res.n_unique, res.n_unoriented[0],
+                                                                              res.n_unoriented[1], 1]
+    # reference README (graf1-graf6, classic config): 2665 / 3287 regions, 2331 / 2912 descriptors (+-2 here: OpenCV unpinned)
+    assert abs(res.n_unoriented[0] - 2665) <= 3 and abs(res.n_unoriented[1] - 3287) <= 3
+    assert abs(res.n_described[0] - 2331) <= 3 and abs(res.n_described[1] - 2912) <= 3
+    H = np.loadtxt(tmp_path / "H.txt")
+    assert H.shape == (3, 3) and np.allclose(H, np.array(res.H).reshape(3, 3), rtol=1e-4, atol=1e-6)
+    for fn, r in (("k1.txt", regs[0]), ("k2.txt", regs[1])):
+        lines = (tmp_path / fn).read_text().splitlines()
+        assert lines[0] == "1" and lines[1] == "HessianAffine 1" and lines[2] == "RootSIFT %d" % len(r) and lines[3] == "128"
+        assert len(lines) == 4 + len(r)
+        row = np.array(lines[4].split(), float)
+        assert len(row) == 7 + 1 + 128 and row[7] == 128
+        assert np.allclose(row[:7], [r[0][f] for f in ("x", "y", "s", "a11", "a12", "a21", "a22")], rtol=1e-5)
+        assert np.array_equal(row[8:], r[0]["desc"].astype(float))
+    assert "Done in 1 iterations" in err
+    assert os.path.exists(tmp_path / "time.log")
+
+
+def test_cli_ladder_and_epipolar(pkg, tmp_path):
+    """A multi-step iterations file with out-of-scope sections: MSER step skipped, HessianAffine steps run until
+    minMatches; ver_type 2 switches to DEGENSAC."""
+    err = _run(tmp_path, "iters_ladder.ini", ver_type="2")
+    steps = [pkg.LadderStep.make((1,), 360.0), pkg.LadderStep.make((1, 2, 4), 360.0), pkg.LadderStep.make((1, 2, 4), 120.0)]
+    res, m, _ = _library_run(pkg, steps, use_f=1)
+    got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    assert len(got) == res.n_inliers > 15
+    assert np.allclose(got, m, rtol=1e-5, atol=1e-3)
+    log = (tmp_path / "log.txt").read_text().split()
+    assert int(log[6]) == 1 + res.steps_done            # step numbering counts the skipped MSER step
+    assert "detector MSER is outside this build" in err
