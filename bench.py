@@ -48,6 +48,114 @@ def cpu_baseline(img1, img2, seed):
     return 1.0 / dt, dt, ninl
 
 
+MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 = 2 x the bf16 rate (MI355X_MICROARCH.md MFMA table; measured ceiling >= 3944)
+
+
+def _hard_pair(synth, np, w, h, seed, tilt=6.0):
+    """image 2 = image 1 under a strong tilt (anisotropy `tilt` at 35 degrees) + rotation."""
+    a = synth.texture(w, h, seed)
+    ang = np.deg2rad(35.0)
+    R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+    A = R @ np.diag([1.0, 1.0 / tilt]) @ R.T @ np.array([[np.cos(0.3), -np.sin(0.3)], [np.sin(0.3), np.cos(0.3)]])
+    c = np.array([w / 2.0, h / 2.0])
+    Hm = np.eye(3)
+    Hm[:2, :2] = A
+    Hm[:2, 2] = c - A @ c
+    return a, synth.warp(a, Hm, seed=seed)
+
+
+def other_configs(args):
+    """Measurement of the non-headline configurations (not what the driver runs; same JSON shape)."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    import synth
+    pkg = ge.load_package()
+    if pkg.lib().mods_device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: libmodsgpu has no CPU path")
+    torch.cuda.set_device(0)
+    pkg.ransac_pin_seed(12345)
+    out = {"metric": "image_pairs_per_sec_end_to_end", "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    if args.config == "c4":
+        w = h = 1024
+        pairs = [synth.pair(w, h, seed=4000 + i) for i in range(args.pairs)]
+        dev = [torch.from_numpy(np.stack([a, b])).cuda() for a, b, _ in pairs]
+        params = pkg.PairParams.default()
+        pipe = pkg.Pipeline(0, w, h, params, args.gpu_workers, args.verify_workers)
+
+        def run(n):
+            res, pending = [], 0
+            for i in range(n):
+                if pending >= pipe.capacity - 1:
+                    res.append(pipe.next()[0]); pending -= 1
+                pipe.submit(dev[i % len(dev)].data_ptr(), i); pending += 1
+            while pending:
+                res.append(pipe.next()[0]); pending -= 1
+            return res
+        run(args.warmup)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = run(args.steps)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out.update(value=round(args.steps / dt, 3), ms_per_step=round(dt / args.steps * 1e3, 4),
+                   config={"workload": "1024x1024 pairs, HessianAffine+RootSIFT, LO-RANSAC H (BASELINE configs[3], per-GPU rate)",
+                           "overlap": "%d gpu workers + %d verify workers" % (args.gpu_workers, args.verify_workers),
+                           "keypoints_per_image": list(res[-1].n_described), "mean_inliers": round(sum(r.n_inliers for r in res) / len(res), 1)})
+        pipe.close()
+    elif args.config == "c5":
+        w = h = 4096
+        a, b, _ = synth.pair(w, h, seed=5000) if False else (None, None, None)
+        a = synth.texture(w, h, 5000, blobs=30000)
+        Hm = synth.random_homography(np.random.default_rng(5000 + 104729), w, h)
+        b = synth.warp(a, Hm, seed=5000)
+        t = torch.from_numpy(np.stack([a, b])).cuda()
+        ctx = pkg.Context(0, w, h, 2)
+        params = pkg.PairParams.default()
+        params.ransac.useF = 1
+        for _ in range(args.warmup):
+            pkg.match_pair_dev(ctx, t.data_ptr(), w, h, params)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = [pkg.match_pair_dev(ctx, t.data_ptr(), w, h, params)[0] for _ in range(args.steps)]
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        ctx.timing_enable(["match"]); ctx.timing_reset()
+        last = pkg.match_pair_dev(ctx, t.data_ptr(), w, h, params)[0]
+        mms, mn, _ = ctx.timing_read("match")
+        flops = 2.0 * 2.0 * last.n_described[0] * last.n_described[1] * 128      # two passes over the N x M x 128 contraction
+        ach = flops / (mms * 1e-3) / 1e12 if mms else 0.0
+        out.update(value=round(args.steps / dt, 4), ms_per_step=round(dt / args.steps * 1e3, 3),
+                   config={"workload": "4096x4096 pair, exact FGINN match + DEGENSAC F (BASELINE configs[4])",
+                           "keypoints_per_image": list(last.n_described), "tentatives": last.n_tentatives, "inliers": last.n_inliers,
+                           "ransac_samples": last.ransac_samples, "ransac_lo": last.ransac_lo,
+                           "stage_ms": {"detect_describe": round(last.ms_detect_describe, 2), "match": round(last.ms_match, 2),
+                                        "duplicates": round(last.ms_duplicates, 2), "ransac": round(last.ms_ransac, 2)}},
+                   roofline={"kernel": "match stage (match_nn1_kernel + match_fginn_kernel, i8 MFMA)", "bound": "mfma", "achieved": round(ach, 2),
+                             "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(ach / MFMA_I8_PEAK_TOPS, 4), "traffic": None,
+                             "stage_ms": round(mms, 3)})
+        ctx.close()
+    else:   # c3
+        w, h = 1920, 1080
+        a, b = _hard_pair(synth, np, w, h, 3000)
+        t = torch.from_numpy(np.stack([a, b])).cuda()
+        d = pkg.view_ctx_dims(w, h)
+        ctx = pkg.Context(0, d[0], d[1], 1)
+        rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
+        steps = pkg.iters_mods_steps()
+        for _ in range(args.warmup):
+            pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = [pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2)[0] for _ in range(args.steps)]
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        r = res[-1]
+        out.update(value=round(args.steps / dt, 4), ms_per_step=round(dt / args.steps * 1e3, 3),
+                   config={"workload": "iters_MODS.ini HessianAffine steps on one hard 1920x1080 pair (tilt 6), 1 GPU (BASELINE configs[2])",
+                           "steps_done": r.steps_done, "views": r.n_views, "regions": list(r.n_described), "tentatives": r.n_tentatives,
+                           "inliers": r.n_inliers,
+                           "stage_ms": {"synth_detect_describe": round(r.ms_detect_describe, 2), "match": round(r.ms_match, 2),
+                                        "duplicates": round(r.ms_duplicates, 2), "ransac": round(r.ms_ransac, 2)}})
+        rep1.close(); rep2.close(); ctx.close()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,7 +166,12 @@ def main():
     ap.add_argument("--gpu-workers", type=int, default=2, help="pipeline threads running detect/describe/match (one context each)")
     ap.add_argument("--verify-workers", type=int, default=3, help="pipeline threads running duplicate filter + LO-RANSAC")
     ap.add_argument("--serial", action="store_true", help="no cross-pair overlap: one mods_match_pair_dev call per step")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs[]: c2 = the headline 1080p pair (default, what the driver runs); c3 = view-synthesis "
+                         "ladder on a hard 1080p pair; c4 = 1-MP pairs (throughput); c5 = 4096x4096 pair with DEGENSAC F verification")
     args = ap.parse_args()
+    if args.config != "c2":
+        return other_configs(args)
 
     import numpy as np
     import torch
