@@ -20,8 +20,11 @@
 #include "common.hpp"
 #include "ransac_f_host.hpp"
 #include "ransac_gpu.hpp"
+#include "ransac_dev.hpp"
 #include <ctime>
 #include <cstdlib>
+#include <memory>
+#include <chrono>
 
 namespace mods {
 
@@ -32,29 +35,6 @@ enum { FERR_SAMPSON = 0, FERR_SYM = 1 };
 struct HypF { double f[9]; };
 static_assert(sizeof(HypF) <= HYP_SLOT_BYTES, "hypothesis slot too small");
 
-struct FTerms { double r, a, b; };
-__device__ __forceinline__ FTerms f_terms(const double *u, const double *F) {   // common part of FDs / FDsSym, Ftools.c:94-135
-  const double rxc = F[0] * u[3] + F[3] * u[4] + F[6];
-  const double ryc = F[1] * u[3] + F[4] * u[4] + F[7];
-  const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
-  const double r = (u[0] * rxc + u[1] * ryc + rwc);
-  const double rx = F[0] * u[0] + F[1] * u[1] + F[2];
-  const double ry = F[3] * u[0] + F[4] * u[1] + F[5];
-  FTerms t;
-  t.r = r;
-  t.a = rxc * rxc + ryc * ryc;
-  t.b = rx * rx + ry * ry;
-  return t;
-}
-__device__ __forceinline__ double fds_from(const double *u, const double *F) {
-  const double rxc = F[0] * u[3] + F[3] * u[4] + F[6];
-  const double ryc = F[1] * u[3] + F[4] * u[4] + F[7];
-  const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
-  const double r = (u[0] * rxc + u[1] * ryc + rwc);
-  const double rx = F[0] * u[0] + F[1] * u[1] + F[2];
-  const double ry = F[3] * u[0] + F[4] * u[1] + F[5];
-  return r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
-}
 __device__ __forceinline__ double trunc_quad_f(double epsilon, double thr) {
   if (thr == 0) return 0;
   if (epsilon >= thr * 9 / 4) return 0;
@@ -125,6 +105,67 @@ static bool gpu_score_f(RansacGpu *ws, int len, int n, int err_type, int do_sym,
   ws->launches += 2;
   return true;
 }
+
+// one model over all correspondences in u_dev -> d (and the LSQ weight w for the ex* variants).  grid = ceil(len/256)
+enum { EV_HDS = 0, EV_FDS = 1, EV_FDS_SYM = 2, EV_EXFDS = 3, EV_EXFDS_SYM = 4 };
+struct Model9 { double m[9]; };
+__global__ void __launch_bounds__(256) ransac_eval_kernel(const double *__restrict__ u, int len, Model9 M, int kind, double *__restrict__ d_out,
+                                                          double *__restrict__ w_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= len) return;
+  double uu[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) uu[q] = u[(size_t)i * 6 + q];
+  double d, w = 0;
+  if (kind == EV_HDS) d = hds_dev(uu, M.m);
+  else if (kind == EV_FDS) d = fds_from(uu, M.m);
+  else if (kind == EV_EXFDS) { double ws; d = fds_from(uu, M.m, &ws); w = 1 / sqrt(ws); }
+  else {
+    const FTerms t = f_terms(uu, M.m);
+    if (kind == EV_FDS_SYM) d = t.r * t.r * (t.a + t.b) / (t.a * t.b);
+    else { w = (t.a * t.b) / (t.a + t.b); d = t.r * t.r / w; }
+  }
+  d_out[i] = d;
+  if (kind >= EV_EXFDS) w_out[i] = w;
+}
+
+// PointEval on the GPU: the correspondences are already in ws->u_dev; results come back through the pinned row buffer.
+// Rows live at the end of d_dev/gain_dev?  No: in their own small buffers, so that the candidate rows of the current
+// batch stay intact.
+struct GpuEval : rs::PointEval {
+  RansacGpu *ws;
+  double *d_dev = nullptr, *w_dev = nullptr, *host = nullptr;
+  GpuEval(RansacGpu *ws_, const double *u_, int len_) : rs::PointEval(u_, len_), ws(ws_) {
+    if ((size_t)len_ * 2 > ws->ev_cap) {          // persistent per-thread buffers, grown geometrically
+      (void)hipFree(ws->ev_dev); (void)hipHostFree(ws->ev_host);
+      ws->ev_dev = nullptr; ws->ev_host = nullptr;
+      ws->ev_cap = (size_t)len_ * 4;
+      if (hipMalloc(&ws->ev_dev, sizeof(double) * ws->ev_cap) != hipSuccess || hipHostMalloc(&ws->ev_host, sizeof(double) * ws->ev_cap) != hipSuccess) {
+        set_error("evaluation buffers: allocation failed");
+        ws->ev_cap = 0;
+        return;
+      }
+    }
+    d_dev = ws->ev_dev; w_dev = d_dev + len_; host = ws->ev_host;
+  }
+  bool ok() const { return d_dev != nullptr; }
+  void run(int kind, const double *model, double *d, double *w) {
+    Model9 M;
+    memcpy(M.m, model, sizeof(M.m));
+    hipLaunchKernelGGL(ransac_eval_kernel, dim3((len + 255) / 256), dim3(256), 0, ws->stream, ws->u_dev, len, M, kind, d_dev, w_dev);
+    const size_t n = (size_t)len * (w ? 2 : 1);
+    if (hipMemcpyAsync(host, d_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ws->stream) != hipSuccess ||
+        hipStreamSynchronize(ws->stream) != hipSuccess) { fprintf(stderr, "libmodsgpu: error-function evaluation failed\n"); abort(); }
+    memcpy(d, host, sizeof(double) * len);
+    if (w) memcpy(w, host + len, sizeof(double) * len);
+    ws->launches++;
+  }
+  void hds(const double *H, double *out) override { run(EV_HDS, H, out, nullptr); }
+  void fds(const double *F, double *out) override { run(EV_FDS, F, out, nullptr); }
+  void fds_sym(const double *F, double *out) override { run(EV_FDS_SYM, F, out, nullptr); }
+  void exfds(const double *F, double *p, double *w) override { run(EV_EXFDS, F, p, w); }
+  void exfds_sym(const double *F, double *p, double *w) override { run(EV_EXFDS_SYM, F, p, w); }
+};
 
 // off-plane set of rFtH -> aux_dev
 static bool gpu_upload_aux(RansacGpu *ws, const double *uN, unsigned n) {
@@ -221,7 +262,8 @@ struct FLo {
   rs::GlibcRand *rng;
   rs::HashTable *ht;
   unsigned inlLimit;
-  FDsPtr fds; exFDsPtr exfds;
+  std::function<void(const double *F, double *d)> fds;
+  std::function<void(const double *F, double *d, double *w)> exfds;
 };
 
 // least squares on (a subset of) the inliers, exp_ranF.c:647-668 / 706-727 (__D3__: D3_F_RATIO 1, D3_F_MIN 0)
@@ -249,7 +291,7 @@ static Score lo_iter_f(FLo &L, int *inliers, double th, double ths, int iters, d
   S = rs::inlidxs(L.errs[4], len, th * 2, inliers);   // th*MWM
   lo_lsq(L, inliers, S.I, nullptr, f);
   for (int it = 0; it < iters; it++) {
-    L.exfds(L.u, f, d, w.data(), len);
+    L.exfds(f, d, w.data());
     memcpy(resids + (size_t)it * len, d, len * sizeof(double));
     S = rs::inlidxs(d, len, th, inliers);
     const uint32_t hash = rs::super_fast_hash((const char *)inliers, (int)(S.I * sizeof(*inliers)));
@@ -270,7 +312,7 @@ static Score lo_iter_f(FLo &L, int *inliers, double th, double ths, int iters, d
     lo_lsq(L, inliers, Ss.I, w.data(), f);
     ths -= dth;
   }
-  L.fds(L.u, f, d, len);
+  L.fds(f, d);
   memcpy(resids + (size_t)4 * len, d, len * sizeof(double));
   S = rs::inlidxs(d, len, th, inliers);
   if (rs::score_less(maxS, S)) {
@@ -298,7 +340,7 @@ static Score lo_inner_f(FLo &L, int *inliers, int ninl, double th, double *F, in
   for (int i = 0; i < 10; i++) {
     int *sample = rs::randsubset(*L.rng, inliers, ninl, ssiz);
     rs::u2f(L.u, sample, ssiz, f, L.buffer);
-    L.fds(L.u, f, L.errs[0], len);
+    L.fds(f, L.errs[0]);
     memcpy(resids + (size_t)i * 6 * len, L.errs[0], len * sizeof(double));
     L.errs[4] = L.errs[0];
     S = lo_iter_f(L, intbuff.data(), th, 4 * th, 4, f, ++*iterID, resids + (size_t)i * 6 * len + len);
@@ -313,6 +355,8 @@ static Score lo_inner_f(FLo &L, int *inliers, int ninl, double th, double *F, in
 }
 
 }  // namespace mods
+
+static double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #define F_FATAL() do { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); } while (0)
 
@@ -332,6 +376,9 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
   if (!EXFDS1) EXFDS1 = FDS1 == &FDsSym ? &exFDsSym : &exFDs;
   int err_type = FDS1 == &FDs ? FERR_SAMPSON : FDS1 == &FDsSym ? FERR_SYM : -1;   // -1: foreign error function, evaluated on the host
 
+  const bool prof = getenv("MODS_RANSAC_PROFILE") != nullptr;
+  const double t_begin = prof ? wall_ms() : 0;
+  double t_innerh = 0, t_rfth = 0, t_lo = 0;
   const long pinned = ransac_pinned_seed();
   rs::GlibcRand rng, gen;
   rng.seed((unsigned)(pinned >= 0 ? (time_t)pinned : time(NULL)));   // srand(time(NULL)), exp_ranF.c:832
@@ -342,7 +389,7 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
   std::vector<double> Z((size_t)len * 9), buffer((size_t)len * 18 + 96), err((size_t)len * 4), errorsBest(len), HDsv(len), d_check(len);
   rs::lin_fm(u, Z.data(), pool.data(), len);
   FLo L;
-  L.u = u; L.len = len; L.buffer = buffer.data(); L.rng = &rng; L.ht = &ht; L.inlLimit = inlLimit; L.fds = FDS1; L.exfds = EXFDS1;
+  L.u = u; L.len = len; L.buffer = buffer.data(); L.rng = &rng; L.ht = &ht; L.inlLimit = inlLimit;
   for (int i = 0; i < 4; i++) L.errs[i] = err.data() + (size_t)i * len;
   L.errs[4] = L.errs[3];
   double **errs = L.errs;
@@ -360,6 +407,23 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
   if (!ransac_ws_reserve(ws, len, 96)) F_FATAL();
   if (hipMemcpyAsync(ws->u_dev, u, sizeof(double) * 6 * len, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
       hipStreamSynchronize(ws->stream) != hipSuccess) { set_error("upload of the correspondences failed"); F_FATAL(); }
+  // O(len) evaluations of one model (LO steps, degenerate branch): on the GPU for long lists, where a launch +
+  // a row copy (~30 us) beats the host loop; the library's own error functions only
+  rs::PointEval host_eval(u, len);
+  std::unique_ptr<GpuEval> gpu_eval;
+  if (len >= 2048) { gpu_eval.reset(new GpuEval(ws, u, len)); if (!gpu_eval->ok()) F_FATAL(); }
+  rs::PointEval *ev = gpu_eval ? (rs::PointEval *)gpu_eval.get() : &host_eval;
+  auto eval_fds = [&](const double *Fm, double *dd) {
+    if (FDS1 == &FDs) ev->fds(Fm, dd);
+    else if (FDS1 == &FDsSym) ev->fds_sym(Fm, dd);
+    else FDS1(u, Fm, dd, len);
+  };
+  L.fds = eval_fds;
+  L.exfds = [&](const double *Fm, double *dd, double *ww) {
+    if (EXFDS1 == &exFDs) ev->exfds(Fm, dd, ww);
+    else if (EXFDS1 == &exFDsSym) ev->exfds_sym(Fm, dd, ww);
+    else EXFDS1(u, Fm, dd, ww, len);
+  };
 
   // plane-and-parallax search with its two-point candidates counted on the GPU
   unsigned aux_n = 0;
@@ -378,7 +442,7 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
     double *d = errs[0];
     S = rs::inlidxs(source, len, 4 * th * 2, inliers.data());   // TC*th*MWM
     rs::u2f(u, inliers.data(), (int)S.I, f, buffer.data());
-    FDS1(u, f, d, len);
+    eval_fds(f, d);
     S = rs::inlidxs(d, len, th, inliers.data());
     memcpy(rbase + len, d, len * sizeof(double));
     S = lo_inner_f(L, inliers.data(), (int)S.I, th, f, &iterID, rbase + 2 * len);
@@ -515,24 +579,28 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
         if (rs::score_less(maxSs, S)) {
           maxSs = S;
           if (rs::checksample(f, u7, 3 * th, H)) {
-            rs::dHDs(H, u, (unsigned)len, HDsv.data());
+            ev->hds(H, HDsv.data());
             unsigned I = 0;
             for (int j = 0; j < len; ++j) if (HDsv[j] < th * 3) ++I;
             if (I < 8) break;
             ensure_rng();
-            I = rs::innerH(H, u, (unsigned)len, 16 * th, 10, inl, rng, buffer.data());
+            const double tp0 = prof ? wall_ms() : 0;
+            I = rs::innerH(H, u, (unsigned)len, 16 * th, 10, inl, rng, buffer.data(), ev);
+            if (prof) t_innerh += wall_ms() - tp0;
             if ((int)I > Ihmax) { Ihmax = (int)I; memcpy(Hbest, H, sizeof(Hbest)); }
             if (I > 6) {
               materialise_all();
-              I = rs::rFtH(rng, u, inl, th, H, (unsigned)len, f, upload_offplane, count_pairs);
+              const double tp1 = prof ? wall_ms() : 0;
+              I = rs::rFtH(rng, u, inl, th, H, (unsigned)len, f, upload_offplane, count_pairs, ev);
+              if (prof) t_rfth += wall_ms() - tp1;
               if (I > maxS.I) {
-                FDS1(u, f, errs[3], len);
+                eval_fds(f, errs[3]);
                 maxS.I = I;                       // maxS.J follows below
                 memcpy(F, f, 9 * sizeof(double));
                 new_max = true;
                 d = errs[3];
               } else {
-                FDS1(u, f, errs[i], len);
+                eval_fds(f, errs[i]);
                 d = errs[i];
               }
               double jj = 0;
@@ -556,7 +624,9 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
       if (do_iterate) {
         ensure_rng();
         materialise_all();
+        const double tp2 = prof ? wall_ms() : 0;
         run_lo(errs[4], &new_max);
+        if (prof) t_lo += wall_ms() - tp2;
       }
       if (new_max) {
         const int new_sam = rs::nsamples((int)maxS.I + 1, len, 7, conf);
@@ -584,6 +654,8 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
   }
   data_out[0] = no_sam;
   data_out[1] = iter_cnt;
+  if (prof) fprintf(stderr, "[mods ransacF] len %d samples %d lo %d degen %d | total %.2f ms: innerH %.2f rFtH %.2f LO %.2f\n", len, no_sam, iter_cnt,
+                    degen_cnt, wall_ms() - t_begin, t_innerh, t_rfth, t_lo);
   if (Ih) *Ih = Ihmax;
   return (int)maxS.I;
 }

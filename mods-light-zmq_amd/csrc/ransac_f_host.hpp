@@ -501,6 +501,21 @@ static inline void dHDs(const double *H, const double *u, unsigned len, double *
   for (unsigned i = 0; i < len; i++) Ds[i] = hds_point(u + 6 * i, H);
 }
 
+// Evaluates an error function over ALL correspondences of a run.  The default works on the host;
+// ransac_f.hip substitutes a GPU evaluation for long lists (same operations, same bits), which is what the
+// O(len) passes of the local optimisations and of the degenerate branch cost on large inputs.
+struct PointEval {
+  const double *u = nullptr;
+  int len = 0;
+  PointEval(const double *u_, int len_) : u(u_), len(len_) {}
+  virtual ~PointEval() {}
+  virtual void hds(const double *H, double *out) { dHDs(H, u, (unsigned)len, out); }
+  virtual void fds(const double *F, double *out) { FDs_all(u, F, out, len); }
+  virtual void fds_sym(const double *F, double *out) { FDsSym_all(u, F, out, len); }
+  virtual void exfds(const double *F, double *p, double *w) { exFDs_all(u, F, p, w, len); }
+  virtual void exfds_sym(const double *F, double *p, double *w) { exFDsSym_all(u, F, p, w, len); }
+};
+
 // Hdetect, DegUtils.c:93-156: homography compatible with F through three correspondences
 // (Hartley & Zisserman, "scene planes and homographies"); H stored column-wise like every H here
 static inline void Hdetect(const double *F, const double *u7, const unsigned char *idx3, double *H) {
@@ -578,6 +593,7 @@ struct HLo {
   GlibcRand *rng;
   double *errs[5];
   double *buffer;
+  PointEval *ev;
 };
 static inline Score iterH(HLo &L, int *inliers, double th, double ths, double *H, unsigned inlLimit) {
   const int len = L.len;
@@ -596,7 +612,7 @@ static inline Score iterH(HLo &L, int *inliers, double th, double ths, double *H
   if (maxS.I < 4) return S;
   lsq(maxS.I);
   for (int it = 0; it < 4; ++it) {
-    dHDs(h, L.u, (unsigned)len, d);
+    L.ev->hds(h, d);
     S = inlidxs(d, len, th, inliers);
     Ss = inlidxs(d, len, ths, inliers);
     if (score_less(maxS, S)) {
@@ -610,7 +626,7 @@ static inline Score iterH(HLo &L, int *inliers, double th, double ths, double *H
     lsq(Ss.I);
     ths -= dth;
   }
-  dHDs(h, L.u, (unsigned)len, d);
+  L.ev->hds(h, d);
   S = inlidxs(d, len, th, inliers);
   if (score_less(maxS, S)) {
     maxS = S;
@@ -631,7 +647,7 @@ static inline Score inHrani(HLo &L, int *inliers, int ninl, double th, double *H
   for (int i = 0; i < 10; ++i) {
     int *sample = randsubset(*L.rng, inliers, ninl, ssiz);
     u2h(L.u, sample, ssiz, h, L.buffer);
-    dHDs(h, L.u, (unsigned)L.len, L.errs[0]);
+    L.ev->hds(h, L.errs[0]);
     L.errs[4] = L.errs[0];
     S = iterH(L, intbuff.data(), th, 4 * th, h, inlLimit);
     if (score_less(maxS, S)) {
@@ -644,15 +660,17 @@ static inline Score inHrani(HLo &L, int *inliers, int ninl, double th, double *H
   return maxS;
 }
 // innerH: note that the reference passes its `iters` argument on as the inlier limit of the LSQ steps
-static inline unsigned innerH(double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl, GlibcRand &rng, double *buffer) {
+static inline unsigned innerH(double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl, GlibcRand &rng, double *buffer,
+                              PointEval *ev = nullptr) {
   std::vector<double> err((size_t)len * 4);
   std::vector<int> inliers(len);
+  PointEval host_ev(u, (int)len);
   HLo L;
-  L.u = u; L.len = (int)len; L.rng = &rng; L.buffer = buffer;
+  L.u = u; L.len = (int)len; L.rng = &rng; L.buffer = buffer; L.ev = ev ? ev : &host_ev;
   for (int i = 0; i < 4; i++) L.errs[i] = err.data() + (size_t)i * len;
   L.errs[4] = nullptr;
   double *d = L.errs[0];
-  dHDs(H, u, len, d);
+  L.ev->hds(H, d);
   Score S = inlidxs(d, (int)len, th, inliers.data());
   S = inHrani(L, inliers.data(), (int)S.I, th, H, iters);
   d = L.errs[0];
@@ -666,13 +684,15 @@ static inline unsigned innerH(double *H, const double *u, unsigned len, double t
 
 // ---- plane-and-parallax search ----------------------------------------------------------------------------
 // u2Fit, DegUtils.c:629-697
-static inline unsigned u2Fit(const double *u, unsigned len, double *F, unsigned char *inl, double th, double ths, unsigned iters) {
+static inline unsigned u2Fit(PointEval &ev, double *F, unsigned char *inl, double th, double ths, unsigned iters) {
+  const double *u = ev.u;
+  const unsigned len = (unsigned)ev.len;
   const double dth = (ths - th) / (iters - 1);
   std::vector<int> inlI(len);
   std::vector<double> Ds(len), buffer((size_t)9 * len + 96);
   unsigned no_i;
   for (unsigned iter = 0; iter < iters; ++iter) {
-    FDs_all(u, F, Ds.data(), (int)len);
+    ev.fds(F, Ds.data());
     no_i = 0;
     for (unsigned i = 0; i < len; ++i) {
       if (Ds[i] < ths) { inl[i] = 1; ++no_i; }
@@ -685,7 +705,7 @@ static inline unsigned u2Fit(const double *u, unsigned len, double *F, unsigned 
     u2f(u, inlI.data(), (int)no_i, F, buffer.data());
     ths -= dth;
   }
-  FDs_all(u, F, Ds.data(), (int)len);
+  ev.fds(F, Ds.data());
   no_i = 0;
   for (unsigned i = 0; i < len; ++i) {
     if (Ds[i] < th) { inl[i] = 1; ++no_i; }
@@ -713,8 +733,9 @@ static inline void dual_sample(GlibcRand &rng, const double *uA, unsigned lenA, 
 }
 
 // innerFH, DegUtils.c:476-584: F from sam_sizH on-plane + sam_sizO off-plane correspondences, repCount times
-static inline void innerFH(GlibcRand &rng, const double *uH, unsigned lenH, const double *uO, unsigned lenO, const double *u, unsigned len,
+static inline void innerFH(GlibcRand &rng, const double *uH, unsigned lenH, const double *uO, unsigned lenO, PointEval &ev,
                            double th, unsigned repCount, unsigned sam_sizH, unsigned sam_sizO, double *F, unsigned char *inl) {
+  const unsigned len = (unsigned)ev.len;
   const unsigned ns = sam_sizH + sam_sizO;
   std::vector<unsigned char> v(len);
   std::vector<double> usam((size_t)6 * ns), Ds(len), buffer((size_t)9 * ns + 96);
@@ -727,7 +748,7 @@ static inline void innerFH(GlibcRand &rng, const double *uH, unsigned lenH, cons
   for (unsigned rep = 0; rep < repCount; ++rep) {
     dual_sample(rng, uH, lenH, sam_sizH, uO, lenO, sam_sizO, usam.data());
     u2f(usam.data(), allInl.data(), (int)ns, aF, buffer.data());
-    FDs_all(u, aF, Ds.data(), (int)len);
+    ev.fds(aF, Ds.data());
     unsigned no_i = 0;
     for (unsigned i = 0; i < len; ++i) {
       if (Ds[i] < th) { v[i] = 1; ++no_i; }
@@ -740,7 +761,7 @@ static inline void innerFH(GlibcRand &rng, const double *uH, unsigned lenH, cons
     }
     if (no_i > max_s) {
       max_s = no_i;
-      no_i = u2Fit(u, len, aF, v.data(), th, th * 3, 4);
+      no_i = u2Fit(ev, aF, v.data(), th, th * 3, 4);
       if (max_i < no_i) {
         std::memcpy(inl, v.data(), len);
         std::memcpy(F, aF, sizeof(aF));
@@ -759,7 +780,10 @@ typedef std::function<void(const double *Fs, int k, unsigned *counts)> PairCount
 // 0 when there is not enough data) and writes F only on improvement.
 // `upload_offplane(uN, n)` is called once with the off-plane set before `count` is used.
 static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F,
-                            const std::function<void(const double *uN, unsigned n)> &upload_offplane, const PairCounter &count) {
+                            const std::function<void(const double *uN, unsigned n)> &upload_offplane, const PairCounter &count,
+                            PointEval *ev_in = nullptr) {
+  PointEval host_ev(u, (int)len);
+  PointEval &ev = ev_in ? *ev_in : host_ev;
   const unsigned MAX_SAM = 10000;
   const double conf = .999;
   const unsigned sam_sizH = 6, sam_sizO = 4;
@@ -767,7 +791,7 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
   unsigned nN = 0, nH = 0;
   {
     std::vector<double> Ds(len);
-    dHDs(H, u, len, Ds.data());
+    ev.hds(H, Ds.data());
     for (unsigned i = 0; i < len; ++i) {
       if (Ds[i] > 100 * th) { nhinl[i] = 1; ++nN; }
       else nhinl[i] = 0;
@@ -859,7 +883,7 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
     for (unsigned i = 0; i < nN; ++i)
       if (v[i]) { std::memcpy(&uV[6 * no_i], &uN[6 * i], 6 * sizeof(double)); ++no_i; }
     m_i = no_i;
-    innerFH(rng, uH.data(), nH, uV.data(), no_i, u, len, th, 15, sam_sizH, sam_sizO, aF, inl.data());
+    innerFH(rng, uH.data(), nH, uV.data(), no_i, ev, th, 15, sam_sizH, sam_sizO, aF, inl.data());
     unsigned ninl = 0;
     for (unsigned i = 0; i < len; ++i) if (inl[i]) ++ninl;
     if (ninl > max_i) {

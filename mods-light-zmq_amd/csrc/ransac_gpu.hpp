@@ -18,6 +18,7 @@ struct RansacGpu {
   double *aux_dev = nullptr; size_t aux_cap = 0;        // second point set (off-plane correspondences of rFtH)
   double *cand_dev = nullptr, *cand_host = nullptr;     // two-point candidates of rFtH (9 doubles each) and their counts
   int *candc_dev = nullptr, *candc_host = nullptr; int cand_cap = 0;
+  double *ev_dev = nullptr, *ev_host = nullptr; size_t ev_cap = 0;   // single-model evaluations over all points (d, w rows)
   double score_ms = 0; long launches = 0;
   ~RansacGpu();
 };

@@ -328,16 +328,33 @@ static inline void lin_hgN(const double *u, double *p, const int *inl, int len, 
   }
 }
 
-// cov_mat, utools.c:172-185: Cv = Z^T Z, sums over the rows in order
+// cov_mat, utools.c:172-185: Cv = Z^T Z; every entry is the sum over the rows IN ROW ORDER (that order is part
+// of the result).  The reference walks the rows once per entry; here one walk over the rows feeds all
+// siz*(siz+1)/2 running sums at once - the same additions in the same order per entry, 45x fewer passes
+// over Z for siz = 9 (the least-squares steps on 10^4 inliers are dominated by this loop).
 static inline void cov_mat(double *Cv, const double *Z, int len, int siz) {
-  const int lenM = len * siz;
-  for (int i = 0; i < siz; i++)
-    for (int j = 0; j <= i; j++) {
-      double val = 0;
-      for (int k = 0; k < lenM; k += siz) val += Z[k + i] * Z[k + j];
-      Cv[siz * i + j] = val;
-      Cv[i + siz * j] = val;
-    }
+  double acc[45];
+  if (siz != 9) {     // generic form
+    const int lenM = len * siz;
+    for (int i = 0; i < siz; i++)
+      for (int j = 0; j <= i; j++) {
+        double val = 0;
+        for (int k = 0; k < lenM; k += siz) val += Z[k + i] * Z[k + j];
+        Cv[siz * i + j] = val;
+        Cv[i + siz * j] = val;
+      }
+    return;
+  }
+  for (int q = 0; q < 45; q++) acc[q] = 0;
+  for (int k = 0; k < len; k++) {
+    const double *z = Z + (size_t)k * 9;
+    int q = 0;
+    for (int i = 0; i < 9; i++)
+      for (int j = 0; j <= i; j++) acc[q++] += z[i] * z[j];
+  }
+  int q = 0;
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j <= i; j++) { Cv[9 * i + j] = acc[q]; Cv[i + 9 * j] = acc[q]; q++; }
 }
 
 // denormH, utools.c:76-98
