@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libmodsgpu.so")
+LIB_PATH = os.environ.get("MODS_LIB") or os.path.join(PKG_DIR, "libmodsgpu.so")
 
 MODS_OK = 0
 STAGES = ["blur", "response", "resize", "nms", "localize", "baumberg", "sort", "orient", "describe", "match",

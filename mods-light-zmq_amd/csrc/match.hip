@@ -38,10 +38,17 @@ struct MatchConst {
 // centre coordinates.  grid = ceil(n/4), block = 256 (one wave per region).
 __global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__restrict__ reg, const int *__restrict__ count_ptr,
                                                          int count_fixed, int8_t *__restrict__ desc, int *__restrict__ cvec,
+                                                         int *__restrict__ c2neg, unsigned int *__restrict__ parity,
                                                          double2 *__restrict__ xy, int max_n) {
   int n = count_ptr ? *count_ptr : count_fixed;
   if (n > max_n) n = max_n;
   const int lane = threadIdx.x & 63;
+  // rows of the last tile beyond the list: a seed that can never be a tile maximum (stale or zero entries there
+  // must not shadow the valid rows; -2 * seed still fits an int)
+  if (blockIdx.x == 0 && threadIdx.x < 32) {
+    const int i = n + (int)threadIdx.x;
+    if (i < ((n + 31) & ~31)) c2neg[i] = -(1 << 29);
+  }
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
     const uint8_t *d = reg[i].desc;
     const int v0 = d[lane * 2], v1 = d[lane * 2 + 1];
@@ -51,7 +58,10 @@ __global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__re
     int s1 = (v0 - 128) + (v1 - 128);
     for (int off = 32; off > 0; off >>= 1) { n2 += __shfl_xor(n2, off); s1 += __shfl_xor(s1, off); }
     if (lane == 0) {
-      cvec[i] = n2 - 256 * s1;
+      const int c = n2 - 256 * s1;
+      cvec[i] = c;
+      c2neg[i] = -(c >> 1);       // accumulator seed of the distance tiles: acc = dot - floor(c/2)
+      if (c & 1) atomicOr(&parity[i >> 5], 1u << (i & 31));   // c & 1 of the 32 rows of a tile in one word (zeroed by the caller)
       xy[i] = make_double2(reg[i].x, reg[i].y);
     }
   }
@@ -63,56 +73,105 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// One 32-train x 32-query tile: returns the 16 integer distances of this lane (rows
-// (reg&3) + 8*(reg>>2) + 4*(lane>>5) of the tile, column lane&31).
-__device__ __forceinline__ void tile_distances(const int8_t *__restrict__ tdesc, const int *__restrict__ tc, int tbase,
-                                               const v4i bq[4], int cq, int lane, int d[16]) {
-  const int g = lane >> 5;
-  const int8_t *arow = tdesc + (size_t)(tbase + (lane & 31)) * 128 + g * 16;
-  v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
-    const v4i a = *(const v4i *)(arow + ks * 32);
-    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[ks], acc, 0, 0, 0);
-  }
+// Epilogue design.  A 32x32x128 tile costs 4 MFMAs (~128 clk of the matrix pipe) and leaves 16 results per
+// lane; building 64-bit (distance, index) keys for all of them costs several times that in VALU work.  So:
+//   - the accumulators are seeded with -floor(ct/2) of their train rows (the seed loads land directly in the
+//     C registers), which makes the MFMA result acc = dot - floor(ct/2) and the squared distance
+//     d = cq + (ct & 1) - 2*acc: the nearest trains of a tile are simply its LARGEST accumulators;
+//   - the fast path takes the maximum of the 16 accumulators (eight 3-input max) and compares -2*max with the
+//     lane's threshold on d - cq (pass 1: best distance so far; pass 2: max(D*, best distance >= D* so far));
+//     -2*acc <= d - cq, so a tile that cannot matter never passes, and only passing tiles take the exact path;
+//   - train tiles stream in index order, so after the first few hundred trains a lane passes with probability
+//     ~32/T per tile.
+// A wave keeps QB query blocks resident (QB x 4 B-operand registers): every A tile fetched from L1/L2 feeds
+// QB x 4 MFMAs.
+constexpr int MATCH_QB = 2;
+
+__device__ __forceinline__ int acc_max16(const v16i &acc) {
+  int m = max(max(acc[0], acc[1]), acc[2]);
+  m = max(max(m, acc[3]), acc[4]);
+  m = max(max(m, acc[5]), acc[6]);
+  m = max(max(m, acc[7]), acc[8]);
+  m = max(max(m, acc[9]), acc[10]);
+  m = max(max(m, acc[11]), acc[12]);
+  m = max(max(m, acc[13]), acc[14]);
+  return max(m, acc[15]);
+}
+// accumulator seed of one tile for this lane: rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ v16i acc_seed(const int *__restrict__ c2n, int tbase, int g) {
+  v16i acc;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int4 ct = *(const int4 *)(tc + tbase + 8 * q + 4 * g);
-    d[4 * q + 0] = cq + ct.x - 2 * acc[4 * q + 0];
-    d[4 * q + 1] = cq + ct.y - 2 * acc[4 * q + 1];
-    d[4 * q + 2] = cq + ct.z - 2 * acc[4 * q + 2];
-    d[4 * q + 3] = cq + ct.w - 2 * acc[4 * q + 3];
+    const int4 c = *(const int4 *)(c2n + tbase + 8 * q + 4 * g);
+    acc[4 * q + 0] = c.x; acc[4 * q + 1] = c.y; acc[4 * q + 2] = c.z; acc[4 * q + 3] = c.w;
   }
+  return acc;
 }
 
-// Pass 1: nearest neighbour key (d << 32 | t) per query.  grid = (ceil(n_q/128), splits), block 256.
+// Pass 1: nearest neighbour key (d << 32 | t) per query.  grid = (ceil(n_q/(128*QB)), splits), block 256.
 __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                         const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
+                                                        const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                         unsigned long long *__restrict__ best) {
+  constexpr int QB = MATCH_QB;
   const int lane = threadIdx.x & 63, g = lane >> 5;
-  const int j = blockIdx.x * 128 + (threadIdx.x >> 6) * 32 + (lane & 31);
-  const int jc = j < k.n_q ? j : k.n_q - 1;
-  v4i bq[4];
+  const int jbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
+  v4i bq[QB][4];
+  int cq[QB], thr[QB];
+  unsigned long long mine[QB];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) bq[ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
-  const int cq = qc[jc] - 4194304;
+  for (int b = 0; b < QB; b++) {
+    const int j = jbase + 32 * b;
+    const int jc = j < k.n_q ? j : k.n_q - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) bq[b][ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
+    cq[b] = qc[jc] - 4194304;
+    thr[b] = 0x7fffffff;
+    mine[b] = ~0ull;
+  }
   const int n_tiles = (k.n_t + 31) / 32;
   const int t0 = blockIdx.y * k.tiles_per_split;
   const int t1 = min(n_tiles, t0 + k.tiles_per_split);
-  unsigned long long mine = ~0ull;
   for (int tt = t0; tt < t1; tt++) {
-    int d[16];
-    tile_distances(tdesc, tc, tt * 32, bq, cq, lane, d);
+    const int tbase = tt * 32;
+    const int8_t *arow = tdesc + (size_t)(tbase + (lane & 31)) * 128 + g * 16;
+    v4i a[4];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int t = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      const unsigned long long key = ((unsigned long long)(unsigned int)d[r] << 32) | (unsigned int)t;
-      if (t < k.n_t && key < mine) mine = key;
+    for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(arow + ks * 32);
+    const unsigned int par = tpar[tt];   // wave-uniform: ct & 1 of the 32 train rows
+    v16i acc[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++) acc[b] = acc_seed(tc2n, tbase, g);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+      for (int b = 0; b < QB; b++) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], bq[b][ks], acc[b], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+      const int amax = acc_max16(acc[b]);
+      if (-2 * amax < thr[b]) {        // some train of this tile may be nearer than the best so far
+        // d - cq = (ct & 1) - 2*acc: the nearest train of the tile is among the rows that hold the maximum
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          if (acc[b][r] != amax) continue;
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+          const int t = tbase + row;
+          const int dpr = (int)((par >> row) & 1u) - 2 * amax;             // exact
+          const unsigned long long key = ((unsigned long long)(unsigned int)(dpr + cq[b]) << 32) | (unsigned int)t;
+          if (t < k.n_t && dpr < thr[b] && key < mine[b]) mine[b] = key;   // ties: the earlier index stays
+        }
+        if (mine[b] != ~0ull) thr[b] = (int)(mine[b] >> 32) - cq[b];
+      }
+      thr[b] = min(thr[b], __shfl_xor(thr[b], 32));   // the two half-waves hold the same 32 queries (different train rows)
     }
   }
-  const unsigned long long other = shfl_xor_u64(mine, 32);
-  if (other < mine) mine = other;
-  if (g == 0 && j < k.n_q && mine != ~0ull) atomicMin(&best[j], mine);
+#pragma unroll
+  for (int b = 0; b < QB; b++) {
+    const unsigned long long other = shfl_xor_u64(mine[b], 32);
+    if (other < mine[b]) mine[b] = other;
+    const int j = jbase + 32 * b;
+    if (g == 0 && j < k.n_q && mine[b] != ~0ull) atomicMin(&best[j], mine[b]);
+  }
 }
 
 struct QueryMid {        // per query state between the passes
@@ -155,113 +214,174 @@ __global__ __launch_bounds__(256) void match_mid_kernel(MatchConst k, const unsi
   key_ge[j] = ~0ull; key_lt[j] = ~0ull; n_lt[j] = 0; bad[j] = 0;
 }
 
-// Pass 2: FGINN reductions.  Same tiling as pass 1.
+// Pass 2: FGINN reductions.  Same tiling and the same two-speed epilogue as pass 1: a tile is examined exactly
+// only when one of its partial distances lies below max(D*, smallest distance >= D* found so far).
 __global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                           const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
+                                                          const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                           const double2 *__restrict__ txy, const QueryMid *__restrict__ mid,
                                                           unsigned long long *__restrict__ key_ge, unsigned long long *__restrict__ key_lt,
                                                           int *__restrict__ n_lt, int *__restrict__ bad) {
+  constexpr int QB = MATCH_QB;
   const int lane = threadIdx.x & 63, g = lane >> 5;
-  const int j = blockIdx.x * 128 + (threadIdx.x >> 6) * 32 + (lane & 31);
-  const int jc = j < k.n_q ? j : k.n_q - 1;
-  v4i bq[4];
+  const int jbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
+  v4i bq[QB][4];
+  int cq[QB], thr[QB], cnt[QB], isbad[QB], i0[QB], dstar[QB];
+  double x0[QB], y0[QB];
+  unsigned long long kge[QB], klt[QB];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) bq[ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
-  const int cq = qc[jc] - 4194304;
-  const QueryMid m = mid[jc];
+  for (int b = 0; b < QB; b++) {
+    const int j = jbase + 32 * b;
+    const int jc = j < k.n_q ? j : k.n_q - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) bq[b][ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
+    cq[b] = qc[jc] - 4194304;
+    const QueryMid m = mid[jc];
+    i0[b] = m.i0; dstar[b] = m.dstar; x0[b] = m.x0; y0[b] = m.y0;
+    thr[b] = 0x7fffffff;          // until a distance >= D* has been seen every tile is examined
+    kge[b] = ~0ull; klt[b] = ~0ull; cnt[b] = 0; isbad[b] = 0;
+  }
   const int n_tiles = (k.n_t + 31) / 32;
   const int t0 = blockIdx.y * k.tiles_per_split;
   const int t1 = min(n_tiles, t0 + k.tiles_per_split);
-  unsigned long long kge = ~0ull, klt = ~0ull;
-  int cnt = 0, isbad = 0;
   for (int tt = t0; tt < t1; tt++) {
-    int d[16];
-    tile_distances(tdesc, tc, tt * 32, bq, cq, lane, d);
+    const int tbase = tt * 32;
+    const int8_t *arow = tdesc + (size_t)(tbase + (lane & 31)) * 128 + g * 16;
+    v4i a[4];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int t = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      if (t >= k.n_t || t == m.i0) continue;
-      const unsigned long long key = ((unsigned long long)(unsigned int)d[r] << 32) | (unsigned int)t;
-      if (d[r] >= m.dstar) {
-        if (key < kge) kge = key;
-      } else {
-        cnt++;
-        if (key < klt) klt = key;
-        const double2 p = txy[t];
-        const double dx = m.x0 - p.x, dy = m.y0 - p.y;
-        if (dx * dx + dy * dy > k.contr_sq) isbad = 1;
+    for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(arow + ks * 32);
+    const unsigned int par = tpar[tt];   // wave-uniform: ct & 1 of the 32 train rows
+    v16i acc[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++) acc[b] = acc_seed(tc2n, tbase, g);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+      for (int b = 0; b < QB; b++) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], bq[b][ks], acc[b], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+      if (-2 * acc_max16(acc[b]) < thr[b]) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          if (-2 * acc[b][r] >= thr[b]) continue;                 // d - cq >= -2*acc
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+          const int t = tbase + row;
+          if (t >= k.n_t || t == i0[b]) continue;
+          const int dpr = (int)((par >> row) & 1u) - 2 * acc[b][r];
+          if (!(dpr < thr[b])) continue;
+          const int d = dpr + cq[b];
+          const unsigned long long key = ((unsigned long long)(unsigned int)d << 32) | (unsigned int)t;
+          if (d >= dstar[b]) {
+            if (key < kge[b]) kge[b] = key;
+          } else {
+            cnt[b]++;
+            if (key < klt[b]) klt[b] = key;
+            const double2 p = txy[t];
+            const double dx = x0[b] - p.x, dy = y0[b] - p.y;
+            if (dx * dx + dy * dy > k.contr_sq) isbad[b] = 1;
+          }
+        }
+        // everything below D* always counts; at or above D* only a smaller distance than the best one matters
+        // (an equal distance at a later index loses the (d, t) order)
+        if (kge[b] != ~0ull) thr[b] = max(dstar[b], (int)(kge[b] >> 32)) - cq[b];
       }
+      thr[b] = min(thr[b], __shfl_xor(thr[b], 32));
     }
   }
-  unsigned long long o = shfl_xor_u64(kge, 32); if (o < kge) kge = o;
-  o = shfl_xor_u64(klt, 32); if (o < klt) klt = o;
-  cnt += __shfl_xor(cnt, 32);
-  isbad |= __shfl_xor(isbad, 32);
-  if (g == 0 && j < k.n_q) {
-    if (kge != ~0ull) atomicMin(&key_ge[j], kge);
-    if (klt != ~0ull) atomicMin(&key_lt[j], klt);
-    if (cnt) atomicAdd(&n_lt[j], cnt);
-    if (isbad) atomicOr(&bad[j], 1);
+#pragma unroll
+  for (int b = 0; b < QB; b++) {
+    unsigned long long o = shfl_xor_u64(kge[b], 32); if (o < kge[b]) kge[b] = o;
+    o = shfl_xor_u64(klt[b], 32); if (o < klt[b]) klt[b] = o;
+    cnt[b] += __shfl_xor(cnt[b], 32);
+    isbad[b] |= __shfl_xor(isbad[b], 32);
+    const int j = jbase + 32 * b;
+    if (g == 0 && j < k.n_q) {
+      if (kge[b] != ~0ull) atomicMin(&key_ge[j], kge[b]);
+      if (klt[b] != ~0ull) atomicMin(&key_lt[j], klt[b]);
+      if (cnt[b]) atomicAdd(&n_lt[j], cnt[b]);
+      if (isbad[b]) atomicOr(&bad[j], 1);
+    }
   }
 }
 
-// Decision + order-preserving compaction into the tentative list.  grid = 1, block = 1024.
+// Decision + order-preserving compaction into the tentative list, in two launches over ceil(n_q/1024) blocks:
+// the first counts the accepted queries of every block, the second adds up the counts of the blocks before it
+// and writes its own tentatives at that offset (query order is the output order of the reference's loop).
+__device__ __forceinline__ bool fginn_accept(const MatchConst &k, int j, const QueryMid *__restrict__ mid,
+                                             const unsigned long long *__restrict__ key_ge, const unsigned long long *__restrict__ key_lt,
+                                             const int *__restrict__ n_lt, const int *__restrict__ bad, mods_tentative *tc) {
+  if (j >= k.n_q) return false;
+  const int K = min(k.nn, k.n_t);
+  const unsigned long long kg = key_ge[j];
+  const int c = n_lt[j];
+  if (bad[j] || kg == ~0ull || c + 1 > K - 1) return false;
+  const QueryMid m = mid[j];
+  const unsigned long long k2 = c > 0 ? key_lt[j] : kg;
+  const int d2 = (int)(kg >> 32);
+  tc->q = j; tc->t = m.i0; tc->t_bad = (int)(unsigned int)kg; tc->t_2nd = (int)(unsigned int)k2;
+  tc->d1 = (float)m.d0; tc->d2 = (float)d2; tc->d2nd = (float)(int)(k2 >> 32); tc->pad = 0;
+  tc->ratio = sqrt((double)((float)m.d0 / (float)d2));
+  return true;
+}
+
+__global__ __launch_bounds__(1024) void match_emit_count_kernel(MatchConst k, const QueryMid *__restrict__ mid,
+                                                                const unsigned long long *__restrict__ key_ge,
+                                                                const unsigned long long *__restrict__ key_lt, const int *__restrict__ n_lt,
+                                                                const int *__restrict__ bad, int *__restrict__ block_counts) {
+  mods_tentative tc;
+  const bool emit = fginn_accept(k, blockIdx.x * 1024 + threadIdx.x, mid, key_ge, key_lt, n_lt, bad, &tc);
+  const int c = __syncthreads_count(emit ? 1 : 0);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
+}
+
 __global__ __launch_bounds__(1024) void match_emit_kernel(MatchConst k, const QueryMid *__restrict__ mid,
                                                           const unsigned long long *__restrict__ key_ge,
                                                           const unsigned long long *__restrict__ key_lt, const int *__restrict__ n_lt,
                                                           const int *__restrict__ bad, const double2 *__restrict__ qxy,
                                                           const double2 *__restrict__ txy, const mods_region *__restrict__ qreg,
-                                                          const mods_region *__restrict__ treg, mods_tentative *__restrict__ out,
-                                                          double *__restrict__ u6, double *__restrict__ laf, int *__restrict__ out_count,
-                                                          int max_out) {
+                                                          const mods_region *__restrict__ treg, const int *__restrict__ block_counts,
+                                                          mods_tentative *__restrict__ out, double *__restrict__ u6, double *__restrict__ laf,
+                                                          int *__restrict__ out_count, int max_out) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) s_base = 0;
+  // offset of this block = accepted queries of all earlier blocks
+  int part = 0;
+  for (int q = tid; q < (int)blockIdx.x; q += 1024) part += block_counts[q];
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if (lane == 0) s_wave[wv] = part;
   __syncthreads();
-  const int K = min(k.nn, k.n_t);
-  for (int base = 0; base < k.n_q; base += 1024) {
-    const int j = base + tid;
-    bool emit = false;
-    mods_tentative tc;
-    if (j < k.n_q) {
-      const unsigned long long kg = key_ge[j];
-      const int c = n_lt[j];
-      if (!bad[j] && kg != ~0ull && c + 1 <= K - 1) {
-        const QueryMid m = mid[j];
-        const unsigned long long k2 = c > 0 ? key_lt[j] : kg;
-        const int d2 = (int)(kg >> 32);
-        tc.q = j; tc.t = m.i0; tc.t_bad = (int)(unsigned int)kg; tc.t_2nd = (int)(unsigned int)k2;
-        tc.d1 = (float)m.d0; tc.d2 = (float)d2; tc.d2nd = (float)(int)(k2 >> 32); tc.pad = 0;
-        tc.ratio = sqrt((double)((float)m.d0 / (float)d2));
-        emit = true;
-      }
+  if (tid == 0) { int t = 0; for (int q = 0; q < 16; q++) t += s_wave[q]; s_base = t; }
+  __syncthreads();
+  const int base = s_base;
+  __syncthreads();
+  mods_tentative tc;
+  const bool emit = fginn_accept(k, blockIdx.x * 1024 + tid, mid, key_ge, key_lt, n_lt, bad, &tc);
+  const unsigned long long mm = __ballot(emit);
+  if (lane == 0) s_wave[wv] = __popcll(mm);
+  __syncthreads();
+  int off = base;
+  for (int q = 0; q < wv; q++) off += s_wave[q];
+  if (emit) {
+    const int slot = off + __popcll(mm & ((1ull << lane) - 1ull));
+    if (slot < max_out) {
+      out[slot] = tc;
+      // correspondence in the layout LORANSACFiltering hands to degensac (matching.cpp:691-713)
+      const double2 a = qxy[tc.q], bpt = txy[tc.t];
+      double *u = u6 + (size_t)slot * 6;
+      u[0] = a.x; u[1] = a.y; u[2] = 1.; u[3] = bpt.x; u[4] = bpt.y; u[5] = 1.;
+      // local affine frames of both regions for the LAF checks (matching.cpp:192-308)
+      double *f = laf + (size_t)slot * 14;
+      const mods_region &r1 = qreg[tc.q], &r2 = treg[tc.t];
+      f[0] = r1.x; f[1] = r1.y; f[2] = r1.a11; f[3] = r1.a12; f[4] = r1.a21; f[5] = r1.a22; f[6] = r1.s;
+      f[7] = r2.x; f[8] = r2.y; f[9] = r2.a11; f[10] = r2.a12; f[11] = r2.a21; f[12] = r2.a22; f[13] = r2.s;
     }
-    const unsigned long long mm = __ballot(emit);
-    if (lane == 0) s_wave[wv] = __popcll(mm);
-    __syncthreads();
-    int off = s_base;
-    for (int q = 0; q < wv; q++) off += s_wave[q];
-    if (emit) {
-      const int slot = off + __popcll(mm & ((1ull << lane) - 1ull));
-      if (slot < max_out) {
-        out[slot] = tc;
-        // correspondence in the layout LORANSACFiltering hands to degensac (matching.cpp:691-713)
-        const double2 a = qxy[tc.q], bpt = txy[tc.t];
-        double *u = u6 + (size_t)slot * 6;
-        u[0] = a.x; u[1] = a.y; u[2] = 1.; u[3] = bpt.x; u[4] = bpt.y; u[5] = 1.;
-        // local affine frames of both regions for the LAF checks (matching.cpp:192-308)
-        double *f = laf + (size_t)slot * 14;
-        const mods_region &r1 = qreg[tc.q], &r2 = treg[tc.t];
-        f[0] = r1.x; f[1] = r1.y; f[2] = r1.a11; f[3] = r1.a12; f[4] = r1.a21; f[5] = r1.a22; f[6] = r1.s;
-        f[7] = r2.x; f[8] = r2.y; f[9] = r2.a11; f[10] = r2.a12; f[11] = r2.a21; f[12] = r2.a22; f[13] = r2.s;
-      }
-    }
-    __syncthreads();
-    if (tid == 0) { int t = 0; for (int q = 0; q < 16; q++) t += s_wave[q]; s_base += t; }
-    __syncthreads();
   }
-  if (tid == 0) *out_count = s_base;
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {   // total = offset of the last block + its own count
+    int t = base;
+    for (int q = 0; q < 16; q++) t += s_wave[q];
+    *out_count = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -271,18 +391,18 @@ int match_ensure_buffers(mods_ctx *ctx) {
   if (ctx->m_desc) return MODS_OK;
   const size_t n = match_pad(ctx);
   MODS_HIP_CHECK(hipMalloc(&ctx->m_desc, 2 * n * 128));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_c, 2 * n * sizeof(int)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_c, (4 * n + 2 * (n / 32 + 2)) * sizeof(int)));   // c of queries, trains; -floor(c/2) of both; parity words of both
   MODS_HIP_CHECK(hipMalloc(&ctx->m_u6, n * 6 * sizeof(double)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_laf, n * 14 * sizeof(double)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_regs, 2 * (size_t)ctx->max_cand * sizeof(mods_region)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_xy, 2 * n * sizeof(double2)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_u64, 3 * n * sizeof(unsigned long long)));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_int, 2 * n * sizeof(int)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_int, (2 * n + n / 1024 + 2) * sizeof(int)));   // n_lt, bad, per-block counts of the compaction
   MODS_HIP_CHECK(hipMalloc(&ctx->m_mid, n * sizeof(QueryMid)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, n * sizeof(mods_tentative)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_count, sizeof(int)));
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_desc, 0, 2 * n * 128, ctx->stream));
-  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_c, 0, 2 * n * sizeof(int), ctx->stream));
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_c, 0, 4 * n * sizeof(int), ctx->stream));
   return MODS_OK;
 }
 
@@ -301,23 +421,29 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   if (n_q == 0 || n_t == 0) return MODS_OK;
   const size_t n = match_pad(ctx);
   int8_t *qd = ctx->m_desc, *td = ctx->m_desc + n * 128;
-  int *qc = ctx->m_c, *tc = ctx->m_c + n;
+  int *qc = ctx->m_c, *tc = ctx->m_c + n, *qc2 = ctx->m_c + 2 * n, *tc2 = ctx->m_c + 3 * n;
+  unsigned int *qpar = (unsigned int *)(ctx->m_c + 4 * n), *tpar = qpar + n / 32 + 2;
+  MODS_HIP_CHECK(hipMemsetAsync(qpar, 0, sizeof(unsigned int) * 2 * (n / 32 + 2), ctx->stream));
   double2 *qxy = (double2 *)ctx->m_xy, *txy = (double2 *)ctx->m_xy + n;
   unsigned long long *best = ctx->m_u64, *key_ge = ctx->m_u64 + n, *key_lt = ctx->m_u64 + 2 * n;
   int *n_lt = ctx->m_int, *bad = ctx->m_int + n;
   StageScope ts(ctx, MODS_STAGE_MATCH);
-  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qxy, ctx->max_cand);
-  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, txy, ctx->max_cand);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
   MODS_HIP_CHECK(hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * n_q, ctx->stream));
   const int n_tiles = (n_t + 31) / 32;
-  const int qblocks = (n_q + 127) / 128;
-  int splits = std::max(1, std::min(n_tiles, 2048 / std::max(1, qblocks)));
+  const int qblocks = (n_q + 128 * MATCH_QB - 1) / (128 * MATCH_QB);
+  static const int target_blocks = getenv("MODS_MATCH_BLOCKS") ? atoi(getenv("MODS_MATCH_BLOCKS")) : 2048;
+  int splits = std::max(1, std::min(n_tiles, target_blocks / std::max(1, qblocks)));
   k.tiles_per_split = (n_tiles + splits - 1) / splits;
   splits = (n_tiles + k.tiles_per_split - 1) / k.tiles_per_split;
-  hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, best);
+  hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, tc2, tpar, best);
   hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best, txy, (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
-  hipLaunchKernelGGL(match_fginn_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, txy, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
-  hipLaunchKernelGGL(match_emit_kernel, dim3(1), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, ctx->m_tent, ctx->m_u6, ctx->m_laf, ctx->m_count, ctx->max_cand);
+  hipLaunchKernelGGL(match_fginn_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, tc2, tpar, txy, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
+  const int eblocks = (n_q + 1023) / 1024;
+  int *block_counts = (int *)(ctx->m_int + 2 * n);
+  hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, ctx->m_tent, ctx->m_u6, ctx->m_laf, ctx->m_count, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }

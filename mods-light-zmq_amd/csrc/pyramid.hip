@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
   const int x0 = txi * FB_TW, y0 = tyi * FB_TH;
   const int tc = tid & 31;                    // 4-pixel column group
   const int x4 = x0 + 4 * tc;
-  const bool fast_x = (x4 - 4 * R4 >= 0) && (x4 + 4 * R4 + 3 <= w - 1);   // whole window inside the row
+  const bool fast_x = ((w & 3) == 0) && (x4 - 4 * R4 >= 0) && (x4 + 4 * R4 + 3 <= w - 1);   // aligned rows, whole window inside the row
   auto load_window = [&](int ly, float *win) {
     int gy = y0 - R + ly;
     gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
@@ -206,48 +206,61 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
       }
     }
   };
-  float win[4 * NV], nxt[4 * NV];
-  int ly = tid >> 5;
-  if (ly < ROWS) load_window(ly, win);
-  for (; ly < ROWS; ly += 8) {
-    const bool more = ly + 8 < ROWS;
-    if (more) load_window(ly + 8, nxt);     // in flight while this row is reduced
-    float o[4];
+  // Row pass.  A thread owns 4 columns and every 8th row of the (TH + 2R)-row strip; DEPTH row windows are in flight
+  // (a ring of register windows, statically indexed after unrolling).
+  constexpr int NI = (ROWS + 7) / 8;
+  constexpr int DEPTH = 1;   // measured: 2 or 4 windows in flight are slower (22-29 us vs 13 us per 1080p-pair plane)
+  float win[DEPTH][4 * NV];
+  const int ly0 = tid >> 5;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      float s = taps.t[0] * win[D + u];
+  for (int i = 0; i < DEPTH; i++)
+    if (ly0 + 8 * i < ROWS) load_window(ly0 + 8 * i, win[i]);
 #pragma unroll
-      for (int j = 1; j < N; j++) s += taps.t[j] * win[D + u + j];
-      o[u] = s;
+  for (int i = 0; i < NI; i++) {
+    const int ly = ly0 + 8 * i;
+    if (ly < ROWS) {
+      const float *wv = win[i % DEPTH];
+      float o[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        float s = taps.t[0] * wv[D + u];
+#pragma unroll
+        for (int j = 1; j < N; j++) s += taps.t[j] * wv[D + u + j];
+        o[u] = s;
+      }
+      *(float4 *)(smem + ly * FB_TW + 4 * tc) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    *(float4 *)(smem + ly * FB_TW + 4 * tc) = make_float4(o[0], o[1], o[2], o[3]);
-    if (more) {
-#pragma unroll
-      for (int e = 0; e < 4 * NV; e++) win[e] = nxt[e];
-    }
+    if (i + DEPTH < NI && ly + 8 * DEPTH < ROWS) load_window(ly + 8 * DEPTH, win[i % DEPTH]);
   }
   __syncthreads();
+  // Column pass.  A thread makes RPT vertically adjacent outputs of its 4 columns: the 2R + RPT strip rows it
+  // needs are read from LDS once into registers (instead of 2R + 1 reads per output).
   if (x4 < w) {
-    for (int k = 0; k < FB_TH / 8; k++) {
-      const int ly = (tid >> 5) * (FB_TH / 8) + k;
-      const int gy = y0 + ly;
-      if (gy >= h) break;
-      const float *p = smem + (ly + R) * FB_TW + 4 * tc;
-      const float4 c = *(const float4 *)p;
-      float4 s = make_float4(taps.t[R] * c.x, taps.t[R] * c.y, taps.t[R] * c.z, taps.t[R] * c.w);
+    constexpr int RPT = FB_TH / 8;
+    const int lyb = (tid >> 5) * RPT;
+    float4 col[2 * R + RPT];
 #pragma unroll
-      for (int j = 1; j <= R; j++) {
-        const float4 a = *(const float4 *)(p + j * FB_TW), b = *(const float4 *)(p - j * FB_TW);
-        const float t = taps.t[R + j];
-        s.x += t * (a.x + b.x); s.y += t * (a.y + b.y); s.z += t * (a.z + b.z); s.w += t * (a.w + b.w);
-      }
-      float *d = dst + (size_t)gy * w + x4;
-      if (x4 + 3 < w && ((w & 3) == 0)) *(float4 *)d = s;
-      else {
-        d[0] = s.x;
-        if (x4 + 1 < w) d[1] = s.y;
-        if (x4 + 2 < w) d[2] = s.z;
-        if (x4 + 3 < w) d[3] = s.w;
+    for (int q = 0; q < 2 * R + RPT; q++) col[q] = *(const float4 *)(smem + (lyb + q) * FB_TW + 4 * tc);
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int gy = y0 + lyb + k;
+      if (gy < h) {
+        const float4 c = col[k + R];
+        float4 s = make_float4(taps.t[R] * c.x, taps.t[R] * c.y, taps.t[R] * c.z, taps.t[R] * c.w);
+#pragma unroll
+        for (int j = 1; j <= R; j++) {
+          const float4 a = col[k + R + j], b = col[k + R - j];
+          const float t = taps.t[R + j];
+          s.x += t * (a.x + b.x); s.y += t * (a.y + b.y); s.z += t * (a.z + b.z); s.w += t * (a.w + b.w);
+        }
+        float *d = dst + (size_t)gy * w + x4;
+        if (x4 + 3 < w && ((w & 3) == 0)) *(float4 *)d = s;
+        else {
+          d[0] = s.x;
+          if (x4 + 1 < w) d[1] = s.y;
+          if (x4 + 2 < w) d[2] = s.z;
+          if (x4 + 3 < w) d[3] = s.w;
+        }
       }
     }
   }
@@ -334,9 +347,11 @@ static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
 
 template <int R>
 static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, const BlurTaps &taps) {
+#define BLUR_TH_BIG 32   // measured on 1080p pairs: 32-row tiles (4 workgroups per CU, phases of different tiles overlap) beat 64-row tiles by ~15 %
   const int tiles64 = ((w + FB_TW - 1) / FB_TW) * ((h + 63) / 64) * n_img;
-  if (tiles64 >= 384) {   // at least ~1.5 tiles per CU: tall tiles (halo overhead (64+2R)/64)
-    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 64>), dim3(tiles64), dim3(256), sizeof(float) * (size_t)(64 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
+  if (tiles64 >= 384) {   // at least ~1.5 tiles per CU: large planes: 32-row tiles
+    const int tilesB = ((w + FB_TW - 1) / FB_TW) * ((h + BLUR_TH_BIG - 1) / BLUR_TH_BIG) * n_img;
+    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG>), dim3(tilesB), dim3(256), sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
   } else {                // small planes: short tiles, more workgroups, shorter per-thread row chains
     const int tiles16 = ((w + FB_TW - 1) / FB_TW) * ((h + 15) / 16) * n_img;
     hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16>), dim3(tiles16), dim3(256), sizeof(float) * (size_t)(16 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
@@ -345,7 +360,7 @@ static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w,
 
 static int blur_with_slot(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, int slot, int n) {
   const int r = n / 2;
-  if (r >= 1 && r <= 8 && (w & 3) == 0 && ctx->taps_host_n[slot] == n) {
+  if (r >= 1 && r <= 8 && ctx->taps_host_n[slot] == n) {
     BlurTaps taps;
     for (int i = 0; i < 17; i++) taps.t[i] = i < n ? ctx->taps_host[slot][i] : 0.f;
     StageScope ts(ctx, MODS_STAGE_BLUR, 8.0 * w * h * n_img);

@@ -24,6 +24,8 @@
 #include <ctime>
 #include <cstdlib>
 #include <mutex>
+#include <unistd.h>
+#include <sys/syscall.h>
 
 namespace mods {
 
@@ -89,6 +91,10 @@ __global__ void __launch_bounds__(64) ransac_gain_kernel(const double *__restric
 
 RansacGpu::~RansacGpu() {
   if (device < 0) return;
+  // The workspace is thread-local.  A worker thread returns its HBM when it ends; the main thread's copy is
+  // destroyed during process exit, when the HIP runtime (or a profiler layered on it) may already be shutting
+  // down and a hipFree can block forever - the process is going away, so nothing is released there.
+  if ((long)getpid() == (long)syscall(SYS_gettid)) return;
   (void)hipSetDevice(device);
   (void)hipFree(u_dev); (void)hipFree(hyp_dev); (void)hipHostFree(hyp_host); (void)hipFree(d_dev); (void)hipFree(gain_dev);
   (void)hipFree(counts_dev); (void)hipFree(J_dev); (void)hipHostFree(counts_host); (void)hipHostFree(J_host);
