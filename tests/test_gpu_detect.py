@@ -85,3 +85,24 @@ def test_empty_image(gpu_ctx):
     assert len(gpu_ctx.detect_hessian_affine(img)) == 0
     tiny = synth.texture(12, 12, seed=1)          # below 2*border+2: no octave at all
     assert len(gpu_ctx.detect_hessian_affine(tiny)) == 0
+
+
+@pytest.mark.parametrize("w,h", [(13, 13), (12, 40), (14, 14), (30, 17), (31, 57), (129, 65), (801, 603)])
+def test_small_and_odd_sizes_end_to_end(pkg, w, h):
+    """Sizes around the octave cut-off (rows, cols > 12, pyramid.cpp:520), non-multiples of every tile size:
+    detector + orientation + descriptor identical to the oracle (mostly empty lists; must not crash or overrun)."""
+    import orc
+    import synth
+    img = synth.texture(w, h, seed=w * 1000 + h, blobs=max(4, w * h // 300))
+    ctx = pkg.Context(0, max(w, 16), max(h, 16), 1)
+    keys = ctx.detect_hessian_affine(img)
+    want = orc.detect_hessian_affine(img)
+    assert len(keys) == len(want)
+    for f in ("x", "y", "s", "a11", "a12", "a21", "a22", "response"):
+        assert np.array_equal(keys[f], want[f]), f
+    wr, _ = orc.detect_describe(img)
+    regs = ctx.orient_describe(img, keys)
+    assert len(regs) == len(wr)
+    if len(wr):
+        assert np.array_equal(regs["desc"], wr["desc"]) and np.array_equal(regs["x"], wr["x"])
+    ctx.close()

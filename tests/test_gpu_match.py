@@ -59,6 +59,35 @@ def test_match_clusters_rank_cap(gpu_ctx):
         _assert_tents_equal(got, want)
 
 
+def test_match_ties_and_parity(gpu_ctx):
+    """Descriptors from a tiny alphabet: many trains at exactly the same distance (index order decides), odd and even
+    norms mixed (the matcher ranks by a half-precision seed and settles parity on the exact path), shrinking lists
+    (stale entries of an earlier, larger call stay behind the end of the lists)."""
+    rng = np.random.default_rng(77)
+    for nq, nt in ((700, 1900), (257, 95), (64, 33)):
+        q, t = _rand_regions(nq, 1000 + nq), _rand_regions(nt, 2000 + nt)
+        q["desc"] = rng.integers(0, 3, (nq, 128)).astype(np.uint8) * 40
+        t["desc"] = rng.integers(0, 3, (nt, 128)).astype(np.uint8) * 40
+        t["desc"][::7, :3] += 1                      # odd norms on a subset
+        t["desc"][nt // 2:] = t["desc"][: nt - nt // 2]   # every train of the first half has an exact twin later in the list
+        for ratio in (0.8, 0.999):
+            got, _ = gpu_ctx.match_fginn(q, t, ratio, 1e9)     # no contradiction cut: deep neighbour walks
+            want = orc.match_fginn(q, t, ratio, 1e9)
+            _assert_tents_equal(got, want)
+
+
+def test_match_large_lists(gpu_ctx, pkg):
+    """Lists of the size of a view-synthesis bank (more than one query block per wave, many train splits)."""
+    ctx = pkg.Context(0, 2048, 2048, 1)      # capacity 524288 regions
+    q, t = _rand_regions(9000, 5), _rand_regions(23000, 6)
+    t["desc"][:4000] = np.clip(q["desc"][:4000].astype(np.int16) + np.random.default_rng(1).integers(-3, 4, (4000, 128)), 0, 255).astype(np.uint8)
+    got, _ = ctx.match_fginn(q, t, 0.8)
+    want = orc.match_fginn(q, t, 0.8)
+    _assert_tents_equal(got, want)
+    assert len(got) > 3000
+    ctx.close()
+
+
 def test_match_empty(gpu_ctx):
     q, t = _rand_regions(10, 1), _rand_regions(0, 2)
     assert len(gpu_ctx.match_fginn(q, t)[0]) == 0
