@@ -159,12 +159,13 @@ def other_configs(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=160)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gpu-workers", type=int, default=2, help="pipeline threads running detect/describe/match (one context each)")
-    ap.add_argument("--verify-workers", type=int, default=3, help="pipeline threads running duplicate filter + LO-RANSAC")
+    ap.add_argument("--verify-workers", type=int, default=4, help="pipeline threads running duplicate filter + LO-RANSAC")
+    ap.add_argument("--pairs-per-batch", type=int, default=4, help="pairs a GPU worker pushes through detect/describe as one batch of launches")
     ap.add_argument("--serial", action="store_true", help="no cross-pair overlap: one mods_match_pair_dev call per step")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs[]: c2 = the headline 1080p pair (default, what the driver runs); c3 = view-synthesis "
@@ -202,7 +203,7 @@ def main():
     pkg.lib().mods_ransac_set_device(device)
     params = pkg.PairParams.default()
     pkg.ransac_pin_seed(12345)
-    pipe = None if args.serial else pkg.Pipeline(device, W, H, params, args.gpu_workers, args.verify_workers)
+    pipe = None if args.serial else pkg.Pipeline(device, W, H, params, args.gpu_workers, args.verify_workers, args.pairs_per_batch)
 
     def step(i):
         res, _ = pkg.match_pair_dev(ctx, pairs_dev[i % len(pairs_dev)].data_ptr(), W, H, params)
@@ -233,14 +234,29 @@ def main():
     dt = time.perf_counter() - t0
     inl = sum(r.n_inliers for r in results)
     stage_ms = [sum(getattr(r, f) for r in results) for f in ("ms_detect_describe", "ms_match", "ms_duplicates", "ms_ransac")]
-    # roofline leg: the pyramid blur launches of the same workload, bracketed by HIP events on the
-    # context's stream (a separate short pass so that event recording does not perturb the timed region)
-    ctx.timing_enable(["blur"])
-    ctx.timing_reset()
-    for i in range(min(args.steps, 8)):
-        step(i)
-    blur_ms, blur_n, blur_bytes = ctx.timing_read("blur")
-    ctx.timing_enable([])
+    # roofline leg: the pyramid blur launches of the same workload in the same batching, bracketed by HIP events on
+    # the worker's stream (a separate short pass with ONE gpu worker: event recording does not perturb the timed region
+    # and a second stream does not stretch the kernels that are being timed)
+    if pipe is None:
+        ctx.timing_enable(["blur"]); ctx.timing_reset()
+        for i in range(min(args.steps, 8)):
+            step(i)
+        blur_ms, blur_n, blur_bytes = ctx.timing_read("blur")
+        ctx.timing_enable([])
+    else:
+        rp = pkg.Pipeline(device, W, H, params, 1, args.verify_workers, args.pairs_per_batch)
+        nroof = max(args.pairs_per_batch * 4, 8)
+        for i in range(nroof):      # warm this pipeline's context
+            rp.submit(pairs_dev[i % len(pairs_dev)].data_ptr(), i)
+        for i in range(nroof):
+            rp.next()
+        rp.timing_enable(["blur"])
+        for i in range(nroof):
+            rp.submit(pairs_dev[i % len(pairs_dev)].data_ptr(), i)
+        for i in range(nroof):
+            rp.next()
+        blur_ms, blur_n, blur_bytes = rp.timing_read("blur")
+        rp.close()
     last = step(0)
 
     if world > 1:
@@ -257,7 +273,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "single 1920x1080 pair, HessianAffine+RootSIFT, 1 synth iteration (BASELINE configs[1])",
                        "pairs_per_step": 1, "image": "1920x1080",
-                       "overlap": "serial" if pipe is None else "%d gpu workers + %d verify workers" % (args.gpu_workers, args.verify_workers), "matcher": "linear (exact), FGINN 0.8",
+                       "overlap": "serial" if pipe is None else "%d gpu workers x %d pairs per batch + %d verify workers" % (args.gpu_workers, args.pairs_per_batch, args.verify_workers), "matcher": "linear (exact), FGINN 0.8",
                        "verification": "LO-RANSAC homography, Sampson, th 4 px", "parallelism": "pairs sharded, %d rank(s)" % world,
                        "keypoints_per_image": list(last.n_described), "tentatives": last.n_tentatives,
                        "inliers_last_pair": last.n_inliers, "mean_inliers": round(inl / args.steps, 1),

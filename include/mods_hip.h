@@ -369,6 +369,14 @@ int mods_dev_download(void *dst_host, const void *src_dev, size_t bytes);
 typedef struct mods_pipeline mods_pipeline;
 int mods_pipeline_create(int device, int w, int h, const mods_pair_params *par, int gpu_workers, int verify_workers,
                          mods_pipeline **out);
+/* pairs_per_batch > 1: a GPU worker takes up to that many queued pairs through detect/describe as one batch of
+ * launches (same results; larger launches, fewer of them per pair) */
+int mods_pipeline_create_ex(int device, int w, int h, const mods_pair_params *par, int gpu_workers, int verify_workers,
+                            int pairs_per_batch, mods_pipeline **out);
+int mods_pipeline_capacity(const mods_pipeline *p);    /* pairs that may be in flight before submit blocks */
+/* HIP-event timing of the workers' contexts (sums over them); enable/read while nothing is in flight */
+int mods_pipeline_timing_enable(mods_pipeline *p, int stage_mask);
+int mods_pipeline_timing_read(mods_pipeline *p, int stage, double *total_ms, int *launches, double *bytes);
 int mods_pipeline_submit(mods_pipeline *p, const float *img_dev, long tag);
 int mods_pipeline_next(mods_pipeline *p, mods_pair_result *res, long *tag);
 void mods_pipeline_destroy(mods_pipeline *p);

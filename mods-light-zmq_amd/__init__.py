@@ -599,11 +599,12 @@ class Pipeline:
     """mods_pipeline_*: GPU workers (detect/describe/match) overlapped with verify workers (duplicate
     filter + LO-RANSAC) across pairs; results in submission order."""
 
-    def __init__(self, device, w, h, params=None, gpu_workers=1, verify_workers=1):
+    def __init__(self, device, w, h, params=None, gpu_workers=1, verify_workers=1, pairs_per_batch=1):
         self.params = params or PairParams.default()
         self.h = C.c_void_p()
-        _check(lib().mods_pipeline_create(device, w, h, C.byref(self.params), gpu_workers, verify_workers, C.byref(self.h)))
-        self.capacity = 2 * (gpu_workers + verify_workers)
+        _check(lib().mods_pipeline_create_ex(device, w, h, C.byref(self.params), gpu_workers, verify_workers, pairs_per_batch,
+                                             C.byref(self.h)))
+        self.capacity = lib().mods_pipeline_capacity(self.h)
 
     def submit(self, dev_ptr, tag=0):
         _check(lib().mods_pipeline_submit(self.h, C.c_void_p(dev_ptr), C.c_long(tag)))
@@ -612,6 +613,17 @@ class Pipeline:
         res, tag = PairResult(), C.c_long()
         _check(lib().mods_pipeline_next(self.h, C.byref(res), C.byref(tag)))
         return res, tag.value
+
+    def timing_enable(self, stages):
+        mask = 0
+        for s in stages:
+            mask |= 1 << STAGES.index(s)
+        _check(lib().mods_pipeline_timing_enable(self.h, mask))
+
+    def timing_read(self, stage):
+        ms, n, by = C.c_double(), C.c_int(), C.c_double()
+        _check(lib().mods_pipeline_timing_read(self.h, STAGES.index(stage), C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value
 
     def close(self):
         if self.h:

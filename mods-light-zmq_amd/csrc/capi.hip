@@ -645,6 +645,52 @@ int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int str
   return MODS_OK;
 }
 
+// GPU half of up to batch/2 pairs in one pass: the images of all pairs go through the pyramid / detector /
+// describe kernels as ONE batch (launches n times larger, the many tiny launches of the small octaves amortised
+// over n pairs), then every pair is matched on its own.  img_dev[i]: [2][h][w] fp32 of pair i.
+int mods_pairs_gpu_stage(mods_ctx *c, const float *const *img_dev, int n_pairs, int w, int h, const mods_pair_params *par,
+                         mods_pair_result **res, std::vector<mods_tentative> **tent, std::vector<double> **u6, std::vector<double> **laf) {
+  if (!c || !img_dev || !par || !res || n_pairs < 1) { set_error("match_pairs: null argument"); return MODS_E_ARG; }
+  if (n_pairs == 1) return mods_pair_gpu_stage(c, img_dev[0], w, h, w, par, res[0], tent[0], u6[0], laf[0]);
+  if (c->batch < 2 * n_pairs) { set_error("match_pairs: context batch %d < %d images", c->batch, 2 * n_pairs); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  const size_t plane2 = (size_t)2 * w * h;
+  const int n_img = 2 * n_pairs;
+  for (int i = 0; i < n_pairs; i++) {
+    memset(res[i], 0, sizeof(*res[i]));
+    for (int q = 0; q < 9; q++) res[i]->H[q] = -1;
+    MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev + plane2 * i, img_dev[i], sizeof(float) * plane2, hipMemcpyDeviceToDevice, c->stream));
+  }
+  std::vector<int> nd(n_img), nr(n_img);
+  int rc;
+  const double t0 = now_ms();
+  if ((rc = mods_detect_describe_dev(c, c->input_dev, n_img, w, h, w, &par->det, &par->desc, nd.data(), nr.data()))) return rc;
+  const double t1 = now_ms();
+  for (int i = 0; i < n_pairs; i++) {
+    const double tm0 = now_ms();
+    mods_pair_result *r = res[i];
+    r->n_detected[0] = nd[2 * i]; r->n_detected[1] = nd[2 * i + 1];
+    r->n_described[0] = nr[2 * i]; r->n_described[1] = nr[2 * i + 1];
+    r->ms_detect_describe = (t1 - t0) / n_pairs;
+    if ((rc = match_run(c, c->regions_dev + (size_t)(2 * i) * c->max_cand, nr[2 * i], c->regions_dev + (size_t)(2 * i + 1) * c->max_cand,
+                        nr[2 * i + 1], par->fginn_ratio, par->contradDist, par->nn))) return rc;
+    int n = 0;
+    MODS_HIP_CHECK(hipMemcpyAsync(&n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    r->n_tentatives = n;
+    if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
+    tent[i]->resize(n); u6[i]->resize((size_t)n * 6); laf[i]->resize((size_t)n * 14);
+    if (n > 0) {
+      MODS_HIP_CHECK(hipMemcpyAsync(tent[i]->data(), c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(hipMemcpyAsync(u6[i]->data(), c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(hipMemcpyAsync(laf[i]->data(), c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    r->ms_match = now_ms() - tm0;
+  }
+  return MODS_OK;
+}
+
 // Host-driven half: duplicate filtering + LO-RANSAC (hypotheses scored on `device`) + checks.
 int mods_pair_verify_stage(int device, const mods_pair_params *par, mods_pair_result *res, std::vector<mods_tentative> *tent,
                            std::vector<double> *u6, std::vector<double> *laf, double *matches_out, int max_matches) {

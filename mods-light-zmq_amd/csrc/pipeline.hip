@@ -13,6 +13,9 @@ extern "C" int mods_ctx_create_ex(int device, int max_w, int max_h, int batch, i
 extern "C" int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
                                    mods_pair_result *res, std::vector<mods_tentative> *tent, std::vector<double> *u6,
                                    std::vector<double> *laf);
+extern "C" int mods_pairs_gpu_stage(mods_ctx *c, const float *const *img_dev, int n_pairs, int w, int h, const mods_pair_params *par,
+                                    mods_pair_result **res, std::vector<mods_tentative> **tent, std::vector<double> **u6,
+                                    std::vector<double> **laf);
 extern "C" int mods_pair_verify_stage(int device, const mods_pair_params *par, mods_pair_result *res, std::vector<mods_tentative> *tent,
                                       std::vector<double> *u6, std::vector<double> *laf, double *matches_out, int max_matches);
 
@@ -40,6 +43,7 @@ struct mods_pipeline {
   std::condition_variable cv_gpu, cv_verify, cv_done, cv_space;
   std::deque<std::shared_ptr<mods::Job>> q_gpu, q_verify, q_order;
   int max_in_flight = 8;
+  int pairs_per_batch = 1;        // pairs a GPU worker pushes through detect/describe in one batch of launches
   bool stop = false;
 };
 
@@ -48,20 +52,27 @@ using namespace mods;
 static void gpu_worker(mods_pipeline *p, mods_ctx *ctx) {
   (void)hipSetDevice(p->device);
   for (;;) {
-    std::shared_ptr<Job> j;
+    std::vector<std::shared_ptr<Job>> js;
     {
       std::unique_lock<std::mutex> lk(p->mu);
       p->cv_gpu.wait(lk, [&] { return p->stop || !p->q_gpu.empty(); });
       if (p->stop && p->q_gpu.empty()) return;
-      j = p->q_gpu.front(); p->q_gpu.pop_front();
+      // whatever is queued, up to the batch size: no waiting for a full batch
+      while (!p->q_gpu.empty() && (int)js.size() < p->pairs_per_batch) { js.push_back(p->q_gpu.front()); p->q_gpu.pop_front(); }
     }
-    j->rc = mods_pair_gpu_stage(ctx, j->img, p->w, p->h, p->w, &p->par, &j->res, &j->tent, &j->u6, &j->laf);
-    if (j->rc) j->err = mods_last_error();
+    const int n = (int)js.size();
+    std::vector<const float *> imgs(n);
+    std::vector<mods_pair_result *> res(n);
+    std::vector<std::vector<mods_tentative> *> tent(n);
+    std::vector<std::vector<double> *> u6(n), laf(n);
+    for (int i = 0; i < n; i++) { imgs[i] = js[i]->img; res[i] = &js[i]->res; tent[i] = &js[i]->tent; u6[i] = &js[i]->u6; laf[i] = &js[i]->laf; }
+    const int rc = mods_pairs_gpu_stage(ctx, imgs.data(), n, p->w, p->h, &p->par, res.data(), tent.data(), u6.data(), laf.data());
+    const std::string err = rc ? mods_last_error() : "";
     {
       std::lock_guard<std::mutex> lk(p->mu);
-      p->q_verify.push_back(j);
+      for (auto &j : js) { j->rc = rc; j->err = err; p->q_verify.push_back(j); }
     }
-    p->cv_verify.notify_one();
+    p->cv_verify.notify_all();
   }
 }
 
@@ -89,15 +100,48 @@ static void verify_worker(mods_pipeline *p) {
 
 extern "C" {
 
+int mods_pipeline_create_ex(int device, int w, int h, const mods_pair_params *par, int gpu_workers, int verify_workers,
+                            int pairs_per_batch, mods_pipeline **out);
+
 int mods_pipeline_create(int device, int w, int h, const mods_pair_params *par, int gpu_workers, int verify_workers,
                          mods_pipeline **out) {
-  if (!par || !out || gpu_workers < 1 || verify_workers < 1 || gpu_workers > 8 || verify_workers > 32) { set_error("pipeline: bad arguments"); return MODS_E_ARG; }
+  return mods_pipeline_create_ex(device, w, h, par, gpu_workers, verify_workers, 1, out);
+}
+
+int mods_pipeline_capacity(const mods_pipeline *p) { return p ? p->max_in_flight : 0; }
+
+// per-kernel HIP-event timing of the GPU workers' contexts (see mods_ctx_timing_*); call while nothing is in flight
+int mods_pipeline_timing_enable(mods_pipeline *p, int stage_mask) {
+  if (!p) return MODS_E_ARG;
+  for (auto *c : p->ctxs) { int rc = mods_ctx_timing_enable(c, stage_mask); if (rc) return rc; rc = mods_ctx_timing_reset(c); if (rc) return rc; }
+  return MODS_OK;
+}
+int mods_pipeline_timing_read(mods_pipeline *p, int stage, double *total_ms, int *launches, double *bytes) {
+  if (!p) return MODS_E_ARG;
+  double ms = 0, by = 0; int n = 0;
+  for (auto *c : p->ctxs) {
+    double m1 = 0, b1 = 0; int n1 = 0;
+    const int rc = mods_ctx_timing_read(c, stage, &m1, &n1, &b1);
+    if (rc) return rc;
+    ms += m1; by += b1; n += n1;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (bytes) *bytes = by;
+  return MODS_OK;
+}
+
+int mods_pipeline_create_ex(int device, int w, int h, const mods_pair_params *par, int gpu_workers, int verify_workers,
+                            int pairs_per_batch, mods_pipeline **out) {
+  if (!par || !out || gpu_workers < 1 || verify_workers < 1 || gpu_workers > 8 || verify_workers > 32 || pairs_per_batch < 1 ||
+      pairs_per_batch > 16) { set_error("pipeline: bad arguments"); return MODS_E_ARG; }
   std::unique_ptr<mods_pipeline> p(new mods_pipeline());
   p->device = device; p->w = w; p->h = h; p->par = *par;
-  p->max_in_flight = 2 * (gpu_workers + verify_workers);
+  p->pairs_per_batch = pairs_per_batch;
+  p->max_in_flight = 2 * gpu_workers * pairs_per_batch + 2 * verify_workers;
   for (int i = 0; i < gpu_workers; i++) {
     mods_ctx *c = nullptr;
-    int rc = mods_ctx_create_ex(device, w, h, 2, 1, &c);   // non-blocking streams: the workers overlap on the GPU
+    int rc = mods_ctx_create_ex(device, w, h, 2 * pairs_per_batch, 1, &c);   // non-blocking streams: the workers overlap on the GPU
     if (rc) { for (auto *q : p->ctxs) mods_ctx_destroy(q); return rc; }
     p->ctxs.push_back(c);
   }

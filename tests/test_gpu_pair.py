@@ -93,3 +93,36 @@ def test_pair_end_to_end_epipolar(pkg, planar):
         assert (da < 3).sum() > 20 and (db < 3).sum() > 20
         assert ((da < 3) | (db < 3)).mean() > 0.9
     ctx.close()
+
+
+@pytest.mark.parametrize("gpu_workers,verify_workers,ppb", [(1, 1, 1), (2, 3, 1), (2, 2, 4), (1, 2, 3)])
+def test_pipeline_equals_serial(pkg, gpu_workers, verify_workers, ppb):
+    """The overlapped / batched pair pipeline returns, in submission order, exactly what one
+    mods_match_pair_dev call per pair returns (same pinned seed)."""
+    import torch
+    w, h = 640, 480
+    pairs = [synth.pair(w, h, seed=40 + i) for i in range(5)]
+    dev = [torch.from_numpy(np.stack([a, b])).cuda() for a, b, _ in pairs]
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    pkg.ransac_pin_seed(7)
+    ctx = pkg.Context(0, w, h, 2)
+    want = [pkg.match_pair_dev(ctx, d.data_ptr(), w, h, par)[0] for d in dev]
+    pipe = pkg.Pipeline(0, w, h, par, gpu_workers, verify_workers, ppb)
+    order = [0, 1, 2, 3, 4, 2, 0, 4, 1, 3, 3]
+    got = []
+    pending = 0
+    for i, k in enumerate(order):          # submit blocks once `capacity` pairs are in flight: drain as we go
+        if pending >= pipe.capacity - 1:
+            got.append(pipe.next()); pending -= 1
+        pipe.submit(dev[k].data_ptr(), 100 + i); pending += 1
+    while pending:
+        got.append(pipe.next()); pending -= 1
+    for i, k in enumerate(order):
+        res, tag = got[i]
+        assert tag == 100 + i
+        exp = want[k]
+        for f in ("n_tentatives", "n_unique", "n_inliers", "ransac_samples", "ransac_lo", "ransac_rejects"):
+            assert getattr(res, f) == getattr(exp, f), (f, i)
+        assert list(res.n_described) == list(exp.n_described) and list(res.H) == list(exp.H)
+    pipe.close(); ctx.close()
