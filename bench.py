@@ -244,19 +244,19 @@ def main():
         blur_ms, blur_n, blur_bytes = ctx.timing_read("blur")
         ctx.timing_enable([])
     else:
-        rp = pkg.Pipeline(device, W, H, params, 1, args.verify_workers, args.pairs_per_batch)
-        nroof = max(args.pairs_per_batch * 4, 8)
-        for i in range(nroof):      # warm this pipeline's context
-            rp.submit(pairs_dev[i % len(pairs_dev)].data_ptr(), i)
-        for i in range(nroof):
-            rp.next()
-        rp.timing_enable(["blur"])
-        for i in range(nroof):
-            rp.submit(pairs_dev[i % len(pairs_dev)].data_ptr(), i)
-        for i in range(nroof):
-            rp.next()
-        blur_ms, blur_n, blur_bytes = rp.timing_read("blur")
-        rp.close()
+        # what a GPU worker launches for one batch: the images of pairs_per_batch pairs in one detect/describe pass
+        nb = max(1, args.pairs_per_batch)
+        batch_t = torch.cat([pairs_dev[i % len(pairs_dev)] for i in range(nb)], dim=0).contiguous()
+        bctx = pkg.Context(device, W, H, 2 * nb)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            bctx.detect_describe_dev(batch_t.data_ptr(), 2 * nb, W, H, params.det, params.desc)
+        bctx.timing_enable(["blur"]); bctx.timing_reset()
+        for _ in range(6):
+            bctx.detect_describe_dev(batch_t.data_ptr(), 2 * nb, W, H, params.det, params.desc)
+        blur_ms, blur_n, blur_bytes = bctx.timing_read("blur")
+        bctx.close()
+        del batch_t
     last = step(0)
 
     if world > 1:
@@ -283,8 +283,8 @@ def main():
             "roofline": {"kernel": "gauss_blur_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC passes committed in profiles/r01_pmc_blur_traffic.csv
-                         # (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, mean over the 29 blur launches of a pair)
-                         "traffic": 7493921,
+                         # (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, mean over the blur launches of the same batching: 8 images per launch)
+                         "traffic": 27618208,
                          "launches": blur_n, "mean_launch_us": round(blur_ms / max(blur_n, 1) * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(blur_bytes / max(blur_n, 1), 1)},
         }
