@@ -634,8 +634,8 @@ struct SiftLds {   // carve of the dynamic LDS of the SIFT kernels
   __device__ SiftLds(float *base, int ps) {
     const int pp = ps * ps, ppa = (pp + 3) & ~3;
     patch = base;
-    g = patch + ppa;
-    px = (float2 *)(g + ppa);
+    px = (float2 *)(patch + ppa);
+    g = (float *)px;                       // photometric normalisation scratch: dead before the gradients are written
     w = (float *)(px + ppa);
     vec = (double *)(((uintptr_t)(w + 4 * ps) + 7) & ~(uintptr_t)7);
     red = vec + 128;
@@ -647,11 +647,11 @@ struct SiftLds {   // carve of the dynamic LDS of the SIFT kernels
 };
 static size_t sift_lds_bytes(int ps) {
   const size_t ppa = ((size_t)ps * ps + 3) & ~(size_t)3;
-  return sizeof(float) * (2 * ppa + 2 * ppa + 4 * ps + 4) + sizeof(double) * (130 + 256) + sizeof(unsigned short) * ppa + ppa + 32;
+  return sizeof(float) * (ppa + 2 * ppa + 4 * ps + 4) + sizeof(double) * (130 + 256) + sizeof(unsigned short) * ppa + ppa + 32;
 }
 
 // grid = (N, n_img), block = 256: patches -> descriptors
-__global__ __launch_bounds__(256, 4) void sift_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
+__global__ __launch_bounds__(256, 5) void sift_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
                                                    const int *__restrict__ reg_count, const float *__restrict__ mask,
                                                    const SiftTab *__restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
