@@ -88,3 +88,24 @@ def test_loransac_rejects_small_sets_without_a_gpu(pkg):
 def test_struct_layouts(pkg):
     assert pkg.REGION_DTYPE.itemsize == 208 and pkg.AFFKEY_DTYPE.itemsize == 88 and pkg.TENT_DTYPE.itemsize == 40
     assert orc.REGION_DTYPE == pkg.REGION_DTYPE and orc.TENT_DTYPE == pkg.TENT_DTYPE
+
+
+def test_view_geometry_and_schedule_host_side(pkg):
+    """mods_view_geometry / mods_view_schedule are host-only: checked here against the committed fixture
+    (generated with the oracle) and against the view counts of the reference's MODS ladder (11 + 20)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "views.npz"))
+    for row in g["geometry"]:
+        w, h, tilt, phi, zoom = int(row[0]), int(row[1]), row[2], row[3], row[4]
+        v = pkg.view_geometry(w, h, tilt, phi, zoom, 0.2)
+        got = [v.identity, v.w_rot, v.h_rot, v.w_new, v.h_new, v.ksize_x, v.ksize_y, v.sigma_x, v.sigma_y] + list(v.H) + list(v.warpRot) + list(v.warpTilt)
+        assert got == list(row[5:]), (w, h, tilt, phi, zoom)
+    hist = []
+    steps = pkg.iters_mods_steps()
+    first = pkg.view_schedule(steps[0], hist)
+    second = pkg.view_schedule(steps[1], hist)
+    assert len(first) == 11 and len(second) == 20 and len(hist) == 31
+    assert first[0] == (1.0, 1.0, 0.0) and all(t in (1, 2, 4, 6, 8) for _, t, _ in hist)
+    assert len({(z, t, round(p, 9)) for z, t, p in hist}) == 31        # no view is scheduled twice
+    neg = pkg.view_schedule(pkg.LadderStep.make((3,), -360.0), [])     # negative density: vertical + horizontal tilt, no rotation
+    assert neg == [(1.0, -3.0, 0.0), (1.0, 3.0, 0.0)]

@@ -77,6 +77,35 @@ def test_reference_degensac_reproduces_its_fixtures():
         assert [r["I"], r["samples"], r["lo"], r["rej"]] == list(g["stat_" + str(key)])
 
 
+@pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_reference_degensac_f_reproduces_its_fixtures():
+    g = np.load(os.path.join(GOLD, "ransac_f.npz"))
+    for key in g["keys"][::4]:
+        parts = str(key).split("_")
+        ci, seed, sym, err = int(parts[0]), int(parts[-1]), int(parts[-2]), "_".join(parts[1:-2])
+        r = refdeg.ransac_f(g["u_%d" % ci], 16.0, max_sam=20000, err=err, sym_check=sym, seed_time=seed)
+        assert np.array_equal(r["inl"], g["inl_" + str(key)])
+        assert [r["I"], r["samples"], r["lo"], r["Ih"]] == list(g["stat_" + str(key)])
+        nz = np.flatnonzero(r["hist"])
+        assert np.array_equal(nz, g["hist_" + str(key)]) and np.array_equal(r["hist"][nz], g["histv_" + str(key)])
+
+
+def test_view_fixtures():
+    """View-synthesis geometry, one synthesised view and its region list against the committed fixtures."""
+    import math
+    g = np.load(os.path.join(GOLD, "views.npz"))
+    for row in g["geometry"]:
+        w, h, tilt, phi, zoom = int(row[0]), int(row[1]), row[2], row[3], row[4]
+        v = orc.view_geometry(w, h, tilt, phi, zoom, 0.2)
+        got = [v.identity, v.w_rot, v.h_rot, v.w_new, v.h_new, v.ksize_x, v.ksize_y, v.sigma_x, v.sigma_y] + list(v.H) + list(v.warpRot) + list(v.warpTilt)
+        assert got == list(row[5:]), (w, h, tilt, phi, zoom)
+    img = g["img"].astype(np.float32)
+    px, geom = orc.synth_view(img, 4.0, math.pi / 3, 1.0, 0.2, 1)
+    assert np.array_equal(px, g["view_4_60"])
+    reg, _, _ = orc.detect_describe_view(px, np.array(geom.H), 240, 180)
+    assert np.array_equal(reg, g["view_regions"]) and len(reg) > 10
+
+
 def test_resize_dims_follow_half_to_even():
     for (w, h), (dw, dh) in {(1920, 1080): (960, 540), (240, 135): (120, 68), (30, 17): (15, 8), (135, 67): (68, 34)}.items():
         out = orc.resize_half(np.zeros((h, w), np.float32))

@@ -81,3 +81,18 @@ def test_ransac_f_properties(pkg):
     assert a["I"] == int(a["inl"].sum())
     assert (a["inl"].astype(bool) & true_in).sum() > 0.95 * true_in.sum()
     assert abs(np.linalg.det(F.reshape(3, 3))) < 1e-9 * np.linalg.norm(F) ** 3
+
+
+def test_ransac_f_matches_golden_fixtures(pkg):
+    """The committed outputs of the reference's exp_ransacFcustom (tests/golden/ransac_f.npz, tools/gen_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ransac_f.npz"))
+    for key in g["keys"]:
+        parts = str(key).split("_")
+        ci, seed, sym, err = int(parts[0]), int(parts[-1]), int(parts[-2]), "_".join(parts[1:-2])
+        got = pkg.ransac_f(g["u_%d" % ci], 16.0, max_sam=20000, err=err, sym_check=sym, seed_time=seed)
+        assert [got["I"], got["samples"], got["lo"], got["Ih"]] == list(g["stat_" + str(key)]), key
+        assert np.array_equal(got["inl"], g["inl_" + str(key)]), key
+        nz = np.flatnonzero(got["hist"])
+        assert np.array_equal(nz, g["hist_" + str(key)]) and np.array_equal(got["hist"][nz], g["histv_" + str(key)]), key
+        assert np.max(np.abs(_normed(got["F"]) - _normed(g["F_" + str(key)]))) < 1e-7, key
