@@ -104,7 +104,6 @@ def other_configs(args):
         pipe.close()
     elif args.config == "c5":
         w = h = 4096
-        a, b, _ = synth.pair(w, h, seed=5000) if False else (None, None, None)
         a = synth.texture(w, h, 5000, blobs=30000)
         Hm = synth.random_homography(np.random.default_rng(5000 + 104729), w, h)
         b = synth.warp(a, Hm, seed=5000)

@@ -398,8 +398,7 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
   int no_sam = 0, iter_cnt = 0, degen_cnt = 0, iterID = 0, Ihmax = 0;
   unsigned non_degen_samples_count = 0;
   int samidxBest[7] = {0, 0, 0, 0, 0, 0, 0};
-  double FBest[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Hbest[9], H[9], f[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  (void)Hbest;
+  double FBest[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, H[9], f[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool bad_model = false;
   const double th_check = CHECK_COEF * th;
   unsigned seed = (unsigned)rng.next();   // seed = rand()
@@ -587,7 +586,7 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
             const double tp0 = prof ? wall_ms() : 0;
             I = rs::innerH(H, u, (unsigned)len, 16 * th, 10, inl, rng, buffer.data(), ev);
             if (prof) t_innerh += wall_ms() - tp0;
-            if ((int)I > Ihmax) { Ihmax = (int)I; memcpy(Hbest, H, sizeof(Hbest)); }
+            if ((int)I > Ihmax) Ihmax = (int)I;      // the reference also keeps H here but never hands it out (exp_ranF.c:1199)
             if (I > 6) {
               materialise_all();
               const double tp1 = prof ? wall_ms() : 0;
