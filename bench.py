@@ -5,8 +5,8 @@ synthetic 1920x1080 pairs, HessianAffine + RootSIFT, one identity view per image
 
   python bench.py --gpus N --steps K --warmup W
 
-A step = one image pair through the whole hot path (mods_match_pair_dev) with both images already
-resident in HBM.  N > 1 is launched by torch.distributed.run, one rank per GPU; pairs are independent
+A step = one batch of --pairs-per-step (default 16) image pairs through the whole hot path (detect, describe,
+match, duplicate filter, LO-RANSAC) with all images already resident in HBM; the reported value is pairs / second.  N > 1 is launched by torch.distributed.run, one rank per GPU; pairs are independent
 units, so every rank works on its own pairs (weak scaling, no data-path collective) and the reported
 value is all pairs / max-over-ranks time.
 
@@ -82,7 +82,7 @@ def other_configs(args):
         pairs = [synth.pair(w, h, seed=4000 + i) for i in range(args.pairs)]
         dev = [torch.from_numpy(np.stack([a, b])).cuda() for a, b, _ in pairs]
         params = pkg.PairParams.default()
-        pipe = pkg.Pipeline(0, w, h, params, args.gpu_workers, args.verify_workers)
+        pipe = pkg.Pipeline(0, w, h, params, args.gpu_workers, args.verify_workers, args.pairs_per_batch)
 
         def run(n):
             res, pending = [], 0
@@ -93,12 +93,14 @@ def other_configs(args):
             while pending:
                 res.append(pipe.next()[0]); pending -= 1
             return res
-        run(args.warmup)
+        pps = max(1, args.pairs_per_step)
+        run(args.warmup * pps)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        res = run(args.steps)
+        res = run(args.steps * pps)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        out.update(value=round(args.steps / dt, 3), ms_per_step=round(dt / args.steps * 1e3, 4),
+        out.update(value=round(len(res) / dt, 3), ms_per_step=round(dt / args.steps * 1e3, 4),
                    config={"workload": "1024x1024 pairs, HessianAffine+RootSIFT, LO-RANSAC H (BASELINE configs[3], per-GPU rate)",
+                           "pairs_per_step": pps,
                            "overlap": "%d gpu workers + %d verify workers" % (args.gpu_workers, args.verify_workers),
                            "keypoints_per_image": list(res[-1].n_described), "mean_inliers": round(sum(r.n_inliers for r in res) / len(res), 1)})
         pipe.close()
@@ -158,9 +160,10 @@ def other_configs(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=160)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs cycled through the steps")
+    ap.add_argument("--pairs-per-step", type=int, default=16, help="image pairs in the batch that one step processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gpu-workers", type=int, default=2, help="pipeline threads running detect/describe/match (one context each)")
     ap.add_argument("--verify-workers", type=int, default=4, help="pipeline threads running duplicate filter + LO-RANSAC")
@@ -221,16 +224,18 @@ def main():
             out.append(pipe.next()[0]); pending -= 1
         return out
 
-    run(args.warmup)
+    pps = max(1, args.pairs_per_step)
+    run(args.warmup * pps)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    results = run(args.steps)
+    results = run(args.steps * pps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    n_pairs = len(results)
     inl = sum(r.n_inliers for r in results)
     stage_ms = [sum(getattr(r, f) for r in results) for f in ("ms_detect_describe", "ms_match", "ms_duplicates", "ms_ransac")]
     # roofline leg: the pyramid blur launches of the same workload in the same batching, bracketed by HIP events on
@@ -238,7 +243,7 @@ def main():
     # and a second stream does not stretch the kernels that are being timed)
     if pipe is None:
         ctx.timing_enable(["blur"]); ctx.timing_reset()
-        for i in range(min(args.steps, 8)):
+        for i in range(8):
             step(i)
         blur_ms, blur_n, blur_bytes = ctx.timing_read("blur")
         ctx.timing_enable([])
@@ -264,21 +269,21 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        value = world * args.steps / dt
+        value = world * n_pairs / dt
         achieved = (blur_bytes / blur_n) / (blur_ms / blur_n * 1e-3) / 1e9 if blur_n else 0.0
         out = {
             "metric": "image_pairs_per_sec_end_to_end", "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "single 1920x1080 pair, HessianAffine+RootSIFT, 1 synth iteration (BASELINE configs[1])",
-                       "pairs_per_step": 1, "image": "1920x1080",
+                       "pairs_per_step": pps, "image": "1920x1080",
                        "overlap": "serial" if pipe is None else "%d gpu workers x %d pairs per batch + %d verify workers" % (args.gpu_workers, args.pairs_per_batch, args.verify_workers), "matcher": "linear (exact), FGINN 0.8",
                        "verification": "LO-RANSAC homography, Sampson, th 4 px", "parallelism": "pairs sharded, %d rank(s)" % world,
                        "keypoints_per_image": list(last.n_described), "tentatives": last.n_tentatives,
-                       "inliers_last_pair": last.n_inliers, "mean_inliers": round(inl / args.steps, 1),
+                       "inliers_last_pair": last.n_inliers, "mean_inliers": round(inl / n_pairs, 1),
                        "ransac_samples_last_pair": last.ransac_samples, "ransac_lo_last_pair": last.ransac_lo,
-                       "stage_ms_per_pair": {"detect_describe": round(stage_ms[0] / args.steps, 3), "match": round(stage_ms[1] / args.steps, 3),
-                                             "duplicates": round(stage_ms[2] / args.steps, 3), "ransac": round(stage_ms[3] / args.steps, 3)}},
+                       "stage_ms_per_pair": {"detect_describe": round(stage_ms[0] / n_pairs, 3), "match": round(stage_ms[1] / n_pairs, 3),
+                                             "duplicates": round(stage_ms[2] / n_pairs, 3), "ransac": round(stage_ms[3] / n_pairs, 3)}},
             "roofline": {"kernel": "gauss_blur_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC passes committed in profiles/r01_pmc_blur_traffic.csv
