@@ -158,6 +158,14 @@ int mods_orient_describe(mods_ctx *ctx, const float *img, int w, int h, int stri
 int mods_detect_describe_dev(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, int stride,
                              const mods_hessaff_params *det, const mods_describe_params *desc,
                              int *n_detected_host, int *n_regions_host);
+/* External descriptors (reference: the "ZMQ" descriptor, DescribeWithZmq, imagerepresentation.cpp:21-103, 992-1006).  While
+ * a function is set, the describe stage extracts ExtractPatchesColumn's patches (patchSize x patchSize at mrSize, fp32, no
+ * photometric normalisation) and hands them to it; the function returns 128 values per patch (0..255, integer valued, as
+ * the HardNet daemon delivers them), which become the descriptor bytes.  libmodszmq.so provides mods_zmq_descriptor_hook
+ * (user = endpoint string) with this signature. */
+typedef int (*mods_descriptor_fn)(void *user, const float *patches, int n, int ps, float *out, size_t out_cap_floats, int *dim);
+int mods_ctx_set_external_descriptor(mods_ctx *ctx, mods_descriptor_fn fn, void *user, double mrSize, int patchSize);
+int mods_patches_fetch(mods_ctx *ctx, int img, int ps, float *out, int max_regions, int *n_out);   /* patches of the last describe call */
 int mods_unoriented_count(mods_ctx *ctx, int img);   /* |"None" region list| of slot img after the last describe call */
 int mods_regions_fetch(mods_ctx *ctx, int img, mods_region *out, int max_out, int *n_out);
 

@@ -33,6 +33,9 @@ const char *mods_zmq_last_error(void);
 int mods_zmq_describe(const char *endpoint, const float *patches, int n, int ps, float *out, size_t out_cap_floats, int *dim,
                       int timeout_ms);
 
+/* mods_descriptor_fn of include/mods_hip.h: user = endpoint string (e.g. "tcp://localhost:5555"); waits for ever */
+int mods_zmq_descriptor_hook(void *user, const float *patches, int n, int ps, float *out, size_t out_cap_floats, int *dim);
+
 /* the two message bodies */
 int mods_zmq_encode_request(const float *patches, int n, int ps, unsigned char **png, size_t *len);      /* free with mods_zmq_free */
 int mods_zmq_decode_request(const unsigned char *png, size_t len, unsigned char **pixels, int *n, int *ps);   /* pixels: (n*ps) x ps bytes */

@@ -241,6 +241,21 @@ class Context:
         _check(lib().mods_regions_fetch(self.h, img, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
         return out[:n.value].copy()
 
+    def set_external_descriptor(self, fn_ptr, user, mr_size=3.0 * np.sqrt(3.0), patch_size=32):
+        """fn_ptr: address of a mods_descriptor_fn (e.g. mods_zmq_descriptor_hook of libmodszmq.so), user: its void* argument
+        (keep the object it points to alive).  fn_ptr = None restores RootSIFT."""
+        _check(lib().mods_ctx_set_external_descriptor(self.h, C.c_void_p(fn_ptr), C.c_void_p(user), C.c_double(mr_size), patch_size))
+
+    def patches_fetch(self, img, ps, max_regions=1 << 17):
+        n = C.c_int()
+        out = np.zeros((max_regions, ps, ps), np.float32) if max_regions <= 4096 else None
+        if out is None:
+            cnt = C.c_int()
+            _check(lib().mods_regions_fetch(self.h, img, None, 0, C.byref(cnt)))
+            out = np.zeros((max(cnt.value, 1), ps, ps), np.float32)
+        _check(lib().mods_patches_fetch(self.h, img, ps, _fp(out), out.shape[0], C.byref(n)))
+        return out[:n.value].copy()
+
     def regions_copy_dev(self, img, dst_ptr, n):
         """Device-to-device copy of the first n regions of image slot img (e.g. into a torch tensor)."""
         _check(lib().mods_regions_copy_dev(self.h, img, C.c_void_p(dst_ptr), n))

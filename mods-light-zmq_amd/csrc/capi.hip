@@ -276,6 +276,28 @@ int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w
   return check_desc_err(c);
 }
 
+// Route the description of every following call through `fn` (NULL: back to the built-in RootSIFT).  The patches are
+// ExtractPatchesColumn's (synth-detection.cpp:38-132; fp32, no photometric normalisation): patchSize x patchSize at mrSize.
+int mods_ctx_set_external_descriptor(mods_ctx *c, mods_descriptor_fn fn, void *user, double mrSize, int patchSize) {
+  if (!c) return MODS_E_ARG;
+  c->ext_fn = fn; c->ext_user = user; c->ext_mr = mrSize; c->ext_ps = patchSize;
+  return MODS_OK;
+}
+// host copy of the patches the describe stage extracted for image slot img in its last call ([n][ps][ps] fp32)
+int mods_patches_fetch(mods_ctx *c, int img, int ps, float *out, int max_regions, int *n_out) {
+  if (!c || !out || !n_out || img < 0 || img >= c->batch || !c->desc_scratch) { set_error("patches_fetch: nothing described"); return MODS_E_ARG; }
+  const int reg_cap = std::min(c->max_cand, 1 << 17);
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  int n = 0;
+  MODS_HIP_CHECK(hipMemcpy(&n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
+  if (n > reg_cap) n = reg_cap;
+  if (n > max_regions) { set_error("patch output overflow: %d > %d", n, max_regions); return MODS_E_CAPACITY; }
+  MODS_HIP_CHECK(hipMemcpy(out, c->desc_scratch + (size_t)img * reg_cap * ps * ps, sizeof(float) * (size_t)n * ps * ps, hipMemcpyDeviceToHost));
+  *n_out = n;
+  return MODS_OK;
+}
+
 // size of the reference's unoriented ("None") region list of image slot img after the last describe call:
 // detections whose centre, in the original frame, lies inside the image (imagerepresentation.cpp:867, 939)
 int mods_unoriented_count(mods_ctx *c, int img) {

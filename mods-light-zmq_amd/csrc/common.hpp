@@ -105,6 +105,11 @@ struct mods_ctx {
   int *inside_count = nullptr;       // [batch] keypoints that pass the centre test (the reference's unoriented list)
   std::vector<int> last_inside_counts;
   float *desc_scratch = nullptr;
+  // external descriptor (e.g. a ZMQ daemon): when set, patches go to this function instead of the SIFT kernel
+  mods_descriptor_fn ext_fn = nullptr;
+  void *ext_user = nullptr;
+  double ext_mr = 0;
+  int ext_ps = 0;
   size_t desc_scratch_elems = 0;
   const float *last_img_dev = nullptr;
   std::vector<int> last_region_counts;

@@ -313,6 +313,7 @@ static void build_sift_tab(int ps, SiftTab *t) {   // siftdesc.cpp:22-71, spatia
 }
 
 int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
+  if (ctx->ext_fn && (ctx->ext_ps < 8 || ctx->ext_ps > 63)) { set_error("external descriptor: patch size %d unsupported", ctx->ext_ps); return MODS_E_ARG; }
   if (par->ori_patchSize < 8 || par->ori_patchSize > 48 || par->desc_patchSize < 9 || par->desc_patchSize > 63 ||
       !(par->desc_patchSize & 1)) { set_error("unsupported patch sizes (ori %d, desc %d)", par->ori_patchSize, par->desc_patchSize); return MODS_E_ARG; }
   if (par->ori_maxAngles > 1) { set_error("maxAngles > 1 is not supported"); return MODS_E_ARG; }
@@ -340,6 +341,34 @@ int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
 // or uploaded by mods_orient_describe) for images `img_dev` [n_img][h][w].
 int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par) {
   return describe_run_view(ctx, img_dev, n_img, w, h, par, nullptr, 0, 0, nullptr);
+}
+
+// Descriptors from outside the library (the ZMQ daemon of the reference's "ZMQ" descriptor, imagerepresentation.cpp:992-1006):
+// the extracted patches of every image go to ctx->ext_fn, the 128 returned values per region (integer valued 0..255, as the
+// HardNet daemon delivers them) become the region's descriptor bytes.
+static int external_describe(mods_ctx *ctx, int n_img, const DescConst &k) {
+  const int pp = k.desc_ps * k.desc_ps;
+  std::vector<int> counts(n_img);
+  MODS_HIP_CHECK(hipMemcpyAsync(counts.data(), ctx->region_count, sizeof(int) * n_img, hipMemcpyDeviceToHost, ctx->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  std::vector<float> patches, out;
+  std::vector<uint8_t> desc;
+  for (int b = 0; b < n_img; b++) {
+    const int n = std::min(counts[b], k.reg_cap);
+    if (n <= 0) continue;
+    patches.resize((size_t)n * pp); out.assign((size_t)n * 128, 0.f); desc.resize((size_t)n * 128);
+    MODS_HIP_CHECK(hipMemcpy(patches.data(), ctx->desc_scratch + (size_t)b * k.reg_cap * pp, sizeof(float) * patches.size(), hipMemcpyDeviceToHost));
+    int dim = 0;
+    const int rc = ctx->ext_fn(ctx->ext_user, patches.data(), n, k.desc_ps, out.data(), out.size(), &dim);
+    if (rc || dim != 128) { set_error("external descriptor failed (rc %d, %d values per patch; 128 expected)", rc, dim); return MODS_E_ARG; }
+    for (size_t i = 0; i < desc.size(); i++) {
+      const float v = out[i];
+      desc[i] = v <= 0.f ? 0 : (v >= 255.f ? 255 : (uint8_t)(v + 0.5f));
+    }
+    MODS_HIP_CHECK(hipMemcpy2D((uint8_t *)(ctx->regions_dev + (size_t)b * ctx->max_cand) + offsetof(mods_region, desc), sizeof(mods_region),
+                               desc.data(), 128, 128, n, hipMemcpyHostToDevice));
+  }
+  return MODS_OK;
 }
 
 // cv::invert(H, Hinv, DECOMP_LU) for 3x3 doubles: OpenCV's closed form (all zeros when singular)
@@ -383,6 +412,9 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   k.ori_th = par->ori_threshold;
   k.desc_mr = par->desc_mrSize; k.desc_ps = par->desc_patchSize; k.photo = par->photoNorm; k.root = par->rootSift;
   k.max_bin = par->maxBinValue;
+  k.patch_rule = 0;
+  const bool external = ctx->ext_fn != nullptr;
+  if (external) { k.desc_mr = ctx->ext_mr; k.desc_ps = ctx->ext_ps; k.photo = 0; k.patch_rule = 1; }
   int *key_count = ctx->cand_count + 2 * ctx->batch;
   const float *orimask = ctx->desc_tables_dev, *dmask = ctx->desc_tables_dev + 4096;
   const SiftTab *tab = (const SiftTab *)(ctx->desc_tables_dev + 8192);
@@ -395,8 +427,9 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
                        (const OriOut *)ctx->ori_dev, ctx->regions_dev, ctx->region_count, ctx->inside_count);
     MODS_HIP_CHECK(hipGetLastError());
   }
-  rc = launch_extract_and_sift(ctx, img_dev, n_img, k, dmask, tab);
+  rc = launch_extract_and_sift(ctx, img_dev, n_img, k, dmask, tab, !external);
   if (rc) return rc;
+  if (external && (rc = external_describe(ctx, n_img, k))) return rc;
   if (det_copy_dev)
     MODS_HIP_CHECK(hipMemcpyAsync(det_copy_dev, ctx->regions_dev, sizeof(mods_region) * (size_t)ctx->max_cand, hipMemcpyDeviceToDevice, ctx->stream));
   if (k.view) {

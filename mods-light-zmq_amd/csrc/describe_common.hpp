@@ -22,6 +22,8 @@ struct DescConst {
   int tap_cap;
   // synthesised view (H != I): keypoints live in the view frame; the inside / touch-boundary tests of
   // ReprojectRegions* run on their reprojection into the original image (ow x oh) through Hinv
+  int patch_rule;          // size of the sampled region: 0 = DescribeRegions (2*ceil(s*mr)+1, synth-detection.hpp:189),
+                           // 1 = ExtractPatchesColumn (the same for odd patch sizes, 2*ceil(s*mr) for even ones, synth-detection.cpp:57)
   int view;                // 0: identity view (reproj_kp == det_kp)
   int ow, oh;
   double Hinv[6];          // affine part of inv(H), row-major 2x3
@@ -33,7 +35,8 @@ struct SiftTab {           // precomputeBinsAndWeights, siftdesc.cpp:22-71 (host
 };
 
 // sift.hip
-int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, DescConst k, const float *dmask, const SiftTab *tab);
+int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, DescConst k, const float *dmask, const SiftTab *tab,
+                            bool run_sift = true);
 int launch_sift_patch_test(mods_ctx *ctx, const float *patch_dev, int ps, int root, double max_bin, uint8_t *out_dev);
 
 }  // namespace mods

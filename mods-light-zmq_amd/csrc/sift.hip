@@ -33,10 +33,10 @@ struct RegionGeom {             // per-region constants of DescribeRegions
   float fx, fy, f11, f12, f21, f22;
 };
 
-__device__ __forceinline__ RegionGeom region_geom(const mods_region &r, double desc_mr, int ps) {
+__device__ __forceinline__ RegionGeom region_geom(const mods_region &r, double desc_mr, int ps, int patch_rule) {
   RegionGeom g;
   const float mrScale = (float)ceil(r.s * desc_mr);
-  const int P = 2 * int(mrScale) + 1;
+  const int P = (patch_rule == 0 || (ps & 1)) ? 2 * int(mrScale) + 1 : 2 * int(mrScale);
   g.scale = float(P) / float(ps);
   g.P2 = ((double)g.scale > 0.4) ? P + 2 : 0;
   g.fx = (float)r.x; g.fy = (float)r.y;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
   int n = reg_count[b];
   if (n > k.reg_cap) n = k.reg_cap;
   for (int ri = blockIdx.x; ri < n; ri += gridDim.x) {
-    const RegionGeom g = region_geom(reg[ri], k.desc_mr, ps);
+    const RegionGeom g = region_geom(reg[ri], k.desc_mr, ps, k.patch_rule);
     if (g.P2 > SMALL_CAP) continue;
     float *out = patches + ((size_t)b * k.reg_cap + ri) * pp;
     __syncthreads();
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mo
   if (n > k.reg_cap) n = k.reg_cap;
   const int ri = blockIdx.x * 256 + threadIdx.x;
   if (ri >= n) return;
-  const RegionGeom g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps);
+  const RegionGeom g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps, k.patch_rule);
   if (g.P2 <= SMALL_CAP) return;
   const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
   const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2) +
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void big_sample_kernel(const float *__restrict
     const int2 item = items[it];
     const BigRegion br = regions[item.x];
     if (br.n_tap > k.tap_cap) { if (threadIdx.x == 0) atomicExch(err_flag, 1); continue; }
-    const RegionGeom g = region_geom(reg_all[(size_t)br.img * k.max_reg + br.ri], k.desc_mr, k.desc_ps);
+    const RegionGeom g = region_geom(reg_all[(size_t)br.img * k.max_reg + br.ri], k.desc_mr, k.desc_ps, k.patch_rule);
     const float *img = img_all + (size_t)k.w * k.h * br.img;
     float *S = pool + br.slab + big_hdr_floats(br.n_tap, k.desc_ps);
     const int P2 = br.P2;
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void sift_patch_test_kernel(const float *__res
 }
 
 // ---------------------------------------------------------------------------------------
-int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, DescConst k, const float *dmask, const SiftTab *tab) {
+int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, DescConst k, const float *dmask, const SiftTab *tab, bool run_sift) {
   StageScope ts(ctx, MODS_STAGE_DESCRIBE);
   const int ps = k.desc_ps, ps2 = 2 * ps, pp = ps * ps;
   // HBM layout of the description scratch: patch store [n_img][reg_cap][ps*ps] | big-tier bookkeeping | slab pool
@@ -734,8 +734,9 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
                      ctx->regions_dev, pool, ctx->desc_err_dev);
   hipLaunchKernelGGL(big_rowpass_kernel, dim3(4096), dim3(256), ldsH, ctx->stream, k, bl, bregs, items, max_items, pool);
   hipLaunchKernelGGL(big_colres_kernel, dim3(2048), dim3(256), ldsH, ctx->stream, k, bl, bregs, max_big, pool, patches);
-  hipLaunchKernelGGL(sift_kernel, dim3(2048, n_img), dim3(256), sift_lds_bytes(ps), ctx->stream, k, patches, ctx->regions_dev,
-                     ctx->region_count, dmask, tab);
+  if (run_sift)
+    hipLaunchKernelGGL(sift_kernel, dim3(2048, n_img), dim3(256), sift_lds_bytes(ps), ctx->stream, k, patches, ctx->regions_dev,
+                       ctx->region_count, dmask, tab);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }

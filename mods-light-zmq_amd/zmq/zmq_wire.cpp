@@ -117,6 +117,10 @@ int mods_zmq_describe(const char *endpoint, const float *patches, int n, int ps,
   return MODS_ZMQ_OK;
 }
 
+int mods_zmq_descriptor_hook(void *user, const float *patches, int n, int ps, float *out, size_t out_cap_floats, int *dim) {
+  return mods_zmq_describe((const char *)user, patches, n, ps, out, out_cap_floats, dim, 0);
+}
+
 int mods_zmq_serve(const char *bind_endpoint, mods_zmq_model_fn model, void *user, int max_requests) {
   if (!bind_endpoint || !model) { set_err("serve: bad arguments"); return MODS_ZMQ_E_ARG; }
   void *ctx = zmq_ctx_new();

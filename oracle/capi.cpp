@@ -179,6 +179,17 @@ void orc_extract_desc_patch(const float *img, int w, int h, const orc_region *r,
   extract_desc_patch(v[0], wrap(img, w, h), mrSize, patchSize, photoNorm != 0, patch);
   std::memcpy(patch_out, patch.d.data(), sizeof(float) * (size_t)patchSize * patchSize);
 }
+// ExtractPatchesColumn (non-fast, no photometric normalisation): n patches of patchSize x patchSize, fp32
+void orc_extract_patches_column(const float *img, int w, int h, const orc_region *r, int n, double mrSize, int patchSize,
+                                float *patches_out) {
+  std::vector<Region> v; to_regions(r, n, v);
+  Img im = wrap(img, w, h);
+  Img patch(patchSize, patchSize);
+  for (int i = 0; i < n; i++) {
+    extract_desc_patch(v[i], im, mrSize, patchSize, false, patch, true);
+    std::memcpy(patches_out + (size_t)i * patchSize * patchSize, patch.d.data(), sizeof(float) * (size_t)patchSize * patchSize);
+  }
+}
 int orc_detect_orientation(const float *img, int w, int h, const orc_region *in, int n, double mrSize, int patchSize,
                            int maxAngles, double th, orc_region *out, int max_out) {
   std::vector<Region> v, o; to_regions(in, n, v);

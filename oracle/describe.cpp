@@ -312,13 +312,14 @@ void sift_patch_to_desc(const Img &patch, uint8_t out[128], bool rootsift, doubl
   }
 }
 
-// Non-fast branch of DescribeRegions<>, synth-detection.hpp:186-231.
-void extract_desc_patch(const Region &k, const Img &img, double mrSize, int patchSize, bool photoNorm, Img &patch) {
+// Non-fast branch of DescribeRegions<>, synth-detection.hpp:186-231; with column_rule the same code as it appears in
+// ExtractPatchesColumn, synth-detection.cpp:52-102 (the sampled region is 2*ceil(s*mr) wide for even patch sizes).
+void extract_desc_patch(const Region &k, const Img &img, double mrSize, int patchSize, bool photoNorm, Img &patch, bool column_rule) {
   static thread_local Img mask;
   if (mask.w != patchSize) { mask = Img(patchSize, patchSize); compute_circular_gauss_mask(mask, 0); }
   if (patch.w != patchSize || patch.h != patchSize) patch = Img(patchSize, patchSize);
   float mrScale = (float)std::ceil(k.s * mrSize);
-  int patchImageSize = 2 * int(mrScale) + 1;
+  int patchImageSize = (!column_rule || patchSize % 2 != 0) ? 2 * int(mrScale) + 1 : 2 * int(mrScale);
   float imageToPatchScale = float(patchImageSize) / float(patchSize);
   if (imageToPatchScale > 0.4) {
     patchImageSize += 2;

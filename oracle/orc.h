@@ -120,7 +120,7 @@ void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, in
                        bool photoNorm);                                     // synth-detection.hpp:170-263
 void sift_patch_to_desc(const Img &patch41, uint8_t out[128], bool rootsift, double maxBinValue = 0.2);   // matching/siftdesc.cpp
 void extract_desc_patch(const Region &r, const Img &img, double mrSize, int patchSize, bool photoNorm,
-                        Img &patch);
+                        Img &patch, bool column_rule = false);
 bool dominant_angle(const Img &patch, double th, float *angle);              // :836-929 (maxAngles=1)
 
 // ---- matching (match.cpp) ------------------------------------------------------------------

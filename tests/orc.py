@@ -255,6 +255,16 @@ def detect_describe(img, params=None, max_out=1 << 18):
     return out[:n].copy(), ndet.value
 
 
+def extract_patches_column(img, regions, mr_size=ORI_MRSIZE, patch_size=32):
+    """ExtractPatchesColumn (what DescribeWithZmq sends to a daemon), fp32 [n][ps][ps]."""
+    a, p = _f(img)
+    r = np.ascontiguousarray(regions)
+    out = np.zeros((len(r), patch_size, patch_size), np.float32)
+    lib().orc_extract_patches_column(p, a.shape[1], a.shape[0], r.ctypes.data_as(C.c_void_p), len(r), C.c_double(mr_size), patch_size,
+                                     out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 # ---- view synthesis ------------------------------------------------------------------------------
 class ViewGeom(C.Structure):
     _fields_ = [("identity", C.c_int), ("w_rot", C.c_int), ("h_rot", C.c_int), ("w_new", C.c_int), ("h_new", C.c_int),

@@ -45,8 +45,12 @@ def _describe(lib, endpoint, patches, cap_dim=512, timeout_ms=60000):
 def _start(model, port, extra=()):
     p = subprocess.Popen([sys.executable, DAEMON, "--model", model, "--bind", "tcp://127.0.0.1:%d" % port, "--device", "cpu"] + list(extra),
                          stderr=subprocess.PIPE)
-    line = p.stderr.readline().decode()       # "serving ..." is printed once the model is built
-    assert "serving" in line, line + p.stderr.read().decode()
+    line = ""
+    for _ in range(20):                       # "serving ..." is printed once the model is built (runtime warnings may come first)
+        line = p.stderr.readline().decode()
+        if "serving" in line or not line:
+            break
+    assert "serving" in line, line
     time.sleep(0.2)
     return p
 
