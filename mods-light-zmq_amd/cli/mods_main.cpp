@@ -18,6 +18,7 @@
 // warning, match images (out1/out2) are not drawn, pre-extracted input and ground-truth verification are
 // refused.  The vector matcher is always the exact (linear) search.
 #include "../../include/mods_hip.h"
+#include "../../include/mods_zmq.h"
 #include "image_io.hpp"
 #include "ini_reader.hpp"
 #include <chrono>
@@ -46,6 +47,11 @@ struct Config {
   int max_steps = 4, min_matches = 15;
   int load_color = 1;
   int verbose = 0, time_log = 1, write_keypoints = 1, write_matches = 1, output_h = 0;
+  // [zmqDescriptor] (io_mods.cpp:395-407): used when a step asks for the "ZMQ" descriptor instead of RootSIFT
+  bool use_zmq = false;
+  std::string zmq_port = "tcp://localhost:5555";
+  double zmq_mr = 3.0 * 1.7320508075688772;
+  int zmq_ps = 32;
 };
 
 int read_config(const std::string &config_fn, const std::string &iters_fn, int ver_type, Config *cfg) {
@@ -118,6 +124,9 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   cfg->output_h = (int)ini.GetInteger("TextOutput", "outputEstimatedHorF", 0);
   if (ini.GetInteger("TextOutput", "outputAllTentatives", 0)) std::cerr << "Warning: outputAllTentatives is not supported, only verified matches are written" << std::endl;
   cfg->load_color = (int)ini.GetInteger("Computing", "LoadColor", 1);
+  if (ini.Has("zmqDescriptor", "port")) cfg->zmq_port = ini.GetString("zmqDescriptor", "port", "");
+  cfg->zmq_mr = ini.GetDouble("zmqDescriptor", "mrSize", cfg->zmq_mr);
+  cfg->zmq_ps = (int)ini.GetInteger("zmqDescriptor", "patchSize", cfg->zmq_ps);
   // iterations file :457-492
   cfg->max_steps = (int)it.GetInteger("Iterations", "Steps", 4);
   cfg->min_matches = (int)it.GetInteger("Iterations", "minMatches", 15);
@@ -141,14 +150,19 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
       for (size_t k = 0; k < scales.size(); k++) st.scale_set[k] = scales[k];
       const std::vector<std::string> descs = it.GetStringVector(sec, "Descriptors");
       const std::vector<double> fginn = it.GetDoubleVector(sec, "FGINNThreshold");
-      bool has_root = false;
+      bool has_root = false, has_zmq = false;
+      double zmq_ratio = 0;
       for (size_t k = 0; k < descs.size(); k++) {
         std::string name = descs[k];
         name.erase(0, name.find_first_not_of(" \t"));
         name.erase(name.find_last_not_of(" \t") + 1);
         if (name == "RootSIFT") { has_root = true; st.fginn_ratio = k < fginn.size() ? fginn[k] : 0.0; }
+        else if (name == "ZMQ") { has_zmq = true; zmq_ratio = k < fginn.size() ? fginn[k] : 0.0; }
         else if (!name.empty()) std::cerr << "Warning: " << sec << ": descriptor " << name << " is outside this build" << std::endl;
       }
+      if (has_zmq && !has_root) {      // the daemon's descriptor takes the place of RootSIFT for the whole run
+        cfg->use_zmq = true; has_root = true; st.fginn_ratio = zmq_ratio;
+      } else if (has_zmq) std::cerr << "Warning: " << sec << ": RootSIFT and ZMQ in one step: RootSIFT is used" << std::endl;
       if (!has_root) { std::cerr << "Warning: " << sec << " does not ask for RootSIFT; the step is skipped" << std::endl; st.n_tilts = st.n_scales = -1; }
       else if (!(st.fginn_ratio > 0 && st.fginn_ratio < 1)) { std::cerr << sec << ": FGINNThreshold of RootSIFT must lie in (0, 1)" << std::endl; return 1; }
     } else st.n_tilts = st.n_scales = -1;      // no views of this detector in this step
@@ -177,7 +191,7 @@ bool load_grey(const std::string &fn, int load_color, GreyImage *img) {
   return true;
 }
 
-void write_regions(const std::string &fn, mods_imgrep *rep) {
+void write_regions(const std::string &fn, mods_imgrep *rep, const char *desc_name) {
   std::ofstream kp(fn);
   if (!kp.is_open()) { std::cerr << "Cannot open file " << fn << " to save keypoints" << std::endl; return; }
   const int n = mods_imgrep_count(rep);
@@ -185,7 +199,7 @@ void write_regions(const std::string &fn, mods_imgrep *rep) {
   if (n > 0 && mods_imgrep_fetch(rep, 0, n, regs.data())) { std::cerr << mods_last_error() << std::endl; return; }
   kp << 1 << std::endl;
   kp << "HessianAffine " << 1 << std::endl;
-  kp << "RootSIFT " << n << std::endl;
+  kp << desc_name << " " << n << std::endl;
   if (n > 0) kp << 128 << std::endl;
   for (int i = 0; i < n; i++) {
     const mods_region &r = regs[i];
@@ -245,6 +259,11 @@ int main(int argc, char **argv) {
   if (steps.empty()) { std::cerr << "The iterations file has no HessianAffine step with RootSIFT; nothing to do" << std::endl; return 1; }
   if (cfg.verbose) std::cerr << steps.size() << " HessianAffine step(s) of " << cfg.steps.size() << " will be run, minMatches = " << cfg.min_matches << std::endl;
 
+  if (cfg.use_zmq) {
+    while (!cfg.zmq_port.empty() && isspace((unsigned char)cfg.zmq_port.back())) cfg.zmq_port.pop_back();
+    if (cfg.verbose) std::cerr << "Descriptors from the daemon at " << cfg.zmq_port << " (" << cfg.zmq_ps << "x" << cfg.zmq_ps << " patches)" << std::endl;
+    if (mods_ctx_set_external_descriptor(ctx, &mods_zmq_descriptor_hook, (void *)cfg.zmq_port.c_str(), cfg.zmq_mr, cfg.zmq_ps)) return fail("external descriptor");
+  }
   mods_ladder_result res;
   std::vector<double> matches((size_t)4 << 20);
   if (mods_match_ladder_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, steps.data(), (int)steps.size(),
@@ -285,8 +304,8 @@ int main(int argc, char **argv) {
     }
     if (cfg.write_keypoints) {
       if (ends_with(k1_fn, ".npz") || ends_with(k2_fn, ".npz")) std::cerr << "Warning: .npz keypoint output is not part of this build; text is written" << std::endl;
-      write_regions(k1_fn, rep1);
-      write_regions(k2_fn, rep2);
+      write_regions(k1_fn, rep1, cfg.use_zmq ? "ZMQ" : "RootSIFT");
+      write_regions(k2_fn, rep2, cfg.use_zmq ? "ZMQ" : "RootSIFT");
     }
   }
   std::cerr << "Image1: regions descriptors | Image2: regions descriptors " << std::endl;

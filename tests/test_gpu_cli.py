@@ -86,3 +86,43 @@ def test_cli_ladder_and_epipolar(pkg, tmp_path):
     log = (tmp_path / "log.txt").read_text().split()
     assert int(log[6]) == 1 + res.steps_done            # step numbering counts the skipped MSER step
     assert "detector MSER is outside this build" in err
+
+
+def test_cli_with_zmq_descriptor_daemon(pkg, tmp_path):
+    """[zmqDescriptor] + Descriptors=ZMQ (io_mods.cpp:395-407, imagerepresentation.cpp:1390-1455): the command line
+    sends ExtractPatchesColumn patches to the daemon and matches on what comes back."""
+    import ctypes as C
+    import sys
+    import time
+    from test_cpu_zmq import _stop
+    from test_gpu_zmq import _free_port, LIB, DAEMON
+    wire = C.CDLL(LIB)
+    port = _free_port()
+    endpoint = "tcp://127.0.0.1:%d" % port
+    d = subprocess.Popen([sys.executable, DAEMON, "--model", "hardnet", "--bind", endpoint, "--device", "cuda", "--seed", "5"],
+                         stderr=subprocess.PIPE)
+    line = ""
+    for _ in range(20):
+        line = d.stderr.readline().decode()
+        if "serving" in line or not line:
+            break
+    assert "serving" in line, line
+    time.sleep(0.2)
+    try:
+        cfg = (open(os.path.join(CFG, "classic.ini")).read()
+               + "\n[zmqDescriptor]\nport=%s\npatchSize=32\nmrSize=5.196\n" % endpoint)
+        (tmp_path / "zmq.ini").write_text(cfg)
+        args = [MODS, G1, G1, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", "0", "H.txt",
+                str(tmp_path / "zmq.ini"), os.path.join(CFG, "iters_zmq.ini")]
+        p = subprocess.run(args, cwd=tmp_path, env=dict(os.environ, MODS_RANSAC_SEED="4242"), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()
+        # an image against itself: (random-weight) HardNet descriptors match 1:1, the homography is the identity
+        got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+        assert len(got) > 500 and np.allclose(got[:, :2], got[:, 2:], atol=1e-3)
+        H = np.loadtxt(tmp_path / "H.txt")
+        assert np.allclose(H / H[2, 2], np.eye(3), atol=1e-3)
+        lines = (tmp_path / "k1.txt").read_text().splitlines()
+        assert lines[2].startswith("ZMQ ") and lines[3] == "128"
+    finally:
+        _stop(wire, d, port)
