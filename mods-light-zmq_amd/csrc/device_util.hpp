@@ -70,6 +70,37 @@ __device__ __forceinline__ float tap_combine(const TapLoads &t) {
 // +/- is a double operation rounded to float on return.
 __device__ const double g_atan_lut[256] = MODS_ATAN_LUT_INIT;
 
+// Branch-free form of atan2LUTff (helpers.cpp:160-207).  Every branch of the reference returns
+// (float)(B + s * L[(int)(255.f * num / den)]) with (num, den) = (min, max) of |x|, |y| chosen by |x| > |y|, and (B, s) fixed by
+// the signs and that comparison: 8 cases ("octants") x 256 table entries.  atan2_lut_sel picks the case and the index;
+// atan2_lut_case evaluates a case exactly as its branch does (used to tabulate functions of the result per (case, index)).
+struct AtanSel { int oct, idx; bool zero; };   // zero: the reference's `x == 0` exit (returns 0.f)
+__device__ __forceinline__ AtanSel atan2_lut_sel(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const bool xp = x > 0.f, yp = y > 0.f, first = ax > ay;
+  const float num = first ? ay : ax, den = first ? ax : ay;
+  AtanSel r;
+  r.zero = !xp && !yp && !first && x == 0.f;
+  r.oct = (xp ? 0 : 4) | (yp ? 0 : 2) | (first ? 0 : 1);
+  const int idx = (int)(255.f * num / den);
+  r.idx = r.zero ? 0 : idx;
+  return r;
+}
+__device__ __forceinline__ float atan2_lut_case(int oct, double L) {
+  const float PI_2f = 1.57079632679489661923f;
+  const float PIf = 3.14159265358979323846f;
+  switch (oct) {
+    case 0: return (float)L;                              // x > 0, y > 0, x > y
+    case 1: return (float)((double)PI_2f - L);
+    case 2: return (float)(-L);                           // x > 0, y <= 0, x > |y|
+    case 3: return (float)((double)(-PI_2f) + L);
+    case 4: return (float)((double)PIf - L);              // x <= 0, y > 0, |x| > y
+    case 5: return (float)((double)PI_2f + L);
+    case 6: return (float)((double)(-PIf) + L);           // x <= 0, y <= 0, |x| > |y|
+    default: return (float)((double)(-PI_2f) - L);
+  }
+}
+
 // table pointer variant (e.g. an LDS copy of the table)
 __device__ __forceinline__ float atan2_lut_ff_t(float y, float x, const double *__restrict__ L) {
   const float PI_2f = 1.57079632679489661923f;

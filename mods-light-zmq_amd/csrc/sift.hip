@@ -196,51 +196,68 @@ __device__ __forceinline__ float col_value(const float *T, int P2, int ps2, int 
 }
 
 // column pass fused with interpolate(smoothed, c0, c0, scale, 0, 0, scale): every blurred value is
-// used by exactly one output pixel, so it is produced where it is consumed.
+// used by exactly one output pixel, so it is produced where it is consumed.  One output pixel p = (j, i):
+__device__ __forceinline__ float col_resample_pixel(const float *T, int P2, int ps, int r_tap, bool touch2, const float *s_tap,
+                                                    const float *s_seq, const int *s_cidx, int p) {
+  const int ps2 = 2 * ps;
+  const int j = p / ps, i = p - j * ps;
+  const float WX = s_seq[i], WY = s_seq[j];
+  const int x = touch2 ? (int)floorf(WX) : (int)WX;
+  const int y = touch2 ? (int)floorf(WY) : (int)WY;
+  if (touch2 && !(WX >= 0 && WY >= 0 && x < P2 - 1 && y < P2 - 1)) return 0.f;
+  const int y0 = s_cidx[2 * j], y1 = s_cidx[2 * j + 1];
+  float r00, r01, r10, r11;
+  if (y1 == y0 + 1 && y0 - r_tap >= 0 && y1 + r_tap <= P2 - 1) {
+    // the four blurred values of this pixel share their column windows: rows y0-r .. y0+1+r of the
+    // column pair (2i, 2i+1) are loaded once (float2) and feed all four sums, each in tap order
+    const float2 *c = (const float2 *)(T + (size_t)y0 * ps2 + 2 * i);
+    const int st = ps2 >> 1;                       // row stride in float2
+    const float2 m0 = c[0], m1 = c[st];
+    const float tc = s_tap[r_tap];
+    r00 = tc * m0.x; r01 = tc * m0.y; r10 = tc * m1.x; r11 = tc * m1.y;
+    float2 up = m1;                                 // row y0 + jj       (jj = 1)
+    float2 dn_prev = m0;                            // row y0 + 1 - jj   (jj = 1)
+    int jj = 1;
+    for (; jj + 3 <= r_tap; jj += 4) {              // 8 loads in flight, then the sums in tap order
+      float2 u[4], d[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        u[q] = c[(ptrdiff_t)(jj + q + 1) * st];     // row y0 + 1 + jj
+        d[q] = c[-(ptrdiff_t)(jj + q) * st];        // row y0 - jj
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float t = s_tap[r_tap + jj + q];
+        r00 += t * (up.x + d[q].x);         r01 += t * (up.y + d[q].y);
+        r10 += t * (u[q].x + dn_prev.x);    r11 += t * (u[q].y + dn_prev.y);
+        up = u[q]; dn_prev = d[q];
+      }
+    }
+    for (; jj <= r_tap; jj++) {
+      const float2 up1 = c[(ptrdiff_t)(jj + 1) * st];
+      const float2 dn = c[-(ptrdiff_t)jj * st];
+      const float t = s_tap[r_tap + jj];
+      r00 += t * (up.x + dn.x);        r01 += t * (up.y + dn.y);
+      r10 += t * (up1.x + dn_prev.x);  r11 += t * (up1.y + dn_prev.y);
+      up = up1; dn_prev = dn;
+    }
+  } else {
+    r00 = col_value(T, P2, ps2, y0, 2 * i, r_tap, s_tap);
+    r01 = col_value(T, P2, ps2, y0, 2 * i + 1, r_tap, s_tap);
+    r10 = col_value(T, P2, ps2, y1, 2 * i, r_tap, s_tap);
+    r11 = col_value(T, P2, ps2, y1, 2 * i + 1, r_tap, s_tap);
+  }
+  const float wx = WX - (float)x;
+  const float I1 = wx * (r01 - r00) + r00;
+  return (WY - y) * (wx * (r11 - r10) + r10 - I1) + I1;
+}
+
 __device__ __forceinline__ void col_resample(const float *T, int P2, int ps, int n_tap, float scale, const float *s_tap,
                                              const float *s_seq, const int *s_cidx, float *patch_out) {
-  const int ps2 = 2 * ps, r_tap = n_tap >> 1;
   const float c0 = (float)(P2 >> 1);
   const bool touch2 = check_borders(P2, P2, c0, c0, scale, 0.f, 0.f, scale, ps, ps);
-  for (int p = threadIdx.x; p < ps * ps; p += 256) {
-    const int j = p / ps, i = p - j * ps;
-    const float WX = s_seq[i], WY = s_seq[j];
-    const int x = touch2 ? (int)floorf(WX) : (int)WX;
-    const int y = touch2 ? (int)floorf(WY) : (int)WY;
-    float v = 0.f;
-    if (!touch2 || (WX >= 0 && WY >= 0 && x < P2 - 1 && y < P2 - 1)) {
-      const int y0 = s_cidx[2 * j], y1 = s_cidx[2 * j + 1];
-      float r00, r01, r10, r11;
-      if (y1 == y0 + 1 && y0 - r_tap >= 0 && y1 + r_tap <= P2 - 1) {
-        // the four blurred values of this pixel share their column windows: rows y0-r .. y0+1+r of the
-        // column pair (2i, 2i+1) are loaded once (float2) and feed all four sums, each in tap order
-        const float2 *c = (const float2 *)(T + (size_t)y0 * ps2 + 2 * i);
-        const int st = ps2 >> 1;                       // row stride in float2
-        const float2 m0 = c[0], m1 = c[st];
-        const float tc = s_tap[r_tap];
-        r00 = tc * m0.x; r01 = tc * m0.y; r10 = tc * m1.x; r11 = tc * m1.y;
-        float2 up = m1;                                 // row y0 + jj       (jj = 1)
-        float2 dn_prev = m0;                            // row y0 + 1 - jj   (jj = 1)
-        for (int jj = 1; jj <= r_tap; jj++) {
-          const float2 up1 = c[(ptrdiff_t)(jj + 1) * st];   // row y0 + 1 + jj
-          const float2 dn = c[-(ptrdiff_t)jj * st];         // row y0 - jj
-          const float t = s_tap[r_tap + jj];
-          r00 += t * (up.x + dn.x);        r01 += t * (up.y + dn.y);
-          r10 += t * (up1.x + dn_prev.x);  r11 += t * (up1.y + dn_prev.y);
-          up = up1; dn_prev = dn;
-        }
-      } else {
-        r00 = col_value(T, P2, ps2, y0, 2 * i, r_tap, s_tap);
-        r01 = col_value(T, P2, ps2, y0, 2 * i + 1, r_tap, s_tap);
-        r10 = col_value(T, P2, ps2, y1, 2 * i, r_tap, s_tap);
-        r11 = col_value(T, P2, ps2, y1, 2 * i + 1, r_tap, s_tap);
-      }
-      const float wx = WX - (float)x;
-      const float I1 = wx * (r01 - r00) + r00;
-      v = (WY - y) * (wx * (r11 - r10) + r10 - I1) + I1;
-    }
-    patch_out[p] = v;
-  }
+  for (int p = threadIdx.x; p < ps * ps; p += 256)
+    patch_out[p] = col_resample_pixel(T, P2, ps, n_tap >> 1, touch2, s_tap, s_seq, s_cidx, p);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
   if (n > k.reg_cap) n = k.reg_cap;
   for (int ri = blockIdx.x; ri < n; ri += gridDim.x) {
     const RegionGeom g = region_geom(reg[ri], k.desc_mr, ps, k.patch_rule);
-    if (g.P2 > SMALL_CAP) continue;
+    if (g.P2 > k.p2_hi) continue;
     float *out = patches + ((size_t)b * k.reg_cap + ri) * pp;
     __syncthreads();
     if (g.P2 > 0) {
@@ -283,50 +300,68 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------
-// extract, HBM tier (P2 > SMALL_CAP): phase kernels over a device-built work list, so that a large
-// region is spread over many workgroups.  Per region a slab is reserved in the pool:
-//   header (taps n_tap | seq ps | cidx 2ps ints, padded to HDR floats) | S (P2 x P2) | T (P2 x 2ps)
+// extract, HBM tier (P2 > k.p2_hi): phase kernels over device-built work lists, one WAVE per work item, no
+// barriers and no LDS, so that the loads of many items are in flight per CU.  Per region a slab is reserved:
+//   header (taps n_tap | seq ps | cidx 2ps ints, padded) | St (P2 columns x P2r) | T (P2 x 2ps)
+// St is S = interpolate(img, x, y, A) stored TRANSPOSED (column-major, column stride P2r = P2 rounded up to 4):
+// the row pass then reads 4 consecutive rows of a column as one float4, contiguous across the lanes.
 // ---------------------------------------------------------------------------------------
-constexpr int BIG_RC = 32;            // sample / row-pass rows per work item
-struct BigRegion { int img, ri, P2, n_tap; unsigned long long slab; float scale; int pad; };   // slab: float offset in the pool
+constexpr int BIG_SROWS = 16;         // rows per sample item
+constexpr int BIG_RROWS = 64;         // rows per row-pass item
+constexpr int BIG_RLOADS = 128;       // float4 loads per lane a row-pass item aims at
+struct BigRegion { int img, ri, P2, n_tap; unsigned long long slab; float scale; int P2r; };   // slab: float offset in the pool
 struct BigLists {                     // device-resident bookkeeping, zeroed before every batch
-  int n_regions, n_items;
+  int n_regions, n_sitems, n_ritems, pad;
   unsigned long long pool_used;
 };
 
 __device__ __forceinline__ int big_hdr_floats(int n_tap, int ps) { return (n_tap + 3 * ps + 8 + 3) & ~3; }
-__device__ __forceinline__ unsigned long long big_s_floats(int P2) { return ((unsigned long long)P2 * P2 + 1ull) & ~1ull; }   // keeps T 8-byte aligned
+__device__ __forceinline__ unsigned long long big_s_floats(int P2, int P2r) { return (unsigned long long)P2 * P2r; }
+// a row-pass item covers `steps` groups of 4 column pairs
+__device__ __forceinline__ int big_rsteps(int n_tap) { const int v = BIG_RLOADS / (n_tap + 1); return v < 1 ? 1 : v; }
 
-// grid = (ceil(reg_cap/256), n_img), block 256: reserve slabs, emit (region, row chunk) work items
+// grid = (ceil(reg_cap/256), n_img), block 256: reserve slabs, emit the work items
 __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mods_region *__restrict__ reg_all,
                                                            const int *__restrict__ reg_count, BigLists *__restrict__ bl,
-                                                           BigRegion *__restrict__ regions, int2 *__restrict__ items, int max_regions,
-                                                           int max_items, unsigned long long pool_elems, int *__restrict__ err_flag) {
+                                                           BigRegion *__restrict__ regions, int2 *__restrict__ sitems,
+                                                           int2 *__restrict__ ritems, int max_regions, int max_items,
+                                                           unsigned long long pool_elems, int *__restrict__ err_flag) {
   const int b = blockIdx.y;
   int n = reg_count[b];
   if (n > k.reg_cap) n = k.reg_cap;
   const int ri = blockIdx.x * 256 + threadIdx.x;
   if (ri >= n) return;
   const RegionGeom g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps, k.patch_rule);
-  if (g.P2 <= SMALL_CAP) return;
+  if (g.P2 <= k.p2_hi) return;
   const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
-  const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2) +
+  const int P2r = (g.P2 + 3) & ~3;
+  const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2, P2r) +
                                    (unsigned long long)g.P2 * 2 * k.desc_ps + 3ull) & ~3ull;
+  const int s_chunks = (g.P2 + BIG_SROWS - 1) / BIG_SROWS;
+  const int r_chunks = (g.P2 + BIG_RROWS - 1) / BIG_RROWS;
+  const int steps = (k.desc_ps + 3) / 4, per = big_rsteps(n_tap), r_parts = (steps + per - 1) / per;
   const int li = atomicAdd(&bl->n_regions, 1);
-  const int chunks = (g.P2 + BIG_RC - 1) / BIG_RC;
   const unsigned long long off = atomicAdd(&bl->pool_used, need);
-  const int it0 = atomicAdd(&bl->n_items, chunks);
-  if (li >= max_regions || off + need > pool_elems || it0 + chunks > max_items) { atomicExch(err_flag, 1); return; }
+  const int s0 = atomicAdd(&bl->n_sitems, s_chunks);
+  const int r0 = atomicAdd(&bl->n_ritems, r_chunks * r_parts);
+  if (li >= max_regions || off + need > pool_elems || s0 + s_chunks > max_items || r0 + r_chunks * r_parts > max_items ||
+      g.P2 >= 65536 || n_tap > k.tap_cap) {
+    atomicExch(err_flag, 1);
+    return;
+  }
   BigRegion br;
-  br.img = b; br.ri = ri; br.P2 = g.P2; br.n_tap = n_tap; br.slab = off; br.scale = g.scale; br.pad = 0;
+  br.img = b; br.ri = ri; br.P2 = g.P2; br.n_tap = n_tap; br.slab = off; br.scale = g.scale; br.P2r = P2r;
   regions[li] = br;
-  for (int c = 0; c < chunks; c++) items[it0 + c] = make_int2(li, c * BIG_RC);
+  for (int c = 0; c < s_chunks; c++) sitems[s0 + c] = make_int2(li, c * BIG_SROWS);
+  for (int c = 0; c < r_chunks; c++)
+    for (int q = 0; q < r_parts; q++) ritems[r0 + c * r_parts + q] = make_int2(li, c * BIG_RROWS | (q * per << 16));
 }
 
 // grid-stride over the big regions, block 256: taps / resampling sequence into the slab header
 __global__ __launch_bounds__(256) void big_setup_kernel(DescConst k, const BigLists *__restrict__ bl, const BigRegion *__restrict__ regions,
-                                                        int max_regions, float *__restrict__ pool) {
+                                                        int max_regions, float *__restrict__ pool, const int *__restrict__ err_flag) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // taps tap_cap | seq ps | cidx 2ps | red
+  if (*err_flag) return;   // a list or the pool overflowed in big_classify_kernel: the host reports it
   const int ps = k.desc_ps, ps2 = 2 * ps;
   float *s_tap = smem;
   float *s_seq = s_tap + k.tap_cap;
@@ -335,7 +370,6 @@ __global__ __launch_bounds__(256) void big_setup_kernel(DescConst k, const BigLi
   const int n = min(bl->n_regions, max_regions);
   for (int li = blockIdx.x; li < n; li += gridDim.x) {
     const BigRegion br = regions[li];
-    if (br.n_tap > k.tap_cap) continue;   // flagged by the host-visible error path in the sample kernel
     __syncthreads();
     blur_setup(br.P2, br.scale, ps, br.n_tap, s_tap, s_seq, s_cidx, s_red);
     float *hdr = pool + br.slab;
@@ -345,105 +379,183 @@ __global__ __launch_bounds__(256) void big_setup_kernel(DescConst k, const BigLi
   }
 }
 
-// grid-stride over the work items, block 256: rows [r0, r0+BIG_RC) of S = interpolate(img, x, y, A)
+// the wave's work item (uniform): grid-stride in units of waves
+#define BIG_WAVE_LOOP(n_items, it) \
+  for (int it = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); it < (n_items); it += (int)gridDim.x * 4)
+
+// two horizontally adjacent pixels by one 8-byte load (only 4-byte aligned)
+struct __attribute__((packed, aligned(4))) PixPair { float a, b; };
+
+// wave per sample item = 16 rows of St.  Lane (r = lane & 3, s = (lane >> 2) & 3, q = lane >> 4) owns row r0 + 4q + r and
+// the columns s, s + 4, s + 8, ...: at any time every group of 16 lanes (the unit in which the L1 looks up cache lines)
+// samples a 4 x 4 block of the grid, i.e. a compact block of the image with few cache lines per gather.  The running coordinates of interpolate() (helpers.cpp:551-626) are a sequential fp32
+// recurrence: a lane replays the row steps up to its row and then advances its own copy four column steps per sample -
+// the same additions in the same order as the reference.
 __global__ __launch_bounds__(256) void big_sample_kernel(const float *__restrict__ img_all, DescConst k, const BigLists *__restrict__ bl,
-                                                         const BigRegion *__restrict__ regions, const int2 *__restrict__ items,
+                                                         const BigRegion *__restrict__ regions, const int2 *__restrict__ sitems,
                                                          int max_items, const mods_region *__restrict__ reg_all,
-                                                         float *__restrict__ pool, int *__restrict__ err_flag) {
-  const int n_items = min(bl->n_items, max_items);
-  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-    const int2 item = items[it];
+                                                         float *__restrict__ pool, const int *__restrict__ err_flag) {
+  if (*err_flag) return;
+  const int n_items = min(bl->n_sitems, max_items);
+  const int lane = threadIdx.x & 63;
+  BIG_WAVE_LOOP(n_items, it) {
+    const int2 item = sitems[it];
     const BigRegion br = regions[item.x];
-    if (br.n_tap > k.tap_cap) { if (threadIdx.x == 0) atomicExch(err_flag, 1); continue; }
     const RegionGeom g = region_geom(reg_all[(size_t)br.img * k.max_reg + br.ri], k.desc_mr, k.desc_ps, k.patch_rule);
     const float *img = img_all + (size_t)k.w * k.h * br.img;
-    float *S = pool + br.slab + big_hdr_floats(br.n_tap, k.desc_ps);
-    const int P2 = br.P2;
-    const int r0 = item.y, r1 = min(P2, r0 + BIG_RC);
-    const bool touch = check_borders(k.w, k.h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, P2, P2);
-    const int half = P2 / 2;
-    const int total = (r1 - r0) * P2;
-    const int L = (total + 255) / 256;
-    int idx = threadIdx.x * L;
-    if (idx >= total) continue;
-    int row = r0 + idx / P2, col = idx % P2;
+    const int P2 = br.P2, P2r = br.P2r, half = P2 / 2, w = k.w, h = k.h;
+    const int row = item.y + 4 * (lane >> 4) + (lane & 3), s = (lane >> 2) & 3;
+    if (row >= P2) continue;
+    const bool touch = check_borders(w, h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, P2, P2);
     float rx = g.fx - (float)half * g.f12;
     float ry = g.fy - (float)half * g.f22;
     for (int q = 0; q < row; q++) { rx += g.f12; ry += g.f22; }
     float WX = rx - (float)half * g.f11;
     float WY = ry - (float)half * g.f21;
-    for (int q = 0; q < col; q++) { WX += g.f11; WY += g.f21; }
-    const int end = min(total, idx + L);
-    float *dst = S + (size_t)r0 * P2;
-    while (idx < end) {
-      TapLoads t[4];
-      int cnt = 0;
+    for (int q = 0; q < s; q++) { WX += g.f11; WY += g.f21; }
+    float *dst = pool + br.slab + big_hdr_floats(br.n_tap, k.desc_ps) + (size_t)s * P2r + row;
+    for (int c = s; c < P2; c += 32, dst += (size_t)32 * P2r) {
+      PixPair t0[8], t1[8];
+      float wx[8], wy[8];
+      bool ok[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (idx + u < end) {
-          t[u] = tap_load(img, k.w, k.h, WX, WY, touch);
-          cnt++;
-          if (++col == P2) {
-            col = 0;
-            rx += g.f12; ry += g.f22;
-            WX = rx - (float)half * g.f11;
-            WY = ry - (float)half * g.f21;
-          } else { WX += g.f11; WY += g.f21; }
+      for (int u = 0; u < 8; u++) {
+        ok[u] = false;
+        if (c + 4 * u < P2) {
+          int x, y;
+          if (!touch) { x = (int)WX; y = (int)WY; ok[u] = true; }
+          else { x = (int)floorf(WX); y = (int)floorf(WY); ok[u] = WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1; }
+          wx[u] = WX - (float)x;
+          wy[u] = WY - (float)y;
+          if (ok[u]) {
+            const float *Row0 = img + (size_t)y * w + x;
+            t0[u] = *(const PixPair *)Row0;
+            t1[u] = *(const PixPair *)(Row0 + w);
+          }
+          WX += g.f11; WY += g.f21; WX += g.f11; WY += g.f21; WX += g.f11; WY += g.f21; WX += g.f11; WY += g.f21;
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (u < cnt) dst[idx + u] = tap_combine(t[u]);
-      idx += cnt;
+      for (int u = 0; u < 8; u++)
+        if (c + 4 * u < P2) {
+          float v = 0.f;
+          if (ok[u]) {
+            const float I1 = wx[u] * (t0[u].b - t0[u].a) + t0[u].a;
+            v = wy[u] * (wx[u] * (t1[u].b - t1[u].a) + t1[u].a - I1) + I1;
+          }
+          dst[(size_t)4 * u * P2r] = v;
+        }
     }
   }
 }
 
-// grid-stride over the work items, block 256: rows [r0, r0+BIG_RC) of the row-pass strip T
+// wave per row-pass item = 64 rows x `steps` groups of 4 column pairs.  Lane (yq = lane & 15, pg = lane >> 4) owns
+// rows y0 + 4 yq .. + 3 and one column pair of the group:
+//   T[y][q] = sum_j tap[j] * S[y][clamp(cidx[q] - r + j)], taps left to right.
+// The two columns of a pair are x0 and x1 = x0 + 1 (their windows overlap in all but one sample, also after clamping)
+// or, for a grid line clamped at the edge, x1 = x0 (both sums are the same).  Taps are wave-uniform (scalar loads).
 __global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const BigLists *__restrict__ bl, const BigRegion *__restrict__ regions,
-                                                          const int2 *__restrict__ items, int max_items, float *__restrict__ pool) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // taps tap_cap | cidx 2ps
+                                                          const int2 *__restrict__ ritems, int max_items, float *__restrict__ pool,
+                                                          const int *__restrict__ err_flag) {
+  if (*err_flag) return;
   const int ps = k.desc_ps, ps2 = 2 * ps;
-  float *s_tap = smem;
-  int *s_cidx = (int *)(s_tap + k.tap_cap);
-  const int n_items = min(bl->n_items, max_items);
-  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-    const int2 item = items[it];
+  const int n_items = min(bl->n_ritems, max_items);
+  const int lane = threadIdx.x & 63;
+  BIG_WAVE_LOOP(n_items, it) {
+    const int2 item = ritems[it];
     const BigRegion br = regions[item.x];
-    if (br.n_tap > k.tap_cap) continue;
-    const float *hdr = pool + br.slab;
-    __syncthreads();
-    for (int i = threadIdx.x; i < br.n_tap; i += 256) s_tap[i] = hdr[i];
-    for (int i = threadIdx.x; i < ps2; i += 256) s_cidx[i] = ((const int *)(hdr + br.n_tap + ps))[i];
-    __syncthreads();
-    const int P2 = br.P2;
-    const float *S = hdr + big_hdr_floats(br.n_tap, ps);
-    float *T = (float *)S + big_s_floats(P2);
-    const int r0 = item.y, r1 = min(P2, r0 + BIG_RC);
-    row_pass(S + (size_t)r0 * P2, T + (size_t)r0 * ps2, r1 - r0, P2, ps2, br.n_tap, s_tap, s_cidx);
+    const int P2 = br.P2, P2r = br.P2r, n_tap = br.n_tap, r_tap = n_tap >> 1;
+    const int y = (item.y & 0xffff) + 4 * (lane & 15), pg = lane >> 4;
+    const int step0 = item.y >> 16, step1 = min((ps + 3) / 4, step0 + big_rsteps(n_tap));
+    const float *tap = pool + br.slab;
+    const int *cidx = (const int *)(tap + n_tap + ps);
+    const float *St = tap + big_hdr_floats(n_tap, ps);
+    float *T = (float *)St + big_s_floats(P2, P2r);
+    for (int step = step0; step < step1; step++) {
+      const int pi = step * 4 + pg;
+      const bool live = y < P2 && pi < ps;
+      const int x0 = live ? cidx[2 * pi] : r_tap, x1 = live ? cidx[2 * pi + 1] : r_tap + 1;
+      const bool interior = x0 - r_tap >= 0 && x0 + 1 + r_tap <= P2 - 1;
+      const int yy = live ? y : 0;
+      float4 s0, s1;
+      if (__all(interior)) {
+        const float *p = St + (size_t)(x0 - r_tap) * P2r + yy;
+        float4 prev = *(const float4 *)p;
+        float t = tap[0];
+        s0 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+        prev = *(const float4 *)(p + P2r);
+        s1 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+        int j = 1;
+        for (; j + 7 < n_tap; j += 8) {
+          float4 c[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) c[u] = *(const float4 *)(p + (size_t)(j + 1 + u) * P2r);
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            t = tap[j + u];
+            s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
+            s1.x += t * c[u].x; s1.y += t * c[u].y; s1.z += t * c[u].z; s1.w += t * c[u].w;
+            prev = c[u];
+          }
+        }
+        for (; j < n_tap; j++) {
+          const float4 c = *(const float4 *)(p + (size_t)(j + 1) * P2r);
+          t = tap[j];
+          s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
+          s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+          prev = c;
+        }
+      } else {
+        // windows reaching over the edge: every sample index is clamped (a_j = S[clamp(x0 - r + j)]; the second
+        // column uses a_{j+1})
+        const float *p = St + yy;
+        int xa = x0 - r_tap; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+        float4 prev = *(const float4 *)(p + (size_t)xa * P2r);
+        float t = tap[0];
+        s0 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+        xa = x0 - r_tap + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+        prev = *(const float4 *)(p + (size_t)xa * P2r);
+        s1 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+        for (int j = 1; j < n_tap; j++) {
+          xa = x0 - r_tap + j + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+          const float4 c = *(const float4 *)(p + (size_t)xa * P2r);
+          t = tap[j];
+          s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
+          s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+          prev = c;
+        }
+      }
+      if (live) {
+        if (x1 == x0) s1 = s0;
+        float *o = T + (size_t)y * ps2 + 2 * pi;
+        *(float2 *)o = make_float2(s0.x, s1.x);
+        if (y + 1 < P2) *(float2 *)(o + ps2) = make_float2(s0.y, s1.y);
+        if (y + 2 < P2) *(float2 *)(o + 2 * ps2) = make_float2(s0.z, s1.z);
+        if (y + 3 < P2) *(float2 *)(o + 3 * ps2) = make_float2(s0.w, s1.w);
+      }
+    }
   }
 }
 
-// grid-stride over the big regions, block 256: column pass + resampling -> patch
+// wave per 64 output pixels of a region: column pass + resampling -> patch
 __global__ __launch_bounds__(256) void big_colres_kernel(DescConst k, const BigLists *__restrict__ bl, const BigRegion *__restrict__ regions,
-                                                         int max_regions, const float *__restrict__ pool, float *__restrict__ patches) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // taps tap_cap | seq ps | cidx 2ps
-  const int ps = k.desc_ps, ps2 = 2 * ps, pp = ps * ps;
-  float *s_tap = smem;
-  float *s_seq = s_tap + k.tap_cap;
-  int *s_cidx = (int *)(s_seq + ps2);
-  const int n = min(bl->n_regions, max_regions);
-  for (int li = blockIdx.x; li < n; li += gridDim.x) {
+                                                         int max_regions, const float *__restrict__ pool, float *__restrict__ patches,
+                                                         const int *__restrict__ err_flag) {
+  if (*err_flag) return;
+  const int ps = k.desc_ps, pp = ps * ps, chunks = (pp + 63) / 64;
+  const int n_items = min(bl->n_regions, max_regions) * chunks;
+  const int lane = threadIdx.x & 63;
+  BIG_WAVE_LOOP(n_items, it) {
+    const int li = it / chunks, p = (it - li * chunks) * 64 + lane;
     const BigRegion br = regions[li];
-    if (br.n_tap > k.tap_cap) continue;
-    const float *hdr = pool + br.slab;
-    __syncthreads();
-    for (int i = threadIdx.x; i < br.n_tap; i += 256) s_tap[i] = hdr[i];
-    for (int i = threadIdx.x; i < ps; i += 256) s_seq[i] = hdr[br.n_tap + i];
-    for (int i = threadIdx.x; i < ps2; i += 256) s_cidx[i] = ((const int *)(hdr + br.n_tap + ps))[i];
-    __syncthreads();
-    const float *T = hdr + big_hdr_floats(br.n_tap, ps) + big_s_floats(br.P2);
-    col_resample(T, br.P2, ps, br.n_tap, br.scale, s_tap, s_seq, s_cidx, patches + ((size_t)br.img * k.reg_cap + br.ri) * pp);
+    if (p >= pp) continue;
+    const float *tap = pool + br.slab;
+    const float *seq = tap + br.n_tap;
+    const int *cidx = (const int *)(seq + ps);
+    const float *T = tap + big_hdr_floats(br.n_tap, ps) + big_s_floats(br.P2, br.P2r);
+    const float c0 = (float)(br.P2 >> 1);
+    const bool touch2 = check_borders(br.P2, br.P2, c0, c0, br.scale, 0.f, 0.f, br.scale, ps, ps);
+    patches[((size_t)br.img * k.reg_cap + br.ri) * pp + p] = col_resample_pixel(T, br.P2, ps, br.n_tap >> 1, touch2, tap, seq, cidx, p);
   }
 }
 
@@ -687,6 +799,321 @@ __global__ __launch_bounds__(256, 5) void sift_kernel(DescConst k, const float *
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// SIFT, wave-per-8-regions form.  The ordered sums (photometric mean / variance, the histogram bins, the norms) are
+// sequential chains whose cost on a SIMD is the same for 1 or 64 active lanes, so the lanes of a wave carry the chains of
+// 8 regions at once:
+//   photometric normalisation  lanes 0..7 = the 8 regions, masked values staged through LDS in 64-value chunks
+//   per pixel row r            64 lanes: normalised row r+1 -> ring; gradient / orientation of row r -> (mask*grad, o - bo0), bo0
+//                              lane (region, which of the two row bins of r, column bin) walks its <= 18 columns in order
+//                              and adds the two orientation contributions to the LDS accumulators with ds_add_f64
+//                              (LDS executes a wave's instructions in order, so every bin receives its terms in raster
+//                              order; lanes of one instruction never share a bin)
+//   norms                      lanes 0..7 run the 128-term sums, all lanes scale / clip / quantise
+// No workgroup barrier: the 4 waves of a block only share read-only tables.
+// ---------------------------------------------------------------------------------------
+constexpr int SW_R = 8;          // regions per wave
+constexpr int SW_ACC = 130;      // accumulator stride in doubles (lanes 0..7 read bank-conflict free)
+constexpr int SW_G = 68;         // photometric chunk stride in floats
+constexpr int SW_CW = 18;        // pixel columns a spatial bin spans at most (patch sizes <= 45)
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+static size_t sift_wave_scratch_floats(int ps) {   // per wave: ring 3 rows | pxrow (float2) + pad | borow + pad   (g aliases the ring)
+  const size_t row = (size_t)SW_R * ps;
+  size_t f = 3 * row + 2 * (row + SW_CW) + (row + SW_CW + 3) / 4 + 8;
+  const size_t g = (size_t)SW_R * SW_G;
+  if (f < g) f = g;
+  return (f + 3) & ~(size_t)3;
+}
+static size_t sift_wave_lds_bytes(int ps) {
+  const size_t ppa = ((size_t)ps * ps + 7) & ~(size_t)7;
+  return sizeof(float) * 2048 + sizeof(float) * (4 * ps + 4) + sizeof(unsigned short) * ppa +
+         4 * (sizeof(double) * SW_R * SW_ACC + sizeof(float) * (sift_wave_scratch_floats(ps) + 4 * SW_R)) + 64;
+}
+
+// grid = (N, n_img), block = 256 (4 independent waves): patches -> descriptors
+__global__ __launch_bounds__(256) void sift_wave_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
+                                                        const int *__restrict__ reg_count, const float *__restrict__ mask,
+                                                        const SiftTab *__restrict__ tab, int scratch_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ps = k.desc_ps, pp = ps * ps, ppa = (pp + 7) & ~7;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // block-shared, read-only after the setup (every part a multiple of 16 bytes; plain pointer arithmetic only, so
+  // that the compiler keeps treating these as LDS addresses)
+  float *s_ot = smem;   // [8][256]: the orientation coordinate o of computeSiftDescriptor per atan2LUTff (case, table index)
+  float *s_w = s_ot + 2048;
+  int *s_nmask = (int *)(s_w + 4 * ps);
+  unsigned short *s_midx = (unsigned short *)(s_nmask + 4);
+  // per wave
+  double *acc = (double *)(s_midx + ppa) + (size_t)wv * (SW_R * SW_ACC + (scratch_floats + 4 * SW_R) / 2);
+  float *scr = (float *)(acc + SW_R * SW_ACC);
+  float *s_mean = scr + scratch_floats, *s_fac = s_mean + SW_R;
+  int *s_flag = (int *)(s_fac + SW_R);
+  const int rowf = SW_R * ps;
+  float *ring = scr;                                 // [3][rowf]
+  float2 *pxrow = (float2 *)(scr + 3 * rowf);        // [rowf + SW_CW]
+  unsigned char *borow = (unsigned char *)(pxrow + rowf + SW_CW);
+  float *g = scr;                                    // photometric chunk [SW_R][SW_G], dead before the ring is filled
+
+  const double M_PI_DOUBLED = 6.28318530718;
+  sift_tables(tab, ps, s_w);
+  for (int oct = 0; oct < 8; oct++) {   // o = (float)(8.0f * ((double)ori + 2 pi) / 2 pi), siftdesc.cpp:181, for every value ori can take
+    const float ori = atan2_lut_case(oct, g_atan_lut[tid]);
+    s_ot[oct * 256 + tid] = (float)(8.0f * ((double)ori + M_PI_DOUBLED) / M_PI_DOUBLED);
+  }
+  if (tid < 64) {   // raster-ordered list of the masked pixels, one wave, ballot compaction
+    int c = 0;
+    for (int base = 0; base < pp; base += 64) {
+      const int p = base + tid;
+      const bool m = p < pp && mask[p] > 0;
+      const unsigned long long bm = __ballot(m);
+      if (m) s_midx[c + __popcll(bm & ((1ull << tid) - 1ull))] = (unsigned short)p;
+      c += __popcll(bm);
+    }
+    if (tid == 0) s_nmask[0] = c;
+  }
+  __syncthreads();
+  const int n_mask = s_nmask[0];
+  const int b = blockIdx.y;
+  mods_region *reg = reg_all + (size_t)b * k.max_reg;
+  int n = reg_count[b];
+  if (n > k.reg_cap) n = k.reg_cap;
+  const int groups = (n + SW_R - 1) / SW_R;
+  const float o_zero = (float)(8.0f * ((double)0.f + M_PI_DOUBLED) / M_PI_DOUBLED);
+
+  // histogram lane: region hr, row-bin selector hsel, column bin hbc; its column window and weights
+  const int hr = lane >> 3, hsel = (lane >> 2) & 1, hbc = lane & 3;
+  int clo = ps;
+  for (int i = ps - 1; i >= 0; i--) if (s_w[hbc * ps + i] > 0) clo = i;
+  float wcw[SW_CW];
+#pragma unroll
+  for (int q = 0; q < SW_CW; q++) wcw[q] = (clo + q < ps) ? s_w[hbc * ps + clo + q] : 0.f;
+
+  for (int grp = blockIdx.x * 4 + wv; grp < groups; grp += gridDim.x * 4) {
+    const int ri0 = grp * SW_R;
+    // patch of region slot rr (slots past the end repeat the last region; their results are not stored)
+    auto patch_of = [&](int rr) { return patches + ((size_t)b * k.reg_cap + min(ri0 + rr, n - 1)) * pp; };
+    wave_sync();
+    for (int i = lane; i < SW_R * SW_ACC; i += 64) acc[i] = 0.0;
+    if (lane < SW_R) { s_flag[lane] = 0; s_mean[lane] = 0.f; s_fac[lane] = 0.f; }
+    // ---- photometricallyNormalize, helpers.cpp:666-715: mean, then deviation, both as sequential sums over the masked pixels
+    if (k.photo) {
+      float mean_l = 0.f;
+      for (int pass = 0; pass < 2; pass++) {
+        float sum = 0.f;
+        // the values of chunk q0 + 64 are in flight while lanes 0..7 add chunk q0
+        float v[SW_R];
+        {
+          const int idx = s_midx[min(lane, n_mask - 1)];
+#pragma unroll
+          for (int rr = 0; rr < SW_R; rr++) v[rr] = patch_of(rr)[idx];
+        }
+        for (int q0 = 0; q0 < n_mask; q0 += 64) {
+          const int cnt = min(64, n_mask - q0);
+          wave_sync();
+#pragma unroll
+          for (int rr = 0; rr < SW_R; rr++) {
+            float x = v[rr];
+            if (pass) { const float d = s_mean[rr] - x; x = d * d; }
+            g[rr * SW_G + lane] = x;
+          }
+          if (q0 + 64 < n_mask) {
+            const int idx = s_midx[min(q0 + 64 + lane, n_mask - 1)];
+#pragma unroll
+            for (int rr = 0; rr < SW_R; rr++) v[rr] = patch_of(rr)[idx];
+          }
+          wave_sync();
+          if (lane < SW_R) {
+            const float *gl = g + lane * SW_G;
+            int q = 0;
+            for (; q + 3 < cnt; q += 4) {
+              const float4 a = *(const float4 *)(gl + q);
+              sum += a.x; sum += a.y; sum += a.z; sum += a.w;
+            }
+            for (; q < cnt; q++) sum += gl[q];
+          }
+        }
+        if (lane < SW_R) {
+          if (pass == 0) { mean_l = sum / (float)n_mask; s_mean[lane] = mean_l; }
+          else {
+            const float var = sqrtf(sum / (float)n_mask);
+            if (!((double)var < 0.0001)) { s_flag[lane] = 1; s_fac[lane] = 50.0f / var; }
+          }
+        }
+        wave_sync();
+      }
+    }
+    wave_sync();
+    // normalised patch row -> ring slot; the row after next is fetched into registers while the current row is worked on
+    constexpr int RL = 8;                               // >= ceil(SW_R * ps / 64) for ps <= 64
+    float nxt[RL];
+    auto fetch_row = [&](int r) {
+#pragma unroll
+      for (int u = 0; u < RL; u++) {
+        const int e = lane + 64 * u;
+        if (e < rowf) { const int rr = e / ps; nxt[u] = patch_of(rr)[r * ps + e - rr * ps]; }
+      }
+    };
+    auto store_row = [&](int r) {
+      float *dst = ring + (r % 3) * rowf;
+#pragma unroll
+      for (int u = 0; u < RL; u++) {
+        const int e = lane + 64 * u;
+        if (e < rowf) {
+          const int rr = e / ps;
+          float v = nxt[u];
+          if (s_flag[rr]) {
+            v = 128 + s_fac[rr] * (v - s_mean[rr]);
+            if (v > 255) v = 255;
+            if (v < 0) v = 0;
+          }
+          dst[e] = v;
+        }
+      }
+    };
+    fetch_row(0); store_row(0);
+    if (ps > 1) { fetch_row(1); store_row(1); }
+    // ---- computeSiftDescriptor / samplePatch (siftdesc.cpp:73-131, 160-198), one pixel row at a time
+    for (int r = 0; r < ps; r++) {
+      if (r + 2 < ps) fetch_row(r + 2);
+      wave_sync();
+      {
+        const float *R0 = ring + (r % 3) * rowf;
+        const float *Rm = ring + ((r + 2) % 3) * rowf;   // row r - 1
+        const float *Rp = ring + ((r + 1) % 3) * rowf;   // row r + 1
+        for (int e = lane; e < rowf; e += 64) {
+          const int rr = e / ps, c = e - rr * ps;
+          float xgrad, ygrad;
+          if (c == 0) xgrad = R0[e + 1] - R0[e];
+          else if (c == ps - 1) xgrad = R0[e] - R0[e - 1];
+          else xgrad = R0[e + 1] - R0[e - 1];
+          if (r == 0) ygrad = Rp[e] - R0[e];
+          else if (r == ps - 1) ygrad = R0[e] - Rm[e];
+          else ygrad = Rp[e] - Rm[e];
+          const float grad = sqrtf(xgrad * xgrad + ygrad * ygrad);
+          const AtanSel as = atan2_lut_sel(ygrad, xgrad);
+          const float o = as.zero ? o_zero : s_ot[as.oct * 256 + as.idx];
+          const int bo0 = (int)o;
+          pxrow[e] = make_float2(mask[r * ps + c] * grad, o - bo0);
+          borow[e] = (unsigned char)(bo0 % 8);
+        }
+      }
+      wave_sync();
+      {
+        // the row's two spatial row bins (bin0 / bin1 and their weights; already multiplied by 8 = orientation bins)
+        const int rb = hsel ? tab->bin1[r] : tab->bin0[r];
+        const float wrr = hsel ? tab->w1[r] : tab->w0[r];
+        if (wrr > 0) {
+          double *abin = acc + hr * SW_ACC + rb * 4 + hbc * 8;
+          const float2 *px = pxrow + hr * ps + clo;
+          const unsigned char *bop = borow + hr * ps + clo;
+#pragma unroll
+          for (int q = 0; q < SW_CW; q++) {
+            const float2 pv = px[q];
+            const int bo0 = bop[q];
+            const float val = wrr * (wcw[q] * pv.x);
+            if (val > 0) {
+              const float c0 = val * (1.0f - pv.y), c1 = val * pv.y;
+#ifdef SIFT_RMW
+              abin[bo0] += (double)c0;
+              abin[(bo0 + 1) & 7] += (double)c1;
+#else
+              __hip_atomic_fetch_add(abin + bo0, (double)c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              __hip_atomic_fetch_add(abin + ((bo0 + 1) & 7), (double)c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
+            }
+          }
+        }
+      }
+      if (r + 2 < ps) store_row(r + 2);   // slot of row r - 1, which the gradients of row r have finished reading
+    }
+    wave_sync();
+    // ---- normalize / clip / renormalise (siftdesc.cpp:133-158, 199-210, 248-257) and the RootSIFT mapping
+    unsigned long long redo = ~0ull;   // bit 8 rr.. : region rr still takes part
+    for (int pass = 0; pass < 2; pass++) {
+      if (lane < SW_R && ((redo >> (8 * lane)) & 1)) {
+        const double *v = acc + lane * SW_ACC;
+        double len = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < 128; i += 8) {
+          double x[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) x[q] = v[i + q];
+#pragma unroll
+          for (int q = 0; q < 8; q++) x[q] = x[q] * x[q];
+          len += x[0] + x[1] + x[2] + x[3];
+          len += x[4] + x[5] + x[6] + x[7];
+        }
+        len = sqrt(len);
+        ((double *)g)[lane] = 1.0 / len;     // the ring / chunk area is idle here
+      }
+      wave_sync();
+      bool changed = false;
+      {
+        const int rr = lane >> 3;
+        if ((redo >> (8 * rr)) & 1) {
+          const double inv = ((const double *)g)[rr];
+          double *v = acc + rr * SW_ACC;
+          for (int i = lane & 7; i < 128; i += 8) {
+            double x = v[i] * inv;
+            if (pass == 0 && x > k.max_bin) { x = k.max_bin; changed = true; }
+            v[i] = x;
+          }
+        }
+      }
+      const unsigned long long ch = __ballot(changed);
+      unsigned long long next = 0;
+      for (int rr = 0; rr < SW_R; rr++)
+        if ((ch >> (8 * rr)) & 0xffull) next |= 0xffull << (8 * rr);
+      redo = next;
+      wave_sync();
+      if (!redo) break;
+    }
+    if (k.root) {
+      if (lane < SW_R) {
+        const double *v = acc + lane * SW_ACC;
+        double sum = 0.;
+#pragma unroll 1
+        for (int i = 0; i < 128; i += 8) {
+          double x[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) x[q] = v[i + q];
+#pragma unroll
+          for (int q = 0; q < 8; q++) sum += fabs(x[q]);
+        }
+        ((double *)g)[lane] = sum;
+      }
+      wave_sync();
+    }
+    {
+      const int rr = lane >> 3;
+      if (ri0 + rr < n) {
+        const double *v = acc + rr * SW_ACC;
+        const double rs = k.root ? ((const double *)g)[rr] : 1.0;
+        uint32_t *out = (uint32_t *)reg[ri0 + rr].desc;
+        for (int w4 = lane & 7; w4 < 32; w4 += 8) {
+          uint32_t word = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const double x = v[4 * w4 + q];
+            const double y = k.root ? sqrt(x / rs) : x;
+            int bq = (int)(512.0 * y + 0.5);
+            bq = bq < 255 ? bq : 255;
+            bq = bq > 0 ? bq : 0;
+            word |= (uint32_t)bq << (8 * q);
+          }
+          out[w4] = word;
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sift_patch_test_kernel(const float *__restrict__ patch, int ps, int root, double max_bin,
                                                               const float *__restrict__ mask, const SiftTab *__restrict__ tab,
                                                               uint8_t *out) {
@@ -705,9 +1132,9 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   const int ps = k.desc_ps, ps2 = 2 * ps, pp = ps * ps;
   // HBM layout of the description scratch: patch store [n_img][reg_cap][ps*ps] | big-tier bookkeeping | slab pool
   const size_t patch_elems = (size_t)n_img * k.reg_cap * pp;
-  const int max_big = 1 << 16, max_items = 1 << 19;
-  const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + sizeof(int2) * max_items + 15) / 4;
-  const unsigned long long pool_elems = 768ull << 20;   // 3 GiB of slabs
+  const int max_big = 1 << 17, max_items = 1 << 20;
+  const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + 2 * sizeof(int2) * max_items + 15) / 4;
+  const unsigned long long pool_elems = 1024ull << 20;   // 4 GiB of slabs
   const size_t need = patch_elems + book_elems + pool_elems;
   if (need > ctx->desc_scratch_elems) {
     MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -719,24 +1146,39 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   float *patches = ctx->desc_scratch;
   BigLists *bl = (BigLists *)(ctx->desc_scratch + patch_elems);
   BigRegion *bregs = (BigRegion *)(bl + 1);
-  int2 *items = (int2 *)(bregs + max_big);
+  int2 *sitems = (int2 *)(bregs + max_big);
+  int2 *ritems = sitems + max_items;
   float *pool = ctx->desc_scratch + patch_elems + book_elems;
   MODS_HIP_CHECK(hipMemsetAsync(bl, 0, sizeof(BigLists), ctx->stream));
   k.tap_cap = 4096;
+  static const int small_cap = [] {   // P2 limit of the LDS tier (tuning knob, <= SMALL_CAP)
+    const char *e = getenv("MODS_SMALL_CAP");
+    const int v = e ? atoi(e) : SMALL_CAP;
+    return v < 0 ? 0 : (v > SMALL_CAP ? SMALL_CAP : v);
+  }();
+  k.p2_hi = small_cap;
   const size_t ldsS = sizeof(float) * ((size_t)SMALL_CAP * SMALL_CAP + (size_t)SMALL_CAP * ps2 + 2 * ps2 + 32) + 32;
+  hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
+                     ctx->region_count, bl, bregs, sitems, ritems, max_big, max_items, pool_elems, ctx->desc_err_dev);
   hipLaunchKernelGGL(extract_small_kernel, dim3(2048, n_img), dim3(256), ldsS, ctx->stream, img_dev, k, ctx->regions_dev,
                      ctx->region_count, patches);
-  hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
-                     ctx->region_count, bl, bregs, items, max_big, max_items, pool_elems, ctx->desc_err_dev);
   const size_t ldsH = sizeof(float) * (k.tap_cap + 4 * ps2) + 32;
-  hipLaunchKernelGGL(big_setup_kernel, dim3(1024), dim3(256), ldsH, ctx->stream, k, bl, bregs, max_big, pool);
-  hipLaunchKernelGGL(big_sample_kernel, dim3(4096), dim3(256), 0, ctx->stream, img_dev, k, bl, bregs, items, max_items,
+  hipLaunchKernelGGL(big_setup_kernel, dim3(1024), dim3(256), ldsH, ctx->stream, k, bl, bregs, max_big, pool, ctx->desc_err_dev);
+  hipLaunchKernelGGL(big_sample_kernel, dim3(4096), dim3(256), 0, ctx->stream, img_dev, k, bl, bregs, sitems, max_items,
                      ctx->regions_dev, pool, ctx->desc_err_dev);
-  hipLaunchKernelGGL(big_rowpass_kernel, dim3(4096), dim3(256), ldsH, ctx->stream, k, bl, bregs, items, max_items, pool);
-  hipLaunchKernelGGL(big_colres_kernel, dim3(2048), dim3(256), ldsH, ctx->stream, k, bl, bregs, max_big, pool, patches);
-  if (run_sift)
+  hipLaunchKernelGGL(big_rowpass_kernel, dim3(4096), dim3(256), 0, ctx->stream, k, bl, bregs, ritems, max_items, pool,
+                     ctx->desc_err_dev);
+  hipLaunchKernelGGL(big_colres_kernel, dim3(4096), dim3(256), 0, ctx->stream, k, bl, bregs, max_big, pool, patches, ctx->desc_err_dev);
+  static const bool sift_block_form = getenv("MODS_SIFT_BLOCK") != nullptr;   // the block-per-region form (A/B measurements)
+  if (run_sift && (sift_block_form || ps > 45))
     hipLaunchKernelGGL(sift_kernel, dim3(2048, n_img), dim3(256), sift_lds_bytes(ps), ctx->stream, k, patches, ctx->regions_dev,
                        ctx->region_count, dmask, tab);
+  else if (run_sift) {
+    static const hipError_t attr = hipFuncSetAttribute((const void *)sift_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    MODS_HIP_CHECK(attr);
+    hipLaunchKernelGGL(sift_wave_kernel, dim3(1024, n_img), dim3(256), sift_wave_lds_bytes(ps), ctx->stream, k, patches,
+                       ctx->regions_dev, ctx->region_count, dmask, tab, (int)sift_wave_scratch_floats(ps));
+  }
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }
