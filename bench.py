@@ -5,7 +5,7 @@ synthetic 1920x1080 pairs, HessianAffine + RootSIFT, one identity view per image
 
   python bench.py --gpus N --steps K --warmup W
 
-A step = one batch of --pairs-per-step (default 16) image pairs through the whole hot path (detect, describe,
+A step = one batch of --pairs-per-step (default 32) image pairs through the whole hot path (detect, describe,
 match, duplicate filter, LO-RANSAC) with all images already resident in HBM; the reported value is pairs / second.  N > 1 is launched by torch.distributed.run, one rank per GPU; pairs are independent
 units, so every rank works on its own pairs (weak scaling, no data-path collective) and the reported
 value is all pairs / max-over-ranks time.
@@ -163,11 +163,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs cycled through the steps")
-    ap.add_argument("--pairs-per-step", type=int, default=16, help="image pairs in the batch that one step processes")
+    ap.add_argument("--pairs-per-step", type=int, default=32, help="image pairs in the batch that one step processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gpu-workers", type=int, default=2, help="pipeline threads running detect/describe/match (one context each)")
-    ap.add_argument("--verify-workers", type=int, default=4, help="pipeline threads running duplicate filter + LO-RANSAC")
-    ap.add_argument("--pairs-per-batch", type=int, default=4, help="pairs a GPU worker pushes through detect/describe as one batch of launches")
+    ap.add_argument("--gpu-workers", type=int, default=3, help="pipeline threads running detect/describe/match (one context each)")
+    ap.add_argument("--verify-workers", type=int, default=6, help="pipeline threads running duplicate filter + LO-RANSAC")
+    ap.add_argument("--pairs-per-batch", type=int, default=8, help="pairs a GPU worker pushes through detect/describe as one batch of launches")
     ap.add_argument("--serial", action="store_true", help="no cross-pair overlap: one mods_match_pair_dev call per step")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs[]: c2 = the headline 1080p pair (default, what the driver runs); c3 = view-synthesis "

@@ -20,6 +20,18 @@ namespace mods {
 
 struct OriOut { double a11, a12, a21, a22; int alive; int pad; };
 
+// Histogram bin of EstimateDominantAnglesFunctor, (int)(36 * (ori / pi + 1) / 2) (synth-detection.cpp:870), for every
+// value ori = atan2LUTff(.) can take: [8 cases][256 table entries], see atan2_lut_sel.  Rewritten (same values) by
+// ori_bin_table_kernel at the start of every orientation pass.
+__device__ unsigned char g_ori_bin[2048];
+__global__ __launch_bounds__(256) void ori_bin_table_kernel() {
+  const float PIf = 3.14159265358979323846f;
+  const int bins = 36;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const float ori = atan2_lut_case(e >> 8, g_atan_lut[e & 255]);
+  g_ori_bin[e] = (unsigned char)(int)(bins * (ori / PIf + 1.0f) / 2.0f);
+}
+
 // ---------------------------------------------------------------------------------------
 // EstimateDominantAnglesFunctor for maxAngles = 1 on a ps x ps patch held in LDS.
 // Block = 64 lanes.  s_val/s_bin: ps*(ps-2) entries, s_hist: 40 floats.  Returns found/angle
@@ -37,16 +49,18 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
     float v = 0.f;
     if (p < n) {
       const int r = 1 + p / ps, c = p - (r - 1) * ps;
-      float mag = 0.f, ori = 0.f;
+      float mag = 0.f;
+      int obin = 0;
       if (c >= 1 && c < ps - 1) {
         const float xgrad = s_patch[r * ps + c + 1] - s_patch[r * ps + c - 1];
         const float ygrad = s_patch[(r + 1) * ps + c] - s_patch[(r - 1) * ps + c];
         mag = sqrtf(xgrad * xgrad + ygrad * ygrad);
-        ori = atan2_lut_ff_t(ygrad, xgrad, s_lut);
+        const AtanSel as = atan2_lut_sel(ygrad, xgrad);
+        obin = as.zero ? (int)(bins * (0.f / PIf + 1.0f) / 2.0f) : g_ori_bin[as.oct * 256 + as.idx];
       }
       const float m = orimask[r * ps + c];
       if (m > 0 && (double)mag > 1.0) {
-        bin = (int)(bins * (ori / PIf + 1.0f) / 2.0f);
+        bin = obin;
         v = mag * m;
       }
     }
@@ -421,6 +435,7 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   {
     StageScope ts(ctx, MODS_STAGE_ORIENT);
     const size_t lds = orient_lds_bytes(k.ori_ps);
+    hipLaunchKernelGGL(ori_bin_table_kernel, dim3(8), dim3(256), 0, ctx->stream);
     hipLaunchKernelGGL(orient_kernel, dim3(8192, n_img), dim3(64), lds, ctx->stream, img_dev, k, ctx->keys_dev, key_count,
                        orimask, (OriOut *)ctx->ori_dev);
     hipLaunchKernelGGL(compact_regions_kernel, dim3(1, n_img), dim3(1024), 0, ctx->stream, k, ctx->keys_dev, key_count,
@@ -441,6 +456,7 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
 
 int launch_dominant_angle_test(mods_ctx *ctx, const float *patch_dev, int ps, double th, float *out_dev) {
   const size_t lds = orient_lds_bytes(ps);
+  hipLaunchKernelGGL(ori_bin_table_kernel, dim3(8), dim3(256), 0, ctx->stream);
   hipLaunchKernelGGL(dominant_angle_test_kernel, dim3(1), dim3(64), lds, ctx->stream, patch_dev, ps, th,
                      ctx->desc_tables_dev, out_dev);
   MODS_HIP_CHECK(hipGetLastError());

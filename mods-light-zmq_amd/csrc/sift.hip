@@ -269,9 +269,10 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
                                                             float *__restrict__ patches) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ps = k.desc_ps, pp = ps * ps, ps2 = 2 * ps;
+  const int cap = k.p2_hi > 4 ? k.p2_hi : 4;       // (the direct branch writes to the patch store, not to LDS)
   float *s_S = smem;
-  float *s_T = s_S + SMALL_CAP * SMALL_CAP;
-  float *s_seq = s_T + SMALL_CAP * ps2;
+  float *s_T = s_S + ((cap * cap + 3) & ~3);
+  float *s_seq = s_T + cap * ps2;
   int *s_cidx = (int *)(s_seq + ps2);
   float *s_tap = (float *)(s_cidx + ps2);
   double *s_red = (double *)(((uintptr_t)(s_tap + 32) + 7) & ~(uintptr_t)7);
@@ -1134,7 +1135,8 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   const size_t patch_elems = (size_t)n_img * k.reg_cap * pp;
   const int max_big = 1 << 17, max_items = 1 << 20;
   const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + 2 * sizeof(int2) * max_items + 15) / 4;
-  const unsigned long long pool_elems = 1024ull << 20;   // 4 GiB of slabs
+  // slab pool: ~45 M floats per 1080p image in practice; 64 M per image of the batch, at least 1 GiB
+  const unsigned long long pool_elems = std::max<unsigned long long>(256ull << 20, (unsigned long long)n_img * (64ull << 20));
   const size_t need = patch_elems + book_elems + pool_elems;
   if (need > ctx->desc_scratch_elems) {
     MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1157,7 +1159,8 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
     return v < 0 ? 0 : (v > SMALL_CAP ? SMALL_CAP : v);
   }();
   k.p2_hi = small_cap;
-  const size_t ldsS = sizeof(float) * ((size_t)SMALL_CAP * SMALL_CAP + (size_t)SMALL_CAP * ps2 + 2 * ps2 + 32) + 32;
+  const size_t capS = small_cap > 4 ? small_cap : 4;
+  const size_t ldsS = sizeof(float) * (((capS * capS + 3) & ~(size_t)3) + capS * ps2 + 2 * ps2 + 32) + 32;
   hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
                      ctx->region_count, bl, bregs, sitems, ritems, max_big, max_items, pool_elems, ctx->desc_err_dev);
   hipLaunchKernelGGL(extract_small_kernel, dim3(2048, n_img), dim3(256), ldsS, ctx->stream, img_dev, k, ctx->regions_dev,
