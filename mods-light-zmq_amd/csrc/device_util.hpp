@@ -24,22 +24,28 @@ __device__ __forceinline__ bool check_borders(int img_w, int img_h, float ofsx, 
   return touch;
 }
 
+// two horizontally adjacent pixels by one 8-byte load (only 4-byte aligned): a gather costs the memory pipeline per lane
+// and per instruction, so the four pixels of a bilinear tap are fetched with two loads
+struct __attribute__((packed, aligned(4))) PixPair { float a, b; };
+
 // One bilinear tap of interpolate(), helpers.cpp:551-626: `touch` selects the unchecked
 // (int-cast) branch or the per-pixel checked (floor, zero fill) branch.
 __device__ __forceinline__ float bilinear_tap(const float *__restrict__ im, int w, int h, float WX, float WY, bool touch) {
   if (!touch) {
     const int x = (int)WX, y = (int)WY;
     const float wx = WX - (float)x;
-    const float *Row0 = im + (size_t)y * w, *Row1 = Row0 + w;
-    const float I1 = wx * (Row0[x + 1] - Row0[x]) + Row0[x];
-    return (WY - y) * (wx * (Row1[x + 1] - Row1[x]) + Row1[x] - I1) + I1;
+    const float *Row0 = im + (size_t)y * w + x;
+    const PixPair p0 = *(const PixPair *)Row0, p1 = *(const PixPair *)(Row0 + w);
+    const float I1 = wx * (p0.b - p0.a) + p0.a;
+    return (WY - y) * (wx * (p1.b - p1.a) + p1.a - I1) + I1;
   }
   const int x = (int)floorf(WX), y = (int)floorf(WY);
   if (WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1) {
     const float wx = WX - x;
-    const float *Row0 = im + (size_t)y * w, *Row1 = Row0 + w;
-    const float I1 = wx * (Row0[x + 1] - Row0[x]) + Row0[x];
-    return (WY - y) * (wx * (Row1[x + 1] - Row1[x]) + Row1[x] - I1) + I1;
+    const float *Row0 = im + (size_t)y * w + x;
+    const PixPair p0 = *(const PixPair *)Row0, p1 = *(const PixPair *)(Row0 + w);
+    const float I1 = wx * (p0.b - p0.a) + p0.a;
+    return (WY - y) * (wx * (p1.b - p1.a) + p1.a - I1) + I1;
   }
   return 0.f;
 }
@@ -56,7 +62,8 @@ __device__ __forceinline__ TapLoads tap_load(const float *__restrict__ im, int w
   t.wy = WY - (float)y;
   if (t.valid) {
     const float *Row0 = im + (size_t)y * w + x;
-    t.r00 = Row0[0]; t.r01 = Row0[1]; t.r10 = Row0[w]; t.r11 = Row0[w + 1];
+    const PixPair p0 = *(const PixPair *)Row0, p1 = *(const PixPair *)(Row0 + w);
+    t.r00 = p0.a; t.r01 = p0.b; t.r10 = p1.a; t.r11 = p1.b;
   } else { t.r00 = t.r01 = t.r10 = t.r11 = 0.f; }
   return t;
 }

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
   if (n > k.reg_cap) n = k.reg_cap;
   for (int ri = blockIdx.x; ri < n; ri += gridDim.x) {
     const RegionGeom g = region_geom(reg[ri], k.desc_mr, ps, k.patch_rule);
-    if (g.P2 > k.p2_hi) continue;
+    if (g.P2 > k.p2_hi || g.P2 <= k.p2_lo) continue;
     float *out = patches + ((size_t)b * k.reg_cap + ri) * pp;
     __syncthreads();
     if (g.P2 > 0) {
@@ -383,9 +383,6 @@ __global__ __launch_bounds__(256) void big_setup_kernel(DescConst k, const BigLi
 // the wave's work item (uniform): grid-stride in units of waves
 #define BIG_WAVE_LOOP(n_items, it) \
   for (int it = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); it < (n_items); it += (int)gridDim.x * 4)
-
-// two horizontally adjacent pixels by one 8-byte load (only 4-byte aligned)
-struct __attribute__((packed, aligned(4))) PixPair { float a, b; };
 
 // wave per sample item = 16 rows of St.  Lane (r = lane & 3, s = (lane >> 2) & 3, q = lane >> 4) owns row r0 + 4q + r and
 // the columns s, s + 4, s + 8, ...: at any time every group of 16 lanes (the unit in which the L1 looks up cache lines)
@@ -1159,12 +1156,22 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
     return v < 0 ? 0 : (v > SMALL_CAP ? SMALL_CAP : v);
   }();
   k.p2_hi = small_cap;
-  const size_t capS = small_cap > 4 ? small_cap : 4;
-  const size_t ldsS = sizeof(float) * (((capS * capS + 3) & ~(size_t)3) + capS * ps2 + 2 * ps2 + 32) + 32;
   hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
                      ctx->region_count, bl, bregs, sitems, ritems, max_big, max_items, pool_elems, ctx->desc_err_dev);
-  hipLaunchKernelGGL(extract_small_kernel, dim3(2048, n_img), dim3(256), ldsS, ctx->stream, img_dev, k, ctx->regions_dev,
-                     ctx->region_count, patches);
+  // LDS tier in two launches (P2 <= 48 takes half the LDS of the 80 class: twice the workgroups per CU);
+  // the HBM tier takes P2 > small_cap
+  {
+    const int tiers[3] = {-1, small_cap < 48 ? small_cap : 48, small_cap};
+    for (int t = 0; t < 2; t++) {
+      if (tiers[t + 1] <= tiers[t]) continue;
+      DescConst kt = k;
+      kt.p2_lo = tiers[t]; kt.p2_hi = tiers[t + 1];
+      const size_t capS = kt.p2_hi > 4 ? kt.p2_hi : 4;
+      const size_t ldsS = sizeof(float) * (((capS * capS + 3) & ~(size_t)3) + capS * ps2 + 2 * ps2 + 32) + 32;
+      hipLaunchKernelGGL(extract_small_kernel, dim3(2048, n_img), dim3(256), ldsS, ctx->stream, img_dev, kt, ctx->regions_dev,
+                         ctx->region_count, patches);
+    }
+  }
   const size_t ldsH = sizeof(float) * (k.tap_cap + 4 * ps2) + 32;
   hipLaunchKernelGGL(big_setup_kernel, dim3(1024), dim3(256), ldsH, ctx->stream, k, bl, bregs, max_big, pool, ctx->desc_err_dev);
   hipLaunchKernelGGL(big_sample_kernel, dim3(4096), dim3(256), 0, ctx->stream, img_dev, k, bl, bregs, sitems, max_items,
