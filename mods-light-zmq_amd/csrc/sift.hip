@@ -172,6 +172,99 @@ __device__ __forceinline__ void row_pass(const float *S, float *T, int rows, int
   }
 }
 
+// interpolate() as sample_region, stored transposed: dst[col * stride + row] (stride = n rounded up to 4)
+__device__ void sample_region_t(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12, float a21,
+                                float a22, int n, int stride, float *dst) {
+  const bool touch = check_borders(w, h, fx, fy, a11, a12, a21, a22, n, n);
+  const int half = n / 2;
+  const int total = n * n;
+  const int L = (total + 255) / 256;
+  int idx = threadIdx.x * L;
+  if (idx >= total) return;
+  int row = idx / n, col = idx - row * n;
+  float rx = fx - (float)half * a12;
+  float ry = fy - (float)half * a22;
+  for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
+  float WX = rx - (float)half * a11;
+  float WY = ry - (float)half * a21;
+  for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
+  const int end = min(total, idx + L);
+  while (idx < end) {
+    TapLoads t[8];
+    int at[8];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (idx + u < end) {
+        t[u] = tap_load(img, w, h, WX, WY, touch);
+        at[u] = col * stride + row;
+        cnt++;
+        if (++col == n) {
+          col = 0; row++;
+          rx += a12; ry += a22;
+          WX = rx - (float)half * a11;
+          WY = ry - (float)half * a21;
+        } else { WX += a11; WY += a21; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (u < cnt) dst[at[u]] = tap_combine(t[u]);
+    idx += cnt;
+  }
+}
+
+// row pass of the separable blur at the needed columns from a transposed tile St[col][stride]:
+//   T[y][q] = sum_j tap[j] * S[y][clamp(cidx[q] - r + j)], taps left to right.
+// A thread owns four consecutive rows (one float4 per tap) of one column pair (x0, x1): x1 = x0 + 1, whose window is the
+// window of x0 shifted by one sample (also after clamping), or x1 = x0 for a grid line clamped at the edge.
+__device__ __forceinline__ void row_pass_t(const float *St, float *T, int P2, int stride, int ps, int n_tap, const float *s_tap,
+                                           const int *s_cidx) {
+  const int r_tap = n_tap >> 1, nq = stride >> 2, ps2 = 2 * ps;
+  for (int e = threadIdx.x; e < nq * ps; e += 256) {
+    const int pi = e / nq, y = 4 * (e - pi * nq);
+    const int x0 = s_cidx[2 * pi], x1 = s_cidx[2 * pi + 1];
+    const float *p = St + y;
+    int xa = x0 - r_tap; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+    float4 prev = *(const float4 *)(p + xa * stride);
+    float t = s_tap[0];
+    float4 s0 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+    xa = x0 - r_tap + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+    prev = *(const float4 *)(p + xa * stride);
+    float4 s1 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+    int j = 1;
+    for (; j + 3 < n_tap; j += 4) {
+      float4 c[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        xa = x0 - r_tap + j + u + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+        c[u] = *(const float4 *)(p + xa * stride);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        t = s_tap[j + u];
+        s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
+        s1.x += t * c[u].x; s1.y += t * c[u].y; s1.z += t * c[u].z; s1.w += t * c[u].w;
+        prev = c[u];
+      }
+    }
+    for (; j < n_tap; j++) {
+      xa = x0 - r_tap + j + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+      const float4 c = *(const float4 *)(p + xa * stride);
+      t = s_tap[j];
+      s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
+      s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+      prev = c;
+    }
+    if (x1 == x0) s1 = s0;
+    float *o = T + y * ps2 + 2 * pi;
+    *(float2 *)o = make_float2(s0.x, s1.x);
+    if (y + 1 < P2) *(float2 *)(o + ps2) = make_float2(s0.y, s1.y);
+    if (y + 2 < P2) *(float2 *)(o + 2 * ps2) = make_float2(s0.z, s1.z);
+    if (y + 3 < P2) *(float2 *)(o + 3 * ps2) = make_float2(s0.w, s1.w);
+  }
+}
+
 // column pass value at (needed row y, strip column q): centre tap first, symmetric pairs
 __device__ __forceinline__ float col_value(const float *T, int P2, int ps2, int y, int q, int r_tap, const float *s_tap) {
   float s = s_tap[r_tap] * T[(size_t)y * ps2 + q];
@@ -271,7 +364,7 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
   const int ps = k.desc_ps, pp = ps * ps, ps2 = 2 * ps;
   const int cap = k.p2_hi > 4 ? k.p2_hi : 4;       // (the direct branch writes to the patch store, not to LDS)
   float *s_S = smem;
-  float *s_T = s_S + ((cap * cap + 3) & ~3);
+  float *s_T = s_S + cap * ((cap + 3) & ~3);
   float *s_seq = s_T + cap * ps2;
   int *s_cidx = (int *)(s_seq + ps2);
   float *s_tap = (float *)(s_cidx + ps2);
@@ -281,23 +374,44 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
   const mods_region *reg = reg_all + (size_t)b * k.max_reg;
   int n = reg_count[b];
   if (n > k.reg_cap) n = k.reg_cap;
+#ifdef EXTRACT_PROF
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
+  int pn = 0;
+#define PROF_MARK(i) { __syncthreads(); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pl; pl = t_; }
+#else
+#define PROF_MARK(i)
+#endif
   for (int ri = blockIdx.x; ri < n; ri += gridDim.x) {
     const RegionGeom g = region_geom(reg[ri], k.desc_mr, ps, k.patch_rule);
     if (g.P2 > k.p2_hi || g.P2 <= k.p2_lo) continue;
     float *out = patches + ((size_t)b * k.reg_cap + ri) * pp;
     __syncthreads();
+    PROF_MARK(0)
     if (g.P2 > 0) {
       const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
-      sample_region(img, k.w, k.h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, g.P2, s_S);
+      const int stride = (g.P2 + 3) & ~3;
+      sample_region_t(img, k.w, k.h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, g.P2, stride, s_S);
+      PROF_MARK(1)
       blur_setup(g.P2, g.scale, ps, n_tap, s_tap, s_seq, s_cidx, s_red);
-      row_pass(s_S, s_T, g.P2, g.P2, ps2, n_tap, s_tap, s_cidx);
+      PROF_MARK(2)
+      row_pass_t(s_S, s_T, g.P2, stride, ps, n_tap, s_tap, s_cidx);
       __syncthreads();
+      PROF_MARK(3)
       col_resample(s_T, g.P2, ps, n_tap, g.scale, s_tap, s_seq, s_cidx, out);
+      PROF_MARK(4)
+#ifdef EXTRACT_PROF
+      pn++;
+#endif
     } else {
       // direct branch: interpolate(img, x, y, A*scale) -> ps x ps
       sample_region(img, k.w, k.h, g.fx, g.fy, g.f11 * g.scale, g.f12 * g.scale, g.f21 * g.scale, g.f22 * g.scale, ps, out);
     }
   }
+#ifdef EXTRACT_PROF
+  if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x % 512) == 7)
+    printf("extract_small prof: block %d tier %d regions %d cycles: skip %llu sample %llu setup %llu rowpass %llu colres %llu\n", blockIdx.x,
+           k.p2_hi, pn, pt[0], pt[1], pt[2], pt[3], pt[4]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -312,12 +426,15 @@ constexpr int BIG_RROWS = 64;         // rows per row-pass item
 constexpr int BIG_RLOADS = 128;       // float4 loads per lane a row-pass item aims at
 struct BigRegion { int img, ri, P2, n_tap; unsigned long long slab; float scale; int P2r; };   // slab: float offset in the pool
 struct BigLists {                     // device-resident bookkeeping, zeroed before every batch
-  int n_regions, n_sitems, n_ritems, pad;
+  int n_regions, n_sitems, n_ritems, n_fitems;
   unsigned long long pool_used;
 };
+// regions up to this size take the fused sample + row-pass kernel (S stays in LDS, no S slab); larger ones the phase kernels
+constexpr int BIG_FUSE_P2 = 256;
+__device__ __forceinline__ int big_fuse_rows(int P2) { return P2 <= 128 ? 64 : 32; }   // rows per fused item: rows * P2 floats <= 32 KB
 
 __device__ __forceinline__ int big_hdr_floats(int n_tap, int ps) { return (n_tap + 3 * ps + 8 + 3) & ~3; }
-__device__ __forceinline__ unsigned long long big_s_floats(int P2, int P2r) { return (unsigned long long)P2 * P2r; }
+__device__ __forceinline__ unsigned long long big_s_floats(int P2, int P2r) { return P2 <= BIG_FUSE_P2 ? 0ull : (unsigned long long)P2 * P2r; }
 // a row-pass item covers `steps` groups of 4 column pairs
 __device__ __forceinline__ int big_rsteps(int n_tap) { const int v = BIG_RLOADS / (n_tap + 1); return v < 1 ? 1 : v; }
 
@@ -325,7 +442,7 @@ __device__ __forceinline__ int big_rsteps(int n_tap) { const int v = BIG_RLOADS 
 __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mods_region *__restrict__ reg_all,
                                                            const int *__restrict__ reg_count, BigLists *__restrict__ bl,
                                                            BigRegion *__restrict__ regions, int2 *__restrict__ sitems,
-                                                           int2 *__restrict__ ritems, int max_regions, int max_items,
+                                                           int2 *__restrict__ ritems, int2 *__restrict__ fitems, int max_regions, int max_items,
                                                            unsigned long long pool_elems, int *__restrict__ err_flag) {
   const int b = blockIdx.y;
   int n = reg_count[b];
@@ -338,21 +455,26 @@ __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mo
   const int P2r = (g.P2 + 3) & ~3;
   const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2, P2r) +
                                    (unsigned long long)g.P2 * 2 * k.desc_ps + 3ull) & ~3ull;
-  const int s_chunks = (g.P2 + BIG_SROWS - 1) / BIG_SROWS;
-  const int r_chunks = (g.P2 + BIG_RROWS - 1) / BIG_RROWS;
+  const bool fused = g.P2 <= BIG_FUSE_P2;
+  const int f_rows = big_fuse_rows(g.P2);
+  const int f_chunks = fused ? (g.P2 + f_rows - 1) / f_rows : 0;
+  const int s_chunks = fused ? 0 : (g.P2 + BIG_SROWS - 1) / BIG_SROWS;
+  const int r_chunks = fused ? 0 : (g.P2 + BIG_RROWS - 1) / BIG_RROWS;
   const int steps = (k.desc_ps + 3) / 4, per = big_rsteps(n_tap), r_parts = (steps + per - 1) / per;
   const int li = atomicAdd(&bl->n_regions, 1);
   const unsigned long long off = atomicAdd(&bl->pool_used, need);
-  const int s0 = atomicAdd(&bl->n_sitems, s_chunks);
-  const int r0 = atomicAdd(&bl->n_ritems, r_chunks * r_parts);
+  const int s0 = s_chunks ? atomicAdd(&bl->n_sitems, s_chunks) : 0;
+  const int r0 = r_chunks ? atomicAdd(&bl->n_ritems, r_chunks * r_parts) : 0;
+  const int f0 = f_chunks ? atomicAdd(&bl->n_fitems, f_chunks) : 0;
   if (li >= max_regions || off + need > pool_elems || s0 + s_chunks > max_items || r0 + r_chunks * r_parts > max_items ||
-      g.P2 >= 65536 || n_tap > k.tap_cap) {
+      f0 + f_chunks > max_items || g.P2 >= 65536 || n_tap > k.tap_cap) {
     atomicExch(err_flag, 1);
     return;
   }
   BigRegion br;
   br.img = b; br.ri = ri; br.P2 = g.P2; br.n_tap = n_tap; br.slab = off; br.scale = g.scale; br.P2r = P2r;
   regions[li] = br;
+  for (int c = 0; c < f_chunks; c++) fitems[f0 + c] = make_int2(li, c * f_rows);
   for (int c = 0; c < s_chunks; c++) sitems[s0 + c] = make_int2(li, c * BIG_SROWS);
   for (int c = 0; c < r_chunks; c++)
     for (int q = 0; q < r_parts; q++) ritems[r0 + c * r_parts + q] = make_int2(li, c * BIG_RROWS | (q * per << 16));
@@ -530,6 +652,147 @@ __global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const Big
         if (y + 1 < P2) *(float2 *)(o + ps2) = make_float2(s0.y, s1.y);
         if (y + 2 < P2) *(float2 *)(o + 2 * ps2) = make_float2(s0.z, s1.z);
         if (y + 3 < P2) *(float2 *)(o + 3 * ps2) = make_float2(s0.w, s1.w);
+      }
+    }
+  }
+}
+
+// block per fused item = R rows (64 for P2 <= 128, else 32) of a region with P2 <= BIG_FUSE_P2: the rows are sampled into
+// LDS (transposed, St[col][R]) and the row pass reads them from there, so S never leaves the CU.
+//   phase 1  thread (row = tid % R, phase = tid / R) walks the coordinate recurrence of its row and samples the columns
+//            phase, phase + nph, ... (nph = 256 / R column steps between two of its samples)
+//   phase 2  as big_rowpass_kernel, float4 = 4 rows from LDS; wave w takes the pair groups w, w + 4, ...
+__global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict__ img_all, DescConst k, const BigLists *__restrict__ bl,
+                                                        const BigRegion *__restrict__ regions, const int2 *__restrict__ fitems,
+                                                        int max_items, const mods_region *__restrict__ reg_all,
+                                                        float *__restrict__ pool, const int *__restrict__ err_flag) {
+  extern __shared__ __attribute__((aligned(16))) float s_St[];
+  if (*err_flag) return;
+  const int ps = k.desc_ps, ps2 = 2 * ps;
+  const int n_items = min(bl->n_fitems, max_items);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int2 item = fitems[it];
+    const BigRegion br = regions[item.x];
+    const RegionGeom g = region_geom(reg_all[(size_t)br.img * k.max_reg + br.ri], k.desc_mr, ps, k.patch_rule);
+    const float *img = img_all + (size_t)k.w * k.h * br.img;
+    const int P2 = br.P2, half = P2 / 2, w = k.w, h = k.h;
+    const int R = big_fuse_rows(P2), nph = 256 / R, r0 = item.y;
+    __syncthreads();   // the previous item's row pass is done with the tile
+    {
+      const int lr = tid % R, ph = tid / R, row = r0 + lr;
+      if (row < P2) {
+        const bool touch = check_borders(w, h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, P2, P2);
+        float rx = g.fx - (float)half * g.f12;
+        float ry = g.fy - (float)half * g.f22;
+        for (int q = 0; q < row; q++) { rx += g.f12; ry += g.f22; }
+        float WX = rx - (float)half * g.f11;
+        float WY = ry - (float)half * g.f21;
+        for (int q = 0; q < ph; q++) { WX += g.f11; WY += g.f21; }
+        float *dst = s_St + lr;
+        for (int c = ph; c < P2; c += 8 * nph) {
+          PixPair t0[8], t1[8];
+          float wx[8], wy[8];
+          bool ok[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            ok[u] = false;
+            if (c + u * nph < P2) {
+              int x, y;
+              if (!touch) { x = (int)WX; y = (int)WY; ok[u] = true; }
+              else { x = (int)floorf(WX); y = (int)floorf(WY); ok[u] = WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1; }
+              wx[u] = WX - (float)x;
+              wy[u] = WY - (float)y;
+              if (ok[u]) {
+                const float *Row0 = img + (size_t)y * w + x;
+                t0[u] = *(const PixPair *)Row0;
+                t1[u] = *(const PixPair *)(Row0 + w);
+              }
+              for (int q = 0; q < nph; q++) { WX += g.f11; WY += g.f21; }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (c + u * nph < P2) {
+              float v = 0.f;
+              if (ok[u]) {
+                const float I1 = wx[u] * (t0[u].b - t0[u].a) + t0[u].a;
+                v = wy[u] * (wx[u] * (t1[u].b - t1[u].a) + t1[u].a - I1) + I1;
+              }
+              dst[(c + u * nph) * R] = v;
+            }
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int n_tap = br.n_tap, r_tap = n_tap >> 1;
+      const int nq = R / 4, PS = 64 / nq;          // row quads, column pairs per step
+      const int yq = lane % nq, pg = lane / nq;
+      const int y = r0 + 4 * yq;
+      const float *tap = pool + br.slab;
+      const int *cidx = (const int *)(tap + n_tap + ps);
+      float *T = pool + br.slab + big_hdr_floats(n_tap, ps);
+      const float *Sl = s_St + 4 * yq;
+      const int steps = (ps + PS - 1) / PS;
+      for (int step = wv; step < steps; step += 4) {
+        const int pi = step * PS + pg;
+        const bool live = y < P2 && pi < ps;
+        const int x0 = live ? cidx[2 * pi] : r_tap, x1 = live ? cidx[2 * pi + 1] : r_tap + 1;
+        const bool interior = x0 - r_tap >= 0 && x0 + 1 + r_tap <= P2 - 1;
+        float4 s0, s1;
+        if (__all(interior)) {
+          const float *p = Sl + (x0 - r_tap) * R;
+          float4 prev = *(const float4 *)p;
+          float t = tap[0];
+          s0 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+          prev = *(const float4 *)(p + R);
+          s1 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+          int j = 1;
+          for (; j + 7 < n_tap; j += 8) {
+            float4 c[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) c[u] = *(const float4 *)(p + (j + 1 + u) * R);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              t = tap[j + u];
+              s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
+              s1.x += t * c[u].x; s1.y += t * c[u].y; s1.z += t * c[u].z; s1.w += t * c[u].w;
+              prev = c[u];
+            }
+          }
+          for (; j < n_tap; j++) {
+            const float4 c = *(const float4 *)(p + (j + 1) * R);
+            t = tap[j];
+            s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
+            s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+            prev = c;
+          }
+        } else {
+          int xa = x0 - r_tap; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+          float4 prev = *(const float4 *)(Sl + xa * R);
+          float t = tap[0];
+          s0 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+          xa = x0 - r_tap + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+          prev = *(const float4 *)(Sl + xa * R);
+          s1 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
+          for (int j = 1; j < n_tap; j++) {
+            xa = x0 - r_tap + j + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
+            const float4 c = *(const float4 *)(Sl + xa * R);
+            t = tap[j];
+            s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
+            s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+            prev = c;
+          }
+        }
+        if (live) {
+          if (x1 == x0) s1 = s0;
+          float *o = T + (size_t)y * ps2 + 2 * pi;
+          *(float2 *)o = make_float2(s0.x, s1.x);
+          if (y + 1 < P2) *(float2 *)(o + ps2) = make_float2(s0.y, s1.y);
+          if (y + 2 < P2) *(float2 *)(o + 2 * ps2) = make_float2(s0.z, s1.z);
+          if (y + 3 < P2) *(float2 *)(o + 3 * ps2) = make_float2(s0.w, s1.w);
+        }
       }
     }
   }
@@ -1131,7 +1394,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   // HBM layout of the description scratch: patch store [n_img][reg_cap][ps*ps] | big-tier bookkeeping | slab pool
   const size_t patch_elems = (size_t)n_img * k.reg_cap * pp;
   const int max_big = 1 << 17, max_items = 1 << 20;
-  const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + 2 * sizeof(int2) * max_items + 15) / 4;
+  const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + 3 * sizeof(int2) * max_items + 15) / 4;
   // slab pool: ~45 M floats per 1080p image in practice; 64 M per image of the batch, at least 1 GiB
   const unsigned long long pool_elems = std::max<unsigned long long>(256ull << 20, (unsigned long long)n_img * (64ull << 20));
   const size_t need = patch_elems + book_elems + pool_elems;
@@ -1147,6 +1410,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   BigRegion *bregs = (BigRegion *)(bl + 1);
   int2 *sitems = (int2 *)(bregs + max_big);
   int2 *ritems = sitems + max_items;
+  int2 *fitems = ritems + max_items;
   float *pool = ctx->desc_scratch + patch_elems + book_elems;
   MODS_HIP_CHECK(hipMemsetAsync(bl, 0, sizeof(BigLists), ctx->stream));
   k.tap_cap = 4096;
@@ -1157,7 +1421,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   }();
   k.p2_hi = small_cap;
   hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
-                     ctx->region_count, bl, bregs, sitems, ritems, max_big, max_items, pool_elems, ctx->desc_err_dev);
+                     ctx->region_count, bl, bregs, sitems, ritems, fitems, max_big, max_items, pool_elems, ctx->desc_err_dev);
   // LDS tier in two launches (P2 <= 48 takes half the LDS of the 80 class: twice the workgroups per CU);
   // the HBM tier takes P2 > small_cap
   {
@@ -1167,13 +1431,15 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
       DescConst kt = k;
       kt.p2_lo = tiers[t]; kt.p2_hi = tiers[t + 1];
       const size_t capS = kt.p2_hi > 4 ? kt.p2_hi : 4;
-      const size_t ldsS = sizeof(float) * (((capS * capS + 3) & ~(size_t)3) + capS * ps2 + 2 * ps2 + 32) + 32;
+      const size_t ldsS = sizeof(float) * (capS * ((capS + 3) & ~(size_t)3) + capS * ps2 + 2 * ps2 + 32) + 32;
       hipLaunchKernelGGL(extract_small_kernel, dim3(2048, n_img), dim3(256), ldsS, ctx->stream, img_dev, kt, ctx->regions_dev,
                          ctx->region_count, patches);
     }
   }
   const size_t ldsH = sizeof(float) * (k.tap_cap + 4 * ps2) + 32;
   hipLaunchKernelGGL(big_setup_kernel, dim3(1024), dim3(256), ldsH, ctx->stream, k, bl, bregs, max_big, pool, ctx->desc_err_dev);
+  hipLaunchKernelGGL(big_fused_kernel, dim3(8192), dim3(256), 32 * 1024, ctx->stream, img_dev, k, bl, bregs, fitems, max_items,
+                     ctx->regions_dev, pool, ctx->desc_err_dev);
   hipLaunchKernelGGL(big_sample_kernel, dim3(4096), dim3(256), 0, ctx->stream, img_dev, k, bl, bregs, sitems, max_items,
                      ctx->regions_dev, pool, ctx->desc_err_dev);
   hipLaunchKernelGGL(big_rowpass_kernel, dim3(4096), dim3(256), 0, ctx->stream, k, bl, bregs, ritems, max_items, pool,
