@@ -1098,7 +1098,7 @@ static size_t sift_wave_lds_bytes(int ps) {
 }
 
 // grid = (N, n_img), block = 256 (4 independent waves): patches -> descriptors
-__global__ __launch_bounds__(256) void sift_wave_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
+__global__ __launch_bounds__(256, 2) void sift_wave_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
                                                         const int *__restrict__ reg_count, const float *__restrict__ mask,
                                                         const SiftTab *__restrict__ tab, int scratch_floats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1155,8 +1155,16 @@ __global__ __launch_bounds__(256) void sift_wave_kernel(DescConst k, const float
 #pragma unroll
   for (int q = 0; q < SW_CW; q++) wcw[q] = (clo + q < ps) ? s_w[hbc * ps + clo + q] : 0.f;
 
+#ifdef SIFT_PROF
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
+  int pn = 0;
+#define SPROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pl; pl = t_; }
+#else
+#define SPROF(i)
+#endif
   for (int grp = blockIdx.x * 4 + wv; grp < groups; grp += gridDim.x * 4) {
     const int ri0 = grp * SW_R;
+    SPROF(0)
     // patch of region slot rr (slots past the end repeat the last region; their results are not stored)
     auto patch_of = [&](int rr) { return patches + ((size_t)b * k.reg_cap + min(ri0 + rr, n - 1)) * pp; };
     wave_sync();
@@ -1211,7 +1219,7 @@ __global__ __launch_bounds__(256) void sift_wave_kernel(DescConst k, const float
     }
     wave_sync();
     // normalised patch row -> ring slot; the row after next is fetched into registers while the current row is worked on
-    constexpr int RL = 8;                               // >= ceil(SW_R * ps / 64) for ps <= 64
+    constexpr int RL = 6;                               // >= ceil(SW_R * ps / 64) for ps <= 48 (this kernel runs for ps <= 45)
     float nxt[RL];
     auto fetch_row = [&](int r) {
 #pragma unroll
@@ -1237,34 +1245,55 @@ __global__ __launch_bounds__(256) void sift_wave_kernel(DescConst k, const float
         }
       }
     };
+    SPROF(1)
     fetch_row(0); store_row(0);
     if (ps > 1) { fetch_row(1); store_row(1); }
     // ---- computeSiftDescriptor / samplePatch (siftdesc.cpp:73-131, 160-198), one pixel row at a time
     for (int r = 0; r < ps; r++) {
       if (r + 2 < ps) fetch_row(r + 2);
+      float mrow[RL];   // descriptor mask of this pixel row, per lane slot
+#pragma unroll
+      for (int u = 0; u < RL; u++) {
+        const int e = lane + 64 * u;
+        if (e < rowf) mrow[u] = mask[r * ps + e - (e / ps) * ps];
+      }
       wave_sync();
+      SPROF(2)
       {
+        // branch-free: the one-sided differences at the patch border are the same subtraction with one operand at the pixel
+        // itself; all loads of the row are issued before the first use
         const float *R0 = ring + (r % 3) * rowf;
-        const float *Rm = ring + ((r + 2) % 3) * rowf;   // row r - 1
-        const float *Rp = ring + ((r + 1) % 3) * rowf;   // row r + 1
-        for (int e = lane; e < rowf; e += 64) {
-          const int rr = e / ps, c = e - rr * ps;
-          float xgrad, ygrad;
-          if (c == 0) xgrad = R0[e + 1] - R0[e];
-          else if (c == ps - 1) xgrad = R0[e] - R0[e - 1];
-          else xgrad = R0[e + 1] - R0[e - 1];
-          if (r == 0) ygrad = Rp[e] - R0[e];
-          else if (r == ps - 1) ygrad = R0[e] - Rm[e];
-          else ygrad = Rp[e] - Rm[e];
-          const float grad = sqrtf(xgrad * xgrad + ygrad * ygrad);
-          const AtanSel as = atan2_lut_sel(ygrad, xgrad);
-          const float o = as.zero ? o_zero : s_ot[as.oct * 256 + as.idx];
-          const int bo0 = (int)o;
-          pxrow[e] = make_float2(mask[r * ps + c] * grad, o - bo0);
-          borow[e] = (unsigned char)(bo0 % 8);
+        const float *Rdn = r == 0 ? R0 : ring + ((r + 2) % 3) * rowf;        // row r - 1 (row r at the top border)
+        const float *Rup = r == ps - 1 ? R0 : ring + ((r + 1) % 3) * rowf;   // row r + 1 (row r at the bottom border)
+        float xa[RL], xb[RL], ya[RL], yb[RL];
+#pragma unroll
+        for (int u = 0; u < RL; u++) {
+          const int e = lane + 64 * u;
+          if (e < rowf) {
+            const int c = e - (e / ps) * ps;
+            xa[u] = R0[e + (c < ps - 1 ? 1 : 0)];
+            xb[u] = R0[e - (c > 0 ? 1 : 0)];
+            ya[u] = Rup[e];
+            yb[u] = Rdn[e];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RL; u++) {
+          const int e = lane + 64 * u;
+          if (e < rowf) {
+            const float xgrad = xa[u] - xb[u], ygrad = ya[u] - yb[u];
+            const float grad = sqrtf(xgrad * xgrad + ygrad * ygrad);
+            const AtanSel as = atan2_lut_sel(ygrad, xgrad);
+            const float ot = s_ot[as.oct * 256 + as.idx];
+            const float o = as.zero ? o_zero : ot;
+            const int bo0 = (int)o;
+            pxrow[e] = make_float2(mrow[u] * grad, o - bo0);
+            borow[e] = (unsigned char)(bo0 % 8);
+          }
         }
       }
       wave_sync();
+      SPROF(3)
       {
         // the row's two spatial row bins (bin0 / bin1 and their weights; already multiplied by 8 = orientation bins)
         const int rb = hsel ? tab->bin1[r] : tab->bin0[r];
@@ -1273,24 +1302,27 @@ __global__ __launch_bounds__(256) void sift_wave_kernel(DescConst k, const float
           double *abin = acc + hr * SW_ACC + rb * 4 + hbc * 8;
           const float2 *px = pxrow + hr * ps + clo;
           const unsigned char *bop = borow + hr * ps + clo;
+          float2 pv[SW_CW];
+          int bo[SW_CW];
+#pragma unroll
+          for (int q = 0; q < SW_CW; q++) { pv[q] = px[q]; bo[q] = bop[q]; }
 #pragma unroll
           for (int q = 0; q < SW_CW; q++) {
-            const float2 pv = px[q];
-            const int bo0 = bop[q];
-            const float val = wrr * (wcw[q] * pv.x);
+            const float val = wrr * (wcw[q] * pv[q].x);
             if (val > 0) {
-              const float c0 = val * (1.0f - pv.y), c1 = val * pv.y;
+              const float c0 = val * (1.0f - pv[q].y), c1 = val * pv[q].y;
 #ifdef SIFT_RMW
-              abin[bo0] += (double)c0;
-              abin[(bo0 + 1) & 7] += (double)c1;
+              abin[bo[q]] += (double)c0;
+              abin[(bo[q] + 1) & 7] += (double)c1;
 #else
-              __hip_atomic_fetch_add(abin + bo0, (double)c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-              __hip_atomic_fetch_add(abin + ((bo0 + 1) & 7), (double)c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              __hip_atomic_fetch_add(abin + bo[q], (double)c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              __hip_atomic_fetch_add(abin + ((bo[q] + 1) & 7), (double)c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #endif
             }
           }
         }
       }
+      SPROF(4)
       if (r + 2 < ps) store_row(r + 2);   // slot of row r - 1, which the gradients of row r have finished reading
     }
     wave_sync();
@@ -1372,7 +1404,16 @@ __global__ __launch_bounds__(256) void sift_wave_kernel(DescConst k, const float
         }
       }
     }
+    SPROF(5)
+#ifdef SIFT_PROF
+    pn++;
+#endif
   }
+#ifdef SIFT_PROF
+  if (lane == 0 && blockIdx.y == 0 && (blockIdx.x % 64) == 3 && wv == 1)
+    printf("sift_wave prof: block %d groups %d cycles: other %llu photo %llu rowfetch+store %llu grad %llu hist %llu norm %llu\n", blockIdx.x, pn,
+           pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
+#endif
 }
 
 __global__ __launch_bounds__(256) void sift_patch_test_kernel(const float *__restrict__ patch, int ps, int root, double max_bin,
