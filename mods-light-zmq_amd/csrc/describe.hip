@@ -49,16 +49,15 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
     float v = 0.f;
     if (p < n) {
       const int r = 1 + p / ps, c = p - (r - 1) * ps;
-      float mag = 0.f;
-      int obin = 0;
-      if (c >= 1 && c < ps - 1) {
-        const float xgrad = s_patch[r * ps + c + 1] - s_patch[r * ps + c - 1];
-        const float ygrad = s_patch[(r + 1) * ps + c] - s_patch[(r - 1) * ps + c];
-        mag = sqrtf(xgrad * xgrad + ygrad * ygrad);
-        const AtanSel as = atan2_lut_sel(ygrad, xgrad);
-        obin = as.zero ? (int)(bins * (0.f / PIf + 1.0f) / 2.0f) : g_ori_bin[as.oct * 256 + as.idx];
-      }
+      // (border columns have no gradient: their loads are clamped into the row and the result is dropped)
+      const bool inner = c >= 1 && c < ps - 1;
+      const float xgrad = s_patch[r * ps + (c < ps - 1 ? c + 1 : c)] - s_patch[r * ps + (c >= 1 ? c - 1 : c)];
+      const float ygrad = s_patch[(r + 1) * ps + c] - s_patch[(r - 1) * ps + c];
+      const AtanSel as = atan2_lut_sel(ygrad, xgrad);
+      const int tbin = g_ori_bin[as.oct * 256 + as.idx];
       const float m = orimask[r * ps + c];
+      const float mag = inner ? sqrtf(xgrad * xgrad + ygrad * ygrad) : 0.f;
+      const int obin = as.zero ? (int)(bins * (0.f / PIf + 1.0f) / 2.0f) : tbin;
       if (m > 0 && (double)mag > 1.0) {
         bin = obin;
         v = mag * m;
@@ -73,7 +72,21 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
   // and reads four votes per LDS access.
   if (lane < bins) {
     float acc = 0.f;
-    for (int p = 0; p < n4; p += 4) {
+    int p = 0;
+    for (; p + 15 < n4; p += 16) {   // 8 LDS reads in flight, then their 16 votes in order
+      int4 b4[4];
+      float4 v4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { b4[u] = *(const int4 *)(s_bin + p + 4 * u); v4[u] = *(const float4 *)(s_val + p + 4 * u); }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        acc += (b4[u].x == lane) ? v4[u].x : 0.f;
+        acc += (b4[u].y == lane) ? v4[u].y : 0.f;
+        acc += (b4[u].z == lane) ? v4[u].z : 0.f;
+        acc += (b4[u].w == lane) ? v4[u].w : 0.f;
+      }
+    }
+    for (; p < n4; p += 4) {
       const int4 b4 = *(const int4 *)(s_bin + p);
       const float4 v4 = *(const float4 *)(s_val + p);
       acc += (b4.x == lane) ? v4.x : 0.f;
@@ -172,14 +185,27 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
           float WY = ry - (float)half * a21;
           for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
           const int end = min(pp2, idx + L);
-          for (; idx < end; idx++) {
-            s_patch[idx] = bilinear_tap(img, k.w, k.h, WX, WY, touch);
-            if (++col == ps) {
-              col = 0;
-              rx += a12; ry += a22;
-              WX = rx - (float)half * a11;
-              WY = ry - (float)half * a21;
-            } else { WX += a11; WY += a21; }
+          // coordinates first (sequential fp32 additions), then all loads of a batch, then the lerps
+          while (idx < end) {
+            TapLoads t[8];
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              if (idx + u < end) {
+                t[u] = tap_load(img, k.w, k.h, WX, WY, touch);
+                cnt++;
+                if (++col == ps) {
+                  col = 0;
+                  rx += a12; ry += a22;
+                  WX = rx - (float)half * a11;
+                  WY = ry - (float)half * a21;
+                } else { WX += a11; WY += a21; }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+              if (u < cnt) s_patch[idx + u] = tap_combine(t[u]);
+            idx += cnt;
           }
         }
       }

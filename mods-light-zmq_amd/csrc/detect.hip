@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
         // every lane samples a contiguous run of the W x W window; its first coordinates are rebuilt by
         // replaying the reference's sequential fp32 additions (row steps, then column steps)
         {
-          const int L = (WW + 63) / 64;
+          const int L = (WW + 63) / 64;   // <= 8 for windows up to 22 x 22
           int idx = lane * L;
           if (idx < WW) {
             int row = idx / W, col = idx - row * W;
@@ -348,28 +348,38 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
             float WY = ry - (float)half * a21;
             for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
             const int end = min(WW, idx + L);
-            for (; idx < end; idx++) {
-              s_img[idx] = bilinear_tap(im, iw, ih, WX, WY, touch);
-              if (++col == W) {
-                col = 0;
-                rx += a12; ry += a22;
-                WX = rx - (float)half * a11;
-                WY = ry - (float)half * a21;
-              } else { WX += a11; WY += a21; }
+            // coordinates first (sequential fp32 additions), then all loads of the run, then the lerps
+            while (idx < end) {
+              TapLoads t[8];
+              int cnt = 0;
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                if (idx + u < end) {
+                  t[u] = tap_load(im, iw, ih, WX, WY, touch);
+                  cnt++;
+                  if (++col == W) {
+                    col = 0;
+                    rx += a12; ry += a22;
+                    WX = rx - (float)half * a11;
+                    WY = ry - (float)half * a21;
+                  } else { WX += a11; WY += a21; }
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < 8; u++)
+                if (u < cnt) s_img[idx + u] = tap_combine(t[u]);
+              idx += cnt;
             }
           }
         }
         __syncthreads();
         // computeGradient (helpers.cpp:779-797) and the three SMM products
+        // (the one-sided differences at the window border are the same subtraction with one operand at the pixel itself)
         for (int p = lane; p < WW; p += 64) {
           const int r = p / W, c = p - r * W;
-          float xgrad, ygrad;
-          if (c == 0) xgrad = s_img[p + 1] - s_img[p];
-          else if (c == W - 1) xgrad = s_img[p] - s_img[p - 1];
-          else xgrad = s_img[p + 1] - s_img[p - 1];
-          if (r == 0) ygrad = s_img[p + W] - s_img[p];
-          else if (r == W - 1) ygrad = s_img[p] - s_img[p - W];
-          else ygrad = s_img[p + W] - s_img[p - W];
+          const float xa = s_img[p + (c < W - 1 ? 1 : 0)], xb = s_img[p - (c > 0 ? 1 : 0)];
+          const float ya = s_img[p + (r < W - 1 ? W : 0)], yb = s_img[p - (r > 0 ? W : 0)];
+          const float xgrad = xa - xb, ygrad = ya - yb;
           const float v = s_mask[p];
           const float gxy = xgrad * ygrad;
           s_pa[p] = xgrad * xgrad * v;
@@ -382,6 +392,13 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
           const float *arr = lane == 0 ? s_pa : (lane == 1 ? s_pb : s_pc);
           float acc = 0;
           int i = 0;
+          for (; i + 31 < WW; i += 32) {   // 8 LDS reads in flight, then their 32 terms in order
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = *(const float4 *)(arr + i + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { acc += v[u].x; acc += v[u].y; acc += v[u].z; acc += v[u].w; }
+          }
           for (; i + 3 < WW; i += 4) {
             const float4 v4 = *(const float4 *)(arr + i);
             acc += v4.x; acc += v4.y; acc += v4.z; acc += v4.w;
