@@ -287,8 +287,9 @@ def main():
             "roofline": {"kernel": "gauss_blur_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC passes committed in profiles/r01_pmc_blur_traffic.csv
-                         # (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, mean over the blur launches of the same batching: 8 images per launch)
-                         "traffic": 27618208,
+                         # (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, mean over the blur launches of the default batching,
+                         # 16 images per launch; other batchings were not measured)
+                         "traffic": 58270632 if (pipe is not None and args.pairs_per_batch == 8 and args.config == "c2") else None,
                          "launches": blur_n, "mean_launch_us": round(blur_ms / max(blur_n, 1) * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(blur_bytes / max(blur_n, 1), 1)},
         }
