@@ -159,14 +159,17 @@ struct BlurTaps { float t[17]; };
 constexpr int FB_TW = 128;   // tile width; the tile height is a template parameter (64: large planes, 16: small planes,
                              // where a short per-thread row chain matters more than halo reuse)
 
-template <int R, int FB_TH>
+template <int R, int FB_TH, int OV>
 __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               BlurTaps taps) {
   constexpr int N = 2 * R + 1;
-  constexpr int R4 = (R + 3) / 4;            // float4s on each side of the 4 outputs
-  constexpr int NV = 2 * R4 + 1;             // float4s in the register window
+  constexpr int R4 = (R + 3) / 4;            // float4s on each side of the outputs
+  constexpr int NV = 2 * R4 + OV;            // float4s in the register window
+  constexpr int NO = 4 * OV;                 // adjacent outputs per thread and strip row
   constexpr int D = 4 * R4 - R;              // window offset of tap 0 for output 0
   constexpr int ROWS = FB_TH + 2 * R;
+  constexpr int TPR = FB_TW / NO;            // threads per strip row
+  constexpr int RPS = 256 / TPR;             // strip rows per step
   extern __shared__ __attribute__((aligned(16))) float smem[];   // ROWS x FB_TW row-pass results
   const int tid = threadIdx.x;
   const size_t plane = (size_t)w * h;
@@ -184,9 +187,11 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
   src += plane * img;
   dst += plane * img;
   const int x0 = txi * FB_TW, y0 = tyi * FB_TH;
-  const int tc = tid & 31;                    // 4-pixel column group
-  const int x4 = x0 + 4 * tc;
-  const bool fast_x = ((w & 3) == 0) && (x4 - 4 * R4 >= 0) && (x4 + 4 * R4 + 3 <= w - 1);   // aligned rows, whole window inside the row
+  // Row pass.  The memory pipeline takes about one clock per lane and load whatever the width, so the window of a thread is
+  // kept wide: NO outputs from NV aligned float4 loads (1.25 loads per 4 outputs at OV = 1, R = 5..8; 0.75 at OV = 2).
+  const int rc = tid % TPR;                   // output group within the row
+  const int xg = x0 + NO * rc;
+  const bool fast_x = ((w & 3) == 0) && (xg - 4 * R4 >= 0) && (xg + NO - 1 + 4 * R4 <= w - 1);   // aligned rows, whole window inside the row
   auto load_window = [&](int ly, float *win) {
     int gy = y0 - R + ly;
     gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
@@ -194,47 +199,51 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
     if (fast_x) {
 #pragma unroll
       for (int v = 0; v < NV; v++) {
-        const float4 q = *(const float4 *)(row + x4 - 4 * R4 + 4 * v);
+        const float4 q = *(const float4 *)(row + xg - 4 * R4 + 4 * v);
         win[4 * v] = q.x; win[4 * v + 1] = q.y; win[4 * v + 2] = q.z; win[4 * v + 3] = q.w;
       }
     } else {
 #pragma unroll
       for (int e = 0; e < 4 * NV; e++) {
-        int gx = x4 - 4 * R4 + e;
+        int gx = xg - 4 * R4 + e;
         gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
         win[e] = row[gx];
       }
     }
   };
-  // Row pass.  A thread owns 4 columns and every 8th row of the (TH + 2R)-row strip; DEPTH row windows are in flight
-  // (a ring of register windows, statically indexed after unrolling).
-  constexpr int NI = (ROWS + 7) / 8;
+  // A thread owns NO columns and every RPS-th row of the (TH + 2R)-row strip; the next row window is in flight while the
+  // current one is used (a ring of register windows, statically indexed after unrolling).
+  constexpr int NI = (ROWS + RPS - 1) / RPS;
   constexpr int DEPTH = 1;   // measured: 2 or 4 windows in flight are slower (22-29 us vs 13 us per 1080p-pair plane)
   float win[DEPTH][4 * NV];
-  const int ly0 = tid >> 5;
+  const int ly0 = tid / TPR;
 #pragma unroll
   for (int i = 0; i < DEPTH; i++)
-    if (ly0 + 8 * i < ROWS) load_window(ly0 + 8 * i, win[i]);
+    if (ly0 + RPS * i < ROWS) load_window(ly0 + RPS * i, win[i]);
 #pragma unroll
   for (int i = 0; i < NI; i++) {
-    const int ly = ly0 + 8 * i;
+    const int ly = ly0 + RPS * i;
     if (ly < ROWS) {
       const float *wv = win[i % DEPTH];
-      float o[4];
+      float o[NO];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < NO; u++) {
         float s = taps.t[0] * wv[D + u];
 #pragma unroll
         for (int j = 1; j < N; j++) s += taps.t[j] * wv[D + u + j];
         o[u] = s;
       }
-      *(float4 *)(smem + ly * FB_TW + 4 * tc) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+      for (int v = 0; v < OV; v++)
+        *(float4 *)(smem + ly * FB_TW + NO * rc + 4 * v) = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
     }
-    if (i + DEPTH < NI && ly + 8 * DEPTH < ROWS) load_window(ly + 8 * DEPTH, win[i % DEPTH]);
+    if (i + DEPTH < NI && ly + RPS * DEPTH < ROWS) load_window(ly + RPS * DEPTH, win[i % DEPTH]);
   }
   __syncthreads();
   // Column pass.  A thread makes RPT vertically adjacent outputs of its 4 columns: the 2R + RPT strip rows it
   // needs are read from LDS once into registers (instead of 2R + 1 reads per output).
+  const int tc = tid & 31;                    // 4-pixel column group
+  const int x4 = x0 + 4 * tc;
   if (x4 < w) {
     constexpr int RPT = FB_TH / 8;
     const int lyb = (tid >> 5) * RPT;
@@ -347,14 +356,17 @@ static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
 
 template <int R>
 static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, const BlurTaps &taps) {
+#ifndef BLUR_OV_BIG
+#define BLUR_OV_BIG 2   // float4 output groups per thread and strip row on the large planes
+#endif
 #define BLUR_TH_BIG 32   // measured on 1080p pairs: 32-row tiles (4 workgroups per CU, phases of different tiles overlap) beat 64-row tiles by ~15 %
   const int tiles64 = ((w + FB_TW - 1) / FB_TW) * ((h + 63) / 64) * n_img;
   if (tiles64 >= 384) {   // at least ~1.5 tiles per CU: large planes: 32-row tiles
     const int tilesB = ((w + FB_TW - 1) / FB_TW) * ((h + BLUR_TH_BIG - 1) / BLUR_TH_BIG) * n_img;
-    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG>), dim3(tilesB), dim3(256), sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
+    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG>), dim3(tilesB), dim3(256), sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
   } else {                // small planes: short tiles, more workgroups, shorter per-thread row chains
     const int tiles16 = ((w + FB_TW - 1) / FB_TW) * ((h + 15) / 16) * n_img;
-    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16>), dim3(tiles16), dim3(256), sizeof(float) * (size_t)(16 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
+    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1>), dim3(tiles16), dim3(256), sizeof(float) * (size_t)(16 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
   }
 }
 
