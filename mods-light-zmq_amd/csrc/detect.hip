@@ -76,6 +76,12 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
   const int cc = col_ok ? c : k.border;      // idle lanes read a valid column
   if (r_base >= h - k.border) return;
   const int ih = h - 2 * k.border, words = gridDim.x;
+  // in-plane extrema above the gate are rare per lane but not per wave: they are collected into a wave-private LDS list and
+  // the 18 loads of the other two planes run over the list with all lanes busy (instead of once per row for a few lanes)
+  __shared__ unsigned int s_code[4][64 * NMS_ROWS];
+  __shared__ float s_val[4][64 * NMS_ROWS];
+  __shared__ unsigned long long s_hit[4][NMS_ROWS];
+  const int wv = threadIdx.x >> 6;
   for (int lv = 1; lv <= k.n_scales; lv++) {
     const float *cur = o.resp[lv] + plane;
     // the whole (NMS_ROWS+2) x 3 window of this thread is loaded up front: 30 independent loads in
@@ -88,7 +94,9 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
       const float *p = cur + (size_t)r * w + cc;
       win[rr][0] = p[-1]; win[rr][1] = p[0]; win[rr][2] = p[1];
     }
-    unsigned long long *mrow = mask + (((size_t)b * k.n_scales + (lv - 1)) * ih + (r_base - k.border)) * words + blockIdx.x;
+    wave_sync();                              // the previous level's list and hit words have been consumed
+    if (lane < NMS_ROWS) s_hit[wv][lane] = 0ull;
+    int n_c = 0;
 #pragma unroll
     for (int rr = 0; rr < NMS_ROWS; rr++) {
       const int r = r_base + rr;
@@ -104,12 +112,31 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
           mx = mx && !(win[rr + q][e] > val);
           mn = mn && !(win[rr + q][e] < val);
         }
-      bool hit = false;
-      if (row_ok && col_ok && val > k.pos_th && mx) hit = nms_other_planes(o.resp[lv - 1] + plane, o.resp[lv + 1] + plane, w, r, c, val, true);
-      else if (row_ok && col_ok && val < k.neg_th && mn) hit = nms_other_planes(o.resp[lv - 1] + plane, o.resp[lv + 1] + plane, w, r, c, val, false);
-      const unsigned long long m = __ballot(hit);
-      if (row_ok && lane == 0) mrow[(size_t)rr * words] = m;
+      const bool cmax = row_ok && col_ok && val > k.pos_th && mx;
+      const bool cmin = row_ok && col_ok && !cmax && val < k.neg_th && mn;
+      const bool cnd = cmax || cmin;
+      const unsigned long long m = __ballot(cnd);
+      if (cnd) {
+        const int pos = n_c + __popcll(m & ((1ull << lane) - 1ull));
+        s_code[wv][pos] = ((unsigned int)rr << 7) | ((unsigned int)lane << 1) | (cmax ? 1u : 0u);
+        s_val[wv][pos] = val;
+      }
+      n_c += __popcll(m);
     }
+    wave_sync();
+    const float *low = o.resp[lv - 1] + plane, *high = o.resp[lv + 1] + plane;
+    for (int t0 = 0; t0 < n_c; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < n_c) {
+        const unsigned int code = s_code[wv][t];
+        const int rr = code >> 7, ln = (code >> 1) & 63;
+        if (nms_other_planes(low, high, w, r_base + rr, k.border + blockIdx.x * 64 + ln, s_val[wv][t], (code & 1u) != 0))
+          atomicOr(&s_hit[wv][rr], 1ull << ln);
+      }
+    }
+    wave_sync();
+    unsigned long long *mrow = mask + (((size_t)b * k.n_scales + (lv - 1)) * ih + (r_base - k.border)) * words + blockIdx.x;
+    if (lane < NMS_ROWS && r_base + lane < h - k.border) mrow[(size_t)lane * words] = s_hit[wv][lane];
   }
 }
 

@@ -24,6 +24,14 @@ __device__ __forceinline__ bool check_borders(int img_w, int img_h, float ofsx, 
   return touch;
 }
 
+// LDS hand-over between the lanes of ONE wave (LDS executes a wave's instructions in order; this only stops the
+// compiler from moving LDS accesses across)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // two horizontally adjacent pixels by one 8-byte load (only 4-byte aligned): a gather costs the memory pipeline per lane
 // and per instruction, so the four pixels of a bilinear tap are fetched with two loads
 struct __attribute__((packed, aligned(4))) PixPair { float a, b; };

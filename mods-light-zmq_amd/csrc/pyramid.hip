@@ -300,6 +300,52 @@ __global__ __launch_bounds__(256) void hessian_response_kernel(const float *__re
   dst[(size_t)y * w + x] = out;
 }
 
+// The same response for planes whose width is a multiple of 4: a thread makes a 4 x 2 block of outputs from 4 rows x
+// (one aligned float4 + the two pixels beside it): 12 loads per 8 pixels instead of 72.
+// grid = (ceil(w/256), ceil(h/8), n_img), block = 256 (64 column groups x 4 row pairs).
+__global__ __launch_bounds__(256) void hessian_response4_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                                int w, int h, float norm2) {
+  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 2;
+  if (x4 >= w || y0 >= h) return;
+  const size_t plane = (size_t)w * h;
+  src += plane * blockIdx.z;
+  dst += plane * blockIdx.z;
+  float v[4][6];   // rows y0-1 .. y0+2 (clamped into the image: clamped rows only feed frame outputs, which are 0), columns x4-1 .. x4+4
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    int y = y0 - 1 + q;
+    y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+    const float *row = src + (size_t)y * w + x4;
+    const float4 c = *(const float4 *)row;
+    v[q][0] = x4 > 0 ? row[-1] : 0.f;
+    v[q][1] = c.x; v[q][2] = c.y; v[q][3] = c.z; v[q][4] = c.w;
+    v[q][5] = x4 + 4 < w ? row[4] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int y = y0 + k;
+    if (y >= h) break;
+    float o[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int x = x4 + u;
+      float out = 0.f;   // the reference leaves the 1-px frame undefined; it is never read
+      if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+        const float v11 = v[k][u], v12 = v[k][u + 1], v13 = v[k][u + 2];
+        const float v21 = v[k + 1][u], v22 = v[k + 1][u + 1], v23 = v[k + 1][u + 2];
+        const float v31 = v[k + 2][u], v32 = v[k + 2][u + 1], v33 = v[k + 2][u + 2];
+        float Lxx = (v21 - 2 * v22 + v23);
+        float Lyy = (v12 - 2 * v22 + v32);
+        float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
+        out = (Lxx * Lyy - Lxy * Lxy) * norm2;
+      }
+      o[u] = out;
+    }
+    *(float4 *)(dst + (size_t)y * w + x4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // cv::resize 0.5x: full 2x2 blocks ((a+b)+(c+d))*0.25f, edge blocks running sum / count.
 __global__ __launch_bounds__(256) void resize_half_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                           int w, int h, int dw, int dh) {
@@ -407,7 +453,11 @@ int launch_gauss_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h,
 int launch_hessian_response(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, float norm) {
   dim3 grid((w + 63) / 64, (h + 3) / 4, n_img);
   StageScope ts(ctx, MODS_STAGE_RESPONSE, 8.0 * w * h * n_img);
-  hipLaunchKernelGGL(hessian_response_kernel, grid, dim3(256), 0, ctx->stream, src, dst, w, h, norm * norm);
+  if ((w & 3) == 0)
+    hipLaunchKernelGGL(hessian_response4_kernel, dim3((w + 255) / 256, (h + 7) / 8, n_img), dim3(256), 0, ctx->stream, src, dst, w, h,
+                       norm * norm);
+  else
+    hipLaunchKernelGGL(hessian_response_kernel, grid, dim3(256), 0, ctx->stream, src, dst, w, h, norm * norm);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }

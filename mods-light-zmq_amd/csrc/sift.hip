@@ -1078,12 +1078,6 @@ constexpr int SW_ACC = 130;      // accumulator stride in doubles (lanes 0..7 re
 constexpr int SW_G = 68;         // photometric chunk stride in floats
 constexpr int SW_CW = 18;        // pixel columns a spatial bin spans at most (patch sizes <= 45)
 
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 static size_t sift_wave_scratch_floats(int ps) {   // per wave: ring 3 rows | pxrow (float2) + pad | borow + pad   (g aliases the ring)
   const size_t row = (size_t)SW_R * ps;
   size_t f = 3 * row + 2 * (row + SW_CW) + (row + SW_CW + 3) / 4 + 8;
