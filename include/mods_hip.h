@@ -363,6 +363,11 @@ int mods_match_reps(mods_ctx *ctx, const mods_imgrep *q, int q_begin, int q_end,
 int mods_match_ladder_dev(mods_ctx *ctx, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
                           const mods_ladder_step *steps, int n_steps, int min_matches, const mods_pair_params *par,
                           mods_imgrep *rep1, mods_imgrep *rep2, mods_ladder_result *res, double *matches_out, int max_matches);
+
+/* Pre-extracted mode (mods.cpp:196-229, 288-383): the banks were filled by the caller (mods_imgrep_append_host, e.g. from the
+ * k1 / k2 files of an earlier run); one matching + duplicate filtering + verification pass, no detection. */
+int mods_match_verify_reps(mods_ctx *ctx, mods_imgrep *rep1, mods_imgrep *rep2, double fginn_ratio, const mods_pair_params *par,
+                           mods_ladder_result *res, double *matches_out, int max_matches);
 /* plain device-memory helpers for callers that do not link a HIP runtime themselves (the mods CLI) */
 int mods_dev_alloc(size_t bytes, void **out);
 int mods_dev_free(void *p);

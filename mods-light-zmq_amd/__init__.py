@@ -580,6 +580,16 @@ def match_ladder_dev(ctx, img_ptr, w, h, steps, rep1, rep2, params=None, min_mat
     return res, m[:min(res.n_inliers, max_matches)]
 
 
+def match_verify_reps(ctx, rep1, rep2, fginn_ratio=0.8, params=None, max_matches=0):
+    """Pre-extracted mode (mods.cpp:196-229): match + duplicate filter + verification on banks filled by the caller."""
+    params = params or PairParams.default()
+    res = LadderResult()
+    m = np.zeros((max(max_matches, 1), 4), np.float64)
+    _check(lib().mods_match_verify_reps(ctx.h, rep1.h, rep2.h, C.c_double(fginn_ratio), C.byref(params), C.byref(res),
+                                        m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
+    return res, m[:min(res.n_inliers, max_matches)]
+
+
 # ---- one pair end to end ------------------------------------------------------------------------------
 class PairParams(C.Structure):
     _fields_ = [("det", HessAffParams), ("desc", DescribeParams), ("fginn_ratio", C.c_double),

@@ -20,6 +20,7 @@
 #include "../../include/mods_hip.h"
 #include "../../include/mods_zmq.h"
 #include "image_io.hpp"
+#include "npz_io.hpp"
 #include "ini_reader.hpp"
 #include <chrono>
 #include <cmath>
@@ -210,9 +211,75 @@ void write_regions(const std::string &fn, mods_imgrep *rep, const char *desc_nam
   }
 }
 
+// SaveRegionsNPZ, imagerepresentation.cpp:1257-1316: xy, scales, responses, A (reproj_kp, doubles) and descs (uchar)
+bool write_regions_npz(const std::string &fn, mods_imgrep *rep) {
+  const int n = mods_imgrep_count(rep);
+  std::vector<mods_region> regs((size_t)std::max(n, 1));
+  if (n > 0 && mods_imgrep_fetch(rep, 0, n, regs.data())) { std::cerr << mods_last_error() << std::endl; return false; }
+  modscli::NpyArray xy, sc, rs, A, ds;
+  auto f8 = [&](modscli::NpyArray &a, size_t cols) { a.descr = "<f8"; a.shape = {(size_t)n, cols}; a.data.resize(sizeof(double) * n * cols); };
+  f8(xy, 2); f8(sc, 1); f8(rs, 1); f8(A, 4);
+  ds.descr = "|u1"; ds.shape = {(size_t)n, 128}; ds.data.resize((size_t)n * 128);
+  for (int i = 0; i < n; i++) {
+    const mods_region &r = regs[i];
+    const double v2[2] = {r.x, r.y}, v4[4] = {r.a11, r.a12, r.a21, r.a22};
+    memcpy(&xy.data[sizeof(double) * 2 * i], v2, sizeof(v2));
+    memcpy(&sc.data[sizeof(double) * i], &r.s, sizeof(double));
+    memcpy(&rs.data[sizeof(double) * i], &r.response, sizeof(double));
+    memcpy(&A.data[sizeof(double) * 4 * i], v4, sizeof(v4));
+    memcpy(&ds.data[(size_t)128 * i], r.desc, 128);
+  }
+  std::string err;
+  if (!modscli::npz_write(fn, {{"xy", xy}, {"scales", sc}, {"responses", rs}, {"A", A}, {"descs", ds}}, &err)) { std::cerr << err << std::endl; return false; }
+  return true;
+}
+
+// PreLoadRegionsNPZ, imagerepresentation.cpp:1355-1503: xy, scales, responses, descs and either A, angles (degrees) or neither
+// (upright circles); det_kp = reproj_kp
+bool read_regions_npz(const std::string &fn, std::vector<mods_region> *out) {
+  std::map<std::string, modscli::NpyArray> z;
+  std::string err;
+  if (!modscli::npz_read(fn, &z, &err)) { std::cerr << err << std::endl; return false; }
+  for (const char *key : {"xy", "scales", "responses", "descs"})
+    if (!z.count(key)) { std::cerr << fn << ": no array " << key << std::endl; return false; }
+  const modscli::NpyArray &xy = z["xy"], &sc = z["scales"], &rs = z["responses"], &ds = z["descs"];
+  if (xy.descr != "<f8" || sc.descr != "<f8" || rs.descr != "<f8" || ds.descr != "|u1" || xy.shape.empty() || ds.shape.size() != 2) {
+    std::cerr << fn << ": xy / scales / responses must be float64 and descs uint8 (n x dim)" << std::endl; return false;
+  }
+  const size_t n = xy.shape[0];
+  if (ds.shape[1] != 128) { std::cerr << fn << ": descriptors of dimension " << ds.shape[1] << " (this build matches 128-byte descriptors)" << std::endl; return false; }
+  if (xy.count() != 2 * n || sc.count() != n || rs.count() != n || ds.shape[0] != n) { std::cerr << fn << ": array lengths differ" << std::endl; return false; }
+  const double *pxy = (const double *)xy.data.data(), *psc = (const double *)sc.data.data(), *prs = (const double *)rs.data.data();
+  const double *pA = nullptr, *pang = nullptr;
+  if (z.count("A")) { if (z["A"].descr != "<f8" || z["A"].count() != 4 * n) { std::cerr << fn << ": bad A" << std::endl; return false; } pA = (const double *)z["A"].data.data(); }
+  else if (z.count("angles")) { if (z["angles"].descr != "<f8" || z["angles"].count() != n) { std::cerr << fn << ": bad angles" << std::endl; return false; } pang = (const double *)z["angles"].data.data(); }
+  out->assign(n, mods_region());
+  for (size_t i = 0; i < n; i++) {
+    mods_region &r = (*out)[i];
+    memset(&r, 0, sizeof(r));
+    r.x = pxy[2 * i]; r.y = pxy[2 * i + 1]; r.s = psc[i]; r.response = prs[i];
+    if (pA) { r.a11 = pA[4 * i]; r.a12 = pA[4 * i + 1]; r.a21 = pA[4 * i + 2]; r.a22 = pA[4 * i + 3]; }
+    else {
+      const double angle = pang ? pang[i] * M_PI / 180.0 : 0.0;
+      r.a11 = cos(angle); r.a12 = sin(angle); r.a21 = -sin(angle); r.a22 = cos(angle);
+    }
+    r.id = (int)i; r.parent = -1;
+    memcpy(r.desc, &ds.data[(size_t)128 * i], 128);
+  }
+  return true;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
+  if (argc == 4 && std::string(argv[1]) == "--npz-echo") {   // read an .npz keypoint file and write it back (format check, no GPU involved)
+    std::map<std::string, modscli::NpyArray> z;
+    std::string err;
+    if (!modscli::npz_read(argv[2], &z, &err)) { std::cerr << err << std::endl; return 1; }
+    std::vector<std::pair<std::string, modscli::NpyArray>> members(z.begin(), z.end());
+    if (!modscli::npz_write(argv[3], members, &err)) { std::cerr << err << std::endl; return 1; }
+    return 0;
+  }
   if (argc < Tmin) return usage();
   const double c_start = now_s();
   const std::string img1_fn = argv[1], img2_fn = argv[2], k1_fn = argv[5], k2_fn = argv[6], match_fn = argv[7], log_fn = argv[8];
@@ -229,7 +296,12 @@ int main(int argc, char **argv) {
   }
   if (argc >= Tmin + 4) config_fn = argv[Tmin + 3];
   if (argc >= Tmin + 5) iters_fn = argv[Tmin + 4];
-  if (argc >= Tmin + 6 && atoi(argv[Tmin + 5]) > 0) { std::cerr << "read_pre_extracted is not part of this build" << std::endl; return 1; }
+  const bool pre_extracted = argc >= Tmin + 6 && atoi(argv[Tmin + 5]) > 0;   // conf1.read_pre_extracted, io_mods.cpp:602
+  if (pre_extracted && !(ends_with(k1_fn, ".npz") && ends_with(k2_fn, ".npz"))) {
+    // (the reference's text reader, loadAR, expects a layout that its own SaveRegions does not write)
+    std::cerr << "read_pre_extracted: k1 and k2 must be .npz keypoint files" << std::endl;
+    return 1;
+  }
   Config cfg;
   memset(&cfg.pair, 0, sizeof(cfg.pair));
   if (read_config(config_fn, iters_fn, ver_type, &cfg)) return 1;
@@ -266,8 +338,16 @@ int main(int argc, char **argv) {
   }
   mods_ladder_result res;
   std::vector<double> matches((size_t)4 << 20);
-  if (mods_match_ladder_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, steps.data(), (int)steps.size(),
-                            cfg.min_matches, &cfg.pair, rep1, rep2, &res, matches.data(), 1 << 20))
+  if (pre_extracted) {   // mods.cpp:196-229: one step, the banks come from the keypoint files
+    std::vector<mods_region> r1, r2;
+    if (!read_regions_npz(k1_fn, &r1) || !read_regions_npz(k2_fn, &r2)) return 1;
+    if (cfg.verbose) std::cerr << "Pre-extracted regions: " << r1.size() << " | " << r2.size() << std::endl;
+    if ((!r1.empty() && mods_imgrep_append_host(rep1, r1.data(), (int)r1.size())) || (!r2.empty() && mods_imgrep_append_host(rep2, r2.data(), (int)r2.size())))
+      return fail("region banks");
+    if (mods_match_verify_reps(ctx, rep1, rep2, steps[0].fginn_ratio, &cfg.pair, &res, matches.data(), 1 << 20)) return fail("matching");
+    res.n_unoriented[0] = (int)r1.size(); res.n_unoriented[1] = (int)r2.size();
+  } else if (mods_match_ladder_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, steps.data(), (int)steps.size(),
+                                   cfg.min_matches, &cfg.pair, rep1, rep2, &res, matches.data(), 1 << 20))
     return fail("matching");
   const double final_time = now_s() - c_start;
   const int final_step = res.steps_done > 0 ? step_index[res.steps_done - 1] + 1 : 0;
@@ -302,10 +382,11 @@ int main(int argc, char **argv) {
         for (int i = 0; i < res.n_inliers; i++)
           mf << matches[4 * (size_t)i] << " " << matches[4 * (size_t)i + 1] << " " << matches[4 * (size_t)i + 2] << " " << matches[4 * (size_t)i + 3] << std::endl;
     }
-    if (cfg.write_keypoints) {
-      if (ends_with(k1_fn, ".npz") || ends_with(k2_fn, ".npz")) std::cerr << "Warning: .npz keypoint output is not part of this build; text is written" << std::endl;
-      write_regions(k1_fn, rep1, cfg.use_zmq ? "ZMQ" : "RootSIFT");
-      write_regions(k2_fn, rep2, cfg.use_zmq ? "ZMQ" : "RootSIFT");
+    if (cfg.write_keypoints && !pre_extracted) {   // mods.cpp:433-447
+      if (ends_with(k1_fn, ".npz")) write_regions_npz(k1_fn, rep1);
+      else write_regions(k1_fn, rep1, cfg.use_zmq ? "ZMQ" : "RootSIFT");
+      if (ends_with(k2_fn, ".npz")) write_regions_npz(k2_fn, rep2);
+      else write_regions(k2_fn, rep2, cfg.use_zmq ? "ZMQ" : "RootSIFT");
     }
   }
   std::cerr << "Image1: regions descriptors | Image2: regions descriptors " << std::endl;

@@ -45,3 +45,31 @@ def test_config_parsing_and_no_cpu_path(tmp_path):
     assert "Image1: 800x640, Image2: 800x640" in err
     assert "no MI355X / HIP device available" in err and "no CPU path" in err
     assert not os.path.exists(tmp_path / "m")
+
+
+def test_npz_keypoint_files_round_trip_with_numpy(tmp_path):
+    """The .npz reader / writer of the command line (cnpy's role, imagerepresentation.cpp:1257-1316, 1355-1513): an archive
+    written by numpy is read and written back member for member, and numpy reads the result."""
+    import subprocess
+    import numpy as np
+    rng = np.random.default_rng(5)
+    n = 37
+    src = {"xy": rng.random((n, 2)) * 500, "scales": rng.random((n, 1)) * 9 + 1, "responses": rng.standard_normal((n, 1)),
+           "A": rng.standard_normal((n, 4)), "descs": rng.integers(0, 256, (n, 128), dtype=np.uint8)}
+    np.savez(tmp_path / "in.npz", **src)
+    p = subprocess.run([MODS, "--npz-echo", str(tmp_path / "in.npz"), str(tmp_path / "out.npz")], stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 0, p.stderr.decode()
+    got = np.load(tmp_path / "out.npz")
+    assert sorted(got.files) == sorted(src)
+    for k, v in src.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+    # a one-dimensional member and an empty one
+    np.savez(tmp_path / "in2.npz", angles=np.arange(5, dtype=np.float64), empty=np.zeros((0, 2)))
+    p = subprocess.run([MODS, "--npz-echo", str(tmp_path / "in2.npz"), str(tmp_path / "out2.npz")], stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 0, p.stderr.decode()
+    got = np.load(tmp_path / "out2.npz")
+    assert np.array_equal(got["angles"], np.arange(5.0)) and got["empty"].shape == (0, 2)
+    # compressed archives are refused with a message
+    np.savez_compressed(tmp_path / "c.npz", **src)
+    p = subprocess.run([MODS, "--npz-echo", str(tmp_path / "c.npz"), str(tmp_path / "o.npz")], stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode != 0 and b"compressed" in p.stderr

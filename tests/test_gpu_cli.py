@@ -126,3 +126,39 @@ def test_cli_with_zmq_descriptor_daemon(pkg, tmp_path):
         assert lines[2].startswith("ZMQ ") and lines[3] == "128"
     finally:
         _stop(wire, d, port)
+
+
+def test_cli_npz_keypoints_and_pre_extracted_mode(pkg, tmp_path):
+    """k1 / k2 as .npz (SaveRegionsNPZ, imagerepresentation.cpp:1257-1316) and the pre-extracted mode (argument 15,
+    mods.cpp:196-229): the second run loads the regions of the first and must verify the same matches."""
+    env = dict(os.environ, MODS_RANSAC_SEED="4242")
+    base = [MODS, G1, G6, "o1.png", "o2.png", "k1.npz", "k2.npz"]
+    cfgs = [os.path.join(CFG, "classic.ini"), os.path.join(CFG, "iters_one_view.ini")]
+    p = subprocess.run(base + ["m.txt", "log.txt", "0", "0", "H.txt"] + cfgs, cwd=tmp_path, env=env, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()
+    res, m, regs = _library_run(pkg, [pkg.LadderStep.make((1,), 360.0)])
+    for fn, r in (("k1.npz", regs[0]), ("k2.npz", regs[1])):
+        z = np.load(tmp_path / fn)
+        assert sorted(z.files) == ["A", "descs", "responses", "scales", "xy"]
+        assert z["xy"].shape == (len(r), 2) and z["descs"].dtype == np.uint8 and z["descs"].shape == (len(r), 128)
+        assert np.array_equal(z["xy"], np.stack([r["x"], r["y"]], 1)) and np.array_equal(z["scales"][:, 0], r["s"])
+        assert np.array_equal(z["A"], np.stack([r["a11"], r["a12"], r["a21"], r["a22"]], 1))
+        assert np.array_equal(z["responses"][:, 0], r["response"]) and np.array_equal(z["descs"], r["desc"])
+    first = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    p = subprocess.run(base + ["m2.txt", "log2.txt", "0", "0", "H2.txt"] + cfgs + ["1"], cwd=tmp_path, env=env, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()
+    second = np.loadtxt(tmp_path / "m2.txt").reshape(-1, 4)
+    assert len(first) == res.n_inliers and np.array_equal(first, second)
+    assert np.array_equal(np.loadtxt(tmp_path / "H.txt"), np.loadtxt(tmp_path / "H2.txt"))
+    l1, l2 = (tmp_path / "log.txt").read_text().split(), (tmp_path / "log2.txt").read_text().split()
+    assert l1[1:4] == l2[1:4]          # inliers, unique tentatives, ratio
+    # the same through the library: banks filled from the host, one match + verify pass
+    import torch
+    ctx = pkg.Context(0, 64, 64, 1)
+    rep1, rep2 = pkg.ImgRep(ctx, 1 << 16), pkg.ImgRep(ctx, 1 << 16)
+    rep1.append_host(regs[0]); rep2.append_host(regs[1])
+    pkg.ransac_pin_seed(4242)
+    r2, m2 = pkg.match_verify_reps(ctx, rep1, rep2, 0.8, max_matches=1 << 16)
+    pkg.ransac_pin_seed(-1)
+    assert (r2.n_tentatives, r2.n_unique, r2.n_inliers) == (res.n_tentatives, res.n_unique, res.n_inliers) and np.array_equal(m2, m)
+    rep1.close(); rep2.close(); ctx.close()
