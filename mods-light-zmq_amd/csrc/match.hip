@@ -85,7 +85,11 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 //     ~32/T per tile.
 // A wave keeps QB query blocks resident (QB x 4 B-operand registers): every A tile fetched from L1/L2 feeds
 // QB x 4 MFMAs.
-constexpr int MATCH_QB = 2;
+constexpr int MATCH_QB = 2;        // pass 2 (its exact path is taken per wave: fewer queries per wave, fewer exact tiles)
+#ifndef MATCH_QB_NN1
+#define MATCH_QB_NN1 2   // measured: 4 blocks per wave (16 MFMAs per tile) run slower, 0.67 vs 0.39 ms on 56 k x 40 k
+#endif
+constexpr int MATCH_QB1 = MATCH_QB_NN1;   // pass 1: 16 MFMAs per train tile and wave
 
 __device__ __forceinline__ int acc_max16(const v16i &acc) {
   int m = max(max(acc[0], acc[1]), acc[2]);
@@ -108,12 +112,28 @@ __device__ __forceinline__ v16i acc_seed(const int *__restrict__ c2n, int tbase,
   return acc;
 }
 
+// LDS image of a train tile: 32 rows of 128 int8 at a padded stride (144 B: the 16-byte operand reads of 16 consecutive
+// rows then fall into distinct banks), followed by the 32 accumulator seeds
+constexpr int MT_ROW = 144;
+constexpr int MT_BYTES = 32 * MT_ROW + 128;
+struct TileRegs { v4i a; int s; };
+__device__ __forceinline__ TileRegs tile_fetch(const int8_t *__restrict__ tdesc, const int *__restrict__ tc2n, int tt) {
+  TileRegs r;
+  r.a = *(const v4i *)(tdesc + (size_t)tt * 4096 + threadIdx.x * 16);
+  r.s = threadIdx.x < 32 ? tc2n[tt * 32 + threadIdx.x] : 0;
+  return r;
+}
+__device__ __forceinline__ void tile_store(char *buf, const TileRegs &r) {
+  *(v4i *)(buf + (threadIdx.x >> 3) * MT_ROW + (threadIdx.x & 7) * 16) = r.a;
+  if (threadIdx.x < 32) ((int *)(buf + 32 * MT_ROW))[threadIdx.x] = r.s;
+}
+
 // Pass 1: nearest neighbour key (d << 32 | t) per query.  grid = (ceil(n_q/(128*QB)), splits), block 256.
 __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                         const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
                                                         const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                         unsigned long long *__restrict__ best) {
-  constexpr int QB = MATCH_QB;
+  constexpr int QB = MATCH_QB1;
   const int lane = threadIdx.x & 63, g = lane >> 5;
   const int jbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
   v4i bq[QB][4];
@@ -132,16 +152,25 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
   const int n_tiles = (k.n_t + 31) / 32;
   const int t0 = blockIdx.y * k.tiles_per_split;
   const int t1 = min(n_tiles, t0 + k.tiles_per_split);
+  // The four waves of a workgroup walk the same train tiles: a tile (32 x 128 B) and its 32 accumulator seeds are fetched
+  // from global memory once per workgroup (one 16-byte load per thread), handed over through LDS (double buffered, one
+  // barrier per tile) and read from there as MFMA operands; the next tile's loads are in flight during the MFMAs.
+  __shared__ __attribute__((aligned(16))) char s_tile[2 * MT_BYTES];
+  TileRegs nxt;
+  if (t0 < t1) { nxt = tile_fetch(tdesc, tc2n, t0); tile_store(s_tile, nxt); }
+  __syncthreads();
   for (int tt = t0; tt < t1; tt++) {
     const int tbase = tt * 32;
-    const int8_t *arow = tdesc + (size_t)(tbase + (lane & 31)) * 128 + g * 16;
+    const char *cur = s_tile + ((tt - t0) & 1) * MT_BYTES;
+    if (tt + 1 < t1) nxt = tile_fetch(tdesc, tc2n, tt + 1);
     v4i a[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(arow + ks * 32);
+    for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(cur + (lane & 31) * MT_ROW + ks * 32 + g * 16);
     const unsigned int par = tpar[tt];   // wave-uniform: ct & 1 of the 32 train rows
     v16i acc[QB];
+    acc[0] = acc_seed((const int *)(cur + 32 * MT_ROW), 0, g);
 #pragma unroll
-    for (int b = 0; b < QB; b++) acc[b] = acc_seed(tc2n, tbase, g);
+    for (int b = 1; b < QB; b++) acc[b] = acc[0];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++)
 #pragma unroll
@@ -164,6 +193,8 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
       }
       thr[b] = min(thr[b], __shfl_xor(thr[b], 32));   // the two half-waves hold the same 32 queries (different train rows)
     }
+    if (tt + 1 < t1) tile_store(s_tile + (((tt - t0) & 1) ^ 1) * MT_BYTES, nxt);
+    __syncthreads();
   }
 #pragma unroll
   for (int b = 0; b < QB; b++) {
@@ -244,6 +275,29 @@ __global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const in
   const int n_tiles = (k.n_t + 31) / 32;
   const int t0 = blockIdx.y * k.tiles_per_split;
   const int t1 = min(n_tiles, t0 + k.tiles_per_split);
+#ifdef MATCH_FGINN_SHARED
+  // The four waves of a workgroup walk the same train tiles: a tile (32 x 128 B) and its 32 accumulator seeds are fetched
+  // from global memory once per workgroup (one 16-byte load per thread), handed over through LDS (double buffered, one
+  // barrier per tile) and read from there as MFMA operands; the next tile's loads are in flight during the MFMAs.
+  __shared__ __attribute__((aligned(16))) char s_tile[2 * MT_BYTES];
+  TileRegs nxt;
+  if (t0 < t1) { nxt = tile_fetch(tdesc, tc2n, t0); tile_store(s_tile, nxt); }
+  __syncthreads();
+  for (int tt = t0; tt < t1; tt++) {
+    const int tbase = tt * 32;
+    const char *cur = s_tile + ((tt - t0) & 1) * MT_BYTES;
+    if (tt + 1 < t1) nxt = tile_fetch(tdesc, tc2n, tt + 1);
+    v4i a[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(cur + (lane & 31) * MT_ROW + ks * 32 + g * 16);
+    const unsigned int par = tpar[tt];   // wave-uniform: ct & 1 of the 32 train rows
+    v16i acc[QB];
+    acc[0] = acc_seed((const int *)(cur + 32 * MT_ROW), 0, g);
+#pragma unroll
+    for (int b = 1; b < QB; b++) acc[b] = acc[0];
+#else
+  // (pass 2 takes the exact path on most tiles at these list sizes: its waves drift apart, a barrier per tile costs more than
+  // the shared fetch saves, so every wave fetches its own operands)
   for (int tt = t0; tt < t1; tt++) {
     const int tbase = tt * 32;
     const int8_t *arow = tdesc + (size_t)(tbase + (lane & 31)) * 128 + g * 16;
@@ -252,8 +306,10 @@ __global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const in
     for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(arow + ks * 32);
     const unsigned int par = tpar[tt];   // wave-uniform: ct & 1 of the 32 train rows
     v16i acc[QB];
+    acc[0] = acc_seed(tc2n, tbase, g);
 #pragma unroll
-    for (int b = 0; b < QB; b++) acc[b] = acc_seed(tc2n, tbase, g);
+    for (int b = 1; b < QB; b++) acc[b] = acc[0];
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ks++)
 #pragma unroll
@@ -287,6 +343,10 @@ __global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const in
       }
       thr[b] = min(thr[b], __shfl_xor(thr[b], 32));
     }
+#ifdef MATCH_FGINN_SHARED
+    if (tt + 1 < t1) tile_store(s_tile + (((tt - t0) & 1) ^ 1) * MT_BYTES, nxt);
+    __syncthreads();
+#endif
   }
 #pragma unroll
   for (int b = 0; b < QB; b++) {
@@ -437,7 +497,14 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   int splits = std::max(1, std::min(n_tiles, target_blocks / std::max(1, qblocks)));
   k.tiles_per_split = (n_tiles + splits - 1) / splits;
   splits = (n_tiles + k.tiles_per_split - 1) / k.tiles_per_split;
-  hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, tc2, tpar, best);
+  {
+    const int qblocks1 = (n_q + 128 * MATCH_QB1 - 1) / (128 * MATCH_QB1);
+    int splits1 = std::max(1, std::min(n_tiles, target_blocks / std::max(1, qblocks1)));
+    MatchConst k1 = k;
+    k1.tiles_per_split = (n_tiles + splits1 - 1) / splits1;
+    splits1 = (n_tiles + k1.tiles_per_split - 1) / k1.tiles_per_split;
+    hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks1, splits1), dim3(256), 0, ctx->stream, k1, qd, qc, td, tc, tc2, tpar, best);
+  }
   hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best, txy, (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
   hipLaunchKernelGGL(match_fginn_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, tc2, tpar, txy, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
   const int eblocks = (n_q + 1023) / 1024;

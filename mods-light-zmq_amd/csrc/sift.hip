@@ -1430,8 +1430,10 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   const size_t patch_elems = (size_t)n_img * k.reg_cap * pp;
   const int max_big = 1 << 17, max_items = 1 << 20;
   const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + 3 * sizeof(int2) * max_items + 15) / 4;
-  // slab pool: ~45 M floats per 1080p image in practice; 64 M per image of the batch, at least 1 GiB
-  const unsigned long long pool_elems = std::max<unsigned long long>(256ull << 20, (unsigned long long)n_img * (64ull << 20));
+  // slab pool: ~25 M floats per 1080p image in practice (row-pass strips, S only above 256 px); 64 M per image of the batch
+  // and per 2 Mpx of image area, at least 1 GiB
+  const unsigned long long area_units = std::max<unsigned long long>(1, ((unsigned long long)k.w * k.h + (1ull << 21) - 1) >> 21);
+  const unsigned long long pool_elems = std::max<unsigned long long>(256ull << 20, (unsigned long long)n_img * area_units * (64ull << 20));
   const size_t need = patch_elems + book_elems + pool_elems;
   if (need > ctx->desc_scratch_elems) {
     MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
