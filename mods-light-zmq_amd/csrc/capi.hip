@@ -119,6 +119,8 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipHostFree(c->host_counts);
   (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
+  (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
+  (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipFree(c->m_u6); (void)hipFree(c->m_laf); (void)hipFree(c->m_count); (void)hipFree(c->m_regs);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -120,6 +120,8 @@ struct mods_ctx {
   unsigned long long *m_u64 = nullptr;
   int *m_int = nullptr;
   void *m_mid = nullptr;
+  void *m_p2 = nullptr;              // pass-1 top-2 keys per train split, pass-2 query subset (see match.hip)
+  size_t m_best2_cap = 0;            // entries (pairs of keys) in the top-2 table
   mods_tentative *m_tent = nullptr;
   double *m_u6 = nullptr;            // [pad][6] correspondences (x1 y1 1 x2 y2 1)
   double *m_laf = nullptr;           // [pad][14] frames (x y a11 a12 a21 a22 s) of both regions

@@ -128,17 +128,20 @@ __device__ __forceinline__ void tile_store(char *buf, const TileRegs &r) {
   if (threadIdx.x < 32) ((int *)(buf + 32 * MT_ROW))[threadIdx.x] = r.s;
 }
 
-// Pass 1: nearest neighbour key (d << 32 | t) per query.  grid = (ceil(n_q/(128*QB)), splits), block 256.
+// Pass 1: the two smallest keys (d << 32 | t) per query and train split.  grid = (ceil(n_q/(128*QB)), splits), block 256.
+// The second key is what makes pass 2 rare: with (d1, t1) the smallest key over t != i0, a query whose d1 is >= D* has no
+// train below D* at all and its first train at or above D* IS (d1, t1) - see match_mid_kernel.
+// best2: [split][n_qpad][2], n_qpad = gridDim.x * 128 * QB (plain stores: every (split, query) has one owner).
 __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                         const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
                                                         const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
-                                                        unsigned long long *__restrict__ best) {
+                                                        unsigned long long *__restrict__ best2, int *__restrict__ gthr) {
   constexpr int QB = MATCH_QB1;
   const int lane = threadIdx.x & 63, g = lane >> 5;
   const int jbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
   v4i bq[QB][4];
   int cq[QB], thr[QB];
-  unsigned long long mine[QB];
+  unsigned long long mine[QB], sec[QB];
 #pragma unroll
   for (int b = 0; b < QB; b++) {
     const int j = jbase + 32 * b;
@@ -146,8 +149,11 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) bq[b][ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
     cq[b] = qc[jc] - 4194304;
-    thr[b] = 0x7fffffff;
-    mine[b] = ~0ull;
+    // bound on (second smallest distance) - cq + 1 shared by the workgroups that scan other train ranges for the same queries
+    // (gthr starts at 0x7f7f7f7f = no bound): the global second key is at most any split's second key, so trains above it
+    // cannot be among the two nearest
+    thr[b] = __hip_atomic_load(&gthr[jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mine[b] = ~0ull; sec[b] = ~0ull;
   }
   const int n_tiles = (k.n_t + 31) / 32;
   const int t0 = blockIdx.y * k.tiles_per_split;
@@ -177,31 +183,51 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
       for (int b = 0; b < QB; b++) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], bq[b][ks], acc[b], 0, 0, 0);
 #pragma unroll
     for (int b = 0; b < QB; b++) {
-      const int amax = acc_max16(acc[b]);
-      if (-2 * amax < thr[b]) {        // some train of this tile may be nearer than the best so far
-        // d - cq = (ct & 1) - 2*acc: the nearest train of the tile is among the rows that hold the maximum
+      // -2*acc < thr  <=>  acc >= alim (one compare per accumulator)
+      const int alim = (-thr[b] >> 1) + 1;
+      if (acc_max16(acc[b]) >= alim) {   // some train of this tile may be among the two nearest so far
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          if (acc[b][r] != amax) continue;
+          if (acc[b][r] < alim) continue;                                  // d - cq >= -2*acc >= thr
           const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
           const int t = tbase + row;
-          const int dpr = (int)((par >> row) & 1u) - 2 * amax;             // exact
+          const int dpr = (int)((par >> row) & 1u) - 2 * acc[b][r];       // exact
+          if (t >= k.n_t || !(dpr < thr[b])) continue;
           const unsigned long long key = ((unsigned long long)(unsigned int)(dpr + cq[b]) << 32) | (unsigned int)t;
-          if (t < k.n_t && dpr < thr[b] && key < mine[b]) mine[b] = key;   // ties: the earlier index stays
+          if (key < mine[b]) { sec[b] = mine[b]; mine[b] = key; }
+          else if (key < sec[b]) sec[b] = key;
         }
-        if (mine[b] != ~0ull) thr[b] = (int)(mine[b] >> 32) - cq[b];
+        if (sec[b] != ~0ull) thr[b] = min(thr[b], (int)(sec[b] >> 32) - cq[b] + 1);    // an equal distance at a lower index still counts
       }
-      thr[b] = min(thr[b], __shfl_xor(thr[b], 32));   // the two half-waves hold the same 32 queries (different train rows)
+      // the two half-waves hold the same 32 queries (different train rows): the second key of their union is at most the
+      // smaller of their second keys
+      thr[b] = min(thr[b], __shfl_xor(thr[b], 32));
+    }
+    if (((tt - t0) & 15) == 15) {   // publish / pick up the bound every 16 tiles
+#pragma unroll
+      for (int b = 0; b < QB; b++) {
+        const int j = jbase + 32 * b;
+        if (g == 0 && j < k.n_q) thr[b] = min(thr[b], atomicMin(&gthr[j], thr[b]));
+        thr[b] = min(thr[b], __shfl_xor(thr[b], 32));
+      }
     }
     if (tt + 1 < t1) tile_store(s_tile + (((tt - t0) & 1) ^ 1) * MT_BYTES, nxt);
     __syncthreads();
   }
+  const size_t n_qpad = (size_t)gridDim.x * 128 * QB;
 #pragma unroll
   for (int b = 0; b < QB; b++) {
-    const unsigned long long other = shfl_xor_u64(mine[b], 32);
-    if (other < mine[b]) mine[b] = other;
+    const unsigned long long o1 = shfl_xor_u64(mine[b], 32), o2 = shfl_xor_u64(sec[b], 32);
+    const unsigned long long m1 = mine[b] < o1 ? mine[b] : o1;
+    const unsigned long long hi = mine[b] < o1 ? o1 : mine[b];
+    const unsigned long long lo2 = sec[b] < o2 ? sec[b] : o2;
+    const unsigned long long m2 = hi < lo2 ? hi : lo2;
     const int j = jbase + 32 * b;
-    if (g == 0 && j < k.n_q && mine[b] != ~0ull) atomicMin(&best[j], mine[b]);
+    if (g == 0 && j < k.n_q) {
+      atomicMin(&gthr[j], thr[b]);
+      unsigned long long *o = best2 + ((size_t)blockIdx.y * n_qpad + j) * 2;
+      o[0] = m1; o[1] = m2;
+    }
   }
 }
 
@@ -216,17 +242,31 @@ __device__ __forceinline__ bool ratio_ok(int d0, int d, double sqmin) {
   return ratio <= sqmin;
 }
 
-// grid = ceil(n_q/256), block 256.  Also clears the pass-2 accumulators.
-__global__ __launch_bounds__(256) void match_mid_kernel(MatchConst k, const unsigned long long *__restrict__ best,
+// grid = ceil(n_q/256), block 256.  Merges the top-2 keys of the train splits and settles every query that does not need
+// pass 2.  With (d0, i0) the nearest train, D* the smallest distance passing the ratio test and (d1, t1) the smallest key over
+// t != i0:
+//   d1 >= D*                       no train lies below D*, and the first train at or above D* is (d1, t1): accepted with
+//                                  key_ge = (d1, t1), n_lt = 0 (what pass 2 would have found)
+//   d1 <  D*, t1 far from i0       a contradicting neighbour below D*: bad, rejected whatever the other trains are
+//   d1 <  D*, t1 near i0           undecided: the query goes on the pass-2 list (descriptor, norm and state are copied to the
+//                                  compact arrays by match_gather_kernel)
+__global__ __launch_bounds__(256) void match_mid_kernel(MatchConst k, const unsigned long long *__restrict__ best2, int splits, size_t n_qpad,
                                                         const double2 *__restrict__ txy, QueryMid *__restrict__ mid,
                                                         unsigned long long *__restrict__ key_ge, unsigned long long *__restrict__ key_lt,
-                                                        int *__restrict__ n_lt, int *__restrict__ bad) {
+                                                        int *__restrict__ n_lt, int *__restrict__ bad, int *__restrict__ list2,
+                                                        int *__restrict__ count2) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= k.n_q) return;
-  const unsigned long long b = best[j];
+  unsigned long long m1 = ~0ull, m2 = ~0ull;
+  for (int sp = 0; sp < splits; sp++) {
+    const unsigned long long *p = best2 + ((size_t)sp * n_qpad + j) * 2;
+    const unsigned long long a = p[0], b = p[1];
+    if (a < m1) { m2 = m1 < b ? m1 : b; m1 = a; }      // (a <= b within a split)
+    else if (a < m2) m2 = a;
+  }
   QueryMid m;
-  m.i0 = (int)(unsigned int)b;
-  m.d0 = (int)(b >> 32);
+  m.i0 = (int)(unsigned int)m1;
+  m.d0 = (int)(m1 >> 32);
   m.pad = 0;
   int ds;
   if (m.d0 == 0) ds = 1;
@@ -242,7 +282,32 @@ __global__ __launch_bounds__(256) void match_mid_kernel(MatchConst k, const unsi
   const double2 p = txy[m.i0];
   m.x0 = p.x; m.y0 = p.y;
   mid[j] = m;
-  key_ge[j] = ~0ull; key_lt[j] = ~0ull; n_lt[j] = 0; bad[j] = 0;
+  unsigned long long kg = ~0ull;
+  int isbad = 0;
+  if (m2 != ~0ull) {
+    if ((int)(m2 >> 32) >= ds) kg = m2;
+    else {
+      const double2 q = txy[(unsigned int)m2];
+      const double dx = m.x0 - q.x, dy = m.y0 - q.y;
+      if (dx * dx + dy * dy > k.contr_sq) isbad = 1;
+      else list2[atomicAdd(count2, 1)] = j;
+    }
+  }
+  key_ge[j] = kg; key_lt[j] = ~0ull; n_lt[j] = 0; bad[j] = isbad;
+}
+
+// one wave per pass-2 query: descriptor row, norm and state into the compact arrays.  grid = ceil(n_q/4), block 256.
+__global__ __launch_bounds__(256) void match_gather_kernel(const int *__restrict__ list2, const int *__restrict__ count2,
+                                                           const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
+                                                           const QueryMid *__restrict__ mid, int8_t *__restrict__ qdesc2,
+                                                           int *__restrict__ qc2, QueryMid *__restrict__ mid2) {
+  const int n2 = *count2;
+  const int lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n2; i += gridDim.x * 4) {
+    const int j = list2[i];
+    ((short *)(qdesc2 + (size_t)i * 128))[lane] = ((const short *)(qdesc + (size_t)j * 128))[lane];
+    if (lane == 0) { qc2[i] = qc[j]; mid2[i] = mid[j]; }
+  }
 }
 
 // Pass 2: FGINN reductions.  Same tiling and the same two-speed epilogue as pass 1: a tile is examined exactly
@@ -252,8 +317,13 @@ __global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const in
                                                           const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                           const double2 *__restrict__ txy, const QueryMid *__restrict__ mid,
                                                           unsigned long long *__restrict__ key_ge, unsigned long long *__restrict__ key_lt,
-                                                          int *__restrict__ n_lt, int *__restrict__ bad) {
+                                                          int *__restrict__ n_lt, int *__restrict__ bad,
+                                                          const int *__restrict__ n_q_dev, const int *__restrict__ out_index) {
   constexpr int QB = MATCH_QB;
+  // the query list of this pass is the compact list of match_mid_kernel: its length lives on the device, and results go to
+  // the slots of the original queries
+  k.n_q = *n_q_dev;
+  if ((int)blockIdx.x * 4 * 32 * QB >= k.n_q) return;
   const int lane = threadIdx.x & 63, g = lane >> 5;
   const int jbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
   v4i bq[QB][4];
@@ -354,8 +424,9 @@ __global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const in
     o = shfl_xor_u64(klt[b], 32); if (o < klt[b]) klt[b] = o;
     cnt[b] += __shfl_xor(cnt[b], 32);
     isbad[b] |= __shfl_xor(isbad[b], 32);
-    const int j = jbase + 32 * b;
-    if (g == 0 && j < k.n_q) {
+    const int jq = jbase + 32 * b;
+    if (g == 0 && jq < k.n_q) {
+      const int j = out_index[jq];
       if (kge[b] != ~0ull) atomicMin(&key_ge[j], kge[b]);
       if (klt[b] != ~0ull) atomicMin(&key_lt[j], klt[b]);
       if (cnt[b]) atomicAdd(&n_lt[j], cnt[b]);
@@ -445,6 +516,10 @@ __global__ __launch_bounds__(1024) void match_emit_kernel(MatchConst k, const Qu
 }
 
 // ---------------------------------------------------------------------------------------
+static int match_target_blocks() {
+  static const int v = getenv("MODS_MATCH_BLOCKS") ? std::max(1, atoi(getenv("MODS_MATCH_BLOCKS"))) : 2048;
+  return v;
+}
 static size_t match_pad(const mods_ctx *ctx) { return ((size_t)ctx->max_cand + 127) & ~(size_t)63; }   // list stride, tile tail included
 
 int match_ensure_buffers(mods_ctx *ctx) {
@@ -459,6 +534,10 @@ int match_ensure_buffers(mods_ctx *ctx) {
   MODS_HIP_CHECK(hipMalloc(&ctx->m_u64, 3 * n * sizeof(unsigned long long)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_int, (2 * n + n / 1024 + 2) * sizeof(int)));   // n_lt, bad, per-block counts of the compaction
   MODS_HIP_CHECK(hipMalloc(&ctx->m_mid, n * sizeof(QueryMid)));
+  // pass-1 top-2 table (one pair of keys per query and train split; splits * query blocks <= target blocks + query blocks) and
+  // the pass-2 subset: list | count | norms | descriptors | state
+  ctx->m_best2_cap = (size_t)match_target_blocks() * 128 * MATCH_QB1 + n + 128 * MATCH_QB1;
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_p2, ctx->m_best2_cap * 16 + n * (3 * sizeof(int) + 128 + sizeof(QueryMid)) + 128));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, n * sizeof(mods_tentative)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_count, sizeof(int)));
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_desc, 0, 2 * n * 128, ctx->stream));
@@ -490,23 +569,39 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   StageScope ts(ctx, MODS_STAGE_MATCH);
   hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
   hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
-  MODS_HIP_CHECK(hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * n_q, ctx->stream));
   const int n_tiles = (n_t + 31) / 32;
-  const int qblocks = (n_q + 128 * MATCH_QB - 1) / (128 * MATCH_QB);
-  static const int target_blocks = getenv("MODS_MATCH_BLOCKS") ? atoi(getenv("MODS_MATCH_BLOCKS")) : 2048;
-  int splits = std::max(1, std::min(n_tiles, target_blocks / std::max(1, qblocks)));
-  k.tiles_per_split = (n_tiles + splits - 1) / splits;
-  splits = (n_tiles + k.tiles_per_split - 1) / k.tiles_per_split;
+  const int target_blocks = match_target_blocks();
+  // carve of m_p2 (every part 16-byte aligned)
+  unsigned long long *best2 = (unsigned long long *)ctx->m_p2;
+  QueryMid *mid2 = (QueryMid *)(best2 + 2 * ctx->m_best2_cap);
+  int8_t *qd2 = (int8_t *)(mid2 + n);
+  int *list2 = (int *)(qd2 + n * 128), *qcs = list2 + n, *count2 = qcs + n;
+  int *gthr = count2 + 16;
+  MODS_HIP_CHECK(hipMemsetAsync(count2, 0, sizeof(int), ctx->stream));
+  MODS_HIP_CHECK(hipMemsetAsync(gthr, 0x7f, sizeof(int) * n_q, ctx->stream));
+  (void)best;
+  // pass 1: top-2 keys per query and train split
+  const int qblocks1 = (n_q + 128 * MATCH_QB1 - 1) / (128 * MATCH_QB1);
+  int splits1 = std::max(1, std::min(n_tiles, target_blocks / std::max(1, qblocks1)));
+  MatchConst k1 = k;
+  k1.tiles_per_split = (n_tiles + splits1 - 1) / splits1;
+  splits1 = (n_tiles + k1.tiles_per_split - 1) / k1.tiles_per_split;
+  const size_t n_qpad = (size_t)qblocks1 * 128 * MATCH_QB1;
+  if ((size_t)splits1 * n_qpad > ctx->m_best2_cap) { set_error("match: top-2 table too small"); return MODS_E_CAPACITY; }
+  hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks1, splits1), dim3(256), 0, ctx->stream, k1, qd, qc, td, tc, tc2, tpar, best2, gthr);
+  hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best2, splits1, n_qpad, txy, (QueryMid *)ctx->m_mid,
+                     key_ge, key_lt, n_lt, bad, list2, count2);
+  // pass 2 on the undecided queries only (their number stays on the device: the grid covers the worst case, idle blocks exit)
+  hipLaunchKernelGGL(match_gather_kernel, dim3(std::min(1024, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, list2, count2, qd, qc,
+                     (const QueryMid *)ctx->m_mid, qd2, qcs, mid2);
   {
-    const int qblocks1 = (n_q + 128 * MATCH_QB1 - 1) / (128 * MATCH_QB1);
-    int splits1 = std::max(1, std::min(n_tiles, target_blocks / std::max(1, qblocks1)));
-    MatchConst k1 = k;
-    k1.tiles_per_split = (n_tiles + splits1 - 1) / splits1;
-    splits1 = (n_tiles + k1.tiles_per_split - 1) / k1.tiles_per_split;
-    hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks1, splits1), dim3(256), 0, ctx->stream, k1, qd, qc, td, tc, tc2, tpar, best);
+    const int qblocks = (n_q + 128 * MATCH_QB - 1) / (128 * MATCH_QB);
+    int splits = std::max(1, std::min(n_tiles, std::max(32, target_blocks / std::max(1, qblocks))));
+    k.tiles_per_split = (n_tiles + splits - 1) / splits;
+    splits = (n_tiles + k.tiles_per_split - 1) / k.tiles_per_split;
+    hipLaunchKernelGGL(match_fginn_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd2, qcs, td, tc, tc2, tpar, txy,
+                       (const QueryMid *)mid2, key_ge, key_lt, n_lt, bad, count2, list2);
   }
-  hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best, txy, (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
-  hipLaunchKernelGGL(match_fginn_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd, qc, td, tc, tc2, tpar, txy, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad);
   const int eblocks = (n_q + 1023) / 1024;
   int *block_counts = (int *)(ctx->m_int + 2 * n);
   hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
