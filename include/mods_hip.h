@@ -97,7 +97,9 @@ void *mods_ctx_stream(mods_ctx *ctx);            /* hipStream_t the kernels run 
  * named stage is bracketed by events on the context's stream. */
 enum { MODS_STAGE_BLUR = 0, MODS_STAGE_RESPONSE, MODS_STAGE_RESIZE, MODS_STAGE_NMS, MODS_STAGE_LOCALIZE,
        MODS_STAGE_BAUMBERG, MODS_STAGE_SORT, MODS_STAGE_ORIENT, MODS_STAGE_DESCRIBE, MODS_STAGE_MATCH,
-       MODS_STAGE_RANSAC_SCORE, MODS_STAGE_SYNTH, MODS_STAGE_COUNT };
+       MODS_STAGE_RANSAC_SCORE, MODS_STAGE_SYNTH,
+       MODS_STAGE_BLUR_SMALL,   /* blur launches of the small planes (the 16-row tile instantiation); MODS_STAGE_BLUR: 32-row tiles */
+       MODS_STAGE_COUNT };
 int mods_ctx_timing_enable(mods_ctx *ctx, int stage_mask);
 /* sums since the last reset; resolves pending events (synchronises the stream) */
 int mods_ctx_timing_read(mods_ctx *ctx, int stage, double *total_ms, int *launches, double *bytes);

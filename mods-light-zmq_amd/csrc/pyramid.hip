@@ -421,7 +421,9 @@ static int blur_with_slot(mods_ctx *ctx, const float *src, float *dst, int w, in
   if (r >= 1 && r <= 8 && ctx->taps_host_n[slot] == n) {
     BlurTaps taps;
     for (int i = 0; i < 17; i++) taps.t[i] = i < n ? ctx->taps_host[slot][i] : 0.f;
-    StageScope ts(ctx, MODS_STAGE_BLUR, 8.0 * w * h * n_img);
+    // (the two tile instantiations are timed separately: launches of the small planes are launch-size bound)
+    const bool big_tiles = ((w + FB_TW - 1) / FB_TW) * ((h + 63) / 64) * n_img >= 384;
+    StageScope ts(ctx, big_tiles ? MODS_STAGE_BLUR : MODS_STAGE_BLUR_SMALL, 8.0 * w * h * n_img);
     switch (r) {
       case 1: launch_fast_blur<1>(ctx, src, dst, w, h, n_img, taps); break;
       case 2: launch_fast_blur<2>(ctx, src, dst, w, h, n_img, taps); break;

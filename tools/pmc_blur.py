@@ -16,7 +16,7 @@ def load(fn, counter):
     return per
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-rows, tot_b, tot_n = [], 0.0, 0
+rows, tot_b, tot_n, big_b, big_n = [], 0.0, 0, 0.0, 0
 for key in sorted(fetch):
     f, w = fetch[key], write.get(key, [])
     n = min(len(f), len(w)) if w else len(f)
@@ -24,10 +24,13 @@ for key in sorted(fetch):
     wm = sum(w) / len(w) * 1024 / 1e6 if w else float("nan")
     rows.append((key[0], key[1], len(f), fm, wm))
     tot_b += (fm + wm) * 1e6 * len(f); tot_n += len(f)
+    if "; 32;" in key[0]:          # the 32-row-tile instantiation (the large planes): the kernel bench.py's roofline names
+        big_b += (fm + wm) * 1e6 * len(f); big_n += len(f)
 out = open(sys.argv[3], "w") if len(sys.argv) > 3 else sys.stdout
 out.write("# HBM traffic of the pyramid blur kernels: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)\n")
 out.write("# counters in KB; FETCH_SIZE doubled (gfx950); mean over all blur launches = %.0f bytes per launch (%d launches)\n" % (tot_b / max(tot_n, 1), tot_n))
+out.write("# launches of gauss_blur_fast_kernel<R; 32; 2> only: %.0f bytes per launch (%d launches)\n" % (big_b / max(big_n, 1), big_n))
 out.write("kernel,grid_threads,launches,fetch_MB_per_launch(x2),write_MB_per_launch\n")
 for r in rows:
     out.write("%s,%d,%d,%.3f,%.3f\n" % r)
-print("mean_traffic_bytes_per_launch %.0f over %d launches" % (tot_b / max(tot_n, 1), tot_n))
+print("mean_traffic_bytes_per_launch %.0f over %d launches; 32-row instantiation %.0f over %d" % (tot_b / max(tot_n, 1), tot_n, big_b / max(big_n, 1), big_n))
