@@ -167,6 +167,14 @@ int mods_detect_describe_dev(mods_ctx *ctx, const float *img_dev, int n_img, int
  * (user = endpoint string) with this signature. */
 typedef int (*mods_descriptor_fn)(void *user, const float *patches, int n, int ps, float *out, size_t out_cap_floats, int *dim);
 int mods_ctx_set_external_descriptor(mods_ctx *ctx, mods_descriptor_fn fn, void *user, double mrSize, int patchSize);
+/* External affine shape and orientation (reference: [AffineAdaptation] useZMQ=1 with AffNet, [DominantOrientation] useZMQ=1 with
+ * OriNet; imagerepresentation.cpp:786-856, 874-900).  While a shape function is set, the describe stage replaces the frame of
+ * every detected keypoint (detect with doBaumberg = 0) by the function's (a11, a21, a22) for its ExtractPatchesColumn patch
+ * (3 values per patch), rectified "up is up", and drops keypoints by the reference's eigenvalue-ratio and border tests.  While
+ * an orientation function is set, the dominant-orientation estimate is replaced by atan2(y, x) of the function's 2 values per
+ * patch.  Same callback type as the descriptor (libmodszmq's mods_zmq_descriptor_hook with the daemon's endpoint as user). */
+int mods_ctx_set_external_shape(mods_ctx *ctx, mods_descriptor_fn fn, void *user, double mrSize, int patchSize);
+int mods_ctx_set_external_orientation(mods_ctx *ctx, mods_descriptor_fn fn, void *user, double mrSize, int patchSize);
 int mods_patches_fetch(mods_ctx *ctx, int img, int ps, float *out, int max_regions, int *n_out);   /* patches of the last describe call */
 int mods_unoriented_count(mods_ctx *ctx, int img);   /* |"None" region list| of slot img after the last describe call */
 int mods_regions_fetch(mods_ctx *ctx, int img, mods_region *out, int max_out, int *n_out);

@@ -246,6 +246,14 @@ class Context:
         (keep the object it points to alive).  fn_ptr = None restores RootSIFT."""
         _check(lib().mods_ctx_set_external_descriptor(self.h, C.c_void_p(fn_ptr), C.c_void_p(user), C.c_double(mr_size), patch_size))
 
+    def set_external_shape(self, fn_ptr, user, mr_size=3.0 * np.sqrt(3.0), patch_size=32):
+        """AffNet in the place of Baumberg (detect with doBaumberg = 0): fn returns (a11, a21, a22) per patch.  None: off."""
+        _check(lib().mods_ctx_set_external_shape(self.h, C.c_void_p(fn_ptr), C.c_void_p(user), C.c_double(mr_size), patch_size))
+
+    def set_external_orientation(self, fn_ptr, user, mr_size=3.0 * np.sqrt(3.0), patch_size=32):
+        """OriNet in the place of the dominant gradient orientation: fn returns (y, x) per patch.  None: off."""
+        _check(lib().mods_ctx_set_external_orientation(self.h, C.c_void_p(fn_ptr), C.c_void_p(user), C.c_double(mr_size), patch_size))
+
     def patches_fetch(self, img, ps, max_regions=1 << 17):
         n = C.c_int()
         out = np.zeros((max_regions, ps, ps), np.float32) if max_regions <= 4096 else None

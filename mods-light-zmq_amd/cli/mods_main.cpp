@@ -53,6 +53,11 @@ struct Config {
   std::string zmq_port = "tcp://localhost:5555";
   double zmq_mr = 3.0 * 1.7320508075688772;
   int zmq_ps = 32;
+  // [AffineAdaptation] useZMQ + [AffNet], [DominantOrientation] useZMQ + [OriNet] (io_mods.cpp:124-134, 523-524, 727-736)
+  bool aff_zmq = false, ori_zmq = false;
+  std::string aff_port = "tcp://localhost:5556", ori_port = "tcp://localhost:5557";
+  double aff_mr = 3.0 * 1.7320508075688772, ori_mr = 3.0 * 1.7320508075688772;
+  int aff_ps = 32, ori_ps = 32;
 };
 
 int read_config(const std::string &config_fn, const std::string &iters_fn, int ver_type, Config *cfg) {
@@ -128,6 +133,14 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   if (ini.Has("zmqDescriptor", "port")) cfg->zmq_port = ini.GetString("zmqDescriptor", "port", "");
   cfg->zmq_mr = ini.GetDouble("zmqDescriptor", "mrSize", cfg->zmq_mr);
   cfg->zmq_ps = (int)ini.GetInteger("zmqDescriptor", "patchSize", cfg->zmq_ps);
+  cfg->aff_zmq = ini.GetBoolean("AffineAdaptation", "useZMQ", false);
+  if (ini.Has("AffNet", "port")) cfg->aff_port = ini.GetString("AffNet", "port", "");
+  cfg->aff_mr = ini.GetDouble("AffNet", "mrSize", cfg->aff_mr);
+  cfg->aff_ps = (int)ini.GetInteger("AffNet", "patchSize", cfg->aff_ps);
+  cfg->ori_zmq = ini.GetBoolean("DominantOrientation", "useZMQ", false);
+  if (ini.Has("OriNet", "port")) cfg->ori_port = ini.GetString("OriNet", "port", "");
+  cfg->ori_mr = ini.GetDouble("OriNet", "mrSize", cfg->ori_mr);
+  cfg->ori_ps = (int)ini.GetInteger("OriNet", "patchSize", cfg->ori_ps);
   // iterations file :457-492
   cfg->max_steps = (int)it.GetInteger("Iterations", "Steps", 4);
   cfg->min_matches = (int)it.GetInteger("Iterations", "minMatches", 15);
@@ -335,6 +348,18 @@ int main(int argc, char **argv) {
     while (!cfg.zmq_port.empty() && isspace((unsigned char)cfg.zmq_port.back())) cfg.zmq_port.pop_back();
     if (cfg.verbose) std::cerr << "Descriptors from the daemon at " << cfg.zmq_port << " (" << cfg.zmq_ps << "x" << cfg.zmq_ps << " patches)" << std::endl;
     if (mods_ctx_set_external_descriptor(ctx, &mods_zmq_descriptor_hook, (void *)cfg.zmq_port.c_str(), cfg.zmq_mr, cfg.zmq_ps)) return fail("external descriptor");
+  }
+  auto rtrim = [](std::string &t) { while (!t.empty() && isspace((unsigned char)t.back())) t.pop_back(); };
+  if (cfg.aff_zmq) {
+    rtrim(cfg.aff_port);
+    if (cfg.verbose) std::cerr << "Affine shapes from the daemon at " << cfg.aff_port << std::endl;
+    if (cfg.pair.det.doBaumberg) std::cerr << "Warning: [AffineAdaptation] useZMQ=1 with doBaumberg=1 in [HessianAffine]: the Baumberg frames are replaced" << std::endl;
+    if (mods_ctx_set_external_shape(ctx, &mods_zmq_descriptor_hook, (void *)cfg.aff_port.c_str(), cfg.aff_mr, cfg.aff_ps)) return fail("external shape");
+  }
+  if (cfg.ori_zmq) {
+    rtrim(cfg.ori_port);
+    if (cfg.verbose) std::cerr << "Orientations from the daemon at " << cfg.ori_port << std::endl;
+    if (mods_ctx_set_external_orientation(ctx, &mods_zmq_descriptor_hook, (void *)cfg.ori_port.c_str(), cfg.ori_mr, cfg.ori_ps)) return fail("external orientation");
   }
   mods_ladder_result res;
   std::vector<double> matches((size_t)4 << 20);

@@ -285,6 +285,20 @@ int mods_ctx_set_external_descriptor(mods_ctx *c, mods_descriptor_fn fn, void *u
   c->ext_fn = fn; c->ext_user = user; c->ext_mr = mrSize; c->ext_ps = patchSize;
   return MODS_OK;
 }
+
+int mods_ctx_set_external_shape(mods_ctx *c, mods_descriptor_fn fn, void *user, double mrSize, int patchSize) {
+  if (!c) return MODS_E_ARG;
+  if (fn && (patchSize < 8 || patchSize > 63)) { set_error("external shape: patch size %d unsupported", patchSize); return MODS_E_ARG; }
+  c->shape_fn = fn; c->shape_user = user; c->shape_mr = mrSize; c->shape_ps = patchSize;
+  return MODS_OK;
+}
+
+int mods_ctx_set_external_orientation(mods_ctx *c, mods_descriptor_fn fn, void *user, double mrSize, int patchSize) {
+  if (!c) return MODS_E_ARG;
+  if (fn && (patchSize < 8 || patchSize > 63)) { set_error("external orientation: patch size %d unsupported", patchSize); return MODS_E_ARG; }
+  c->ori_fn = fn; c->ori_user = user; c->ori_mr = mrSize; c->ori_ps = patchSize;
+  return MODS_OK;
+}
 // host copy of the patches the describe stage extracted for image slot img in its last call ([n][ps][ps] fp32)
 int mods_patches_fetch(mods_ctx *c, int img, int ps, float *out, int max_regions, int *n_out) {
   if (!c || !out || !n_out || img < 0 || img >= c->batch || !c->desc_scratch) { set_error("patches_fetch: nothing described"); return MODS_E_ARG; }

@@ -110,6 +110,11 @@ struct mods_ctx {
   void *ext_user = nullptr;
   double ext_mr = 0;
   int ext_ps = 0;
+  // AffNet / OriNet in the place of Baumberg / the dominant gradient orientation (imagerepresentation.cpp:786-856, 874-900)
+  mods_descriptor_fn shape_fn = nullptr, ori_fn = nullptr;
+  void *shape_user = nullptr, *ori_user = nullptr;
+  double shape_mr = 0, ori_mr = 0;
+  int shape_ps = 0, ori_ps = 0;
   size_t desc_scratch_elems = 0;
   const float *last_img_dev = nullptr;
   std::vector<int> last_region_counts;

@@ -411,6 +411,176 @@ static int external_describe(mods_ctx *ctx, int n_img, const DescConst &k) {
   return MODS_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// AffNet / OriNet in the place of Baumberg / the dominant orientation (imagerepresentation.cpp:786-856, 874-900).  The
+// networks live behind a callback (the ZMQ client); the patches come from the GPU extraction kernels, the per-keypoint
+// arithmetic around the callback (a few thousand keypoints, double precision, libm) runs on the host as in the reference.
+// ---------------------------------------------------------------------------------------
+// ExtractPatchesColumn patches (mr, ps) of host region lists, one list per image: staged through the region slots
+static int net_patches(mods_ctx *ctx, const float *img_dev, int n_img, DescConst k, double mr, int ps,
+                       const std::vector<std::vector<mods_region>> &regs, const float *dmask, const SiftTab *tab,
+                       std::vector<std::vector<float>> *patches) {
+  std::vector<int> counts(n_img);
+  for (int b = 0; b < n_img; b++) {
+    counts[b] = (int)regs[b].size();
+    if (counts[b] > k.reg_cap) { set_error("external shape / orientation: more keypoints than the patch store holds"); return MODS_E_CAPACITY; }
+    if (counts[b])
+      MODS_HIP_CHECK(hipMemcpyAsync(ctx->regions_dev + (size_t)b * ctx->max_cand, regs[b].data(), sizeof(mods_region) * counts[b],
+                                    hipMemcpyHostToDevice, ctx->stream));
+  }
+  MODS_HIP_CHECK(hipMemcpyAsync(ctx->region_count, counts.data(), sizeof(int) * n_img, hipMemcpyHostToDevice, ctx->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // (the host vectors above are pageable)
+  k.desc_mr = mr; k.desc_ps = ps; k.patch_rule = 1; k.photo = 0;
+  int rc = launch_extract_and_sift(ctx, img_dev, n_img, k, dmask, tab, false);
+  if (rc) return rc;
+  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  patches->assign(n_img, std::vector<float>());
+  const size_t pp = (size_t)ps * ps;
+  for (int b = 0; b < n_img; b++) {
+    (*patches)[b].resize(pp * counts[b]);
+    if (counts[b])
+      MODS_HIP_CHECK(hipMemcpy((*patches)[b].data(), ctx->desc_scratch + (size_t)b * k.reg_cap * pp, sizeof(float) * pp * counts[b], hipMemcpyDeviceToHost));
+  }
+  return MODS_OK;
+}
+
+static int fetch_keys(mods_ctx *ctx, int n_img, const int *key_count, std::vector<std::vector<mods_affkey>> *keys) {
+  std::vector<int> counts(n_img);
+  MODS_HIP_CHECK(hipMemcpyAsync(counts.data(), key_count, sizeof(int) * n_img, hipMemcpyDeviceToHost, ctx->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  keys->assign(n_img, std::vector<mods_affkey>());
+  for (int b = 0; b < n_img; b++) {
+    const int n = std::min(counts[b], ctx->max_cand);
+    (*keys)[b].resize(n);
+    if (n) MODS_HIP_CHECK(hipMemcpy((*keys)[b].data(), ctx->keys_dev + (size_t)b * ctx->max_cand, sizeof(mods_affkey) * n, hipMemcpyDeviceToHost));
+  }
+  return MODS_OK;
+}
+
+static mods_region region_of_key(const mods_affkey &kp, int id) {
+  mods_region r;
+  memset(&r, 0, sizeof(r));
+  r.x = kp.x; r.y = kp.y; r.s = kp.s; r.a11 = kp.a11; r.a12 = kp.a12; r.a21 = kp.a21; r.a22 = kp.a22;
+  r.response = kp.response; r.sub_type = kp.sub_type; r.id = id; r.parent = id;
+  return r;
+}
+
+// imagerepresentation.cpp:798-842: every keypoint's frame becomes the network's (a11, 0, a21, a22), rectified; keypoints with
+// complex or too anisotropic eigenvalues, or whose measurement region touches the image border, are dropped.
+static int external_shape(mods_ctx *ctx, const float *img_dev, int n_img, const DescConst &k, int *key_count, const float *dmask,
+                          const SiftTab *tab) {
+  std::vector<std::vector<mods_affkey>> keys;
+  int rc = fetch_keys(ctx, n_img, key_count, &keys);
+  if (rc) return rc;
+  std::vector<std::vector<mods_region>> regs(n_img);
+  for (int b = 0; b < n_img; b++)
+    for (size_t i = 0; i < keys[b].size(); i++) regs[b].push_back(region_of_key(keys[b][i], (int)i));
+  std::vector<std::vector<float>> patches;
+  if ((rc = net_patches(ctx, img_dev, n_img, k, ctx->shape_mr, ctx->shape_ps, regs, dmask, tab, &patches))) return rc;
+  std::vector<int> counts(n_img, 0);
+  std::vector<float> out;
+  for (int b = 0; b < n_img; b++) {
+    const int n = (int)keys[b].size();
+    std::vector<mods_affkey> kept;
+    if (n > 0) {
+      out.assign((size_t)n * 3, 0.f);
+      int dim = 0;
+      const int frc = ctx->shape_fn(ctx->shape_user, patches[b].data(), n, ctx->shape_ps, out.data(), out.size(), &dim);
+      if (frc || dim != 3) { set_error("external shape function failed (rc %d, %d values per patch; 3 expected)", frc, dim); return MODS_E_ARG; }
+      for (int i = 0; i < n; i++) {
+        mods_affkey kp = keys[b][i];
+        const double a = out[3 * i], bb = 0, c = out[3 * i + 1], d = out[3 * i + 2];
+        // rectifyAffineTransformationUpIsUp (double), helpers.cpp:401-410
+        const double det = sqrt(fabs(a * d - bb * c));
+        const double b2a2 = sqrt(bb * bb + a * a);
+        kp.a11 = b2a2 / det; kp.a12 = 0; kp.a21 = (d * bb + c * a) / (b2a2 * det); kp.a22 = det / b2a2;
+        // getEigenvalues, helpers.cpp:504-515
+        const float fa = (float)kp.a11, fb = (float)kp.a12, fc = (float)kp.a21, fd = (float)kp.a22;
+        const float trace = fa + fd;
+        const float delta1 = (trace * trace - 4 * (fa * fd - fb * fc));
+        if (delta1 < 0) continue;
+        const float delta = sqrtf(delta1);
+        const float l1 = (trace + delta) / 2.0f, l2 = (trace - delta) / 2.0f;
+        if ((l1 / l2 > 6) || (l2 / l1 > 6)) continue;
+        const int box = (int)(ctx->shape_mr * kp.s);
+        if (check_borders(k.w, k.h, (float)kp.x, (float)kp.y, fa, fb, fc, fd, box, box)) continue;
+        kept.push_back(kp);
+      }
+    }
+    counts[b] = (int)kept.size();
+    if (counts[b]) MODS_HIP_CHECK(hipMemcpy(ctx->keys_dev + (size_t)b * ctx->max_cand, kept.data(), sizeof(mods_affkey) * counts[b], hipMemcpyHostToDevice));
+  }
+  MODS_HIP_CHECK(hipMemcpy(key_count, counts.data(), sizeof(int) * n_img, hipMemcpyHostToDevice));
+  return MODS_OK;
+}
+
+// imagerepresentation.cpp:866-900 and what follows it for every detector: centres inside the original image
+// (ReprojectRegionsAndRemoveTouchBoundary, dontRemove), frame rotated by atan2(y, x) of the network's two values, then the
+// tests of ReprojectRegions.  Fills the region slots, region counts and the count of the unoriented ("None") list.
+static int external_orientation(mods_ctx *ctx, const float *img_dev, int n_img, const DescConst &k, const int *key_count,
+                                const float *dmask, const SiftTab *tab) {
+  std::vector<std::vector<mods_affkey>> keys;
+  int rc = fetch_keys(ctx, n_img, key_count, &keys);
+  if (rc) return rc;
+  std::vector<std::vector<mods_region>> regs(n_img);
+  std::vector<int> inside(n_img, 0);
+  for (int b = 0; b < n_img; b++)
+    for (size_t i = 0; i < keys[b].size(); i++) {
+      const mods_affkey &kp = keys[b][i];
+      bool alive;
+      if (k.view) {
+        const double rx = (k.Hinv[0] * kp.x + k.Hinv[1] * kp.y + k.Hinv[2]);
+        const double ry = (k.Hinv[3] * kp.x + k.Hinv[4] * kp.y + k.Hinv[5]);
+        alive = (rx < k.ow) && (ry < k.oh) && (rx > 0) && (ry > 0);
+      } else alive = (kp.x < k.w) && (kp.y < k.h) && (kp.x > 0) && (kp.y > 0);
+      if (alive) regs[b].push_back(region_of_key(kp, (int)i));
+    }
+  for (int b = 0; b < n_img; b++) inside[b] = (int)regs[b].size();
+  std::vector<std::vector<float>> patches;
+  if ((rc = net_patches(ctx, img_dev, n_img, k, ctx->ori_mr, ctx->ori_ps, regs, dmask, tab, &patches))) return rc;
+  std::vector<int> counts(n_img, 0);
+  std::vector<float> out;
+  for (int b = 0; b < n_img; b++) {
+    const int n = (int)regs[b].size();
+    std::vector<mods_region> kept;
+    if (n > 0) {
+      out.assign((size_t)n * 2, 0.f);
+      int dim = 0;
+      const int frc = ctx->ori_fn(ctx->ori_user, patches[b].data(), n, ctx->ori_ps, out.data(), out.size(), &dim);
+      if (frc || dim != 2) { set_error("external orientation function failed (rc %d, %d values per patch; 2 expected)", frc, dim); return MODS_E_ARG; }
+      for (int i = 0; i < n; i++) {
+        mods_region r = regs[b][i];
+        const double angle = atan2f(out[2 * i], out[2 * i + 1]);   // atan2(float, float): the float overload
+        const double ci = cos(angle), si = sin(angle);
+        const double a11 = r.a11, a12 = r.a12, a21 = r.a21, a22 = r.a22;
+        r.a11 = a11 * ci - a12 * si;
+        r.a12 = a11 * si + a12 * ci;
+        r.a21 = a21 * ci - a22 * si;
+        r.a22 = a21 * si + a22 * ci;
+        const int box = (int)(k.ks * r.s);
+        bool alive = true;
+        if (k.view) {
+          const double rx = (k.Hinv[0] * r.x + k.Hinv[1] * r.y + k.Hinv[2]);
+          const double ry = (k.Hinv[3] * r.x + k.Hinv[4] * r.y + k.Hinv[5]);
+          const double r11 = (k.Hinv[0] * r.a11 + k.Hinv[1] * r.a21), r12 = (k.Hinv[0] * r.a12 + k.Hinv[1] * r.a22);
+          const double r21 = (k.Hinv[3] * r.a11 + k.Hinv[4] * r.a21), r22 = (k.Hinv[3] * r.a12 + k.Hinv[4] * r.a22);
+          if (!((rx < k.ow) && (ry < k.oh) && (rx > 0) && (ry > 0))) alive = false;
+          else if (check_borders(k.ow, k.oh, (float)rx, (float)ry, (float)r11, (float)r12, (float)r21, (float)r22, box, box)) alive = false;
+        } else if (check_borders(k.w, k.h, (float)r.x, (float)r.y, (float)r.a11, (float)r.a12, (float)r.a21, (float)r.a22, box, box)) alive = false;
+        if (!alive) continue;
+        r.parent = r.id; r.id = (int)kept.size();
+        kept.push_back(r);
+      }
+    }
+    counts[b] = (int)kept.size();
+    if (counts[b] > k.reg_cap) counts[b] = k.reg_cap;
+    if (counts[b]) MODS_HIP_CHECK(hipMemcpy(ctx->regions_dev + (size_t)b * ctx->max_cand, kept.data(), sizeof(mods_region) * counts[b], hipMemcpyHostToDevice));
+  }
+  MODS_HIP_CHECK(hipMemcpy(ctx->region_count, counts.data(), sizeof(int) * n_img, hipMemcpyHostToDevice));
+  MODS_HIP_CHECK(hipMemcpy(ctx->inside_count, inside.data(), sizeof(int) * n_img, hipMemcpyHostToDevice));
+  return MODS_OK;
+}
+
 // cv::invert(H, Hinv, DECOMP_LU) for 3x3 doubles: OpenCV's closed form (all zeros when singular)
 static void invert3_cv(const double *S, double *t) {
   double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
@@ -458,7 +628,10 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   int *key_count = ctx->cand_count + 2 * ctx->batch;
   const float *orimask = ctx->desc_tables_dev, *dmask = ctx->desc_tables_dev + 4096;
   const SiftTab *tab = (const SiftTab *)(ctx->desc_tables_dev + 8192);
-  {
+  if (ctx->shape_fn && (rc = external_shape(ctx, img_dev, n_img, k, key_count, dmask, tab))) return rc;
+  if (ctx->ori_fn) {
+    if ((rc = external_orientation(ctx, img_dev, n_img, k, key_count, dmask, tab))) return rc;
+  } else {
     StageScope ts(ctx, MODS_STAGE_ORIENT);
     const size_t lds = orient_lds_bytes(k.ori_ps);
     hipLaunchKernelGGL(ori_bin_table_kernel, dim3(8), dim3(256), 0, ctx->stream);

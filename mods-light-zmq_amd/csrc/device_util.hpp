@@ -7,7 +7,7 @@
 namespace mods {
 
 // interpolateCheckBorders, helpers.cpp:527-549
-__device__ __forceinline__ bool check_borders(int img_w, int img_h, float ofsx, float ofsy, float a11, float a12,
+__host__ __device__ __forceinline__ bool check_borders(int img_w, int img_h, float ofsx, float ofsy, float a11, float a12,
                                               float a21, float a22, int res_w, int res_h) {
   const int width = img_w - 2, height = img_h - 2;
   const float halfWidth = (float)ceil((double)((float)res_w) / 2.0);

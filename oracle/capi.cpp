@@ -201,6 +201,16 @@ int orc_filter_centres_inside(orc_region *r, int n, int w, int h) {
   filter_centres_inside(v, w, h);
   return from_regions(v, r, n);
 }
+int orc_affnet_apply(orc_region *r, int n, const float *a3, int w, int h, double mrSize) {
+  std::vector<Region> v; to_regions(r, n, v);
+  affnet_apply(v, a3, w, h, mrSize);
+  return from_regions(v, r, n);
+}
+void orc_orinet_apply(orc_region *r, int n, const float *yx) {
+  std::vector<Region> v; to_regions(r, n, v);
+  orinet_apply(v, yx);
+  from_regions(v, r, n);
+}
 int orc_filter_touch_boundary(orc_region *r, int n, int w, int h) {
   std::vector<Region> v; to_regions(r, n, v);
   filter_touch_boundary(v, w, h);

@@ -37,6 +37,55 @@ void filter_touch_boundary(std::vector<Region> &r, int w, int h) {
   r.swap(keep);
 }
 
+// AffNet branch of the external affine adaptation, imagerepresentation.cpp:798-842: the network's (a11, a21, a22) per keypoint
+// (a12 := 0), rectifyAffineTransformationUpIsUp (helpers.cpp:401-410), getEigenvalues (helpers.cpp:504-515) with the
+// anisotropy limit 6, interpolateCheckBorders on the mrSize * s box.  a3: n x 3 floats.
+void affnet_apply(std::vector<Region> &r, const float *a3, int w, int h, double mrSize) {
+  std::vector<Region> keep;
+  keep.reserve(r.size());
+  for (size_t i = 0; i < r.size(); i++) {
+    Region t = r[i];
+    t.a11 = a3[3 * i]; t.a12 = 0; t.a21 = a3[3 * i + 1]; t.a22 = a3[3 * i + 2];
+    {
+      double a = t.a11, b = t.a12, c = t.a21, d = t.a22;
+      double det = std::sqrt(std::fabs(a * d - b * c));
+      double b2a2 = std::sqrt(b * b + a * a);
+      t.a11 = b2a2 / det; t.a12 = 0; t.a21 = (d * b + c * a) / (b2a2 * det); t.a22 = det / b2a2;
+    }
+    float l1 = 1.0f, l2 = 1.0f;
+    {
+      const float a = (float)t.a11, b = (float)t.a12, c = (float)t.a21, d = (float)t.a22;
+      float trace = a + d;
+      float delta1 = (trace * trace - 4 * (a * d - b * c));
+      if (delta1 < 0) continue;
+      float delta = std::sqrt(delta1);
+      l1 = (trace + delta) / 2.0f;
+      l2 = (trace - delta) / 2.0f;
+    }
+    if ((l1 / l2 > 6) || (l2 / l1 > 6)) continue;
+    if (interpolate_check_borders(w, h, (float)t.x, (float)t.y, (float)t.a11, (float)t.a12, (float)t.a21, (float)t.a22,
+                                  (int)(mrSize * t.s), (int)(mrSize * t.s)))
+      continue;
+    keep.push_back(t);
+  }
+  r.swap(keep);
+}
+
+// OriNet branch of the orientation estimate, imagerepresentation.cpp:877-899: angle = atan2(y, x) of the network's two values
+// per keypoint (float arguments: the float overload), frame rotated as DetectOrientation does.  yx: n x 2 floats.
+void orinet_apply(std::vector<Region> &r, const float *yx) {
+  for (size_t i = 0; i < r.size(); i++) {
+    const Region c = r[i];
+    double angle = std::atan2(yx[2 * i], yx[2 * i + 1]);
+    double ci = std::cos(angle);
+    double si = std::sin(angle);
+    r[i].a11 = c.a11 * ci - c.a12 * si;
+    r[i].a12 = c.a11 * si + c.a12 * ci;
+    r[i].a21 = c.a21 * ci - c.a22 * si;
+    r[i].a22 = c.a21 * si + c.a22 * ci;
+  }
+}
+
 // cv::invert(H, Hinv, DECOMP_LU) for a 3x3 CV_64F matrix: OpenCV's closed form (determinant by the first
 // row, cofactors times 1/det; all zeros when det == 0).  Parity unpinned, benign.
 void invert3(const double *S, double *t) {

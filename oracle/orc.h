@@ -111,6 +111,8 @@ void filter_centres_inside(std::vector<Region> &r, int w, int h);           // s
 int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, const Img &img,
                        double mrSize, int patchSize, int maxAngles, double th);   // :1039-1149
 void filter_touch_boundary(std::vector<Region> &r, int w, int h);           // ReprojectRegions :631-706
+void affnet_apply(std::vector<Region> &r, const float *a3, int w, int h, double mrSize);   // imagerepresentation.cpp:798-842
+void orinet_apply(std::vector<Region> &r, const float *yx);                               // imagerepresentation.cpp:877-899
 // the same two steps for a synthesised view (H: original -> view); det = view frame, rep = original frame
 void invert3(const double *S, double *t);                                   // cv::invert 3x3
 bool h_is_eye(const double *H);                                             // synth-detection.cpp:144-149

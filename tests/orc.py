@@ -229,6 +229,20 @@ def filter_centres_inside(regions, w, h):
     return r[:n].copy()
 
 
+def affnet_apply(regions, a3, w, h, mrsize):
+    r = np.ascontiguousarray(regions).copy()
+    a = np.ascontiguousarray(a3, np.float32)
+    n = lib().orc_affnet_apply(r.ctypes.data_as(C.c_void_p), len(r), a.ctypes.data_as(C.c_void_p), w, h, C.c_double(mrsize))
+    return r[:n].copy()
+
+
+def orinet_apply(regions, yx):
+    r = np.ascontiguousarray(regions).copy()
+    a = np.ascontiguousarray(yx, np.float32)
+    lib().orc_orinet_apply(r.ctypes.data_as(C.c_void_p), len(r), a.ctypes.data_as(C.c_void_p))
+    return r
+
+
 def filter_touch_boundary(regions, w, h):
     r = np.ascontiguousarray(regions).copy()
     n = lib().orc_filter_touch_boundary(r.ctypes.data_as(C.c_void_p), len(r), w, h)

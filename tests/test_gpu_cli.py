@@ -162,3 +162,48 @@ def test_cli_npz_keypoints_and_pre_extracted_mode(pkg, tmp_path):
     pkg.ransac_pin_seed(-1)
     assert (r2.n_tentatives, r2.n_unique, r2.n_inliers) == (res.n_tentatives, res.n_unique, res.n_inliers) and np.array_equal(m2, m)
     rep1.close(); rep2.close(); ctx.close()
+
+
+def test_cli_deep_configuration_three_daemons(pkg, tmp_path):
+    """config_aff_ori_desc_zeromq.ini's layout: [AffineAdaptation] useZMQ=1 + [AffNet], [DominantOrientation] useZMQ=1 + [OriNet],
+    [zmqDescriptor] + Descriptors=ZMQ; HessianAffine with doBaumberg=0 (imagerepresentation.cpp:786-856, 874-900, 992-1006)."""
+    import ctypes as C
+    import sys
+    import time
+    from test_cpu_zmq import _stop
+    from test_gpu_zmq import _free_port, LIB, DAEMON
+    wire = C.CDLL(LIB)
+    procs, eps = [], {}
+    try:
+        for model in ("affnet", "orinet", "hardnet"):
+            port = _free_port()
+            eps[model] = "tcp://127.0.0.1:%d" % port
+            d = subprocess.Popen([sys.executable, DAEMON, "--model", model, "--bind", eps[model], "--device", "cuda", "--seed", "5"], stderr=subprocess.PIPE)
+            line = ""
+            for _ in range(20):
+                line = d.stderr.readline().decode()
+                if "serving" in line or not line:
+                    break
+            assert "serving" in line, line
+            procs.append((d, port))
+        time.sleep(0.3)
+        cfg = open(os.path.join(CFG, "classic.ini")).read()
+        assert "doBaumberg=1" in cfg.replace(" ", "")
+        import re
+        cfg = re.sub(r"doBaumberg\s*=\s*1", "doBaumberg=0", cfg)
+        cfg += ("\n[AffineAdaptation]\nuseZMQ=1\n[AffNet]\nport=%s\npatchSize=32\nmrSize=5.1962\n" % eps["affnet"]
+                + "[DominantOrientation]\nuseZMQ=1\nmaxAngles=1\n[OriNet]\nport=%s\npatchSize=32\nmrSize=5.1962\n" % eps["orinet"]
+                + "[zmqDescriptor]\nport=%s\npatchSize=32\nmrSize=5.1962\n" % eps["hardnet"])
+        (tmp_path / "deep.ini").write_text(cfg)
+        args = [MODS, G1, G1, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", "0", "H.txt",
+                str(tmp_path / "deep.ini"), os.path.join(CFG, "iters_zmq.ini")]
+        p = subprocess.run(args, cwd=tmp_path, env=dict(os.environ, MODS_RANSAC_SEED="4242"), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()
+        got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+        assert len(got) > 300 and np.allclose(got[:, :2], got[:, 2:], atol=1e-3)
+        H = np.loadtxt(tmp_path / "H.txt")
+        assert np.allclose(H / H[2, 2], np.eye(3), atol=1e-3)
+    finally:
+        for d, port in procs:
+            _stop(wire, d, port)
