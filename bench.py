@@ -186,11 +186,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # MODS_BENCH_SHARE_GPU=1 (development aid for 1-GPU boxes): every rank uses GPU 0 and the ranks meet over gloo, so that the
+    # multi-rank control flow can be exercised without a multi-GPU node
+    share = os.environ.get("MODS_BENCH_SHARE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if world > 1 else 0
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = local_rank if (world > 1 and not share) else 0
     torch.cuda.set_device(device)
 
     pkg = ge.load_package()
@@ -267,7 +273,7 @@ def main():
     last = step(0)
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
