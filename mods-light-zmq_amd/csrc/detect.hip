@@ -328,23 +328,31 @@ __device__ void inv_sqrt(float &a, float &b, float &c, float &l1, float &l2) {
   c = float(t * t * x + r * r * z);
 }
 
-// grid = (N, n_img) grid-stride over the accepted list; block = 64 (one wave).
-// dynamic LDS: 7 * W*W floats (+3)
+// grid = (N, n_img) grid-stride over the accepted list; block = 64 (one wave) = KP keypoints side by side, 64 / KP lanes each.
+// Most of an iteration is work that costs the SIMD the same for one lane or for sixty-four (three 361-term ordered sums, the
+// double-precision inverse square root of the 2x2 moment matrix), so several keypoints share the wave; a keypoint that has
+// converged or failed idles until the others of its wave are done.
+// dynamic LDS: mask WP | KP x (img, pa, pb, pc: 4 WP | 4 sums)
+template <int KP>
 __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restrict__ P, DetectConst k,
                                                       CandDev *__restrict__ cand, const int *__restrict__ acc_list,
                                                       const int *__restrict__ acc_count, const float *__restrict__ mask,
                                                       unsigned long long *__restrict__ sort_keys, int *__restrict__ sort_idx,
                                                       int *__restrict__ key_count) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int G = 64 / KP;                                  // lanes per keypoint
   const int W = k.smm, WW = W * W, WP = (WW + 3) & ~3;
-  float *s_img = smem, *s_pa = s_img + WP, *s_pb = s_pa + WP, *s_pc = s_pb + WP, *s_mask = s_pc + WP, *s_sum = s_mask + WP;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, sub = lane / G, sl = lane % G;
+  float *s_mask = smem;
+  float *s_img = smem + WP + sub * (4 * WP + 4), *s_pa = s_img + WP, *s_pb = s_pa + WP, *s_pc = s_pb + WP, *s_sum = s_pc + WP;
   const int b = blockIdx.y;
   const int half = W / 2;
   for (int p = lane; p < WW; p += 64) s_mask[p] = mask[p];
   const int n_acc = acc_count[b];
-  for (int slot = blockIdx.x; slot < n_acc; slot += gridDim.x) {
-    const int ci = acc_list[(size_t)b * k.max_cand + slot];
+  for (int slot0 = blockIdx.x * KP; slot0 < n_acc; slot0 += gridDim.x * KP) {
+    const int slot = slot0 + sub;
+    const bool have = slot < n_acc;
+    const int ci = acc_list[(size_t)b * k.max_cand + (have ? slot : slot0)];
     CandDev &cd = cand[(size_t)b * k.max_cand + ci];
     const OctaveDev &o = P->oct[cd.octave];
     const int iw = o.w, ih = o.h;
@@ -355,54 +363,55 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
     const float lx = cd.x / pd, ly = cd.y / pd;
     const float ratio = cd.s / (k.initial_sigma * pd);
     bool converged = false;
+    bool active = have && k.do_baumberg;       // still iterating (uniform within the keypoint's lanes)
     if (!k.do_baumberg) converged = true;
-    else
-      for (int l = 0; l < k.max_iter; l++) {
-        const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
+    for (int l = 0; l < k.max_iter && __any(active); l++) {
+      const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
+      wave_sync();   // previous iteration's readers are done with the tiles
+      // every lane samples a contiguous run of the W x W window; its first coordinates are rebuilt by
+      // replaying the reference's sequential fp32 additions (row steps, then column steps)
+      if (active) {
         const bool touch = check_borders(iw, ih, lx, ly, a11, a12, a21, a22, W, W);
-        __syncthreads();   // previous iteration's readers are done with the tiles
-        // every lane samples a contiguous run of the W x W window; its first coordinates are rebuilt by
-        // replaying the reference's sequential fp32 additions (row steps, then column steps)
-        {
-          const int L = (WW + 63) / 64;   // <= 8 for windows up to 22 x 22
-          int idx = lane * L;
-          if (idx < WW) {
-            int row = idx / W, col = idx - row * W;
-            float rx = lx - (float)half * a12;
-            float ry = ly - (float)half * a22;
-            for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
-            float WX = rx - (float)half * a11;
-            float WY = ry - (float)half * a21;
-            for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
-            const int end = min(WW, idx + L);
-            // coordinates first (sequential fp32 additions), then all loads of the run, then the lerps
-            while (idx < end) {
-              TapLoads t[8];
-              int cnt = 0;
+        const int L = (WW + G - 1) / G;
+        int idx = sl * L;
+        if (idx < WW) {
+          int row = idx / W, col = idx - row * W;
+          float rx = lx - (float)half * a12;
+          float ry = ly - (float)half * a22;
+          for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
+          float WX = rx - (float)half * a11;
+          float WY = ry - (float)half * a21;
+          for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
+          const int end = min(WW, idx + L);
+          // coordinates first (sequential fp32 additions), then all loads of the batch, then the lerps
+          while (idx < end) {
+            TapLoads t[8];
+            int cnt = 0;
 #pragma unroll
-              for (int u = 0; u < 8; u++) {
-                if (idx + u < end) {
-                  t[u] = tap_load(im, iw, ih, WX, WY, touch);
-                  cnt++;
-                  if (++col == W) {
-                    col = 0;
-                    rx += a12; ry += a22;
-                    WX = rx - (float)half * a11;
-                    WY = ry - (float)half * a21;
-                  } else { WX += a11; WY += a21; }
-                }
+            for (int u = 0; u < 8; u++) {
+              if (idx + u < end) {
+                t[u] = tap_load(im, iw, ih, WX, WY, touch);
+                cnt++;
+                if (++col == W) {
+                  col = 0;
+                  rx += a12; ry += a22;
+                  WX = rx - (float)half * a11;
+                  WY = ry - (float)half * a21;
+                } else { WX += a11; WY += a21; }
               }
-#pragma unroll
-              for (int u = 0; u < 8; u++)
-                if (u < cnt) s_img[idx + u] = tap_combine(t[u]);
-              idx += cnt;
             }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+              if (u < cnt) s_img[idx + u] = tap_combine(t[u]);
+            idx += cnt;
           }
         }
-        __syncthreads();
-        // computeGradient (helpers.cpp:779-797) and the three SMM products
-        // (the one-sided differences at the window border are the same subtraction with one operand at the pixel itself)
-        for (int p = lane; p < WW; p += 64) {
+      }
+      wave_sync();
+      // computeGradient (helpers.cpp:779-797) and the three SMM products
+      // (the one-sided differences at the window border are the same subtraction with one operand at the pixel itself)
+      if (active)
+        for (int p = sl; p < WW; p += G) {
           const int r = p / W, c = p - r * W;
           const float xa = s_img[p + (c < W - 1 ? 1 : 0)], xb = s_img[p - (c > 0 ? 1 : 0)];
           const float ya = s_img[p + (r < W - 1 ? W : 0)], yb = s_img[p - (r > 0 ? W : 0)];
@@ -413,49 +422,55 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
           s_pb[p] = gxy * v;
           s_pc[p] = ygrad * ygrad * v;
         }
-        __syncthreads();
-        // ordered accumulation (raster order, fp32): three lanes, one sum each, four terms per LDS read
-        if (lane < 3) {
-          const float *arr = lane == 0 ? s_pa : (lane == 1 ? s_pb : s_pc);
-          float acc = 0;
-          int i = 0;
-          for (; i + 31 < WW; i += 32) {   // 8 LDS reads in flight, then their 32 terms in order
-            float4 v[8];
+      wave_sync();
+      // ordered accumulation (raster order, fp32): three lanes per keypoint, one sum each
+      if (active && sl < 3) {
+        const float *arr = sl == 0 ? s_pa : (sl == 1 ? s_pb : s_pc);
+        float acc = 0;
+        int i = 0;
+        for (; i + 31 < WW; i += 32) {   // 8 LDS reads in flight, then their 32 terms in order
+          float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = *(const float4 *)(arr + i + 4 * u);
+          for (int u = 0; u < 8; u++) v[u] = *(const float4 *)(arr + i + 4 * u);
 #pragma unroll
-            for (int u = 0; u < 8; u++) { acc += v[u].x; acc += v[u].y; acc += v[u].z; acc += v[u].w; }
-          }
-          for (; i + 3 < WW; i += 4) {
-            const float4 v4 = *(const float4 *)(arr + i);
-            acc += v4.x; acc += v4.y; acc += v4.z; acc += v4.w;
-          }
-          for (; i < WW; i++) acc += arr[i];
-          s_sum[lane] = acc;
+          for (int u = 0; u < 8; u++) { acc += v[u].x; acc += v[u].y; acc += v[u].z; acc += v[u].w; }
         }
-        __syncthreads();
+        for (; i + 3 < WW; i += 4) {
+          const float4 v4 = *(const float4 *)(arr + i);
+          acc += v4.x; acc += v4.y; acc += v4.z; acc += v4.w;
+        }
+        for (; i < WW; i++) acc += arr[i];
+        s_sum[sl] = acc;
+      }
+      wave_sync();
+      if (active) {
         float a = s_sum[0], bq = s_sum[1], c = s_sum[2];
         a /= WW; bq /= WW; c /= WW;
         inv_sqrt(a, bq, c, l1, l2);
-        if ((a != a) || (bq != bq) || (c != c)) break;
-        eigen_ratio_bef = eigen_ratio_act;
-        eigen_ratio_act = (float)(1.0 - l2 / l1);
-        const float u11t = u11, u12t = u12;
-        u11 = a * u11t + bq * u21;
-        u12 = a * u12t + bq * u22;
-        u21 = bq * u11t + c * u21;
-        u22 = bq * u12t + c * u22;
-        // getEigenvalues, helpers.cpp:504-515
-        const float trace = u11 + u22;
-        const float delta1 = (trace * trace - 4 * (u11 * u22 - u12 * u21));
-        if (delta1 < 0) break;
-        const float delta = sqrtf(delta1);
-        l1 = (trace + delta) / 2.0f;
-        l2 = (trace - delta) / 2.0f;
-        if ((l1 / l2 > 6) || (l2 / l1 > 6)) break;
-        if (eigen_ratio_act < k.conv_th && eigen_ratio_bef < k.conv_th) { converged = true; break; }
+        if ((a != a) || (bq != bq) || (c != c)) active = false;
+        else {
+          eigen_ratio_bef = eigen_ratio_act;
+          eigen_ratio_act = (float)(1.0 - l2 / l1);
+          const float u11t = u11, u12t = u12;
+          u11 = a * u11t + bq * u21;
+          u12 = a * u12t + bq * u22;
+          u21 = bq * u11t + c * u21;
+          u22 = bq * u12t + c * u22;
+          // getEigenvalues, helpers.cpp:504-515
+          const float trace = u11 + u22;
+          const float delta1 = (trace * trace - 4 * (u11 * u22 - u12 * u21));
+          if (delta1 < 0) active = false;
+          else {
+            const float delta = sqrtf(delta1);
+            l1 = (trace + delta) / 2.0f;
+            l2 = (trace - delta) / 2.0f;
+            if ((l1 / l2 > 6) || (l2 / l1 > 6)) active = false;
+            else if (eigen_ratio_act < k.conv_th && eigen_ratio_bef < k.conv_th) { converged = true; active = false; }
+          }
+        }
       }
-    if (lane == 0) {
+    }
+    if (have && sl == 0) {
       if (converged) {
         cd.a11 = u11; cd.a12 = u12; cd.a21 = u21; cd.a22 = u22;
         cd.state = 3;
@@ -463,9 +478,9 @@ __global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restri
         const unsigned int absbits = __float_as_uint(fabsf(cd.response));
         const unsigned int order = ((unsigned int)cd.octave << 28) | ((unsigned int)cd.level << ORDER_POS_BITS) |
                                    (unsigned int)(cd.r0 * iw + cd.c0);
-        const int sl = atomicAdd(&key_count[b], 1);
-        sort_keys[(size_t)b * k.max_cand + sl] = ((unsigned long long)(~absbits) << 32) | order;
-        sort_idx[(size_t)b * k.max_cand + sl] = ci;
+        const int sl2 = atomicAdd(&key_count[b], 1);
+        sort_keys[(size_t)b * k.max_cand + sl2] = ((unsigned long long)(~absbits) << 32) | order;
+        sort_idx[(size_t)b * k.max_cand + sl2] = ci;
       } else cd.state = 4;   // accepted by the pyramid, dropped by the affine adaptation
     }
   }
@@ -582,8 +597,12 @@ int detect_run(mods_ctx *ctx) {
   }
   {
     StageScope ts(ctx, MODS_STAGE_BAUMBERG);
-    const size_t lds = sizeof(float) * (5 * ((((size_t)par.smmWindowSize * par.smmWindowSize) + 3) & ~(size_t)3) + 4);
-    hipLaunchKernelGGL(baumberg_kernel, dim3(8192, n_img), dim3(64), lds, ctx->stream, ctx->pyr_dev, k, ctx->cand,
+#ifndef BAUMBERG_KP
+#define BAUMBERG_KP 2
+#endif
+    const size_t wp = (((size_t)par.smmWindowSize * par.smmWindowSize) + 3) & ~(size_t)3;
+    const size_t lds = sizeof(float) * (wp + BAUMBERG_KP * (4 * wp + 4));
+    hipLaunchKernelGGL(baumberg_kernel<BAUMBERG_KP>, dim3(8192, n_img), dim3(64), lds, ctx->stream, ctx->pyr_dev, k, ctx->cand,
                        ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->smm_mask_dev, ctx->sort_keys,
                        ctx->sort_idx, key_count);
     MODS_HIP_CHECK(hipGetLastError());
