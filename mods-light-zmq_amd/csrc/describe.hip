@@ -37,15 +37,15 @@ __global__ __launch_bounds__(256) void ori_bin_table_kernel() {
 // Block = 64 lanes.  s_val/s_bin: ps*(ps-2) entries, s_hist: 40 floats.  Returns found/angle
 // (uniform across lanes).
 // ---------------------------------------------------------------------------------------
-__device__ bool dominant_angle_wave(const float *s_patch, const float *__restrict__ orimask, const double *s_lut, int ps, double th,
-                                    float *s_val, int *s_bin, float *s_hist, float *angle_out) {
+__device__ bool dominant_angle_wave(const float *s_patch, const float *__restrict__ orimask, int ps, double th,
+                                    float *s_val, unsigned char *s_bin, float *s_hist, float *angle_out) {
   const int lane = threadIdx.x;
   const int bins = 36;
   const float PIf = 3.14159265358979323846f;
   const int n = ps * (ps - 2);
-  const int n4 = (n + 3) & ~3;
-  for (int p = lane; p < n4; p += 64) {
-    int bin = -1;
+  const int n16 = (n + 15) & ~15;   // votes are scanned 16 at a time; the tail carries bin 255 (no bin)
+  for (int p = lane; p < n16; p += 64) {
+    int bin = 255;
     float v = 0.f;
     if (p < n) {
       const int r = 1 + p / ps, c = p - (r - 1) * ps;
@@ -64,7 +64,7 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
       }
     }
     s_val[p] = v;
-    s_bin[p] = bin;
+    s_bin[p] = (unsigned char)bin;
   }
   __syncthreads();
   // one lane per bin, votes in raster order (bin 36 is write-only in the reference).  Votes of other
@@ -72,27 +72,19 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
   // and reads four votes per LDS access.
   if (lane < bins) {
     float acc = 0.f;
-    int p = 0;
-    for (; p + 15 < n4; p += 16) {   // 8 LDS reads in flight, then their 16 votes in order
-      int4 b4[4];
+    for (int p = 0; p < n16; p += 16) {   // 5 LDS reads (16 bins as bytes, 16 values), then the 16 votes in order
+      const uint4 bb = *(const uint4 *)(s_bin + p);
       float4 v4[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { b4[u] = *(const int4 *)(s_bin + p + 4 * u); v4[u] = *(const float4 *)(s_val + p + 4 * u); }
+      for (int u = 0; u < 4; u++) v4[u] = *(const float4 *)(s_val + p + 4 * u);
+      const unsigned int bw[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        acc += (b4[u].x == lane) ? v4[u].x : 0.f;
-        acc += (b4[u].y == lane) ? v4[u].y : 0.f;
-        acc += (b4[u].z == lane) ? v4[u].z : 0.f;
-        acc += (b4[u].w == lane) ? v4[u].w : 0.f;
+        acc += ((bw[u] & 0xffu) == (unsigned)lane) ? v4[u].x : 0.f;
+        acc += (((bw[u] >> 8) & 0xffu) == (unsigned)lane) ? v4[u].y : 0.f;
+        acc += (((bw[u] >> 16) & 0xffu) == (unsigned)lane) ? v4[u].z : 0.f;
+        acc += ((bw[u] >> 24) == (unsigned)lane) ? v4[u].w : 0.f;
       }
-    }
-    for (; p < n4; p += 4) {
-      const int4 b4 = *(const int4 *)(s_bin + p);
-      const float4 v4 = *(const float4 *)(s_val + p);
-      acc += (b4.x == lane) ? v4.x : 0.f;
-      acc += (b4.y == lane) ? v4.y : 0.f;
-      acc += (b4.z == lane) ? v4.z : 0.f;
-      acc += (b4.w == lane) ? v4.w : 0.f;
     }
     s_hist[lane] = acc;
   }
@@ -128,18 +120,17 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
 }
 
 // grid = (N, n_img), block = 64.  One wave per detected keypoint.
-// dynamic LDS: lut 256 doubles | patch ps*ps | val, bin ps*(ps-2) (padded to 4) | hist 40
+// dynamic LDS: patch ps*ps | vote values ps*(ps-2) (padded to 16) | vote bins (bytes) | hist 40
 __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ img_all, DescConst k,
                                                     const mods_affkey *__restrict__ keys_all,
                                                     const int *__restrict__ key_count, const float *__restrict__ orimask,
                                                     OriOut *__restrict__ ori_all) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ps = k.ori_ps, pp2 = ps * ps;
-  const int nv = (ps * (ps - 2) + 3) & ~3;
-  double *s_lut = (double *)smem;
-  float *s_patch = (float *)(s_lut + 256);
+  const int nv = (ps * (ps - 2) + 15) & ~15;
+  float *s_patch = smem;
   float *s_val = s_patch + ((pp2 + 3) & ~3);
-  int *s_bin = (int *)(s_val + nv);
+  unsigned char *s_bin = (unsigned char *)(s_val + nv);
   float *s_hist = (float *)(s_bin + nv);
   const int lane = threadIdx.x;
   const int b = blockIdx.y;
@@ -149,7 +140,6 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
   int n = key_count[b];
   if (n > k.max_cand) n = k.max_cand;
   const int half = ps / 2;
-  for (int q = lane; q < 256; q += 64) s_lut[q] = g_atan_lut[q];
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const mods_affkey kp = keys[i];
     // ReprojectRegionsAndRemoveTouchBoundary(dontRemove): centre, in the original frame, strictly inside
@@ -211,7 +201,7 @@ __global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ im
       }
       __syncthreads();
       float ang = 0.f;
-      const bool found = dominant_angle_wave(s_patch, orimask, s_lut, ps, k.ori_th, s_val, s_bin, s_hist, &ang);
+      const bool found = dominant_angle_wave(s_patch, orimask, ps, k.ori_th, s_val, s_bin, s_hist, &ang);
       if (!found) alive = false;
       else {
         double si, ci;
@@ -310,23 +300,21 @@ __global__ __launch_bounds__(256) void reproject_regions_kernel(DescConst k, mod
 __global__ __launch_bounds__(64) void dominant_angle_test_kernel(const float *__restrict__ patch, int ps, double th,
                                                                  const float *__restrict__ orimask, float *out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int nv = (ps * (ps - 2) + 3) & ~3;
-  double *s_lut = (double *)smem;
-  float *s_patch = (float *)(s_lut + 256);
+  const int nv = (ps * (ps - 2) + 15) & ~15;
+  float *s_patch = smem;
   float *s_val = s_patch + ((ps * ps + 3) & ~3);
-  int *s_bin = (int *)(s_val + nv);
+  unsigned char *s_bin = (unsigned char *)(s_val + nv);
   float *s_hist = (float *)(s_bin + nv);
-  for (int q = threadIdx.x; q < 256; q += 64) s_lut[q] = g_atan_lut[q];
   for (int p = threadIdx.x; p < ps * ps; p += 64) s_patch[p] = patch[p];
   __syncthreads();
   float ang = 0.f;
-  const bool f = dominant_angle_wave(s_patch, orimask, s_lut, ps, th, s_val, s_bin, s_hist, &ang);
+  const bool f = dominant_angle_wave(s_patch, orimask, ps, th, s_val, s_bin, s_hist, &ang);
   if (threadIdx.x == 0) { out[0] = f ? 1.f : 0.f; out[1] = ang; }
 }
 
-static size_t orient_lds_bytes(int ps) {
-  const size_t nv = ((size_t)ps * (ps - 2) + 3) & ~(size_t)3;
-  return sizeof(double) * 256 + sizeof(float) * ((((size_t)ps * ps + 3) & ~(size_t)3) + 2 * nv + 48);
+static size_t orient_lds_bytes(int ps) {   // patch | vote values | vote bins (bytes) | histogram
+  const size_t nv = ((size_t)ps * (ps - 2) + 15) & ~(size_t)15;
+  return sizeof(float) * ((((size_t)ps * ps + 3) & ~(size_t)3) + nv + 48) + nv;
 }
 
 // ---------------------------------------------------------------------------------------
