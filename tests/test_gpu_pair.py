@@ -95,7 +95,7 @@ def test_pair_end_to_end_epipolar(pkg, planar):
     ctx.close()
 
 
-@pytest.mark.parametrize("gpu_workers,verify_workers,ppb", [(1, 1, 1), (2, 3, 1), (2, 2, 4), (1, 2, 3)])
+@pytest.mark.parametrize("gpu_workers,verify_workers,ppb", [(1, 1, 1), (2, 3, 1), (2, 2, 4), (1, 2, 3), (3, 6, 8)])
 def test_pipeline_equals_serial(pkg, gpu_workers, verify_workers, ppb):
     """The overlapped / batched pair pipeline returns, in submission order, exactly what one
     mods_match_pair_dev call per pair returns (same pinned seed)."""
