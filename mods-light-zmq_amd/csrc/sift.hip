@@ -123,54 +123,8 @@ __device__ void blur_setup(int P2, float scale, int ps, int n_tap, float *s_tap,
   __syncthreads();
 }
 
-// row pass of the separable blur at the needed columns: T[y][q] = sum_j tap[j] * S[y][clamp(cidx[q]-r+j)],
-// taps left to right.  The needed columns come in pairs (x, x+1) whose windows overlap in all but one
-// sample: one thread produces both and loads every sample once.
-__device__ __forceinline__ void row_pass(const float *S, float *T, int rows, int P2, int ps2, int n_tap, const float *s_tap,
-                                         const int *s_cidx) {
-  const int r_tap = n_tap >> 1;
-  const int pairs = ps2 >> 1;
-  for (int e = threadIdx.x; e < rows * pairs; e += 256) {
-    const int y = e / pairs, pi = e - y * pairs;
-    const int x0 = s_cidx[2 * pi], x1 = s_cidx[2 * pi + 1];
-    const float *row = S + (size_t)y * P2;
-    float s0, s1;
-    if (x1 == x0 + 1 && x0 - r_tap >= 0 && x1 + r_tap <= P2 - 1) {
-      const float *p = row + x0 - r_tap;
-      float prev = p[1];
-      s0 = s_tap[0] * p[0];
-      s1 = s_tap[0] * prev;
-      int j = 1;
-      for (; j + 3 < n_tap; j += 4) {
-        const float c0 = p[j + 1], c1 = p[j + 2], c2 = p[j + 3], c3 = p[j + 4];
-        const float t0 = s_tap[j], t1 = s_tap[j + 1], t2 = s_tap[j + 2], t3 = s_tap[j + 3];
-        s0 += t0 * prev; s1 += t0 * c0;
-        s0 += t1 * c0;   s1 += t1 * c1;
-        s0 += t2 * c1;   s1 += t2 * c2;
-        s0 += t3 * c2;   s1 += t3 * c3;
-        prev = c3;
-      }
-      for (; j < n_tap; j++) {
-        const float c = p[j + 1];
-        s0 += s_tap[j] * prev; s1 += s_tap[j] * c;
-        prev = c;
-      }
-    } else {
-      int xa = x0 - r_tap; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
-      int xb = x1 - r_tap; xb = xb < 0 ? 0 : (xb > P2 - 1 ? P2 - 1 : xb);
-      s0 = s_tap[0] * row[xa];
-      s1 = s_tap[0] * row[xb];
-      for (int j = 1; j < n_tap; j++) {
-        xa = x0 - r_tap + j; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
-        xb = x1 - r_tap + j; xb = xb < 0 ? 0 : (xb > P2 - 1 ? P2 - 1 : xb);
-        s0 += s_tap[j] * row[xa];
-        s1 += s_tap[j] * row[xb];
-      }
-    }
-    T[(size_t)y * ps2 + 2 * pi] = s0;
-    T[(size_t)y * ps2 + 2 * pi + 1] = s1;
-  }
-}
+// row stride of the row-pass strip T (2 * ps columns, padded so that two adjacent column pairs are one aligned float4)
+__host__ __device__ __forceinline__ int t_stride(int ps) { return (2 * ps + 3) & ~3; }
 
 // interpolate() as sample_region, stored transposed: dst[col * stride + row] (stride = n rounded up to 4)
 __device__ void sample_region_t(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12, float a21,
@@ -220,7 +174,7 @@ __device__ void sample_region_t(const float *__restrict__ img, int w, int h, flo
 // window of x0 shifted by one sample (also after clamping), or x1 = x0 for a grid line clamped at the edge.
 __device__ __forceinline__ void row_pass_t(const float *St, float *T, int P2, int stride, int ps, int n_tap, const float *s_tap,
                                            const int *s_cidx) {
-  const int r_tap = n_tap >> 1, nq = stride >> 2, ps2 = 2 * ps;
+  const int r_tap = n_tap >> 1, nq = stride >> 2, ps2 = t_stride(ps);
   for (int e = threadIdx.x; e < nq * ps; e += 256) {
     const int pi = e / nq, y = 4 * (e - pi * nq);
     const int x0 = s_cidx[2 * pi], x1 = s_cidx[2 * pi + 1];
@@ -288,69 +242,85 @@ __device__ __forceinline__ float col_value(const float *T, int P2, int ps2, int 
   return s;
 }
 
-// column pass fused with interpolate(smoothed, c0, c0, scale, 0, 0, scale): every blurred value is
-// used by exactly one output pixel, so it is produced where it is consumed.  One output pixel p = (j, i):
-__device__ __forceinline__ float col_resample_pixel(const float *T, int P2, int ps, int r_tap, bool touch2, const float *s_tap,
-                                                    const float *s_seq, const int *s_cidx, int p) {
-  const int ps2 = 2 * ps;
-  const int j = p / ps, i = p - j * ps;
-  const float WX = s_seq[i], WY = s_seq[j];
-  const int x = touch2 ? (int)floorf(WX) : (int)WX;
+// column pass fused with interpolate(smoothed, c0, c0, scale, 0, 0, scale): every blurred value is used by exactly one output
+// pixel, so it is produced where it is consumed.  One call makes the two horizontally adjacent output pixels (j, 2m) and
+// (j, 2m + 1): their four strip columns 4m .. 4m + 3 are one float4 per strip row.  For an output row between the grid rows y0
+// and y1 = y0 + 1 the row windows of the two share all but one row (also when rows are clamped at the edge of the strip):
+// rows are loaded once and feed all sums, each in the reference's order (centre tap, then symmetric pairs).
+__device__ __forceinline__ void col_resample_pair(const float *T, int ts, int P2, int ps, int r_tap, bool touch2, const float *s_tap,
+                                                  const float *s_seq, const int *s_cidx, int j, int m, float *out0, float *out1) {
+  const int i0 = 2 * m, i1 = min(2 * m + 1, ps - 1);
+  const float WY = s_seq[j], WX0 = s_seq[i0], WX1 = s_seq[i1];
   const int y = touch2 ? (int)floorf(WY) : (int)WY;
-  if (touch2 && !(WX >= 0 && WY >= 0 && x < P2 - 1 && y < P2 - 1)) return 0.f;
+  const int x0 = touch2 ? (int)floorf(WX0) : (int)WX0, x1 = touch2 ? (int)floorf(WX1) : (int)WX1;
   const int y0 = s_cidx[2 * j], y1 = s_cidx[2 * j + 1];
-  float r00, r01, r10, r11;
-  if (y1 == y0 + 1 && y0 - r_tap >= 0 && y1 + r_tap <= P2 - 1) {
-    // the four blurred values of this pixel share their column windows: rows y0-r .. y0+1+r of the
-    // column pair (2i, 2i+1) are loaded once (float2) and feed all four sums, each in tap order
-    const float2 *c = (const float2 *)(T + (size_t)y0 * ps2 + 2 * i);
-    const int st = ps2 >> 1;                       // row stride in float2
-    const float2 m0 = c[0], m1 = c[st];
+  float4 r0, r1;   // blurred values at grid rows y0 / y1, strip columns 4m .. 4m+3
+  if (y1 == y0 + 1) {
+    const float *c = T + 4 * m;
+    const float4 m0 = *(const float4 *)(c + y0 * ts), m1 = *(const float4 *)(c + y1 * ts);
     const float tc = s_tap[r_tap];
-    r00 = tc * m0.x; r01 = tc * m0.y; r10 = tc * m1.x; r11 = tc * m1.y;
-    float2 up = m1;                                 // row y0 + jj       (jj = 1)
-    float2 dn_prev = m0;                            // row y0 + 1 - jj   (jj = 1)
+    r0 = make_float4(tc * m0.x, tc * m0.y, tc * m0.z, tc * m0.w);
+    r1 = make_float4(tc * m1.x, tc * m1.y, tc * m1.z, tc * m1.w);
+    float4 up = m1;                                 // row y0 + jj       (jj = 1)
+    float4 dn_prev = m0;                            // row y1 - jj       (jj = 1)
     int jj = 1;
     for (; jj + 3 <= r_tap; jj += 4) {              // 8 loads in flight, then the sums in tap order
-      float2 u[4], d[4];
+      float4 u[4], d[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        u[q] = c[(ptrdiff_t)(jj + q + 1) * st];     // row y0 + 1 + jj
-        d[q] = c[-(ptrdiff_t)(jj + q) * st];        // row y0 - jj
+        const int yu = min(y1 + jj + q, P2 - 1), yd = max(y0 - jj - q, 0);
+        u[q] = *(const float4 *)(c + yu * ts);      // row y1 + jj  (= y0 + jj + 1)
+        d[q] = *(const float4 *)(c + yd * ts);      // row y0 - jj
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const float t = s_tap[r_tap + jj + q];
-        r00 += t * (up.x + d[q].x);         r01 += t * (up.y + d[q].y);
-        r10 += t * (u[q].x + dn_prev.x);    r11 += t * (u[q].y + dn_prev.y);
+        r0.x += t * (up.x + d[q].x); r0.y += t * (up.y + d[q].y); r0.z += t * (up.z + d[q].z); r0.w += t * (up.w + d[q].w);
+        r1.x += t * (u[q].x + dn_prev.x); r1.y += t * (u[q].y + dn_prev.y); r1.z += t * (u[q].z + dn_prev.z); r1.w += t * (u[q].w + dn_prev.w);
         up = u[q]; dn_prev = d[q];
       }
     }
     for (; jj <= r_tap; jj++) {
-      const float2 up1 = c[(ptrdiff_t)(jj + 1) * st];
-      const float2 dn = c[-(ptrdiff_t)jj * st];
+      const int yu = min(y1 + jj, P2 - 1), yd = max(y0 - jj, 0);
+      const float4 u = *(const float4 *)(c + yu * ts), d = *(const float4 *)(c + yd * ts);
       const float t = s_tap[r_tap + jj];
-      r00 += t * (up.x + dn.x);        r01 += t * (up.y + dn.y);
-      r10 += t * (up1.x + dn_prev.x);  r11 += t * (up1.y + dn_prev.y);
-      up = up1; dn_prev = dn;
+      r0.x += t * (up.x + d.x); r0.y += t * (up.y + d.y); r0.z += t * (up.z + d.z); r0.w += t * (up.w + d.w);
+      r1.x += t * (u.x + dn_prev.x); r1.y += t * (u.y + dn_prev.y); r1.z += t * (u.z + dn_prev.z); r1.w += t * (u.w + dn_prev.w);
+      up = u; dn_prev = d;
     }
-  } else {
-    r00 = col_value(T, P2, ps2, y0, 2 * i, r_tap, s_tap);
-    r01 = col_value(T, P2, ps2, y0, 2 * i + 1, r_tap, s_tap);
-    r10 = col_value(T, P2, ps2, y1, 2 * i, r_tap, s_tap);
-    r11 = col_value(T, P2, ps2, y1, 2 * i + 1, r_tap, s_tap);
+  } else {   // both grid rows clamped onto one strip row (output rows outside the strip)
+    r0.x = col_value(T, P2, ts, y0, 4 * m, r_tap, s_tap);     r0.y = col_value(T, P2, ts, y0, 4 * m + 1, r_tap, s_tap);
+    r0.z = col_value(T, P2, ts, y0, 4 * m + 2, r_tap, s_tap); r0.w = col_value(T, P2, ts, y0, 4 * m + 3, r_tap, s_tap);
+    r1.x = col_value(T, P2, ts, y1, 4 * m, r_tap, s_tap);     r1.y = col_value(T, P2, ts, y1, 4 * m + 1, r_tap, s_tap);
+    r1.z = col_value(T, P2, ts, y1, 4 * m + 2, r_tap, s_tap); r1.w = col_value(T, P2, ts, y1, 4 * m + 3, r_tap, s_tap);
   }
-  const float wx = WX - (float)x;
-  const float I1 = wx * (r01 - r00) + r00;
-  return (WY - y) * (wx * (r11 - r10) + r10 - I1) + I1;
+  const bool oky = !touch2 || (WY >= 0 && y < P2 - 1);
+  {
+    const float wx = WX0 - (float)x0;
+    const float I1 = wx * (r0.y - r0.x) + r0.x;
+    const float v = (WY - y) * (wx * (r1.y - r1.x) + r1.x - I1) + I1;
+    *out0 = (oky && (!touch2 || (WX0 >= 0 && x0 < P2 - 1))) ? v : 0.f;
+  }
+  {
+    const float wx = WX1 - (float)x1;
+    const float I1 = wx * (r0.w - r0.z) + r0.z;
+    const float v = (WY - y) * (wx * (r1.w - r1.z) + r1.z - I1) + I1;
+    *out1 = (oky && (!touch2 || (WX1 >= 0 && x1 < P2 - 1))) ? v : 0.f;
+  }
 }
 
 __device__ __forceinline__ void col_resample(const float *T, int P2, int ps, int n_tap, float scale, const float *s_tap,
                                              const float *s_seq, const int *s_cidx, float *patch_out) {
   const float c0 = (float)(P2 >> 1);
   const bool touch2 = check_borders(P2, P2, c0, c0, scale, 0.f, 0.f, scale, ps, ps);
-  for (int p = threadIdx.x; p < ps * ps; p += 256)
-    patch_out[p] = col_resample_pixel(T, P2, ps, n_tap >> 1, touch2, s_tap, s_seq, s_cidx, p);
+  const int np = (ps + 1) >> 1, ts = t_stride(ps);
+  for (int e = threadIdx.x; e < ps * np; e += 256) {
+    const int j = e / np, m = e - j * np;
+    float v0, v1;
+    col_resample_pair(T, ts, P2, ps, n_tap >> 1, touch2, s_tap, s_seq, s_cidx, j, m, &v0, &v1);
+    patch_out[j * ps + 2 * m] = v0;
+    if (2 * m + 1 < ps) patch_out[j * ps + 2 * m + 1] = v1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -365,7 +335,7 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
   const int cap = k.p2_hi > 4 ? k.p2_hi : 4;       // (the direct branch writes to the patch store, not to LDS)
   float *s_S = smem;
   float *s_T = s_S + cap * ((cap + 3) & ~3);
-  float *s_seq = s_T + cap * ps2;
+  float *s_seq = s_T + cap * t_stride(ps);
   int *s_cidx = (int *)(s_seq + ps2);
   float *s_tap = (float *)(s_cidx + ps2);
   double *s_red = (double *)(((uintptr_t)(s_tap + 32) + 7) & ~(uintptr_t)7);
@@ -454,7 +424,7 @@ __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mo
   const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
   const int P2r = (g.P2 + 3) & ~3;
   const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2, P2r) +
-                                   (unsigned long long)g.P2 * 2 * k.desc_ps + 3ull) & ~3ull;
+                                   (unsigned long long)g.P2 * t_stride(k.desc_ps) + 3ull) & ~3ull;
   const bool fused = g.P2 <= BIG_FUSE_P2;
   const int f_rows = big_fuse_rows(g.P2);
   const int f_chunks = fused ? (g.P2 + f_rows - 1) / f_rows : 0;
@@ -578,7 +548,7 @@ __global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const Big
                                                           const int2 *__restrict__ ritems, int max_items, float *__restrict__ pool,
                                                           const int *__restrict__ err_flag) {
   if (*err_flag) return;
-  const int ps = k.desc_ps, ps2 = 2 * ps;
+  const int ps = k.desc_ps, ps2 = t_stride(ps);   // (row stride of T)
   const int n_items = min(bl->n_ritems, max_items);
   const int lane = threadIdx.x & 63;
   BIG_WAVE_LOOP(n_items, it) {
@@ -668,7 +638,7 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
                                                         float *__restrict__ pool, const int *__restrict__ err_flag) {
   extern __shared__ __attribute__((aligned(16))) float s_St[];
   if (*err_flag) return;
-  const int ps = k.desc_ps, ps2 = 2 * ps;
+  const int ps = k.desc_ps, ps2 = t_stride(ps);   // (row stride of T)
   const int n_items = min(bl->n_fitems, max_items);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -798,25 +768,30 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
   }
 }
 
-// wave per 64 output pixels of a region: column pass + resampling -> patch
+// wave per 64 pairs of adjacent output pixels of a region: column pass + resampling -> patch
 __global__ __launch_bounds__(256) void big_colres_kernel(DescConst k, const BigLists *__restrict__ bl, const BigRegion *__restrict__ regions,
                                                          int max_regions, const float *__restrict__ pool, float *__restrict__ patches,
                                                          const int *__restrict__ err_flag) {
   if (*err_flag) return;
-  const int ps = k.desc_ps, pp = ps * ps, chunks = (pp + 63) / 64;
+  const int ps = k.desc_ps, pp = ps * ps, np = (ps + 1) >> 1, tasks = ps * np, chunks = (tasks + 63) / 64;
   const int n_items = min(bl->n_regions, max_regions) * chunks;
   const int lane = threadIdx.x & 63;
   BIG_WAVE_LOOP(n_items, it) {
-    const int li = it / chunks, p = (it - li * chunks) * 64 + lane;
+    const int li = it / chunks, e = (it - li * chunks) * 64 + lane;
     const BigRegion br = regions[li];
-    if (p >= pp) continue;
+    if (e >= tasks) continue;
     const float *tap = pool + br.slab;
     const float *seq = tap + br.n_tap;
     const int *cidx = (const int *)(seq + ps);
     const float *T = tap + big_hdr_floats(br.n_tap, ps) + big_s_floats(br.P2, br.P2r);
     const float c0 = (float)(br.P2 >> 1);
     const bool touch2 = check_borders(br.P2, br.P2, c0, c0, br.scale, 0.f, 0.f, br.scale, ps, ps);
-    patches[((size_t)br.img * k.reg_cap + br.ri) * pp + p] = col_resample_pixel(T, br.P2, ps, br.n_tap >> 1, touch2, tap, seq, cidx, p);
+    const int j = e / np, m = e - j * np;
+    float v0, v1;
+    col_resample_pair(T, t_stride(ps), br.P2, ps, br.n_tap >> 1, touch2, tap, seq, cidx, j, m, &v0, &v1);
+    float *o = patches + ((size_t)br.img * k.reg_cap + br.ri) * pp + j * ps + 2 * m;
+    o[0] = v0;
+    if (2 * m + 1 < ps) o[1] = v1;
   }
 }
 
@@ -1468,7 +1443,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
       DescConst kt = k;
       kt.p2_lo = tiers[t]; kt.p2_hi = tiers[t + 1];
       const size_t capS = kt.p2_hi > 4 ? kt.p2_hi : 4;
-      const size_t ldsS = sizeof(float) * (capS * ((capS + 3) & ~(size_t)3) + capS * ps2 + 2 * ps2 + 32) + 32;
+      const size_t ldsS = sizeof(float) * (capS * ((capS + 3) & ~(size_t)3) + capS * t_stride(ps) + 2 * ps2 + 32) + 32;
       hipLaunchKernelGGL(extract_small_kernel, dim3(2048, n_img), dim3(256), ldsS, ctx->stream, img_dev, kt, ctx->regions_dev,
                          ctx->region_count, patches);
     }
