@@ -328,7 +328,8 @@ __device__ __forceinline__ void col_resample(const float *T, int P2, int ps, int
 // dynamic LDS: S cap*cap | T cap*2ps | cx,cy aliases S | seq 2ps | cidx 2ps | taps 32 | red 2 doubles
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restrict__ img_all, DescConst k,
-                                                            const mods_region *__restrict__ reg_all, const int *__restrict__ reg_count,
+                                                            const mods_region *__restrict__ reg_all, const int *__restrict__ items,
+                                                            const int *__restrict__ n_items_dev, int items_cap,
                                                             float *__restrict__ patches) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ps = k.desc_ps, pp = ps * ps, ps2 = 2 * ps;
@@ -339,11 +340,7 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
   int *s_cidx = (int *)(s_seq + ps2);
   float *s_tap = (float *)(s_cidx + ps2);
   double *s_red = (double *)(((uintptr_t)(s_tap + 32) + 7) & ~(uintptr_t)7);
-  const int b = blockIdx.y;
-  const float *img = img_all + (size_t)k.w * k.h * b;
-  const mods_region *reg = reg_all + (size_t)b * k.max_reg;
-  int n = reg_count[b];
-  if (n > k.reg_cap) n = k.reg_cap;
+  const int n = min(*n_items_dev, items_cap);
 #ifdef EXTRACT_PROF
   unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
   int pn = 0;
@@ -351,9 +348,10 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
 #else
 #define PROF_MARK(i)
 #endif
-  for (int ri = blockIdx.x; ri < n; ri += gridDim.x) {
-    const RegionGeom g = region_geom(reg[ri], k.desc_mr, ps, k.patch_rule);
-    if (g.P2 > k.p2_hi || g.P2 <= k.p2_lo) continue;
+  for (int it = blockIdx.x; it < n; it += gridDim.x) {
+    const int code = items[it], b = code >> 17, ri = code & 0x1ffff;
+    const float *img = img_all + (size_t)k.w * k.h * b;
+    const RegionGeom g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, ps, k.patch_rule);
     float *out = patches + ((size_t)b * k.reg_cap + ri) * pp;
     __syncthreads();
     PROF_MARK(0)
@@ -378,7 +376,7 @@ __global__ __launch_bounds__(256) void extract_small_kernel(const float *__restr
     }
   }
 #ifdef EXTRACT_PROF
-  if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x % 512) == 7)
+  if (threadIdx.x == 0 && (blockIdx.x % 512) == 7)
     printf("extract_small prof: block %d tier %d regions %d cycles: skip %llu sample %llu setup %llu rowpass %llu colres %llu\n", blockIdx.x,
            k.p2_hi, pn, pt[0], pt[1], pt[2], pt[3], pt[4]);
 #endif
@@ -398,6 +396,7 @@ struct BigRegion { int img, ri, P2, n_tap; unsigned long long slab; float scale;
 struct BigLists {                     // device-resident bookkeeping, zeroed before every batch
   int n_regions, n_sitems, n_ritems, n_fitems;
   unsigned long long pool_used;
+  int n_small[2], pad[2];           // regions of the two LDS tiers (P2 <= t_lo, t_lo < P2 <= p2_hi), over all images
 };
 // regions up to this size take the fused sample + row-pass kernel (S stays in LDS, no S slab); larger ones the phase kernels
 constexpr int BIG_FUSE_P2 = 256;
@@ -412,15 +411,35 @@ __device__ __forceinline__ int big_rsteps(int n_tap) { const int v = BIG_RLOADS 
 __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mods_region *__restrict__ reg_all,
                                                            const int *__restrict__ reg_count, BigLists *__restrict__ bl,
                                                            BigRegion *__restrict__ regions, int2 *__restrict__ sitems,
-                                                           int2 *__restrict__ ritems, int2 *__restrict__ fitems, int max_regions, int max_items,
+                                                           int2 *__restrict__ ritems, int2 *__restrict__ fitems, int *__restrict__ small_items, int small_cap_items, int t_lo,
+                                                           int max_regions, int max_items,
                                                            unsigned long long pool_elems, int *__restrict__ err_flag) {
   const int b = blockIdx.y;
   int n = reg_count[b];
   if (n > k.reg_cap) n = k.reg_cap;
   const int ri = blockIdx.x * 256 + threadIdx.x;
-  if (ri >= n) return;
-  const RegionGeom g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps, k.patch_rule);
-  if (g.P2 <= k.p2_hi) return;
+  const bool have = ri < n;
+  RegionGeom g;
+  g.P2 = 0;
+  if (have) g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps, k.patch_rule);
+  // LDS tier: work lists of the two size classes (image << 17 | region), one atomic per wave and class
+  {
+    const int lane = threadIdx.x & 63;
+    const int tier = !have || g.P2 > k.p2_hi ? -1 : (g.P2 <= t_lo ? 0 : 1);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const unsigned long long m = __ballot(tier == t);
+      if (m == 0) continue;
+      int base = 0;
+      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&bl->n_small[t], __popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1);
+      if (tier == t) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < small_cap_items) small_items[(size_t)t * small_cap_items + pos] = (b << 17) | ri;
+      }
+    }
+  }
+  if (!have || g.P2 <= k.p2_hi) return;
   const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
   const int P2r = (g.P2 + 3) & ~3;
   const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2, P2r) +
@@ -1404,7 +1423,8 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   // HBM layout of the description scratch: patch store [n_img][reg_cap][ps*ps] | big-tier bookkeeping | slab pool
   const size_t patch_elems = (size_t)n_img * k.reg_cap * pp;
   const int max_big = 1 << 17, max_items = 1 << 20;
-  const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + 3 * sizeof(int2) * max_items + 15) / 4;
+  const int small_cap_items = n_img * k.reg_cap;
+  const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + 3 * sizeof(int2) * max_items + 2 * sizeof(int) * (size_t)small_cap_items + 15) / 4;
   // slab pool: ~25 M floats per 1080p image in practice (row-pass strips, S only above 256 px); 64 M per image of the batch
   // and per 2 Mpx of image area, at least 1 GiB
   const unsigned long long area_units = std::max<unsigned long long>(1, ((unsigned long long)k.w * k.h + (1ull << 21) - 1) >> 21);
@@ -1423,6 +1443,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   int2 *sitems = (int2 *)(bregs + max_big);
   int2 *ritems = sitems + max_items;
   int2 *fitems = ritems + max_items;
+  int *small_items = (int *)(fitems + max_items);
   float *pool = ctx->desc_scratch + patch_elems + book_elems;
   MODS_HIP_CHECK(hipMemsetAsync(bl, 0, sizeof(BigLists), ctx->stream));
   k.tap_cap = 4096;
@@ -1433,19 +1454,20 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   }();
   k.p2_hi = small_cap;
   hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
-                     ctx->region_count, bl, bregs, sitems, ritems, fitems, max_big, max_items, pool_elems, ctx->desc_err_dev);
-  // LDS tier in two launches (P2 <= 48 takes half the LDS of the 80 class: twice the workgroups per CU);
-  // the HBM tier takes P2 > small_cap
+                     ctx->region_count, bl, bregs, sitems, ritems, fitems, small_items, small_cap_items, std::min(small_cap, 48), max_big, max_items,
+                     pool_elems, ctx->desc_err_dev);
+  // LDS tier in two launches over the work lists of big_classify_kernel (P2 <= 48 takes half the LDS of the 80 class: twice
+  // the workgroups per CU); the HBM tier takes P2 > small_cap
   {
     const int tiers[3] = {-1, small_cap < 48 ? small_cap : 48, small_cap};
     for (int t = 0; t < 2; t++) {
-      if (tiers[t + 1] <= tiers[t]) continue;
+      if (t == 1 && tiers[2] <= tiers[1]) continue;
       DescConst kt = k;
       kt.p2_lo = tiers[t]; kt.p2_hi = tiers[t + 1];
       const size_t capS = kt.p2_hi > 4 ? kt.p2_hi : 4;
       const size_t ldsS = sizeof(float) * (capS * ((capS + 3) & ~(size_t)3) + capS * t_stride(ps) + 2 * ps2 + 32) + 32;
-      hipLaunchKernelGGL(extract_small_kernel, dim3(2048, n_img), dim3(256), ldsS, ctx->stream, img_dev, kt, ctx->regions_dev,
-                         ctx->region_count, patches);
+      hipLaunchKernelGGL(extract_small_kernel, dim3(4096), dim3(256), ldsS, ctx->stream, img_dev, kt, ctx->regions_dev,
+                         small_items + (size_t)t * small_cap_items, &bl->n_small[t], small_cap_items, patches);
     }
   }
   const size_t ldsH = sizeof(float) * (k.tap_cap + 4 * ps2) + 32;
