@@ -121,7 +121,10 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
 
 // grid = (N, n_img), block = 64.  One wave per detected keypoint.
 // dynamic LDS: patch ps*ps | vote values ps*(ps-2) (padded to 16) | vote bins (bytes) | hist 40
-__global__ __launch_bounds__(64) void orient_kernel(const float *__restrict__ img_all, DescConst k,
+#ifndef ORIENT_WAVES
+#define ORIENT_WAVES 4
+#endif
+__global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *__restrict__ img_all, DescConst k,
                                                     const mods_affkey *__restrict__ keys_all,
                                                     const int *__restrict__ key_count, const float *__restrict__ orimask,
                                                     OriOut *__restrict__ ori_all) {

@@ -333,8 +333,11 @@ __device__ void inv_sqrt(float &a, float &b, float &c, float &l1, float &l2) {
 // double-precision inverse square root of the 2x2 moment matrix), so several keypoints share the wave; a keypoint that has
 // converged or failed idles until the others of its wave are done.
 // dynamic LDS: mask WP | KP x (img, pa, pb, pc: 4 WP | 4 sums)
+#ifndef BAUMBERG_WAVES
+#define BAUMBERG_WAVES 4
+#endif
 template <int KP>
-__global__ __launch_bounds__(64) void baumberg_kernel(const PyramidDev *__restrict__ P, DetectConst k,
+__global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const PyramidDev *__restrict__ P, DetectConst k,
                                                       CandDev *__restrict__ cand, const int *__restrict__ acc_list,
                                                       const int *__restrict__ acc_count, const float *__restrict__ mask,
                                                       unsigned long long *__restrict__ sort_keys, int *__restrict__ sort_idx,
