@@ -1143,15 +1143,6 @@ __global__ __launch_bounds__(256, 2) void sift_wave_kernel(DescConst k, const fl
 #pragma unroll
   for (int q = 0; q < SW_CW; q++) wcw[q] = (clo + q < ps) ? s_w[hbc * ps + clo + q] : 0.f;
 
-  // region slot and pixel column of this lane's RL pixel slots of a row (row independent: the divisions are done once)
-  constexpr int RL = 6;                                 // >= ceil(SW_R * ps / 64) for ps <= 48 (this kernel runs for ps <= 45)
-  int slot_rr[RL], slot_c[RL];
-#pragma unroll
-  for (int u = 0; u < RL; u++) {
-    const int e = lane + 64 * u;
-    slot_rr[u] = min(e / ps, SW_R - 1);
-    slot_c[u] = e - (e / ps) * ps;
-  }
 #ifdef SIFT_PROF
   unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
   int pn = 0;
@@ -1216,12 +1207,13 @@ __global__ __launch_bounds__(256, 2) void sift_wave_kernel(DescConst k, const fl
     }
     wave_sync();
     // normalised patch row -> ring slot; the row after next is fetched into registers while the current row is worked on
+    constexpr int RL = 6;                               // >= ceil(SW_R * ps / 64) for ps <= 48 (this kernel runs for ps <= 45)
     float nxt[RL];
     auto fetch_row = [&](int r) {
 #pragma unroll
       for (int u = 0; u < RL; u++) {
         const int e = lane + 64 * u;
-        if (e < rowf) nxt[u] = patch_of(slot_rr[u])[r * ps + slot_c[u]];
+        if (e < rowf) { const int rr = e / ps; nxt[u] = patch_of(rr)[r * ps + e - rr * ps]; }
       }
     };
     auto store_row = [&](int r) {
@@ -1230,7 +1222,7 @@ __global__ __launch_bounds__(256, 2) void sift_wave_kernel(DescConst k, const fl
       for (int u = 0; u < RL; u++) {
         const int e = lane + 64 * u;
         if (e < rowf) {
-          const int rr = slot_rr[u];
+          const int rr = e / ps;
           float v = nxt[u];
           if (s_flag[rr]) {
             v = 128 + s_fac[rr] * (v - s_mean[rr]);
@@ -1251,7 +1243,7 @@ __global__ __launch_bounds__(256, 2) void sift_wave_kernel(DescConst k, const fl
 #pragma unroll
       for (int u = 0; u < RL; u++) {
         const int e = lane + 64 * u;
-        if (e < rowf) mrow[u] = mask[r * ps + slot_c[u]];
+        if (e < rowf) mrow[u] = mask[r * ps + e - (e / ps) * ps];
       }
       wave_sync();
       SPROF(2)
@@ -1266,7 +1258,7 @@ __global__ __launch_bounds__(256, 2) void sift_wave_kernel(DescConst k, const fl
         for (int u = 0; u < RL; u++) {
           const int e = lane + 64 * u;
           if (e < rowf) {
-            const int c = slot_c[u];
+            const int c = e - (e / ps) * ps;
             xa[u] = R0[e + (c < ps - 1 ? 1 : 0)];
             xb[u] = R0[e - (c > 0 ? 1 : 0)];
             ya[u] = Rup[e];
