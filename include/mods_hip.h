@@ -44,7 +44,15 @@ typedef struct mods_hessaff_params {
   float convergenceThreshold;  /* 0.05 */
   int smmWindowSize;           /* 19 */
   int doBaumberg;              /* 1 */
+  /* keypoint selection, AffineDetector::prepareKeysForExport (scale-space-detector.hpp:126-198); in every mode but FixedTh the
+   * detector's thresholds are 0 (pyramid.h:58-59): every 3x3x3 extremum is localised and adapted, then the sorted list is cut */
+  int mode;                    /* [HessianAffine] mode: MODS_DET_* (FixedTh) */
+  float relativeThreshold;     /* RelativeTh: keep |response| > relativeThreshold * max|response| */
+  int regionsNumber;           /* FixedRegNumber: the strongest regionsNumber; NotLessThanRegions: at least that many */
+  float relativeRegionsNumber; /* RelativeRegNumber: the strongest floor(relativeRegionsNumber * n) */
 } mods_hessaff_params;
+enum { MODS_DET_FIXED_TH = 0, MODS_DET_RELATIVE_TH, MODS_DET_FIXED_REG_NUMBER, MODS_DET_RELATIVE_REG_NUMBER,
+       MODS_DET_NOT_LESS_THAN_REGIONS };   /* detection_mode_t, detectors/structures.hpp:10-14 */
 
 /* AffineKeypoint (detectors/structures.hpp:185-195) + provenance of the pyramid hit. */
 typedef struct mods_affkey {
@@ -110,7 +118,7 @@ int mods_ctx_timing_reset(mods_ctx *ctx);
  *           ScaleSpaceDetectorParams, ScalePyramid&, double tilt, double zoom)
  * (detectors/affinedetectors/scale-space-detector.cpp:13-32) followed by the
  * s*=sqrt|det A| / rectifyTransformation loop of DetectAffineRegions<>
- * (synth-detection.hpp:79-112).  FIXED_TH mode.  Output sorted by |response| descending. */
+ * (synth-detection.hpp:79-112).  Output sorted by |response| descending, cut as par->mode says. */
 int mods_detect_hessian_affine(mods_ctx *ctx, const float *img, int w, int h, int stride,
                                const mods_hessaff_params *par, mods_affkey *out, int max_out, int *n_out);
 /* batch of `n_img` same-size device-resident images; out[i*max_out ...], n_out[i] */
@@ -272,6 +280,15 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
  * stats3 = {samples drawn, LO runs, plane consensus *Ih}. */
 int mods_loransac_f(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask,
                     double *F_out, int *n_inliers, int *stats3);
+/* The verification half of one step of the reference's loop (mods.cpp:278-368), in place on (tent, u6, laf):
+ *   par->dup_before_ransac = 1 ([DuplicateFiltering] doBeforeRANSAC): DuplicateFiltering (mods.cpp:283), then LORANSACFiltering;
+ *   par->dup_before_ransac = 0: LORANSACFiltering on every tentative, then DuplicateFiltering on the verified list
+ *   (mods.cpp:357-368; TrueMatch1st = the size of the de-duplicated list, which also drives the minMatches stop).
+ * On return the first *n_verified entries of tent / u6 / laf are the verified correspondences in output order and *n_unique is
+ * the size of the list the RANSAC ran on.  H_out, stats3 as mods_loransac_h / _f; ms_dup / ms_ransac (optional): wall clock. */
+struct mods_pair_params;
+int mods_verify_tentatives(int device, const struct mods_pair_params *par, mods_tentative *tent, double *u6, double *laf, int n,
+                           int *n_unique, int *n_verified, double *H_out, int *stats3, double *ms_dup, double *ms_ransac);
 /* GPU used by the degensac entry points of the calling thread (default 0). */
 int mods_ransac_set_device(int device);
 /* The reference seeds with srand(time(NULL)) (exp_ranH.c:823).  seed >= 0 makes every call behave as if

@@ -26,6 +26,7 @@ extern "C" {
 #define MODS_ZMQ_E_SOCKET (-3)
 #define MODS_ZMQ_E_REPLY (-4)      /* reply size is not a multiple of 4 * n, or does not fit the output buffer */
 #define MODS_ZMQ_MAX_PATCHES 2000  /* per request (imagerepresentation.cpp:27) */
+#define MODS_ZMQ_MAX_PATCH_SIZE 256  /* px; the shipped configurations use 32 (a request wider than this is refused) */
 
 const char *mods_zmq_last_error(void);
 

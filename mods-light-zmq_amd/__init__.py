@@ -28,11 +28,14 @@ class HessAffParams(C.Structure):
     """[HessianAffine] section of the reference .ini (io_mods.cpp:167-207)."""
     _fields_ = [("numberOfScales", C.c_int), ("initialSigma", C.c_float), ("threshold", C.c_float),
                 ("edgeEigenValueRatio", C.c_float), ("border", C.c_int), ("maxIterations", C.c_int),
-                ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int)]
+                ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int),
+                ("mode", C.c_int), ("relativeThreshold", C.c_float), ("regionsNumber", C.c_int),
+                ("relativeRegionsNumber", C.c_float)]
 
     @staticmethod
     def default():
-        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1)   # build/config_affori_classic.ini
+        # build/config_affori_classic.ini; mode FixedTh, the other selection keys at PyramidParams' defaults (-1)
+        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1, 0, -1.0, -1, -1.0)
 
 
 AFFKEY_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("s", "f8"), ("a11", "f8"), ("a12", "f8"), ("a21", "f8"),
@@ -119,6 +122,7 @@ class Context:
         self.h = C.c_void_p()
         _check(lib().mods_ctx_create(device, max_w, max_h, batch, C.byref(self.h)))
         self.batch = batch
+        self.device = device
 
     def close(self):
         if self.h:
@@ -462,6 +466,24 @@ def loransac_f(u6, laf, params=None, seed_time=12345):
                                  n, C.byref(params), mask.ctypes.data_as(C.c_void_p), F.ctypes.data_as(C.c_void_p),
                                  C.byref(ninl), stats))
     return mask[:n].astype(bool), F, ninl.value, list(stats)
+
+
+def verify_tentatives(tent, u6, laf, params, device=0, seed_time=None):
+    """mods_verify_tentatives: duplicate filtering + LORANSACFiltering in the order [DuplicateFiltering] doBeforeRANSAC asks for
+    (mods.cpp:278-368).  Returns (verified tentatives, their u6, their laf, n_unique, H, stats)."""
+    if seed_time is not None:
+        ransac_pin_seed(seed_time)
+    tent = np.ascontiguousarray(tent).copy()
+    u = np.ascontiguousarray(u6, np.float64).copy()
+    lf = np.ascontiguousarray(laf, np.float64).copy()
+    nu, nv = C.c_int(), C.c_int()
+    H = np.zeros(9, np.float64)
+    stats = (C.c_int * 3)()
+    _check(lib().mods_verify_tentatives(device, C.byref(params), tent.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p),
+                                        lf.ctypes.data_as(C.c_void_p), len(tent), C.byref(nu), C.byref(nv),
+                                        H.ctypes.data_as(C.c_void_p), stats, None, None))
+    m = nv.value
+    return tent[:m].copy(), u[:m].copy(), lf[:m].copy(), nu.value, H, list(stats)
 
 
 # ---- multi-view representation and the MODS step loop --------------------------------------------------------

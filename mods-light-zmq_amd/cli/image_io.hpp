@@ -1,11 +1,14 @@
 // Image input of the mods CLI: PNG (libpng) and binary PGM/PPM, to a grey float image.
 //
 // Reference behaviour: cv::imread (mods.cpp:116-118).  With [Computing] LoadColor=1 a colour file stays
-// colour and GenerateSynthImageCorr averages it, (B + G + R) / 3 in float (synth-detection.cpp:343-354);
+// colour and GenerateSynthImageCorr averages it, (B + G + R) / 3.0 on float planes (synth-detection.cpp:343-354): a cv::MatExpr
+// that OpenCV evaluates as addWeighted(B + G, 1/3, R, 1/3, 0) with float weights, fused: fma(B + G, a, R * a), a = (float)(1/3.)
+// (the reading that reproduces the reference's README counts, tools/readme_count_hunt.py);
 // with LoadColor=0 imread itself converts, i.e. OpenCV's fixed-point BT.601 luma
 // (R*4899 + G*9617 + B*1868 + 8192) >> 14.  PNG decoding is exact; JPEG is not available in this build
 // (no libjpeg) and is reported as an error.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -18,7 +21,10 @@ namespace modscli {
 struct GreyImage { int w = 0, h = 0; std::vector<float> px; };
 
 static inline float grey_of(const unsigned char *rgb, bool average) {
-  if (average) return ((float)rgb[2] + (float)rgb[1] + (float)rgb[0]) / 3.0f;      // B + G + R
+  if (average) {
+    const float a = (float)(1.0 / 3.0);
+    return std::fmaf((float)rgb[2] + (float)rgb[1], a, (float)rgb[0] * a);         // fma(B + G, a, R * a)
+  }
   return (float)((rgb[0] * 4899 + rgb[1] * 9617 + rgb[2] * 1868 + 8192) >> 14);
 }
 

@@ -15,8 +15,9 @@
 //                      keypoint files (imagerepresentation.cpp:198-204, 1219-1255), H/F file (matching.cpp:2681-2686),
 //                      time.log (io_mods.cpp:67-99, mods.cpp:528-540); exit code 0 / 1
 // Not built (outside the hot path): MSER/DoG/Harris/ORB steps of an iterations file are skipped with a
-// warning, match images (out1/out2) are not drawn, pre-extracted input and ground-truth verification are
-// refused.  The vector matcher is always the exact (linear) search.
+// warning, match images (out1/out2) are not drawn, ground-truth verification is refused.  Pre-extracted input
+// (read_pre_extracted = 1) is read from .npz keypoint files.  The vector matcher is always the exact (linear) search;
+// external (ZMQ) descriptor / AffNet / OriNet daemons are used when the configuration asks for them.
 #include "../../include/mods_hip.h"
 #include "../../include/mods_zmq.h"
 #include "image_io.hpp"
@@ -66,6 +67,7 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   IniReader it(iters_fn);
   if (it.ParseError() < 0) { std::cerr << "Can't load  " << iters_fn << std::endl; return 1; }
   mods_pair_params &p = cfg->pair;
+  cfg->verbose = (int)ini.GetInteger("TextOutput", "verbose", 0);     // first: the notes below depend on it
   // [HessianAffine], io_mods.cpp:160-207; defaults = PyramidParams / AffineShapeParams constructors
   mods_hessaff_params &d = p.det;
   d.threshold = (float)ini.GetDouble("HessianAffine", "threshold", 16.0 / 3.0);
@@ -77,11 +79,15 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   d.smmWindowSize = (int)ini.GetInteger("HessianAffine", "smmWindowSize", 19);
   d.convergenceThreshold = (float)ini.GetDouble("HessianAffine", "convergenceThreshold", 0.05);
   d.doBaumberg = (int)ini.GetInteger("HessianAffine", "doBaumberg", 1);
+  // keypoint selection, io_mods.cpp:170-173, 194-205 (defaults: PyramidParams, structures.hpp:138-150)
+  d.relativeThreshold = (float)ini.GetDouble("HessianAffine", "relativeThreshold", -1.0);
+  d.relativeRegionsNumber = (float)ini.GetDouble("HessianAffine", "relativeRegionsNumber", -1.0);
+  d.regionsNumber = (int)ini.GetInteger("HessianAffine", "regionsNumber", -1);
   const std::string mode = ini.GetStringVector("HessianAffine", "mode")[0];
-  if (!mode.empty() && mode != "FixedTh") std::cerr << "Warning: [HessianAffine] mode=" << mode << " is not supported, FixedTh is used" << std::endl;
+  d.mode = mode == "RelativeTh" ? MODS_DET_RELATIVE_TH : mode == "FixedRegNumber" ? MODS_DET_FIXED_REG_NUMBER
+         : mode == "NotLessThanRegions" ? MODS_DET_NOT_LESS_THAN_REGIONS : mode == "RelativeRegNumber" ? MODS_DET_RELATIVE_REG_NUMBER
+         : MODS_DET_FIXED_TH;
   if (ini.GetInteger("HessianAffine", "affBmbrgMethod", 0) != 0) std::cerr << "Warning: affBmbrgMethod != 0 (Hessian Baumberg) is not supported, SMM is used" << std::endl;
-  if (ini.GetBoolean("AffineAdaptation", "useZMQ", false) || ini.GetBoolean("DominantOrientation", "useZMQ", false))
-    std::cerr << "Warning: external (ZMQ) affine shape / orientation estimators are not supported, the built-in ones are used" << std::endl;
   // [DominantOrientation] :731-740 and [SIFTDescriptor] :423-436
   mods_describe_params &q = p.desc;
   q.ori_mrSize = ini.GetDouble("DominantOrientation", "mrSize", 3.0 * std::sqrt(3.0));
@@ -123,7 +129,6 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   r.errorType = et == "Sampson" ? 0 : et == "SymmMax" ? 1 : 2;
   r.useF = ver_type == 2 ? 1 : 0;
   // [TextOutput], [Computing]
-  cfg->verbose = (int)ini.GetInteger("TextOutput", "verbose", 0);
   cfg->time_log = (int)ini.GetInteger("TextOutput", "timeLog", 0);
   cfg->write_keypoints = (int)ini.GetInteger("TextOutput", "writeKeypoints", 1);
   cfg->write_matches = (int)ini.GetInteger("TextOutput", "writeMatches", 1);

@@ -100,26 +100,42 @@ inline bool npy_parse(const unsigned char *p, size_t n, NpyArray *a, std::string
   else { if (n < 12) return false; hlen = get32(p + 8); hoff = 12; }
   if (hoff + hlen > n) { if (err) *err = "truncated .npy header"; return false; }
   const std::string h((const char *)p + hoff, hlen);
+  // every field is looked up defensively: a corrupt or hostile k1 / k2 file must be refused, not read out of bounds
   size_t i = h.find("'descr'");
   if (i == std::string::npos) { if (err) *err = "no descr in .npy header"; return false; }
-  i = h.find('\'', h.find(':', i)); const size_t j = h.find('\'', i + 1);
+  const size_t colon = h.find(':', i);
+  i = colon == std::string::npos ? colon : h.find('\'', colon);
+  const size_t j = i == std::string::npos ? i : h.find('\'', i + 1);
+  if (j == std::string::npos) { if (err) *err = "malformed descr in .npy header"; return false; }
   a->descr = h.substr(i + 1, j - i - 1);
   if (h.find("'fortran_order': True") != std::string::npos) { if (err) *err = "Fortran-order arrays are not supported"; return false; }
-  i = h.find('(', h.find("'shape'"));
-  const size_t e = h.find(')', i);
+  const size_t sh = h.find("'shape'");
+  i = sh == std::string::npos ? sh : h.find('(', sh);
+  const size_t e = i == std::string::npos ? i : h.find(')', i);
+  if (e == std::string::npos) { if (err) *err = "malformed shape in .npy header"; return false; }
   a->shape.clear();
   size_t pos = i + 1;
   while (pos < e) {
     while (pos < e && (h[pos] == ' ' || h[pos] == ',')) pos++;
     if (pos >= e) break;
+    if (h[pos] < '0' || h[pos] > '9') { if (err) *err = "malformed shape in .npy header"; return false; }
     size_t v = 0;
-    while (pos < e && h[pos] >= '0' && h[pos] <= '9') v = v * 10 + (h[pos++] - '0');
+    while (pos < e && h[pos] >= '0' && h[pos] <= '9') {
+      if (v > (SIZE_MAX - 9) / 10) { if (err) *err = ".npy dimension overflows"; return false; }
+      v = v * 10 + (size_t)(h[pos++] - '0');
+    }
     a->shape.push_back(v);
   }
   size_t item = 0;
-  if (a->descr.size() >= 3) item = (size_t)atoi(a->descr.c_str() + 2);
-  const size_t bytes = a->count() * item;
-  if (item == 0 || hoff + hlen + bytes > n) { if (err) *err = "bad .npy payload size"; return false; }
+  if (a->descr.size() >= 3) { const int it = atoi(a->descr.c_str() + 2); item = it > 0 && it <= 16 ? (size_t)it : 0; }
+  if (item == 0) { if (err) *err = "bad .npy element type " + a->descr; return false; }
+  const size_t avail = n - hoff - hlen;      // hoff + hlen <= n was checked above
+  size_t bytes = item;
+  for (size_t d : a->shape) {
+    if (d != 0 && bytes > avail / d) { if (err) *err = "bad .npy payload size"; return false; }   // also rules out overflow
+    bytes *= d;
+  }
+  if (bytes > avail) { if (err) *err = "bad .npy payload size"; return false; }
   a->data.assign(p + hoff + hlen, p + hoff + hlen + bytes);
   return true;
 }
@@ -147,12 +163,13 @@ inline bool npz_read(const std::string &fn, std::map<std::string, NpyArray> *out
     const size_t csize = get32(&buf[p + 20]), usize = get32(&buf[p + 24]);
     const size_t nlen = get16(&buf[p + 28]), xlen = get16(&buf[p + 30]), clen = get16(&buf[p + 32]);
     const size_t loff = get32(&buf[p + 42]);
+    if (p + 46 + nlen + xlen + clen > buf.size()) { if (err) *err = fn + ": truncated central directory"; return false; }
     std::string name((const char *)&buf[p + 46], nlen);
     p += 46 + nlen + xlen + clen;
     if (method != 0 || csize != usize) { if (err) *err = fn + ": member " + name + " is compressed (only stored members are read)"; return false; }
     if (loff + 30 > buf.size() || get32(&buf[loff]) != 0x04034b50) { if (err) *err = fn + ": bad local header"; return false; }
     const size_t data = loff + 30 + get16(&buf[loff + 26]) + get16(&buf[loff + 28]);
-    if (data + usize > buf.size()) { if (err) *err = fn + ": truncated member " + name; return false; }
+    if (data > buf.size() || usize > buf.size() - data) { if (err) *err = fn + ": truncated member " + name; return false; }
     if (name.size() > 4 && name.substr(name.size() - 4) == ".npy") name.resize(name.size() - 4);
     NpyArray a;
     if (!npy_parse(&buf[data], usize, &a, err)) return false;

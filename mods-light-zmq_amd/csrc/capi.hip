@@ -166,7 +166,8 @@ int mods_ctx_timing_reset(mods_ctx *c) {
 static int detect_common(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride,
                          const mods_hessaff_params *par, mods_affkey *out_host, int max_out, int *n_out_host) {
   if (!c || !img_dev || !par || !n_out_host) { set_error("detect: null argument"); return MODS_E_ARG; }
-  if (w > c->max_w * 1 && (size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image larger than the context"); return MODS_E_ARG; }
+  if (w <= 0 || h <= 0 || (size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image larger than the context"); return MODS_E_ARG; }
+  if (stride < w) { set_error("detect: stride %d < width %d", stride, w); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   int rc;
   if ((rc = pyramid_configure(c, w, h, n_img, par))) return rc;
@@ -255,6 +256,8 @@ int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w
                              const mods_hessaff_params *det, const mods_describe_params *desc, int *n_detected_host,
                              int *n_regions_host) {
   if (!c || !img_dev || !det || !desc) { set_error("detect_describe: null argument"); return MODS_E_ARG; }
+  if (w <= 0 || h <= 0 || (size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("detect_describe: image larger than the context"); return MODS_E_ARG; }
+  if (stride < w) { set_error("detect_describe: stride %d < width %d", stride, w); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   int rc;
   if ((rc = pyramid_configure(c, w, h, n_img, det))) return rc;
@@ -730,34 +733,63 @@ int mods_pairs_gpu_stage(mods_ctx *c, const float *const *img_dev, int n_pairs, 
 }
 
 // Host-driven half: duplicate filtering + LO-RANSAC (hypotheses scored on `device`) + checks.
-int mods_pair_verify_stage(int device, const mods_pair_params *par, mods_pair_result *res, std::vector<mods_tentative> *tent,
-                           std::vector<double> *u6, std::vector<double> *laf, double *matches_out, int max_matches) {
+// The verification half of one step of the reference's loop (mods.cpp:278-368), in place on (tent, u6, laf):
+//   [DuplicateFiltering] doBeforeRANSAC = 1: DuplicateFiltering on the tentatives, then LORANSACFiltering;
+//   doBeforeRANSAC = 0: LORANSACFiltering on every tentative, then DuplicateFiltering on the VERIFIED list (mods.cpp:357-368;
+//   TrueMatch1st, which also drives the minMatches stop, is the size of the de-duplicated list).
+// On return the first *n_verified entries of the three arrays are the verified correspondences in output order;
+// *n_unique = the size of the list RANSAC ran on.
+int mods_verify_tentatives(int device, const mods_pair_params *par, mods_tentative *tent, double *u6, double *laf, int n,
+                           int *n_unique, int *n_verified, double *H_out, int *stats3, double *ms_dup, double *ms_ransac) {
+  if (!par || !n_unique || !n_verified || (n > 0 && (!tent || !u6 || !laf))) { set_error("verify_tentatives: null argument"); return MODS_E_ARG; }
   int rc;
-  const double t2 = now_ms();
-  const int n = (int)tent->size();
+  const double t0 = now_ms();
   int nu = n;
   if (par->dup_before_ransac && n > 0)
-    if ((rc = mods_duplicate_filter(tent->data(), u6->data(), laf->data(), n, par->dup_dist, par->dup_mode, &nu))) return rc;
-  res->n_unique = nu;
-  const double t3 = now_ms();
-  res->ms_duplicates = t3 - t2;
-  int stats[3] = {0, 0, 0};
+    if ((rc = mods_duplicate_filter(tent, u6, laf, n, par->dup_dist, par->dup_mode, &nu))) return rc;
+  *n_unique = nu;
+  const double t1 = now_ms();
+  int stats[3] = {0, 0, 0}, ninl = 0;
   mods_ransac_set_device(device);
   std::vector<unsigned char> mask(nu > 0 ? nu : 1);
-  if (par->ransac.useF) rc = mods_loransac_f(u6->data(), laf->data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats);
-  else rc = mods_loransac_h(u6->data(), laf->data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats);
+  double H[9];
+  if (par->ransac.useF) rc = mods_loransac_f(u6, laf, nu, &par->ransac, mask.data(), H, &ninl, stats);
+  else rc = mods_loransac_h(u6, laf, nu, &par->ransac, mask.data(), H, &ninl, stats);
+  if (rc) return rc;
+  const double t2 = now_ms();
+  int m = 0;
+  for (int i = 0; i < nu; i++)
+    if (mask[i]) {
+      if (m != i) {
+        tent[m] = tent[i];
+        memcpy(&u6[(size_t)m * 6], &u6[(size_t)i * 6], 6 * sizeof(double));
+        memcpy(&laf[(size_t)m * 14], &laf[(size_t)i * 14], 14 * sizeof(double));
+      }
+      m++;
+    }
+  if (!par->dup_before_ransac && m > 0)
+    if ((rc = mods_duplicate_filter(tent, u6, laf, m, par->dup_dist, par->dup_mode, &m))) return rc;
+  *n_verified = m;
+  if (H_out) memcpy(H_out, H, sizeof(H));
+  if (stats3) memcpy(stats3, stats, sizeof(stats));
+  const double t3 = now_ms();
+  if (ms_dup) *ms_dup = (t1 - t0) + (t3 - t2);
+  if (ms_ransac) *ms_ransac = t2 - t1;
+  return MODS_OK;
+}
+
+int mods_pair_verify_stage(int device, const mods_pair_params *par, mods_pair_result *res, std::vector<mods_tentative> *tent,
+                           std::vector<double> *u6, std::vector<double> *laf, double *matches_out, int max_matches) {
+  int stats[3] = {0, 0, 0};
+  const int rc = mods_verify_tentatives(device, par, tent->data(), u6->data(), laf->data(), (int)tent->size(), &res->n_unique,
+                                        &res->n_inliers, res->H, stats, &res->ms_duplicates, &res->ms_ransac);
   if (rc) return rc;
   res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
-  res->ms_ransac = now_ms() - t3;
-  if (matches_out) {
-    int m = 0;
-    for (int i = 0; i < nu && m < max_matches; i++)
-      if (mask[i]) {
-        const double *p = &(*u6)[(size_t)i * 6];
-        matches_out[4 * m] = p[0]; matches_out[4 * m + 1] = p[1]; matches_out[4 * m + 2] = p[3]; matches_out[4 * m + 3] = p[4];
-        m++;
-      }
-  }
+  if (matches_out)
+    for (int m = 0; m < res->n_inliers && m < max_matches; m++) {
+      const double *p = &(*u6)[(size_t)m * 6];
+      matches_out[4 * m] = p[0]; matches_out[4 * m + 1] = p[1]; matches_out[4 * m + 2] = p[3]; matches_out[4 * m + 3] = p[4];
+    }
   return MODS_OK;
 }
 

@@ -94,6 +94,7 @@ struct mods_ctx {
   int *key_count = nullptr;          // [batch]
   int *host_counts = nullptr;        // pinned
   mods_hessaff_params par;
+  int reg_number_eff = -1;           // par.regionsNumber after the tilt / zoom scaling of DetectAffineKeypoints (scale-space-detector.cpp:20-21)
   int last_w = 0, last_h = 0, last_n_img = 0;
   // orientation + description
   float *desc_tables_dev = nullptr;  // [orimask 64x64][desc mask 64x64][SiftTab]

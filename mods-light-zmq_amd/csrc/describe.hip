@@ -394,7 +394,7 @@ static int external_describe(mods_ctx *ctx, int n_img, const DescConst &k) {
     if (rc || dim != 128) { set_error("external descriptor failed (rc %d, %d values per patch; 128 expected)", rc, dim); return MODS_E_ARG; }
     for (size_t i = 0; i < desc.size(); i++) {
       const float v = out[i];
-      desc[i] = v <= 0.f ? 0 : (v >= 255.f ? 255 : (uint8_t)(v + 0.5f));
+      desc[i] = !(v > 0.f) ? 0 : (v >= 255.f ? 255 : (uint8_t)(v + 0.5f));   // !(v > 0): also NaN replies -> 0
     }
     MODS_HIP_CHECK(hipMemcpy2D((uint8_t *)(ctx->regions_dev + (size_t)b * ctx->max_cand) + offsetof(mods_region, desc), sizeof(mods_region),
                                desc.data(), 128, 128, n, hipMemcpyHostToDevice));

@@ -543,6 +543,38 @@ __global__ __launch_bounds__(256) void export_kernel(DetectConst k, const CandDe
   }
 }
 
+// AffineDetector::prepareKeysForExport (scale-space-detector.hpp:126-198) on the exported (sorted by |response|, descending)
+// list: the number of keys that survive the cut of `mode`.  One block per image.  std::lower_bound with
+// responseCompareInvOrder = #{|response| > |threshold|} on a sorted list, counted here without relying on the order.
+__global__ __launch_bounds__(256) void select_keys_kernel(int max_cand, const mods_affkey *__restrict__ keys, int *__restrict__ key_count,
+                                                          int mode, float rel_threshold, float threshold, int reg_number,
+                                                          float rel_reg_number) {
+  __shared__ int s_cnt;
+  const int b = blockIdx.x;
+  const int n = key_count[b];
+  if (n <= 0) return;
+  const mods_affkey *k = keys + (size_t)b * max_cand;
+  double thr = 0;
+  if (mode == MODS_DET_RELATIVE_TH) thr = (double)(float)(fabs(k[0].response) * rel_threshold);   // float effectiveThreshold, pyramid.h:74
+  else if (mode == MODS_DET_NOT_LESS_THAN_REGIONS) thr = (double)threshold;                       // un-squared, as written (:173)
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  if (mode == MODS_DET_RELATIVE_TH || mode == MODS_DET_NOT_LESS_THAN_REGIONS) {
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) c += fabs(k[i].response) > fabs(thr) ? 1 : 0;
+    if (c) atomicAdd(&s_cnt, c);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int keep = n;
+    if (mode == MODS_DET_RELATIVE_TH) keep = s_cnt;
+    else if (mode == MODS_DET_FIXED_REG_NUMBER) keep = min(n, reg_number);
+    else if (mode == MODS_DET_RELATIVE_REG_NUMBER) keep = (int)floor((double)rel_reg_number * (double)n);
+    else if (mode == MODS_DET_NOT_LESS_THAN_REGIONS) keep = s_cnt < reg_number ? min(reg_number, n) : min(s_cnt, n);
+    key_count[b] = max(0, min(keep, n));
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 int detect_run(mods_ctx *ctx) {
   const PyramidDev &P = ctx->pyr;
@@ -557,6 +589,15 @@ int detect_run(mods_ctx *ctx) {
   k.pos_th = (float)(0.8 * par.threshold);
   k.neg_th = -k.pos_th;
   k.final_th = par.threshold * par.threshold;
+  if (par.mode != MODS_DET_FIXED_TH) {   // pyramid.h:58-59: every extremum is a candidate, the sorted list is cut afterwards
+    if (par.mode < 0 || par.mode > MODS_DET_NOT_LESS_THAN_REGIONS) { set_error("unknown detector mode %d", par.mode); return MODS_E_ARG; }
+    // the reference resizes its list to these numbers unchecked (negative / > 1 values end in std::length_error or in
+    // default-constructed keypoints): refuse them
+    if ((par.mode == MODS_DET_FIXED_REG_NUMBER || par.mode == MODS_DET_NOT_LESS_THAN_REGIONS) && par.regionsNumber < 0) { set_error("regionsNumber must be >= 0 in this mode"); return MODS_E_ARG; }
+    if (par.mode == MODS_DET_RELATIVE_REG_NUMBER && !(par.relativeRegionsNumber >= 0.f && par.relativeRegionsNumber <= 1.f)) { set_error("relativeRegionsNumber must be in [0, 1]"); return MODS_E_ARG; }
+    if (par.mode == MODS_DET_RELATIVE_TH && !(par.relativeThreshold >= 0.f)) { set_error("relativeThreshold must be >= 0"); return MODS_E_ARG; }
+    k.pos_th = k.neg_th = k.final_th = 0.f;
+  }
   k.max_cand = ctx->max_cand;
   k.smm = par.smmWindowSize;
   k.max_iter = par.maxIterations;
@@ -617,6 +658,9 @@ int detect_run(mods_ctx *ctx) {
     hipLaunchKernelGGL(rank_count_kernel, dim3(64, 32, n_img), dim3(256), 0, ctx->stream, k, ctx->sort_keys, key_count, ctx->rank_dev);
     hipLaunchKernelGGL(export_kernel, dim3(256, n_img), dim3(256), 0, ctx->stream, k, ctx->cand, ctx->sort_idx, key_count,
                        ctx->rank_dev, ctx->keys_dev);
+    if (par.mode != MODS_DET_FIXED_TH)
+      hipLaunchKernelGGL(select_keys_kernel, dim3(n_img), dim3(256), 0, ctx->stream, ctx->max_cand, ctx->keys_dev, key_count, par.mode,
+                         par.relativeThreshold, par.threshold, ctx->reg_number_eff, par.relativeRegionsNumber);
     MODS_HIP_CHECK(hipGetLastError());
   }
   return MODS_OK;

@@ -191,22 +191,18 @@ int mods_match_reps(mods_ctx *c, const mods_imgrep *q, int q_begin, int q_end, c
 // img1_dev / img2_dev: dense fp32 images in HBM (the two images may differ in size).  Every step adds the step's new views of both images to the two region
 // banks, matches bank 1 against bank 2, filters duplicates, verifies, and stops once the verified
 // matches reach min_matches.
-static void copy_verified(mods_ctx *c, const mods_ladder_result *res, const std::vector<unsigned char> &mask, double *matches_out,
-                          int max_matches) {
+static void copy_verified(mods_ctx *c, const mods_ladder_result *res, double *matches_out, int max_matches) {
   if (!matches_out) return;
-  int m = 0;
-  for (int i = 0; i < res->n_unique && m < max_matches; i++)
-    if (mask[i]) {
-      const double *p = &c->h_u6[(size_t)i * 6];
-      matches_out[4 * m] = p[0]; matches_out[4 * m + 1] = p[1]; matches_out[4 * m + 2] = p[3]; matches_out[4 * m + 3] = p[4];
-      m++;
-    }
+  for (int m = 0; m < res->n_inliers && m < max_matches; m++) {   // mods_verify_tentatives left the verified rows first
+    const double *p = &c->h_u6[(size_t)m * 6];
+    matches_out[4 * m] = p[0]; matches_out[4 * m + 1] = p[1]; matches_out[4 * m + 2] = p[3]; matches_out[4 * m + 3] = p[4];
+  }
 }
 
 // match bank 1 against bank 2, drop duplicates, verify (MatchImgReps + DuplicateFiltering + LORANSACFiltering,
 // mods.cpp:288-383): fills the match / verification fields of res and mask (one byte per unique tentative)
 static int match_verify_banks(mods_ctx *c, mods_imgrep *rep1, mods_imgrep *rep2, double fginn_ratio, const mods_pair_params *par,
-                              mods_ladder_result *res, std::vector<unsigned char> &mask) {
+                              mods_ladder_result *res) {
   int rc;
   const double t1 = now_ms2();
   int n = 0;
@@ -224,20 +220,13 @@ static int match_verify_banks(mods_ctx *c, mods_imgrep *rep1, mods_imgrep *rep2,
   const double t2 = now_ms2();
   res->ms_match += t2 - t1;
   res->n_tentatives = n;
-  int nu = n;
-  if (par->dup_before_ransac && n > 0)
-    if ((rc = mods_duplicate_filter(c->h_tent.data(), c->h_u6.data(), c->h_laf.data(), n, par->dup_dist, par->dup_mode, &nu))) return rc;
-  res->n_unique = nu;
-  const double t3 = now_ms2();
-  res->ms_duplicates += t3 - t2;
   int stats[3] = {0, 0, 0};
-  mods_ransac_set_device(c->device);
-  mask.assign(nu > 0 ? nu : 1, 0);
-  if (par->ransac.useF) rc = mods_loransac_f(c->h_u6.data(), c->h_laf.data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats);
-  else rc = mods_loransac_h(c->h_u6.data(), c->h_laf.data(), nu, &par->ransac, mask.data(), res->H, &res->n_inliers, stats);
+  double ms_dup = 0, ms_ran = 0;
+  rc = mods_verify_tentatives(c->device, par, c->h_tent.data(), c->h_u6.data(), c->h_laf.data(), n, &res->n_unique, &res->n_inliers,
+                              res->H, stats, &ms_dup, &ms_ran);
   if (rc) return rc;
+  res->ms_duplicates += ms_dup; res->ms_ransac += ms_ran;
   res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
-  res->ms_ransac += now_ms2() - t3;
   return MODS_OK;
 }
 
@@ -252,7 +241,6 @@ int mods_match_ladder_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, co
   std::vector<mods_view_par> hist(1024), views(256);
   int n_hist = 0, rc;
   int curr_matches = 0;
-  std::vector<unsigned char> mask(1, 0);
   for (int step = 0; step < n_steps && curr_matches < min_matches; step++) {
     const mods_ladder_step &st = steps[step];
     const int nv = mods_view_schedule(st.scale_set, st.n_scales, st.tilt_set, st.n_tilts, st.phi, hist.data(), &n_hist, (int)hist.size(),
@@ -276,11 +264,11 @@ int mods_match_ladder_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, co
     res->n_described[0] = rep1->n; res->n_described[1] = rep2->n;
     const double t1 = now_ms2();
     res->ms_detect_describe += t1 - t0;
-    if ((rc = match_verify_banks(c, rep1, rep2, st.fginn_ratio, par, res, mask))) return rc;
+    if ((rc = match_verify_banks(c, rep1, rep2, st.fginn_ratio, par, res))) return rc;
     curr_matches = res->n_inliers;
     res->steps_done = step + 1;
   }
-  copy_verified(c, res, mask, matches_out, max_matches);
+  copy_verified(c, res, matches_out, max_matches);
   return MODS_OK;
 }
 
@@ -290,11 +278,10 @@ int mods_match_verify_reps(mods_ctx *c, mods_imgrep *rep1, mods_imgrep *rep2, do
   memset(res, 0, sizeof(*res));
   for (int i = 0; i < 9; i++) res->H[i] = -1;
   res->n_described[0] = rep1->n; res->n_described[1] = rep2->n;
-  std::vector<unsigned char> mask(1, 0);
-  const int rc = match_verify_banks(c, rep1, rep2, fginn_ratio, par, res, mask);
+  const int rc = match_verify_banks(c, rep1, rep2, fginn_ratio, par, res);
   if (rc) return rc;
   res->steps_done = 1;
-  copy_verified(c, res, mask, matches_out, max_matches);
+  copy_verified(c, res, matches_out, max_matches);
   return MODS_OK;
 }
 

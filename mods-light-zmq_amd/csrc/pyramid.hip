@@ -6,9 +6,10 @@
 //   HessianResponse                      detectors/affinedetectors/pyramid.cpp:196-254
 //   octave loop, sigma schedule          pyramid.cpp:428-529
 //   cv::resize(.., 0.5, 0.5, LINEAR)     pyramid.cpp:476
-// Arithmetic contract (shared with the CPU oracle): fp32, one rounding per operation
-// (-ffp-contract=off), row pass accumulates taps left to right, column pass centre tap first
-// then symmetric pairs k[r+j]*(T[y+j]+T[y-j]) for j = 1..r.
+// Arithmetic contract (shared with the CPU oracle): fp32, built with -ffp-contract=off so that every fusion is
+// written out.  cv::GaussianBlur as an FMA build of OpenCV evaluates it (the variant that reproduces the reference's
+// README counts exactly, tools/readme_count_hunt.py): row pass s = k[0]*S[0]; s = fma(k[j], S[j], s) left to right,
+// column pass s = k[r]*T[y]; s = fma(k[r+j], T[y+j] + T[y-j], s) for j = 1..r.
 #include "common.hpp"
 #include "detmath.hpp"
 #include <algorithm>
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float *__restrict
     for (int ly = tid / 64; ly < IH; ly += 4) {
       const float *p = s_in + ly * IW + lx;
       float s = s_tap[0] * p[0];
-      for (int j = 1; j < n; j++) s += s_tap[j] * p[j];
+      for (int j = 1; j < n; j++) s = fmaf(s_tap[j], p[j], s);
       s_row[ly * BLUR_TW + lx] = s;
     }
   }
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float *__restrict
         if (gy >= h) break;
         const float *p = s_row + (ly + r) * BLUR_TW + lx;
         float s = s_tap[r] * p[0];
-        for (int j = 1; j <= r; j++) s += s_tap[r + j] * (p[j * BLUR_TW] + p[-j * BLUR_TW]);
+        for (int j = 1; j <= r; j++) s = fmaf(s_tap[r + j], p[j * BLUR_TW] + p[-j * BLUR_TW], s);
         dst[(size_t)gy * w + gx] = s;
       }
     }
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
       for (int u = 0; u < NO; u++) {
         float s = taps.t[0] * wv[D + u];
 #pragma unroll
-        for (int j = 1; j < N; j++) s += taps.t[j] * wv[D + u + j];
+        for (int j = 1; j < N; j++) s = fmaf(taps.t[j], wv[D + u + j], s);
         o[u] = s;
       }
 #pragma unroll
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
         for (int j = 1; j <= R; j++) {
           const float4 a = col[k + R + j], b = col[k + R - j];
           const float t = taps.t[R + j];
-          s.x += t * (a.x + b.x); s.y += t * (a.y + b.y); s.z += t * (a.z + b.z); s.w += t * (a.w + b.w);
+          s.x = fmaf(t, a.x + b.x, s.x); s.y = fmaf(t, a.y + b.y, s.y); s.z = fmaf(t, a.z + b.z, s.z); s.w = fmaf(t, a.w + b.w, s.w);
         }
         float *d = dst + (size_t)gy * w + x4;
         if (x4 + 3 < w && ((w & 3) == 0)) *(float4 *)d = s;
@@ -478,6 +479,8 @@ int launch_resize_half(mods_ctx *ctx, const float *src, float *dst, int w, int h
 // Computes the octave ladder (pyramid.cpp:520-528) and carves the planes out of the pools.
 int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff_params *par) {
   if (w <= 0 || h <= 0 || n_img <= 0 || n_img > ctx->batch) { set_error("bad image batch %dx%d x%d (ctx batch %d)", w, h, n_img, ctx->batch); return MODS_E_ARG; }
+  // every per-image scratch plane (input_dev, tmp_dev, the pyramid pool's first octave) is sized max_w * max_h
+  if ((size_t)w * h > (size_t)ctx->max_w * ctx->max_h) { set_error("image %dx%d larger than the context (%dx%d)", w, h, ctx->max_w, ctx->max_h); return MODS_E_ARG; }
   const int n_levels = par->numberOfScales + 2;
   if (par->numberOfScales < 1 || n_levels > kMaxLevels) { set_error("numberOfScales %d unsupported", par->numberOfScales); return MODS_E_ARG; }
   if (par->border < 2) { set_error("border must be >= 2"); return MODS_E_ARG; }
@@ -524,6 +527,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
   }
   MODS_HIP_CHECK(hipMemcpyAsync(ctx->pyr_dev, &P, sizeof(PyramidDev), hipMemcpyHostToDevice, ctx->stream));
   ctx->par = *par;
+  ctx->reg_number_eff = par->regionsNumber;   // identity view; mods_detect_describe_view_dev rescales it
   ctx->last_w = w; ctx->last_h = h; ctx->last_n_img = n_img;
   // SMM mask for Baumberg
   if (ctx->smm_mask_size != par->smmWindowSize) {

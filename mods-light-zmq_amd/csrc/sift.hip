@@ -169,7 +169,8 @@ __device__ void sample_region_t(const float *__restrict__ img, int w, int h, flo
 }
 
 // row pass of the separable blur at the needed columns from a transposed tile St[col][stride]:
-//   T[y][q] = sum_j tap[j] * S[y][clamp(cidx[q] - r + j)], taps left to right.
+//   T[y][q] = sum_j tap[j] * S[y][clamp(cidx[q] - r + j)], taps left to right, fused multiply-adds (the contract of
+//   pyramid.hip: cv::GaussianBlur as an FMA build of OpenCV evaluates it); 5 taps: centre, then symmetric pairs.
 // A thread owns four consecutive rows (one float4 per tap) of one column pair (x0, x1): x1 = x0 + 1, whose window is the
 // window of x0 shifted by one sample (also after clamping), or x1 = x0 for a grid line clamped at the edge.
 __device__ __forceinline__ void row_pass_t(const float *St, float *T, int P2, int stride, int ps, int n_tap, const float *s_tap,
@@ -179,6 +180,28 @@ __device__ __forceinline__ void row_pass_t(const float *St, float *T, int P2, in
     const int pi = e / nq, y = 4 * (e - pi * nq);
     const int x0 = s_cidx[2 * pi], x1 = s_cidx[2 * pi + 1];
     const float *p = St + y;
+    if (n_tap == 5) {   // cv::GaussianBlur's row filter for ksize <= 5 (SymmRowSmallFilter): centre tap, then the symmetric pairs
+      float4 v[6];
+#pragma unroll
+      for (int u = 0; u < 6; u++) {
+        int xb = x0 - 2 + u; xb = xb < 0 ? 0 : (xb > P2 - 1 ? P2 - 1 : xb);
+        v[u] = *(const float4 *)(p + xb * stride);
+      }
+      const float k0 = s_tap[2], k1 = s_tap[3], k2 = s_tap[4];
+      float4 a0 = make_float4(v[2].x * k0, v[2].y * k0, v[2].z * k0, v[2].w * k0);
+      float4 a1 = make_float4(v[3].x * k0, v[3].y * k0, v[3].z * k0, v[3].w * k0);
+      a0.x = fmaf(v[1].x + v[3].x, k1, a0.x); a0.y = fmaf(v[1].y + v[3].y, k1, a0.y); a0.z = fmaf(v[1].z + v[3].z, k1, a0.z); a0.w = fmaf(v[1].w + v[3].w, k1, a0.w);
+      a1.x = fmaf(v[2].x + v[4].x, k1, a1.x); a1.y = fmaf(v[2].y + v[4].y, k1, a1.y); a1.z = fmaf(v[2].z + v[4].z, k1, a1.z); a1.w = fmaf(v[2].w + v[4].w, k1, a1.w);
+      a0.x = fmaf(v[0].x + v[4].x, k2, a0.x); a0.y = fmaf(v[0].y + v[4].y, k2, a0.y); a0.z = fmaf(v[0].z + v[4].z, k2, a0.z); a0.w = fmaf(v[0].w + v[4].w, k2, a0.w);
+      a1.x = fmaf(v[1].x + v[5].x, k2, a1.x); a1.y = fmaf(v[1].y + v[5].y, k2, a1.y); a1.z = fmaf(v[1].z + v[5].z, k2, a1.z); a1.w = fmaf(v[1].w + v[5].w, k2, a1.w);
+      if (x1 == x0) a1 = a0;
+      float *o = T + y * ps2 + 2 * pi;
+      *(float2 *)o = make_float2(a0.x, a1.x);
+      if (y + 1 < P2) *(float2 *)(o + ps2) = make_float2(a0.y, a1.y);
+      if (y + 2 < P2) *(float2 *)(o + 2 * ps2) = make_float2(a0.z, a1.z);
+      if (y + 3 < P2) *(float2 *)(o + 3 * ps2) = make_float2(a0.w, a1.w);
+      continue;
+    }
     int xa = x0 - r_tap; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
     float4 prev = *(const float4 *)(p + xa * stride);
     float t = s_tap[0];
@@ -197,8 +220,8 @@ __device__ __forceinline__ void row_pass_t(const float *St, float *T, int P2, in
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         t = s_tap[j + u];
-        s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
-        s1.x += t * c[u].x; s1.y += t * c[u].y; s1.z += t * c[u].z; s1.w += t * c[u].w;
+        s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
+        s1.x = fmaf(t, c[u].x, s1.x); s1.y = fmaf(t, c[u].y, s1.y); s1.z = fmaf(t, c[u].z, s1.z); s1.w = fmaf(t, c[u].w, s1.w);
         prev = c[u];
       }
     }
@@ -206,8 +229,8 @@ __device__ __forceinline__ void row_pass_t(const float *St, float *T, int P2, in
       xa = x0 - r_tap + j + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
       const float4 c = *(const float4 *)(p + xa * stride);
       t = s_tap[j];
-      s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
-      s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+      s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
+      s1.x = fmaf(t, c.x, s1.x); s1.y = fmaf(t, c.y, s1.y); s1.z = fmaf(t, c.z, s1.z); s1.w = fmaf(t, c.w, s1.w);
       prev = c;
     }
     if (x1 == x0) s1 = s0;
@@ -228,15 +251,15 @@ __device__ __forceinline__ float col_value(const float *T, int P2, int ps2, int 
     for (; j + 1 <= r_tap; j += 2) {
       const float p0 = c[(size_t)j * ps2], m0 = c[-(ptrdiff_t)j * ps2];
       const float p1 = c[(size_t)(j + 1) * ps2], m1 = c[-(ptrdiff_t)(j + 1) * ps2];
-      s += s_tap[r_tap + j] * (p0 + m0);
-      s += s_tap[r_tap + j + 1] * (p1 + m1);
+      s = fmaf(s_tap[r_tap + j], p0 + m0, s);
+      s = fmaf(s_tap[r_tap + j + 1], p1 + m1, s);
     }
-    for (; j <= r_tap; j++) s += s_tap[r_tap + j] * (c[(size_t)j * ps2] + c[-(ptrdiff_t)j * ps2]);
+    for (; j <= r_tap; j++) s = fmaf(s_tap[r_tap + j], (c[(size_t)j * ps2] + c[-(ptrdiff_t)j * ps2]), s);
   } else {
     for (int j = 1; j <= r_tap; j++) {
       int yp = y + j; yp = yp > P2 - 1 ? P2 - 1 : yp;
       int ym = y - j; ym = ym < 0 ? 0 : ym;
-      s += s_tap[r_tap + j] * (T[(size_t)yp * ps2 + q] + T[(size_t)ym * ps2 + q]);
+      s = fmaf(s_tap[r_tap + j], (T[(size_t)yp * ps2 + q] + T[(size_t)ym * ps2 + q]), s);
     }
   }
   return s;
@@ -275,8 +298,8 @@ __device__ __forceinline__ void col_resample_pair(const float *T, int ts, int P2
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const float t = s_tap[r_tap + jj + q];
-        r0.x += t * (up.x + d[q].x); r0.y += t * (up.y + d[q].y); r0.z += t * (up.z + d[q].z); r0.w += t * (up.w + d[q].w);
-        r1.x += t * (u[q].x + dn_prev.x); r1.y += t * (u[q].y + dn_prev.y); r1.z += t * (u[q].z + dn_prev.z); r1.w += t * (u[q].w + dn_prev.w);
+        r0.x = fmaf(t, up.x + d[q].x, r0.x); r0.y = fmaf(t, up.y + d[q].y, r0.y); r0.z = fmaf(t, up.z + d[q].z, r0.z); r0.w = fmaf(t, up.w + d[q].w, r0.w);
+        r1.x = fmaf(t, u[q].x + dn_prev.x, r1.x); r1.y = fmaf(t, u[q].y + dn_prev.y, r1.y); r1.z = fmaf(t, u[q].z + dn_prev.z, r1.z); r1.w = fmaf(t, u[q].w + dn_prev.w, r1.w);
         up = u[q]; dn_prev = d[q];
       }
     }
@@ -284,8 +307,8 @@ __device__ __forceinline__ void col_resample_pair(const float *T, int ts, int P2
       const int yu = min(y1 + jj, P2 - 1), yd = max(y0 - jj, 0);
       const float4 u = *(const float4 *)(c + yu * ts), d = *(const float4 *)(c + yd * ts);
       const float t = s_tap[r_tap + jj];
-      r0.x += t * (up.x + d.x); r0.y += t * (up.y + d.y); r0.z += t * (up.z + d.z); r0.w += t * (up.w + d.w);
-      r1.x += t * (u.x + dn_prev.x); r1.y += t * (u.y + dn_prev.y); r1.z += t * (u.z + dn_prev.z); r1.w += t * (u.w + dn_prev.w);
+      r0.x = fmaf(t, up.x + d.x, r0.x); r0.y = fmaf(t, up.y + d.y, r0.y); r0.z = fmaf(t, up.z + d.z, r0.z); r0.w = fmaf(t, up.w + d.w, r0.w);
+      r1.x = fmaf(t, u.x + dn_prev.x, r1.x); r1.y = fmaf(t, u.y + dn_prev.y, r1.y); r1.z = fmaf(t, u.z + dn_prev.z, r1.z); r1.w = fmaf(t, u.w + dn_prev.w, r1.w);
       up = u; dn_prev = d;
     }
   } else {   // both grid rows clamped onto one strip row (output rows outside the strip)
@@ -602,16 +625,16 @@ __global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const Big
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             t = tap[j + u];
-            s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
-            s1.x += t * c[u].x; s1.y += t * c[u].y; s1.z += t * c[u].z; s1.w += t * c[u].w;
+            s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
+            s1.x = fmaf(t, c[u].x, s1.x); s1.y = fmaf(t, c[u].y, s1.y); s1.z = fmaf(t, c[u].z, s1.z); s1.w = fmaf(t, c[u].w, s1.w);
             prev = c[u];
           }
         }
         for (; j < n_tap; j++) {
           const float4 c = *(const float4 *)(p + (size_t)(j + 1) * P2r);
           t = tap[j];
-          s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
-          s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+          s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
+          s1.x = fmaf(t, c.x, s1.x); s1.y = fmaf(t, c.y, s1.y); s1.z = fmaf(t, c.z, s1.z); s1.w = fmaf(t, c.w, s1.w);
           prev = c;
         }
       } else {
@@ -629,8 +652,8 @@ __global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const Big
           xa = x0 - r_tap + j + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
           const float4 c = *(const float4 *)(p + (size_t)xa * P2r);
           t = tap[j];
-          s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
-          s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+          s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
+          s1.x = fmaf(t, c.x, s1.x); s1.y = fmaf(t, c.y, s1.y); s1.z = fmaf(t, c.z, s1.z); s1.w = fmaf(t, c.w, s1.w);
           prev = c;
         }
       }
@@ -745,16 +768,16 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
 #pragma unroll
             for (int u = 0; u < 8; u++) {
               t = tap[j + u];
-              s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
-              s1.x += t * c[u].x; s1.y += t * c[u].y; s1.z += t * c[u].z; s1.w += t * c[u].w;
+              s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
+              s1.x = fmaf(t, c[u].x, s1.x); s1.y = fmaf(t, c[u].y, s1.y); s1.z = fmaf(t, c[u].z, s1.z); s1.w = fmaf(t, c[u].w, s1.w);
               prev = c[u];
             }
           }
           for (; j < n_tap; j++) {
             const float4 c = *(const float4 *)(p + (j + 1) * R);
             t = tap[j];
-            s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
-            s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+            s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
+            s1.x = fmaf(t, c.x, s1.x); s1.y = fmaf(t, c.y, s1.y); s1.z = fmaf(t, c.z, s1.z); s1.w = fmaf(t, c.w, s1.w);
             prev = c;
           }
         } else {
@@ -769,8 +792,8 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
             xa = x0 - r_tap + j + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
             const float4 c = *(const float4 *)(Sl + xa * R);
             t = tap[j];
-            s0.x += t * prev.x; s0.y += t * prev.y; s0.z += t * prev.z; s0.w += t * prev.w;
-            s1.x += t * c.x; s1.y += t * c.y; s1.z += t * c.z; s1.w += t * c.w;
+            s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
+            s1.x = fmaf(t, c.x, s1.x); s1.y = fmaf(t, c.y, s1.y); s1.z = fmaf(t, c.z, s1.z); s1.w = fmaf(t, c.w, s1.w);
             prev = c;
           }
         }

@@ -67,7 +67,8 @@ __device__ __forceinline__ int reflect101_dev(int p, int len) {
 struct SmallTaps { float k[32]; int n; };   // n <= 31 taps
 
 // Row pass of cv::GaussianBlur with BORDER_REFLECT_101: n <= 5 -> symmetric small filter order
-// (centre, then pairs outwards); larger -> generic left-to-right order.
+// (centre, then pairs outwards); larger -> generic left-to-right order.  Fused multiply-adds as an FMA build of OpenCV
+// has them (the contract shared with the oracle, see pyramid.hip).
 __global__ void __launch_bounds__(256) blur_row_reflect_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h, SmallTaps t) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= w || y >= h) return;
@@ -76,25 +77,25 @@ __global__ void __launch_bounds__(256) blur_row_reflect_kernel(const float *__re
   float s;
   if (t.n <= 5) {
     s = S[x] * t.k[r];
-    for (int j = 1; j <= r; j++) s += (S[reflect101_dev(x - j, w)] + S[reflect101_dev(x + j, w)]) * t.k[r + j];
+    for (int j = 1; j <= r; j++) s = fmaf(S[reflect101_dev(x - j, w)] + S[reflect101_dev(x + j, w)], t.k[r + j], s);
   } else {
     s = t.k[0] * S[reflect101_dev(x - r, w)];
-    for (int j = 1; j < t.n; j++) s += t.k[j] * S[reflect101_dev(x - r + j, w)];
+    for (int j = 1; j < t.n; j++) s = fmaf(t.k[j], S[reflect101_dev(x - r + j, w)], s);
   }
   dst[(size_t)y * w + x] = s;
 }
 
-// Column pass: n == 3 -> (S0 + S2)*f1 + S1*f0 (small symmetric column filter); otherwise centre first, then pairs.
+// Column pass: n == 3 -> fma(S0 + S2, f1, S1*f0) (small symmetric column filter); otherwise centre first, then pairs.
 __global__ void __launch_bounds__(256) blur_col_reflect_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h, SmallTaps t) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= w || y >= h) return;
   const int r = t.n / 2;
   float s;
   if (t.n == 3) {
-    s = (src[(size_t)reflect101_dev(y - 1, h) * w + x] + src[(size_t)reflect101_dev(y + 1, h) * w + x]) * t.k[2] + src[(size_t)y * w + x] * t.k[1];
+    s = fmaf(src[(size_t)reflect101_dev(y - 1, h) * w + x] + src[(size_t)reflect101_dev(y + 1, h) * w + x], t.k[2], src[(size_t)y * w + x] * t.k[1]);
   } else {
     s = t.k[r] * src[(size_t)y * w + x];
-    for (int j = 1; j <= r; j++) s += t.k[r + j] * (src[(size_t)reflect101_dev(y + j, h) * w + x] + src[(size_t)reflect101_dev(y - j, h) * w + x]);
+    for (int j = 1; j <= r; j++) s = fmaf(t.k[r + j], src[(size_t)reflect101_dev(y + j, h) * w + x] + src[(size_t)reflect101_dev(y - j, h) * w + x], s);
   }
   dst[(size_t)y * w + x] = s;
 }
@@ -285,6 +286,8 @@ int mods_detect_describe_view_dev(mods_ctx *c, const float *src_dev, int w, int 
   if (!c->view_dev) MODS_HIP_CHECK(hipMalloc(&c->view_dev, sizeof(float) * (size_t)c->max_w * c->max_h));
   if ((rc = mods_synth_view_dev(c, src_dev, w, h, stride, &g, doBlur, c->view_dev))) return rc;
   if ((rc = pyramid_configure(c, g.w_new, g.h_new, 1, det))) return rc;
+  // DetectAffineKeypoints, scale-space-detector.cpp:20-21 (tilt, zoom = the SynthImage fields: |tilt|, zoom)
+  if (g.tilt > 2.0 || g.zoom < 0.5) c->reg_number_eff = (int)floor(g.zoom * (double)det->regionsNumber / g.tilt);
   if ((rc = pyramid_build(c, c->view_dev, g.w_new))) return rc;
   if ((rc = detect_run(c))) return rc;
   if ((rc = describe_run_view(c, c->view_dev, 1, g.w_new, g.h_new, desc, g.H, w, h, nullptr))) return rc;

@@ -157,17 +157,11 @@ def match_ladder_distributed(pkg, ctx, img_ptr, w, h, steps, dist, device, param
         laf_all, _ = allgather_ragged(laf, dist, None if dist.get_backend() == "gloo" else device)
         out = np.zeros(16, np.float64)
         if rank == 0:
-            nu = len(tent_all)
-            if params.dup_before_ransac and nu:
-                tent_u, u6_u, laf_u = pkg.duplicate_filter(tent_all, u6_all, params.dup_dist, params.dup_mode, laf_all)
-            else:
-                tent_u, u6_u, laf_u = tent_all, u6_all, laf_all
-            kw = {} if seed_time is None else {"seed_time": seed_time}
-            fn = pkg.loransac_f if params.ransac.useF else pkg.loransac_h
-            mask, Hm, ninl, stats = fn(u6_u, laf_u, params.ransac, **kw)
+            tent_v, u6_v, _, nu, Hm, stats = pkg.verify_tentatives(tent_all, u6_all, laf_all, params, device=ctx.device, seed_time=seed_time)
+            ninl = len(tent_v)
             res = dict(steps_done=si + 1, n_views=n_views, n_described=[len(rep1), len(rep2)], n_tentatives=len(tent_all),
-                       n_unique=len(tent_u), n_inliers=ninl, stats=stats, H=np.asarray(Hm).reshape(-1),
-                       matches=u6_u[mask][:, [0, 1, 3, 4]] if len(u6_u) else np.zeros((0, 4)))
+                       n_unique=nu, n_inliers=ninl, stats=stats, H=np.asarray(Hm).reshape(-1),
+                       matches=u6_v[:, [0, 1, 3, 4]] if ninl else np.zeros((0, 4)))
             out[0] = ninl
         t = torch.from_numpy(out)
         if dist.get_backend() != "gloo":

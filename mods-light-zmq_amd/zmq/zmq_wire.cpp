@@ -59,6 +59,13 @@ int mods_zmq_decode_request(const unsigned char *png, size_t len, unsigned char 
   if (!png_image_begin_read_from_memory(&img, png, len)) { set_err("png: %s", img.message); return MODS_ZMQ_E_PNG; }
   img.format = PNG_FORMAT_GRAY;          // cv2.imdecode(buf, 0): 8-bit grey whatever the file holds
   if (img.width == 0 || img.height % img.width != 0) { png_image_free(&img); set_err("request image %ux%u is not a column of square patches", img.width, img.height); return MODS_ZMQ_E_PNG; }
+  // the protocol sends at most MODS_ZMQ_MAX_PATCHES patches per request (imagerepresentation.cpp:27-61); anything larger is
+  // refused before a byte of it is decompressed (decompression bombs, absurd patch sizes)
+  if (img.width > MODS_ZMQ_MAX_PATCH_SIZE || img.height / img.width > MODS_ZMQ_MAX_PATCHES) {
+    set_err("request image %ux%u exceeds the protocol limits (%d patches of at most %d px)", img.width, img.height, MODS_ZMQ_MAX_PATCHES, MODS_ZMQ_MAX_PATCH_SIZE);
+    png_image_free(&img);
+    return MODS_ZMQ_E_ARG;
+  }
   unsigned char *buf = (unsigned char *)malloc(PNG_IMAGE_SIZE(img));
   if (!buf || !png_image_finish_read(&img, nullptr, buf, 0, nullptr)) { free(buf); set_err("png: %s", img.message); png_image_free(&img); return MODS_ZMQ_E_PNG; }
   *pixels = buf; *ps = (int)img.width; *n = (int)(img.height / img.width);

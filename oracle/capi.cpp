@@ -3,6 +3,7 @@
 // product library.
 #include "orc.h"
 #include "detmath.h"
+#include <cmath>
 #include <cstring>
 
 using namespace orc;
@@ -19,6 +20,10 @@ struct orc_hessaff_params {     // mirrors include/mods_hip.h: mods_hessaff_para
   float convergenceThreshold;
   int smmWindowSize;
   int doBaumberg;
+  int mode;
+  float relativeThreshold;
+  int regionsNumber;
+  float relativeRegionsNumber;
 };
 
 struct orc_candidate { int octave, level, r0, c0, r, c; float x, y, s, pixelDistance, response; int type; };
@@ -30,6 +35,7 @@ static HessAffParams cvt(const orc_hessaff_params *p) {
     q.numberOfScales = p->numberOfScales; q.initialSigma = p->initialSigma; q.threshold = p->threshold;
     q.edgeEigenValueRatio = p->edgeEigenValueRatio; q.border = p->border; q.maxIterations = p->maxIterations;
     q.convergenceThreshold = p->convergenceThreshold; q.smmWindowSize = p->smmWindowSize; q.doBaumberg = p->doBaumberg;
+    q.mode = p->mode; q.rel_threshold = p->relativeThreshold; q.reg_number = p->regionsNumber; q.rel_reg_number = p->relativeRegionsNumber;
   }
   return q;
 }
@@ -39,6 +45,26 @@ static Img wrap(const float *src, int w, int h) {
   return im;
 }
 
+// experiment switches (tools/readme_count_hunt.py only); returns 0 for an unknown name
+int orc_set_variant(const char *name, int v) {
+  if (!std::strcmp(name, "kernel")) g_variant.kernel = v;
+  else if (!std::strcmp(name, "row_fma")) g_variant.row_fma = v;
+  else if (!std::strcmp(name, "col_fma")) g_variant.col_fma = v;
+  else if (!std::strcmp(name, "small_row")) g_variant.small_row = v;
+  else if (!std::strcmp(name, "resize_tail")) g_variant.resize_tail = v;
+  else if (!std::strcmp(name, "libm")) { g_variant.libm = v; g_libm_variant = v; }
+  else return 0;
+  return 1;
+}
+// (B + G + R) / 3.0 of GenerateSynthImageCorr (synth-detection.cpp:343-354) on interleaved 8-bit RGB: the MatExpr becomes
+// addWeighted(B + G, 1/3, R, 1/3, 0) with float weights; an FMA build of OpenCV evaluates fma(B + G, a, R * a), a = (float)(1/3.).
+void orc_grey_of_rgb(const unsigned char *rgb, long n, float *out) {
+  const float a = (float)(1.0 / 3.0);
+  for (long i = 0; i < n; i++) {
+    const float bg = (float)rgb[3 * i + 2] + (float)rgb[3 * i + 1], r = (float)rgb[3 * i];
+    out[i] = std::fmaf(bg, a, r * a);
+  }
+}
 int orc_gauss_ksize(float sigma) { return gauss_ksize(sigma); }
 void orc_gauss_kernel(int n, double sigma, float *out) {
   std::vector<float> k = gauss_kernel(n, sigma);

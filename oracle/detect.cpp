@@ -79,6 +79,7 @@ struct Thresholds {
     positiveThreshold = (float)(0.8 * finalThreshold);
     negativeThreshold = -positiveThreshold;
     finalThreshold = p.threshold * p.threshold;
+    if (p.mode != 0) finalThreshold = positiveThreshold = negativeThreshold = 0.0f;   // pyramid.h:58-59: every mode but FIXED_TH
   }
 };
 
@@ -244,7 +245,7 @@ static void rectify_transformation(double &a11, double &a12, double &a21, double
 // findAffineShape on prevBlur (= blur level-1 of the detection level, pyramid.cpp:402,478) ->
 // exportKeypoints: sort by |response| descending (scale-space-detector.hpp:120-131; std::sort is
 // unstable on ties, fixed here as processing order) -> DetectAffineRegions
-// (synth-detection.hpp:79-112): s *= sqrt|det A|, A -> lower-triangular det 1.  FIXED_TH mode.
+// (synth-detection.hpp:79-112): s *= sqrt|det A|, A -> lower-triangular det 1.
 void detect_hessian_affine(const Img &image, const HessAffParams &p, std::vector<AffKey> &out) {
   Pyramid pyr;
   build_pyramid(image, p, pyr);
@@ -267,6 +268,32 @@ void detect_hessian_affine(const Img &image, const HessAffParams &p, std::vector
   }
   std::stable_sort(keys.begin(), keys.end(),
                    [](const AffKey &k1, const AffKey &k2) { return std::fabs(k1.response) > std::fabs(k2.response); });
+  // AffineDetector::prepareKeysForExport, scale-space-detector.hpp:126-198: the sorted list is cut as the mode says
+  if (p.mode != 0 && !keys.empty()) {
+    const int regNumber = (int)keys.size();
+    auto above = [&](double thr) {      // std::lower_bound(keys, tempKey, responseCompareInvOrder): #{|response| > |thr|}
+      int m = 0;
+      while (m < regNumber && std::fabs(keys[m].response) > std::fabs(thr)) m++;
+      return m;
+    };
+    int keep = regNumber;
+    switch (p.mode) {
+      case 1: {                                                       // RELATIVE_TH
+        const float effectiveThreshold = (float)(std::fabs(keys[0].response) * p.rel_threshold);   // float member, pyramid.h:74
+        keep = above((double)effectiveThreshold);
+        break;
+      }
+      case 2: keep = std::min(regNumber, p.reg_number); break;       // FIXED_REG_NUMBER (the 3x Baumberg margin is cut again at :193-194)
+      case 3: keep = (int)std::floor(p.rel_reg_number * (double)regNumber); break;   // RELATIVE_REG_NUMBER
+      case 4: {                                                       // NOT_LESS_THAN_REGIONS (threshold un-squared, as written)
+        const int fixTh = above((double)p.threshold);
+        keep = fixTh < p.reg_number ? std::min(p.reg_number, regNumber) : std::min(fixTh, regNumber);
+        break;
+      }
+    }
+    if (keep < 0) keep = 0;
+    if (keep < regNumber) keys.resize(keep);
+  }
   out.clear();
   out.reserve(keys.size());
   for (size_t i = 0; i < keys.size(); i++) {

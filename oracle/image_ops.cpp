@@ -11,6 +11,12 @@ namespace orc {
 static const double g_atan_lut[256] = ORC_ATAN_LUT_INIT;
 const double *atan_lut() { return g_atan_lut; }
 
+// Rounding variants of the OpenCV-dependent primitives (tools/readme_count_hunt.py).  The defaults (orc.h) are the
+// contract stated in DESIGN.md - the reading that reproduces the reference's README counts; the other values are
+// alternative readings of what an OpenCV build may do, kept so that the script can reproduce its table.
+Variant g_variant;
+int g_libm_variant = 0;
+
 // detectors/helpers.cpp:720-721 / 728-729
 int gauss_ksize(float sigma) {
   int size = (int)(2.0 * 3.0 * sigma + 1.0);
@@ -22,43 +28,55 @@ int gauss_ksize(float sigma) {
 // double, stored as float, normalised by the double sum of the float taps.  exp -> det_exp.
 std::vector<float> gauss_kernel(int n, double sigma) {
   std::vector<float> k(n);
+  std::vector<double> kd(n);
   double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
   double scale2X = -0.5 / (sigmaX * sigmaX);
   double sum = 0;
   for (int i = 0; i < n; i++) {
     double x = i - (n - 1) * 0.5;
-    double t = det_exp(scale2X * x * x);
-    k[i] = (float)t;
-    sum += k[i];
+    double t = g_variant.libm ? std::exp(scale2X * x * x) : det_exp(scale2X * x * x);
+    if (g_variant.kernel == 0) { k[i] = (float)t; sum += k[i]; }
+    else { kd[i] = t; sum += t; }
   }
+  if (g_variant.kernel == 2) { for (int i = 0; i < n; i++) k[i] = (float)(kd[i] / sum); return k; }   // one division per tap
   sum = 1. / sum;
-  for (int i = 0; i < n; i++) k[i] = (float)(k[i] * sum);
+  for (int i = 0; i < n; i++) k[i] = g_variant.kernel == 0 ? (float)(k[i] * sum) : (float)(kd[i] * sum);
   return k;
 }
 
 // cv::GaussianBlur(src, dst, Size(n,n), sigma, sigma, BORDER_REPLICATE) on CV_32F
-// (helpers.cpp:717-731) = sepFilter2D with a float intermediate.
-//   row pass    : generic RowFilter order   s = k[0]*S[x-r]; s += k[j]*S[x-r+j], j = 1..n-1
-//   column pass : SymmColumnFilter order    s = k[r]*T[y];   s += k[r+j]*(T[y+j] + T[y-j]), j = 1..r
-// fp32 throughout, one rounding per operation.  (OpenCV's SIMD paths may fuse or reorder;
-// the reference pins no OpenCV build => parity unpinned, order fixed here.)
+// (helpers.cpp:717-731) = sepFilter2D with a float intermediate, evaluated as an FMA build of OpenCV does
+// (v_muladd / _mm256_fmadd_ps in the row and column filters).  Of the readings tried by tools/readme_count_hunt.py
+// this is the one that reproduces the reference's README counts exactly (2665/2331, 3287/2912); DESIGN.md has the table.
+//   row pass, n > 5  : RowFilter order          s = k[0]*S[x-r]; s = fma(k[j], S[x-r+j], s), j = 1..n-1
+//   row pass, n <= 5 : SymmRowSmallFilter order s = k[r]*S[x];   s = fma(S[x-j] + S[x+j], k[r+j], s), j = 1..r
+//   column pass      : SymmColumnFilter order   s = k[r]*T[y];   s = fma(k[r+j], T[y+j] + T[y-j], s), j = 1..r
+// fp32 throughout.  g_variant.row_fma / col_fma = 0 give the unfused (two roundings) form for the hunt script.
 void gauss_blur(const Img &src, Img &dst, float sigma) {
   const int n = gauss_ksize(sigma);
   const int r = n / 2;
   const std::vector<float> k = gauss_kernel(n, (double)sigma);
   const int w = src.w, h = src.h;
+  const bool rf = g_variant.row_fma != 0, cf = g_variant.col_fma != 0;
+  auto cl = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
   Img tmp(w, h);
   for (int y = 0; y < h; y++) {
     const float *S = src.row(y);
     float *T = tmp.row(y);
     for (int x = 0; x < w; x++) {
-      int x0 = x - r; if (x0 < 0) x0 = 0;
-      float s = k[0] * S[x0];
-      for (int j = 1; j < n; j++) {
-        int xx = x - r + j;
-        if (xx < 0) xx = 0;
-        if (xx > w - 1) xx = w - 1;
-        s += k[j] * S[xx];
+      float s;
+      if (n <= 5 && g_variant.small_row) {
+        s = S[x] * k[r];
+        for (int j = 1; j <= r; j++) {
+          const float pr = S[cl(x - j, w - 1)] + S[cl(x + j, w - 1)];
+          s = rf ? std::fmaf(pr, k[r + j], s) : s + pr * k[r + j];
+        }
+      } else {
+        s = k[0] * S[cl(x - r, w - 1)];
+        for (int j = 1; j < n; j++) {
+          const float v = S[cl(x - r + j, w - 1)];
+          s = rf ? std::fmaf(k[j], v, s) : s + k[j] * v;
+        }
       }
       T[x] = s;
     }
@@ -69,9 +87,8 @@ void gauss_blur(const Img &src, Img &dst, float sigma) {
     for (int x = 0; x < w; x++) {
       float s = k[r] * tmp.at(y, x);
       for (int j = 1; j <= r; j++) {
-        int yp = y + j; if (yp > h - 1) yp = h - 1;
-        int ym = y - j; if (ym < 0) ym = 0;
-        s += k[r + j] * (tmp.at(yp, x) + tmp.at(ym, x));
+        const float pr = tmp.at(cl(y + j, h - 1), x) + tmp.at(cl(y - j, h - 1), x);
+        s = cf ? std::fmaf(k[r + j], pr, s) : s + k[r + j] * pr;
       }
       D[x] = s;
     }
@@ -105,7 +122,11 @@ void resize_half(const Img &src, Img &dst) {
     for (; dx < wfull; dx++) {
       const float *S0 = src.row(sy0) + 2 * dx;
       const float *S1 = src.row(sy0 + 1) + 2 * dx;
-      D[dx] = ((S0[0] + S0[1]) + (S1[0] + S1[1])) * 0.25f;
+      // resize_tail = L: the last wfull % L outputs of a row come from the scalar loop (running sum of the block)
+      if (g_variant.resize_tail > 0 && dx >= wfull - wfull % g_variant.resize_tail)
+        D[dx] = (((S0[0] + S0[1]) + S1[0]) + S1[1]) * 0.25f;
+      else
+        D[dx] = ((S0[0] + S0[1]) + (S1[0] + S1[1])) * 0.25f;
     }
     for (; dx < dw; dx++) {
       const int sx0 = dx * 2;

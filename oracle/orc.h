@@ -25,6 +25,10 @@ struct Img {
   float at(int y, int x) const { return d[(size_t)y * w + x]; }
 };
 
+// experiment switches of the unpinned OpenCV arithmetic (the defaults are the contract; see image_ops.cpp)
+struct Variant { int kernel = 0, row_fma = 1, col_fma = 1, small_row = 1, resize_tail = 0, libm = 0; };
+extern Variant g_variant;
+
 // ---- image primitives (image_ops.cpp) -------------------------------------------------
 int gauss_ksize(float sigma);                                  // detectors/helpers.cpp:720-721
 std::vector<float> gauss_kernel(int n, double sigma);          // OpenCV getGaussianKernel, CV_32F
@@ -70,6 +74,10 @@ struct HessAffParams {          // PyramidParams + AffineShapeParams, detectors/
   float convergenceThreshold = 0.05f;
   int smmWindowSize = 19;
   int doBaumberg = 1;
+  int mode = 0;                 // detection_mode_t (structures.hpp:10-14): 0 FIXED_TH, 1 RELATIVE_TH, 2 FIXED_REG_NUMBER,
+  float rel_threshold = -1;     //   3 RELATIVE_REG_NUMBER, 4 NOT_LESS_THAN_REGIONS; defaults of PyramidParams (:138-150)
+  int reg_number = -1;
+  float rel_reg_number = -1;
 };
 
 struct Candidate {              // one accepted pyramid keypoint before affine adaptation

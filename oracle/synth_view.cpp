@@ -84,10 +84,11 @@ static inline int reflect101(int p, int len) {
 }
 
 // cv::GaussianBlur(img, img, Size(kx,ky), sx, sy) with the default BORDER_REFLECT_101, kx, ky in {3, 5}
-// (synth-detection.cpp:499).  Row pass: SymmRowSmallFilter  s = S[0]*k0 + (S[-1]+S[1])*k1 [+ (S[-2]+S[2])*k2];
-// column pass: ksize 3 -> SymmColumnSmallFilter  s = (S0+S2)*f1 + S1*f0;  ksize 5 -> SymmColumnFilter
-// s = f0*S[0]; s += f1*(S[1]+S[-1]); s += f2*(S[2]+S[-2]).  Larger (odd) sizes follow the generic orders
-// used by gauss_blur() in image_ops.cpp.
+// (synth-detection.cpp:499), fused like gauss_blur() in image_ops.cpp (an FMA build of OpenCV).  Row pass:
+// SymmRowSmallFilter  s = S[0]*k0; s = fma(S[-1]+S[1], k1, s) [; s = fma(S[-2]+S[2], k2, s)];
+// column pass: ksize 3 -> SymmColumnSmallFilter  s = fma(S0+S2, f1, S1*f0);  ksize 5 -> SymmColumnFilter
+// s = f0*S[0]; s = fma(f1, S[1]+S[-1], s); s = fma(f2, S[2]+S[-2], s).  Larger (odd) sizes follow the generic
+// orders used by gauss_blur().
 void gauss_blur_xy(const Img &src, Img &dst, int kx, int ky, double sx, double sy) {
   const std::vector<float> kxv = gauss_kernel(kx, sx), kyv = gauss_kernel(ky, sy);
   const int w = src.w, h = src.h, rx = kx / 2, ry = ky / 2;
@@ -99,10 +100,10 @@ void gauss_blur_xy(const Img &src, Img &dst, int kx, int ky, double sx, double s
       float s;
       if (kx <= 5) {
         s = S[x] * kxv[rx];
-        for (int j = 1; j <= rx; j++) s += (S[reflect101(x - j, w)] + S[reflect101(x + j, w)]) * kxv[rx + j];
+        for (int j = 1; j <= rx; j++) s = std::fmaf(S[reflect101(x - j, w)] + S[reflect101(x + j, w)], kxv[rx + j], s);
       } else {
         s = kxv[0] * S[reflect101(x - rx, w)];
-        for (int j = 1; j < kx; j++) s += kxv[j] * S[reflect101(x - rx + j, w)];
+        for (int j = 1; j < kx; j++) s = std::fmaf(kxv[j], S[reflect101(x - rx + j, w)], s);
       }
       T[x] = s;
     }
@@ -113,10 +114,10 @@ void gauss_blur_xy(const Img &src, Img &dst, int kx, int ky, double sx, double s
     for (int x = 0; x < w; x++) {
       float s;
       if (ky == 3) {
-        s = (tmp.at(reflect101(y - 1, h), x) + tmp.at(reflect101(y + 1, h), x)) * kyv[2] + tmp.at(y, x) * kyv[1];
+        s = std::fmaf(tmp.at(reflect101(y - 1, h), x) + tmp.at(reflect101(y + 1, h), x), kyv[2], tmp.at(y, x) * kyv[1]);
       } else {
         s = kyv[ry] * tmp.at(y, x);
-        for (int j = 1; j <= ry; j++) s += kyv[ry + j] * (tmp.at(reflect101(y + j, h), x) + tmp.at(reflect101(y - j, h), x));
+        for (int j = 1; j <= ry; j++) s = std::fmaf(kyv[ry + j], tmp.at(reflect101(y + j, h), x) + tmp.at(reflect101(y - j, h), x), s);
       }
       D[x] = s;
     }

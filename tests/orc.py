@@ -12,12 +12,14 @@ _lib = None
 class HessAffParams(C.Structure):
     _fields_ = [("numberOfScales", C.c_int), ("initialSigma", C.c_float), ("threshold", C.c_float),
                 ("edgeEigenValueRatio", C.c_float), ("border", C.c_int), ("maxIterations", C.c_int),
-                ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int)]
+                ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int),
+                ("mode", C.c_int), ("relativeThreshold", C.c_float), ("regionsNumber", C.c_int),
+                ("relativeRegionsNumber", C.c_float)]
 
     @staticmethod
     def default():
         # build/config_affori_classic.ini [HessianAffine]
-        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1)
+        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1, 0, -1.0, -1, -1.0)
 
 
 class Candidate(C.Structure):
@@ -66,6 +68,15 @@ def lib():
 def _f(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def grey_of_rgb(rgb):
+    """(B + G + R) / 3.0 of GenerateSynthImageCorr on an 8-bit RGB array [h, w, 3] the way OpenCV evaluates the expression
+    (fma(B + G, a, R * a), a = (float)(1/3.); see oracle/capi.cpp)."""
+    a = np.ascontiguousarray(rgb[..., :3], dtype=np.uint8)
+    out = np.empty(a.shape[:2], np.float32)
+    lib().orc_grey_of_rgb(a.ctypes.data_as(C.c_void_p), C.c_long(a.shape[0] * a.shape[1]), out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 def gauss_ksize(sigma):

@@ -1,9 +1,34 @@
 """CPU oracle for the whole pair path (test infrastructure): restated detect/describe/match/duplicate
 filter + RANSAC from the reference's own degensac (oracle/_ref) when it is built."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 import orc
 import refdeg
+
+
+def pmap(fn, items, threads=None):
+    """Independent oracle calls side by side (ctypes releases the GIL; the oracle keeps no state between calls)."""
+    items = list(items)
+    threads = threads or min(len(items), os.cpu_count() or 1, 16)
+    if threads <= 1:
+        return [fn(x) for x in items]
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(fn, items))
+
+
+def match_fginn_par(ra, rb, ratio=0.8, contrad=10.0, nn=50, chunks=None):
+    """orc.match_fginn with the queries split over threads (every query is searched on its own); same list, same order."""
+    chunks = chunks or max(1, min(os.cpu_count() or 1, 16, len(ra) // 512))
+    cuts = [len(ra) * i // chunks for i in range(chunks + 1)]
+
+    def part(i):
+        tc = orc.match_fginn(ra[cuts[i]:cuts[i + 1]], rb, ratio, contrad, nn)
+        tc["q"] += cuts[i]
+        return tc
+    return np.concatenate(pmap(part, range(chunks)))
 
 
 def laf_of(ra, rb, tc):
@@ -133,18 +158,27 @@ def loransac_f(u6, laf, err_threshold=4.0, conf=0.99, max_samples=1000000, laf_c
     return mask, F, len(good), stats
 
 
-def match_pair(img1, img2, seed_time=12345, ratio=0.8, use_f=False):
-    ra, nd1 = orc.detect_describe(img1)
-    rb, nd2 = orc.detect_describe(img2)
-    tc = orc.match_fginn(ra, rb, ratio)
-    un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
+def match_pair(img1, img2, seed_time=12345, ratio=0.8, use_f=False, dup_before_ransac=True, regions=None):
+    """One step of mods.cpp:202-383 on identity views.  dup_before_ransac = False: [DuplicateFiltering] doBeforeRANSAC = 0,
+    the verified list is de-duplicated after RANSAC (mods.cpp:357-368)."""
+    if regions is None:
+        (ra, nd1), (rb, nd2) = pmap(orc.detect_describe, (img1, img2))
+    else:
+        (ra, nd1), (rb, nd2) = regions
+    tc = match_fginn_par(ra, rb, ratio)
+    un = orc.duplicate_filter(tc, ra, rb, 2.0, 1) if dup_before_ransac else tc
     u6, laf = u6_of(ra, rb, un), laf_of(ra, rb, un)
     if use_f:
         mask, H, ninl, stats = loransac_f(u6, laf, seed_time=seed_time)
     else:
         mask, H, ninl, stats = loransac_h(u6, laf, seed_time=seed_time)
+    matches = u6[mask][:, [0, 1, 3, 4]]
+    if not dup_before_ransac:
+        ver = orc.duplicate_filter(un[mask], ra, rb, 2.0, 1)
+        matches = u6_of(ra, rb, ver)[:, [0, 1, 3, 4]]
+        ninl = len(ver)
     return dict(n_detected=[nd1, nd2], n_described=[len(ra), len(rb)], n_tentatives=len(tc), n_unique=len(un),
-                n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6)
+                n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6, matches=matches, regions=(ra, rb))
 
 
 def view_schedule(tilts, phi_base, history, scales=(1.0,)):
@@ -179,16 +213,19 @@ def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=
     n_views = 0
     for si, (tilts, phi_base) in enumerate(steps):
         views = view_schedule(tilts, phi_base, history)
+
+        def one_view(job):
+            img, (zoom, tilt, phi) = job
+            px, g = orc.synth_view(img, tilt, phi, zoom, init_sigma, 1)
+            if g.w_new < 16 or g.h_new < 16:
+                return None
+            return orc.detect_describe_view(px, np.array(g.H), w, h)[0]
         for im, img in enumerate((img1, img2)):
-            for (zoom, tilt, phi) in views:
-                px, g = orc.synth_view(img, tilt, phi, zoom, init_sigma, 1)
-                n_views += 1
-                if g.w_new < 16 or g.h_new < 16:
-                    continue
-                reg, _, _ = orc.detect_describe_view(px, np.array(g.H), w, h)
-                banks[im].append(reg)
+            regs = pmap(one_view, [(img, v) for v in views])      # views are independent; banks keep the view order
+            n_views += len(views)
+            banks[im] += [r for r in regs if r is not None]
         ra, rb = np.concatenate(banks[0]), np.concatenate(banks[1])
-        tc = orc.match_fginn(ra, rb, ratio)
+        tc = match_fginn_par(ra, rb, ratio)
         un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
         u6, laf = u6_of(ra, rb, un), laf_of(ra, rb, un)
         mask, H, ninl, stats = loransac_h(u6, laf, seed_time=seed_time)

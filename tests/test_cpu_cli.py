@@ -73,3 +73,41 @@ def test_npz_keypoint_files_round_trip_with_numpy(tmp_path):
     np.savez_compressed(tmp_path / "c.npz", **src)
     p = subprocess.run([MODS, "--npz-echo", str(tmp_path / "c.npz"), str(tmp_path / "o.npz")], stderr=subprocess.PIPE, timeout=60)
     assert p.returncode != 0 and b"compressed" in p.stderr
+
+
+def test_npz_reader_refuses_malformed_archives(tmp_path):
+    """A corrupt or hostile k1 / k2 .npz (pre-extracted mode) must be refused with a message: truncated central directory,
+    headers without descr / shape, sizes that overflow, payloads shorter than the shape claims."""
+    import numpy as np
+    src = {"xy": np.arange(12, dtype=np.float64).reshape(6, 2), "descs": np.arange(6 * 128, dtype=np.uint8).reshape(6, 128)}
+    np.savez(tmp_path / "ok.npz", **src)
+    good = (tmp_path / "ok.npz").read_bytes()
+
+    def echo(data):
+        (tmp_path / "bad.npz").write_bytes(data)
+        p = subprocess.run([MODS, "--npz-echo", str(tmp_path / "bad.npz"), str(tmp_path / "o.npz")], stderr=subprocess.PIPE, timeout=60)
+        return p.returncode, p.stderr.decode()
+
+    rc, _ = echo(good)
+    assert rc == 0
+    cases = {
+        "descr": good.replace(b"'descr'", b"'dexcr'"),
+        "shape": good.replace(b"'shape'", b"'shxpe'"),
+        "paren": good.replace(b"(6, 2)", b" 6, 2 "),
+        "huge": good.replace(b"(6, 2)", b"(9, 9)"),                      # payload shorter than the shape claims
+        "overflow": good.replace(b"(6, 128), }", b"(99999999999, 99999999999), }"[:len(b"(6, 128), }")]),
+    }
+    for name, data in cases.items():
+        assert len(data) == len(good), name
+        rc, err = echo(data)
+        assert rc not in (0, -11, -6) and rc > 0 and err.strip(), (name, rc, err)      # refused with a message, no crash
+    # central directory entry whose name length runs past the end of the file
+    cd = good.rfind(b"PK\x01\x02")
+    data = bytearray(good)
+    data[cd + 28:cd + 30] = (60000).to_bytes(2, "little")
+    rc, err = echo(bytes(data))
+    assert rc > 0 and "central directory" in err
+    # every truncation of the archive is refused, none crashes
+    for cut in range(0, len(good) - 1, 37):
+        rc, _ = echo(good[:cut])
+        assert rc > 0, cut

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 from PIL import Image
 
+import orc
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODS = os.path.join(ROOT, "mods-light-zmq_amd", "mods")
@@ -15,8 +17,7 @@ G1, G6 = (os.path.join(ROOT, "tests", "golden", n) for n in ("graf1.png", "graf6
 
 
 def _grey(fn):
-    a = np.asarray(Image.open(fn).convert("RGB"), np.float32)
-    return ((a[:, :, 2] + a[:, :, 1]) + a[:, :, 0]) / np.float32(3.0)     # (B + G + R) / 3
+    return orc.grey_of_rgb(np.asarray(Image.open(fn).convert("RGB")))     # (B + G + R) / 3.0 as OpenCV evaluates it
 
 
 def _run(tmp_path, iters, ver_type="0"):
@@ -57,9 +58,9 @@ def test_cli_one_view_matches_library_and_readme(pkg, tmp_path):
     assert len(log) == 7
     assert [int(log[1]), int(log[2]), int(log[4]), int(log[5]), int(log[6])] == [res.n_inliers, res.n_unique, res.n_unoriented[0],
                                                                               res.n_unoriented[1], 1]
-    # reference README (graf1-graf6, classic config): 2665 / 3287 regions, 2331 / 2912 descriptors (+-2 here: OpenCV unpinned)
-    assert abs(res.n_unoriented[0] - 2665) <= 3 and abs(res.n_unoriented[1] - 3287) <= 3
-    assert abs(res.n_described[0] - 2331) <= 3 and abs(res.n_described[1] - 2912) <= 3
+    # reference README (graf1-graf6, classic config): 2665 / 3287 regions, 2331 / 2912 descriptors
+    assert (res.n_unoriented[0], res.n_unoriented[1]) == (2665, 3287)
+    assert (res.n_described[0], res.n_described[1]) == (2331, 2912)
     H = np.loadtxt(tmp_path / "H.txt")
     assert H.shape == (3, 3) and np.allclose(H, np.array(res.H).reshape(3, 3), rtol=1e-4, atol=1e-6)
     for fn, r in (("k1.txt", regs[0]), ("k2.txt", regs[1])):

@@ -62,8 +62,7 @@ def test_detect_graf(gpu_ctx):
     from PIL import Image
     import os
     p = os.path.join(os.path.dirname(__file__), "golden", "graf1.png")
-    im = np.asarray(Image.open(p)).astype(np.float32)
-    g = (((im[..., 2] + im[..., 1]) + im[..., 0]) / np.float32(3.0)).astype(np.float32)
+    g = orc.grey_of_rgb(np.asarray(Image.open(p).convert("RGB")))
     _assert_keys_equal(gpu_ctx.detect_hessian_affine(g), orc.detect_hessian_affine(g))
 
 
@@ -105,4 +104,40 @@ def test_small_and_odd_sizes_end_to_end(pkg, w, h):
     assert len(regs) == len(wr)
     if len(wr):
         assert np.array_equal(regs["desc"], wr["desc"]) and np.array_equal(regs["x"], wr["x"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_keypoint_selection_modes(pkg, mode):
+    """[HessianAffine] mode = RelativeTh / FixedRegNumber / RelativeRegNumber / NotLessThanRegions
+    (AffineDetector::prepareKeysForExport, scale-space-detector.hpp:126-198): in these modes the detector's thresholds are 0
+    (pyramid.h:58-59), every 3x3x3 extremum is localised and adapted, and the sorted list is cut."""
+    import orc
+    import synth
+    w, h = 400, 300
+    img = synth.texture(w, h, seed=11)
+    ctx = pkg.Context(0, w, h, 1)
+    for reg, rel_th, rel_n in ((300, 0.02, 0.25), (5000, 0.5, 1.0), (0, 0.0, 0.0)):
+        po, pg = orc.HessAffParams.default(), pkg.HessAffParams.default()
+        for p in (po, pg):
+            p.mode, p.relativeThreshold, p.regionsNumber, p.relativeRegionsNumber = mode, rel_th, reg, rel_n
+        want = orc.detect_hessian_affine(img, po)
+        keys = ctx.detect_hessian_affine(img, pg)
+        assert len(keys) == len(want), (mode, reg, rel_th, rel_n)
+        for f in ("x", "y", "s", "a11", "a12", "a21", "a22", "response", "sub_type"):
+            assert np.array_equal(keys[f], want[f]), f
+    # the selection applies to whole-pair calls too (counts feed the describe stage on the device)
+    po, pg = orc.HessAffParams.default(), pkg.HessAffParams.default()
+    for p in (po, pg):
+        p.mode, p.relativeThreshold, p.regionsNumber, p.relativeRegionsNumber = mode, 0.02, 300, 0.25
+    wr, nd = orc.detect_describe(img, po)
+    import torch
+    t = torch.from_numpy(img).cuda()
+    got_nd, got_nr = ctx.detect_describe_dev(t.data_ptr(), 1, w, h, pg)
+    assert got_nd[0] == nd and got_nr[0] == len(wr)
+    assert np.array_equal(ctx.regions_fetch(0)["desc"], wr["desc"])
+    bad = pkg.HessAffParams.default()
+    bad.mode = 2                      # regionsNumber = -1: the reference would resize its list to (size_t)-1
+    with pytest.raises(Exception):
+        ctx.detect_hessian_affine(img, bad)
     ctx.close()

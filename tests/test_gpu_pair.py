@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("w,h,seed", [(800, 600, 3), (1280, 960, 5)])
+@pytest.mark.parametrize("w,h,seed", [(800, 600, 3), (1280, 960, 5), (1920, 1080, 2000)])   # the last: BASELINE configs[1], the benchmark's first pair
 def test_pair_end_to_end(pkg, w, h, seed):
     import torch
     import pipeline_oracle as po
@@ -31,6 +31,68 @@ def test_pair_end_to_end(pkg, w, h, seed):
     # and the recovered homography is the generating one
     assert np.max(np.abs(Hg / Hg[2, 2] - Htrue) / np.maximum(1.0, np.abs(Htrue))) < 5e-2
     ctx.close()
+
+
+@pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built")
+def test_pair_duplicates_after_ransac(pkg):
+    """[DuplicateFiltering] doBeforeRANSAC = 0: RANSAC runs on every tentative and the verified list is de-duplicated
+    afterwards (mods.cpp:357-368); the count that drives the minMatches stop is the de-duplicated one."""
+    import torch
+    import pipeline_oracle as po
+    w, h = 800, 600
+    a, b, _ = synth.pair(w, h, seed=3)
+    want = po.match_pair(a, b, seed_time=777, dup_before_ransac=False)
+    ctx = pkg.Context(0, w, h, 2)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    par.dup_before_ransac = 0
+    pkg.ransac_pin_seed(777)
+    res, m = pkg.match_pair_dev(ctx, t.data_ptr(), w, h, par, max_matches=100000)
+    assert res.n_tentatives == want["n_tentatives"] == res.n_unique          # nothing filtered before RANSAC
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] < int(want["mask"].sum())      # duplicates did leave the verified list
+    assert np.array_equal(m, want["matches"])
+    ctx.close()
+
+
+@pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built")
+def test_pair_4096_epipolar(pkg):
+    """BASELINE configs[4]: one 4096 x 4096 pair (9 octaves, ~50 k keypoints per image) through detect, describe, the
+    exact FGINN search and DEGENSAC, every stage against the CPU oracle chain."""
+    import torch
+    import pipeline_oracle as po
+    w = h = 4096
+    a = synth.texture(w, h, 5000, blobs=30000)
+    Hm = synth.random_homography(np.random.default_rng(5000 + 104729), w, h)
+    b = synth.warp(a, Hm, seed=5000)
+    want = po.match_pair(a, b, seed_time=4096, use_f=True)
+    ctx = pkg.Context(0, w, h, 2)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    par.ransac.useF = 1
+    pkg.ransac_pin_seed(4096)
+    res, m = pkg.match_pair_dev(ctx, t.data_ptr(), w, h, par, max_matches=1 << 20)
+    assert list(res.n_detected) == want["n_detected"] and list(res.n_described) == want["n_described"]
+    assert min(res.n_described) > 30000
+    for i in (0, 1):
+        got, exp = ctx.regions_fetch(i), want["regions"][i]
+        for f in ("x", "y", "s", "a11", "a12", "a21", "a22"):
+            assert np.array_equal(got[f], exp[f]), (i, f)
+        assert np.array_equal(got["desc"], exp["desc"]), i
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] > 1000
+    assert np.array_equal(m, want["matches"])
+    Fg, Fw = np.array(res.H), np.asarray(want["H"])
+    Fg, Fw = Fg / np.linalg.norm(Fg), Fw / np.linalg.norm(Fw)
+    if np.dot(Fg, Fw) < 0:
+        Fg = -Fg
+    assert np.max(np.abs(Fg - Fw)) < 1e-6
+    ctx.close()
+    del t
+    torch.cuda.empty_cache()
 
 
 def test_pair_no_overlap(pkg):

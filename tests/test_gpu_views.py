@@ -110,7 +110,11 @@ def test_view_schedule_counts(pkg):
     assert po.view_schedule((1, 2, 4, 6, 8), 120.0, h2) == hist[11:]
 
 
-def test_ladder_matches_oracle(pkg):
+@pytest.mark.parametrize("w,h,steps_spec", [
+    (480, 360, [((1,), 360.0), ((1, 2, 4), 360.0), ((1, 2, 4), 120.0)]),
+    # the HessianAffine steps of build/iters_MODS.ini: TiltSet 1 2 4 6 8, Phi 360 then 120 (11 + 20 new views per image)
+    (640, 480, [((1, 2, 4, 6, 8), 360.0), ((1, 2, 4, 6, 8), 120.0)])])
+def test_ladder_matches_oracle(pkg, w, h, steps_spec):
     """The step loop on a pair that the identity view alone cannot match: same views, same accumulated regions,
     same tentatives, same inlier set as the CPU oracle chain."""
     import torch
@@ -118,9 +122,7 @@ def test_ladder_matches_oracle(pkg):
     import refdeg
     if not refdeg.available():
         pytest.skip("oracle/_ref not built")
-    w, h = 480, 360
     a, b, Htrue = _hard_pair(w, h, seed=21)
-    steps_spec = [((1,), 360.0), ((1, 2, 4), 360.0), ((1, 2, 4), 120.0)]
     want = po.match_ladder(a, b, steps_spec, seed_time=31)
     d = pkg.view_ctx_dims(w, h)
     ctx = pkg.Context(0, d[0], d[1], 1)
@@ -130,7 +132,8 @@ def test_ladder_matches_oracle(pkg):
     pkg.ransac_pin_seed(31)
     steps = [pkg.LadderStep.make(tl, ph) for tl, ph in steps_spec]
     res, m = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2, max_matches=100000)
-    assert res.steps_done == want["steps_done"] and res.steps_done >= 2      # the identity view alone must fail
+    assert res.steps_done == want["steps_done"]
+    assert res.steps_done >= 2 or len(steps_spec) == 2                       # first case: the identity view alone must fail
     assert res.n_views == want["n_views"]
     assert list(res.n_described) == want["n_described"] == [len(rep1), len(rep2)]
     ra, rb = rep1.fetch(), rep2.fetch()
