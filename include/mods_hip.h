@@ -396,6 +396,8 @@ int mods_match_ladder_dev(mods_ctx *ctx, const float *img1_dev, int w1, int h1, 
 int mods_match_verify_reps(mods_ctx *ctx, mods_imgrep *rep1, mods_imgrep *rep2, double fginn_ratio, const mods_pair_params *par,
                            mods_ladder_result *res, double *matches_out, int max_matches);
 /* plain device-memory helpers for callers that do not link a HIP runtime themselves (the mods CLI) */
+int mods_host_alloc(size_t bytes, void **out);     /* pinned host memory */
+int mods_host_free(void *p);
 int mods_dev_alloc(size_t bytes, void **out);
 int mods_dev_free(void *p);
 int mods_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
@@ -418,6 +420,11 @@ int mods_pipeline_capacity(const mods_pipeline *p);    /* pairs that may be in f
 int mods_pipeline_timing_enable(mods_pipeline *p, int stage_mask);
 int mods_pipeline_timing_read(mods_pipeline *p, int stage, double *total_ms, int *launches, double *bytes);
 int mods_pipeline_submit(mods_pipeline *p, const float *img_dev, long tag);
+/* the pair in HOST memory, [2][h][w] fp32 or 8-bit grey (what cv::imread hands to the ImageRepresentation constructor,
+ * mods.cpp:111-121, 184-185): uploaded on the worker's stream (asynchronously when the memory is pinned, see
+ * mods_host_alloc); the memory must stay valid until the pair's result has been fetched */
+int mods_pipeline_submit_host(mods_pipeline *p, const float *img_host, long tag);
+int mods_pipeline_submit_host_u8(mods_pipeline *p, const unsigned char *img_host, long tag);
 int mods_pipeline_next(mods_pipeline *p, mods_pair_result *res, long *tag);
 void mods_pipeline_destroy(mods_pipeline *p);
 

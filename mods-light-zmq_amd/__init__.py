@@ -650,6 +650,24 @@ def match_pair_dev(ctx, dev_ptr, w, h, params=None, max_matches=0):
     return res, m[:min(res.n_inliers, max_matches)]
 
 
+class PinnedBuffer:
+    """Page-locked host memory (mods_host_alloc) viewed as a numpy array: uploads from it are asynchronous."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = C.c_void_p()
+        _check(lib().mods_host_alloc(C.c_size_t(self.nbytes), C.byref(self.ptr)))
+        buf = (C.c_char * self.nbytes).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            lib().mods_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+
 class Pipeline:
     """mods_pipeline_*: GPU workers (detect/describe/match) overlapped with verify workers (duplicate
     filter + LO-RANSAC) across pairs; results in submission order."""
@@ -663,6 +681,11 @@ class Pipeline:
 
     def submit(self, dev_ptr, tag=0):
         _check(lib().mods_pipeline_submit(self.h, C.c_void_p(dev_ptr), C.c_long(tag)))
+
+    def submit_host(self, host_ptr, tag=0, u8=False):
+        """The pair in host memory ([2][h][w] fp32, or 8-bit grey with u8=True): uploaded on the worker's stream."""
+        fn = lib().mods_pipeline_submit_host_u8 if u8 else lib().mods_pipeline_submit_host
+        _check(fn(self.h, C.c_void_p(host_ptr), C.c_long(tag)))
 
     def next(self):
         res, tag = PairResult(), C.c_long()

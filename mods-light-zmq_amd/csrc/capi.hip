@@ -113,7 +113,7 @@ void mods_ctx_destroy(mods_ctx *c) {
     for (auto &p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &e : t.pool) (void)hipEventDestroy(e);
   }
-  (void)hipFree(c->pyr_dev); (void)hipFree(c->plane_pool); (void)hipFree(c->omap_pool); (void)hipFree(c->input_dev);
+  (void)hipFree(c->pyr_dev); (void)hipFree(c->plane_pool); (void)hipFree(c->omap_pool); (void)hipFree(c->input_dev); (void)hipFree(c->u8_stage_dev);
   (void)hipFree(c->tmp_dev); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
   (void)hipHostFree(c->host_counts);
@@ -686,22 +686,44 @@ int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int str
   return MODS_OK;
 }
 
+// 8-bit grey -> float (the ImageRepresentation constructor's convertTo(CV_32F), imagerepresentation.cpp:293-302): exact
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const unsigned char *__restrict__ src, float *__restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const uchar4 v = ((const uchar4 *)src)[i];
+    ((float4 *)dst)[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+  }
+}
+
 // GPU half of up to batch/2 pairs in one pass: the images of all pairs go through the pyramid / detector /
 // describe kernels as ONE batch (launches n times larger, the many tiny launches of the small octaves amortised
-// over n pairs), then every pair is matched on its own.  img_dev[i]: [2][h][w] fp32 of pair i.
-int mods_pairs_gpu_stage(mods_ctx *c, const float *const *img_dev, int n_pairs, int w, int h, const mods_pair_params *par,
+// over n pairs), then every pair is matched on its own.  img[i]: [2][h][w] of pair i; kinds[i] (NULL = all 0):
+// 0 fp32 in HBM, 1 fp32 in (pinned) host memory, 2 8-bit grey in (pinned) host memory - host images are uploaded on
+// the context's stream, so the transfer of one worker overlaps the kernels of the others.
+int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, int n_pairs, int w, int h, const mods_pair_params *par,
                          mods_pair_result **res, std::vector<mods_tentative> **tent, std::vector<double> **u6, std::vector<double> **laf) {
-  if (!c || !img_dev || !par || !res || n_pairs < 1) { set_error("match_pairs: null argument"); return MODS_E_ARG; }
-  if (n_pairs == 1) return mods_pair_gpu_stage(c, img_dev[0], w, h, w, par, res[0], tent[0], u6[0], laf[0]);
+  if (!c || !img || !par || !res || n_pairs < 1) { set_error("match_pairs: null argument"); return MODS_E_ARG; }
+  if (n_pairs == 1 && (!kinds || kinds[0] == 0)) return mods_pair_gpu_stage(c, (const float *)img[0], w, h, w, par, res[0], tent[0], u6[0], laf[0]);
   if (c->batch < 2 * n_pairs) { set_error("match_pairs: context batch %d < %d images", c->batch, 2 * n_pairs); return MODS_E_ARG; }
+  if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("match_pairs: image larger than the context"); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   const size_t plane2 = (size_t)2 * w * h;
   const int n_img = 2 * n_pairs;
   for (int i = 0; i < n_pairs; i++) {
     memset(res[i], 0, sizeof(*res[i]));
     for (int q = 0; q < 9; q++) res[i]->H[q] = -1;
-    MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev + plane2 * i, img_dev[i], sizeof(float) * plane2, hipMemcpyDeviceToDevice, c->stream));
+    const int kind = kinds ? kinds[i] : 0;
+    if (kind == 2) {
+      if (!c->u8_stage_dev) MODS_HIP_CHECK(hipMalloc(&c->u8_stage_dev, (size_t)c->max_w * c->max_h * c->batch + 16));
+      unsigned char *st = c->u8_stage_dev + plane2 * i;
+      MODS_HIP_CHECK(hipMemcpyAsync(st, img[i], plane2, hipMemcpyHostToDevice, c->stream));
+      if ((plane2 & 3) || ((uintptr_t)st & 3)) { set_error("match_pairs: 8-bit input needs w*h*2 divisible by 4"); return MODS_E_ARG; }
+      hipLaunchKernelGGL(u8_to_f32_kernel, dim3(1024), dim3(256), 0, c->stream, st, c->input_dev + plane2 * i, plane2 / 4);
+    } else {
+      MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev + plane2 * i, img[i], sizeof(float) * plane2,
+                                    kind == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+    }
   }
+  MODS_HIP_CHECK(hipGetLastError());
   std::vector<int> nd(n_img), nr(n_img);
   int rc;
   const double t0 = now_ms();

@@ -93,6 +93,7 @@ struct mods_ctx {
   size_t nms_mask_words = 0;
   int *key_count = nullptr;          // [batch]
   int *host_counts = nullptr;        // pinned
+  unsigned char *u8_stage_dev = nullptr;   // [batch][max_h][max_w] staging of 8-bit host images (pair pipeline), lazily allocated
   mods_hessaff_params par;
   int reg_number_eff = -1;           // par.regionsNumber after the tilt / zoom scaling of DetectAffineKeypoints (scale-space-detector.cpp:20-21)
   int last_w = 0, last_h = 0, last_n_img = 0;

@@ -542,7 +542,8 @@ static int external_orientation(mods_ctx *ctx, const float *img_dev, int n_img, 
       for (int i = 0; i < n; i++) {
         mods_region r = regs[b][i];
         const double angle = atan2f(out[2 * i], out[2 * i + 1]);   // atan2(float, float): the float overload
-        const double ci = cos(angle), si = sin(angle);
+        double ci, si;
+        det_sincos(angle, &si, &ci);   // the contract's cos / sin (detmath.hpp), as in the built-in orientation path
         const double a11 = r.a11, a12 = r.a12, a21 = r.a21, a22 = r.a22;
         r.a11 = a11 * ci - a12 * si;
         r.a12 = a11 * si + a12 * ci;

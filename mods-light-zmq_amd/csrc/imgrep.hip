@@ -50,6 +50,8 @@ int mods_ransac_set_device(int device);
 int mods_unoriented_count(mods_ctx *c, int img);
 int mods_match_fetch_internal(mods_ctx *c, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out);   // capi.hip
 
+int mods_host_alloc(size_t bytes, void **out) { if (!out) return MODS_E_ARG; MODS_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 4, hipHostMallocDefault)); return MODS_OK; }
+int mods_host_free(void *p) { MODS_HIP_CHECK(hipHostFree(p)); return MODS_OK; }
 int mods_dev_alloc(size_t bytes, void **out) { if (!out) return MODS_E_ARG; MODS_HIP_CHECK(hipMalloc(out, bytes ? bytes : 4)); return MODS_OK; }
 int mods_dev_free(void *p) { MODS_HIP_CHECK(hipFree(p)); return MODS_OK; }
 int mods_dev_upload(void *dst_dev, const void *src_host, size_t bytes) { MODS_HIP_CHECK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return MODS_OK; }

@@ -13,7 +13,7 @@ extern "C" int mods_ctx_create_ex(int device, int max_w, int max_h, int batch, i
 extern "C" int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
                                    mods_pair_result *res, std::vector<mods_tentative> *tent, std::vector<double> *u6,
                                    std::vector<double> *laf);
-extern "C" int mods_pairs_gpu_stage(mods_ctx *c, const float *const *img_dev, int n_pairs, int w, int h, const mods_pair_params *par,
+extern "C" int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, int n_pairs, int w, int h, const mods_pair_params *par,
                                     mods_pair_result **res, std::vector<mods_tentative> **tent, std::vector<double> **u6,
                                     std::vector<double> **laf);
 extern "C" int mods_pair_verify_stage(int device, const mods_pair_params *par, mods_pair_result *res, std::vector<mods_tentative> *tent,
@@ -23,7 +23,8 @@ namespace mods {
 
 struct Job {
   long tag = 0;
-  const float *img = nullptr;
+  const void *img = nullptr;
+  int kind = 0;                   // 0 fp32 in HBM, 1 fp32 on the host, 2 8-bit grey on the host
   mods_pair_result res;
   std::vector<mods_tentative> tent;
   std::vector<double> u6, laf;
@@ -61,12 +62,13 @@ static void gpu_worker(mods_pipeline *p, mods_ctx *ctx) {
       while (!p->q_gpu.empty() && (int)js.size() < p->pairs_per_batch) { js.push_back(p->q_gpu.front()); p->q_gpu.pop_front(); }
     }
     const int n = (int)js.size();
-    std::vector<const float *> imgs(n);
+    std::vector<const void *> imgs(n);
+    std::vector<int> kinds(n);
     std::vector<mods_pair_result *> res(n);
     std::vector<std::vector<mods_tentative> *> tent(n);
     std::vector<std::vector<double> *> u6(n), laf(n);
-    for (int i = 0; i < n; i++) { imgs[i] = js[i]->img; res[i] = &js[i]->res; tent[i] = &js[i]->tent; u6[i] = &js[i]->u6; laf[i] = &js[i]->laf; }
-    const int rc = mods_pairs_gpu_stage(ctx, imgs.data(), n, p->w, p->h, &p->par, res.data(), tent.data(), u6.data(), laf.data());
+    for (int i = 0; i < n; i++) { imgs[i] = js[i]->img; kinds[i] = js[i]->kind; res[i] = &js[i]->res; tent[i] = &js[i]->tent; u6[i] = &js[i]->u6; laf[i] = &js[i]->laf; }
+    const int rc = mods_pairs_gpu_stage(ctx, imgs.data(), kinds.data(), n, p->w, p->h, &p->par, res.data(), tent.data(), u6.data(), laf.data());
     const std::string err = rc ? mods_last_error() : "";
     {
       std::lock_guard<std::mutex> lk(p->mu);
@@ -153,10 +155,10 @@ int mods_pipeline_create_ex(int device, int w, int h, const mods_pair_params *pa
 
 // Queues one pair ([2][h][w] fp32 in HBM; must stay valid until its result has been fetched).  Blocks
 // only while too many pairs are in flight.
-int mods_pipeline_submit(mods_pipeline *p, const float *img_dev, long tag) {
-  if (!p || !img_dev) return MODS_E_ARG;
+static int submit_any(mods_pipeline *p, const void *img, int kind, long tag) {
+  if (!p || !img) return MODS_E_ARG;
   auto j = std::make_shared<Job>();
-  j->tag = tag; j->img = img_dev;
+  j->tag = tag; j->img = img; j->kind = kind;
   {
     std::unique_lock<std::mutex> lk(p->mu);
     p->cv_space.wait(lk, [&] { return (int)p->q_order.size() < p->max_in_flight; });
@@ -166,6 +168,12 @@ int mods_pipeline_submit(mods_pipeline *p, const float *img_dev, long tag) {
   p->cv_gpu.notify_one();
   return MODS_OK;
 }
+
+int mods_pipeline_submit(mods_pipeline *p, const float *img_dev, long tag) { return submit_any(p, img_dev, 0, tag); }
+// The same with the pair in host memory ([2][h][w], fp32 or 8-bit grey; pinned memory makes the upload asynchronous): the
+// boundary of the reference's step loop, mods.cpp:184-383 (decoded images in host memory in, verified matches + H / F out).
+int mods_pipeline_submit_host(mods_pipeline *p, const float *img_host, long tag) { return submit_any(p, img_host, 1, tag); }
+int mods_pipeline_submit_host_u8(mods_pipeline *p, const unsigned char *img_host, long tag) { return submit_any(p, img_host, 2, tag); }
 
 // Result of the oldest submitted pair (blocks until it is verified).  Returns MODS_E_ARG when nothing
 // is in flight.

@@ -12,6 +12,7 @@
 // its four taps through L2.  One thread per output pixel, 64x4 tiles so that a wave covers one row
 // segment (coalesced stores; the rotation makes loads walk a slanted line, which L2 absorbs).
 #include "common.hpp"
+#include "detmath.hpp"
 #include <cmath>
 
 namespace mods {
@@ -164,7 +165,8 @@ int mods_view_geometry(int w, int h, double tilt, double phi, double zoom, doubl
   g->rotation = phi * 180 / M_PI; g->tilt = tilt; g->zoom = zoom;
   double kV = 1., kH = 1.;
   if (zoomed) { kV = (double)w / (double)wS1; kH = (double)h / (double)hS1; }
-  const double cp = cos(phi), sp = sin(phi);
+  double cp, sp;
+  det_sincos(phi, &sp, &cp);   // the contract's cos / sin (detmath.hpp): libm's sincos() and cos()/sin() disagree in the last bit
   const bool first = (phi >= 0) && (phi < M_PI / 2);
   // the tilt compresses x (division by tilt*kH) unless it is "vertical", in which case it compresses y
   const double fx = vertical_tilt ? kH : tilt * kH;

@@ -72,13 +72,14 @@ void affnet_apply(std::vector<Region> &r, const float *a3, int w, int h, double 
 }
 
 // OriNet branch of the orientation estimate, imagerepresentation.cpp:877-899: angle = atan2(y, x) of the network's two values
-// per keypoint (float arguments: the float overload), frame rotated as DetectOrientation does.  yx: n x 2 floats.
+// per keypoint (float arguments: the float overload, host libm), frame rotated as DetectOrientation does.  yx: n x 2 floats.
 void orinet_apply(std::vector<Region> &r, const float *yx) {
   for (size_t i = 0; i < r.size(); i++) {
     const Region c = r[i];
     double angle = std::atan2(yx[2 * i], yx[2 * i + 1]);
-    double ci = std::cos(angle);
-    double si = std::sin(angle);
+    double ci, si;
+    det_sincos(angle, &si, &ci);      // cos / sin by the fixed sequences of detmath.h (glibc's sincos() and cos()/sin() disagree
+                                      // in the last bit for ~1e-3 of the arguments, and compilers choose between them freely)
     r[i].a11 = c.a11 * ci - c.a12 * si;
     r[i].a12 = c.a11 * si + c.a12 * ci;
     r[i].a21 = c.a21 * ci - c.a22 * si;

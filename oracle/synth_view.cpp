@@ -10,6 +10,7 @@
 // The view geometry (sizes, H, warp matrices, sigmas) is plain double arithmetic + libm and follows
 // the reference line by line.
 #include "orc.h"
+#include "detmath.h"
 #include <cmath>
 
 namespace orc {
@@ -142,37 +143,42 @@ bool view_geometry(int w, int h, double tilt, double phi, double zoom, double In
     return true;
   }
   double d, d2, w_new, h_new;
+  // cos(phi) / sin(phi): one evaluation each by the fixed sequences of detmath.h (the reference calls libm per use; glibc's
+  // sincos() and cos()/sin() differ in the last bit for ~1e-3 of the arguments and compilers pick between them freely, so a
+  // contract on top of libm cannot be bit exact)
+  double cp, sp;
+  det_sincos(phi, &sp, &cp);
   double kV = 1., kH = 1.;
   if (zoomed) { kV = (double)w / (double)wS1; kH = (double)h / (double)hS1; }
   double *H = g->H;
   const bool first = (phi >= 0) && (phi < M_PI / 2);
   if (vertical_tilt) {
     if (first) {
-      w_new = std::floor((0.5 + std::cos(phi) * w + std::sin(phi) * h) / (kH));
-      h_new = std::floor((0.5 + std::sin(phi) * w + std::cos(phi) * h) / (tilt * kV));
-      H[0] = std::cos(phi) / kH; H[1] = std::sin(phi) / kH; H[2] = 0;
-      H[3] = -std::sin(phi) / (tilt * kV); H[4] = std::cos(phi) / (tilt * kV); H[5] = std::floor(0.5 + std::sin(phi) * w / (tilt * kV));
+      w_new = std::floor((0.5 + cp * w + sp * h) / (kH));
+      h_new = std::floor((0.5 + sp * w + cp * h) / (tilt * kV));
+      H[0] = cp / kH; H[1] = sp / kH; H[2] = 0;
+      H[3] = -sp / (tilt * kV); H[4] = cp / (tilt * kV); H[5] = std::floor(0.5 + sp * w / (tilt * kV));
     } else {
-      w_new = std::floor((0.5 - std::cos(phi) * w + std::sin(phi) * h) / (kH));
-      h_new = std::floor((0.5 + std::sin(phi) * w - std::cos(phi) * h) / (tilt * kV));
-      d = -std::floor(std::cos(phi) * w / kH);
-      d2 = std::floor(0.5 + (std::sin(phi) * w - std::cos(phi) * h) / (tilt * kV));
-      H[0] = std::cos(phi) / kH; H[1] = std::sin(phi) / kH; H[2] = d;
-      H[3] = -std::sin(phi) / (tilt * kV); H[4] = std::cos(phi) / (tilt * kV); H[5] = d2;
+      w_new = std::floor((0.5 - cp * w + sp * h) / (kH));
+      h_new = std::floor((0.5 + sp * w - cp * h) / (tilt * kV));
+      d = -std::floor(cp * w / kH);
+      d2 = std::floor(0.5 + (sp * w - cp * h) / (tilt * kV));
+      H[0] = cp / kH; H[1] = sp / kH; H[2] = d;
+      H[3] = -sp / (tilt * kV); H[4] = cp / (tilt * kV); H[5] = d2;
     }
   } else {
     if (first) {
-      w_new = std::floor((0.5 + std::cos(phi) * w + std::sin(phi) * h) / (tilt * kH));
-      h_new = std::floor((0.5 + std::sin(phi) * w + std::cos(phi) * h) / (kV));
-      H[0] = std::cos(phi) / (tilt * kH); H[1] = std::sin(phi) / (tilt * kH); H[2] = 0;
-      H[3] = -std::sin(phi) / kV; H[4] = std::cos(phi) / kV; H[5] = std::floor(0.5 + std::sin(phi) * w / kV);
+      w_new = std::floor((0.5 + cp * w + sp * h) / (tilt * kH));
+      h_new = std::floor((0.5 + sp * w + cp * h) / (kV));
+      H[0] = cp / (tilt * kH); H[1] = sp / (tilt * kH); H[2] = 0;
+      H[3] = -sp / kV; H[4] = cp / kV; H[5] = std::floor(0.5 + sp * w / kV);
     } else {
-      w_new = std::floor((0.5 - std::cos(phi) * w + std::sin(phi) * h) / (tilt * kH));
-      h_new = std::floor((0.5 + std::sin(phi) * w - std::cos(phi) * h) / (kV));
-      d = -std::floor(std::cos(phi) * w / (tilt * kH));
-      d2 = std::floor(0.5 + (std::sin(phi) * w - std::cos(phi) * h) / kV);
-      H[0] = std::cos(phi) / (tilt * kH); H[1] = std::sin(phi) / (tilt * kH); H[2] = d;
-      H[3] = -std::sin(phi) / kV; H[4] = std::cos(phi) / kV; H[5] = d2;
+      w_new = std::floor((0.5 - cp * w + sp * h) / (tilt * kH));
+      h_new = std::floor((0.5 + sp * w - cp * h) / (kV));
+      d = -std::floor(cp * w / (tilt * kH));
+      d2 = std::floor(0.5 + (sp * w - cp * h) / kV);
+      H[0] = cp / (tilt * kH); H[1] = sp / (tilt * kH); H[2] = d;
+      H[3] = -sp / kV; H[4] = cp / kV; H[5] = d2;
     }
   }
   H[6] = 0; H[7] = 0; H[8] = 1;
@@ -184,17 +190,17 @@ bool view_geometry(int w, int h, double tilt, double phi, double zoom, double In
   else { g->sigma_x = sigma_aa; g->sigma_y = sigma_aa_2; }
   double *R = g->warpRot;
   if (first) {
-    g->w_rot = (int)std::floor((0.5 + std::cos(phi) * w + std::sin(phi) * h));
-    g->h_rot = (int)std::floor((0.5 + std::sin(phi) * w + std::cos(phi) * h));
-    R[0] = std::cos(phi); R[1] = std::sin(phi); R[2] = 0;
-    R[3] = -std::sin(phi); R[4] = std::cos(phi); R[5] = std::floor(0.5 + std::sin(phi) * w);
+    g->w_rot = (int)std::floor((0.5 + cp * w + sp * h));
+    g->h_rot = (int)std::floor((0.5 + sp * w + cp * h));
+    R[0] = cp; R[1] = sp; R[2] = 0;
+    R[3] = -sp; R[4] = cp; R[5] = std::floor(0.5 + sp * w);
   } else {
-    g->w_rot = (int)std::floor((0.5 - std::cos(phi) * w + std::sin(phi) * h));
-    g->h_rot = (int)std::floor((0.5 + std::sin(phi) * w - std::cos(phi) * h));
-    d = -std::floor(std::cos(phi) * w);
-    d2 = std::floor(0.5 + (std::sin(phi) * w - std::cos(phi) * h));
-    R[0] = std::cos(phi); R[1] = std::sin(phi); R[2] = d;
-    R[3] = -std::sin(phi); R[4] = std::cos(phi); R[5] = d2;
+    g->w_rot = (int)std::floor((0.5 - cp * w + sp * h));
+    g->h_rot = (int)std::floor((0.5 + sp * w - cp * h));
+    d = -std::floor(cp * w);
+    d2 = std::floor(0.5 + (sp * w - cp * h));
+    R[0] = cp; R[1] = sp; R[2] = d;
+    R[3] = -sp; R[4] = cp; R[5] = d2;
   }
   int kx = (int)std::floor(2.0 * 3.0 * g->sigma_x + 1.0);
   if (kx % 2 == 0) kx++;

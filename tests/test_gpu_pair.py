@@ -188,3 +188,41 @@ def test_pipeline_equals_serial(pkg, gpu_workers, verify_workers, ppb):
             assert getattr(res, f) == getattr(exp, f), (f, i)
         assert list(res.n_described) == list(exp.n_described) and list(res.H) == list(exp.H)
     pipe.close(); ctx.close()
+
+
+@pytest.mark.parametrize("ppb", [1, 4])
+def test_pipeline_host_input(pkg, ppb):
+    """Pairs handed over in host memory (pinned fp32, pinned 8-bit grey, and pageable fp32) give what the same pairs give
+    from HBM: the upload + the 8-bit -> float conversion are part of the GPU worker's stage."""
+    import torch
+    w, h = 640, 480
+    pairs = [synth.pair(w, h, seed=60 + i) for i in range(4)]
+    host = [np.stack([a, b]) for a, b, _ in pairs]
+    assert all(np.array_equal(x, np.round(x)) and x.min() >= 0 and x.max() <= 255 for x in host)   # synthetic images are 8-bit valued
+    dev = [torch.from_numpy(x).cuda() for x in host]
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    pkg.ransac_pin_seed(7)
+    pipe = pkg.Pipeline(0, w, h, par, 2, 2, ppb)
+    pin32 = [pkg.PinnedBuffer(x.shape, np.float32) for x in host]
+    pin8 = [pkg.PinnedBuffer(x.shape, np.uint8) for x in host]
+    for b32, b8, x in zip(pin32, pin8, host):
+        b32.array[...] = x
+        b8.array[...] = x.astype(np.uint8)
+    results = {}
+    for name, sub in (("dev", lambda i: pipe.submit(dev[i].data_ptr(), i)),
+                      ("pinned_f32", lambda i: pipe.submit_host(pin32[i].ptr.value, i)),
+                      ("pinned_u8", lambda i: pipe.submit_host(pin8[i].ptr.value, i, u8=True)),
+                      ("pageable_f32", lambda i: pipe.submit_host(host[i].ctypes.data, i))):
+        for i in range(4):
+            sub(i)
+        results[name] = [pipe.next()[0] for _ in range(4)]
+    for name in ("pinned_f32", "pinned_u8", "pageable_f32"):
+        for got, exp in zip(results[name], results["dev"]):
+            for f in ("n_tentatives", "n_unique", "n_inliers", "ransac_samples", "ransac_lo", "ransac_rejects"):
+                assert getattr(got, f) == getattr(exp, f), (name, f)
+            assert list(got.n_described) == list(exp.n_described) and list(got.H) == list(exp.H), name
+    assert results["dev"][0].n_inliers > 50
+    pipe.close()
+    for b in pin32 + pin8:
+        b.close()
