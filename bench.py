@@ -5,16 +5,21 @@ synthetic 1920x1080 pairs, HessianAffine + RootSIFT, one identity view per image
 
   python bench.py --gpus N --steps K --warmup W
 
-A step = one batch of --pairs-per-step (default 32) image pairs through the whole hot path (detect, describe,
-match, duplicate filter, LO-RANSAC) with all images already resident in HBM; the reported value is pairs / second.  N > 1 is launched by torch.distributed.run, one rank per GPU; pairs are independent
-units, so every rank works on its own pairs (weak scaling, no data-path collective) and the reported
-value is all pairs / max-over-ranks time.
+A step = one batch of --pairs-per-step (default 32) image pairs through the whole hot path, SURVEY.md 8d's boundary:
+two decoded 8-bit grey images in (pinned) host memory -> upload -> detect, describe, match, duplicate filter, LO-RANSAC ->
+inlier set + H on the host (mods.cpp:184-383).  --input hbm keeps the images resident in HBM instead (fp32).  The reported
+value is pairs / second.  N > 1 is launched by torch.distributed.run, one rank per GPU; pairs are independent units, so every
+rank works on its own pairs (weak scaling, no data-path collective) and the reported value is all pairs / max-over-ranks time.
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
-  roofline     - the Gaussian-blur kernel of the Hessian pyramid (largest share of the HBM-bound
-                 pyramid time): algorithmic bytes (8 B/px per blur launch) / mean launch time
-                 measured with HIP events on the context's stream during the timed steps
-  cpu_baseline - the CPU oracle (oracle/) timed on this host on one pair of the same workload
+  roofline       - the Gaussian-blur kernel of the Hessian pyramid (largest share of the HBM-bound pyramid time): algorithmic
+                   bytes (8 B/px per blur launch) / mean launch time from HIP events recorded on the workers'
+                   streams DURING the timed steps (the kernels of the other workers run beside it); "isolated" inside it is
+                   the same launch sequence on one stream with nothing else on the GPU (a separate short leg)
+  roofline_match - the brute-force descriptor search at the size of BASELINE configs[4]: 2*N*M*128 integer operations / the
+                   time of the match stage (HIP events), against the dense int8 MFMA peak
+  cpu_baseline   - the CPU oracle (oracle/) timed on this host on pairs of the same workload: all cores (OpenMP inside the
+                   stages), the reference's own task structure (2 images side by side, mods.cpp:234-251), and one core
 """
 import argparse
 import json
@@ -28,24 +33,41 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_BLUR_TRAFFIC = 177224280   # bytes per launch of the dominant blur instantiation, profiles/r01_pmc_blur_traffic.csv
 
 
 def cpu_baseline(img1, img2, seed):
-    """Oracle chain on one pair, single thread.  Returns (pairs_per_s, seconds, inliers)."""
+    """The CPU oracle on one pair of the workload, three ways.  Returns the cpu_baseline object of the JSON line."""
+    import orc
     import pipeline_oracle as po
     import refdeg
-    t0 = time.time()
-    if refdeg.available():
-        r = po.match_pair(img1, img2, seed_time=seed)
-        ninl = r["n_inliers"]
-    else:   # GPU box without oracle/_ref: everything up to the tentatives (RANSAC is <1% of the CPU time)
-        import orc
-        ra, _ = orc.detect_describe(img1)
-        rb, _ = orc.detect_describe(img2)
+    ncpu = os.cpu_count() or 1
+
+    def verify(ra, rb, tc):
+        un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
+        if refdeg.available():       # the reference's own degensac (oracle/_ref), single thread as in the reference
+            return po.loransac_h(po.u6_of(ra, rb, un), po.laf_of(ra, rb, un), seed_time=seed)[2]
+        return len(un)               # GPU box without oracle/_ref: RANSAC is < 1 % of the CPU time
+
+    def chain(inner_threads, image_tasks):
+        orc.lib().orc_set_threads(inner_threads)
+        t0 = time.time()
+        (ra, _), (rb, _) = po.pmap(orc.detect_describe, (img1, img2), threads=image_tasks)
         tc = orc.match_fginn(ra, rb, 0.8)
-        ninl = len(orc.duplicate_filter(tc, ra, rb, 2.0, 1))
-    dt = time.time() - t0
-    return 1.0 / dt, dt, ninl
+        ninl = verify(ra, rb, tc)
+        orc.lib().orc_set_threads(1)
+        return time.time() - t0, ninl
+
+    t_all, ninl = chain(ncpu, 1)          # OpenMP over rows / keypoints / queries inside every stage, all cores
+    t_ref, _ = chain(1, 2)                # the reference's structure: the two images as two tasks, the rest serial
+    t_one, _ = chain(1, 1)
+    return {"value": round(1.0 / t_all, 5), "unit": "pairs/s", "cores": ncpu, "kind": "port",
+            "sample": "1 of the benchmark's 1920x1080 pairs through the CPU oracle (oracle/; RANSAC = the reference's degensac "
+                      "when oracle/_ref is present), %d inliers: %.1f s with OpenMP over rows / keypoints / queries on %d "
+                      "cores, %.1f s in the reference's task structure (2 images side by side, mods.cpp:234-251), %.1f s on 1 core"
+                      % (ninl, t_all, ncpu, t_ref, t_one),
+            "reference_task_structure": {"value": round(1.0 / t_ref, 5), "cores": 2},
+            "one_core": {"value": round(1.0 / t_one, 5), "cores": 1}}
 
 
 MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 = 2 x the bf16 rate (MI355X_MICROARCH.md MFMA table; measured ceiling >= 3944)
@@ -163,13 +185,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs cycled through the steps")
+    ap.add_argument("--pairs", type=int, default=5, help="distinct synthetic pairs cycled through the steps")
     ap.add_argument("--pairs-per-step", type=int, default=32, help="image pairs in the batch that one step processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gpu-workers", type=int, default=3, help="pipeline threads running detect/describe/match (one context each)")
     ap.add_argument("--verify-workers", type=int, default=6, help="pipeline threads running duplicate filter + LO-RANSAC")
     ap.add_argument("--pairs-per-batch", type=int, default=8, help="pairs a GPU worker pushes through detect/describe as one batch of launches")
-    ap.add_argument("--serial", action="store_true", help="no cross-pair overlap: one mods_match_pair_dev call per step")
+    ap.add_argument("--serial", action="store_true", help="no cross-pair overlap: one mods_match_pair_dev call per step (images in HBM)")
+    ap.add_argument("--input", default="host_u8", choices=["host_u8", "host_f32", "hbm"],
+                    help="where a pair lives when its step starts: 8-bit grey in pinned host memory (default: the boundary of the "
+                         "reference's step loop), fp32 in pinned host memory, or fp32 resident in HBM")
+    ap.add_argument("--no-match-leg", action="store_true", help="skip the configs[4]-sized match measurement (roofline_match)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs[]: c2 = the headline 1080p pair (default, what the driver runs); c3 = view-synthesis "
                          "ladder on a hard 1080p pair; c4 = 1-MP pairs (throughput); c5 = 4096x4096 pair with DEGENSAC F verification")
@@ -202,10 +228,21 @@ def main():
     pkg = ge.load_package()
     if pkg.lib().mods_device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: libmodsgpu has no CPU path")
+    if args.serial:
+        args.input = "hbm"
 
-    # synthetic inputs: seed = 1000*config + pair index (config 2 = the 1080p pair), distinct per rank
+    # synthetic inputs: seed = 1000*config + pair index (config 2 = the 1080p pair), distinct per rank.  The generator makes
+    # 8-bit valued images ("uint8 then float32"), so the 8-bit and the fp32 form of a pair are the same image.
     pairs_host = [synth.pair(W, H, seed=2000 + rank * 100 + i) for i in range(args.pairs)]
-    pairs_dev = [torch.from_numpy(np.stack([a, b])).cuda(device) for a, b, _ in pairs_host]
+    stacks = [np.stack([a, b]) for a, b, _ in pairs_host]
+    pairs_dev = [torch.from_numpy(x).cuda(device) for x in stacks]
+    pinned = []
+    if args.input != "hbm":
+        dt_in = np.uint8 if args.input == "host_u8" else np.float32
+        for x in stacks:
+            buf = pkg.PinnedBuffer(x.shape, dt_in)
+            buf.array[...] = x.astype(dt_in)
+            pinned.append(buf)
     torch.cuda.synchronize()
 
     ctx = pkg.Context(device, W, H, 2)
@@ -218,6 +255,13 @@ def main():
         res, _ = pkg.match_pair_dev(ctx, pairs_dev[i % len(pairs_dev)].data_ptr(), W, H, params)
         return res
 
+    def submit(i):
+        k = i % len(pairs_dev)
+        if args.input == "hbm":
+            pipe.submit(pairs_dev[k].data_ptr(), i)
+        else:
+            pipe.submit_host(pinned[k].ptr.value, i, u8=(args.input == "host_u8"))
+
     def run(n_steps):
         """n_steps pairs through the hot path; returns the per-pair results in step order."""
         if pipe is None:
@@ -226,13 +270,18 @@ def main():
         for i in range(n_steps):
             if pending >= pipe.capacity - 1:
                 out.append(pipe.next()[0]); pending -= 1
-            pipe.submit(pairs_dev[i % len(pairs_dev)].data_ptr(), i); pending += 1
+            submit(i); pending += 1
         while pending:
             out.append(pipe.next()[0]); pending -= 1
         return out
 
     pps = max(1, args.pairs_per_step)
     run(args.warmup * pps)
+    # HIP events around every blur launch of the timed steps, on the streams the launches go to (the workers' streams)
+    if pipe is not None:
+        pipe.timing_enable(["blur", "blur_small"])
+    else:
+        ctx.timing_enable(["blur", "blur_small"]); ctx.timing_reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -242,22 +291,22 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    timed = pipe if pipe is not None else ctx
+    blur_ms, blur_n, blur_bytes = timed.timing_read("blur")
+    small_ms, small_n, small_bytes = timed.timing_read("blur_small")
+    timed.timing_enable([])
     n_pairs = len(results)
     inl = sum(r.n_inliers for r in results)
     stage_ms = [sum(getattr(r, f) for r in results) for f in ("ms_detect_describe", "ms_match", "ms_duplicates", "ms_ransac")]
-    # roofline leg: the pyramid blur launches of the same workload in the same batching, bracketed by HIP events on
-    # the worker's stream (a separate short pass with ONE gpu worker: event recording does not perturb the timed region
-    # and a second stream does not stretch the kernels that are being timed)
-    if pipe is None:
-        ctx.timing_enable(["blur", "blur_small"]); ctx.timing_reset()
-        for i in range(8):
-            step(i)
-        blur_ms, blur_n, blur_bytes = ctx.timing_read("blur")
-        small_ms, small_n, small_bytes = ctx.timing_read("blur_small")
-        ctx.timing_enable([])
-    else:
-        # what a GPU worker launches for one batch: the images of pairs_per_batch pairs in one detect/describe pass
-        nb = max(1, args.pairs_per_batch)
+
+    # isolated leg: what a GPU worker launches for one batch (the images of pairs_per_batch pairs in one detect/describe pass),
+    # on ONE stream with nothing else on the GPU; also yields the regions for the match leg
+    nb = 1 if pipe is None else max(1, args.pairs_per_batch)
+    iso = None
+    match_leg = None
+    if rank == 0:
+        n_img = 2 * min(nb, len(pairs_dev)) if nb > 1 else 2
+        reps = (2 * nb + n_img - 1) // n_img
         batch_t = torch.cat([pairs_dev[i % len(pairs_dev)] for i in range(nb)], dim=0).contiguous()
         bctx = pkg.Context(device, W, H, 2 * nb)
         torch.cuda.synchronize()
@@ -266,8 +315,31 @@ def main():
         bctx.timing_enable(["blur", "blur_small"]); bctx.timing_reset()
         for _ in range(6):
             bctx.detect_describe_dev(batch_t.data_ptr(), 2 * nb, W, H, params.det, params.desc)
-        blur_ms, blur_n, blur_bytes = bctx.timing_read("blur")
-        small_ms, small_n, small_bytes = bctx.timing_read("blur_small")
+        i_ms, i_n, i_bytes = bctx.timing_read("blur")
+        is_ms, is_n, is_bytes = bctx.timing_read("blur_small")
+        bctx.timing_enable([])
+        iso = (i_ms, i_n, i_bytes, is_ms, is_n, is_bytes)
+        del reps
+        if not args.no_match_leg:
+            # BASELINE configs[4]-sized search: the regions of all first images against the regions of all second images
+            # of the benchmark's pairs, repeated until both lists hold ~50 k descriptors (N x M x 128)
+            rep_q, rep_t = pkg.ImgRep(bctx, 1 << 17), pkg.ImgRep(bctx, 1 << 17)
+            k = 0
+            while min(len(rep_q), len(rep_t)) < 50000 and k < 64:
+                p = k % len(pairs_dev)
+                bctx.detect_describe_dev(pairs_dev[p].data_ptr(), 2, W, H, params.det, params.desc)
+                rep_q.append_ctx(0); rep_t.append_ctx(1)
+                k += 1
+            nq, nt = len(rep_q), len(rep_t)
+            pkg.match_reps(bctx, rep_q, rep_t)                      # warm-up
+            bctx.timing_enable(["match"]); bctx.timing_reset()
+            reps_m = 5
+            for _ in range(reps_m):
+                tent, _, _ = pkg.match_reps(bctx, rep_q, rep_t)
+            m_ms, m_n, _ = bctx.timing_read("match")
+            bctx.timing_enable([])
+            match_leg = (nq, nt, m_ms / reps_m, len(tent))
+            rep_q.close(); rep_t.close()
         bctx.close()
         del batch_t
     last = step(0)
@@ -279,15 +351,21 @@ def main():
 
     if rank == 0:
         value = world * n_pairs / dt
-        achieved = (blur_bytes / blur_n) / (blur_ms / blur_n * 1e-3) / 1e9 if blur_n else 0.0
-        all_n, all_ms, all_bytes = blur_n + small_n, blur_ms + small_ms, blur_bytes + small_bytes
-        achieved_all = all_bytes / (all_ms * 1e-3) / 1e9 if all_n else 0.0
+
+        def gbs(by, ms):
+            return by / (ms * 1e-3) / 1e9 if ms else 0.0
+        achieved = gbs(blur_bytes, blur_ms)
+        i_ms, i_n, i_bytes, is_ms, is_n, is_bytes = iso
         out = {
             "metric": "image_pairs_per_sec_end_to_end", "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "single 1920x1080 pair, HessianAffine+RootSIFT, 1 synth iteration (BASELINE configs[1])",
                        "pairs_per_step": pps, "image": "1920x1080",
+                       "input": {"host_u8": "two 8-bit grey images in pinned host memory per pair, uploaded inside the timed region",
+                                 "host_f32": "two fp32 grey images in pinned host memory per pair, uploaded inside the timed region",
+                                 "hbm": "fp32 images resident in HBM"}[args.input],
+                       "output": "inlier set + H on the host",
                        "overlap": "serial" if pipe is None else "%d gpu workers x %d pairs per batch + %d verify workers" % (args.gpu_workers, args.pairs_per_batch, args.verify_workers), "matcher": "linear (exact), FGINN 0.8",
                        "verification": "LO-RANSAC homography, Sampson, th 4 px", "parallelism": "pairs sharded, %d rank(s)" % world,
                        "keypoints_per_image": list(last.n_described), "tentatives": last.n_tentatives,
@@ -296,29 +374,45 @@ def main():
                        "stage_ms_per_pair": {"detect_describe": round(stage_ms[0] / n_pairs, 3), "match": round(stage_ms[1] / n_pairs, 3),
                                              "duplicates": round(stage_ms[2] / n_pairs, 3), "ransac": round(stage_ms[3] / n_pairs, 3)}},
             # the dominant kernel of the pyramid: the 32-row-tile instantiation of the blur (octaves 0-1 at this batching: 95 % of
-            # the pyramid's bytes, 3/4 of its time); the launches of the smaller planes use the 16-row instantiation and are
-            # launch-size bound: "all_blur_launches" is the figure over both
+            # the pyramid's bytes, 3/4 of its time), measured during the timed steps; the launches of the smaller planes use the
+            # 16-row instantiation and are launch-size bound: "all_blur_launches" is the figure over both
             "roofline": {"kernel": "gauss_blur_fast_kernel<R,32,2>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # HBM bytes per launch from the PMC passes committed in profiles/r01_pmc_blur_traffic.csv
-                         # (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, mean over the blur launches of the default batching,
-                         # 16 images per launch; other batchings were not measured)
-                         "traffic": 177224280 if (pipe is not None and args.pairs_per_batch == 8 and args.config == "c2") else None,
+                         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
+                         # note + WRITE_SIZE, mean over the blur launches of the default batching, 16 images per launch)
+                         "traffic": PMC_BLUR_TRAFFIC if (pipe is not None and args.pairs_per_batch == 8) else None,
+                         "measured": "HIP events on the workers' streams during the timed steps",
                          "launches": blur_n, "mean_launch_us": round(blur_ms / max(blur_n, 1) * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(blur_bytes / max(blur_n, 1), 1),
-                         "all_blur_launches": {"achieved": round(achieved_all, 2), "frac": round(achieved_all / HBM_PEAK_GBS, 4),
-                                               "launches": all_n, "mean_launch_us": round(all_ms / max(all_n, 1) * 1e3, 3),
-                                               "algorithmic_bytes_per_launch": round(all_bytes / max(all_n, 1), 1)}},
+                         "all_blur_launches": {"achieved": round(gbs(blur_bytes + small_bytes, blur_ms + small_ms), 2),
+                                               "frac": round(gbs(blur_bytes + small_bytes, blur_ms + small_ms) / HBM_PEAK_GBS, 4),
+                                               "launches": blur_n + small_n},
+                         "isolated": {"what": "the same launches on one stream, nothing else on the GPU (separate leg after the timed steps)",
+                                      "achieved": round(gbs(i_bytes, i_ms), 2), "frac": round(gbs(i_bytes, i_ms) / HBM_PEAK_GBS, 4),
+                                      "launches": i_n, "mean_launch_us": round(i_ms / max(i_n, 1) * 1e3, 3),
+                                      "all_blur_launches": {"achieved": round(gbs(i_bytes + is_bytes, i_ms + is_ms), 2),
+                                                            "frac": round(gbs(i_bytes + is_bytes, i_ms + is_ms) / HBM_PEAK_GBS, 4),
+                                                            "launches": i_n + is_n}}},
         }
+        if match_leg:
+            nq, nt, mms, ntent = match_leg
+            ops = 2.0 * nq * nt * 128
+            ach = ops / (mms * 1e-3) / 1e12
+            out["roofline_match"] = {"kernel": "match stage (pack + match_nn1_kernel + mid + match_fginn_kernel + emit; i8 MFMA)", "bound": "mfma",
+                                     "achieved": round(ach, 2), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                                     "frac": round(ach / MFMA_I8_PEAK_TOPS, 4), "traffic": None,
+                                     "queries": nq, "trains": nt, "ops": ops, "stage_ms": round(mms, 4), "tentatives": ntent,
+                                     "measured": "HIP events around the match stage, BASELINE configs[4]-sized lists built from the "
+                                                 "benchmark's regions (separate leg after the timed steps)"}
         if not args.no_cpu_baseline and world == 1:
             a, b, _ = pairs_host[0]
-            v, secs, ninl = cpu_baseline(a, b, 12345)
-            out["cpu_baseline"] = {"value": round(v, 5), "unit": "pairs/s", "cores": 1, "kind": "port",
-                                   "sample": "1 of the benchmark's 1920x1080 pairs through the CPU oracle (oracle/), %.1f s, %d inliers" % (secs, ninl)}
+            out["cpu_baseline"] = cpu_baseline(a, b, 12345)
         print(json.dumps(out))
     if pipe is not None:
         pipe.close()
     ctx.close()
+    for b in pinned:
+        b.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -8,7 +8,8 @@
 //   cv::resize(.., 0.5, 0.5, LINEAR)     pyramid.cpp:476
 // Arithmetic contract (shared with the CPU oracle): fp32, built with -ffp-contract=off so that every fusion is
 // written out.  cv::GaussianBlur as an FMA build of OpenCV evaluates it (the variant that reproduces the reference's
-// README counts exactly, tools/readme_count_hunt.py): row pass s = k[0]*S[0]; s = fma(k[j], S[j], s) left to right,
+// README counts exactly, tools/readme_count_hunt.py): row pass s = k[0]*S[0]; s = fma(k[j], S[j], s) left to right
+// (ksize <= 5, which the pyramid never uses: centre tap, then s = fma(S[-j] + S[j], k[r+j], s)),
 // column pass s = k[r]*T[y]; s = fma(k[r+j], T[y+j] + T[y-j], s) for j = 1..r.
 #include "common.hpp"
 #include "detmath.hpp"
@@ -124,8 +125,14 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float *__restrict
     const int lx = tid & 63;
     for (int ly = tid / 64; ly < IH; ly += 4) {
       const float *p = s_in + ly * IW + lx;
-      float s = s_tap[0] * p[0];
-      for (int j = 1; j < n; j++) s = fmaf(s_tap[j], p[j], s);
+      float s;
+      if (n <= 5) {             // SymmRowSmallFilter order (ksize <= 5)
+        s = p[r] * s_tap[r];
+        for (int j = 1; j <= r; j++) s = fmaf(p[r - j] + p[r + j], s_tap[r + j], s);
+      } else {
+        s = s_tap[0] * p[0];
+        for (int j = 1; j < n; j++) s = fmaf(s_tap[j], p[j], s);
+      }
       s_row[ly * BLUR_TW + lx] = s;
     }
   }
@@ -229,9 +236,16 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
       float o[NO];
 #pragma unroll
       for (int u = 0; u < NO; u++) {
-        float s = taps.t[0] * wv[D + u];
+        float s;
+        if constexpr (R <= 2) {   // ksize <= 5: cv::GaussianBlur's SymmRowSmallFilter, centre tap then the symmetric pairs
+          s = wv[D + u + R] * taps.t[R];
 #pragma unroll
-        for (int j = 1; j < N; j++) s = fmaf(taps.t[j], wv[D + u + j], s);
+          for (int j = 1; j <= R; j++) s = fmaf(wv[D + u + R - j] + wv[D + u + R + j], taps.t[R + j], s);
+        } else {
+          s = taps.t[0] * wv[D + u];
+#pragma unroll
+          for (int j = 1; j < N; j++) s = fmaf(taps.t[j], wv[D + u + j], s);
+        }
         o[u] = s;
       }
 #pragma unroll

@@ -46,6 +46,8 @@ static Img wrap(const float *src, int w, int h) {
 }
 
 // experiment switches (tools/readme_count_hunt.py only); returns 0 for an unknown name
+// threads used inside one oracle call (bench.py's row-parallel CPU baseline); results do not depend on it
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 int orc_set_variant(const char *name, int v) {
   if (!std::strcmp(name, "kernel")) g_variant.kernel = v;
   else if (!std::strcmp(name, "row_fma")) g_variant.row_fma = v;

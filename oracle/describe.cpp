@@ -220,8 +220,11 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
   tmp.reserve(in.size());
   const int patchImageSize = 2 * int(mrSize) + 1;
   const double imageToPatchScale = double(patchImageSize) / (double)patchSize;
-  Img patch(patchSize, patchSize);
-  for (size_t i = 0; i < in.size(); i++) {
+  std::vector<Region> slot(in.size());
+  std::vector<char> ok(in.size(), 0);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 16)
+  for (long i = 0; i < (long)in.size(); i++) {
+    Img patch(patchSize, patchSize);
     const Region &k = in[i];
     float curr_sc = (float)(imageToPatchScale * k.s);
     if (interpolate_check_borders(img.w, img.h, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12, (float)k.a21,
@@ -240,9 +243,11 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
       t.a21 = k.a21 * ci - k.a22 * si;
       t.a22 = k.a21 * si + k.a22 * ci;
       t.parent = (int)i;
-      tmp.push_back(t);
+      slot[i] = t; ok[i] = 1;
     }
   }
+  for (size_t i = 0; i < in.size(); i++)
+    if (ok[i]) tmp.push_back(slot[i]);
   out.swap(tmp);
   return (int)out.size();
 }
@@ -389,8 +394,9 @@ void extract_desc_patch(const Region &k, const Img &img, double mrSize, int patc
 }
 
 void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize, bool photoNorm) {
-  Img patch(patchSize, patchSize);
-  for (size_t i = 0; i < r.size(); i++) {
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 16)
+  for (long i = 0; i < (long)r.size(); i++) {
+    Img patch(patchSize, patchSize);
     extract_desc_patch(r[i], img, mrSize, patchSize, photoNorm, patch);
     sift_patch_to_desc(patch, r[i].desc, true, 0.2);   // [SIFTDescriptor] maxBinValue = 0.2 (io_mods.cpp:427)
   }

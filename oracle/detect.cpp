@@ -254,7 +254,10 @@ void detect_hessian_affine(const Img &image, const HessAffParams &p, std::vector
   Img mask(p.smmWindowSize, p.smmWindowSize);
   compute_gauss_mask(mask);
   std::vector<AffKey> keys;
-  for (size_t i = 0; i < cand.size(); i++) {
+  std::vector<AffKey> slot(cand.size());
+  std::vector<char> ok(cand.size(), 0);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 16)
+  for (long i = 0; i < (long)cand.size(); i++) {
     const Candidate &cd = cand[i];
     const Img &prevBlur = pyr.oct[cd.octave].blur[cd.level - 1];
     float a[4]; int it;
@@ -264,8 +267,10 @@ void detect_hessian_affine(const Img &image, const HessAffParams &p, std::vector
     k.a11 = a[0]; k.a12 = a[1]; k.a21 = a[2]; k.a22 = a[3];
     k.response = cd.response; k.sub_type = cd.type;
     k.octave = cd.octave; k.level = cd.level; k.r0 = cd.r0; k.c0 = cd.c0;
-    keys.push_back(k);
+    slot[i] = k; ok[i] = 1;
   }
+  for (size_t i = 0; i < cand.size(); i++)
+    if (ok[i]) keys.push_back(slot[i]);
   std::stable_sort(keys.begin(), keys.end(),
                    [](const AffKey &k1, const AffKey &k2) { return std::fabs(k1.response) > std::fabs(k2.response); });
   // AffineDetector::prepareKeysForExport, scale-space-detector.hpp:126-198: the sorted list is cut as the mode says

@@ -16,6 +16,7 @@ const double *atan_lut() { return g_atan_lut; }
 // alternative readings of what an OpenCV build may do, kept so that the script can reproduce its table.
 Variant g_variant;
 int g_libm_variant = 0;
+int g_threads = 1;
 
 // detectors/helpers.cpp:720-721 / 728-729
 int gauss_ksize(float sigma) {
@@ -60,6 +61,7 @@ void gauss_blur(const Img &src, Img &dst, float sigma) {
   const bool rf = g_variant.row_fma != 0, cf = g_variant.col_fma != 0;
   auto cl = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
   Img tmp(w, h);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int y = 0; y < h; y++) {
     const float *S = src.row(y);
     float *T = tmp.row(y);
@@ -82,6 +84,7 @@ void gauss_blur(const Img &src, Img &dst, float sigma) {
     }
   }
   Img out(w, h);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int y = 0; y < h; y++) {
     float *D = out.row(y);
     for (int x = 0; x < w; x++) {
@@ -152,6 +155,7 @@ void hessian_response(const Img &in, Img &out, float norm) {
   const int rows = in.h, cols = in.w;
   Img o(cols, rows);
   const float norm2 = norm * norm;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int r = 1; r < rows - 1; ++r) {
     const float *p0 = in.row(r - 1), *p1 = in.row(r), *p2 = in.row(r + 1);
     float *q = o.row(r);

@@ -24,10 +24,13 @@ int match_fginn(const std::vector<Region> &list1, const std::vector<Region> &lis
   if (list1.empty() || list2.empty()) return 0;
   const int M = (int)list2.size();
   const int K = std::min(nn, M);
-  std::vector<std::pair<float, int>> all(M);
-  std::vector<int> idx(K);
-  std::vector<float> dst(K);
-  for (size_t i = 0; i < list1.size(); i++) {
+  std::vector<Tentative> slot(list1.size());
+  std::vector<char> have(list1.size(), 0);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
+  for (long i = 0; i < (long)list1.size(); i++) {
+    std::vector<std::pair<float, int>> all(M);
+    std::vector<int> idx(K);
+    std::vector<float> dst(K);
     for (int t = 0; t < M; t++) {
       float d = 0;
       for (int q = 0; q < 128; q++) {
@@ -51,12 +54,14 @@ int match_fginn(const std::vector<Region> &list1, const std::vector<Region> &lis
         tc.q = (int)i; tc.t = idx[0]; tc.t_bad = idx[j]; tc.t_2nd = idx[1];
         tc.d1 = dst[0]; tc.d2 = dst[j]; tc.d2nd = dst[1];
         tc.ratio = std::sqrt(ratio);
-        out.push_back(tc);
+        slot[i] = tc; have[i] = 1;
         break;
       }
       if (sqminratio < 1.0 && dist1 > contrDistSq) break;   // first contradictive
     }
   }
+  for (size_t i = 0; i < list1.size(); i++)
+    if (have[i]) out.push_back(slot[i]);
   return (int)out.size();
 }
 

@@ -29,6 +29,10 @@ struct Img {
 struct Variant { int kernel = 0, row_fma = 1, col_fma = 1, small_row = 1, resize_tail = 0, libm = 0; };
 extern Variant g_variant;
 
+// Threads used inside one oracle call (OpenMP over image rows, keypoints, queries: the "row-parallel" CPU baseline of
+// bench.py).  Default 1; every parallel loop writes per-item slots and keeps the serial order, so results do not depend on it.
+extern int g_threads;
+
 // ---- image primitives (image_ops.cpp) -------------------------------------------------
 int gauss_ksize(float sigma);                                  // detectors/helpers.cpp:720-721
 std::vector<float> gauss_kernel(int n, double sigma);          // OpenCV getGaussianKernel, CV_32F
