@@ -41,7 +41,7 @@ def cpu_baseline(img1, img2, seed):
     import orc
     import pipeline_oracle as po
     import refdeg
-    ncpu = os.cpu_count() or 1
+    ncpu = min(os.cpu_count() or 1, 64)   # one thread per core of a socket: the loops are short, more threads only add fork/join cost
 
     def verify(ra, rb, tc):
         un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=5, help="distinct synthetic pairs cycled through the steps")
+    ap.add_argument("--pairs", type=int, default=6, help="distinct synthetic pairs cycled through the steps")
     ap.add_argument("--pairs-per-step", type=int, default=32, help="image pairs in the batch that one step processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gpu-workers", type=int, default=3, help="pipeline threads running detect/describe/match (one context each)")
@@ -321,12 +321,12 @@ def main():
         iso = (i_ms, i_n, i_bytes, is_ms, is_n, is_bytes)
         del reps
         if not args.no_match_leg:
-            # BASELINE configs[4]-sized search: the regions of all first images against the regions of all second images
-            # of the benchmark's pairs, repeated until both lists hold ~50 k descriptors (N x M x 128)
+            # BASELINE configs[4]-sized search (~50 k descriptors per side, SURVEY 8d: N x M x 128): the regions of the first
+            # images of the benchmark's pairs against the regions of their second images
             rep_q, rep_t = pkg.ImgRep(bctx, 1 << 17), pkg.ImgRep(bctx, 1 << 17)
             k = 0
-            while min(len(rep_q), len(rep_t)) < 50000 and k < 64:
-                p = k % len(pairs_dev)
+            while k < len(pairs_dev):          # distinct images only (a repeated image would add exact duplicates)
+                p = k
                 bctx.detect_describe_dev(pairs_dev[p].data_ptr(), 2, W, H, params.det, params.desc)
                 rep_q.append_ctx(0); rep_t.append_ctx(1)
                 k += 1

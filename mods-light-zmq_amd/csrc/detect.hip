@@ -62,18 +62,22 @@ __device__ __forceinline__ bool nms_other_planes(const float *__restrict__ low, 
 
 // Hits are written as ballot words (one u64 per wave-row per level: no atomics); nms_compact_kernel
 // turns the words into the hit list with one atomic per block.
-// mask layout per octave: [n_img][S][h - 2*border][words], words = ceil((w - 2*border) / 64)
+// A wave covers NMS_COLS = 62 pixel columns: lanes 1..62 answer for a column each, lanes 0 and 63 only carry the columns beside
+// them, so that every lane loads ONE value per row and takes its left / right neighbours from the adjacent lanes (the
+// earlier form loaded three values per row and lane: the kernel is bound by the number of lane-loads, not by bytes).
+// mask layout per octave: [n_img][S][h - 2*border][words], words = ceil((w - 2*border) / 62), bit = lane
+constexpr int NMS_COLS = 62;
 __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__ P, int oi, DetectConst k,
                                                   unsigned long long *__restrict__ mask) {
   const OctaveDev &o = P->oct[oi];
   const int w = o.w, h = o.h;
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63;
-  const int c = k.border + blockIdx.x * 64 + lane;
+  const int c = k.border + blockIdx.x * NMS_COLS - 1 + lane;
   const int r_base = k.border + (blockIdx.y * 4 + (threadIdx.x >> 6)) * NMS_ROWS;
   const size_t plane = (size_t)w * h * b;
-  const bool col_ok = c < w - k.border;
-  const int cc = col_ok ? c : k.border;      // idle lanes read a valid column
+  const bool col_ok = lane >= 1 && lane <= NMS_COLS && c < w - k.border;
+  const int cc = c < w - 1 ? c : w - 1;      // lanes past the row read a valid column (c >= border - 1 >= 1)
   if (r_base >= h - k.border) return;
   const int ih = h - 2 * k.border, words = gridDim.x;
   // in-plane extrema above the gate are rare per lane but not per wave: they are collected into a wave-private LDS list and
@@ -84,15 +88,19 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
   const int wv = threadIdx.x >> 6;
   for (int lv = 1; lv <= k.n_scales; lv++) {
     const float *cur = o.resp[lv] + plane;
-    // the whole (NMS_ROWS+2) x 3 window of this thread is loaded up front: 30 independent loads in
-    // flight instead of a load -> compare chain per row
+    // the (NMS_ROWS+2)-row column of this lane is loaded up front (independent loads in flight), the columns beside it come
+    // from the neighbour lanes
     float win[NMS_ROWS + 2][3];
 #pragma unroll
     for (int rr = 0; rr < NMS_ROWS + 2; rr++) {
       int r = r_base - 1 + rr;
       r = r < h - 1 ? r : h - 1;             // rows past the image are never used (clamped to stay in bounds)
-      const float *p = cur + (size_t)r * w + cc;
-      win[rr][0] = p[-1]; win[rr][1] = p[0]; win[rr][2] = p[1];
+      win[rr][1] = cur[(size_t)r * w + cc];
+    }
+#pragma unroll
+    for (int rr = 0; rr < NMS_ROWS + 2; rr++) {
+      win[rr][0] = __shfl_up(win[rr][1], 1);
+      win[rr][2] = __shfl_down(win[rr][1], 1);
     }
     wave_sync();                              // the previous level's list and hit words have been consumed
     if (lane < NMS_ROWS) s_hit[wv][lane] = 0ull;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
       if (t < n_c) {
         const unsigned int code = s_code[wv][t];
         const int rr = code >> 7, ln = (code >> 1) & 63;
-        if (nms_other_planes(low, high, w, r_base + rr, k.border + blockIdx.x * 64 + ln, s_val[wv][t], (code & 1u) != 0))
+        if (nms_other_planes(low, high, w, r_base + rr, k.border + blockIdx.x * NMS_COLS - 1 + ln, s_val[wv][t], (code & 1u) != 0))
           atomicOr(&s_hit[wv][rr], 1ull << ln);
       }
     }
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(int oi, int w, int h, 
   const int lv = idx / (ih * words) + 1;
   const int rem = idx - (lv - 1) * ih * words;
   const int r = k.border + rem / words;
-  const int c0 = k.border + (rem % words) * 64;
+  const int c0 = k.border + (rem % words) * NMS_COLS - 1;   // bit = lane of nms_kernel (1..62)
   while (m) {
     const int bit = __ffsll((long long)m) - 1;
     m &= m - 1;
@@ -619,7 +627,7 @@ int detect_run(mods_ctx *ctx) {
       const OctaveDev &o = P.oct[oi];
       const int iw = o.w - 2 * par.border, ih = o.h - 2 * par.border;
       if (iw <= 0 || ih <= 0) continue;
-      const int words = (iw + 63) / 64;
+      const int words = (iw + NMS_COLS - 1) / NMS_COLS;
       dim3 grid(words, (ih + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), n_img);
       // the ballot words of this octave live at the start of the (not yet used) accept-list half of sort_idx
       unsigned long long *mask = (unsigned long long *)ctx->nms_mask;

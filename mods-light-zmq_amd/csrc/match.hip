@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
   const int jbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
   v4i bq[QB][4];
   int cq[QB], thr[QB];
-  unsigned long long mine[QB], sec[QB];
+  // smallest / second smallest key of every (query block, lane): in LDS, they are touched on the exact path only and the
+  // kernel has to stay at 128 VGPRs (4 waves per SIMD)
+  __shared__ unsigned long long s_keys[QB][2][256];
 #pragma unroll
   for (int b = 0; b < QB; b++) {
     const int j = jbase + 32 * b;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
     // (gthr starts at 0x7f7f7f7f = no bound): the global second key is at most any split's second key, so trains above it
     // cannot be among the two nearest
     thr[b] = __hip_atomic_load(&gthr[jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mine[b] = ~0ull; sec[b] = ~0ull;
+    s_keys[b][0][threadIdx.x] = ~0ull; s_keys[b][1][threadIdx.x] = ~0ull;
   }
   const int n_tiles = (k.n_t + 31) / 32;
   const int t0 = blockIdx.y * k.tiles_per_split;
@@ -185,19 +187,32 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
     for (int b = 0; b < QB; b++) {
       // -2*acc < thr  <=>  acc >= alim (one compare per accumulator)
       const int alim = (-thr[b] >> 1) + 1;
-      if (acc_max16(acc[b]) >= alim) {   // some train of this tile may be among the two nearest so far
+      // maxima of the four register groups (rows 8q + 4g .. 8q + 4g + 3): the exact path descends only into the groups
+      // that can hold a candidate (a wave takes the exact path as soon as ONE of its 64 lanes passes, and then every test
+      // inside it is a wave-level branch: 4 + 4 tests for the usual single candidate instead of 16)
+      int gm[4];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          if (acc[b][r] < alim) continue;                                  // d - cq >= -2*acc >= thr
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
-          const int t = tbase + row;
-          const int dpr = (int)((par >> row) & 1u) - 2 * acc[b][r];       // exact
-          if (t >= k.n_t || !(dpr < thr[b])) continue;
-          const unsigned long long key = ((unsigned long long)(unsigned int)(dpr + cq[b]) << 32) | (unsigned int)t;
-          if (key < mine[b]) { sec[b] = mine[b]; mine[b] = key; }
-          else if (key < sec[b]) sec[b] = key;
+      for (int q = 0; q < 4; q++) gm[q] = max(max(max(acc[b][4 * q], acc[b][4 * q + 1]), acc[b][4 * q + 2]), acc[b][4 * q + 3]);
+      if (max(max(max(gm[0], gm[1]), gm[2]), gm[3]) >= alim) {   // some train of this tile may be among the two nearest so far
+        unsigned long long mine_b = s_keys[b][0][threadIdx.x], sec_b = s_keys[b][1][threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (gm[q] < alim) continue;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int r = 4 * q + e;
+            if (acc[b][r] < alim) continue;                                  // d - cq >= -2*acc >= thr
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+            const int t = tbase + row;
+            const int dpr = (int)((par >> row) & 1u) - 2 * acc[b][r];       // exact
+            if (t >= k.n_t || !(dpr < thr[b])) continue;
+            const unsigned long long key = ((unsigned long long)(unsigned int)(dpr + cq[b]) << 32) | (unsigned int)t;
+            if (key < mine_b) { sec_b = mine_b; mine_b = key; }
+            else if (key < sec_b) sec_b = key;
+          }
         }
-        if (sec[b] != ~0ull) thr[b] = min(thr[b], (int)(sec[b] >> 32) - cq[b] + 1);    // an equal distance at a lower index still counts
+        s_keys[b][0][threadIdx.x] = mine_b; s_keys[b][1][threadIdx.x] = sec_b;
+        if (sec_b != ~0ull) thr[b] = min(thr[b], (int)(sec_b >> 32) - cq[b] + 1);    // an equal distance at a lower index still counts
       }
       // the two half-waves hold the same 32 queries (different train rows): the second key of their union is at most the
       // smaller of their second keys
@@ -217,10 +232,11 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
   const size_t n_qpad = (size_t)gridDim.x * 128 * QB;
 #pragma unroll
   for (int b = 0; b < QB; b++) {
-    const unsigned long long o1 = shfl_xor_u64(mine[b], 32), o2 = shfl_xor_u64(sec[b], 32);
-    const unsigned long long m1 = mine[b] < o1 ? mine[b] : o1;
-    const unsigned long long hi = mine[b] < o1 ? o1 : mine[b];
-    const unsigned long long lo2 = sec[b] < o2 ? sec[b] : o2;
+    const unsigned long long mine_b = s_keys[b][0][threadIdx.x], sec_b = s_keys[b][1][threadIdx.x];
+    const unsigned long long o1 = shfl_xor_u64(mine_b, 32), o2 = shfl_xor_u64(sec_b, 32);
+    const unsigned long long m1 = mine_b < o1 ? mine_b : o1;
+    const unsigned long long hi = mine_b < o1 ? o1 : mine_b;
+    const unsigned long long lo2 = sec_b < o2 ? sec_b : o2;
     const unsigned long long m2 = hi < lo2 ? hi : lo2;
     const int j = jbase + 32 * b;
     if (g == 0 && j < k.n_q) {

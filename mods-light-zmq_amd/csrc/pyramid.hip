@@ -164,12 +164,22 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float *__restrict
 // pairs.  Same arithmetic order as gauss_blur_kernel.
 // ---------------------------------------------------------------------------------------
 struct BlurTaps { float t[17]; };
+// overlapping tiles of the fused blur + response kernel: origins step by `step`, a tile blurs step + lap pixels
+__host__ __device__ static inline int blur_resp_tiles(int n, int step, int lap) { return n > lap ? (n - lap + step - 1) / step : 1; }
 constexpr int FB_TW = 128;   // tile width; the tile height is a template parameter (64: large planes, 16: small planes,
                              // where a short per-thread row chain matters more than halo reuse)
 
-template <int R, int FB_TH, int OV>
+// RESP = true additionally writes the Hessian response of the blurred plane (pyramid.cpp:196-254) to `resp`: the blurred tile
+// goes back to LDS after the column pass and a third phase makes the 3x3 stencil from it, so the blurred plane is not read
+// again from HBM (12 B/px per level instead of 8 + 8).  The stencil needs a 1-px ring of blurred values around the pixels a
+// workgroup answers for, so RESP tiles overlap: tile origins step by (FB_TW - 4, FB_TH - 2), a workgroup still blurs
+// FB_TW x FB_TH pixels (the overlap is blurred, and stored, twice with identical values) and owns the response of the
+// (FB_TW - 4) x (FB_TH - 2) pixels starting at (x0 + 1, y0 + 1).
+struct f4u { float x, y, z, w; } __attribute__((packed, aligned(4)));   // float4 store at a 4-byte aligned address
+
+template <int R, int FB_TH, int OV, bool RESP>
 __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
-                                                              BlurTaps taps) {
+                                                              BlurTaps taps, float *__restrict__ resp, float norm2) {
   constexpr int N = 2 * R + 1;
   constexpr int R4 = (R + 3) / 4;            // float4s on each side of the outputs
   constexpr int NV = 2 * R4 + OV;            // float4s in the register window
@@ -184,7 +194,9 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2), so every XCD gets a
   // contiguous band of tiles in (image, tile row, tile column) order and the halo rows shared by
   // vertically adjacent tiles are served by one L2 instead of being fetched by two.
-  const int tiles_x = (w + FB_TW - 1) / FB_TW, tiles_y = (h + FB_TH - 1) / FB_TH;
+  constexpr int SX = RESP ? FB_TW - 4 : FB_TW, SY = RESP ? FB_TH - 2 : FB_TH;   // tile origin steps
+  const int tiles_x = RESP ? blur_resp_tiles(w, SX, 4) : (w + FB_TW - 1) / FB_TW;
+  const int tiles_y = RESP ? blur_resp_tiles(h, SY, 2) : (h + FB_TH - 1) / FB_TH;
   const int nwg = gridDim.x;
   const int q8 = nwg / 8, r8 = nwg % 8;
   const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
   const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
   src += plane * img;
   dst += plane * img;
-  const int x0 = txi * FB_TW, y0 = tyi * FB_TH;
+  const int x0 = txi * SX, y0 = tyi * SY;
   // Row pass.  The memory pipeline takes about one clock per lane and load whatever the width, so the window of a thread is
   // kept wide: NO outputs from NV aligned float4 loads (1.25 loads per 4 outputs at OV = 1, R = 5..8; 0.75 at OV = 2).
   const int rc = tid % TPR;                   // output group within the row
@@ -259,6 +271,9 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
   // needs are read from LDS once into registers (instead of 2R + 1 reads per output).
   const int tc = tid & 31;                    // 4-pixel column group
   const int x4 = x0 + 4 * tc;
+  float4 bl[RESP ? FB_TH / 8 : 1];            // RESP: this thread's blurred outputs, for the response phase
+#pragma unroll
+  for (int k = 0; k < (RESP ? FB_TH / 8 : 1); k++) bl[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (x4 < w) {
     constexpr int RPT = FB_TH / 8;
     const int lyb = (tid >> 5) * RPT;
@@ -285,6 +300,76 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
           if (x4 + 2 < w) d[2] = s.z;
           if (x4 + 3 < w) d[3] = s.w;
         }
+        if constexpr (RESP) bl[k] = s;
+      }
+    }
+  }
+  if constexpr (RESP) {
+    // blurred tile -> LDS (the strip is dead once every thread holds its columns in registers)
+    __syncthreads();
+    {
+      constexpr int RPT = FB_TH / 8;
+      const int lyb = (tid >> 5) * RPT;
+#pragma unroll
+      for (int k = 0; k < RPT; k++) *(float4 *)(smem + (lyb + k) * FB_TW + 4 * tc) = bl[k];
+    }
+    __syncthreads();
+    // Response phase: thread = 4 columns x RQ rows of the owned region; rows / columns of the image frame and pixels whose
+    // stencil would leave the image hold 0 (the reference leaves the frame undefined and never reads it).
+    resp += plane * img;
+    constexpr int RQ = (SY + 7) / 8;
+    const int rg = tid >> 5;
+    if (tc < SX / 4) {
+      const int xr = x0 + 1 + 4 * tc;                     // first response column of this thread
+      float v[RQ + 2][6];
+#pragma unroll
+      for (int q = 0; q < RQ + 2; q++) {
+        const int ly = RQ * rg + q;                       // tile row of stencil row q (owned rows start at tile row 1)
+        if (ly < FB_TH) {
+          const float4 a = *(const float4 *)(smem + ly * FB_TW + 4 * tc);
+          const float2 b = *(const float2 *)(smem + ly * FB_TW + 4 * tc + 4);   // tc < 31: inside the row
+          v[q][0] = a.x; v[q][1] = a.y; v[q][2] = a.z; v[q][3] = a.w; v[q][4] = b.x; v[q][5] = b.y;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 6; e++) v[q][e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < RQ; k++) {
+        const int ly = RQ * rg + k + 1;                   // tile row of the output
+        const int y = y0 + ly;
+        if (ly <= SY && y < h) {
+          float o[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int x = xr + u;
+            float out = 0.f;
+            if (x < w - 1 && y >= 1 && y < h - 1) {        // x >= 1 by construction
+              const float v11 = v[k][u], v12 = v[k][u + 1], v13 = v[k][u + 2];
+              const float v21 = v[k + 1][u], v22 = v[k + 1][u + 1], v23 = v[k + 1][u + 2];
+              const float v31 = v[k + 2][u], v32 = v[k + 2][u + 1], v33 = v[k + 2][u + 2];
+              float Lxx = (v21 - 2 * v22 + v23);
+              float Lyy = (v12 - 2 * v22 + v32);
+              float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
+              out = (Lxx * Lyy - Lxy * Lxy) * norm2;
+            }
+            o[u] = out;
+          }
+          float *d = resp + (size_t)y * w + xr;
+          if (xr + 3 < w) { f4u q4; q4.x = o[0]; q4.y = o[1]; q4.z = o[2]; q4.w = o[3]; *(f4u *)d = q4; }
+          else {
+            if (xr < w) d[0] = o[0];
+            if (xr + 1 < w) d[1] = o[1];
+            if (xr + 2 < w) d[2] = o[2];
+          }
+          if (xr == 1) d[-1] = 0.f;                       // column 0 of the frame
+        }
+      }
+      if (y0 == 0 && rg == 0) {                           // row 0 of the frame
+        float *d = resp + xr;
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (xr + u < w) d[u] = 0.f;
+        if (xr == 1) d[-1] = 0.f;
       }
     }
   }
@@ -416,47 +501,68 @@ static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
 }
 
 template <int R>
-static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, const BlurTaps &taps) {
+static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, const BlurTaps &taps, float *resp,
+                             float norm2) {
 #ifndef BLUR_OV_BIG
 #define BLUR_OV_BIG 2   // float4 output groups per thread and strip row on the large planes
 #endif
 #define BLUR_TH_BIG 32   // measured on 1080p pairs: 32-row tiles (4 workgroups per CU, phases of different tiles overlap) beat 64-row tiles by ~15 %
   const int tiles64 = ((w + FB_TW - 1) / FB_TW) * ((h + 63) / 64) * n_img;
   if (tiles64 >= 384) {   // at least ~1.5 tiles per CU: large planes: 32-row tiles
-    const int tilesB = ((w + FB_TW - 1) / FB_TW) * ((h + BLUR_TH_BIG - 1) / BLUR_TH_BIG) * n_img;
-    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG>), dim3(tilesB), dim3(256), sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
+    const size_t lds = sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * FB_TW;
+    if (resp) {
+      const int tilesB = blur_resp_tiles(w, FB_TW - 4, 4) * blur_resp_tiles(h, BLUR_TH_BIG - 2, 2) * n_img;
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, true>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
+    } else {
+      const int tilesB = ((w + FB_TW - 1) / FB_TW) * ((h + BLUR_TH_BIG - 1) / BLUR_TH_BIG) * n_img;
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, false>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
+    }
   } else {                // small planes: short tiles, more workgroups, shorter per-thread row chains
-    const int tiles16 = ((w + FB_TW - 1) / FB_TW) * ((h + 15) / 16) * n_img;
-    hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1>), dim3(tiles16), dim3(256), sizeof(float) * (size_t)(16 + 2 * R) * FB_TW, ctx->stream, src, dst, w, h, taps);
+    const size_t lds = sizeof(float) * (size_t)(16 + 2 * R) * FB_TW;
+    if (resp) {
+      const int tiles16 = blur_resp_tiles(w, FB_TW - 4, 4) * blur_resp_tiles(h, 16 - 2, 2) * n_img;
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, true>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
+    } else {
+      const int tiles16 = ((w + FB_TW - 1) / FB_TW) * ((h + 15) / 16) * n_img;
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, false>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
+    }
   }
 }
 
-static int blur_with_slot(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, int slot, int n) {
+// blur of one level; resp != nullptr: the Hessian response of the blurred plane (norm = sigma^2 of the level) comes out of the
+// same launch (register-blocked kernel only; the generic kernel falls back to a separate response launch)
+static int blur_with_slot(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, int slot, int n, float *resp = nullptr,
+                          float norm = 0.f) {
   const int r = n / 2;
   if (r >= 1 && r <= 8 && ctx->taps_host_n[slot] == n) {
     BlurTaps taps;
     for (int i = 0; i < 17; i++) taps.t[i] = i < n ? ctx->taps_host[slot][i] : 0.f;
     // (the two tile instantiations are timed separately: launches of the small planes are launch-size bound)
     const bool big_tiles = ((w + FB_TW - 1) / FB_TW) * ((h + 63) / 64) * n_img >= 384;
-    StageScope ts(ctx, big_tiles ? MODS_STAGE_BLUR : MODS_STAGE_BLUR_SMALL, 8.0 * w * h * n_img);
+    // algorithmic bytes of the launch by SURVEY 8d's unfused model: 8 B/px for the blur (+ 8 B/px for the response)
+    StageScope ts(ctx, big_tiles ? MODS_STAGE_BLUR : MODS_STAGE_BLUR_SMALL, (resp ? 16.0 : 8.0) * w * h * n_img);
+    const float norm2 = norm * norm;
     switch (r) {
-      case 1: launch_fast_blur<1>(ctx, src, dst, w, h, n_img, taps); break;
-      case 2: launch_fast_blur<2>(ctx, src, dst, w, h, n_img, taps); break;
-      case 3: launch_fast_blur<3>(ctx, src, dst, w, h, n_img, taps); break;
-      case 4: launch_fast_blur<4>(ctx, src, dst, w, h, n_img, taps); break;
-      case 5: launch_fast_blur<5>(ctx, src, dst, w, h, n_img, taps); break;
-      case 6: launch_fast_blur<6>(ctx, src, dst, w, h, n_img, taps); break;
-      case 7: launch_fast_blur<7>(ctx, src, dst, w, h, n_img, taps); break;
-      default: launch_fast_blur<8>(ctx, src, dst, w, h, n_img, taps); break;
+      case 1: launch_fast_blur<1>(ctx, src, dst, w, h, n_img, taps, resp, norm2); break;
+      case 2: launch_fast_blur<2>(ctx, src, dst, w, h, n_img, taps, resp, norm2); break;
+      case 3: launch_fast_blur<3>(ctx, src, dst, w, h, n_img, taps, resp, norm2); break;
+      case 4: launch_fast_blur<4>(ctx, src, dst, w, h, n_img, taps, resp, norm2); break;
+      case 5: launch_fast_blur<5>(ctx, src, dst, w, h, n_img, taps, resp, norm2); break;
+      case 6: launch_fast_blur<6>(ctx, src, dst, w, h, n_img, taps, resp, norm2); break;
+      case 7: launch_fast_blur<7>(ctx, src, dst, w, h, n_img, taps, resp, norm2); break;
+      default: launch_fast_blur<8>(ctx, src, dst, w, h, n_img, taps, resp, norm2); break;
     }
     MODS_HIP_CHECK(hipGetLastError());
     return MODS_OK;
   }
   const size_t lds = sizeof(float) * ((size_t)(BLUR_TH + 2 * r) * (BLUR_TW + 2 * r) + (size_t)(BLUR_TH + 2 * r) * BLUR_TW + 64);
   dim3 grid((w + BLUR_TW - 1) / BLUR_TW, (h + BLUR_TH - 1) / BLUR_TH, n_img);
-  StageScope ts(ctx, MODS_STAGE_BLUR, 8.0 * w * h * n_img);
-  hipLaunchKernelGGL(gauss_blur_kernel, grid, dim3(256), lds, ctx->stream, src, dst, w, h, ctx->gauss_taps_dev + slot * 64, n);
-  MODS_HIP_CHECK(hipGetLastError());
+  {
+    StageScope ts(ctx, MODS_STAGE_BLUR, 8.0 * w * h * n_img);
+    hipLaunchKernelGGL(gauss_blur_kernel, grid, dim3(256), lds, ctx->stream, src, dst, w, h, ctx->gauss_taps_dev + slot * 64, n);
+    MODS_HIP_CHECK(hipGetLastError());
+  }
+  if (resp) return launch_hessian_response(ctx, dst, resp, w, h, n_img, norm);
   return MODS_OK;
 }
 
@@ -585,18 +691,20 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
                                     (size_t)h * n_img, hipMemcpyDeviceToDevice, ctx->stream));
     src0 = packed;
   }
+  // every blur launch also writes the Hessian response of its output (fused kernel): the separate response launch is left for
+  // the first level of the octaves that start from a decimated plane
   if (initial_blur) {
-    if ((rc = blur_with_slot(ctx, src0, P.oct[0].blur[0], w, h, n_img, 0, ntap[0]))) return rc;
+    if ((rc = blur_with_slot(ctx, src0, P.oct[0].blur[0], w, h, n_img, 0, ntap[0], P.oct[0].resp[0], P.oct[0].sigma[0] * P.oct[0].sigma[0]))) return rc;
   } else {
     MODS_HIP_CHECK(hipMemcpyAsync(P.oct[0].blur[0], src0, sizeof(float) * (size_t)w * h * n_img, hipMemcpyDeviceToDevice, ctx->stream));
   }
   for (int oi = 0; oi < P.n_oct; oi++) {
     OctaveDev &o = P.oct[oi];
-    if ((rc = launch_hessian_response(ctx, o.blur[0], o.resp[0], o.w, o.h, n_img, o.sigma[0] * o.sigma[0]))) return rc;
+    if (oi > 0 || !initial_blur)
+      if ((rc = launch_hessian_response(ctx, o.blur[0], o.resp[0], o.w, o.h, n_img, o.sigma[0] * o.sigma[0]))) return rc;
     for (int l = 1; l < P.n_levels; l++) {
-      if ((rc = blur_with_slot(ctx, o.blur[l - 1], o.blur[l], o.w, o.h, n_img, l, ntap[l]))) return rc;
       const float sigma = o.sigma[l - 1] * sigmaStep;   // pyramid.cpp:455-458
-      if ((rc = launch_hessian_response(ctx, o.blur[l], o.resp[l], o.w, o.h, n_img, sigma * sigma))) return rc;
+      if ((rc = blur_with_slot(ctx, o.blur[l - 1], o.blur[l], o.w, o.h, n_img, l, ntap[l], o.resp[l], sigma * sigma))) return rc;
       if (l == S && oi + 1 < P.n_oct) {
         OctaveDev &nx = P.oct[oi + 1];
         if ((rc = launch_resize_half(ctx, o.blur[l], nx.blur[0], o.w, o.h, nx.w, nx.h, n_img))) return rc;

@@ -222,9 +222,11 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
   const double imageToPatchScale = double(patchImageSize) / (double)patchSize;
   std::vector<Region> slot(in.size());
   std::vector<char> ok(in.size(), 0);
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 16)
+#pragma omp parallel num_threads(g_threads)
+  {
+  Img patch(patchSize, patchSize);
+#pragma omp for schedule(dynamic, 16)
   for (long i = 0; i < (long)in.size(); i++) {
-    Img patch(patchSize, patchSize);
     const Region &k = in[i];
     float curr_sc = (float)(imageToPatchScale * k.s);
     if (interpolate_check_borders(img.w, img.h, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12, (float)k.a21,
@@ -246,6 +248,7 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
       slot[i] = t; ok[i] = 1;
     }
   }
+  }   // omp parallel
   for (size_t i = 0; i < in.size(); i++)
     if (ok[i]) tmp.push_back(slot[i]);
   out.swap(tmp);
@@ -394,11 +397,14 @@ void extract_desc_patch(const Region &k, const Img &img, double mrSize, int patc
 }
 
 void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize, bool photoNorm) {
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 16)
-  for (long i = 0; i < (long)r.size(); i++) {
+#pragma omp parallel num_threads(g_threads)
+  {
     Img patch(patchSize, patchSize);
-    extract_desc_patch(r[i], img, mrSize, patchSize, photoNorm, patch);
-    sift_patch_to_desc(patch, r[i].desc, true, 0.2);   // [SIFTDescriptor] maxBinValue = 0.2 (io_mods.cpp:427)
+#pragma omp for schedule(dynamic, 16)
+    for (long i = 0; i < (long)r.size(); i++) {
+      extract_desc_patch(r[i], img, mrSize, patchSize, photoNorm, patch);
+      sift_patch_to_desc(patch, r[i].desc, true, 0.2);   // [SIFTDescriptor] maxBinValue = 0.2 (io_mods.cpp:427)
+    }
   }
 }
 

@@ -26,11 +26,13 @@ int match_fginn(const std::vector<Region> &list1, const std::vector<Region> &lis
   const int K = std::min(nn, M);
   std::vector<Tentative> slot(list1.size());
   std::vector<char> have(list1.size(), 0);
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
+#pragma omp parallel num_threads(g_threads)
+  {
+  std::vector<std::pair<float, int>> all(M);     // per-thread scratch
+  std::vector<int> idx(K);
+  std::vector<float> dst(K);
+#pragma omp for schedule(dynamic, 8)
   for (long i = 0; i < (long)list1.size(); i++) {
-    std::vector<std::pair<float, int>> all(M);
-    std::vector<int> idx(K);
-    std::vector<float> dst(K);
     for (int t = 0; t < M; t++) {
       float d = 0;
       for (int q = 0; q < 128; q++) {
@@ -60,6 +62,7 @@ int match_fginn(const std::vector<Region> &list1, const std::vector<Region> &lis
       if (sqminratio < 1.0 && dist1 > contrDistSq) break;   // first contradictive
     }
   }
+  }   // omp parallel
   for (size_t i = 0; i < list1.size(); i++)
     if (have[i]) out.push_back(slot[i]);
   return (int)out.size();
