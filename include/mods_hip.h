@@ -151,6 +151,12 @@ typedef struct mods_describe_params {
   int photoNorm;           /* 1 */
   int rootSift;            /* 1 = RootSIFT, 0 = SIFT */
   double maxBinValue;      /* 0.2 */
+  /* Half descriptors (imagerepresentation.cpp:725-731, 909-943, 970-979; siftdesc.cpp:401-436).  As soon as a step's
+   * descriptor list names a "Half*" descriptor the reference estimates the dominant orientation in doHalfSIFT mode
+   * (orientation modulo pi: histogram bins i and i + 18 folded after the threshold is taken) for EVERY descriptor of the view. */
+  int ori_halfMode;        /* 0 */
+  int halfDesc;            /* 1: also HalfRootSIFT (64 values: orientation bins j and j + 4 of the raw histogram added, then the
+                              RootSIFT normalisation) for the same regions, see mods_regions_half_dev */
 } mods_describe_params;
 
 /* Replaces, for one identity view (H = I), the chain of imagerepresentation.cpp:867-968:
@@ -219,6 +225,9 @@ int mods_detect_describe_view_dev(mods_ctx *ctx, const float *src_dev, int w, in
                                   double zoom, double initSigma, int doBlur, const mods_hessaff_params *det,
                                   const mods_describe_params *desc, mods_view_geom *geom_out, int *n_detected, int *n_regions);
 const mods_region *mods_regions_dev(mods_ctx *ctx, int img);     /* device pointer of the region list of image `img` */
+/* the same regions with desc[0..63] = HalfRootSIFT, desc[64..127] = 0 (filled when mods_describe_params.halfDesc was set) */
+const mods_region *mods_regions_half_dev(mods_ctx *ctx, int img);
+int mods_regions_fetch_half(mods_ctx *ctx, int img, mods_region *out, int max_out, int *n_out);
 int mods_regions_copy_dev(mods_ctx *ctx, int img, mods_region *dst_dev, int n);   /* D2D copy of its first n entries */
 const float *mods_view_pixels_dev(mods_ctx *ctx);                /* pixels of the last synthesised view (w_new x h_new) */
 int mods_view_fetch(mods_ctx *ctx, const mods_view_geom *geom, float *dst_host);   /* host copy of those pixels */
@@ -361,7 +370,11 @@ typedef struct mods_ladder_step {     /* one [HessianAffine<i>] section of the i
   double phi;                         /* Phi: rotation density in degrees */
   double initSigma;                   /* initSigma */
   int doBlur;                         /* 1 (io_mods.cpp:475) */
-  double fginn_ratio;                 /* FGINNThreshold of RootSIFT */
+  double fginn_ratio;                 /* FGINNThreshold of RootSIFT (0: RootSIFT lists are not matched) */
+  int half_orientation;               /* a descriptor of the step is a Half* one: orientation in doHalfSIFT mode for all of them */
+  double fginn_ratio_half;            /* FGINNThreshold of HalfRootSIFT; 0: not described / not matched.  [Matching<i>]
+                                         SeparateDescriptors = RootSIFT,HalfRootSIFT: both lists are matched, tentatives joined
+                                         (correspondencebank.cpp:288-340) */
 } mods_ladder_step;
 typedef struct mods_ladder_result {
   int steps_done, n_views;            /* steps executed; views synthesised (both images) */
@@ -381,6 +394,7 @@ int mods_imgrep_clear(mods_imgrep *rep);
 int mods_imgrep_count(const mods_imgrep *rep);
 const mods_region *mods_imgrep_regions_dev(const mods_imgrep *rep);
 int mods_imgrep_append_ctx(mods_imgrep *rep, mods_ctx *ctx, int img);      /* regions the context holds for image slot img */
+int mods_imgrep_append_ctx_half(mods_imgrep *rep, mods_ctx *ctx, int img); /* their HalfRootSIFT twins */
 int mods_imgrep_append_dev(mods_imgrep *rep, const mods_region *src_dev, int n);
 int mods_imgrep_append_host(mods_imgrep *rep, const mods_region *src, int n);
 int mods_imgrep_fetch(mods_imgrep *rep, int begin, int count, mods_region *out);

@@ -54,12 +54,13 @@ class DescribeParams(C.Structure):
     """[DominantOrientation] + [SIFTDescriptor] (io_mods.cpp:731-740, 423-436)."""
     _fields_ = [("ori_mrSize", C.c_double), ("ori_patchSize", C.c_int), ("ori_maxAngles", C.c_int),
                 ("ori_threshold", C.c_double), ("desc_mrSize", C.c_double), ("desc_patchSize", C.c_int),
-                ("photoNorm", C.c_int), ("rootSift", C.c_int), ("maxBinValue", C.c_double)]
+                ("photoNorm", C.c_int), ("rootSift", C.c_int), ("maxBinValue", C.c_double),
+                ("ori_halfMode", C.c_int), ("halfDesc", C.c_int)]
 
     @staticmethod
     def default():
         # config_affori_classic.ini; threshold is parsed into a float member (descriptors_parameters.hpp:10)
-        return DescribeParams(5.1962, 32, 1, float(np.float32(0.8)), 5.1962, 41, 1, 1, 0.2)
+        return DescribeParams(5.1962, 32, 1, float(np.float32(0.8)), 5.1962, 41, 1, 1, 0.2, 0, 0)
 
 
 _lib = None
@@ -229,6 +230,13 @@ class Context:
         n = C.c_int()
         _check(lib().mods_orient_describe(self.h, _fp(a), a.shape[1], a.shape[0], a.shape[1], k.ctypes.data_as(C.c_void_p),
                                           len(k), C.byref(params), out.ctypes.data_as(C.c_void_p), max_out, C.byref(n)))
+        return out[:n.value].copy()
+
+    def regions_fetch_half(self, img=0, max_out=1 << 18):
+        """HalfRootSIFT twins of the regions of image slot img (desc[:64]; describe with DescribeParams.halfDesc = 1)."""
+        out = np.zeros(max_out, REGION_DTYPE)
+        n = C.c_int()
+        _check(lib().mods_regions_fetch_half(self.h, img, out.ctypes.data_as(C.c_void_p), max_out, C.byref(n)))
         return out[:n.value].copy()
 
     def detect_describe_dev(self, dev_ptr, n_img, w, h, det=None, desc=None):
@@ -494,22 +502,29 @@ class ViewPar(C.Structure):
 class LadderStep(C.Structure):
     """One [HessianAffine<i>] section of an iterations .ini (io_mods.cpp:457-492)."""
     _fields_ = [("scale_set", C.c_double * 8), ("n_scales", C.c_int), ("tilt_set", C.c_double * 8), ("n_tilts", C.c_int),
-                ("phi", C.c_double), ("initSigma", C.c_double), ("doBlur", C.c_int), ("fginn_ratio", C.c_double)]
+                ("phi", C.c_double), ("initSigma", C.c_double), ("doBlur", C.c_int), ("fginn_ratio", C.c_double),
+                ("half_orientation", C.c_int), ("fginn_ratio_half", C.c_double)]
 
     @staticmethod
-    def make(tilts, phi, scales=(1.0,), init_sigma=0.2, do_blur=1, fginn=0.8):
+    def make(tilts, phi, scales=(1.0,), init_sigma=0.2, do_blur=1, fginn=0.8, half_orientation=0, fginn_half=0.0):
+        """half_orientation: the step's descriptor list names a Half* descriptor; fginn_half > 0: HalfRootSIFT lists are built and
+        matched too (SeparateDescriptors = RootSIFT,HalfRootSIFT)."""
         s = LadderStep()
         for i, v in enumerate(scales):
             s.scale_set[i] = v
         for i, v in enumerate(tilts):
             s.tilt_set[i] = v
         s.n_scales, s.n_tilts, s.phi, s.initSigma, s.doBlur, s.fginn_ratio = len(scales), len(tilts), phi, init_sigma, do_blur, fginn
+        s.half_orientation, s.fginn_ratio_half = half_orientation, fginn_half
         return s
 
 
-def iters_mods_steps():
-    """[HessianAffine2] and [HessianAffine3] of build/iters_MODS.ini (the HessianAffine steps of the MODS ladder)."""
-    return [LadderStep.make((1, 2, 4, 6, 8), 360.0), LadderStep.make((1, 2, 4, 6, 8), 120.0)]
+def iters_mods_steps(half=True):
+    """[HessianAffine2] and [HessianAffine3] of build/iters_MODS.ini (the HessianAffine steps of the MODS ladder):
+    Descriptors = RootSIFT,HalfRootSIFT with FGINNThreshold = 0.8 for the first of them only, i.e. the orientation runs in
+    doHalfSIFT mode and the RootSIFT lists are matched (the reference reads the missing second threshold past the end of a
+    one-element vector; it is 0 here: HalfRootSIFT lists are not matched)."""
+    return [LadderStep.make((1, 2, 4, 6, 8), 360.0, half_orientation=int(half)), LadderStep.make((1, 2, 4, 6, 8), 120.0, half_orientation=int(half))]
 
 
 class LadderResult(C.Structure):

@@ -175,10 +175,33 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
         std::string name = descs[k];
         name.erase(0, name.find_first_not_of(" \t"));
         name.erase(name.find_last_not_of(" \t") + 1);
+        // a "Half*" name anywhere in the list switches the step's orientation estimate to doHalfSIFT mode for every descriptor
+        // (imagerepresentation.cpp:725-731)
+        if (name.find("Half") != std::string::npos) st.half_orientation = 1;
         if (name == "RootSIFT") { has_root = true; st.fginn_ratio = k < fginn.size() ? fginn[k] : 0.0; }
         else if (name == "ZMQ") { has_zmq = true; zmq_ratio = k < fginn.size() ? fginn[k] : 0.0; }
+        else if (name == "HalfRootSIFT") {
+          // the reference indexes FGINNThreshold by the descriptor's position without a bounds check (synth-detection.cpp:221):
+          // a missing entry is read past the end of the vector; it counts as 0 = "not matched" here
+          if (k < fginn.size()) st.fginn_ratio_half = fginn[k];
+          else std::cerr << "Warning: " << sec << ": no FGINNThreshold for HalfRootSIFT: its lists are not matched" << std::endl;
+        }
         else if (!name.empty()) std::cerr << "Warning: " << sec << ": descriptor " << name << " is outside this build" << std::endl;
       }
+      // [Matching<i>] SeparateDescriptors: only the listed descriptors are matched (correspondencebank.cpp:288-299)
+      const std::string msec = "Matching" + std::to_string(i);
+      if (it.Has(msec, "SeparateDescriptors")) {
+        bool root_listed = false, half_listed = false;
+        for (std::string name : it.GetStringVector(msec, "SeparateDescriptors")) {
+          name.erase(0, name.find_first_not_of(" \t"));
+          name.erase(name.find_last_not_of(" \t") + 1);
+          root_listed = root_listed || name == "RootSIFT" || name == "ZMQ";
+          half_listed = half_listed || name == "HalfRootSIFT";
+        }
+        if (!half_listed) st.fginn_ratio_half = 0.0;
+        if (!root_listed && has_root) std::cerr << "Warning: " << msec << ": SeparateDescriptors does not list the step's descriptor; it is matched anyway" << std::endl;
+      }
+      if (st.fginn_ratio_half != 0 && !(st.fginn_ratio_half > 0 && st.fginn_ratio_half < 1)) { std::cerr << sec << ": FGINNThreshold of HalfRootSIFT must lie in (0, 1)" << std::endl; return 1; }
       if (has_zmq && !has_root) {      // the daemon's descriptor takes the place of RootSIFT for the whole run
         cfg->use_zmq = true; has_root = true; st.fginn_ratio = zmq_ratio;
       } else if (has_zmq) std::cerr << "Warning: " << sec << ": RootSIFT and ZMQ in one step: RootSIFT is used" << std::endl;

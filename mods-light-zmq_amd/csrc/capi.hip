@@ -117,7 +117,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->tmp_dev); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
   (void)hipHostFree(c->host_counts);
-  (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
+  (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
   (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipFree(c->m_u6); (void)hipFree(c->m_laf); (void)hipFree(c->m_count); (void)hipFree(c->m_regs);
@@ -336,6 +336,24 @@ int mods_regions_fetch(mods_ctx *c, int img, mods_region *out, int max_out, int 
     MODS_HIP_CHECK(hipMemcpy(out, c->regions_dev + (size_t)img * c->max_cand, sizeof(mods_region) * n, hipMemcpyDeviceToHost));
   }
   return MODS_OK;
+}
+
+int mods_regions_fetch_half(mods_ctx *c, int img, mods_region *out, int max_out, int *n_out) {
+  if (!c || img < 0 || img >= c->batch || !n_out) return MODS_E_ARG;
+  if (!c->have_half || !c->regions_half_dev) { set_error("no HalfRootSIFT descriptors: the last describe call did not ask for them"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  int n = 0;
+  MODS_HIP_CHECK(hipMemcpy(&n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
+  *n_out = n;
+  if (out) {
+    if (n > max_out) { set_error("region output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
+    MODS_HIP_CHECK(hipMemcpy(out, c->regions_half_dev + (size_t)img * c->max_cand, sizeof(mods_region) * n, hipMemcpyDeviceToHost));
+  }
+  return MODS_OK;
+}
+const mods_region *mods_regions_half_dev(mods_ctx *c, int img) {
+  return (c && c->have_half && c->regions_half_dev) ? c->regions_half_dev + (size_t)img * c->max_cand : nullptr;
 }
 
 int mods_orient_describe(mods_ctx *c, const float *img, int w, int h, int stride, const mods_affkey *keys, int n_keys,

@@ -103,6 +103,8 @@ struct mods_ctx {
   int desc_ori_ps = 0, desc_ps = 0;
   void *ori_dev = nullptr;           // [batch][max_cand] OriOut
   mods_region *regions_dev = nullptr;  // [batch][max_cand]
+  mods_region *regions_half_dev = nullptr;   // HalfRootSIFT twins (allocated on first use)
+  bool have_half = false;
   int *region_count = nullptr;       // [batch]
   int *inside_count = nullptr;       // [batch] keypoints that pass the centre test (the reference's unoriented list)
   std::vector<int> last_inside_counts;

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void ori_bin_table_kernel() {
 // (uniform across lanes).
 // ---------------------------------------------------------------------------------------
 __device__ bool dominant_angle_wave(const float *s_patch, const float *__restrict__ orimask, int ps, double th,
-                                    float *s_val, unsigned char *s_bin, float *s_hist, float *angle_out) {
+                                    float *s_val, unsigned char *s_bin, float *s_hist, float *angle_out, int half = 0) {
   const int lane = threadIdx.x;
   const int bins = 36;
   const float PIf = 3.14159265358979323846f;
@@ -104,6 +104,13 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
   for (int i = 0; i < bins; i++)
     if (s_hist[i] > thresh) thresh = s_hist[i];
   thresh = (float)((double)thresh * th);
+  if (half) {   // doHalfSIFT (synth-detection.cpp:891-898): bins i and i + 18 folded AFTER the threshold was taken
+    float nv = 0.f;
+    if (lane < bins / 2) nv = s_hist[lane] + s_hist[lane + bins / 2];
+    __syncthreads();
+    if (lane < bins) s_hist[lane] = lane < bins / 2 ? nv : 0.f;
+    __syncthreads();
+  }
   bool peak = false;
   if (lane < bins) {
     const int a = lane == 0 ? bins - 1 : lane - 1, c = lane == bins - 1 ? 0 : lane + 1;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
       }
       __syncthreads();
       float ang = 0.f;
-      const bool found = dominant_angle_wave(s_patch, orimask, ps, k.ori_th, s_val, s_bin, s_hist, &ang);
+      const bool found = dominant_angle_wave(s_patch, orimask, ps, k.ori_th, s_val, s_bin, s_hist, &ang, k.ori_half);
       if (!found) alive = false;
       else {
         double si, ci;
@@ -612,6 +619,7 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   k.ori_i2p = double(2 * int(par->ori_mrSize) + 1) / (double)par->ori_patchSize;
   k.max_angles = par->ori_maxAngles;
   k.ori_th = par->ori_threshold;
+  k.ori_half = par->ori_halfMode; k.half_desc = 0;
   k.desc_mr = par->desc_mrSize; k.desc_ps = par->desc_patchSize; k.photo = par->photoNorm; k.root = par->rootSift;
   k.max_bin = par->maxBinValue;
   k.patch_rule = 0;
@@ -635,11 +643,18 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   }
   rc = launch_extract_and_sift(ctx, img_dev, n_img, k, dmask, tab, !external);
   if (rc) return rc;
+  ctx->have_half = false;
+  if (par->halfDesc && !external) {
+    if ((rc = launch_half_sift(ctx, n_img, k, dmask, tab))) return rc;
+    ctx->have_half = true;
+  }
   if (external && (rc = external_describe(ctx, n_img, k))) return rc;
   if (det_copy_dev)
     MODS_HIP_CHECK(hipMemcpyAsync(det_copy_dev, ctx->regions_dev, sizeof(mods_region) * (size_t)ctx->max_cand, hipMemcpyDeviceToDevice, ctx->stream));
   if (k.view) {
     hipLaunchKernelGGL(reproject_regions_kernel, dim3(256), dim3(256), 0, ctx->stream, k, ctx->regions_dev, ctx->region_count);
+    if (ctx->have_half)
+      hipLaunchKernelGGL(reproject_regions_kernel, dim3(256), dim3(256), 0, ctx->stream, k, ctx->regions_half_dev, ctx->region_count);
     MODS_HIP_CHECK(hipGetLastError());
   }
   return MODS_OK;

@@ -13,6 +13,8 @@ struct DescConst {
   double ori_i2p;          // imageToPatchScale of DetectOrientation = (2*int(mrSize)+1)/patchSize
   int max_angles;
   double ori_th;
+  int ori_half;            // doHalfSIFT of EstimateDominantAnglesFunctor
+  int half_desc;           // sift_kernel: HalfRootSIFT (64 values) instead of the 128-value descriptor
   double desc_mr;
   int desc_ps;
   int photo, root;
@@ -37,6 +39,9 @@ struct SiftTab {           // precomputeBinsAndWeights, siftdesc.cpp:22-71 (host
 // sift.hip
 int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, DescConst k, const float *dmask, const SiftTab *tab,
                             bool run_sift = true);
+// HalfRootSIFT twins of the described regions: copies regions_dev to regions_half_dev and overwrites the descriptors from the
+// patch store left by launch_extract_and_sift (block-per-region SIFT kernel)
+int launch_half_sift(mods_ctx *ctx, int n_img, DescConst k, const float *dmask, const SiftTab *tab);
 int launch_sift_patch_test(mods_ctx *ctx, const float *patch_dev, int ps, int root, double max_bin, uint8_t *out_dev);
 
 }  // namespace mods

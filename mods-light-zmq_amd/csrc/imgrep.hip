@@ -127,20 +127,24 @@ int mods_imgrep_count(const mods_imgrep *r) { return r ? r->n : 0; }
 const mods_region *mods_imgrep_regions_dev(const mods_imgrep *r) { return r ? r->reg : nullptr; }
 
 // AddRegions: the regions the context holds for image slot `img` (after mods_detect_describe[_view]_dev)
-int mods_imgrep_append_ctx(mods_imgrep *r, mods_ctx *c, int img) {
+static int imgrep_append_from(mods_imgrep *r, mods_ctx *c, int img, const mods_region *base) {
   if (!r || !c || img < 0 || img >= (int)c->last_region_counts.size()) { set_error("imgrep_append: nothing described in that slot"); return MODS_E_ARG; }
   const int n = c->last_region_counts[img];
   if (r->n + n > r->cap) { set_error("imgrep: capacity %d exceeded (%d + %d)", r->cap, r->n, n); return MODS_E_CAPACITY; }
   if (n == 0) return MODS_OK;
   MODS_HIP_CHECK(hipSetDevice(r->device));
-  MODS_HIP_CHECK(hipMemcpyAsync(r->reg + r->n, c->regions_dev + (size_t)img * c->max_cand, sizeof(mods_region) * (size_t)n,
+  MODS_HIP_CHECK(hipMemcpyAsync(r->reg + r->n, base + (size_t)img * c->max_cand, sizeof(mods_region) * (size_t)n,
                                 hipMemcpyDeviceToDevice, c->stream));
   if (r->n > 0) hipLaunchKernelGGL(shift_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, r->reg + r->n, n, r->n);
   MODS_HIP_CHECK(hipGetLastError());
   r->n += n;
   return MODS_OK;
 }
-// the same from a device buffer (e.g. the slice of an all-gather) or a host array
+int mods_imgrep_append_ctx(mods_imgrep *r, mods_ctx *c, int img) { return imgrep_append_from(r, c, img, c ? c->regions_dev : nullptr); }
+int mods_imgrep_append_ctx_half(mods_imgrep *r, mods_ctx *c, int img) {
+  if (!c || !c->have_half || !c->regions_half_dev) { set_error("imgrep_append: no HalfRootSIFT descriptors in the context"); return MODS_E_ARG; }
+  return imgrep_append_from(r, c, img, c->regions_half_dev);
+}
 int mods_imgrep_append_dev(mods_imgrep *r, const mods_region *src_dev, int n) {
   if (!r || (n > 0 && !src_dev)) { set_error("imgrep_append_dev: null argument"); return MODS_E_ARG; }
   if (r->n + n > r->cap) { set_error("imgrep: capacity %d exceeded (%d + %d)", r->cap, r->n, n); return MODS_E_CAPACITY; }
@@ -204,20 +208,30 @@ static void copy_verified(mods_ctx *c, const mods_ladder_result *res, double *ma
 // match bank 1 against bank 2, drop duplicates, verify (MatchImgReps + DuplicateFiltering + LORANSACFiltering,
 // mods.cpp:288-383): fills the match / verification fields of res and mask (one byte per unique tentative)
 static int match_verify_banks(mods_ctx *c, mods_imgrep *rep1, mods_imgrep *rep2, double fginn_ratio, const mods_pair_params *par,
-                              mods_ladder_result *res) {
+                              mods_ladder_result *res, mods_imgrep *rep1h = nullptr, mods_imgrep *rep2h = nullptr, double fginn_ratio_half = 0) {
   int rc;
   const double t1 = now_ms2();
   int n = 0;
-  if ((rc = match_run(c, rep1->reg, rep1->n, rep2->reg, rep2->n, fginn_ratio, par->contradDist, par->nn))) return rc;
-  MODS_HIP_CHECK(hipMemcpyAsync(&n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
-  if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
-  c->h_tent.resize(n); c->h_u6.resize((size_t)n * 6); c->h_laf.resize((size_t)n * 14);
-  if (n > 0) {
-    MODS_HIP_CHECK(hipMemcpyAsync(c->h_tent.data(), c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipMemcpyAsync(c->h_u6.data(), c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipMemcpyAsync(c->h_laf.data(), c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost, c->stream));
+  c->h_tent.clear(); c->h_u6.clear(); c->h_laf.clear();
+  // [Matching<i>] SeparateDescriptors = RootSIFT[,HalfRootSIFT]: one FGINN search per descriptor whose threshold is > 0
+  // (correspondencebank.cpp:288-340), tentatives joined in that order
+  for (int pass = 0; pass < 2; pass++) {
+    mods_imgrep *q = pass ? rep1h : rep1, *t = pass ? rep2h : rep2;
+    const double ratio = pass ? fginn_ratio_half : fginn_ratio;
+    if (!q || !t || !(ratio > 0)) continue;
+    int m = 0;
+    if ((rc = match_run(c, q->reg, q->n, t->reg, t->n, ratio, par->contradDist, par->nn))) return rc;
+    MODS_HIP_CHECK(hipMemcpyAsync(&m, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (m > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
+    c->h_tent.resize(n + m); c->h_u6.resize((size_t)(n + m) * 6); c->h_laf.resize((size_t)(n + m) * 14);
+    if (m > 0) {
+      MODS_HIP_CHECK(hipMemcpyAsync(c->h_tent.data() + n, c->m_tent, sizeof(mods_tentative) * m, hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(hipMemcpyAsync(c->h_u6.data() + (size_t)n * 6, c->m_u6, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(hipMemcpyAsync(c->h_laf.data() + (size_t)n * 14, c->m_laf, sizeof(double) * 14 * m, hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    n += m;
   }
   const double t2 = now_ms2();
   res->ms_match += t2 - t1;
@@ -243,11 +257,22 @@ int mods_match_ladder_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, co
   std::vector<mods_view_par> hist(1024), views(256);
   int n_hist = 0, rc;
   int curr_matches = 0;
+  // HalfRootSIFT banks (the reference keeps one region list per descriptor name): created when a step asks for them
+  mods_imgrep *rep1h = nullptr, *rep2h = nullptr;
+  struct HalfGuard { mods_imgrep *&a, *&b; ~HalfGuard() { mods_imgrep_destroy(a); mods_imgrep_destroy(b); } } guard{rep1h, rep2h};
   for (int step = 0; step < n_steps && curr_matches < min_matches; step++) {
     const mods_ladder_step &st = steps[step];
     const int nv = mods_view_schedule(st.scale_set, st.n_scales, st.tilt_set, st.n_tilts, st.phi, hist.data(), &n_hist, (int)hist.size(),
                                       views.data(), (int)views.size());
     if (nv < 0) return nv;
+    const bool want_half = st.fginn_ratio_half > 0;
+    if (want_half && !rep1h) {
+      if ((rc = mods_imgrep_create(c, rep1->cap, &rep1h))) return rc;
+      if ((rc = mods_imgrep_create(c, rep2->cap, &rep2h))) return rc;
+    }
+    mods_describe_params desc = par->desc;
+    desc.ori_halfMode = (st.half_orientation || want_half) ? 1 : 0;
+    desc.halfDesc = want_half ? 1 : 0;
     const double t0 = now_ms2();
     for (int im = 0; im < 2; im++) {
       mods_imgrep *rep = im ? rep2 : rep1;
@@ -256,8 +281,9 @@ int mods_match_ladder_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, co
         const float *img = im ? img2_dev : img1_dev;
         const int w = im ? w2 : w1, h = im ? h2 : h1;
         if ((rc = mods_detect_describe_view_dev(c, img, w, h, w, views[v].tilt, views[v].phi, views[v].zoom, st.initSigma,
-                                                st.doBlur, &par->det, &par->desc, nullptr, &nd, &nr))) return rc;
+                                                st.doBlur, &par->det, &desc, nullptr, &nd, &nr))) return rc;
         if ((rc = mods_imgrep_append_ctx(rep, c, 0))) return rc;
+        if (want_half && nr > 0 && (rc = mods_imgrep_append_ctx_half(im ? rep2h : rep1h, c, 0))) return rc;
         res->n_views++;
         res->n_detected[im] += nd;
         res->n_unoriented[im] += mods_unoriented_count(c, 0);
@@ -266,7 +292,7 @@ int mods_match_ladder_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, co
     res->n_described[0] = rep1->n; res->n_described[1] = rep2->n;
     const double t1 = now_ms2();
     res->ms_detect_describe += t1 - t0;
-    if ((rc = match_verify_banks(c, rep1, rep2, st.fginn_ratio, par, res))) return rc;
+    if ((rc = match_verify_banks(c, rep1, rep2, st.fginn_ratio, par, res, rep1h, rep2h, st.fginn_ratio_half))) return rc;
     curr_matches = res->n_inliers;
     res->steps_done = step + 1;
   }

@@ -900,7 +900,7 @@ __device__ void sift_tables(const SiftTab *__restrict__ tab, int ps, float *s_wr
 
 __device__ void sift_from_patch(float *s_patch, const float *__restrict__ mask, const float *s_w, const double *s_lut, int ps,
                                 bool rootsift, double max_bin, float2 *s_px, unsigned char *s_bo, double *s_vec, double *s_red,
-                                uint8_t *out) {
+                                uint8_t *out, bool half = false) {
   double *s_sq = (double *)(((uintptr_t)s_patch + 7) & ~(uintptr_t)7);   // the patch is dead once the gradients are taken
   const int tid = threadIdx.x;
   const int pp = ps * ps;
@@ -960,6 +960,15 @@ __device__ void sift_from_patch(float *s_patch, const float *__restrict__ mask, 
     s_vec[tid] = acc;
   }
   __syncthreads();
+  // doHalfSIFT (siftdesc.cpp:411-436): the raw histogram is folded, half[i*4 + j] = vec[i*8 + j] + vec[i*8 + j + 4], and the
+  // 64 values take the place of the 128 below (the upper half is zero: it adds +0.0 to the ordered sums and quantises to 0)
+  if (half) {
+    double hv = 0.0;
+    if (tid < 64) hv = s_vec[(tid >> 2) * 8 + (tid & 3)] + s_vec[(tid >> 2) * 8 + (tid & 3) + 4];
+    __syncthreads();
+    if (tid < 128) s_vec[tid] = tid < 64 ? hv : 0.0;
+    __syncthreads();
+  }
   // normalize (siftdesc.cpp:133-158) / clip / renormalise (:199-210, :248-257)
   for (int pass = 0; pass < 2; pass++) {
     // squares in parallel (into s_red[2..129] would alias nothing: use the idle patch buffer instead)
@@ -1073,7 +1082,7 @@ __global__ __launch_bounds__(256, 5) void sift_kernel(DescConst k, const float *
     for (int p = tid; p < pp; p += 256) L.patch[p] = src[p];
     __syncthreads();
     if (k.photo) photonorm_patch(L.patch, L.midx, n_mask, L.g, pp, L.redf);
-    sift_from_patch(L.patch, mask, L.w, L.lut, ps, k.root != 0, k.max_bin, L.px, L.bo, L.vec, L.red, reg[ri].desc);
+    sift_from_patch(L.patch, mask, L.w, L.lut, ps, k.root != 0, k.max_bin, L.px, L.bo, L.vec, L.red, reg[ri].desc, k.half_desc != 0);
   }
 }
 
@@ -1512,6 +1521,20 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
     hipLaunchKernelGGL(sift_wave_kernel, dim3(1024, n_img), dim3(256), sift_wave_lds_bytes(ps), ctx->stream, k, patches,
                        ctx->regions_dev, ctx->region_count, dmask, tab, (int)sift_wave_scratch_floats(ps));
   }
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
+int launch_half_sift(mods_ctx *ctx, int n_img, DescConst k, const float *dmask, const SiftTab *tab) {
+  StageScope ts(ctx, MODS_STAGE_DESCRIBE);
+  if (!ctx->regions_half_dev) MODS_HIP_CHECK(hipMalloc(&ctx->regions_half_dev, sizeof(mods_region) * (size_t)ctx->max_cand * ctx->batch));
+  MODS_HIP_CHECK(hipMemcpyAsync(ctx->regions_half_dev, ctx->regions_dev, sizeof(mods_region) * (size_t)ctx->max_cand * n_img,
+                                hipMemcpyDeviceToDevice, ctx->stream));
+  k.half_desc = 1;
+  const int ps = k.desc_ps;
+  const float *patches = ctx->desc_scratch;      // the patch store of launch_extract_and_sift: [n_img][reg_cap][ps*ps]
+  hipLaunchKernelGGL(sift_kernel, dim3(2048, n_img), dim3(256), sift_lds_bytes(ps), ctx->stream, k, patches, ctx->regions_half_dev,
+                     ctx->region_count, dmask, tab);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }

@@ -194,6 +194,12 @@ static int from_regions(const std::vector<Region> &v, orc_region *out, int max_o
   return n;
 }
 
+int orc_dominant_angle_half(const float *patch, int ps, double th, float *angle) {
+  return dominant_angle(wrap(patch, ps, ps), th, angle, true) ? 1 : 0;
+}
+void orc_half_rootsift_patch(const float *patch, int ps, double maxBinValue, unsigned char *out128) {
+  sift_patch_to_desc(wrap(patch, ps, ps), out128, true, maxBinValue, true);
+}
 int orc_dominant_angle(const float *patch, int ps, double th, float *angle) {
   return dominant_angle(wrap(patch, ps, ps), th, angle) ? 1 : 0;
 }
@@ -253,9 +259,12 @@ void orc_describe_rootsift(const float *img, int w, int h, orc_region *r, int n,
 // SynthDetectDescribeKeypoints for one identity view, HessianAffine + RootSIFT
 // (imagerepresentation.cpp:686-1104): detect -> centres inside -> orientation -> touch-boundary
 // filter -> RootSIFT.
-int orc_detect_describe(const float *img, int w, int h, const orc_hessaff_params *p, double ori_mrSize,
-                        int ori_patchSize, int maxAngles, double ori_th, double desc_mrSize, int desc_patchSize,
-                        int photoNorm, orc_region *out, int max_out, int *n_detected) {
+// flags: bit 0 = DetectOrientation in doHalfSIFT mode (what the reference does for every descriptor of a view as soon as one
+// descriptor name of the step contains "Half", imagerepresentation.cpp:725-731, 909-943); bit 1 = also HalfRootSIFT:
+// out_half (same regions, desc[0..63] = HalfRootSIFT, desc[64..127] = 0) is filled.
+int orc_detect_describe_ex(const float *img, int w, int h, const orc_hessaff_params *p, double ori_mrSize,
+                           int ori_patchSize, int maxAngles, double ori_th, double desc_mrSize, int desc_patchSize,
+                           int photoNorm, int flags, orc_region *out, orc_region *out_half, int max_out, int *n_detected) {
   Img im = wrap(img, w, h);
   std::vector<AffKey> k;
   detect_hessian_affine(im, cvt(p), k);
@@ -268,10 +277,21 @@ int orc_detect_describe(const float *img, int w, int h, const orc_hessaff_params
     std::memset(r.desc, 0, 128);
   }
   filter_centres_inside(v, w, h);
-  detect_orientation(v, o, im, ori_mrSize, ori_patchSize, maxAngles, ori_th);
+  detect_orientation(v, o, im, ori_mrSize, ori_patchSize, maxAngles, ori_th, (flags & 1) != 0);
   filter_touch_boundary(o, w, h);
+  if ((flags & 2) && out_half) {
+    std::vector<Region> hv = o;
+    describe_rootsift(hv, im, desc_mrSize, desc_patchSize, photoNorm != 0, true);
+    from_regions(hv, out_half, max_out);
+  }
   describe_rootsift(o, im, desc_mrSize, desc_patchSize, photoNorm != 0);
   return from_regions(o, out, max_out);
+}
+int orc_detect_describe(const float *img, int w, int h, const orc_hessaff_params *p, double ori_mrSize,
+                        int ori_patchSize, int maxAngles, double ori_th, double desc_mrSize, int desc_patchSize,
+                        int photoNorm, orc_region *out, int max_out, int *n_detected) {
+  return orc_detect_describe_ex(img, w, h, p, ori_mrSize, ori_patchSize, maxAngles, ori_th, desc_mrSize, desc_patchSize, photoNorm, 0, out,
+                                nullptr, max_out, n_detected);
 }
 
 // ---- view synthesis -------------------------------------------------------------------------------
@@ -317,10 +337,10 @@ void orc_synth_view(const float *src, int w, int h, double tilt, double phi, dou
 // RootSIFT: detect on the view -> centres (in the original frame) inside -> orientation on the view ->
 // ReprojectRegions -> RootSIFT on the view.  `out` carries reproj_kp (original frame) + descriptor;
 // `out_det` (optional) the matching det_kp (view frame).
-int orc_detect_describe_view(const float *view, int vw, int vh, const double *H, int orig_w, int orig_h,
-                             const orc_hessaff_params *p, double ori_mrSize, int ori_patchSize, int maxAngles, double ori_th,
-                             double desc_mrSize, int desc_patchSize, int photoNorm, orc_region *out, orc_region *out_det,
-                             int max_out, int *n_detected) {
+int orc_detect_describe_view_ex(const float *view, int vw, int vh, const double *H, int orig_w, int orig_h,
+                                const orc_hessaff_params *p, double ori_mrSize, int ori_patchSize, int maxAngles, double ori_th,
+                                double desc_mrSize, int desc_patchSize, int photoNorm, int flags, orc_region *out, orc_region *out_det,
+                                orc_region *out_half, int max_out, int *n_detected) {
   Img im = wrap(view, vw, vh);
   std::vector<AffKey> k;
   detect_hessian_affine(im, cvt(p), k);
@@ -333,12 +353,25 @@ int orc_detect_describe_view(const float *view, int vw, int vh, const double *H,
     std::memset(r.desc, 0, 128);
   }
   filter_centres_inside_view(v, H, orig_w, orig_h);
-  detect_orientation(v, o, im, ori_mrSize, ori_patchSize, maxAngles, ori_th);
+  detect_orientation(v, o, im, ori_mrSize, ori_patchSize, maxAngles, ori_th, (flags & 1) != 0);
   reproject_regions_view(o, rep, H, orig_w, orig_h);
+  if ((flags & 2) && out_half) {
+    std::vector<Region> hv = o, hrep = rep;
+    describe_rootsift(hv, im, desc_mrSize, desc_patchSize, photoNorm != 0, true);
+    for (size_t i = 0; i < hv.size(); i++) std::memcpy(hrep[i].desc, hv[i].desc, 128);
+    from_regions(hrep, out_half, max_out);
+  }
   describe_rootsift(o, im, desc_mrSize, desc_patchSize, photoNorm != 0);
   for (size_t i = 0; i < o.size(); i++) std::memcpy(rep[i].desc, o[i].desc, 128);
   if (out_det) from_regions(o, out_det, max_out);
   return from_regions(rep, out, max_out);
+}
+int orc_detect_describe_view(const float *view, int vw, int vh, const double *H, int orig_w, int orig_h,
+                             const orc_hessaff_params *p, double ori_mrSize, int ori_patchSize, int maxAngles, double ori_th,
+                             double desc_mrSize, int desc_patchSize, int photoNorm, orc_region *out, orc_region *out_det,
+                             int max_out, int *n_detected) {
+  return orc_detect_describe_view_ex(view, vw, vh, H, orig_w, orig_h, p, ori_mrSize, ori_patchSize, maxAngles, ori_th, desc_mrSize,
+                                     desc_patchSize, photoNorm, 0, out, out_det, nullptr, max_out, n_detected);
 }
 
 // ---- matching -----------------------------------------------------------------------------------

@@ -166,10 +166,11 @@ static void smooth_circular(float *hist, int bins) {
   hist[bins - 1] = prev + hist[bins - 1] + first;
 }
 
-// EstimateDominantAnglesFunctor::operator() for maxAngles = 1, doHalfSIFT = 0
-// (synth-detection.cpp:836-929): first local maximum >= 0.8*max in bin order 0..35, with
-// parabolic refinement.  Returns false when the histogram has no such peak.
-bool dominant_angle(const Img &img, double max_th, float *angle_out) {
+// EstimateDominantAnglesFunctor::operator() for maxAngles = 1 (synth-detection.cpp:836-929): first local maximum
+// >= 0.8*max in bin order 0..35, with parabolic refinement.  Returns false when the histogram has no such peak.
+// half = doHalfSIFT: after the threshold has been taken from the full histogram, bins i and i + 18 are added into
+// bin i (orientation modulo pi) and the upper half is cleared (:891-898).
+bool dominant_angle(const Img &img, double max_th, float *angle_out, bool half) {
   const int pS = img.w;
   const int bins = 36;
   const float PIf = float(M_PI);
@@ -201,6 +202,10 @@ bool dominant_angle(const Img &img, double max_th, float *angle_out) {
   for (int i = 0; i < bins; i++)
     if (hist[i] > thresh) thresh = hist[i];
   thresh = (float)(thresh * max_th);
+  if (half) {
+    const int halfbins = bins / 2;
+    for (int i = 0; i < halfbins; i++) { hist[i] += hist[i + halfbins]; hist[i + halfbins] = 0; }
+  }
   for (int k = 0; k < bins; k++) {
     int b = k, a = (k == 0) ? bins - 1 : k - 1, c = (k == bins - 1) ? 0 : k + 1;
     if (hist[b] >= thresh && hist[b] > hist[a] && hist[b] > hist[c]) {
@@ -214,7 +219,7 @@ bool dominant_angle(const Img &img, double max_th, float *angle_out) {
 
 // DetectOrientation, synth-detection.cpp:1039-1149 (maxAngNum = 1, addUpRight = false).
 int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, const Img &img, double mrSize,
-                       int patchSize, int maxAngles, double th) {
+                       int patchSize, int maxAngles, double th, bool half) {
   const double ks = k_sigma_synth();
   std::vector<Region> tmp;
   tmp.reserve(in.size());
@@ -236,7 +241,7 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
       interpolate(img, (float)k.x, (float)k.y, (float)k.a11 * curr_sc, (float)k.a12 * curr_sc,
                   (float)k.a21 * curr_sc, (float)k.a22 * curr_sc, patch);
       float ang;
-      if (!dominant_angle(patch, th, &ang)) continue;
+      if (!dominant_angle(patch, th, &ang, half)) continue;
       double si, ci;
       det_sincos(-(double)ang, &si, &ci);
       Region t = k;
@@ -301,7 +306,9 @@ static double normalize_d(std::vector<double> &v) {   // siftdesc.cpp:133-158 (s
 
 // computeRootSiftDescriptor / computeSiftDescriptor + (Root)SIFTnorm(double),
 // siftdesc.cpp:346-400, 288-345, 73-131, 199-222, 248-263.
-void sift_patch_to_desc(const Img &patch, uint8_t out[128], bool rootsift, double maxBinValue) {
+// half = doHalfSIFT (siftdesc.cpp:401-436): the raw histogram (no normalisation) is folded, half[i*4 + j] =
+// vec[i*8 + j] + vec[i*8 + j + 4], and the 64 values go through the same normalisation; out[64..127] = 0.
+void sift_patch_to_desc(const Img &patch, uint8_t out[128], bool rootsift, double maxBinValue, bool half) {
   const int ps = patch.w;
   static thread_local SiftTables *T = nullptr;
   if (!T || T->ps != ps) { delete T; T = new SiftTables(ps); }
@@ -348,6 +355,14 @@ void sift_patch_to_desc(const Img &patch, uint8_t out[128], bool rootsift, doubl
       val = wr1 * wc1;
       if (val > 0) { vec[br1 + bc1 + bo0] += val * wo0; vec[br1 + bc1 + bo1] += val * wo1; }
     }
+  }
+  if (half) {
+    std::vector<double> hv(spatialBins * spatialBins * orientationBins / 2);
+    int bin1 = 0;
+    for (int i = 0; i < spatialBins * spatialBins; i++)
+      for (int j = 0; j < orientationBins / 2; j++) hv[bin1++] = vec[i * orientationBins + j] + vec[i * orientationBins + j + orientationBins / 2];
+    vec.swap(hv);
+    std::memset(out, 0, 128);
   }
   normalize_d(vec);
   bool changed = false;
@@ -396,14 +411,14 @@ void extract_desc_patch(const Region &k, const Img &img, double mrSize, int patc
   }
 }
 
-void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize, bool photoNorm) {
+void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize, bool photoNorm, bool half) {
 #pragma omp parallel num_threads(g_threads)
   {
     Img patch(patchSize, patchSize);
 #pragma omp for schedule(dynamic, 16)
     for (long i = 0; i < (long)r.size(); i++) {
       extract_desc_patch(r[i], img, mrSize, patchSize, photoNorm, patch);
-      sift_patch_to_desc(patch, r[i].desc, true, 0.2);   // [SIFTDescriptor] maxBinValue = 0.2 (io_mods.cpp:427)
+      sift_patch_to_desc(patch, r[i].desc, true, 0.2, half);   // [SIFTDescriptor] maxBinValue = 0.2 (io_mods.cpp:427)
     }
   }
 }

@@ -121,7 +121,7 @@ struct Region {                 // AffineRegion subset: det_kp == reproj_kp for 
 // ReprojectRegionsAndRemoveTouchBoundary(dontRemove=true) for H=I: keep centres inside.
 void filter_centres_inside(std::vector<Region> &r, int w, int h);           // synth-detection.cpp:151-190
 int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, const Img &img,
-                       double mrSize, int patchSize, int maxAngles, double th);   // :1039-1149
+                       double mrSize, int patchSize, int maxAngles, double th, bool half = false);   // :1039-1149 (half: doHalfSIFT)
 void filter_touch_boundary(std::vector<Region> &r, int w, int h);           // ReprojectRegions :631-706
 void affnet_apply(std::vector<Region> &r, const float *a3, int w, int h, double mrSize);   // imagerepresentation.cpp:798-842
 void orinet_apply(std::vector<Region> &r, const float *yx);                               // imagerepresentation.cpp:877-899
@@ -131,11 +131,11 @@ bool h_is_eye(const double *H);                                             // s
 void filter_centres_inside_view(std::vector<Region> &det, const double *H, int orig_w, int orig_h);
 void reproject_regions_view(std::vector<Region> &det, std::vector<Region> &rep, const double *H, int orig_w, int orig_h);
 void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize,
-                       bool photoNorm);                                     // synth-detection.hpp:170-263
-void sift_patch_to_desc(const Img &patch41, uint8_t out[128], bool rootsift, double maxBinValue = 0.2);   // matching/siftdesc.cpp
+                       bool photoNorm, bool half = false);                  // synth-detection.hpp:170-263 (half: HalfRootSIFT, 64 values)
+void sift_patch_to_desc(const Img &patch41, uint8_t out[128], bool rootsift, double maxBinValue = 0.2, bool half = false);   // matching/siftdesc.cpp
 void extract_desc_patch(const Region &r, const Img &img, double mrSize, int patchSize, bool photoNorm,
                         Img &patch, bool column_rule = false);
-bool dominant_angle(const Img &patch, double th, float *angle);              // :836-929 (maxAngles=1)
+bool dominant_angle(const Img &patch, double th, float *angle, bool half = false);   // :836-929 (maxAngles=1)
 
 // ---- matching (match.cpp) ------------------------------------------------------------------
 struct Tentative {

@@ -268,15 +268,22 @@ def describe_rootsift(img, regions, mrsize=DESC_MRSIZE, ps=DESC_PATCH, photonorm
     return r
 
 
-def detect_describe(img, params=None, max_out=1 << 18):
-    """HessianAffine + RootSIFT for one identity view; returns (regions, n_detected)."""
+def detect_describe(img, params=None, max_out=1 << 18, half_orientation=False, half_desc=False):
+    """HessianAffine + RootSIFT for one identity view; returns (regions, n_detected).  half_orientation: DetectOrientation in
+    doHalfSIFT mode (what the reference does for a step whose descriptor list names a Half* descriptor); half_desc: also the
+    HalfRootSIFT descriptors of the same regions -> (regions, half regions, n_detected)."""
     params = params or HessAffParams.default()
     a, p = _f(img)
     out = np.zeros(max_out, REGION_DTYPE)
+    outh = np.zeros(max_out if half_desc else 1, REGION_DTYPE)
     ndet = C.c_int()
-    n = lib().orc_detect_describe(p, a.shape[1], a.shape[0], C.byref(params), C.c_double(ORI_MRSIZE), ORI_PATCH,
-                                  ORI_MAXANG, C.c_double(ORI_TH), C.c_double(DESC_MRSIZE), DESC_PATCH, 1,
-                                  out.ctypes.data_as(C.c_void_p), max_out, C.byref(ndet))
+    flags = (1 if half_orientation else 0) | (2 if half_desc else 0)
+    n = lib().orc_detect_describe_ex(p, a.shape[1], a.shape[0], C.byref(params), C.c_double(ORI_MRSIZE), ORI_PATCH,
+                                     ORI_MAXANG, C.c_double(ORI_TH), C.c_double(DESC_MRSIZE), DESC_PATCH, 1, flags,
+                                     out.ctypes.data_as(C.c_void_p), outh.ctypes.data_as(C.c_void_p) if half_desc else None, max_out,
+                                     C.byref(ndet))
+    if half_desc:
+        return out[:n].copy(), outh[:n].copy(), ndet.value
     return out[:n].copy(), ndet.value
 
 
@@ -330,19 +337,24 @@ def synth_view(img, tilt, phi, zoom=1.0, init_sigma=0.2, do_blur=1):
     return out, g
 
 
-def detect_describe_view(view, H, orig_w, orig_h, params=None, max_out=1 << 18):
+def detect_describe_view(view, H, orig_w, orig_h, params=None, max_out=1 << 18, half_orientation=False, half_desc=False):
     """One synthesised view through detect/orient/reproject/describe; returns (regions in the original frame,
-    the same regions in the view frame, n_detected)."""
+    the same regions in the view frame, n_detected) [+ the HalfRootSIFT regions (original frame) with half_desc]."""
     params = params or HessAffParams.default()
     a, p = _f(view)
     Hc = np.ascontiguousarray(H, np.float64).ravel()
     out = np.zeros(max_out, REGION_DTYPE)
     det = np.zeros(max_out, REGION_DTYPE)
+    outh = np.zeros(max_out if half_desc else 1, REGION_DTYPE)
     ndet = C.c_int()
-    n = lib().orc_detect_describe_view(p, a.shape[1], a.shape[0], Hc.ctypes.data_as(C.c_void_p), orig_w, orig_h,
-                                       C.byref(params), C.c_double(ORI_MRSIZE), ORI_PATCH, ORI_MAXANG, C.c_double(ORI_TH),
-                                       C.c_double(DESC_MRSIZE), DESC_PATCH, 1, out.ctypes.data_as(C.c_void_p),
-                                       det.ctypes.data_as(C.c_void_p), max_out, C.byref(ndet))
+    flags = (1 if half_orientation else 0) | (2 if half_desc else 0)
+    n = lib().orc_detect_describe_view_ex(p, a.shape[1], a.shape[0], Hc.ctypes.data_as(C.c_void_p), orig_w, orig_h,
+                                          C.byref(params), C.c_double(ORI_MRSIZE), ORI_PATCH, ORI_MAXANG, C.c_double(ORI_TH),
+                                          C.c_double(DESC_MRSIZE), DESC_PATCH, 1, flags, out.ctypes.data_as(C.c_void_p),
+                                          det.ctypes.data_as(C.c_void_p), outh.ctypes.data_as(C.c_void_p) if half_desc else None,
+                                          max_out, C.byref(ndet))
+    if half_desc:
+        return out[:n].copy(), det[:n].copy(), ndet.value, outh[:n].copy()
     return out[:n].copy(), det[:n].copy(), ndet.value
 
 

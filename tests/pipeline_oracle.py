@@ -204,10 +204,15 @@ def view_schedule(tilts, phi_base, history, scales=(1.0,)):
     return new
 
 
-def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=0.2, ratio=0.8):
-    """mods.cpp:202-383 for HessianAffine + RootSIFT: steps = [(tilts, phi_base), ...]."""
+def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=0.2, ratio=0.8, half_orientation=False,
+                 ratio_half=0.0):
+    """mods.cpp:202-383 for HessianAffine + RootSIFT: steps = [(tilts, phi_base), ...].  half_orientation: the steps' descriptor
+    lists name a Half* descriptor (DetectOrientation in doHalfSIFT mode for every descriptor); ratio_half > 0: HalfRootSIFT lists
+    are built and matched as a second separate descriptor, tentatives joined (correspondencebank.cpp:288-340)."""
     h, w = img1.shape
     banks = [[], []]
+    banks_h = [[], []]
+    want_half = ratio_half > 0
     history = []
     out = None
     n_views = 0
@@ -219,18 +224,31 @@ def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=
             px, g = orc.synth_view(img, tilt, phi, zoom, init_sigma, 1)
             if g.w_new < 16 or g.h_new < 16:
                 return None
-            return orc.detect_describe_view(px, np.array(g.H), w, h)[0]
+            r = orc.detect_describe_view(px, np.array(g.H), w, h, half_orientation=half_orientation or want_half, half_desc=want_half)
+            return (r[0], r[3]) if want_half else (r[0], None)
         for im, img in enumerate((img1, img2)):
             regs = pmap(one_view, [(img, v) for v in views])      # views are independent; banks keep the view order
             n_views += len(views)
-            banks[im] += [r for r in regs if r is not None]
+            banks[im] += [r[0] for r in regs if r is not None]
+            banks_h[im] += [r[1] for r in regs if r is not None and want_half]
         ra, rb = np.concatenate(banks[0]), np.concatenate(banks[1])
         tc = match_fginn_par(ra, rb, ratio)
+        u6_all, laf_all = u6_of(ra, rb, tc), laf_of(ra, rb, tc)
+        if want_half:
+            ha, hb = np.concatenate(banks_h[0]), np.concatenate(banks_h[1])
+            tch = match_fginn_par(ha, hb, ratio_half)
+            u6_all = np.concatenate([u6_all, u6_of(ha, hb, tch)]); laf_all = np.concatenate([laf_all, laf_of(ha, hb, tch)])
+            # the duplicate filter and what follows only need coordinates, frames and the ratio / distance keys: one joint list
+            # whose q / t index a joint region array (RootSIFT lists first)
+            tch = tch.copy(); tch["q"] += len(ra); tch["t"] += len(rb)
+            tc = np.concatenate([tc, tch])
+            ra, rb = np.concatenate([ra, ha]), np.concatenate([rb, hb])
         un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
         u6, laf = u6_of(ra, rb, un), laf_of(ra, rb, un)
         mask, H, ninl, stats = loransac_h(u6, laf, seed_time=seed_time)
-        out = dict(steps_done=si + 1, n_views=n_views, n_described=[len(ra), len(rb)], n_tentatives=len(tc), n_unique=len(un),
-                   n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6, regions=(ra, rb))
+        n_desc = [sum(len(x) for x in banks[0]), sum(len(x) for x in banks[1])]
+        out = dict(steps_done=si + 1, n_views=n_views, n_described=n_desc, n_tentatives=len(tc), n_unique=len(un),
+                   n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6, regions=(ra[:n_desc[0]], rb[:n_desc[1]]))
         if ninl >= min_matches:
             break
     return out

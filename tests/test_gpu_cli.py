@@ -79,7 +79,9 @@ def test_cli_ladder_and_epipolar(pkg, tmp_path):
     """A multi-step iterations file with out-of-scope sections: MSER step skipped, HessianAffine steps run until
     minMatches; ver_type 2 switches to DEGENSAC."""
     err = _run(tmp_path, "iters_ladder.ini", ver_type="2")
-    steps = [pkg.LadderStep.make((1,), 360.0), pkg.LadderStep.make((1, 2, 4), 360.0), pkg.LadderStep.make((1, 2, 4), 120.0)]
+    # [HessianAffine1] Descriptors = RootSIFT,HalfRootSIFT with both thresholds: doHalfSIFT orientation, both lists matched
+    steps = [pkg.LadderStep.make((1,), 360.0, half_orientation=1, fginn_half=0.8), pkg.LadderStep.make((1, 2, 4), 360.0),
+             pkg.LadderStep.make((1, 2, 4), 120.0)]
     res, m, _ = _library_run(pkg, steps, use_f=1)
     got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
     assert len(got) == res.n_inliers > 15

@@ -117,3 +117,25 @@ def test_batch16_1080p_vs_oracle(pkg):
         assert nd[i] == nd_exp and nr[i] == len(exp), i
         _assert_regions_equal(ctx.regions_fetch(i), exp)
     ctx.close()
+
+
+def test_half_orientation_and_half_rootsift(pkg):
+    """DetectOrientation in doHalfSIFT mode + HalfRootSIFT (64 values) for the same regions, as a step with
+    Descriptors = RootSIFT,HalfRootSIFT asks for (imagerepresentation.cpp:725-731, 909-943, 970-979; siftdesc.cpp:401-436)."""
+    import torch
+    w, h = 640, 480
+    img = synth.texture(w, h, seed=33)
+    want, want_half, nd_want = orc.detect_describe(img, half_orientation=True, half_desc=True)
+    plain, _ = orc.detect_describe(img)
+    assert not np.array_equal(want["a11"][:50], plain["a11"][:50])      # the half mode does pick other angles
+    ctx = pkg.Context(0, w, h, 1)
+    desc = pkg.DescribeParams.default()
+    desc.ori_halfMode, desc.halfDesc = 1, 1
+    t = torch.from_numpy(img).cuda()
+    nd, nr = ctx.detect_describe_dev(t.data_ptr(), 1, w, h, None, desc)
+    assert nd[0] == nd_want and nr[0] == len(want) > 500
+    _assert_regions_equal(ctx.regions_fetch(0), want)
+    got_half = ctx.regions_fetch_half(0)
+    _assert_regions_equal(got_half, want_half)
+    assert np.all(got_half["desc"][:, 64:] == 0) and got_half["desc"][:, :64].any()
+    ctx.close()

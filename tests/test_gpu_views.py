@@ -154,3 +154,37 @@ def test_ladder_matches_oracle(pkg, w, h, steps_spec):
     parts = [pkg.match_reps(ctx, rep1, rep2, q0, q1)[0] for q0, q1 in ((0, n // 3), (n // 3, n // 2), (n // 2, n))]
     assert np.array_equal(np.concatenate(parts), full)
     rep1.close(); rep2.close(); ctx.close()
+
+
+def test_ladder_with_half_descriptors(pkg):
+    """A step whose descriptor list is RootSIFT,HalfRootSIFT with both thresholds given: orientation in doHalfSIFT mode, both
+    descriptor lists matched separately, tentatives joined, then duplicate filter + RANSAC - against the oracle chain."""
+    import torch
+    import pipeline_oracle as po
+    import refdeg
+    if not refdeg.available():
+        pytest.skip("oracle/_ref not built")
+    w, h = 480, 360
+    a, b, Htrue = _hard_pair(w, h, seed=21)
+    steps_spec = [((1, 2, 4), 360.0), ((1, 2, 4), 120.0)]
+    want = po.match_ladder(a, b, steps_spec, seed_time=31, half_orientation=True, ratio_half=0.8)
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    rep1, rep2 = pkg.ImgRep(ctx), pkg.ImgRep(ctx)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(31)
+    steps = [pkg.LadderStep.make(tl, ph, half_orientation=1, fginn_half=0.8) for tl, ph in steps_spec]
+    res, m = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2, max_matches=100000)
+    assert res.steps_done == want["steps_done"] and res.n_views == want["n_views"]
+    assert list(res.n_described) == want["n_described"]
+    ra, rb = rep1.fetch(), rep2.fetch()
+    for got, exp in ((ra, want["regions"][0]), (rb, want["regions"][1])):
+        for f in ("x", "y", "a11", "a12", "a21", "a22"):
+            assert np.array_equal(got[f], exp[f]), f
+        assert np.array_equal(got["desc"], exp["desc"])
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] >= 15
+    assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
+    rep1.close(); rep2.close(); ctx.close()
