@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------
 struct BlurTaps { float t[17]; };
 // overlapping tiles of the fused blur + response kernel: origins step by `step`, a tile blurs step + lap pixels
-__host__ __device__ static inline int blur_resp_tiles(int n, int step, int lap) { return n > lap ? (n - lap + step - 1) / step : 1; }
+// (the tile that owns response row / column n - 1, the last of the frame, is the last one: origins up to n - 2)
+__host__ __device__ static inline int blur_resp_tiles(int n, int step, int lap) { (void)lap; return n > 2 ? (n - 1 + step - 1) / step : 1; }
 constexpr int FB_TW = 128;   // tile width; the tile height is a template parameter (64: large planes, 16: small planes,
                              // where a short per-thread row chain matters more than halo reuse)
 
