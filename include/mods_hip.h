@@ -405,6 +405,24 @@ int mods_match_ladder_dev(mods_ctx *ctx, const float *img1_dev, int w1, int h1, 
                           const mods_ladder_step *steps, int n_steps, int min_matches, const mods_pair_params *par,
                           mods_imgrep *rep1, mods_imgrep *rep2, mods_ladder_result *res, double *matches_out, int max_matches);
 
+/* ---- one hard pair on several GPUs of a node ------------------------------------------------------
+ * The views of every step (ImageRepresentation::SynthDetectDescribeKeypoints' views loop, imagerepresentation.cpp:704-1099) are
+ * sharded over the devices, largest first; the described regions travel in ONE all-gather per step (RCCL over xGMI, device
+ * buffers; the one host process knows all counts, so nothing else is exchanged); every device searches its slice of the query
+ * rows against all trains (CorrespondenceBank::MatchImgReps, correspondencebank.cpp:234-343) and the host of device 0 filters
+ * duplicates and verifies.  Same result as mods_match_ladder_dev.  devices[]: HIP device ids; a device listed twice makes
+ * the exchange use plain device copies (development on a one-GPU box).  The `mods` command line takes MODS_DEVICES=0,1,... */
+typedef struct mods_multi mods_multi;
+int mods_multi_create(const int *devices, int n, int w, int h, int rep_capacity, mods_multi **out);
+void mods_multi_destroy(mods_multi *m);
+int mods_multi_uses_rccl(const mods_multi *m);
+mods_imgrep *mods_multi_bank(mods_multi *m, int image);   /* regions of image 1 (0) / 2 (1) after a run; owned by m */
+int mods_match_ladder_multi(mods_multi *m, const float *img1_host, int w1, int h1, const float *img2_host, int w2, int h2,
+                            const mods_ladder_step *steps, int n_steps, int min_matches, const mods_pair_params *par,
+                            mods_ladder_result *res, double *matches_out, int max_matches);
+/* host logic of the sharding (no device needed): owner[i] = device of view job i with area areas[i] */
+int mods_multi_assign(const double *areas, int n, int n_dev, int *owner);
+
 /* Pre-extracted mode (mods.cpp:196-229, 288-383): the banks were filled by the caller (mods_imgrep_append_host, e.g. from the
  * k1 / k2 files of an earlier run); one matching + duplicate filtering + verification pass, no detection. */
 int mods_match_verify_reps(mods_ctx *ctx, mods_imgrep *rep1, mods_imgrep *rep2, double fginn_ratio, const mods_pair_params *par,

@@ -625,6 +625,50 @@ def match_ladder_dev(ctx, img_ptr, w, h, steps, rep1, rep2, params=None, min_mat
     return res, m[:min(res.n_inliers, max_matches)]
 
 
+class Multi:
+    """mods_multi_*: one hard pair on several GPUs (views sharded, one all-gather of the regions per step)."""
+
+    def __init__(self, devices, w, h, rep_capacity=1 << 19):
+        self.h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().mods_multi_create(arr, len(devices), w, h, rep_capacity, C.byref(self.h)))
+        self.uses_rccl = bool(lib().mods_multi_uses_rccl(self.h))
+
+    def match_ladder(self, img1, img2, steps, params=None, min_matches=15, max_matches=0):
+        a = np.ascontiguousarray(img1, np.float32); b = np.ascontiguousarray(img2, np.float32)
+        params = params or PairParams.default()
+        arr = (LadderStep * len(steps))(*steps)
+        res = LadderResult()
+        m = np.zeros((max(max_matches, 1), 4), np.float64)
+        _check(lib().mods_match_ladder_multi(self.h, _fp(a), a.shape[1], a.shape[0], _fp(b), b.shape[1], b.shape[0], arr, len(steps),
+                                             min_matches, C.byref(params), C.byref(res),
+                                             m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
+        return res, m[:min(res.n_inliers, max_matches)]
+
+    def bank(self, image):
+        """Regions of image 1 (0) / 2 (1) after a run."""
+        lib().mods_multi_bank.restype = C.c_void_p
+        hnd = C.c_void_p(lib().mods_multi_bank(self.h, image))
+        n = lib().mods_imgrep_count(hnd)
+        out = np.zeros(max(n, 1), REGION_DTYPE)
+        if n:
+            _check(lib().mods_imgrep_fetch(hnd, 0, n, out.ctypes.data_as(C.c_void_p)))
+        return out[:n].copy()
+
+    def close(self):
+        if self.h:
+            lib().mods_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def multi_assign(areas, n_dev):
+    """Host logic of the view sharding: owner device of every view job (largest first onto the least loaded device)."""
+    a = np.ascontiguousarray(areas, np.float64)
+    owner = np.zeros(len(a), np.int32)
+    _check(lib().mods_multi_assign(a.ctypes.data_as(C.c_void_p), len(a), n_dev, owner.ctypes.data_as(C.c_void_p)))
+    return owner
+
+
 def match_verify_reps(ctx, rep1, rep2, fginn_ratio=0.8, params=None, max_matches=0):
     """Pre-extracted mode (mods.cpp:196-229): match + duplicate filter + verification on banks filled by the caller."""
     params = params or PairParams.default()

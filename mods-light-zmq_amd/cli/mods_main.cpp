@@ -389,6 +389,23 @@ int main(int argc, char **argv) {
     if (cfg.verbose) std::cerr << "Orientations from the daemon at " << cfg.ori_port << std::endl;
     if (mods_ctx_set_external_orientation(ctx, &mods_zmq_descriptor_hook, (void *)cfg.ori_port.c_str(), cfg.ori_mr, cfg.ori_ps)) return fail("external orientation");
   }
+  // MODS_DEVICES=0,1,...: several GPUs for one pair (not with the ZMQ daemons: their hooks belong to one context)
+  mods_multi *multi = nullptr;
+  if (const char *md = getenv("MODS_DEVICES")) {
+    std::vector<int> devs;
+    for (const char *q = md; *q;) {
+      char *e = nullptr;
+      const long v = strtol(q, &e, 10);
+      if (e == q) break;
+      devs.push_back((int)v);
+      q = *e == ',' ? e + 1 : e;
+    }
+    if (pre_extracted || cfg.use_zmq || cfg.aff_zmq || cfg.ori_zmq) std::cerr << "Note: MODS_DEVICES is ignored in pre-extracted mode and with ZMQ daemons" << std::endl;
+    else if (!devs.empty()) {
+      if (mods_multi_create(devs.data(), (int)devs.size(), std::max(img1.w, img2.w), std::max(img1.h, img2.h), 1 << 20, &multi)) return fail("multi-GPU setup");
+      if (cfg.verbose) std::cerr << devs.size() << " device(s), exchange over " << (mods_multi_uses_rccl(multi) ? "RCCL" : "device copies") << std::endl;
+    }
+  }
   mods_ladder_result res;
   std::vector<double> matches((size_t)4 << 20);
   if (pre_extracted) {   // mods.cpp:196-229: one step, the banks come from the keypoint files
@@ -399,6 +416,11 @@ int main(int argc, char **argv) {
       return fail("region banks");
     if (mods_match_verify_reps(ctx, rep1, rep2, steps[0].fginn_ratio, &cfg.pair, &res, matches.data(), 1 << 20)) return fail("matching");
     res.n_unoriented[0] = (int)r1.size(); res.n_unoriented[1] = (int)r2.size();
+  } else if (multi) {   // MODS_DEVICES: the views of every step sharded over several GPUs, one all-gather of the regions per step
+    if (mods_match_ladder_multi(multi, img1.px.data(), img1.w, img1.h, img2.px.data(), img2.w, img2.h, steps.data(), (int)steps.size(),
+                                cfg.min_matches, &cfg.pair, &res, matches.data(), 1 << 20))
+      return fail("matching");
+    rep1 = mods_multi_bank(multi, 0); rep2 = mods_multi_bank(multi, 1);     // for the keypoint files
   } else if (mods_match_ladder_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, steps.data(), (int)steps.size(),
                                    cfg.min_matches, &cfg.pair, rep1, rep2, &res, matches.data(), 1 << 20))
     return fail("matching");

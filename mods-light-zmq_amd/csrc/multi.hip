@@ -1,0 +1,313 @@
+// One hard pair on several GPUs of a node: the synthesised views of a step are sharded over the devices, the described
+// regions are exchanged in ONE all-gather per step (RCCL over xGMI, HBM to HBM), every device then searches its slice of the
+// query rows against all trains, and device 0's host verifies.
+//
+// Reference seams: the views loop of ImageRepresentation::SynthDetectDescribeKeypoints (imagerepresentation.cpp:704-1099: views
+// are independent until AddRegions), CorrespondenceBank::MatchImgReps (correspondencebank.cpp:234-343: queries are searched one by
+// one), the step loop of mods.cpp:202-383.  The result is identical to mods_match_ladder_dev on one GPU: the banks are rebuilt
+// in canonical (image, view) order on every device and the tentatives are joined in query order.
+//
+// One host process drives all devices (one context and one host thread per device, one RCCL communicator per device created
+// with ncclCommInitAll): that is what the `mods` command line needs (MODS_DEVICES=0,1,..).  bench.py's throughput scaling uses
+// one process per GPU instead (pairs are independent there: no collective at all).
+//
+// Exchange record = mods_region (208 B): the matcher needs the 128 descriptor bytes and the centre, the emit kernel builds the
+// RANSAC correspondences and the local affine frames of the LAF checks (x, y, a11..a22, s = 56 B) from the same lists on the
+// device, so the frame travels too; only response / ids (24 B) are not strictly needed.  3*10^5 regions = 62 MB per step.
+#include "common.hpp"
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <memory>
+#include <string>
+#include <thread>
+
+extern "C" int mods_ctx_create_ex(int device, int max_w, int max_h, int batch, int flags, mods_ctx **out);
+using mods::set_error;
+
+struct mods_multi {
+  int n = 0;
+  std::vector<int> dev;
+  std::vector<mods_ctx *> ctx;
+  std::vector<mods_imgrep *> rep1, rep2;
+  std::vector<ncclComm_t> comm;
+  bool use_rccl = false;              // distinct devices: RCCL all-gather; a device listed twice (development on one GPU): copies
+  std::vector<mods_region *> send;    // [dev] regions of the views a device described in this step, packed in job order
+  std::vector<mods_region *> recv;    // [dev] n x cap: what every device contributed
+  std::vector<float *> img;           // [dev] both images
+  size_t cap = 0;                     // regions per device and step
+  int rep_cap = 0;
+};
+
+namespace {
+
+// Greedy longest-processing-time assignment of the view jobs to the devices (tilted views are much smaller than the frontal
+// one); deterministic.  The same rule as shard.largest_first_views.
+void assign_views(const std::vector<double> &areas, int n_dev, std::vector<std::vector<int>> *out) {
+  std::vector<int> order(areas.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return areas[a] > areas[b]; });
+  std::vector<double> load(n_dev, 0.0);
+  out->assign(n_dev, std::vector<int>());
+  for (int i : order) {
+    int r = 0;
+    for (int q = 1; q < n_dev; q++)
+      if (load[q] < load[r]) r = q;
+    (*out)[r].push_back(i);
+    load[r] += areas[i];
+  }
+  for (auto &v : *out) std::sort(v.begin(), v.end());   // a device walks its jobs in job order
+}
+
+struct Job { int im; mods_view_par v; };
+
+}  // namespace
+
+extern "C" {
+
+// host-side piece for the CPU tests: the assignment of `n` view jobs with the given areas to n_dev devices; owner[i] = device
+int mods_multi_assign(const double *areas, int n, int n_dev, int *owner) {
+  if (!areas || !owner || n < 0 || n_dev < 1) return MODS_E_ARG;
+  std::vector<std::vector<int>> a;
+  assign_views(std::vector<double>(areas, areas + n), n_dev, &a);
+  for (int d = 0; d < n_dev; d++)
+    for (int i : a[d]) owner[i] = d;
+  return MODS_OK;
+}
+
+void mods_multi_destroy(mods_multi *m) {
+  if (!m) return;
+  for (int d = 0; d < (int)m->ctx.size(); d++) {
+    (void)hipSetDevice(m->dev[d]);
+    if (d < (int)m->comm.size() && m->comm[d]) ncclCommDestroy(m->comm[d]);
+    if (d < (int)m->rep1.size()) mods_imgrep_destroy(m->rep1[d]);
+    if (d < (int)m->rep2.size()) mods_imgrep_destroy(m->rep2[d]);
+    if (d < (int)m->send.size()) (void)hipFree(m->send[d]);
+    if (d < (int)m->recv.size()) (void)hipFree(m->recv[d]);
+    if (d < (int)m->img.size()) (void)hipFree(m->img[d]);
+    mods_ctx_destroy(m->ctx[d]);
+  }
+  delete m;
+}
+
+// devices[n]: HIP device ids (a device may be listed more than once: the exchange then uses device copies instead of RCCL -
+// a development aid for one-GPU boxes).  w, h: the larger image; rep_capacity: regions per image bank.
+int mods_multi_create(const int *devices, int n, int w, int h, int rep_capacity, mods_multi **out) {
+  if (!devices || n < 1 || n > 16 || !out || w <= 0 || h <= 0) { set_error("multi_create: bad arguments"); return MODS_E_ARG; }
+  std::unique_ptr<mods_multi, void (*)(mods_multi *)> m(new mods_multi(), mods_multi_destroy);
+  m->n = n;
+  m->dev.assign(devices, devices + n);
+  bool distinct = true;
+  for (int a = 0; a < n; a++)
+    for (int b = a + 1; b < n; b++) distinct = distinct && devices[a] != devices[b];
+  const int side = (int)std::ceil(std::hypot((double)w, (double)h));     // a rotated view fits a side x side canvas
+  m->rep_cap = rep_capacity > 0 ? rep_capacity : (1 << 20);
+  m->cap = (size_t)m->rep_cap * 2 / n + (1 << 16);
+  for (int d = 0; d < n; d++) {
+    mods_ctx *c = nullptr;
+    int rc = mods_ctx_create_ex(devices[d], side, side, 1, 1, &c);
+    if (rc) return rc;
+    m->ctx.push_back(c);
+    mods_imgrep *r1 = nullptr, *r2 = nullptr;
+    if ((rc = mods_imgrep_create(c, m->rep_cap, &r1))) return rc;
+    m->rep1.push_back(r1);
+    if ((rc = mods_imgrep_create(c, m->rep_cap, &r2))) return rc;
+    m->rep2.push_back(r2);
+    MODS_HIP_CHECK(hipSetDevice(devices[d]));
+    mods_region *s = nullptr, *r = nullptr;
+    float *im = nullptr;
+    MODS_HIP_CHECK(hipMalloc(&s, sizeof(mods_region) * m->cap));
+    m->send.push_back(s);
+    MODS_HIP_CHECK(hipMalloc(&r, sizeof(mods_region) * m->cap * n));
+    m->recv.push_back(r);
+    MODS_HIP_CHECK(hipMalloc(&im, sizeof(float) * (size_t)w * h * 2));
+    m->img.push_back(im);
+  }
+  if (distinct) {
+    m->comm.assign(n, nullptr);
+    const ncclResult_t nr = ncclCommInitAll(m->comm.data(), n, devices);
+    if (nr != ncclSuccess) { set_error("ncclCommInitAll: %s", ncclGetErrorString(nr)); return MODS_E_HIP; }
+    m->use_rccl = true;
+  }
+  *out = m.release();
+  return MODS_OK;
+}
+
+int mods_multi_uses_rccl(const mods_multi *m) { return m && m->use_rccl ? 1 : 0; }
+// the accumulated regions of image 1 / 2 after a run (device 0's copy of the banks; every device holds the same lists)
+mods_imgrep *mods_multi_bank(mods_multi *m, int image) { return m ? (image ? m->rep2[0] : m->rep1[0]) : nullptr; }
+
+// The step loop of mods.cpp:202-383 with the views of every step sharded over the devices.  img1_host / img2_host: dense fp32
+// images in host memory.  Same results as mods_match_ladder_dev.  (RootSIFT lists; HalfRootSIFT steps run their doHalfSIFT
+// orientation but only the RootSIFT lists are exchanged and matched.)
+int mods_match_ladder_multi(mods_multi *m, const float *img1_host, int w1, int h1, const float *img2_host, int w2, int h2,
+                            const mods_ladder_step *steps, int n_steps, int min_matches, const mods_pair_params *par,
+                            mods_ladder_result *res, double *matches_out, int max_matches) {
+  if (!m || !img1_host || !img2_host || !steps || !par || !res) { set_error("match_ladder_multi: null argument"); return MODS_E_ARG; }
+  memset(res, 0, sizeof(*res));
+  for (int i = 0; i < 9; i++) res->H[i] = -1;
+  const int D = m->n;
+  const size_t px1 = (size_t)w1 * h1, px2 = (size_t)w2 * h2;
+  for (int d = 0; d < D; d++) {
+    MODS_HIP_CHECK(hipSetDevice(m->dev[d]));
+    hipStream_t st = (hipStream_t)mods_ctx_stream(m->ctx[d]);
+    MODS_HIP_CHECK(hipMemcpyAsync(m->img[d], img1_host, sizeof(float) * px1, hipMemcpyHostToDevice, st));
+    MODS_HIP_CHECK(hipMemcpyAsync(m->img[d] + px1, img2_host, sizeof(float) * px2, hipMemcpyHostToDevice, st));
+    mods_imgrep_clear(m->rep1[d]); mods_imgrep_clear(m->rep2[d]);
+  }
+  std::vector<mods_view_par> hist(1024), views(256);
+  int n_hist = 0;
+  int curr_matches = 0;
+  std::vector<mods_tentative> tent;
+  std::vector<double> u6, laf;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  for (int step = 0; step < n_steps && curr_matches < min_matches; step++) {
+    const mods_ladder_step &st = steps[step];
+    const int nv = mods_view_schedule(st.scale_set, st.n_scales, st.tilt_set, st.n_tilts, st.phi, hist.data(), &n_hist, (int)hist.size(),
+                                      views.data(), (int)views.size());
+    if (nv < 0) return nv;
+    // jobs in canonical order: image 1's views, then image 2's
+    std::vector<Job> jobs;
+    std::vector<double> areas;
+    for (int im = 0; im < 2; im++)
+      for (int v = 0; v < nv; v++) {
+        jobs.push_back({im, views[v]});
+        mods_view_geom g;
+        const int rc = mods_view_geometry(im ? w2 : w1, im ? h2 : h1, views[v].tilt, views[v].phi, views[v].zoom, st.initSigma, &g);
+        if (rc) return rc;
+        areas.push_back((double)g.w_new * g.h_new);
+      }
+    std::vector<std::vector<int>> mine;
+    assign_views(areas, D, &mine);
+    const double t0 = now();
+    // ---- every device: synthesise / detect / describe its views, pack the regions in job order
+    std::vector<int> job_count(jobs.size(), 0), job_det(jobs.size(), 0), job_unor(jobs.size(), 0);
+    std::vector<int> rcs(D, MODS_OK);
+    std::vector<std::string> errs(D);
+    std::vector<int> sent(D, 0);
+    {
+      std::vector<std::thread> th;
+      for (int d = 0; d < D; d++)
+        th.emplace_back([&, d] {
+          mods_ctx *c = m->ctx[d];
+          if (hipSetDevice(m->dev[d]) != hipSuccess) { rcs[d] = MODS_E_HIP; errs[d] = "hipSetDevice"; return; }
+          mods_describe_params desc = par->desc;
+          desc.ori_halfMode = (st.half_orientation || st.fginn_ratio_half > 0) ? 1 : 0;
+          desc.halfDesc = 0;
+          int off = 0;
+          for (int j : mine[d]) {
+            const Job &jb = jobs[j];
+            int nd = 0, nr = 0;
+            const float *img = m->img[d] + (jb.im ? px1 : 0);
+            int rc = mods_detect_describe_view_dev(c, img, jb.im ? w2 : w1, jb.im ? h2 : h1, jb.im ? w2 : w1, jb.v.tilt, jb.v.phi, jb.v.zoom,
+                                                   st.initSigma, st.doBlur, &par->det, &desc, nullptr, &nd, &nr);
+            if (!rc && (size_t)off + nr > m->cap) { rc = MODS_E_CAPACITY; set_error("multi: exchange buffer too small"); }
+            if (!rc && nr > 0) rc = mods_regions_copy_dev(c, 0, m->send[d] + off, nr);
+            if (rc) { rcs[d] = rc; errs[d] = mods_last_error(); return; }
+            job_count[j] = nr; job_det[j] = nd; job_unor[j] = mods_unoriented_count(c, 0);
+            off += nr;
+          }
+          sent[d] = off;
+          mods_ctx_sync(c);
+        });
+      for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < D; d++)
+      if (rcs[d]) { set_error("device %d: %s", m->dev[d], errs[d].c_str()); return rcs[d]; }
+    // ---- one all-gather of the padded blocks (the counts are known to the one host process: nothing to exchange first)
+    size_t pad = 1;
+    for (int d = 0; d < D; d++) pad = std::max(pad, (size_t)sent[d]);
+    if (m->use_rccl) {
+      ncclGroupStart();
+      for (int d = 0; d < D; d++) {
+        (void)hipSetDevice(m->dev[d]);
+        const ncclResult_t nr = ncclAllGather(m->send[d], m->recv[d], pad * sizeof(mods_region), ncclChar, m->comm[d],
+                                              (hipStream_t)mods_ctx_stream(m->ctx[d]));
+        if (nr != ncclSuccess) { ncclGroupEnd(); set_error("ncclAllGather: %s", ncclGetErrorString(nr)); return MODS_E_HIP; }
+      }
+      const ncclResult_t ge = ncclGroupEnd();
+      if (ge != ncclSuccess) { set_error("ncclGroupEnd: %s", ncclGetErrorString(ge)); return MODS_E_HIP; }
+    } else {
+      for (int dst = 0; dst < D; dst++) {
+        (void)hipSetDevice(m->dev[dst]);
+        for (int src = 0; src < D; src++)
+          if (sent[src] > 0)
+            MODS_HIP_CHECK(hipMemcpyAsync(m->recv[dst] + (size_t)src * pad, m->send[src], sizeof(mods_region) * sent[src],
+                                          hipMemcpyDeviceToDevice, (hipStream_t)mods_ctx_stream(m->ctx[dst])));
+      }
+    }
+    // ---- every device rebuilds both banks in canonical job order from what it received
+    std::vector<int> owner(jobs.size(), 0), off_in_owner(jobs.size(), 0);
+    for (int d = 0; d < D; d++) {
+      int off = 0;
+      for (int j : mine[d]) { owner[j] = d; off_in_owner[j] = off; off += job_count[j]; }
+    }
+    for (int d = 0; d < D; d++) {
+      MODS_HIP_CHECK(hipSetDevice(m->dev[d]));
+      for (size_t j = 0; j < jobs.size(); j++) {
+        if (!job_count[j]) continue;
+        const mods_region *src = m->recv[d] + (size_t)owner[j] * pad + off_in_owner[j];
+        const int rc = mods_imgrep_append_dev(jobs[j].im ? m->rep2[d] : m->rep1[d], src, job_count[j]);
+        if (rc) return rc;
+      }
+    }
+    for (size_t j = 0; j < jobs.size(); j++) {
+      res->n_views++;
+      res->n_detected[jobs[j].im] += job_det[j];
+      res->n_unoriented[jobs[j].im] += job_unor[j];
+    }
+    const int nq = mods_imgrep_count(m->rep1[0]), nt = mods_imgrep_count(m->rep2[0]);
+    res->n_described[0] = nq; res->n_described[1] = nt;
+    const double t1 = now();
+    res->ms_detect_describe += t1 - t0;
+    // ---- every device: FGINN search of its slice of the query rows against all trains
+    std::vector<std::vector<mods_tentative>> ptent(D);
+    std::vector<std::vector<double>> pu6(D), plaf(D);
+    {
+      std::vector<std::thread> th;
+      for (int d = 0; d < D; d++)
+        th.emplace_back([&, d] {
+          if (hipSetDevice(m->dev[d]) != hipSuccess) { rcs[d] = MODS_E_HIP; errs[d] = "hipSetDevice"; return; }
+          const int q0 = (int)((long long)nq * d / D), q1 = (int)((long long)nq * (d + 1) / D);
+          const int cap = std::max(1, q1 - q0);
+          ptent[d].resize(cap); pu6[d].resize((size_t)cap * 6); plaf[d].resize((size_t)cap * 14);
+          int n = 0;
+          const int rc = mods_match_reps(m->ctx[d], m->rep1[d], q0, q1, m->rep2[d], st.fginn_ratio, par->contradDist, par->nn, ptent[d].data(),
+                                         pu6[d].data(), plaf[d].data(), cap, &n);
+          if (rc) { rcs[d] = rc; errs[d] = mods_last_error(); return; }
+          ptent[d].resize(n); pu6[d].resize((size_t)n * 6); plaf[d].resize((size_t)n * 14);
+        });
+      for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < D; d++)
+      if (rcs[d]) { set_error("device %d: %s", m->dev[d], errs[d].c_str()); return rcs[d]; }
+    tent.clear(); u6.clear(); laf.clear();
+    for (int d = 0; d < D; d++) {
+      tent.insert(tent.end(), ptent[d].begin(), ptent[d].end());
+      u6.insert(u6.end(), pu6[d].begin(), pu6[d].end());
+      laf.insert(laf.end(), plaf[d].begin(), plaf[d].end());
+    }
+    const double t2 = now();
+    res->ms_match += t2 - t1;
+    res->n_tentatives = (int)tent.size();
+    // ---- device 0's host: duplicate filter + verification
+    int stats[3] = {0, 0, 0};
+    double ms_dup = 0, ms_ran = 0;
+    const int rc = mods_verify_tentatives(m->dev[0], par, tent.data(), u6.data(), laf.data(), (int)tent.size(), &res->n_unique, &res->n_inliers,
+                                          res->H, stats, &ms_dup, &ms_ran);
+    if (rc) return rc;
+    res->ms_duplicates += ms_dup; res->ms_ransac += ms_ran;
+    res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
+    curr_matches = res->n_inliers;
+    res->steps_done = step + 1;
+  }
+  if (matches_out)
+    for (int i = 0; i < res->n_inliers && i < max_matches; i++) {
+      const double *p = &u6[(size_t)i * 6];
+      matches_out[4 * i] = p[0]; matches_out[4 * i + 1] = p[1]; matches_out[4 * i + 2] = p[3]; matches_out[4 * i + 3] = p[4];
+    }
+  return MODS_OK;
+}
+
+}  // extern "C"

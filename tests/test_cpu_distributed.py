@@ -76,3 +76,22 @@ def test_two_rank_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\\n%s" % (r, o)
         assert "rank %d ok" % r in o
+
+
+def test_multi_gpu_view_assignment_matches_the_python_rule(pkg):
+    """mods_multi_assign (the C++ multi-GPU ladder's sharding of view jobs, csrc/multi.hip) = shard.largest_first_views:
+    every job has one owner, loads are balanced, deterministic."""
+    import numpy as np
+    import importlib
+    shard = importlib.import_module("mods_light_zmq_amd.shard")
+    rng = np.random.default_rng(3)
+    for n_dev in (1, 2, 3, 8):
+        for n_jobs in (1, 5, 22, 62):
+            areas = rng.uniform(1e4, 2e6, n_jobs).round()
+            areas[::7] = areas[0]                                   # ties
+            owner = pkg.multi_assign(areas, n_dev)
+            want = shard.largest_first_views(list(areas), n_dev)
+            for d, jobs in enumerate(want):
+                assert sorted(jobs) == list(np.flatnonzero(owner == d)), (n_dev, n_jobs, d)
+            loads = [areas[owner == d].sum() for d in range(n_dev)]
+            assert max(loads) - min(loads) <= areas.max() + 1e-9      # LPT: no device is more than one job ahead
