@@ -77,9 +77,11 @@ def build_model(name, weights=None, seed=0, device="cpu"):
 
     torch.manual_seed(seed)
     net = {"hardnet": lambda: HardNet(), "affnet": lambda: ShapeNet(3, 0), "orinet": lambda: ShapeNet(2, 1)}[name]()
-    if weights:
-        ck = torch.load(weights, map_location="cpu")
-        net.load_state_dict(ck["state_dict"] if "state_dict" in ck else ck)
+    if isinstance(weights, dict):           # tensors by name (e.g. the arrays of tests/golden/nets.npz)
+        net.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in weights.items()})
+    elif weights:
+        ck = torch.load(weights, map_location="cpu", weights_only=False)
+        net.load_state_dict(ck["state_dict"] if "state_dict" in ck else ck)   # strict: the architecture has to be the checkpoint's
     net = net.eval().to(device)
 
     def run(p):
@@ -120,7 +122,8 @@ def main():
     ap.add_argument("--model", default="hardnet", choices=["hardnet", "affnet", "orinet", "stats"])
     ap.add_argument("--port", default=None, help="TCP port (default: 5555 hardnet, 5556 affnet, 5557 orinet)")
     ap.add_argument("--bind", default=None, help="full endpoint instead of tcp://*:PORT")
-    ap.add_argument("--weights", default=None)
+    ap.add_argument("--weights", default=None, help="checkpoint (.pth with a 'state_dict' entry, as the reference's servers load it); "
+                                                    "FILE.npz: arrays named <model>.<parameter> (tests/golden/nets.npz)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", default=None, help="cuda (MI355X through ROCm) or cpu; default: cuda when available")
     ap.add_argument("--max-requests", type=int, default=0)
@@ -131,7 +134,13 @@ def main():
         device = "cuda" if torch.cuda.is_available() else "cpu"
     port = args.port or {"hardnet": "5555", "affnet": "5556", "orinet": "5557", "stats": "5558"}[args.model]
     endpoint = args.bind or "tcp://*:" + port
-    model = build_model(args.model, args.weights, args.seed, device or "cpu")
+    weights = args.weights
+    if weights and weights.endswith(".npz"):
+        g = np.load(weights)
+        weights = {k[len(args.model) + 1:]: g[k] for k in g.files if k.startswith(args.model + ".")}
+        if not weights:
+            raise SystemExit("zmq_daemon: %s holds no arrays named %s.*" % (args.weights, args.model))
+    model = build_model(args.model, weights, args.seed, device or "cpu")
     print("zmq_daemon: %s on %s, serving %s" % (args.model, device or "cpu", endpoint), file=sys.stderr, flush=True)
     serve(endpoint, model, args.max_requests)
 

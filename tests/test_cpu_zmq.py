@@ -141,3 +141,27 @@ def test_client_times_out_without_a_daemon(wire):
     rc = wire.mods_zmq_describe(("tcp://127.0.0.1:%d" % _free_port()).encode(), p.ctypes.data_as(C.c_void_p), 1, 32,
                                 out.ctypes.data_as(C.c_void_p), C.c_size_t(512), C.byref(dim), 300)
     assert rc != 0 and b"zmq_recv" in wire.mods_zmq_last_error()
+
+
+def _nets_fixture():
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nets.npz"))
+    weights = {tag: {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + ".")} for tag in ("affnet", "orinet")}
+    return g, weights
+
+
+def test_daemon_networks_match_the_reference_checkpoints():
+    """tests/golden/nets.npz (tools/gen_nets_golden.py): outputs of the REFERENCE's AffNetFast / OriNetFast classes
+    (build/affnet_server.py, build/orinet_server.py) with the reference's build/AffNet.pth / OriNet.pth on fixed patches.
+    The daemon's modules take the same tensors (strict load) and give the same numbers on the CPU."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("zmq_daemon", DAEMON)
+    zd = importlib.util.module_from_spec(spec); spec.loader.exec_module(zd)
+    g, weights = _nets_fixture()
+    patches = g["patches"].astype(np.float32)[:, None]
+    for tag in ("affnet", "orinet"):
+        got = zd.build_model(tag, weights=weights[tag], device="cpu")(patches)
+        assert got.shape == g[tag + "_out"].shape
+        assert np.max(np.abs(got - g[tag + "_out"])) < 1e-5, tag
+    assert np.all(g["affnet_out"][:, 0] > 0.5) and np.all(g["affnet_out"][:, 2] > 0.5)      # the +1 of AffNetFast.forward

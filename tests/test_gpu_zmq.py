@@ -78,3 +78,31 @@ def test_patch_columns_bit_exact_and_hardnet_daemon(pkg):
         ctx.close()
     finally:
         _stop(wire, d, port)
+
+
+@pytest.mark.parametrize("model", ["affnet", "orinet"])
+def test_daemon_with_reference_weights_on_the_gpu(model):
+    """The AffNet / OriNet daemon on the MI355X (PyTorch-ROCm forward) with the reference's own weights, over the wire, against
+    the outputs of the reference's network classes on the CPU (tests/golden/nets.npz, tools/gen_nets_golden.py)."""
+    from test_cpu_zmq import _describe, _stop
+    wire = C.CDLL(LIB)
+    wire.mods_zmq_last_error.restype = C.c_char_p
+    g = np.load(os.path.join(ROOT, "tests", "golden", "nets.npz"))
+    port = _free_port()
+    endpoint = "tcp://127.0.0.1:%d" % port
+    d = subprocess.Popen([sys.executable, DAEMON, "--model", model, "--bind", endpoint, "--device", "cuda", "--weights",
+                          os.path.join(ROOT, "tests", "golden", "nets.npz")], stderr=subprocess.PIPE)
+    line = ""
+    for _ in range(20):
+        line = d.stderr.readline().decode()
+        if "serving" in line or not line:
+            break
+    assert "serving" in line and "cuda" in line, line
+    time.sleep(0.2)
+    try:
+        got = _describe(wire, endpoint, g["patches"].astype(np.float32))
+        want = g[model + "_out"]
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-2)) < 1e-4     # fp32 convolutions: GPU vs the reference on the CPU
+    finally:
+        _stop(wire, d, port)
