@@ -33,7 +33,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_BLUR_TRAFFIC = 177224280   # bytes per launch of the dominant blur instantiation, profiles/r01_pmc_blur_traffic.csv
+
+
+def pmc_blur_traffic():
+    """HBM bytes per launch of the dominant blur instantiation from the committed PMC passes (profiles/r02_pmc_blur_traffic.csv:
+    FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc runs, 16 images per launch)."""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r02_pmc_blur_traffic.csv")):
+            if line.startswith("# launches of gauss_blur_fast_kernel<R; 32; 2> only:"):
+                return int(line.split(":")[1].split()[0])
+    except OSError:
+        pass
+    return None
 
 
 def cpu_baseline(img1, img2, seed):
@@ -373,14 +384,15 @@ def main():
                        "ransac_samples_last_pair": last.ransac_samples, "ransac_lo_last_pair": last.ransac_lo,
                        "stage_ms_per_pair": {"detect_describe": round(stage_ms[0] / n_pairs, 3), "match": round(stage_ms[1] / n_pairs, 3),
                                              "duplicates": round(stage_ms[2] / n_pairs, 3), "ransac": round(stage_ms[3] / n_pairs, 3)}},
-            # the dominant kernel of the pyramid: the 32-row-tile instantiation of the blur (octaves 0-1 at this batching: 95 % of
-            # the pyramid's bytes, 3/4 of its time), measured during the timed steps; the launches of the smaller planes use the
-            # 16-row instantiation and are launch-size bound: "all_blur_launches" is the figure over both
-            "roofline": {"kernel": "gauss_blur_fast_kernel<R,32,2>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            # the dominant kernel of the pyramid: the 32-row-tile instantiation of the fused blur + Hessian-response kernel (octaves
+            # 0-1 at this batching: 95 % of the pyramid's bytes), measured during the timed steps; algorithmic bytes by SURVEY 8d's
+            # unfused model: 8 B/px for the blur + 8 B/px for the response of every level it produces.  The launches of the smaller
+            # planes use the 16-row instantiation and are launch-size bound: "all_blur_launches" is the figure over both
+            "roofline": {"kernel": "gauss_blur_fast_kernel<R,32,2,true> (blur + Hessian response)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
                          # note + WRITE_SIZE, mean over the blur launches of the default batching, 16 images per launch)
-                         "traffic": PMC_BLUR_TRAFFIC if (pipe is not None and args.pairs_per_batch == 8) else None,
+                         "traffic": pmc_blur_traffic() if (pipe is not None and args.pairs_per_batch == 8) else None,
                          "measured": "HIP events on the workers' streams during the timed steps",
                          "launches": blur_n, "mean_launch_us": round(blur_ms / max(blur_n, 1) * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(blur_bytes / max(blur_n, 1), 1),

@@ -178,7 +178,12 @@ constexpr int FB_TW = 128;   // tile width; the tile height is a template parame
 // (FB_TW - 4) x (FB_TH - 2) pixels starting at (x0 + 1, y0 + 1).
 struct f4u { float x, y, z, w; } __attribute__((packed, aligned(4)));   // float4 store at a 4-byte aligned address
 
-template <int R, int FB_TH, int OV, bool RESP>
+// STAGE = true: the input tile (ROWS x (FB_TW + 8*R4) pixels) is first brought into LDS with one coalesced, non-redundant
+// pass of 16-byte loads (all of a thread's loads in flight together), and the row pass takes its register windows from LDS.
+// Without it every thread loads its own window from global memory: adjacent threads' windows overlap, a workgroup issues
+// ~4.6x the tile's bytes as vector-memory instructions, and the PMC counters show the waves stalled at issue behind the
+// memory pipeline (profiles/r02_describe_pmc_digest.txt: stall 0.35-0.49 of the wave time).
+template <int R, int FB_TH, int OV, bool RESP, bool STAGE>
 __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               BlurTaps taps, float *__restrict__ resp, float norm2) {
   constexpr int N = 2 * R + 1;
@@ -208,12 +213,56 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
   src += plane * img;
   dst += plane * img;
   const int x0 = txi * SX, y0 = tyi * SY;
+  constexpr int IW4 = FB_TW / 4 + 2 * R4;     // float4s per staged input row
+  constexpr int IWP = 4 * IW4 + 4;            // its LDS pitch in floats
+  float *s_in = smem + ROWS * FB_TW;
+  if constexpr (STAGE) {
+    constexpr int NL = (ROWS * IW4 + 255) / 256;
+    const bool rows_aligned = (w & 3) == 0;
+    float4 q[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int e = tid + 256 * i;
+      q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < ROWS * IW4) {
+        const int ly = e / IW4, c4 = e - ly * IW4;
+        int gy = y0 - R + ly;
+        gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+        const float *row = src + (size_t)gy * w;
+        const int gx = x0 - 4 * R4 + 4 * c4;
+        if (rows_aligned && gx >= 0 && gx + 3 <= w - 1) q[i] = *(const float4 *)(row + gx);
+        else {   // BORDER_REPLICATE at the left / right edge (and planes whose rows are not 16-byte aligned)
+          const int g0 = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx), g1 = gx + 1 < 0 ? 0 : (gx + 1 > w - 1 ? w - 1 : gx + 1);
+          const int g2 = gx + 2 < 0 ? 0 : (gx + 2 > w - 1 ? w - 1 : gx + 2), g3 = gx + 3 < 0 ? 0 : (gx + 3 > w - 1 ? w - 1 : gx + 3);
+          q[i] = make_float4(row[g0], row[g1], row[g2], row[g3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int e = tid + 256 * i;
+      if (e < ROWS * IW4) {
+        const int ly = e / IW4, c4 = e - ly * IW4;
+        *(float4 *)(s_in + ly * IWP + 4 * c4) = q[i];
+      }
+    }
+    __syncthreads();
+  }
   // Row pass.  The memory pipeline takes about one clock per lane and load whatever the width, so the window of a thread is
   // kept wide: NO outputs from NV aligned float4 loads (1.25 loads per 4 outputs at OV = 1, R = 5..8; 0.75 at OV = 2).
   const int rc = tid % TPR;                   // output group within the row
   const int xg = x0 + NO * rc;
   const bool fast_x = ((w & 3) == 0) && (xg - 4 * R4 >= 0) && (xg + NO - 1 + 4 * R4 <= w - 1);   // aligned rows, whole window inside the row
   auto load_window = [&](int ly, float *win) {
+    if constexpr (STAGE) {
+      const float *row = s_in + ly * IWP + NO * rc;
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        const float4 q = *(const float4 *)(row + 4 * v);
+        win[4 * v] = q.x; win[4 * v + 1] = q.y; win[4 * v + 2] = q.z; win[4 * v + 3] = q.w;
+      }
+      return;
+    }
     int gy = y0 - R + ly;
     gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
     const float *row = src + (size_t)gy * w;
@@ -328,8 +377,8 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
         const int ly = RQ * rg + q;                       // tile row of stencil row q (owned rows start at tile row 1)
         if (ly < FB_TH) {
           const float4 a = *(const float4 *)(smem + ly * FB_TW + 4 * tc);
-          const float2 b = *(const float2 *)(smem + ly * FB_TW + 4 * tc + 4);   // tc < 31: inside the row
-          v[q][0] = a.x; v[q][1] = a.y; v[q][2] = a.z; v[q][3] = a.w; v[q][4] = b.x; v[q][5] = b.y;
+          const float4 b = *(const float4 *)(smem + ly * FB_TW + 4 * tc + 4);   // tc < 31: inside the row (a 16-byte read: an
+          v[q][0] = a.x; v[q][1] = a.y; v[q][2] = a.z; v[q][3] = a.w; v[q][4] = b.x; v[q][5] = b.y;   // 8-byte one at this stride is a 2-way bank conflict)
         } else {
 #pragma unroll
           for (int e = 0; e < 6; e++) v[q][e] = 0.f;
@@ -513,19 +562,24 @@ static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w,
     const size_t lds = sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * FB_TW;
     if (resp) {
       const int tilesB = blur_resp_tiles(w, FB_TW - 4, 4) * blur_resp_tiles(h, BLUR_TH_BIG - 2, 2) * n_img;
-      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, true>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
+      static const bool stage = getenv("MODS_BLUR_STAGE") != nullptr;   // measured neutral (0.739 vs 0.741 ms per 16-image batch): off
+      if (stage) {
+        const size_t lds_in = sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * (FB_TW + 8 * ((R + 3) / 4) + 4);
+        hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, true, true>), dim3(tilesB), dim3(256), lds + lds_in, ctx->stream, src, dst, w, h, taps, resp, norm2);
+      } else
+        hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, true, false>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
     } else {
       const int tilesB = ((w + FB_TW - 1) / FB_TW) * ((h + BLUR_TH_BIG - 1) / BLUR_TH_BIG) * n_img;
-      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, false>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, false, false>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
     }
   } else {                // small planes: short tiles, more workgroups, shorter per-thread row chains
     const size_t lds = sizeof(float) * (size_t)(16 + 2 * R) * FB_TW;
     if (resp) {
       const int tiles16 = blur_resp_tiles(w, FB_TW - 4, 4) * blur_resp_tiles(h, 16 - 2, 2) * n_img;
-      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, true>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, true, false>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
     } else {
       const int tiles16 = ((w + FB_TW - 1) / FB_TW) * ((h + 15) / 16) * n_img;
-      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, false>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, false, false>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
     }
   }
 }
