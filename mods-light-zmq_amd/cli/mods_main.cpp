@@ -16,7 +16,7 @@
 //                      time.log (io_mods.cpp:67-99, mods.cpp:528-540); exit code 0 / 1
 // Not built (outside the hot path): MSER/DoG/Harris/ORB steps of an iterations file are skipped with a
 // warning, match images (out1/out2) are not drawn, ground-truth verification is refused.  Pre-extracted input
-// (read_pre_extracted = 1) is read from .npz keypoint files.  The vector matcher is always the exact (linear) search;
+// (read_pre_extracted = 1) is read from .npz or text keypoint files.  The vector matcher is always the exact (linear) search;
 // external (ZMQ) descriptor / AffNet / OriNet daemons are used when the configuration asks for them.
 #include "../../include/mods_hip.h"
 #include "../../include/mods_zmq.h"
@@ -310,6 +310,71 @@ bool read_regions_npz(const std::string &fn, std::vector<mods_region> *out) {
   return true;
 }
 
+// ImageRepresentation::LoadRegions, imagerepresentation.cpp:1317-1354: the text keypoint file.  Header as SaveRegions writes
+// it (number of detectors; per detector: name, number of descriptors; per descriptor: name, number of regions, dimension),
+// rows as loadAR reads them (:241-253: id img_id img_reproj_id parent_id, det_kp and reproj_kp as "x y a11 a12 a21 a22
+// pyramid_scale octave_number s sub_type", dimension, values).  The reference's own SaveRegions writes a different row
+// (saveAR, :198-204: "x y s a11 a12 a21 a22 dimension values", the file this program writes too), which its LoadRegions cannot
+// read back; both row forms are accepted here, told apart by the number of values on the first row.  The regions of the first
+// 128-value descriptor list of the HessianAffine detector (or of the first detector) are returned.
+bool read_regions_txt(const std::string &fn, std::vector<mods_region> *out) {
+  std::ifstream f(fn);
+  if (!f.is_open()) { std::cerr << "Cannot open file " << fn << " to load keypoints" << std::endl; return false; }
+  int n_det = 0;
+  if (!(f >> n_det) || n_det < 0 || n_det > 64) { std::cerr << fn << ": not a keypoint file" << std::endl; return false; }
+  out->clear();
+  bool have = false;
+  for (int d = 0; d < n_det; d++) {
+    std::string det_name;
+    int n_desc = 0;
+    if (!(f >> det_name >> n_desc) || n_desc < 0 || n_desc > 64) { std::cerr << fn << ": bad detector header" << std::endl; return false; }
+    for (int k = 0; k < n_desc; k++) {
+      std::string desc_name;
+      long n = 0, dim = 0;
+      if (!(f >> desc_name >> n) || n < 0 || n > (1 << 24)) { std::cerr << fn << ": bad descriptor header" << std::endl; return false; }
+      if (n > 0 && (!(f >> dim) || dim < 0 || dim > 4096)) { std::cerr << fn << ": bad descriptor dimension" << std::endl; return false; }
+      std::string rest;
+      std::getline(f, rest);
+      const bool take = !have && dim == 128 && (det_name == "HessianAffine" || d == 0) && desc_name != "HalfRootSIFT";
+      for (long i = 0; i < n; i++) {
+        std::string line;
+        if (!std::getline(f, line)) { std::cerr << fn << ": truncated (" << desc_name << ", row " << i << ")" << std::endl; return false; }
+        if (!take) continue;
+        std::istringstream ls(line);
+        std::vector<double> v;
+        double t;
+        while (ls >> t) v.push_back(t);
+        mods_region r;
+        memset(&r, 0, sizeof(r));
+        size_t dpos;
+        if (v.size() == (size_t)(8 + dim)) {            // saveAR row
+          r.x = v[0]; r.y = v[1]; r.s = v[2]; r.a11 = v[3]; r.a12 = v[4]; r.a21 = v[5]; r.a22 = v[6];
+          if ((long)v[7] != dim) { std::cerr << fn << ": row " << i << ": dimension mismatch" << std::endl; return false; }
+          dpos = 8; r.id = (int)i; r.parent = -1;
+        } else if (v.size() == (size_t)(25 + dim)) {    // loadAR row: reproj_kp is what matching and verification use
+          r.id = (int)v[0]; r.parent = (int)v[3];
+          const double *kp = &v[14];
+          r.x = kp[0]; r.y = kp[1]; r.a11 = kp[2]; r.a12 = kp[3]; r.a21 = kp[4]; r.a22 = kp[5]; r.s = kp[8]; r.sub_type = (int)kp[9];
+          if ((long)v[24] != dim) { std::cerr << fn << ": row " << i << ": dimension mismatch" << std::endl; return false; }
+          dpos = 25;
+        } else { std::cerr << fn << ": row " << i << " of " << desc_name << " has " << v.size() << " values" << std::endl; return false; }
+        for (long q = 0; q < 128; q++) {
+          const double dv = v[dpos + q];
+          r.desc[q] = (uint8_t)(dv <= 0 ? 0 : (dv >= 255 ? 255 : (int)(dv + 0.5)));
+        }
+        out->push_back(r);
+      }
+      if (take) have = true;
+    }
+  }
+  if (!have) { std::cerr << fn << ": no 128-value descriptor list" << std::endl; return false; }
+  return true;
+}
+
+bool read_regions_any(const std::string &fn, std::vector<mods_region> *out) {   // mods.cpp:216-229: .npz or the text format
+  return ends_with(fn, ".npz") ? read_regions_npz(fn, out) : read_regions_txt(fn, out);
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -338,11 +403,7 @@ int main(int argc, char **argv) {
   if (argc >= Tmin + 4) config_fn = argv[Tmin + 3];
   if (argc >= Tmin + 5) iters_fn = argv[Tmin + 4];
   const bool pre_extracted = argc >= Tmin + 6 && atoi(argv[Tmin + 5]) > 0;   // conf1.read_pre_extracted, io_mods.cpp:602
-  if (pre_extracted && !(ends_with(k1_fn, ".npz") && ends_with(k2_fn, ".npz"))) {
-    // (the reference's text reader, loadAR, expects a layout that its own SaveRegions does not write)
-    std::cerr << "read_pre_extracted: k1 and k2 must be .npz keypoint files" << std::endl;
-    return 1;
-  }
+  // argv[Tmin + 6] = match_one_to_many: parsed by the reference (io_mods.cpp:603) and used nowhere; ignored here too
   Config cfg;
   memset(&cfg.pair, 0, sizeof(cfg.pair));
   if (read_config(config_fn, iters_fn, ver_type, &cfg)) return 1;
@@ -410,7 +471,7 @@ int main(int argc, char **argv) {
   std::vector<double> matches((size_t)4 << 20);
   if (pre_extracted) {   // mods.cpp:196-229: one step, the banks come from the keypoint files
     std::vector<mods_region> r1, r2;
-    if (!read_regions_npz(k1_fn, &r1) || !read_regions_npz(k2_fn, &r2)) return 1;
+    if (!read_regions_any(k1_fn, &r1) || !read_regions_any(k2_fn, &r2)) return 1;
     if (cfg.verbose) std::cerr << "Pre-extracted regions: " << r1.size() << " | " << r2.size() << std::endl;
     if ((!r1.empty() && mods_imgrep_append_host(rep1, r1.data(), (int)r1.size())) || (!r2.empty() && mods_imgrep_append_host(rep2, r2.data(), (int)r2.size())))
       return fail("region banks");

@@ -210,3 +210,36 @@ def test_cli_deep_configuration_three_daemons(pkg, tmp_path):
     finally:
         for d, port in procs:
             _stop(wire, d, port)
+
+
+def test_cli_pre_extracted_text_keypoint_files(pkg, tmp_path):
+    """Pre-extracted mode from TEXT keypoint files (ImageRepresentation::LoadRegions, imagerepresentation.cpp:1317-1354): rows as
+    the reference's loadAR reads them (:241-253) and rows as its SaveRegions writes them (saveAR, :198-204); with the values
+    printed at full precision both give the matches of the run that detected the regions itself."""
+    env = dict(os.environ, MODS_RANSAC_SEED="4242")
+    cfgs = [os.path.join(CFG, "classic.ini"), os.path.join(CFG, "iters_one_view.ini")]
+    res, m, regs = _library_run(pkg, [pkg.LadderStep.make((1,), 360.0)])
+
+    def write(fn, r, form):
+        with open(tmp_path / fn, "w") as f:
+            f.write("1\nHessianAffine 1\nRootSIFT %d\n128\n" % len(r))
+            for i, q in enumerate(r):
+                d = " ".join(str(int(v)) for v in q["desc"])
+                if form == "saveAR":
+                    f.write("%r %r %r %r %r %r %r 128 %s \n" % (float(q["x"]), float(q["y"]), float(q["s"]), float(q["a11"]), float(q["a12"]),
+                                                               float(q["a21"]), float(q["a22"]), d))
+                else:
+                    kp = "%r %r %r %r %r %r 0 0 %r %d" % (float(q["x"]), float(q["y"]), float(q["a11"]), float(q["a12"]), float(q["a21"]),
+                                                       float(q["a22"]), float(q["s"]), int(q["sub_type"]))
+                    f.write("%d 0 0 %d %s %s 128 %s\n" % (i, int(q["parent"]), kp, kp, d))
+    for form in ("saveAR", "loadAR"):
+        write("k1.txt", regs[0], form); write("k2.txt", regs[1], form)
+        p = subprocess.run([MODS, G1, G6, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", "0", "H.txt"] + cfgs + ["1"],
+                           cwd=tmp_path, env=env, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()
+        got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+        assert len(got) == res.n_inliers and np.allclose(got, m, rtol=1e-5, atol=1e-3), form
+    (tmp_path / "k1.txt").write_text("1\nHessianAffine 1\nRootSIFT 2\n128\n1 2 3\n")
+    p = subprocess.run([MODS, G1, G6, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", "0", "H.txt"] + cfgs + ["1"],
+                       cwd=tmp_path, env=env, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 1 and b"k1.txt" in p.stderr
