@@ -155,6 +155,8 @@ typedef struct mods_describe_params {
    * descriptor list names a "Half*" descriptor the reference estimates the dominant orientation in doHalfSIFT mode
    * (orientation modulo pi: histogram bins i and i + 18 folded after the threshold is taken) for EVERY descriptor of the view. */
   int ori_halfMode;        /* 0 */
+  int addUpRight;          /* [DominantOrientation] addUpRight (imagerepresentation.cpp:915-930): the unrotated copy of every region
+                              that passes DetectOrientation's border test is described too; those copies come first in the list */
   int halfDesc;            /* 1: also HalfRootSIFT (64 values: orientation bins j and j + 4 of the raw histogram added, then the
                               RootSIFT normalisation) for the same regions, see mods_regions_half_dev */
 } mods_describe_params;

@@ -94,6 +94,8 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   q.ori_patchSize = (int)ini.GetInteger("DominantOrientation", "patchSize", 32);
   q.ori_maxAngles = (int)ini.GetInteger("DominantOrientation", "maxAngles", 1);
   q.ori_threshold = (double)(float)ini.GetDouble("DominantOrientation", "threshold", 0.8);
+  q.addUpRight = ini.GetBoolean("DominantOrientation", "addUpRight", false) ? 1 : 0;      // io_mods.cpp:732
+  // (halfSIFTMode and addMirrored of the same section are parsed by the reference and used nowhere: io_mods.cpp:733-734)
   q.desc_mrSize = ini.GetDouble("SIFTDescriptor", "mrSize", 3.0 * std::sqrt(3.0));
   q.desc_patchSize = (int)ini.GetInteger("SIFTDescriptor", "patchSize", 41);
   q.photoNorm = ini.GetBoolean("SIFTDescriptor", "photoNorm", true) ? 1 : 0;

@@ -165,7 +165,17 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
     const int box = (int)(k.ks * kp.s);
     if (alive && check_borders(k.w, k.h, fx, fy, f11, f12, f21, f22, box, box)) alive = false;
     double n11 = kp.a11, n12 = kp.a12, n21 = kp.a21, n22 = kp.a22;
-    if (alive && k.max_angles <= 0) alive = false;   // DetectOrientation pushes nothing (addUpRight = false)
+    // addUpRight: DetectOrientation(maxAngNum = 0, addUpRight) keeps the unrotated region when the border test above passes;
+    // ReprojectRegions then repeats that test on the reprojected frame (for H = I the same test: nothing more to check)
+    bool upright = alive && k.add_upright;
+    if (upright && k.view) {
+      const double rx = (k.Hinv[0] * kp.x + k.Hinv[1] * kp.y + k.Hinv[2]);
+      const double ry = (k.Hinv[3] * kp.x + k.Hinv[4] * kp.y + k.Hinv[5]);
+      const double r11 = (k.Hinv[0] * n11 + k.Hinv[1] * n21), r12 = (k.Hinv[0] * n12 + k.Hinv[1] * n22);
+      const double r21 = (k.Hinv[3] * n11 + k.Hinv[4] * n21), r22 = (k.Hinv[3] * n12 + k.Hinv[4] * n22);
+      if (check_borders(k.ow, k.oh, (float)rx, (float)ry, (float)r11, (float)r12, (float)r21, (float)r22, box, box)) upright = false;
+    }
+    if (alive && k.max_angles <= 0) alive = false;   // DetectOrientation pushes no oriented copy
     if (alive) {
       const float curr_sc = (float)(k.ori_i2p * kp.s);
       const float a11 = f11 * curr_sc, a12 = f12 * curr_sc, a21 = f21 * curr_sc, a22 = f22 * curr_sc;
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
     }
     if (lane == 0) {
       OriOut o;
-      o.a11 = n11; o.a12 = n12; o.a21 = n21; o.a22 = n22; o.alive = alive ? 1 : 0; o.pad = inside ? 1 : 0;
+      o.a11 = n11; o.a12 = n12; o.a21 = n21; o.a22 = n22; o.alive = alive ? 1 : 0; o.pad = (inside ? 1 : 0) | (upright ? 2 : 0);
       ori[i] = o;
     }
   }
@@ -261,30 +271,35 @@ __global__ __launch_bounds__(1024) void compact_regions_kernel(DescConst k, cons
   if (n > k.max_cand) n = k.max_cand;
   if (tid == 0) { s_base = 0; s_inside = 0; }
   __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const bool alive = i < n && ori[i].alive;
-    const unsigned long long m = __ballot(alive);
-    const unsigned long long mi = __ballot(i < n && ori[i].pad);
-    if (lane == 0) { s_wave[wv] = __popcll(m); if (mi) atomicAdd(&s_inside, __popcll(mi)); }
-    __syncthreads();
-    int off = s_base;
-    for (int q = 0; q < wv; q++) off += s_wave[q];
-    if (alive) {
-      const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
-      if (slot < k.reg_cap) {
-        const mods_affkey kp = keys[i];
-        const OriOut o = ori[i];
-        mods_region r;
-        r.x = kp.x; r.y = kp.y; r.s = kp.s; r.a11 = o.a11; r.a12 = o.a12; r.a21 = o.a21; r.a22 = o.a22;
-        r.response = kp.response; r.sub_type = kp.sub_type; r.id = slot; r.parent = i; r.pad = 0;
-        // descriptor bytes are written by describe_kernel; copy the POD head only
-        memcpy(&reg[slot], &r, offsetof(mods_region, desc));
+  // pass 0 (addUpRight only): the upright copies, frames as detected; pass 1: the oriented regions behind them
+  for (int pass = k.add_upright ? 0 : 1; pass < 2; pass++) {
+    for (int base = 0; base < n; base += 1024) {
+      const int i = base + tid;
+      const bool alive = i < n && (pass ? ori[i].alive != 0 : (ori[i].pad & 2) != 0);
+      const unsigned long long m = __ballot(alive);
+      const unsigned long long mi = __ballot(pass == 1 && i < n && (ori[i].pad & 1));
+      if (lane == 0) { s_wave[wv] = __popcll(m); if (mi) atomicAdd(&s_inside, __popcll(mi)); }
+      __syncthreads();
+      int off = s_base;
+      for (int q = 0; q < wv; q++) off += s_wave[q];
+      if (alive) {
+        const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < k.reg_cap) {
+          const mods_affkey kp = keys[i];
+          const OriOut o = ori[i];
+          mods_region r;
+          r.x = kp.x; r.y = kp.y; r.s = kp.s;
+          if (pass) { r.a11 = o.a11; r.a12 = o.a12; r.a21 = o.a21; r.a22 = o.a22; }
+          else { r.a11 = kp.a11; r.a12 = kp.a12; r.a21 = kp.a21; r.a22 = kp.a22; }
+          r.response = kp.response; r.sub_type = kp.sub_type; r.id = slot; r.parent = i; r.pad = 0;
+          // descriptor bytes are written by describe_kernel; copy the POD head only
+          memcpy(&reg[slot], &r, offsetof(mods_region, desc));
+        }
       }
+      __syncthreads();
+      if (tid == 0) { int t = 0; for (int q = 0; q < 16; q++) t += s_wave[q]; s_base += t; }
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0) { int t = 0; for (int q = 0; q < 16; q++) t += s_wave[q]; s_base += t; }
-    __syncthreads();
   }
   if (tid == 0) { reg_count[b] = s_base; inside_count[b] = s_inside; }
 }
@@ -619,7 +634,7 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   k.ori_i2p = double(2 * int(par->ori_mrSize) + 1) / (double)par->ori_patchSize;
   k.max_angles = par->ori_maxAngles;
   k.ori_th = par->ori_threshold;
-  k.ori_half = par->ori_halfMode; k.half_desc = 0;
+  k.ori_half = par->ori_halfMode; k.half_desc = 0; k.add_upright = par->addUpRight;
   k.desc_mr = par->desc_mrSize; k.desc_ps = par->desc_patchSize; k.photo = par->photoNorm; k.root = par->rootSift;
   k.max_bin = par->maxBinValue;
   k.patch_rule = 0;

@@ -14,6 +14,7 @@ struct DescConst {
   int max_angles;
   double ori_th;
   int ori_half;            // doHalfSIFT of EstimateDominantAnglesFunctor
+  int add_upright;         // [DominantOrientation] addUpRight: unrotated copies, ahead of the oriented ones
   int half_desc;           // sift_kernel: HalfRootSIFT (64 values) instead of the 128-value descriptor
   double desc_mr;
   int desc_ps;

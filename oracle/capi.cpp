@@ -259,7 +259,7 @@ void orc_describe_rootsift(const float *img, int w, int h, orc_region *r, int n,
 // SynthDetectDescribeKeypoints for one identity view, HessianAffine + RootSIFT
 // (imagerepresentation.cpp:686-1104): detect -> centres inside -> orientation -> touch-boundary
 // filter -> RootSIFT.
-// flags: bit 0 = DetectOrientation in doHalfSIFT mode (what the reference does for every descriptor of a view as soon as one
+// flags: bit 2 = [DominantOrientation] addUpRight; bit 0 = DetectOrientation in doHalfSIFT mode (what the reference does for every descriptor of a view as soon as one
 // descriptor name of the step contains "Half", imagerepresentation.cpp:725-731, 909-943); bit 1 = also HalfRootSIFT:
 // out_half (same regions, desc[0..63] = HalfRootSIFT, desc[64..127] = 0) is filled.
 int orc_detect_describe_ex(const float *img, int w, int h, const orc_hessaff_params *p, double ori_mrSize,
@@ -278,6 +278,12 @@ int orc_detect_describe_ex(const float *img, int w, int h, const orc_hessaff_par
   }
   filter_centres_inside(v, w, h);
   detect_orientation(v, o, im, ori_mrSize, ori_patchSize, maxAngles, ori_th, (flags & 1) != 0);
+  if (flags & 4) {   // [DominantOrientation] addUpRight (imagerepresentation.cpp:915-930): the upright copies come first
+    std::vector<Region> up;
+    detect_orientation(v, up, im, ori_mrSize, ori_patchSize, 0, 1.0, false, true);
+    up.insert(up.end(), o.begin(), o.end());
+    o.swap(up);
+  }
   filter_touch_boundary(o, w, h);
   if ((flags & 2) && out_half) {
     std::vector<Region> hv = o;

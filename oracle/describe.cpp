@@ -219,7 +219,7 @@ bool dominant_angle(const Img &img, double max_th, float *angle_out, bool half) 
 
 // DetectOrientation, synth-detection.cpp:1039-1149 (maxAngNum = 1, addUpRight = false).
 int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, const Img &img, double mrSize,
-                       int patchSize, int maxAngles, double th, bool half) {
+                       int patchSize, int maxAngles, double th, bool half, bool add_upright) {
   const double ks = k_sigma_synth();
   std::vector<Region> tmp;
   tmp.reserve(in.size());
@@ -241,21 +241,25 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
       interpolate(img, (float)k.x, (float)k.y, (float)k.a11 * curr_sc, (float)k.a12 * curr_sc,
                   (float)k.a21 * curr_sc, (float)k.a22 * curr_sc, patch);
       float ang;
-      if (!dominant_angle(patch, th, &ang, half)) continue;
-      double si, ci;
-      det_sincos(-(double)ang, &si, &ci);
-      Region t = k;
-      t.a11 = k.a11 * ci - k.a12 * si;
-      t.a12 = k.a11 * si + k.a12 * ci;
-      t.a21 = k.a21 * ci - k.a22 * si;
-      t.a22 = k.a21 * si + k.a22 * ci;
-      t.parent = (int)i;
-      slot[i] = t; ok[i] = 1;
+      if (dominant_angle(patch, th, &ang, half)) {
+        double si, ci;
+        det_sincos(-(double)ang, &si, &ci);
+        Region t = k;
+        t.a11 = k.a11 * ci - k.a12 * si;
+        t.a12 = k.a11 * si + k.a12 * ci;
+        t.a21 = k.a21 * ci - k.a22 * si;
+        t.a22 = k.a21 * si + k.a22 * ci;
+        t.parent = (int)i;
+        slot[i] = t; ok[i] = 1;
+      }
     }
+    if (add_upright) ok[i] |= 2;     // addUpRight (:1140-1142): the unrotated region itself, after its oriented copy
   }
   }   // omp parallel
-  for (size_t i = 0; i < in.size(); i++)
-    if (ok[i]) tmp.push_back(slot[i]);
+  for (size_t i = 0; i < in.size(); i++) {
+    if (ok[i] & 1) tmp.push_back(slot[i]);
+    if (ok[i] & 2) { Region t = in[i]; t.parent = (int)i; tmp.push_back(t); }
+  }
   out.swap(tmp);
   return (int)out.size();
 }

@@ -121,7 +121,7 @@ struct Region {                 // AffineRegion subset: det_kp == reproj_kp for 
 // ReprojectRegionsAndRemoveTouchBoundary(dontRemove=true) for H=I: keep centres inside.
 void filter_centres_inside(std::vector<Region> &r, int w, int h);           // synth-detection.cpp:151-190
 int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, const Img &img,
-                       double mrSize, int patchSize, int maxAngles, double th, bool half = false);   // :1039-1149 (half: doHalfSIFT)
+                       double mrSize, int patchSize, int maxAngles, double th, bool half = false, bool add_upright = false);   // :1039-1149 (half: doHalfSIFT)
 void filter_touch_boundary(std::vector<Region> &r, int w, int h);           // ReprojectRegions :631-706
 void affnet_apply(std::vector<Region> &r, const float *a3, int w, int h, double mrSize);   // imagerepresentation.cpp:798-842
 void orinet_apply(std::vector<Region> &r, const float *yx);                               // imagerepresentation.cpp:877-899

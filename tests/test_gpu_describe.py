@@ -139,3 +139,24 @@ def test_half_orientation_and_half_rootsift(pkg):
     _assert_regions_equal(got_half, want_half)
     assert np.all(got_half["desc"][:, 64:] == 0) and got_half["desc"][:, :64].any()
     ctx.close()
+
+
+@pytest.mark.parametrize("max_angles", [1, 0])
+def test_add_upright(pkg, max_angles):
+    """[DominantOrientation] addUpRight (imagerepresentation.cpp:915-930, synth-detection.cpp:1140-1142): the unrotated copy of
+    every region that passes the border test is described too and comes first; maxAngles = 0 leaves only those."""
+    import torch
+    w, h = 640, 480
+    img = synth.texture(w, h, seed=34)
+    want, nd_want = orc.detect_describe(img, add_upright=True, max_angles=max_angles)
+    ctx = pkg.Context(0, w, h, 1)
+    desc = pkg.DescribeParams.default()
+    desc.addUpRight, desc.ori_maxAngles = 1, max_angles
+    t = torch.from_numpy(img).cuda()
+    nd, nr = ctx.detect_describe_dev(t.data_ptr(), 1, w, h, None, desc)
+    assert nd[0] == nd_want and nr[0] == len(want) > 500
+    got = ctx.regions_fetch(0)
+    _assert_regions_equal(got, want)
+    n_up = int(np.sum(got["a12"] == 0))
+    assert n_up >= len(got) // 2 and np.all(got["a12"][:n_up] == 0)
+    ctx.close()
