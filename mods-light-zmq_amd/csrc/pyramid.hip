@@ -176,15 +176,31 @@ constexpr int FB_TW = 128;   // tile width; the tile height is a template parame
 // workgroup answers for, so RESP tiles overlap: tile origins step by (FB_TW - 4, FB_TH - 2), a workgroup still blurs
 // FB_TW x FB_TH pixels (the overlap is blurred, and stored, twice with identical values) and owns the response of the
 // (FB_TW - 4) x (FB_TH - 2) pixels starting at (x0 + 1, y0 + 1).
-struct f4u { float x, y, z, w; } __attribute__((packed, aligned(4)));   // float4 store at a 4-byte aligned address
+// One 16-byte store per lane, at any 4-byte aligned address.  hipcc turns `if (whole) *(float4 *)d = s; else <guarded scalar
+// stores>` into a 12-byte + a 4-byte store (it sinks the common scalar stores of the two branches), and a float4 of alignment 4
+// likewise; the fused kernel's tail is store-issue bound (switching its stores off takes it from 0.75 to 0.40 ms per batch), so
+// the instruction is written out.  gfx950 global memory accesses only need dword alignment.
+__device__ __forceinline__ void store_f4(float *p, float x, float y, float z, float w) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f q = {x, y, z, w};
+  asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ void store_f4_nt(float *p, float x, float y, float z, float w) {   // streaming (non-temporal) form
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f q = {x, y, z, w};
+  asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(q) : "memory");
+}
 
 // STAGE = true: the input tile (ROWS x (FB_TW + 8*R4) pixels) is first brought into LDS with one coalesced, non-redundant
 // pass of 16-byte loads (all of a thread's loads in flight together), and the row pass takes its register windows from LDS.
 // Without it every thread loads its own window from global memory: adjacent threads' windows overlap, a workgroup issues
 // ~4.6x the tile's bytes as vector-memory instructions, and the PMC counters show the waves stalled at issue behind the
 // memory pipeline (profiles/r02_describe_pmc_digest.txt: stall 0.35-0.49 of the wave time).
+#ifndef BLUR_WAVES
+#define BLUR_WAVES 1
+#endif
 template <int R, int FB_TH, int OV, bool RESP, bool STAGE>
-__global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+__global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               BlurTaps taps, float *__restrict__ resp, float norm2) {
   constexpr int N = 2 * R + 1;
   constexpr int R4 = (R + 3) / 4;            // float4s on each side of the outputs
@@ -299,6 +315,9 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
 #pragma unroll
       for (int u = 0; u < NO; u++) {
         float s;
+#if defined(BLUR_DIAG) && (BLUR_DIAG & 4)
+        if (true) { s = wv[D + u + R]; } else
+#endif
         if constexpr (R <= 2) {   // ksize <= 5: cv::GaussianBlur's SymmRowSmallFilter, centre tap then the symmetric pairs
           s = wv[D + u + R] * taps.t[R];
 #pragma unroll
@@ -337,13 +356,24 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
         const float4 c = col[k + R];
         float4 s = make_float4(taps.t[R] * c.x, taps.t[R] * c.y, taps.t[R] * c.z, taps.t[R] * c.w);
 #pragma unroll
+#if defined(BLUR_DIAG) && (BLUR_DIAG & 8)
+        for (int j = 1; j <= 0; j++) {
+#else
         for (int j = 1; j <= R; j++) {
+#endif
           const float4 a = col[k + R + j], b = col[k + R - j];
           const float t = taps.t[R + j];
           s.x = fmaf(t, a.x + b.x, s.x); s.y = fmaf(t, a.y + b.y, s.y); s.z = fmaf(t, a.z + b.z, s.z); s.w = fmaf(t, a.w + b.w, s.w);
         }
         float *d = dst + (size_t)gy * w + x4;
-        if (x4 + 3 < w && ((w & 3) == 0)) *(float4 *)d = s;
+#if defined(BLUR_DIAG) && (BLUR_DIAG & 1)
+        if (s.x == 123456.f)
+#endif
+#if defined(BLUR_NT) && (BLUR_NT & 2)
+        if (x4 + 3 < w) store_f4_nt(d, s.x, s.y, s.z, s.w);
+#else
+        if (x4 + 3 < w) store_f4(d, s.x, s.y, s.z, s.w);
+#endif
         else {
           d[0] = s.x;
           if (x4 + 1 < w) d[1] = s.y;
@@ -406,7 +436,14 @@ __global__ __launch_bounds__(256) void gauss_blur_fast_kernel(const float *__res
             o[u] = out;
           }
           float *d = resp + (size_t)y * w + xr;
-          if (xr + 3 < w) { f4u q4; q4.x = o[0]; q4.y = o[1]; q4.z = o[2]; q4.w = o[3]; *(f4u *)d = q4; }
+#if defined(BLUR_DIAG) && (BLUR_DIAG & 2)
+          if (o[0] == 123456.f)
+#endif
+#if !defined(BLUR_NT) || (BLUR_NT & 1)
+          if (xr + 3 < w) store_f4_nt(d, o[0], o[1], o[2], o[3]);
+#else
+          if (xr + 3 < w) store_f4(d, o[0], o[1], o[2], o[3]);
+#endif
           else {
             if (xr < w) d[0] = o[0];
             if (xr + 1 < w) d[1] = o[1];
