@@ -148,9 +148,104 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
   }
 }
 
+// The same NMS for planes whose width is a multiple of 4: a lane answers for FOUR adjacent columns and loads them as one
+// aligned 16-byte value per row (a quarter of the load instructions per byte; these kernels are bound by the number of
+// vector-memory instructions, not by bytes), a wave covers 62 x 4 = 248 columns x NMS_ROWS rows (lanes 0 and 63 only carry the
+// columns beside the block).  In-plane test: isMax <=> val equals the maximum of its 3x3 block (no neighbour strictly larger,
+// pyramid.cpp:41-51), so the six column maxima of a lane's 3-row window are taken once (v_max3) and every pixel needs one more
+// v_max3; likewise for isMin.
+// mask layout per octave: [n_img][S][h - 2*border][words], words = 4 * ceil(w / 248): word (block, sub-column), bit = lane
+constexpr int NMS4_COLS = 248;
+constexpr int NMS4_CAP = 1024;     // in-plane extrema listed per wave before the other planes are consulted
+__global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict__ P, int oi, DetectConst k,
+                                                   unsigned long long *__restrict__ mask) {
+  const OctaveDev &o = P->oct[oi];
+  const int w = o.w, h = o.h;
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c0 = (int)blockIdx.x * NMS4_COLS - 4 + 4 * lane;          // first of the lane's four columns (multiple of 4)
+  const int r_base = k.border + (blockIdx.y * 4 + wv) * NMS_ROWS;
+  const size_t plane = (size_t)w * h * b;
+  if (r_base >= h - k.border) return;
+  const int ih = h - 2 * k.border, words = 4 * gridDim.x;
+  const int cl = c0 < 0 ? 0 : (c0 > w - 4 ? w - 4 : c0);              // lanes beside the row read a valid address (values unused)
+  const bool lane_ok = lane >= 1 && lane <= 62;
+  __shared__ unsigned int s_code[4][NMS4_CAP];
+  __shared__ float s_val[4][NMS4_CAP];
+  __shared__ unsigned long long s_hit[4][NMS_ROWS][4];
+  for (int lv = 1; lv <= k.n_scales; lv++) {
+    const float *cur = o.resp[lv] + plane;
+    const float *low = o.resp[lv - 1] + plane, *high = o.resp[lv + 1] + plane;
+    float4 own[NMS_ROWS + 2];
+#pragma unroll
+    for (int rr = 0; rr < NMS_ROWS + 2; rr++) {
+      int r = r_base - 1 + rr;
+      r = r < h - 1 ? r : h - 1;             // rows past the image are never used (clamped to stay in bounds)
+      own[rr] = *(const float4 *)(cur + (size_t)r * w + cl);
+    }
+    wave_sync();                              // the previous level's list and hit words have been consumed
+    if (lane < NMS_ROWS * 4) s_hit[wv][lane >> 2][lane & 3] = 0ull;
+    wave_sync();
+    int n_c = 0;
+    auto flush = [&]() {                      // the listed in-plane extrema against the other two planes (18 loads each)
+      wave_sync();
+      for (int t0 = 0; t0 < n_c; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < n_c) {
+          const unsigned int code = s_code[wv][t];
+          const int rr = code >> 9, ln = (code >> 3) & 63, sub = (code >> 1) & 3;
+          const int c = (int)blockIdx.x * NMS4_COLS - 4 + 4 * ln + sub;
+          if (nms_other_planes(low, high, w, r_base + rr, c, s_val[wv][t], (code & 1u) != 0)) atomicOr(&s_hit[wv][rr][sub], 1ull << ln);
+        }
+      }
+      wave_sync();
+      n_c = 0;
+    };
+#pragma unroll
+    for (int rr = 0; rr < NMS_ROWS; rr++) {
+      const int r = r_base + rr;
+      const bool row_ok = r < h - k.border;  // uniform per wave
+      if (n_c > NMS4_CAP - 4 * 64) flush();  // uniform per wave; keeps the list within its capacity whatever the plane holds
+      // the lane's 3 x 6 window: its own four columns of rows rr .. rr+2 and the columns beside them from the neighbour lanes
+      float cmx[6], cmn[6];
+      {
+        const float4 a = own[rr], m = own[rr + 1], z = own[rr + 2];
+        cmx[1] = fmaxf(fmaxf(a.x, m.x), z.x); cmn[1] = fminf(fminf(a.x, m.x), z.x);
+        cmx[2] = fmaxf(fmaxf(a.y, m.y), z.y); cmn[2] = fminf(fminf(a.y, m.y), z.y);
+        cmx[3] = fmaxf(fmaxf(a.z, m.z), z.z); cmn[3] = fminf(fminf(a.z, m.z), z.z);
+        cmx[4] = fmaxf(fmaxf(a.w, m.w), z.w); cmn[4] = fminf(fminf(a.w, m.w), z.w);
+        cmx[0] = __shfl_up(cmx[4], 1); cmn[0] = __shfl_up(cmn[4], 1);
+        cmx[5] = __shfl_down(cmx[1], 1); cmn[5] = __shfl_down(cmn[1], 1);
+      }
+      const float vals[4] = {own[rr + 1].x, own[rr + 1].y, own[rr + 1].z, own[rr + 1].w};
+#pragma unroll
+      for (int sub = 0; sub < 4; sub++) {
+        const float val = vals[sub];
+        const int c = c0 + sub;
+        const bool col_ok = lane_ok && c >= k.border && c < w - k.border;
+        const float m9 = fmaxf(fmaxf(cmx[sub], cmx[sub + 1]), cmx[sub + 2]);
+        const float n9 = fminf(fminf(cmn[sub], cmn[sub + 1]), cmn[sub + 2]);
+        const bool cmax = row_ok && col_ok && val > k.pos_th && !(m9 > val);
+        const bool cmin = row_ok && col_ok && !cmax && val < k.neg_th && !(n9 < val);
+        const bool cnd = cmax || cmin;
+        const unsigned long long m = __ballot(cnd);
+        if (cnd) {
+          const int pos = n_c + __popcll(m & ((1ull << lane) - 1ull));
+          s_code[wv][pos] = ((unsigned int)rr << 9) | ((unsigned int)lane << 3) | ((unsigned int)sub << 1) | (cmax ? 1u : 0u);
+          s_val[wv][pos] = val;
+        }
+        n_c += __popcll(m);
+      }
+    }
+    flush();
+    unsigned long long *mrow = mask + (((size_t)b * k.n_scales + (lv - 1)) * ih + (r_base - k.border)) * words + 4 * blockIdx.x;
+    if (lane < NMS_ROWS * 4 && r_base + (lane >> 2) < h - k.border) mrow[(size_t)(lane >> 2) * words + (lane & 3)] = s_hit[wv][lane >> 2][lane & 3];
+  }
+}
+
 // grid = (ceil(total_words/256), n_img), block 256: ballot words -> hit records
 __global__ __launch_bounds__(256) void nms_compact_kernel(int oi, int w, int h, DetectConst k, const unsigned long long *__restrict__ mask,
-                                                          int words, CandDev *__restrict__ cand, int *__restrict__ cand_count) {
+                                                          int words, CandDev *__restrict__ cand, int *__restrict__ cand_count, int wide) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
   const int b = blockIdx.y;
@@ -177,13 +272,16 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(int oi, int w, int h, 
   const int lv = idx / (ih * words) + 1;
   const int rem = idx - (lv - 1) * ih * words;
   const int r = k.border + rem / words;
-  const int c0 = k.border + (rem % words) * NMS_COLS - 1;   // bit = lane of nms_kernel (1..62)
+  // column of bit `bit`: nms_kernel: border + block * 62 - 1 + bit; nms4_kernel (wide): block * 248 - 4 + 4 * bit + sub-column
+  const int wi = rem % words;
+  const int c0 = wide ? (wi >> 2) * NMS4_COLS - 4 + (wi & 3) : k.border + wi * NMS_COLS - 1;
+  const int cstep = wide ? 4 : 1;
   while (m) {
     const int bit = __ffsll((long long)m) - 1;
     m &= m - 1;
     if (slot < k.max_cand) {
       CandDev &cd = cand[(size_t)b * k.max_cand + slot];
-      cd.octave = oi; cd.level = lv; cd.r0 = r; cd.c0 = c0 + bit; cd.state = 0;
+      cd.octave = oi; cd.level = lv; cd.r0 = r; cd.c0 = c0 + cstep * bit; cd.state = 0;
     }
     slot++;
   }
@@ -627,16 +725,19 @@ int detect_run(mods_ctx *ctx) {
       const OctaveDev &o = P.oct[oi];
       const int iw = o.w - 2 * par.border, ih = o.h - 2 * par.border;
       if (iw <= 0 || ih <= 0) continue;
-      const int words = (iw + NMS_COLS - 1) / NMS_COLS;
-      dim3 grid(words, (ih + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), n_img);
+      const bool wide = (o.w & 3) == 0 && o.w >= 8;     // rows of 16-byte aligned float4s: the four-columns-per-lane kernel
+      const int nblk = wide ? (o.w + NMS4_COLS - 1) / NMS4_COLS : (iw + NMS_COLS - 1) / NMS_COLS;
+      const int words = wide ? 4 * nblk : nblk;
+      dim3 grid(nblk, (ih + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), n_img);
       // the ballot words of this octave live at the start of the (not yet used) accept-list half of sort_idx
       unsigned long long *mask = (unsigned long long *)ctx->nms_mask;
       const size_t need_words = (size_t)n_img * par.numberOfScales * ih * words;
       if (need_words > ctx->nms_mask_words) { set_error("nms mask buffer too small"); return MODS_E_CAPACITY; }
-      hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, ctx->stream, ctx->pyr_dev, oi, k, mask);
+      if (wide) hipLaunchKernelGGL(nms4_kernel, grid, dim3(256), 0, ctx->stream, ctx->pyr_dev, oi, k, mask);
+      else hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, ctx->stream, ctx->pyr_dev, oi, k, mask);
       const int total = par.numberOfScales * ih * words;
       hipLaunchKernelGGL(nms_compact_kernel, dim3((total + 255) / 256, n_img), dim3(256), 0, ctx->stream, oi, o.w, o.h, k, mask, words,
-                         ctx->cand, ctx->cand_count);
+                         ctx->cand, ctx->cand_count, wide ? 1 : 0);
     }
     MODS_HIP_CHECK(hipGetLastError());
   }
