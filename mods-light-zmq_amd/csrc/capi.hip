@@ -540,8 +540,11 @@ static bool invert3(const double *S, double *t) {
 // LORANSACFiltering for the homography branch (useF = 0), matching.cpp:637-805: degensac LO-RANSAC,
 // H -> row-major img1->img2 by inv(H^T), NaiveHCheck (10 px, :1014-1043), H_LAF_check (:250-308).
 // mask[i] = 1 for the correspondences that survive every check.
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask, double *H_out,
                     int *n_inliers, int *stats3) {
+  const double t_enter = now_ms();
   if (!par || !mask || !H_out || !n_inliers || (n > 0 && !u6)) { set_error("loransac_h: null argument"); return MODS_E_ARG; }
   *n_inliers = 0;
   for (int i = 0; i < 9; i++) H_out[i] = -1;   // TentativeCorrespListExt(): H[i] = -1 (matching.hpp:92-99)
@@ -565,6 +568,7 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
   exp_ransacHcustom(u2.data(), n, par->err_threshold * par->err_threshold, par->confidence, max_samples, Hloran, inl2.data(), 4,
                     data_out.data(), 1, 0, &resids, f0, f1, f2, par->doSymmCheck);
   free(resids);
+  const double t_post0 = now_ms();
   if (stats3) { stats3[0] = data_out[0]; stats3[1] = data_out[1]; stats3[2] = data_out[2]; }
   // H: inv(Hloran^T); reading the column-major h as a row-major matrix is H^T, its transpose is h read column-wise
   const double Ht[9] = {Hloran[0], Hloran[3], Hloran[6], Hloran[1], Hloran[4], Hloran[7], Hloran[2], Hloran[5], Hloran[8]};
@@ -618,6 +622,7 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
   if ((int)cur.size() < MIN_POINTS) cur.clear();
   for (int i : cur) mask[i] = 1;
   *n_inliers = (int)cur.size();
+  if (getenv("MODS_RANSAC_PROF")) fprintf(stderr, "loransac_h prof: whole %.0f us, checks after RANSAC %.0f us\n", 1e3 * (now_ms() - t_enter), 1e3 * (now_ms() - t_post0));
   return MODS_OK;
 }
 
@@ -672,7 +677,6 @@ int mods_loransac_f(const double *u6, const double *laf, int n, const mods_ransa
 }
 
 // ---- one pair end to end -------------------------------------------------------------------------------
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // GPU half of a pair: detect + describe both images, match, bring the tentatives to the host.
 int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,

@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "ransac_host.hpp"
 #include "ransac_gpu.hpp"
+#include "ransac_simd.hpp"
 #include "ransac_dev.hpp"
 #include <ctime>
 #include <cstdlib>
@@ -71,22 +72,46 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double *__restr
   }
 }
 
-// grid = ceil(n_hyp/64), block 64: lane k sums gain[i][k] for i = 0..len-1 in order.
-__global__ void __launch_bounds__(64) ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride,
-                                                         double *__restrict__ J) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= n_hyp) return;
-  double s = 0;
-  int i = 0;
-  for (; i + 15 < len; i += 16) {   // loads batched, additions in correspondence order
-    double v[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = gain[(size_t)(i + q) * kstride + k];
-#pragma unroll
-    for (int q = 0; q < 16; q++) s += v[q];
+// grid = ceil(n_hyp/64), block 256: lane k of wave 0 sums gain[i][k] for i = 0..len-1 in order.  The sum is a serial
+// chain, so one wave adds; what it would wait for is the memory latency of 8 bytes per row, so all four waves fetch the
+// next GAIN_ROWS rows into registers while wave 0 adds the current ones out of LDS.  The gain matrix has hyp_cap (a
+// multiple of 64) columns, so every lane's column exists.
+constexpr int GAIN_ROWS = 128;
+__global__ void __launch_bounds__(256) ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride,
+                                                          double *__restrict__ J) {
+  __shared__ double s_rows[GAIN_ROWS][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  constexpr int PER = GAIN_ROWS / 4;
+  double v[PER];
+  double sum = 0;
+#define GAIN_FETCH(c0)                                                                  \
+  _Pragma("unroll") for (int j = 0; j < PER; j++) {                                     \
+    const int row = (c0) + wv + 4 * j;                                                  \
+    v[j] = row < len ? gain[(size_t)row * kstride + k] : 0.0;                           \
   }
-  for (; i < len; i++) s += gain[(size_t)i * kstride + k];
-  J[k] = s;
+  GAIN_FETCH(0)
+  for (int c0 = 0; c0 < len; c0 += GAIN_ROWS) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) s_rows[wv + 4 * j][lane] = v[j];
+    __syncthreads();
+    if (c0 + GAIN_ROWS < len) { GAIN_FETCH(c0 + GAIN_ROWS) }
+    if (wv == 0) {
+      const int rows = min(GAIN_ROWS, len - c0);
+      int r = 0;
+      for (; r + 15 < rows; r += 16) {
+        double t[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) t[q] = s_rows[r + q][lane];
+#pragma unroll
+        for (int q = 0; q < 16; q++) sum += t[q];
+      }
+      for (; r < rows; r++) sum += s_rows[r][lane];
+    }
+    __syncthreads();
+  }
+#undef GAIN_FETCH
+  if (wv == 0 && k < n_hyp) J[k] = sum;
 }
 
 RansacGpu::~RansacGpu() {
@@ -123,7 +148,11 @@ RansacGpu *ransac_gpu() {
     int dev;
     { std::lock_guard<std::mutex> lk(g_cfg_mutex); dev = g_ransac_device; }
     if (hipSetDevice(dev) != hipSuccess) { set_error("hipSetDevice(%d) failed", dev); return nullptr; }
-    if (hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking) != hipSuccess) { set_error("stream creation failed"); return nullptr; }
+    // the scoring launches are tiny and a host thread waits for each of them: highest priority, so that they do not
+    // queue behind a describe batch of the pipeline's GPU workers (16-25 ms per call when they did)
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (hipStreamCreateWithPriority(&ws.stream, hipStreamNonBlocking, prio_high) != hipSuccess) { set_error("stream creation failed"); return nullptr; }
     ws.device = dev;
   }
   (void)hipSetDevice(ws.device);
@@ -134,12 +163,15 @@ bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
   if ((size_t)len * 6 > ws->u_cap) {
     if (ws->u_dev) RS_CHECK(hipFree(ws->u_dev));
     ws->u_cap = (size_t)len * 6 * 2;
+    if (ws->u_cap < 6 * 16384) ws->u_cap = 6 * 16384;
     RS_CHECK(hipMalloc(&ws->u_dev, ws->u_cap * sizeof(double)));
   }
   if (n_hyp > ws->hyp_cap) {
     if (ws->hyp_dev) { RS_CHECK(hipFree(ws->hyp_dev)); RS_CHECK(hipHostFree(ws->hyp_host)); RS_CHECK(hipFree(ws->counts_dev));
                        RS_CHECK(hipFree(ws->J_dev)); RS_CHECK(hipHostFree(ws->counts_host)); RS_CHECK(hipHostFree(ws->J_host)); }
-    ws->hyp_cap = n_hyp;
+    ws->hyp_cap = 64;
+    while (ws->hyp_cap < n_hyp) ws->hyp_cap *= 2;
+    n_hyp = ws->hyp_cap;
     RS_CHECK(hipMalloc(&ws->hyp_dev, (size_t)HYP_SLOT_BYTES * n_hyp));
     RS_CHECK(hipHostMalloc(&ws->hyp_host, (size_t)HYP_SLOT_BYTES * n_hyp));
     RS_CHECK(hipMalloc(&ws->counts_dev, sizeof(int) * 2 * n_hyp));
@@ -148,7 +180,11 @@ bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
     RS_CHECK(hipHostMalloc(&ws->J_host, sizeof(double) * n_hyp));
     ws->dg_cap = 0;
   }
-  const size_t need = (size_t)len * ws->hyp_cap;
+  // hipFree / hipMalloc synchronise the whole device (20+ ms under a running pipeline): grow in powers of two from a
+  // floor that covers an ordinary pair, so that a worker stops reallocating after its first call
+  size_t len_cap = 16384;
+  while (len_cap < (size_t)len) len_cap *= 2;
+  const size_t need = len_cap * ws->hyp_cap;
   if (need > ws->dg_cap) {
     if (ws->d_dev) { RS_CHECK(hipFree(ws->d_dev)); RS_CHECK(hipFree(ws->gain_dev)); }
     ws->dg_cap = need;
@@ -158,6 +194,7 @@ bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
   if ((size_t)len > ws->row_cap) {
     if (ws->row_host) RS_CHECK(hipHostFree(ws->row_host));
     ws->row_cap = (size_t)len * 2;
+    if (ws->row_cap < 16384) ws->row_cap = 16384;
     RS_CHECK(hipHostMalloc(&ws->row_host, ws->row_cap * sizeof(double)));
   }
   return true;
@@ -169,7 +206,7 @@ static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, d
   RS_CHECK(hipMemsetAsync(ws->counts_dev, 0, sizeof(int) * 2 * n, ws->stream));
   hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, (const HypDev *)ws->hyp_dev, err_type,
                      do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
-  hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(64), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
+  hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
   RS_CHECK(hipGetLastError());
   RS_CHECK(hipMemcpyAsync(ws->counts_host, ws->counts_dev, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
   RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ws->stream));
@@ -247,13 +284,44 @@ void mods_ransac_pin_seed(long seed) { std::lock_guard<std::mutex> lk(g_cfg_mute
 
 namespace mods {
 
-struct ErrFn {   // host-side error function of the run (LO path)
-  int type; HDsPtr custom;
+// MODS_RANSAC_PROF=1: per-call breakdown of the verification on stderr (development aid)
+struct RsProf { double us[8]; };   // 0 hypotheses, 1 gpu_score, 2 fetch_row, 3 LO u2h, 4 LO error function, 5 LO, 6 upload, 7 whole call
+static thread_local RsProf g_rsprof;
+static int rsprof_on() { static const int on = getenv("MODS_RANSAC_PROF") ? 1 : 0; return on; }
+static inline double rs_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+struct RsTimer {
+  int slot; double t0;
+  explicit RsTimer(int s) : slot(s), t0(rsprof_on() ? rs_now_us() : 0) {}
+  ~RsTimer() { if (rsprof_on()) g_rsprof.us[slot] += rs_now_us() - t0; }
+};
+
+// Structure-of-arrays copy of the correspondences for the host SIMD error functions (ransac_simd.hpp); every per-point
+// buffer of the run is padded to n_pad so that whole vectors can be read and written.
+struct PointsSoA {
+  const rs::SimdOps *ops = rs::simd_ops();
+  int len = 0, n_pad = 0;
+  std::vector<double> store, gains;
+  const double *col[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  void build(const double *u, int n) {
+    len = n; n_pad = (n + rs::SIMD_PAD - 1) / rs::SIMD_PAD * rs::SIMD_PAD;
+    store.resize((size_t)5 * n_pad); gains.assign(n_pad, 0.0);
+    const int comp[5] = {0, 1, 3, 4, 5};
+    for (int c = 0; c < 5; c++) {
+      double *dst = store.data() + (size_t)c * n_pad;
+      for (int i = 0; i < n_pad; i++) dst[i] = u[(size_t)6 * (i < n ? i : n - 1) + comp[c]];
+      col[c] = dst;
+    }
+  }
+};
+
+struct ErrFn {   // host-side error function of the run (LO path); d has room for n_pad values
+  int type; HDsPtr custom; const PointsSoA *pts;
   void operator()(const double *u, const double *H, double *d, int len) const {
+    RsTimer t_(4);
     if (custom) { custom(nullptr, u, H, d, len); return; }
-    if (type == ERR_SAMPSON) HDs(nullptr, u, H, d, len);
-    else if (type == ERR_SYMSUM) HDsSym(nullptr, u, H, d, len);
-    else HDsSymMax(nullptr, u, H, d, len);
+    if (type == ERR_SAMPSON) { pts->ops->hds_all(pts->col, pts->n_pad, H, d); return; }
+    rs::SymH s; rs::sym_prepare(H, &s);
+    pts->ops->hsym_all(pts->col, pts->n_pad, s.H1, s.Hinv, type == ERR_SYMSUM ? 0 : 1, d);
   }
 };
 
@@ -265,7 +333,22 @@ struct LoState {
   rs::HashTable *ht;
   unsigned inlLimit;
   ErrFn errfn;
+  PointsSoA *pts;
 };
+
+// inlidxs, rtools.c:155-166: the gains are computed lanes-wide, the MSAC sum and the index list stay sequential
+static rs::Score inlidxs_v(const LoState &L, const double *err, double th, int *inl) {
+  if (th == 0) return rs::inlidxs(err, L.len, th, inl);
+  double *g = L.pts->gains.data();
+  L.pts->ops->gains_all(err, L.pts->n_pad, th * 9 / 4, g);
+  rs::Score s = {0, 0};
+  const int len = L.len;
+  for (int i = 0; i < len; ++i) {
+    s.J += g[i];
+    if (err[i] <= th) { inl[s.I] = i; ++(s.I); }
+  }
+  return s;
+}
 
 // exp_iterHcustom, exp_ranH.c:617-737 (__D3__ with inlLimit = 1e6 => least squares on all
 // inliers; __HASHING__ on)
@@ -279,25 +362,26 @@ static Score lo_iter(LoState &L, int *inliers, double th, double ths, int steps,
     unsigned detached = (unsigned)(int)(Sc.I * 1);
     if (detached > L.inlLimit) detached = L.inlLimit;
     if (detached < 4) detached = 4;
+    RsTimer t_(3);
     if (detached >= Sc.I) rs::u2h(L.u, inliers, (int)Sc.I, h, L.buffer);
     else {
       int *sub = rs::randsubset(*L.rng, inliers, (int)Sc.I, (int)detached);
       rs::u2h(L.u, sub, (int)detached, h, L.buffer);
     }
   };
-  maxS = rs::inlidxs(L.errs[4], len, th, inliers);
+  maxS = inlidxs_v(L, L.errs[4], th, inliers);
   if (maxS.I < 4) return S;
-  S = rs::inlidxs(L.errs[4], len, th * 2, inliers);   // th*MWM, MWM = (9/4) = 2 (rtools.h:33)
+  S = inlidxs_v(L, L.errs[4], th * 2, inliers);   // th*MWM, MWM = (9/4) = 2 (rtools.h:33)
   lsq(S);
   for (int it = 0; it < steps; it++) {
     L.errfn(L.u, h, d, len);
     memcpy(resids + (size_t)it * len, d, len * sizeof(double));
-    Ss = rs::inlidxs(d, len, th, inliers);
+    Ss = inlidxs_v(L, d, th, inliers);
     const uint32_t hash = rs::super_fast_hash((const char *)inliers, (int)(Ss.I * sizeof(*inliers)));
     const int ret = L.ht->contains(hash, (int)Ss.I, iterID);
     if (ret != -1 && ret != iterID) { S.I = 0; S.J = 0; return S; }
     if (ret == -1) L.ht->insert(hash, (int)Ss.I, iterID);
-    S = rs::inlidxs(d, len, ths * 2, inliers);
+    S = inlidxs_v(L, d, ths * 2, inliers);
     if (rs::score_less(maxS, Ss)) {
       maxS = Ss;
       L.errs[1] = L.errs[0];
@@ -311,7 +395,7 @@ static Score lo_iter(LoState &L, int *inliers, double th, double ths, int steps,
   }
   L.errfn(L.u, h, d, len);
   memcpy(resids + (size_t)4 * len, d, len * sizeof(double));
-  S = rs::inlidxs(d, len, th, inliers);
+  S = inlidxs_v(L, d, th, inliers);
   if (rs::score_less(maxS, S)) {
     maxS = S;
     L.errs[1] = L.errs[0];
@@ -363,6 +447,67 @@ static double h_tol3(const double *h) {   // exp_ranH.c:877-885
 
 }  // namespace mods
 
+// ---- host-only self-test hooks of the LO step's fast forms (no device needed) ----------------------------------------
+extern "C" {
+// type 0 Sampson, 1 symmetric sum, 2 symmetric max; lanes 0 = the scalar functions above, 1 / 4 / 8 = ransac_simd at that
+// width (MODS_E_ARG when this CPU lacks it)
+int mods_test_host_errfn(int type, const double *u6, int len, const double *H, int lanes, double *out) {
+  if (!u6 || !H || !out || len < 1 || type < 0 || type > 2) return MODS_E_ARG;
+  if (lanes == 0) {
+    if (type == 0) HDs(nullptr, u6, H, out, len); else if (type == 1) HDsSym(nullptr, u6, H, out, len); else HDsSymMax(nullptr, u6, H, out, len);
+    return MODS_OK;
+  }
+  PointsSoA pts;
+  pts.ops = rs::simd_ops_lanes(lanes);
+  if (!pts.ops) return MODS_E_ARG;
+  pts.build(u6, len);
+  std::vector<double> d(pts.n_pad);
+  ErrFn f = {type == 0 ? ERR_SAMPSON : type == 1 ? ERR_SYMSUM : ERR_SYMMAX, nullptr, &pts};
+  f(u6, H, d.data(), len);
+  memcpy(out, d.data(), sizeof(double) * len);
+  return MODS_OK;
+}
+// u2h (Htools.c:100-132) of the correspondences inl[0..n): reference_form 1 = lin_hgN + cov_mat as written there, 0 = cov_hgN
+int mods_test_host_u2h(const double *u6, const int *inl, int n, int reference_form, double *H) {
+  if (!u6 || !inl || !H || n < 4) return MODS_E_ARG;
+  std::vector<double> buffer((size_t)18 * n + 81);
+  rs::u2h(u6, inl, n, H, buffer.data(), reference_form != 0);
+  return MODS_OK;
+}
+// the 9 x 9 moment matrix alone (normu + lin_hgN + cov_mat, or cov_hgN)
+int mods_test_host_cov(const double *u6, const int *inl, int n, int reference_form, double *Cv) {
+  if (!u6 || !inl || !Cv || n < 1) return MODS_E_ARG;
+  double A1[3], A2[3];
+  rs::normu(u6, inl, n, A1, A2);
+  if (reference_form) {
+    std::vector<double> Z((size_t)18 * n);
+    rs::lin_hgN(u6, Z.data(), inl, n, A1, A2);
+    rs::cov_mat(Cv, Z.data(), 2 * n, 9);
+  } else rs::cov_hgN(u6, inl, n, A1, A2, Cv);
+  return MODS_OK;
+}
+// inlidxs (rtools.c:155-166): lanes 0 = scalar
+int mods_test_host_inlidxs(const double *err, int len, double th, int lanes, int *inl, unsigned *I, double *J) {
+  if (!err || !inl || !I || !J || len < 1) return MODS_E_ARG;
+  rs::Score s;
+  if (lanes == 0) s = rs::inlidxs(err, len, th, inl);
+  else {
+    PointsSoA pts;
+    pts.ops = rs::simd_ops_lanes(lanes);
+    if (!pts.ops) return MODS_E_ARG;
+    pts.len = len; pts.n_pad = (len + rs::SIMD_PAD - 1) / rs::SIMD_PAD * rs::SIMD_PAD;
+    pts.gains.assign(pts.n_pad, 0.0);
+    std::vector<double> e(pts.n_pad, 0.0);
+    memcpy(e.data(), err, sizeof(double) * len);
+    LoState L = {};
+    L.len = len; L.pts = &pts;
+    s = inlidxs_v(L, e.data(), th, inl);
+  }
+  *I = s.I; *J = s.J;
+  return MODS_OK;
+}
+}  // extern "C"
+
 extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
                                     int iter_type, int *data_out, int oriented_constraint, unsigned inlLimit, double **resids,
                                     HDsPtr HDS1, HDsiPtr HDSi1, HDsidxPtr HDSidx1, int doSymCheck) {
@@ -371,6 +516,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
   const int RESIDS_M = 2 + 10 * (1 + 4 + 1);
   if (resids) *resids = (double *)malloc(0 * sizeof(double) + 8);
   if (len < 4 || !u || !H || !inl || !data_out) { if (data_out) { data_out[0] = 0; data_out[1] = 0; data_out[2] = 0; } return maxS; }
+  const double t_call0 = rsprof_on() ? rs_now_us() : 0;
   RansacGpu *ws = ransac_gpu();
   if (!ws) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }   // no CPU fallback
   int err_type; HDsPtr custom = nullptr;
@@ -387,9 +533,11 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
 
   std::vector<int> pool(len), inliers(len);
   for (int i = 0; i < len; i++) pool[i] = i;
-  std::vector<double> buffer((size_t)len * 18), err((size_t)len * 4), d_check(len);
+  PointsSoA pts;
+  pts.build(u, len);
+  std::vector<double> buffer((size_t)len * 18), err((size_t)pts.n_pad * 4), d_check(len);
   double *errs[5];
-  for (int i = 0; i < 4; i++) errs[i] = err.data() + (size_t)i * len;
+  for (int i = 0; i < 4; i++) errs[i] = err.data() + (size_t)i * pts.n_pad;
   errs[4] = errs[3];
   int no_sam = 0, iter_cnt = 0, no_rej = 0, iterID = 0;
   unsigned seed = (unsigned)rng.next();   // seed = rand()
@@ -397,12 +545,14 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
   const double CHECK_COEF = 9.0;
   const unsigned MIN_GOOD_SYM_PTS = 5;
   const double th_check = CHECK_COEF * th;
-  ErrFn errfn = {err_type, custom};
-  LoState L = {u, len, th, {errs[0], errs[1], errs[2], errs[3], errs[4]}, buffer.data(), &rng, &ht, inlLimit, errfn};
+  ErrFn errfn = {err_type, custom, &pts};
+  LoState L = {u, len, th, {errs[0], errs[1], errs[2], errs[3], errs[4]}, buffer.data(), &rng, &ht, inlLimit, errfn, &pts};
 
+  const double t_up0 = rsprof_on() ? rs_now_us() : 0;
   if (!ransac_ws_reserve(ws, len, 64)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
   if (hipMemcpyAsync(ws->u_dev, u, sizeof(double) * 6 * len, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
       hipStreamSynchronize(ws->stream) != hipSuccess) { fprintf(stderr, "libmodsgpu: upload failed\n"); abort(); }
+  if (rsprof_on()) g_rsprof.us[6] += rs_now_us() - t_up0;
 
   // sym check of a host-side model (LO results); the per-sample check comes from the GPU counts
   auto sym_bad = [&](const double *hh) -> bool {
@@ -414,6 +564,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
   // LO block of the main loop, exp_ranH.c:961-1074 (iter_type 4 = inner RANSAC + iterated LSQ; other
   // types follow the same switch)
   auto run_lo = [&](bool *new_max) {
+    RsTimer t_lo(5);
     iter_cnt++;
     *resids = (double *)realloc(*resids, (size_t)iter_cnt * RESIDS_M * len * sizeof(double));
     double *rbase = *resids + (size_t)RESIDS_M * (iter_cnt - 1) * len;
@@ -421,7 +572,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
     switch (iter_type) {
       case 0: break;
       case 1:
-        S = rs::inlidxs(L.errs[4], len, 4 * th, inliers.data());
+        S = inlidxs_v(L, L.errs[4], 4 * th, inliers.data());
         rs::u2h(u, inliers.data(), (int)S.I, h, buffer.data());
         d = L.errs[0];
         errfn(u, h, d, len);
@@ -433,18 +584,18 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
         break;
       case 3:
         d = L.errs[0];
-        S = rs::inlidxs(L.errs[4], len, 4 * th, inliers.data());
+        S = inlidxs_v(L, L.errs[4], 4 * th, inliers.data());
         rs::u2h(u, inliers.data(), (int)S.I, h, buffer.data());
         errfn(u, h, d, len);
-        S = rs::inlidxs(d, len, th, inliers.data());
+        S = inlidxs_v(L, d, th, inliers.data());
         break;
       default: {
         memcpy(rbase, L.errs[4], len * sizeof(double));
         d = L.errs[0];
-        S = rs::inlidxs(L.errs[4], len, 4 * th * 2, inliers.data());   // TC*th*MWM
+        S = inlidxs_v(L, L.errs[4], 4 * th * 2, inliers.data());   // TC*th*MWM
         rs::u2h(u, inliers.data(), (int)S.I, h, buffer.data());
         errfn(u, h, d, len);
-        S = rs::inlidxs(d, len, th, inliers.data());
+        S = inlidxs_v(L, d, th, inliers.data());
         memcpy(rbase + len, d, len * sizeof(double));
         S = lo_inner(L, inliers.data(), (int)S.I, th, h, 10, &iterID, rbase + 2 * len);
         break;
@@ -476,6 +627,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
     batch.resize(want);
     if (!ransac_ws_reserve(ws, len, want)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
     int n_valid = 0;
+    const double t_hyp0 = rsprof_on() ? rs_now_us() : 0;
     for (int b = 0; b < want; b++) {
       Sample &sm = batch[b];
       sm.seed_before = seed;
@@ -514,8 +666,10 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
       sm.valid = 1 + n_valid;                       // 1-based slot in the scored batch
       n_valid++;
     }
+    if (rsprof_on()) g_rsprof.us[0] += rs_now_us() - t_hyp0;
     std::vector<double> custom_d;
     if (n_valid > 0) {
+      RsTimer t_(1);
       if (custom) {
         // foreign error function: scores come from the caller's code, on the host
         custom_d.resize((size_t)n_valid * len);
@@ -530,6 +684,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
       } else if (!gpu_score(ws, len, n_valid, err_type, doSymCheck, th, th_check)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
     }
     auto fetch_row = [&](int slot, double *dst) {
+      RsTimer t_(2);
       if (custom) memcpy(dst, custom_d.data() + (size_t)slot * len, sizeof(double) * len);
       else if (!ransac_fetch_row(ws, len, slot, dst)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
     };
@@ -594,6 +749,12 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
   {
     const double *d = L.errs[3];
     for (int j = 0; j < len; j++) inl[j] = d[j] <= th ? 1 : 0;
+  }
+  if (rsprof_on()) {
+    RsProf &p = g_rsprof;
+    fprintf(stderr, "ransac H prof: len %d samples %d LO %d | call %.0f us: upload %.0f, hypotheses %.0f, gpu_score %.0f, fetch_row %.0f, LO %.0f (u2h %.0f, errfn %.0f)\n", len,
+            no_sam, iter_cnt, rs_now_us() - t_call0, p.us[6], p.us[0], p.us[1], p.us[2], p.us[5], p.us[3], p.us[4]);
+    p = RsProf();
   }
   data_out[0] = no_sam;
   data_out[1] = iter_type == 0 ? 0 : iter_cnt;

@@ -372,8 +372,44 @@ static inline void denormH(double *F, const double *A1, const double *A2) {
   }
 }
 
-// u2h, Htools.c:100-132.  `buffer` holds at least 18*len doubles.
-static inline void u2h(const double *u, const int *inl, int len, double *H, double *buffer) {
+// Z^T Z of the normalised design matrix without the matrix (lin_hgN + cov_mat, Htools.c:60-98, utools.c:172-185).
+// The two rows of correspondence i are
+//   r0 = [b0 0 c0  b1 0 c1  b2 0 c2],  r1 = [0 b0 d0  0 b1 d1  0 b2 d2],   c_j = -a0 b_j, d_j = -a1 b_j, b2 = 1
+// and cov_mat adds z_p z_q over the rows in order r0(0) r1(0) r0(1) ...  A product with a structural zero is +-0, and
+// adding +-0 never changes a running sum that started at +0, so every entry is one of 30 ordered sums:
+//   sum b_j b_k (entries (3j,3k) and (3j+1,3k+1)),  sum b_j c_k,  sum b_j d_k,  sum (c_j c_k then d_j d_k),  or exactly +0.
+// Same additions in the same order per entry as the reference; 36 products per correspondence instead of 90, no 2len x 9
+// buffer.
+static inline void cov_hgN(const double *u, const int *inl, int len, const double *A1, const double *A2, double *Cv) {
+  double bb[6] = {0, 0, 0, 0, 0, 0}, bc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, cd[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < len; i++) {
+    const double *s = u + 6 * inl[i];
+    const double a0 = s[0] * A1[0] + A1[1], a1 = s[1] * A1[0] + A1[2];
+    double b[3], c[3], d[3];
+    b[0] = s[3] * A2[0] + A2[1]; b[1] = s[4] * A2[0] + A2[2]; b[2] = 1;
+    for (int j = 0; j < 3; j++) { c[j] = -a0 * b[j]; d[j] = -a1 * b[j]; }
+    int q = 0;
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k <= j; k++, q++) { bb[q] += b[j] * b[k]; cd[q] += c[j] * c[k]; cd[q] += d[j] * d[k]; }
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 3; k++) { bc[3 * j + k] += b[j] * c[k]; bd[3 * j + k] += b[j] * d[k]; }
+  }
+  auto tri = [](int j, int k) { return j >= k ? j * (j + 1) / 2 + k : k * (k + 1) / 2 + j; };
+  for (int i = 0; i < 9; i++)
+    for (int q = 0; q <= i; q++) {
+      const int j = i / 3, al = i % 3, k = q / 3, be = q % 3;
+      double v;
+      if (al == 2 && be == 2) v = cd[tri(j, k)];
+      else if (al == 2) v = be == 0 ? bc[3 * k + j] : bd[3 * k + j];
+      else if (be == 2) v = al == 0 ? bc[3 * j + k] : bd[3 * j + k];
+      else v = al == be ? bb[tri(j, k)] : 0.0;
+      Cv[9 * i + q] = v; Cv[i + 9 * q] = v;
+    }
+}
+
+// u2h, Htools.c:100-132.  `reference_form` runs lin_hgN + cov_mat as written there (`buffer` then holds at least
+// 18*len doubles; kept for the self-test that pins cov_hgN to it), otherwise `buffer` is unused.
+static inline void u2h(const double *u, const int *inl, int len, double *H, double *buffer, bool reference_form = false) {
   double A1[3], A2[3];
   double V[9 * 9], D[9];
   int nb[2 * 9];
@@ -390,10 +426,11 @@ static inline void u2h(const double *u, const int *inl, int len, double *H, doub
     nullspace(Z2, V, 9, nb);
     std::memcpy(H, V, 9 * sizeof(double));
   } else {
-    double *Z = buffer;
     normu(u, inl, len, A1, A2);
-    lin_hgN(u, Z, inl, len, A1, A2);
-    cov_mat(V, Z, 2 * len, 9);
+    if (reference_form) {
+      lin_hgN(u, buffer, inl, len, A1, A2);
+      cov_mat(V, buffer, 2 * len, 9);
+    } else cov_hgN(u, inl, len, A1, A2, V);
     sym_eig(V, D, 9);
     std::memcpy(H, V, 9 * sizeof(double));
     denormH(H, A1, A2);

@@ -1,0 +1,14 @@
+// Host SIMD forms of the LO step's error functions: one table per lane count, chosen once from the CPU's features.
+#pragma once
+namespace mods { namespace rs {
+struct SimdOps {
+  int lanes;
+  // soa = {u0, u1, u3, u4, u5}, each n_pad doubles (n_pad a multiple of `lanes`, tail filled with any valid point)
+  void (*hds_all)(const double *const *soa, int n_pad, const double *H, double *d);
+  void (*hsym_all)(const double *const *soa, int n_pad, const double *H1, const double *Hinv, int mode, double *d);
+  void (*gains_all)(const double *err, int n_pad, double lim, double *g);
+};
+const SimdOps *simd_ops();                 // widest table this CPU runs
+const SimdOps *simd_ops_lanes(int lanes);  // 1, 4 (AVX2) or 8 (AVX-512F); nullptr when the CPU lacks it
+enum { SIMD_PAD = 8 };                     // buffers are padded to a multiple of this many doubles
+}}

@@ -1,0 +1,110 @@
+"""CPU tests of the fast host forms of the homography LO step: the SIMD error functions, the gain pass of inlidxs and the
+moment matrix folded into 30 ordered sums must give the bits of the scalar code they replace (libmodsgpu's own scalar
+functions) and of the reference's own degensac build where it is available (oracle/_ref; Htools.c, utools.c, rtools.c)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import refdeg
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _points(n, seed, noise=0.8, outliers=0.3):
+    g = np.random.default_rng(seed)
+    H = np.array([[1.02, -0.04, 14.0], [0.03, 0.97, -9.0], [2e-5, 1e-5, 1.0]])
+    x = g.uniform(0, 1900, (n, 2))
+    y = np.c_[x, np.ones(n)] @ H.T
+    y = y[:, :2] / y[:, 2:] + g.normal(0, noise, (n, 2))
+    out = g.random(n) < outliers
+    y[out] = g.uniform(0, 1900, (int(out.sum()), 2))
+    u = np.ones((n, 6))
+    u[:, 0:2], u[:, 3:5] = x, y
+    # the model in the layout exp_ransacHcustom carries (column-major h, applied as in Htools.c)
+    h = np.ascontiguousarray(np.linalg.inv(H).T.ravel() / np.linalg.inv(H)[2, 2])
+    return np.ascontiguousarray(u), h
+
+
+LANES = (1, 4, 8)
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 63, 1000, 6001])
+@pytest.mark.parametrize("etype", [0, 1, 2])
+def test_simd_error_functions_bitexact(pkg, n, etype):
+    M = pkg.lib()
+    u, h = _points(n, 3 + n)
+    ref = np.zeros(n)
+    assert M.mods_test_host_errfn(etype, P(u), n, P(h), 0, P(ref)) == 0
+    assert np.isfinite(ref).all() and ref.max() > 0
+    ran = 0
+    for lanes in LANES:
+        out = np.full(n, -1.0)
+        rc = M.mods_test_host_errfn(etype, P(u), n, P(h), lanes, P(out))
+        if rc != 0:
+            continue   # this CPU lacks the width
+        ran += 1
+        assert np.array_equal(out.view(np.uint64), ref.view(np.uint64)), (lanes, etype)
+    assert ran >= 1
+    if refdeg.available():
+        R = refdeg.lib()
+        pool = np.arange(n, dtype=np.int32)
+        Z = np.zeros(18 * n)
+        R.lin_hg(P(u), P(Z), P(pool), n)
+        r = np.zeros(n)
+        getattr(R, ("HDs", "HDsSym", "HDsSymMax")[etype])(P(Z), P(u), P(h), P(r), n)
+        assert np.array_equal(r.view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.parametrize("n", [5, 12, 13, 200, 5000])
+def test_moment_matrix_folded_bitexact(pkg, n):
+    M = pkg.lib()
+    u, _ = _points(6000, 11)
+    g = np.random.default_rng(n)
+    inl = np.ascontiguousarray(g.permutation(6000)[:n].astype(np.int32))
+    a, b = np.zeros(81), np.zeros(81)
+    assert M.mods_test_host_cov(P(u), P(inl), n, 1, P(a)) == 0
+    assert M.mods_test_host_cov(P(u), P(inl), n, 0, P(b)) == 0
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert np.array_equal(a.reshape(9, 9), a.reshape(9, 9).T)
+    Ha, Hb = np.zeros(9), np.zeros(9)
+    assert M.mods_test_host_u2h(P(u), P(inl), n, 1, P(Ha)) == 0
+    assert M.mods_test_host_u2h(P(u), P(inl), n, 0, P(Hb)) == 0
+    assert np.array_equal(Ha.view(np.uint64), Hb.view(np.uint64)) and np.abs(Ha).max() > 0
+    if refdeg.available():
+        R = refdeg.lib()
+        A1, A2 = np.zeros(3), np.zeros(3)
+        R.normu(P(u), P(inl), n, P(A1), P(A2))
+        Z = np.zeros(18 * n)
+        R.lin_hgN(P(u), P(Z), P(inl), n, P(A1), P(A2))
+        c = np.zeros(81)
+        R.cov_mat(P(c), P(Z), 2 * n, 9)
+        assert np.array_equal(c.view(np.uint64), b.view(np.uint64))
+
+
+@pytest.mark.parametrize("th", [0.0, 4.0, 16.0, 128.0])
+def test_inlidxs_gain_pass_bitexact(pkg, th):
+    M = pkg.lib()
+    n = 4099
+    u, h = _points(n, 5)
+    err = np.zeros(n)
+    assert M.mods_test_host_errfn(0, P(u), n, P(h), 0, P(err)) == 0
+    err[::97] = th * 9 / 4           # the boundary of the truncation
+    err[1::97] = th
+    want_inl, I0, J0 = np.zeros(n, np.int32), C.c_uint(), C.c_double()
+    assert M.mods_test_host_inlidxs(P(err), n, C.c_double(th), 0, P(want_inl), C.byref(I0), C.byref(J0)) == 0
+    for lanes in LANES:
+        inl, I, J = np.zeros(n, np.int32), C.c_uint(), C.c_double()
+        if M.mods_test_host_inlidxs(P(err), n, C.c_double(th), lanes, P(inl), C.byref(I), C.byref(J)) != 0:
+            continue
+        assert I.value == I0.value and np.float64(J.value).view(np.uint64) == np.float64(J0.value).view(np.uint64)
+        assert np.array_equal(inl[:I.value], want_inl[:I0.value])
+    if refdeg.available():
+        R = refdeg.lib()
+        R.inlidxs.restype = refdeg.Score
+        inl = np.zeros(n, np.int32)
+        S = R.inlidxs(P(err), n, C.c_double(th), P(inl))
+        assert S.I == I0.value and np.float64(S.J).view(np.uint64) == np.float64(J0.value).view(np.uint64)
+        assert np.array_equal(inl[:S.I], want_inl[:S.I])
