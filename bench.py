@@ -5,7 +5,7 @@ synthetic 1920x1080 pairs, HessianAffine + RootSIFT, one identity view per image
 
   python bench.py --gpus N --steps K --warmup W
 
-A step = one batch of --pairs-per-step (default 32) image pairs through the whole hot path, SURVEY.md 8d's boundary:
+A step = one batch of --pairs-per-step (default 48) image pairs through the whole hot path, SURVEY.md 8d's boundary:
 two decoded 8-bit grey images in (pinned) host memory -> upload -> detect, describe, match, duplicate filter, LO-RANSAC ->
 inlier set + H on the host (mods.cpp:184-383).  --input hbm keeps the images resident in HBM instead (fp32).  The reported
 value is pairs / second.  N > 1 is launched by torch.distributed.run, one rank per GPU; pairs are independent units, so every
@@ -197,10 +197,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=6, help="distinct synthetic pairs cycled through the steps")
-    ap.add_argument("--pairs-per-step", type=int, default=32, help="image pairs in the batch that one step processes")
+    ap.add_argument("--pairs-per-step", type=int, default=48, help="image pairs in the batch that one step processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gpu-workers", type=int, default=3, help="pipeline threads running detect/describe/match (one context each)")
-    ap.add_argument("--verify-workers", type=int, default=6, help="pipeline threads running duplicate filter + LO-RANSAC")
+    ap.add_argument("--gpu-workers", type=int, default=6, help="pipeline threads running detect/describe/match (one context each)")
+    ap.add_argument("--verify-workers", type=int, default=8, help="pipeline threads running duplicate filter + LO-RANSAC")
     ap.add_argument("--pairs-per-batch", type=int, default=8, help="pairs a GPU worker pushes through detect/describe as one batch of launches")
     ap.add_argument("--serial", action="store_true", help="no cross-pair overlap: one mods_match_pair_dev call per step (images in HBM)")
     ap.add_argument("--input", default="host_u8", choices=["host_u8", "host_f32", "hbm"],

@@ -50,14 +50,21 @@ typedef struct mods_hessaff_params {
   float relativeThreshold;     /* RelativeTh: keep |response| > relativeThreshold * max|response| */
   int regionsNumber;           /* FixedRegNumber: the strongest regionsNumber; NotLessThanRegions: at least that many */
   float relativeRegionsNumber; /* RelativeRegNumber: the strongest floor(relativeRegionsNumber * n) */
+  /* which response the scale space is searched in: the [HessianAffine] / [DoG] / [HarrisAffine] sections of the .ini fill the
+   * same parameter set and differ in DetectorType (io_mods.cpp:167-169, 208-210, 260-262).  ScaleSpaceDetector::Response,
+   * pyramid.cpp:126-163; final threshold = threshold^2 for Hessian, threshold otherwise (pyramid.h:55-56); point types
+   * pyramid.cpp:65-124 */
+  int detectorType;            /* MODS_DET_HESSIAN */
+  int iiDoGMode;               /* DoG only: illumination-invariant rescale of the response (pyramid.cpp:172-194) */
 } mods_hessaff_params;
 enum { MODS_DET_FIXED_TH = 0, MODS_DET_RELATIVE_TH, MODS_DET_FIXED_REG_NUMBER, MODS_DET_RELATIVE_REG_NUMBER,
        MODS_DET_NOT_LESS_THAN_REGIONS };   /* detection_mode_t, detectors/structures.hpp:10-14 */
+enum { MODS_DET_HESSIAN = 0, MODS_DET_DOG = 1, MODS_DET_HARRIS = 2 };   /* detector_type, detectors/structures.hpp:16-18 */
 
 /* AffineKeypoint (detectors/structures.hpp:185-195) + provenance of the pyramid hit. */
 typedef struct mods_affkey {
   double x, y, s, a11, a12, a21, a22, response;
-  int sub_type;                /* 0 dark, 1 bright, 2 saddle (pyramid.h:33-36) */
+  int sub_type;                /* Hessian: 0 dark, 1 bright, 2 saddle; DoG: 10 dark, 11 bright; Harris: 30 dark, 31 bright (pyramid.h:33-40) */
   int octave, level, r0, c0;   /* NMS cell that produced the point */
   int pad;
 } mods_affkey;
@@ -383,8 +390,8 @@ typedef struct mods_ladder_step {     /* one [HessianAffine<i>] section of the i
   double fginn_ratio;                 /* FGINNThreshold of RootSIFT (0: RootSIFT lists are not matched) */
   int half_orientation;               /* a descriptor of the step is a Half* one: orientation in doHalfSIFT mode for all of them */
   double fginn_ratio_half;            /* FGINNThreshold of HalfRootSIFT; 0: not described / not matched.  [Matching<i>]
-                                         SeparateDescriptors = RootSIFT,HalfRootSIFT: both lists are matched, tentatives joined
-                                         (correspondencebank.cpp:288-340) */
+                                         SeparateDescriptors = RootSIFT,HalfRootSIFT: both lists are matched and joined,
+                                         HalfRootSIFT first (the bank's key order, correspondencebank.cpp:114-148, 288-340) */
 } mods_ladder_step;
 typedef struct mods_ladder_result {
   int steps_done, n_views;            /* steps executed; views synthesised (both images) */
@@ -414,6 +421,18 @@ int mods_match_reps(mods_ctx *ctx, const mods_imgrep *q, int q_begin, int q_end,
 int mods_match_ladder_dev(mods_ctx *ctx, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
                           const mods_ladder_step *steps, int n_steps, int min_matches, const mods_pair_params *par,
                           mods_imgrep *rep1, mods_imgrep *rep2, mods_ladder_result *res, double *matches_out, int max_matches);
+
+/* The same loop with several scale-space detectors per step (the [HessianAffine<i>] / [DoG<i>] / [HarrisAffine<i>] sections of the
+ * iterations file next to each other, io_mods.cpp:457-492): steps[step * n_det + d] is detector d's section of that step
+ * (n_tilts = n_scales = -1: none), dets[d] its parameter set, reps1[d] / reps2[d] its region banks.  Every detector has its own
+ * view history and its own lists; a detector is matched in the steps that bring new views of it, lists that a step does not
+ * touch keep their tentatives (fginn_ratio / fginn_ratio_half < 0: not named in [Matching<i>]; 0: named but not searched), and
+ * the joint list is the bank's key order: HalfRootSIFT before RootSIFT, detectors in the order given - list them sorted by
+ * name (CorrespondenceBank::MatchImgReps / GetCorresponcesVector, correspondencebank.cpp:114-148, 286-340). */
+int mods_match_ladder_dets_dev(mods_ctx *ctx, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
+                               const mods_ladder_step *steps, const mods_hessaff_params *dets, int n_steps, int n_det, int min_matches,
+                               const struct mods_pair_params *par, mods_imgrep **reps1, mods_imgrep **reps2, mods_ladder_result *res,
+                               double *matches_out, int max_matches);
 
 /* ---- one hard pair on several GPUs of a node ------------------------------------------------------
  * The views of every step (ImageRepresentation::SynthDetectDescribeKeypoints' views loop, imagerepresentation.cpp:704-1099) are

@@ -30,12 +30,23 @@ class HessAffParams(C.Structure):
                 ("edgeEigenValueRatio", C.c_float), ("border", C.c_int), ("maxIterations", C.c_int),
                 ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int),
                 ("mode", C.c_int), ("relativeThreshold", C.c_float), ("regionsNumber", C.c_int),
-                ("relativeRegionsNumber", C.c_float)]
+                ("relativeRegionsNumber", C.c_float), ("detectorType", C.c_int), ("iiDoGMode", C.c_int)]
 
     @staticmethod
     def default():
         # build/config_affori_classic.ini; mode FixedTh, the other selection keys at PyramidParams' defaults (-1)
-        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1, 0, -1.0, -1, -1.0)
+        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1, 0, -1.0, -1, -1.0, 0, 0)
+
+    @staticmethod
+    def dog():
+        """[DoG] of build/config_affori_classic.ini: the same detector searching the difference-of-Gaussians response
+        (DetectorType = DET_DOG, io_mods.cpp:260-262)."""
+        return HessAffParams(3, 1.6, 8.0, 10.0, 5, 32, 0.05, 19, 0, 0, 0.01, 3000, 0.5, 1, 0)
+
+    @staticmethod
+    def harris():
+        """[HarrisAffine] of build/config_affori_classic.ini (DetectorType = DET_HARRIS, io_mods.cpp:208-210)."""
+        return HessAffParams(3, 1.6, 15.0, 10.0, 5, 16, 0.1, 19, 0, 0, 0.1, 1000, 0.5, 2, 0)
 
 
 AFFKEY_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("s", "f8"), ("a11", "f8"), ("a12", "f8"), ("a21", "f8"),
@@ -622,6 +633,28 @@ def match_ladder_dev(ctx, img_ptr, w, h, steps, rep1, rep2, params=None, min_mat
     _check(lib().mods_match_ladder_dev(ctx.h, C.c_void_p(img_ptr), w, h, C.c_void_p(img2_ptr), w2, h2, arr, len(steps), min_matches,
                                        C.byref(params), rep1.h, rep2.h,
                                        C.byref(res), m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
+    return res, m[:min(res.n_inliers, max_matches)]
+
+
+def match_ladder_dets_dev(ctx, img_ptr, w, h, det_steps, det_params, reps1, reps2, params=None, min_matches=15, max_matches=0):
+    """mods_match_ladder_dets_dev: det_steps[d] = the steps of detector d (LadderStep, or None where the detector has no section),
+    det_params[d] its HessAffParams; list the detectors sorted by name.  img_ptr: [2][h][w] fp32 in HBM."""
+    n_det, n_steps = len(det_steps), max(len(x) for x in det_steps)
+    arr = (LadderStep * (n_steps * n_det))()
+    for d, steps in enumerate(det_steps):
+        for i in range(n_steps):
+            st = steps[i] if i < len(steps) and steps[i] is not None else None
+            if st is None:
+                st = LadderStep(); st.n_tilts = st.n_scales = -1
+            arr[i * n_det + d] = st
+    dets = (HessAffParams * n_det)(*det_params)
+    r1 = (C.c_void_p * n_det)(*[r.h for r in reps1]); r2 = (C.c_void_p * n_det)(*[r.h for r in reps2])
+    params = params or PairParams.default()
+    res = LadderResult()
+    m = np.zeros((max(max_matches, 1), 4), np.float64)
+    _check(lib().mods_match_ladder_dets_dev(ctx.h, C.c_void_p(img_ptr), w, h, C.c_void_p(img_ptr + 4 * w * h), w, h, arr, dets, n_steps, n_det,
+                                            min_matches, C.byref(params), r1, r2, C.byref(res),
+                                            m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
     return res, m[:min(res.n_inliers, max_matches)]
 
 

@@ -42,6 +42,8 @@ StageScope::~StageScope() {
 
 using namespace mods;
 
+namespace mods { int ransac_failed(); }   // ransac.hip: the calling thread's last exp_ransac*custom hit a device failure
+
 extern "C" {
 
 const char *mods_last_error(void) { return g_err; }
@@ -114,7 +116,7 @@ void mods_ctx_destroy(mods_ctx *c) {
     for (auto &e : t.pool) (void)hipEventDestroy(e);
   }
   (void)hipFree(c->pyr_dev); (void)hipFree(c->plane_pool); (void)hipFree(c->omap_pool); (void)hipFree(c->input_dev); (void)hipFree(c->u8_stage_dev);
-  (void)hipFree(c->tmp_dev); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
+  (void)hipFree(c->tmp_dev); (void)hipFree(c->alt_taps_dev); (void)hipFree(c->alt_planes); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
   (void)hipHostFree(c->host_counts);
   (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
@@ -458,11 +460,12 @@ int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, 
     if (laf) memcpy(&ls[(size_t)i * 14], &laf[(size_t)order[i] * 14], 14 * sizeof(double));
   }
   const double r_sq = r * r;
-  // hash grid of the kept correspondences, keyed by the first-image cell
-  struct Cell { long long key; int idx; };
-  std::vector<std::vector<int>> buckets(1 << 14);
+  // hash grid of the kept correspondences, keyed by the first-image cell: chained buckets in two flat arrays (which
+  // kept correspondence is met first inside a cell does not matter, only whether one is met)
+  constexpr int kBuckets = 1 << 14;
+  std::vector<int> head(kBuckets, -1), next(n);
   auto cell_of = [&](double v) { return (long long)std::floor(v / r); };
-  auto hash = [&](long long cx, long long cy) { return (size_t)(((unsigned long long)cx * 73856093ull) ^ ((unsigned long long)cy * 19349663ull)) & ((1 << 14) - 1); };
+  auto hash = [&](long long cx, long long cy) { return (size_t)(((unsigned long long)cx * 73856093ull) ^ ((unsigned long long)cy * 19349663ull)) & (kBuckets - 1); };
   std::vector<char> keep(n, 0);
   int m = 0;
   for (int j = 0; j < n; j++) {
@@ -470,16 +473,14 @@ int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, 
     const long long cx = cell_of(x1), cy = cell_of(y1);
     bool dup = false;
     for (long long dy = -1; dy <= 1 && !dup; dy++)
-      for (long long dx = -1; dx <= 1 && !dup; dx++) {
-        const std::vector<int> &bk = buckets[hash(cx + dx, cy + dy)];
-        for (int i : bk) {
+      for (long long dx = -1; dx <= 1 && !dup; dx++)
+        for (int i = head[hash(cx + dx, cy + dy)]; i >= 0; i = next[i]) {
           double ex = us[(size_t)i * 6] - x1, ey = us[(size_t)i * 6 + 1] - y1;
           if (ex * ex + ey * ey > r_sq) continue;
           ex = us[(size_t)i * 6 + 3] - x2; ey = us[(size_t)i * 6 + 4] - y2;
           if (ex * ex + ey * ey <= r_sq) { dup = true; break; }
         }
-      }
-    if (!dup) { keep[j] = 1; buckets[hash(cx, cy)].push_back(j); }
+    if (!dup) { keep[j] = 1; const size_t b = hash(cx, cy); next[j] = head[b]; head[b] = j; }
   }
   for (int j = 0; j < n; j++)
     if (keep[j]) {
@@ -568,6 +569,7 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
   exp_ransacHcustom(u2.data(), n, par->err_threshold * par->err_threshold, par->confidence, max_samples, Hloran, inl2.data(), 4,
                     data_out.data(), 1, 0, &resids, f0, f1, f2, par->doSymmCheck);
   free(resids);
+  if (mods::ransac_failed()) return MODS_E_HIP;   // device failure inside the control loop; mods_last_error() says which
   const double t_post0 = now_ms();
   if (stats3) { stats3[0] = data_out[0]; stats3[1] = data_out[1]; stats3[2] = data_out[2]; }
   // H: inv(Hloran^T); reading the column-major h as a row-major matrix is H^T, its transpose is h read column-wise
@@ -647,6 +649,7 @@ int mods_loransac_f(const double *u6, const double *laf, int n, const mods_ransa
   exp_ransacFcustom(u2.data(), n, par->err_threshold * par->err_threshold, par->confidence, par->max_samples, Floran, inl2.data(),
                     data_out.data(), par->localOptimization, 0, &resids, HinF, &I_H, exfds, fds, par->doSymmCheck);
   free(resids);
+  if (mods::ransac_failed()) return MODS_E_HIP;
   if (stats3) { stats3[0] = data_out[0]; stats3[1] = data_out[1]; stats3[2] = I_H; }
   std::vector<int> cur;
   for (int i = 0; i < n; i++) if (inl2[i]) cur.push_back(i);

@@ -24,6 +24,7 @@ void set_error(const char *fmt, ...);
 constexpr int kMaxOctaves = 16;
 constexpr int kMaxLevels = 8;        // numberOfScales + 2 <= 8
 constexpr int kMaxBlurRadius = 16;   // fused separable blur: ksize <= 33
+constexpr int kAltTapStride = 512;   // widest kernel of the DoG / Harris response blurs (ksize <= 511)
 
 // One octave of the scale space for a batch of images: plane(b) = base + b * w * h.
 struct OctaveDev {
@@ -74,6 +75,11 @@ struct mods_ctx {
   size_t omap_pool_elems = 0;
   float *input_dev = nullptr;        // staging for host-pointer entry points
   float *tmp_dev = nullptr;
+  // DoG / Harris responses (pyramid.cpp:165-194, 256-278): per-level tap tables of the response's own blur and scratch planes
+  float *alt_taps_dev = nullptr;           // [kMaxLevels][kAltTapStride]
+  int alt_ntap[mods::kMaxLevels] = {0};
+  float alt_sigma[mods::kMaxLevels] = {0};  // sigma the tables were built for
+  float *alt_planes = nullptr; size_t alt_plane_elems = 0;   // 4 planes of the first octave's size
   float *view_dev = nullptr;         // pixels of the current synthesised view (allocated on first use)
   float *gauss_taps_dev = nullptr;   // [16 slots][64] Gaussian taps
   float taps_sigma[16] = {0};        // sigma currently held by each slot (0 = empty)

@@ -34,6 +34,7 @@ struct DetectConst {
   float conv_th;
   float initial_sigma;
   int do_baumberg;
+  int det_type;           // MODS_DET_HESSIAN / DOG / HARRIS
 };
 
 // ---------------------------------------------------------------------------------------
@@ -366,8 +367,10 @@ __global__ __launch_bounds__(256) void localize_kernel(const PyramidDev *__restr
     if (ok && (fabsf(bb[0]) > 1.5f || fabsf(bb[1]) > 1.5f || fabsf(bb[2]) > 1.5f || fabsf(val) < k.final_th)) ok = false;
     if (!ok) { cd.state = 0; continue; }
     const float scale = o.sigma[cd.level] * det_pow2f(bb[2] / k.n_scales);
-    int type;
-    if (val < 0) type = 2;
+    int type;   // getPointType, pyramid.cpp:65-124
+    if (k.det_type == MODS_DET_DOG) type = val < 0 ? 11 : 10;
+    else if (k.det_type == MODS_DET_HARRIS) type = val < 0 ? 31 : 30;
+    else if (val < 0) type = 2;
     else {
       const float *ptr = o.blur[cd.level] + plane + (size_t)r * cols + c;
       float Lxx = (ptr[-1] - 2 * ptr[0] + ptr[1]);
@@ -694,7 +697,8 @@ int detect_run(mods_ctx *ctx) {
   k.edge_th = (er + 1.0f) * (er + 1.0f) / er;
   k.pos_th = (float)(0.8 * par.threshold);
   k.neg_th = -k.pos_th;
-  k.final_th = par.threshold * par.threshold;
+  k.final_th = par.detectorType == MODS_DET_HESSIAN ? par.threshold * par.threshold : par.threshold;   // pyramid.h:55-56
+  k.det_type = par.detectorType;
   if (par.mode != MODS_DET_FIXED_TH) {   // pyramid.h:58-59: every extremum is a candidate, the sorted list is cut afterwards
     if (par.mode < 0 || par.mode > MODS_DET_NOT_LESS_THAN_REGIONS) { set_error("unknown detector mode %d", par.mode); return MODS_E_ARG; }
     // the reference resizes its list to these numbers unchecked (negative / > 1 values end in std::length_error or in

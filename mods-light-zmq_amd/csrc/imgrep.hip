@@ -205,44 +205,149 @@ static void copy_verified(mods_ctx *c, const mods_ladder_result *res, double *ma
   }
 }
 
+// One FGINN search of bank q against bank t into a host list (MatchFlannFGINN of one (detector, descriptor) pair,
+// correspondencebank.cpp:288-340)
+struct TentList { std::vector<mods_tentative> t; std::vector<double> u6, laf; void clear() { t.clear(); u6.clear(); laf.clear(); } };
+static int match_into(mods_ctx *c, mods_imgrep *q, mods_imgrep *t, double ratio, const mods_pair_params *par, TentList *out) {
+  int rc, m = 0;
+  out->clear();
+  if (!q || !t) return MODS_OK;
+  if ((rc = match_run(c, q->reg, q->n, t->reg, t->n, ratio, par->contradDist, par->nn))) return rc;
+  MODS_HIP_CHECK(hipMemcpyAsync(&m, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (m > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
+  out->t.resize(m); out->u6.resize((size_t)m * 6); out->laf.resize((size_t)m * 14);
+  if (m > 0) {
+    MODS_HIP_CHECK(hipMemcpyAsync(out->t.data(), c->m_tent, sizeof(mods_tentative) * m, hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipMemcpyAsync(out->u6.data(), c->m_u6, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipMemcpyAsync(out->laf.data(), c->m_laf, sizeof(double) * 14 * m, hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  }
+  return MODS_OK;
+}
+
+// CorrespondenceBank::GetCorresponcesVector("All", "All") (correspondencebank.cpp:114-148): the bank is a std::map keyed by
+// descriptor name, then by detector name, and the joint list walks it in key order - "HalfRootSIFT" before "RootSIFT",
+// detectors in the (name-sorted) order the caller listed them.  lists[desc][det], desc 0 = RootSIFT, 1 = HalfRootSIFT.
+static void gather_tentatives(mods_ctx *c, const std::vector<TentList> lists[2]) {
+  c->h_tent.clear(); c->h_u6.clear(); c->h_laf.clear();
+  for (int desc = 1; desc >= 0; desc--)
+    for (const TentList &l : lists[desc]) {
+      c->h_tent.insert(c->h_tent.end(), l.t.begin(), l.t.end());
+      c->h_u6.insert(c->h_u6.end(), l.u6.begin(), l.u6.end());
+      c->h_laf.insert(c->h_laf.end(), l.laf.begin(), l.laf.end());
+    }
+}
+
+// DuplicateFiltering + LORANSACFiltering of the gathered list (mods.cpp:278-383)
+static int verify_gathered(mods_ctx *c, const mods_pair_params *par, mods_ladder_result *res) {
+  const int n = (int)c->h_tent.size();
+  res->n_tentatives = n;
+  int stats[3] = {0, 0, 0};
+  double ms_dup = 0, ms_ran = 0;
+  const int rc = mods_verify_tentatives(c->device, par, c->h_tent.data(), c->h_u6.data(), c->h_laf.data(), n, &res->n_unique, &res->n_inliers,
+                                        res->H, stats, &ms_dup, &ms_ran);
+  if (rc) return rc;
+  res->ms_duplicates += ms_dup; res->ms_ransac += ms_ran;
+  res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
+  return MODS_OK;
+}
+
 // match bank 1 against bank 2, drop duplicates, verify (MatchImgReps + DuplicateFiltering + LORANSACFiltering,
-// mods.cpp:288-383): fills the match / verification fields of res and mask (one byte per unique tentative)
+// mods.cpp:288-383) for one detector: fills the match / verification fields of res
 static int match_verify_banks(mods_ctx *c, mods_imgrep *rep1, mods_imgrep *rep2, double fginn_ratio, const mods_pair_params *par,
                               mods_ladder_result *res, mods_imgrep *rep1h = nullptr, mods_imgrep *rep2h = nullptr, double fginn_ratio_half = 0) {
   int rc;
   const double t1 = now_ms2();
-  int n = 0;
-  c->h_tent.clear(); c->h_u6.clear(); c->h_laf.clear();
-  // [Matching<i>] SeparateDescriptors = RootSIFT[,HalfRootSIFT]: one FGINN search per descriptor whose threshold is > 0
-  // (correspondencebank.cpp:288-340), tentatives joined in that order
-  for (int pass = 0; pass < 2; pass++) {
-    mods_imgrep *q = pass ? rep1h : rep1, *t = pass ? rep2h : rep2;
-    const double ratio = pass ? fginn_ratio_half : fginn_ratio;
-    if (!q || !t || !(ratio > 0)) continue;
-    int m = 0;
-    if ((rc = match_run(c, q->reg, q->n, t->reg, t->n, ratio, par->contradDist, par->nn))) return rc;
-    MODS_HIP_CHECK(hipMemcpyAsync(&m, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (m > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
-    c->h_tent.resize(n + m); c->h_u6.resize((size_t)(n + m) * 6); c->h_laf.resize((size_t)(n + m) * 14);
-    if (m > 0) {
-      MODS_HIP_CHECK(hipMemcpyAsync(c->h_tent.data() + n, c->m_tent, sizeof(mods_tentative) * m, hipMemcpyDeviceToHost, c->stream));
-      MODS_HIP_CHECK(hipMemcpyAsync(c->h_u6.data() + (size_t)n * 6, c->m_u6, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, c->stream));
-      MODS_HIP_CHECK(hipMemcpyAsync(c->h_laf.data() + (size_t)n * 14, c->m_laf, sizeof(double) * 14 * m, hipMemcpyDeviceToHost, c->stream));
-      MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  std::vector<TentList> lists[2];
+  lists[0].resize(1); lists[1].resize(1);
+  if (fginn_ratio > 0 && (rc = match_into(c, rep1, rep2, fginn_ratio, par, &lists[0][0]))) return rc;
+  if (fginn_ratio_half > 0 && (rc = match_into(c, rep1h, rep2h, fginn_ratio_half, par, &lists[1][0]))) return rc;
+  gather_tentatives(c, lists);
+  res->ms_match += now_ms2() - t1;
+  return verify_gathered(c, par, res);
+}
+
+int mods_match_ladder_dets_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
+                               const mods_ladder_step *steps, const mods_hessaff_params *dets, int n_steps, int n_det, int min_matches,
+                               const mods_pair_params *par, mods_imgrep **reps1, mods_imgrep **reps2, mods_ladder_result *res,
+                               double *matches_out, int max_matches) {
+  if (!c || !img1_dev || !img2_dev || !steps || !dets || !par || !reps1 || !reps2 || !res || n_det < 1 || n_det > 8) { set_error("match_ladder: bad argument"); return MODS_E_ARG; }
+  for (int d = 0; d < n_det; d++) if (!reps1[d] || !reps2[d]) { set_error("match_ladder: null region bank"); return MODS_E_ARG; }
+  memset(res, 0, sizeof(*res));
+  for (int i = 0; i < 9; i++) res->H[i] = -1;
+  int rc, curr_matches = 0;
+  struct PerDet {
+    std::vector<mods_view_par> hist = std::vector<mods_view_par>(1024);
+    int n_hist = 0;
+    mods_imgrep *h1 = nullptr, *h2 = nullptr;    // HalfRootSIFT banks (the reference keeps one region list per descriptor name)
+    ~PerDet() { mods_imgrep_destroy(h1); mods_imgrep_destroy(h2); }
+  };
+  std::vector<PerDet> pd(n_det);
+  std::vector<mods_view_par> views(256);
+  std::vector<TentList> lists[2];                // per (descriptor, detector): kept from step to step until re-matched
+  lists[0].resize(n_det); lists[1].resize(n_det);
+  for (int d = 0; d < n_det; d++) { mods_imgrep_clear(reps1[d]); mods_imgrep_clear(reps2[d]); }
+  for (int step = 0; step < n_steps && curr_matches < min_matches; step++) {
+    std::vector<int> new_views(n_det, 0);
+    const double t0 = now_ms2();
+    for (int d = 0; d < n_det; d++) {
+      const mods_ladder_step &st = steps[(size_t)step * n_det + d];
+      if (st.n_tilts < 0 || st.n_scales < 0) continue;          // the detector has no section in this step
+      const int nv = mods_view_schedule(st.scale_set, st.n_scales, st.tilt_set, st.n_tilts, st.phi, pd[d].hist.data(), &pd[d].n_hist,
+                                        (int)pd[d].hist.size(), views.data(), (int)views.size());
+      if (nv < 0) return nv;
+      new_views[d] = nv;
+      const bool want_half = st.fginn_ratio_half > 0;
+      if (want_half && !pd[d].h1) {
+        if ((rc = mods_imgrep_create(c, reps1[d]->cap, &pd[d].h1))) return rc;
+        if ((rc = mods_imgrep_create(c, reps2[d]->cap, &pd[d].h2))) return rc;
+      }
+      mods_describe_params desc = par->desc;
+      desc.ori_halfMode = (st.half_orientation || want_half) ? 1 : 0;
+      desc.halfDesc = want_half ? 1 : 0;
+      for (int im = 0; im < 2; im++) {
+        mods_imgrep *rep = im ? reps2[d] : reps1[d];
+        for (int v = 0; v < nv; v++) {
+          int nd = 0, nr = 0;
+          const float *img = im ? img2_dev : img1_dev;
+          const int w = im ? w2 : w1, h = im ? h2 : h1;
+          if ((rc = mods_detect_describe_view_dev(c, img, w, h, w, views[v].tilt, views[v].phi, views[v].zoom, st.initSigma,
+                                                  st.doBlur, &dets[d], &desc, nullptr, &nd, &nr))) return rc;
+          if ((rc = mods_imgrep_append_ctx(rep, c, 0))) return rc;
+          if (want_half && nr > 0 && (rc = mods_imgrep_append_ctx_half(im ? pd[d].h2 : pd[d].h1, c, 0))) return rc;
+          res->n_views++;
+          res->n_detected[im] += nd;
+          res->n_unoriented[im] += mods_unoriented_count(c, 0);
+        }
+      }
     }
-    n += m;
+    res->n_described[0] = res->n_described[1] = 0;
+    for (int d = 0; d < n_det; d++) { res->n_described[0] += reps1[d]->n; res->n_described[1] += reps2[d]->n; }
+    const double t1 = now_ms2();
+    res->ms_detect_describe += t1 - t0;
+    // MatchImgReps, correspondencebank.cpp:286-340: a detector is matched in a step that brought new views of it; each of its
+    // descriptor lists is cleared and searched again over everything accumulated.  Lists that are not touched keep their
+    // tentatives (ratio < 0: descriptor / detector not named in [Matching<i>]; 0: named, not searched, so it ends up empty)
+    for (int d = 0; d < n_det; d++) {
+      const mods_ladder_step &st = steps[(size_t)step * n_det + d];
+      if (st.n_tilts < 0 || st.n_scales < 0 || new_views[d] == 0) continue;
+      if (st.fginn_ratio >= 0) {
+        lists[0][d].clear();
+        if (st.fginn_ratio > 0 && (rc = match_into(c, reps1[d], reps2[d], st.fginn_ratio, par, &lists[0][d]))) return rc;
+      }
+      if (st.fginn_ratio_half >= 0) {
+        lists[1][d].clear();
+        if (st.fginn_ratio_half > 0 && (rc = match_into(c, pd[d].h1, pd[d].h2, st.fginn_ratio_half, par, &lists[1][d]))) return rc;
+      }
+    }
+    gather_tentatives(c, lists);
+    res->ms_match += now_ms2() - t1;
+    if ((rc = verify_gathered(c, par, res))) return rc;
+    curr_matches = res->n_inliers;
+    res->steps_done = step + 1;
   }
-  const double t2 = now_ms2();
-  res->ms_match += t2 - t1;
-  res->n_tentatives = n;
-  int stats[3] = {0, 0, 0};
-  double ms_dup = 0, ms_ran = 0;
-  rc = mods_verify_tentatives(c->device, par, c->h_tent.data(), c->h_u6.data(), c->h_laf.data(), n, &res->n_unique, &res->n_inliers,
-                              res->H, stats, &ms_dup, &ms_ran);
-  if (rc) return rc;
-  res->ms_duplicates += ms_dup; res->ms_ransac += ms_ran;
-  res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
+  copy_verified(c, res, matches_out, max_matches);
   return MODS_OK;
 }
 
@@ -250,54 +355,9 @@ int mods_match_ladder_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, co
                           const mods_ladder_step *steps, int n_steps, int min_matches,
                           const mods_pair_params *par, mods_imgrep *rep1, mods_imgrep *rep2, mods_ladder_result *res, double *matches_out,
                           int max_matches) {
-  if (!c || !img1_dev || !img2_dev || !steps || !par || !rep1 || !rep2 || !res) { set_error("match_ladder: null argument"); return MODS_E_ARG; }
-  memset(res, 0, sizeof(*res));
-  for (int i = 0; i < 9; i++) res->H[i] = -1;
-  mods_imgrep_clear(rep1); mods_imgrep_clear(rep2);
-  std::vector<mods_view_par> hist(1024), views(256);
-  int n_hist = 0, rc;
-  int curr_matches = 0;
-  // HalfRootSIFT banks (the reference keeps one region list per descriptor name): created when a step asks for them
-  mods_imgrep *rep1h = nullptr, *rep2h = nullptr;
-  struct HalfGuard { mods_imgrep *&a, *&b; ~HalfGuard() { mods_imgrep_destroy(a); mods_imgrep_destroy(b); } } guard{rep1h, rep2h};
-  for (int step = 0; step < n_steps && curr_matches < min_matches; step++) {
-    const mods_ladder_step &st = steps[step];
-    const int nv = mods_view_schedule(st.scale_set, st.n_scales, st.tilt_set, st.n_tilts, st.phi, hist.data(), &n_hist, (int)hist.size(),
-                                      views.data(), (int)views.size());
-    if (nv < 0) return nv;
-    const bool want_half = st.fginn_ratio_half > 0;
-    if (want_half && !rep1h) {
-      if ((rc = mods_imgrep_create(c, rep1->cap, &rep1h))) return rc;
-      if ((rc = mods_imgrep_create(c, rep2->cap, &rep2h))) return rc;
-    }
-    mods_describe_params desc = par->desc;
-    desc.ori_halfMode = (st.half_orientation || want_half) ? 1 : 0;
-    desc.halfDesc = want_half ? 1 : 0;
-    const double t0 = now_ms2();
-    for (int im = 0; im < 2; im++) {
-      mods_imgrep *rep = im ? rep2 : rep1;
-      for (int v = 0; v < nv; v++) {
-        int nd = 0, nr = 0;
-        const float *img = im ? img2_dev : img1_dev;
-        const int w = im ? w2 : w1, h = im ? h2 : h1;
-        if ((rc = mods_detect_describe_view_dev(c, img, w, h, w, views[v].tilt, views[v].phi, views[v].zoom, st.initSigma,
-                                                st.doBlur, &par->det, &desc, nullptr, &nd, &nr))) return rc;
-        if ((rc = mods_imgrep_append_ctx(rep, c, 0))) return rc;
-        if (want_half && nr > 0 && (rc = mods_imgrep_append_ctx_half(im ? rep2h : rep1h, c, 0))) return rc;
-        res->n_views++;
-        res->n_detected[im] += nd;
-        res->n_unoriented[im] += mods_unoriented_count(c, 0);
-      }
-    }
-    res->n_described[0] = rep1->n; res->n_described[1] = rep2->n;
-    const double t1 = now_ms2();
-    res->ms_detect_describe += t1 - t0;
-    if ((rc = match_verify_banks(c, rep1, rep2, st.fginn_ratio, par, res, rep1h, rep2h, st.fginn_ratio_half))) return rc;
-    curr_matches = res->n_inliers;
-    res->steps_done = step + 1;
-  }
-  copy_verified(c, res, matches_out, max_matches);
-  return MODS_OK;
+  if (!par) { set_error("match_ladder: null argument"); return MODS_E_ARG; }
+  return mods_match_ladder_dets_dev(c, img1_dev, w1, h1, img2_dev, w2, h2, steps, &par->det, n_steps, 1, min_matches, par, &rep1, &rep2, res,
+                                    matches_out, max_matches);
 }
 
 int mods_match_verify_reps(mods_ctx *c, mods_imgrep *rep1, mods_imgrep *rep2, double fginn_ratio, const mods_pair_params *par,

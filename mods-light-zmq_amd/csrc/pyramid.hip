@@ -567,6 +567,84 @@ __global__ __launch_bounds__(256) void resize_half_kernel(const float *__restric
   dst[(size_t)dy * dw + dx] = out;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// DoG and Harris responses (ScaleSpaceDetector::dogResponse / iidogResponse / HarrisResponse, pyramid.cpp:165-194, 256-278).
+// Their own Gaussian blurs are wide (DoG passes sigma^2 of the level as the sigma: ksize up to 99 with the default
+// schedule), so they run as two plain passes over global memory with the taps in a device table: row pass as OpenCV's
+// RowFilter (first tap, then fused multiply-adds left to right; SymmRowSmall order for ksize <= 5), column pass as
+// SymmColumnFilter (centre tap, then the symmetric pairs), BORDER_REPLICATE - the arithmetic of gauss_blur_kernel.
+// grid = (ceil(w/256), h, n_img), block = 256
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wide_blur_row_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+                                                            const float *__restrict__ taps, int n) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const size_t plane = (size_t)w * h * blockIdx.z;
+  const float *row = src + plane + (size_t)y * w;
+  const int r = n >> 1;
+  auto at = [&](int j) { int gx = x - r + j; gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx); return row[gx]; };
+  float s;
+  if (n <= 5) {
+    s = at(r) * taps[r];
+    for (int j = 1; j <= r; j++) s = fmaf(at(r - j) + at(r + j), taps[r + j], s);
+  } else {
+    s = taps[0] * at(0);
+    for (int j = 1; j < n; j++) s = fmaf(taps[j], at(j), s);
+  }
+  dst[plane + (size_t)y * w + x] = s;
+}
+__global__ __launch_bounds__(256) void wide_blur_col_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+                                                            const float *__restrict__ taps, int n) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const size_t plane = (size_t)w * h * blockIdx.z;
+  const float *col = src + plane + x;
+  const int r = n >> 1;
+  auto at = [&](int gy) { gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy); return col[(size_t)gy * w]; };
+  float s = taps[r] * at(y);
+  for (int j = 1; j <= r; j++) s = fmaf(taps[r + j], at(y + j) + at(y - j), s);
+  dst[plane + (size_t)y * w + x] = s;
+}
+// DoG = level - blur(level); iiDoG: where level + blur < 255, the value is rescaled by 255 / (level + blur) in double
+__global__ __launch_bounds__(256) void dog_combine_kernel(const float *__restrict__ in, const float *__restrict__ nb, float *__restrict__ out,
+                                                          size_t n, int ii) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float a = in[i], b = nb[i];
+  float v = a - b;
+  if (ii) {
+    const float sum = a + b;
+    if ((double)sum < 255.) v = (float)((double)v * (255. / (double)sum));
+  }
+  out[i] = v;
+}
+// computeGradient (helpers.cpp:779-797: central differences, one-sided at the frame) and the three products
+__global__ __launch_bounds__(256) void harris_products_kernel(const float *__restrict__ src, float *__restrict__ xx, float *__restrict__ yy,
+                                                              float *__restrict__ xy, int w, int h) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const size_t plane = (size_t)w * h * blockIdx.z;
+  const float *p = src + plane + (size_t)y * w + x;
+  float gx, gy;
+  if (x == 0) gx = p[1] - p[0]; else if (x == w - 1) gx = p[0] - p[-1]; else gx = p[1] - p[-1];
+  if (y == 0) gy = p[w] - p[0]; else if (y == h - 1) gy = p[0] - p[-w]; else gy = p[w] - p[-w];
+  const size_t o = plane + (size_t)y * w + x;
+  xx[o] = gx * gx; yy[o] = gy * gy; xy[o] = gx * gy;
+}
+// sigmasq * blurred products, then dx2*dy2 - dxdy^2 - 0.04 (dx2 + dy2)^2 in OpenCV's evaluation order:
+// (fl(dx2*dy2) - fl(dxdy*dxdy)) - fl(fl(0.04f * sum) * sum)
+__global__ __launch_bounds__(256) void harris_combine_kernel(const float *__restrict__ bxx, const float *__restrict__ byy,
+                                                             const float *__restrict__ bxy, float *__restrict__ out, size_t n, float sigmasq) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float dx2 = bxx[i] * sigmasq, dy2 = byy[i] * sigmasq, dxdy = bxy[i] * sigmasq;
+  const float sum = dx2 + dy2;
+  const float t1 = dx2 * dy2, t2 = dxdy * dxdy;
+  const float t3 = ((float)0.04 * sum) * sum;
+  out[i] = (t1 - t2) - t3;
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
@@ -677,6 +755,48 @@ int launch_hessian_response(mods_ctx *ctx, const float *src, float *dst, int w, 
   return MODS_OK;
 }
 
+// sigma of the blur inside the response of level l (pyramid.cpp:165-168: DoG blurs with norm = sigma_l^2 as the sigma;
+// :260-261: Harris with sqrt(0.6 * sigma_l^2))
+static float alt_response_sigma(const mods_hessaff_params &par, float level_sigma) {
+  const float norm = level_sigma * level_sigma;
+  if (par.detectorType == MODS_DET_DOG) return norm;
+  const float sigmasq = (float)(0.6 * (double)norm);
+  return sqrtf(sigmasq);
+}
+
+static int wide_blur(mods_ctx *ctx, const float *src, float *dst, float *tmp, int w, int h, int n_img, int level) {
+  const float *taps = ctx->alt_taps_dev + (size_t)level * kAltTapStride;
+  const int n = ctx->alt_ntap[level];
+  dim3 grid((w + 255) / 256, h, n_img);
+  StageScope ts(ctx, MODS_STAGE_RESPONSE, 16.0 * w * h * n_img);
+  hipLaunchKernelGGL(wide_blur_row_kernel, grid, dim3(256), 0, ctx->stream, src, tmp, w, h, taps, n);
+  hipLaunchKernelGGL(wide_blur_col_kernel, grid, dim3(256), 0, ctx->stream, tmp, dst, w, h, taps, n);
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
+// Response() of one level for DET_DOG / DET_HARRIS, whole batch
+static int launch_alt_response(mods_ctx *ctx, const float *blur, float *resp, int w, int h, int n_img, int level, float level_sigma) {
+  const size_t n = (size_t)w * h * n_img;
+  float *p0 = ctx->alt_planes, *p1 = p0 + ctx->alt_plane_elems, *p2 = p1 + ctx->alt_plane_elems, *p3 = p2 + ctx->alt_plane_elems;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  int rc;
+  if (ctx->par.detectorType == MODS_DET_DOG) {
+    if ((rc = wide_blur(ctx, blur, p0, p1, w, h, n_img, level))) return rc;
+    hipLaunchKernelGGL(dog_combine_kernel, dim3(blocks), dim3(256), 0, ctx->stream, blur, p0, resp, n, ctx->par.iiDoGMode);
+  } else {
+    const float norm = level_sigma * level_sigma;
+    const float sigmasq = (float)(0.6 * (double)norm);
+    hipLaunchKernelGGL(harris_products_kernel, dim3((w + 255) / 256, h, n_img), dim3(256), 0, ctx->stream, blur, p0, p1, p2, w, h);
+    if ((rc = wide_blur(ctx, p0, p0, p3, w, h, n_img, level))) return rc;
+    if ((rc = wide_blur(ctx, p1, p1, p3, w, h, n_img, level))) return rc;
+    if ((rc = wide_blur(ctx, p2, p2, p3, w, h, n_img, level))) return rc;
+    hipLaunchKernelGGL(harris_combine_kernel, dim3(blocks), dim3(256), 0, ctx->stream, p0, p1, p2, resp, n, sigmasq);
+  }
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
 int launch_resize_half(mods_ctx *ctx, const float *src, float *dst, int w, int h, int dw, int dh, int n_img) {
   dim3 grid((dw + 63) / 64, (dh + 3) / 4, n_img);
   StageScope ts(ctx, MODS_STAGE_RESIZE, 5.0 * w * h * n_img);
@@ -696,6 +816,10 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
   const int n_levels = par->numberOfScales + 2;
   if (par->numberOfScales < 1 || n_levels > kMaxLevels) { set_error("numberOfScales %d unsupported", par->numberOfScales); return MODS_E_ARG; }
   if (par->border < 2) { set_error("border must be >= 2"); return MODS_E_ARG; }
+  if (par->detectorType < MODS_DET_HESSIAN || par->detectorType > MODS_DET_HARRIS) { set_error("unknown detector type %d", par->detectorType); return MODS_E_ARG; }
+  // Response() has no iiDoG form for Hessian / Harris: those branches are commented out in the reference and run off the end
+  // of a non-void function (pyramid.cpp:130-136, 148-156)
+  if (par->iiDoGMode && par->detectorType != MODS_DET_DOG) { set_error("iiDoGMode exists for the DoG detector only"); return MODS_E_ARG; }
   PyramidDev &P = ctx->pyr;
   P.n_levels = n_levels;
   P.n_oct = 0;
@@ -738,6 +862,27 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
     o.omap = mp; mp += n;
   }
   MODS_HIP_CHECK(hipMemcpyAsync(ctx->pyr_dev, &P, sizeof(PyramidDev), hipMemcpyHostToDevice, ctx->stream));
+  if (par->detectorType != MODS_DET_HESSIAN) {
+    if (!ctx->alt_taps_dev) MODS_HIP_CHECK(hipMalloc(&ctx->alt_taps_dev, sizeof(float) * kMaxLevels * kAltTapStride));
+    const size_t need = (size_t)w * h * n_img;
+    if (need > ctx->alt_plane_elems) {
+      if (ctx->alt_planes) MODS_HIP_CHECK(hipFree(ctx->alt_planes));
+      ctx->alt_planes = nullptr; ctx->alt_plane_elems = 0;
+      MODS_HIP_CHECK(hipMalloc(&ctx->alt_planes, 4 * need * sizeof(float)));
+      ctx->alt_plane_elems = need;
+    }
+    for (int l = 0; l < n_levels; l++) {
+      const float sigma = alt_response_sigma(*par, P.oct[0].sigma[l]);
+      if (ctx->alt_ntap[l] && ctx->alt_sigma[l] == sigma) continue;
+      const int n = gauss_ksize(sigma);
+      if (n > kAltTapStride - 1) { set_error("response blur too wide: sigma=%g ksize=%d", (double)sigma, n); return MODS_E_ARG; }
+      std::vector<float> taps(n);
+      gauss_kernel_host(n, (double)sigma, taps.data());
+      MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      MODS_HIP_CHECK(hipMemcpy(ctx->alt_taps_dev + (size_t)l * kAltTapStride, taps.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+      ctx->alt_ntap[l] = n; ctx->alt_sigma[l] = sigma;
+    }
+  }
   ctx->par = *par;
   ctx->reg_number_eff = par->regionsNumber;   // identity view; mods_detect_describe_view_dev rescales it
   ctx->last_w = w; ctx->last_h = h; ctx->last_n_img = n_img;
@@ -782,6 +927,26 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
     MODS_HIP_CHECK(hipMemcpy2DAsync(packed, sizeof(float) * w, img_dev, sizeof(float) * stride, sizeof(float) * w,
                                     (size_t)h * n_img, hipMemcpyDeviceToDevice, ctx->stream));
     src0 = packed;
+  }
+  if (par.detectorType != MODS_DET_HESSIAN) {   // DoG / Harris: plain blurs, the response of every level from its own launches
+    if (initial_blur) {
+      if ((rc = blur_with_slot(ctx, src0, P.oct[0].blur[0], w, h, n_img, 0, ntap[0]))) return rc;
+    } else {
+      MODS_HIP_CHECK(hipMemcpyAsync(P.oct[0].blur[0], src0, sizeof(float) * (size_t)w * h * n_img, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    for (int oi = 0; oi < P.n_oct; oi++) {
+      OctaveDev &o = P.oct[oi];
+      if ((rc = launch_alt_response(ctx, o.blur[0], o.resp[0], o.w, o.h, n_img, 0, o.sigma[0]))) return rc;
+      for (int l = 1; l < P.n_levels; l++) {
+        if ((rc = blur_with_slot(ctx, o.blur[l - 1], o.blur[l], o.w, o.h, n_img, l, ntap[l]))) return rc;
+        if ((rc = launch_alt_response(ctx, o.blur[l], o.resp[l], o.w, o.h, n_img, l, o.sigma[l - 1] * sigmaStep))) return rc;
+        if (l == S && oi + 1 < P.n_oct) {
+          OctaveDev &nx = P.oct[oi + 1];
+          if ((rc = launch_resize_half(ctx, o.blur[l], nx.blur[0], o.w, o.h, nx.w, nx.h, n_img))) return rc;
+        }
+      }
+    }
+    return MODS_OK;
   }
   // every blur launch also writes the Hessian response of its output (fused kernel): the separate response launch is left for
   // the first level of the octaves that start from a decimated plane

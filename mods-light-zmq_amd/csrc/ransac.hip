@@ -133,6 +133,10 @@ static int g_ransac_device = 0;
 static long g_pinned_seed = -1;
 static std::mutex g_cfg_mutex;
 
+static thread_local int g_ransac_failed = 0;
+void ransac_set_failed(int failed) { g_ransac_failed = failed; }
+int ransac_failed() { return g_ransac_failed; }
+
 long ransac_pinned_seed() {
   long pinned;
   { std::lock_guard<std::mutex> lk(g_cfg_mutex); pinned = g_pinned_seed; }
@@ -508,7 +512,7 @@ int mods_test_host_inlidxs(const double *err, int len, double th, int lanes, int
 }
 }  // extern "C"
 
-extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
+static Score ransac_h_run(double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
                                     int iter_type, int *data_out, int oriented_constraint, unsigned inlLimit, double **resids,
                                     HDsPtr HDS1, HDsiPtr HDSi1, HDsidxPtr HDSidx1, int doSymCheck) {
   (void)HDSi1; (void)HDSidx1;
@@ -518,7 +522,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
   if (len < 4 || !u || !H || !inl || !data_out) { if (data_out) { data_out[0] = 0; data_out[1] = 0; data_out[2] = 0; } return maxS; }
   const double t_call0 = rsprof_on() ? rs_now_us() : 0;
   RansacGpu *ws = ransac_gpu();
-  if (!ws) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }   // no CPU fallback
+  if (!ws) ransac_fail();   // no CPU fallback
   int err_type; HDsPtr custom = nullptr;
   if (HDS1 == &HDs || HDS1 == nullptr) err_type = ERR_SAMPSON;
   else if (HDS1 == &HDsSym) err_type = ERR_SYMSUM;
@@ -549,9 +553,9 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
   LoState L = {u, len, th, {errs[0], errs[1], errs[2], errs[3], errs[4]}, buffer.data(), &rng, &ht, inlLimit, errfn, &pts};
 
   const double t_up0 = rsprof_on() ? rs_now_us() : 0;
-  if (!ransac_ws_reserve(ws, len, 64)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+  if (!ransac_ws_reserve(ws, len, 64)) ransac_fail();
   if (hipMemcpyAsync(ws->u_dev, u, sizeof(double) * 6 * len, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
-      hipStreamSynchronize(ws->stream) != hipSuccess) { fprintf(stderr, "libmodsgpu: upload failed\n"); abort(); }
+      hipStreamSynchronize(ws->stream) != hipSuccess) { set_error("upload of the correspondences failed"); ransac_fail(); }
   if (rsprof_on()) g_rsprof.us[6] += rs_now_us() - t_up0;
 
   // sym check of a host-side model (LO results); the per-sample check comes from the GPU counts
@@ -625,7 +629,7 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
     int want = batch_size;
     if (want > max_sam - no_sam) want = max_sam - no_sam;
     batch.resize(want);
-    if (!ransac_ws_reserve(ws, len, want)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+    if (!ransac_ws_reserve(ws, len, want)) ransac_fail();
     int n_valid = 0;
     const double t_hyp0 = rsprof_on() ? rs_now_us() : 0;
     for (int b = 0; b < want; b++) {
@@ -681,12 +685,12 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
           if (doSymCheck) { HDsSym(nullptr, u, ((HypDev *)ws->hyp_host)[kq].h, d_check.data(), len); for (int j = 0; j < len; j++) if (d_check[j] <= th_check) Is++; }
           ws->counts_host[2 * kq] = (int)I; ws->counts_host[2 * kq + 1] = (int)Is; ws->J_host[kq] = J;
         }
-      } else if (!gpu_score(ws, len, n_valid, err_type, doSymCheck, th, th_check)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+      } else if (!gpu_score(ws, len, n_valid, err_type, doSymCheck, th, th_check)) ransac_fail();
     }
     auto fetch_row = [&](int slot, double *dst) {
       RsTimer t_(2);
       if (custom) memcpy(dst, custom_d.data() + (size_t)slot * len, sizeof(double) * len);
-      else if (!ransac_fetch_row(ws, len, slot, dst)) { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); }
+      else if (!ransac_fetch_row(ws, len, slot, dst)) ransac_fail();
     };
     // replay the reference's per-iteration decisions in order (exp_ranH.c:858-1083)
     int b = 0;
@@ -760,4 +764,20 @@ extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, i
   data_out[1] = iter_type == 0 ? 0 : iter_cnt;
   data_out[2] = no_rej;
   return maxS;
+}
+
+extern "C" Score exp_ransacHcustom(double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
+                                    int iter_type, int *data_out, int oriented_constraint, unsigned inlLimit, double **resids,
+                                    HDsPtr HDS1, HDsiPtr HDSi1, HDsidxPtr HDSidx1, int doSymCheck) {
+  mods::ransac_set_failed(0);
+  try {
+    return ransac_h_run(u, len, th, conf, max_sam, H, inl, iter_type, data_out, oriented_constraint, inlLimit, resids, HDS1, HDSi1, HDSidx1,
+                        doSymCheck);
+  } catch (const mods::RansacDeviceError &) {
+    mods::ransac_set_failed(1);
+    if (data_out) { data_out[0] = 0; data_out[1] = 0; data_out[2] = 0; }
+    if (inl) memset(inl, 0, (size_t)(len > 0 ? len : 0));
+    const Score none = {0, 0};
+    return none;
+  }
 }

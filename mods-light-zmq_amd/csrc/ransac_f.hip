@@ -155,7 +155,7 @@ struct GpuEval : rs::PointEval {
     hipLaunchKernelGGL(ransac_eval_kernel, dim3((len + 255) / 256), dim3(256), 0, ws->stream, ws->u_dev, len, M, kind, d_dev, w_dev);
     const size_t n = (size_t)len * (w ? 2 : 1);
     if (hipMemcpyAsync(host, d_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ws->stream) != hipSuccess ||
-        hipStreamSynchronize(ws->stream) != hipSuccess) { fprintf(stderr, "libmodsgpu: error-function evaluation failed\n"); abort(); }
+        hipStreamSynchronize(ws->stream) != hipSuccess) { set_error("error-function evaluation failed"); ransac_fail(); }
     memcpy(d, host, sizeof(double) * len);
     if (w) memcpy(w, host + len, sizeof(double) * len);
     ws->launches++;
@@ -358,9 +358,9 @@ static Score lo_inner_f(FLo &L, int *inliers, int ninl, double th, double *F, in
 
 static double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-#define F_FATAL() do { fprintf(stderr, "libmodsgpu: %s\n", mods_last_error()); abort(); } while (0)
+#define F_FATAL() mods::ransac_fail()
 
-extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
+static int ransac_f_run(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
                                   int do_lo, unsigned inlLimit, double **resids, double *H_best, int *Ih, exFDsPtr EXFDS1, FDsPtr FDS1,
                                   int doSymCheck) {
   (void)H_best;   // the reference copies zero elements into it (exp_ranF.c:1199)
@@ -657,4 +657,19 @@ extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int
                     degen_cnt, wall_ms() - t_begin, t_innerh, t_rfth, t_lo);
   if (Ih) *Ih = Ihmax;
   return (int)maxS.I;
+}
+
+extern "C" int exp_ransacFcustom(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
+                                  int do_lo, unsigned inlLimit, double **resids, double *H_best, int *Ih, exFDsPtr EXFDS1, FDsPtr FDS1,
+                                  int doSymCheck) {
+  mods::ransac_set_failed(0);
+  try {
+    return ransac_f_run(u, len, th, conf, max_sam, F, inl, data_out, do_lo, inlLimit, resids, H_best, Ih, EXFDS1, FDS1, doSymCheck);
+  } catch (const mods::RansacDeviceError &) {
+    mods::ransac_set_failed(1);
+    if (data_out) { data_out[0] = 0; data_out[1] = 0; }
+    if (inl) memset(inl, 0, (size_t)(len > 0 ? len : 0));
+    if (Ih) *Ih = 0;
+    return 0;
+  }
 }

@@ -32,6 +32,14 @@ long ransac_pinned_seed();                                // >= 0: pinned (mods_
 // lane k adds gain[i][k], i = 0..len-1, in correspondence order (the MSAC score is a sequential sum)
 __global__ void ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride, double *__restrict__ J);
 
+// A device failure inside the control loops unwinds to the extern "C" entry point (the reference's signatures have no
+// error channel): the entry point returns "no model" and raises the calling thread's failure flag, which
+// mods_loransac_h / mods_loransac_f turn into MODS_E_HIP; the message is in mods_last_error().
+struct RansacDeviceError {};
+[[noreturn]] inline void ransac_fail() { throw RansacDeviceError(); }
+void ransac_set_failed(int failed);       // calling thread's flag
+int ransac_failed();
+
 #define RS_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return false; } } while (0)
 
 }  // namespace mods

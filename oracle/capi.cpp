@@ -24,6 +24,8 @@ struct orc_hessaff_params {     // mirrors include/mods_hip.h: mods_hessaff_para
   float relativeThreshold;
   int regionsNumber;
   float relativeRegionsNumber;
+  int detectorType;
+  int iiDoGMode;
 };
 
 struct orc_candidate { int octave, level, r0, c0, r, c; float x, y, s, pixelDistance, response; int type; };
@@ -36,6 +38,7 @@ static HessAffParams cvt(const orc_hessaff_params *p) {
     q.edgeEigenValueRatio = p->edgeEigenValueRatio; q.border = p->border; q.maxIterations = p->maxIterations;
     q.convergenceThreshold = p->convergenceThreshold; q.smmWindowSize = p->smmWindowSize; q.doBaumberg = p->doBaumberg;
     q.mode = p->mode; q.rel_threshold = p->relativeThreshold; q.reg_number = p->regionsNumber; q.rel_reg_number = p->relativeRegionsNumber;
+    q.detector_type = p->detectorType; q.ii_dog = p->iiDoGMode;
   }
   return q;
 }
@@ -80,6 +83,14 @@ void orc_gauss_blur(const float *src, int w, int h, float sigma, float *dst) {
 void orc_hessian_response(const float *src, int w, int h, float norm, float *dst) {
   Img a = wrap(src, w, h), b;
   hessian_response(a, b, norm);
+  std::memcpy(dst, b.d.data(), sizeof(float) * (size_t)w * h);
+}
+// kind 1 DoG, 2 Harris, 3 iiDoG (anything else: Hessian)
+void orc_response(const float *src, int w, int h, float norm, int kind, float *dst) {
+  Img a = wrap(src, w, h), b;
+  if (kind == 1 || kind == 3) dog_response(a, b, norm, kind == 3);
+  else if (kind == 2) harris_response(a, b, norm);
+  else hessian_response(a, b, norm);
   std::memcpy(dst, b.d.data(), sizeof(float) * (size_t)w * h);
 }
 void orc_resize_half_dims(int w, int h, int *dw, int *dh) {

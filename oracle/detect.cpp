@@ -8,6 +8,14 @@
 
 namespace orc {
 
+// ScaleSpaceDetector::Response, pyramid.cpp:126-163.  Hessian and Harris have no iiDoG form (the branches are commented
+// out and fall through to the end of a non-void function: undefined in the reference, rejected by the front ends here).
+static void response(const Img &in, Img &out, float norm, const HessAffParams &p) {
+  if (p.detector_type == 1) dog_response(in, out, norm, p.ii_dog != 0);
+  else if (p.detector_type == 2) harris_response(in, out, norm);
+  else hessian_response(in, out, norm);
+}
+
 // detectPyramidKeypoints + detectOctaveKeypoints (pyramid.cpp:496-529, 428-494), blur /
 // response planes only.  upscaleInputImage = 0 (structures.hpp:137).
 void build_pyramid(const Img &image, const HessAffParams &p, Pyramid &pyr) {
@@ -28,7 +36,7 @@ void build_pyramid(const Img &image, const HessAffParams &p, Pyramid &pyr) {
     o.blur.push_back(first);
     o.sigma.push_back(curSigma);
     Img r;
-    hessian_response(first, r, curSigma * curSigma);
+    response(first, r, curSigma * curSigma, p);
     o.resp.push_back(r);
     Img next;
     for (int i = 1; i < p.numberOfScales + 2; i++) {
@@ -37,7 +45,7 @@ void build_pyramid(const Img &image, const HessAffParams &p, Pyramid &pyr) {
       gauss_blur(o.blur.back(), nb, sigma);
       sigma = curSigma * sigmaStep;
       Img rr;
-      hessian_response(nb, rr, sigma * sigma);
+      response(nb, rr, sigma * sigma, p);
       if (i == p.numberOfScales) resize_half(nb, next);
       o.blur.push_back(nb);
       o.resp.push_back(rr);
@@ -78,7 +86,7 @@ struct Thresholds {
     finalThreshold = p.threshold;
     positiveThreshold = (float)(0.8 * finalThreshold);
     negativeThreshold = -positiveThreshold;
-    finalThreshold = p.threshold * p.threshold;
+    if (p.detector_type == 0) finalThreshold = p.threshold * p.threshold;   // pyramid.h:55-56: DET_HESSIAN only
     if (p.mode != 0) finalThreshold = positiveThreshold = negativeThreshold = 0.0f;   // pyramid.h:58-59: every mode but FIXED_TH
   }
 };
@@ -129,7 +137,9 @@ static bool localize(const Img &low, const Img &cur, const Img &high, const Img 
   float scale = curScale * det_pow2f(b[2] / p.numberOfScales);
   // getPointType, pyramid.cpp:65-82 (HESSIAN_DARK 0, BRIGHT 1, SADDLE 2)
   int type;
-  if (val < 0) type = 2;
+  if (p.detector_type == 1) type = val < 0 ? 11 : 10;        // DOG_BRIGHT : DOG_DARK, pyramid.cpp:91-99
+  else if (p.detector_type == 2) type = val < 0 ? 31 : 30;   // HARRIS_BRIGHT : HARRIS_DARK, :100-107
+  else if (val < 0) type = 2;
   else {
     const float *ptr = blur.row(r) + c;
     float Lxx = (ptr[-1] - 2 * ptr[0] + ptr[1]);

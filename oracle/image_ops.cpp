@@ -172,6 +172,54 @@ void hessian_response(const Img &in, Img &out, float norm) {
   out = o;
 }
 
+// ScaleSpaceDetector::dogResponse / iidogResponse, pyramid.cpp:165-194.  `norm` (= sigma^2 of the level, pyramid.cpp:445,
+// 458) is what the reference passes to gaussianBlur as the sigma.  Mat - Mat and Mat + Mat are one float operation per
+// pixel; the iiDoG rescale is computed in double (255. / *SumPtr) and stored to float.
+void dog_response(const Img &in, Img &out, float norm, bool ii) {
+  Img nb;
+  gauss_blur(in, nb, norm);
+  Img o(in.w, in.h);
+  const size_t n = (size_t)in.w * in.h;
+  for (size_t i = 0; i < n; i++) {
+    float v = in.d[i] - nb.d[i];
+    if (ii) {
+      const float sum = in.d[i] + nb.d[i];
+      if (sum < 255.) v = (float)((double)v * (255. / (double)sum));
+    }
+    o.d[i] = v;
+  }
+  out = o;
+}
+
+// ScaleSpaceDetector::HarrisResponse, pyramid.cpp:256-278, with the OpenCV expression templates written out:
+//   Lx.mul(Lx)                    cv::multiply, scale 1: one float product
+//   sigmasq * gaussianBlur(..)    MatExpr scale -> convertTo(alpha): src * (float)alpha
+//   dx2 + dy2                     cv::add
+//   a.mul(b) - c.mul(c) - 0.04*s.mul(s)   = (fl(a*b) - fl(c*c)) - fl(fl(0.04f*s)*s): the two products are evaluated to
+//                                 matrices, subtracted (MatOp::subtract -> cv::subtract), and cv::multiply with a scale
+//                                 computes scale*src1*src2 left to right in float (arithm: mul_ / op_mul_scale)
+void harris_response(const Img &in, Img &out, float norm) {
+  const int rows = in.h, cols = in.w;
+  const float sigmasq = (float)(0.6 * (double)norm);
+  const float sigma = std::sqrt(sigmasq);
+  Img Lx(cols, rows), Ly(cols, rows);
+  compute_gradient(in, Lx, Ly);
+  const size_t n = (size_t)cols * rows;
+  Img xx(cols, rows), yy(cols, rows), xy(cols, rows), bxx, byy, bxy;
+  for (size_t i = 0; i < n; i++) { xx.d[i] = Lx.d[i] * Lx.d[i]; yy.d[i] = Ly.d[i] * Ly.d[i]; xy.d[i] = Lx.d[i] * Ly.d[i]; }
+  gauss_blur(xx, bxx, sigma); gauss_blur(yy, byy, sigma); gauss_blur(xy, bxy, sigma);
+  Img o(cols, rows);
+  const float k = (float)0.04;
+  for (size_t i = 0; i < n; i++) {
+    const float dx2 = bxx.d[i] * sigmasq, dy2 = byy.d[i] * sigmasq, dxdy = bxy.d[i] * sigmasq;
+    const float sum = dx2 + dy2;
+    const float t1 = dx2 * dy2, t2 = dxdy * dxdy;
+    const float t3 = (k * sum) * sum;
+    o.d[i] = (t1 - t2) - t3;
+  }
+  out = o;
+}
+
 // detectors/helpers.cpp:524-549
 bool interpolate_check_borders(int orig_img_w, int orig_img_h, float ofsx, float ofsy, float a11,
                                float a12, float a21, float a22, int res_w, int res_h) {

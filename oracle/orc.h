@@ -39,6 +39,8 @@ std::vector<float> gauss_kernel(int n, double sigma);          // OpenCV getGaus
 void gauss_blur(const Img &src, Img &dst, float sigma);        // detectors/helpers.cpp:717-731
 void resize_half(const Img &src, Img &dst);                    // pyramid.cpp:476 (cv::resize 0.5)
 void hessian_response(const Img &in, Img &out, float norm);    // pyramid.cpp:196-254
+void dog_response(const Img &in, Img &out, float norm, bool ii);   // pyramid.cpp:165-194
+void harris_response(const Img &in, Img &out, float norm);     // pyramid.cpp:256-278
 bool interpolate_check_borders(int img_w, int img_h, float ofsx, float ofsy, float a11,
                                float a12, float a21, float a22, int res_w, int res_h);
 bool interpolate(const Img &im, float ofsx, float ofsy, float a11, float a12, float a21,
@@ -82,6 +84,8 @@ struct HessAffParams {          // PyramidParams + AffineShapeParams, detectors/
   float rel_threshold = -1;     //   3 RELATIVE_REG_NUMBER, 4 NOT_LESS_THAN_REGIONS; defaults of PyramidParams (:138-150)
   int reg_number = -1;
   float rel_reg_number = -1;
+  int detector_type = 0;        // detector_type (structures.hpp:16-18): 0 DET_HESSIAN, 1 DET_DOG, 2 DET_HARRIS
+  int ii_dog = 0;               // iiDoGMode (only the DoG response has such a form, pyramid.cpp:126-161)
 };
 
 struct Candidate {              // one accepted pyramid keypoint before affine adaptation

@@ -205,50 +205,73 @@ def view_schedule(tilts, phi_base, history, scales=(1.0,)):
 
 
 def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=0.2, ratio=0.8, half_orientation=False,
-                 ratio_half=0.0):
-    """mods.cpp:202-383 for HessianAffine + RootSIFT: steps = [(tilts, phi_base), ...].  half_orientation: the steps' descriptor
-    lists name a Half* descriptor (DetectOrientation in doHalfSIFT mode for every descriptor); ratio_half > 0: HalfRootSIFT lists
-    are built and matched as a second separate descriptor, tentatives joined (correspondencebank.cpp:288-340)."""
+                 ratio_half=0.0, detectors=None):
+    """mods.cpp:202-383: steps = [(tilts, phi_base), ...] for one HessianAffine detector, or `detectors` = a list (sorted by
+    detector name, the bank's key order) of dicts {params, steps: [(tilts, phi_base) | None per step], ratio, ratio_half,
+    half_orientation}.  half_orientation: the steps' descriptor lists name a Half* descriptor (DetectOrientation in doHalfSIFT
+    mode for every descriptor); ratio_half > 0: HalfRootSIFT lists are built and matched as a second separate descriptor.
+    Every (descriptor, detector) pair keeps its own tentative list, re-made in the steps that bring new views of the detector
+    (MatchImgReps, correspondencebank.cpp:286-340) and joined in the bank's key order - HalfRootSIFT before RootSIFT, then by
+    detector (GetCorresponcesVector, :114-148)."""
     h, w = img1.shape
-    banks = [[], []]
-    banks_h = [[], []]
-    want_half = ratio_half > 0
-    history = []
+    if detectors is None:
+        detectors = [dict(params=None, steps=list(steps), ratio=ratio, ratio_half=ratio_half, half_orientation=half_orientation)]
+    n_steps = max(len(d["steps"]) for d in detectors)
+    st = [dict(banks=[[], []], banks_h=[[], []], history=[], tc=None, tch=None) for _ in detectors]
     out = None
     n_views = 0
-    for si, (tilts, phi_base) in enumerate(steps):
-        views = view_schedule(tilts, phi_base, history)
+    for si in range(n_steps):
+        for d, S in zip(detectors, st):
+            step = d["steps"][si] if si < len(d["steps"]) else None
+            if step is None:
+                continue
+            tilts, phi_base = step
+            views = view_schedule(tilts, phi_base, S["history"])
+            want_half = d.get("ratio_half", 0.0) > 0
+            half_ori = d.get("half_orientation", False) or want_half
 
-        def one_view(job):
-            img, (zoom, tilt, phi) = job
-            px, g = orc.synth_view(img, tilt, phi, zoom, init_sigma, 1)
-            if g.w_new < 16 or g.h_new < 16:
-                return None
-            r = orc.detect_describe_view(px, np.array(g.H), w, h, half_orientation=half_orientation or want_half, half_desc=want_half)
-            return (r[0], r[3]) if want_half else (r[0], None)
-        for im, img in enumerate((img1, img2)):
-            regs = pmap(one_view, [(img, v) for v in views])      # views are independent; banks keep the view order
-            n_views += len(views)
-            banks[im] += [r[0] for r in regs if r is not None]
-            banks_h[im] += [r[1] for r in regs if r is not None and want_half]
-        ra, rb = np.concatenate(banks[0]), np.concatenate(banks[1])
-        tc = match_fginn_par(ra, rb, ratio)
-        u6_all, laf_all = u6_of(ra, rb, tc), laf_of(ra, rb, tc)
-        if want_half:
-            ha, hb = np.concatenate(banks_h[0]), np.concatenate(banks_h[1])
-            tch = match_fginn_par(ha, hb, ratio_half)
-            u6_all = np.concatenate([u6_all, u6_of(ha, hb, tch)]); laf_all = np.concatenate([laf_all, laf_of(ha, hb, tch)])
-            # the duplicate filter and what follows only need coordinates, frames and the ratio / distance keys: one joint list
-            # whose q / t index a joint region array (RootSIFT lists first)
-            tch = tch.copy(); tch["q"] += len(ra); tch["t"] += len(rb)
-            tc = np.concatenate([tc, tch])
-            ra, rb = np.concatenate([ra, ha]), np.concatenate([rb, hb])
+            def one_view(job, d=d, want_half=want_half, half_ori=half_ori):
+                img, (zoom, tilt, phi) = job
+                px, g = orc.synth_view(img, tilt, phi, zoom, init_sigma, 1)
+                if g.w_new < 16 or g.h_new < 16:
+                    return None
+                r = orc.detect_describe_view(px, np.array(g.H), w, h, params=d.get("params"), half_orientation=half_ori, half_desc=want_half)
+                return (r[0], r[3]) if want_half else (r[0], None)
+            for im, img in enumerate((img1, img2)):
+                regs = pmap(one_view, [(img, v) for v in views])      # views are independent; banks keep the view order
+                n_views += len(views)
+                S["banks"][im] += [r[0] for r in regs if r is not None]
+                S["banks_h"][im] += [r[1] for r in regs if r is not None and want_half]
+            if not views:
+                continue
+            if d.get("ratio", 0.8) > 0:
+                ra, rb = np.concatenate(S["banks"][0]), np.concatenate(S["banks"][1])
+                S["tc"] = (match_fginn_par(ra, rb, d.get("ratio", 0.8)), ra, rb)
+            if want_half:
+                ha, hb = np.concatenate(S["banks_h"][0]), np.concatenate(S["banks_h"][1])
+                S["tch"] = (match_fginn_par(ha, hb, d["ratio_half"]), ha, hb)
+        # the duplicate filter and what follows only need coordinates, frames and the ratio / distance keys: one joint list
+        # whose q / t index a joint region array
+        tcs, ras, rbs = [], [], []
+        nq = nt = 0
+        for key in ("tch", "tc"):
+            for S in st:
+                if S[key] is None:
+                    continue
+                tc, ra, rb = S[key]
+                tc = tc.copy(); tc["q"] += nq; tc["t"] += nt
+                nq += len(ra); nt += len(rb)
+                tcs.append(tc); ras.append(ra); rbs.append(rb)
+        tc, ra, rb = np.concatenate(tcs), np.concatenate(ras), np.concatenate(rbs)
         un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
         u6, laf = u6_of(ra, rb, un), laf_of(ra, rb, un)
         mask, H, ninl, stats = loransac_h(u6, laf, seed_time=seed_time)
-        n_desc = [sum(len(x) for x in banks[0]), sum(len(x) for x in banks[1])]
+        n_desc = [sum(len(x) for S in st for x in S["banks"][0]), sum(len(x) for S in st for x in S["banks"][1])]
+        first = st[0]
         out = dict(steps_done=si + 1, n_views=n_views, n_described=n_desc, n_tentatives=len(tc), n_unique=len(un),
-                   n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6, regions=(ra[:n_desc[0]], rb[:n_desc[1]]))
+                   n_inliers=ninl, stats=stats, H=H, mask=mask, u6=u6,
+                   regions=(np.concatenate(first["banks"][0]) if first["banks"][0] else None,
+                            np.concatenate(first["banks"][1]) if first["banks"][1] else None))
         if ninl >= min_matches:
             break
     return out

@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 import orc
 
@@ -83,6 +84,19 @@ def test_loransac_rejects_small_sets_without_a_gpu(pkg):
     u = np.random.default_rng(0).uniform(0, 100, (7, 6))
     mask, H, ninl, stats = pkg.loransac_h(u, None)
     assert ninl == 0 and not mask.any() and np.all(H == -1)     # tent_size < MIN_POINTS (matching.cpp:682-688)
+
+
+def test_verification_without_a_device_is_an_error_not_an_abort(pkg):
+    """The degensac entry points have no error channel (exp_ranH.c / exp_ranF.c signatures): a device failure inside them
+    comes back from mods_loransac_h / mods_loransac_f as an error code, the process lives on, and nothing is computed on
+    the CPU instead."""
+    if pkg.lib().mods_device_count() > 0:
+        return
+    u = np.random.default_rng(0).uniform(0, 100, (40, 6))
+    u[:, 2] = u[:, 5] = 1
+    for fn in (pkg.loransac_h, pkg.loransac_f):
+        with pytest.raises(pkg.ModsError, match="no CPU path"):
+            fn(u, None)
 
 
 def test_struct_layouts(pkg):

@@ -58,6 +58,50 @@ def test_pyramid_and_candidates(gpu_ctx, w, h, seed):
     _assert_keys_equal(got, orc.detect_hessian_affine(img))
 
 
+def _alt_params(mod, det):
+    par = mod.HessAffParams.harris() if det == "harris" else mod.HessAffParams.dog()
+    if det == "iidog":
+        par.iiDoGMode = 1
+    if det == "dog_baumberg":
+        par.doBaumberg = 1
+    return par
+
+
+@pytest.mark.parametrize("det", ["dog", "harris", "iidog", "dog_baumberg"])
+@pytest.mark.parametrize("w,h,seed", [(320, 240, 7), (515, 389, 11)])
+def test_dog_and_harris_detectors(gpu_ctx, pkg, det, w, h, seed):
+    """[DoG] / [HarrisAffine]: the same scale-space detector on another response (pyramid.cpp:126-194, 256-278), final
+    threshold un-squared (pyramid.h:55-56), point types 10/11 and 30/31 (pyramid.cpp:91-107): planes, candidates and
+    keypoints equal the oracle's bit for bit."""
+    img = synth.texture(w, h, seed=seed)
+    got = gpu_ctx.detect_hessian_affine(img, params=_alt_params(pkg, det))
+    po = _alt_params(orc, det)
+    pyr = orc.Pyramid(img, po)
+    assert gpu_ctx.pyramid_octaves() == pyr.n_oct
+    for o in range(pyr.n_oct):
+        for lv in range(5):
+            for kind in (0, 1):
+                assert np.array_equal(gpu_ctx.pyramid_plane(0, o, lv, kind), pyr.plane(o, lv, kind)), (o, lv, kind)
+    cand_want, _ = pyr.candidates()
+    cand_got = gpu_ctx.pyramid_candidates(0)
+    order = np.lexsort((cand_got["c0"], cand_got["r0"], cand_got["level"], cand_got["octave"]))
+    cand_got = cand_got[order]
+    assert len(cand_got) == len(cand_want) and len(cand_want) > 20
+    for f in cand_want.dtype.names:
+        assert np.array_equal(cand_got[f], cand_want[f]), f
+    want = orc.detect_hessian_affine(img, po)
+    _assert_keys_equal(got, want)
+    assert set(np.unique(want["sub_type"])) <= ({30, 31} if det == "harris" else {10, 11})
+
+
+def test_iidog_is_refused_for_hessian_and_harris(gpu_ctx, pkg):
+    img = synth.texture(64, 48, seed=1)
+    for par in (pkg.HessAffParams.default(), pkg.HessAffParams.harris()):
+        par.iiDoGMode = 1
+        with pytest.raises(pkg.ModsError, match="iiDoGMode"):
+            gpu_ctx.detect_hessian_affine(img, params=par)
+
+
 def test_detect_graf(gpu_ctx):
     from PIL import Image
     import os

@@ -188,3 +188,41 @@ def test_ladder_with_half_descriptors(pkg):
     assert res.n_inliers == want["n_inliers"] >= 15
     assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
     rep1.close(); rep2.close(); ctx.close()
+
+
+def test_ladder_with_two_detectors(pkg):
+    """[DoG<i>] next to [HessianAffine<i>]: every detector has its own view history, banks and tentative lists; the joint list
+    is the bank's key order (DoG before HessianAffine), lists of a detector without new views in a step are kept - against the
+    oracle chain (CorrespondenceBank::MatchImgReps, correspondencebank.cpp:286-340)."""
+    import torch
+    import orc
+    import pipeline_oracle as po
+    import refdeg
+    if not refdeg.available():
+        pytest.skip("oracle/_ref not built")
+    w, h = 480, 360
+    a, b, Htrue = _hard_pair(w, h, seed=23)
+    # step 0: both detectors on the plain images; step 1: only HessianAffine brings new (tilted) views, the DoG list stays
+    dets = [dict(params=orc.HessAffParams.dog(), steps=[((1,), 360.0), None], ratio=0.8),
+            dict(params=orc.HessAffParams.default(), steps=[((1,), 360.0), ((1, 2, 4), 360.0)], ratio=0.8)]
+    want = po.match_ladder(a, b, None, seed_time=31, min_matches=100000, detectors=dets)
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    reps1, reps2 = [pkg.ImgRep(ctx), pkg.ImgRep(ctx)], [pkg.ImgRep(ctx), pkg.ImgRep(ctx)]
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(31)
+    det_steps = [[pkg.LadderStep.make((1,), 360.0), None],
+                 [pkg.LadderStep.make((1,), 360.0), pkg.LadderStep.make((1, 2, 4), 360.0)]]
+    res, m = pkg.match_ladder_dets_dev(ctx, t.data_ptr(), w, h, det_steps, [pkg.HessAffParams.dog(), pkg.HessAffParams.default()],
+                                       reps1, reps2, min_matches=100000, max_matches=100000)
+    assert res.steps_done == want["steps_done"] == 2 and res.n_views == want["n_views"]
+    assert list(res.n_described) == want["n_described"]
+    assert len(reps1[0]) > 50 and len(reps1[1]) > 50
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] >= 15
+    assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
+    for r in reps1 + reps2:
+        r.close()
+    ctx.close()
