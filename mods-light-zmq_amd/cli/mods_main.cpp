@@ -45,6 +45,10 @@ bool ends_with(const std::string &s, const std::string &suffix) {
 
 struct Config {
   mods_pair_params pair;
+  // the scale-space detectors that have views in some step, sorted by name (the reference's maps are keyed by name), their
+  // parameter sets, and steps[step * n_det + d] = detector d's section of that step (n_tilts = -1: none)
+  std::vector<std::string> det_names;
+  std::vector<mods_hessaff_params> det_params;
   std::vector<mods_ladder_step> steps;
   int max_steps = 4, min_matches = 15;
   int load_color = 1;
@@ -68,25 +72,33 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   if (it.ParseError() < 0) { std::cerr << "Can't load  " << iters_fn << std::endl; return 1; }
   mods_pair_params &p = cfg->pair;
   cfg->verbose = (int)ini.GetInteger("TextOutput", "verbose", 0);     // first: the notes below depend on it
-  // [HessianAffine], io_mods.cpp:160-207; defaults = PyramidParams / AffineShapeParams constructors
-  mods_hessaff_params &d = p.det;
-  d.threshold = (float)ini.GetDouble("HessianAffine", "threshold", 16.0 / 3.0);
-  d.border = (int)ini.GetInteger("HessianAffine", "border", 5);
-  d.numberOfScales = (int)ini.GetInteger("HessianAffine", "numberOfScales", 3);
-  d.initialSigma = (float)ini.GetDouble("HessianAffine", "initialSigma", 1.6);
-  d.edgeEigenValueRatio = (float)ini.GetDouble("HessianAffine", "edgeEigenValueRatio", 10.0);
-  d.maxIterations = (int)ini.GetInteger("HessianAffine", "max_iter", 16);
-  d.smmWindowSize = (int)ini.GetInteger("HessianAffine", "smmWindowSize", 19);
-  d.convergenceThreshold = (float)ini.GetDouble("HessianAffine", "convergenceThreshold", 0.05);
-  d.doBaumberg = (int)ini.GetInteger("HessianAffine", "doBaumberg", 1);
-  // keypoint selection, io_mods.cpp:170-173, 194-205 (defaults: PyramidParams, structures.hpp:138-150)
-  d.relativeThreshold = (float)ini.GetDouble("HessianAffine", "relativeThreshold", -1.0);
-  d.relativeRegionsNumber = (float)ini.GetDouble("HessianAffine", "relativeRegionsNumber", -1.0);
-  d.regionsNumber = (int)ini.GetInteger("HessianAffine", "regionsNumber", -1);
-  const std::string mode = ini.GetStringVector("HessianAffine", "mode")[0];
-  d.mode = mode == "RelativeTh" ? MODS_DET_RELATIVE_TH : mode == "FixedRegNumber" ? MODS_DET_FIXED_REG_NUMBER
-         : mode == "NotLessThanRegions" ? MODS_DET_NOT_LESS_THAN_REGIONS : mode == "RelativeRegNumber" ? MODS_DET_RELATIVE_REG_NUMBER
-         : MODS_DET_FIXED_TH;
+  // [HessianAffine] / [DoG] / [HarrisAffine], io_mods.cpp:160-207, 208-244, 260-296: one key set, DetectorType set by the
+  // section; defaults = PyramidParams / AffineShapeParams constructors
+  auto read_det = [&](const char *sec, int type) {
+    mods_hessaff_params d;
+    memset(&d, 0, sizeof(d));
+    d.detectorType = type;
+    d.threshold = (float)ini.GetDouble(sec, "threshold", 16.0 / 3.0);
+    d.border = (int)ini.GetInteger(sec, "border", 5);
+    d.numberOfScales = (int)ini.GetInteger(sec, "numberOfScales", 3);
+    d.initialSigma = (float)ini.GetDouble(sec, "initialSigma", 1.6);
+    d.edgeEigenValueRatio = (float)ini.GetDouble(sec, "edgeEigenValueRatio", 10.0);
+    d.maxIterations = (int)ini.GetInteger(sec, "max_iter", 16);
+    d.smmWindowSize = (int)ini.GetInteger(sec, "smmWindowSize", 19);
+    d.convergenceThreshold = (float)ini.GetDouble(sec, "convergenceThreshold", 0.05);
+    d.doBaumberg = (int)ini.GetInteger(sec, "doBaumberg", 1);
+    d.iiDoGMode = ini.GetBoolean(sec, "iiDoGMode", false) ? 1 : 0;
+    // keypoint selection, io_mods.cpp:170-173, 194-205 (defaults: PyramidParams, structures.hpp:138-150)
+    d.relativeThreshold = (float)ini.GetDouble(sec, "relativeThreshold", -1.0);
+    d.relativeRegionsNumber = (float)ini.GetDouble(sec, "relativeRegionsNumber", -1.0);
+    d.regionsNumber = (int)ini.GetInteger(sec, "regionsNumber", -1);
+    const std::string mode = ini.GetStringVector(sec, "mode")[0];
+    d.mode = mode == "RelativeTh" ? MODS_DET_RELATIVE_TH : mode == "FixedRegNumber" ? MODS_DET_FIXED_REG_NUMBER
+           : mode == "NotLessThanRegions" ? MODS_DET_NOT_LESS_THAN_REGIONS : mode == "RelativeRegNumber" ? MODS_DET_RELATIVE_REG_NUMBER
+           : MODS_DET_FIXED_TH;
+    return d;
+  };
+  p.det = read_det("HessianAffine", MODS_DET_HESSIAN);
   if (ini.GetInteger("HessianAffine", "affBmbrgMethod", 0) != 0) std::cerr << "Warning: affBmbrgMethod != 0 (Hessian Baumberg) is not supported, SMM is used" << std::endl;
   // [DominantOrientation] :731-740 and [SIFTDescriptor] :423-436
   mods_describe_params &q = p.desc;
@@ -151,12 +163,28 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   // iterations file :457-492
   cfg->max_steps = (int)it.GetInteger("Iterations", "Steps", 4);
   cfg->min_matches = (int)it.GetInteger("Iterations", "minMatches", 15);
-  static const char *other_detectors[] = {"MSER", "DoG", "HarrisAffine", "ORB", "FAST", "ReadAffs", "STAR", "BRISK", "SURF", "SIFT", "TILDE", "FOCI"};
+  static const char *other_detectors[] = {"MSER", "ORB", "FAST", "ReadAffs", "STAR", "BRISK", "SURF", "SIFT", "TILDE", "FOCI"};
+  // the three scale-space detectors of this build, in name order (the order of the reference's region / correspondence maps)
+  static const struct { const char *name; int type; } ss_detectors[] = {{"DoG", MODS_DET_DOG}, {"HarrisAffine", MODS_DET_HARRIS}, {"HessianAffine", MODS_DET_HESSIAN}};
+  std::vector<mods_ladder_step> all[3];
   for (int i = 0; i < cfg->max_steps; i++) {
-    const std::string sec = "HessianAffine" + std::to_string(i);
     for (const char *od : other_detectors)
       if (it.Has(od + std::to_string(i), "TiltSet") || it.Has(od + std::to_string(i), "ScaleSet"))
         std::cerr << "Warning: step " << i << ": detector " << od << " is outside this build, its views are skipped" << std::endl;
+    // [Matching<i>] SeparateDetectors (io_mods.cpp:320): the detectors whose lists MatchImgReps searches in this step.  The
+    // reference matches nothing when the key is absent; an absent key means "every detector of the step" here.
+    const std::string msec_det = "Matching" + std::to_string(i);
+    std::vector<std::string> sep_det;
+    const bool have_sep_det = it.Has(msec_det, "SeparateDetectors");
+    if (have_sep_det)
+      for (std::string name : it.GetStringVector(msec_det, "SeparateDetectors")) {
+        name.erase(0, name.find_first_not_of(" \t"));
+        name.erase(name.find_last_not_of(" \t") + 1);
+        sep_det.push_back(name);
+      }
+  for (int di = 0; di < 3; di++) {
+    const std::string det_name = ss_detectors[di].name;
+    const std::string sec = det_name + std::to_string(i);
     mods_ladder_step st;
     memset(&st, 0, sizeof(st));
     st.phi = it.GetDouble(sec, "Phi", 360);
@@ -190,6 +218,7 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
         }
         else if (!name.empty()) std::cerr << "Warning: " << sec << ": descriptor " << name << " is outside this build" << std::endl;
       }
+      if (st.fginn_ratio_half != 0 && !(st.fginn_ratio_half > 0 && st.fginn_ratio_half < 1)) { std::cerr << sec << ": FGINNThreshold of HalfRootSIFT must lie in (0, 1)" << std::endl; return 1; }
       // [Matching<i>] SeparateDescriptors: only the listed descriptors are matched (correspondencebank.cpp:288-299)
       const std::string msec = "Matching" + std::to_string(i);
       if (it.Has(msec, "SeparateDescriptors")) {
@@ -200,18 +229,37 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
           root_listed = root_listed || name == "RootSIFT" || name == "ZMQ";
           half_listed = half_listed || name == "HalfRootSIFT";
         }
-        if (!half_listed) st.fginn_ratio_half = 0.0;
+        if (!half_listed) st.fginn_ratio_half = st.fginn_ratio_half > 0 ? -1.0 : 0.0;   // built as the step asks, its list is left alone
         if (!root_listed && has_root) std::cerr << "Warning: " << msec << ": SeparateDescriptors does not list the step's descriptor; it is matched anyway" << std::endl;
       }
-      if (st.fginn_ratio_half != 0 && !(st.fginn_ratio_half > 0 && st.fginn_ratio_half < 1)) { std::cerr << sec << ": FGINNThreshold of HalfRootSIFT must lie in (0, 1)" << std::endl; return 1; }
       if (has_zmq && !has_root) {      // the daemon's descriptor takes the place of RootSIFT for the whole run
         cfg->use_zmq = true; has_root = true; st.fginn_ratio = zmq_ratio;
       } else if (has_zmq) std::cerr << "Warning: " << sec << ": RootSIFT and ZMQ in one step: RootSIFT is used" << std::endl;
       if (!has_root) { std::cerr << "Warning: " << sec << " does not ask for RootSIFT; the step is skipped" << std::endl; st.n_tilts = st.n_scales = -1; }
       else if (!(st.fginn_ratio > 0 && st.fginn_ratio < 1)) { std::cerr << sec << ": FGINNThreshold of RootSIFT must lie in (0, 1)" << std::endl; return 1; }
     } else st.n_tilts = st.n_scales = -1;      // no views of this detector in this step
-    cfg->steps.push_back(st);
+    if (st.n_tilts >= 0 && have_sep_det && std::find(sep_det.begin(), sep_det.end(), det_name) == sep_det.end() &&
+        std::find(sep_det.begin(), sep_det.end(), std::string("All")) == sep_det.end()) {
+      if (cfg->verbose) std::cerr << sec << ": not in SeparateDetectors of [" << msec_det << "]: described, not matched" << std::endl;
+      st.fginn_ratio = -1.0;
+      if (st.fginn_ratio_half > 0) st.half_orientation = 1;   // still described in doHalfSIFT mode
+      st.fginn_ratio_half = -1.0;
+    }
+    all[di].push_back(st);
   }
+  }
+  for (int di = 0; di < 3; di++) {
+    bool any = false;
+    for (const mods_ladder_step &st : all[di]) any = any || st.n_tilts >= 0;
+    if (!any) continue;
+    cfg->det_names.push_back(ss_detectors[di].name);
+    cfg->det_params.push_back(di == 2 ? p.det : read_det(ss_detectors[di].name, ss_detectors[di].type));
+  }
+  const int n_det = (int)cfg->det_names.size();
+  for (int i = 0; i < cfg->max_steps; i++)
+    for (int di = 0, d = 0; di < 3; di++) {
+      if (d < n_det && cfg->det_names[d] == ss_detectors[di].name) { cfg->steps.push_back(all[di][i]); d++; }
+    }
   return 0;
 }
 
@@ -235,30 +283,38 @@ bool load_grey(const std::string &fn, int load_color, GreyImage *img) {
   return true;
 }
 
-void write_regions(const std::string &fn, mods_imgrep *rep, const char *desc_name) {
+// SaveRegions, imagerepresentation.cpp:1219-1255: the detectors in name order (the region map's key order), one descriptor list each
+void write_regions(const std::string &fn, const std::vector<mods_imgrep *> &reps, const std::vector<std::string> &det_names, const char *desc_name) {
   std::ofstream kp(fn);
   if (!kp.is_open()) { std::cerr << "Cannot open file " << fn << " to save keypoints" << std::endl; return; }
-  const int n = mods_imgrep_count(rep);
-  std::vector<mods_region> regs((size_t)std::max(n, 1));
-  if (n > 0 && mods_imgrep_fetch(rep, 0, n, regs.data())) { std::cerr << mods_last_error() << std::endl; return; }
-  kp << 1 << std::endl;
-  kp << "HessianAffine " << 1 << std::endl;
-  kp << desc_name << " " << n << std::endl;
-  if (n > 0) kp << 128 << std::endl;
-  for (int i = 0; i < n; i++) {
-    const mods_region &r = regs[i];
-    kp << r.x << " " << r.y << " " << r.s << " " << r.a11 << " " << r.a12 << " " << r.a21 << " " << r.a22;
-    kp << " " << 128 << " ";
-    for (int j = 0; j < 128; j++) kp << (float)r.desc[j] << " ";
-    kp << std::endl;
+  kp << reps.size() << std::endl;
+  for (size_t d = 0; d < reps.size(); d++) {
+    const int n = mods_imgrep_count(reps[d]);
+    std::vector<mods_region> regs((size_t)std::max(n, 1));
+    if (n > 0 && mods_imgrep_fetch(reps[d], 0, n, regs.data())) { std::cerr << mods_last_error() << std::endl; return; }
+    kp << det_names[d] << " " << 1 << std::endl;
+    kp << desc_name << " " << n << std::endl;
+    if (n > 0) kp << 128 << std::endl;
+    for (int i = 0; i < n; i++) {
+      const mods_region &r = regs[i];
+      kp << r.x << " " << r.y << " " << r.s << " " << r.a11 << " " << r.a12 << " " << r.a21 << " " << r.a22;
+      kp << " " << 128 << " ";
+      for (int j = 0; j < 128; j++) kp << (float)r.desc[j] << " ";
+      kp << std::endl;
+    }
   }
 }
 
 // SaveRegionsNPZ, imagerepresentation.cpp:1257-1316: xy, scales, responses, A (reproj_kp, doubles) and descs (uchar)
-bool write_regions_npz(const std::string &fn, mods_imgrep *rep) {
-  const int n = mods_imgrep_count(rep);
+bool write_regions_npz(const std::string &fn, const std::vector<mods_imgrep *> &reps) {
+  int n = 0;
+  for (mods_imgrep *rep : reps) n += mods_imgrep_count(rep);
   std::vector<mods_region> regs((size_t)std::max(n, 1));
-  if (n > 0 && mods_imgrep_fetch(rep, 0, n, regs.data())) { std::cerr << mods_last_error() << std::endl; return false; }
+  for (size_t d = 0, at = 0; d < reps.size(); d++) {      // all detectors, in name order, in one set of arrays (:1257-1316)
+    const int nd = mods_imgrep_count(reps[d]);
+    if (nd > 0 && mods_imgrep_fetch(reps[d], 0, nd, regs.data() + at)) { std::cerr << mods_last_error() << std::endl; return false; }
+    at += (size_t)nd;
+  }
   modscli::NpyArray xy, sc, rs, A, ds;
   auto f8 = [&](modscli::NpyArray &a, size_t cols) { a.descr = "<f8"; a.shape = {(size_t)n, cols}; a.data.resize(sizeof(double) * n * cols); };
   f8(xy, 2); f8(sc, 1); f8(rs, 1); f8(A, 4);
@@ -419,22 +475,32 @@ int main(int argc, char **argv) {
   const int device = getenv("MODS_DEVICE") ? atoi(getenv("MODS_DEVICE")) : 0;
   const double diag = std::ceil(std::max(std::hypot((double)img1.w, (double)img1.h), std::hypot((double)img2.w, (double)img2.h))) + 2;
   mods_ctx *ctx = nullptr;
-  mods_imgrep *rep1 = nullptr, *rep2 = nullptr;
+  const int n_det = (int)cfg.det_names.size();
+  if (n_det == 0) { std::cerr << "The iterations file has no HessianAffine / DoG / HarrisAffine step with RootSIFT; nothing to do" << std::endl; return 1; }
+  const bool hessian_only = n_det == 1 && cfg.det_names[0] == "HessianAffine";
+  std::vector<mods_imgrep *> reps1((size_t)n_det, nullptr), reps2((size_t)n_det, nullptr);
   void *d1 = nullptr, *d2 = nullptr;
   auto fail = [&](const char *what) { std::cerr << "mods: " << what << ": " << mods_last_error() << std::endl; return 1; };
   if (mods_ctx_create(device, (int)diag, (int)diag, 1, &ctx)) return fail("context");
-  if (mods_imgrep_create(ctx, 1 << 20, &rep1) || mods_imgrep_create(ctx, 1 << 20, &rep2)) return fail("region banks");
+  for (int d = 0; d < n_det; d++)
+    if (mods_imgrep_create(ctx, 1 << 20, &reps1[d]) || mods_imgrep_create(ctx, 1 << 20, &reps2[d])) return fail("region banks");
   if (mods_dev_alloc(sizeof(float) * img1.px.size(), &d1) || mods_dev_alloc(sizeof(float) * img2.px.size(), &d2)) return fail("device memory");
   if (mods_dev_upload(d1, img1.px.data(), sizeof(float) * img1.px.size()) || mods_dev_upload(d2, img2.px.data(), sizeof(float) * img2.px.size())) return fail("upload");
 
-  // steps without HessianAffine views are dropped from the ladder but still count as steps of the loop
+  // one HessianAffine detector (the MODS_DEVICES path takes this form): steps without views are dropped from the ladder but
+  // still count as steps of the loop
   std::vector<mods_ladder_step> steps;
   std::vector<int> step_index;
-  for (size_t i = 0; i < cfg.steps.size(); i++)
-    if (cfg.steps[i].n_tilts >= 0) { steps.push_back(cfg.steps[i]); step_index.push_back((int)i); }
-  if (steps.empty()) { std::cerr << "The iterations file has no HessianAffine step with RootSIFT; nothing to do" << std::endl; return 1; }
-  if (cfg.verbose) std::cerr << steps.size() << " HessianAffine step(s) of " << cfg.steps.size() << " will be run, minMatches = " << cfg.min_matches << std::endl;
-
+  if (hessian_only)
+    for (size_t i = 0; i < cfg.steps.size(); i++)
+      if (cfg.steps[i].n_tilts >= 0) { steps.push_back(cfg.steps[i]); step_index.push_back((int)i); }
+  if (cfg.verbose) {
+    std::cerr << "Detectors:";
+    for (const std::string &nm : cfg.det_names) std::cerr << " " << nm;
+    std::cerr << "; " << cfg.steps.size() / n_det << " step(s), minMatches = " << cfg.min_matches << std::endl;
+  }
+  double first_ratio = 0.8;
+  for (const mods_ladder_step &st : cfg.steps) if (st.n_tilts >= 0 && st.fginn_ratio > 0) { first_ratio = st.fginn_ratio; break; }
   if (cfg.use_zmq) {
     while (!cfg.zmq_port.empty() && isspace((unsigned char)cfg.zmq_port.back())) cfg.zmq_port.pop_back();
     if (cfg.verbose) std::cerr << "Descriptors from the daemon at " << cfg.zmq_port << " (" << cfg.zmq_ps << "x" << cfg.zmq_ps << " patches)" << std::endl;
@@ -464,6 +530,7 @@ int main(int argc, char **argv) {
       q = *e == ',' ? e + 1 : e;
     }
     if (pre_extracted || cfg.use_zmq || cfg.aff_zmq || cfg.ori_zmq) std::cerr << "Note: MODS_DEVICES is ignored in pre-extracted mode and with ZMQ daemons" << std::endl;
+    else if (!hessian_only) std::cerr << "Note: MODS_DEVICES is ignored: the multi-GPU ladder runs one HessianAffine detector" << std::endl;
     else if (!devs.empty()) {
       if (mods_multi_create(devs.data(), (int)devs.size(), std::max(img1.w, img2.w), std::max(img1.h, img2.h), 1 << 20, &multi)) return fail("multi-GPU setup");
       if (cfg.verbose) std::cerr << devs.size() << " device(s), exchange over " << (mods_multi_uses_rccl(multi) ? "RCCL" : "device copies") << std::endl;
@@ -475,20 +542,26 @@ int main(int argc, char **argv) {
     std::vector<mods_region> r1, r2;
     if (!read_regions_any(k1_fn, &r1) || !read_regions_any(k2_fn, &r2)) return 1;
     if (cfg.verbose) std::cerr << "Pre-extracted regions: " << r1.size() << " | " << r2.size() << std::endl;
-    if ((!r1.empty() && mods_imgrep_append_host(rep1, r1.data(), (int)r1.size())) || (!r2.empty() && mods_imgrep_append_host(rep2, r2.data(), (int)r2.size())))
+    if ((!r1.empty() && mods_imgrep_append_host(reps1[0], r1.data(), (int)r1.size())) || (!r2.empty() && mods_imgrep_append_host(reps2[0], r2.data(), (int)r2.size())))
       return fail("region banks");
-    if (mods_match_verify_reps(ctx, rep1, rep2, steps[0].fginn_ratio, &cfg.pair, &res, matches.data(), 1 << 20)) return fail("matching");
+    if (mods_match_verify_reps(ctx, reps1[0], reps2[0], first_ratio, &cfg.pair, &res, matches.data(), 1 << 20)) return fail("matching");
     res.n_unoriented[0] = (int)r1.size(); res.n_unoriented[1] = (int)r2.size();
   } else if (multi) {   // MODS_DEVICES: the views of every step sharded over several GPUs, one all-gather of the regions per step
     if (mods_match_ladder_multi(multi, img1.px.data(), img1.w, img1.h, img2.px.data(), img2.w, img2.h, steps.data(), (int)steps.size(),
                                 cfg.min_matches, &cfg.pair, &res, matches.data(), 1 << 20))
       return fail("matching");
-    rep1 = mods_multi_bank(multi, 0); rep2 = mods_multi_bank(multi, 1);     // for the keypoint files
-  } else if (mods_match_ladder_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, steps.data(), (int)steps.size(),
-                                   cfg.min_matches, &cfg.pair, rep1, rep2, &res, matches.data(), 1 << 20))
+    mods_imgrep_destroy(reps1[0]); mods_imgrep_destroy(reps2[0]);
+    reps1[0] = mods_multi_bank(multi, 0); reps2[0] = mods_multi_bank(multi, 1);     // for the keypoint files; owned by `multi`
+  } else if (hessian_only) {
+    if (steps.empty()) { res = mods_ladder_result(); }
+    else if (mods_match_ladder_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, steps.data(), (int)steps.size(),
+                                   cfg.min_matches, &cfg.pair, reps1[0], reps2[0], &res, matches.data(), 1 << 20))
+      return fail("matching");
+  } else if (mods_match_ladder_dets_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, cfg.steps.data(), cfg.det_params.data(),
+                                        (int)cfg.steps.size() / n_det, n_det, cfg.min_matches, &cfg.pair, reps1.data(), reps2.data(), &res, matches.data(), 1 << 20))
     return fail("matching");
   const double final_time = now_s() - c_start;
-  const int final_step = res.steps_done > 0 ? step_index[res.steps_done - 1] + 1 : 0;
+  const int final_step = res.steps_done <= 0 ? 0 : (hessian_only && !pre_extracted) ? step_index[res.steps_done - 1] + 1 : res.steps_done;
   if (cfg.verbose) {
     std::cerr << res.n_views << " views synthesised, " << res.n_tentatives << " tentatives found." << std::endl;
     std::cerr << res.n_unique << " unique tentatives left" << std::endl;
@@ -521,10 +594,10 @@ int main(int argc, char **argv) {
           mf << matches[4 * (size_t)i] << " " << matches[4 * (size_t)i + 1] << " " << matches[4 * (size_t)i + 2] << " " << matches[4 * (size_t)i + 3] << std::endl;
     }
     if (cfg.write_keypoints && !pre_extracted) {   // mods.cpp:433-447
-      if (ends_with(k1_fn, ".npz")) write_regions_npz(k1_fn, rep1);
-      else write_regions(k1_fn, rep1, cfg.use_zmq ? "ZMQ" : "RootSIFT");
-      if (ends_with(k2_fn, ".npz")) write_regions_npz(k2_fn, rep2);
-      else write_regions(k2_fn, rep2, cfg.use_zmq ? "ZMQ" : "RootSIFT");
+      if (ends_with(k1_fn, ".npz")) write_regions_npz(k1_fn, reps1);
+      else write_regions(k1_fn, reps1, cfg.det_names, cfg.use_zmq ? "ZMQ" : "RootSIFT");
+      if (ends_with(k2_fn, ".npz")) write_regions_npz(k2_fn, reps2);
+      else write_regions(k2_fn, reps2, cfg.det_names, cfg.use_zmq ? "ZMQ" : "RootSIFT");
     }
   }
   std::cerr << "Image1: regions descriptors | Image2: regions descriptors " << std::endl;
@@ -541,7 +614,7 @@ int main(int argc, char **argv) {
     std::cerr << "Timings: (sec) " << std::endl << "Synth+Detect+Orient+Desc|Match|RANSAC|MISC|Total " << std::endl
               << dd << " " << mt << " " << rs << " " << total - (dd + mt + rs) << " " << total << std::endl;
   }
-  mods_imgrep_destroy(rep1); mods_imgrep_destroy(rep2);
+  if (!multi) for (int d = 0; d < n_det; d++) { mods_imgrep_destroy(reps1[d]); mods_imgrep_destroy(reps2[d]); }
   mods_dev_free(d1); mods_dev_free(d2);
   mods_ctx_destroy(ctx);
   return 0;

@@ -180,15 +180,18 @@ constexpr int FB_TW = 128;   // tile width; the tile height is a template parame
 // stores>` into a 12-byte + a 4-byte store (it sinks the common scalar stores of the two branches), and a float4 of alignment 4
 // likewise; the fused kernel's tail is store-issue bound (switching its stores off takes it from 0.75 to 0.40 ms per batch), so
 // the instruction is written out.  gfx950 global memory accesses only need dword alignment.
+// The `s_nop 1` belongs to the store: a VMEM store of more than 8 bytes reads its data registers late, and a VALU write to them
+// within the next 2 wait states corrupts the last dword(s) (the compiler inserts this wait for its own stores, it does not look
+// inside inline assembly; without it the .w of a float4 was occasionally the next iteration's value).
 __device__ __forceinline__ void store_f4(float *p, float x, float y, float z, float w) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   const v4f q = {x, y, z, w};
-  asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(q) : "memory");
 }
 __device__ __forceinline__ void store_f4_nt(float *p, float x, float y, float z, float w) {   // streaming (non-temporal) form
   typedef float v4f __attribute__((ext_vector_type(4)));
   const v4f q = {x, y, z, w};
-  asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(q) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(q) : "memory");
 }
 
 // STAGE = true: the input tile (ROWS x (FB_TW + 8*R4) pixels) is first brought into LDS with one coalesced, non-redundant

@@ -243,3 +243,42 @@ def test_cli_pre_extracted_text_keypoint_files(pkg, tmp_path):
     p = subprocess.run([MODS, G1, G6, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", "0", "H.txt"] + cfgs + ["1"],
                        cwd=tmp_path, env=env, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 1 and b"k1.txt" in p.stderr
+
+
+def test_cli_dog_and_harris_detectors_next_to_hessian(pkg, tmp_path):
+    """[DoG0] + [HessianAffine0], then [HarrisAffine1] (not in SeparateDetectors: described, not matched) + [HessianAffine1]:
+    the command line against the library's multi-detector ladder; keypoint files list the detectors in name order."""
+    import torch
+    err = _run(tmp_path, "iters_two_detectors.ini")
+    a, b = _grey(G1), _grey(G6)
+    h, w = a.shape
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    reps1 = [pkg.ImgRep(ctx, 1 << 20) for _ in range(3)]
+    reps2 = [pkg.ImgRep(ctx, 1 << 20) for _ in range(3)]
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(4242)
+    one = pkg.LadderStep.make((1,), 360.0)
+    harris = pkg.LadderStep.make((1,), 360.0, fginn=-1.0)
+    harris.fginn_ratio_half = -1.0
+    det_steps = [[one, None], [None, harris], [one, pkg.LadderStep.make((1, 2), 360.0)]]
+    res, m = pkg.match_ladder_dets_dev(ctx, t.data_ptr(), w, h, det_steps,
+                                       [pkg.HessAffParams.dog(), pkg.HessAffParams.harris(), pkg.HessAffParams.default()],
+                                       reps1, reps2, min_matches=100000, max_matches=1 << 20)
+    pkg.ransac_pin_seed(-1)
+    got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    assert len(got) == res.n_inliers > 15
+    assert np.allclose(got, m, rtol=1e-5, atol=1e-3)
+    log = (tmp_path / "log.txt").read_text().split()
+    assert [int(log[1]), int(log[2]), int(log[6])] == [res.n_inliers, res.n_unique, 2]
+    lines = (tmp_path / "k1.txt").read_text().splitlines()
+    assert lines[0] == "3" and lines[1] == "DoG 1" and lines[2] == "RootSIFT %d" % len(reps1[0])
+    at = 4 + len(reps1[0])
+    assert lines[at] == "HarrisAffine 1" and lines[at + 1] == "RootSIFT %d" % len(reps1[1])
+    at += 3 + len(reps1[1])
+    assert lines[at] == "HessianAffine 1" and lines[at + 1] == "RootSIFT %d" % len(reps1[2])
+    assert min(len(r) for r in reps1) > 100
+    for r in reps1 + reps2:
+        r.close()
+    ctx.close()
