@@ -257,6 +257,11 @@ int mods_gauss_blur_xy(mods_ctx *ctx, const float *src, int w, int h, int kx, in
 int mods_match_fginn(mods_ctx *ctx, const mods_region *q, int n_q, const mods_region *t, int n_t, double ratio,
                      double contradDist, int nn, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out);
 /* same, on the HBM-resident region lists of images img_q / img_t left by mods_detect_describe_dev */
+/* MatchFLANNDistance (matching/matching.cpp:572-633) with binary_dist = Hamming (io_mods.cpp:365) and an exact index: the
+ * nearest train of every query by Hamming distance over the 128 descriptor bytes is a tentative when the distance is at most
+ * (int)(float)threshold; d1, d2 = the two smallest distances (ties by train index), ratio = d1 / d2. */
+int mods_match_distance(mods_ctx *ctx, const mods_region *q, int n_q, const mods_region *t, int n_t, double threshold,
+                        mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out);
 int mods_match_dev(mods_ctx *ctx, int img_q, int img_t, double ratio, double contradDist, int nn, mods_tentative *out,
                    double *u6_out, double *laf_out, int max_out, int *n_out);
 
@@ -392,6 +397,9 @@ typedef struct mods_ladder_step {     /* one [HessianAffine<i>] section of the i
   double fginn_ratio_half;            /* FGINNThreshold of HalfRootSIFT; 0: not described / not matched.  [Matching<i>]
                                          SeparateDescriptors = RootSIFT,HalfRootSIFT: both lists are matched and joined,
                                          HalfRootSIFT first (the bank's key order, correspondencebank.cpp:114-148, 288-340) */
+  double dist_threshold;              /* DistanceThreshold of RootSIFT / of HalfRootSIFT: > 0 runs MatchFLANNDistance (nearest by */
+  double dist_threshold_half;         /* Hamming distance within the threshold, matching.cpp:572-633), whose tentatives REPLACE the
+                                         FGINN ones of that descriptor (it clears the list it appends to) */
 } mods_ladder_step;
 typedef struct mods_ladder_result {
   int steps_done, n_views;            /* steps executed; views synthesised (both images) */

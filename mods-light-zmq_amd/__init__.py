@@ -354,6 +354,19 @@ class Context:
         self.last_laf = laf[:n.value].copy()
         return out[:n.value].copy(), u6[:n.value].copy()
 
+    def match_distance(self, q, t, threshold):
+        """MatchFLANNDistance (matching.cpp:572-633): nearest train by Hamming distance, kept within the threshold."""
+        q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+        cap = max(len(q), 1)
+        out = np.zeros(cap, TENT_DTYPE)
+        u6 = np.zeros((cap, 6), np.float64)
+        laf = np.zeros((cap, 14), np.float64)
+        n = C.c_int()
+        _check(lib().mods_match_distance(self.h, q.ctypes.data_as(C.c_void_p), len(q), t.ctypes.data_as(C.c_void_p), len(t),
+                                         C.c_double(threshold), out.ctypes.data_as(C.c_void_p),
+                                         u6.ctypes.data_as(C.c_void_p), laf.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy(), u6[:n.value].copy()
+
     def match_dev(self, img_q, img_t, ratio=0.8, contrad=10.0, nn=50, cap=1 << 18):
         out = np.zeros(cap, TENT_DTYPE)
         u6 = np.zeros((cap, 6), np.float64)
@@ -514,10 +527,11 @@ class LadderStep(C.Structure):
     """One [HessianAffine<i>] section of an iterations .ini (io_mods.cpp:457-492)."""
     _fields_ = [("scale_set", C.c_double * 8), ("n_scales", C.c_int), ("tilt_set", C.c_double * 8), ("n_tilts", C.c_int),
                 ("phi", C.c_double), ("initSigma", C.c_double), ("doBlur", C.c_int), ("fginn_ratio", C.c_double),
-                ("half_orientation", C.c_int), ("fginn_ratio_half", C.c_double)]
+                ("half_orientation", C.c_int), ("fginn_ratio_half", C.c_double), ("dist_threshold", C.c_double),
+                ("dist_threshold_half", C.c_double)]
 
     @staticmethod
-    def make(tilts, phi, scales=(1.0,), init_sigma=0.2, do_blur=1, fginn=0.8, half_orientation=0, fginn_half=0.0):
+    def make(tilts, phi, scales=(1.0,), init_sigma=0.2, do_blur=1, fginn=0.8, half_orientation=0, fginn_half=0.0, dist=0.0, dist_half=0.0):
         """half_orientation: the step's descriptor list names a Half* descriptor; fginn_half > 0: HalfRootSIFT lists are built and
         matched too (SeparateDescriptors = RootSIFT,HalfRootSIFT)."""
         s = LadderStep()
@@ -527,6 +541,7 @@ class LadderStep(C.Structure):
             s.tilt_set[i] = v
         s.n_scales, s.n_tilts, s.phi, s.initSigma, s.doBlur, s.fginn_ratio = len(scales), len(tilts), phi, init_sigma, do_blur, fginn
         s.half_orientation, s.fginn_ratio_half = half_orientation, fginn_half
+        s.dist_threshold, s.dist_threshold_half = dist, dist_half     # DistanceThreshold: MatchFLANNDistance replaces the FGINN list
         return s
 
 

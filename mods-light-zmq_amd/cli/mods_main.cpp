@@ -199,8 +199,10 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
       for (size_t k = 0; k < scales.size(); k++) st.scale_set[k] = scales[k];
       const std::vector<std::string> descs = it.GetStringVector(sec, "Descriptors");
       const std::vector<double> fginn = it.GetDoubleVector(sec, "FGINNThreshold");
+      // DistanceThreshold, same order: > 0 runs MatchFLANNDistance on that descriptor's lists (correspondencebank.cpp:320-334)
+      const std::vector<double> dthr = it.Has(sec, "DistanceThreshold") ? it.GetDoubleVector(sec, "DistanceThreshold") : std::vector<double>();
       bool has_root = false, has_zmq = false;
-      double zmq_ratio = 0;
+      double zmq_ratio = 0, zmq_dist = 0;
       for (size_t k = 0; k < descs.size(); k++) {
         std::string name = descs[k];
         name.erase(0, name.find_first_not_of(" \t"));
@@ -208,9 +210,10 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
         // a "Half*" name anywhere in the list switches the step's orientation estimate to doHalfSIFT mode for every descriptor
         // (imagerepresentation.cpp:725-731)
         if (name.find("Half") != std::string::npos) st.half_orientation = 1;
-        if (name == "RootSIFT") { has_root = true; st.fginn_ratio = k < fginn.size() ? fginn[k] : 0.0; }
-        else if (name == "ZMQ") { has_zmq = true; zmq_ratio = k < fginn.size() ? fginn[k] : 0.0; }
+        if (name == "RootSIFT") { has_root = true; st.fginn_ratio = k < fginn.size() ? fginn[k] : 0.0; st.dist_threshold = k < dthr.size() ? dthr[k] : 0.0; }
+        else if (name == "ZMQ") { has_zmq = true; zmq_ratio = k < fginn.size() ? fginn[k] : 0.0; zmq_dist = k < dthr.size() ? dthr[k] : 0.0; }
         else if (name == "HalfRootSIFT") {
+          st.dist_threshold_half = k < dthr.size() ? dthr[k] : 0.0;
           // the reference indexes FGINNThreshold by the descriptor's position without a bounds check (synth-detection.cpp:221):
           // a missing entry is read past the end of the vector; it counts as 0 = "not matched" here
           if (k < fginn.size()) st.fginn_ratio_half = fginn[k];
@@ -229,14 +232,15 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
           root_listed = root_listed || name == "RootSIFT" || name == "ZMQ";
           half_listed = half_listed || name == "HalfRootSIFT";
         }
-        if (!half_listed) st.fginn_ratio_half = st.fginn_ratio_half > 0 ? -1.0 : 0.0;   // built as the step asks, its list is left alone
+        if (!half_listed) { st.fginn_ratio_half = st.fginn_ratio_half > 0 ? -1.0 : 0.0; st.dist_threshold_half = 0.0; }   // its list is left alone
         if (!root_listed && has_root) std::cerr << "Warning: " << msec << ": SeparateDescriptors does not list the step's descriptor; it is matched anyway" << std::endl;
       }
       if (has_zmq && !has_root) {      // the daemon's descriptor takes the place of RootSIFT for the whole run
-        cfg->use_zmq = true; has_root = true; st.fginn_ratio = zmq_ratio;
+        cfg->use_zmq = true; has_root = true; st.fginn_ratio = zmq_ratio; st.dist_threshold = zmq_dist;
       } else if (has_zmq) std::cerr << "Warning: " << sec << ": RootSIFT and ZMQ in one step: RootSIFT is used" << std::endl;
       if (!has_root) { std::cerr << "Warning: " << sec << " does not ask for RootSIFT; the step is skipped" << std::endl; st.n_tilts = st.n_scales = -1; }
-      else if (!(st.fginn_ratio > 0 && st.fginn_ratio < 1)) { std::cerr << sec << ": FGINNThreshold of RootSIFT must lie in (0, 1)" << std::endl; return 1; }
+      else if (!(st.fginn_ratio > 0 && st.fginn_ratio < 1) && !(st.dist_threshold > 0)) { std::cerr << sec << ": FGINNThreshold of RootSIFT must lie in (0, 1)" << std::endl; return 1; }
+      if (st.dist_threshold < 0 || st.dist_threshold_half < 0) { std::cerr << sec << ": DistanceThreshold must be >= 0" << std::endl; return 1; }
     } else st.n_tilts = st.n_scales = -1;      // no views of this detector in this step
     if (st.n_tilts >= 0 && have_sep_det && std::find(sep_det.begin(), sep_det.end(), det_name) == sep_det.end() &&
         std::find(sep_det.begin(), sep_det.end(), std::string("All")) == sep_det.end()) {
@@ -244,6 +248,7 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
       st.fginn_ratio = -1.0;
       if (st.fginn_ratio_half > 0) st.half_orientation = 1;   // still described in doHalfSIFT mode
       st.fginn_ratio_half = -1.0;
+      st.dist_threshold = st.dist_threshold_half = 0.0;
     }
     all[di].push_back(st);
   }

@@ -428,6 +428,21 @@ int mods_match_fginn(mods_ctx *c, const mods_region *q, int n_q, const mods_regi
   return mods_match_fetch_internal(c, out, u6_out, laf_out, max_out, n_out);
 }
 
+// MatchFLANNDistance (matching.cpp:572-633): nearest neighbour by Hamming distance over the descriptor bytes, kept when the
+// distance is at most (int)(float)threshold; exact search
+int mods_match_distance(mods_ctx *c, const mods_region *q, int n_q, const mods_region *t, int n_t, double threshold,
+                        mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out) {
+  if (!c || !n_out || (n_q > 0 && !q) || (n_t > 0 && !t)) { set_error("match: null argument"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc = match_ensure_buffers(c);
+  if (rc) return rc;
+  if (n_q > c->max_cand || n_t > c->max_cand) { set_error("match: list larger than the context capacity"); return MODS_E_CAPACITY; }
+  MODS_HIP_CHECK(hipMemcpyAsync(c->m_regs, q, sizeof(mods_region) * n_q, hipMemcpyHostToDevice, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(c->m_regs + c->max_cand, t, sizeof(mods_region) * n_t, hipMemcpyHostToDevice, c->stream));
+  if ((rc = match_run_distance(c, c->m_regs, n_q, c->m_regs + c->max_cand, n_t, threshold))) return rc;
+  return mods_match_fetch_internal(c, out, u6_out, laf_out, max_out, n_out);
+}
+
 int mods_match_dev(mods_ctx *c, int img_q, int img_t, double ratio, double contradDist, int nn, mods_tentative *out,
                    double *u6_out, double *laf_out, int max_out, int *n_out) {
   if (!c || !n_out) { set_error("match: null argument"); return MODS_E_ARG; }
@@ -724,6 +739,30 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const unsigned char *__r
 // over n pairs), then every pair is matched on its own.  img[i]: [2][h][w] of pair i; kinds[i] (NULL = all 0):
 // 0 fp32 in HBM, 1 fp32 in (pinned) host memory, 2 8-bit grey in (pinned) host memory - host images are uploaded on
 // the context's stream, so the transfer of one worker overlaps the kernels of the others.
+// One batch of a synthetic blob lattice through detect / describe and one match: allocates every pool a batch of n_img
+// images of w x h needs (they are sized by the geometry and the context's capacities) and loads every kernel of the path.
+int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_pair_params *par) {
+  if (!c || !par || n_img < 1 || n_img > c->batch) { set_error("warmup: bad argument"); return MODS_E_ARG; }
+  if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("warmup: image larger than the context"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  if (!c->u8_stage_dev) MODS_HIP_CHECK(hipMalloc(&c->u8_stage_dev, (size_t)c->max_w * c->max_h * c->batch + 16));
+  std::vector<float> img((size_t)w * h);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++)   // blobs every 14 px on top of blobs every 90 px: a few thousand regions of both patch tiers
+      img[(size_t)y * w + x] = 128.f + 70.f * sinf(0.22f * x) * sinf(0.22f * y) + 50.f * sinf(0.035f * x + 1.f) * sinf(0.035f * y);
+  const size_t plane = (size_t)w * h;
+  MODS_HIP_CHECK(hipMemcpy(c->input_dev, img.data(), sizeof(float) * plane, hipMemcpyHostToDevice));
+  for (int i = 1; i < n_img; i++)
+    MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev + plane * i, c->input_dev, sizeof(float) * plane, hipMemcpyDeviceToDevice, c->stream));
+  std::vector<int> nd(n_img), nr(n_img);
+  int rc = mods_detect_describe_dev(c, c->input_dev, n_img, w, h, w, &par->det, &par->desc, nd.data(), nr.data());
+  if (rc) return rc;
+  const int last = n_img - 1;
+  if ((rc = match_run(c, c->regions_dev, nr[0], c->regions_dev + (size_t)last * c->max_cand, nr[last], par->fginn_ratio, par->contradDist, par->nn))) return rc;
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return MODS_OK;
+}
+
 int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, int n_pairs, int w, int h, const mods_pair_params *par,
                          mods_pair_result **res, std::vector<mods_tentative> **tent, std::vector<double> **u6, std::vector<double> **laf) {
   if (!c || !img || !par || !res || n_pairs < 1) { set_error("match_pairs: null argument"); return MODS_E_ARG; }

@@ -176,6 +176,7 @@ int detect_run(mods_ctx *ctx);       // NMS -> localise -> dedup -> Baumberg -> 
 // match.hip
 int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double ratio,
               double contradDist, int nn);
+int match_run_distance(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double threshold);   // MatchFLANNDistance, Hamming
 int match_ensure_buffers(mods_ctx *ctx);
 
 // describe.hip

@@ -208,11 +208,14 @@ static void copy_verified(mods_ctx *c, const mods_ladder_result *res, double *ma
 // One FGINN search of bank q against bank t into a host list (MatchFlannFGINN of one (detector, descriptor) pair,
 // correspondencebank.cpp:288-340)
 struct TentList { std::vector<mods_tentative> t; std::vector<double> u6, laf; void clear() { t.clear(); u6.clear(); laf.clear(); } };
-static int match_into(mods_ctx *c, mods_imgrep *q, mods_imgrep *t, double ratio, const mods_pair_params *par, TentList *out) {
+// distance > 0: MatchFLANNDistance (Hamming, threshold `distance`) instead of the FGINN search
+static int match_into(mods_ctx *c, mods_imgrep *q, mods_imgrep *t, double ratio, const mods_pair_params *par, TentList *out, double distance = 0) {
   int rc, m = 0;
   out->clear();
   if (!q || !t) return MODS_OK;
-  if ((rc = match_run(c, q->reg, q->n, t->reg, t->n, ratio, par->contradDist, par->nn))) return rc;
+  if (distance > 0) rc = match_run_distance(c, q->reg, q->n, t->reg, t->n, distance);
+  else rc = match_run(c, q->reg, q->n, t->reg, t->n, ratio, par->contradDist, par->nn);
+  if (rc) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(&m, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (m > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
@@ -298,7 +301,7 @@ int mods_match_ladder_dets_dev(mods_ctx *c, const float *img1_dev, int w1, int h
                                         (int)pd[d].hist.size(), views.data(), (int)views.size());
       if (nv < 0) return nv;
       new_views[d] = nv;
-      const bool want_half = st.fginn_ratio_half > 0;
+      const bool want_half = st.fginn_ratio_half > 0 || st.dist_threshold_half > 0;
       if (want_half && !pd[d].h1) {
         if ((rc = mods_imgrep_create(c, reps1[d]->cap, &pd[d].h1))) return rc;
         if ((rc = mods_imgrep_create(c, reps2[d]->cap, &pd[d].h2))) return rc;
@@ -332,13 +335,17 @@ int mods_match_ladder_dets_dev(mods_ctx *c, const float *img1_dev, int w1, int h
     for (int d = 0; d < n_det; d++) {
       const mods_ladder_step &st = steps[(size_t)step * n_det + d];
       if (st.n_tilts < 0 || st.n_scales < 0 || new_views[d] == 0) continue;
+      // (a descriptor with a DistanceThreshold: MatchFLANNDistance runs after MatchFlannFGINN and clears the list it is
+      // given, so its tentatives replace the FGINN ones, correspondencebank.cpp:328-334, matching.cpp:585)
       if (st.fginn_ratio >= 0) {
         lists[0][d].clear();
-        if (st.fginn_ratio > 0 && (rc = match_into(c, reps1[d], reps2[d], st.fginn_ratio, par, &lists[0][d]))) return rc;
+        if (st.dist_threshold > 0) { if ((rc = match_into(c, reps1[d], reps2[d], 0, par, &lists[0][d], st.dist_threshold))) return rc; }
+        else if (st.fginn_ratio > 0 && (rc = match_into(c, reps1[d], reps2[d], st.fginn_ratio, par, &lists[0][d]))) return rc;
       }
       if (st.fginn_ratio_half >= 0) {
         lists[1][d].clear();
-        if (st.fginn_ratio_half > 0 && (rc = match_into(c, pd[d].h1, pd[d].h2, st.fginn_ratio_half, par, &lists[1][d]))) return rc;
+        if (st.dist_threshold_half > 0 && pd[d].h1) { if ((rc = match_into(c, pd[d].h1, pd[d].h2, 0, par, &lists[1][d], st.dist_threshold_half))) return rc; }
+        else if (st.fginn_ratio_half > 0 && (rc = match_into(c, pd[d].h1, pd[d].h2, st.fginn_ratio_half, par, &lists[1][d]))) return rc;
       }
     }
     gather_tentatives(c, lists);

@@ -32,6 +32,7 @@ struct MatchConst {
   int nn;
   double sqminratio, contr_sq;
   int tiles_per_split;
+  int max_distance;       // >= 0: MatchFLANNDistance (Hamming) decisions in the emit stage; -1: FGINN
 };
 
 // Packs one region list for the matcher: int8 descriptors (v-128), c = sum v^2 - 256*sum(v-128),
@@ -458,6 +459,15 @@ __device__ __forceinline__ bool fginn_accept(const MatchConst &k, int j, const Q
                                              const unsigned long long *__restrict__ key_ge, const unsigned long long *__restrict__ key_lt,
                                              const int *__restrict__ n_lt, const int *__restrict__ bad, mods_tentative *tc) {
   if (j >= k.n_q) return false;
+  if (k.max_distance >= 0) {   // MatchFLANNDistance, matching.cpp:612-627: mid = nearest, key_ge = second nearest
+    const QueryMid m = mid[j];
+    if (m.d0 > k.max_distance) return false;
+    const unsigned long long k2 = key_ge[j];
+    tc->q = j; tc->t = m.i0; tc->t_bad = tc->t_2nd = (int)(unsigned int)k2;
+    tc->d1 = (float)m.d0; tc->d2 = tc->d2nd = (float)(int)(k2 >> 32); tc->pad = 0;
+    tc->ratio = (double)tc->d1 / (double)tc->d2;
+    return true;
+  }
   const int K = min(k.nn, k.n_t);
   const unsigned long long kg = key_ge[j];
   const int c = n_lt[j];
@@ -569,6 +579,7 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   if (n_q > ctx->max_cand || n_t > ctx->max_cand) { set_error("match: list larger than the context capacity"); return MODS_E_CAPACITY; }
   MatchConst k;
   k.n_q = n_q; k.n_t = n_t; k.nn = nn;
+  k.max_distance = -1;
   k.sqminratio = ratio * ratio;
   k.contr_sq = contradDist * contradDist;
   if (!(k.sqminratio < 1.0)) { set_error("FGINN ratio >= 1 (all-neighbours mode) is not supported"); return MODS_E_ARG; }
@@ -618,6 +629,78 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
     hipLaunchKernelGGL(match_fginn_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd2, qcs, td, tc, tc2, tpar, txy,
                        (const QueryMid *)mid2, key_ge, key_lt, n_lt, bad, count2, list2);
   }
+  const int eblocks = (n_q + 1023) / 1024;
+  int *block_counts = (int *)(ctx->m_int + 2 * n);
+  hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, ctx->m_tent, ctx->m_u6, ctx->m_laf, ctx->m_count, ctx->max_cand);
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// MatchFLANNDistance (matching.cpp:572-633) with the default binary_dist = Hamming and an exact (linear) index: the two
+// nearest trains of every query by Hamming distance over the 128 descriptor bytes, ascending distance then ascending index
+// (FLANN's KNNSimpleResultSet over a linear scan).  The packed lists hold v - 128 per byte; the XOR of two such bytes is
+// the XOR of the values.  Thread = query (32 dwords in registers), the block walks the trains in LDS tiles of 64.
+// grid = ceil(n_q / 256), block = 256
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hamming_nn2_kernel(MatchConst k, const int8_t *__restrict__ qd, const int8_t *__restrict__ td,
+                                                          QueryMid *__restrict__ mid, unsigned long long *__restrict__ key2) {
+  __shared__ uint32_t s_t[64][33];   // 33: the per-thread walk over a row is conflict free, the staging is coalesced
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  uint32_t q[32];
+  const uint32_t *qp = (const uint32_t *)(qd + (size_t)min(j, k.n_q - 1) * 128);
+#pragma unroll
+  for (int e = 0; e < 32; e++) q[e] = qp[e];
+  unsigned long long k1 = ~0ull, k2 = ~0ull;
+  for (int t0 = 0; t0 < k.n_t; t0 += 64) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+      const int r = e >> 5, c = e & 31;
+      s_t[r][c] = t0 + r < k.n_t ? ((const uint32_t *)(td + (size_t)(t0 + r) * 128))[c] : 0u;
+    }
+    __syncthreads();
+    const int nt = min(64, k.n_t - t0);
+    for (int r = 0; r < nt; r++) {
+      int d = 0;
+#pragma unroll
+      for (int e = 0; e < 32; e++) d += __popc(q[e] ^ s_t[r][e]);
+      const unsigned long long key = ((unsigned long long)(unsigned int)d << 32) | (unsigned int)(t0 + r);
+      if (key < k1) { k2 = k1; k1 = key; }
+      else if (key < k2) k2 = key;
+    }
+  }
+  if (j < k.n_q) {
+    QueryMid m;
+    m.i0 = (int)(unsigned int)k1; m.d0 = (int)(k1 >> 32); m.dstar = 0; m.pad = 0; m.x0 = 0; m.y0 = 0;
+    mid[j] = m;
+    key2[j] = k2 == ~0ull ? (((unsigned long long)2147483647u << 32) | 0xffffffffull) : k2;   // a single train: distance INT_MAX, index -1
+  }
+}
+
+int match_run_distance(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double threshold) {
+  int rc = match_ensure_buffers(ctx);
+  if (rc) return rc;
+  if (n_q > ctx->max_cand || n_t > ctx->max_cand) { set_error("match: list larger than the context capacity"); return MODS_E_CAPACITY; }
+  MatchConst k;
+  memset(&k, 0, sizeof(k));
+  k.n_q = n_q; k.n_t = n_t; k.nn = 2;
+  k.max_distance = (int)(float)threshold;                       // int max_distance = (int)float(par.matchDistanceThreshold)
+  if (k.max_distance < 0) { set_error("match: negative distance threshold"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_count, 0, sizeof(int), ctx->stream));
+  if (n_q == 0 || n_t == 0) return MODS_OK;
+  const size_t n = match_pad(ctx);
+  int8_t *qd = ctx->m_desc, *td = ctx->m_desc + n * 128;
+  int *qc = ctx->m_c, *tc = ctx->m_c + n, *qc2 = ctx->m_c + 2 * n, *tc2 = ctx->m_c + 3 * n;
+  unsigned int *qpar = (unsigned int *)(ctx->m_c + 4 * n), *tpar = qpar + n / 32 + 2;
+  MODS_HIP_CHECK(hipMemsetAsync(qpar, 0, sizeof(unsigned int) * 2 * (n / 32 + 2), ctx->stream));
+  double2 *qxy = (double2 *)ctx->m_xy, *txy = (double2 *)ctx->m_xy + n;
+  unsigned long long *key_ge = ctx->m_u64 + n, *key_lt = ctx->m_u64 + 2 * n;
+  int *n_lt = ctx->m_int, *bad = ctx->m_int + n;
+  StageScope ts(ctx, MODS_STAGE_MATCH);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
+  hipLaunchKernelGGL(hamming_nn2_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, qd, td, (QueryMid *)ctx->m_mid, key_ge);
   const int eblocks = (n_q + 1023) / 1024;
   int *block_counts = (int *)(ctx->m_int + 2 * n);
   hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);

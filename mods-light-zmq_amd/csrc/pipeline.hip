@@ -46,12 +46,30 @@ struct mods_pipeline {
   int max_in_flight = 8;
   int pairs_per_batch = 1;        // pairs a GPU worker pushes through detect/describe in one batch of launches
   bool stop = false;
+  int ready = 0, warm_rc = MODS_OK;   // workers that finished their warm-up (mods_pipeline_create_ex waits for all of them)
+  std::string warm_err;
+  std::condition_variable cv_ready;
 };
 
 using namespace mods;
 
+extern "C" int mods_ransac_warmup(int device, int len);
+extern "C" int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_pair_params *par);
+
+static void worker_ready(mods_pipeline *p, int rc) {
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (rc && p->warm_rc == MODS_OK) { p->warm_rc = rc; p->warm_err = mods_last_error(); }
+    p->ready++;
+  }
+  p->cv_ready.notify_all();
+}
+
 static void gpu_worker(mods_pipeline *p, mods_ctx *ctx) {
   (void)hipSetDevice(p->device);
+  // every pool a full batch needs (pyramid planes, candidate / region / matcher buffers, code objects) is allocated now: a
+  // hipMalloc inside the running pipeline synchronises the whole device
+  worker_ready(p, mods_ctx_warmup(ctx, 2 * p->pairs_per_batch, p->w, p->h, &p->par));
   for (;;) {
     std::vector<std::shared_ptr<Job>> js;
     {
@@ -80,6 +98,7 @@ static void gpu_worker(mods_pipeline *p, mods_ctx *ctx) {
 
 static void verify_worker(mods_pipeline *p) {
   (void)hipSetDevice(p->device);
+  worker_ready(p, mods_ransac_warmup(p->device, 16384));   // this thread's scoring stream and workspace
   for (;;) {
     std::shared_ptr<Job> j;
     {
@@ -149,6 +168,17 @@ int mods_pipeline_create_ex(int device, int w, int h, const mods_pair_params *pa
   }
   for (int i = 0; i < gpu_workers; i++) p->gpu_threads.emplace_back(gpu_worker, p.get(), p->ctxs[i]);
   for (int i = 0; i < verify_workers; i++) p->verify_threads.emplace_back(verify_worker, p.get());
+  {
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_ready.wait(lk, [&] { return p->ready == gpu_workers + verify_workers; });
+  }
+  if (p->warm_rc) {
+    const int rc = p->warm_rc;
+    const std::string err = p->warm_err;
+    mods_pipeline_destroy(p.release());
+    set_error("pipeline warm-up: %s", err.c_str());
+    return rc;
+  }
   *out = p.release();
   return MODS_OK;
 }

@@ -280,6 +280,18 @@ void mods_test_glibc_rand(unsigned seed, int n, int *out) {
   for (int i = 0; i < n; i++) out[i] = g.next();
 }
 
+// creates the calling thread's scoring stream and workspace for correspondence lists up to `len` (what the first
+// exp_ransac*custom call of a thread would otherwise do, with its hipMallocs, in the middle of a running pipeline)
+int mods_ransac_warmup(int device, int len) {
+  mods_ransac_set_device(device);
+  RansacGpu *ws = ransac_gpu();
+  if (!ws) return MODS_E_NODEVICE;
+  if (!ransac_ws_reserve(ws, len > 0 ? len : 1, 64)) return MODS_E_HIP;
+  hipLaunchKernelGGL(ransac_gain_kernel, dim3(1), dim3(256), 0, ws->stream, ws->gain_dev, 0, 0, ws->hyp_cap, ws->J_dev);   // loads the code object
+  if (hipStreamSynchronize(ws->stream) != hipSuccess) { set_error("ransac warm-up failed"); return MODS_E_HIP; }
+  return MODS_OK;
+}
+
 int mods_ransac_set_device(int device) { std::lock_guard<std::mutex> lk(g_cfg_mutex); g_ransac_device = device; return MODS_OK; }
 // seed >= 0: every call behaves as if time(NULL) returned `seed`; < 0: back to the wall clock
 void mods_ransac_pin_seed(long seed) { std::lock_guard<std::mutex> lk(g_cfg_mutex); g_pinned_seed = seed; }

@@ -406,6 +406,17 @@ int orc_match_fginn(const orc_region *q, int nq, const orc_region *t, int nt, do
   }
   return (int)tc.size();
 }
+int orc_match_distance(const orc_region *q, int nq, const orc_region *t, int nt, double threshold, orc_tentative *out, int max_out) {
+  std::vector<Region> a, b; to_regions(q, nq, a); to_regions(t, nt, b);
+  std::vector<Tentative> tc;
+  match_distance(a, b, tc, threshold);
+  for (size_t i = 0; i < tc.size() && (int)i < max_out; i++) {
+    orc_tentative &o = out[i];
+    o.q = tc[i].q; o.t = tc[i].t; o.t_bad = tc[i].t_bad; o.t_2nd = tc[i].t_2nd; o.d1 = tc[i].d1; o.d2 = tc[i].d2;
+    o.d2nd = tc[i].d2nd; o.pad = 0; o.ratio = tc[i].ratio;
+  }
+  return (int)tc.size();
+}
 int orc_duplicate_filter(orc_tentative *tcs, int n, const orc_region *q, int nq, const orc_region *t, int nt, double r,
                          int mode) {
   std::vector<Region> a, b; to_regions(q, nq, a); to_regions(t, nt, b);

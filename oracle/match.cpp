@@ -68,6 +68,40 @@ int match_fginn(const std::vector<Region> &list1, const std::vector<Region> &lis
   return (int)out.size();
 }
 
+// MatchFLANNDistance, matching.cpp:572-633, with [Matching] binary_matcher = linear and binary_dist = Hamming (the default,
+// io_mods.cpp:365): the descriptor bytes (floor of the stored values) of list1 against list2, the two nearest by Hamming
+// distance - ascending distance, ties by ascending train index, as FLANN's KNNSimpleResultSet orders a linear scan - and a
+// tentative for every query whose nearest lies within max_distance = (int)float(matchDistanceThreshold):
+// d1, d2 = the two distances, ratio = d1 / d2 in double.  With a single train the reference reads a distance FLANN never
+// wrote; it is INT_MAX (index -1) here.  The function clears the list it is given, so it REPLACES what MatchFlannFGINN put
+// there when a descriptor has both thresholds (correspondencebank.cpp:328-334).
+int match_distance(const std::vector<Region> &list1, const std::vector<Region> &list2, std::vector<Tentative> &out, double matchDistanceThreshold) {
+  out.clear();
+  const int max_distance = (int)float(matchDistanceThreshold);
+  if (list1.empty() || list2.empty()) return 0;
+  for (size_t i = 0; i < list1.size(); i++) {
+    long long k1 = -1, k2 = -1;   // (distance << 32) | index, smallest two
+    for (size_t j = 0; j < list2.size(); j++) {
+      int d = 0;
+      for (int b = 0; b < 128; b++) d += __builtin_popcount((unsigned)(list1[i].desc[b] ^ list2[j].desc[b]));
+      const long long key = ((long long)d << 32) | (long long)j;
+      if (k1 < 0 || key < k1) { k2 = k1; k1 = key; }
+      else if (k2 < 0 || key < k2) k2 = key;
+    }
+    const int d1 = (int)(k1 >> 32);
+    if (d1 <= max_distance) {
+      Tentative tc;
+      tc.q = (int)i; tc.t = (int)(k1 & 0xffffffffll);
+      const int d2 = k2 < 0 ? 2147483647 : (int)(k2 >> 32);
+      tc.t_bad = tc.t_2nd = k2 < 0 ? -1 : (int)(k2 & 0xffffffffll);
+      tc.d1 = (float)d1; tc.d2 = (float)d2; tc.d2nd = (float)d2;
+      tc.ratio = (double)tc.d1 / (double)tc.d2;
+      out.push_back(tc);
+    }
+  }
+  return (int)out.size();
+}
+
 // DuplicateFiltering, matching.cpp:2615-2679.  mode 1 = MODE_FGINN (sort by ratio), 2 =
 // MODE_DISTANCE (sort by d1), 0 = MODE_RANDOM (keep order).  std::sort is unstable on equal
 // keys; ties are fixed here as list order (stable sort).

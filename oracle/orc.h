@@ -150,6 +150,7 @@ struct Tentative {
 };
 int match_fginn(const std::vector<Region> &q, const std::vector<Region> &t, std::vector<Tentative> &out,
                 double ratio, double contradDist, int nn);                   // matching.cpp:356-460
+int match_distance(const std::vector<Region> &q, const std::vector<Region> &t, std::vector<Tentative> &out, double matchDistanceThreshold);   // matching.cpp:572-633
 void duplicate_filter(std::vector<Tentative> &tc, const std::vector<Region> &q,
                       const std::vector<Region> &t, double r, int mode);      // matching.cpp:2615-2679
 

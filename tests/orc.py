@@ -381,6 +381,15 @@ TENT_DTYPE = np.dtype([("q", "i4"), ("t", "i4"), ("t_bad", "i4"), ("t_2nd", "i4"
                        ("d2nd", "f4"), ("pad", "f4"), ("ratio", "f8")])
 
 
+def match_distance(q, t, threshold):
+    """MatchFLANNDistance (matching.cpp:572-633), Hamming distance, exact search."""
+    q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+    out = np.zeros(len(q) + 1, TENT_DTYPE)
+    n = lib().orc_match_distance(q.ctypes.data_as(C.c_void_p), len(q), t.ctypes.data_as(C.c_void_p), len(t),
+                                 C.c_double(threshold), out.ctypes.data_as(C.c_void_p), len(out))
+    return out[:n].copy()
+
+
 def match_fginn(q, t, ratio=0.8, contrad=10.0, nn=50):
     q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
     out = np.zeros(len(q) + 1, TENT_DTYPE)

@@ -212,7 +212,7 @@ def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=
     mode for every descriptor); ratio_half > 0: HalfRootSIFT lists are built and matched as a second separate descriptor.
     Every (descriptor, detector) pair keeps its own tentative list, re-made in the steps that bring new views of the detector
     (MatchImgReps, correspondencebank.cpp:286-340) and joined in the bank's key order - HalfRootSIFT before RootSIFT, then by
-    detector (GetCorresponcesVector, :114-148)."""
+    detector (GetCorresponcesVector, :114-148).  A detector dict may carry dist > 0 = DistanceThreshold of RootSIFT."""
     h, w = img1.shape
     if detectors is None:
         detectors = [dict(params=None, steps=list(steps), ratio=ratio, ratio_half=ratio_half, half_orientation=half_orientation)]
@@ -244,7 +244,10 @@ def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=
                 S["banks_h"][im] += [r[1] for r in regs if r is not None and want_half]
             if not views:
                 continue
-            if d.get("ratio", 0.8) > 0:
+            if d.get("dist", 0.0) > 0:      # MatchFLANNDistance replaces what MatchFlannFGINN found (it clears the list, matching.cpp:585)
+                ra, rb = np.concatenate(S["banks"][0]), np.concatenate(S["banks"][1])
+                S["tc"] = (orc.match_distance(ra, rb, d["dist"]), ra, rb)
+            elif d.get("ratio", 0.8) > 0:
                 ra, rb = np.concatenate(S["banks"][0]), np.concatenate(S["banks"][1])
                 S["tc"] = (match_fginn_par(ra, rb, d.get("ratio", 0.8)), ra, rb)
             if want_half:

@@ -114,3 +114,24 @@ def test_match_pair_and_dupfilter(gpu_ctx, pkg):
     err = np.hypot(p[:, 0] / p[:, 2] - fu[:, 3], p[:, 1] / p[:, 2] - fu[:, 4])
     assert (err < 3).mean() > 0.5
     ctx2.close()
+
+
+@pytest.mark.parametrize("nq,nt,seed", [(1, 1, 1), (1, 2, 2), (5, 3, 3), (65, 64, 4), (300, 257, 5), (1000, 1500, 6)])
+@pytest.mark.parametrize("threshold", [0.9, 260.0, 1024.0])
+def test_distance_matcher_hamming(gpu_ctx, nq, nt, seed, threshold):
+    """MatchFLANNDistance (matching.cpp:572-633): nearest by Hamming distance within (int)(float)threshold, ties by train
+    index, d2 = the second smallest distance - equal to the oracle on random lists with many ties (few distinct bytes)."""
+    q = _rand_regions(nq, seed)
+    t = _rand_regions(nt, seed + 100)
+    rng = np.random.default_rng(seed)
+    q["desc"] = rng.integers(0, 4, (nq, 128)).astype(np.uint8) * 85      # distances cluster: ties between trains are common
+    t["desc"] = rng.integers(0, 4, (nt, 128)).astype(np.uint8) * 85
+    if nt > 2:
+        t["desc"][nt // 2] = t["desc"][0]                                   # an exact duplicate train: index order decides
+    got, u6 = gpu_ctx.match_distance(q, t, threshold)
+    want = orc.match_distance(q, t, threshold)
+    _assert_tents_equal(got, want)
+    if len(want):
+        assert np.array_equal(u6[:, 0], q["x"][want["q"]]) and np.array_equal(u6[:, 3], t["x"][want["t"]])
+    if threshold >= 1024:
+        assert len(want) == nq

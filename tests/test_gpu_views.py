@@ -226,3 +226,29 @@ def test_ladder_with_two_detectors(pkg):
     for r in reps1 + reps2:
         r.close()
     ctx.close()
+
+
+def test_ladder_with_distance_threshold(pkg):
+    """DistanceThreshold > 0 for RootSIFT: the step's tentatives come from MatchFLANNDistance (Hamming nearest neighbour within
+    the threshold) instead of the FGINN search, then the same duplicate filter and RANSAC - against the oracle chain."""
+    import torch
+    import pipeline_oracle as po
+    import refdeg
+    if not refdeg.available():
+        pytest.skip("oracle/_ref not built")
+    w, h = 480, 360
+    a, b, Htrue = _hard_pair(w, h, seed=25)
+    dets = [dict(params=None, steps=[((1, 2), 360.0)], ratio=0.8, dist=330.0)]
+    want = po.match_ladder(a, b, None, seed_time=31, detectors=dets)
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    rep1, rep2 = pkg.ImgRep(ctx), pkg.ImgRep(ctx)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(31)
+    res, m = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, [pkg.LadderStep.make((1, 2), 360.0, dist=330.0)], rep1, rep2, max_matches=100000)
+    assert res.n_tentatives == want["n_tentatives"] > 100 and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"]
+    assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
+    rep1.close(); rep2.close(); ctx.close()
