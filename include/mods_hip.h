@@ -328,6 +328,8 @@ int mods_test_host_errfn(int type, const double *u6, int len, const double *H, i
 int mods_test_host_u2h(const double *u6, const int *inl, int n, int reference_form, double *H);
 int mods_test_host_cov(const double *u6, const int *inl, int n, int reference_form, double *Cv);
 int mods_test_host_inlidxs(const double *err, int len, double th, int lanes, int *inl, unsigned *I, double *J);
+/* the same for the epipolar error functions of the F-matrix path: mode 0 FDs, 1 FDsSym, 2 exFDs, 3 exFDsSym (Ftools.c:94-209) */
+int mods_test_host_fds(int mode, const double *u6, int len, const double *F, int lanes, double *p, double *w);
 /* self-test hooks of the host-side pieces of the F-matrix path (no device needed; they let the CPU
  * test-suite compare the restated solvers with the reference's own degensac build, oracle/_ref):
  *   seven_point : u7 = 7 correspondences (7 x 6) -> up to 3 matrices in F27, returns their number
@@ -338,6 +340,7 @@ int mods_test_host_inlidxs(const double *err, int len, double th, int lanes, int
  *   rfth        : plane-and-parallax search, generator seeded with `seed`, candidates counted on the host  [DegUtils.c:233-444] */
 int mods_test_seven_point(const double *u7, double *F27);
 void mods_test_u2f(const double *u, const int *idx, int n, const double *w, double *F);
+void mods_test_u2f_form(const double *u, const int *idx, int n, const double *w, int reference_form, double *F);   /* 1: matrix written out */
 int mods_test_checksample(const double *F, const double *u7, double th, double *H);
 unsigned mods_test_inner_h(unsigned seed, double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl);
 unsigned mods_test_rfth(unsigned seed, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F);

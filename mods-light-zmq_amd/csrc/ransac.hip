@@ -20,7 +20,7 @@
 #include "common.hpp"
 #include "ransac_host.hpp"
 #include "ransac_gpu.hpp"
-#include "ransac_simd.hpp"
+#include "ransac_soa.hpp"
 #include "ransac_dev.hpp"
 #include <ctime>
 #include <cstdlib>
@@ -156,6 +156,7 @@ RansacGpu *ransac_gpu() {
     // queue behind a describe batch of the pipeline's GPU workers (16-25 ms per call when they did)
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (getenv("MODS_RANSAC_PRIO")) prio_high = atoi(getenv("MODS_RANSAC_PRIO"));   // development aid
     if (hipStreamCreateWithPriority(&ws.stream, hipStreamNonBlocking, prio_high) != hipSuccess) { set_error("stream creation failed"); return nullptr; }
     ws.device = dev;
   }
@@ -309,25 +310,6 @@ struct RsTimer {
   int slot; double t0;
   explicit RsTimer(int s) : slot(s), t0(rsprof_on() ? rs_now_us() : 0) {}
   ~RsTimer() { if (rsprof_on()) g_rsprof.us[slot] += rs_now_us() - t0; }
-};
-
-// Structure-of-arrays copy of the correspondences for the host SIMD error functions (ransac_simd.hpp); every per-point
-// buffer of the run is padded to n_pad so that whole vectors can be read and written.
-struct PointsSoA {
-  const rs::SimdOps *ops = rs::simd_ops();
-  int len = 0, n_pad = 0;
-  std::vector<double> store, gains;
-  const double *col[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  void build(const double *u, int n) {
-    len = n; n_pad = (n + rs::SIMD_PAD - 1) / rs::SIMD_PAD * rs::SIMD_PAD;
-    store.resize((size_t)5 * n_pad); gains.assign(n_pad, 0.0);
-    const int comp[5] = {0, 1, 3, 4, 5};
-    for (int c = 0; c < 5; c++) {
-      double *dst = store.data() + (size_t)c * n_pad;
-      for (int i = 0; i < n_pad; i++) dst[i] = u[(size_t)6 * (i < n ? i : n - 1) + comp[c]];
-      col[c] = dst;
-    }
-  }
 };
 
 struct ErrFn {   // host-side error function of the run (LO path); d has room for n_pad values

@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "ransac_f_host.hpp"
 #include "ransac_gpu.hpp"
+#include "ransac_soa.hpp"
 #include "ransac_dev.hpp"
 #include <ctime>
 #include <cstdlib>
@@ -167,6 +168,26 @@ struct GpuEval : rs::PointEval {
   void exfds_sym(const double *F, double *p, double *w) override { run(EV_EXFDS_SYM, F, p, w); }
 };
 
+// PointEval as host SIMD across correspondences (ransac_simd.hpp: the scalar code's operations in the scalar code's order, 4
+// or 8 correspondences per instruction).  One evaluation of 24 k correspondences takes ~25 us here against ~100 us for the
+// launch + copy + synchronise round trip of GpuEval, and the degenerate branch of a large planar pair makes over a thousand
+// of them (BASELINE configs[4]).
+struct SimdEval : rs::PointEval {
+  PointsSoA pts;
+  std::vector<double> tp, tw;
+  SimdEval(const double *u_, int len_) : rs::PointEval(u_, len_) { pts.build(u_, len_); tp.resize(pts.n_pad); tw.resize(pts.n_pad); }
+  void f(const double *F, int mode, double *p, double *w) {
+    pts.ops->fds_all(pts.col, pts.n_pad, F, mode, tp.data(), tw.data());
+    memcpy(p, tp.data(), sizeof(double) * len);
+    if (w) memcpy(w, tw.data(), sizeof(double) * len);
+  }
+  void hds(const double *H, double *out) override { pts.ops->hds_all(pts.col, pts.n_pad, H, tp.data()); memcpy(out, tp.data(), sizeof(double) * len); }
+  void fds(const double *F, double *out) override { f(F, 0, out, nullptr); }
+  void fds_sym(const double *F, double *out) override { f(F, 1, out, nullptr); }
+  void exfds(const double *F, double *p, double *w) override { f(F, 2, p, w); }
+  void exfds_sym(const double *F, double *p, double *w) override { f(F, 3, p, w); }
+};
+
 // off-plane set of rFtH -> aux_dev
 static bool gpu_upload_aux(RansacGpu *ws, const double *uN, unsigned n) {
   if ((size_t)n * 6 > ws->aux_cap) {
@@ -237,6 +258,11 @@ int mods_test_seven_point(const double *u7, double *F27) {
 void mods_test_u2f(const double *u, const int *idx, int n, const double *w, double *F) {
   std::vector<double> buffer((size_t)9 * n + 96);
   rs::u2fw(u, idx, w, n, F, buffer.data());
+}
+// reference_form 1: lin_fmN + row weights + cov_mat as written in Ftools.c:302-405; 0: cov_fmN (what u2fw runs)
+void mods_test_u2f_form(const double *u, const int *idx, int n, const double *w, int reference_form, double *F) {
+  std::vector<double> buffer((size_t)9 * n + 96);
+  rs::u2fw(u, idx, w, n, F, buffer.data(), reference_form != 0);
 }
 int mods_test_checksample(const double *F, const double *u7, double th, double *H) { return rs::checksample(F, u7, th, H); }
 unsigned mods_test_inner_h(unsigned seed, double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl) {
@@ -360,6 +386,23 @@ static double wall_ms() { return std::chrono::duration<double, std::milli>(std::
 
 #define F_FATAL() mods::ransac_fail()
 
+// host-only self-test hook: mode 0 FDs, 1 FDsSym, 2 exFDs, 3 exFDsSym over all correspondences; lanes 0 = the scalar loops,
+// 1 / 4 / 8 = ransac_simd at that width (MODS_E_ARG when this CPU lacks it)
+extern "C" int mods_test_host_fds(int mode, const double *u6, int len, const double *F, int lanes, double *p, double *w) {
+  if (!u6 || !F || !p || len < 1 || mode < 0 || mode > 3 || (mode >= 2 && !w)) return MODS_E_ARG;
+  if (lanes == 0) {
+    if (mode == 0) rs::FDs_all(u6, F, p, len); else if (mode == 1) rs::FDsSym_all(u6, F, p, len);
+    else if (mode == 2) rs::exFDs_all(u6, F, p, w, len); else rs::exFDsSym_all(u6, F, p, w, len);
+    return MODS_OK;
+  }
+  const rs::SimdOps *ops = rs::simd_ops_lanes(lanes);
+  if (!ops) return MODS_E_ARG;
+  SimdEval ev(u6, len);
+  ev.pts.ops = ops;
+  ev.f(F, mode, p, mode >= 2 ? w : nullptr);
+  return MODS_OK;
+}
+
 static int ransac_f_run(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
                                   int do_lo, unsigned inlLimit, double **resids, double *H_best, int *Ih, exFDsPtr EXFDS1, FDsPtr FDS1,
                                   int doSymCheck) {
@@ -409,9 +452,13 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
   // O(len) evaluations of one model (LO steps, degenerate branch): on the GPU for long lists, where a launch +
   // a row copy (~30 us) beats the host loop; the library's own error functions only
   rs::PointEval host_eval(u, len);
+  // evaluations of one model over all correspondences: host SIMD (MODS_F_EVAL=gpu: the device round trip, =scalar: the plain loops)
   std::unique_ptr<GpuEval> gpu_eval;
-  if (len >= 2048) { gpu_eval.reset(new GpuEval(ws, u, len)); if (!gpu_eval->ok()) F_FATAL(); }
-  rs::PointEval *ev = gpu_eval ? (rs::PointEval *)gpu_eval.get() : &host_eval;
+  std::unique_ptr<SimdEval> simd_eval;
+  static const char *eval_mode = getenv("MODS_F_EVAL");
+  if (eval_mode && !strcmp(eval_mode, "gpu")) { if (len >= 2048) { gpu_eval.reset(new GpuEval(ws, u, len)); if (!gpu_eval->ok()) F_FATAL(); } }
+  else if (!eval_mode || strcmp(eval_mode, "scalar")) simd_eval.reset(new SimdEval(u, len));
+  rs::PointEval *ev = gpu_eval ? (rs::PointEval *)gpu_eval.get() : simd_eval ? (rs::PointEval *)simd_eval.get() : &host_eval;
   auto eval_fds = [&](const double *Fm, double *dd) {
     if (FDS1 == &FDs) ev->fds(Fm, dd);
     else if (FDS1 == &FDsSym) ev->fds_sym(Fm, dd);
@@ -653,6 +700,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
   }
   data_out[0] = no_sam;
   data_out[1] = iter_cnt;
+  if (prof) { fprintf(stderr, "[mods ransacF] rFtH: candidates %.2f ms, counting %.2f ms, %.0f blocks, %.0f off-plane; innerFH %.0f calls %.2f ms, of which %.0f fits in u2Fit %.2f ms\n", rs::g_rfth_prof[0], rs::g_rfth_prof[1], rs::g_rfth_prof[2], rs::g_rfth_prof[3], rs::g_rfth_prof[6], rs::g_rfth_prof[4], rs::g_rfth_prof[7], rs::g_rfth_prof[5]); for (double &x : rs::g_rfth_prof) x = 0; }
   if (prof) fprintf(stderr, "[mods ransacF] len %d samples %d lo %d degen %d | total %.2f ms: innerH %.2f rFtH %.2f LO %.2f\n", len, no_sam, iter_cnt,
                     degen_cnt, wall_ms() - t_begin, t_innerh, t_rfth, t_lo);
   if (Ih) *Ih = Ihmax;

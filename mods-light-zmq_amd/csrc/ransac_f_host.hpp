@@ -24,6 +24,7 @@
 #pragma once
 #include "ransac_host.hpp"
 #include <functional>
+#include <ctime>
 
 namespace mods {
 namespace rs {
@@ -417,6 +418,33 @@ static inline void lin_fmN(const double *u, double *p, const int *inl, int len, 
       for (int l = 0; l < 3; l++) *p++ = a[l] * b[k];
   }
 }
+// lin_fmN (+ the optional row weights of u2fw) + cov_mat without the len x 9 matrix: the nine entries of a row are made in
+// registers and go straight into the 45 running sums - the same products and the same additions in the same row order
+static inline void cov_fmN(const double *u, const int *inl, const double *w, int len, const double *A1, const double *A2, double *Cv) {
+  double acc[45];
+  for (int q = 0; q < 45; q++) acc[q] = 0;
+  double a[3], b[3], z[9];
+  a[2] = 1; b[2] = 1;
+  for (int i = 0; i < len; i++) {
+    const double *s = u + 6 * inl[i];
+    a[0] = s[0] * A1[0] + A1[1];
+    a[1] = s[1] * A1[0] + A1[2];
+    b[0] = s[3] * A2[0] + A2[1];
+    b[1] = s[4] * A2[0] + A2[2];
+    for (int k = 0; k < 3; k++)
+      for (int l = 0; l < 3; l++) z[3 * k + l] = a[l] * b[k];
+    if (w) {
+      const double m = w[inl[i]];
+      for (int k = 0; k < 9; k++) z[k] *= m;
+    }
+    int q = 0;
+    for (int r = 0; r < 9; r++)
+      for (int c = 0; c <= r; c++) acc[q++] += z[r] * z[c];
+  }
+  int q = 0;
+  for (int r = 0; r < 9; r++)
+    for (int c = 0; c <= r; c++) { Cv[9 * r + c] = acc[q]; Cv[r + 9 * c] = acc[q]; q++; }
+}
 // denormF, utools.c:53-70
 static inline void denormF(double *F, const double *A1, const double *A2) {
   double r = A2[0], x = A2[1], y = A2[2];
@@ -437,19 +465,21 @@ static inline void denormF(double *F, const double *A1, const double *A2) {
 // len > 8: normalised 8-point algorithm through the 9x9 moment matrix; len <= 8: null direction of the
 // unnormalised design matrix.  For len < 8 the reference runs its 9x8 SVD over a 9 x len buffer, i.e. on
 // stale memory; that input is not defined and is not reproduced (callers guard it, see ransac_f.hip).
-static inline void u2fw(const double *u, const int *inl, const double *w, int len, double *F, double *buffer) {
+static inline void u2fw(const double *u, const int *inl, const double *w, int len, double *F, double *buffer, bool reference_form = false) {
   double A1[3], A2[3];
   double V[9 * 9], D[9];
   double *Z = buffer;
   if (len > 8) {
     normu(u, inl, len, A1, A2);
-    lin_fmN(u, Z, inl, len, A1, A2);
-    if (w)
-      for (int i = 0; i < len; i++) {
-        const double m = w[inl[i]];
-        for (int k = 0; k < 9; k++) Z[9 * i + k] *= m;
-      }
-    cov_mat(V, Z, len, 9);
+    if (reference_form) {   // the matrix written out, as Ftools.c:302-405 has it (kept for the self-test that pins cov_fmN to it)
+      lin_fmN(u, Z, inl, len, A1, A2);
+      if (w)
+        for (int i = 0; i < len; i++) {
+          const double m = w[inl[i]];
+          for (int k = 0; k < 9; k++) Z[9 * i + k] *= m;
+        }
+      cov_mat(V, Z, len, 9);
+    } else cov_fmN(u, inl, w, len, A1, A2, V);
     sym_eig(V, D, 9);                       // ascending: vector 0 belongs to the smallest eigenvalue
     for (int i = 0; i < 9; i++) F[i] = V[i];
   } else {
@@ -682,6 +712,11 @@ static inline unsigned innerH(double *H, const double *u, unsigned len, double t
   return I;
 }
 
+// development aid (MODS_RANSAC_PROFILE): [0] rFtH candidate loops ms, [1] counting calls ms, [2] blocks, [3] off-plane points,
+// [4] innerFH ms, [5] least-squares fits inside u2Fit ms, [6] innerFH calls, [7] u2Fit fits
+static thread_local double g_rfth_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static inline double rfth_prof_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
 // ---- plane-and-parallax search ----------------------------------------------------------------------------
 // u2Fit, DegUtils.c:629-697
 static inline unsigned u2Fit(PointEval &ev, double *F, unsigned char *inl, double th, double ths, unsigned iters) {
@@ -702,7 +737,7 @@ static inline unsigned u2Fit(PointEval &ev, double *F, unsigned char *inl, doubl
     no_i = 0;
     for (unsigned i = 0; i < len; ++i)
       if (inl[i]) inlI[no_i++] = (int)i;
-    u2f(u, inlI.data(), (int)no_i, F, buffer.data());
+    { const double t_ = rfth_prof_now(); u2f(u, inlI.data(), (int)no_i, F, buffer.data()); g_rfth_prof[5] += rfth_prof_now() - t_; g_rfth_prof[7] += 1; }
     ths -= dth;
   }
   ev.fds(F, Ds.data());
@@ -817,6 +852,7 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
   unsigned max_i = 3, m_i = sam_sizO, max_sam = MAX_SAM;
   if (nN < 4 || nH < 6) return 0;
   if (upload_offplane) upload_offplane(uN.data(), nN);
+  g_rfth_prof[3] = nN;
 
   double Ht[9];
   mat3_tr(Ht, H);
@@ -850,11 +886,14 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
     if (nb > BLOCK) nb = BLOCK;
     const GlibcRand rng0 = rng;
     const std::vector<unsigned> ptr0 = ptr;
+    const double tq0 = rfth_prof_now();
     for (unsigned s = 0; s < nb; s++) {
       draw(rng, ptr);
       candidate(ptr[0], ptr[1], &Fs[9 * s]);
     }
-    if (count) count(Fs.data(), (int)nb, cnt.data());
+    const double tq1 = rfth_prof_now();
+    g_rfth_prof[0] += tq1 - tq0; g_rfth_prof[2] += 1;
+    if (count) { count(Fs.data(), (int)nb, cnt.data()); g_rfth_prof[1] += rfth_prof_now() - tq1; }
     else {
       FDs_all(uN.data(), Fs.data(), Ds.data(), (int)nN);
       unsigned c = 0;
@@ -883,7 +922,7 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
     for (unsigned i = 0; i < nN; ++i)
       if (v[i]) { std::memcpy(&uV[6 * no_i], &uN[6 * i], 6 * sizeof(double)); ++no_i; }
     m_i = no_i;
-    innerFH(rng, uH.data(), nH, uV.data(), no_i, ev, th, 15, sam_sizH, sam_sizO, aF, inl.data());
+    { const double t_ = rfth_prof_now(); innerFH(rng, uH.data(), nH, uV.data(), no_i, ev, th, 15, sam_sizH, sam_sizO, aF, inl.data()); g_rfth_prof[4] += rfth_prof_now() - t_; g_rfth_prof[6] += 1; }
     unsigned ninl = 0;
     for (unsigned i = 0; i < len; ++i) if (inl[i]) ++ninl;
     if (ninl > max_i) {

@@ -7,6 +7,8 @@ struct SimdOps {
   void (*hds_all)(const double *const *soa, int n_pad, const double *H, double *d);
   void (*hsym_all)(const double *const *soa, int n_pad, const double *H1, const double *Hinv, int mode, double *d);
   void (*gains_all)(const double *err, int n_pad, double lim, double *g);
+  // FDs (mode 0), FDsSym (1), exFDs (2: + weight 1/sqrt(w)), exFDsSym (3: + weight a b/(a+b)); w may be null for modes 0, 1
+  void (*fds_all)(const double *const *soa, int n_pad, const double *F, int mode, double *p, double *w);
 };
 const SimdOps *simd_ops();                 // widest table this CPU runs
 const SimdOps *simd_ops_lanes(int lanes);  // 1, 4 (AVX2) or 8 (AVX-512F); nullptr when the CPU lacks it

@@ -108,3 +108,60 @@ def test_inlidxs_gain_pass_bitexact(pkg, th):
         S = R.inlidxs(P(err), n, C.c_double(th), P(inl))
         assert S.I == I0.value and np.float64(S.J).view(np.uint64) == np.float64(J0.value).view(np.uint64)
         assert np.array_equal(inl[:S.I], want_inl[:S.I])
+
+
+@pytest.mark.parametrize("n", [1, 9, 1000, 6001])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_simd_epipolar_error_functions_bitexact(pkg, n, mode):
+    """FDs / FDsSym / exFDs / exFDsSym over all correspondences (Ftools.c:94-209): every SIMD width gives the scalar bits,
+    and the scalar loops give the reference's (oracle/_ref)."""
+    import fsynth
+    M = pkg.lib()
+    u, _, _ = fsynth.two_view(max(n, 16), 0.6, 0.0, 0.5, seed=4 + n)
+    u = np.ascontiguousarray(u[:n])
+    F = np.ascontiguousarray(np.random.default_rng(n + mode).normal(0, 1, 9) * [1e-6, 1e-6, 1e-3, 1e-6, 1e-6, 1e-3, 1e-3, 1e-3, 1.0])
+    p0, w0 = np.zeros(n), np.zeros(n)
+    assert M.mods_test_host_fds(mode, P(u), n, P(F), 0, P(p0), P(w0)) == 0
+    assert np.isfinite(p0).all()
+    ran = 0
+    for lanes in LANES:
+        p1, w1 = np.full(n, -1.0), np.full(n, -1.0)
+        if M.mods_test_host_fds(mode, P(u), n, P(F), lanes, P(p1), P(w1)) != 0:
+            continue
+        ran += 1
+        assert np.array_equal(p1.view(np.uint64), p0.view(np.uint64)), (lanes, mode)
+        if mode >= 2:
+            assert np.array_equal(w1.view(np.uint64), w0.view(np.uint64)), (lanes, mode)
+    assert ran >= 1
+    if refdeg.available():
+        R = refdeg.lib()
+        r, rw = np.zeros(n), np.zeros(n)
+        if mode == 0:
+            R.FDs(P(u), P(F), P(r), n)
+        elif mode == 1:
+            R.FDsSym(P(u), P(F), P(r), n)
+        elif mode == 2:
+            R.exFDs(P(u), P(F), P(r), P(rw), n)
+        else:
+            R.exFDsSym(P(u), P(F), P(r), P(rw), n)
+        assert np.array_equal(r.view(np.uint64), p0.view(np.uint64))
+        if mode >= 2:
+            assert np.array_equal(rw.view(np.uint64), w0.view(np.uint64))
+
+
+@pytest.mark.parametrize("n", [9, 14, 200, 5000])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_least_squares_f_without_the_design_matrix_bitexact(pkg, n, weighted):
+    """u2f / u2fw (Ftools.c:302-405): the moment matrix accumulated straight from the rows (cov_fmN) gives the bits of
+    lin_fmN + weights + cov_mat."""
+    import fsynth
+    M = pkg.lib()
+    u, _, _ = fsynth.two_view(6000, 0.6, 0.0, 0.5, seed=9)
+    u = np.ascontiguousarray(u)
+    g = np.random.default_rng(n)
+    idx = np.ascontiguousarray(g.permutation(6000)[:n].astype(np.int32))
+    w = np.ascontiguousarray(g.uniform(0.5, 1.5, 6000))
+    Fa, Fb = np.zeros(9), np.zeros(9)
+    M.mods_test_u2f_form(P(u), P(idx), n, P(w) if weighted else None, 1, P(Fa))
+    M.mods_test_u2f_form(P(u), P(idx), n, P(w) if weighted else None, 0, P(Fb))
+    assert np.array_equal(Fa.view(np.uint64), Fb.view(np.uint64)) and np.abs(Fa).max() > 0
