@@ -445,6 +445,22 @@ int mods_match_ladder_dets_dev(mods_ctx *ctx, const float *img1_dev, int w1, int
                                const struct mods_pair_params *par, mods_imgrep **reps1, mods_imgrep **reps2, mods_ladder_result *res,
                                double *matches_out, int max_matches);
 
+/* Grouped matching of a step ([Matching<i>] GroupDetectors / GroupDescriptors, CorrespondenceBank::MatchImgReps,
+ * correspondencebank.cpp:245-285): the regions of the named detectors, joined in the order they are named, are searched as ONE
+ * query and ONE train list per named descriptor, with the [Matching]-wide thresholds (matchRatio<Descriptor> /
+ * matchDistance<Descriptor>, io_mods.cpp:448-452), in every step that names a group - whether or not the step brought new
+ * views.  The result is the bank's list of the pseudo-detector "Group"; group_pos = the number of real detectors whose name
+ * sorts before "Group" (its place in the joint list). */
+typedef struct mods_ladder_group {
+  int n_dets, dets[8];                /* GroupDetectors as indices into the detector array, in the order given; 0: no group */
+  double fginn_ratio, fginn_ratio_half;        /* matchRatioRootSIFT / matchRatioHalfRootSIFT; < 0: descriptor not in GroupDescriptors */
+  double dist_threshold, dist_threshold_half;  /* matchDistanceRootSIFT / matchDistanceHalfRootSIFT (> 0: MatchFLANNDistance replaces) */
+} mods_ladder_group;
+int mods_match_ladder_groups_dev(mods_ctx *ctx, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
+                                 const mods_ladder_step *steps, const mods_hessaff_params *dets, const mods_ladder_group *groups /* [n_steps] or NULL */,
+                                 int group_pos, int n_steps, int n_det, int min_matches, const struct mods_pair_params *par,
+                                 mods_imgrep **reps1, mods_imgrep **reps2, mods_ladder_result *res, double *matches_out, int max_matches);
+
 /* ---- one hard pair on several GPUs of a node ------------------------------------------------------
  * The views of every step (ImageRepresentation::SynthDetectDescribeKeypoints' views loop, imagerepresentation.cpp:704-1099) are
  * sharded over the devices, largest first; the described regions travel in ONE all-gather per step (RCCL over xGMI, device

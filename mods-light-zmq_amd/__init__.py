@@ -651,7 +651,23 @@ def match_ladder_dev(ctx, img_ptr, w, h, steps, rep1, rep2, params=None, min_mat
     return res, m[:min(res.n_inliers, max_matches)]
 
 
-def match_ladder_dets_dev(ctx, img_ptr, w, h, det_steps, det_params, reps1, reps2, params=None, min_matches=15, max_matches=0):
+class LadderGroup(C.Structure):
+    """[Matching<i>] GroupDetectors / GroupDescriptors of one step (mods_ladder_group)."""
+    _fields_ = [("n_dets", C.c_int), ("dets", C.c_int * 8), ("fginn_ratio", C.c_double), ("fginn_ratio_half", C.c_double),
+                ("dist_threshold", C.c_double), ("dist_threshold_half", C.c_double)]
+
+    @staticmethod
+    def make(dets=(), ratio=0.0, ratio_half=-1.0, dist=0.0, dist_half=0.0):
+        g = LadderGroup()
+        g.n_dets = len(dets)
+        for i, d in enumerate(dets):
+            g.dets[i] = d
+        g.fginn_ratio, g.fginn_ratio_half, g.dist_threshold, g.dist_threshold_half = ratio, ratio_half, dist, dist_half
+        return g
+
+
+def match_ladder_dets_dev(ctx, img_ptr, w, h, det_steps, det_params, reps1, reps2, params=None, min_matches=15, max_matches=0,
+                          groups=None, group_pos=0):
     """mods_match_ladder_dets_dev: det_steps[d] = the steps of detector d (LadderStep, or None where the detector has no section),
     det_params[d] its HessAffParams; list the detectors sorted by name.  img_ptr: [2][h][w] fp32 in HBM."""
     n_det, n_steps = len(det_steps), max(len(x) for x in det_steps)
@@ -667,9 +683,12 @@ def match_ladder_dets_dev(ctx, img_ptr, w, h, det_steps, det_params, reps1, reps
     params = params or PairParams.default()
     res = LadderResult()
     m = np.zeros((max(max_matches, 1), 4), np.float64)
-    _check(lib().mods_match_ladder_dets_dev(ctx.h, C.c_void_p(img_ptr), w, h, C.c_void_p(img_ptr + 4 * w * h), w, h, arr, dets, n_steps, n_det,
-                                            min_matches, C.byref(params), r1, r2, C.byref(res),
-                                            m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
+    garr = None
+    if groups is not None:
+        garr = (LadderGroup * n_steps)(*[g if g is not None else LadderGroup.make() for g in list(groups) + [None] * (n_steps - len(groups))])
+    _check(lib().mods_match_ladder_groups_dev(ctx.h, C.c_void_p(img_ptr), w, h, C.c_void_p(img_ptr + 4 * w * h), w, h, arr, dets, garr, group_pos,
+                                              n_steps, n_det, min_matches, C.byref(params), r1, r2, C.byref(res),
+                                              m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
     return res, m[:min(res.n_inliers, max_matches)]
 
 

@@ -50,6 +50,10 @@ struct Config {
   std::vector<std::string> det_names;
   std::vector<mods_hessaff_params> det_params;
   std::vector<mods_ladder_step> steps;
+  // grouped matching ([Matching<i>] GroupDetectors / GroupDescriptors, correspondencebank.cpp:245-285): one entry per step when
+  // any step names a group; group_pos = place of the bank's "Group" entry among the detector names
+  std::vector<mods_ladder_group> groups;
+  int group_pos = 0;
   int max_steps = 4, min_matches = 15;
   int load_color = 1;
   int verbose = 0, time_log = 1, write_keypoints = 1, write_matches = 1, output_h = 0;
@@ -265,6 +269,41 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
     for (int di = 0, d = 0; di < 3; di++) {
       if (d < n_det && cfg->det_names[d] == ss_detectors[di].name) { cfg->steps.push_back(all[di][i]); d++; }
     }
+  // grouped matching: thresholds are the [Matching]-wide ones (io_mods.cpp:448-452), the detector order is the order named
+  auto trimmed = [](std::string name) { name.erase(0, name.find_first_not_of(" \t")); name.erase(name.find_last_not_of(" \t") + 1); return name; };
+  bool any_group = false;
+  std::vector<mods_ladder_group> groups((size_t)cfg->max_steps);
+  for (int i = 0; i < cfg->max_steps; i++) {
+    mods_ladder_group &g = groups[i];
+    memset(&g, 0, sizeof(g));
+    g.fginn_ratio = g.fginn_ratio_half = -1.0;
+    const std::string msec = "Matching" + std::to_string(i);
+    if (!it.Has(msec, "GroupDetectors") || !it.Has(msec, "GroupDescriptors")) continue;
+    for (const std::string &raw : it.GetStringVector(msec, "GroupDetectors")) {
+      const std::string name = trimmed(raw);
+      if (name.empty()) continue;
+      const auto at = std::find(cfg->det_names.begin(), cfg->det_names.end(), name);
+      if (at == cfg->det_names.end()) { std::cerr << "Warning: [" << msec << "] GroupDetectors: " << name << " has no views in this build's steps, left out of the group" << std::endl; continue; }
+      if (g.n_dets < 8) g.dets[g.n_dets++] = (int)(at - cfg->det_names.begin());
+    }
+    bool any_desc = false;
+    for (const std::string &raw : it.GetStringVector(msec, "GroupDescriptors")) {
+      const std::string name = trimmed(raw);
+      if (name == "RootSIFT" || (name == "ZMQ" && cfg->use_zmq)) {
+        g.fginn_ratio = ini.GetDouble("Matching", "matchRatio" + name, 0.0); g.dist_threshold = ini.GetDouble("Matching", "matchDistance" + name, 0.0); any_desc = true;
+      } else if (name == "HalfRootSIFT") {
+        g.fginn_ratio_half = ini.GetDouble("Matching", "matchRatioHalfRootSIFT", 0.0); g.dist_threshold_half = ini.GetDouble("Matching", "matchDistanceHalfRootSIFT", 0.0); any_desc = true;
+      } else if (!name.empty()) std::cerr << "Warning: [" << msec << "] GroupDescriptors: " << name << " is outside this build" << std::endl;
+    }
+    if (!any_desc || g.n_dets == 0) { g.n_dets = 0; continue; }
+    if ((g.fginn_ratio > 0 && !(g.fginn_ratio < 1)) || (g.fginn_ratio_half > 0 && !(g.fginn_ratio_half < 1))) { std::cerr << "[Matching] matchRatio* must lie in (0, 1)" << std::endl; return 1; }
+    any_group = true;
+  }
+  if (any_group) {
+    cfg->groups = groups;
+    cfg->group_pos = 0;
+    for (const std::string &nm : cfg->det_names) if (nm < std::string("Group")) cfg->group_pos++;
+  }
   return 0;
 }
 
@@ -482,7 +521,7 @@ int main(int argc, char **argv) {
   mods_ctx *ctx = nullptr;
   const int n_det = (int)cfg.det_names.size();
   if (n_det == 0) { std::cerr << "The iterations file has no HessianAffine / DoG / HarrisAffine step with RootSIFT; nothing to do" << std::endl; return 1; }
-  const bool hessian_only = n_det == 1 && cfg.det_names[0] == "HessianAffine";
+  const bool hessian_only = n_det == 1 && cfg.det_names[0] == "HessianAffine" && cfg.groups.empty();
   std::vector<mods_imgrep *> reps1((size_t)n_det, nullptr), reps2((size_t)n_det, nullptr);
   void *d1 = nullptr, *d2 = nullptr;
   auto fail = [&](const char *what) { std::cerr << "mods: " << what << ": " << mods_last_error() << std::endl; return 1; };
@@ -562,8 +601,9 @@ int main(int argc, char **argv) {
     else if (mods_match_ladder_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, steps.data(), (int)steps.size(),
                                    cfg.min_matches, &cfg.pair, reps1[0], reps2[0], &res, matches.data(), 1 << 20))
       return fail("matching");
-  } else if (mods_match_ladder_dets_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, cfg.steps.data(), cfg.det_params.data(),
-                                        (int)cfg.steps.size() / n_det, n_det, cfg.min_matches, &cfg.pair, reps1.data(), reps2.data(), &res, matches.data(), 1 << 20))
+  } else if (mods_match_ladder_groups_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, cfg.steps.data(), cfg.det_params.data(),
+                                          cfg.groups.empty() ? nullptr : cfg.groups.data(), cfg.group_pos, (int)cfg.steps.size() / n_det, n_det, cfg.min_matches,
+                                          &cfg.pair, reps1.data(), reps2.data(), &res, matches.data(), 1 << 20))
     return fail("matching");
   const double final_time = now_s() - c_start;
   const int final_step = res.steps_done <= 0 ? 0 : (hessian_only && !pre_extracted) ? step_index[res.steps_done - 1] + 1 : res.steps_done;

@@ -271,10 +271,11 @@ static int match_verify_banks(mods_ctx *c, mods_imgrep *rep1, mods_imgrep *rep2,
   return verify_gathered(c, par, res);
 }
 
-int mods_match_ladder_dets_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
-                               const mods_ladder_step *steps, const mods_hessaff_params *dets, int n_steps, int n_det, int min_matches,
-                               const mods_pair_params *par, mods_imgrep **reps1, mods_imgrep **reps2, mods_ladder_result *res,
-                               double *matches_out, int max_matches) {
+int mods_match_ladder_groups_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
+                                 const mods_ladder_step *steps, const mods_hessaff_params *dets, const mods_ladder_group *groups, int group_pos,
+                                 int n_steps, int n_det, int min_matches, const mods_pair_params *par, mods_imgrep **reps1, mods_imgrep **reps2,
+                                 mods_ladder_result *res, double *matches_out, int max_matches) {
+  if (groups && (group_pos < 0 || group_pos > n_det)) { set_error("match_ladder: bad group position"); return MODS_E_ARG; }
   if (!c || !img1_dev || !img2_dev || !steps || !dets || !par || !reps1 || !reps2 || !res || n_det < 1 || n_det > 8) { set_error("match_ladder: bad argument"); return MODS_E_ARG; }
   for (int d = 0; d < n_det; d++) if (!reps1[d] || !reps2[d]) { set_error("match_ladder: null region bank"); return MODS_E_ARG; }
   memset(res, 0, sizeof(*res));
@@ -288,8 +289,13 @@ int mods_match_ladder_dets_dev(mods_ctx *c, const float *img1_dev, int w1, int h
   };
   std::vector<PerDet> pd(n_det);
   std::vector<mods_view_par> views(256);
-  std::vector<TentList> lists[2];                // per (descriptor, detector): kept from step to step until re-matched
-  lists[0].resize(n_det); lists[1].resize(n_det);
+  // per (descriptor, detector): kept from step to step until re-matched.  With grouped matching the bank has one more
+  // "detector", named Group, at its place in the name order: slot of detector d = d + (d >= group_pos)
+  std::vector<TentList> lists[2];
+  const int n_slots = n_det + (groups ? 1 : 0);
+  lists[0].resize(n_slots); lists[1].resize(n_slots);
+  auto slot_of = [&](int d) { return groups && d >= group_pos ? d + 1 : d; };
+  struct GroupBanks { mods_imgrep *q = nullptr, *t = nullptr; ~GroupBanks() { mods_imgrep_destroy(q); mods_imgrep_destroy(t); } } gb;
   for (int d = 0; d < n_det; d++) { mods_imgrep_clear(reps1[d]); mods_imgrep_clear(reps2[d]); }
   for (int step = 0; step < n_steps && curr_matches < min_matches; step++) {
     std::vector<int> new_views(n_det, 0);
@@ -332,20 +338,53 @@ int mods_match_ladder_dets_dev(mods_ctx *c, const float *img1_dev, int w1, int h
     // MatchImgReps, correspondencebank.cpp:286-340: a detector is matched in a step that brought new views of it; each of its
     // descriptor lists is cleared and searched again over everything accumulated.  Lists that are not touched keep their
     // tentatives (ratio < 0: descriptor / detector not named in [Matching<i>]; 0: named, not searched, so it ends up empty)
+    // Grouped matching first, correspondencebank.cpp:245-285: the regions of the GroupDetectors, joined in the order they
+    // are named, searched as one list per GroupDescriptor with the [Matching]-wide thresholds; done in every step that names
+    // a group, new views or not
+    if (groups && groups[step].n_dets > 0) {
+      const mods_ladder_group &g = groups[step];
+      for (int desc = 0; desc < 2; desc++) {
+        const double ratio = desc ? g.fginn_ratio_half : g.fginn_ratio, dist = desc ? g.dist_threshold_half : g.dist_threshold;
+        if (ratio < 0) continue;
+        TentList &out = lists[desc][group_pos];
+        out.clear();
+        if (!(ratio > 0) && !(dist > 0)) continue;
+        int nq = 0, nt = 0;
+        for (int i = 0; i < g.n_dets; i++) {
+          const int d = g.dets[i];
+          if (d < 0 || d >= n_det) { set_error("match_ladder: group names detector %d of %d", d, n_det); return MODS_E_ARG; }
+          const mods_imgrep *a = desc ? pd[d].h1 : reps1[d], *b = desc ? pd[d].h2 : reps2[d];
+          if (a) nq += a->n;
+          if (b) nt += b->n;
+        }
+        if (nq == 0 || nt == 0) continue;
+        if (!gb.q || gb.q->cap < nq) { mods_imgrep_destroy(gb.q); gb.q = nullptr; if ((rc = mods_imgrep_create(c, nq, &gb.q))) return rc; }
+        if (!gb.t || gb.t->cap < nt) { mods_imgrep_destroy(gb.t); gb.t = nullptr; if ((rc = mods_imgrep_create(c, nt, &gb.t))) return rc; }
+        mods_imgrep_clear(gb.q); mods_imgrep_clear(gb.t);
+        for (int i = 0; i < g.n_dets; i++) {
+          const int d = g.dets[i];
+          const mods_imgrep *a = desc ? pd[d].h1 : reps1[d], *b = desc ? pd[d].h2 : reps2[d];
+          if (a && a->n && (rc = mods_imgrep_append_dev(gb.q, a->reg, a->n))) return rc;
+          if (b && b->n && (rc = mods_imgrep_append_dev(gb.t, b->reg, b->n))) return rc;
+        }
+        if (ratio > 0 && (rc = match_into(c, gb.q, gb.t, ratio, par, &out))) return rc;
+        if (dist > 0 && (rc = match_into(c, gb.q, gb.t, 0, par, &out, dist))) return rc;
+      }
+    }
     for (int d = 0; d < n_det; d++) {
       const mods_ladder_step &st = steps[(size_t)step * n_det + d];
       if (st.n_tilts < 0 || st.n_scales < 0 || new_views[d] == 0) continue;
       // (a descriptor with a DistanceThreshold: MatchFLANNDistance runs after MatchFlannFGINN and clears the list it is
       // given, so its tentatives replace the FGINN ones, correspondencebank.cpp:328-334, matching.cpp:585)
       if (st.fginn_ratio >= 0) {
-        lists[0][d].clear();
-        if (st.dist_threshold > 0) { if ((rc = match_into(c, reps1[d], reps2[d], 0, par, &lists[0][d], st.dist_threshold))) return rc; }
-        else if (st.fginn_ratio > 0 && (rc = match_into(c, reps1[d], reps2[d], st.fginn_ratio, par, &lists[0][d]))) return rc;
+        lists[0][slot_of(d)].clear();
+        if (st.dist_threshold > 0) { if ((rc = match_into(c, reps1[d], reps2[d], 0, par, &lists[0][slot_of(d)], st.dist_threshold))) return rc; }
+        else if (st.fginn_ratio > 0 && (rc = match_into(c, reps1[d], reps2[d], st.fginn_ratio, par, &lists[0][slot_of(d)]))) return rc;
       }
       if (st.fginn_ratio_half >= 0) {
-        lists[1][d].clear();
-        if (st.dist_threshold_half > 0 && pd[d].h1) { if ((rc = match_into(c, pd[d].h1, pd[d].h2, 0, par, &lists[1][d], st.dist_threshold_half))) return rc; }
-        else if (st.fginn_ratio_half > 0 && (rc = match_into(c, pd[d].h1, pd[d].h2, st.fginn_ratio_half, par, &lists[1][d]))) return rc;
+        lists[1][slot_of(d)].clear();
+        if (st.dist_threshold_half > 0 && pd[d].h1) { if ((rc = match_into(c, pd[d].h1, pd[d].h2, 0, par, &lists[1][slot_of(d)], st.dist_threshold_half))) return rc; }
+        else if (st.fginn_ratio_half > 0 && (rc = match_into(c, pd[d].h1, pd[d].h2, st.fginn_ratio_half, par, &lists[1][slot_of(d)]))) return rc;
       }
     }
     gather_tentatives(c, lists);
@@ -356,6 +395,14 @@ int mods_match_ladder_dets_dev(mods_ctx *c, const float *img1_dev, int w1, int h
   }
   copy_verified(c, res, matches_out, max_matches);
   return MODS_OK;
+}
+
+int mods_match_ladder_dets_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
+                               const mods_ladder_step *steps, const mods_hessaff_params *dets, int n_steps, int n_det, int min_matches,
+                               const mods_pair_params *par, mods_imgrep **reps1, mods_imgrep **reps2, mods_ladder_result *res,
+                               double *matches_out, int max_matches) {
+  return mods_match_ladder_groups_dev(c, img1_dev, w1, h1, img2_dev, w2, h2, steps, dets, nullptr, 0, n_steps, n_det, min_matches, par, reps1, reps2,
+                                      res, matches_out, max_matches);
 }
 
 int mods_match_ladder_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,

@@ -205,14 +205,17 @@ def view_schedule(tilts, phi_base, history, scales=(1.0,)):
 
 
 def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=0.2, ratio=0.8, half_orientation=False,
-                 ratio_half=0.0, detectors=None):
+                 ratio_half=0.0, detectors=None, groups=None, group_pos=0):
     """mods.cpp:202-383: steps = [(tilts, phi_base), ...] for one HessianAffine detector, or `detectors` = a list (sorted by
     detector name, the bank's key order) of dicts {params, steps: [(tilts, phi_base) | None per step], ratio, ratio_half,
     half_orientation}.  half_orientation: the steps' descriptor lists name a Half* descriptor (DetectOrientation in doHalfSIFT
     mode for every descriptor); ratio_half > 0: HalfRootSIFT lists are built and matched as a second separate descriptor.
     Every (descriptor, detector) pair keeps its own tentative list, re-made in the steps that bring new views of the detector
     (MatchImgReps, correspondencebank.cpp:286-340) and joined in the bank's key order - HalfRootSIFT before RootSIFT, then by
-    detector (GetCorresponcesVector, :114-148).  A detector dict may carry dist > 0 = DistanceThreshold of RootSIFT."""
+    detector (GetCorresponcesVector, :114-148).  A detector dict may carry dist > 0 = DistanceThreshold of RootSIFT.
+    groups: per step None or dict(dets=[detector indices in the order named], ratio, ratio_half): grouped matching
+    (correspondencebank.cpp:245-285) - the detectors' regions joined into one query / train list per descriptor, the result
+    kept as the bank's "Group" detector at position group_pos of the detector order."""
     h, w = img1.shape
     if detectors is None:
         detectors = [dict(params=None, steps=list(steps), ratio=ratio, ratio_half=ratio_half, half_orientation=half_orientation)]
@@ -220,6 +223,7 @@ def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=
     st = [dict(banks=[[], []], banks_h=[[], []], history=[], tc=None, tch=None) for _ in detectors]
     out = None
     n_views = 0
+    G = dict(tc=None, tch=None)
     for si in range(n_steps):
         for d, S in zip(detectors, st):
             step = d["steps"][si] if si < len(d["steps"]) else None
@@ -253,12 +257,26 @@ def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=
             if want_half:
                 ha, hb = np.concatenate(S["banks_h"][0]), np.concatenate(S["banks_h"][1])
                 S["tch"] = (match_fginn_par(ha, hb, d["ratio_half"]), ha, hb)
+        if groups is not None and si < len(groups) and groups[si]:
+            gspec = groups[si]
+            for key, bk, r in (("tc", "banks", gspec.get("ratio", 0.0)), ("tch", "banks_h", gspec.get("ratio_half", -1.0))):
+                if r < 0:
+                    continue
+                G[key] = None
+                qa = [x for d in gspec["dets"] for x in st[d][bk][0]]
+                ta = [x for d in gspec["dets"] for x in st[d][bk][1]]
+                if r > 0 and qa and ta:
+                    ra, rb = np.concatenate(qa), np.concatenate(ta)
+                    G[key] = (match_fginn_par(ra, rb, r), ra, rb)
         # the duplicate filter and what follows only need coordinates, frames and the ratio / distance keys: one joint list
         # whose q / t index a joint region array
         tcs, ras, rbs = [], [], []
         nq = nt = 0
         for key in ("tch", "tc"):
-            for S in st:
+            slots = list(st)
+            if groups is not None:
+                slots.insert(group_pos, G)
+            for S in slots:
                 if S[key] is None:
                     continue
                 tc, ra, rb = S[key]

@@ -282,3 +282,33 @@ def test_cli_dog_and_harris_detectors_next_to_hessian(pkg, tmp_path):
     for r in reps1 + reps2:
         r.close()
     ctx.close()
+
+
+def test_cli_grouped_detectors(pkg, tmp_path):
+    """[Matching0] GroupDetectors = HessianAffine, DoG / GroupDescriptors = RootSIFT with the [Matching]-wide matchRatioRootSIFT,
+    next to a separate DoG list: the command line against the library's grouped ladder."""
+    import torch
+    _run(tmp_path, "iters_grouped.ini")
+    a, b = _grey(G1), _grey(G6)
+    h, w = a.shape
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    reps1 = [pkg.ImgRep(ctx, 1 << 20) for _ in range(2)]
+    reps2 = [pkg.ImgRep(ctx, 1 << 20) for _ in range(2)]
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(4242)
+    hess = pkg.LadderStep.make((1,), 360.0, fginn=-1.0)       # not in SeparateDetectors
+    hess.fginn_ratio_half = -1.0
+    res, m = pkg.match_ladder_dets_dev(ctx, t.data_ptr(), w, h, [[pkg.LadderStep.make((1,), 360.0)], [hess]],
+                                       [pkg.HessAffParams.dog(), pkg.HessAffParams.default()], reps1, reps2, max_matches=1 << 20,
+                                       groups=[pkg.LadderGroup.make((1, 0), ratio=0.8)], group_pos=1)
+    pkg.ransac_pin_seed(-1)
+    got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    assert len(got) == res.n_inliers > 15
+    assert np.allclose(got, m, rtol=1e-5, atol=1e-3)
+    log = (tmp_path / "log.txt").read_text().split()
+    assert [int(log[1]), int(log[2])] == [res.n_inliers, res.n_unique]
+    for r in reps1 + reps2:
+        r.close()
+    ctx.close()

@@ -252,3 +252,41 @@ def test_ladder_with_distance_threshold(pkg):
     assert res.n_inliers == want["n_inliers"]
     assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
     rep1.close(); rep2.close(); ctx.close()
+
+
+def test_ladder_with_grouped_detectors(pkg):
+    """[Matching<i>] GroupDetectors = HessianAffine, DoG with GroupDescriptors = RootSIFT (correspondencebank.cpp:245-285): the
+    two detectors' regions are searched as one list (HessianAffine first, the order named), the result sits in the bank as
+    detector "Group" - between DoG and HessianAffine in the joint list - next to the separate DoG list; step 1 names the group
+    again without new DoG views - against the oracle chain."""
+    import torch
+    import orc
+    import pipeline_oracle as po
+    import refdeg
+    if not refdeg.available():
+        pytest.skip("oracle/_ref not built")
+    w, h = 480, 360
+    a, b, Htrue = _hard_pair(w, h, seed=27)
+    dets = [dict(params=orc.HessAffParams.dog(), steps=[((1,), 360.0), None], ratio=0.8),
+            dict(params=orc.HessAffParams.default(), steps=[((1,), 360.0), ((1, 2, 4), 360.0)], ratio=0.0)]   # Hessian: only through the group
+    groups = [dict(dets=[1, 0], ratio=0.8), dict(dets=[1, 0], ratio=0.8)]
+    want = po.match_ladder(a, b, None, seed_time=31, min_matches=100000, detectors=dets, groups=groups, group_pos=1)
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    reps1, reps2 = [pkg.ImgRep(ctx), pkg.ImgRep(ctx)], [pkg.ImgRep(ctx), pkg.ImgRep(ctx)]
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(31)
+    det_steps = [[pkg.LadderStep.make((1,), 360.0), None],
+                 [pkg.LadderStep.make((1,), 360.0, fginn=0.0), pkg.LadderStep.make((1, 2, 4), 360.0, fginn=0.0)]]
+    g = [pkg.LadderGroup.make((1, 0), ratio=0.8), pkg.LadderGroup.make((1, 0), ratio=0.8)]
+    res, m = pkg.match_ladder_dets_dev(ctx, t.data_ptr(), w, h, det_steps, [pkg.HessAffParams.dog(), pkg.HessAffParams.default()],
+                                       reps1, reps2, min_matches=100000, max_matches=100000, groups=g, group_pos=1)
+    assert res.steps_done == want["steps_done"] == 2 and res.n_views == want["n_views"]
+    assert res.n_tentatives == want["n_tentatives"] > 20 and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] >= 15
+    assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
+    for r in reps1 + reps2:
+        r.close()
+    ctx.close()
