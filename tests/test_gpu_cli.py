@@ -312,3 +312,19 @@ def test_cli_grouped_detectors(pkg, tmp_path):
     for r in reps1 + reps2:
         r.close()
     ctx.close()
+
+
+def test_cli_distance_threshold(pkg, tmp_path):
+    """DistanceThreshold in a step section: the tentatives come from MatchFLANNDistance (matching.cpp:572-633)."""
+    _run(tmp_path, "iters_distance.ini")
+    res, m, _ = _library_run(pkg, [pkg.LadderStep.make((1,), 360.0, dist=330.0)])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    assert len(got) == res.n_inliers                      # (nearest neighbours without a ratio test on this hard pair: few or none survive)
+    assert np.allclose(got, m, rtol=1e-5, atol=1e-3)
+    log = (tmp_path / "log.txt").read_text().split()
+    assert [int(log[1]), int(log[2])] == [res.n_inliers, res.n_unique] and res.n_unique > 100
+    fg, _, _ = _library_run(pkg, [pkg.LadderStep.make((1,), 360.0)])
+    assert fg.n_tentatives != res.n_tentatives          # not the FGINN list
