@@ -357,7 +357,7 @@ typedef struct mods_pair_params {
   int nn;                    /* 50 */
   int dup_before_ransac;     /* [DuplicateFiltering] doBeforeRANSAC = 1 */
   double dup_dist;           /* duplicateDist = 2.0 */
-  int dup_mode;              /* whichCorrespondenceRemains = bestFGINN -> 1 */
+  int dup_mode;              /* whichCorrespondenceRemains: random 0, bestFGINN 1, bestDistance 2, biggerRegion 3 */
   mods_ransac_params ransac;
 } mods_pair_params;
 

@@ -133,7 +133,6 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   p.dup_before_ransac = (int)ini.GetDouble("DuplicateFiltering", "doBeforeRANSAC", 1);
   const std::string fm = ini.GetString("DuplicateFiltering", "whichCorrespondenceRemains", "random");
   p.dup_mode = fm == "bestFGINN" ? 1 : fm == "bestDistance" ? 2 : fm == "biggerRegion" ? 3 : 0;
-  if (p.dup_mode == 3) { std::cerr << "Warning: whichCorrespondenceRemains=biggerRegion is not supported, list order is used" << std::endl; p.dup_mode = 0; }
   // [RANSAC] :437-455
   mods_ransac_params &r = p.ransac;
   r.err_threshold = ini.GetDouble("RANSAC", "err_threshold", 2.0);

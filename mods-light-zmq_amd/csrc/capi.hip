@@ -467,6 +467,10 @@ int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, 
   for (int i = 0; i < n; i++) order[i] = i;
   if (mode == 1) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(tent[a].ratio) < std::fabs(tent[b].ratio); });
   else if (mode == 2) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs((double)tent[a].d1) < std::fabs((double)tent[b].d1); });
+  else if (mode == 3) {   // MODE_BIGGER_REGION: ascending |s| of the first image's region (CompareCorrespondenceByScale, matching.cpp:74)
+    if (!laf) { set_error("duplicate_filter: biggerRegion needs the local affine frames"); return MODS_E_ARG; }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(laf[(size_t)a * 14 + 6]) < std::fabs(laf[(size_t)b * 14 + 6]); });
+  }
   std::vector<mods_tentative> ts(n);
   std::vector<double> us((size_t)n * 6), ls(laf ? (size_t)n * 14 : 0);
   for (int i = 0; i < n; i++) {

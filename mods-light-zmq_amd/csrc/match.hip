@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__re
   // must not shadow the valid rows; -2 * seed still fits an int)
   if (blockIdx.x == 0 && threadIdx.x < 32) {
     const int i = n + (int)threadIdx.x;
-    if (i < ((n + 31) & ~31)) c2neg[i] = -(1 << 29);
+    if (i < ((n + 31) & ~31)) c2neg[i] = -(1 << 25);
   }
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
     const uint8_t *d = reg[i].desc;
@@ -133,49 +133,90 @@ __device__ __forceinline__ void tile_store(char *buf, const TileRegs &r) {
 // The second key is what makes pass 2 rare: with (d1, t1) the smallest key over t != i0, a query whose d1 is >= D* has no
 // train below D* at all and its first train at or above D* IS (d1, t1) - see match_mid_kernel.
 // best2: [split][n_qpad][2], n_qpad = gridDim.x * 128 * QB (plain stores: every (split, query) has one owner).
+//
+// Exact path = branch-free register top-2 of packed 32-bit keys.  With acc = dot - floor(ct/2) the distance is
+// d = cq + (ct & 1) - 2*acc, so k = 2*acc - (ct & 1) = -(d - cq) orders the trains of a query (larger = nearer).  A lane
+// packs k4 = (k << 4) | (15 - r) (r = accumulator register = row order inside the lane) with ONE v_lshl_add_u32 per value:
+// k4 = (acc << 5) + C[row], C[row] = (-(ct & 1) << 4) | (15 - r(row)) comes with the tile through LDS.  The two largest
+// k4 of a lane are kept by v_med3_i32 + v_max_i32 per value (no compares, no exec masks, no LDS keys), and the tile
+// they came from by five selects per tile: values of one tile are distinct (distinct r), equal k4 of different tiles
+// keep the earlier tile = the lower train index, which is the (d, t) order.  |acc| < 2^23 (dot within +-2.1 M, ct/2 within
+// 2.1 M), rows past the end of the list carry the seed -2^25: their k4 lie below every real one and do not wrap.
+constexpr int MT2_BYTES = 32 * MT_ROW + 256;
+__device__ __forceinline__ TileRegs tile_fetch2(const int8_t *__restrict__ tdesc, const int *__restrict__ tc2n, const int *__restrict__ tc, int tt) {
+  TileRegs r;
+  r.a = *(const v4i *)(tdesc + (size_t)tt * 4096 + threadIdx.x * 16);
+  // threads 0..31: the seeds, 32..63: ct of the rows (turned into the key constants when the tile is stored: nothing
+  // waits for this load before the MFMAs)
+  r.s = threadIdx.x < 64 ? (threadIdx.x < 32 ? tc2n : tc - 32)[tt * 32 + threadIdx.x] : 0;
+  return r;
+}
+__device__ __forceinline__ void tile_store2(char *buf, const TileRegs &r) {
+  *(v4i *)(buf + (threadIdx.x >> 3) * MT_ROW + (threadIdx.x & 7) * 16) = r.a;
+  if (threadIdx.x < 64) {
+    const int row = threadIdx.x & 31;
+    const int ck = (-(r.s & 1) * 16) | (15 - ((row & 3) + 4 * (row >> 3)));
+    ((int *)(buf + 32 * MT_ROW))[threadIdx.x] = threadIdx.x < 32 ? r.s : ck;
+  }
+}
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {
+  int o;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+  return o;
+}
+#ifdef MATCH_STATS
+__device__ unsigned long long g_match_stats[4];
+#endif
+// development switches (timing experiments, wrong results): bit 0 = no bound exchange inside the loop, bit 1 = never take the
+// exact path, bit 2 = always take it, bit 3 = no epilogue at all
+#ifndef MATCH_EXP
+#define MATCH_EXP 0
+#endif
+
 __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                         const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
                                                         const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                         unsigned long long *__restrict__ best2, int *__restrict__ gthr) {
   constexpr int QB = MATCH_QB1;
+  constexpr int NONE = (int)0x80000000;
   const int lane = threadIdx.x & 63, g = lane >> 5;
   const int jbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
   v4i bq[QB][4];
-  int cq[QB], thr[QB];
-  // smallest / second smallest key of every (query block, lane): in LDS, they are touched on the exact path only and the
-  // kernel has to stay at 128 VGPRs (4 waves per SIMD)
-  __shared__ unsigned long long s_keys[QB][2][256];
+  int M1[QB], M2[QB], T1[QB], T2[QB];   // two largest packed keys of this lane's rows and their tiles
+  int bk[QB], alim[QB];                 // bound on k = -(d - cq): only k >= bk can matter; acc >= alim <=> 2*acc >= bk
 #pragma unroll
   for (int b = 0; b < QB; b++) {
     const int j = jbase + 32 * b;
     const int jc = j < k.n_q ? j : k.n_q - 1;
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) bq[b][ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
-    cq[b] = qc[jc] - 4194304;
-    // bound on (second smallest distance) - cq + 1 shared by the workgroups that scan other train ranges for the same queries
-    // (gthr starts at 0x7f7f7f7f = no bound): the global second key is at most any split's second key, so trains above it
-    // cannot be among the two nearest
-    thr[b] = __hip_atomic_load(&gthr[jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_keys[b][0][threadIdx.x] = ~0ull; s_keys[b][1][threadIdx.x] = ~0ull;
+    // gthr = (second smallest distance) - cq + 1 shared by the workgroups that scan other train ranges for the same queries
+    // (starts at 0x7f7f7f7f = no bound): the global second key is at most any split's second key, so trains above it
+    // cannot be among the two nearest.  d - cq < gthr  <=>  k >= 1 - gthr
+    bk[b] = 1 - __hip_atomic_load(&gthr[jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    alim[b] = (bk[b] + 1) >> 1;
+    M1[b] = NONE; M2[b] = NONE; T1[b] = 0; T2[b] = 0;
   }
   const int n_tiles = (k.n_t + 31) / 32;
   const int t0 = blockIdx.y * k.tiles_per_split;
   const int t1 = min(n_tiles, t0 + k.tiles_per_split);
-  // The four waves of a workgroup walk the same train tiles: a tile (32 x 128 B) and its 32 accumulator seeds are fetched
-  // from global memory once per workgroup (one 16-byte load per thread), handed over through LDS (double buffered, one
-  // barrier per tile) and read from there as MFMA operands; the next tile's loads are in flight during the MFMAs.
-  __shared__ __attribute__((aligned(16))) char s_tile[2 * MT_BYTES];
+  // The four waves of a workgroup walk the same train tiles: a tile (32 x 128 B), its 32 accumulator seeds and its 32 key
+  // constants are fetched from global memory once per workgroup (one 16-byte load per thread), handed over through LDS
+  // (double buffered, one barrier per tile) and read from there as MFMA operands; the next tile's loads are in flight
+  // during the MFMAs.
+  __shared__ __attribute__((aligned(16))) char s_tile[2 * MT2_BYTES];
   TileRegs nxt;
-  if (t0 < t1) { nxt = tile_fetch(tdesc, tc2n, t0); tile_store(s_tile, nxt); }
+  if (t0 < t1) { nxt = tile_fetch2(tdesc, tc2n, tc, t0); tile_store2(s_tile, nxt); }
   __syncthreads();
+#ifdef MATCH_STATS
+  unsigned int st_exact = 0, st_all = 0;
+#endif
   for (int tt = t0; tt < t1; tt++) {
-    const int tbase = tt * 32;
-    const char *cur = s_tile + ((tt - t0) & 1) * MT_BYTES;
-    if (tt + 1 < t1) nxt = tile_fetch(tdesc, tc2n, tt + 1);
+    const char *cur = s_tile + ((tt - t0) & 1) * MT2_BYTES;
+    if (tt + 1 < t1) nxt = tile_fetch2(tdesc, tc2n, tc, tt + 1);
     v4i a[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(cur + (lane & 31) * MT_ROW + ks * 32 + g * 16);
-    const unsigned int par = tpar[tt];   // wave-uniform: ct & 1 of the 32 train rows
     v16i acc[QB];
     acc[0] = acc_seed((const int *)(cur + 32 * MT_ROW), 0, g);
 #pragma unroll
@@ -186,62 +227,85 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
       for (int b = 0; b < QB; b++) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], bq[b][ks], acc[b], 0, 0, 0);
 #pragma unroll
     for (int b = 0; b < QB; b++) {
-      // -2*acc < thr  <=>  acc >= alim (one compare per accumulator)
-      const int alim = (-thr[b] >> 1) + 1;
-      // maxima of the four register groups (rows 8q + 4g .. 8q + 4g + 3): the exact path descends only into the groups
-      // that can hold a candidate (a wave takes the exact path as soon as ONE of its 64 lanes passes, and then every test
-      // inside it is a wave-level branch: 4 + 4 tests for the usual single candidate instead of 16)
-      int gm[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) gm[q] = max(max(max(acc[b][4 * q], acc[b][4 * q + 1]), acc[b][4 * q + 2]), acc[b][4 * q + 3]);
-      if (max(max(max(gm[0], gm[1]), gm[2]), gm[3]) >= alim) {   // some train of this tile may be among the two nearest so far
-        unsigned long long mine_b = s_keys[b][0][threadIdx.x], sec_b = s_keys[b][1][threadIdx.x];
+#ifdef MATCH_STATS
+      st_all++;
+#endif
+      // some train of this tile may be among the two nearest so far: a wave-level branch, every lane inserts its 16 values
+      // (harmless for the lanes that did not pass: the insertion is exact whatever the bound)
+#if MATCH_EXP & 8
+      if (acc[b][0] == 0x12345678) M1[b] = tt;
+      if (false) {
+#elif MATCH_EXP & 2
+      if (__any(acc_max16(acc[b]) >= alim[b] + (1 << 30))) {
+#elif MATCH_EXP & 4
+      if (__any(acc_max16(acc[b]) >= alim[b] - (1 << 30))) {
+#else
+      if (__any(acc_max16(acc[b]) >= alim[b])) {
+#endif
+#ifdef MATCH_STATS
+        st_exact++;
+#endif
+        const int4 *cp = (const int4 *)(cur + 32 * MT_ROW + 128);
+        const int m1o = M1[b], m2o = M2[b];
+        int m1 = m1o, m2 = m2o;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          if (gm[q] < alim) continue;
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const int r = 4 * q + e;
-            if (acc[b][r] < alim) continue;                                  // d - cq >= -2*acc >= thr
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
-            const int t = tbase + row;
-            const int dpr = (int)((par >> row) & 1u) - 2 * acc[b][r];       // exact
-            if (t >= k.n_t || !(dpr < thr[b])) continue;
-            const unsigned long long key = ((unsigned long long)(unsigned int)(dpr + cq[b]) << 32) | (unsigned int)t;
-            if (key < mine_b) { sec_b = mine_b; mine_b = key; }
-            else if (key < sec_b) sec_b = key;
-          }
+          const int4 c = cp[2 * q + g];   // rows 8q + 4g .. + 3
+          const int x0 = (acc[b][4 * q + 0] << 5) + c.x, x1 = (acc[b][4 * q + 1] << 5) + c.y;
+          const int x2 = (acc[b][4 * q + 2] << 5) + c.z, x3 = (acc[b][4 * q + 3] << 5) + c.w;
+          m2 = med3_i32(m1, m2, x0); m1 = max(m1, x0);
+          m2 = med3_i32(m1, m2, x1); m1 = max(m1, x1);
+          m2 = med3_i32(m1, m2, x2); m1 = max(m1, x2);
+          m2 = med3_i32(m1, m2, x3); m1 = max(m1, x3);
         }
-        s_keys[b][0][threadIdx.x] = mine_b; s_keys[b][1][threadIdx.x] = sec_b;
-        if (sec_b != ~0ull) thr[b] = min(thr[b], (int)(sec_b >> 32) - cq[b] + 1);    // an equal distance at a lower index still counts
+        const bool c1 = m1 != m1o;
+        T2[b] = (c1 && m2 == m1o) ? T1[b] : (m2 == m2o ? T2[b] : tt);
+        T1[b] = c1 ? tt : T1[b];
+        M1[b] = m1; M2[b] = m2;
+        // the two half-waves hold the same 32 queries (different train rows): the second key of their union is at least the
+        // larger of their second keys; an equal distance at a lower index still counts, hence k >= bound
+        int nb = max(bk[b], m2 >> 4);
+        nb = max(nb, __shfl_xor(nb, 32));
+        bk[b] = nb; alim[b] = (nb + 1) >> 1;
       }
-      // the two half-waves hold the same 32 queries (different train rows): the second key of their union is at most the
-      // smaller of their second keys
-      thr[b] = min(thr[b], __shfl_xor(thr[b], 32));
     }
-    if (((tt - t0) & 15) == 15) {   // publish / pick up the bound every 16 tiles
+    if (!(MATCH_EXP & 1) && ((tt - t0) & 15) == 15) {   // publish / pick up the bound every 16 tiles
 #pragma unroll
       for (int b = 0; b < QB; b++) {
         const int j = jbase + 32 * b;
-        if (g == 0 && j < k.n_q) thr[b] = min(thr[b], atomicMin(&gthr[j], thr[b]));
-        thr[b] = min(thr[b], __shfl_xor(thr[b], 32));
+        int nb = bk[b];
+        if (g == 0 && j < k.n_q) nb = max(nb, 1 - atomicMin(&gthr[j], 1 - nb));
+        nb = max(nb, __shfl_xor(nb, 32));
+        bk[b] = nb; alim[b] = (nb + 1) >> 1;
       }
     }
-    if (tt + 1 < t1) tile_store(s_tile + (((tt - t0) & 1) ^ 1) * MT_BYTES, nxt);
+    if (tt + 1 < t1) tile_store2(s_tile + (((tt - t0) & 1) ^ 1) * MT2_BYTES, nxt);
     __syncthreads();
   }
+#ifdef MATCH_STATS
+  if (lane == 0) { atomicAdd(&g_match_stats[0], (unsigned long long)st_all); atomicAdd(&g_match_stats[1], (unsigned long long)st_exact); }
+#endif
   const size_t n_qpad = (size_t)gridDim.x * 128 * QB;
 #pragma unroll
   for (int b = 0; b < QB; b++) {
-    const unsigned long long mine_b = s_keys[b][0][threadIdx.x], sec_b = s_keys[b][1][threadIdx.x];
+    const int j = jbase + 32 * b;
+    const int cqv = qc[j < k.n_q ? j : k.n_q - 1] - 4194304;
+    unsigned long long mine_b = ~0ull, sec_b = ~0ull;
+    {
+      const int r = 15 - (M1[b] & 15), t = T1[b] * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (M1[b] != NONE && t < k.n_t) mine_b = ((unsigned long long)(unsigned int)(cqv - (M1[b] >> 4)) << 32) | (unsigned int)t;
+    }
+    {
+      const int r = 15 - (M2[b] & 15), t = T2[b] * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (M2[b] != NONE && t < k.n_t) sec_b = ((unsigned long long)(unsigned int)(cqv - (M2[b] >> 4)) << 32) | (unsigned int)t;
+    }
     const unsigned long long o1 = shfl_xor_u64(mine_b, 32), o2 = shfl_xor_u64(sec_b, 32);
     const unsigned long long m1 = mine_b < o1 ? mine_b : o1;
     const unsigned long long hi = mine_b < o1 ? o1 : mine_b;
     const unsigned long long lo2 = sec_b < o2 ? sec_b : o2;
     const unsigned long long m2 = hi < lo2 ? hi : lo2;
-    const int j = jbase + 32 * b;
     if (g == 0 && j < k.n_q) {
-      atomicMin(&gthr[j], thr[b]);
+      atomicMin(&gthr[j], 1 - bk[b]);
       unsigned long long *o = best2 + ((size_t)blockIdx.y * n_qpad + j) * 2;
       o[0] = m1; o[1] = m2;
     }
@@ -710,3 +774,13 @@ int match_run_distance(mods_ctx *ctx, const mods_region *q_dev, int n_q, const m
 }
 
 }  // namespace mods
+
+#ifdef MATCH_STATS
+// development aid: (query block, tile) pairs visited / taken through the exact path by match_nn1_kernel since the last call
+extern "C" void mods_debug_match_stats(unsigned long long out[2]) {
+  unsigned long long z[4] = {0, 0, 0, 0};
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mods::g_match_stats), 16);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(mods::g_match_stats), z, 32);
+}
+#endif

@@ -103,7 +103,8 @@ int match_distance(const std::vector<Region> &list1, const std::vector<Region> &
 }
 
 // DuplicateFiltering, matching.cpp:2615-2679.  mode 1 = MODE_FGINN (sort by ratio), 2 =
-// MODE_DISTANCE (sort by d1), 0 = MODE_RANDOM (keep order).  std::sort is unstable on equal
+// MODE_DISTANCE (sort by d1), 3 = MODE_BIGGER_REGION (sort by |s| of the first image's region, ascending:
+// CompareCorrespondenceByScale, matching.cpp:74), 0 = MODE_RANDOM (keep order).  std::sort is unstable on equal
 // keys; ties are fixed here as list order (stable sort).
 void duplicate_filter(std::vector<Tentative> &tc, const std::vector<Region> &q, const std::vector<Region> &t,
                       double r, int mode) {
@@ -113,6 +114,8 @@ void duplicate_filter(std::vector<Tentative> &tc, const std::vector<Region> &q, 
     std::stable_sort(tc.begin(), tc.end(), [](const Tentative &a, const Tentative &b) { return std::fabs(a.ratio) < std::fabs(b.ratio); });
   else if (mode == 2)
     std::stable_sort(tc.begin(), tc.end(), [](const Tentative &a, const Tentative &b) { return std::fabs((double)a.d1) < std::fabs((double)b.d1); });
+  else if (mode == 3)
+    std::stable_sort(tc.begin(), tc.end(), [&](const Tentative &a, const Tentative &b) { return std::fabs((double)q[a.q].s) < std::fabs((double)q[b.q].s); });
   const size_t n = tc.size();
   std::vector<char> uniq(n, 1);
   for (size_t i = 0; i < n; i++) {

@@ -68,10 +68,13 @@ def test_duplicate_filter_matches_oracle(pkg):
     tc["ratio"] = np.round(rng.uniform(0.2, 0.8, n), 2)        # many equal keys: stable order matters
     tc["d1"] = rng.integers(100, 9000, n)
     u6 = np.c_[q["x"][tc["q"]], q["y"][tc["q"]], np.ones(n), t["x"][tc["t"]], t["y"][tc["t"]], np.ones(n)]
-    for mode in (0, 1, 2):
+    q["s"] = np.round(rng.uniform(1.5, 40.0, n), 1) * rng.choice([-1.0, 1.0], n)   # biggerRegion sorts by |s|; equal keys exist
+    laf = np.zeros((n, 14)); laf[:, 6] = q["s"][tc["q"]]
+    for mode in (0, 1, 2, 3):
         for r in (2.0, 0.5, 7.0):
             want = orc.duplicate_filter(tc, q, t, r, mode)
-            got, gu = pkg.duplicate_filter(tc, u6, r, mode)
+            got, gu, gl = pkg.duplicate_filter(tc, u6, r, mode, laf)
+            assert np.array_equal(gl[:, 6], q["s"][got["q"]])
             assert len(got) == len(want) < n
             for f in ("q", "t", "ratio", "d1"):
                 assert np.array_equal(got[f], want[f])

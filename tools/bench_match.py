@@ -50,9 +50,16 @@ def main():
         wall = (time.time() - t0) / reps
         ms, n, _ = ctx.timing_read("match")
         ops = 2.0 * len(a) * len(b) * 128
+        if hasattr(pkg.lib(), "mods_debug_match_stats"):    # library built with -DMATCH_STATS
+            import ctypes
+            st = (ctypes.c_ulonglong * 2)()
+            pkg.lib().mods_debug_match_stats(st)
+            print("nn1 exact path: %d of %d (query block, tile) pairs = %.3f" % (st[1], st[0], st[1] / max(1, st[0])))
         print("%s: %d x %d, %d tentatives, match stage %.4f ms (%.1f TOP/s, %.3f of 5 POP/s), wall %.3f ms, checksum %d"
               % (name, len(a), len(b), len(tent), ms / reps, ops / (ms / reps * 1e-3) / 1e12, ops / (ms / reps * 1e-3) / 5e15, wall * 1e3,
                  int(tent["t"].astype(np.int64).sum() + tent["q"].astype(np.int64).sum())))
+    if "--c5only" in sys.argv:
+        return
     # one 1080p pair (configs[1] size)
     n1, n2 = 10040, 8969
     r1, r2 = pkg.ImgRep(ctx, 1 << 15), pkg.ImgRep(ctx, 1 << 15)
