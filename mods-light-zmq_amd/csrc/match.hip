@@ -225,6 +225,11 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
     for (int ks = 0; ks < 4; ks++)
 #pragma unroll
       for (int b = 0; b < QB; b++) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], bq[b][ks], acc[b], 0, 0, 0);
+    // key constants of this lane's 16 rows: read for every tile (they share the A operands' dead registers), so that the exact
+    // path does not start with an LDS round trip
+    int4 ck[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) ck[q] = ((const int4 *)(cur + 32 * MT_ROW + 128))[2 * q + g];
 #pragma unroll
     for (int b = 0; b < QB; b++) {
 #ifdef MATCH_STATS
@@ -245,18 +250,25 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
 #ifdef MATCH_STATS
         st_exact++;
 #endif
-        const int4 *cp = (const int4 *)(cur + 32 * MT_ROW + 128);
         const int m1o = M1[b], m2o = M2[b];
-        int m1 = m1o, m2 = m2o;
+        // two independent insertion chains (even / odd register pairs) and one merge: half the dependent depth of a single
+        // chain of 16 insertions (the exact path is latency, not issue, that the other waves of the workgroup wait for)
+        int m1 = m1o, m2 = m2o, n1 = NONE, n2 = NONE;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const int4 c = cp[2 * q + g];   // rows 8q + 4g .. + 3
+          const int4 c = ck[q];   // rows 8q + 4g .. + 3
           const int x0 = (acc[b][4 * q + 0] << 5) + c.x, x1 = (acc[b][4 * q + 1] << 5) + c.y;
           const int x2 = (acc[b][4 * q + 2] << 5) + c.z, x3 = (acc[b][4 * q + 3] << 5) + c.w;
           m2 = med3_i32(m1, m2, x0); m1 = max(m1, x0);
-          m2 = med3_i32(m1, m2, x1); m1 = max(m1, x1);
+          n2 = med3_i32(n1, n2, x1); n1 = max(n1, x1);
           m2 = med3_i32(m1, m2, x2); m1 = max(m1, x2);
-          m2 = med3_i32(m1, m2, x3); m1 = max(m1, x3);
+          n2 = med3_i32(n1, n2, x3); n1 = max(n1, x3);
+        }
+        // top 2 of {m1 >= m2} and {n1 >= n2}: the second is the median of (smaller top, larger second, larger top)
+        {
+          const int hi = max(m1, n1), lo = min(m1, n1);
+          m2 = max(lo, max(m2, n2));
+          m1 = hi;
         }
         const bool c1 = m1 != m1o;
         T2[b] = (c1 && m2 == m1o) ? T1[b] : (m2 == m2o ? T2[b] : tt);
@@ -403,10 +415,18 @@ __global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const in
   constexpr int QB = MATCH_QB;
   // the query list of this pass is the compact list of match_mid_kernel: its length lives on the device, and results go to
   // the slots of the original queries
+  // the grid is ONE row of workgroups: the few query blocks the compact list fills share it, each with as many train splits
+  // as fit (a list of a few hundred queries would otherwise occupy a few workgroups for the length of the whole train list)
   k.n_q = *n_q_dev;
-  if ((int)blockIdx.x * 4 * 32 * QB >= k.n_q) return;
+  const int n_qb = (k.n_q + 4 * 32 * QB - 1) / (4 * 32 * QB);
+  if (n_qb == 0) return;
+  const int n_tiles = (k.n_t + 31) / 32;
+  int splits = max(1, min(n_tiles, (int)gridDim.x / n_qb));
+  const int tps = (n_tiles + splits - 1) / splits;
+  const int qb = blockIdx.x % n_qb, sp = blockIdx.x / n_qb;
+  if (sp * tps >= n_tiles) return;
   const int lane = threadIdx.x & 63, g = lane >> 5;
-  const int jbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
+  const int jbase = (qb * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
   v4i bq[QB][4];
   int cq[QB], thr[QB], cnt[QB], isbad[QB], i0[QB], dstar[QB];
   double x0[QB], y0[QB];
@@ -423,9 +443,8 @@ __global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const in
     thr[b] = 0x7fffffff;          // until a distance >= D* has been seen every tile is examined
     kge[b] = ~0ull; klt[b] = ~0ull; cnt[b] = 0; isbad[b] = 0;
   }
-  const int n_tiles = (k.n_t + 31) / 32;
-  const int t0 = blockIdx.y * k.tiles_per_split;
-  const int t1 = min(n_tiles, t0 + k.tiles_per_split);
+  const int t0 = sp * tps;
+  const int t1 = min(n_tiles, t0 + tps);
 #ifdef MATCH_FGINN_SHARED
   // The four waves of a workgroup walk the same train tiles: a tile (32 x 128 B) and its 32 accumulator seeds are fetched
   // from global memory once per workgroup (one 16-byte load per thread), handed over through LDS (double buffered, one
@@ -687,10 +706,7 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
                      (const QueryMid *)ctx->m_mid, qd2, qcs, mid2);
   {
     const int qblocks = (n_q + 128 * MATCH_QB - 1) / (128 * MATCH_QB);
-    int splits = std::max(1, std::min(n_tiles, std::max(32, target_blocks / std::max(1, qblocks))));
-    k.tiles_per_split = (n_tiles + splits - 1) / splits;
-    splits = (n_tiles + k.tiles_per_split - 1) / k.tiles_per_split;
-    hipLaunchKernelGGL(match_fginn_kernel, dim3(qblocks, splits), dim3(256), 0, ctx->stream, k, qd2, qcs, td, tc, tc2, tpar, txy,
+    hipLaunchKernelGGL(match_fginn_kernel, dim3(std::max(target_blocks, qblocks)), dim3(256), 0, ctx->stream, k, qd2, qcs, td, tc, tc2, tpar, txy,
                        (const QueryMid *)mid2, key_ge, key_lt, n_lt, bad, count2, list2);
   }
   const int eblocks = (n_q + 1023) / 1024;
