@@ -118,7 +118,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->pyr_dev); (void)hipFree(c->plane_pool); (void)hipFree(c->omap_pool); (void)hipFree(c->input_dev); (void)hipFree(c->u8_stage_dev);
   (void)hipFree(c->tmp_dev); (void)hipFree(c->alt_taps_dev); (void)hipFree(c->alt_planes); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
-  (void)hipHostFree(c->host_counts);
+  (void)hipHostFree(c->host_counts); (void)hipHostFree(c->pin_arena);
   (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
@@ -730,6 +730,8 @@ int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int str
   return MODS_OK;
 }
 
+constexpr size_t kPinArena = (size_t)24 << 20;   // pinned staging of a batch's tentative lists
+
 // 8-bit grey -> float (the ImageRepresentation constructor's convertTo(CV_32F), imagerepresentation.cpp:293-302): exact
 __global__ __launch_bounds__(256) void u8_to_f32_kernel(const unsigned char *__restrict__ src, float *__restrict__ dst, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -750,6 +752,7 @@ int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_pair_params
   if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("warmup: image larger than the context"); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   if (!c->u8_stage_dev) MODS_HIP_CHECK(hipMalloc(&c->u8_stage_dev, (size_t)c->max_w * c->max_h * c->batch + 16));
+  if (!c->pin_arena) { MODS_HIP_CHECK(hipHostMalloc(&c->pin_arena, kPinArena)); c->pin_arena_cap = kPinArena; }
   std::vector<float> img((size_t)w * h);
   for (int y = 0; y < h; y++)
     for (int x = 0; x < w; x++)   // blobs every 14 px on top of blobs every 90 px: a few thousand regions of both patch tiers
@@ -797,6 +800,13 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
   const double t0 = now_ms();
   if ((rc = mods_detect_describe_dev(c, c->input_dev, n_img, w, h, w, &par->det, &par->desc, nd.data(), nr.data()))) return rc;
   const double t1 = now_ms();
+  // The tentative lists of the batch go to the host through a pinned arena: the three copies of a pair are plain DMA
+  // transfers queued behind its match kernels, the stream is synchronised once per pair for the COUNT only (4 bytes) and once
+  // per batch for the lists; a pair that does not fit the arena takes the direct (pageable, synchronous) path.
+  if (!c->pin_arena) { MODS_HIP_CHECK(hipHostMalloc(&c->pin_arena, kPinArena)); c->pin_arena_cap = kPinArena; }
+  int *pin_n = c->host_counts;                   // pinned; free between detect_describe's read-back and the next batch
+  std::vector<size_t> off(n_pairs, (size_t)-1);
+  size_t used = 0;
   for (int i = 0; i < n_pairs; i++) {
     const double tm0 = now_ms();
     mods_pair_result *r = res[i];
@@ -805,19 +815,37 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
     r->ms_detect_describe = (t1 - t0) / n_pairs;
     if ((rc = match_run(c, c->regions_dev + (size_t)(2 * i) * c->max_cand, nr[2 * i], c->regions_dev + (size_t)(2 * i + 1) * c->max_cand,
                         nr[2 * i + 1], par->fginn_ratio, par->contradDist, par->nn))) return rc;
-    int n = 0;
-    MODS_HIP_CHECK(hipMemcpyAsync(&n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MODS_HIP_CHECK(hipMemcpyAsync(pin_n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const int n = *pin_n;
     r->n_tentatives = n;
     if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
     tent[i]->resize(n); u6[i]->resize((size_t)n * 6); laf[i]->resize((size_t)n * 14);
     if (n > 0) {
-      MODS_HIP_CHECK(hipMemcpyAsync(tent[i]->data(), c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost, c->stream));
-      MODS_HIP_CHECK(hipMemcpyAsync(u6[i]->data(), c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, c->stream));
-      MODS_HIP_CHECK(hipMemcpyAsync(laf[i]->data(), c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost, c->stream));
-      MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+      const size_t b_t = sizeof(mods_tentative) * n, b_u = sizeof(double) * 6 * n, b_l = sizeof(double) * 14 * n;
+      if (used + b_t + b_u + b_l <= c->pin_arena_cap) {
+        char *a = c->pin_arena + used;
+        MODS_HIP_CHECK(hipMemcpyAsync(a, c->m_tent, b_t, hipMemcpyDeviceToHost, c->stream));
+        MODS_HIP_CHECK(hipMemcpyAsync(a + b_t, c->m_u6, b_u, hipMemcpyDeviceToHost, c->stream));
+        MODS_HIP_CHECK(hipMemcpyAsync(a + b_t + b_u, c->m_laf, b_l, hipMemcpyDeviceToHost, c->stream));
+        off[i] = used; used += b_t + b_u + b_l;
+      } else {
+        MODS_HIP_CHECK(hipMemcpyAsync(tent[i]->data(), c->m_tent, b_t, hipMemcpyDeviceToHost, c->stream));
+        MODS_HIP_CHECK(hipMemcpyAsync(u6[i]->data(), c->m_u6, b_u, hipMemcpyDeviceToHost, c->stream));
+        MODS_HIP_CHECK(hipMemcpyAsync(laf[i]->data(), c->m_laf, b_l, hipMemcpyDeviceToHost, c->stream));
+        MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+      }
     }
     r->ms_match = now_ms() - tm0;
+  }
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n_pairs; i++) {
+    if (off[i] == (size_t)-1) continue;
+    const size_t n = tent[i]->size();
+    const char *a = c->pin_arena + off[i];
+    memcpy(tent[i]->data(), a, sizeof(mods_tentative) * n);
+    memcpy(u6[i]->data(), a + sizeof(mods_tentative) * n, sizeof(double) * 6 * n);
+    memcpy(laf[i]->data(), a + sizeof(mods_tentative) * n + sizeof(double) * 6 * n, sizeof(double) * 14 * n);
   }
   return MODS_OK;
 }

@@ -100,6 +100,8 @@ struct mods_ctx {
   int *key_count = nullptr;          // [batch]
   int *host_counts = nullptr;        // pinned
   unsigned char *u8_stage_dev = nullptr;   // [batch][max_h][max_w] staging of 8-bit host images (pair pipeline), lazily allocated
+  char *pin_arena = nullptr;         // pinned host staging of a batch's tentative lists (pair pipeline), lazily allocated
+  size_t pin_arena_cap = 0;
   mods_hessaff_params par;
   int reg_number_eff = -1;           // par.regionsNumber after the tilt / zoom scaling of DetectAffineKeypoints (scale-space-detector.cpp:20-21)
   int last_w = 0, last_h = 0, last_n_img = 0;
