@@ -166,6 +166,8 @@ typedef struct mods_describe_params {
                               that passes DetectOrientation's border test is described too; those copies come first in the list */
   int halfDesc;            /* 1: also HalfRootSIFT (64 values: orientation bins j and j + 4 of the raw histogram added, then the
                               RootSIFT normalisation) for the same regions, see mods_regions_half_dev */
+  int fastExtraction;      /* [SIFTDescriptor] FastPatchExtraction: the fast branch of DescribeRegions (synth-detection.hpp:232-253): one
+                              interpolate() of the image at imageToPatchScale = (2*int(mrSize*s)+1)/patchSize (double), no smoothing */
 } mods_describe_params;
 
 /* Replaces, for one identity view (H = I), the chain of imagerepresentation.cpp:867-968:

@@ -66,12 +66,12 @@ class DescribeParams(C.Structure):
     _fields_ = [("ori_mrSize", C.c_double), ("ori_patchSize", C.c_int), ("ori_maxAngles", C.c_int),
                 ("ori_threshold", C.c_double), ("desc_mrSize", C.c_double), ("desc_patchSize", C.c_int),
                 ("photoNorm", C.c_int), ("rootSift", C.c_int), ("maxBinValue", C.c_double),
-                ("ori_halfMode", C.c_int), ("addUpRight", C.c_int), ("halfDesc", C.c_int)]
+                ("ori_halfMode", C.c_int), ("addUpRight", C.c_int), ("halfDesc", C.c_int), ("fastExtraction", C.c_int)]
 
     @staticmethod
     def default():
         # config_affori_classic.ini; threshold is parsed into a float member (descriptors_parameters.hpp:10)
-        return DescribeParams(5.1962, 32, 1, float(np.float32(0.8)), 5.1962, 41, 1, 1, 0.2, 0, 0, 0)
+        return DescribeParams(5.1962, 32, 1, float(np.float32(0.8)), 5.1962, 41, 1, 1, 0.2, 0, 0, 0, 0)
 
 
 _lib = None

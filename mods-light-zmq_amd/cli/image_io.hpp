@@ -1,12 +1,13 @@
-// Image input of the mods CLI: PNG (libpng) and binary PGM/PPM, to a grey float image.
+// Image input of the mods CLI: PNG (libpng), JPEG (libjpeg) and binary PGM/PPM, to a grey float image.
 //
 // Reference behaviour: cv::imread (mods.cpp:116-118).  With [Computing] LoadColor=1 a colour file stays
 // colour and GenerateSynthImageCorr averages it, (B + G + R) / 3.0 on float planes (synth-detection.cpp:343-354): a cv::MatExpr
 // that OpenCV evaluates as addWeighted(B + G, 1/3, R, 1/3, 0) with float weights, fused: fma(B + G, a, R * a), a = (float)(1/3.)
 // (the reading that reproduces the reference's README counts, tools/readme_count_hunt.py);
 // with LoadColor=0 imread itself converts, i.e. OpenCV's fixed-point BT.601 luma
-// (R*4899 + G*9617 + B*1868 + 8192) >> 14.  PNG decoding is exact; JPEG is not available in this build
-// (no libjpeg) and is reported as an error.
+// (R*4899 + G*9617 + B*1868 + 8192) >> 14.  PNG decoding is exact; JPEG is decoded with the image's libjpeg (ISLOW DCT, the
+// library default, fancy upsampling on): a JPEG decoder's output is only defined up to +-1 per sample, so pixel values can
+// differ from those of the libjpeg-turbo that an OpenCV build carries.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -78,6 +79,21 @@ static bool read_png(const std::string &fn, bool average, GreyImage *out, std::s
   return true;
 }
 
+// libmodsjpeg.so (cli/jpeg_read.c): the decoder sits behind a C function so that only that library carries the run path of
+// the tree libjpeg lives in
+extern "C" int mods_jpeg_read(const char *fn, int colour, unsigned char **out, int *w, int *h, int *ch, char *err);
+extern "C" void mods_jpeg_free(unsigned char *p);
+static bool read_jpeg(const std::string &fn, bool average, GreyImage *out, std::string *err) {
+  unsigned char *buf = nullptr;
+  int w = 0, h = 0, ch = 0;
+  char msg[256] = {0};
+  if (mods_jpeg_read(fn.c_str(), average ? 1 : 0, &buf, &w, &h, &ch, msg)) { *err = msg; return false; }
+  out->w = w; out->h = h; out->px.resize((size_t)w * h);
+  for (size_t i = 0; i < (size_t)w * h; i++) out->px[i] = ch == 1 ? (float)buf[i] : grey_of(&buf[3 * i], average);
+  mods_jpeg_free(buf);
+  return true;
+}
+
 // average = true: LoadColor=1 semantics ((B+G+R)/3); false: imread-as-grey semantics
 static bool read_image(const std::string &fn, bool average, GreyImage *out, std::string *err) {
   FILE *f = fopen(fn.c_str(), "rb");
@@ -87,8 +103,8 @@ static bool read_image(const std::string &fn, bool average, GreyImage *out, std:
   fclose(f);
   if (n >= 8 && !png_sig_cmp(sig, 0, 8)) return read_png(fn, average, out, err);
   if (n >= 2 && sig[0] == 'P' && (sig[1] == '5' || sig[1] == '6')) return read_pnm(fn, average, out, err);
-  if (n >= 2 && sig[0] == 0xFF && sig[1] == 0xD8) { *err = fn + ": JPEG input is not supported by this build (convert to PNG or PPM)"; return false; }
-  *err = fn + ": unknown image format (PNG, binary PGM/PPM supported)";
+  if (n >= 2 && sig[0] == 0xFF && sig[1] == 0xD8) return read_jpeg(fn, average, out, err);
+  *err = fn + ": unknown image format (PNG, JPEG, binary PGM/PPM supported)";
   return false;
 }
 

@@ -117,7 +117,7 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   q.photoNorm = ini.GetBoolean("SIFTDescriptor", "photoNorm", true) ? 1 : 0;
   q.rootSift = 1;
   q.maxBinValue = ini.GetDouble("SIFTDescriptor", "maxBinValue", 0.2);
-  if (ini.GetBoolean("SIFTDescriptor", "FastPatchExtraction", false)) std::cerr << "Warning: FastPatchExtraction is not supported, the exact extraction is used" << std::endl;
+  q.fastExtraction = ini.GetBoolean("SIFTDescriptor", "FastPatchExtraction", false) ? 1 : 0;
   if (ini.GetInteger("SIFTDescriptor", "spatialBins", 4) != 4 || ini.GetInteger("SIFTDescriptor", "orientationBins", 8) != 8) {
     std::cerr << "Only 4x4x8 SIFT is supported" << std::endl;
     return 1;

@@ -637,8 +637,9 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   k.ori_half = par->ori_halfMode; k.half_desc = 0; k.add_upright = par->addUpRight;
   k.desc_mr = par->desc_mrSize; k.desc_ps = par->desc_patchSize; k.photo = par->photoNorm; k.root = par->rootSift;
   k.max_bin = par->maxBinValue;
-  k.patch_rule = 0;
+  k.patch_rule = par->fastExtraction ? 2 : 0;
   const bool external = ctx->ext_fn != nullptr;
+  if (external && par->fastExtraction) { set_error("FastPatchExtraction with an external descriptor is not supported"); return MODS_E_ARG; }
   if (external) { k.desc_mr = ctx->ext_mr; k.desc_ps = ctx->ext_ps; k.photo = 0; k.patch_rule = 1; }
   int *key_count = ctx->cand_count + 2 * ctx->batch;
   const float *orimask = ctx->desc_tables_dev, *dmask = ctx->desc_tables_dev + 4096;

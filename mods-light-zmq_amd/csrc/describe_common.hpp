@@ -26,7 +26,8 @@ struct DescConst {
   // synthesised view (H != I): keypoints live in the view frame; the inside / touch-boundary tests of
   // ReprojectRegions* run on their reprojection into the original image (ow x oh) through Hinv
   int patch_rule;          // size of the sampled region: 0 = DescribeRegions (2*ceil(s*mr)+1, synth-detection.hpp:189),
-                           // 1 = ExtractPatchesColumn (the same for odd patch sizes, 2*ceil(s*mr) for even ones, synth-detection.cpp:57)
+                           // 1 = ExtractPatchesColumn (the same for odd patch sizes, 2*ceil(s*mr) for even ones, synth-detection.cpp:57),
+                           // 2 = the fast branch of DescribeRegions (direct interpolation at (2*int(mr*s)+1)/patchSize, :232-253)
   int view;                // 0: identity view (reproj_kp == det_kp)
   int ow, oh;
   double Hinv[6];          // affine part of inv(H), row-major 2x3

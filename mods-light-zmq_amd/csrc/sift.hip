@@ -35,12 +35,18 @@ struct RegionGeom {             // per-region constants of DescribeRegions
 
 __device__ __forceinline__ RegionGeom region_geom(const mods_region &r, double desc_mr, int ps, int patch_rule) {
   RegionGeom g;
+  g.fx = (float)r.x; g.fy = (float)r.y;
+  g.f11 = (float)r.a11; g.f12 = (float)r.a12; g.f21 = (float)r.a21; g.f22 = (float)r.a22;
+  if (patch_rule == 2) {   // fast branch of DescribeRegions, synth-detection.hpp:232-253: always the direct interpolation
+    const double mrs = desc_mr * r.s;
+    g.scale = (float)(double(2 * int(mrs) + 1) / (double)ps);
+    g.P2 = 0;
+    return g;
+  }
   const float mrScale = (float)ceil(r.s * desc_mr);
   const int P = (patch_rule == 0 || (ps & 1)) ? 2 * int(mrScale) + 1 : 2 * int(mrScale);
   g.scale = float(P) / float(ps);
   g.P2 = ((double)g.scale > 0.4) ? P + 2 : 0;
-  g.fx = (float)r.x; g.fy = (float)r.y;
-  g.f11 = (float)r.a11; g.f12 = (float)r.a12; g.f21 = (float)r.a21; g.f22 = (float)r.a22;
   return g;
 }
 

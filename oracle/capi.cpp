@@ -298,10 +298,10 @@ int orc_detect_describe_ex(const float *img, int w, int h, const orc_hessaff_par
   filter_touch_boundary(o, w, h);
   if ((flags & 2) && out_half) {
     std::vector<Region> hv = o;
-    describe_rootsift(hv, im, desc_mrSize, desc_patchSize, photoNorm != 0, true);
+    describe_rootsift(hv, im, desc_mrSize, desc_patchSize, photoNorm != 0, true, (flags & 8) != 0);
     from_regions(hv, out_half, max_out);
   }
-  describe_rootsift(o, im, desc_mrSize, desc_patchSize, photoNorm != 0);
+  describe_rootsift(o, im, desc_mrSize, desc_patchSize, photoNorm != 0, false, (flags & 8) != 0);   // bit 3: [SIFTDescriptor] FastPatchExtraction
   return from_regions(o, out, max_out);
 }
 int orc_detect_describe(const float *img, int w, int h, const orc_hessaff_params *p, double ori_mrSize,

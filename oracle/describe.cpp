@@ -391,10 +391,23 @@ void sift_patch_to_desc(const Img &patch, uint8_t out[128], bool rootsift, doubl
 
 // Non-fast branch of DescribeRegions<>, synth-detection.hpp:186-231; with column_rule the same code as it appears in
 // ExtractPatchesColumn, synth-detection.cpp:52-102 (the sampled region is 2*ceil(s*mr) wide for even patch sizes).
-void extract_desc_patch(const Region &k, const Img &img, double mrSize, int patchSize, bool photoNorm, Img &patch, bool column_rule) {
+void extract_desc_patch(const Region &k, const Img &img, double mrSize, int patchSize, bool photoNorm, Img &patch, bool column_rule, bool fast) {
   static thread_local Img mask;
   if (mask.w != patchSize) { mask = Img(patchSize, patchSize); compute_circular_gauss_mask(mask, 0); }
   if (patch.w != patchSize || patch.h != patchSize) patch = Img(patchSize, patchSize);
+  if (fast) {   // the fast_extraction branch of DescribeRegions<>, synth-detection.hpp:232-253
+    double mrScale = (double)mrSize * k.s;
+    int patchImageSize = 2 * int(mrScale) + 1;
+    double imageToPatchScale = double(patchImageSize) / (double)patchSize;
+    float curr_sc = imageToPatchScale;
+    interpolate(img, (float)k.x, (float)k.y, (float)k.a11 * curr_sc, (float)k.a12 * curr_sc, (float)k.a21 * curr_sc,
+                (float)k.a22 * curr_sc, patch);
+    if (photoNorm) {
+      float mean, var;
+      photometrically_normalize(patch, mask, mean, var);
+    }
+    return;
+  }
   float mrScale = (float)std::ceil(k.s * mrSize);
   int patchImageSize = (!column_rule || patchSize % 2 != 0) ? 2 * int(mrScale) + 1 : 2 * int(mrScale);
   float imageToPatchScale = float(patchImageSize) / float(patchSize);
@@ -415,13 +428,13 @@ void extract_desc_patch(const Region &k, const Img &img, double mrSize, int patc
   }
 }
 
-void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize, bool photoNorm, bool half) {
+void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize, bool photoNorm, bool half, bool fast) {
 #pragma omp parallel num_threads(g_threads)
   {
     Img patch(patchSize, patchSize);
 #pragma omp for schedule(dynamic, 16)
     for (long i = 0; i < (long)r.size(); i++) {
-      extract_desc_patch(r[i], img, mrSize, patchSize, photoNorm, patch);
+      extract_desc_patch(r[i], img, mrSize, patchSize, photoNorm, patch, false, fast);
       sift_patch_to_desc(patch, r[i].desc, true, 0.2, half);   // [SIFTDescriptor] maxBinValue = 0.2 (io_mods.cpp:427)
     }
   }

@@ -135,10 +135,10 @@ bool h_is_eye(const double *H);                                             // s
 void filter_centres_inside_view(std::vector<Region> &det, const double *H, int orig_w, int orig_h);
 void reproject_regions_view(std::vector<Region> &det, std::vector<Region> &rep, const double *H, int orig_w, int orig_h);
 void describe_rootsift(std::vector<Region> &r, const Img &img, double mrSize, int patchSize,
-                       bool photoNorm, bool half = false);                  // synth-detection.hpp:170-263 (half: HalfRootSIFT, 64 values)
+                       bool photoNorm, bool half = false, bool fast = false);                  // synth-detection.hpp:170-263 (half: HalfRootSIFT, 64 values)
 void sift_patch_to_desc(const Img &patch41, uint8_t out[128], bool rootsift, double maxBinValue = 0.2, bool half = false);   // matching/siftdesc.cpp
 void extract_desc_patch(const Region &r, const Img &img, double mrSize, int patchSize, bool photoNorm,
-                        Img &patch, bool column_rule = false);
+                        Img &patch, bool column_rule = false, bool fast = false);
 bool dominant_angle(const Img &patch, double th, float *angle, bool half = false);   // :836-929 (maxAngles=1)
 
 // ---- matching (match.cpp) ------------------------------------------------------------------

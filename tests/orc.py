@@ -286,7 +286,8 @@ def describe_rootsift(img, regions, mrsize=DESC_MRSIZE, ps=DESC_PATCH, photonorm
     return r
 
 
-def detect_describe(img, params=None, max_out=1 << 18, half_orientation=False, half_desc=False, add_upright=False, max_angles=None):
+def detect_describe(img, params=None, max_out=1 << 18, half_orientation=False, half_desc=False, add_upright=False, max_angles=None,
+                    fast_extraction=False):
     """HessianAffine + RootSIFT for one identity view; returns (regions, n_detected).  half_orientation: DetectOrientation in
     doHalfSIFT mode (what the reference does for a step whose descriptor list names a Half* descriptor); half_desc: also the
     HalfRootSIFT descriptors of the same regions -> (regions, half regions, n_detected)."""
@@ -295,7 +296,7 @@ def detect_describe(img, params=None, max_out=1 << 18, half_orientation=False, h
     out = np.zeros(max_out, REGION_DTYPE)
     outh = np.zeros(max_out if half_desc else 1, REGION_DTYPE)
     ndet = C.c_int()
-    flags = (1 if half_orientation else 0) | (2 if half_desc else 0) | (4 if add_upright else 0)
+    flags = (1 if half_orientation else 0) | (2 if half_desc else 0) | (4 if add_upright else 0) | (8 if fast_extraction else 0)
     n = lib().orc_detect_describe_ex(p, a.shape[1], a.shape[0], C.byref(params), C.c_double(ORI_MRSIZE), ORI_PATCH,
                                      ORI_MAXANG if max_angles is None else max_angles, C.c_double(ORI_TH), C.c_double(DESC_MRSIZE), DESC_PATCH, 1, flags,
                                      out.ctypes.data_as(C.c_void_p), outh.ctypes.data_as(C.c_void_p) if half_desc else None, max_out,

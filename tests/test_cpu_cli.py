@@ -111,3 +111,38 @@ def test_npz_reader_refuses_malformed_archives(tmp_path):
     for cut in range(0, len(good) - 1, 37):
         rc, _ = echo(good[:cut])
         assert rc > 0, cut
+
+
+def test_jpeg_input(tmp_path):
+    """JPEG files (cv::imread, mods.cpp:116-118) are decoded by libmodsjpeg.so: colour and grey files, both LoadColor settings;
+    the decoder's output agrees with PIL's decoder within the +-1 a JPEG decoder is specified to."""
+    import ctypes as C
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:96, 0:128]
+    rgb = np.stack([127 + 100 * np.sin(xx / 9.0), 127 + 100 * np.cos(yy / 7.0), 60 + xx], -1).clip(0, 255).astype(np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "c.jpg", quality=92, subsampling=0)
+    Image.fromarray(rgb[:, :, 1]).save(tmp_path / "g.jpg", quality=92)
+    lib = C.CDLL(os.path.join(ROOT, "mods-light-zmq_amd", "libmodsjpeg.so"))
+    lib.mods_jpeg_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int), C.c_char_p]
+    for name, colour, ch_want in (("c.jpg", 1, 3), ("c.jpg", 0, 1), ("g.jpg", 1, 3), ("g.jpg", 0, 1)):
+        buf = C.POINTER(C.c_ubyte)()
+        w, h, ch = C.c_int(), C.c_int(), C.c_int()
+        err = C.create_string_buffer(256)
+        assert lib.mods_jpeg_read(str(tmp_path / name).encode(), colour, C.byref(buf), C.byref(w), C.byref(h), C.byref(ch), err) == 0, err.value
+        assert (w.value, h.value, ch.value) == (128, 96, ch_want)
+        got = np.ctypeslib.as_array(buf, (96, 128, ch_want)).astype(np.int32).copy()
+        lib.mods_jpeg_free(buf)
+        ref = np.asarray(Image.open(tmp_path / name).convert("RGB" if colour else "L")).astype(np.int32).reshape(96, 128, ch_want)
+        assert np.abs(got - ref).max() <= 2 and np.abs(got - ref).mean() < 0.5
+    err = C.create_string_buffer(256)
+    buf = C.POINTER(C.c_ubyte)()
+    (tmp_path / "bad.jpg").write_bytes(b"\xff\xd8\xff\xe0 not a jpeg")
+    assert lib.mods_jpeg_read(str(tmp_path / "bad.jpg").encode(), 1, C.byref(buf), C.byref(w), C.byref(h), C.byref(ch), err) == -1 and err.value
+    # the command line takes the file (and then stops at the missing GPU, or runs on one)
+    Image.fromarray(np.asarray(Image.open(G1).convert("RGB"))).save(tmp_path / "graf1.jpg", quality=95)
+    rc, msg = run([str(tmp_path / "graf1.jpg"), G6, "o1", "o2", "k1", "k2", "m", "log", "0", "0", "H", os.path.join(CFG, "classic.ini"),
+                   os.path.join(CFG, "iters_one_view.ini")], tmp_path)
+    assert "Cannot read image" not in msg and "Image1: 800x640" in msg

@@ -160,3 +160,22 @@ def test_add_upright(pkg, max_angles):
     n_up = int(np.sum(got["a12"] == 0))
     assert n_up >= len(got) // 2 and np.all(got["a12"][:n_up] == 0)
     ctx.close()
+
+
+def test_fast_patch_extraction(pkg):
+    """[SIFTDescriptor] FastPatchExtraction: the fast_extraction branch of DescribeRegions (synth-detection.hpp:232-253) - one
+    interpolation of the image at (2*int(mrSize*s)+1)/patchSize, no smoothing - for every region, large ones included."""
+    import torch
+    w, h = 800, 600
+    img = synth.texture(w, h, seed=35)
+    want, nd_want = orc.detect_describe(img, fast_extraction=True)
+    plain, _ = orc.detect_describe(img)
+    assert len(want) == len(plain) and not np.array_equal(want["desc"], plain["desc"])
+    ctx = pkg.Context(0, w, h, 1)
+    desc = pkg.DescribeParams.default()
+    desc.fastExtraction = 1
+    t = torch.from_numpy(img).cuda()
+    nd, nr = ctx.detect_describe_dev(t.data_ptr(), 1, w, h, None, desc)
+    assert nd[0] == nd_want and nr[0] == len(want) > 500
+    _assert_regions_equal(ctx.regions_fetch(0), want)
+    ctx.close()
