@@ -264,6 +264,14 @@ void mods_test_u2f_form(const double *u, const int *idx, int n, const double *w,
   std::vector<double> buffer((size_t)9 * n + 96);
   rs::u2fw(u, idx, w, n, F, buffer.data(), reference_form != 0);
 }
+// the 9 x 9 moment matrix of u2f / u2fw alone; lanes 0: scalar loop, 1 / 4 / 8: host SIMD across the sums
+int mods_test_cov_fm(const double *u, const int *idx, int n, const double *w, int lanes, double *Cv81) {
+  if (lanes != 0 && !rs::simd_ops_lanes(lanes)) return MODS_E_ARG;
+  double A1[3], A2[3];
+  rs::normu(u, idx, n, A1, A2);
+  rs::cov_fmN(u, idx, w, n, A1, A2, Cv81, lanes);
+  return MODS_OK;
+}
 int mods_test_checksample(const double *F, const double *u7, double th, double *H) { return rs::checksample(F, u7, th, H); }
 unsigned mods_test_inner_h(unsigned seed, double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl) {
   rs::GlibcRand g;

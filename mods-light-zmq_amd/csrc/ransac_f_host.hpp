@@ -23,6 +23,7 @@
 // fp64, one rounding per operation (-ffp-contract=off).
 #pragma once
 #include "ransac_host.hpp"
+#include "ransac_simd.hpp"
 #include <functional>
 #include <ctime>
 
@@ -420,8 +421,20 @@ static inline void lin_fmN(const double *u, double *p, const int *inl, int len, 
 }
 // lin_fmN (+ the optional row weights of u2fw) + cov_mat without the len x 9 matrix: the nine entries of a row are made in
 // registers and go straight into the 45 running sums - the same products and the same additions in the same row order
-static inline void cov_fmN(const double *u, const int *inl, const double *w, int len, const double *A1, const double *A2, double *Cv) {
+// lanes < 0: the widest host SIMD form of this CPU (rs::SimdOps::cov_fm_all: the 45 sums side by side in vector lanes, same
+// additions per sum); 0: the scalar loop below; 1 / 4 / 8: that lane count (self-test)
+static inline void cov_fmN(const double *u, const int *inl, const double *w, int len, const double *A1, const double *A2, double *Cv, int lanes = -1) {
   double acc[45];
+  if (lanes != 0) {
+    const SimdOps *ops = lanes < 0 ? simd_ops() : simd_ops_lanes(lanes);
+    if (ops) {
+      ops->cov_fm_all(u, inl, w, len, A1, A2, acc);
+      int q = 0;
+      for (int r = 0; r < 9; r++)
+        for (int c = 0; c <= r; c++) { Cv[9 * r + c] = acc[q]; Cv[r + 9 * c] = acc[q]; q++; }
+      return;
+    }
+  }
   for (int q = 0; q < 45; q++) acc[q] = 0;
   double a[3], b[3], z[9];
   a[2] = 1; b[2] = 1;

@@ -9,6 +9,8 @@ struct SimdOps {
   void (*gains_all)(const double *err, int n_pad, double lim, double *g);
   // FDs (mode 0), FDsSym (1), exFDs (2: + weight 1/sqrt(w)), exFDsSym (3: + weight a b/(a+b)); w may be null for modes 0, 1
   void (*fds_all)(const double *const *soa, int n_pad, const double *F, int mode, double *p, double *w);
+  // the 45 ordered sums of the least-squares F's moment matrix (lower triangle, row-major); w may be null
+  void (*cov_fm_all)(const double *u, const int *inl, const double *w, int len, const double *A1, const double *A2, double *acc45);
 };
 const SimdOps *simd_ops();                 // widest table this CPU runs
 const SimdOps *simd_ops_lanes(int lanes);  // 1, 4 (AVX2) or 8 (AVX-512F); nullptr when the CPU lacks it

@@ -165,3 +165,28 @@ def test_least_squares_f_without_the_design_matrix_bitexact(pkg, n, weighted):
     M.mods_test_u2f_form(P(u), P(idx), n, P(w) if weighted else None, 1, P(Fa))
     M.mods_test_u2f_form(P(u), P(idx), n, P(w) if weighted else None, 0, P(Fb))
     assert np.array_equal(Fa.view(np.uint64), Fb.view(np.uint64)) and np.abs(Fa).max() > 0
+
+
+@pytest.mark.parametrize("n", [9, 200, 21000])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_moment_matrix_across_vector_lanes_bitexact(pkg, n, weighted):
+    """The 45 ordered sums of the least-squares F's moment matrix side by side in vector lanes (SimdOps::cov_fm_all: what the
+    degenerate branch of DEGENSAC spends its time in on a large planar pair) give the scalar loop's bits at 1, 4 and 8 lanes."""
+    import fsynth
+    M = pkg.lib()
+    u, _, _ = fsynth.two_view(30000, 0.6, 0.0, 0.5, seed=11)
+    u = np.ascontiguousarray(u)
+    g = np.random.default_rng(n)
+    idx = np.ascontiguousarray(g.permutation(30000)[:n].astype(np.int32))
+    w = np.ascontiguousarray(g.uniform(0.5, 1.5, 30000))
+    ref = np.zeros(81)
+    assert M.mods_test_cov_fm(P(u), P(idx), n, P(w) if weighted else None, 0, P(ref)) == 0
+    assert np.abs(ref).max() > 0 and np.array_equal(ref.reshape(9, 9), ref.reshape(9, 9).T)
+    ran = 0
+    for lanes in LANES:
+        out = np.zeros(81)
+        if M.mods_test_cov_fm(P(u), P(idx), n, P(w) if weighted else None, lanes, P(out)) != 0:
+            continue            # this CPU lacks the instruction set of that lane count
+        ran += 1
+        assert np.array_equal(out.view(np.uint64), ref.view(np.uint64)), lanes
+    assert ran >= 1
