@@ -167,10 +167,8 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) {
 #ifdef MATCH_STATS
 __device__ unsigned long long g_match_stats[4];
 #endif
-// development switches (timing experiments, wrong results): bit 0 = no bound exchange inside the loop, bit 1 = never take the
-// exact path, bit 2 = always take it, bit 3 = no epilogue at all
-#ifndef MATCH_EXP
-#define MATCH_EXP 0
+#ifndef MATCH_XCH
+#define MATCH_XCH 16   // tiles between two exchanges of the shared bound (a power of two)
 #endif
 
 __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
@@ -237,16 +235,7 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
 #endif
       // some train of this tile may be among the two nearest so far: a wave-level branch, every lane inserts its 16 values
       // (harmless for the lanes that did not pass: the insertion is exact whatever the bound)
-#if MATCH_EXP & 8
-      if (acc[b][0] == 0x12345678) M1[b] = tt;
-      if (false) {
-#elif MATCH_EXP & 2
-      if (__any(acc_max16(acc[b]) >= alim[b] + (1 << 30))) {
-#elif MATCH_EXP & 4
-      if (__any(acc_max16(acc[b]) >= alim[b] - (1 << 30))) {
-#else
       if (__any(acc_max16(acc[b]) >= alim[b])) {
-#endif
 #ifdef MATCH_STATS
         st_exact++;
 #endif
@@ -281,7 +270,7 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
         bk[b] = nb; alim[b] = (nb + 1) >> 1;
       }
     }
-    if (!(MATCH_EXP & 1) && ((tt - t0) & 15) == 15) {   // publish / pick up the bound every 16 tiles
+    if (((tt - t0) & (MATCH_XCH - 1)) == MATCH_XCH - 1) {   // publish / pick up the bound every MATCH_XCH tiles
 #pragma unroll
       for (int b = 0; b < QB; b++) {
         const int j = jbase + 32 * b;

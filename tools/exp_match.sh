@@ -1,11 +1,13 @@
-# development aid: matcher experiment variants (libmodsgpu_v*.so built with -DMATCH_EXP=...) + PMC passes of the current kernel
+# development aid: matcher variants (libmodsgpu_v*.so built with other -D flags): stage time and nn1 / pass-2 kernel times
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/mexp
-mkdir -p $OUT
-echo "== current"; python $R/tools/bench_match.py 2>&1 | grep "^C[25]"
-for v in $R/mods-light-zmq_amd/libmodsgpu_v*.so; do echo "== $v"; MODS_LIB=$v python $R/tools/bench_match.py --c5only 2>&1 | grep "^C5"; done
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/mpmc1 -- python $R/tools/bench_match.py --c5only > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mpmc2 -- python $R/tools/bench_match.py --c5only > /dev/null 2>&1
-( python3 $R/tools/pmc_summary.py $(find $OUT/mpmc1 -name "*counter_collection.csv" | head -1) match_nn1; python3 $R/tools/pmc_summary.py $(find $OUT/mpmc2 -name "*counter_collection.csv" | head -1) match_nn1 ) | tee $OUT/match_pmc.txt
-rm -rf $OUT/mpmc1 $OUT/mpmc2
+for v in $R/mods-light-zmq_amd/libmodsgpu.so $R/mods-light-zmq_amd/libmodsgpu_v*.so; do
+  echo "== $v"
+  rm -rf /tmp/ks; MODS_LIB=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/tools/bench_match.py 2>&1 | grep "^C[25]"
+  python3 - <<'PY'
+import csv, glob
+f = glob.glob("/tmp/ks/**/*kernel_stats.csv", recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if "match_nn1" in r["Name"] or "match_fginn" in r["Name"]: print("   %s min %.1f max %.1f us" % (r["Name"][6:22], float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+PY
+done
