@@ -159,6 +159,13 @@ __device__ __forceinline__ void tile_store2(char *buf, const TileRegs &r) {
     ((int *)(buf + 32 * MT_ROW))[threadIdx.x] = threadIdx.x < 32 ? r.s : ck;
   }
 }
+// max of a value over the two half-waves (lane l and lane l ^ 32) in one VALU instruction: v_permlane32_swap exchanges the upper
+// half of one copy with the lower half of the other, so both copies then hold both halves' values lane by lane (the shuffle
+// builtin goes through ds_bpermute: eight address instructions and an LDS round trip inside the exact path)
+__device__ __forceinline__ int max_halves(int x) {
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+  return max((int)r[0], (int)r[1]);
+}
 __device__ __forceinline__ int med3_i32(int a, int b, int c) {
   int o;
   asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
@@ -202,20 +209,14 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
   // constants are fetched from global memory once per workgroup (one 16-byte load per thread), handed over through LDS
   // (double buffered, one barrier per tile) and read from there as MFMA operands; the next tile's loads are in flight
   // during the MFMAs.
-  __shared__ __attribute__((aligned(16))) char s_tile[2 * MT2_BYTES];
-  TileRegs nxt;
-  if (t0 < t1) { nxt = tile_fetch2(tdesc, tc2n, tc, t0); tile_store2(s_tile, nxt); }
-  __syncthreads();
 #ifdef MATCH_STATS
   unsigned int st_exact = 0, st_all = 0;
 #endif
-  for (int tt = t0; tt < t1; tt++) {
-    const char *cur = s_tile + ((tt - t0) & 1) * MT2_BYTES;
-    if (tt + 1 < t1) nxt = tile_fetch2(tdesc, tc2n, tc, tt + 1);
+  // the 8 MFMAs of one tile (LDS image `cur`) into acc
+  auto mm = [&](const char *cur, v16i (&acc)[QB]) {
     v4i a[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(cur + (lane & 31) * MT_ROW + ks * 32 + g * 16);
-    v16i acc[QB];
     acc[0] = acc_seed((const int *)(cur + 32 * MT_ROW), 0, g);
 #pragma unroll
     for (int b = 1; b < QB; b++) acc[b] = acc[0];
@@ -223,6 +224,9 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
     for (int ks = 0; ks < 4; ks++)
 #pragma unroll
       for (int b = 0; b < QB; b++) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], bq[b][ks], acc[b], 0, 0, 0);
+  };
+  // epilogue of tile tt (its LDS image `cur` still holds the key constants)
+  auto epi = [&](const char *cur, v16i (&acc)[QB], int tt) {
     // key constants of this lane's 16 rows: read for every tile (they share the A operands' dead registers), so that the exact
     // path does not start with an LDS round trip
     int4 ck[4];
@@ -265,8 +269,7 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
         M1[b] = m1; M2[b] = m2;
         // the two half-waves hold the same 32 queries (different train rows): the second key of their union is at least the
         // larger of their second keys; an equal distance at a lower index still counts, hence k >= bound
-        int nb = max(bk[b], m2 >> 4);
-        nb = max(nb, __shfl_xor(nb, 32));
+        const int nb = max_halves(max(bk[b], m2 >> 4));
         bk[b] = nb; alim[b] = (nb + 1) >> 1;
       }
     }
@@ -276,10 +279,21 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
         const int j = jbase + 32 * b;
         int nb = bk[b];
         if (g == 0 && j < k.n_q) nb = max(nb, 1 - atomicMin(&gthr[j], 1 - nb));
-        nb = max(nb, __shfl_xor(nb, 32));
+        nb = max_halves(nb);
         bk[b] = nb; alim[b] = (nb + 1) >> 1;
       }
     }
+  };
+  __shared__ __attribute__((aligned(16))) char s_tile[2 * MT2_BYTES];
+  TileRegs nxt;
+  if (t0 < t1) { nxt = tile_fetch2(tdesc, tc2n, tc, t0); tile_store2(s_tile, nxt); }
+  __syncthreads();
+  for (int tt = t0; tt < t1; tt++) {
+    const char *cur = s_tile + ((tt - t0) & 1) * MT2_BYTES;
+    if (tt + 1 < t1) nxt = tile_fetch2(tdesc, tc2n, tc, tt + 1);
+    v16i acc[QB];
+    mm(cur, acc);
+    epi(cur, acc, tt);
     if (tt + 1 < t1) tile_store2(s_tile + (((tt - t0) & 1) ^ 1) * MT2_BYTES, nxt);
     __syncthreads();
   }
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const in
         // (an equal distance at a later index loses the (d, t) order)
         if (kge[b] != ~0ull) thr[b] = max(dstar[b], (int)(kge[b] >> 32)) - cq[b];
       }
-      thr[b] = min(thr[b], __shfl_xor(thr[b], 32));
+      thr[b] = -max_halves(-thr[b]);   // min over the two half-waves (thr <= 0x7fffffff, so the negation is exact)
     }
 #ifdef MATCH_FGINN_SHARED
     if (tt + 1 < t1) tile_store(s_tile + (((tt - t0) & 1) ^ 1) * MT_BYTES, nxt);
