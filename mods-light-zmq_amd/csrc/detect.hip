@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
     }
 #pragma unroll
     for (int rr = 0; rr < NMS_ROWS + 2; rr++) {
-      win[rr][0] = __shfl_up(win[rr][1], 1);
-      win[rr][2] = __shfl_down(win[rr][1], 1);
+      win[rr][0] = lane_up1(win[rr][1]);
+      win[rr][2] = lane_down1(win[rr][1]);
     }
     wave_sync();                              // the previous level's list and hit words have been consumed
     if (lane < NMS_ROWS) s_hit[wv][lane] = 0ull;
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict_
         cmx[2] = fmaxf(fmaxf(a.y, m.y), z.y); cmn[2] = fminf(fminf(a.y, m.y), z.y);
         cmx[3] = fmaxf(fmaxf(a.z, m.z), z.z); cmn[3] = fminf(fminf(a.z, m.z), z.z);
         cmx[4] = fmaxf(fmaxf(a.w, m.w), z.w); cmn[4] = fminf(fminf(a.w, m.w), z.w);
-        cmx[0] = __shfl_up(cmx[4], 1); cmn[0] = __shfl_up(cmn[4], 1);
-        cmx[5] = __shfl_down(cmx[1], 1); cmn[5] = __shfl_down(cmn[1], 1);
+        cmx[0] = lane_up1(cmx[4]); cmn[0] = lane_up1(cmn[4]);
+        cmx[5] = lane_down1(cmx[1]); cmn[5] = lane_down1(cmn[1]);
       }
       const float vals[4] = {own[rr + 1].x, own[rr + 1].y, own[rr + 1].z, own[rr + 1].w};
 #pragma unroll

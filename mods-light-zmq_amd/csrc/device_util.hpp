@@ -26,6 +26,15 @@ __host__ __device__ __forceinline__ bool check_borders(int img_w, int img_h, flo
 
 // LDS hand-over between the lanes of ONE wave (LDS executes a wave's instructions in order; this only stops the
 // compiler from moving LDS accesses across)
+// value of the neighbouring lane (lane - 1 / lane + 1; the first / last lane keeps its own value, as __shfl_up / __shfl_down
+// by 1 do) as ONE DPP move (wave_shr:1 / wave_shl:1): the shuffle builtins go through ds_bpermute, i.e. address arithmetic and
+// an LDS round trip per value
+__device__ __forceinline__ float lane_up1(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_down1(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130, 0xf, 0xf, false));
+}
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
