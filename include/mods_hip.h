@@ -289,7 +289,19 @@ typedef struct mods_ransac_params {
   int errorType;            /* 0 */
   int doSymmCheck;          /* 1 */
   int useF;                 /* 0: homography (ver_type "Homog"), 1: epipolar geometry (DEGENSAC, ver_type "Epipolar") */
+  /* ver_type 1 of the command line (GR_TRUTH, mods.cpp:290-320): verification against a known homography.
+   * groundTruth 0: off; 1: HMatrixFiltering of the tentatives only; 2: doBothRANSACgroundTruth - LORANSACFiltering first, then
+   * HMatrixFiltering of its inliers (the verified list), next to HMatrixFiltering of all tentatives for the log. */
+  int groundTruth;
+  int ransacForStopping;    /* [Matching] RANSACforStopping: in ground-truth mode the step loop stops on the RANSAC inlier count */
+  double gtH[9];            /* the homography img1 -> img2, row-major, as the file of argv[Tmin+2] holds it (mods.cpp:92-98) */
 } mods_ransac_params;
+
+/* Replaces  int HMatrixFiltering(TentativeCorrespListExt &in, TentativeCorrespListExt &true_corresp, double *H, const int isExtended,
+ *           const RANSACPars pars)  (matching/matching.cpp:917-1012): mask[i] = 1 where the error of correspondence i under H
+ * (errorType: 0 HDs Sampson, 1 HDsSymMax, otherwise HDsSym; the point of the second image first, as the reference stacks it) is at
+ * most (float)(err_threshold^2).  H_rowmajor: img1 -> img2.  Host-side. */
+int mods_hmatrix_filter(const double *u6, int n, const double *H_rowmajor, const mods_ransac_params *par, unsigned char *mask, int *n_true);
 
 /* Replaces  int LORANSACFiltering(TentativeCorrespListExt &in, TentativeCorrespListExt &out, double *H,
  *           const RANSACPars pars)  (matching/matching.hpp:267-269, matching.cpp:637-805) for useF = 0.
@@ -314,6 +326,9 @@ int mods_loransac_f(const double *u6, const double *laf, int n, const mods_ransa
 struct mods_pair_params;
 int mods_verify_tentatives(int device, const struct mods_pair_params *par, mods_tentative *tent, double *u6, double *laf, int n,
                            int *n_unique, int *n_verified, double *H_out, int *stats3, double *ms_dup, double *ms_ransac);
+/* the same with the three ground-truth counts of mods_ladder_result (gt3, may be NULL; zeros outside ground-truth mode) */
+int mods_verify_tentatives_ex(int device, const struct mods_pair_params *par, mods_tentative *tent, double *u6, double *laf, int n,
+                              int *n_unique, int *n_verified, double *H_out, int *stats3, int *gt3, double *ms_dup, double *ms_ransac);
 /* GPU used by the degensac entry points of the calling thread (default 0). */
 int mods_ransac_set_device(int device);
 /* The reference seeds with srand(time(NULL)) (exp_ranH.c:823).  seed >= 0 makes every call behave as if
@@ -414,6 +429,10 @@ typedef struct mods_ladder_result {
   int ransac_samples, ransac_lo, ransac_rejects;
   double H[9];
   double ms_detect_describe, ms_match, ms_duplicates, ms_ransac;
+  /* ground-truth mode (mods_ransac_params.groundTruth), of the last step: TrueMatch1st of HMatrixFiltering over all unique
+   * tentatives, Tentatives1stRANSAC (LORANSAC inliers), TrueMatch1stRANSAC (of those, the ones the ground truth confirms);
+   * n_inliers = the verified list that is written out */
+  int gt_true, gt_ransac_inliers, gt_true_of_ransac;
 } mods_ladder_result;
 
 int mods_view_schedule(const double *scale_set, int n_scales, const double *tilt_set, int n_tilts, double phi_base,

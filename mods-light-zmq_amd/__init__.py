@@ -406,11 +406,12 @@ class RansacParams(C.Structure):
     """[RANSAC] section (io_mods.cpp:437-455).  errorType 0 Sampson, 1 SymmMax, 2 SymmSum."""
     _fields_ = [("err_threshold", C.c_double), ("confidence", C.c_double), ("max_samples", C.c_int),
                 ("localOptimization", C.c_int), ("LAFCoef", C.c_double), ("HLAFCoef", C.c_double),
-                ("errorType", C.c_int), ("doSymmCheck", C.c_int), ("useF", C.c_int)]
+                ("errorType", C.c_int), ("doSymmCheck", C.c_int), ("useF", C.c_int),
+                ("groundTruth", C.c_int), ("ransacForStopping", C.c_int), ("gtH", C.c_double * 9)]
 
     @staticmethod
     def default(useF=0):
-        return RansacParams(4.0, 0.99, 1000000, 1, 2.0, 12.0, 0, 1, useF)   # config_affori_classic.ini
+        return RansacParams(4.0, 0.99, 1000000, 1, 2.0, 12.0, 0, 1, useF, 0, 0)   # config_affori_classic.ini
 
 
 _ERR = {"sampson": ("HDs", "HDsi", "HDsidx"), "symm_max": ("HDsSymMax", "HDsiSymMax", "HDsSymidxMax"),
@@ -558,7 +559,19 @@ class LadderResult(C.Structure):
                 ("n_unoriented", C.c_int * 2), ("n_tentatives", C.c_int), ("n_unique", C.c_int), ("n_inliers", C.c_int),
                 ("ransac_samples", C.c_int), ("ransac_lo", C.c_int), ("ransac_rejects", C.c_int), ("H", C.c_double * 9),
                 ("ms_detect_describe", C.c_double), ("ms_match", C.c_double), ("ms_duplicates", C.c_double),
-                ("ms_ransac", C.c_double)]
+                ("ms_ransac", C.c_double), ("gt_true", C.c_int), ("gt_ransac_inliers", C.c_int), ("gt_true_of_ransac", C.c_int)]
+
+
+def hmatrix_filter(u6, H, ransac=None):
+    """HMatrixFiltering (matching.cpp:917-1012): mask of the correspondences within err_threshold of the row-major homography H."""
+    u = np.ascontiguousarray(u6, np.float64)
+    Hm = np.ascontiguousarray(H, np.float64).reshape(9)
+    par = ransac or RansacParams.default()
+    mask = np.zeros(max(len(u), 1), np.uint8)
+    n = C.c_int()
+    _check(lib().mods_hmatrix_filter(u.ctypes.data_as(C.c_void_p), len(u), Hm.ctypes.data_as(C.c_void_p), C.byref(par),
+                                     mask.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return mask[:len(u)].astype(bool), n.value
 
 
 def view_schedule(step, history):

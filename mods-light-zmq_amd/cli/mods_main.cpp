@@ -6,7 +6,7 @@
 //   argv layout        getCLIparam, io_mods.cpp:558-603 (Tmin = 9, io_mods.h:13):
 //       mods img1 img2 out1 out2 k1 k2 matchings log [logOnly] [ver_type] [H/F file] [config.ini] [iters.ini]
 //            [read_pre_extracted] [match_one_to_many]
-//       ver_type 0 = LO-RANSAC homography, 2 = LO-RANSAC epipolar (1 = ground truth, 3 = ORSA: not built)
+//       ver_type 0 = LO-RANSAC homography, 1 = ground-truth homography (the H file is read), 2 = LO-RANSAC epipolar (3 = ORSA: not built)
 //   configuration      the [HessianAffine], [DominantOrientation], [SIFTDescriptor], [Matching], [DuplicateFiltering],
 //                      [RANSAC], [TextOutput], [Computing] keys of io_mods.cpp:160-207, 423-455, 605-740 and the
 //                      [Iterations] / [HessianAffine<i>] sections of the iterations file (:457-492)
@@ -145,6 +145,10 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   const std::string et = ini.GetStringVector("RANSAC", "ErrorType")[0];
   r.errorType = et == "Sampson" ? 0 : et == "SymmMax" ? 1 : 2;
   r.useF = ver_type == 2 ? 1 : 0;
+  // GR_TRUTH (mods.cpp:85-87, 290-320, 381-383; io_mods.cpp:340-341): with doBothRANSACgroundTruth the verified list is the
+  // LORANSAC inliers that the ground truth confirms, RANSACforStopping stops the step loop on the RANSAC inlier count
+  r.groundTruth = ver_type == 1 ? (ini.GetInteger("Matching", "doBothRANSACgroundTruth", 1) ? 2 : 1) : 0;
+  r.ransacForStopping = ini.GetInteger("Matching", "RANSACforStopping", 1) ? 1 : 0;
   // [TextOutput], [Computing]
   cfg->time_log = (int)ini.GetInteger("TextOutput", "timeLog", 0);
   cfg->write_keypoints = (int)ini.GetInteger("TextOutput", "writeKeypoints", 1);
@@ -316,7 +320,7 @@ int usage() {
             << "  k1, k2       keypoint + descriptor files (text)" << std::endl
             << "  matchings    verified correspondences, x1 y1 x2 y2 per line" << std::endl
             << "  log          one line: time matches tentatives inlier% regions1 regions2 steps" << std::endl
-            << "  ver_type     0 LO-RANSAC homography, 2 LO-RANSAC (DEGENSAC) epipolar geometry" << std::endl;
+            << "  ver_type     0 LO-RANSAC homography, 1 ground-truth homography (read from the H/F file), 2 LO-RANSAC (DEGENSAC) epipolar geometry" << std::endl;
   return 1;
 }
 
@@ -495,9 +499,13 @@ int main(int argc, char **argv) {
   if (argc >= Tmin + 1) log_only = atoi(argv[Tmin]);
   if (argc >= Tmin + 2) {
     ver_type = atoi(argv[Tmin + 1]);
-    if (ver_type != 0 && ver_type != 2) {
+    if (ver_type != 0 && ver_type != 1 && ver_type != 2) {
       std::cerr << ver_type << " is wrong correspondence verification type." << std::endl
-                << "Try 0 for LO-RANSAC(homography) or 2 for LO-RANSAC(epipolar) (1, ground truth, and 3, ORSA, are not part of this build)" << std::endl;
+                << "Try 0 for LO-RANSAC(homography), 1 for ground truth matrix or 2 for LO-RANSAC(epipolar) (3, ORSA, is not part of this build)" << std::endl;
+      return 1;
+    }
+    if (ver_type == 1 && argc < Tmin + 3) {   // io_mods.cpp:594-599
+      std::cerr << "Ground truth homography file is needed for verification type 1" << std::endl;
       return 1;
     }
   }
@@ -508,6 +516,14 @@ int main(int argc, char **argv) {
   Config cfg;
   memset(&cfg.pair, 0, sizeof(cfg.pair));
   if (read_config(config_fn, iters_fn, ver_type, &cfg)) return 1;
+  if (ver_type == 1) {   // mods.cpp:89-104: the file holds the matrix row by row
+    std::ifstream gf(argv[Tmin + 2]);
+    double *g = cfg.pair.ransac.gtH;
+    if (!gf.is_open() || !(gf >> g[0] >> g[1] >> g[2] >> g[3] >> g[4] >> g[5] >> g[6] >> g[7] >> g[8])) {
+      std::cerr << "Cannot open ground truth file " << argv[Tmin + 2] << std::endl;
+      return 1;
+    }
+  }
 
   GreyImage img1, img2;
   if (!load_grey(img1_fn, cfg.load_color, &img1)) { std::cerr << "Cannot read image " << img1_fn << std::endl; return 1; }
@@ -609,8 +625,16 @@ int main(int argc, char **argv) {
   if (cfg.verbose) {
     std::cerr << res.n_views << " views synthesised, " << res.n_tentatives << " tentatives found." << std::endl;
     std::cerr << res.n_unique << " unique tentatives left" << std::endl;
-    std::cerr << (cfg.pair.ransac.useF ? "LO-RANSAC(epipolar)" : "LO-RANSAC(homography)") << " verification is used..." << std::endl;
-    std::cerr << res.n_inliers << " RANSAC correspondences got" << std::endl;
+    if (cfg.pair.ransac.groundTruth) {
+      std::cerr << "Ground truth verification is used..." << std::endl
+                << res.gt_true << " true matches got with error threshold = " << cfg.pair.ransac.err_threshold << std::endl;
+      if (cfg.pair.ransac.groundTruth >= 2)
+        std::cerr << "Now RANSAC" << std::endl << res.gt_ransac_inliers << " RANSAC matches are identified" << std::endl
+                  << res.gt_true_of_ransac << " RANSAC true matches are identified" << std::endl;
+    } else {
+      std::cerr << (cfg.pair.ransac.useF ? "LO-RANSAC(epipolar)" : "LO-RANSAC(homography)") << " verification is used..." << std::endl;
+      std::cerr << res.n_inliers << " RANSAC correspondences got" << std::endl;
+    }
   }
   std::cerr << "Done in " << final_step << " iterations" << std::endl << "*********************" << std::endl;
 
@@ -618,10 +642,21 @@ int main(int argc, char **argv) {
     std::ofstream lf(log_fn);
     if (lf.is_open()) {
       const double ratio = res.n_unique > 0 ? (double)res.n_inliers / (double)res.n_unique : std::nan("");
-      lf << std::setprecision(3) << final_time << " " << res.n_inliers << " " << res.n_unique << " " << ratio * 100 << " ";
-      if (cfg.pair.ransac.useF) lf << res.n_described[0] << " " << res.n_described[1] << " ";
-      else lf << res.n_unoriented[0] << " " << res.n_unoriented[1] << " ";
-      lf << final_step << " " << std::endl;
+      if (cfg.pair.ransac.groundTruth) {   // GR_TRUTH / GR_PLUS_RANSAC rows of WriteLog
+        const double r_all = res.n_unique > 0 ? (double)res.gt_true / (double)res.n_unique : std::nan("");
+        lf << std::setprecision(3) << final_time << " ";
+        if (cfg.pair.ransac.groundTruth >= 2) {
+          const double r_rs = res.gt_ransac_inliers > 0 ? (double)res.gt_true_of_ransac / (double)res.gt_ransac_inliers : std::nan("");
+          lf << res.gt_true_of_ransac << " " << res.gt_ransac_inliers << " " << r_rs * 100 << " ";
+        }
+        lf << res.gt_true << " " << res.n_unique << " " << r_all * 100 << " " << res.n_described[0] << " " << res.n_described[1] << " "
+           << final_step << " " << std::endl;
+      } else {
+        lf << std::setprecision(3) << final_time << " " << res.n_inliers << " " << res.n_unique << " " << ratio * 100 << " ";
+        if (cfg.pair.ransac.useF) lf << res.n_described[0] << " " << res.n_described[1] << " ";
+        else lf << res.n_unoriented[0] << " " << res.n_unoriented[1] << " ";
+        lf << final_step << " " << std::endl;
+      }
     }
   }
   if (cfg.output_h && argc >= Tmin + 3) {   // WriteH
@@ -647,8 +682,16 @@ int main(int argc, char **argv) {
   std::cerr << "Image1: regions descriptors | Image2: regions descriptors " << std::endl;
   std::cerr << res.n_unoriented[0] << " " << res.n_described[0] << " | " << res.n_unoriented[1] << " " << res.n_described[1] << std::endl << std::endl;
   std::cerr << "True matches | unique tentatives" << std::endl;
-  if (res.n_unique > 0) std::cerr << res.n_inliers << " | " << res.n_unique << " | " << std::setprecision(3) << 100.0 * res.n_inliers / res.n_unique << "%  1st geom inc" << std::endl;
-  else std::cerr << res.n_inliers << " | " << res.n_unique << " |  -  1st geom inc" << std::endl;
+  {
+    const int tm = cfg.pair.ransac.groundTruth ? res.gt_true : res.n_inliers;   // TrueMatch1st
+    if (res.n_unique > 0) std::cerr << tm << " | " << res.n_unique << " | " << std::setprecision(3) << 100.0 * tm / res.n_unique << "%  1st geom inc" << std::endl;
+    else std::cerr << tm << " | " << res.n_unique << " |  -  1st geom inc" << std::endl;
+    if (cfg.pair.ransac.groundTruth >= 2) {   // mods.cpp:515-519
+      if (res.gt_ransac_inliers > 0) std::cerr << res.gt_true_of_ransac << " | " << res.gt_ransac_inliers << " | " << std::setprecision(3)
+                                               << 100.0 * res.gt_true_of_ransac / res.gt_ransac_inliers << "% RANSACed  1st geom inc" << std::endl;
+      else std::cerr << res.gt_true_of_ransac << " | " << res.gt_ransac_inliers << " | -  RANSACed  1st geom inc" << std::endl;
+    }
+  }
   const double total = now_s() - c_start;
   std::cerr << std::endl << "Main matching | All Time: " << std::endl << final_time << " | " << total << " seconds" << std::endl;
   if (cfg.time_log) {   // WriteTimeLog(TimingLog, file, 0, 1, 0): Synth Detect Orient Desc Match RANSAC MISC Total (seconds)

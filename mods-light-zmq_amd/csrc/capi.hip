@@ -857,8 +857,38 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
 //   TrueMatch1st, which also drives the minMatches stop, is the size of the de-duplicated list).
 // On return the first *n_verified entries of the three arrays are the verified correspondences in output order;
 // *n_unique = the size of the list RANSAC ran on.
+// HMatrixFiltering, matching.cpp:917-1012: the reference stacks (second image point, first image point) and hands the
+// column-major H to the error function; th = (float)(err_threshold^2) compared in double
+int mods_hmatrix_filter(const double *u6, int n, const double *H_rowmajor, const mods_ransac_params *par, unsigned char *mask, int *n_true) {
+  if (!par || !H_rowmajor || !n_true || (n > 0 && (!u6 || !mask))) { set_error("hmatrix_filter: null argument"); return MODS_E_ARG; }
+  *n_true = 0;
+  if (n <= 0) return MODS_OK;
+  std::vector<double> u2((size_t)n * 6), d(n);
+  for (int i = 0; i < n; i++) {
+    const double *s = u6 + (size_t)i * 6;
+    double *q = &u2[(size_t)i * 6];
+    q[0] = s[3]; q[1] = s[4]; q[2] = 1.; q[3] = s[0]; q[4] = s[1]; q[5] = 1.;
+  }
+  const double *M = H_rowmajor;
+  const double Hc[9] = {M[0], M[3], M[6], M[1], M[4], M[7], M[2], M[5], M[8]};   // Hready[0], [3], [6] <- first row of the file
+  if (par->errorType == 0) HDs(nullptr, u2.data(), Hc, d.data(), n);
+  else if (par->errorType == 1) HDsSymMax(nullptr, u2.data(), Hc, d.data(), n);
+  else HDsSym(nullptr, u2.data(), Hc, d.data(), n);
+  const float th = (float)(par->err_threshold * par->err_threshold);
+  int c = 0;
+  for (int i = 0; i < n; i++) { mask[i] = d[i] <= th ? 1 : 0; c += mask[i]; }
+  *n_true = c;
+  return MODS_OK;
+}
+
 int mods_verify_tentatives(int device, const mods_pair_params *par, mods_tentative *tent, double *u6, double *laf, int n,
                            int *n_unique, int *n_verified, double *H_out, int *stats3, double *ms_dup, double *ms_ransac) {
+  return mods_verify_tentatives_ex(device, par, tent, u6, laf, n, n_unique, n_verified, H_out, stats3, nullptr, ms_dup, ms_ransac);
+}
+
+int mods_verify_tentatives_ex(int device, const mods_pair_params *par, mods_tentative *tent, double *u6, double *laf, int n,
+                              int *n_unique, int *n_verified, double *H_out, int *stats3, int *gt3, double *ms_dup, double *ms_ransac) {
+  if (gt3) gt3[0] = gt3[1] = gt3[2] = 0;
   if (!par || !n_unique || !n_verified || (n > 0 && (!tent || !u6 || !laf))) { set_error("verify_tentatives: null argument"); return MODS_E_ARG; }
   int rc;
   const double t0 = now_ms();
@@ -871,9 +901,35 @@ int mods_verify_tentatives(int device, const mods_pair_params *par, mods_tentati
   mods_ransac_set_device(device);
   std::vector<unsigned char> mask(nu > 0 ? nu : 1);
   double H[9];
-  if (par->ransac.useF) rc = mods_loransac_f(u6, laf, nu, &par->ransac, mask.data(), H, &ninl, stats);
-  else rc = mods_loransac_h(u6, laf, nu, &par->ransac, mask.data(), H, &ninl, stats);
-  if (rc) return rc;
+  if (par->ransac.groundTruth) {
+    // GR_TRUTH, mods.cpp:292-320: HMatrixFiltering of all unique tentatives (TrueMatch1st); with doBothRANSACgroundTruth the
+    // verified list is instead the LORANSAC inliers that the ground truth confirms
+    int n_true = 0;
+    if ((rc = mods_hmatrix_filter(u6, nu, par->ransac.gtH, &par->ransac, mask.data(), &n_true))) return rc;
+    if (gt3) gt3[0] = n_true;
+    ninl = n_true;
+    if (par->ransac.groundTruth >= 2) {
+      std::vector<unsigned char> mr(nu > 0 ? nu : 1);
+      double Hr[9];
+      if ((rc = mods_loransac_h(u6, laf, nu, &par->ransac, mr.data(), Hr, &ninl, stats))) return rc;
+      std::vector<double> ur((size_t)(ninl > 0 ? ninl : 1) * 6);
+      std::vector<unsigned char> mt(ninl > 0 ? ninl : 1);
+      int q = 0;
+      for (int i = 0; i < nu; i++)
+        if (mr[i]) { memcpy(&ur[(size_t)q * 6], &u6[(size_t)i * 6], 6 * sizeof(double)); q++; }
+      int n_tr = 0;
+      if ((rc = mods_hmatrix_filter(ur.data(), ninl, par->ransac.gtH, &par->ransac, mt.data(), &n_tr))) return rc;
+      if (gt3) { gt3[1] = ninl; gt3[2] = n_tr; }
+      q = 0;
+      for (int i = 0; i < nu; i++) { mask[i] = mr[i] ? mt[q++] : 0; }
+      ninl = n_tr;
+    }
+    memcpy(H, par->ransac.gtH, sizeof(H));     // true_corresp.H = the ground truth, row-major again (matching.cpp:1002-1010)
+  } else {
+    if (par->ransac.useF) rc = mods_loransac_f(u6, laf, nu, &par->ransac, mask.data(), H, &ninl, stats);
+    else rc = mods_loransac_h(u6, laf, nu, &par->ransac, mask.data(), H, &ninl, stats);
+    if (rc) return rc;
+  }
   const double t2 = now_ms();
   int m = 0;
   for (int i = 0; i < nu; i++)

@@ -248,12 +248,22 @@ static int verify_gathered(mods_ctx *c, const mods_pair_params *par, mods_ladder
   res->n_tentatives = n;
   int stats[3] = {0, 0, 0};
   double ms_dup = 0, ms_ran = 0;
-  const int rc = mods_verify_tentatives(c->device, par, c->h_tent.data(), c->h_u6.data(), c->h_laf.data(), n, &res->n_unique, &res->n_inliers,
-                                        res->H, stats, &ms_dup, &ms_ran);
+  int gt3[3] = {0, 0, 0};
+  const int rc = mods_verify_tentatives_ex(c->device, par, c->h_tent.data(), c->h_u6.data(), c->h_laf.data(), n, &res->n_unique, &res->n_inliers,
+                                           res->H, stats, gt3, &ms_dup, &ms_ran);
   if (rc) return rc;
   res->ms_duplicates += ms_dup; res->ms_ransac += ms_ran;
   res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
+  res->gt_true = gt3[0]; res->gt_ransac_inliers = gt3[1]; res->gt_true_of_ransac = gt3[2];
   return MODS_OK;
+}
+// curr_matches of the step loop (mods.cpp:286, 357-383): TrueMatch1st - the verified list, or in ground-truth mode
+// HMatrixFiltering's count over all unique tentatives (the de-duplicated verified list when duplicates are filtered after the
+// verification) - and Tentatives1stRANSAC when [Matching] RANSACforStopping is set in ground-truth mode
+static int stop_count(const mods_pair_params *par, const mods_ladder_result *res) {
+  if (!par->ransac.groundTruth) return res->n_inliers;
+  if (par->ransac.ransacForStopping) return res->gt_ransac_inliers;
+  return par->dup_before_ransac ? res->gt_true : res->n_inliers;
 }
 
 // match bank 1 against bank 2, drop duplicates, verify (MatchImgReps + DuplicateFiltering + LORANSACFiltering,
@@ -390,7 +400,7 @@ int mods_match_ladder_groups_dev(mods_ctx *c, const float *img1_dev, int w1, int
     gather_tentatives(c, lists);
     res->ms_match += now_ms2() - t1;
     if ((rc = verify_gathered(c, par, res))) return rc;
-    curr_matches = res->n_inliers;
+    curr_matches = stop_count(par, res);
     res->steps_done = step + 1;
   }
   copy_verified(c, res, matches_out, max_matches);

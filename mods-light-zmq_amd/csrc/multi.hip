@@ -294,12 +294,16 @@ int mods_match_ladder_multi(mods_multi *m, const float *img1_host, int w1, int h
     // ---- device 0's host: duplicate filter + verification
     int stats[3] = {0, 0, 0};
     double ms_dup = 0, ms_ran = 0;
-    const int rc = mods_verify_tentatives(m->dev[0], par, tent.data(), u6.data(), laf.data(), (int)tent.size(), &res->n_unique, &res->n_inliers,
-                                          res->H, stats, &ms_dup, &ms_ran);
+    int gt3[3] = {0, 0, 0};
+    const int rc = mods_verify_tentatives_ex(m->dev[0], par, tent.data(), u6.data(), laf.data(), (int)tent.size(), &res->n_unique, &res->n_inliers,
+                                             res->H, stats, gt3, &ms_dup, &ms_ran);
     if (rc) return rc;
     res->ms_duplicates += ms_dup; res->ms_ransac += ms_ran;
     res->ransac_samples = stats[0]; res->ransac_lo = stats[1]; res->ransac_rejects = stats[2];
-    curr_matches = res->n_inliers;
+    res->gt_true = gt3[0]; res->gt_ransac_inliers = gt3[1]; res->gt_true_of_ransac = gt3[2];
+    // the stop criterion of the step loop, as in mods_match_ladder_groups_dev (ground-truth mode: mods.cpp:381-383)
+    curr_matches = !par->ransac.groundTruth ? res->n_inliers
+                   : (par->ransac.ransacForStopping ? res->gt_ransac_inliers : (par->dup_before_ransac ? res->gt_true : res->n_inliers));
     res->steps_done = step + 1;
   }
   if (matches_out)

@@ -158,6 +158,48 @@ def loransac_f(u6, laf, err_threshold=4.0, conf=0.99, max_samples=1000000, laf_c
     return mask, F, len(good), stats
 
 
+def hmatrix_filter(u6, H, err_threshold=4.0, err="sampson"):
+    """HMatrixFiltering, matching.cpp:917-1012, on top of the reference's own HDs / HDsSymMax / HDsSym (oracle/_ref): the second
+    image's point first, the column-major H, th = (float)(err_threshold^2).  H: row-major img1 -> img2."""
+    import ctypes as C
+    n = len(u6)
+    if n == 0:
+        return np.zeros(0, bool)
+    u2 = np.ascontiguousarray(np.c_[u6[:, 3], u6[:, 4], np.ones(n), u6[:, 0], u6[:, 1], np.ones(n)], np.float64)
+    M = np.asarray(H, np.float64).reshape(9)
+    Hc = np.ascontiguousarray([M[0], M[3], M[6], M[1], M[4], M[7], M[2], M[5], M[8]], np.float64)
+    d = np.zeros(n)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    Z = np.zeros(18 * n)
+    p = np.ascontiguousarray(np.arange(n, dtype=np.int32))
+    L = refdeg.lib()
+    L.lin_hg(P(u2), P(Z), P(p), n)
+    getattr(L, refdeg.ERR[err][0])(P(Z), P(u2), P(Hc), P(d), n)
+    return d <= float(np.float32(err_threshold * err_threshold))
+
+
+def match_pair_ground_truth(img1, img2, H_gt, both=True, seed_time=12345, ratio=0.8, regions=None):
+    """One step of mods.cpp:202-383 with ver_type = GR_TRUTH (mods.cpp:290-320): HMatrixFiltering of the unique tentatives, and with
+    doBothRANSACgroundTruth LORANSACFiltering + HMatrixFiltering of its inliers (the verified list)."""
+    if regions is None:
+        (ra, nd1), (rb, nd2) = pmap(orc.detect_describe, (img1, img2))
+    else:
+        (ra, nd1), (rb, nd2) = regions
+    tc = match_fginn_par(ra, rb, ratio)
+    un = orc.duplicate_filter(tc, ra, rb, 2.0, 1)
+    u6, laf = u6_of(ra, rb, un), laf_of(ra, rb, un)
+    true_all = hmatrix_filter(u6, H_gt)
+    out = dict(n_tentatives=len(tc), n_unique=len(un), gt_true=int(true_all.sum()), gt_ransac_inliers=0, gt_true_of_ransac=0)
+    if both:
+        mask, _, ninl, _ = loransac_h(u6, laf, seed_time=seed_time)
+        tr = hmatrix_filter(u6[mask], H_gt)
+        out.update(gt_ransac_inliers=int(ninl), gt_true_of_ransac=int(tr.sum()), matches=u6[mask][tr][:, [0, 1, 3, 4]])
+    else:
+        out.update(matches=u6[true_all][:, [0, 1, 3, 4]])
+    out["n_inliers"] = len(out["matches"])
+    return out
+
+
 def match_pair(img1, img2, seed_time=12345, ratio=0.8, use_f=False, dup_before_ransac=True, regions=None):
     """One step of mods.cpp:202-383 on identity views.  dup_before_ransac = False: [DuplicateFiltering] doBeforeRANSAC = 0,
     the verified list is de-duplicated after RANSAC (mods.cpp:357-368)."""

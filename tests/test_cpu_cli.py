@@ -25,8 +25,12 @@ def test_usage_and_bad_arguments(tmp_path):
     rc, err = run([], tmp_path)
     assert rc == 1 and "Usage: mods img1 img2" in err
     base = [G1, G6, "o1", "o2", "k1", "k2", "m", "log", "0"]
-    rc, err = run(base + ["1", "H", os.path.join(CFG, "classic.ini"), os.path.join(CFG, "iters_one_view.ini")], tmp_path)
+    rc, err = run(base + ["3", "H", os.path.join(CFG, "classic.ini"), os.path.join(CFG, "iters_one_view.ini")], tmp_path)
     assert rc == 1 and "wrong correspondence verification type" in err
+    rc, err = run(base + ["1", "no_such_H.txt", os.path.join(CFG, "classic.ini"), os.path.join(CFG, "iters_one_view.ini")], tmp_path)
+    assert rc == 1 and "Cannot open ground truth file no_such_H.txt" in err      # ver_type 1 reads the homography (mods.cpp:89-104)
+    rc, err = run(base + ["1"], tmp_path)
+    assert rc == 1 and "Ground truth homography file is needed" in err
     rc, err = run(base + ["0", "H", "/nonexistent.ini", os.path.join(CFG, "iters_one_view.ini")], tmp_path)
     assert rc == 1 and "Can't load /nonexistent.ini" in err
     rc, err = run(["/nonexistent.png"] + base[1:] + ["0", "H", os.path.join(CFG, "classic.ini"), os.path.join(CFG, "iters_one_view.ini")], tmp_path)

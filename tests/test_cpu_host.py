@@ -126,3 +126,27 @@ def test_view_geometry_and_schedule_host_side(pkg):
     assert len({(z, t, round(p, 9)) for z, t, p in hist}) == 31        # no view is scheduled twice
     neg = pkg.view_schedule(pkg.LadderStep.make((3,), -360.0), [])     # negative density: vertical + horizontal tilt, no rotation
     assert neg == [(1.0, -3.0, 0.0), (1.0, 3.0, 0.0)]
+
+
+@pytest.mark.parametrize("err_type,err_name", [(0, "sampson"), (1, "symm_max"), (2, "symm_sum")])
+def test_hmatrix_filter_matches_the_reference_error_functions(pkg, err_type, err_name):
+    """mods_hmatrix_filter (HMatrixFiltering, matching.cpp:917-1012, the verification of ver_type 1) against the reference's own
+    HDs / HDsSymMax / HDsSym (oracle/_ref): the same mask, points on both sides of the threshold."""
+    import pipeline_oracle as po
+    import refdeg
+    if not refdeg.available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(17 + err_type)
+    n = 4000
+    H = np.array([[0.9, 0.12, 30.0], [-0.08, 1.05, -12.0], [1e-4, -6e-5, 1.0]])
+    x1 = np.c_[rng.uniform(0, 800, n), rng.uniform(0, 600, n), np.ones(n)]
+    p = x1 @ H.T
+    x2 = p[:, :2] / p[:, 2:3] + rng.normal(0, 1.0, (n, 2)) * rng.choice([0.3, 3.0, 30.0], (n, 1))
+    u6 = np.ascontiguousarray(np.c_[x1[:, 0], x1[:, 1], np.ones(n), x2[:, 0], x2[:, 1], np.ones(n)])
+    par = pkg.RansacParams.default()
+    par.errorType = err_type
+    got, n_true = pkg.hmatrix_filter(u6, H, par)
+    want = po.hmatrix_filter(u6, H, 4.0, err_name)
+    assert n_true == int(got.sum()) and 0.2 * n < n_true < 0.9 * n
+    assert np.array_equal(got, want)
+    assert pkg.hmatrix_filter(u6[:0], H, par)[1] == 0

@@ -328,3 +328,38 @@ def test_cli_distance_threshold(pkg, tmp_path):
     assert [int(log[1]), int(log[2])] == [res.n_inliers, res.n_unique] and res.n_unique > 100
     fg, _, _ = _library_run(pkg, [pkg.LadderStep.make((1,), 360.0)])
     assert fg.n_tentatives != res.n_tentatives          # not the FGINN list
+
+
+def test_cli_ground_truth_verification(pkg, tmp_path):
+    """ver_type 1: the H file is read as the ground truth (here the homography a ver_type 0 run has just written), the log row is
+    WriteLog's GR_PLUS_RANSAC row (10 fields, io_mods.cpp:38-52) and the written matches are the LORANSAC inliers the ground truth
+    confirms - the same numbers as the library call with mods_ransac_params.groundTruth = 2."""
+    import torch
+    _run(tmp_path, "iters_one_view.ini")                                  # leaves H.txt (6 significant digits)
+    Hgt = np.loadtxt(tmp_path / "H.txt").reshape(3, 3)
+    err = _run(tmp_path, "iters_one_view.ini", ver_type="1")
+    assert "1st geom inc" in err and "RANSACed" in err
+    log = (tmp_path / "log.txt").read_text().split()
+    assert len(log) == 10
+    tr_r, n_r, tr_all, n_un = int(log[1]), int(log[2]), int(log[4]), int(log[5])
+    assert 15 <= tr_r <= n_r <= n_un and tr_r <= tr_all <= n_un
+    got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    assert len(got) == tr_r
+    # the library call with the same parameters gives the same counts and the same matches
+    a, b = _grey(G1), _grey(G6)
+    h, w = a.shape
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    par.ransac.groundTruth, par.ransac.ransacForStopping = 2, 1
+    for i, v in enumerate(Hgt.reshape(9)):
+        par.ransac.gtH[i] = v
+    pkg.ransac_pin_seed(4242)
+    res, m = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, [pkg.LadderStep.make((1,), 360.0)], rep1, rep2, par, max_matches=1 << 20)
+    pkg.ransac_pin_seed(-1)
+    rep1.close(); rep2.close(); ctx.close()
+    assert [res.gt_true_of_ransac, res.gt_ransac_inliers, res.gt_true, res.n_unique] == [tr_r, n_r, tr_all, n_un]
+    assert np.allclose(got, m, rtol=1e-5, atol=1e-3)

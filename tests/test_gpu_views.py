@@ -290,3 +290,38 @@ def test_ladder_with_grouped_detectors(pkg):
     for r in reps1 + reps2:
         r.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("both", [True, False])
+def test_ladder_with_ground_truth_verification(pkg, both):
+    """ver_type 1 (GR_TRUTH, mods.cpp:290-320): HMatrixFiltering of the unique tentatives against a known homography and, with
+    doBothRANSACgroundTruth, LORANSACFiltering + HMatrixFiltering of its inliers - counts and verified list equal to the oracle chain
+    (the reference's own error functions and degensac)."""
+    import torch
+    import pipeline_oracle as po
+    import refdeg
+    if not refdeg.available():
+        pytest.skip("oracle/_ref not built")
+    w, h = 640, 480
+    a, b, Htrue = synth.pair(w, h, seed=41)
+    Hgt = Htrue.copy()
+    Hgt[0, 2] += 1.5                                   # a slightly wrong ground truth: both sides of the threshold occur
+    want = po.match_pair_ground_truth(a, b, Hgt, both=both, seed_time=31)
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    rep1, rep2 = pkg.ImgRep(ctx), pkg.ImgRep(ctx)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(31)
+    par = pkg.PairParams.default()
+    par.ransac.groundTruth = 2 if both else 1
+    par.ransac.ransacForStopping = 1
+    for i, v in enumerate(Hgt.reshape(9)):
+        par.ransac.gtH[i] = v
+    res, m = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, [pkg.LadderStep.make((1,), 360.0)], rep1, rep2, params=par, max_matches=100000)
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"] > 500
+    assert res.gt_true == want["gt_true"] and 0.1 * res.n_unique < res.gt_true < res.n_unique
+    assert res.gt_ransac_inliers == want["gt_ransac_inliers"] and res.gt_true_of_ransac == want["gt_true_of_ransac"]
+    assert res.n_inliers == want["n_inliers"] == len(m) and np.array_equal(m, want["matches"])
+    assert np.array_equal(np.array(res.H), Hgt.reshape(9))
+    rep1.close(); rep2.close(); ctx.close()
