@@ -127,7 +127,7 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   p.contradDist = ini.GetDouble("Matching", "contradDist", 10.0);
   p.nn = 50;
   const std::string vm = ini.GetString("Matching", "vector_matcher", "");
-  if (!vm.empty() && vm != "linear" && cfg->verbose) std::cerr << "Note: vector_matcher=" << vm << ": this build always searches exactly (linear)" << std::endl;
+  if (!vm.empty() && vm != "linear") std::cerr << "Note: vector_matcher=" << vm << ": this build always searches exactly (the linear index), the approximate indices of FLANN are not reproduced" << std::endl;
   // [DuplicateFiltering] :665-679
   p.dup_dist = ini.GetDouble("DuplicateFiltering", "duplicateDist", 3.0);
   p.dup_before_ransac = (int)ini.GetDouble("DuplicateFiltering", "doBeforeRANSAC", 1);
