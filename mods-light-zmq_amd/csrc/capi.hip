@@ -122,7 +122,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
-  (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipFree(c->m_u6); (void)hipFree(c->m_laf); (void)hipFree(c->m_count); (void)hipFree(c->m_regs);
+  (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipFree(c->m_count); (void)hipFree(c->m_regs);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -403,16 +403,27 @@ int mods_sift_patch(mods_ctx *c, const float *patch, int ps, int rootsift, doubl
 }
 
 // ---- matching ----------------------------------------------------------------------------------
+// The packed output of the last search (n tentatives | correspondences | frames, common.hpp) in ONE device-to-host copy,
+// split into the caller's arrays (any of them may be null).  Synchronises the context's stream.
+int mods_match_copy_out(mods_ctx *c, int n, mods_tentative *tent, double *u6, double *laf) {
+  if (n <= 0) return MODS_OK;
+  static thread_local std::vector<char> stage;
+  stage.resize(tent_bytes((size_t)n));
+  MODS_HIP_CHECK(hipMemcpyAsync(stage.data(), c->m_tent, stage.size(), hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (tent) memcpy(tent, stage.data(), sizeof(mods_tentative) * n);
+  if (u6) memcpy(u6, stage.data() + tent_u6_off((size_t)n), sizeof(double) * 6 * n);
+  if (laf) memcpy(laf, stage.data() + tent_laf_off((size_t)n), sizeof(double) * 14 * n);
+  return MODS_OK;
+}
+
 int mods_match_fetch_internal(mods_ctx *c, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out) {
   int n = 0;
   MODS_HIP_CHECK(hipMemcpyAsync(&n, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
   *n_out = n;
   if (n > max_out) { set_error("tentative output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
-  if (n > 0 && out) MODS_HIP_CHECK(hipMemcpy(out, c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost));
-  if (n > 0 && u6_out) MODS_HIP_CHECK(hipMemcpy(u6_out, c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost));
-  if (n > 0 && laf_out) MODS_HIP_CHECK(hipMemcpy(laf_out, c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost));
-  return MODS_OK;
+  return mods_match_copy_out(c, n, out, u6_out, laf_out);
 }
 
 int mods_match_fginn(mods_ctx *c, const mods_region *q, int n_q, const mods_region *t, int n_t, double ratio,
@@ -720,12 +731,7 @@ int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int str
   res->n_tentatives = n;
   if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
   tent->resize(n); u6->resize((size_t)n * 6); laf->resize((size_t)n * 14);
-  if (n > 0) {
-    MODS_HIP_CHECK(hipMemcpyAsync(tent->data(), c->m_tent, sizeof(mods_tentative) * n, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipMemcpyAsync(u6->data(), c->m_u6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipMemcpyAsync(laf->data(), c->m_laf, sizeof(double) * 14 * n, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
-  }
+  if ((rc = mods_match_copy_out(c, n, tent->data(), u6->data(), laf->data()))) return rc;
   res->ms_match = now_ms() - t1;
   return MODS_OK;
 }
@@ -800,8 +806,8 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
   const double t0 = now_ms();
   if ((rc = mods_detect_describe_dev(c, c->input_dev, n_img, w, h, w, &par->det, &par->desc, nd.data(), nr.data()))) return rc;
   const double t1 = now_ms();
-  // The tentative lists of the batch go to the host through a pinned arena: the three copies of a pair are plain DMA
-  // transfers queued behind its match kernels, the stream is synchronised once per pair for the COUNT only (4 bytes) and once
+  // The tentative lists of the batch go to the host through a pinned arena: the packed list of a pair (tentatives |
+  // correspondences | frames) is ONE transfer queued behind its match kernels, the stream is synchronised once per pair for the COUNT only (4 bytes) and once
   // per batch for the lists; a pair that does not fit the arena takes the direct (pageable, synchronous) path.
   if (!c->pin_arena) { MODS_HIP_CHECK(hipHostMalloc(&c->pin_arena, kPinArena)); c->pin_arena_cap = kPinArena; }
   int *pin_n = c->host_counts;                   // pinned; free between detect_describe's read-back and the next batch
@@ -822,19 +828,11 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
     if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
     tent[i]->resize(n); u6[i]->resize((size_t)n * 6); laf[i]->resize((size_t)n * 14);
     if (n > 0) {
-      const size_t b_t = sizeof(mods_tentative) * n, b_u = sizeof(double) * 6 * n, b_l = sizeof(double) * 14 * n;
-      if (used + b_t + b_u + b_l <= c->pin_arena_cap) {
-        char *a = c->pin_arena + used;
-        MODS_HIP_CHECK(hipMemcpyAsync(a, c->m_tent, b_t, hipMemcpyDeviceToHost, c->stream));
-        MODS_HIP_CHECK(hipMemcpyAsync(a + b_t, c->m_u6, b_u, hipMemcpyDeviceToHost, c->stream));
-        MODS_HIP_CHECK(hipMemcpyAsync(a + b_t + b_u, c->m_laf, b_l, hipMemcpyDeviceToHost, c->stream));
-        off[i] = used; used += b_t + b_u + b_l;
-      } else {
-        MODS_HIP_CHECK(hipMemcpyAsync(tent[i]->data(), c->m_tent, b_t, hipMemcpyDeviceToHost, c->stream));
-        MODS_HIP_CHECK(hipMemcpyAsync(u6[i]->data(), c->m_u6, b_u, hipMemcpyDeviceToHost, c->stream));
-        MODS_HIP_CHECK(hipMemcpyAsync(laf[i]->data(), c->m_laf, b_l, hipMemcpyDeviceToHost, c->stream));
-        MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
-      }
+      const size_t bytes = tent_bytes((size_t)n);
+      if (used + bytes <= c->pin_arena_cap) {
+        MODS_HIP_CHECK(hipMemcpyAsync(c->pin_arena + used, c->m_tent, bytes, hipMemcpyDeviceToHost, c->stream));
+        off[i] = used; used += (bytes + 15) & ~(size_t)15;
+      } else if ((rc = mods_match_copy_out(c, n, tent[i]->data(), u6[i]->data(), laf[i]->data()))) return rc;
     }
     r->ms_match = now_ms() - tm0;
   }
@@ -844,8 +842,8 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
     const size_t n = tent[i]->size();
     const char *a = c->pin_arena + off[i];
     memcpy(tent[i]->data(), a, sizeof(mods_tentative) * n);
-    memcpy(u6[i]->data(), a + sizeof(mods_tentative) * n, sizeof(double) * 6 * n);
-    memcpy(laf[i]->data(), a + sizeof(mods_tentative) * n + sizeof(double) * 6 * n, sizeof(double) * 14 * n);
+    memcpy(u6[i]->data(), a + tent_u6_off(n), sizeof(double) * 6 * n);
+    memcpy(laf[i]->data(), a + tent_laf_off(n), sizeof(double) * 14 * n);
   }
   return MODS_OK;
 }

@@ -62,6 +62,10 @@ struct StageTimer {
 
 }  // namespace mods
 
+__host__ __device__ inline size_t tent_u6_off(size_t n) { return (n * sizeof(mods_tentative) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t tent_laf_off(size_t n) { return tent_u6_off(n) + n * 6 * sizeof(double); }
+__host__ __device__ inline size_t tent_bytes(size_t n) { return tent_laf_off(n) + n * 14 * sizeof(double); }
+
 struct mods_ctx {
   int device = 0;
   int max_w = 0, max_h = 0, batch = 1;
@@ -140,8 +144,9 @@ struct mods_ctx {
   void *m_p2 = nullptr;              // pass-1 top-2 keys per train split, pass-2 query subset (see match.hip)
   size_t m_best2_cap = 0;            // entries (pairs of keys) in the top-2 table
   mods_tentative *m_tent = nullptr;
-  double *m_u6 = nullptr;            // [pad][6] correspondences (x1 y1 1 x2 y2 1)
-  double *m_laf = nullptr;           // [pad][14] frames (x y a11 a12 a21 a22 s) of both regions
+  // m_tent holds the n tentatives of the last search PACKED: mods_tentative[n] | (16-byte aligned) u6[n][6] = the correspondences
+  // (x1 y1 1 x2 y2 1) | laf[n][14] = the frames (x y a11 a12 a21 a22 s) of both regions - one device-to-host copy of
+  // tent_bytes(n) bytes brings all three (tent_u6_off / tent_laf_off give the parts)
   int *m_count = nullptr;
   mods_region *m_regs = nullptr;     // [2][max_cand] staging for host-side lists
   std::vector<mods_tentative> h_tent;  // host copies for the sequential stages
@@ -191,3 +196,6 @@ int launch_sift_patch_test(mods_ctx *ctx, const float *patch_dev, int ps, int ro
 
 
 }  // namespace mods
+
+// capi.hip: the packed output of the last search in one device-to-host copy, split into the caller's arrays (synchronises the stream)
+extern "C" int mods_match_copy_out(mods_ctx *c, int n, mods_tentative *tent, double *u6, double *laf);

@@ -220,13 +220,7 @@ static int match_into(mods_ctx *c, mods_imgrep *q, mods_imgrep *t, double ratio,
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (m > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
   out->t.resize(m); out->u6.resize((size_t)m * 6); out->laf.resize((size_t)m * 14);
-  if (m > 0) {
-    MODS_HIP_CHECK(hipMemcpyAsync(out->t.data(), c->m_tent, sizeof(mods_tentative) * m, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipMemcpyAsync(out->u6.data(), c->m_u6, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipMemcpyAsync(out->laf.data(), c->m_laf, sizeof(double) * 14 * m, hipMemcpyDeviceToHost, c->stream));
-    MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
-  }
-  return MODS_OK;
+  return mods_match_copy_out(c, m, out->t.data(), out->u6.data(), out->laf.data());
 }
 
 // CorrespondenceBank::GetCorresponcesVector("All", "All") (correspondencebank.cpp:114-148): the bank is a std::map keyed by

@@ -583,20 +583,22 @@ __global__ __launch_bounds__(1024) void match_emit_kernel(MatchConst k, const Qu
                                                           const int *__restrict__ bad, const double2 *__restrict__ qxy,
                                                           const double2 *__restrict__ txy, const mods_region *__restrict__ qreg,
                                                           const mods_region *__restrict__ treg, const int *__restrict__ block_counts,
-                                                          mods_tentative *__restrict__ out, double *__restrict__ u6, double *__restrict__ laf,
-                                                          int *__restrict__ out_count, int max_out) {
-  __shared__ int s_wave[16];
-  __shared__ int s_base;
+                                                          mods_tentative *__restrict__ out, int *__restrict__ out_count, int max_out) {
+  __shared__ int s_wave[16], s_wtot[16];
+  __shared__ int s_base, s_total;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // offset of this block = accepted queries of all earlier blocks
-  int part = 0;
-  for (int q = tid; q < (int)blockIdx.x; q += 1024) part += block_counts[q];
-  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-  if (lane == 0) s_wave[wv] = part;
+  // offset of this block = accepted queries of all earlier blocks; the total fixes the packed layout of the output
+  // (tentatives | correspondences | frames, see common.hpp)
+  int part = 0, tot = 0;
+  for (int q = tid; q < (int)gridDim.x; q += 1024) { const int c = block_counts[q]; tot += c; if (q < (int)blockIdx.x) part += c; }
+  for (int off = 32; off > 0; off >>= 1) { part += __shfl_xor(part, off); tot += __shfl_xor(tot, off); }
+  if (lane == 0) { s_wave[wv] = part; s_wtot[wv] = tot; }
   __syncthreads();
-  if (tid == 0) { int t = 0; for (int q = 0; q < 16; q++) t += s_wave[q]; s_base = t; }
+  if (tid == 0) { int t = 0, u = 0; for (int q = 0; q < 16; q++) { t += s_wave[q]; u += s_wtot[q]; } s_base = t; s_total = u; }
   __syncthreads();
   const int base = s_base;
+  const size_t n_out = (size_t)min(s_total, max_out);
+  double *u6 = (double *)((char *)out + tent_u6_off(n_out)), *laf = (double *)((char *)out + tent_laf_off(n_out));
   __syncthreads();
   mods_tentative tc;
   const bool emit = fginn_accept(k, blockIdx.x * 1024 + tid, mid, key_ge, key_lt, n_lt, bad, &tc);
@@ -639,8 +641,6 @@ int match_ensure_buffers(mods_ctx *ctx) {
   const size_t n = match_pad(ctx);
   MODS_HIP_CHECK(hipMalloc(&ctx->m_desc, 2 * n * 128));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_c, (4 * n + 2 * (n / 32 + 2)) * sizeof(int)));   // c of queries, trains; -floor(c/2) of both; parity words of both
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_u6, n * 6 * sizeof(double)));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_laf, n * 14 * sizeof(double)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_regs, 2 * (size_t)ctx->max_cand * sizeof(mods_region)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_xy, 2 * n * sizeof(double2)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_u64, 3 * n * sizeof(unsigned long long)));
@@ -650,11 +650,23 @@ int match_ensure_buffers(mods_ctx *ctx) {
   // the pass-2 subset: list | count | norms | descriptors | state
   ctx->m_best2_cap = (size_t)match_target_blocks() * 128 * MATCH_QB1 + n + 128 * MATCH_QB1;
   MODS_HIP_CHECK(hipMalloc(&ctx->m_p2, ctx->m_best2_cap * 16 + n * (3 * sizeof(int) + 128 + sizeof(QueryMid)) + 128));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, n * sizeof(mods_tentative)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, tent_bytes(n) + 64));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_count, sizeof(int)));
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_desc, 0, 2 * n * 128, ctx->stream));
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_c, 0, 4 * n * sizeof(int), ctx->stream));
   return MODS_OK;
+}
+
+// One launch instead of four memsets per search: tentative counter, pass-2 list counter, the parity words the pack kernels OR
+// into, and the shared bounds of pass 1 (0x7f7f7f7f = none).  grid = ceil(max(n_q, n_t) / 256), block 256
+__global__ __launch_bounds__(256) void match_init_kernel(int n_q, int n_t, int *__restrict__ m_count, int *__restrict__ count2,
+                                                         unsigned int *__restrict__ qpar, unsigned int *__restrict__ tpar,
+                                                         int *__restrict__ gthr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) { *m_count = 0; *count2 = 0; }
+  if (i < n_q) gthr[i] = 0x7f7f7f7f;
+  if (i <= n_q / 32) qpar[i] = 0u;
+  if (i <= n_t / 32) tpar[i] = 0u;
 }
 
 // queries / trains: device region lists with host-known sizes n_q, n_t.
@@ -669,19 +681,15 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   k.sqminratio = ratio * ratio;
   k.contr_sq = contradDist * contradDist;
   if (!(k.sqminratio < 1.0)) { set_error("FGINN ratio >= 1 (all-neighbours mode) is not supported"); return MODS_E_ARG; }
-  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_count, 0, sizeof(int), ctx->stream));
-  if (n_q == 0 || n_t == 0) return MODS_OK;
+  if (n_q == 0 || n_t == 0) { MODS_HIP_CHECK(hipMemsetAsync(ctx->m_count, 0, sizeof(int), ctx->stream)); return MODS_OK; }
   const size_t n = match_pad(ctx);
   int8_t *qd = ctx->m_desc, *td = ctx->m_desc + n * 128;
   int *qc = ctx->m_c, *tc = ctx->m_c + n, *qc2 = ctx->m_c + 2 * n, *tc2 = ctx->m_c + 3 * n;
   unsigned int *qpar = (unsigned int *)(ctx->m_c + 4 * n), *tpar = qpar + n / 32 + 2;
-  MODS_HIP_CHECK(hipMemsetAsync(qpar, 0, sizeof(unsigned int) * 2 * (n / 32 + 2), ctx->stream));
   double2 *qxy = (double2 *)ctx->m_xy, *txy = (double2 *)ctx->m_xy + n;
   unsigned long long *best = ctx->m_u64, *key_ge = ctx->m_u64 + n, *key_lt = ctx->m_u64 + 2 * n;
   int *n_lt = ctx->m_int, *bad = ctx->m_int + n;
   StageScope ts(ctx, MODS_STAGE_MATCH);
-  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
-  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
   const int n_tiles = (n_t + 31) / 32;
   const int target_blocks = match_target_blocks();
   // carve of m_p2 (every part 16-byte aligned)
@@ -690,8 +698,9 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   int8_t *qd2 = (int8_t *)(mid2 + n);
   int *list2 = (int *)(qd2 + n * 128), *qcs = list2 + n, *count2 = qcs + n;
   int *gthr = count2 + 16;
-  MODS_HIP_CHECK(hipMemsetAsync(count2, 0, sizeof(int), ctx->stream));
-  MODS_HIP_CHECK(hipMemsetAsync(gthr, 0x7f, sizeof(int) * n_q, ctx->stream));
+  hipLaunchKernelGGL(match_init_kernel, dim3((std::max(n_q, n_t) + 255) / 256), dim3(256), 0, ctx->stream, n_q, n_t, ctx->m_count, count2, qpar, tpar, gthr);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
   (void)best;
   // pass 1: top-2 keys per query and train split
   const int qblocks1 = (n_q + 128 * MATCH_QB1 - 1) / (128 * MATCH_QB1);
@@ -715,7 +724,7 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   const int eblocks = (n_q + 1023) / 1024;
   int *block_counts = (int *)(ctx->m_int + 2 * n);
   hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
-  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, ctx->m_tent, ctx->m_u6, ctx->m_laf, ctx->m_count, ctx->max_cand);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, ctx->m_tent, ctx->m_count, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }
@@ -787,7 +796,7 @@ int match_run_distance(mods_ctx *ctx, const mods_region *q_dev, int n_q, const m
   const int eblocks = (n_q + 1023) / 1024;
   int *block_counts = (int *)(ctx->m_int + 2 * n);
   hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
-  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, ctx->m_tent, ctx->m_u6, ctx->m_laf, ctx->m_count, ctx->max_cand);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, ctx->m_tent, ctx->m_count, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }

@@ -122,7 +122,7 @@ RansacGpu::~RansacGpu() {
   if ((long)getpid() == (long)syscall(SYS_gettid)) return;
   (void)hipSetDevice(device);
   (void)hipFree(u_dev); (void)hipFree(hyp_dev); (void)hipHostFree(hyp_host); (void)hipFree(d_dev); (void)hipFree(gain_dev);
-  (void)hipFree(counts_dev); (void)hipFree(J_dev); (void)hipHostFree(counts_host); (void)hipHostFree(J_host);
+  (void)hipFree(J_dev); (void)hipHostFree(J_host);   // (the counts live behind the J values in the same allocations)
   (void)hipHostFree(row_host); (void)hipFree(aux_dev);
   (void)hipFree(ev_dev); (void)hipHostFree(ev_host);
   (void)hipFree(cand_dev); (void)hipHostFree(cand_host); (void)hipFree(candc_dev); (void)hipHostFree(candc_host);
@@ -172,17 +172,18 @@ bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
     RS_CHECK(hipMalloc(&ws->u_dev, ws->u_cap * sizeof(double)));
   }
   if (n_hyp > ws->hyp_cap) {
-    if (ws->hyp_dev) { RS_CHECK(hipFree(ws->hyp_dev)); RS_CHECK(hipHostFree(ws->hyp_host)); RS_CHECK(hipFree(ws->counts_dev));
-                       RS_CHECK(hipFree(ws->J_dev)); RS_CHECK(hipHostFree(ws->counts_host)); RS_CHECK(hipHostFree(ws->J_host)); }
+    if (ws->hyp_dev) { RS_CHECK(hipFree(ws->hyp_dev)); RS_CHECK(hipHostFree(ws->hyp_host));
+                       RS_CHECK(hipFree(ws->J_dev)); RS_CHECK(hipHostFree(ws->J_host)); }
     ws->hyp_cap = 64;
     while (ws->hyp_cap < n_hyp) ws->hyp_cap *= 2;
     n_hyp = ws->hyp_cap;
     RS_CHECK(hipMalloc(&ws->hyp_dev, (size_t)HYP_SLOT_BYTES * n_hyp));
     RS_CHECK(hipHostMalloc(&ws->hyp_host, (size_t)HYP_SLOT_BYTES * n_hyp));
-    RS_CHECK(hipMalloc(&ws->counts_dev, sizeof(int) * 2 * n_hyp));
-    RS_CHECK(hipMalloc(&ws->J_dev, sizeof(double) * n_hyp));
-    RS_CHECK(hipHostMalloc(&ws->counts_host, sizeof(int) * 2 * n_hyp));
-    RS_CHECK(hipHostMalloc(&ws->J_host, sizeof(double) * n_hyp));
+    // J[hyp_cap] | counts[2 * hyp_cap] in ONE allocation on either side: the scores of a batch come back in one copy
+    RS_CHECK(hipMalloc(&ws->J_dev, 2 * sizeof(double) * n_hyp));
+    RS_CHECK(hipHostMalloc(&ws->J_host, 2 * sizeof(double) * n_hyp));
+    ws->counts_dev = (int *)(ws->J_dev + n_hyp);
+    ws->counts_host = (int *)(ws->J_host + n_hyp);
     ws->dg_cap = 0;
   }
   // hipFree / hipMalloc synchronise the whole device (20+ ms under a running pipeline): grow in powers of two from a
@@ -213,8 +214,7 @@ static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, d
                      do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
   hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
   RS_CHECK(hipGetLastError());
-  RS_CHECK(hipMemcpyAsync(ws->counts_host, ws->counts_dev, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
-  RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ws->stream));
+  RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * ws->hyp_cap + sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
   RS_CHECK(hipStreamSynchronize(ws->stream));
   ws->launches += 2;
   return true;

@@ -100,8 +100,7 @@ static bool gpu_score_f(RansacGpu *ws, int len, int n, int err_type, int do_sym,
                      err_type, do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
   hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
   RS_CHECK(hipGetLastError());
-  RS_CHECK(hipMemcpyAsync(ws->counts_host, ws->counts_dev, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
-  RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ws->stream));
+  RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * ws->hyp_cap + sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
   RS_CHECK(hipStreamSynchronize(ws->stream));
   ws->launches += 2;
   return true;
