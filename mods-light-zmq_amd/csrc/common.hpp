@@ -147,7 +147,7 @@ struct mods_ctx {
   // m_tent holds the n tentatives of the last search PACKED: mods_tentative[n] | (16-byte aligned) u6[n][6] = the correspondences
   // (x1 y1 1 x2 y2 1) | laf[n][14] = the frames (x y a11 a12 a21 a22 s) of both regions - one device-to-host copy of
   // tent_bytes(n) bytes brings all three (tent_u6_off / tent_laf_off give the parts)
-  int *m_count = nullptr;
+  int *m_count = nullptr;            // tentatives of the last search: PINNED HOST memory written by the emit kernel
   mods_region *m_regs = nullptr;     // [2][max_cand] staging for host-side lists
   std::vector<mods_tentative> h_tent;  // host copies for the sequential stages
   std::vector<double> h_u6, h_laf;

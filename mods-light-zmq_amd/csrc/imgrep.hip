@@ -216,8 +216,8 @@ static int match_into(mods_ctx *c, mods_imgrep *q, mods_imgrep *t, double ratio,
   if (distance > 0) rc = match_run_distance(c, q->reg, q->n, t->reg, t->n, distance);
   else rc = match_run(c, q->reg, q->n, t->reg, t->n, ratio, par->contradDist, par->nn);
   if (rc) return rc;
-  MODS_HIP_CHECK(hipMemcpyAsync(&m, c->m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  m = *(volatile int *)c->m_count;
   if (m > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
   out->t.resize(m); out->u6.resize((size_t)m * 6); out->laf.resize((size_t)m * 14);
   return mods_match_copy_out(c, m, out->t.data(), out->u6.data(), out->laf.data());

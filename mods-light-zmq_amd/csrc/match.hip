@@ -651,7 +651,9 @@ int match_ensure_buffers(mods_ctx *ctx) {
   ctx->m_best2_cap = (size_t)match_target_blocks() * 128 * MATCH_QB1 + n + 128 * MATCH_QB1;
   MODS_HIP_CHECK(hipMalloc(&ctx->m_p2, ctx->m_best2_cap * 16 + n * (3 * sizeof(int) + 128 + sizeof(QueryMid)) + 128));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, tent_bytes(n) + 64));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_count, sizeof(int)));
+  // the tentative count lives in pinned host memory: the emit kernel's single store lands there, the host reads it after a
+  // stream synchronisation - no 4-byte copy launch per search
+  MODS_HIP_CHECK(hipHostMalloc(&ctx->m_count, 64));
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_desc, 0, 2 * n * 128, ctx->stream));
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_c, 0, 4 * n * sizeof(int), ctx->stream));
   return MODS_OK;
