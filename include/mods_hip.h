@@ -535,6 +535,9 @@ int mods_pipeline_submit(mods_pipeline *p, const float *img_dev, long tag);
 int mods_pipeline_submit_host(mods_pipeline *p, const float *img_host, long tag);
 int mods_pipeline_submit_host_u8(mods_pipeline *p, const unsigned char *img_host, long tag);
 int mods_pipeline_next(mods_pipeline *p, mods_pair_result *res, long *tag);
+/* the same, and the verified matches of the pair (rows x1 y1 x2 y2, the order of mods_match_pair_dev's matches_out): the first
+ * min(res->n_inliers, max_matches) rows are written */
+int mods_pipeline_next_matches(mods_pipeline *p, mods_pair_result *res, long *tag, double *matches_out, int max_matches);
 void mods_pipeline_destroy(mods_pipeline *p);
 
 #ifdef __cplusplus

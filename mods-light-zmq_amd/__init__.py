@@ -831,6 +831,13 @@ class Pipeline:
         _check(lib().mods_pipeline_next(self.h, C.byref(res), C.byref(tag)))
         return res, tag.value
 
+    def next_matches(self, max_matches=1 << 16):
+        """(PairResult, tag, matches[n,4]) of the oldest submitted pair: the verified matches as mods_match_pair_dev returns them."""
+        res, tag = PairResult(), C.c_long()
+        m = np.zeros((max_matches, 4), np.float64)
+        _check(lib().mods_pipeline_next_matches(self.h, C.byref(res), C.byref(tag), m.ctypes.data_as(C.c_void_p), max_matches))
+        return res, tag.value, m[:min(res.n_inliers, max_matches)]
+
     def timing_enable(self, stages):
         mask = 0
         for s in stages:

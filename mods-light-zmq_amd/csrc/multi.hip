@@ -38,6 +38,8 @@ struct mods_multi {
   std::vector<float *> img;           // [dev] both images
   size_t cap = 0;                     // regions per device and step
   int rep_cap = 0;
+  size_t img_px = 0;                  // pixels the image buffer of a device holds (both images together)
+  int side = 0;                       // side of the contexts' square canvas (>= the diagonal of the images given at creation)
 };
 
 namespace {
@@ -102,6 +104,8 @@ int mods_multi_create(const int *devices, int n, int w, int h, int rep_capacity,
   for (int a = 0; a < n; a++)
     for (int b = a + 1; b < n; b++) distinct = distinct && devices[a] != devices[b];
   const int side = (int)std::ceil(std::hypot((double)w, (double)h));     // a rotated view fits a side x side canvas
+  m->img_px = (size_t)w * h * 2;
+  m->side = side;
   m->rep_cap = rep_capacity > 0 ? rep_capacity : (1 << 20);
   m->cap = (size_t)m->rep_cap * 2 / n + (1 << 16);
   for (int d = 0; d < n; d++) {
@@ -144,11 +148,18 @@ mods_imgrep *mods_multi_bank(mods_multi *m, int image) { return m ? (image ? m->
 int mods_match_ladder_multi(mods_multi *m, const float *img1_host, int w1, int h1, const float *img2_host, int w2, int h2,
                             const mods_ladder_step *steps, int n_steps, int min_matches, const mods_pair_params *par,
                             mods_ladder_result *res, double *matches_out, int max_matches) {
-  if (!m || !img1_host || !img2_host || !steps || !par || !res) { set_error("match_ladder_multi: null argument"); return MODS_E_ARG; }
+  if (!m || !img1_host || !img2_host || (!steps && n_steps > 0) || !par || !res) { set_error("match_ladder_multi: null argument"); return MODS_E_ARG; }
+  if (w1 <= 0 || h1 <= 0 || w2 <= 0 || h2 <= 0 || n_steps < 0) { set_error("match_ladder_multi: bad image size or step count"); return MODS_E_ARG; }
   memset(res, 0, sizeof(*res));
   for (int i = 0; i < 9; i++) res->H[i] = -1;
   const int D = m->n;
   const size_t px1 = (size_t)w1 * h1, px2 = (size_t)w2 * h2;
+  // the device buffers were sized by mods_multi_create: both images must fit, and a rotated view of either must fit the canvas
+  if (px1 + px2 > m->img_px || std::ceil(std::hypot((double)w1, (double)h1)) > m->side || std::ceil(std::hypot((double)w2, (double)h2)) > m->side) {
+    set_error("match_ladder_multi: images %dx%d + %dx%d exceed what mods_multi_create was sized for (%zu pixels, canvas side %d)",
+              w1, h1, w2, h2, m->img_px, m->side);
+    return MODS_E_ARG;
+  }
   for (int d = 0; d < D; d++) {
     MODS_HIP_CHECK(hipSetDevice(m->dev[d]));
     hipStream_t st = (hipStream_t)mods_ctx_stream(m->ctx[d]);

@@ -207,7 +207,7 @@ int mods_pipeline_submit_host_u8(mods_pipeline *p, const unsigned char *img_host
 
 // Result of the oldest submitted pair (blocks until it is verified).  Returns MODS_E_ARG when nothing
 // is in flight.
-int mods_pipeline_next(mods_pipeline *p, mods_pair_result *res, long *tag) {
+int mods_pipeline_next_matches(mods_pipeline *p, mods_pair_result *res, long *tag, double *matches_out, int max_matches) {
   if (!p || !res) return MODS_E_ARG;
   std::shared_ptr<Job> j;
   {
@@ -221,8 +221,16 @@ int mods_pipeline_next(mods_pipeline *p, mods_pair_result *res, long *tag) {
   *res = j->res;
   if (tag) *tag = j->tag;
   if (j->rc) set_error("%s", j->err.c_str());
+  // the verify stage leaves the verified correspondences in the first n_inliers rows of the job's list
+  if (!j->rc && matches_out)
+    for (int m = 0; m < j->res.n_inliers && m < max_matches && (size_t)m * 6 + 5 < j->u6.size(); m++) {
+      const double *q = &j->u6[(size_t)m * 6];
+      matches_out[4 * m] = q[0]; matches_out[4 * m + 1] = q[1]; matches_out[4 * m + 2] = q[3]; matches_out[4 * m + 3] = q[4];
+    }
   return j->rc;
 }
+
+int mods_pipeline_next(mods_pipeline *p, mods_pair_result *res, long *tag) { return mods_pipeline_next_matches(p, res, tag, nullptr, 0); }
 
 void mods_pipeline_destroy(mods_pipeline *p) {
   if (!p) return;

@@ -338,3 +338,21 @@ def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=
         if ninl >= min_matches:
             break
     return out
+
+
+_PAIR_CACHE = {}
+
+
+def cached_pair(w, h, seed, seed_time, **kw):
+    """match_pair of synth.pair(w, h, seed), kept for the session: several tests check different entry points against the
+    same oracle result (a 1080p pair takes seconds on the CPU).  Returns (img1, img2, H_true, oracle result)."""
+    import synth
+    key = (w, h, seed, seed_time, tuple(sorted(kw.items())))
+    if key not in _PAIR_CACHE:
+        ik = (w, h, seed)
+        if ik not in _PAIR_CACHE:
+            a, b, Ht = synth.pair(w, h, seed=seed)
+            _PAIR_CACHE[ik] = (a, b, Ht, tuple(pmap(orc.detect_describe, (a, b))))
+        a, b, Ht, regs = _PAIR_CACHE[ik]
+        _PAIR_CACHE[key] = (a, b, Ht, match_pair(a, b, seed_time=seed_time, regions=regs, **kw))
+    return _PAIR_CACHE[key]

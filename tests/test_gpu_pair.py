@@ -13,8 +13,7 @@ pytestmark = pytest.mark.gpu
 def test_pair_end_to_end(pkg, w, h, seed):
     import torch
     import pipeline_oracle as po
-    a, b, Htrue = synth.pair(w, h, seed=seed)
-    want = po.match_pair(a, b, seed_time=777)
+    a, b, Htrue, want = po.cached_pair(w, h, seed, 777)
     ctx = pkg.Context(0, w, h, 2)
     t = torch.from_numpy(np.stack([a, b])).cuda()
     torch.cuda.synchronize()
@@ -226,3 +225,92 @@ def test_pipeline_host_input(pkg, ppb):
     pipe.close()
     for b in pin32 + pin8:
         b.close()
+
+
+def _check_against_oracle(res, m, want, Htrue):
+    assert list(res.n_detected) == want["n_detected"] and list(res.n_described) == want["n_described"]
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] and res.n_inliers > 50
+    assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])          # identical inlier set, same order
+    Hg, Hw = np.array(res.H).reshape(3, 3), want["H"]
+    assert np.max(np.abs(Hg / Hg[2, 2] - Hw / Hw[2, 2]) / np.maximum(1e-3, np.abs(Hw / Hw[2, 2]))) < 1e-4   # north_star: 1e-4 relative
+    assert np.max(np.abs(Hg / Hg[2, 2] - Htrue) / np.maximum(1.0, np.abs(Htrue))) < 5e-2
+
+
+@pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built")
+def test_bench_pipeline_path_vs_oracle(pkg):
+    """bench.py's own code path (BASELINE configs[1]): Pipeline(6 GPU workers x 8 pairs per batch + 8 verify workers) fed with the
+    benchmark's six 1920 x 1080 pairs as 8-bit images in pinned host memory, 48 submissions = one bench step; every result -
+    counts, RANSAC statistics, the inlier list and H - against the CPU oracle chain of its pair (mods.cpp:202-383)."""
+    import pipeline_oracle as po
+    w, h = 1920, 1080
+    n_pairs, n_sub = 6, 48
+    oracle = [po.cached_pair(w, h, 2000 + i, 12345) for i in range(n_pairs)]
+    pinned = []
+    for a, b, _, _ in oracle:
+        buf = pkg.PinnedBuffer((2, h, w), np.uint8)
+        buf.array[...] = np.stack([a, b]).astype(np.uint8)
+        pinned.append(buf)
+    par = pkg.PairParams.default()
+    pkg.ransac_pin_seed(12345)
+    pipe = pkg.Pipeline(0, w, h, par, 6, 8, 8)
+    got, pending = [], 0
+    for i in range(n_sub):
+        if pending >= pipe.capacity - 1:
+            got.append(pipe.next_matches()); pending -= 1
+        pipe.submit_host(pinned[i % n_pairs].ptr.value, i, u8=True); pending += 1
+    while pending:
+        got.append(pipe.next_matches()); pending -= 1
+    assert [tag for _, tag, _ in got] == list(range(n_sub))
+    for i, (res, _, m) in enumerate(got):
+        _, _, Htrue, want = oracle[i % n_pairs]
+        _check_against_oracle(res, m, want, Htrue)
+    pipe.close()
+    for b in pinned:
+        b.close()
+
+
+@pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built")
+def test_config3_1mp_pairs_through_pipeline(pkg):
+    """BASELINE configs[3] at its shape: a batch of 1024 x 1024 pairs through the pair pipeline (bench.py --config c4: 6 x 8 + 8).
+    32 distinct pairs, every one equal to the serial mods_match_pair_dev of the pair and following its generating homography,
+    four of them against the CPU oracle chain."""
+    import torch
+    import pipeline_oracle as po
+    w = h = 1024
+    n = 32
+    pairs = po.pmap(lambda i: synth.pair(w, h, seed=4000 + i), range(n), threads=8)
+    dev = [torch.from_numpy(np.stack([a, b])).cuda() for a, b, _ in pairs]
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    pkg.ransac_pin_seed(4321)
+    ctx = pkg.Context(0, w, h, 2)
+    serial = [pkg.match_pair_dev(ctx, d.data_ptr(), w, h, par, max_matches=1 << 16) for d in dev]
+    ctx.close()
+    pipe = pkg.Pipeline(0, w, h, par, 6, 8, 8)
+    got, pending = [], 0
+    for i in range(n):
+        if pending >= pipe.capacity - 1:
+            got.append(pipe.next_matches()); pending -= 1
+        pipe.submit(dev[i].data_ptr(), i); pending += 1
+    while pending:
+        got.append(pipe.next_matches()); pending -= 1
+    pipe.close()
+    for i, (res, tag, m) in enumerate(got):
+        exp, em = serial[i]
+        assert tag == i
+        for f in ("n_tentatives", "n_unique", "n_inliers", "ransac_samples", "ransac_lo", "ransac_rejects"):
+            assert getattr(res, f) == getattr(exp, f), (f, i)
+        assert list(res.n_detected) == list(exp.n_detected) and list(res.n_described) == list(exp.n_described)
+        assert list(res.H) == list(exp.H) and np.array_equal(m, em)
+        # the inliers follow the generating homography (the pair's ground truth)
+        Ht = pairs[i][2]
+        assert res.n_inliers > 50
+        x1 = np.c_[m[:, 0], m[:, 1], np.ones(len(m))] @ Ht.T
+        d = np.hypot(x1[:, 0] / x1[:, 2] - m[:, 2], x1[:, 1] / x1[:, 2] - m[:, 3])
+        assert np.mean(d < 4.0) > 0.97, (i, float(np.mean(d < 4.0)))
+    for i in (0, 9, 18, 31):
+        a, b, Ht = pairs[i]
+        want = po.match_pair(a, b, seed_time=4321)
+        _check_against_oracle(got[i][0], got[i][2], want, Ht)
