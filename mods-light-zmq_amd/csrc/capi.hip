@@ -78,6 +78,7 @@ static int ctx_create_impl(int device, int max_w, int max_h, int batch, unsigned
   MODS_HIP_CHECK(hipSetDevice(device));
   mods_ctx *c = new mods_ctx();
   c->device = device; c->max_w = max_w; c->max_h = max_h; c->batch = batch;
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cu = cus; }
   MODS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, stream_flags));
   const size_t px = (size_t)max_w * max_h;
   size_t mc = px / 8;

@@ -68,6 +68,7 @@ __host__ __device__ inline size_t tent_bytes(size_t n) { return tent_laf_off(n) 
 
 struct mods_ctx {
   int device = 0;
+  int n_cu = 256;                    // compute units of the device (sizes the persistent grids)
   int max_w = 0, max_h = 0, batch = 1;
   hipStream_t stream = nullptr;
   // scale space

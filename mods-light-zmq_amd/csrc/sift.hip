@@ -425,7 +425,8 @@ struct BigRegion { int img, ri, P2, n_tap; unsigned long long slab; float scale;
 struct BigLists {                     // device-resident bookkeeping, zeroed before every batch
   int n_regions, n_sitems, n_ritems, n_fitems;
   unsigned long long pool_used;
-  int n_small[2], pad[2];           // regions of the two LDS tiers (P2 <= t_lo, t_lo < P2 <= p2_hi), over all images
+  int n_small[2];                   // regions of the two LDS tiers (P2 <= t_lo, t_lo < P2 <= p2_hi), over all images
+  int sift_next, pad;               // next work unit of sift_wave2_kernel
 };
 // regions up to this size take the fused sample + row-pass kernel (S stays in LDS, no S slab); larger ones the phase kernels
 constexpr int BIG_FUSE_P2 = 256;
@@ -1442,6 +1443,370 @@ __global__ __launch_bounds__(256, 2) void sift_wave_kernel(DescConst k, const fl
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// SIFT, wave-per-8-regions form, second generation (round 3).  Same arithmetic and the same lane roles as sift_wave_kernel;
+// what changed is everything around the arithmetic (profiles/r03_sift_*):
+//   * persistent waves: 2 workgroups of 6 waves per CU pull work units (8 regions of one image) from a device counter, so
+//     the tables are set up once per workgroup instead of once per 8 regions (the old grid spent 71 % of its workgroups on
+//     set-up alone) and the images of a batch balance;
+//   * the histogram bins live at  bo * 128 + (g >> 2) * 64 + br * 16 + (g & 3) * 4 + bc  (doubles): the 32 lanes of a
+//     half-wave - 4 regions x 2 row bins x 4 column bins - always hit 32 different bank pairs whatever the orientation
+//     bins are, so ds_add_f64 runs at its conflict-free rate (10 instead of 23 cycles per wave instruction, tools/ubench);
+//   * the three pixel rows a gradient needs stay in registers (vertical neighbours = the lane's own values of the previous /
+//     next row, horizontal neighbours = one DPP move from the adjacent lane), the patch rows are fetched three rows ahead;
+//     photometric mean / factor sit in registers per pixel slot;
+//   * 11 KB of LDS per wave and <= 168 VGPRs: 12 waves per CU instead of 8.
+// LDS: o table 8 KB | row / column weights | work prefix | masked-pixel list || per wave: bins 8 KB | pixel row (x, o) + pad
+// (the photometric chunk aliases it) | mean, factor, flag.
+// ---------------------------------------------------------------------------------------
+constexpr int S2_WAVES = 12;               // one workgroup per CU: 3 waves per SIMD (<= 168 VGPRs), 145 KB of LDS
+constexpr int S2_BINS = 1024;                 // doubles per wave
+__device__ __forceinline__ int s2_bin(int g, int br, int bc) { return (g >> 2) * 64 + br * 16 + (g & 3) * 4 + bc; }   // + bo * 128
+__device__ __forceinline__ int s2_vec(int g, int i) { return (i & 7) * 128 + s2_bin(g, i >> 5, (i >> 3) & 3); }          // vec[i], i = (br*4 + bc)*8 + bo
+
+static size_t sift_wave2_wave_bytes(int ps) {
+  return sizeof(double) * S2_BINS + sizeof(float2) * ((size_t)SW_R * ps + SW_CW + 2) + sizeof(float) * 3 * SW_R;
+}
+static size_t sift_wave2_lds_bytes(int ps) {
+  const size_t ppa = ((size_t)ps * ps + 7) & ~(size_t)7;
+  return sizeof(float) * 2048 + sizeof(float) * (4 * ps + 4) + sizeof(int) * 72 + sizeof(unsigned short) * ppa + S2_WAVES * sift_wave2_wave_bytes(ps) + 64;
+}
+
+__global__ __launch_bounds__(64 * S2_WAVES, 3) void sift_wave2_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
+                                                                        const int *__restrict__ reg_count, const float *__restrict__ mask,
+                                                                        const SiftTab *__restrict__ tab, int n_img, int *__restrict__ next_unit) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ps = k.desc_ps, pp = ps * ps, ppa = (pp + 7) & ~7;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float *s_ot = smem;                               // [8][256]: o of computeSiftDescriptor per atan2LUTff (case, table index)
+  float *s_w = s_ot + 2048;                         // [4][ps] spatial weights
+  int *s_pref = (int *)(s_w + 4 * ps + 4);          // [n_img + 1] work units before image b; [68]: n_mask
+  unsigned short *s_midx = (unsigned short *)(s_pref + 72);
+  unsigned char *wbase = (unsigned char *)(s_midx + ppa) + (size_t)wv * (sizeof(double) * S2_BINS + sizeof(float2) * (SW_R * ps + SW_CW + 2) + sizeof(float) * 3 * SW_R);
+  double *acc = (double *)wbase;
+  float2 *pxrow = (float2 *)(acc + S2_BINS);        // [8 * ps + pad]: (mask * |grad|, o) of the current pixel row
+  float *s_mean = (float *)(pxrow + SW_R * ps + SW_CW + 2), *s_fac = s_mean + SW_R;
+  int *s_flag = (int *)(s_fac + SW_R);
+  float *g = (float *)pxrow;                        // photometric chunk [8][SW_G], dead before the first pixel row is written
+  const int rowf = SW_R * ps;
+
+  const double M_PI_DOUBLED = 6.28318530718;
+  sift_tables(tab, ps, s_w);
+  for (int i = tid; i < 2048; i += 64 * S2_WAVES) {   // o = (float)(8.0f * ((double)ori + 2 pi) / 2 pi), siftdesc.cpp:181, for every value ori can take
+    const float ori = atan2_lut_case(i >> 8, g_atan_lut[i & 255]);
+    s_ot[i] = (float)(8.0f * ((double)ori + M_PI_DOUBLED) / M_PI_DOUBLED);
+  }
+  if (tid < 64) {   // raster-ordered list of the masked pixels, one wave, ballot compaction
+    int c = 0;
+    for (int base = 0; base < pp; base += 64) {
+      const int p = base + tid;
+      const bool m = p < pp && mask[p] > 0;
+      const unsigned long long bm = __ballot(m);
+      if (m) s_midx[c + __popcll(bm & ((1ull << tid) - 1ull))] = (unsigned short)p;
+      c += __popcll(bm);
+    }
+    if (tid == 0) s_pref[68] = c;
+  }
+  if (tid == 64) {  // work units (groups of 8 regions) before every image
+    int cum = 0;
+    for (int b = 0; b < n_img; b++) { s_pref[b] = cum; int n = reg_count[b]; if (n > k.reg_cap) n = k.reg_cap; cum += (n + SW_R - 1) / SW_R; }
+    s_pref[n_img] = cum;
+  }
+  __syncthreads();
+  const int n_mask = s_pref[68];
+  const int total_units = s_pref[n_img];
+  const float o_zero = (float)(8.0f * ((double)0.f + M_PI_DOUBLED) / M_PI_DOUBLED);
+
+  // histogram lane: region hr, row-bin selector hsel, column bin hbc; its column window and weights
+  const int hr = lane >> 3, hsel = (lane >> 2) & 1, hbc = lane & 3;
+  int clo = ps;
+  for (int i = ps - 1; i >= 0; i--) if (s_w[hbc * ps + i] > 0) clo = i;
+  float wcw[SW_CW];
+#pragma unroll
+  for (int q = 0; q < SW_CW; q++) wcw[q] = (clo + q < ps) ? s_w[hbc * ps + clo + q] : 0.f;
+  // pixel slots of a lane: e = lane + 64 u -> region e / ps, column e % ps (the same for every row and every unit)
+  constexpr int RL = 6;                               // >= ceil(SW_R * ps / 64) for ps <= 48 (this kernel runs for ps <= 45)
+  int s_rr[RL], s_c[RL];
+#pragma unroll
+  for (int u = 0; u < RL; u++) { const int e = lane + 64 * u; s_rr[u] = e < rowf ? e / ps : SW_R - 1; s_c[u] = e < rowf ? e - (e / ps) * ps : 0; }
+
+#ifdef SIFT_PROF
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
+  int pn = 0;
+#define S2PROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pl; pl = t_; }
+#else
+#define S2PROF(i)
+#endif
+  for (;;) {
+    int unit = 0;
+    if (lane == 0) unit = atomicAdd(next_unit, 1);
+    unit = __builtin_amdgcn_readfirstlane(unit);
+    if (unit >= total_units) break;
+    int b = 0;
+    while (b + 1 < n_img && s_pref[b + 1] <= unit) b++;
+    const int ri0 = (unit - s_pref[b]) * SW_R;
+    mods_region *reg = reg_all + (size_t)b * k.max_reg;
+    int n = reg_count[b];
+    if (n > k.reg_cap) n = k.reg_cap;
+    const float *pbase = patches + (size_t)b * k.reg_cap * pp;
+    // patch of region slot rr (slots past the end repeat the last region; their results are not stored)
+    auto patch_of = [&](int rr) { return pbase + (size_t)min(ri0 + rr, n - 1) * pp; };
+    wave_sync();
+    S2PROF(0)
+#pragma unroll
+    for (int i = 0; i < S2_BINS / 64; i++) acc[lane + 64 * i] = 0.0;
+    if (lane < SW_R) { s_flag[lane] = 0; s_mean[lane] = 0.f; s_fac[lane] = 0.f; }
+    // ---- photometricallyNormalize, helpers.cpp:666-715: mean, then deviation, both as sequential sums over the masked pixels
+    if (k.photo) {
+      for (int pass = 0; pass < 2; pass++) {
+        float sum = 0.f;
+        // the values of chunk q0 + 64 are in flight while lanes 0..7 add chunk q0
+        float v[SW_R];
+        {
+          const int idx = s_midx[min(lane, n_mask - 1)];
+#pragma unroll
+          for (int rr = 0; rr < SW_R; rr++) v[rr] = patch_of(rr)[idx];
+        }
+        for (int q0 = 0; q0 < n_mask; q0 += 64) {
+          const int cnt = min(64, n_mask - q0);
+          wave_sync();
+#pragma unroll
+          for (int rr = 0; rr < SW_R; rr++) {
+            float x = v[rr];
+            if (pass) { const float d = s_mean[rr] - x; x = d * d; }
+            g[rr * SW_G + lane] = x;
+          }
+          if (q0 + 64 < n_mask) {
+            const int idx = s_midx[min(q0 + 64 + lane, n_mask - 1)];
+#pragma unroll
+            for (int rr = 0; rr < SW_R; rr++) v[rr] = patch_of(rr)[idx];
+          }
+          wave_sync();
+          if (lane < SW_R) {
+            const float *gl = g + lane * SW_G;
+            int q = 0;
+            for (; q + 15 < cnt; q += 16) {     // 4 reads in flight, then their 16 terms in order
+              const float4 a0 = *(const float4 *)(gl + q), a1 = *(const float4 *)(gl + q + 4), a2 = *(const float4 *)(gl + q + 8), a3 = *(const float4 *)(gl + q + 12);
+              sum += a0.x; sum += a0.y; sum += a0.z; sum += a0.w; sum += a1.x; sum += a1.y; sum += a1.z; sum += a1.w;
+              sum += a2.x; sum += a2.y; sum += a2.z; sum += a2.w; sum += a3.x; sum += a3.y; sum += a3.z; sum += a3.w;
+            }
+            for (; q + 3 < cnt; q += 4) {
+              const float4 a = *(const float4 *)(gl + q);
+              sum += a.x; sum += a.y; sum += a.z; sum += a.w;
+            }
+            for (; q < cnt; q++) sum += gl[q];
+          }
+        }
+        if (lane < SW_R) {
+          if (pass == 0) s_mean[lane] = sum / (float)n_mask;
+          else {
+            const float var = sqrtf(sum / (float)n_mask);
+            if (!((double)var < 0.0001)) { s_flag[lane] = 1; s_fac[lane] = 50.0f / var; }
+          }
+        }
+        wave_sync();
+      }
+    }
+    wave_sync();
+    S2PROF(1)
+    // per pixel slot: byte offset of its column in the patch store (32 bits from the image's first patch: scalar base + lane
+    // offset loads; slots past the 8 * ps pixels of a row read the last pixel again and store nothing), and the normalisation
+    // of its region (flag off: factor 1, mean 0 never used - the raw value is selected)
+    unsigned sbyte[RL], cbyte[RL];
+    float sm[RL], sf[RL];
+    unsigned nflag = 0, has_left = 0, has_right = 0;
+#pragma unroll
+    for (int u = 0; u < RL; u++) {
+      sbyte[u] = ((unsigned)min(ri0 + s_rr[u], n - 1) * (unsigned)pp + (unsigned)s_c[u]) * 4u;
+      cbyte[u] = (unsigned)s_c[u] * 4u;
+      sm[u] = s_mean[s_rr[u]]; sf[u] = s_fac[s_rr[u]];
+      nflag |= (s_flag[s_rr[u]] ? 1u : 0u) << u;
+      has_left |= (s_c[u] > 0 ? 1u : 0u) << u;
+      has_right |= (s_c[u] < ps - 1 ? 1u : 0u) << u;
+    }
+    auto fetch_row = [&](int r, float *dst) {
+      const char *rowp = (const char *)(pbase + r * ps);           // uniform: scalar base + 32-bit lane offset
+#pragma unroll
+      for (int u = 0; u < RL; u++) dst[u] = *(const float *)(rowp + sbyte[u]);
+    };
+    auto norm_row = [&](const float *raw, float *dst) {
+#pragma unroll
+      for (int u = 0; u < RL; u++) {
+        // 128 + fac * (v - mean) clamped to [0, 255] (helpers.cpp:705-712; the value is finite, so the median of (v, 0, 255)
+        // is the two comparisons of the reference)
+        const float t = __builtin_amdgcn_fmed3f(128 + sf[u] * (raw[u] - sm[u]), 0.f, 255.f);
+        dst[u] = ((nflag >> u) & 1) ? t : raw[u];
+      }
+    };
+    auto fetch_mask = [&](int r, float *dst) {
+      const char *mrowp = (const char *)(mask + r * ps);
+#pragma unroll
+      for (int u = 0; u < RL; u++) dst[u] = *(const float *)(mrowp + cbyte[u]);
+    };
+    // rows r - 1, r, r + 1 normalised (nm, n0, np); row r + 2 as fetched (ra), row r + 3 in flight (rb)
+    float nm[RL], n0[RL], np[RL], ra[RL], rb[RL], mcur[RL];
+    fetch_row(0, ra); norm_row(ra, n0);
+    fetch_row(min(1, ps - 1), ra); norm_row(ra, np);
+    fetch_row(min(2, ps - 1), ra);
+    fetch_row(min(3, ps - 1), rb);
+    fetch_mask(0, mcur);
+#pragma unroll
+    for (int u = 0; u < RL; u++) nm[u] = n0[u];
+    // ---- computeSiftDescriptor / samplePatch (siftdesc.cpp:73-131, 160-198), one pixel row at a time
+#pragma unroll 1
+    for (int r = 0; r < ps; r++) {
+      {
+        // branch-free: the one-sided differences at the patch border are the same subtraction with one operand at the pixel itself
+        const bool top = r == 0, bot = r == ps - 1;
+#pragma unroll
+        for (int u = 0; u < RL; u++) {
+          const int e = lane + 64 * u;
+          // horizontal neighbours: the adjacent lanes of this slot; across the slot boundary lane 63 <-> lane 0 of the next slot
+          float right = lane_down1(n0[u]), left = lane_up1(n0[u]);
+          if (u + 1 < RL) { const float nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n0[u + 1 < RL ? u + 1 : u]), 0)); right = lane == 63 ? nx : right; }
+          if (u > 0) { const float pl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n0[u > 0 ? u - 1 : u]), 63)); left = lane == 0 ? pl : left; }
+          const float xa = ((has_right >> u) & 1) ? right : n0[u];
+          const float xb = ((has_left >> u) & 1) ? left : n0[u];
+          const float ya = bot ? n0[u] : np[u];
+          const float yb = top ? n0[u] : nm[u];
+          const float xgrad = xa - xb, ygrad = ya - yb;
+          const float grad = sqrtf(xgrad * xgrad + ygrad * ygrad);
+          const AtanSel as = atan2_lut_sel(ygrad, xgrad);
+          const float ot = s_ot[as.oct * 256 + as.idx];
+          const float o = as.zero ? o_zero : ot;
+          if (e < rowf) pxrow[e] = make_float2(mcur[u] * grad, o);
+        }
+      }
+      fetch_mask(min(r + 1, ps - 1), mcur);     // in flight during the histogram pass
+      wave_sync();
+      S2PROF(2)
+      {
+        // the row's two spatial row bins (bin0 / bin1 and their weights; already multiplied by 8 = orientation bins)
+        const int rb8 = hsel ? tab->bin1[r] : tab->bin0[r];
+        const float wrr = hsel ? tab->w1[r] : tab->w0[r];
+        if (wrr > 0) {
+          double *abin = acc + s2_bin(hr, rb8 >> 3, hbc);
+          const float2 *px = pxrow + hr * ps + clo;
+#pragma unroll
+          for (int q0 = 0; q0 < SW_CW; q0 += SW_CW / 2) {
+            float2 pv[SW_CW / 2];
+#pragma unroll
+            for (int q = 0; q < SW_CW / 2; q++) pv[q] = px[q0 + q];
+#pragma unroll
+            for (int q = 0; q < SW_CW / 2; q++) {
+              // a pixel that the reference skips (val <= 0; also the NaN that a zero weight makes of the idle words behind
+              // the row) adds +0.0, which leaves a bin as it is: no branch per pixel
+              const float val = wrr * (wcw[q0 + q] * pv[q].x);
+              const bool on = val > 0;
+              const int bo0 = (int)pv[q].y;
+              const float y = pv[q].y - bo0;
+              const float c0 = on ? val * (1.0f - y) : 0.f, c1 = on ? val * y : 0.f;
+              __hip_atomic_fetch_add(abin + (bo0 & 7) * 128, (double)c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              __hip_atomic_fetch_add(abin + ((bo0 + 1) & 7) * 128, (double)c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+          }
+        }
+      }
+      wave_sync();
+      S2PROF(3)
+      // next row: r + 1 becomes the centre, the row fetched two iterations ago is normalised, row r + 4 starts its way
+#pragma unroll
+      for (int u = 0; u < RL; u++) { nm[u] = n0[u]; n0[u] = np[u]; }
+      norm_row(ra, np);
+#pragma unroll
+      for (int u = 0; u < RL; u++) ra[u] = rb[u];
+      fetch_row(min(r + 4, ps - 1), rb);
+      S2PROF(4)
+    }
+    wave_sync();
+    // ---- normalize / clip / renormalise (siftdesc.cpp:133-158, 199-210, 248-257) and the RootSIFT mapping
+    double *tmp = (double *)pxrow;      // 8 doubles of hand-over; the pixel row is idle here
+    unsigned long long redo = ~0ull;   // bit 8 rr.. : region rr still takes part
+    for (int pass = 0; pass < 2; pass++) {
+      if (lane < SW_R && ((redo >> (8 * lane)) & 1)) {
+        double len = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < 128; i += 8) {
+          double x[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) x[q] = acc[s2_vec(lane, i + q)];
+#pragma unroll
+          for (int q = 0; q < 8; q++) x[q] = x[q] * x[q];
+          len += x[0] + x[1] + x[2] + x[3];
+          len += x[4] + x[5] + x[6] + x[7];
+        }
+        len = sqrt(len);
+        tmp[lane] = 1.0 / len;
+      }
+      wave_sync();
+      bool changed = false;
+      {
+        const int rr = lane >> 3;
+        if ((redo >> (8 * rr)) & 1) {
+          const double inv = tmp[rr];
+          for (int i = lane & 7; i < 128; i += 8) {
+            double *vp = acc + s2_vec(rr, i);
+            double x = *vp * inv;
+            if (pass == 0 && x > k.max_bin) { x = k.max_bin; changed = true; }
+            *vp = x;
+          }
+        }
+      }
+      const unsigned long long ch = __ballot(changed);
+      unsigned long long next = 0;
+      for (int rr = 0; rr < SW_R; rr++)
+        if ((ch >> (8 * rr)) & 0xffull) next |= 0xffull << (8 * rr);
+      redo = next;
+      wave_sync();
+      if (!redo) break;
+    }
+    if (k.root) {
+      if (lane < SW_R) {
+        double sum = 0.;
+#pragma unroll 1
+        for (int i = 0; i < 128; i += 8) {
+          double x[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) x[q] = acc[s2_vec(lane, i + q)];
+#pragma unroll
+          for (int q = 0; q < 8; q++) sum += fabs(x[q]);
+        }
+        tmp[lane] = sum;
+      }
+      wave_sync();
+    }
+    {
+      const int rr = lane >> 3;
+      if (ri0 + rr < n) {
+        const double rs = k.root ? tmp[rr] : 1.0;
+        uint32_t *out = (uint32_t *)reg[ri0 + rr].desc;
+        for (int w4 = lane & 7; w4 < 32; w4 += 8) {
+          uint32_t word = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const double x = acc[s2_vec(rr, 4 * w4 + q)];
+            const double y = k.root ? sqrt(x / rs) : x;
+            int bq = (int)(512.0 * y + 0.5);
+            bq = bq < 255 ? bq : 255;
+            bq = bq > 0 ? bq : 0;
+            word |= (uint32_t)bq << (8 * q);
+          }
+          out[w4] = word;
+        }
+      }
+    }
+    S2PROF(5)
+#ifdef SIFT_PROF
+    pn++;
+#endif
+  }
+#ifdef SIFT_PROF
+  if (lane == 0 && (blockIdx.x % 64) == 3 && wv == 1)
+    printf("sift_wave2 prof: block %d units %d cycles per unit: other %llu photo %llu grad %llu hist %llu shift+norm %llu norms %llu\n", blockIdx.x, pn,
+           pt[0] / max(pn, 1), pt[1] / max(pn, 1), pt[2] / max(pn, 1), pt[3] / max(pn, 1), pt[4] / max(pn, 1), pt[5] / max(pn, 1));
+#endif
+}
+
 __global__ __launch_bounds__(256) void sift_patch_test_kernel(const float *__restrict__ patch, int ps, int root, double max_bin,
                                                               const float *__restrict__ mask, const SiftTab *__restrict__ tab,
                                                               uint8_t *out) {
@@ -1522,10 +1887,19 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
     hipLaunchKernelGGL(sift_kernel, dim3(2048, n_img), dim3(256), sift_lds_bytes(ps), ctx->stream, k, patches, ctx->regions_dev,
                        ctx->region_count, dmask, tab);
   else if (run_sift) {
-    static const hipError_t attr = hipFuncSetAttribute((const void *)sift_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    MODS_HIP_CHECK(attr);
-    hipLaunchKernelGGL(sift_wave_kernel, dim3(1024, n_img), dim3(256), sift_wave_lds_bytes(ps), ctx->stream, k, patches,
-                       ctx->regions_dev, ctx->region_count, dmask, tab, (int)sift_wave_scratch_floats(ps));
+    static const bool first_form = getenv("MODS_SIFT_V1") != nullptr;   // the round-2 kernel (A/B measurements)
+    if (first_form || n_img > 64) {
+      static const hipError_t attr = hipFuncSetAttribute((const void *)sift_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      MODS_HIP_CHECK(attr);
+      hipLaunchKernelGGL(sift_wave_kernel, dim3(1024, n_img), dim3(256), sift_wave_lds_bytes(ps), ctx->stream, k, patches,
+                         ctx->regions_dev, ctx->region_count, dmask, tab, (int)sift_wave_scratch_floats(ps));
+    } else {
+      static const hipError_t attr = hipFuncSetAttribute((const void *)sift_wave2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      MODS_HIP_CHECK(attr);
+      // persistent: one workgroup of 12 waves per CU, work units pulled from bl->sift_next (zeroed with bl above)
+      hipLaunchKernelGGL(sift_wave2_kernel, dim3(ctx->n_cu), dim3(64 * S2_WAVES), sift_wave2_lds_bytes(ps), ctx->stream, k, patches,
+                         ctx->regions_dev, ctx->region_count, dmask, tab, n_img, &bl->sift_next);
+    }
   }
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
