@@ -150,6 +150,12 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
   int n = key_count[b];
   if (n > k.max_cand) n = k.max_cand;
   const int half = ps / 2;
+#ifdef ORIENT_PROF
+  unsigned long long pt[4] = {0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
+#define OPROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pl; pl = t_; }
+#else
+#define OPROF(i)
+#endif
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const mods_affkey kp = keys[i];
     // ReprojectRegionsAndRemoveTouchBoundary(dontRemove): centre, in the original frame, strictly inside
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
       const float a11 = f11 * curr_sc, a12 = f12 * curr_sc, a21 = f21 * curr_sc, a22 = f22 * curr_sc;
       const bool touch = check_borders(k.w, k.h, fx, fy, a11, a12, a21, a22, ps, ps);
       __syncthreads();
+      OPROF(0)
       // every lane samples a contiguous run of the ps x ps patch; the run's first coordinates are rebuilt
       // by replaying the reference's fp32 additions (row steps, then column steps)
       {
@@ -220,8 +227,10 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
         }
       }
       __syncthreads();
+      OPROF(1)
       float ang = 0.f;
       const bool found = dominant_angle_wave(s_patch, orimask, ps, k.ori_th, s_val, s_bin, s_hist, &ang, k.ori_half);
+      OPROF(2)
       if (!found) alive = false;
       else {
         double si, ci;
@@ -249,7 +258,12 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
       o.a11 = n11; o.a12 = n12; o.a21 = n21; o.a22 = n22; o.alive = alive ? 1 : 0; o.pad = (inside ? 1 : 0) | (upright ? 2 : 0);
       ori[i] = o;
     }
+    OPROF(3)
   }
+#ifdef ORIENT_PROF
+  if (lane == 0 && b == 0 && (blockIdx.x % 1024) == 5)
+    printf("orient prof: block %d cycles: head %llu sample %llu angle %llu tail %llu\n", blockIdx.x, pt[0], pt[1], pt[2], pt[3]);
+#endif
 }
 
 // Order-preserving compaction of the surviving keypoints into the region list.

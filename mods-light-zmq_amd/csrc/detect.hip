@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
   __shared__ unsigned long long s_hit[4][NMS_ROWS];
   const int wv = threadIdx.x >> 6;
   for (int lv = 1; lv <= k.n_scales; lv++) {
-    const float *cur = o.resp[lv] + plane;
+    const float *cur = as_global(o.resp[lv]) + plane;
     // the (NMS_ROWS+2)-row column of this lane is loaded up front (independent loads in flight), the columns beside it come
     // from the neighbour lanes
     float win[NMS_ROWS + 2][3];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
       n_c += __popcll(m);
     }
     wave_sync();
-    const float *low = o.resp[lv - 1] + plane, *high = o.resp[lv + 1] + plane;
+    const float *low = as_global(o.resp[lv - 1]) + plane, *high = as_global(o.resp[lv + 1]) + plane;
     for (int t0 = 0; t0 < n_c; t0 += 64) {
       const int t = t0 + lane;
       if (t < n_c) {
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict_
   __shared__ float s_val[4][NMS4_CAP];
   __shared__ unsigned long long s_hit[4][NMS_ROWS][4];
   for (int lv = 1; lv <= k.n_scales; lv++) {
-    const float *cur = o.resp[lv] + plane;
-    const float *low = o.resp[lv - 1] + plane, *high = o.resp[lv + 1] + plane;
+    const float *cur = as_global(o.resp[lv]) + plane;
+    const float *low = as_global(o.resp[lv - 1]) + plane, *high = as_global(o.resp[lv + 1]) + plane;
     float4 own[NMS_ROWS + 2];
 #pragma unroll
     for (int rr = 0; rr < NMS_ROWS + 2; rr++) {
@@ -326,9 +326,9 @@ __global__ __launch_bounds__(256) void localize_kernel(const PyramidDev *__restr
     const OctaveDev &o = P->oct[cd.octave];
     const int cols = o.w, rows = o.h;
     const size_t plane = (size_t)cols * rows * b;
-    const float *low = o.resp[cd.level - 1] + plane;
-    const float *cur = o.resp[cd.level] + plane;
-    const float *high = o.resp[cd.level + 1] + plane;
+    const float *low = as_global(o.resp[cd.level - 1]) + plane;
+    const float *cur = as_global(o.resp[cd.level]) + plane;
+    const float *high = as_global(o.resp[cd.level + 1]) + plane;
     int r = cd.r0, c = cd.c0;
     float bb[3] = {0, 0, 0};
     float val = 0;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void localize_kernel(const PyramidDev *__restr
     else if (k.det_type == MODS_DET_HARRIS) type = val < 0 ? 31 : 30;
     else if (val < 0) type = 2;
     else {
-      const float *ptr = o.blur[cd.level] + plane + (size_t)r * cols + c;
+      const float *ptr = as_global(o.blur[cd.level]) + plane + (size_t)r * cols + c;
       float Lxx = (ptr[-1] - 2 * ptr[0] + ptr[1]);
       type = (Lxx < 0) ? 0 : 1;
     }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void localize_kernel(const PyramidDev *__restr
     cd.response = val;
     cd.state = 1;
     const unsigned int key = ((unsigned int)cd.level << ORDER_POS_BITS) | (unsigned int)(cd.r0 * cols + cd.c0);
-    atomicMin(&o.omap[plane + (size_t)r * cols + c], key);
+    atomicMin(as_global(o.omap) + plane + (size_t)r * cols + c, key);
   }
 }
 
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void accept_kernel(const PyramidDev *__restric
     const OctaveDev &o = P->oct[cd.octave];
     const size_t plane = (size_t)o.w * o.h * b;
     const unsigned int key = ((unsigned int)cd.level << ORDER_POS_BITS) | (unsigned int)(cd.r0 * o.w + cd.c0);
-    if (o.omap[plane + (size_t)cd.r * o.w + cd.c] == key) {
+    if (as_global(o.omap)[plane + (size_t)cd.r * o.w + cd.c] == key) {
       cd.state = 2;
       const int slot = atomicAdd(&acc_count[b], 1);
       acc_list[(size_t)b * k.max_cand + slot] = i;
@@ -461,6 +461,13 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
   const int half = W / 2;
   for (int p = lane; p < WW; p += 64) s_mask[p] = mask[p];
   const int n_acc = acc_count[b];
+#ifdef BAUMBERG_PROF
+  unsigned long long pt[5] = {0, 0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
+  int pn = 0;
+#define BPROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pl; pl = t_; }
+#else
+#define BPROF(i)
+#endif
   for (int slot0 = blockIdx.x * KP; slot0 < n_acc; slot0 += gridDim.x * KP) {
     const int slot = slot0 + sub;
     const bool have = slot < n_acc;
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
     CandDev &cd = cand[(size_t)b * k.max_cand + ci];
     const OctaveDev &o = P->oct[cd.octave];
     const int iw = o.w, ih = o.h;
-    const float *im = o.blur[cd.level - 1] + (size_t)iw * ih * b;   // prevBlur, pyramid.cpp:402
+    const float *im = as_global(o.blur[cd.level - 1]) + (size_t)iw * ih * b;   // prevBlur, pyramid.cpp:402
     const float pd = cd.pixelDistance;
     float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
     float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
@@ -480,46 +487,49 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
     for (int l = 0; l < k.max_iter && __any(active); l++) {
       const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
       wave_sync();   // previous iteration's readers are done with the tiles
+      BPROF(0)
       // every lane samples a contiguous run of the W x W window; its first coordinates are rebuilt by
       // replaying the reference's sequential fp32 additions (row steps, then column steps)
       if (active) {
         const bool touch = check_borders(iw, ih, lx, ly, a11, a12, a21, a22, W, W);
-        const int L = (WW + G - 1) / G;
-        int idx = sl * L;
-        if (idx < WW) {
-          int row = idx / W, col = idx - row * W;
-          float rx = lx - (float)half * a12;
-          float ry = ly - (float)half * a22;
-          for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
+        // The lanes of a keypoint sample the window tile by tile (8 columns x G / 8 rows per step), lane = position inside
+        // the tile: what a gather costs is the number of cache lines its 64 lanes touch (tools/ubench/gather.hip: 4 cycles
+        // per line, 266 for 64 scattered lanes, 42 for an 8 x 8 pixel block), and a tile of neighbouring samples lies on a
+        // few image rows.  A lane keeps the reference's sequential fp32 coordinate chains by walking ITS rows column by
+        // column (8 additions between two of its taps) and from row to row (G / 8 additions).
+        constexpr int TH = G / 8;                   // rows of a tile
+        const int tcol = sl & 7, trow = sl >> 3;
+        float rx = lx - (float)half * a12;
+        float ry = ly - (float)half * a22;
+#pragma unroll
+        for (int q = 0; q < TH - 1; q++) { const bool m = q < trow; const float nx = rx + a12, ny = ry + a22; rx = m ? nx : rx; ry = m ? ny : ry; }
+        for (int r0 = 0; r0 < W; r0 += TH) {
+          const int row = r0 + trow;
           float WX = rx - (float)half * a11;
           float WY = ry - (float)half * a21;
-          for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
-          const int end = min(WW, idx + L);
-          // coordinates first (sequential fp32 additions), then all loads of the batch, then the lerps
-          while (idx < end) {
-            TapLoads t[8];
-            int cnt = 0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-              if (idx + u < end) {
-                t[u] = tap_load(im, iw, ih, WX, WY, touch);
-                cnt++;
-                if (++col == W) {
-                  col = 0;
-                  rx += a12; ry += a22;
-                  WX = rx - (float)half * a11;
-                  WY = ry - (float)half * a21;
-                } else { WX += a11; WY += a21; }
-              }
+          for (int q = 0; q < 7; q++) { const bool m = q < tcol; const float nx = WX + a11, ny = WY + a21; WX = m ? nx : WX; WY = m ? ny : WY; }
+          // column tiles of the row in batches of three (the 19-wide window of the .ini is one batch): 6 loads in flight
+          for (int c0 = 0; c0 < W; c0 += 24) {
+            TapLoads t[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+              t[u] = tap_load_bf(im, iw, ih, WX, WY, touch);
+#pragma unroll
+              for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-              if (u < cnt) s_img[idx + u] = tap_combine(t[u]);
-            idx += cnt;
+            for (int u = 0; u < 3; u++) {
+              const int col = c0 + 8 * u + tcol;
+              if (row < W && col < W) s_img[row * W + col] = tap_combine(t[u]);
+            }
           }
+#pragma unroll
+          for (int q = 0; q < TH; q++) { rx += a12; ry += a22; }
         }
       }
       wave_sync();
+      BPROF(1)
       // computeGradient (helpers.cpp:779-797) and the three SMM products
       // (the one-sided differences at the window border are the same subtraction with one operand at the pixel itself)
       if (active)
@@ -535,6 +545,7 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
           s_pc[p] = ygrad * ygrad * v;
         }
       wave_sync();
+      BPROF(2)
       // ordered accumulation (raster order, fp32): three lanes per keypoint, one sum each
       if (active && sl < 3) {
         const float *arr = sl == 0 ? s_pa : (sl == 1 ? s_pb : s_pc);
@@ -555,6 +566,10 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
         s_sum[sl] = acc;
       }
       wave_sync();
+      BPROF(3)
+#ifdef BAUMBERG_PROF
+      pn++;
+#endif
       if (active) {
         float a = s_sum[0], bq = s_sum[1], c = s_sum[2];
         a /= WW; bq /= WW; c /= WW;
@@ -595,7 +610,12 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
         sort_idx[(size_t)b * k.max_cand + sl2] = ci;
       } else cd.state = 4;   // accepted by the pyramid, dropped by the affine adaptation
     }
+    BPROF(4)
   }
+#ifdef BAUMBERG_PROF
+  if (lane == 0 && b == 0 && (blockIdx.x % 512) == 5)
+    printf("baumberg prof: block %d iterations %d cycles: invsqrt+update %llu sample %llu gradient %llu sums %llu tail %llu\n", blockIdx.x, pn, pt[0], pt[1], pt[2], pt[3], pt[4]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -24,6 +24,16 @@ __host__ __device__ __forceinline__ bool check_borders(int img_w, int img_h, flo
   return touch;
 }
 
+// A pointer read out of a structure in memory (the pyramid's plane table) has no known address space, so the compiler
+// addresses through it with FLAT instructions: slower than global ones, counted on both wait counters, and every load is
+// followed by a full s_waitcnt, which serialises the gathers of the keypoint kernels (round 3: 16 flat loads per Baumberg
+// iteration, 45 in the NMS kernel).  The round trip through the global address space lets InferAddressSpaces settle it.
+template <class T> __device__ __forceinline__ T *as_global(T *p) {
+  typedef __attribute__((address_space(1))) T GT;
+  GT *g = (GT *)(unsigned long long)p;     // through an integer: a pointer-to-pointer cast pair is folded away before the pass sees it
+  return (T *)g;
+}
+
 // LDS hand-over between the lanes of ONE wave (LDS executes a wave's instructions in order; this only stops the
 // compiler from moving LDS accesses across)
 // value of the neighbouring lane (lane - 1 / lane + 1; the first / last lane keeps its own value, as __shfl_up / __shfl_down
@@ -82,6 +92,23 @@ __device__ __forceinline__ TapLoads tap_load(const float *__restrict__ im, int w
     const PixPair p0 = *(const PixPair *)Row0, p1 = *(const PixPair *)(Row0 + w);
     t.r00 = p0.a; t.r01 = p0.b; t.r10 = p1.a; t.r11 = p1.b;
   } else { t.r00 = t.r01 = t.r10 = t.r11 = 0.f; }
+  return t;
+}
+// Branch-free form of tap_load for the keypoint kernels: the loads are issued whatever the tap is (indices clamped into the
+// image), and the checked branch's "outside -> 0" becomes a select in tap_combine.  With a branch per tap the compiler waits for
+// every tap's loads before it starts the next one (s_waitcnt vmcnt(0) in front of each conditional block: 25-35 thousand cycles
+// per Baumberg iteration went into 12 serial round trips).  floorf == the unchecked branch's (int) cast there: coordinates of
+// an untouched window are >= 1.
+__device__ __forceinline__ TapLoads tap_load_bf(const float *__restrict__ im, int w, int h, float WX, float WY, bool touch) {
+  TapLoads t;
+  const int x = (int)floorf(WX), y = (int)floorf(WY);
+  t.valid = !touch || (WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1);
+  t.wx = WX - (float)x;
+  t.wy = WY - (float)y;
+  const int xc = min(max(x, 0), w - 2), yc = min(max(y, 0), h - 2);
+  const float *Row0 = im + (unsigned)(__mul24(yc, w) + xc);
+  const PixPair p0 = *(const PixPair *)Row0, p1 = *(const PixPair *)(Row0 + w);
+  t.r00 = p0.a; t.r01 = p0.b; t.r10 = p1.a; t.r11 = p1.b;
   return t;
 }
 __device__ __forceinline__ float tap_combine(const TapLoads &t) {

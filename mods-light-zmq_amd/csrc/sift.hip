@@ -27,6 +27,13 @@ namespace mods {
 
 constexpr int SMALL_CAP = 80;   // P2 limit of the LDS-resident extraction tier
 
+// 8-byte aligned place at or behind p inside the (16-byte aligned) dynamic LDS block `base`, by pointer arithmetic: rounding the
+// address as an integer would make the result a FLAT pointer (its accesses wait on both counters)
+__device__ __forceinline__ double *lds_doubles(float *base, const void *p) {
+  const int off = (int)((const float *)p - base);
+  return (double *)(base + ((off + 1) & ~1));
+}
+
 struct RegionGeom {             // per-region constants of DescribeRegions
   int P2;                       // 0: direct branch (imageToPatchScale <= 0.4)
   float scale;                  // imageToPatchScale
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(256, 5) void extract_small_kernel(const float *__re
   float *s_seq = s_T + cap * t_stride(ps);
   int *s_cidx = (int *)(s_seq + ps2);
   float *s_tap = (float *)(s_cidx + ps2);
-  double *s_red = (double *)(((uintptr_t)(s_tap + 32) + 7) & ~(uintptr_t)7);
+  double *s_red = lds_doubles(smem, s_tap + 32);
   const int n = min(*n_items_dev, items_cap);
 #ifdef EXTRACT_PROF
   unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(256) void big_setup_kernel(DescConst k, const BigLi
   float *s_tap = smem;
   float *s_seq = s_tap + k.tap_cap;
   int *s_cidx = (int *)(s_seq + ps2);
-  double *s_red = (double *)(((uintptr_t)(s_cidx + ps2) + 7) & ~(uintptr_t)7);
+  double *s_red = lds_doubles(smem, s_cidx + ps2);
   const int n = min(bl->n_regions, max_regions);
   for (int li = blockIdx.x; li < n; li += gridDim.x) {
     const BigRegion br = regions[li];
