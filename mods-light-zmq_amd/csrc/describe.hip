@@ -72,6 +72,9 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
   // and reads four votes per LDS access.
   if (lane < bins) {
     float acc = 0.f;
+    // per vote: compare its bin byte with the lane number, select the value or +0.0f, add - three vector instructions, written
+    // out because the compiler turns the select into a branch with a conditional LDS read per vote (the bin bytes are
+    // wave-uniform, so it unpacks them on the scalar unit: ~8 issued instructions and a taken branch per vote)
     for (int p = 0; p < n16; p += 16) {   // 5 LDS reads (16 bins as bytes, 16 values), then the 16 votes in order
       const uint4 bb = *(const uint4 *)(s_bin + p);
       float4 v4[4];
@@ -80,10 +83,22 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
       const unsigned int bw[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        acc += ((bw[u] & 0xffu) == (unsigned)lane) ? v4[u].x : 0.f;
-        acc += (((bw[u] >> 8) & 0xffu) == (unsigned)lane) ? v4[u].y : 0.f;
-        acc += (((bw[u] >> 16) & 0xffu) == (unsigned)lane) ? v4[u].z : 0.f;
-        acc += ((bw[u] >> 24) == (unsigned)lane) ? v4[u].w : 0.f;
+        float t;
+        asm volatile("v_cmp_eq_u32_sdwa vcc, %2, %7 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+                     "v_cndmask_b32_e32 %1, 0, %3, vcc\n\t"
+                     "v_add_f32_e32 %0, %0, %1\n\t"
+                     "v_cmp_eq_u32_sdwa vcc, %2, %7 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+                     "v_cndmask_b32_e32 %1, 0, %4, vcc\n\t"
+                     "v_add_f32_e32 %0, %0, %1\n\t"
+                     "v_cmp_eq_u32_sdwa vcc, %2, %7 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+                     "v_cndmask_b32_e32 %1, 0, %5, vcc\n\t"
+                     "v_add_f32_e32 %0, %0, %1\n\t"
+                     "v_cmp_eq_u32_sdwa vcc, %2, %7 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+                     "v_cndmask_b32_e32 %1, 0, %6, vcc\n\t"
+                     "v_add_f32_e32 %0, %0, %1"
+                     : "+v"(acc), "=&v"(t)
+                     : "v"(bw[u]), "v"(v4[u].x), "v"(v4[u].y), "v"(v4[u].z), "v"(v4[u].w), "v"(lane)
+                     : "vcc");
       }
     }
     s_hist[lane] = acc;
@@ -149,7 +164,6 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
   OriOut *ori = ori_all + (size_t)b * k.max_cand;
   int n = key_count[b];
   if (n > k.max_cand) n = k.max_cand;
-  const int half = ps / 2;
 #ifdef ORIENT_PROF
   unsigned long long pt[4] = {0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
 #define OPROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pl; pl = t_; }
@@ -185,47 +199,10 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
     if (alive) {
       const float curr_sc = (float)(k.ori_i2p * kp.s);
       const float a11 = f11 * curr_sc, a12 = f12 * curr_sc, a21 = f21 * curr_sc, a22 = f22 * curr_sc;
-      const bool touch = check_borders(k.w, k.h, fx, fy, a11, a12, a21, a22, ps, ps);
       __syncthreads();
       OPROF(0)
-      // every lane samples a contiguous run of the ps x ps patch; the run's first coordinates are rebuilt
-      // by replaying the reference's fp32 additions (row steps, then column steps)
-      {
-        const int L = (pp2 + 63) / 64;
-        int idx = lane * L;
-        if (idx < pp2) {
-          int row = idx / ps, col = idx - row * ps;
-          float rx = fx - (float)half * a12;
-          float ry = fy - (float)half * a22;
-          for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
-          float WX = rx - (float)half * a11;
-          float WY = ry - (float)half * a21;
-          for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
-          const int end = min(pp2, idx + L);
-          // coordinates first (sequential fp32 additions), then all loads of a batch, then the lerps
-          while (idx < end) {
-            TapLoads t[8];
-            int cnt = 0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-              if (idx + u < end) {
-                t[u] = tap_load(img, k.w, k.h, WX, WY, touch);
-                cnt++;
-                if (++col == ps) {
-                  col = 0;
-                  rx += a12; ry += a22;
-                  WX = rx - (float)half * a11;
-                  WY = ry - (float)half * a21;
-                } else { WX += a11; WY += a21; }
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-              if (u < cnt) s_patch[idx + u] = tap_combine(t[u]);
-            idx += cnt;
-          }
-        }
-      }
+      // the wave samples the ps x ps patch tile by tile (device_util.hpp: sample_tiles)
+      sample_tiles(img, k.w, k.h, fx, fy, a11, a12, a21, a22, ps, 0, 1, [&](int row, int col, float v) { s_patch[row * ps + col] = v; });
       __syncthreads();
       OPROF(1)
       float ang = 0.f;

@@ -117,6 +117,46 @@ __device__ __forceinline__ float tap_combine(const TapLoads &t) {
   return t.wy * (t.wx * (t.r11 - t.r10) + t.r10 - I1) + I1;
 }
 
+// interpolate(img, x, y, A) over an n x n window (helpers.cpp:551-626), tile by tile: the 64 lanes of a wave sit on an 8 x 8
+// block of neighbouring samples, wave `wv` of `nw` takes the tile rows wv, wv + nw, ...  A gather costs the memory pipeline
+// per cache line that its lanes touch (tools/ubench/gather.hip: ~4 cycles per line, 266 cycles when every lane has its own
+// line - which is what a contiguous run of samples per lane gives - 42 for an 8 x 8 pixel block), and the 64 taps of a tile lie
+// on about nine image rows.  The reference's coordinates are sequential fp32 sums (row starts: += a12 / a22 per row, then
+// += a11 / a21 per column): a lane walks its rows column by column, eight additions between two of its taps.
+// store(row, col, value) is called for every sample of the window.
+template <class Store>
+__device__ __forceinline__ void sample_tiles(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
+                                             float a21, float a22, int n, int wv, int nw, Store store) {
+  const bool touch = check_borders(w, h, fx, fy, a11, a12, a21, a22, n, n);
+  const int half = n / 2;
+  const int lane = threadIdx.x & 63, tcol = lane & 7, trow = lane >> 3;
+  float rx = fx - (float)half * a12;
+  float ry = fy - (float)half * a22;
+  for (int q = wv * 8 + trow; q > 0; q--) { rx += a12; ry += a22; }
+  for (int r0 = wv * 8; r0 < n; r0 += nw * 8) {
+    const int row = r0 + trow;
+    float WX = rx - (float)half * a11;
+    float WY = ry - (float)half * a21;
+#pragma unroll
+    for (int q = 0; q < 7; q++) { const bool m = q < tcol; const float nx = WX + a11, ny = WY + a21; WX = m ? nx : WX; WY = m ? ny : WY; }
+    for (int c0 = 0; c0 < n; c0 += 16) {          // two column tiles per batch (at most one idle tile per row of tiles)
+      TapLoads t[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        t[u] = tap_load_bf(img, w, h, WX, WY, touch);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int col = c0 + 8 * u + tcol;
+        if (row < n && col < n) store(row, col, tap_combine(t[u]));
+      }
+    }
+    for (int q = nw * 8; q > 0; q--) { rx += a12; ry += a22; }
+  }
+}
+
 // atan2LUTff, helpers.cpp:160-207.  The octant constants are float, the table double: each
 // +/- is a double operation rounded to float on return.
 __device__ const double g_atan_lut[256] = MODS_ATAN_LUT_INIT;

@@ -111,25 +111,25 @@ __device__ void blur_setup(int P2, float scale, int ps, int n_tap, float *s_tap,
     const double x = i - (n_tap - 1) * 0.5;
     s_tap[i] = (float)det_exp(scale2X * x * x);
   }
-  if (tid == 64) {   // a different wave than the tap normalisation below
+  if (tid == 64) {   // a different wave than the tap normalisation below: the sequential sum only, the indices follow in parallel
     const float c0 = (float)(P2 >> 1);
     float v = c0 - (float)(ps / 2) * scale;
-    for (int i = 0; i < ps; i++) {
-      s_seq[i] = v;
-      const int fl = (int)floorf(v);
-      int i0 = fl, i1 = fl + 1;
-      i0 = i0 < 0 ? 0 : (i0 > P2 - 1 ? P2 - 1 : i0);
-      i1 = i1 < 0 ? 0 : (i1 > P2 - 1 ? P2 - 1 : i1);
-      s_cidx[2 * i] = i0;
-      s_cidx[2 * i + 1] = i1;
-      v += scale;
-    }
+    for (int i = 0; i < ps; i++) { s_seq[i] = v; v += scale; }
   }
   __syncthreads();
   if (tid == 0) {
     double sum = 0;
     for (int i = 0; i < n_tap; i++) sum += s_tap[i];
     s_red[0] = 1. / sum;
+  }
+  if (tid >= 64 && tid < 64 + ps) {
+    const int i = tid - 64;
+    const int fl = (int)floorf(s_seq[i]);
+    int i0 = fl, i1 = fl + 1;
+    i0 = i0 < 0 ? 0 : (i0 > P2 - 1 ? P2 - 1 : i0);
+    i1 = i1 < 0 ? 0 : (i1 > P2 - 1 ? P2 - 1 : i1);
+    s_cidx[2 * i] = i0;
+    s_cidx[2 * i + 1] = i1;
   }
   __syncthreads();
   for (int i = tid; i < n_tap; i += 256) s_tap[i] = (float)(s_tap[i] * s_red[0]);
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256, 5) void extract_small_kernel(const float *__re
     if (g.P2 > 0) {
       const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
       const int stride = (g.P2 + 3) & ~3;
-      sample_region_t(img, k.w, k.h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, g.P2, stride, s_S);
+      sample_tiles(img, k.w, k.h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, g.P2, threadIdx.x >> 6, 4,
+                   [&](int row, int col, float v) { s_S[col * stride + row] = v; });   // transposed: see row_pass_t
       PROF_MARK(1)
       blur_setup(g.P2, g.scale, ps, n_tap, s_tap, s_seq, s_cidx, s_red);
       PROF_MARK(2)
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(256, 5) void extract_small_kernel(const float *__re
 #endif
     } else {
       // direct branch: interpolate(img, x, y, A*scale) -> ps x ps
-      sample_region(img, k.w, k.h, g.fx, g.fy, g.f11 * g.scale, g.f12 * g.scale, g.f21 * g.scale, g.f22 * g.scale, ps, out);
+      sample_tiles(img, k.w, k.h, g.fx, g.fy, g.f11 * g.scale, g.f12 * g.scale, g.f21 * g.scale, g.f22 * g.scale, ps, threadIdx.x >> 6, 4,
+                   [&](int row, int col, float v) { out[row * ps + col] = v; });
     }
   }
 #ifdef EXTRACT_PROF
