@@ -43,8 +43,11 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
   const int bins = 36;
   const float PIf = 3.14159265358979323846f;
   const int n = ps * (ps - 2);
-  const int n16 = (n + 15) & ~15;   // votes are scanned 16 at a time; the tail carries bin 255 (no bin)
-  for (int p = lane; p < n16; p += 64) {
+  // pixels that cast a vote are compacted in raster order (a pixel without a vote would add +0.0f to every bin: skipping it
+  // changes nothing); the list is padded to a multiple of 16 with bin 255 (no bin), the scan below takes 16 votes per step
+  int n_votes = 0;
+  for (int p0 = 0; p0 < n; p0 += 64) {
+    const int p = p0 + lane;
     int bin = 255;
     float v = 0.f;
     if (p < n) {
@@ -63,9 +66,17 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
         v = mag * m;
       }
     }
-    s_val[p] = v;
-    s_bin[p] = (unsigned char)bin;
+    const bool vote = bin != 255;
+    const unsigned long long vm = __ballot(vote);
+    if (vote) {
+      const int pos = n_votes + __popcll(vm & ((1ull << lane) - 1ull));
+      s_val[pos] = v;
+      s_bin[pos] = (unsigned char)bin;
+    }
+    n_votes += __popcll(vm);
   }
+  const int n16 = (n_votes + 15) & ~15;
+  if (lane < n16 - n_votes) { s_val[n_votes + lane] = 0.f; s_bin[n_votes + lane] = 255; }
   __syncthreads();
   // one lane per bin, votes in raster order (bin 36 is write-only in the reference).  Votes of other
   // bins add +0.0f, which leaves the non-negative running sum unchanged, so the scan is branch-free

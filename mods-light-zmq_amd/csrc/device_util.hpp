@@ -124,22 +124,38 @@ __device__ __forceinline__ float tap_combine(const TapLoads &t) {
 // on about nine image rows.  The reference's coordinates are sequential fp32 sums (row starts: += a12 / a22 per row, then
 // += a11 / a21 per column): a lane walks its rows column by column, eight additions between two of its taps.
 // store(row, col, value) is called for every sample of the window.
-template <class Store>
-__device__ __forceinline__ void sample_tiles(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
-                                             float a21, float a22, int n, int wv, int nw, Store store) {
+// The rows [row_begin, row_end) of the window are sampled (all columns).
+template <bool WIDE, class Store>
+__device__ __forceinline__ void sample_tiles_rows(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
+                                                  float a21, float a22, int n, int row_begin, int row_end, int wv, int nw, Store store) {
   const bool touch = check_borders(w, h, fx, fy, a11, a12, a21, a22, n, n);
   const int half = n / 2;
   const int lane = threadIdx.x & 63, tcol = lane & 7, trow = lane >> 3;
   float rx = fx - (float)half * a12;
   float ry = fy - (float)half * a22;
-  for (int q = wv * 8 + trow; q > 0; q--) { rx += a12; ry += a22; }
-  for (int r0 = wv * 8; r0 < n; r0 += nw * 8) {
+  for (int q = row_begin + wv * 8 + trow; q > 0; q--) { rx += a12; ry += a22; }
+  for (int r0 = row_begin + wv * 8; r0 < row_end; r0 += nw * 8) {
     const int row = r0 + trow;
     float WX = rx - (float)half * a11;
     float WY = ry - (float)half * a21;
 #pragma unroll
     for (int q = 0; q < 7; q++) { const bool m = q < tcol; const float nx = WX + a11, ny = WY + a21; WX = m ? nx : WX; WY = m ? ny : WY; }
-    for (int c0 = 0; c0 < n; c0 += 16) {          // two column tiles per batch (at most one idle tile per row of tiles)
+    // column tiles in batches: eight per batch while at least eight remain (16 loads in flight: a wide window is latency
+    // bound otherwise), then two per batch (at most one idle tile per row of tiles: small windows are throughput bound)
+    int c0 = 0;
+    for (; WIDE && c0 + 64 <= n; c0 += 64) {
+      TapLoads t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        t[u] = tap_load_bf(img, w, h, WX, WY, touch);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (row < row_end) store(row, c0 + 8 * u + tcol, tap_combine(t[u]));
+    }
+    for (; c0 < n; c0 += 16) {
       TapLoads t[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
@@ -150,11 +166,16 @@ __device__ __forceinline__ void sample_tiles(const float *__restrict__ img, int 
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int col = c0 + 8 * u + tcol;
-        if (row < n && col < n) store(row, col, tap_combine(t[u]));
+        if (row < row_end && col < n) store(row, col, tap_combine(t[u]));
       }
     }
     for (int q = nw * 8; q > 0; q--) { rx += a12; ry += a22; }
   }
+}
+template <class Store>
+__device__ __forceinline__ void sample_tiles(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
+                                             float a21, float a22, int n, int wv, int nw, Store store) {
+  sample_tiles_rows<false>(img, w, h, fx, fy, a11, a12, a21, a22, n, 0, n, wv, nw, store);
 }
 
 // atan2LUTff, helpers.cpp:160-207.  The octant constants are float, the table double: each

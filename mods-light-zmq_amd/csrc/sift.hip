@@ -695,71 +695,46 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
                                                         int max_items, const mods_region *__restrict__ reg_all,
                                                         float *__restrict__ pool, const int *__restrict__ err_flag) {
   extern __shared__ __attribute__((aligned(16))) float s_St[];
+  // the region's Gaussian taps, copied from its slab: read through `pool` (which this kernel also writes) they would be
+  // per-lane global loads with a full wait in front of every use - one L2 round trip per tap in the clamped branch
+  // (round 3: 36 of the 66 thousand cycles of an item).  P2 <= BIG_FUSE_P2 = 256 gives at most 57 taps.
+  __shared__ float s_ftap[64];
   if (*err_flag) return;
   const int ps = k.desc_ps, ps2 = t_stride(ps);   // (row stride of T)
   const int n_items = min(bl->n_fitems, max_items);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef FUSED_PROF
+  unsigned long long pt[3] = {0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
+  int pn = 0, prows = 0;
+#define FPROF(i) { __syncthreads(); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pl; pl = t_; }
+#else
+#define FPROF(i)
+#endif
   for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
     const int2 item = fitems[it];
     const BigRegion br = regions[item.x];
     const RegionGeom g = region_geom(reg_all[(size_t)br.img * k.max_reg + br.ri], k.desc_mr, ps, k.patch_rule);
     const float *img = img_all + (size_t)k.w * k.h * br.img;
-    const int P2 = br.P2, half = P2 / 2, w = k.w, h = k.h;
-    const int R = big_fuse_rows(P2), nph = 256 / R, r0 = item.y;
+    const int P2 = br.P2, w = k.w, h = k.h;
+    const int R = big_fuse_rows(P2), r0 = item.y;
     __syncthreads();   // the previous item's row pass is done with the tile
-    {
-      const int lr = tid % R, ph = tid / R, row = r0 + lr;
-      if (row < P2) {
-        const bool touch = check_borders(w, h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, P2, P2);
-        float rx = g.fx - (float)half * g.f12;
-        float ry = g.fy - (float)half * g.f22;
-        for (int q = 0; q < row; q++) { rx += g.f12; ry += g.f22; }
-        float WX = rx - (float)half * g.f11;
-        float WY = ry - (float)half * g.f21;
-        for (int q = 0; q < ph; q++) { WX += g.f11; WY += g.f21; }
-        float *dst = s_St + lr;
-        for (int c = ph; c < P2; c += 8 * nph) {
-          PixPair t0[8], t1[8];
-          float wx[8], wy[8];
-          bool ok[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            ok[u] = false;
-            if (c + u * nph < P2) {
-              int x, y;
-              if (!touch) { x = (int)WX; y = (int)WY; ok[u] = true; }
-              else { x = (int)floorf(WX); y = (int)floorf(WY); ok[u] = WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1; }
-              wx[u] = WX - (float)x;
-              wy[u] = WY - (float)y;
-              if (ok[u]) {
-                const float *Row0 = img + (size_t)y * w + x;
-                t0[u] = *(const PixPair *)Row0;
-                t1[u] = *(const PixPair *)(Row0 + w);
-              }
-              for (int q = 0; q < nph; q++) { WX += g.f11; WY += g.f21; }
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 8; u++)
-            if (c + u * nph < P2) {
-              float v = 0.f;
-              if (ok[u]) {
-                const float I1 = wx[u] * (t0[u].b - t0[u].a) + t0[u].a;
-                v = wy[u] * (wx[u] * (t1[u].b - t1[u].a) + t1[u].a - I1) + I1;
-              }
-              dst[(c + u * nph) * R] = v;
-            }
-        }
-      }
-    }
+    if (tid < 64) s_ftap[tid] = tid < br.n_tap ? (pool + br.slab)[tid] : 0.f;
+    FPROF(0)
+    // phase 1: the item's rows, tile by tile (device_util.hpp: sample_tiles), stored transposed St[col][R]
+    sample_tiles_rows<true>(img, w, h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, P2, r0, min(P2, r0 + R), wv, 4,
+                      [&](int row, int col, float v) { s_St[col * R + (row - r0)] = v; });
     __syncthreads();
+    FPROF(1)
+#ifdef FUSED_PROF
+    pn++; prows += P2;
+#endif
     {
       const int n_tap = br.n_tap, r_tap = n_tap >> 1;
       const int nq = R / 4, PS = 64 / nq;          // row quads, column pairs per step
       const int yq = lane % nq, pg = lane / nq;
       const int y = r0 + 4 * yq;
-      const float *tap = pool + br.slab;
-      const int *cidx = (const int *)(tap + n_tap + ps);
+      const float *tap = s_ftap;
+      const int *cidx = (const int *)(pool + br.slab + n_tap + ps);
       float *T = pool + br.slab + big_hdr_floats(n_tap, ps);
       const float *Sl = s_St + 4 * yq;
       const int steps = (ps + PS - 1) / PS;
@@ -823,7 +798,13 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
         }
       }
     }
+    FPROF(2)
   }
+#ifdef FUSED_PROF
+  if (tid == 0 && (blockIdx.x % 1024) == 9)
+    printf("big_fused prof: block %d items %d mean P2 %d cycles per item: head %llu sample %llu rowpass %llu\n", blockIdx.x, pn, prows / max(pn, 1),
+           pt[0] / max(pn, 1), pt[1] / max(pn, 1), pt[2] / max(pn, 1));
+#endif
 }
 
 // wave per 64 pairs of adjacent output pixels of a region: column pass + resampling -> patch
