@@ -140,8 +140,8 @@ __device__ __forceinline__ void sample_tiles_rows(const float *__restrict__ img,
     float WY = ry - (float)half * a21;
 #pragma unroll
     for (int q = 0; q < 7; q++) { const bool m = q < tcol; const float nx = WX + a11, ny = WY + a21; WX = m ? nx : WX; WY = m ? ny : WY; }
-    // column tiles in batches: eight per batch while at least eight remain (16 loads in flight: a wide window is latency
-    // bound otherwise), then two per batch (at most one idle tile per row of tiles: small windows are throughput bound)
+    // column tiles in batches: eight per batch while at least eight remain (wide windows only), four while three or more
+    // remain, then two: a wave waits for every batch, so the number of batches per row of tiles is what its time follows
     int c0 = 0;
     for (; WIDE && c0 + 64 <= n; c0 += 64) {
       TapLoads t[8];
@@ -154,6 +154,20 @@ __device__ __forceinline__ void sample_tiles_rows(const float *__restrict__ img,
 #pragma unroll
       for (int u = 0; u < 8; u++)
         if (row < row_end) store(row, c0 + 8 * u + tcol, tap_combine(t[u]));
+    }
+    for (; c0 + 16 < n; c0 += 32) {              // four column tiles per batch while three or more remain (8 loads in flight)
+      TapLoads t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        t[u] = tap_load_bf(img, w, h, WX, WY, touch);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int col = c0 + 8 * u + tcol;
+        if (row < row_end && col < n) store(row, col, tap_combine(t[u]));
+      }
     }
     for (; c0 < n; c0 += 16) {
       TapLoads t[2];
