@@ -29,6 +29,9 @@ static inline float grey_of(const unsigned char *rgb, bool average) {
   return (float)((rgb[0] * 4899 + rgb[1] * 9617 + rgb[2] * 1868 + 8192) >> 14);
 }
 
+// decoded images are limited to 2^28 pixels (16 k x 16 k): a crafted header must not become a multi-gigabyte allocation
+constexpr double kMaxImagePixels = 268435456.0;
+
 static bool read_pnm(const std::string &fn, bool average, GreyImage *out, std::string *err) {
   FILE *f = fopen(fn.c_str(), "rb");
   if (!f) { *err = "cannot open " + fn; return false; }
@@ -49,6 +52,7 @@ static bool read_pnm(const std::string &fn, bool average, GreyImage *out, std::s
   };
   if (fread(magic, 1, 2, f) != 2 || magic[0] != 'P' || (magic[1] != '5' && magic[1] != '6')) { fclose(f); *err = fn + ": not a binary PGM/PPM"; return false; }
   if (!next_int(&w) || !next_int(&h) || !next_int(&maxv) || w <= 0 || h <= 0 || maxv <= 0 || maxv > 255) { fclose(f); *err = fn + ": bad PNM header"; return false; }
+  if ((double)w * h > kMaxImagePixels) { fclose(f); *err = fn + ": image exceeds the limit of 2^28 pixels"; return false; }
   const int ch = magic[1] == '6' ? 3 : 1;
   std::vector<unsigned char> buf((size_t)w * h * ch);
   if (fread(buf.data(), 1, buf.size(), f) != buf.size()) { fclose(f); *err = fn + ": truncated"; return false; }
@@ -66,6 +70,7 @@ static bool read_png(const std::string &fn, bool average, GreyImage *out, std::s
   memset(&img, 0, sizeof(img));
   img.version = PNG_IMAGE_VERSION;
   if (!png_image_begin_read_from_file(&img, fn.c_str())) { *err = fn + ": " + img.message; return false; }
+  if ((double)img.width * img.height > kMaxImagePixels) { png_image_free(&img); *err = fn + ": image exceeds the limit of 2^28 pixels"; return false; }
   const bool colour = (img.format & PNG_FORMAT_FLAG_COLOR) != 0;
   img.format = colour ? PNG_FORMAT_RGB : PNG_FORMAT_GRAY;      // 8-bit, alpha dropped as cv::imread(IMREAD_COLOR) does
   std::vector<unsigned char> buf(PNG_IMAGE_SIZE(img));

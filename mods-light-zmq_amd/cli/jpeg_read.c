@@ -22,20 +22,31 @@ int mods_jpeg_read(const char *fn, int colour, unsigned char **out, int *w, int 
   struct jpeg_decompress_struct d;
   struct mods_jpeg_err je;
   unsigned char *volatile buf = NULL;
+  volatile int created = 0;       /* jpeg_create_decompress itself can fail (library / header mismatch): nothing to destroy then */
   if (!f) { snprintf(err, 256, "cannot open %s", fn); return -1; }
+  memset(&d, 0, sizeof(d));
   d.err = jpeg_std_error(&je.pub);
   je.pub.error_exit = mods_jpeg_fail;
   if (setjmp(je.jb)) {
-    jpeg_destroy_decompress(&d); fclose(f); free(buf);
+    if (created) jpeg_destroy_decompress(&d);
+    fclose(f); free(buf);
     snprintf(err, 256, "%s: %s", fn, je.msg);
     return -1;
   }
   jpeg_create_decompress(&d);
+  created = 1;
   jpeg_stdio_src(&d, f);
   jpeg_read_header(&d, TRUE);
   d.out_color_space = colour ? JCS_RGB : JCS_GRAYSCALE;
   jpeg_start_decompress(&d);
   *w = (int)d.output_width; *h = (int)d.output_height; *ch = (int)d.output_components;
+  /* the same pixel limit as the other decoders of the command line (MODS_MAX_IMAGE_PIXELS, image_io.hpp): a crafted header
+   * must not turn into a multi-gigabyte allocation */
+  if ((double)*w * (double)*h > 268435456.0) {
+    jpeg_destroy_decompress(&d); fclose(f);
+    snprintf(err, 256, "%s: %d x %d pixels exceed the limit of 2^28", fn, *w, *h);
+    return -1;
+  }
   if (*w <= 0 || *h <= 0 || (*ch != 1 && *ch != 3)) {
     jpeg_destroy_decompress(&d); fclose(f);
     snprintf(err, 256, "%s: unsupported JPEG layout", fn);

@@ -697,8 +697,9 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
   extern __shared__ __attribute__((aligned(16))) float s_St[];
   // the region's Gaussian taps, copied from its slab: read through `pool` (which this kernel also writes) they would be
   // per-lane global loads with a full wait in front of every use - one L2 round trip per tap in the clamped branch
-  // (round 3: 36 of the 66 thousand cycles of an item).  P2 <= BIG_FUSE_P2 = 256 gives at most 57 taps.
-  __shared__ float s_ftap[64];
+  // (round 3: 36 of the 66 thousand cycles of an item).  P2 <= BIG_FUSE_P2 = 256 and patch sizes >= 8 give at most
+  // (int)(9 * 254 / 8 + 1) | 1 = 287 taps (57 with the 41-pixel patch of the .ini).
+  __shared__ float s_ftap[320];
   if (*err_flag) return;
   const int ps = k.desc_ps, ps2 = t_stride(ps);   // (row stride of T)
   const int n_items = min(bl->n_fitems, max_items);
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
     const int P2 = br.P2, w = k.w, h = k.h;
     const int R = big_fuse_rows(P2), r0 = item.y;
     __syncthreads();   // the previous item's row pass is done with the tile
-    if (tid < 64) s_ftap[tid] = tid < br.n_tap ? (pool + br.slab)[tid] : 0.f;
+    for (int i = tid; i < br.n_tap && i < 320; i += 256) s_ftap[i] = (pool + br.slab)[i];
     FPROF(0)
     // phase 1: the item's rows, tile by tile (device_util.hpp: sample_tiles), stored transposed St[col][R]
     sample_tiles_rows<true>(img, w, h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, P2, r0, min(P2, r0 + R), wv, 4,

@@ -30,6 +30,9 @@ def wire():
     return lib
 
 
+TRUST_CHECKPOINT = False   # --trust-checkpoint: load a pickled checkpoint with the full unpickler (runs code from the file)
+
+
 def build_model(name, weights=None, seed=0, device="cpu"):
     """Returns f(patches float32 [n,1,ps,ps] in 0..255) -> float32 [n, dim]."""
     if name == "stats":
@@ -80,7 +83,9 @@ def build_model(name, weights=None, seed=0, device="cpu"):
     if isinstance(weights, dict):           # tensors by name (e.g. the arrays of tests/golden/nets.npz)
         net.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in weights.items()})
     elif weights:
-        ck = torch.load(weights, map_location="cpu", weights_only=False)
+        # a checkpoint is a pickle: the restricted unpickler (tensors and plain containers only - all the reference's
+        # checkpoints need) unless the operator vouches for the file with --trust-checkpoint
+        ck = torch.load(weights, map_location="cpu", weights_only=not TRUST_CHECKPOINT)
         net.load_state_dict(ck["state_dict"] if "state_dict" in ck else ck)   # strict: the architecture has to be the checkpoint's
     net = net.eval().to(device)
 
@@ -127,7 +132,13 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", default=None, help="cuda (MI355X through ROCm) or cpu; default: cuda when available")
     ap.add_argument("--max-requests", type=int, default=0)
+    ap.add_argument("--trust-checkpoint", action="store_true",
+                    help="load --weights with the unrestricted unpickler (executes code stored in the file: only for checkpoints "
+                         "of known origin; the default accepts tensors and plain containers, which is all a state_dict holds; "
+                         "a .npz file needs no pickle at all)")
     args = ap.parse_args()
+    global TRUST_CHECKPOINT
+    TRUST_CHECKPOINT = bool(args.trust_checkpoint)
     device = args.device
     if device is None and args.model != "stats":
         import torch
