@@ -56,6 +56,9 @@ typedef struct mods_hessaff_params {
    * pyramid.cpp:65-124 */
   int detectorType;            /* MODS_DET_HESSIAN */
   int iiDoGMode;               /* DoG only: illumination-invariant rescale of the response (pyramid.cpp:172-194) */
+  int sampleFromImage;         /* AffineShapeParams::sampleFromImage (affine.h:47, io_mods.cpp:184): findAffineShape samples the input
+                                * image at pixel distance 1 instead of the blur level below the detection level
+                                * (scale-space-detector.hpp:47-55); dense (stride == w) input only */
 } mods_hessaff_params;
 enum { MODS_DET_FIXED_TH = 0, MODS_DET_RELATIVE_TH, MODS_DET_FIXED_REG_NUMBER, MODS_DET_RELATIVE_REG_NUMBER,
        MODS_DET_NOT_LESS_THAN_REGIONS };   /* detection_mode_t, detectors/structures.hpp:10-14 */

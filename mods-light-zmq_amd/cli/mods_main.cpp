@@ -92,6 +92,11 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
     d.convergenceThreshold = (float)ini.GetDouble(sec, "convergenceThreshold", 0.05);
     d.doBaumberg = (int)ini.GetInteger(sec, "doBaumberg", 1);
     d.iiDoGMode = ini.GetBoolean(sec, "iiDoGMode", false) ? 1 : 0;
+    d.sampleFromImage = ini.GetBoolean(sec, "sampleFromImage", false) ? 1 : 0;     // io_mods.cpp:184, 222, 275
+    // patch_size (io_mods.cpp:187): the side of the normalised patch that normalizeAffine renders for a callback which only
+    // records the geometry (scale-space-detector.hpp:56-90): it never reaches a keypoint, here or in the reference
+    if (ini.GetInteger(sec, "patch_size", 41) != 41 && cfg->verbose)
+      std::cerr << "Note: [" << sec << "] patch_size has no effect on the keypoints (the reference renders that patch and drops it)" << std::endl;
     // keypoint selection, io_mods.cpp:170-173, 194-205 (defaults: PyramidParams, structures.hpp:138-150)
     d.relativeThreshold = (float)ini.GetDouble(sec, "relativeThreshold", -1.0);
     d.relativeRegionsNumber = (float)ini.GetDouble(sec, "relativeRegionsNumber", -1.0);
@@ -197,6 +202,10 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
     st.phi = it.GetDouble(sec, "Phi", 360);
     st.initSigma = it.GetDouble(sec, "initSigma", 0.5);
     st.doBlur = 1;
+    // DSPLevels / minSigma / maxSigma (io_mods.cpp:480-482): SetVSPars stores them in ViewSynthParameters
+    // (synth-detection.cpp:244-289) and nothing in the reference reads them again
+    if (cfg->verbose && (it.Has(sec, "DSPLevels") || it.Has(sec, "minSigma") || it.Has(sec, "maxSigma")))
+      std::cerr << "Note: [" << sec << "] DSPLevels / minSigma / maxSigma are stored and never used by the reference; no effect" << std::endl;
     st.fginn_ratio = 0.0;
     if (it.Has(sec, "TiltSet") && it.Has(sec, "ScaleSet")) {
       const std::vector<double> tilts = it.GetDoubleVector(sec, "TiltSet"), scales = it.GetDoubleVector(sec, "ScaleSet");

@@ -110,6 +110,7 @@ struct mods_ctx {
   mods_hessaff_params par;
   int reg_number_eff = -1;           // par.regionsNumber after the tilt / zoom scaling of DetectAffineKeypoints (scale-space-detector.cpp:20-21)
   int last_w = 0, last_h = 0, last_n_img = 0;
+  const float *last_img_dev = nullptr; int last_stride = 0;   // the batch the pyramid was built from (sampleFromImage)
   // orientation + description
   float *desc_tables_dev = nullptr;  // [orimask 64x64][desc mask 64x64][SiftTab]
   int *desc_err_dev = nullptr;
@@ -133,7 +134,6 @@ struct mods_ctx {
   double shape_mr = 0, ori_mr = 0;
   int shape_ps = 0, ori_ps = 0;
   size_t desc_scratch_elems = 0;
-  const float *last_img_dev = nullptr;
   std::vector<int> last_region_counts;
   // matching
   int8_t *m_desc = nullptr;          // [2][pad][128] int8 descriptors (query list, train list)

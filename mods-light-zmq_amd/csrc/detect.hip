@@ -35,6 +35,8 @@ struct DetectConst {
   float initial_sigma;
   int do_baumberg;
   int det_type;           // MODS_DET_HESSIAN / DOG / HARRIS
+  const float *sfi_img;   // sampleFromImage: the batch's input images [n_img][sfi_h][sfi_w], else null
+  int sfi_w, sfi_h;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -474,9 +476,11 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
     const int ci = acc_list[(size_t)b * k.max_cand + (have ? slot : slot0)];
     CandDev &cd = cand[(size_t)b * k.max_cand + ci];
     const OctaveDev &o = P->oct[cd.octave];
-    const int iw = o.w, ih = o.h;
-    const float *im = as_global(o.blur[cd.level - 1]) + (size_t)iw * ih * b;   // prevBlur, pyramid.cpp:402
-    const float pd = cd.pixelDistance;
+    // prevBlur (pyramid.cpp:402), or with sampleFromImage the input image at pixel distance 1 (scale-space-detector.hpp:47-55)
+    const bool sfi = k.sfi_img != nullptr;
+    const int iw = sfi ? k.sfi_w : o.w, ih = sfi ? k.sfi_h : o.h;
+    const float *im = sfi ? k.sfi_img + (size_t)iw * ih * b : as_global(o.blur[cd.level - 1]) + (size_t)iw * ih * b;
+    const float pd = sfi ? 1.0f : cd.pixelDistance;
     float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
     float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
     const float lx = cd.x / pd, ly = cd.y / pd;
@@ -734,6 +738,9 @@ int detect_run(mods_ctx *ctx) {
   k.conv_th = par.convergenceThreshold;
   k.initial_sigma = par.initialSigma;
   k.do_baumberg = par.doBaumberg;
+  k.sfi_img = par.sampleFromImage ? ctx->last_img_dev : nullptr;
+  k.sfi_w = ctx->last_w; k.sfi_h = ctx->last_h;
+  if (par.sampleFromImage && (!ctx->last_img_dev || ctx->last_stride != ctx->last_w)) { set_error("sampleFromImage needs the dense input image of the batch"); return MODS_E_ARG; }
   for (int oi = 0; oi < P.n_oct; oi++)
     if ((size_t)P.oct[oi].w * P.oct[oi].h >= (1u << ORDER_POS_BITS)) { set_error("octave too large for the order key"); return MODS_E_ARG; }
 

@@ -903,6 +903,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
 // detectPyramidKeypoints / detectOctaveKeypoints (pyramid.cpp:496-529, 428-494): every blur and
 // response plane of every octave, for the whole batch.  `img_dev`: [n_img][h][stride].
 int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
+  ctx->last_img_dev = img_dev; ctx->last_stride = stride;
   PyramidDev &P = ctx->pyr;
   const mods_hessaff_params &par = ctx->par;
   const int n_img = ctx->last_n_img, w = ctx->last_w, h = ctx->last_h;

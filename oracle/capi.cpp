@@ -26,6 +26,7 @@ struct orc_hessaff_params {     // mirrors include/mods_hip.h: mods_hessaff_para
   float relativeRegionsNumber;
   int detectorType;
   int iiDoGMode;
+  int sampleFromImage;
 };
 
 struct orc_candidate { int octave, level, r0, c0, r, c; float x, y, s, pixelDistance, response; int type; };
@@ -38,7 +39,7 @@ static HessAffParams cvt(const orc_hessaff_params *p) {
     q.edgeEigenValueRatio = p->edgeEigenValueRatio; q.border = p->border; q.maxIterations = p->maxIterations;
     q.convergenceThreshold = p->convergenceThreshold; q.smmWindowSize = p->smmWindowSize; q.doBaumberg = p->doBaumberg;
     q.mode = p->mode; q.rel_threshold = p->relativeThreshold; q.reg_number = p->regionsNumber; q.rel_reg_number = p->relativeRegionsNumber;
-    q.detector_type = p->detectorType; q.ii_dog = p->iiDoGMode;
+    q.detector_type = p->detectorType; q.ii_dog = p->iiDoGMode; q.sample_from_image = p->sampleFromImage;
   }
   return q;
 }

@@ -271,7 +271,9 @@ void detect_hessian_affine(const Img &image, const HessAffParams &p, std::vector
     const Candidate &cd = cand[i];
     const Img &prevBlur = pyr.oct[cd.octave].blur[cd.level - 1];
     float a[4]; int it;
-    if (!find_affine_shape(prevBlur, cd.x, cd.y, cd.s, cd.pixelDistance, p, mask, a, &it)) continue;
+    // onKeypointDetected, scale-space-detector.hpp:47-55: sampleFromImage -> findAffineShape(image, x, y, s, 1.0, ...)
+    if (!(p.sample_from_image ? find_affine_shape(image, cd.x, cd.y, cd.s, 1.0f, p, mask, a, &it)
+                              : find_affine_shape(prevBlur, cd.x, cd.y, cd.s, cd.pixelDistance, p, mask, a, &it))) continue;
     AffKey k;
     k.x = cd.x; k.y = cd.y; k.s = cd.s;
     k.a11 = a[0]; k.a12 = a[1]; k.a21 = a[2]; k.a22 = a[3];

@@ -86,6 +86,7 @@ struct HessAffParams {          // PyramidParams + AffineShapeParams, detectors/
   float rel_reg_number = -1;
   int detector_type = 0;        // detector_type (structures.hpp:16-18): 0 DET_HESSIAN, 1 DET_DOG, 2 DET_HARRIS
   int ii_dog = 0;               // iiDoGMode (only the DoG response has such a form, pyramid.cpp:126-161)
+  int sample_from_image = 0;    // AffineShapeParams::sampleFromImage (affine.h:47): findAffineShape on the input image, pixel distance 1
 };
 
 struct Candidate {              // one accepted pyramid keypoint before affine adaptation

@@ -14,22 +14,23 @@ class HessAffParams(C.Structure):
                 ("edgeEigenValueRatio", C.c_float), ("border", C.c_int), ("maxIterations", C.c_int),
                 ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int),
                 ("mode", C.c_int), ("relativeThreshold", C.c_float), ("regionsNumber", C.c_int),
-                ("relativeRegionsNumber", C.c_float), ("detectorType", C.c_int), ("iiDoGMode", C.c_int)]
+                ("relativeRegionsNumber", C.c_float), ("detectorType", C.c_int), ("iiDoGMode", C.c_int),
+                ("sampleFromImage", C.c_int)]
 
     @staticmethod
     def default():
         # build/config_affori_classic.ini [HessianAffine]
-        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1, 0, -1.0, -1, -1.0, 0, 0)
+        return HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1, 0, -1.0, -1, -1.0, 0, 0, 0)
 
     @staticmethod
     def dog():
         # build/config_affori_classic.ini [DoG] (DetectorType = DET_DOG, io_mods.cpp:260-262)
-        return HessAffParams(3, 1.6, 8.0, 10.0, 5, 32, 0.05, 19, 0, 0, 0.01, 3000, 0.5, 1, 0)
+        return HessAffParams(3, 1.6, 8.0, 10.0, 5, 32, 0.05, 19, 0, 0, 0.01, 3000, 0.5, 1, 0, 0)
 
     @staticmethod
     def harris():
         # build/config_affori_classic.ini [HarrisAffine] (DetectorType = DET_HARRIS, io_mods.cpp:208-210)
-        return HessAffParams(3, 1.6, 15.0, 10.0, 5, 16, 0.1, 19, 0, 0, 0.1, 1000, 0.5, 2, 0)
+        return HessAffParams(3, 1.6, 15.0, 10.0, 5, 16, 0.1, 19, 0, 0, 0.1, 1000, 0.5, 2, 0, 0)
 
 
 class Candidate(C.Structure):

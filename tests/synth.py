@@ -126,3 +126,18 @@ def pair_two_planes(w, h, seed=0, noise_sigma=2.0):
     ex = np.array([[0, -e[2], e[1]], [e[2], 0, -e[0]], [-e[1], e[0], 0]])
     F = ex @ HA
     return img1, img2, F / np.linalg.norm(F), HA, HB
+
+
+def pair_partial(w, h, seed=0, frac=0.4):
+    """(img1, img2, H): as pair(), but only the left `frac` of image 2 follows H; the rest shows the same scene under a second,
+    unrelated homography (a second motion), so that about 1 - frac of the tentative matches are outliers to the dominant model
+    - the verification then needs hundreds of samples instead of three (bench.py --inlier-ratio)."""
+    img1 = texture(w, h, seed)
+    rng = np.random.default_rng(seed + 104729)
+    H = random_homography(rng, w, h)
+    H2 = random_homography(np.random.default_rng(seed + 350377), w, h)
+    a, b = warp(img1, H, seed=seed), warp(img1, H2, seed=seed + 1)
+    cut = int(round(w * frac))
+    out = a.copy()
+    out[:, cut:] = b[:, cut:]
+    return img1, out, H

@@ -185,3 +185,22 @@ def test_keypoint_selection_modes(pkg, mode):
     with pytest.raises(Exception):
         ctx.detect_hessian_affine(img, bad)
     ctx.close()
+
+
+def test_sample_from_image(pkg):
+    """[HessianAffine] sampleFromImage = 1 (io_mods.cpp:184): the Baumberg iteration samples the input image at pixel distance 1
+    (scale-space-detector.hpp:47-55) instead of the blur level; keypoints equal the oracle's bit for bit and differ from the
+    default's."""
+    import orc
+    img = synth.texture(640, 480, seed=11)
+    par, opar = pkg.HessAffParams.default(), orc.HessAffParams.default()
+    par.sampleFromImage = 1; opar.sampleFromImage = 1
+    ctx = pkg.Context(0, 640, 480, 1)
+    got = ctx.detect_hessian_affine(img, par)
+    want = orc.detect_hessian_affine(img, opar)
+    base = ctx.detect_hessian_affine(img)
+    assert len(got) == len(want) > 300
+    for f in ("x", "y", "s", "a11", "a12", "a21", "a22", "response", "sub_type"):
+        assert np.array_equal(got[f], want[f]), f
+    assert len(base) != len(got) or not np.array_equal(base["a11"], got["a11"])
+    ctx.close()
