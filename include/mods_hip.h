@@ -497,9 +497,22 @@ int mods_multi_create(const int *devices, int n, int w, int h, int rep_capacity,
 void mods_multi_destroy(mods_multi *m);
 int mods_multi_uses_rccl(const mods_multi *m);
 mods_imgrep *mods_multi_bank(mods_multi *m, int image);   /* regions of image 1 (0) / 2 (1) after a run; owned by m */
+mods_imgrep *mods_multi_bank_det(mods_multi *m, int image, int det);   /* the same for detector `det` of a several-detector run */
 int mods_match_ladder_multi(mods_multi *m, const float *img1_host, int w1, int h1, const float *img2_host, int w2, int h2,
                             const mods_ladder_step *steps, int n_steps, int min_matches, const mods_pair_params *par,
                             mods_ladder_result *res, double *matches_out, int max_matches);
+/* The whole step loop of mods_match_ladder_groups_dev on several GPUs: several detectors per step (steps[step * n_det + det],
+ * dets[n_det]), HalfRootSIFT lists (a job's HalfRootSIFT twins travel behind its RootSIFT regions in the same all-gather), the
+ * distance matcher, grouped matching (groups[n_steps] or NULL, group_pos).  Same result as on one GPU, field by field. */
+int mods_match_ladder_groups_multi(mods_multi *m, const float *img1_host, int w1, int h1, const float *img2_host, int w2, int h2,
+                                   const mods_ladder_step *steps, const mods_hessaff_params *dets, const mods_ladder_group *groups /* or NULL */,
+                                   int group_pos, int n_steps, int n_det, int min_matches, const struct mods_pair_params *par,
+                                   mods_ladder_result *res, double *matches_out, int max_matches);
+/* queries [q_begin, q_end) of bank q against bank t with either matcher: distance > 0 runs MatchFLANNDistance (Hamming threshold)
+ * instead of the FGINN search; tentative indices refer to the full lists */
+int mods_match_reps_any(mods_ctx *ctx, const mods_imgrep *q, int q_begin, int q_end, const mods_imgrep *t, double ratio, double contradDist,
+                        int nn, double distance, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out);
+int mods_regions_half_copy_dev(mods_ctx *ctx, int img, mods_region *dst_dev, int n);   /* HalfRootSIFT twins of slot img, D2D */
 /* host logic of the sharding (no device needed): owner[i] = device of view job i with area areas[i] */
 int mods_multi_assign(const double *areas, int n, int n_dev, int *owner);
 

@@ -726,10 +726,33 @@ class Multi:
                                              m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
         return res, m[:min(res.n_inliers, max_matches)]
 
-    def bank(self, image):
-        """Regions of image 1 (0) / 2 (1) after a run."""
-        lib().mods_multi_bank.restype = C.c_void_p
-        hnd = C.c_void_p(lib().mods_multi_bank(self.h, image))
+    def match_ladder_dets(self, img1, img2, det_steps, det_params, params=None, min_matches=15, max_matches=0, groups=None, group_pos=0):
+        """mods_match_ladder_groups_multi: the arguments of match_ladder_dets_dev with the images in host memory."""
+        a = np.ascontiguousarray(img1, np.float32); b = np.ascontiguousarray(img2, np.float32)
+        n_det, n_steps = len(det_steps), max(len(x) for x in det_steps)
+        arr = (LadderStep * (n_steps * n_det))()
+        for d, steps in enumerate(det_steps):
+            for i in range(n_steps):
+                st = steps[i] if i < len(steps) and steps[i] is not None else None
+                if st is None:
+                    st = LadderStep(); st.n_tilts = st.n_scales = -1
+                arr[i * n_det + d] = st
+        dets = (HessAffParams * n_det)(*det_params)
+        params = params or PairParams.default()
+        res = LadderResult()
+        m = np.zeros((max(max_matches, 1), 4), np.float64)
+        garr = None
+        if groups is not None:
+            garr = (LadderGroup * n_steps)(*[g if g is not None else LadderGroup.make() for g in list(groups) + [None] * (n_steps - len(groups))])
+        _check(lib().mods_match_ladder_groups_multi(self.h, _fp(a), a.shape[1], a.shape[0], _fp(b), b.shape[1], b.shape[0], arr, dets, garr, group_pos,
+                                                    n_steps, n_det, min_matches, C.byref(params), C.byref(res),
+                                                    m.ctypes.data_as(C.c_void_p) if max_matches else None, max_matches))
+        return res, m[:min(res.n_inliers, max_matches)]
+
+    def bank(self, image, det=0):
+        """Regions of image 1 (0) / 2 (1) of detector `det` after a run."""
+        lib().mods_multi_bank_det.restype = C.c_void_p
+        hnd = C.c_void_p(lib().mods_multi_bank_det(self.h, image, det))
         n = lib().mods_imgrep_count(hnd)
         out = np.zeros(max(n, 1), REGION_DTYPE)
         if n:

@@ -598,7 +598,6 @@ int main(int argc, char **argv) {
       q = *e == ',' ? e + 1 : e;
     }
     if (pre_extracted || cfg.use_zmq || cfg.aff_zmq || cfg.ori_zmq) std::cerr << "Note: MODS_DEVICES is ignored in pre-extracted mode and with ZMQ daemons" << std::endl;
-    else if (!hessian_only) std::cerr << "Note: MODS_DEVICES is ignored: the multi-GPU ladder runs one HessianAffine detector" << std::endl;
     else if (!devs.empty()) {
       if (mods_multi_create(devs.data(), (int)devs.size(), std::max(img1.w, img2.w), std::max(img1.h, img2.h), 1 << 20, &multi)) return fail("multi-GPU setup");
       if (cfg.verbose) std::cerr << devs.size() << " device(s), exchange over " << (mods_multi_uses_rccl(multi) ? "RCCL" : "device copies") << std::endl;
@@ -615,11 +614,15 @@ int main(int argc, char **argv) {
     if (mods_match_verify_reps(ctx, reps1[0], reps2[0], first_ratio, &cfg.pair, &res, matches.data(), 1 << 20)) return fail("matching");
     res.n_unoriented[0] = (int)r1.size(); res.n_unoriented[1] = (int)r2.size();
   } else if (multi) {   // MODS_DEVICES: the views of every step sharded over several GPUs, one all-gather of the regions per step
-    if (mods_match_ladder_multi(multi, img1.px.data(), img1.w, img1.h, img2.px.data(), img2.w, img2.h, steps.data(), (int)steps.size(),
-                                cfg.min_matches, &cfg.pair, &res, matches.data(), 1 << 20))
+    // (every detector, descriptor list and group of the configuration: the step loop of mods_match_ladder_groups_dev)
+    if (mods_match_ladder_groups_multi(multi, img1.px.data(), img1.w, img1.h, img2.px.data(), img2.w, img2.h, cfg.steps.data(), cfg.det_params.data(),
+                                       cfg.groups.empty() ? nullptr : cfg.groups.data(), cfg.group_pos, (int)cfg.steps.size() / n_det, n_det,
+                                       cfg.min_matches, &cfg.pair, &res, matches.data(), 1 << 20))
       return fail("matching");
-    mods_imgrep_destroy(reps1[0]); mods_imgrep_destroy(reps2[0]);
-    reps1[0] = mods_multi_bank(multi, 0); reps2[0] = mods_multi_bank(multi, 1);     // for the keypoint files; owned by `multi`
+    for (int d = 0; d < n_det; d++) {      // for the keypoint files; owned by `multi`
+      mods_imgrep_destroy(reps1[d]); mods_imgrep_destroy(reps2[d]);
+      reps1[d] = mods_multi_bank_det(multi, 0, d); reps2[d] = mods_multi_bank_det(multi, 1, d);
+    }
   } else if (hessian_only) {
     if (steps.empty()) { res = mods_ladder_result(); }
     else if (mods_match_ladder_dev(ctx, (const float *)d1, img1.w, img1.h, (const float *)d2, img2.w, img2.h, steps.data(), (int)steps.size(),
@@ -630,7 +633,7 @@ int main(int argc, char **argv) {
                                           &cfg.pair, reps1.data(), reps2.data(), &res, matches.data(), 1 << 20))
     return fail("matching");
   const double final_time = now_s() - c_start;
-  const int final_step = res.steps_done <= 0 ? 0 : (hessian_only && !pre_extracted) ? step_index[res.steps_done - 1] + 1 : res.steps_done;
+  const int final_step = res.steps_done <= 0 ? 0 : (hessian_only && !pre_extracted && !multi) ? step_index[res.steps_done - 1] + 1 : res.steps_done;
   if (cfg.verbose) {
     std::cerr << res.n_views << " views synthesised, " << res.n_tentatives << " tentatives found." << std::endl;
     std::cerr << res.n_unique << " unique tentatives left" << std::endl;

@@ -193,6 +193,22 @@ int mods_match_reps(mods_ctx *c, const mods_imgrep *q, int q_begin, int q_end, c
   return MODS_OK;
 }
 
+// The same for either matcher: distance > 0 runs MatchFLANNDistance (Hamming, threshold `distance`) on the query slice instead
+int mods_match_reps_any(mods_ctx *c, const mods_imgrep *q, int q_begin, int q_end, const mods_imgrep *t, double ratio, double contradDist,
+                        int nn, double distance, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out) {
+  if (!(distance > 0)) return mods_match_reps(c, q, q_begin, q_end, t, ratio, contradDist, nn, out, u6_out, laf_out, max_out, n_out);
+  if (!c || !q || !t || !n_out) { set_error("match_reps: null argument"); return MODS_E_ARG; }
+  if (q_begin < 0 || q_end > q->n || q_begin > q_end) { set_error("match_reps: bad query range"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc = match_run_distance(c, q->reg + q_begin, q_end - q_begin, t->reg, t->n, distance);
+  if (rc) return rc;
+  rc = mods_match_fetch_internal(c, out, u6_out, laf_out, max_out, n_out);
+  if (rc) return rc;
+  if (out && q_begin)
+    for (int i = 0; i < *n_out; i++) out[i].q += q_begin;
+  return MODS_OK;
+}
+
 // ---- the step loop of mods.cpp:202-383 on one GPU ---------------------------------------------------------------
 // img1_dev / img2_dev: dense fp32 images in HBM (the two images may differ in size).  Every step adds the step's new views of both images to the two region
 // banks, matches bank 1 against bank 2, filters duplicates, verifies, and stops once the verified

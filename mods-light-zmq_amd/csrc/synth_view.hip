@@ -331,6 +331,16 @@ int mods_regions_copy_dev(mods_ctx *c, int img, mods_region *dst_dev, int n) {
   return MODS_OK;
 }
 
+// the HalfRootSIFT twins of the regions of slot `img` (describe stage with halfDesc), same order
+int mods_regions_half_copy_dev(mods_ctx *c, int img, mods_region *dst_dev, int n) {
+  if (!c || !dst_dev || img < 0 || img >= c->batch || n < 0 || n > c->max_cand) { set_error("regions_half_copy_dev: bad arguments"); return MODS_E_ARG; }
+  if (!c->have_half || !c->regions_half_dev) { set_error("regions_half_copy_dev: no HalfRootSIFT descriptors in the context"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(hipMemcpyAsync(dst_dev, c->regions_half_dev + (size_t)img * c->max_cand, sizeof(mods_region) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return MODS_OK;
+}
+
 const mods_region *mods_regions_dev(mods_ctx *c, int img) { return c->regions_dev + (size_t)img * c->max_cand; }
 const float *mods_view_pixels_dev(mods_ctx *c) { return c->view_dev; }
 

@@ -99,8 +99,61 @@ def test_multi_gpu_ladder_in_cpp(pkg, devices):
     multi.close(); rep1.close(); rep2.close(); ctx.close()
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_multi_gpu_ladder_half_lists_and_two_detectors(pkg, devices):
+    """The whole step loop on several devices (mods_match_ladder_groups_multi): a HessianAffine detector whose steps ask for
+    RootSIFT and HalfRootSIFT lists (iters_MODS.ini: Descriptors = RootSIFT, HalfRootSIFT; the HalfRootSIFT twins of a view travel
+    behind its RootSIFT regions in the step's one exchange) next to a DoG detector that only has views in the first step;
+    identical to mods_match_ladder_groups_dev on one GPU, field by field, banks included."""
+    import torch
+    from test_gpu_views import _hard_pair
+    w, h = 480, 360
+    a, b, _ = _hard_pair(w, h, seed=23)
+    mk = pkg.LadderStep.make
+    det_steps = [[mk((1,), 360.0), None, None],
+                 [mk((1,), 360.0, half_orientation=1, fginn_half=0.8), mk((1, 2), 360.0, half_orientation=1, fginn_half=0.8),
+                  mk((1, 2, 4), 120.0, half_orientation=1, fginn_half=0.8)]]
+    det_params = [pkg.HessAffParams.dog(), pkg.HessAffParams.default()]
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    reps1, reps2 = [pkg.ImgRep(ctx), pkg.ImgRep(ctx)], [pkg.ImgRep(ctx), pkg.ImgRep(ctx)]
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(31)
+    want, wm = pkg.match_ladder_dets_dev(ctx, t.data_ptr(), w, h, det_steps, det_params, reps1, reps2, min_matches=100000, max_matches=100000)
+    banks = [[r.fetch() for r in reps1], [r.fetch() for r in reps2]]
+    multi = pkg.Multi(devices, w, h)
+    pkg.ransac_pin_seed(31)
+    got, gm = multi.match_ladder_dets(a, b, det_steps, det_params, min_matches=100000, max_matches=100000)
+    assert want.steps_done == 3 and want.n_tentatives > 100
+    for f in ("steps_done", "n_views", "n_tentatives", "n_unique", "n_inliers", "ransac_samples", "ransac_lo", "ransac_rejects"):
+        assert getattr(got, f) == getattr(want, f), f
+    assert list(got.n_described) == list(want.n_described) and list(got.n_detected) == list(want.n_detected)
+    assert list(got.n_unoriented) == list(want.n_unoriented)
+    assert list(got.H) == list(want.H) and np.array_equal(gm, wm) and got.n_inliers >= 15
+    for im in (0, 1):
+        for det in (0, 1):
+            bank, exp = multi.bank(im, det), banks[im][det]
+            assert len(bank) == len(exp) > 30
+            assert np.array_equal(bank["desc"], exp["desc"]) and np.array_equal(bank["x"], exp["x"]) and np.array_equal(bank["id"], exp["id"])
+    multi.close()
+    for r in reps1 + reps2:
+        r.close()
+    ctx.close()
+
+
+def test_multi_gpu_rejects_images_larger_than_created(pkg):
+    """mods_multi_create sizes the device buffers; a later call with larger images is refused instead of overflowing them."""
+    multi = pkg.Multi([0, 0], 320, 240)
+    big = np.zeros((480, 640), np.float32)
+    with pytest.raises(pkg.ModsError, match="exceed"):
+        multi.match_ladder(big, big, [pkg.LadderStep.make((1,), 360.0)])
+    multi.close()
+
+
 def test_cli_on_several_devices(tmp_path):
-    """MODS_DEVICES: the command line runs the ladder through mods_match_ladder_multi and writes the same files."""
+    """MODS_DEVICES: the command line runs the whole configuration (HessianAffine steps with RootSIFT + HalfRootSIFT lists next to
+    DoG steps: tests/configs/iters_ladder.ini) through mods_match_ladder_groups_multi and writes the SAME files as on one GPU."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -117,7 +170,6 @@ def test_cli_on_several_devices(tmp_path):
                            stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, p.stderr.decode()
         outs[name] = {f: (wd / f).read_text() for f in ("m.txt", "k1.txt", "k2.txt", "H.txt")}
-    # iters_ladder.ini's first HessianAffine step asks for HalfRootSIFT lists too, which the multi-GPU path does not exchange:
-    # compare on a RootSIFT-only result only when both runs ended in the same step
-    assert outs["multi"]["k1.txt"].splitlines()[2].startswith("RootSIFT")
     assert len(outs["multi"]["m.txt"].splitlines()) >= 15
+    for f in ("m.txt", "k1.txt", "k2.txt", "H.txt"):
+        assert outs["multi"][f] == outs["one"][f], f
