@@ -96,6 +96,50 @@ def cpu_baseline(img1, img2, seed):
             "one_core": {"value": round(1.0 / t_one, 5), "cores": 1}}
 
 
+def host_share(torch, device, local_rank, local_world):
+    """Cores of this rank: usable cores (affinity, cgroup quota) / ranks of the node, from the GPU's NUMA node when known.
+    Pins the process (threads created later inherit the mask).  Returns the "host" object of the JSON line."""
+    try:
+        usable = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = list(range(os.cpu_count() or 1))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(period)))
+    except (OSError, ValueError):
+        pass
+    n_usable = min(len(usable), quota) if quota else len(usable)
+    per_rank = max(1, n_usable // max(1, local_world))
+    pinned, numa = False, None
+    if local_world > 1:
+        cand = usable
+        try:   # cores next to the GPU: /sys/bus/pci/devices/<domain:bus:device.0>/local_cpulist
+            pr = torch.cuda.get_device_properties(device)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            numa = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+            local = set()
+            for part in open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                local.update(range(int(lo), int(hi or lo) + 1))
+            near = [c for c in usable if c in local]
+            if len(near) >= per_rank:
+                cand = near
+        except (OSError, ValueError, AttributeError, RuntimeError):
+            pass
+        # the ranks that share `cand` take consecutive slices of it
+        k = local_rank % max(1, len(cand) // per_rank)
+        mine = cand[k * per_rank:(k + 1) * per_rank] or cand[:per_rank]
+        try:
+            os.sched_setaffinity(0, mine)
+            pinned = True
+        except (OSError, AttributeError):
+            pass
+    return {"cores_visible": os.cpu_count(), "cores_usable": n_usable, "cgroup_quota": quota, "cores_per_rank": per_rank,
+            "pinned": pinned, "gpu_numa_node": numa}
+
+
 MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 = 2 x the bf16 rate (MI355X_MICROARCH.md MFMA table; measured ceiling >= 3944)
 
 
@@ -222,6 +266,7 @@ def main():
                     help="where a pair lives when its step starts: 8-bit grey in pinned host memory (default: the boundary of the "
                          "reference's step loop), fp32 in pinned host memory, or fp32 resident in HBM")
     ap.add_argument("--no-match-leg", action="store_true", help="skip the configs[4]-sized match measurement (roofline_match)")
+    ap.add_argument("--keep-workers", action="store_true", help="N > 1: do not shrink the worker counts to the rank's share of the host cores")
     ap.add_argument("--inlier-ratio", type=float, default=0.0,
                     help="0 (default): SURVEY 8d's pairs (one homography, ~94 %% of the tentatives are inliers: 3 RANSAC samples); "
                          "0 < R < 1: only the left R of image 2 follows the homography, the rest a second motion, so the "
@@ -242,16 +287,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     # MODS_BENCH_SHARE_GPU=1 (development aid for 1-GPU boxes): every rank uses GPU 0 and the ranks meet over gloo, so that the
     # multi-rank control flow can be exercised without a multi-GPU node
     share = os.environ.get("MODS_BENCH_SHARE_GPU") == "1"
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that never arrives makes the others fail after this long instead of hanging the node
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("MODS_BENCH_PG_TIMEOUT", "300")))
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
     device = local_rank if (world > 1 and not share) else 0
     torch.cuda.set_device(device)
 
@@ -260,6 +309,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libmodsgpu has no CPU path")
     if args.serial:
         args.input = "hbm"
+    # host side of a rank: the cores this process may use (affinity mask, cgroup quota) are split between the ranks of the node,
+    # each rank takes its share from the cores of its GPU's NUMA node when sysfs tells them (the pipeline's worker threads inherit
+    # the mask), and the worker counts shrink to what the share can run: 8 ranks x (6 + 8) threads on a box that exposes 8 cores
+    # would measure the host scheduler, not the GPUs
+    host = host_share(torch, device, local_rank, local_world if world > 1 else 1)
+    if world > 1 and not args.keep_workers:
+        args.gpu_workers = max(2, min(args.gpu_workers, host["cores_per_rank"] // 2))
+        args.verify_workers = max(2, min(args.verify_workers, host["cores_per_rank"] - args.gpu_workers))
 
     # synthetic inputs: seed = 1000*config + pair index (config 2 = the 1080p pair), distinct per rank.  The generator makes
     # 8-bit valued images ("uint8 then float32"), so the 8-bit and the fp32 form of a pair are the same image.
@@ -377,8 +434,13 @@ def main():
         del batch_t
     last = step(0)
 
+    rank_rates = [n_pairs / dt]
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+        mine = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_rates = [round(n_pairs / float(t.item()), 2) for t in every]     # a slow rank (host cores, a busy GPU) shows here
+        tmax = mine.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -393,6 +455,7 @@ def main():
             "metric": "image_pairs_per_sec_end_to_end", "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "host": host, "pairs_per_s_by_rank": rank_rates,
             "config": {"workload": "single 1920x1080 pair, HessianAffine+RootSIFT, 1 synth iteration (BASELINE configs[1])"
                                    + (" - VARIANT: second motion over %.0f %% of image 2 (--inlier-ratio)" % (100 * (1 - args.inlier_ratio)) if args.inlier_ratio > 0 else ""),
                        "pairs_per_step": pps, "image": "1920x1080",
