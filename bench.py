@@ -198,9 +198,12 @@ def other_configs(args):
         pipe.close()
     elif args.config == "c5":
         w = h = 4096
-        a = synth.texture(w, h, 5000, blobs=30000)
-        Hm = synth.random_homography(np.random.default_rng(5000 + 104729), w, h)
-        b = synth.warp(a, Hm, seed=5000)
+        if args.scene == "two_planes":     # a scene with parallax: no single homography explains it, DEGENSAC's ordinary branch
+            a, b, _, _, _ = synth.pair_two_planes(w, h, seed=5000, blobs=30000)
+        else:                              # one plane: every good 7-point sample is H-degenerate (plane-and-parallax search)
+            a = synth.texture(w, h, 5000, blobs=30000)
+            Hm = synth.random_homography(np.random.default_rng(5000 + 104729), w, h)
+            b = synth.warp(a, Hm, seed=5000)
         t = torch.from_numpy(np.stack([a, b])).cuda()
         ctx = pkg.Context(0, w, h, 2)
         params = pkg.PairParams.default()
@@ -217,7 +220,7 @@ def other_configs(args):
         flops = 2.0 * last.n_described[0] * last.n_described[1] * 128
         ach = flops / (mms * 1e-3) / 1e12 if mms else 0.0
         out.update(value=round(args.steps / dt, 4), ms_per_step=round(dt / args.steps * 1e3, 3),
-                   config={"workload": "4096x4096 pair, exact FGINN match + DEGENSAC F (BASELINE configs[4])",
+                   config={"workload": "4096x4096 pair, exact FGINN match + DEGENSAC F (BASELINE configs[4]); scene: " + args.scene,
                            "keypoints_per_image": list(last.n_described), "tentatives": last.n_tentatives, "inliers": last.n_inliers,
                            "ransac_samples": last.ransac_samples, "ransac_lo": last.ransac_lo,
                            "stage_ms": {"detect_describe": round(last.ms_detect_describe, 2), "match": round(last.ms_match, 2),
@@ -266,6 +269,8 @@ def main():
                     help="where a pair lives when its step starts: 8-bit grey in pinned host memory (default: the boundary of the "
                          "reference's step loop), fp32 in pinned host memory, or fp32 resident in HBM")
     ap.add_argument("--no-match-leg", action="store_true", help="skip the configs[4]-sized match measurement (roofline_match)")
+    ap.add_argument("--scene", default="planar", choices=["planar", "two_planes"],
+                    help="--config c5: one plane (SURVEY 8d's generator: every sample is H-degenerate) or two planes with parallax")
     ap.add_argument("--keep-workers", action="store_true", help="N > 1: do not shrink the worker counts to the rank's share of the host cores")
     ap.add_argument("--inlier-ratio", type=float, default=0.0,
                     help="0 (default): SURVEY 8d's pairs (one homography, ~94 %% of the tentatives are inliers: 3 RANSAC samples); "

@@ -605,6 +605,10 @@ __global__ __launch_bounds__(256) void big_sample_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const BigLists *__restrict__ bl, const BigRegion *__restrict__ regions,
                                                           const int2 *__restrict__ ritems, int max_items, float *__restrict__ pool,
                                                           const int *__restrict__ err_flag) {
+  // the item's Gaussian taps, per wave: read through `pool` (which this kernel also writes) every tap would be a per-lane
+  // global load with a full wait in front of its use (see big_fused_kernel); regions with more taps than fit keep that path
+  constexpr int TAPS_LDS = 1024;
+  __shared__ float s_wtap[4][TAPS_LDS];
   if (*err_flag) return;
   const int ps = k.desc_ps, ps2 = t_stride(ps);   // (row stride of T)
   const int n_items = min(bl->n_ritems, max_items);
@@ -613,11 +617,16 @@ __global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const Big
     const int2 item = ritems[it];
     const BigRegion br = regions[item.x];
     const int P2 = br.P2, P2r = br.P2r, n_tap = br.n_tap, r_tap = n_tap >> 1;
+    const bool taps_in_lds = n_tap <= TAPS_LDS;
+    wave_sync();
+    if (taps_in_lds)
+      for (int i = lane; i < n_tap; i += 64) s_wtap[threadIdx.x >> 6][i] = (pool + br.slab)[i];
+    wave_sync();
     const int y = (item.y & 0xffff) + 4 * (lane & 15), pg = lane >> 4;
     const int step0 = item.y >> 16, step1 = min((ps + 3) / 4, step0 + big_rsteps(n_tap));
-    const float *tap = pool + br.slab;
-    const int *cidx = (const int *)(tap + n_tap + ps);
-    const float *St = tap + big_hdr_floats(n_tap, ps);
+    const float *tap = taps_in_lds ? (const float *)s_wtap[threadIdx.x >> 6] : (const float *)(pool + br.slab);
+    const int *cidx = (const int *)(pool + br.slab + n_tap + ps);
+    const float *St = pool + br.slab + big_hdr_floats(n_tap, ps);
     float *T = (float *)St + big_s_floats(P2, P2r);
     for (int step = step0; step < step1; step++) {
       const int pi = step * 4 + pg;
@@ -1463,6 +1472,9 @@ static size_t sift_wave2_lds_bytes(int ps) {
   return sizeof(float) * 2048 + sizeof(float) * (4 * ps + 4) + sizeof(int) * 72 + sizeof(unsigned short) * ppa + S2_WAVES * sift_wave2_wave_bytes(ps) + 64;
 }
 
+// NC: pixel columns a histogram lane walks per row = the widest span of positive column weights of a spatial bin, rounded up to
+// an even number (15 -> 16 for the 41-pixel patch; SW_CW = 18 covers every patch size this kernel takes)
+template <int NC>
 __global__ __launch_bounds__(64 * S2_WAVES, 3) void sift_wave2_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
                                                                         const int *__restrict__ reg_count, const float *__restrict__ mask,
                                                                         const SiftTab *__restrict__ tab, int n_img, int *__restrict__ next_unit) {
@@ -1512,9 +1524,9 @@ __global__ __launch_bounds__(64 * S2_WAVES, 3) void sift_wave2_kernel(DescConst 
   const int hr = lane >> 3, hsel = (lane >> 2) & 1, hbc = lane & 3;
   int clo = ps;
   for (int i = ps - 1; i >= 0; i--) if (s_w[hbc * ps + i] > 0) clo = i;
-  float wcw[SW_CW];
+  float wcw[NC];
 #pragma unroll
-  for (int q = 0; q < SW_CW; q++) wcw[q] = (clo + q < ps) ? s_w[hbc * ps + clo + q] : 0.f;
+  for (int q = 0; q < NC; q++) wcw[q] = (clo + q < ps) ? s_w[hbc * ps + clo + q] : 0.f;
   // pixel slots of a lane: e = lane + 64 u -> region e / ps, column e % ps (the same for every row and every unit)
   constexpr int RL = 6;                               // >= ceil(SW_R * ps / 64) for ps <= 48 (this kernel runs for ps <= 45)
   int s_rr[RL], s_c[RL];
@@ -1679,12 +1691,12 @@ __global__ __launch_bounds__(64 * S2_WAVES, 3) void sift_wave2_kernel(DescConst 
           double *abin = acc + s2_bin(hr, rb8 >> 3, hbc);
           const float2 *px = pxrow + hr * ps + clo;
 #pragma unroll
-          for (int q0 = 0; q0 < SW_CW; q0 += SW_CW / 2) {
-            float2 pv[SW_CW / 2];
+          for (int q0 = 0; q0 < NC; q0 += NC / 2) {
+            float2 pv[NC / 2];
 #pragma unroll
-            for (int q = 0; q < SW_CW / 2; q++) pv[q] = px[q0 + q];
+            for (int q = 0; q < NC / 2; q++) pv[q] = px[q0 + q];
 #pragma unroll
-            for (int q = 0; q < SW_CW / 2; q++) {
+            for (int q = 0; q < NC / 2; q++) {
               // a pixel that the reference skips (val <= 0; also the NaN that a zero weight makes of the idle words behind
               // the row) adds +0.0, which leaves a bin as it is: no branch per pixel
               const float val = wrr * (wcw[q0 + q] * pv[q].x);
@@ -1885,11 +1897,30 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
       hipLaunchKernelGGL(sift_wave_kernel, dim3(1024, n_img), dim3(256), sift_wave_lds_bytes(ps), ctx->stream, k, patches,
                          ctx->regions_dev, ctx->region_count, dmask, tab, (int)sift_wave_scratch_floats(ps));
     } else {
-      static const hipError_t attr = hipFuncSetAttribute((const void *)sift_wave2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      MODS_HIP_CHECK(attr);
+      static const hipError_t attr16 = hipFuncSetAttribute((const void *)sift_wave2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      static const hipError_t attr18 = hipFuncSetAttribute((const void *)sift_wave2_kernel<SW_CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      MODS_HIP_CHECK(attr16); MODS_HIP_CHECK(attr18);
+      // widest span of positive column weights of a spatial bin (siftdesc.cpp:22-71: step = 5 / (2 * (ps / 2)), bins x - 1 and x)
+      int span = 0;
+      {
+        const float step = 5.0f / (float)(2 * (ps >> 1));
+        for (int bc = 0; bc < 4; bc++) {
+          int lo = ps, hi = -1;
+          for (int i = 0; i < ps; i++) {
+            const float x = step * i; const int xi = (int)x; const float w1 = x - xi, w0 = 1.0f - w1;
+            const bool on = (xi - 1 == bc && w0 > 0) || (xi == bc && w1 > 0);
+            if (on) { lo = std::min(lo, i); hi = i; }
+          }
+          if (hi >= lo) span = std::max(span, hi - lo + 1);
+        }
+      }
       // persistent: one workgroup of 12 waves per CU, work units pulled from bl->sift_next (zeroed with bl above)
-      hipLaunchKernelGGL(sift_wave2_kernel, dim3(ctx->n_cu), dim3(64 * S2_WAVES), sift_wave2_lds_bytes(ps), ctx->stream, k, patches,
-                         ctx->regions_dev, ctx->region_count, dmask, tab, n_img, &bl->sift_next);
+      if (span <= 16)
+        hipLaunchKernelGGL(sift_wave2_kernel<16>, dim3(ctx->n_cu), dim3(64 * S2_WAVES), sift_wave2_lds_bytes(ps), ctx->stream, k, patches,
+                           ctx->regions_dev, ctx->region_count, dmask, tab, n_img, &bl->sift_next);
+      else
+        hipLaunchKernelGGL(sift_wave2_kernel<SW_CW>, dim3(ctx->n_cu), dim3(64 * S2_WAVES), sift_wave2_lds_bytes(ps), ctx->stream, k, patches,
+                           ctx->regions_dev, ctx->region_count, dmask, tab, n_img, &bl->sift_next);
     }
   }
   MODS_HIP_CHECK(hipGetLastError());

@@ -92,11 +92,11 @@ def _warp_src(H, xx, yy):
     return (Hi[0, 0] * xx + Hi[0, 1] * yy + Hi[0, 2]) / den, (Hi[1, 0] * xx + Hi[1, 1] * yy + Hi[1, 2]) / den
 
 
-def pair_two_planes(w, h, seed=0, noise_sigma=2.0):
+def pair_two_planes(w, h, seed=0, noise_sigma=2.0, blobs=None):
     """(img1, img2, F, HA, HB): a scene of two planes seen from two viewpoints.  Image 1 is split by a slanted
     line; the two halves move with homographies HA and HB = HA + e a^T (same epipole e), so that all
     true correspondences satisfy x2^T F x1 = 0 with F = [e]x HA, and no single homography explains them."""
-    img1 = texture(w, h, seed)
+    img1 = texture(w, h, seed, blobs=blobs)
     rng = np.random.default_rng(seed + 15485863)
     HA = random_homography(rng, w, h)
     e = np.array([w * rng.uniform(2.5, 4.0) * rng.choice([-1, 1]), h * rng.uniform(-1.0, 2.0), 1.0])

@@ -1,10 +1,8 @@
+# GPU box: the non-headline configurations (BASELINE configs[2], [3], [4]) through bench.py; usage: bash tools/run_configs.sh <tag>
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02b
-( echo "# python bench.py --config c3|c4|c5 --no-cpu-baseline on one MI355X (BASELINE configs[2], [3], [4]), round 2"
-  for c in c3 c4 c5; do python bench.py --config $c --no-cpu-baseline 2>/dev/null | grep '^{"metric"'; done ) > gpurun_out/r02b/configs_c3_c4_c5.log
-cut -c1-260 gpurun_out/r02b/configs_c3_c4_c5.log
-python bench.py 2>/dev/null | grep '^{"metric"' > gpurun_out/r02b/bench2.json; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r02b/bench2.json').read())
-print(d['value'], d['cpu_baseline'])
-PY
+TAG=${1:-r03}
+mkdir -p gpurun_out/$TAG
+( echo "# python bench.py --config c3|c4|c5 --no-cpu-baseline on one MI355X (BASELINE configs[2], [3], [4])"
+  for c in c3 c4 c5; do python bench.py --config $c --no-cpu-baseline 2>/dev/null | grep '^{"metric"'; done
+  python bench.py --config c5 --scene two_planes --no-cpu-baseline 2>/dev/null | grep '^{"metric"' ) > gpurun_out/$TAG/configs_c3_c4_c5.log
+cut -c1-420 gpurun_out/$TAG/configs_c3_c4_c5.log
