@@ -2,7 +2,7 @@
 # command, the isolated detector leg (one stream, 16 images per launch), the two PMC passes (FETCH_SIZE / WRITE_SIZE, separate
 # runs, --kernel-trace only) for the HBM traffic of the fused blur + response kernel at the bench's batching, the matcher
 # micro-benchmark (kernel statistics + SQ counters), and SQ counters of the describe-stage kernels.  Outputs: gpurun_out/<tag>/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
