@@ -314,3 +314,31 @@ def test_config3_1mp_pairs_through_pipeline(pkg):
         a, b, Ht = pairs[i]
         want = po.match_pair(a, b, seed_time=4321)
         _check_against_oracle(got[i][0], got[i][2], want, Ht)
+
+
+@pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built")
+def test_pair_low_inlier_ratio(pkg):
+    """bench.py --inlier-ratio: two motions of about equal support in one pair, so that half of the tentatives are outliers to
+    whichever homography wins and LO-RANSAC draws ~70 samples with two LO runs and ~20 orientation rejects (speculative scoring
+    batches that are cut short and replayed) instead of the three samples of SURVEY 8d's pairs: counts, RANSAC statistics, inlier
+    list and H against the CPU oracle chain."""
+    import torch
+    import pipeline_oracle as po
+    w, h = 1280, 960
+    a, b, _ = synth.pair_partial(w, h, seed=2300, frac=0.55)
+    want = po.match_pair(a, b, seed_time=555)
+    ctx = pkg.Context(0, w, h, 2)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(555)
+    res, m = pkg.match_pair_dev(ctx, t.data_ptr(), w, h, max_matches=100000)
+    assert want["stats"][0] >= 40 and want["stats"][1] >= 2         # the regime this test is for
+    assert 0.3 * res.n_unique < res.n_inliers < 0.7 * res.n_unique   # about half of the tentatives follow the winning motion
+    assert list(res.n_detected) == want["n_detected"] and list(res.n_described) == want["n_described"]
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"]
+    assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
+    Hg, Hw = np.array(res.H).reshape(3, 3), want["H"]
+    assert np.max(np.abs(Hg / Hg[2, 2] - Hw / Hw[2, 2]) / np.maximum(1e-3, np.abs(Hw / Hw[2, 2]))) < 1e-4
+    ctx.close()
