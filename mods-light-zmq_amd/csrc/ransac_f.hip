@@ -165,6 +165,7 @@ struct GpuEval : rs::PointEval {
   void fds_sym(const double *F, double *out) override { run(EV_FDS_SYM, F, out, nullptr); }
   void exfds(const double *F, double *p, double *w) override { run(EV_EXFDS, F, p, w); }
   void exfds_sym(const double *F, double *p, double *w) override { run(EV_EXFDS_SYM, F, p, w); }
+  bool concurrent() const override { return false; }   // one stream, one pair of staging buffers
 };
 
 // PointEval as host SIMD across correspondences (ransac_simd.hpp: the scalar code's operations in the scalar code's order, 4
@@ -173,18 +174,29 @@ struct GpuEval : rs::PointEval {
 // of them (BASELINE configs[4]).
 struct SimdEval : rs::PointEval {
   PointsSoA pts;
-  std::vector<double> tp, tw;
-  SimdEval(const double *u_, int len_) : rs::PointEval(u_, len_) { pts.build(u_, len_); tp.resize(pts.n_pad); tw.resize(pts.n_pad); }
+  SimdEval(const double *u_, int len_) : rs::PointEval(u_, len_) { pts.build(u_, len_); }
+  // padded outputs of one evaluation; per calling thread, so that the tasks of ransac_pool.hpp can share one SimdEval
+  static std::vector<double> &scratch(int which, size_t n) {
+    static thread_local std::vector<double> v[2];
+    if (v[which].size() < n) v[which].resize(n);
+    return v[which];
+  }
   void f(const double *F, int mode, double *p, double *w) {
+    std::vector<double> &tp = scratch(0, pts.n_pad), &tw = scratch(1, pts.n_pad);
     pts.ops->fds_all(pts.col, pts.n_pad, F, mode, tp.data(), tw.data());
     memcpy(p, tp.data(), sizeof(double) * len);
     if (w) memcpy(w, tw.data(), sizeof(double) * len);
   }
-  void hds(const double *H, double *out) override { pts.ops->hds_all(pts.col, pts.n_pad, H, tp.data()); memcpy(out, tp.data(), sizeof(double) * len); }
+  void hds(const double *H, double *out) override {
+    std::vector<double> &tp = scratch(0, pts.n_pad);
+    pts.ops->hds_all(pts.col, pts.n_pad, H, tp.data());
+    memcpy(out, tp.data(), sizeof(double) * len);
+  }
   void fds(const double *F, double *out) override { f(F, 0, out, nullptr); }
   void fds_sym(const double *F, double *out) override { f(F, 1, out, nullptr); }
   void exfds(const double *F, double *p, double *w) override { f(F, 2, p, w); }
   void exfds_sym(const double *F, double *p, double *w) override { f(F, 3, p, w); }
+  bool concurrent() const override { return true; }
 };
 
 // off-plane set of rFtH -> aux_dev
@@ -282,6 +294,18 @@ unsigned mods_test_rfth(unsigned seed, const double *u, const unsigned char *hin
   rs::GlibcRand g;
   g.seed(seed);
   return rs::rFtH(g, u, hinl, th, H, len, F, nullptr, rs::PairCounter());
+}
+// the same with the host SIMD evaluation of the production path (0: the scalar PointEval) and the generator's next value
+// after the call (what the rest of exp_ransacFcustom would draw next); prof8 (optional) receives and clears g_rfth_prof
+unsigned mods_test_rfth2(unsigned seed, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F,
+                         int simd, int *next_rand, double *prof8) {
+  rs::GlibcRand g;
+  g.seed(seed);
+  SimdEval sev(u, (int)len);
+  const unsigned I = rs::rFtH(g, u, hinl, th, H, len, F, nullptr, rs::PairCounter(), simd ? &sev : nullptr);
+  if (next_rand) *next_rand = g.next();
+  if (prof8) for (int i = 0; i < 8; i++) { prof8[i] = rs::g_rfth_prof[i]; rs::g_rfth_prof[i] = 0; }
+  return I;
 }
 
 }  // extern "C"

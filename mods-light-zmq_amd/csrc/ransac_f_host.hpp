@@ -22,7 +22,11 @@
 // Agreement with the reference: ~1e-12 relative or better, sign included where it matters.
 // fp64, one rounding per operation (-ffp-contract=off).
 #pragma once
+#include <memory>
+#include <utility>
+
 #include "ransac_host.hpp"
+#include "ransac_pool.hpp"
 #include "ransac_simd.hpp"
 #include <functional>
 #include <ctime>
@@ -557,6 +561,7 @@ struct PointEval {
   virtual void fds_sym(const double *F, double *out) { FDsSym_all(u, F, out, len); }
   virtual void exfds(const double *F, double *p, double *w) { exFDs_all(u, F, p, w, len); }
   virtual void exfds_sym(const double *F, double *p, double *w) { exFDsSym_all(u, F, p, w, len); }
+  virtual bool concurrent() const { return true; }   // may several threads evaluate through this object at once?
 };
 
 // Hdetect, DegUtils.c:93-156: homography compatible with F through three correspondences
@@ -637,12 +642,44 @@ struct HLo {
   double *errs[5];
   double *buffer;
   PointEval *ev;
+  int n_pad;          // stride of the error buffers: len rounded up to SIMD_PAD, so that the lanes-wide gain pass may read whole vectors
+  double *gains;      // n_pad doubles
 };
-static inline Score iterH(HLo &L, int *inliers, double th, double ths, double *H, unsigned inlLimit) {
+// inlidxs (rtools.c:155-166) over one error vector for the two thresholds iterH asks about back to back:
+//   S  = inlidxs(err, th)   - count and MSAC sum (the sum is a serial chain of len additions: the gains are made lanes-wide
+//                             first, SimdOps::gains_all = trunc_quad per lane, and added in index order);
+//   Ss = inlidxs(err, ths)  - iterH reads only its count and its index list, so its sum is not formed.
+// ths >= th.  `inl` receives the list of `list_ths ? ths : th`; returns S, *n_ths = Ss.I.
+static inline Score inlidxs2(const HLo &L, const double *err, double th, double ths, bool list_ths, int *inl, unsigned *n_ths) {
   const int len = L.len;
+  const SimdOps *ops = th != 0 ? simd_ops() : nullptr;
+  Score s = {0, 0};
+  unsigned n2 = 0;
+  if (ops) ops->gains_all(err, L.n_pad, th * 9 / 4, L.gains);
+  const double *g = L.gains;
+  if (list_ths) {
+    for (int i = 0; i < len; ++i) {
+      const double e = err[i];
+      s.J += ops ? g[i] : trunc_quad(e, th);
+      if (e <= th) ++s.I;
+      if (e <= ths) inl[n2++] = i;
+    }
+  } else {
+    for (int i = 0; i < len; ++i) {
+      const double e = err[i];
+      s.J += ops ? g[i] : trunc_quad(e, th);
+      if (e <= th) { inl[s.I] = i; ++s.I; }
+      if (e <= ths) ++n2;
+    }
+  }
+  if (n_ths) *n_ths = n2;
+  return s;
+}
+static inline Score iterH(HLo &L, int *inliers, double th, double ths, double *H, unsigned inlLimit) {
   double *d = L.errs[1];
   double h[9];
-  Score S = {0, 0}, Ss, maxS;
+  Score S = {0, 0}, maxS;
+  unsigned SsI = 0;
   const double dth = (ths - th) / 4;
   auto lsq = [&](unsigned n) {
     if (n <= inlLimit) u2h(L.u, inliers, (int)n, h, L.buffer);
@@ -651,13 +688,12 @@ static inline Score iterH(HLo &L, int *inliers, double th, double ths, double *H
       u2h(L.u, sub, (int)inlLimit, h, L.buffer);
     }
   };
-  maxS = inlidxs(L.errs[4], len, th, inliers);
+  maxS = inlidxs2(L, L.errs[4], th, th, false, inliers, nullptr);
   if (maxS.I < 4) return S;
   lsq(maxS.I);
   for (int it = 0; it < 4; ++it) {
     L.ev->hds(h, d);
-    S = inlidxs(d, len, th, inliers);
-    Ss = inlidxs(d, len, ths, inliers);
+    S = inlidxs2(L, d, th, ths, true, inliers, &SsI);   // S = inlidxs(d, th); Ss = inlidxs(d, ths): the list of Ss is the one that stays
     if (score_less(maxS, S)) {
       maxS = S;
       L.errs[1] = L.errs[0];
@@ -665,12 +701,12 @@ static inline Score iterH(HLo &L, int *inliers, double th, double ths, double *H
       d = L.errs[1];
       std::memcpy(H, h, 9 * sizeof(double));
     }
-    if (Ss.I < 4) return maxS;
-    lsq(Ss.I);
+    if (SsI < 4) return maxS;
+    lsq(SsI);
     ths -= dth;
   }
   L.ev->hds(h, d);
-  S = inlidxs(d, len, th, inliers);
+  S = inlidxs2(L, d, th, th, false, inliers, nullptr);
   if (score_less(maxS, S)) {
     maxS = S;
     L.errs[1] = L.errs[0];
@@ -705,16 +741,18 @@ static inline Score inHrani(HLo &L, int *inliers, int ninl, double th, double *H
 // innerH: note that the reference passes its `iters` argument on as the inlier limit of the LSQ steps
 static inline unsigned innerH(double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl, GlibcRand &rng, double *buffer,
                               PointEval *ev = nullptr) {
-  std::vector<double> err((size_t)len * 4);
+  const size_t n_pad = ((size_t)len + SIMD_PAD - 1) / SIMD_PAD * SIMD_PAD;
+  std::vector<double> err(n_pad * 5);
   std::vector<int> inliers(len);
   PointEval host_ev(u, (int)len);
   HLo L;
   L.u = u; L.len = (int)len; L.rng = &rng; L.buffer = buffer; L.ev = ev ? ev : &host_ev;
-  for (int i = 0; i < 4; i++) L.errs[i] = err.data() + (size_t)i * len;
+  L.n_pad = (int)n_pad; L.gains = err.data() + 4 * n_pad;
+  for (int i = 0; i < 4; i++) L.errs[i] = err.data() + (size_t)i * n_pad;
   L.errs[4] = nullptr;
   double *d = L.errs[0];
   L.ev->hds(H, d);
-  Score S = inlidxs(d, (int)len, th, inliers.data());
+  Score S = inlidxs2(L, d, th, th, false, inliers.data(), nullptr);
   S = inHrani(L, inliers.data(), (int)S.I, th, H, iters);
   d = L.errs[0];
   unsigned I = 0;
@@ -732,12 +770,17 @@ static inline double rfth_prof_now() { timespec ts; clock_gettime(CLOCK_MONOTONI
 
 // ---- plane-and-parallax search ----------------------------------------------------------------------------
 // u2Fit, DegUtils.c:629-697
-static inline unsigned u2Fit(PointEval &ev, double *F, unsigned char *inl, double th, double ths, unsigned iters) {
+// prof (optional): [0] += ms inside the least-squares fits, [1] += their number
+static inline unsigned u2Fit(PointEval &ev, double *F, unsigned char *inl, double th, double ths, unsigned iters, double *prof = nullptr) {
   const double *u = ev.u;
   const unsigned len = (unsigned)ev.len;
   const double dth = (ths - th) / (iters - 1);
-  std::vector<int> inlI(len);
-  std::vector<double> Ds(len), buffer((size_t)9 * len + 96);
+  // per-thread scratch that lives across calls: these are hundreds of kilobytes, and a fresh allocation of that size is a
+  // fresh mapping whose page faults serialise the threads of ransac_pool.hpp on the process's memory map
+  static thread_local std::vector<int> inlI;
+  static thread_local std::vector<double> Ds;
+  if (inlI.size() < len) { inlI.resize(len); Ds.resize(len); }
+  double buffer[96];   // u2f's moment-matrix form needs no len x 9 matrix
   unsigned no_i;
   for (unsigned iter = 0; iter < iters; ++iter) {
     ev.fds(F, Ds.data());
@@ -750,7 +793,8 @@ static inline unsigned u2Fit(PointEval &ev, double *F, unsigned char *inl, doubl
     no_i = 0;
     for (unsigned i = 0; i < len; ++i)
       if (inl[i]) inlI[no_i++] = (int)i;
-    { const double t_ = rfth_prof_now(); u2f(u, inlI.data(), (int)no_i, F, buffer.data()); g_rfth_prof[5] += rfth_prof_now() - t_; g_rfth_prof[7] += 1; }
+    if (prof) { const double t_ = rfth_prof_now(); u2f(u, inlI.data(), (int)no_i, F, buffer); prof[0] += rfth_prof_now() - t_; prof[1] += 1; }
+    else u2f(u, inlI.data(), (int)no_i, F, buffer);
     ths -= dth;
   }
   ev.fds(F, Ds.data());
@@ -780,43 +824,116 @@ static inline void dual_sample(GlibcRand &rng, const double *uA, unsigned lenA, 
   for (unsigned i = 0; i < sB; ++i) std::memcpy(usam + 6 * (i + sA), uB + 6 * ptrB[i], 6 * sizeof(double));
 }
 
-// innerFH, DegUtils.c:476-584: F from sam_sizH on-plane + sam_sizO off-plane correspondences, repCount times
-static inline void innerFH(GlibcRand &rng, const double *uH, unsigned lenH, const double *uO, unsigned lenO, PointEval &ev,
-                           double th, unsigned repCount, unsigned sam_sizH, unsigned sam_sizO, double *F, unsigned char *inl) {
-  const unsigned len = (unsigned)ev.len;
-  const unsigned ns = sam_sizH + sam_sizO;
-  std::vector<unsigned char> v(len);
-  std::vector<double> usam((size_t)6 * ns), Ds(len), buffer((size_t)9 * ns + 96);
-  std::vector<int> allInl(ns);
-  double aF[9];
-  for (unsigned i = 0; i < ns; ++i) allInl[i] = (int)i;
-  for (int i = 0; i < 9; ++i) F[i] = 1;
-  for (unsigned i = 0; i < len; ++i) inl[i] = 0;
-  unsigned max_i = 0, max_s = 0;
-  for (unsigned rep = 0; rep < repCount; ++rep) {
-    dual_sample(rng, uH, lenH, sam_sizH, uO, lenO, sam_sizO, usam.data());
-    u2f(usam.data(), allInl.data(), (int)ns, aF, buffer.data());
-    ev.fds(aF, Ds.data());
+// innerFH, DegUtils.c:476-584: F from sam_sizH on-plane + sam_sizO off-plane correspondences, repCount times.
+// The reference's loop is  sample -> 10-point F -> count -> (if the count beats every earlier sample's count) u2Fit -> keep the
+// best.  Only the sampling touches the generator, and whether a repetition runs u2Fit depends on the COUNTS of the samples
+// alone (max_s), never on what an earlier u2Fit returned.  So a call is cut into: draw() the repCount samples in order;
+// eval(r) for every repetition, independent of each other; mark() the record-setting ones; refine(t) those, independent of
+// each other; fold() everything in repetition order with the reference's comparisons.  Same operations on the same inputs
+// as the one-thread loop, hence the same F and mask; eval / refine of one or of several calls run side by side
+// (ransac_pool.hpp).
+struct InnerFHJob {
+  struct Rep {
+    std::vector<double> usam;
+    std::vector<unsigned char> v, v2;   // mask of the sample's F, mask after u2Fit
+    double aF[9], aF2[9];
+    unsigned no_i = 0, no_2 = 0;
+    bool refine = false;
+    double prof[2] = {0, 0};
+  };
+  PointEval *ev = nullptr;
+  double th = 0;
+  unsigned ns = 0, len = 0;
+  std::vector<Rep> reps;
+  std::vector<int> todo;
+  bool want_prof = false;
+
+  void draw(GlibcRand &rng, const double *uH, unsigned lenH, const double *uO, unsigned lenO, PointEval &ev_, double th_, unsigned repCount,
+            unsigned sam_sizH, unsigned sam_sizO) {
+    ev = &ev_; th = th_; ns = sam_sizH + sam_sizO; len = (unsigned)ev_.len;
+    reps.assign(repCount, Rep());
+    for (Rep &R : reps) {
+      R.usam.resize((size_t)6 * ns);
+      dual_sample(rng, uH, lenH, sam_sizH, uO, lenO, sam_sizO, R.usam.data());
+    }
+  }
+  int n_eval() const { return (int)reps.size(); }
+  void eval(int r) {
+    Rep &R = reps[r];
+    static thread_local std::vector<double> Ds;   // (see u2Fit)
+    if (Ds.size() < len) Ds.resize(len);
+    std::vector<double> buffer((size_t)9 * ns + 96);
+    std::vector<int> allInl(ns);
+    for (unsigned i = 0; i < ns; ++i) allInl[i] = (int)i;
+    u2f(R.usam.data(), allInl.data(), (int)ns, R.aF, buffer.data());
+    ev->fds(R.aF, Ds.data());
+    R.v.resize(len);
     unsigned no_i = 0;
     for (unsigned i = 0; i < len; ++i) {
-      if (Ds[i] < th) { v[i] = 1; ++no_i; }
-      else v[i] = 0;
+      if (Ds[i] < th) { R.v[i] = 1; ++no_i; }
+      else R.v[i] = 0;
     }
-    if (max_i < no_i) {
-      std::memcpy(inl, v.data(), len);
-      std::memcpy(F, aF, sizeof(aF));
-      max_i = no_i;
-    }
-    if (no_i > max_s) {
-      max_s = no_i;
-      no_i = u2Fit(ev, aF, v.data(), th, th * 3, 4);
-      if (max_i < no_i) {
-        std::memcpy(inl, v.data(), len);
-        std::memcpy(F, aF, sizeof(aF));
-        max_i = no_i;
+    R.no_i = no_i;
+  }
+  void mark() {
+    unsigned max_s = 0;
+    todo.clear();
+    for (size_t r = 0; r < reps.size(); ++r)
+      if (reps[r].no_i > max_s) { max_s = reps[r].no_i; reps[r].refine = true; todo.push_back((int)r); }
+  }
+  int n_refine() const { return (int)todo.size(); }
+  void refine(int t) {
+    Rep &R = reps[todo[t]];
+    R.v2 = R.v;
+    std::memcpy(R.aF2, R.aF, sizeof(R.aF));
+    R.no_2 = u2Fit(*ev, R.aF2, R.v2.data(), th, th * 3, 4, want_prof ? R.prof : nullptr);
+  }
+  void fold(double *F, unsigned char *inl, double *fit_prof) const {
+    for (int i = 0; i < 9; ++i) F[i] = 1;
+    for (unsigned i = 0; i < len; ++i) inl[i] = 0;
+    unsigned max_i = 0;
+    for (const Rep &R : reps) {
+      if (max_i < R.no_i) {
+        std::memcpy(inl, R.v.data(), len);
+        std::memcpy(F, R.aF, sizeof(R.aF));
+        max_i = R.no_i;
+      }
+      if (R.refine) {
+        if (max_i < R.no_2) {
+          std::memcpy(inl, R.v2.data(), len);
+          std::memcpy(F, R.aF2, sizeof(R.aF2));
+          max_i = R.no_2;
+        }
+        if (fit_prof) { fit_prof[0] += R.prof[0]; fit_prof[1] += R.prof[1]; }
       }
     }
   }
+};
+// runs the eval and refine stages of n drawn jobs: all evaluations side by side, then all refinements side by side
+static inline void run_innerFH_jobs(InnerFHJob *const *jobs, int n, bool parallel) {
+  auto for_each = [&](int m, const std::function<void(int)> &fn) {
+    if (parallel) TaskPool::get().run(m, fn);
+    else for (int i = 0; i < m; i++) fn(i);
+  };
+  std::vector<std::pair<int, int>> work;
+  for (int j = 0; j < n; j++)
+    for (int r = 0; r < jobs[j]->n_eval(); r++) work.push_back({j, r});
+  for_each((int)work.size(), [&](int i) { jobs[work[i].first]->eval(work[i].second); });
+  work.clear();
+  for (int j = 0; j < n; j++) {
+    jobs[j]->mark();
+    for (int t = 0; t < jobs[j]->n_refine(); t++) work.push_back({j, t});
+  }
+  for_each((int)work.size(), [&](int i) { jobs[work[i].first]->refine(work[i].second); });
+}
+static inline void innerFH(GlibcRand &rng, const double *uH, unsigned lenH, const double *uO, unsigned lenO, PointEval &ev,
+                           double th, unsigned repCount, unsigned sam_sizH, unsigned sam_sizO, double *F, unsigned char *inl,
+                           double *fit_prof = nullptr) {
+  InnerFHJob job, *jp = &job;
+  job.want_prof = fit_prof != nullptr;
+  job.draw(rng, uH, lenH, uO, lenO, ev, th, repCount, sam_sizH, sam_sizO);
+  run_innerFH_jobs(&jp, 1, ev.concurrent());
+  job.fold(F, inl, fit_prof);
 }
 
 // Counts, for k candidate matrices (k x 9), the off-plane correspondences with FDs < limit.
@@ -893,62 +1010,98 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
   const unsigned BLOCK = count ? 2048 : 1;
   std::vector<double> Fs((size_t)9 * BLOCK);
   std::vector<unsigned> cnt(BLOCK);
-  unsigned no_sam = 1;
-  while (no_sam < 2 * max_sam) {
-    unsigned nb = 2 * max_sam - no_sam;
-    if (nb > BLOCK) nb = BLOCK;
-    const GlibcRand rng0 = rng;
-    const std::vector<unsigned> ptr0 = ptr;
-    const double tq0 = rfth_prof_now();
-    for (unsigned s = 0; s < nb; s++) {
-      draw(rng, ptr);
-      candidate(ptr[0], ptr[1], &Fs[9 * s]);
+  // Between two inner estimations the loop only draws and counts, and what an inner estimation hands back to it is max_sam (the
+  // budget, which can only shrink) - the generator leaves innerFH in a state that does not depend on its result (150 draws),
+  // and m_i is set from the candidate's own count.  So the search runs AHEAD of the estimations, on the budget it knows: it
+  // collects up to MAX_JOBS triggers (each with its samples drawn, i.e. with the generator advanced as innerFH advances it),
+  // their estimations run side by side, and their results are folded in trigger order.  A trigger that lies beyond the budget
+  // an earlier result has set never happened in the one-thread loop: it and everything after it are dropped, and the generator
+  // is put where that loop leaves it (the state after the last estimation that did happen + two draws per remaining sample).
+  struct LoopState { GlibcRand rng; std::vector<unsigned> ptr; unsigned no_sam, m_i; };
+  struct Trigger { unsigned no_sam_at; InnerFHJob job; LoopState after; };
+  const size_t MAX_JOBS = 8;
+  LoopState done = {rng, ptr, 1, m_i};     // the state behind the last estimation that is known to have happened
+  auto leave = [&]() {                       // the one-thread loop's exit from `done` with the current budget
+    rng = done.rng;
+    if (done.no_sam < 2 * max_sam)
+      for (unsigned s = done.no_sam; s < 2 * max_sam; s++) { (void)rng.next(); (void)rng.next(); }
+    return max_i;
+  };
+  const bool parallel = ev.concurrent();
+  while (done.no_sam < 2 * max_sam) {
+    LoopState w = done;
+    std::vector<std::unique_ptr<Trigger>> trig_list;
+    while (trig_list.size() < MAX_JOBS && w.no_sam < 2 * max_sam) {
+      unsigned nb = 2 * max_sam - w.no_sam;
+      if (nb > BLOCK) nb = BLOCK;
+      const GlibcRand rng0 = w.rng;
+      const std::vector<unsigned> ptr0 = w.ptr;
+      const double tq0 = rfth_prof_now();
+      for (unsigned s = 0; s < nb; s++) {
+        draw(w.rng, w.ptr);
+        candidate(w.ptr[0], w.ptr[1], &Fs[9 * s]);
+      }
+      const double tq1 = rfth_prof_now();
+      g_rfth_prof[0] += tq1 - tq0; g_rfth_prof[2] += 1;
+      if (count) { count(Fs.data(), (int)nb, cnt.data()); g_rfth_prof[1] += rfth_prof_now() - tq1; }
+      else {
+        FDs_all(uN.data(), Fs.data(), Ds.data(), (int)nN);
+        unsigned c = 0;
+        for (unsigned i = 0; i < nN; ++i) if (Ds[i] < th * 2) ++c;
+        cnt[0] = c;
+      }
+      unsigned trig = nb;
+      for (unsigned s = 0; s < nb; s++)
+        if (cnt[s] > w.m_i) { trig = s; break; }
+      if (trig == nb) { w.no_sam += nb; continue; }
+      // rewind to the state right after sample `trig`
+      if (trig + 1 < nb) {
+        w.rng = rng0; w.ptr = ptr0;
+        for (unsigned s = 0; s <= trig; s++) draw(w.rng, w.ptr);
+      }
+      w.no_sam += trig;          // loop variable value while sample `trig` is processed
+      double aFt[9];
+      candidate(w.ptr[0], w.ptr[1], aFt);
+      FDs_all(uN.data(), aFt, Ds.data(), (int)nN);
+      unsigned no_i = 0;
+      for (unsigned i = 0; i < nN; ++i)
+        if (Ds[i] < th * 2) { std::memcpy(&uV[6 * no_i], &uN[6 * i], 6 * sizeof(double)); ++no_i; }
+      w.m_i = no_i;
+      std::unique_ptr<Trigger> t(new Trigger());
+      t->no_sam_at = w.no_sam;
+      t->job.want_prof = true;
+      t->job.draw(w.rng, uH.data(), nH, uV.data(), no_i, ev, th, 15, sam_sizH, sam_sizO);
+      w.no_sam += 1;             // ++no_sam of the for statement
+      t->after = w;
+      trig_list.push_back(std::move(t));
     }
-    const double tq1 = rfth_prof_now();
-    g_rfth_prof[0] += tq1 - tq0; g_rfth_prof[2] += 1;
-    if (count) { count(Fs.data(), (int)nb, cnt.data()); g_rfth_prof[1] += rfth_prof_now() - tq1; }
-    else {
-      FDs_all(uN.data(), Fs.data(), Ds.data(), (int)nN);
-      unsigned c = 0;
-      for (unsigned i = 0; i < nN; ++i) if (Ds[i] < th * 2) ++c;
-      cnt[0] = c;
+    if (trig_list.empty()) return leave();     // the budget ran out without another trigger
+    {
+      const double t_ = rfth_prof_now();
+      std::vector<InnerFHJob *> jobs;
+      for (auto &t : trig_list) jobs.push_back(&t->job);
+      run_innerFH_jobs(jobs.data(), (int)jobs.size(), parallel);
+      g_rfth_prof[4] += rfth_prof_now() - t_;
     }
-    unsigned trig = nb;
-    for (unsigned s = 0; s < nb; s++)
-      if (cnt[s] > m_i) { trig = s; break; }
-    if (trig == nb) { no_sam += nb; continue; }
-    // rewind to the state right after sample `trig`
-    if (trig + 1 < nb) {
-      rng = rng0; ptr = ptr0;
-      for (unsigned s = 0; s <= trig; s++) draw(rng, ptr);
+    for (auto &t : trig_list) {
+      if (!(t->no_sam_at < 2 * max_sam)) return leave();   // an earlier result had ended the loop before this sample
+      double aF[9], fp[2] = {0, 0};
+      t->job.fold(aF, inl.data(), fp);
+      g_rfth_prof[6] += 1; g_rfth_prof[5] += fp[0]; g_rfth_prof[7] += fp[1];
+      unsigned ninl = 0;
+      for (unsigned i = 0; i < len; ++i) if (inl[i]) ++ninl;
+      if (ninl > max_i) {
+        max_i = ninl;
+        std::memcpy(F, aF, sizeof(aF));
+        unsigned maxni = 0;
+        for (unsigned i = 0; i < len; ++i) if (inl[i] && nhinl[i]) ++maxni;
+        const unsigned ns = (unsigned)nsamples((int)maxni, (int)nN, 2, conf);
+        max_sam = max_sam > ns ? ns : max_sam;
+      }
+      done = std::move(t->after);
     }
-    no_sam += trig;          // loop variable value while sample `trig` is processed
-    double aFt[9], aF[9];
-    candidate(ptr[0], ptr[1], aFt);
-    FDs_all(uN.data(), aFt, Ds.data(), (int)nN);
-    unsigned no_i = 0;
-    for (unsigned i = 0; i < nN; ++i) {
-      if (Ds[i] < th * 2) { ++no_i; v[i] = 1; }
-      else v[i] = 0;
-    }
-    no_i = 0;
-    for (unsigned i = 0; i < nN; ++i)
-      if (v[i]) { std::memcpy(&uV[6 * no_i], &uN[6 * i], 6 * sizeof(double)); ++no_i; }
-    m_i = no_i;
-    { const double t_ = rfth_prof_now(); innerFH(rng, uH.data(), nH, uV.data(), no_i, ev, th, 15, sam_sizH, sam_sizO, aF, inl.data()); g_rfth_prof[4] += rfth_prof_now() - t_; g_rfth_prof[6] += 1; }
-    unsigned ninl = 0;
-    for (unsigned i = 0; i < len; ++i) if (inl[i]) ++ninl;
-    if (ninl > max_i) {
-      max_i = ninl;
-      std::memcpy(F, aF, sizeof(aF));
-      unsigned maxni = 0;
-      for (unsigned i = 0; i < len; ++i) if (inl[i] && nhinl[i]) ++maxni;
-      const unsigned ns = (unsigned)nsamples((int)maxni, (int)nN, 2, conf);
-      max_sam = max_sam > ns ? ns : max_sam;
-    }
-    no_sam += 1;             // ++no_sam of the for statement
   }
-  return max_i;
+  return leave();
 }
 
 }  // namespace rs

@@ -29,6 +29,7 @@ def libs(pkg):
     R.rroots3.restype = C.c_int
     R.innerH.restype = C.c_uint
     R.rFtH.restype = C.c_uint
+    M.mods_test_rfth2.restype = C.c_uint
     M.mods_test_inner_h.restype = C.c_uint
     M.mods_test_rfth.restype = C.c_uint
     return R, M
@@ -97,9 +98,11 @@ def test_homography_lo_and_plane_parallax(libs):
     R, M = libs
     libc = C.CDLL(None)
     th = 4.0
-    for seed in range(6):
-        n = 300 + 60 * seed
-        u, _, pl = fsynth.two_view(n, 0.7, 0.7, 0.5, seed=seed)
+    # seeds 0-5: the mixed scene; 6-11: larger lists whose plane holds 50 % ... 97 % of the inliers (few off-plane points: the
+    # search spends its whole budget; many: the first estimations cut the budget and later triggers never happen)
+    cases = [(seed, 300 + 60 * seed, 0.7) for seed in range(6)] + [(6 + k, 1500 + 200 * k, pr) for k, pr in enumerate((0.5, 0.5, 0.9, 0.9, 0.97, 0.97))]
+    for seed, n, plane_ratio in cases:
+        u, _, pl = fsynth.two_view(n, 0.7, plane_ratio, 0.5, seed=seed)
         idx = np.where(pl)[0][:12]
         A = []
         for i in idx:
@@ -123,6 +126,13 @@ def test_homography_lo_and_plane_parallax(libs):
         Fr, Fm = np.zeros(9), np.zeros(9)
         libc.srand(2000 + seed)
         Jr = R.rFtH(P(u), P(inl_r), C.c_double(th), P(Hr), n, P(Fr), P(bufP), P(buf))
+        next_r = libc.rand()       # where the reference's generator stands after the search
         Jm = M.mods_test_rfth(2000 + seed, P(u), P(inl_r), C.c_double(th), P(Hr), n, P(Fm))
         assert Jr == Jm and Jr > 50
         assert np.max(np.abs(_normed(Fr) - _normed(Fm))) < 1e-9
+        # the production form: host SIMD evaluation, inner estimations of several triggers side by side on the pool's threads
+        # (ransac_pool.hpp) - the same F to the bit as the scalar one-evaluation-at-a-time form, and the same generator state
+        Fs, next_m = np.zeros(9), C.c_int(0)
+        Js = M.mods_test_rfth2(2000 + seed, P(u), P(inl_r), C.c_double(th), P(Hr), n, P(Fs), 1, C.byref(next_m), None)
+        assert Js == Jr and np.array_equal(Fs.view(np.uint64), Fm.view(np.uint64))
+        assert next_m.value == next_r
