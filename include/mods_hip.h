@@ -364,10 +364,17 @@ void mods_test_u2f_form(const double *u, const int *idx, int n, const double *w,
 int mods_test_checksample(const double *F, const double *u7, double th, double *H);
 unsigned mods_test_inner_h(unsigned seed, double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl);
 unsigned mods_test_rfth(unsigned seed, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F);
+/* Host threads the degenerate branch of DEGENSAC spreads its independent pieces over (csrc/ransac_pool.hpp): MODS_RANSAC_THREADS, by
+ * default the cores this process may use, at most 8; 1 = the one-thread loops.  Results do not depend on it. */
+int mods_ransac_host_threads(void);
+/* innerH through the host SIMD evaluation of the production path (simd = 0: scalar); *next_rand = the generator's next value after
+ * the call; *path = 0 one-thread loop, 1 repetitions side by side on the pool's threads, 2 side by side, then redone by the loop */
+unsigned mods_test_inner_h2(unsigned seed, double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl, int simd,
+                            int *next_rand, int *path);
 /* the same through the host SIMD evaluation of the production path (simd = 0: scalar); *next_rand = the generator's next value
- * after the call, prof8 (optional) = the call's timing breakdown (ransac_f_host.hpp: g_rfth_prof) */
+ * after the call, prof10 (optional) = the call's breakdown (10 doubles, ransac_f_host.hpp: g_rfth_prof) */
 unsigned mods_test_rfth2(unsigned seed, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F,
-                         int simd, int *next_rand, double *prof8);
+                         int simd, int *next_rand, double *prof10);
 
 /* ---- whole hot path for one image pair ---------------------------------------------------------
  * The step loop body of mods.cpp:202-383 for one step of HessianAffine + RootSIFT on identity views:

@@ -290,21 +290,35 @@ unsigned mods_test_inner_h(unsigned seed, double *H, const double *u, unsigned l
   std::vector<double> buffer((size_t)18 * len + 96);
   return rs::innerH(H, u, len, th, iters, inl, g, buffer.data());
 }
+int mods_ransac_host_threads(void) { return rs::TaskPool::get().threads(); }
+// the same through the host SIMD evaluation of the production path (simd = 0: scalar); *next_rand = the generator's next value
+// after the call; *path = 0 one-thread loop, 1 repetitions side by side, 2 side by side and redone by the one-thread loop
+unsigned mods_test_inner_h2(unsigned seed, double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl, int simd,
+                            int *next_rand, int *path) {
+  rs::GlibcRand g;
+  g.seed(seed);
+  std::vector<double> buffer((size_t)18 * len + 96);
+  SimdEval sev(u, (int)len);
+  const unsigned I = rs::innerH(H, u, len, th, iters, inl, g, buffer.data(), simd ? &sev : nullptr);
+  if (next_rand) *next_rand = g.next();
+  if (path) *path = rs::g_innerh_path;
+  return I;
+}
 unsigned mods_test_rfth(unsigned seed, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F) {
   rs::GlibcRand g;
   g.seed(seed);
   return rs::rFtH(g, u, hinl, th, H, len, F, nullptr, rs::PairCounter());
 }
 // the same with the host SIMD evaluation of the production path (0: the scalar PointEval) and the generator's next value
-// after the call (what the rest of exp_ransacFcustom would draw next); prof8 (optional) receives and clears g_rfth_prof
+// after the call (what the rest of exp_ransacFcustom would draw next); prof10 (optional) receives and clears g_rfth_prof
 unsigned mods_test_rfth2(unsigned seed, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F,
-                         int simd, int *next_rand, double *prof8) {
+                         int simd, int *next_rand, double *prof10) {
   rs::GlibcRand g;
   g.seed(seed);
   SimdEval sev(u, (int)len);
   const unsigned I = rs::rFtH(g, u, hinl, th, H, len, F, nullptr, rs::PairCounter(), simd ? &sev : nullptr);
   if (next_rand) *next_rand = g.next();
-  if (prof8) for (int i = 0; i < 8; i++) { prof8[i] = rs::g_rfth_prof[i]; rs::g_rfth_prof[i] = 0; }
+  if (prof10) for (int i = 0; i < 10; i++) { prof10[i] = rs::g_rfth_prof[i]; rs::g_rfth_prof[i] = 0; }
   return I;
 }
 
@@ -731,7 +745,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
   }
   data_out[0] = no_sam;
   data_out[1] = iter_cnt;
-  if (prof) { fprintf(stderr, "[mods ransacF] rFtH: candidates %.2f ms, counting %.2f ms, %.0f blocks, %.0f off-plane; innerFH %.0f calls %.2f ms, of which %.0f fits in u2Fit %.2f ms\n", rs::g_rfth_prof[0], rs::g_rfth_prof[1], rs::g_rfth_prof[2], rs::g_rfth_prof[3], rs::g_rfth_prof[6], rs::g_rfth_prof[4], rs::g_rfth_prof[7], rs::g_rfth_prof[5]); for (double &x : rs::g_rfth_prof) x = 0; }
+  if (prof) { fprintf(stderr, "[mods ransacF] rFtH: candidates %.2f ms, counting %.2f ms, %.0f blocks, %.0f off-plane; innerFH %.0f calls (+%.0f run ahead and dropped) in %.0f rounds %.2f ms on %d threads, %.0f fits in u2Fit %.2f thread-ms\n", rs::g_rfth_prof[0], rs::g_rfth_prof[1], rs::g_rfth_prof[2], rs::g_rfth_prof[3], rs::g_rfth_prof[6], rs::g_rfth_prof[8], rs::g_rfth_prof[9], rs::g_rfth_prof[4], rs::TaskPool::get().threads(), rs::g_rfth_prof[7], rs::g_rfth_prof[5]); for (double &x : rs::g_rfth_prof) x = 0; }
   if (prof) fprintf(stderr, "[mods ransacF] len %d samples %d lo %d degen %d | total %.2f ms: innerH %.2f rFtH %.2f LO %.2f\n", len, no_sam, iter_cnt,
                     degen_cnt, wall_ms() - t_begin, t_innerh, t_rfth, t_lo);
   if (Ih) *Ih = Ihmax;

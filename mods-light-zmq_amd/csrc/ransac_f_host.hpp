@@ -738,23 +738,93 @@ static inline Score inHrani(HLo &L, int *inliers, int ninl, double th, double *H
   d = L.errs[2]; L.errs[2] = L.errs[0]; L.errs[0] = d;
   return maxS;
 }
-// innerH: note that the reference passes its `iters` argument on as the inlier limit of the LSQ steps
+// innerH: note that the reference passes its `iters` argument on as the inlier limit of the LSQ steps.
+// The ten repetitions of inHrani are independent but for two things they hand on: the generator (a repetition draws its
+// 12-sample and then inlLimit numbers per least-squares step of iterH) and the order of the sampling pool, which the draws
+// permute.  Neither depends on what a repetition computes as long as iterH takes all five of its least-squares steps on more
+// than inlLimit inliers - the normal course.  So the samples of all repetitions are drawn first with the generator stepped
+// over the draws iterH is expected to make, the repetitions run side by side (ransac_pool.hpp) on their own error buffers,
+// and each checks that its generator ended where the next one was started from; if one did not (an early return inside
+// iterH), the whole call is redone by the one-thread loop.  The results are folded in repetition order.
+static thread_local int g_innerh_path = 0;   // how the last innerH of this thread ran: 0 one-thread loop, 1 side by side, 2 side by side, then redone
 static inline unsigned innerH(double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl, GlibcRand &rng, double *buffer,
                               PointEval *ev = nullptr) {
+  const int REPS = 10;
+  g_innerh_path = 0;
   const size_t n_pad = ((size_t)len + SIMD_PAD - 1) / SIMD_PAD * SIMD_PAD;
-  std::vector<double> err(n_pad * 5);
-  std::vector<int> inliers(len);
   PointEval host_ev(u, (int)len);
   HLo L;
   L.u = u; L.len = (int)len; L.rng = &rng; L.buffer = buffer; L.ev = ev ? ev : &host_ev;
-  L.n_pad = (int)n_pad; L.gains = err.data() + 4 * n_pad;
-  for (int i = 0; i < 4; i++) L.errs[i] = err.data() + (size_t)i * n_pad;
+  const bool par = L.ev->concurrent() && TaskPool::get().threads() > 1;
+  // scratch that lives across calls (see u2Fit): 5 buffers for the one-thread form + 3 per repetition, the index lists
+  static thread_local std::vector<double> err;
+  static thread_local std::vector<int> idx;
+  const size_t need = n_pad * (5 + (par ? 3 * REPS : 0));
+  if (err.size() < need) err.resize(need);
+  if (idx.size() < (size_t)len * (2 + (par ? REPS : 0))) idx.resize((size_t)len * (2 + (par ? REPS : 0)));
+  for (size_t i = len; i < n_pad; i++)
+    for (size_t k = 0; k < need / n_pad; k++) err[k * n_pad + i] = 0;   // the tail the lanes-wide gain pass reads
+  double *const err_base = err.data();   // (a lambda that runs on a pool thread would see THAT thread's err / idx)
+  int *const idx_base = idx.data();
+  int *inliers = idx_base;
+  L.n_pad = (int)n_pad; L.gains = err_base + 4 * n_pad;
+  for (int i = 0; i < 4; i++) L.errs[i] = err_base + (size_t)i * n_pad;
   L.errs[4] = nullptr;
   double *d = L.errs[0];
   L.ev->hds(H, d);
-  Score S = inlidxs2(L, d, th, th, false, inliers.data(), nullptr);
-  S = inHrani(L, inliers.data(), (int)S.I, th, H, iters);
-  d = L.errs[0];
+  Score S = inlidxs2(L, d, th, th, false, inliers, nullptr);
+  const int ninl = (int)S.I;
+  bool done = false;
+  if (par && ninl >= 8) {
+    struct Rep { GlibcRand rng, rng_end; int sample[12]; double h[9]; Score S; double *best; };
+    Rep reps[REPS];
+    const GlibcRand rng0 = rng;
+    int *pool0 = idx_base + len;
+    std::memcpy(pool0, inliers, sizeof(int) * ninl);
+    int ssiz = ninl / 2;
+    if (ssiz > 12) ssiz = 12;
+    for (int r = 0; r < REPS; r++) {
+      const int *sample = randsubset(rng, inliers, ninl, ssiz);
+      std::memcpy(reps[r].sample, sample, sizeof(int) * ssiz);
+      reps[r].rng = rng;
+      for (unsigned k = 0; k < 5 * iters; k++) (void)rng.next();   // five randsubset(.., inlLimit) of iterH
+      reps[r].rng_end = rng;
+    }
+    TaskPool::get().run(REPS, [&](int r) {
+      Rep &R = reps[r];
+      HLo T = L;
+      double *base = err_base + (5 + 3 * (size_t)r) * n_pad;
+      T.errs[0] = base; T.errs[1] = base + n_pad; T.errs[2] = T.errs[3] = nullptr; T.gains = base + 2 * n_pad;
+      T.rng = &R.rng;
+      double small[96];
+      T.buffer = small;
+      u2h(T.u, R.sample, ssiz, R.h, small);
+      T.ev->hds(R.h, T.errs[0]);
+      T.errs[4] = T.errs[0];
+      R.S = iterH(T, idx_base + (size_t)len * (2 + r), th, 4 * th, R.h, iters);
+      R.best = T.errs[0];
+    });
+    done = true;
+    for (int r = 0; r < REPS; r++)
+      if (std::memcmp(&reps[r].rng, &reps[r].rng_end, sizeof(GlibcRand)) != 0) done = false;
+    g_innerh_path = done ? 1 : 2;
+    if (done) {
+      Score maxS = {0, 0};
+      for (int r = 0; r < REPS; r++)
+        if (score_less(maxS, reps[r].S)) {
+          maxS = reps[r].S;
+          d = reps[r].best;
+          std::memcpy(H, reps[r].h, 9 * sizeof(double));
+        }
+    } else {
+      rng = rng0;
+      std::memcpy(inliers, pool0, sizeof(int) * ninl);
+    }
+  }
+  if (!done) {
+    inHrani(L, inliers, ninl, th, H, iters);
+    d = L.errs[0];
+  }
   unsigned I = 0;
   for (unsigned j = 0; j < len; j++) {
     if (d[j] <= th) { ++I; inl[j] = 1; }
@@ -764,8 +834,9 @@ static inline unsigned innerH(double *H, const double *u, unsigned len, double t
 }
 
 // development aid (MODS_RANSAC_PROFILE): [0] rFtH candidate loops ms, [1] counting calls ms, [2] blocks, [3] off-plane points,
-// [4] innerFH ms, [5] least-squares fits inside u2Fit ms, [6] innerFH calls, [7] u2Fit fits
-static thread_local double g_rfth_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// [4] innerFH ms, [5] least-squares fits inside u2Fit ms, [6] innerFH calls, [7] u2Fit fits, [8] inner estimations that were run
+// ahead and dropped (their trigger lay beyond the budget an earlier one set), [9] rounds of triggers
+static thread_local double g_rfth_prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static inline double rfth_prof_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 // ---- plane-and-parallax search ----------------------------------------------------------------------------
@@ -1083,8 +1154,10 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
       run_innerFH_jobs(jobs.data(), (int)jobs.size(), parallel);
       g_rfth_prof[4] += rfth_prof_now() - t_;
     }
-    for (auto &t : trig_list) {
-      if (!(t->no_sam_at < 2 * max_sam)) return leave();   // an earlier result had ended the loop before this sample
+    g_rfth_prof[9] += 1;
+    for (size_t ti = 0; ti < trig_list.size(); ti++) {
+      auto &t = trig_list[ti];
+      if (!(t->no_sam_at < 2 * max_sam)) { g_rfth_prof[8] += (double)(trig_list.size() - ti); return leave(); }   // an earlier result had ended the loop before this sample
       double aF[9], fp[2] = {0, 0};
       t->job.fold(aF, inl.data(), fp);
       g_rfth_prof[6] += 1; g_rfth_prof[5] += fp[0]; g_rfth_prof[7] += fp[1];
