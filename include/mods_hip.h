@@ -59,16 +59,27 @@ typedef struct mods_hessaff_params {
   int sampleFromImage;         /* AffineShapeParams::sampleFromImage (affine.h:47, io_mods.cpp:184): findAffineShape samples the input
                                 * image at pixel distance 1 instead of the blur level below the detection level
                                 * (scale-space-detector.hpp:47-55); dense (stride == w) input only */
+  /* detectorType = MODS_DET_MSER: the [MSER] section (io_mods.cpp:101-123) = extrema::ExtremaParams
+   * (detectors/mser/extrema/extremaParams.h:56-89); mode, relativeThreshold, regionsNumber, relativeRegionsNumber above are
+   * shared (regionsNumber of a view is scaled by 2 * zoom / tilt, extrema.cpp:201-202), everything else above is unused.
+   * Replaces DetectMSERs (detectors/mser/extrema/extrema.cpp:196-295) behind DetectAffineRegions<> (imagerepresentation.cpp:780-783):
+   * MSER+ regions first (sub_type 21), then MSER- (20), response = the stability margin; in every mode but FixedTh the margin
+   * bound is 1 and the list is sorted by margin and cut (prepareKeysForExport, extrema.cpp:31-90). */
+  double mserMaxArea;          /* max_area = 0.01 (0.05 in config_affori_classic.ini): largest region as a fraction of the image */
+  double mserMinMargin;        /* min_margin = 10 (8 in the shipped .ini): the stability bound of FixedTh */
+  int mserMinSize;             /* min_size = 30 pixels */
+  int pad_;
 } mods_hessaff_params;
 enum { MODS_DET_FIXED_TH = 0, MODS_DET_RELATIVE_TH, MODS_DET_FIXED_REG_NUMBER, MODS_DET_RELATIVE_REG_NUMBER,
        MODS_DET_NOT_LESS_THAN_REGIONS };   /* detection_mode_t, detectors/structures.hpp:10-14 */
-enum { MODS_DET_HESSIAN = 0, MODS_DET_DOG = 1, MODS_DET_HARRIS = 2 };   /* detector_type, detectors/structures.hpp:16-18 */
+enum { MODS_DET_HESSIAN = 0, MODS_DET_DOG = 1, MODS_DET_HARRIS = 2, MODS_DET_MSER = 3 };   /* detector_type, detectors/structures.hpp:16-19 */
 
 /* AffineKeypoint (detectors/structures.hpp:185-195) + provenance of the pyramid hit. */
 typedef struct mods_affkey {
   double x, y, s, a11, a12, a21, a22, response;
-  int sub_type;                /* Hessian: 0 dark, 1 bright, 2 saddle; DoG: 10 dark, 11 bright; Harris: 30 dark, 31 bright (pyramid.h:33-40) */
-  int octave, level, r0, c0;   /* NMS cell that produced the point */
+  int sub_type;                /* Hessian: 0 dark, 1 bright, 2 saddle; DoG: 10 dark, 11 bright; Harris: 30 dark, 31 bright (pyramid.h:33-40);
+                                * MSER: 21 MSER+, 20 MSER- (extrema.cpp:261, 286) */
+  int octave, level, r0, c0;   /* NMS cell that produced the point (MSER: threshold, polarity, seed row, seed column) */
   int pad;
 } mods_affkey;
 
@@ -364,6 +375,13 @@ void mods_test_u2f_form(const double *u, const int *idx, int n, const double *w,
 int mods_test_checksample(const double *F, const double *u7, double th, double *H);
 unsigned mods_test_inner_h(unsigned seed, double *H, const double *u, unsigned len, double th, unsigned iters, unsigned char *inl);
 unsigned mods_test_rfth(unsigned seed, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F);
+/* self-test hook of the host half of the MSER detector (csrc/mser_host.hpp; no device needed): the grey-level growth of one
+ * polarity (invert = 1: MSER-) of a w x h 8-bit image - GetExtrema + FastSetOptThresholds4StableRegion (getExtrema.cpp:385-437,
+ * optThresh.cpp:73-165).  out5: rows seed_x, seed_y, threshold, margin, area in output order; tree_out (optional): 3 ints per
+ * pixel of the (w + 2) x (h + 2) frame = the merge tree the kernels walk (slot at entry, parent slot or 0x7fffffff, merge level).
+ * Returns the number of stable thresholds. */
+int mods_test_mser_grow(const unsigned char *img8, int w, int h, int min_size, double max_area, double min_margin, int invert,
+                        int *out5, int max_out, int *tree_out);
 /* Host threads the degenerate branch of DEGENSAC spreads its independent pieces over (csrc/ransac_pool.hpp): MODS_RANSAC_THREADS, by
  * default the cores this process may use, at most 8; 1 = the one-thread loops.  Results do not depend on it. */
 int mods_ransac_host_threads(void);

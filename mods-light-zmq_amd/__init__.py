@@ -31,7 +31,15 @@ class HessAffParams(C.Structure):
                 ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int),
                 ("mode", C.c_int), ("relativeThreshold", C.c_float), ("regionsNumber", C.c_int),
                 ("relativeRegionsNumber", C.c_float), ("detectorType", C.c_int), ("iiDoGMode", C.c_int),
-                ("sampleFromImage", C.c_int)]
+                ("sampleFromImage", C.c_int),
+                ("mserMaxArea", C.c_double), ("mserMinMargin", C.c_double), ("mserMinSize", C.c_int), ("pad_", C.c_int)]
+
+    @staticmethod
+    def mser(mode=0, min_margin=8, max_area=0.05, min_size=30, reg_number=500, rel_threshold=-1.0, rel_reg_number=-1.0):
+        """[MSER] of build/config_affori_classic.ini (DetectorType = DET_MSER, detectors/structures.hpp:19; io_mods.cpp:101-123)."""
+        p = HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1, mode, rel_threshold, reg_number, rel_reg_number, 3, 0, 0)
+        p.mserMaxArea, p.mserMinMargin, p.mserMinSize = max_area, min_margin, min_size
+        return p
 
     @staticmethod
     def default():

@@ -14,8 +14,8 @@
 //   outputs            matchings "x1 y1 x2 y2" (matching.cpp:2596-2613), log line (io_mods.cpp:10-66),
 //                      keypoint files (imagerepresentation.cpp:198-204, 1219-1255), H/F file (matching.cpp:2681-2686),
 //                      time.log (io_mods.cpp:67-99, mods.cpp:528-540); exit code 0 / 1
-// Not built (outside the hot path): MSER/DoG/Harris/ORB steps of an iterations file are skipped with a
-// warning, match images (out1/out2) are not drawn, ground-truth verification is refused.  Pre-extracted input
+// Detectors: HessianAffine, DoG, HarrisAffine (one scale-space detector, three responses) and MSER; ORB / FAST / ... steps of an
+// iterations file are skipped with a warning, match images (out1/out2) are not drawn.  Pre-extracted input
 // (read_pre_extracted = 1) is read from .npz or text keypoint files.  The vector matcher is always the exact (linear) search;
 // external (ZMQ) descriptor / AffNet / OriNet daemons are used when the configuration asks for them.
 #include "../../include/mods_hip.h"
@@ -107,6 +107,23 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
            : MODS_DET_FIXED_TH;
     return d;
   };
+  // [MSER], GetMSERPars (io_mods.cpp:101-123); defaults = extrema::ExtremaParams (detectors/mser/extrema/extremaParams.h:72-88)
+  auto read_mser = [&]() {
+    mods_hessaff_params d;
+    memset(&d, 0, sizeof(d));
+    d.detectorType = MODS_DET_MSER;
+    d.relativeThreshold = (float)ini.GetDouble("MSER", "relativeThreshold", -1.0);
+    d.relativeRegionsNumber = (float)ini.GetDouble("MSER", "relativeRegionsNumber", -1.0);
+    d.regionsNumber = (int)ini.GetInteger("MSER", "regionsNumber", -1);
+    d.mserMaxArea = ini.GetDouble("MSER", "max_area", 0.01);
+    d.mserMinSize = (int)ini.GetInteger("MSER", "min_size", 30);
+    d.mserMinMargin = (double)ini.GetInteger("MSER", "min_margin", 10);     // read as an integer (io_mods.cpp:108)
+    const std::string mode = ini.GetStringVector("MSER", "mode")[0];
+    d.mode = mode == "RelativeTh" ? MODS_DET_RELATIVE_TH : mode == "FixedRegNumber" ? MODS_DET_FIXED_REG_NUMBER
+           : mode == "NotLessThanRegions" ? MODS_DET_NOT_LESS_THAN_REGIONS : mode == "RelativeRegNumber" ? MODS_DET_RELATIVE_REG_NUMBER
+           : MODS_DET_FIXED_TH;
+    return d;
+  };
   p.det = read_det("HessianAffine", MODS_DET_HESSIAN);
   if (ini.GetInteger("HessianAffine", "affBmbrgMethod", 0) != 0) std::cerr << "Warning: affBmbrgMethod != 0 (Hessian Baumberg) is not supported, SMM is used" << std::endl;
   // [DominantOrientation] :731-740 and [SIFTDescriptor] :423-436
@@ -175,10 +192,12 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
   // iterations file :457-492
   cfg->max_steps = (int)it.GetInteger("Iterations", "Steps", 4);
   cfg->min_matches = (int)it.GetInteger("Iterations", "minMatches", 15);
-  static const char *other_detectors[] = {"MSER", "ORB", "FAST", "ReadAffs", "STAR", "BRISK", "SURF", "SIFT", "TILDE", "FOCI"};
-  // the three scale-space detectors of this build, in name order (the order of the reference's region / correspondence maps)
-  static const struct { const char *name; int type; } ss_detectors[] = {{"DoG", MODS_DET_DOG}, {"HarrisAffine", MODS_DET_HARRIS}, {"HessianAffine", MODS_DET_HESSIAN}};
-  std::vector<mods_ladder_step> all[3];
+  static const char *other_detectors[] = {"ORB", "FAST", "ReadAffs", "STAR", "BRISK", "SURF", "SIFT", "TILDE", "FOCI"};
+  // the detectors of this build, in name order (the order of the reference's region / correspondence maps)
+  static const struct { const char *name; int type; } ss_detectors[] = {{"DoG", MODS_DET_DOG}, {"HarrisAffine", MODS_DET_HARRIS}, {"HessianAffine", MODS_DET_HESSIAN},
+                                                                        {"MSER", MODS_DET_MSER}};
+  const int kDets = 4;
+  std::vector<mods_ladder_step> all[4];
   for (int i = 0; i < cfg->max_steps; i++) {
     for (const char *od : other_detectors)
       if (it.Has(od + std::to_string(i), "TiltSet") || it.Has(od + std::to_string(i), "ScaleSet"))
@@ -194,7 +213,7 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
         name.erase(name.find_last_not_of(" \t") + 1);
         sep_det.push_back(name);
       }
-  for (int di = 0; di < 3; di++) {
+  for (int di = 0; di < kDets; di++) {
     const std::string det_name = ss_detectors[di].name;
     const std::string sec = det_name + std::to_string(i);
     mods_ladder_step st;
@@ -269,16 +288,16 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
     all[di].push_back(st);
   }
   }
-  for (int di = 0; di < 3; di++) {
+  for (int di = 0; di < kDets; di++) {
     bool any = false;
     for (const mods_ladder_step &st : all[di]) any = any || st.n_tilts >= 0;
     if (!any) continue;
     cfg->det_names.push_back(ss_detectors[di].name);
-    cfg->det_params.push_back(di == 2 ? p.det : read_det(ss_detectors[di].name, ss_detectors[di].type));
+    cfg->det_params.push_back(di == 2 ? p.det : ss_detectors[di].type == MODS_DET_MSER ? read_mser() : read_det(ss_detectors[di].name, ss_detectors[di].type));
   }
   const int n_det = (int)cfg->det_names.size();
   for (int i = 0; i < cfg->max_steps; i++)
-    for (int di = 0, d = 0; di < 3; di++) {
+    for (int di = 0, d = 0; di < kDets; di++) {
       if (d < n_det && cfg->det_names[d] == ss_detectors[di].name) { cfg->steps.push_back(all[di][i]); d++; }
     }
   // grouped matching: thresholds are the [Matching]-wide ones (io_mods.cpp:448-452), the detector order is the order named
@@ -544,7 +563,7 @@ int main(int argc, char **argv) {
   const double diag = std::ceil(std::max(std::hypot((double)img1.w, (double)img1.h), std::hypot((double)img2.w, (double)img2.h))) + 2;
   mods_ctx *ctx = nullptr;
   const int n_det = (int)cfg.det_names.size();
-  if (n_det == 0) { std::cerr << "The iterations file has no HessianAffine / DoG / HarrisAffine step with RootSIFT; nothing to do" << std::endl; return 1; }
+  if (n_det == 0) { std::cerr << "The iterations file has no HessianAffine / DoG / HarrisAffine / MSER step with RootSIFT; nothing to do" << std::endl; return 1; }
   const bool hessian_only = n_det == 1 && cfg.det_names[0] == "HessianAffine" && cfg.groups.empty();
   std::vector<mods_imgrep *> reps1((size_t)n_det, nullptr), reps2((size_t)n_det, nullptr);
   void *d1 = nullptr, *d2 = nullptr;

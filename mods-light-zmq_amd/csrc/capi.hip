@@ -124,6 +124,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
   (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipHostFree(c->m_count); (void)hipFree(c->m_regs);
+  mser_release(c);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -173,9 +174,7 @@ static int detect_common(mods_ctx *c, const float *img_dev, int n_img, int w, in
   if (stride < w) { set_error("detect: stride %d < width %d", stride, w); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   int rc;
-  if ((rc = pyramid_configure(c, w, h, n_img, par))) return rc;
-  if ((rc = pyramid_build(c, img_dev, stride))) return rc;
-  if ((rc = detect_run(c))) return rc;
+  if ((rc = detect_any(c, img_dev, n_img, w, h, stride, par, 1.0, 1.0))) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
   for (int b = 0; b < n_img; b++) {
@@ -263,9 +262,7 @@ int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w
   if (stride < w) { set_error("detect_describe: stride %d < width %d", stride, w); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   int rc;
-  if ((rc = pyramid_configure(c, w, h, n_img, det))) return rc;
-  if ((rc = pyramid_build(c, img_dev, stride))) return rc;
-  if ((rc = detect_run(c))) return rc;
+  if ((rc = detect_any(c, img_dev, n_img, w, h, stride, det, 1.0, 1.0))) return rc;
   const float *planes = img_dev;
   if (stride != w) planes = c->tmp_dev;   // pyramid_build repacked the batch there
   if ((rc = describe_run(c, planes, n_img, w, h, desc))) return rc;

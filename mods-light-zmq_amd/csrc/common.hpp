@@ -153,6 +153,7 @@ struct mods_ctx {
   std::vector<mods_tentative> h_tent;  // host copies for the sequential stages
   std::vector<double> h_u6, h_laf;
   std::vector<unsigned char> h_mask;
+  void *mser = nullptr;              // MserState (mser.hip): buffers of the MSER detector, allocated on first use
   // timing
   int timing_mask = 0;
   mods::StageTimer timers[MODS_STAGE_COUNT];
@@ -180,6 +181,11 @@ void circular_gauss_mask_host(int size, float sigma, float *out);
 
 // detect.hip
 int detect_run(mods_ctx *ctx);       // NMS -> localise -> dedup -> Baumberg -> sort, for the configured batch
+
+// mser.hip
+int detect_any(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, int stride, const mods_hessaff_params *par, double tilt,
+               double zoom);         // the detector the parameter set names: scale space (pyramid + detect_run) or MSER
+void mser_release(mods_ctx *ctx);
 
 // match.hip
 int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double ratio,

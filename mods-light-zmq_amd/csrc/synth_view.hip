@@ -65,7 +65,7 @@ __device__ __forceinline__ int reflect101_dev(int p, int len) {
   return p;
 }
 
-struct SmallTaps { float k[32]; int n; };   // n <= 31 taps
+struct SmallTaps { float k[128]; int n; };   // n <= 127 taps (tilt 6 at zoom 0.25 with initSigma 0.8, [MSER1] of iters_MODS.ini: 59)
 
 // Row pass of cv::GaussianBlur with BORDER_REFLECT_101: n <= 5 -> symmetric small filter order
 // (centre, then pairs outwards); larger -> generic left-to-right order.  Fused multiply-adds as an FMA build of OpenCV
@@ -128,7 +128,7 @@ int launch_warp_affine(mods_ctx *c, const float *src, int sw, int sh, int sstrid
 }
 
 int launch_blur_xy_reflect(mods_ctx *c, const float *src, float *tmp, float *dst, int w, int h, int kx, int ky, double sx, double sy) {
-  if (kx > 31 || ky > 31 || !(kx & 1) || !(ky & 1)) { set_error("anti-aliasing kernel size %dx%d not supported", kx, ky); return MODS_E_ARG; }
+  if (kx > 127 || ky > 127 || !(kx & 1) || !(ky & 1)) { set_error("anti-aliasing kernel size %dx%d not supported", kx, ky); return MODS_E_ARG; }
   SmallTaps tx, ty;
   tx.n = kx; ty.n = ky;
   gauss_kernel_host(kx, sx, tx.k);
@@ -287,11 +287,8 @@ int mods_detect_describe_view_dev(mods_ctx *c, const float *src_dev, int w, int 
   }
   if (!c->view_dev) MODS_HIP_CHECK(hipMalloc(&c->view_dev, sizeof(float) * (size_t)c->max_w * c->max_h));
   if ((rc = mods_synth_view_dev(c, src_dev, w, h, stride, &g, doBlur, c->view_dev))) return rc;
-  if ((rc = pyramid_configure(c, g.w_new, g.h_new, 1, det))) return rc;
-  // DetectAffineKeypoints, scale-space-detector.cpp:20-21 (tilt, zoom = the SynthImage fields: |tilt|, zoom)
-  if (g.tilt > 2.0 || g.zoom < 0.5) c->reg_number_eff = (int)floor(g.zoom * (double)det->regionsNumber / g.tilt);
-  if ((rc = pyramid_build(c, c->view_dev, g.w_new))) return rc;
-  if ((rc = detect_run(c))) return rc;
+  // DetectAffineKeypoints / DetectMSERs scale regionsNumber by the SynthImage fields |tilt|, zoom (scale-space-detector.cpp:20-21, extrema.cpp:201-202)
+  if ((rc = detect_any(c, c->view_dev, 1, g.w_new, g.h_new, g.w_new, det, g.tilt, g.zoom))) return rc;
   if ((rc = describe_run_view(c, c->view_dev, 1, g.w_new, g.h_new, desc, g.H, w, h, nullptr))) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));

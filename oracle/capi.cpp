@@ -27,6 +27,8 @@ struct orc_hessaff_params {     // mirrors include/mods_hip.h: mods_hessaff_para
   int detectorType;
   int iiDoGMode;
   int sampleFromImage;
+  double mserMaxArea, mserMinMargin;
+  int mserMinSize, pad;
 };
 
 struct orc_candidate { int octave, level, r0, c0, r, c; float x, y, s, pixelDistance, response; int type; };
@@ -40,6 +42,7 @@ static HessAffParams cvt(const orc_hessaff_params *p) {
     q.convergenceThreshold = p->convergenceThreshold; q.smmWindowSize = p->smmWindowSize; q.doBaumberg = p->doBaumberg;
     q.mode = p->mode; q.rel_threshold = p->relativeThreshold; q.reg_number = p->regionsNumber; q.rel_reg_number = p->relativeRegionsNumber;
     q.detector_type = p->detectorType; q.ii_dog = p->iiDoGMode; q.sample_from_image = p->sampleFromImage;
+    q.mser_max_area = p->mserMaxArea; q.mser_min_margin = p->mserMinMargin; q.mser_min_size = p->mserMinSize;
   }
   return q;
 }
@@ -169,6 +172,50 @@ int orc_detect_hessian_affine(const float *img, int w, int h, const orc_hessaff_
                               int max_out) {
   std::vector<AffKey> k;
   detect_hessian_affine(wrap(img, w, h), cvt(p), k);
+  int n = (int)k.size();
+  for (int i = 0; i < n && i < max_out; i++) {
+    orc_affkey &o = out[i];
+    o.x = k[i].x; o.y = k[i].y; o.s = k[i].s; o.a11 = k[i].a11; o.a12 = k[i].a12; o.a21 = k[i].a21; o.a22 = k[i].a22;
+    o.response = k[i].response; o.sub_type = k[i].sub_type; o.octave = k[i].octave; o.level = k[i].level;
+    o.r0 = k[i].r0; o.c0 = k[i].c0; o.pad = 0;
+  }
+  return n;
+}
+
+// MSER regions of one image (MSER+ first, then MSER-; extremaRLERegions' order) with their run lists: rows of
+// (thresh, margin, min_int, max_int, area, border, seed_x, seed_y, polarity, n_runs) in info10, the runs (line, col1, col2)
+// concatenated in runs3, the ellipse (cx, cy, sxx, sxy, syy) in ell5.  Returns the number of regions; *n_runs_total = all runs.
+int orc_mser_regions(const float *img, int w, int h, const orc_hessaff_params *p, int *info10, int max_regions, int *runs3,
+                     int max_runs, double *ell5, int *n_runs_total) {
+  HessAffParams q = cvt(p);
+  std::vector<AffKey> k;
+  std::vector<MserRegion> regs;
+  q.mode = 0;
+  detect_mser(wrap(img, w, h), q, 1.0, 1.0, k, &regs);
+  int n_plus = 0;
+  for (const AffKey &a : k) n_plus += a.sub_type == 21;
+  int total = 0;
+  for (size_t i = 0; i < regs.size(); i++) {
+    const MserRegion &r = regs[i];
+    if ((int)i < max_regions) {
+      int *o = info10 + 10 * i;
+      o[0] = r.thresh; o[1] = r.margin; o[2] = r.min_int; o[3] = r.max_int; o[4] = r.area; o[5] = r.border; o[6] = r.seed_x;
+      o[7] = r.seed_y; o[8] = (int)i < n_plus ? 0 : 1; o[9] = (int)r.rle.size();
+      double *e = ell5 + 5 * i;
+      e[0] = r.cx; e[1] = r.cy; e[2] = r.sxx; e[3] = r.sxy; e[4] = r.syy;
+    }
+    for (const MserRun &u : r.rle) {
+      if (total < max_runs) { runs3[3 * total] = u.line; runs3[3 * total + 1] = u.col1; runs3[3 * total + 2] = u.col2; }
+      total++;
+    }
+  }
+  if (n_runs_total) *n_runs_total = total;
+  return (int)regs.size();
+}
+// DetectMSERs for a view with the SynthImage's tilt / zoom (the regionsNumber scaling of extrema.cpp:201-202)
+int orc_detect_mser_view(const float *img, int w, int h, const orc_hessaff_params *p, double tilt, double zoom, orc_affkey *out, int max_out) {
+  std::vector<AffKey> k;
+  detect_mser(wrap(img, w, h), cvt(p), tilt, zoom, k);
   int n = (int)k.size();
   for (int i = 0; i < n && i < max_out; i++) {
     orc_affkey &o = out[i];

@@ -241,7 +241,7 @@ bool find_affine_shape(const Img &blur, float x, float y, float s, float pixelDi
 }
 
 // synth-detection.cpp:134-143
-static void rectify_transformation(double &a11, double &a12, double &a21, double &a22) {
+void rectify_transformation(double &a11, double &a12, double &a21, double &a22) {
   double a = a11, b = a12, c = a21, d = a22;
   double det = std::sqrt(std::fabs(a * d - b * c));
   double b2a2 = std::sqrt(b * b + a * a);
@@ -257,6 +257,7 @@ static void rectify_transformation(double &a11, double &a12, double &a21, double
 // unstable on ties, fixed here as processing order) -> DetectAffineRegions
 // (synth-detection.hpp:79-112): s *= sqrt|det A|, A -> lower-triangular det 1.
 void detect_hessian_affine(const Img &image, const HessAffParams &p, std::vector<AffKey> &out) {
+  if (p.detector_type == 3) { detect_mser(image, p, 1.0, 1.0, out); return; }   // DET_MSER (imagerepresentation.cpp:780-783)
   Pyramid pyr;
   build_pyramid(image, p, pyr);
   std::vector<Candidate> cand;

@@ -87,6 +87,11 @@ struct HessAffParams {          // PyramidParams + AffineShapeParams, detectors/
   int detector_type = 0;        // detector_type (structures.hpp:16-18): 0 DET_HESSIAN, 1 DET_DOG, 2 DET_HARRIS
   int ii_dog = 0;               // iiDoGMode (only the DoG response has such a form, pyramid.cpp:126-161)
   int sample_from_image = 0;    // AffineShapeParams::sampleFromImage (affine.h:47): findAffineShape on the input image, pixel distance 1
+  // detector_type 3 = DET_MSER: extrema::ExtremaParams (detectors/mser/extrema/extremaParams.h:56-89, [MSER] of the .ini,
+  // io_mods.cpp:101-123); mode / rel_threshold / reg_number / rel_reg_number above are shared
+  double mser_max_area = 0.01;
+  double mser_min_margin = 10;
+  int mser_min_size = 30;
 };
 
 struct Candidate {              // one accepted pyramid keypoint before affine adaptation
@@ -115,6 +120,21 @@ bool find_affine_shape(const Img &blur, float x, float y, float s, float pixelDi
 // Full DetectAffineKeypoints + DetectAffineRegions (scale-space-detector.cpp:13-32,
 // synth-detection.hpp:79-112): sorted by |response| desc, s*=sqrt|det|, A rectified.
 void detect_hessian_affine(const Img &image, const HessAffParams &p, std::vector<AffKey> &out);
+void rectify_transformation(double &a11, double &a12, double &a21, double &a22);   // synth-detection.cpp rectifyTransformation
+
+// ---- MSER (mser.cpp; detectors/mser/extrema/) -------------------------------------------
+struct MserParams { int min_size = 30; double max_area = 0.01, min_margin = 10; bool relative = false; };   // the fields the growth reads
+struct MserRun { int line, col1, col2; };                       // RLEItem, libExtrema.h:35-39
+struct MserRegion {                                             // RLERegion, libExtrema.h:42-81
+  int thresh, margin, min_int, max_int, area, border, seed_x, seed_y;
+  std::vector<MserRun> rle;
+  double cx, cy, sxx, sxy, syy;
+};
+void mser_rle_to_ellipse(const std::vector<MserRun> &rle, double &barX, double &barY, double &sumX2, double &sumXY, double &sumY2);
+void mser_regions(const unsigned char *img8, int w, int h, const MserParams &par, bool inverted, std::vector<MserRegion> &out);
+// DetectMSERs + DetectAffineRegions (extrema.cpp:196-295, synth-detection.hpp:79-112); MSER+ first, then MSER-
+void detect_mser(const Img &image, const HessAffParams &p, double tilt, double zoom, std::vector<AffKey> &out,
+                 std::vector<MserRegion> *regions_out = nullptr);
 
 // ---- orientation + descriptor (describe.cpp) -------------------------------------------
 struct Region {                 // AffineRegion subset: det_kp == reproj_kp for the identity view

@@ -15,7 +15,15 @@ class HessAffParams(C.Structure):
                 ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int), ("doBaumberg", C.c_int),
                 ("mode", C.c_int), ("relativeThreshold", C.c_float), ("regionsNumber", C.c_int),
                 ("relativeRegionsNumber", C.c_float), ("detectorType", C.c_int), ("iiDoGMode", C.c_int),
-                ("sampleFromImage", C.c_int)]
+                ("sampleFromImage", C.c_int),
+                ("mserMaxArea", C.c_double), ("mserMinMargin", C.c_double), ("mserMinSize", C.c_int), ("pad", C.c_int)]
+
+    @staticmethod
+    def mser(mode=0, min_margin=8, max_area=0.05, min_size=30, reg_number=500, rel_threshold=-1.0, rel_reg_number=-1.0):
+        # build/config_affori_classic.ini [MSER] (DetectorType = DET_MSER = 3, detectors/structures.hpp:19)
+        p = HessAffParams(3, 1.6, 5.33, 10.0, 5, 16, 0.05, 19, 1, mode, rel_threshold, reg_number, rel_reg_number, 3, 0, 0)
+        p.mserMaxArea, p.mserMinMargin, p.mserMinSize = max_area, min_margin, min_size
+        return p
 
     @staticmethod
     def default():
@@ -198,6 +206,31 @@ def detect_hessian_affine(img, params=None, max_out=1 << 20):
     out = np.zeros(max_out, AFFKEY_DTYPE)
     n = lib().orc_detect_hessian_affine(p, a.shape[1], a.shape[0], C.byref(params),
                                         out.ctypes.data_as(C.POINTER(AffKey)), max_out)
+    return out[:n].copy()
+
+
+def mser_regions(img, params=None, max_regions=1 << 16, max_runs=1 << 24):
+    """MSER+ then MSER- regions of one image: (info[n, 10], runs list per region [k, 3], ell[n, 5])."""
+    params = params or HessAffParams.mser()
+    a, p = _f(img)
+    info = np.zeros((max_regions, 10), np.int32)
+    runs = np.zeros((max_runs, 3), np.int32)
+    ell = np.zeros((max_regions, 5), np.float64)
+    tot = C.c_int(0)
+    n = lib().orc_mser_regions(p, a.shape[1], a.shape[0], C.byref(params), info.ctypes.data_as(C.POINTER(C.c_int)), max_regions,
+                               runs.ctypes.data_as(C.POINTER(C.c_int)), max_runs, ell.ctypes.data_as(C.POINTER(C.c_double)), C.byref(tot))
+    assert n <= max_regions and tot.value <= max_runs
+    info = info[:n].copy()
+    ends = np.cumsum(info[:, 9])
+    per = [runs[e - k:e].copy() for e, k in zip(ends, info[:, 9])]
+    return info, per, ell[:n].copy()
+
+
+def detect_mser_view(img, params, tilt, zoom, max_out=1 << 18):
+    a, p = _f(img)
+    out = np.zeros(max_out, AFFKEY_DTYPE)
+    n = lib().orc_detect_mser_view(p, a.shape[1], a.shape[0], C.byref(params), C.c_double(tilt), C.c_double(zoom),
+                                   out.ctypes.data_as(C.POINTER(AffKey)), max_out)
     return out[:n].copy()
 
 

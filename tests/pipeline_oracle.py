@@ -271,14 +271,18 @@ def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=
             step = d["steps"][si] if si < len(d["steps"]) else None
             if step is None:
                 continue
-            tilts, phi_base = step
-            views = view_schedule(tilts, phi_base, S["history"])
+            # (tilts, phi_base[, scales[, initSigma[, FGINNThreshold]]]): the keys of one [<Detector><i>] section
+            tilts, phi_base = step[0], step[1]
+            scales = step[2] if len(step) > 2 else (1.0,)
+            sigma = step[3] if len(step) > 3 else init_sigma
+            step_ratio = step[4] if len(step) > 4 else d.get("ratio", 0.8)
+            views = view_schedule(tilts, phi_base, S["history"], scales)
             want_half = d.get("ratio_half", 0.0) > 0
             half_ori = d.get("half_orientation", False) or want_half
 
-            def one_view(job, d=d, want_half=want_half, half_ori=half_ori):
+            def one_view(job, d=d, want_half=want_half, half_ori=half_ori, sigma=sigma):
                 img, (zoom, tilt, phi) = job
-                px, g = orc.synth_view(img, tilt, phi, zoom, init_sigma, 1)
+                px, g = orc.synth_view(img, tilt, phi, zoom, sigma, 1)
                 if g.w_new < 16 or g.h_new < 16:
                     return None
                 r = orc.detect_describe_view(px, np.array(g.H), w, h, params=d.get("params"), half_orientation=half_ori, half_desc=want_half)
@@ -293,9 +297,9 @@ def match_ladder(img1, img2, steps, seed_time=12345, min_matches=15, init_sigma=
             if d.get("dist", 0.0) > 0:      # MatchFLANNDistance replaces what MatchFlannFGINN found (it clears the list, matching.cpp:585)
                 ra, rb = np.concatenate(S["banks"][0]), np.concatenate(S["banks"][1])
                 S["tc"] = (orc.match_distance(ra, rb, d["dist"]), ra, rb)
-            elif d.get("ratio", 0.8) > 0:
+            elif step_ratio > 0:
                 ra, rb = np.concatenate(S["banks"][0]), np.concatenate(S["banks"][1])
-                S["tc"] = (match_fginn_par(ra, rb, d.get("ratio", 0.8)), ra, rb)
+                S["tc"] = (match_fginn_par(ra, rb, step_ratio), ra, rb)
             if want_half:
                 ha, hb = np.concatenate(S["banks_h"][0]), np.concatenate(S["banks_h"][1])
                 S["tch"] = (match_fginn_par(ha, hb, d["ratio_half"]), ha, hb)

@@ -45,7 +45,7 @@ def test_config_parsing_and_no_cpu_path(tmp_path):
     rc, err = run([G1, G6, "o1", "o2", "k1", "k2", "m", "log", "0", "0", "H", os.path.join(CFG, "classic.ini"),
                    os.path.join(CFG, "iters_ladder.ini")], tmp_path)
     assert rc == 1
-    assert "detector MSER is outside this build" in err and "HalfRootSIFT is outside" not in err
+    assert "detector ORB is outside this build" in err and "HalfRootSIFT is outside" not in err
     assert "Image1: 800x640, Image2: 800x640" in err
     assert "no MI355X / HIP device available" in err and "no CPU path" in err
     assert not os.path.exists(tmp_path / "m")

@@ -76,7 +76,7 @@ def test_cli_one_view_matches_library_and_readme(pkg, tmp_path):
 
 
 def test_cli_ladder_and_epipolar(pkg, tmp_path):
-    """A multi-step iterations file with out-of-scope sections: MSER step skipped, HessianAffine steps run until
+    """A multi-step iterations file with out-of-scope sections: the ORB step skipped, HessianAffine steps run until
     minMatches; ver_type 2 switches to DEGENSAC."""
     err = _run(tmp_path, "iters_ladder.ini", ver_type="2")
     # [HessianAffine1] Descriptors = RootSIFT,HalfRootSIFT with both thresholds: doHalfSIFT orientation, both lists matched
@@ -87,8 +87,8 @@ def test_cli_ladder_and_epipolar(pkg, tmp_path):
     assert len(got) == res.n_inliers > 15
     assert np.allclose(got, m, rtol=1e-5, atol=1e-3)
     log = (tmp_path / "log.txt").read_text().split()
-    assert int(log[6]) == 1 + res.steps_done            # step numbering counts the skipped MSER step
-    assert "detector MSER is outside this build" in err
+    assert int(log[6]) == 1 + res.steps_done            # step numbering counts the skipped ORB step
+    assert "detector ORB is outside this build" in err
 
 
 def test_cli_with_zmq_descriptor_daemon(pkg, tmp_path):
@@ -279,6 +279,43 @@ def test_cli_dog_and_harris_detectors_next_to_hessian(pkg, tmp_path):
     at += 3 + len(reps1[1])
     assert lines[at] == "HessianAffine 1" and lines[at + 1] == "RootSIFT %d" % len(reps1[2])
     assert min(len(r) for r in reps1) > 100
+    for r in reps1 + reps2:
+        r.close()
+    ctx.close()
+
+
+def test_cli_mser_steps(pkg, tmp_path):
+    """[MSER0] / [MSER1] / [HessianAffine2] in the shape of build/iters_MODS.ini: no step is skipped, the command line equals the
+    library's ladder, the keypoint files list HessianAffine before MSER."""
+    import torch
+    err = _run(tmp_path, "iters_mser.ini")
+    assert "outside this build" not in err
+    a, b = _grey(G1), _grey(G6)
+    h, w = a.shape
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    reps1 = [pkg.ImgRep(ctx, 1 << 20) for _ in range(2)]
+    reps2 = [pkg.ImgRep(ctx, 1 << 20) for _ in range(2)]
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(4242)
+    L = pkg.LadderStep.make
+    det_steps = [[None, None, L((1, 2), 360.0, half_orientation=1)],
+                 [L((1,), 360.0, scales=(1, 0.25, 0.125), init_sigma=0.8, fginn=0.85, half_orientation=1),
+                  L((1, 3, 6), 360.0, scales=(1, 0.25), init_sigma=0.8, fginn=0.8, half_orientation=1), None]]
+    res, m = pkg.match_ladder_dets_dev(ctx, t.data_ptr(), w, h, det_steps, [pkg.HessAffParams.default(), pkg.HessAffParams.mser()],
+                                       reps1, reps2, min_matches=100000, max_matches=1 << 20)
+    pkg.ransac_pin_seed(-1)
+    got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    assert len(got) == res.n_inliers > 15
+    assert np.allclose(got, m, rtol=1e-5, atol=1e-3)
+    log = (tmp_path / "log.txt").read_text().split()
+    assert [int(log[1]), int(log[2]), int(log[6])] == [res.n_inliers, res.n_unique, 3]
+    lines = (tmp_path / "k1.txt").read_text().splitlines()
+    assert lines[0] == "2" and lines[1] == "HessianAffine 1" and lines[2] == "RootSIFT %d" % len(reps1[0])
+    at = 4 + len(reps1[0])
+    assert lines[at] == "MSER 1" and lines[at + 1] == "RootSIFT %d" % len(reps1[1])
+    assert len(reps1[1]) > 500
     for r in reps1 + reps2:
         r.close()
     ctx.close()
