@@ -237,16 +237,32 @@ def other_configs(args):
         ctx = pkg.Context(0, d[0], d[1], 1)
         rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
         steps = pkg.iters_mods_steps()
+        if args.ladder == "hessian":     # the two HessianAffine sections only (what rounds 1-3 measured)
+            def run_once():
+                return pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2)[0]
+            what = "iters_MODS.ini HessianAffine steps"
+        else:                            # the file as it is: [MSER0], [MSER1], [HessianAffine2], [HessianAffine3]
+            L = pkg.LadderStep.make
+            det_steps = [[None, None, steps[0], steps[1]],
+                         [L((1,), 360.0, scales=(1, 0.25, 0.125), init_sigma=0.8, fginn=0.85, half_orientation=1),
+                          L((1, 3, 6), 360.0, scales=(1, 0.25), init_sigma=0.8, fginn=0.8, half_orientation=1), None, None]]
+            dets = [pkg.HessAffParams.default(), pkg.HessAffParams.mser()]
+            repm1, repm2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
+
+            def run_once():
+                return pkg.match_ladder_dets_dev(ctx, t.data_ptr(), w, h, det_steps, dets, [rep1, repm1], [rep2, repm2])[0]
+            what = "iters_MODS.ini, all four steps (MSER, MSER, HessianAffine, HessianAffine)"
         for _ in range(args.warmup):
-            pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2)
+            run_once()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        res = [pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2)[0] for _ in range(args.steps)]
+        res = [run_once() for _ in range(args.steps)]
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         r = res[-1]
         out.update(value=round(args.steps / dt, 4), ms_per_step=round(dt / args.steps * 1e3, 3),
-                   config={"workload": "iters_MODS.ini HessianAffine steps on one hard 1920x1080 pair (tilt 6), 1 GPU (BASELINE configs[2])",
+                   config={"workload": what + " on one hard 1920x1080 pair (tilt 6), 1 GPU (BASELINE configs[2])",
+                           "view_workers": int(os.environ.get("MODS_LADDER_WORKERS", "4")),
                            "steps_done": r.steps_done, "views": r.n_views, "regions": list(r.n_described), "tentatives": r.n_tentatives,
-                           "inliers": r.n_inliers,
+                           "unique": r.n_unique, "inliers": r.n_inliers, "ransac_samples": r.ransac_samples,
                            "stage_ms": {"synth_detect_describe": round(r.ms_detect_describe, 2), "match": round(r.ms_match, 2),
                                         "duplicates": round(r.ms_duplicates, 2), "ransac": round(r.ms_ransac, 2)}})
         rep1.close(); rep2.close(); ctx.close()
@@ -271,6 +287,8 @@ def main():
     ap.add_argument("--no-match-leg", action="store_true", help="skip the configs[4]-sized match measurement (roofline_match)")
     ap.add_argument("--scene", default="planar", choices=["planar", "two_planes"],
                     help="--config c5: one plane (SURVEY 8d's generator: every sample is H-degenerate) or two planes with parallax")
+    ap.add_argument("--ladder", default="full", choices=["full", "hessian"],
+                    help="--config c3: the whole iters_MODS.ini (MSER steps 0-1, HessianAffine steps 2-3) or its HessianAffine steps only")
     ap.add_argument("--keep-workers", action="store_true", help="N > 1: do not shrink the worker counts to the rank's share of the host cores")
     ap.add_argument("--inlier-ratio", type=float, default=0.0,
                     help="0 (default): SURVEY 8d's pairs (one homography, ~94 %% of the tentatives are inliers: 3 RANSAC samples); "

@@ -154,6 +154,10 @@ struct mods_ctx {
   std::vector<double> h_u6, h_laf;
   std::vector<unsigned char> h_mask;
   void *mser = nullptr;              // MserState (mser.hip): buffers of the MSER detector, allocated on first use
+  // the step loop spreads the views of a step over a few more contexts of the same GPU (imgrep.hip: run_view_jobs)
+  std::vector<mods_ctx *> helpers;
+  struct StageArena { mods_region *buf = nullptr; size_t cap = 0; };
+  std::vector<StageArena> helper_stage;
   // timing
   int timing_mask = 0;
   mods::StageTimer timers[MODS_STAGE_COUNT];

