@@ -128,6 +128,9 @@ enum { MODS_STAGE_BLUR = 0, MODS_STAGE_RESPONSE, MODS_STAGE_RESIZE, MODS_STAGE_N
        MODS_STAGE_BAUMBERG, MODS_STAGE_SORT, MODS_STAGE_ORIENT, MODS_STAGE_DESCRIBE, MODS_STAGE_MATCH,
        MODS_STAGE_RANSAC_SCORE, MODS_STAGE_SYNTH,
        MODS_STAGE_BLUR_SMALL,   /* blur launches of the small planes (the 16-row tile instantiation); MODS_STAGE_BLUR: 32-row tiles */
+       MODS_STAGE_PYRAMID,      /* the whole scale space of a batch in ONE scope on the context's stream: every blur, response and
+                                 * resize launch of every octave + NMS + compaction (the small octaves run on a second stream
+                                 * inside it, so the per-stage sums above overlap and add up to more than this) */
        MODS_STAGE_COUNT };
 int mods_ctx_timing_enable(mods_ctx *ctx, int stage_mask);
 /* sums since the last reset; resolves pending events (synchronises the stream) */

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MODS_LIB") or os.path.join(PKG_DIR, "libmodsgpu.so")
 
 MODS_OK = 0
 STAGES = ["blur", "response", "resize", "nms", "localize", "baumberg", "sort", "orient", "describe", "match",
-          "ransac_score", "synth", "blur_small"]
+          "ransac_score", "synth", "blur_small", "pyramid"]
 
 
 class ModsError(RuntimeError):

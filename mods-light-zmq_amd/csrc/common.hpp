@@ -71,6 +71,7 @@ struct mods_ctx {
   int n_cu = 256;                    // compute units of the device (sizes the persistent grids)
   int max_w = 0, max_h = 0, batch = 1;
   hipStream_t stream = nullptr;
+  hipEvent_t pyr_scope_begin = nullptr;   // MODS_STAGE_PYRAMID: opened by pyramid_build, closed by detect_run after the compaction
   // scale space
   mods::PyramidDev pyr;              // host copy of the descriptor table
   mods::PyramidDev *pyr_dev = nullptr;
@@ -78,6 +79,7 @@ struct mods_ctx {
   size_t plane_pool_elems = 0;
   unsigned int *omap_pool = nullptr;
   size_t omap_pool_elems = 0;
+  bool omap_dirty = true;            // the pool holds cells that are not 0xFFFFFFFF (detect_run fills it before use)
   float *input_dev = nullptr;        // staging for host-pointer entry points
   float *tmp_dev = nullptr;
   // DoG / Harris responses (pyramid.cpp:165-194, 256-278): per-level tap tables of the response's own blur and scratch planes

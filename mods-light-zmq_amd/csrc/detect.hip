@@ -46,20 +46,46 @@ struct DetectConst {
 // ---------------------------------------------------------------------------------------
 constexpr int NMS_ROWS = 8;
 
+// One launch covers every octave of a kind (the small octaves are dependent load -> test -> gather chains of ~20 us whatever
+// their size: side by side they cost one chain, not one per octave).  blockIdx.x runs over the octaves' blocks, octave after octave.
+struct NmsPlan {
+  int n;
+  int oi[kMaxOctaves];
+  int blk_begin[kMaxOctaves + 1];
+  int nbx[kMaxOctaves];                       // blocks per block-row of the octave
+  int w[kMaxOctaves], h[kMaxOctaves], words[kMaxOctaves], wide[kMaxOctaves];
+  unsigned long long mask_off[kMaxOctaves];   // where the octave's ballot words start
+};
+__device__ __forceinline__ int nms_plan_entry(const NmsPlan &pl, int blk) {
+  int e = 0;
+  while (e + 1 < pl.n && blk >= pl.blk_begin[e + 1]) e++;
+  return e;
+}
+
 // low/high planes of a pixel that already is an in-plane extremum above the gate: all 18 loads issued
 // together (no short-circuit chain of dependent loads)
+typedef float nms_f3 __attribute__((ext_vector_type(3), aligned(4)));
 __device__ __forceinline__ bool nms_other_planes(const float *__restrict__ low, const float *__restrict__ high, int w, int r, int c,
                                                  float val, bool want_max) {
-  float v[18];
+#ifdef NMS_EXP_NOFLUSH
+  return true;
+#endif
+  // three 12-byte loads per plane (dword alignment is enough for global_load_dwordx3) instead of nine 4-byte ones: a third of
+  // the vector-memory instructions over the same six cache lines
+  nms_f3 v[6];
 #pragma unroll
   for (int dr = -1; dr <= 1; dr++) {
-    const size_t off = (size_t)(r + dr) * w + c;
-#pragma unroll
-    for (int dc = -1; dc <= 1; dc++) { v[(dr + 1) * 6 + (dc + 1) * 2] = low[off + dc]; v[(dr + 1) * 6 + (dc + 1) * 2 + 1] = high[off + dc]; }
+    const size_t off = (size_t)(r + dr) * w + c - 1;
+    v[(dr + 1) * 2] = *(const nms_f3 *)(low + off);
+    v[(dr + 1) * 2 + 1] = *(const nms_f3 *)(high + off);
   }
   bool ok = true;
 #pragma unroll
-  for (int q = 0; q < 18; q++) ok = ok && !(want_max ? (v[q] > val) : (v[q] < val));
+  for (int q = 0; q < 6; q++) {
+    ok = ok && !(want_max ? (v[q].x > val) : (v[q].x < val));
+    ok = ok && !(want_max ? (v[q].y > val) : (v[q].y < val));
+    ok = ok && !(want_max ? (v[q].z > val) : (v[q].z < val));
+  }
   return ok;
 }
 
@@ -70,19 +96,22 @@ __device__ __forceinline__ bool nms_other_planes(const float *__restrict__ low, 
 // earlier form loaded three values per row and lane: the kernel is bound by the number of lane-loads, not by bytes).
 // mask layout per octave: [n_img][S][h - 2*border][words], words = ceil((w - 2*border) / 62), bit = lane
 constexpr int NMS_COLS = 62;
-__global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__ P, int oi, DetectConst k,
+__global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__ P, NmsPlan pl, DetectConst k,
                                                   unsigned long long *__restrict__ mask) {
-  const OctaveDev &o = P->oct[oi];
+  const int pe = nms_plan_entry(pl, blockIdx.x);
+  const OctaveDev &o = P->oct[pl.oi[pe]];
+  const int bx = (blockIdx.x - pl.blk_begin[pe]) % pl.nbx[pe], by = (blockIdx.x - pl.blk_begin[pe]) / pl.nbx[pe];
+  mask += pl.mask_off[pe];
   const int w = o.w, h = o.h;
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63;
-  const int c = k.border + blockIdx.x * NMS_COLS - 1 + lane;
-  const int r_base = k.border + (blockIdx.y * 4 + (threadIdx.x >> 6)) * NMS_ROWS;
+  const int c = k.border + bx * NMS_COLS - 1 + lane;
+  const int r_base = k.border + (by * 4 + (threadIdx.x >> 6)) * NMS_ROWS;
   const size_t plane = (size_t)w * h * b;
   const bool col_ok = lane >= 1 && lane <= NMS_COLS && c < w - k.border;
   const int cc = c < w - 1 ? c : w - 1;      // lanes past the row read a valid column (c >= border - 1 >= 1)
   if (r_base >= h - k.border) return;
-  const int ih = h - 2 * k.border, words = gridDim.x;
+  const int ih = h - 2 * k.border, words = pl.nbx[pe];
   // in-plane extrema above the gate are rare per lane but not per wave: they are collected into a wave-private LDS list and
   // the 18 loads of the other two planes run over the list with all lanes busy (instead of once per row for a few lanes)
   __shared__ unsigned int s_code[4][64 * NMS_ROWS];
@@ -141,12 +170,12 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
       if (t < n_c) {
         const unsigned int code = s_code[wv][t];
         const int rr = code >> 7, ln = (code >> 1) & 63;
-        if (nms_other_planes(low, high, w, r_base + rr, k.border + blockIdx.x * NMS_COLS - 1 + ln, s_val[wv][t], (code & 1u) != 0))
+        if (nms_other_planes(low, high, w, r_base + rr, k.border + bx * NMS_COLS - 1 + ln, s_val[wv][t], (code & 1u) != 0))
           atomicOr(&s_hit[wv][rr], 1ull << ln);
       }
     }
     wave_sync();
-    unsigned long long *mrow = mask + (((size_t)b * k.n_scales + (lv - 1)) * ih + (r_base - k.border)) * words + blockIdx.x;
+    unsigned long long *mrow = mask + (((size_t)b * k.n_scales + (lv - 1)) * ih + (r_base - k.border)) * words + bx;
     if (lane < NMS_ROWS && r_base + lane < h - k.border) mrow[(size_t)lane * words] = s_hit[wv][lane];
   }
 }
@@ -160,17 +189,20 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
 // mask layout per octave: [n_img][S][h - 2*border][words], words = 4 * ceil(w / 248): word (block, sub-column), bit = lane
 constexpr int NMS4_COLS = 248;
 constexpr int NMS4_CAP = 1024;     // in-plane extrema listed per wave before the other planes are consulted
-__global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict__ P, int oi, DetectConst k,
+__global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict__ P, NmsPlan pl, DetectConst k,
                                                    unsigned long long *__restrict__ mask) {
-  const OctaveDev &o = P->oct[oi];
+  const int pe = nms_plan_entry(pl, blockIdx.x);
+  const OctaveDev &o = P->oct[pl.oi[pe]];
+  const int bx = (blockIdx.x - pl.blk_begin[pe]) % pl.nbx[pe], by = (blockIdx.x - pl.blk_begin[pe]) / pl.nbx[pe];
+  mask += pl.mask_off[pe];
   const int w = o.w, h = o.h;
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c0 = (int)blockIdx.x * NMS4_COLS - 4 + 4 * lane;          // first of the lane's four columns (multiple of 4)
-  const int r_base = k.border + (blockIdx.y * 4 + wv) * NMS_ROWS;
+  const int c0 = bx * NMS4_COLS - 4 + 4 * lane;                       // first of the lane's four columns (multiple of 4)
+  const int r_base = k.border + (by * 4 + wv) * NMS_ROWS;
   const size_t plane = (size_t)w * h * b;
   if (r_base >= h - k.border) return;
-  const int ih = h - 2 * k.border, words = 4 * gridDim.x;
+  const int ih = h - 2 * k.border, words = 4 * pl.nbx[pe];
   const int cl = c0 < 0 ? 0 : (c0 > w - 4 ? w - 4 : c0);              // lanes beside the row read a valid address (values unused)
   const bool lane_ok = lane >= 1 && lane <= 62;
   __shared__ unsigned int s_code[4][NMS4_CAP];
@@ -197,7 +229,7 @@ __global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict_
         if (t < n_c) {
           const unsigned int code = s_code[wv][t];
           const int rr = code >> 9, ln = (code >> 3) & 63, sub = (code >> 1) & 3;
-          const int c = (int)blockIdx.x * NMS4_COLS - 4 + 4 * ln + sub;
+          const int c = bx * NMS4_COLS - 4 + 4 * ln + sub;
           if (nms_other_planes(low, high, w, r_base + rr, c, s_val[wv][t], (code & 1u) != 0)) atomicOr(&s_hit[wv][rr][sub], 1ull << ln);
         }
       }
@@ -241,23 +273,34 @@ __global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict_
       }
     }
     flush();
-    unsigned long long *mrow = mask + (((size_t)b * k.n_scales + (lv - 1)) * ih + (r_base - k.border)) * words + 4 * blockIdx.x;
+    unsigned long long *mrow = mask + (((size_t)b * k.n_scales + (lv - 1)) * ih + (r_base - k.border)) * words + 4 * bx;
     if (lane < NMS_ROWS * 4 && r_base + (lane >> 2) < h - k.border) mrow[(size_t)(lane >> 2) * words + (lane & 3)] = s_hit[wv][lane >> 2][lane & 3];
   }
 }
 
-// grid = (ceil(total_words/256), n_img), block 256: ballot words -> hit records
-__global__ __launch_bounds__(256) void nms_compact_kernel(int oi, int w, int h, DetectConst k, const unsigned long long *__restrict__ mask,
-                                                          int words, CandDev *__restrict__ cand, int *__restrict__ cand_count, int wide) {
+// grid = (sum over octaves of ceil(total_words / (256 * NMS_CW)), n_img), block 256: ballot words -> hit records.  A thread
+// takes NMS_CW words (coalesced, 256 apart), so a block owns 2048 words and draws its list slots with ONE returning atomic:
+// at one word per thread the kernel was bound by ~540 serialised atomics per image counter (105 us per 16-image batch).
+constexpr int NMS_CW = 8;
+__global__ __launch_bounds__(256) void nms_compact_kernel(NmsPlan pl, DetectConst k, const unsigned long long *__restrict__ mask,
+                                                          CandDev *__restrict__ cand, int *__restrict__ cand_count) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
+  const int pe = nms_plan_entry(pl, blockIdx.x);
+  const int oi = pl.oi[pe], h = pl.h[pe], words = pl.words[pe], wide = pl.wide[pe];
+  mask += pl.mask_off[pe];
   const int b = blockIdx.y;
   const int ih = h - 2 * k.border;
   const int total = k.n_scales * ih * words;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  unsigned long long m = 0;
-  if (idx < total) m = mask[(size_t)b * total + idx];
-  const int cnt = __popcll(m);
+  const int idx0 = (blockIdx.x - pl.blk_begin[pe]) * 256 * NMS_CW + threadIdx.x;
+  unsigned long long m[NMS_CW];
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < NMS_CW; j++) {
+    const int idx = idx0 + j * 256;
+    m[j] = idx < total ? mask[(size_t)b * total + idx] : 0ull;
+    cnt += __popcll(m[j]);
+  }
   // block-wide exclusive prefix of cnt
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int inc = cnt;
@@ -272,21 +315,27 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(int oi, int w, int h, 
   if (cnt == 0) return;
   int slot = s_base + inc - cnt;
   for (int q = 0; q < wv; q++) slot += s_wave[q];
-  const int lv = idx / (ih * words) + 1;
-  const int rem = idx - (lv - 1) * ih * words;
-  const int r = k.border + rem / words;
-  // column of bit `bit`: nms_kernel: border + block * 62 - 1 + bit; nms4_kernel (wide): block * 248 - 4 + 4 * bit + sub-column
-  const int wi = rem % words;
-  const int c0 = wide ? (wi >> 2) * NMS4_COLS - 4 + (wi & 3) : k.border + wi * NMS_COLS - 1;
-  const int cstep = wide ? 4 : 1;
-  while (m) {
-    const int bit = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    if (slot < k.max_cand) {
-      CandDev &cd = cand[(size_t)b * k.max_cand + slot];
-      cd.octave = oi; cd.level = lv; cd.r0 = r; cd.c0 = c0 + cstep * bit; cd.state = 0;
+#pragma unroll
+  for (int j = 0; j < NMS_CW; j++) {
+    unsigned long long mm = m[j];
+    if (!mm) continue;
+    const int idx = idx0 + j * 256;
+    const int lv = idx / (ih * words) + 1;
+    const int rem = idx - (lv - 1) * ih * words;
+    const int r = k.border + rem / words;
+    // column of bit `bit`: nms_kernel: border + block * 62 - 1 + bit; nms4_kernel (wide): block * 248 - 4 + 4 * bit + sub-column
+    const int wi = rem % words;
+    const int c0 = wide ? (wi >> 2) * NMS4_COLS - 4 + (wi & 3) : k.border + wi * NMS_COLS - 1;
+    const int cstep = wide ? 4 : 1;
+    while (mm) {
+      const int bit = __ffsll((long long)mm) - 1;
+      mm &= mm - 1;
+      if (slot < k.max_cand) {
+        CandDev &cd = cand[(size_t)b * k.max_cand + slot];
+        cd.octave = oi; cd.level = lv; cd.r0 = r; cd.c0 = c0 + cstep * bit; cd.state = 0;
+      }
+      slot++;
     }
-    slot++;
   }
 }
 
@@ -409,7 +458,22 @@ __global__ __launch_bounds__(256) void accept_kernel(const PyramidDev *__restric
       cd.state = 2;
       const int slot = atomicAdd(&acc_count[b], 1);
       acc_list[(size_t)b * k.max_cand + slot] = i;
-    } else cd.state = 0;
+    } else cd.state = 5;      // lost its octaveMap cell to an earlier point; r, c stay valid for omap_reset_kernel
+  }
+}
+
+// The octaveMap cells this batch wrote (every localised point that passed the tests) go back to "empty", so that the map of
+// one u32 per pixel and octave is cleared by ~10^5 stores instead of a 177 MB fill per 16-image batch.
+__global__ __launch_bounds__(256) void omap_reset_kernel(const PyramidDev *__restrict__ P, DetectConst k, const CandDev *__restrict__ cand,
+                                                         const int *__restrict__ cand_count) {
+  const int b = blockIdx.y;
+  int n = cand_count[b];
+  if (n > k.max_cand) n = k.max_cand;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const CandDev &cd = cand[(size_t)b * k.max_cand + i];
+    if (cd.state != 2 && cd.state != 5) continue;
+    const OctaveDev &o = P->oct[cd.octave];
+    as_global(o.omap)[(size_t)o.w * o.h * b + (size_t)cd.r * o.w + cd.c] = 0xFFFFFFFFu;
   }
 }
 
@@ -782,39 +846,65 @@ int detect_run(mods_ctx *ctx) {
     if ((size_t)P.oct[oi].w * P.oct[oi].h >= (1u << ORDER_POS_BITS)) { set_error("octave too large for the order key"); return MODS_E_ARG; }
 
   MODS_HIP_CHECK(hipMemsetAsync(ctx->cand_count, 0, sizeof(int) * 3 * ctx->batch, ctx->stream));   // cand/acc/key counts
-  size_t omap_elems = 0;
-  for (int oi = 0; oi < P.n_oct; oi++) omap_elems += (size_t)P.oct[oi].w * P.oct[oi].h * n_img;
-  MODS_HIP_CHECK(hipMemsetAsync(ctx->omap_pool, 0xFF, omap_elems * sizeof(unsigned int), ctx->stream));
+  if (ctx->omap_dirty) {     // first use of the pool, or a call that did not reach omap_reset_kernel: fill it once
+    MODS_HIP_CHECK(hipMemsetAsync(ctx->omap_pool, 0xFF, ctx->omap_pool_elems * sizeof(unsigned int), ctx->stream));
+  }
+  ctx->omap_dirty = true;    // until this call has put the cells it claims back
   int *acc_count = ctx->cand_count + ctx->batch;
   int *key_count = ctx->cand_count + 2 * ctx->batch;
   {
     StageScope ts(ctx, MODS_STAGE_NMS);
+    // three launches for the whole pyramid: the four-columns-per-lane kernel over every octave whose rows are 16-byte aligned
+    // float4s, the one-column kernel over the others, the compaction of all ballot words
+    NmsPlan wide_pl, narrow_pl, comp_pl;
+    wide_pl.n = narrow_pl.n = comp_pl.n = 0;
+    wide_pl.blk_begin[0] = narrow_pl.blk_begin[0] = comp_pl.blk_begin[0] = 0;
+    size_t mask_words = 0;
     for (int oi = 0; oi < P.n_oct; oi++) {
       const OctaveDev &o = P.oct[oi];
       const int iw = o.w - 2 * par.border, ih = o.h - 2 * par.border;
       if (iw <= 0 || ih <= 0) continue;
-      const bool wide = (o.w & 3) == 0 && o.w >= 8;     // rows of 16-byte aligned float4s: the four-columns-per-lane kernel
+      const bool wide = (o.w & 3) == 0 && o.w >= 8;
       const int nblk = wide ? (o.w + NMS4_COLS - 1) / NMS4_COLS : (iw + NMS_COLS - 1) / NMS_COLS;
       const int words = wide ? 4 * nblk : nblk;
-      dim3 grid(nblk, (ih + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), n_img);
-      // the ballot words of this octave live at the start of the (not yet used) accept-list half of sort_idx
-      unsigned long long *mask = (unsigned long long *)ctx->nms_mask;
-      const size_t need_words = (size_t)n_img * par.numberOfScales * ih * words;
-      if (need_words > ctx->nms_mask_words) { set_error("nms mask buffer too small"); return MODS_E_CAPACITY; }
-      if (wide) hipLaunchKernelGGL(nms4_kernel, grid, dim3(256), 0, ctx->stream, ctx->pyr_dev, oi, k, mask);
-      else hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, ctx->stream, ctx->pyr_dev, oi, k, mask);
+      const int nby = (ih + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS);
+      NmsPlan &pl = wide ? wide_pl : narrow_pl;
+      pl.oi[pl.n] = oi; pl.nbx[pl.n] = nblk; pl.w[pl.n] = o.w; pl.h[pl.n] = o.h; pl.words[pl.n] = words; pl.wide[pl.n] = wide ? 1 : 0;
+      pl.mask_off[pl.n] = mask_words;
+      pl.blk_begin[pl.n + 1] = pl.blk_begin[pl.n] + nblk * nby;
+      pl.n++;
       const int total = par.numberOfScales * ih * words;
-      hipLaunchKernelGGL(nms_compact_kernel, dim3((total + 255) / 256, n_img), dim3(256), 0, ctx->stream, oi, o.w, o.h, k, mask, words,
-                         ctx->cand, ctx->cand_count, wide ? 1 : 0);
+      comp_pl.oi[comp_pl.n] = oi; comp_pl.nbx[comp_pl.n] = nblk; comp_pl.w[comp_pl.n] = o.w; comp_pl.h[comp_pl.n] = o.h;
+      comp_pl.words[comp_pl.n] = words; comp_pl.wide[comp_pl.n] = wide ? 1 : 0; comp_pl.mask_off[comp_pl.n] = mask_words;
+      comp_pl.blk_begin[comp_pl.n + 1] = comp_pl.blk_begin[comp_pl.n] + (total + 256 * NMS_CW - 1) / (256 * NMS_CW);
+      comp_pl.n++;
+      mask_words += (size_t)n_img * total;
     }
+    if (mask_words > ctx->nms_mask_words) { set_error("nms mask buffer too small"); return MODS_E_CAPACITY; }
+    unsigned long long *mask = (unsigned long long *)ctx->nms_mask;
+    if (wide_pl.n) hipLaunchKernelGGL(nms4_kernel, dim3(wide_pl.blk_begin[wide_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, wide_pl, k, mask);
+    if (narrow_pl.n) hipLaunchKernelGGL(nms_kernel, dim3(narrow_pl.blk_begin[narrow_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, narrow_pl, k, mask);
+    if (comp_pl.n) hipLaunchKernelGGL(nms_compact_kernel, dim3(comp_pl.blk_begin[comp_pl.n], n_img), dim3(256), 0, ctx->stream, comp_pl, k, mask, ctx->cand,
+                                      ctx->cand_count);
     MODS_HIP_CHECK(hipGetLastError());
+  }
+  if (ctx->pyr_scope_begin) {      // MODS_STAGE_PYRAMID: from the first blur launch to here
+    StageTimer &t = ctx->timers[MODS_STAGE_PYRAMID];
+    hipEvent_t e1;
+    if (!t.pool.empty()) { e1 = t.pool.back(); t.pool.pop_back(); }
+    else MODS_HIP_CHECK(hipEventCreate(&e1));
+    MODS_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    t.pending.emplace_back(ctx->pyr_scope_begin, e1);
+    ctx->pyr_scope_begin = nullptr;
   }
   {
     StageScope ts(ctx, MODS_STAGE_LOCALIZE);
     hipLaunchKernelGGL(localize_kernel, dim3(256, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, k, ctx->cand, ctx->cand_count);
     hipLaunchKernelGGL(accept_kernel, dim3(256, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, k, ctx->cand, ctx->cand_count,
                        ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count);
+    hipLaunchKernelGGL(omap_reset_kernel, dim3(256, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, k, ctx->cand, ctx->cand_count);
     MODS_HIP_CHECK(hipGetLastError());
+    ctx->omap_dirty = false;
   }
   {
     StageScope ts(ctx, MODS_STAGE_BAUMBERG);

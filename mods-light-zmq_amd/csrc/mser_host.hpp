@@ -22,6 +22,7 @@ namespace mods {
 namespace mser {
 
 constexpr uint32_t kNoParent = 0x7fffffffu, kHasStable = 0x80000000u;
+constexpr size_t kAhead = 24;   // pixels of look-ahead for the label prefetch
 
 struct Stable { int slot, thresh, margin, area; };
 struct GrowParams { int min_size; double max_area, min_margin; bool relative, invert; };
@@ -57,9 +58,17 @@ class Grower {
         for (int x = 1; x <= w; x++) order_[cur[row[x]]++] = (uint32_t)(y * cols_ + x);
       }
     }
+    const size_t n_px = order_.size();
     for (int level = 0; level < 256; level++)
       for (size_t k = hist[level]; k < hist[level + 1]; k++) {
         const int ofs = (int)order_[k];
+        if (k + kAhead < n_px) {      // the visiting order is known: the three label lines of a later pixel are requested now
+          const uint32_t nx = order_[k + kAhead];     // (105 -> 91 ms per 1080p polarity; requesting the slots those labels point at as
+          __builtin_prefetch(&lab_[nx - cols_]);      // well costs more than it hides: 145 ms)
+          __builtin_prefetch(&lab_[nx]);
+          __builtin_prefetch(&lab_[nx + cols_]);
+          __builtin_prefetch(&pix_slot_[nx], 1);
+        }
         gather(ofs);
         if (n_lab_ == 0) {                                               // ConsRegion: size 1, border 4, a min-region
           lab_[ofs] = 0x00080004 | 1;

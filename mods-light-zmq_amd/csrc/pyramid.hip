@@ -855,6 +855,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
     ctx->omap_pool = nullptr;
     MODS_HIP_CHECK(hipMalloc(&ctx->omap_pool, omap_elems * sizeof(unsigned int)));
     ctx->omap_pool_elems = omap_elems;
+    ctx->omap_dirty = true;
   }
   float *pp = ctx->plane_pool;
   unsigned int *mp = ctx->omap_pool;
@@ -904,6 +905,13 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
 // response plane of every octave, for the whole batch.  `img_dev`: [n_img][h][stride].
 int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
   ctx->last_img_dev = img_dev; ctx->last_stride = stride;
+  ctx->pyr_scope_begin = nullptr;
+  if ((ctx->timing_mask >> MODS_STAGE_PYRAMID) & 1) {
+    StageTimer &t = ctx->timers[MODS_STAGE_PYRAMID];
+    if (!t.pool.empty()) { ctx->pyr_scope_begin = t.pool.back(); t.pool.pop_back(); }
+    else MODS_HIP_CHECK(hipEventCreate(&ctx->pyr_scope_begin));
+    MODS_HIP_CHECK(hipEventRecord(ctx->pyr_scope_begin, ctx->stream));
+  }
   PyramidDev &P = ctx->pyr;
   const mods_hessaff_params &par = ctx->par;
   const int n_img = ctx->last_n_img, w = ctx->last_w, h = ctx->last_h;
@@ -959,6 +967,10 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
   } else {
     MODS_HIP_CHECK(hipMemcpyAsync(P.oct[0].blur[0], src0, sizeof(float) * (size_t)w * h * n_img, hipMemcpyDeviceToDevice, ctx->stream));
   }
+  // (Tried in round 3: the octaves below ~3 Mpixel per batch - chains of ~30 launches of 6-10 us each, 0.2 ms per 16-image batch
+  // for 8 % of the pixels - on a second stream next to the last level and the NMS of the large octaves: the small launches
+  // slow down under the large ones (0.196 -> 0.332 ms) and the join waits for them: 1.436 vs 1.416 ms for the whole
+  // scale space.  One stream.)
   for (int oi = 0; oi < P.n_oct; oi++) {
     OctaveDev &o = P.oct[oi];
     if (oi > 0 || !initial_blur)
