@@ -143,16 +143,26 @@ __device__ __forceinline__ void tile_store(char *buf, const TileRegs &r) {
 // keep the earlier tile = the lower train index, which is the (d, t) order.  |acc| < 2^23 (dot within +-2.1 M, ct/2 within
 // 2.1 M), rows past the end of the list carry the seed -2^25: their k4 lie below every real one and do not wrap.
 constexpr int MT2_BYTES = 32 * MT_ROW + 256;
-__device__ __forceinline__ TileRegs tile_fetch2(const int8_t *__restrict__ tdesc, const int *__restrict__ tc2n, const int *__restrict__ tc, int tt) {
-  TileRegs r;
-  r.a = *(const v4i *)(tdesc + (size_t)tt * 4096 + threadIdx.x * 16);
+#ifndef MATCH_WG_WAVES
+#define MATCH_WG_WAVES 4   // waves of a pass-1 workgroup = the waves that wait for each other at the tile barrier
+#endif
+constexpr int NN1_WAVES = MATCH_WG_WAVES, NN1_THREADS = 64 * NN1_WAVES, NN1_LOADS = 256 / NN1_THREADS;   // 16-byte loads per thread and tile
+struct TileRegs2 { v4i a[NN1_LOADS]; int s; };
+__device__ __forceinline__ TileRegs2 tile_fetch2(const int8_t *__restrict__ tdesc, const int *__restrict__ tc2n, const int *__restrict__ tc, int tt) {
+  TileRegs2 r;
+#pragma unroll
+  for (int i = 0; i < NN1_LOADS; i++) r.a[i] = *(const v4i *)(tdesc + (size_t)tt * 4096 + (threadIdx.x + i * NN1_THREADS) * 16);
   // threads 0..31: the seeds, 32..63: ct of the rows (turned into the key constants when the tile is stored: nothing
   // waits for this load before the MFMAs)
   r.s = threadIdx.x < 64 ? (threadIdx.x < 32 ? tc2n : tc - 32)[tt * 32 + threadIdx.x] : 0;
   return r;
 }
-__device__ __forceinline__ void tile_store2(char *buf, const TileRegs &r) {
-  *(v4i *)(buf + (threadIdx.x >> 3) * MT_ROW + (threadIdx.x & 7) * 16) = r.a;
+__device__ __forceinline__ void tile_store2(char *buf, const TileRegs2 &r) {
+#pragma unroll
+  for (int i = 0; i < NN1_LOADS; i++) {
+    const int t = threadIdx.x + i * NN1_THREADS;
+    *(v4i *)(buf + (t >> 3) * MT_ROW + (t & 7) * 16) = r.a[i];
+  }
   if (threadIdx.x < 64) {
     const int row = threadIdx.x & 31;
     const int ck = (-(r.s & 1) * 16) | (15 - ((row & 3) + 4 * (row >> 3)));
@@ -178,14 +188,14 @@ __device__ unsigned long long g_match_stats[4];
 #define MATCH_XCH 16   // tiles between two exchanges of the shared bound (a power of two)
 #endif
 
-__global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
+__global__ __launch_bounds__(NN1_THREADS) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                         const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
                                                         const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                         unsigned long long *__restrict__ best2, int *__restrict__ gthr) {
   constexpr int QB = MATCH_QB1;
   constexpr int NONE = (int)0x80000000;
   const int lane = threadIdx.x & 63, g = lane >> 5;
-  const int jbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
+  const int jbase = (blockIdx.x * NN1_WAVES + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
   v4i bq[QB][4];
   int M1[QB], M2[QB], T1[QB], T2[QB];   // two largest packed keys of this lane's rows and their tiles
   int bk[QB], alim[QB];                 // bound on k = -(d - cq): only k >= bk can matter; acc >= alim <=> 2*acc >= bk
@@ -237,31 +247,32 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
 #ifdef MATCH_STATS
       st_all++;
 #endif
-      // some train of this tile may be among the two nearest so far: a wave-level branch, every lane inserts its 16 values
-      // (harmless for the lanes that did not pass: the insertion is exact whatever the bound)
-      if (__any(acc_max16(acc[b]) >= alim[b])) {
+      // some train of this tile may be among the two nearest so far: a wave-level branch.  The 16 values of a lane are four
+      // groups of four rows (one accumulator quad each); a group is inserted only when some lane of the wave holds a value of
+      // that group at or above its bound - almost always ONE group of the four.  A lane inserts all four values of such a
+      // group (harmless for the lanes that did not pass: the insertion is exact whatever the bound).  Per entry ~30 VALU
+      // instructions instead of 63: the kernel issues about as many VALU cycles as MFMA cycles, so the count matters as much
+      // as the latency.
+      int gm[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) gm[q] = max(max(max(acc[b][4 * q + 0], acc[b][4 * q + 1]), acc[b][4 * q + 2]), acc[b][4 * q + 3]);
+      const int tmax = max(max(max(gm[0], gm[1]), gm[2]), gm[3]);
+      if (__any(tmax >= alim[b])) {
 #ifdef MATCH_STATS
         st_exact++;
 #endif
         const int m1o = M1[b], m2o = M2[b];
-        // two independent insertion chains (even / odd register pairs) and one merge: half the dependent depth of a single
-        // chain of 16 insertions (the exact path is latency, not issue, that the other waves of the workgroup wait for)
-        int m1 = m1o, m2 = m2o, n1 = NONE, n2 = NONE;
+        int m1 = m1o, m2 = m2o;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
+          if (!__any(gm[q] >= alim[b])) continue;
           const int4 c = ck[q];   // rows 8q + 4g .. + 3
           const int x0 = (acc[b][4 * q + 0] << 5) + c.x, x1 = (acc[b][4 * q + 1] << 5) + c.y;
           const int x2 = (acc[b][4 * q + 2] << 5) + c.z, x3 = (acc[b][4 * q + 3] << 5) + c.w;
           m2 = med3_i32(m1, m2, x0); m1 = max(m1, x0);
-          n2 = med3_i32(n1, n2, x1); n1 = max(n1, x1);
+          m2 = med3_i32(m1, m2, x1); m1 = max(m1, x1);
           m2 = med3_i32(m1, m2, x2); m1 = max(m1, x2);
-          n2 = med3_i32(n1, n2, x3); n1 = max(n1, x3);
-        }
-        // top 2 of {m1 >= m2} and {n1 >= n2}: the second is the median of (smaller top, larger second, larger top)
-        {
-          const int hi = max(m1, n1), lo = min(m1, n1);
-          m2 = max(lo, max(m2, n2));
-          m1 = hi;
+          m2 = med3_i32(m1, m2, x3); m1 = max(m1, x3);
         }
         const bool c1 = m1 != m1o;
         T2[b] = (c1 && m2 == m1o) ? T1[b] : (m2 == m2o ? T2[b] : tt);
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
     }
   };
   __shared__ __attribute__((aligned(16))) char s_tile[2 * MT2_BYTES];
-  TileRegs nxt;
+  TileRegs2 nxt;
   if (t0 < t1) { nxt = tile_fetch2(tdesc, tc2n, tc, t0); tile_store2(s_tile, nxt); }
   __syncthreads();
   for (int tt = t0; tt < t1; tt++) {
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(256) void match_nn1_kernel(MatchConst k, const int8
 #ifdef MATCH_STATS
   if (lane == 0) { atomicAdd(&g_match_stats[0], (unsigned long long)st_all); atomicAdd(&g_match_stats[1], (unsigned long long)st_exact); }
 #endif
-  const size_t n_qpad = (size_t)gridDim.x * 128 * QB;
+  const size_t n_qpad = (size_t)gridDim.x * (32 * NN1_WAVES) * QB;
 #pragma unroll
   for (int b = 0; b < QB; b++) {
     const int j = jbase + 32 * b;
@@ -705,14 +716,15 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
   (void)best;
   // pass 1: top-2 keys per query and train split
-  const int qblocks1 = (n_q + 128 * MATCH_QB1 - 1) / (128 * MATCH_QB1);
-  int splits1 = std::max(1, std::min(n_tiles, target_blocks / std::max(1, qblocks1)));
+  constexpr int QPB = 32 * NN1_WAVES * MATCH_QB1;      // queries per pass-1 workgroup
+  const int qblocks1 = (n_q + QPB - 1) / QPB;
+  int splits1 = std::max(1, std::min(n_tiles, target_blocks * (4 / NN1_WAVES) / std::max(1, qblocks1)));
   MatchConst k1 = k;
   k1.tiles_per_split = (n_tiles + splits1 - 1) / splits1;
   splits1 = (n_tiles + k1.tiles_per_split - 1) / k1.tiles_per_split;
-  const size_t n_qpad = (size_t)qblocks1 * 128 * MATCH_QB1;
+  const size_t n_qpad = (size_t)qblocks1 * QPB;
   if ((size_t)splits1 * n_qpad > ctx->m_best2_cap) { set_error("match: top-2 table too small"); return MODS_E_CAPACITY; }
-  hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks1, splits1), dim3(256), 0, ctx->stream, k1, qd, qc, td, tc, tc2, tpar, best2, gthr);
+  hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks1, splits1), dim3(NN1_THREADS), 0, ctx->stream, k1, qd, qc, td, tc, tc2, tpar, best2, gthr);
   hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best2, splits1, n_qpad, txy, (QueryMid *)ctx->m_mid,
                      key_ge, key_lt, n_lt, bad, list2, count2);
   // pass 2 on the undecided queries only (their number stays on the device: the grid covers the worst case, idle blocks exit)

@@ -17,6 +17,9 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#ifdef MSER_PROF
+#include <chrono>
+#endif
 
 namespace mods {
 namespace mser {
@@ -32,6 +35,9 @@ class Grower {
   // img: padded (w + 2) x (h + 2) bytes, the frame is never read.  pix_slot / tpar / tlev: (w + 2) * (h + 2) entries each (only
   // interior entries are written).  out: stable thresholds, regions in creation order, thresholds in list order.
   void run(const uint8_t *img, int w, int h, const GrowParams &gp, int32_t *pix_slot, uint32_t *tpar, uint8_t *tlev, std::vector<Stable> &out) {
+#ifdef MSER_PROF
+    prof_t0 = std::chrono::steady_clock::now();
+#endif
     cols_ = w + 2;
     const int rows = h + 2;
     pix_slot_ = pix_slot; tpar_ = tpar; tlev_ = tlev;
@@ -58,6 +64,9 @@ class Grower {
         for (int x = 1; x <= w; x++) order_[cur[row[x]]++] = (uint32_t)(y * cols_ + x);
       }
     }
+#ifdef MSER_PROF
+    prof_t1 = std::chrono::steady_clock::now();
+#endif
     const size_t n_px = order_.size();
     for (int level = 0; level < 256; level++)
       for (size_t k = hist[level]; k < hist[level + 1]; k++) {
@@ -77,23 +86,29 @@ class Grower {
         } else if (n_lab_ == 1) insert(lab_slot_[0], ofs, level);
         else merge(ofs, level);
       }
+#ifdef MSER_PROF
+    prof_t2 = std::chrono::steady_clock::now();
+#endif
     int root = cols_ + 1;
     if ((lab_[root] & 3) == 0) root = find(root);
     if (lab_[root] & 2) set_thresholds(regs_[(size_t)(lab_[root] >> 2)]);
     out.clear();
     for (int r = first_; r >= 0; r = regs_[r].next) {
       const Region &g = regs_[r];
-      for (const Thr &t : g.th) out.push_back({g.slot, t.thresh, t.margin, g.pixels[t.thresh]});
+      for (const Thr &t : g.th) out.push_back({g.slot, t.thresh, t.margin, g.hist[t.thresh].px});
       if (!g.th.empty()) tpar_[g.slot] |= kHasStable;
     }
   }
 
+#ifdef MSER_PROF
+  std::chrono::steady_clock::time_point prof_t0, prof_t1, prof_t2;
+#endif
  private:
   struct Thr { int thresh, pos, margin; };
   struct Region {
     int minimum_int, maximum_int, pixel_total, border_total, slot, prev, next;
     std::vector<Thr> th;
-    int pixels[256], borders[256];
+    struct { int px, bd; } hist[256];     // pixels / borders of the reference's t_region, side by side: one line per insertion
   };
 
   // labels (getExtrema.cpp:19-34 with A64): 0 = not entered yet; low bits 00 = (slot << 2), a pointer to a slot; bit 0 = packed
@@ -110,11 +125,19 @@ class Grower {
     const int nb[4] = {ofs - cols_, ofs - 1, ofs + 1, ofs + cols_};
     n_lab_ = 0;
     int touched = 0;
+    uint64_t seen_v[4];
+    int seen_root[4], n_seen = 0;
     for (int k = 0; k < 4; k++) {
       const uint64_t v = lab_[nb[k]];
       if (!v) continue;
       touched++;
-      const int root = (v & 3) ? nb[k] : find(nb[k]);
+      int root = -1;
+      if (v & 3) root = nb[k];
+      else {
+        // neighbours inside one component mostly carry the same pointer: the slot it leads to is looked up once
+        for (int q = 0; q < n_seen; q++) if (seen_v[q] == v) root = seen_root[q];
+        if (root < 0) { root = find(nb[k]); seen_v[n_seen] = v; seen_root[n_seen++] = root; }
+      }
       bool seen = false;
       for (int q = 0; q < n_lab_; q++) seen |= lab_slot_[q] == root;
       if (!seen) lab_slot_[n_lab_++] = root;
@@ -125,8 +148,7 @@ class Grower {
     if (!free_.empty()) { const int r = free_.back(); free_.pop_back(); return r; }
     regs_.emplace_back();
     Region &g = regs_.back();
-    std::memset(g.pixels, 0, sizeof(g.pixels));
-    std::memset(g.borders, 0, sizeof(g.borders));
+    std::memset(g.hist, 0, sizeof(g.hist));
     return (int)regs_.size() - 1;
   }
   void drop(int r) {
@@ -145,8 +167,8 @@ class Grower {
     g.border_total = (int)(packed >> 17);
     g.slot = slot;
     g.minimum_int = g.maximum_int = level;
-    g.pixels[level] = g.pixel_total;
-    g.borders[level] = g.border_total;
+    g.hist[level].px = g.pixel_total;
+    g.hist[level].bd = g.border_total;
     g.th.clear();
     g.prev = last_; g.next = -1;
     if (last_ >= 0) regs_[last_].next = ri; else first_ = ri;
@@ -164,8 +186,8 @@ class Grower {
       g.maximum_int = level;
       g.pixel_total++;
       g.border_total += 4 - border_num_;
-      g.pixels[level]++;
-      g.borders[level] += 4 - border_num_;
+      g.hist[level].px++;
+      g.hist[level].bd += 4 - border_num_;
     }
   }
   void link(int from, int to, int level) {                               // the merge tree the kernels walk
@@ -179,7 +201,7 @@ class Grower {
       const uint64_t v = lab_[lab_slot_[i]];
       if (v & 1) continue;
       const Region &g = regs_[(size_t)(v >> 2)];
-      const unsigned size = (unsigned)(g.pixel_total - g.pixels[level]);   // its size one level below
+      const unsigned size = (unsigned)(g.pixel_total - g.hist[level].px);   // its size one level below
       n_large++;
       if (size > best) { best = size; keep = lab_slot_[i]; }
     }
@@ -208,7 +230,7 @@ class Grower {
         } else {
           Region &m = regs_[keep_region];
           m.pixel_total += pt; m.border_total += bt;
-          m.pixels[level] += pt; m.borders[level] += bt;
+          m.hist[level].px += pt; m.hist[level].bd += bt;
         }
         if (!is_min) {
           Region &g = regs_[ri];
@@ -226,18 +248,18 @@ class Grower {
   // FastSetOptThresholds4StableRegion + SuppresOverlappingTresholds4StableRegions, optThresh.cpp:15-165
   void set_thresholds(Region &g) {
     if (g.pixel_total < min_size_) return;
-    int *area = g.pixels, *border = g.borders;
-    for (int i = g.minimum_int + 1; i <= g.maximum_int; i++) { area[i] += area[i - 1]; border[i] += border[i - 1]; }
+    auto *H = g.hist;
+    for (int i = g.minimum_int + 1; i <= g.maximum_int; i++) { H[i].px += H[i - 1].px; H[i].bd += H[i - 1].bd; }
     const int icons = invert_ ? 255 : 0, imul = invert_ ? -1 : 1;
     int up, best_margin = -1, best_pos = -1, i = g.minimum_int;
     auto emit = [&]() {
       const int th = best_pos + best_margin / 2;
-      if (area[th] <= max_size_ && area[th] > min_size_) g.th.push_back({th, best_pos, best_margin});
+      if (H[th].px <= max_size_ && H[th].px > min_size_) g.th.push_back({th, best_pos, best_margin});
     };
     do {
       up = (int)(i + min_margin_);
       if (up > g.maximum_int) break;
-      while ((area[up] - area[i] < border[i]) && (up < g.maximum_int)) up++;
+      while ((H[up].px - H[i].px < H[i].bd) && (up < g.maximum_int)) up++;
       const int margin = up - i;
       double quality = (double)margin;
       if (relative_) quality /= icons + imul * (i + (margin / 2));
@@ -262,7 +284,7 @@ class Grower {
     for (size_t k = 0; k < t.size(); k++)                                 // neighbours within 10 % of area are joined
       while (k + 1 < t.size()) {
         if (t[k].pos + t[k].margin < t[k + 1].pos) break;
-        if (area[t[k + 1].thresh] - area[t[k].thresh] <= 0.1 * area[t[k].thresh]) {
+        if (H[t[k + 1].thresh].px - H[t[k].thresh].px <= 0.1 * H[t[k].thresh].px) {
           t[k].margin = t[k + 1].pos - t[k].pos + t[k + 1].margin;
           t[k].thresh = t[k].pos + t[k].margin / 2;
           t.erase(t.begin() + k + 1);

@@ -151,9 +151,11 @@ def test_multi_gpu_rejects_images_larger_than_created(pkg):
     multi.close()
 
 
-def test_cli_on_several_devices(tmp_path):
-    """MODS_DEVICES: the command line runs the whole configuration (HessianAffine steps with RootSIFT + HalfRootSIFT lists next to
-    DoG steps: tests/configs/iters_ladder.ini) through mods_match_ladder_groups_multi and writes the SAME files as on one GPU."""
+@pytest.mark.parametrize("iters", ["iters_ladder.ini", "iters_mser.ini"])
+def test_cli_on_several_devices(tmp_path, iters):
+    """MODS_DEVICES: the command line runs the whole configuration (HessianAffine steps with RootSIFT + HalfRootSIFT lists:
+    tests/configs/iters_ladder.ini; MSER steps next to a HessianAffine step: iters_mser.ini) through
+    mods_match_ladder_groups_multi and writes the SAME files as on one GPU."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -165,7 +167,7 @@ def test_cli_on_several_devices(tmp_path):
         wd = tmp_path / name
         wd.mkdir()
         args = [mods, g1, g6, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", "0", "H.txt",
-                os.path.join(cfg, "classic.ini"), os.path.join(cfg, "iters_ladder.ini")]
+                os.path.join(cfg, "classic.ini"), os.path.join(cfg, iters)]
         p = subprocess.run(args, cwd=wd, env=dict(os.environ, MODS_RANSAC_SEED="4242", **env), stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, p.stderr.decode()

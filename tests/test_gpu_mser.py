@@ -176,3 +176,19 @@ def test_ladder_with_mser_steps(pkg):
     for r in reps1 + reps2:
         r.close()
     ctx.close()
+
+
+def test_mser_degenerate_inputs(pkg):
+    """a constant image (one component, never stable within max_area), an image smaller than min_size, a two-level image"""
+    ctx = pkg.Context(0, 256, 256, 1)
+    for img in (np.full((64, 96), 77.0, np.float32), np.full((5, 5), 10.0, np.float32),
+                np.kron(np.indices((8, 8)).sum(0) % 2, np.ones((16, 16))).astype(np.float32) * 200.0):
+        want = orc.detect_hessian_affine(img, orc.HessAffParams.mser())
+        got = ctx.detect_hessian_affine(img, pkg.HessAffParams.mser())
+        same_keys(got, want)
+    assert len(want) == 64          # the checkerboard: 32 dark + 32 bright squares
+    # parameters the reference would run into undefined behaviour with are refused
+    bad = pkg.HessAffParams.mser(min_margin=0)
+    with pytest.raises(pkg.ModsError):
+        ctx.detect_hessian_affine(img, bad)
+    ctx.close()
