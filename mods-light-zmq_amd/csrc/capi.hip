@@ -476,11 +476,14 @@ int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, 
   if (r <= 0 || n <= 0) return MODS_OK;
   std::vector<int> order(n);
   for (int i = 0; i < n; i++) order[i] = i;
-  if (mode == 1) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(tent[a].ratio) < std::fabs(tent[b].ratio); });
-  else if (mode == 2) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs((double)tent[a].d1) < std::fabs((double)tent[b].d1); });
-  else if (mode == 3) {   // MODE_BIGGER_REGION: ascending |s| of the first image's region (CompareCorrespondenceByScale, matching.cpp:74)
-    if (!laf) { set_error("duplicate_filter: biggerRegion needs the local affine frames"); return MODS_E_ARG; }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(laf[(size_t)a * 14 + 6]) < std::fabs(laf[(size_t)b * 14 + 6]); });
+  if (mode >= 1 && mode <= 3) {
+    // (key, index) pairs sorted by value: the order of a stable sort by key, without a random access per comparison
+    if (mode == 3 && !laf) { set_error("duplicate_filter: biggerRegion needs the local affine frames"); return MODS_E_ARG; }   // CompareCorrespondenceByScale, matching.cpp:74
+    std::vector<std::pair<double, int>> keyed(n);
+    for (int i = 0; i < n; i++)
+      keyed[i] = {mode == 1 ? std::fabs(tent[i].ratio) : mode == 2 ? std::fabs((double)tent[i].d1) : std::fabs(laf[(size_t)i * 14 + 6]), i};
+    std::sort(keyed.begin(), keyed.end());
+    for (int i = 0; i < n; i++) order[i] = keyed[i].second;
   }
   std::vector<mods_tentative> ts(n);
   std::vector<double> us((size_t)n * 6), ls(laf ? (size_t)n * 14 : 0);
@@ -492,7 +495,10 @@ int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, 
   const double r_sq = r * r;
   // hash grid of the kept correspondences, keyed by the first-image cell: chained buckets in two flat arrays (which
   // kept correspondence is met first inside a cell does not matter, only whether one is met)
-  constexpr int kBuckets = 1 << 14;
+  // ~8 buckets per correspondence: a probe of an empty neighbour cell then rarely walks a chain of unrelated entries (with a fixed
+  // 16 k buckets the 24 k correspondences of a 4096^2 pair cost ~13 useless distance tests each: 8 of the pair's 43 ms)
+  size_t kBuckets = 1 << 14;
+  while (kBuckets < (size_t)n * 8) kBuckets <<= 1;
   std::vector<int> head(kBuckets, -1), next(n);
   auto cell_of = [&](double v) { return (long long)std::floor(v / r); };
   auto hash = [&](long long cx, long long cy) { return (size_t)(((unsigned long long)cx * 73856093ull) ^ ((unsigned long long)cy * 19349663ull)) & (kBuckets - 1); };
