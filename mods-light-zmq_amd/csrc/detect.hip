@@ -96,9 +96,10 @@ __device__ __forceinline__ bool nms_other_planes(const float *__restrict__ low, 
 // earlier form loaded three values per row and lane: the kernel is bound by the number of lane-loads, not by bytes).
 // mask layout per octave: [n_img][S][h - 2*border][words], words = ceil((w - 2*border) / 62), bit = lane
 constexpr int NMS_COLS = 62;
-__global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__ P, NmsPlan pl, DetectConst k,
-                                                  unsigned long long *__restrict__ mask) {
-  const int pe = nms_plan_entry(pl, blockIdx.x);
+// s_code / s_val: the calling wave's list (64 * NMS_ROWS entries), s_hit: its NMS_ROWS hit words
+__device__ __forceinline__ void nms_narrow_body(const PyramidDev *__restrict__ P, const NmsPlan &pl, int pe, const DetectConst &k,
+                                                unsigned long long *__restrict__ mask, unsigned int *s_code, float *s_val,
+                                                unsigned long long *s_hit) {
   const OctaveDev &o = P->oct[pl.oi[pe]];
   const int bx = (blockIdx.x - pl.blk_begin[pe]) % pl.nbx[pe], by = (blockIdx.x - pl.blk_begin[pe]) / pl.nbx[pe];
   mask += pl.mask_off[pe];
@@ -114,10 +115,6 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
   const int ih = h - 2 * k.border, words = pl.nbx[pe];
   // in-plane extrema above the gate are rare per lane but not per wave: they are collected into a wave-private LDS list and
   // the 18 loads of the other two planes run over the list with all lanes busy (instead of once per row for a few lanes)
-  __shared__ unsigned int s_code[4][64 * NMS_ROWS];
-  __shared__ float s_val[4][64 * NMS_ROWS];
-  __shared__ unsigned long long s_hit[4][NMS_ROWS];
-  const int wv = threadIdx.x >> 6;
   for (int lv = 1; lv <= k.n_scales; lv++) {
     const float *cur = as_global(o.resp[lv]) + plane;
     // the (NMS_ROWS+2)-row column of this lane is loaded up front (independent loads in flight), the columns beside it come
@@ -135,7 +132,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
       win[rr][2] = lane_down1(win[rr][1]);
     }
     wave_sync();                              // the previous level's list and hit words have been consumed
-    if (lane < NMS_ROWS) s_hit[wv][lane] = 0ull;
+    if (lane < NMS_ROWS) s_hit[lane] = 0ull;
     int n_c = 0;
 #pragma unroll
     for (int rr = 0; rr < NMS_ROWS; rr++) {
@@ -158,8 +155,8 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
       const unsigned long long m = __ballot(cnd);
       if (cnd) {
         const int pos = n_c + __popcll(m & ((1ull << lane) - 1ull));
-        s_code[wv][pos] = ((unsigned int)rr << 7) | ((unsigned int)lane << 1) | (cmax ? 1u : 0u);
-        s_val[wv][pos] = val;
+        s_code[pos] = ((unsigned int)rr << 7) | ((unsigned int)lane << 1) | (cmax ? 1u : 0u);
+        s_val[pos] = val;
       }
       n_c += __popcll(m);
     }
@@ -168,16 +165,25 @@ __global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__
     for (int t0 = 0; t0 < n_c; t0 += 64) {
       const int t = t0 + lane;
       if (t < n_c) {
-        const unsigned int code = s_code[wv][t];
+        const unsigned int code = s_code[t];
         const int rr = code >> 7, ln = (code >> 1) & 63;
-        if (nms_other_planes(low, high, w, r_base + rr, k.border + bx * NMS_COLS - 1 + ln, s_val[wv][t], (code & 1u) != 0))
-          atomicOr(&s_hit[wv][rr], 1ull << ln);
+        if (nms_other_planes(low, high, w, r_base + rr, k.border + bx * NMS_COLS - 1 + ln, s_val[t], (code & 1u) != 0))
+          atomicOr(&s_hit[rr], 1ull << ln);
       }
     }
     wave_sync();
     unsigned long long *mrow = mask + (((size_t)b * k.n_scales + (lv - 1)) * ih + (r_base - k.border)) * words + bx;
-    if (lane < NMS_ROWS && r_base + lane < h - k.border) mrow[(size_t)lane * words] = s_hit[wv][lane];
+    if (lane < NMS_ROWS && r_base + lane < h - k.border) mrow[(size_t)lane * words] = s_hit[lane];
   }
+}
+
+__global__ __launch_bounds__(256) void nms_kernel(const PyramidDev *__restrict__ P, NmsPlan pl, DetectConst k,
+                                                  unsigned long long *__restrict__ mask) {
+  __shared__ unsigned int s_code[4][64 * NMS_ROWS];
+  __shared__ float s_val[4][64 * NMS_ROWS];
+  __shared__ unsigned long long s_hit[4][NMS_ROWS];
+  const int wv = threadIdx.x >> 6;
+  nms_narrow_body(P, pl, nms_plan_entry(pl, blockIdx.x), k, mask, s_code[wv], s_val[wv], s_hit[wv]);
 }
 
 // The same NMS for planes whose width is a multiple of 4: a lane answers for FOUR adjacent columns and loads them as one
@@ -191,7 +197,15 @@ constexpr int NMS4_COLS = 248;
 constexpr int NMS4_CAP = 1024;     // in-plane extrema listed per wave before the other planes are consulted
 __global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict__ P, NmsPlan pl, DetectConst k,
                                                    unsigned long long *__restrict__ mask) {
+  __shared__ unsigned int s_code[4][NMS4_CAP];
+  __shared__ float s_val[4][NMS4_CAP];
+  __shared__ unsigned long long s_hit[4][NMS_ROWS][4];
   const int pe = nms_plan_entry(pl, blockIdx.x);
+  if (!pl.wide[pe]) {     // a few small octaves whose rows are not float4-aligned ride along in the same launch (same LDS arrays)
+    const int wq = threadIdx.x >> 6;
+    nms_narrow_body(P, pl, pe, k, mask, s_code[wq], s_val[wq], &s_hit[wq][0][0]);
+    return;
+  }
   const OctaveDev &o = P->oct[pl.oi[pe]];
   const int bx = (blockIdx.x - pl.blk_begin[pe]) % pl.nbx[pe], by = (blockIdx.x - pl.blk_begin[pe]) / pl.nbx[pe];
   mask += pl.mask_off[pe];
@@ -205,9 +219,6 @@ __global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict_
   const int ih = h - 2 * k.border, words = 4 * pl.nbx[pe];
   const int cl = c0 < 0 ? 0 : (c0 > w - 4 ? w - 4 : c0);              // lanes beside the row read a valid address (values unused)
   const bool lane_ok = lane >= 1 && lane <= 62;
-  __shared__ unsigned int s_code[4][NMS4_CAP];
-  __shared__ float s_val[4][NMS4_CAP];
-  __shared__ unsigned long long s_hit[4][NMS_ROWS][4];
   for (int lv = 1; lv <= k.n_scales; lv++) {
     const float *cur = as_global(o.resp[lv]) + plane;
     const float *low = as_global(o.resp[lv - 1]) + plane, *high = as_global(o.resp[lv + 1]) + plane;
@@ -882,6 +893,16 @@ int detect_run(mods_ctx *ctx) {
     }
     if (mask_words > ctx->nms_mask_words) { set_error("nms mask buffer too small"); return MODS_E_CAPACITY; }
     unsigned long long *mask = (unsigned long long *)ctx->nms_mask;
+    if (wide_pl.n && narrow_pl.n && narrow_pl.blk_begin[narrow_pl.n] <= 64 && wide_pl.n + narrow_pl.n <= kMaxOctaves) {
+      for (int e = 0; e < narrow_pl.n; e++) {      // the tail octaves (30 x 17 pixels ...): not worth a launch of their own
+        const int d = wide_pl.n;
+        wide_pl.oi[d] = narrow_pl.oi[e]; wide_pl.nbx[d] = narrow_pl.nbx[e]; wide_pl.w[d] = narrow_pl.w[e]; wide_pl.h[d] = narrow_pl.h[e];
+        wide_pl.words[d] = narrow_pl.words[e]; wide_pl.wide[d] = 0; wide_pl.mask_off[d] = narrow_pl.mask_off[e];
+        wide_pl.blk_begin[d + 1] = wide_pl.blk_begin[d] + (narrow_pl.blk_begin[e + 1] - narrow_pl.blk_begin[e]);
+        wide_pl.n++;
+      }
+      narrow_pl.n = 0;
+    }
     if (wide_pl.n) hipLaunchKernelGGL(nms4_kernel, dim3(wide_pl.blk_begin[wide_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, wide_pl, k, mask);
     if (narrow_pl.n) hipLaunchKernelGGL(nms_kernel, dim3(narrow_pl.blk_begin[narrow_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, narrow_pl, k, mask);
     if (comp_pl.n) hipLaunchKernelGGL(nms_compact_kernel, dim3(comp_pl.blk_begin[comp_pl.n], n_img), dim3(256), 0, ctx->stream, comp_pl, k, mask, ctx->cand,

@@ -537,6 +537,27 @@ __global__ __launch_bounds__(256) void hessian_response4_kernel(const float *__r
 }
 
 // cv::resize 0.5x: full 2x2 blocks ((a+b)+(c+d))*0.25f, edge blocks running sum / count.
+__device__ __forceinline__ float decimated_at(const float *__restrict__ src, int w, int h, int dx, int dy) {
+  const int sy0 = dy * 2, sx0 = dx * 2;
+  if (sy0 >= h) return 0.f;
+  const int wfull = (sy0 + 2 <= h) ? (w / 2) : 0;
+  if (dx < wfull) {
+    const float *S0 = src + (size_t)sy0 * w + sx0;
+    const float *S1 = S0 + w;
+    return ((S0[0] + S0[1]) + (S1[0] + S1[1])) * 0.25f;
+  }
+  if (sx0 >= w) return 0.f;
+  float sum = 0; int count = 0;
+  for (int sy = 0; sy < 2; sy++) {
+    if (sy0 + sy >= h) break;
+    for (int sx = 0; sx < 2; sx++) {
+      if (sx0 + sx >= w) break;
+      sum += src[(size_t)(sy0 + sy) * w + sx0 + sx];
+      count++;
+    }
+  }
+  return sum / (float)count;
+}
 __global__ __launch_bounds__(256) void resize_half_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                           int w, int h, int dw, int dh) {
   const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -544,30 +565,41 @@ __global__ __launch_bounds__(256) void resize_half_kernel(const float *__restric
   if (dx >= dw || dy >= dh) return;
   src += (size_t)w * h * blockIdx.z;
   dst += (size_t)dw * dh * blockIdx.z;
-  const int sy0 = dy * 2, sx0 = dx * 2;
-  float out;
-  if (sy0 >= h) out = 0.f;
-  else {
-    const int wfull = (sy0 + 2 <= h) ? (w / 2) : 0;
-    if (dx < wfull) {
-      const float *S0 = src + (size_t)sy0 * w + sx0;
-      const float *S1 = S0 + w;
-      out = ((S0[0] + S0[1]) + (S1[0] + S1[1])) * 0.25f;
-    } else if (sx0 >= w) out = 0.f;
-    else {
-      float sum = 0; int count = 0;
-      for (int sy = 0; sy < 2; sy++) {
-        if (sy0 + sy >= h) break;
-        for (int sx = 0; sx < 2; sx++) {
-          if (sx0 + sx >= w) break;
-          sum += src[(size_t)(sy0 + sy) * w + sx0 + sx];
-          count++;
-        }
-      }
-      out = sum / (float)count;
-    }
+  dst[(size_t)dy * dw + dx] = decimated_at(src, w, h, dx, dy);
+}
+
+// The same decimation, and the Hessian response of the decimated plane (the first level of the next octave) from the block's
+// tile in LDS: the 64 x 4 outputs of a block and the ring of decimated values around them (recomputed, 396 instead of 256
+// values per block).  One launch instead of two per octave - the response launches of the small octaves cost 7-8 us each for
+// a few microseconds of work.  Arithmetic of hessian_response4_kernel.
+__global__ __launch_bounds__(256) void resize_half_resp_kernel(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ resp,
+                                                               int w, int h, int dw, int dh, float norm2) {
+  __shared__ float tile[6][66 + 2];
+  src += (size_t)w * h * blockIdx.z;
+  dst += (size_t)dw * dh * blockIdx.z;
+  resp += (size_t)dw * dh * blockIdx.z;
+  const int bx = blockIdx.x * 64 - 1, by = blockIdx.y * 4 - 1;
+  for (int i = threadIdx.x; i < 6 * 66; i += 256) {
+    const int ty = i / 66, tx = i - ty * 66;
+    const int dx = bx + tx, dy = by + ty;
+    tile[ty][tx] = (dx >= 0 && dx < dw && dy >= 0 && dy < dh) ? decimated_at(src, w, h, dx, dy) : 0.f;
   }
-  dst[(size_t)dy * dw + dx] = out;
+  __syncthreads();
+  const int tx = (threadIdx.x & 63) + 1, ty = (threadIdx.x >> 6) + 1;
+  const int x = bx + tx, y = by + ty;
+  if (x >= dw || y >= dh) return;
+  dst[(size_t)y * dw + x] = tile[ty][tx];
+  float out = 0.f;   // the reference leaves the 1-px frame undefined; it is never read
+  if (x >= 1 && x < dw - 1 && y >= 1 && y < dh - 1) {
+    const float v11 = tile[ty - 1][tx - 1], v12 = tile[ty - 1][tx], v13 = tile[ty - 1][tx + 1];
+    const float v21 = tile[ty][tx - 1], v22 = tile[ty][tx], v23 = tile[ty][tx + 1];
+    const float v31 = tile[ty + 1][tx - 1], v32 = tile[ty + 1][tx], v33 = tile[ty + 1][tx + 1];
+    float Lxx = (v21 - 2 * v22 + v23);
+    float Lyy = (v12 - 2 * v22 + v32);
+    float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
+    out = (Lxx * Lyy - Lxy * Lxy) * norm2;
+  }
+  resp[(size_t)y * dw + x] = out;
 }
 
 
@@ -800,6 +832,15 @@ static int launch_alt_response(mods_ctx *ctx, const float *blur, float *resp, in
   return MODS_OK;
 }
 
+// decimation + Hessian response of the result (norm = sigma^2 of the next octave's first level, squared for the kernel as in launch_hessian_response)
+static int launch_resize_half_resp(mods_ctx *ctx, const float *src, float *dst, float *resp, int w, int h, int dw, int dh, int n_img, float norm) {
+  dim3 grid((dw + 63) / 64, (dh + 3) / 4, n_img);
+  StageScope ts(ctx, MODS_STAGE_RESIZE, 5.0 * w * h * n_img + 4.0 * dw * dh * n_img);
+  hipLaunchKernelGGL(resize_half_resp_kernel, grid, dim3(256), 0, ctx->stream, src, dst, resp, w, h, dw, dh, norm * norm);   // as launch_hessian_response
+  MODS_HIP_CHECK(hipGetLastError());
+  return MODS_OK;
+}
+
 int launch_resize_half(mods_ctx *ctx, const float *src, float *dst, int w, int h, int dw, int dh, int n_img) {
   dim3 grid((dw + 63) / 64, (dh + 3) / 4, n_img);
   StageScope ts(ctx, MODS_STAGE_RESIZE, 5.0 * w * h * n_img);
@@ -973,14 +1014,14 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
   // scale space.  One stream.)
   for (int oi = 0; oi < P.n_oct; oi++) {
     OctaveDev &o = P.oct[oi];
-    if (oi > 0 || !initial_blur)
+    if (oi == 0 && !initial_blur)      // (the first level of a later octave gets its response from the decimation launch)
       if ((rc = launch_hessian_response(ctx, o.blur[0], o.resp[0], o.w, o.h, n_img, o.sigma[0] * o.sigma[0]))) return rc;
     for (int l = 1; l < P.n_levels; l++) {
       const float sigma = o.sigma[l - 1] * sigmaStep;   // pyramid.cpp:455-458
       if ((rc = blur_with_slot(ctx, o.blur[l - 1], o.blur[l], o.w, o.h, n_img, l, ntap[l], o.resp[l], sigma * sigma))) return rc;
       if (l == S && oi + 1 < P.n_oct) {
         OctaveDev &nx = P.oct[oi + 1];
-        if ((rc = launch_resize_half(ctx, o.blur[l], nx.blur[0], o.w, o.h, nx.w, nx.h, n_img))) return rc;
+        if ((rc = launch_resize_half_resp(ctx, o.blur[l], nx.blur[0], nx.resp[0], o.w, o.h, nx.w, nx.h, n_img, nx.sigma[0] * nx.sigma[0]))) return rc;
       }
     }
   }
