@@ -425,11 +425,13 @@ def main():
         torch.cuda.synchronize()
         for _ in range(2):
             bctx.detect_describe_dev(batch_t.data_ptr(), 2 * nb, W, H, params.det, params.desc)
-        bctx.timing_enable(["blur", "blur_small"]); bctx.timing_reset()
+        pyr_stages = ["blur", "blur_small", "response", "resize", "nms", "pyramid"]
+        bctx.timing_enable(pyr_stages); bctx.timing_reset()
         for _ in range(6):
             bctx.detect_describe_dev(batch_t.data_ptr(), 2 * nb, W, H, params.det, params.desc)
         i_ms, i_n, i_bytes = bctx.timing_read("blur")
         is_ms, is_n, is_bytes = bctx.timing_read("blur_small")
+        pyr_ms = {st: bctx.timing_read(st)[0] / 6.0 for st in pyr_stages}
         bctx.timing_enable([])
         iso = (i_ms, i_n, i_bytes, is_ms, is_n, is_bytes)
         del reps
@@ -520,6 +522,29 @@ def main():
                                                             "frac": round(gbs(i_bytes + is_bytes, i_ms + is_ms) / HBM_PEAK_GBS, 4),
                                                             "launches": i_n + is_n}}},
         }
+        if iso is not None:
+            # the scale space as a whole by SURVEY 8d's model (97 B/px over all octaves + 8 B/px initial blur = 284.77 MB per
+            # 1080p image): the same isolated leg, HIP-event scopes per stage on one stream.  "kernels" adds up the launches'
+            # own scopes (blur of the large and of the small planes, response, decimation, NMS + compaction); "one_scope" is a
+            # single scope from the first blur launch to the end of the compaction, i.e. with the gaps between ~45 launches
+            n_images = 2 * nb
+            sum_p = 0
+            cw, ch = W, H
+            while ch > 12 and cw > 12:      # the octave ladder of pyramid.cpp:520-528 (border 5), cvRound halving
+                sum_p += cw * ch
+                cw, ch = int(round(cw * 0.5)), int(round(ch * 0.5))     # Python rounds half to even, as cvRound does
+            pyr_bytes = n_images * (97.0 * sum_p + 8.0 * W * H)
+            k_ms = sum(pyr_ms[st] for st in ("blur", "blur_small", "response", "resize", "nms"))
+            out["roofline_pyramid"] = {"what": "scale space of a %d-image batch on one stream: every blur / response / decimation launch of every octave + NMS + "
+                                               "compaction (isolated leg)" % n_images,
+                                       "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "bytes_model": "SURVEY 8d: 97 B/px over all octaves + 8 B/px initial blur",
+                                       "algorithmic_bytes": pyr_bytes, "stage_ms": {st: round(v, 4) for st, v in pyr_ms.items()},
+                                       "kernels": {"ms": round(k_ms, 4), "achieved": round(gbs(pyr_bytes, k_ms), 2), "frac": round(gbs(pyr_bytes, k_ms) / HBM_PEAK_GBS, 4)},
+                                       "large_planes_only": {"what": "blur (32-row tiles) + response + decimation + NMS: the four scopes round 2 was judged on",
+                                                             "ms": round(k_ms - pyr_ms["blur_small"], 4),
+                                                             "frac": round(gbs(pyr_bytes, k_ms - pyr_ms["blur_small"]) / HBM_PEAK_GBS, 4)},
+                                       "one_scope": {"ms": round(pyr_ms["pyramid"], 4), "achieved": round(gbs(pyr_bytes, pyr_ms["pyramid"]), 2),
+                                                     "frac": round(gbs(pyr_bytes, pyr_ms["pyramid"]) / HBM_PEAK_GBS, 4)}}
         if match_leg:
             nq, nt, mms, ntent = match_leg
             ops = 2.0 * nq * nt * 128

@@ -646,7 +646,9 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   int *key_count = ctx->cand_count + 2 * ctx->batch;
   const float *orimask = ctx->desc_tables_dev, *dmask = ctx->desc_tables_dev + 4096;
   const SiftTab *tab = (const SiftTab *)(ctx->desc_tables_dev + 8192);
-  if (ctx->shape_fn && (rc = external_shape(ctx, img_dev, n_img, k, key_count, dmask, tab))) return rc;
+  // doExternalAffineAdaptation is set in the HessianAffine branch of the detector dispatch only (imagerepresentation.cpp:733-737):
+  // the regions of DoG / HarrisAffine / MSER views keep their own frames
+  if (ctx->shape_fn && ctx->par.detectorType == MODS_DET_HESSIAN && (rc = external_shape(ctx, img_dev, n_img, k, key_count, dmask, tab))) return rc;
   if (ctx->ori_fn) {
     if ((rc = external_orientation(ctx, img_dev, n_img, k, key_count, dmask, tab))) return rc;
   } else {
