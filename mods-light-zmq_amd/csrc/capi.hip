@@ -98,7 +98,7 @@ static int ctx_create_impl(int device, int max_w, int max_h, int batch, unsigned
   MODS_HIP_CHECK(hipMalloc(&c->rank_dev, sizeof(int) * mc * batch));
   c->nms_mask_words = (px / 64 + (size_t)max_h + 64) * kMaxLevels * batch;
   MODS_HIP_CHECK(hipMalloc(&c->nms_mask, sizeof(unsigned long long) * c->nms_mask_words));
-  MODS_HIP_CHECK(hipHostMalloc(&c->host_counts, sizeof(int) * 4 * batch));
+  MODS_HIP_CHECK(hipHostMalloc(&c->host_counts, sizeof(int) * (5 * batch + 4)));   // cand / acc / key / region / inside counts, error flag
   MODS_HIP_CHECK(hipMalloc(&c->ori_dev, 48 * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->regions_dev, sizeof(mods_region) * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->region_count, sizeof(int) * 3 * batch));   // regions, then 2 tier counts per image

@@ -345,18 +345,28 @@ static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, con
           const size_t cap = std::max<size_t>(need + need / 2, 1 << 14);
           mods_region *nb = nullptr;
           if (hipMalloc(&nb, cap * sizeof(mods_region)) != hipSuccess) { j.rc = MODS_E_HIP; j.err = "view staging: out of device memory"; owner[i] = k; continue; }
+          (void)hipStreamSynchronize(wk->stream);               // copies into the old arena may still be in flight
           if (used) (void)hipMemcpy(nb, A.buf, used * sizeof(mods_region), hipMemcpyDeviceToDevice);
           (void)hipFree(A.buf);
           A.buf = nb; A.cap = cap;
         }
+        // the copies are ordered on the worker's stream before the next view overwrites the context's region lists: no
+        // synchronisation per view, one per worker at the end
         placed[i].off = used;
-        if (j.nr > 0) j.rc = mods_regions_copy_dev(wk, 0, A.buf + used, j.nr);
+        if (j.nr > 0 && hipMemcpyAsync(A.buf + used, wk->regions_dev, sizeof(mods_region) * (size_t)j.nr, hipMemcpyDeviceToDevice, wk->stream) != hipSuccess) j.rc = MODS_E_HIP;
         used += j.nr;
-        if (!j.rc && j.want_half && j.nr > 0) { placed[i].off_half = used; j.rc = mods_regions_half_copy_dev(wk, 0, A.buf + used, j.nr); used += j.nr; }
+        if (!j.rc && j.want_half && j.nr > 0) {
+          placed[i].off_half = used;
+          if (!wk->have_half || !wk->regions_half_dev) { j.rc = MODS_E_ARG; set_error("view job: no HalfRootSIFT descriptors in the context"); }
+          else if (hipMemcpyAsync(A.buf + used, wk->regions_half_dev, sizeof(mods_region) * (size_t)j.nr, hipMemcpyDeviceToDevice, wk->stream) != hipSuccess) j.rc = MODS_E_HIP;
+          used += j.nr;
+        }
+        if (j.rc == MODS_E_HIP) set_error("view job: device copy failed");
       }
       if (j.rc) j.err = mods_last_error();
       owner[i] = k;
     }
+    (void)hipStreamSynchronize(wk->stream);
   };
   std::vector<std::thread> pool;
   for (int k = 1; k < n_workers; k++) pool.emplace_back(work, k);

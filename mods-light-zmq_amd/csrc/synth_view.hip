@@ -290,21 +290,21 @@ int mods_detect_describe_view_dev(mods_ctx *c, const float *src_dev, int w, int 
   // DetectAffineKeypoints / DetectMSERs scale regionsNumber by the SynthImage fields |tilt|, zoom (scale-space-detector.cpp:20-21, extrema.cpp:201-202)
   if ((rc = detect_any(c, c->view_dev, 1, g.w_new, g.h_new, g.w_new, det, g.tilt, g.zoom))) return rc;
   if ((rc = describe_run_view(c, c->view_dev, 1, g.w_new, g.h_new, desc, g.H, w, h, nullptr))) return rc;
-  MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
+  // every count and the error flag of the view in ONE round trip (pinned host words; three synchronisations before)
+  int *hc = c->host_counts;
+  MODS_HIP_CHECK(hipMemcpyAsync(hc, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(hc + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(hc + 4 * c->batch, c->inside_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(hc + 5 * c->batch, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
-  if (c->host_counts[0] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", c->host_counts[0], c->max_cand); return MODS_E_CAPACITY; }
-  if (n_detected) *n_detected = c->host_counts[2 * c->batch];
-  const int nr = c->host_counts[3 * c->batch];
+  if (hc[0] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", hc[0], c->max_cand); return MODS_E_CAPACITY; }
+  if (n_detected) *n_detected = hc[2 * c->batch];
+  const int nr = hc[3 * c->batch];
   if (nr > (c->max_cand < (1 << 17) ? c->max_cand : (1 << 17))) { set_error("region list overflow: %d", nr); return MODS_E_CAPACITY; }
   if (n_regions) *n_regions = nr;
   c->last_region_counts.assign(1, nr);
-  c->last_inside_counts.assign(1, 0);
-  MODS_HIP_CHECK(hipMemcpy(c->last_inside_counts.data(), c->inside_count, sizeof(int), hipMemcpyDeviceToHost));
-  int e = 0;
-  MODS_HIP_CHECK(hipMemcpyAsync(&e, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
-  if (e) {
+  c->last_inside_counts.assign(1, hc[4 * c->batch]);
+  if (hc[5 * c->batch]) {
     MODS_HIP_CHECK(hipMemsetAsync(c->desc_err_dev, 0, sizeof(int), c->stream));
     set_error("measurement region larger than the descriptor scratch");
     return MODS_E_CAPACITY;

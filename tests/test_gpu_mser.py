@@ -192,3 +192,38 @@ def test_mser_degenerate_inputs(pkg):
     with pytest.raises(pkg.ModsError):
         ctx.detect_hessian_affine(img, bad)
     ctx.close()
+
+
+def test_mser_pair_and_pipeline(pkg):
+    """MSER as the detector of mods_match_pair_dev and of the pair pipeline (growth on the pipeline's worker threads): counts,
+    RANSAC statistics and the inlier set against the oracle chain"""
+    import torch
+    import pipeline_oracle as po
+    import refdeg
+    if not refdeg.available():
+        pytest.skip("oracle/_ref not built")
+    w, h = 800, 600
+    a, b, Htrue = synth.pair(w, h, seed=31)
+    regs = tuple(orc.detect_describe(im, orc.HessAffParams.mser()) for im in (a, b))
+    want = po.match_pair(a, b, seed_time=55, regions=regs)
+    par = pkg.PairParams.default()
+    par.det = pkg.HessAffParams.mser()
+    ctx = pkg.Context(0, w, h, 2)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    pkg.ransac_pin_seed(55)
+    res, m = pkg.match_pair_dev(ctx, t.data_ptr(), w, h, par, max_matches=100000)
+    assert list(res.n_detected) == want["n_detected"] and list(res.n_described) == want["n_described"]
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] > 30
+    assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
+    ctx.close()
+    pipe = pkg.Pipeline(0, w, h, par, 2, 2, 2)
+    for i in range(4):
+        pipe.submit(t.data_ptr(), i)
+    for i in range(4):
+        r, tag = pipe.next()
+        assert tag == i and r.n_inliers == want["n_inliers"] and r.n_tentatives == want["n_tentatives"]
+    pipe.close()
+    pkg.ransac_pin_seed(-1)
