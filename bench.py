@@ -234,7 +234,7 @@ def other_configs(args):
         a, b = _hard_pair(synth, np, w, h, 3000)
         t = torch.from_numpy(np.stack([a, b])).cuda()
         d = pkg.view_ctx_dims(w, h)
-        ctx = pkg.Context(0, d[0], d[1], 1)
+        ctx = pkg.Context(0, d[0], d[1], 2)      # two image slots: a view of both images in one chain of launches
         rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
         steps = pkg.iters_mods_steps()
         if args.ladder == "hessian":     # the two HessianAffine sections only (what rounds 1-3 measured)

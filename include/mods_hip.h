@@ -252,6 +252,11 @@ int mods_synth_view_dev(mods_ctx *ctx, const float *src_dev, int w, int h, int s
 int mods_detect_describe_view_dev(mods_ctx *ctx, const float *src_dev, int w, int h, int stride, double tilt, double phi,
                                   double zoom, double initSigma, int doBlur, const mods_hessaff_params *det,
                                   const mods_describe_params *desc, mods_view_geom *geom_out, int *n_detected, int *n_regions);
+/* the same view of TWO images of one size (the two images of a pair share their view schedule) in one chain of launches; the
+ * context needs batch >= 2; regions of image i stay in slot i (mods_regions_fetch(ctx, i, ...)), n_detected2 / n_regions2: [2] */
+int mods_detect_describe_view2_dev(mods_ctx *ctx, const float *src1_dev, const float *src2_dev, int w, int h, int stride, double tilt,
+                                   double phi, double zoom, double initSigma, int doBlur, const mods_hessaff_params *det,
+                                   const mods_describe_params *desc, mods_view_geom *geom_out, int *n_detected2, int *n_regions2);
 const mods_region *mods_regions_dev(mods_ctx *ctx, int img);     /* device pointer of the region list of image `img` */
 /* the same regions with desc[0..63] = HalfRootSIFT, desc[64..127] = 0 (filled when mods_describe_params.halfDesc was set) */
 const mods_region *mods_regions_half_dev(mods_ctx *ctx, int img);

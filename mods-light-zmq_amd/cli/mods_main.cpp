@@ -568,7 +568,10 @@ int main(int argc, char **argv) {
   std::vector<mods_imgrep *> reps1((size_t)n_det, nullptr), reps2((size_t)n_det, nullptr);
   void *d1 = nullptr, *d2 = nullptr;
   auto fail = [&](const char *what) { std::cerr << "mods: " << what << ": " << mods_last_error() << std::endl; return 1; };
-  if (mods_ctx_create(device, (int)diag, (int)diag, 1, &ctx)) return fail("context");
+  // two image slots: the same view of both images goes through one chain of launches when the images have one size.
+  // One run of one pair: further contexts for the views of a step (MODS_LADDER_WORKERS) take longer to set up than they save
+  setenv("MODS_LADDER_WORKERS", "1", 0);
+  if (mods_ctx_create(device, (int)diag, (int)diag, 2, &ctx)) return fail("context");
   for (int d = 0; d < n_det; d++)
     if (mods_imgrep_create(ctx, 1 << 20, &reps1[d]) || mods_imgrep_create(ctx, 1 << 20, &reps2[d])) return fail("region banks");
   if (mods_dev_alloc(sizeof(float) * img1.px.size(), &d1) || mods_dev_alloc(sizeof(float) * img2.px.size(), &d2)) return fail("device memory");

@@ -125,7 +125,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
   (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipHostFree(c->m_count); (void)hipFree(c->m_regs);
   mser_release(c);
-  for (mods_ctx *h : c->helpers) mods_ctx_destroy(h);
+  for (mods_ctx *h : c->helpers) if (h) mods_ctx_destroy(h);
   for (auto &a : c->helper_stage) (void)hipFree(a.buf);
   (void)hipSetDevice(c->device);
   (void)hipStreamDestroy(c->stream);

@@ -307,10 +307,12 @@ __global__ __launch_bounds__(1024) void compact_regions_kernel(DescConst k, cons
 }
 
 // det_kp -> reproj_kp of the described regions of a synthesised view, in place (ReprojectByH: centre and
-// frame through the affine part of inv(H); s, response, descriptor unchanged).  grid-stride, image 0 only.
+// frame through the affine part of inv(H); s, response, descriptor unchanged).  grid = (N, n_img), grid-stride per image.
 __global__ __launch_bounds__(256) void reproject_regions_kernel(DescConst k, mods_region *__restrict__ reg, const int *__restrict__ reg_count) {
-  int n = reg_count[0];
+  const int b = blockIdx.y;
+  int n = reg_count[b];
   if (n > k.max_reg) n = k.max_reg;
+  reg += (size_t)b * k.max_reg;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     mods_region *r = reg + i;
     const double x = r->x, y = r->y, a11 = r->a11, a12 = r->a12, a21 = r->a21, a22 = r->a22;
@@ -620,7 +622,7 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   if (H) {
     const bool eye = (std::fabs(H[0] - 1.0) + std::fabs(H[1]) + std::fabs(H[2]) + std::fabs(H[3]) + std::fabs(H[4] - 1.0) + std::fabs(H[5]) +
                       std::fabs(H[6]) + std::fabs(H[7]) + std::fabs(H[8] - 1.0) < 0.01);
-    if (n_img != 1 && !eye) { set_error("a synthesised view is described one image at a time"); return MODS_E_ARG; }
+    // (n_img > 1: the same view of several images of one size - one H for all of them)
     k.ow = orig_w; k.oh = orig_h;
     if (!eye) {
       double Hi[9];
@@ -672,9 +674,9 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   if (det_copy_dev)
     MODS_HIP_CHECK(hipMemcpyAsync(det_copy_dev, ctx->regions_dev, sizeof(mods_region) * (size_t)ctx->max_cand, hipMemcpyDeviceToDevice, ctx->stream));
   if (k.view) {
-    hipLaunchKernelGGL(reproject_regions_kernel, dim3(256), dim3(256), 0, ctx->stream, k, ctx->regions_dev, ctx->region_count);
+    hipLaunchKernelGGL(reproject_regions_kernel, dim3(256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev, ctx->region_count);
     if (ctx->have_half)
-      hipLaunchKernelGGL(reproject_regions_kernel, dim3(256), dim3(256), 0, ctx->stream, k, ctx->regions_half_dev, ctx->region_count);
+      hipLaunchKernelGGL(reproject_regions_kernel, dim3(256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_half_dev, ctx->region_count);
     MODS_HIP_CHECK(hipGetLastError());
   }
   return MODS_OK;

@@ -312,64 +312,115 @@ struct ViewJob {
 static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
                          const mods_hessaff_params *dets, std::vector<ViewJob> &jobs) {
   static const int env_workers = getenv("MODS_LADDER_WORKERS") ? atoi(getenv("MODS_LADDER_WORKERS")) : 4;
+  static const bool no_pairs = getenv("MODS_LADDER_NO_PAIRS") != nullptr;
   int n_workers = std::max(1, std::min(env_workers, 8));
   if (c->ext_fn || c->shape_fn || c->ori_fn) n_workers = 1;      // the daemons' hooks belong to one context
-  n_workers = std::min<int>(n_workers, (int)jobs.size());
   if (jobs.empty()) return MODS_OK;
-  while ((int)c->helpers.size() < n_workers - 1) {
-    mods_ctx *h = nullptr;
-    const int rc = mods_ctx_create_ex(c->device, c->max_w, c->max_h, 1, 1, &h);
-    if (rc) return rc;
-    c->helpers.push_back(h);
+  // Work units: a view of image 1 and the same view of image 2 go through ONE chain of launches when the images have one size
+  // (both images of a pair share their view schedule) and the contexts hold two images; otherwise one job per unit.
+  struct Unit { int a, b; };                                     // job indices; b < 0: a single view
+  std::vector<Unit> units;
+  const bool pair_ok = !no_pairs && w1 == w2 && h1 == h2 && !(c->ext_fn || c->shape_fn || c->ori_fn);
+  {
+    std::vector<char> used(jobs.size(), 0);
+    for (size_t i = 0; i < jobs.size(); i++) {
+      if (used[i]) continue;
+      int mate = -1;
+      if (pair_ok && jobs[i].im == 0)
+        for (size_t k = i + 1; k < jobs.size() && mate < 0; k++)
+          if (!used[k] && jobs[k].im == 1 && jobs[k].d == jobs[i].d && jobs[k].vp.zoom == jobs[i].vp.zoom && jobs[k].vp.tilt == jobs[i].vp.tilt &&
+              jobs[k].vp.phi == jobs[i].vp.phi && jobs[k].initSigma == jobs[i].initSigma && jobs[k].doBlur == jobs[i].doBlur)
+            mate = (int)k;
+      used[i] = 1;
+      if (mate >= 0) used[mate] = 1;
+      units.push_back({(int)i, mate});
+    }
   }
+  n_workers = std::min<int>(n_workers, (int)units.size());
+  // helper contexts are made by their own threads, side by side and only while enough units are left to be worth the ~35 ms a
+  // context takes to set up (a one-shot run with a handful of views is faster on the caller's context alone)
+  if ((int)c->helpers.size() < n_workers - 1) c->helpers.resize(n_workers - 1, nullptr);
   if ((int)c->helper_stage.size() < n_workers) c->helper_stage.resize(n_workers);
   struct Placed { size_t off, off_half; };
   std::vector<Placed> placed(jobs.size());
   std::vector<int> owner(jobs.size(), 0);
   std::atomic<int> next(0);
   auto work = [&](int k) {
+    (void)hipSetDevice(c->device);
+    if (k > 0 && !c->helpers[k - 1]) {
+      if ((int)units.size() - next.load() < 3 * (k + 1)) return;
+      mods_ctx *h = nullptr;
+      if (mods_ctx_create_ex(c->device, c->max_w, c->max_h, 2, 1, &h)) return;      // the other workers take the units
+      c->helpers[k - 1] = h;
+    }
     mods_ctx *wk = k == 0 ? c : c->helpers[k - 1];
     mods_ctx::StageArena &A = c->helper_stage[k];
     size_t used = 0;
-    (void)hipSetDevice(c->device);
-    for (int i; (i = next.fetch_add(1)) < (int)jobs.size();) {
-      ViewJob &j = jobs[i];
-      const float *img = j.im ? img2_dev : img1_dev;
-      const int w = j.im ? w2 : w1, h = j.im ? h2 : h1;
-      j.rc = mods_detect_describe_view_dev(wk, img, w, h, w, j.vp.tilt, j.vp.phi, j.vp.zoom, j.initSigma, j.doBlur, &dets[j.d], &j.desc, nullptr,
-                                           &j.nd, &j.nr);
-      if (!j.rc) {
-        j.unoriented = mods_unoriented_count(wk, 0);
-        const size_t need = used + (size_t)j.nr * (j.want_half ? 2 : 1);
-        if (need > A.cap) {                                     // grow, keeping what earlier jobs of this step left
-          const size_t cap = std::max<size_t>(need + need / 2, 1 << 14);
-          mods_region *nb = nullptr;
-          if (hipMalloc(&nb, cap * sizeof(mods_region)) != hipSuccess) { j.rc = MODS_E_HIP; j.err = "view staging: out of device memory"; owner[i] = k; continue; }
-          (void)hipStreamSynchronize(wk->stream);               // copies into the old arena may still be in flight
-          if (used) (void)hipMemcpy(nb, A.buf, used * sizeof(mods_region), hipMemcpyDeviceToDevice);
-          (void)hipFree(A.buf);
-          A.buf = nb; A.cap = cap;
-        }
-        // the copies are ordered on the worker's stream before the next view overwrites the context's region lists: no
-        // synchronisation per view, one per worker at the end
-        placed[i].off = used;
-        if (j.nr > 0 && hipMemcpyAsync(A.buf + used, wk->regions_dev, sizeof(mods_region) * (size_t)j.nr, hipMemcpyDeviceToDevice, wk->stream) != hipSuccess) j.rc = MODS_E_HIP;
-        used += j.nr;
-        if (!j.rc && j.want_half && j.nr > 0) {
-          placed[i].off_half = used;
-          if (!wk->have_half || !wk->regions_half_dev) { j.rc = MODS_E_ARG; set_error("view job: no HalfRootSIFT descriptors in the context"); }
-          else if (hipMemcpyAsync(A.buf + used, wk->regions_half_dev, sizeof(mods_region) * (size_t)j.nr, hipMemcpyDeviceToDevice, wk->stream) != hipSuccess) j.rc = MODS_E_HIP;
-          used += j.nr;
-        }
-        if (j.rc == MODS_E_HIP) set_error("view job: device copy failed");
+    auto park = [&](int ji, int slot) {                         // regions of context slot `slot` -> this worker's arena
+      ViewJob &j = jobs[ji];
+      const size_t need = used + (size_t)j.nr * (j.want_half ? 2 : 1);
+      if (need > A.cap) {                                       // grow, keeping what earlier jobs of this step left
+        const size_t cap = std::max<size_t>(need + need / 2, 1 << 14);
+        mods_region *nb = nullptr;
+        if (hipMalloc(&nb, cap * sizeof(mods_region)) != hipSuccess) { j.rc = MODS_E_HIP; set_error("view staging: out of device memory"); return; }
+        (void)hipStreamSynchronize(wk->stream);                 // copies into the old arena may still be in flight
+        if (used) (void)hipMemcpy(nb, A.buf, used * sizeof(mods_region), hipMemcpyDeviceToDevice);
+        (void)hipFree(A.buf);
+        A.buf = nb; A.cap = cap;
       }
-      if (j.rc) j.err = mods_last_error();
-      owner[i] = k;
+      // the copies are ordered on the worker's stream before the next view overwrites the context's region lists: no
+      // synchronisation per view, one per worker at the end
+      placed[ji].off = used;
+      if (j.nr > 0 && hipMemcpyAsync(A.buf + used, wk->regions_dev + (size_t)slot * wk->max_cand, sizeof(mods_region) * (size_t)j.nr, hipMemcpyDeviceToDevice,
+                                     wk->stream) != hipSuccess) j.rc = MODS_E_HIP;
+      used += j.nr;
+      if (!j.rc && j.want_half && j.nr > 0) {
+        placed[ji].off_half = used;
+        if (!wk->have_half || !wk->regions_half_dev) { j.rc = MODS_E_ARG; set_error("view job: no HalfRootSIFT descriptors in the context"); }
+        else if (hipMemcpyAsync(A.buf + used, wk->regions_half_dev + (size_t)slot * wk->max_cand, sizeof(mods_region) * (size_t)j.nr, hipMemcpyDeviceToDevice,
+                                wk->stream) != hipSuccess) j.rc = MODS_E_HIP;
+        used += j.nr;
+      }
+      if (j.rc == MODS_E_HIP) set_error("view job: device copy failed");
+    };
+    for (int u; (u = next.fetch_add(1)) < (int)units.size();) {
+      const Unit un = units[u];
+      ViewJob &j = jobs[un.a];
+      if (un.b >= 0 && wk->batch >= 2) {                        // both images of the pair through one chain of launches
+        ViewJob &j2 = jobs[un.b];
+        int nd[2] = {0, 0}, nr[2] = {0, 0};
+        j.rc = mods_detect_describe_view2_dev(wk, img1_dev, img2_dev, w1, h1, w1, j.vp.tilt, j.vp.phi, j.vp.zoom, j.initSigma, j.doBlur, &dets[j.d],
+                                              &j.desc, nullptr, nd, nr);
+        j2.rc = j.rc;
+        if (!j.rc) {
+          j.nd = nd[0]; j.nr = nr[0]; j.unoriented = mods_unoriented_count(wk, 0);
+          j2.nd = nd[1]; j2.nr = nr[1]; j2.unoriented = mods_unoriented_count(wk, 1);
+          park(un.a, 0);
+          if (!j.rc) park(un.b, 1);
+        }
+        if (j.rc) j.err = mods_last_error();
+        if (j2.rc) j2.err = mods_last_error();
+        owner[un.a] = owner[un.b] = k;
+        continue;
+      }
+      for (int ji : {un.a, un.b}) {
+        if (ji < 0) continue;
+        ViewJob &q = jobs[ji];
+        const float *img = q.im ? img2_dev : img1_dev;
+        const int w = q.im ? w2 : w1, h = q.im ? h2 : h1;
+        q.rc = mods_detect_describe_view_dev(wk, img, w, h, w, q.vp.tilt, q.vp.phi, q.vp.zoom, q.initSigma, q.doBlur, &dets[q.d], &q.desc, nullptr,
+                                             &q.nd, &q.nr);
+        if (!q.rc) { q.unoriented = mods_unoriented_count(wk, 0); park(ji, 0); }
+        if (q.rc) q.err = mods_last_error();
+        owner[ji] = k;
+      }
     }
     (void)hipStreamSynchronize(wk->stream);
   };
   std::vector<std::thread> pool;
-  for (int k = 1; k < n_workers; k++) pool.emplace_back(work, k);
+  try {
+    for (int k = 1; k < n_workers; k++) pool.emplace_back(work, k);
+  } catch (...) {}                       // fewer threads than asked for: the others (at least the caller) take the jobs
   work(0);
   for (auto &t : pool) t.join();
   for (size_t i = 0; i < jobs.size(); i++) {

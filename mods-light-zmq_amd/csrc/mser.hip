@@ -331,28 +331,34 @@ int mser_detect(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int 
   std::vector<std::vector<mser::Stable>> stable(n_jobs);
   {
     std::atomic<int> next(0);
+    std::atomic<bool> oom(false);
     auto work = [&]() {
-      mser::Grower g;
-      std::vector<uint8_t> padded(P, 0);
-      for (int j; (j = next.fetch_add(1)) < n_jobs;) {
-        const unsigned char *src = S.h_img8 + (size_t)(j >> 1) * npx;
-        const bool inv = (j & 1) != 0;
-        for (int y = 0; y < h; y++) {
-          uint8_t *d = padded.data() + (size_t)(y + 1) * cols + 1;
-          const unsigned char *s = src + (size_t)y * w;
-          if (inv) for (int x = 0; x < w; x++) d[x] = (uint8_t)(255 - s[x]);          // InvertImageAndHistogram, sortPixels.cpp:134-153
-          else std::memcpy(d, s, w);
+      try {
+        mser::Grower g;
+        std::vector<uint8_t> padded(P, 0);
+        for (int j; (j = next.fetch_add(1)) < n_jobs;) {
+          const unsigned char *src = S.h_img8 + (size_t)(j >> 1) * npx;
+          const bool inv = (j & 1) != 0;
+          for (int y = 0; y < h; y++) {
+            uint8_t *d = padded.data() + (size_t)(y + 1) * cols + 1;
+            const unsigned char *s = src + (size_t)y * w;
+            if (inv) for (int x = 0; x < w; x++) d[x] = (uint8_t)(255 - s[x]);          // InvertImageAndHistogram, sortPixels.cpp:134-153
+            else std::memcpy(d, s, w);
+          }
+          mser::GrowParams q = gp;
+          q.invert = inv;
+          g.run(padded.data(), w, h, q, S.h_pix_slot + j * P, S.h_tpar + j * P, S.h_tlev + j * P, stable[j]);
         }
-        mser::GrowParams q = gp;
-        q.invert = inv;
-        g.run(padded.data(), w, h, q, S.h_pix_slot + j * P, S.h_tpar + j * P, S.h_tlev + j * P, stable[j]);
-      }
+      } catch (...) { oom = true; }      // std::bad_alloc: nothing else throws in there
     };
     const int n_thr = std::max(1, std::min<int>(n_jobs, std::min(8u, std::max(1u, std::thread::hardware_concurrency()))));
     std::vector<std::thread> pool;
-    for (int t = 1; t < n_thr; t++) pool.emplace_back(work);
+    try {
+      for (int t = 1; t < n_thr; t++) pool.emplace_back(work);
+    } catch (...) {}                     // fewer threads than asked for: the others (at least the caller) take the jobs
     work();
     for (auto &t : pool) t.join();
+    if (oom) { set_error("MSER: the grey-level growth ran out of host memory"); return MODS_E_HIP; }
   }
 
   // 3. tables: unique (slot, threshold) pairs per job; the keypoints in the reference's order

@@ -254,12 +254,65 @@ int mods_gauss_blur_xy(mods_ctx *c, const float *src, int w, int h, int kx, int 
   if (!c || !src || !dst) { set_error("gauss_blur_xy: null argument"); return MODS_E_ARG; }
   if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image larger than the context"); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
-  if (!c->view_dev) MODS_HIP_CHECK(hipMalloc(&c->view_dev, sizeof(float) * (size_t)c->max_w * c->max_h));
+  if (!c->view_dev) MODS_HIP_CHECK(hipMalloc(&c->view_dev, sizeof(float) * (size_t)c->max_w * c->max_h * c->batch));
   MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev, src, sizeof(float) * (size_t)w * h, hipMemcpyHostToDevice, c->stream));
   int rc = launch_blur_xy_reflect(c, c->input_dev, c->tmp_dev, c->view_dev, w, h, kx, ky, sx, sy);
   if (rc) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(dst, c->view_dev, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return MODS_OK;
+}
+
+// n_src = 1 or 2 images of one size seen through the SAME view (both images of a pair have the same view schedule): one
+// chain of launches for both - a view of a hard pair is ~100 launches of a few microseconds, so the count is the cost.
+static int view_detect_describe(mods_ctx *c, const float *const *src_dev, int n_src, int w, int h, int stride, double tilt, double phi,
+                                double zoom, double initSigma, int doBlur, const mods_hessaff_params *det, const mods_describe_params *desc,
+                                mods_view_geom *geom_out, int *n_detected, int *n_regions) {
+  if (!c || !src_dev || !det || !desc || n_src < 1 || n_src > c->batch) { set_error("detect_describe_view: bad argument"); return MODS_E_ARG; }
+  for (int i = 0; i < n_src; i++) if (!src_dev[i]) { set_error("detect_describe_view: null image"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  mods_view_geom g;
+  int rc = mods_view_geometry(w, h, tilt, phi, zoom, initSigma, &g);
+  if (rc) return rc;
+  if (geom_out) *geom_out = g;
+  if ((size_t)g.w_new * g.h_new > (size_t)c->max_w * c->max_h) { set_error("view %dx%d larger than the context", g.w_new, g.h_new); return MODS_E_ARG; }
+  if (g.w_new < 16 || g.h_new < 16) {   // nothing to detect on a sliver
+    for (int i = 0; i < n_src; i++) { if (n_detected) n_detected[i] = 0; if (n_regions) n_regions[i] = 0; }
+    MODS_HIP_CHECK(hipMemsetAsync(c->region_count, 0, sizeof(int) * n_src, c->stream));
+    c->last_region_counts.assign(n_src, 0);
+    c->last_inside_counts.assign(n_src, 0);
+    return MODS_OK;
+  }
+  if (!c->view_dev) MODS_HIP_CHECK(hipMalloc(&c->view_dev, sizeof(float) * (size_t)c->max_w * c->max_h * c->batch));
+  const size_t vpx = (size_t)g.w_new * g.h_new;
+  for (int i = 0; i < n_src; i++)
+    if ((rc = mods_synth_view_dev(c, src_dev[i], w, h, stride, &g, doBlur, c->view_dev + i * vpx))) return rc;
+  // DetectAffineKeypoints / DetectMSERs scale regionsNumber by the SynthImage fields |tilt|, zoom (scale-space-detector.cpp:20-21, extrema.cpp:201-202)
+  if ((rc = detect_any(c, c->view_dev, n_src, g.w_new, g.h_new, g.w_new, det, g.tilt, g.zoom))) return rc;
+  if ((rc = describe_run_view(c, c->view_dev, n_src, g.w_new, g.h_new, desc, g.H, w, h, nullptr))) return rc;
+  // every count and the error flag of the view in ONE round trip (pinned host words; three synchronisations before)
+  int *hc = c->host_counts;
+  MODS_HIP_CHECK(hipMemcpyAsync(hc, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(hc + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(hc + 4 * c->batch, c->inside_count, sizeof(int) * n_src, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(hc + 5 * c->batch, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->last_region_counts.assign(n_src, 0);
+  c->last_inside_counts.assign(n_src, 0);
+  for (int i = 0; i < n_src; i++) {
+    if (hc[i] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", hc[i], c->max_cand); return MODS_E_CAPACITY; }
+    if (n_detected) n_detected[i] = hc[2 * c->batch + i];
+    const int nr = hc[3 * c->batch + i];
+    if (nr > (c->max_cand < (1 << 17) ? c->max_cand : (1 << 17))) { set_error("region list overflow: %d", nr); return MODS_E_CAPACITY; }
+    if (n_regions) n_regions[i] = nr;
+    c->last_region_counts[i] = nr;
+    c->last_inside_counts[i] = hc[4 * c->batch + i];
+  }
+  if (hc[5 * c->batch]) {
+    MODS_HIP_CHECK(hipMemsetAsync(c->desc_err_dev, 0, sizeof(int), c->stream));
+    set_error("measurement region larger than the descriptor scratch");
+    return MODS_E_CAPACITY;
+  }
   return MODS_OK;
 }
 
@@ -270,46 +323,16 @@ int mods_gauss_blur_xy(mods_ctx *c, const float *src, int w, int h, int kx, int 
 int mods_detect_describe_view_dev(mods_ctx *c, const float *src_dev, int w, int h, int stride, double tilt, double phi, double zoom,
                                   double initSigma, int doBlur, const mods_hessaff_params *det, const mods_describe_params *desc,
                                   mods_view_geom *geom_out, int *n_detected, int *n_regions) {
-  if (!c || !src_dev || !det || !desc) { set_error("detect_describe_view: null argument"); return MODS_E_ARG; }
-  MODS_HIP_CHECK(hipSetDevice(c->device));
-  mods_view_geom g;
-  int rc = mods_view_geometry(w, h, tilt, phi, zoom, initSigma, &g);
-  if (rc) return rc;
-  if (geom_out) *geom_out = g;
-  if ((size_t)g.w_new * g.h_new > (size_t)c->max_w * c->max_h) { set_error("view %dx%d larger than the context", g.w_new, g.h_new); return MODS_E_ARG; }
-  if (g.w_new < 16 || g.h_new < 16) {   // nothing to detect on a sliver
-    if (n_detected) *n_detected = 0;
-    if (n_regions) *n_regions = 0;
-    MODS_HIP_CHECK(hipMemsetAsync(c->region_count, 0, sizeof(int), c->stream));
-    c->last_region_counts.assign(1, 0);
-    c->last_inside_counts.assign(1, 0);
-    return MODS_OK;
-  }
-  if (!c->view_dev) MODS_HIP_CHECK(hipMalloc(&c->view_dev, sizeof(float) * (size_t)c->max_w * c->max_h));
-  if ((rc = mods_synth_view_dev(c, src_dev, w, h, stride, &g, doBlur, c->view_dev))) return rc;
-  // DetectAffineKeypoints / DetectMSERs scale regionsNumber by the SynthImage fields |tilt|, zoom (scale-space-detector.cpp:20-21, extrema.cpp:201-202)
-  if ((rc = detect_any(c, c->view_dev, 1, g.w_new, g.h_new, g.w_new, det, g.tilt, g.zoom))) return rc;
-  if ((rc = describe_run_view(c, c->view_dev, 1, g.w_new, g.h_new, desc, g.H, w, h, nullptr))) return rc;
-  // every count and the error flag of the view in ONE round trip (pinned host words; three synchronisations before)
-  int *hc = c->host_counts;
-  MODS_HIP_CHECK(hipMemcpyAsync(hc, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipMemcpyAsync(hc + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipMemcpyAsync(hc + 4 * c->batch, c->inside_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipMemcpyAsync(hc + 5 * c->batch, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
-  if (hc[0] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", hc[0], c->max_cand); return MODS_E_CAPACITY; }
-  if (n_detected) *n_detected = hc[2 * c->batch];
-  const int nr = hc[3 * c->batch];
-  if (nr > (c->max_cand < (1 << 17) ? c->max_cand : (1 << 17))) { set_error("region list overflow: %d", nr); return MODS_E_CAPACITY; }
-  if (n_regions) *n_regions = nr;
-  c->last_region_counts.assign(1, nr);
-  c->last_inside_counts.assign(1, hc[4 * c->batch]);
-  if (hc[5 * c->batch]) {
-    MODS_HIP_CHECK(hipMemsetAsync(c->desc_err_dev, 0, sizeof(int), c->stream));
-    set_error("measurement region larger than the descriptor scratch");
-    return MODS_E_CAPACITY;
-  }
-  return MODS_OK;
+  const float *srcs[1] = {src_dev};
+  return view_detect_describe(c, srcs, 1, w, h, stride, tilt, phi, zoom, initSigma, doBlur, det, desc, geom_out, n_detected, n_regions);
+}
+
+// The same view of two images of one size in one chain of launches (context batch >= 2): regions of image i in slot i.
+int mods_detect_describe_view2_dev(mods_ctx *c, const float *src1_dev, const float *src2_dev, int w, int h, int stride, double tilt,
+                                   double phi, double zoom, double initSigma, int doBlur, const mods_hessaff_params *det,
+                                   const mods_describe_params *desc, mods_view_geom *geom_out, int *n_detected2, int *n_regions2) {
+  const float *srcs[2] = {src1_dev, src2_dev};
+  return view_detect_describe(c, srcs, 2, w, h, stride, tilt, phi, zoom, initSigma, doBlur, det, desc, geom_out, n_detected2, n_regions2);
 }
 
 int mods_view_fetch(mods_ctx *c, const mods_view_geom *g, float *dst_host) {
