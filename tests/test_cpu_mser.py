@@ -148,3 +148,36 @@ def test_library_exports_the_mser_symbols(pkg):
     assert hasattr(lib, "mods_test_mser_grow")
     assert C.sizeof(pkg.HessAffParams) == 88 == C.sizeof(orc.HessAffParams)
     assert pkg.HessAffParams.mser().detectorType == 3
+
+
+def _fuzz_image(rng, it):
+    w, h = int(rng.integers(8, 90)), int(rng.integers(8, 70))
+    kind = it % 4
+    if kind == 0:
+        img = rng.integers(0, 4, (h, w)) * 60.0                      # four grey levels: plateaus everywhere
+    elif kind == 1:
+        img = rng.integers(0, 256, (h, w)).astype(float)
+    elif kind == 2:
+        img = np.kron(rng.integers(0, 6, (h // 6 + 1, w // 6 + 1)) * 40.0, np.ones((6, 6)))[:h, :w] + rng.integers(0, 2, (h, w))
+    else:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (128 + 100 * np.sin(xx / 5.0) * np.cos(yy / 7.0) + rng.integers(0, 3, (h, w))).clip(0, 255)
+    return np.ascontiguousarray(img, np.float32)
+
+
+def test_host_growth_equals_oracle_on_random_plateau_images(pkg):
+    """160 small images of four kinds (a few grey levels, white noise, blocky, smooth + noise) with min_size down to 1 and
+    max_area up to 0.9: the order inside a grey level, min-region labels absorbing regions, recycled region records - every
+    stable (seed, threshold, margin, area) row of both polarities equal to the oracle's."""
+    rng = np.random.default_rng(12345)
+    regions = 0
+    for it in range(160):
+        img = _fuzz_image(rng, it)
+        ms, mm, ma = int(rng.choice([1, 2, 5, 12, 30])), float(rng.choice([1, 2, 3, 8])), float(rng.choice([0.05, 0.3, 0.9]))
+        info, runs, ell = orc.mser_regions(img, orc.HessAffParams.mser(min_margin=mm, max_area=ma, min_size=ms))
+        u8 = _u8(img)
+        for pol in (0, 1):
+            got, _ = _grow(pkg, u8, pol, ms, ma, mm)
+            assert np.array_equal(got, info[info[:, 8] == pol][:, [6, 7, 0, 1, 4]]), (it, pol)
+            regions += len(got)
+    assert regions > 5000

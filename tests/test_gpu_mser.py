@@ -227,3 +227,21 @@ def test_mser_pair_and_pipeline(pkg):
         assert tag == i and r.n_inliers == want["n_inliers"] and r.n_tentatives == want["n_tentatives"]
     pipe.close()
     pkg.ransac_pin_seed(-1)
+
+
+def test_mser_random_plateau_images(pkg):
+    """the random small images of tests/test_cpu_mser.py (few grey levels, noise, blocks) through the whole detector: nested regions
+    of every depth, one-pixel runs, regions touching the frame"""
+    from test_cpu_mser import _fuzz_image
+    rng = np.random.default_rng(777)
+    ctx = pkg.Context(0, 128, 128, 1)
+    n = 0
+    for it in range(60):
+        img = _fuzz_image(rng, it)
+        kw = dict(min_size=int(rng.choice([1, 5, 30])), min_margin=float(rng.choice([1, 3, 8])), max_area=float(rng.choice([0.05, 0.9])))
+        want = orc.detect_hessian_affine(img, orc.HessAffParams.mser(**kw))
+        got = ctx.detect_hessian_affine(img, pkg.HessAffParams.mser(**kw))
+        same_keys(got, want)
+        n += len(want)
+    assert n > 2000
+    ctx.close()
