@@ -123,7 +123,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
-  (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipHostFree(c->m_count); (void)hipFree(c->m_regs);
+  (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipFree(c->m_tent_batch); (void)hipHostFree(c->m_count); (void)hipFree(c->m_regs);
   mser_release(c);
   for (mods_ctx *h : c->helpers) if (h) mods_ctx_destroy(h);
   for (auto &a : c->helper_stage) (void)hipFree(a.buf);
@@ -818,32 +818,58 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
   // correspondences | frames) is ONE transfer queued behind its match kernels, the stream is synchronised once per pair for the COUNT only (4 bytes) and once
   // per batch for the lists; a pair that does not fit the arena takes the direct (pageable, synchronous) path.
   if (!c->pin_arena) { MODS_HIP_CHECK(hipHostMalloc(&c->pin_arena, kPinArena)); c->pin_arena_cap = kPinArena; }
-  std::vector<size_t> off(n_pairs, (size_t)-1);
-  size_t used = 0;
+  // every pair's search is queued without waiting: the packed list of pair i goes to its own segment of a device arena (a
+  // list is at most as long as the query list), its length to slot i of the pinned counter array.  Then ONE synchronisation
+  // for the lengths, the transfers of exactly those bytes, and one more for the lists (before: a synchronisation per pair).
+  if (n_pairs > 63) { set_error("match_pairs: at most 63 pairs per batch"); return MODS_E_ARG; }
+  std::vector<size_t> seg(n_pairs + 1, 0);
+  for (int i = 0; i < n_pairs; i++) seg[i + 1] = seg[i] + ((tent_bytes((size_t)std::max(nr[2 * i], 1)) + 255) & ~(size_t)255);
+  if ((rc = match_ensure_buffers(c))) return rc;
+  if (seg[n_pairs] > c->m_tent_batch_cap) {
+    if (c->m_tent_batch) MODS_HIP_CHECK(hipFree(c->m_tent_batch));
+    c->m_tent_batch = nullptr; c->m_tent_batch_cap = 0;
+    MODS_HIP_CHECK(hipMalloc(&c->m_tent_batch, seg[n_pairs] + seg[n_pairs] / 4));
+    c->m_tent_batch_cap = seg[n_pairs] + seg[n_pairs] / 4;
+  }
+  const double tm0 = now_ms();
   for (int i = 0; i < n_pairs; i++) {
-    const double tm0 = now_ms();
     mods_pair_result *r = res[i];
     r->n_detected[0] = nd[2 * i]; r->n_detected[1] = nd[2 * i + 1];
     r->n_described[0] = nr[2 * i]; r->n_described[1] = nr[2 * i + 1];
     r->ms_detect_describe = (t1 - t0) / n_pairs;
-    if ((rc = match_run(c, c->regions_dev + (size_t)(2 * i) * c->max_cand, nr[2 * i], c->regions_dev + (size_t)(2 * i + 1) * c->max_cand,
-                        nr[2 * i + 1], par->fginn_ratio, par->contradDist, par->nn))) return rc;
-    MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    const int n = *(volatile int *)c->m_count;
-    r->n_tentatives = n;
-    if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
+    c->m_tent_out = (mods_tentative *)(c->m_tent_batch + seg[i]);
+    c->m_count_out = c->m_count + 1 + i;
+    rc = match_run(c, c->regions_dev + (size_t)(2 * i) * c->max_cand, nr[2 * i], c->regions_dev + (size_t)(2 * i + 1) * c->max_cand,
+                   nr[2 * i + 1], par->fginn_ratio, par->contradDist, par->nn);
+    c->m_tent_out = nullptr; c->m_count_out = nullptr;
+    if (rc) return rc;
+  }
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  std::vector<size_t> off(n_pairs, (size_t)-1);
+  size_t used = 0;
+  for (int i = 0; i < n_pairs; i++) {
+    const int n = ((volatile int *)c->m_count)[1 + i];
+    res[i]->n_tentatives = n;
+    if (n > c->max_cand || n > nr[2 * i]) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
     tent[i]->resize(n); u6[i]->resize((size_t)n * 6); laf[i]->resize((size_t)n * 14);
     if (n > 0) {
       const size_t bytes = tent_bytes((size_t)n);
       if (used + bytes <= c->pin_arena_cap) {
-        MODS_HIP_CHECK(hipMemcpyAsync(c->pin_arena + used, c->m_tent, bytes, hipMemcpyDeviceToHost, c->stream));
+        MODS_HIP_CHECK(hipMemcpyAsync(c->pin_arena + used, c->m_tent_batch + seg[i], bytes, hipMemcpyDeviceToHost, c->stream));
         off[i] = used; used += (bytes + 15) & ~(size_t)15;
-      } else if ((rc = mods_match_copy_out(c, n, tent[i]->data(), u6[i]->data(), laf[i]->data()))) return rc;
+      } else {      // a list that does not fit the arena: the direct (pageable, synchronous) path
+        std::vector<char> stage(bytes);
+        MODS_HIP_CHECK(hipMemcpy(stage.data(), c->m_tent_batch + seg[i], bytes, hipMemcpyDeviceToHost));
+        memcpy(tent[i]->data(), stage.data(), sizeof(mods_tentative) * n);
+        memcpy(u6[i]->data(), stage.data() + tent_u6_off(n), sizeof(double) * 6 * n);
+        memcpy(laf[i]->data(), stage.data() + tent_laf_off(n), sizeof(double) * 14 * n);
+      }
     }
-    r->ms_match = now_ms() - tm0;
   }
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  const double tm1 = now_ms();
   for (int i = 0; i < n_pairs; i++) {
+    res[i]->ms_match = (tm1 - tm0) / n_pairs;
     if (off[i] == (size_t)-1) continue;
     const size_t n = tent[i]->size();
     const char *a = c->pin_arena + off[i];

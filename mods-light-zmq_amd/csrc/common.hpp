@@ -150,7 +150,9 @@ struct mods_ctx {
   // m_tent holds the n tentatives of the last search PACKED: mods_tentative[n] | (16-byte aligned) u6[n][6] = the correspondences
   // (x1 y1 1 x2 y2 1) | laf[n][14] = the frames (x y a11 a12 a21 a22 s) of both regions - one device-to-host copy of
   // tent_bytes(n) bytes brings all three (tent_u6_off / tent_laf_off give the parts)
-  int *m_count = nullptr;            // tentatives of the last search: PINNED HOST memory written by the emit kernel
+  int *m_count = nullptr;            // tentatives of the last search: PINNED HOST memory (64 ints) written by the emit kernel
+  mods_tentative *m_tent_out = nullptr; int *m_count_out = nullptr;   // set by a batch of pairs: where match_run leaves the packed list / its length
+  char *m_tent_batch = nullptr; size_t m_tent_batch_cap = 0;          // the packed lists of a batch, one segment per pair
   mods_region *m_regs = nullptr;     // [2][max_cand] staging for host-side lists
   std::vector<mods_tentative> h_tent;  // host copies for the sequential stages
   std::vector<double> h_u6, h_laf;

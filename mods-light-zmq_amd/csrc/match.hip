@@ -664,7 +664,7 @@ int match_ensure_buffers(mods_ctx *ctx) {
   MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, tent_bytes(n) + 64));
   // the tentative count lives in pinned host memory: the emit kernel's single store lands there, the host reads it after a
   // stream synchronisation - no 4-byte copy launch per search
-  MODS_HIP_CHECK(hipHostMalloc(&ctx->m_count, 64));
+  MODS_HIP_CHECK(hipHostMalloc(&ctx->m_count, 64 * sizeof(int)));   // [0]: the last search; [i]: pair i of a batch (m_count_out)
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_desc, 0, 2 * n * 128, ctx->stream));
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_c, 0, 4 * n * sizeof(int), ctx->stream));
   return MODS_OK;
@@ -694,7 +694,10 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   k.sqminratio = ratio * ratio;
   k.contr_sq = contradDist * contradDist;
   if (!(k.sqminratio < 1.0)) { set_error("FGINN ratio >= 1 (all-neighbours mode) is not supported"); return MODS_E_ARG; }
-  if (n_q == 0 || n_t == 0) { MODS_HIP_CHECK(hipMemsetAsync(ctx->m_count, 0, sizeof(int), ctx->stream)); return MODS_OK; }
+  // where the packed list and its length go: the context's own buffer / counter, or what a batch of pairs set (capi.hip: match_pairs)
+  mods_tentative *tent_out = ctx->m_tent_out ? ctx->m_tent_out : ctx->m_tent;
+  int *count_out = ctx->m_count_out ? ctx->m_count_out : ctx->m_count;
+  if (n_q == 0 || n_t == 0) { MODS_HIP_CHECK(hipMemsetAsync(count_out, 0, sizeof(int), ctx->stream)); return MODS_OK; }
   const size_t n = match_pad(ctx);
   int8_t *qd = ctx->m_desc, *td = ctx->m_desc + n * 128;
   int *qc = ctx->m_c, *tc = ctx->m_c + n, *qc2 = ctx->m_c + 2 * n, *tc2 = ctx->m_c + 3 * n;
@@ -711,7 +714,7 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   int8_t *qd2 = (int8_t *)(mid2 + n);
   int *list2 = (int *)(qd2 + n * 128), *qcs = list2 + n, *count2 = qcs + n;
   int *gthr = count2 + 16;
-  hipLaunchKernelGGL(match_init_kernel, dim3((std::max(n_q, n_t) + 255) / 256), dim3(256), 0, ctx->stream, n_q, n_t, ctx->m_count, count2, qpar, tpar, gthr);
+  hipLaunchKernelGGL(match_init_kernel, dim3((std::max(n_q, n_t) + 255) / 256), dim3(256), 0, ctx->stream, n_q, n_t, count_out, count2, qpar, tpar, gthr);
   hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
   hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
   (void)best;
@@ -738,7 +741,7 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   const int eblocks = (n_q + 1023) / 1024;
   int *block_counts = (int *)(ctx->m_int + 2 * n);
   hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
-  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, ctx->m_tent, ctx->m_count, ctx->max_cand);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, tent_out, count_out, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }
