@@ -269,19 +269,27 @@ int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w
   const float *planes = img_dev;
   if (stride != w) planes = c->tmp_dev;   // pyramid_build repacked the batch there
   if ((rc = describe_run(c, planes, n_img, w, h, desc))) return rc;
-  MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
+  // every count and the error flag of the batch in one round trip (pinned host words)
+  int *hc = c->host_counts;
+  MODS_HIP_CHECK(hipMemcpyAsync(hc, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(hc + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(hc + 4 * c->batch, c->inside_count, sizeof(int) * n_img, hipMemcpyDeviceToHost, c->stream));
+  MODS_HIP_CHECK(hipMemcpyAsync(hc + 5 * c->batch, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
   for (int b = 0; b < n_img; b++) {
-    if (c->host_counts[b] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", c->host_counts[b], c->max_cand); return MODS_E_CAPACITY; }
-    if (n_detected_host) n_detected_host[b] = c->host_counts[2 * c->batch + b];
-    if (c->host_counts[3 * c->batch + b] > std::min(c->max_cand, 1 << 17)) { set_error("region list overflow: %d", c->host_counts[3 * c->batch + b]); return MODS_E_CAPACITY; }
-    if (n_regions_host) n_regions_host[b] = c->host_counts[3 * c->batch + b];
+    if (hc[b] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", hc[b], c->max_cand); return MODS_E_CAPACITY; }
+    if (n_detected_host) n_detected_host[b] = hc[2 * c->batch + b];
+    if (hc[3 * c->batch + b] > std::min(c->max_cand, 1 << 17)) { set_error("region list overflow: %d", hc[3 * c->batch + b]); return MODS_E_CAPACITY; }
+    if (n_regions_host) n_regions_host[b] = hc[3 * c->batch + b];
   }
-  c->last_region_counts.assign(c->host_counts + 3 * c->batch, c->host_counts + 3 * c->batch + n_img);
-  c->last_inside_counts.resize(n_img);
-  MODS_HIP_CHECK(hipMemcpy(c->last_inside_counts.data(), c->inside_count, sizeof(int) * n_img, hipMemcpyDeviceToHost));
-  return check_desc_err(c);
+  c->last_region_counts.assign(hc + 3 * c->batch, hc + 3 * c->batch + n_img);
+  c->last_inside_counts.assign(hc + 4 * c->batch, hc + 4 * c->batch + n_img);
+  if (hc[5 * c->batch]) {
+    MODS_HIP_CHECK(hipMemsetAsync(c->desc_err_dev, 0, sizeof(int), c->stream));
+    set_error("measurement region larger than the descriptor scratch (P2 > 3*max(w,h) or > 4096 blur taps)");
+    return MODS_E_CAPACITY;
+  }
+  return MODS_OK;
 }
 
 // Route the description of every following call through `fn` (NULL: back to the built-in RootSIFT).  The patches are
