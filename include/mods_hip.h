@@ -168,7 +168,8 @@ int mods_resize_half(mods_ctx *ctx, const float *src, int w, int h, float *dst, 
 typedef struct mods_describe_params {
   double ori_mrSize;       /* 5.1962 */
   int ori_patchSize;       /* 32 */
-  int ori_maxAngles;       /* 1 (only 0/1 supported: the shipped configs use 1) */
+  int ori_maxAngles;       /* 1; > 1: an oriented copy per histogram peak above the threshold, the first maxAngles in bin order
+                              (synth-detection.cpp:900-927, 1095-1106); <= 0: no oriented copies (`if (maxAngNum > 0)`, :1086) */
   double ori_threshold;    /* (double)(float)0.8 */
   double desc_mrSize;      /* 5.1962 */
   int desc_patchSize;      /* 41 */

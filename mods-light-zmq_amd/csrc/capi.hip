@@ -120,7 +120,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->tmp_dev); (void)hipFree(c->alt_taps_dev); (void)hipFree(c->alt_planes); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
   (void)hipHostFree(c->host_counts); (void)hipHostFree(c->pin_arena);
-  (void)hipFree(c->ori_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
+  (void)hipFree(c->ori_dev); (void)hipFree(c->ori_multi_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
   (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipFree(c->m_tent_batch); (void)hipHostFree(c->m_count); (void)hipFree(c->m_regs);

@@ -118,6 +118,7 @@ struct mods_ctx {
   int *desc_err_dev = nullptr;
   int desc_ori_ps = 0, desc_ps = 0;
   void *ori_dev = nullptr;           // [batch][max_cand] OriOut
+  void *ori_multi_dev = nullptr; size_t ori_multi_bytes = 0;   // [batch][max_cand][ori_cap] OriOut (maxAngles > 1), allocated on first use
   mods_region *regions_dev = nullptr;  // [batch][max_cand]
   mods_region *regions_half_dev = nullptr;   // HalfRootSIFT twins (allocated on first use)
   bool have_half = false;

@@ -37,8 +37,18 @@ __global__ __launch_bounds__(256) void ori_bin_table_kernel() {
 // Block = 64 lanes.  s_val/s_bin: ps*(ps-2) entries, s_hist: 40 floats.  Returns found/angle
 // (uniform across lanes).
 // ---------------------------------------------------------------------------------------
+// addPeakAngle (synth-detection.cpp:824-834): parabolic refinement of the peak in bin b of the smoothed histogram
+__device__ __forceinline__ float peak_angle(const float *s_hist, int b) {
+  const int bins = 36;
+  const float PIf = 3.14159265358979323846f;
+  const int a = b == 0 ? bins - 1 : b - 1, c = b == bins - 1 ? 0 : b + 1;
+  const float ha = s_hist[a], hb = s_hist[b], hc = s_hist[c];
+  const float pp = (ha - hc) / (ha - 2.0f * hb + hc) / 2.0f;
+  return 2.0f * PIf * (b + 0.5f + pp) / bins - PIf;
+}
 __device__ bool dominant_angle_wave(const float *s_patch, const float *__restrict__ orimask, int ps, double th,
-                                    float *s_val, unsigned char *s_bin, float *s_hist, float *angle_out, int half = 0) {
+                                    float *s_val, unsigned char *s_bin, float *s_hist, float *angle_out, int half = 0,
+                                    unsigned long long *peaks_out = nullptr) {
   const int lane = threadIdx.x;
   const int bins = 36;
   const float PIf = 3.14159265358979323846f;
@@ -143,12 +153,9 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
     peak = s_hist[lane] >= thresh && s_hist[lane] > s_hist[a] && s_hist[lane] > s_hist[c];
   }
   const unsigned long long m = __ballot(peak);
+  if (peaks_out) *peaks_out = m;          // every local maximum above the threshold, bit = bin (addPeakAngle in bin order)
   if (m == 0) return false;
-  const int b = __ffsll((long long)m) - 1;
-  const int a = b == 0 ? bins - 1 : b - 1, c = b == bins - 1 ? 0 : b + 1;
-  const float ha = s_hist[a], hb = s_hist[b], hc = s_hist[c];
-  const float pp = (ha - hc) / (ha - 2.0f * hb + hc) / 2.0f;
-  *angle_out = 2.0f * PIf * (b + 0.5f + pp) / bins - PIf;
+  *angle_out = peak_angle(s_hist, __ffsll((long long)m) - 1);
   return true;
 }
 
@@ -160,7 +167,7 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
 __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *__restrict__ img_all, DescConst k,
                                                     const mods_affkey *__restrict__ keys_all,
                                                     const int *__restrict__ key_count, const float *__restrict__ orimask,
-                                                    OriOut *__restrict__ ori_all) {
+                                                    OriOut *__restrict__ ori_all, OriOut *__restrict__ ori_multi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ps = k.ori_ps, pp2 = ps * ps;
   const int nv = (ps * (ps - 2) + 15) & ~15;
@@ -217,29 +224,47 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
       __syncthreads();
       OPROF(1)
       float ang = 0.f;
-      const bool found = dominant_angle_wave(s_patch, orimask, ps, k.ori_th, s_val, s_bin, s_hist, &ang, k.ori_half);
+      unsigned long long peaks = 0;
+      const bool found = dominant_angle_wave(s_patch, orimask, ps, k.ori_th, s_val, s_bin, s_hist, &ang, k.ori_half, &peaks);
       OPROF(2)
-      if (!found) alive = false;
-      else {
+      // the oriented copy for angle `a`: rotated frame, then ReprojectRegions' tests; false when it is dropped
+      auto oriented = [&](float a, double &o11, double &o12, double &o21, double &o22) {
         double si, ci;
-        det_sincos(-(double)ang, &si, &ci);
-        n11 = kp.a11 * ci - kp.a12 * si;
-        n12 = kp.a11 * si + kp.a12 * ci;
-        n21 = kp.a21 * ci - kp.a22 * si;
-        n22 = kp.a21 * si + kp.a22 * ci;
+        det_sincos(-(double)a, &si, &ci);
+        o11 = kp.a11 * ci - kp.a12 * si;
+        o12 = kp.a11 * si + kp.a12 * ci;
+        o21 = kp.a21 * ci - kp.a22 * si;
+        o22 = kp.a21 * si + kp.a22 * ci;
         if (k.view) {
           // ReprojectRegions: ReprojectByH (synth-detection.cpp:578-587) then the centre and box tests in the original frame
           const double rx = (k.Hinv[0] * kp.x + k.Hinv[1] * kp.y + k.Hinv[2]);
           const double ry = (k.Hinv[3] * kp.x + k.Hinv[4] * kp.y + k.Hinv[5]);
-          const double r11 = (k.Hinv[0] * n11 + k.Hinv[1] * n21), r12 = (k.Hinv[0] * n12 + k.Hinv[1] * n22);
-          const double r21 = (k.Hinv[3] * n11 + k.Hinv[4] * n21), r22 = (k.Hinv[3] * n12 + k.Hinv[4] * n22);
-          if (!((rx < k.ow) && (ry < k.oh) && (rx > 0) && (ry > 0))) alive = false;
-          else if (check_borders(k.ow, k.oh, (float)rx, (float)ry, (float)r11, (float)r12, (float)r21, (float)r22, box, box)) alive = false;
-        } else {
-          // ReprojectRegions (H = I): same centre, rotated frame
-          if (check_borders(k.w, k.h, fx, fy, (float)n11, (float)n12, (float)n21, (float)n22, box, box)) alive = false;
+          const double r11 = (k.Hinv[0] * o11 + k.Hinv[1] * o21), r12 = (k.Hinv[0] * o12 + k.Hinv[1] * o22);
+          const double r21 = (k.Hinv[3] * o11 + k.Hinv[4] * o21), r22 = (k.Hinv[3] * o12 + k.Hinv[4] * o22);
+          if (!((rx < k.ow) && (ry < k.oh) && (rx > 0) && (ry > 0))) return false;
+          return !check_borders(k.ow, k.oh, (float)rx, (float)ry, (float)r11, (float)r12, (float)r21, (float)r22, box, box);
         }
-      }
+        // ReprojectRegions (H = I): same centre, rotated frame
+        return !check_borders(k.w, k.h, fx, fy, (float)o11, (float)o12, (float)o21, (float)o22, box, box);
+      };
+      if (k.ori_cap > 1) {
+        // maxAngles > 1: the first ori_cap peaks in bin order, one oriented copy each (EstimateDominantAnglesFunctor,
+        // synth-detection.cpp:900-927, DetectOrientation :1095-1106); slot j of the keypoint's ori_cap entries
+        OriOut *om = ori_multi + ((size_t)b * k.max_cand + i) * k.ori_cap;
+        int j = 0;
+        for (unsigned long long pm = found ? peaks : 0ull; pm && j < k.ori_cap; pm &= pm - 1, j++) {
+          const float a = peak_angle(s_hist, __ffsll((long long)pm) - 1);
+          double o11, o12, o21, o22;
+          const bool ok = oriented(a, o11, o12, o21, o22);
+          if (lane == 0) { OriOut o; o.a11 = o11; o.a12 = o12; o.a21 = o21; o.a22 = o22; o.alive = ok ? 1 : 0; o.pad = 0; om[j] = o; }
+        }
+        if (lane == 0) for (; j < k.ori_cap; j++) { OriOut o; o.a11 = o.a12 = o.a21 = o.a22 = 0; o.alive = 0; o.pad = 0; om[j] = o; }
+        alive = false;                   // the single-copy record below only carries the inside / upright bits
+      } else if (!found) alive = false;
+      else if (!oriented(ang, n11, n12, n21, n22)) alive = false;
+    } else if (k.ori_cap > 1 && lane == 0) {
+      OriOut *om = ori_multi + ((size_t)b * k.max_cand + i) * k.ori_cap;
+      for (int j = 0; j < k.ori_cap; j++) { OriOut o; o.a11 = o.a12 = o.a21 = o.a22 = 0; o.alive = 0; o.pad = 0; om[j] = o; }
     }
     if (lane == 0) {
       OriOut o;
@@ -296,6 +321,67 @@ __global__ __launch_bounds__(1024) void compact_regions_kernel(DescConst k, cons
           r.response = kp.response; r.sub_type = kp.sub_type; r.id = slot; r.parent = i; r.pad = 0;
           // descriptor bytes are written by describe_kernel; copy the POD head only
           memcpy(&reg[slot], &r, offsetof(mods_region, desc));
+        }
+      }
+      __syncthreads();
+      if (tid == 0) { int t = 0; for (int q = 0; q < 16; q++) t += s_wave[q]; s_base += t; }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) { reg_count[b] = s_base; inside_count[b] = s_inside; }
+}
+
+// The same compaction with up to k.ori_cap oriented copies per keypoint (maxAngles > 1): keypoint i contributes the alive ones
+// of its ori_cap entries, in angle order, behind the copies of the keypoints before it (DetectOrientation pushes them in that
+// order, synth-detection.cpp:1095-1106).  grid = (1, n_img), block = 1024.
+__global__ __launch_bounds__(1024) void compact_regions_multi_kernel(DescConst k, const mods_affkey *__restrict__ keys_all,
+                                                                     const int *__restrict__ key_count, const OriOut *__restrict__ ori_all,
+                                                                     const OriOut *__restrict__ ori_multi_all, mods_region *__restrict__ reg_all,
+                                                                     int *__restrict__ reg_count, int *__restrict__ inside_count) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  __shared__ int s_inside;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const mods_affkey *keys = keys_all + (size_t)b * k.max_cand;
+  const OriOut *ori = ori_all + (size_t)b * k.max_cand;
+  const OriOut *om = ori_multi_all + (size_t)b * k.max_cand * k.ori_cap;
+  mods_region *reg = reg_all + (size_t)b * k.max_reg;
+  int n = key_count[b];
+  if (n > k.max_cand) n = k.max_cand;
+  if (tid == 0) { s_base = 0; s_inside = 0; }
+  __syncthreads();
+  for (int pass = k.add_upright ? 0 : 1; pass < 2; pass++) {
+    for (int base = 0; base < n; base += 1024) {
+      const int i = base + tid;
+      int cnt = 0;
+      if (i < n) {
+        if (pass == 0) cnt = (ori[i].pad & 2) ? 1 : 0;
+        else for (int j = 0; j < k.ori_cap; j++) cnt += om[(size_t)i * k.ori_cap + j].alive != 0;
+      }
+      const unsigned long long mi = __ballot(pass == 1 && i < n && (ori[i].pad & 1));
+      int inc = cnt;
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+      if (lane == 63) s_wave[wv] = inc;
+      if (lane == 0 && mi) atomicAdd(&s_inside, __popcll(mi));
+      __syncthreads();
+      int slot = s_base + inc - cnt;
+      for (int q = 0; q < wv; q++) slot += s_wave[q];
+      if (cnt) {
+        const mods_affkey kp = keys[i];
+        for (int j = 0; j < (pass ? k.ori_cap : 1); j++) {
+          mods_region r;
+          if (pass) {
+            const OriOut o = om[(size_t)i * k.ori_cap + j];
+            if (!o.alive) continue;
+            r.a11 = o.a11; r.a12 = o.a12; r.a21 = o.a21; r.a22 = o.a22;
+          } else { r.a11 = kp.a11; r.a12 = kp.a12; r.a21 = kp.a21; r.a22 = kp.a22; }
+          if (slot < k.reg_cap) {
+            r.x = kp.x; r.y = kp.y; r.s = kp.s;
+            r.response = kp.response; r.sub_type = kp.sub_type; r.id = slot; r.parent = i; r.pad = 0;
+            memcpy(&reg[slot], &r, offsetof(mods_region, desc));
+          }
+          slot++;
         }
       }
       __syncthreads();
@@ -373,7 +459,6 @@ int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
   if (ctx->ext_fn && (ctx->ext_ps < 8 || ctx->ext_ps > 63)) { set_error("external descriptor: patch size %d unsupported", ctx->ext_ps); return MODS_E_ARG; }
   if (par->ori_patchSize < 8 || par->ori_patchSize > 48 || par->desc_patchSize < 9 || par->desc_patchSize > 63 ||
       !(par->desc_patchSize & 1)) { set_error("unsupported patch sizes (ori %d, desc %d)", par->ori_patchSize, par->desc_patchSize); return MODS_E_ARG; }
-  if (par->ori_maxAngles > 1) { set_error("maxAngles > 1 is not supported"); return MODS_E_ARG; }
   if (!ctx->desc_tables_dev) {
     MODS_HIP_CHECK(hipMalloc(&ctx->desc_tables_dev, sizeof(float) * (64 * 64 * 2) + sizeof(SiftTab)));
     MODS_HIP_CHECK(hipMalloc(&ctx->desc_err_dev, sizeof(int)));
@@ -637,6 +722,9 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   k.ori_ps = par->ori_patchSize;
   k.ori_i2p = double(2 * int(par->ori_mrSize) + 1) / (double)par->ori_patchSize;
   k.max_angles = par->ori_maxAngles;
+  // a 36-bin histogram has at most 18 local maxima; maxAngles <= 0 (the functor's -1 = "all" included): DetectOrientation
+  // estimates nothing (`if (maxAngNum > 0)`, synth-detection.cpp:1086)
+  k.ori_cap = std::max(1, std::min(par->ori_maxAngles, 18));
   k.ori_th = par->ori_threshold;
   k.ori_half = par->ori_halfMode; k.half_desc = 0; k.add_upright = par->addUpRight;
   k.desc_mr = par->desc_mrSize; k.desc_ps = par->desc_patchSize; k.photo = par->photoNorm; k.root = par->rootSift;
@@ -657,10 +745,23 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
     StageScope ts(ctx, MODS_STAGE_ORIENT);
     const size_t lds = orient_lds_bytes(k.ori_ps);
     hipLaunchKernelGGL(ori_bin_table_kernel, dim3(8), dim3(256), 0, ctx->stream);
+    if (k.ori_cap > 1) {     // room for ori_cap oriented copies per keypoint
+      const size_t need = sizeof(OriOut) * (size_t)k.ori_cap * ctx->max_cand * ctx->batch;
+      if (need > ctx->ori_multi_bytes) {
+        if (ctx->ori_multi_dev) MODS_HIP_CHECK(hipFree(ctx->ori_multi_dev));
+        ctx->ori_multi_dev = nullptr; ctx->ori_multi_bytes = 0;
+        MODS_HIP_CHECK(hipMalloc(&ctx->ori_multi_dev, need));
+        ctx->ori_multi_bytes = need;
+      }
+    }
     hipLaunchKernelGGL(orient_kernel, dim3(8192, n_img), dim3(64), lds, ctx->stream, img_dev, k, ctx->keys_dev, key_count,
-                       orimask, (OriOut *)ctx->ori_dev);
-    hipLaunchKernelGGL(compact_regions_kernel, dim3(1, n_img), dim3(1024), 0, ctx->stream, k, ctx->keys_dev, key_count,
-                       (const OriOut *)ctx->ori_dev, ctx->regions_dev, ctx->region_count, ctx->inside_count);
+                       orimask, (OriOut *)ctx->ori_dev, (OriOut *)ctx->ori_multi_dev);
+    if (k.ori_cap > 1)
+      hipLaunchKernelGGL(compact_regions_multi_kernel, dim3(1, n_img), dim3(1024), 0, ctx->stream, k, ctx->keys_dev, key_count,
+                         (const OriOut *)ctx->ori_dev, (const OriOut *)ctx->ori_multi_dev, ctx->regions_dev, ctx->region_count, ctx->inside_count);
+    else
+      hipLaunchKernelGGL(compact_regions_kernel, dim3(1, n_img), dim3(1024), 0, ctx->stream, k, ctx->keys_dev, key_count,
+                         (const OriOut *)ctx->ori_dev, ctx->regions_dev, ctx->region_count, ctx->inside_count);
     MODS_HIP_CHECK(hipGetLastError());
   }
   rc = launch_extract_and_sift(ctx, img_dev, n_img, k, dmask, tab, !external);

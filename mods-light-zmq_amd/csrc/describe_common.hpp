@@ -12,6 +12,7 @@ struct DescConst {
   int ori_ps;
   double ori_i2p;          // imageToPatchScale of DetectOrientation = (2*int(mrSize)+1)/patchSize
   int max_angles;
+  int ori_cap;             // oriented copies kept per keypoint: 1, or min(maxAngles, 18) (18 = the most peaks a 36-bin histogram has)
   double ori_th;
   int ori_half;            // doHalfSIFT of EstimateDominantAnglesFunctor
   int add_upright;         // [DominantOrientation] addUpRight: unrotated copies, ahead of the oriented ones

@@ -166,11 +166,14 @@ static void smooth_circular(float *hist, int bins) {
   hist[bins - 1] = prev + hist[bins - 1] + first;
 }
 
-// EstimateDominantAnglesFunctor::operator() for maxAngles = 1 (synth-detection.cpp:836-929): first local maximum
-// >= 0.8*max in bin order 0..35, with parabolic refinement.  Returns false when the histogram has no such peak.
+// EstimateDominantAnglesFunctor::operator() (synth-detection.cpp:836-929): the local maxima >= max_th * max in bin order
+// 0..35, with parabolic refinement; the first maxAngles of them are returned (the reference sorts a copy of the peak values
+// and never uses it: the order stays the bin order; maxAngles = -1: all).
 // half = doHalfSIFT: after the threshold has been taken from the full histogram, bins i and i + 18 are added into
 // bin i (orientation modulo pi) and the upper half is cleared (:891-898).
-bool dominant_angle(const Img &img, double max_th, float *angle_out, bool half) {
+int dominant_angles(const Img &img, double max_th, int maxAngles, std::vector<float> &angles, bool half) {
+  angles.clear();
+  if (maxAngles == 0) return 0;
   const int pS = img.w;
   const int bins = 36;
   const float PIf = float(M_PI);
@@ -206,18 +209,24 @@ bool dominant_angle(const Img &img, double max_th, float *angle_out, bool half) 
     const int halfbins = bins / 2;
     for (int i = 0; i < halfbins; i++) { hist[i] += hist[i + halfbins]; hist[i + halfbins] = 0; }
   }
-  for (int k = 0; k < bins; k++) {
+  if (maxAngles < 0) maxAngles = 100000000;
+  for (int k = 0; k < bins && (int)angles.size() < maxAngles; k++) {
     int b = k, a = (k == 0) ? bins - 1 : k - 1, c = (k == bins - 1) ? 0 : k + 1;
     if (hist[b] >= thresh && hist[b] > hist[a] && hist[b] > hist[c]) {
       float pp = (hist[a] - hist[c]) / (hist[a] - 2.0f * hist[b] + hist[c]) / 2.0f;
-      *angle_out = 2.0f * PIf * (b + 0.5f + pp) / bins - PIf;
-      return true;
+      angles.push_back(2.0f * PIf * (b + 0.5f + pp) / bins - PIf);
     }
   }
-  return false;
+  return (int)angles.size();
+}
+bool dominant_angle(const Img &img, double max_th, float *angle_out, bool half) {   // maxAngles = 1
+  std::vector<float> a;
+  if (!dominant_angles(img, max_th, 1, a, half)) return false;
+  *angle_out = a[0];
+  return true;
 }
 
-// DetectOrientation, synth-detection.cpp:1039-1149 (maxAngNum = 1, addUpRight = false).
+// DetectOrientation, synth-detection.cpp:1039-1149: up to maxAngles oriented copies per keypoint, in the order of the angles.
 int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, const Img &img, double mrSize,
                        int patchSize, int maxAngles, double th, bool half, bool add_upright) {
   const double ks = k_sigma_synth();
@@ -225,7 +234,7 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
   tmp.reserve(in.size());
   const int patchImageSize = 2 * int(mrSize) + 1;
   const double imageToPatchScale = double(patchImageSize) / (double)patchSize;
-  std::vector<Region> slot(in.size());
+  std::vector<std::vector<Region>> slot(in.size());
   std::vector<char> ok(in.size(), 0);
 #pragma omp parallel num_threads(g_threads)
   {
@@ -240,8 +249,9 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
     if (maxAngles > 0) {
       interpolate(img, (float)k.x, (float)k.y, (float)k.a11 * curr_sc, (float)k.a12 * curr_sc,
                   (float)k.a21 * curr_sc, (float)k.a22 * curr_sc, patch);
-      float ang;
-      if (dominant_angle(patch, th, &ang, half)) {
+      std::vector<float> angs;
+      dominant_angles(patch, th, maxAngles, angs, half);
+      for (float ang : angs) {
         double si, ci;
         det_sincos(-(double)ang, &si, &ci);
         Region t = k;
@@ -250,14 +260,14 @@ int detect_orientation(const std::vector<Region> &in, std::vector<Region> &out, 
         t.a21 = k.a21 * ci - k.a22 * si;
         t.a22 = k.a21 * si + k.a22 * ci;
         t.parent = (int)i;
-        slot[i] = t; ok[i] = 1;
+        slot[i].push_back(t); ok[i] |= 1;
       }
     }
     if (add_upright) ok[i] |= 2;     // addUpRight (:1140-1142): the unrotated region itself, after its oriented copy
   }
   }   // omp parallel
   for (size_t i = 0; i < in.size(); i++) {
-    if (ok[i] & 1) tmp.push_back(slot[i]);
+    if (ok[i] & 1) tmp.insert(tmp.end(), slot[i].begin(), slot[i].end());
     if (ok[i] & 2) { Region t = in[i]; t.parent = (int)i; tmp.push_back(t); }
   }
   out.swap(tmp);

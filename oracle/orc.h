@@ -161,6 +161,7 @@ void sift_patch_to_desc(const Img &patch41, uint8_t out[128], bool rootsift, dou
 void extract_desc_patch(const Region &r, const Img &img, double mrSize, int patchSize, bool photoNorm,
                         Img &patch, bool column_rule = false, bool fast = false);
 bool dominant_angle(const Img &patch, double th, float *angle, bool half = false);   // :836-929 (maxAngles=1)
+int dominant_angles(const Img &patch, double th, int maxAngles, std::vector<float> &angles, bool half = false);   // any maxAngles (-1: all peaks)
 
 // ---- matching (match.cpp) ------------------------------------------------------------------
 struct Tentative {

@@ -179,3 +179,55 @@ def test_fast_patch_extraction(pkg):
     assert nd[0] == nd_want and nr[0] == len(want) > 500
     _assert_regions_equal(ctx.regions_fetch(0), want)
     ctx.close()
+
+
+@pytest.mark.parametrize("max_angles,half,upright", [(2, False, False), (5, False, False), (3, True, False), (2, False, True)])
+def test_several_dominant_orientations(pkg, max_angles, half, upright):
+    """[DominantOrientation] maxAngles > 1 (EstimateDominantAnglesFunctor, synth-detection.cpp:900-927; DetectOrientation
+    :1095-1106): every keypoint yields an oriented copy per histogram peak above the threshold, the first maxAngles of them in
+    bin order, each with its own border test; copies of one keypoint are neighbours in the list."""
+    import torch
+    w, h = 640, 480
+    img = synth.texture(w, h, seed=37)
+    one, _ = orc.detect_describe(img)
+    want, nd_want = orc.detect_describe(img, max_angles=max_angles, half_orientation=half, add_upright=upright)
+    assert len(want) > len(one) * (1.05 if not upright else 2.0)
+    ctx = pkg.Context(0, w, h, 2)
+    desc = pkg.DescribeParams.default()
+    desc.ori_maxAngles, desc.ori_halfMode, desc.addUpRight = max_angles, int(half), int(upright)
+    t = torch.from_numpy(np.stack([img, img[::-1].copy()])).cuda()
+    nd, nr = ctx.detect_describe_dev(t.data_ptr(), 2, w, h, None, desc)
+    assert nd[0] == nd_want and nr[0] == len(want)
+    _assert_regions_equal(ctx.regions_fetch(0), want)
+    want2, _ = orc.detect_describe(img[::-1].copy(), max_angles=max_angles, half_orientation=half, add_upright=upright)
+    _assert_regions_equal(ctx.regions_fetch(1), want2)
+    ctx.close()
+
+
+def test_several_orientations_on_a_view(pkg):
+    import math
+    import torch
+    img = synth.texture(640, 480, seed=38)
+    h, w = img.shape
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 1)
+    t = torch.from_numpy(img).cuda()
+    px, g0 = orc.synth_view(img, 3.0, math.pi / 5, 1.0, 0.2, 1)
+    import ctypes as C
+    a, p = orc._f(px)
+    Hc = np.ascontiguousarray(np.array(g0.H), np.float64).ravel()
+    out = np.zeros(1 << 18, orc.REGION_DTYPE); det = np.zeros(1 << 18, orc.REGION_DTYPE); ndet = C.c_int()
+    par = orc.HessAffParams.default()
+    n = orc.lib().orc_detect_describe_view_ex(p, a.shape[1], a.shape[0], Hc.ctypes.data_as(C.c_void_p), w, h, C.byref(par), C.c_double(orc.ORI_MRSIZE),
+                                             orc.ORI_PATCH, 2, C.c_double(orc.ORI_TH), C.c_double(orc.DESC_MRSIZE), orc.DESC_PATCH, 1, 0,
+                                             out.ctypes.data_as(C.c_void_p), det.ctypes.data_as(C.c_void_p), None, 1 << 18, C.byref(ndet))
+    want = out[:n]
+    desc = pkg.DescribeParams.default()
+    desc.ori_maxAngles = 2
+    g, nd, nr = ctx.detect_describe_view_dev(t.data_ptr(), w, h, 3.0, math.pi / 5, 1.0, 0.2, 1, desc=desc)
+    assert nd == ndet.value and nr == n > 100
+    got = ctx.regions_fetch(0)
+    for f in ("x", "y", "s", "a11", "a12", "a21", "a22", "response", "sub_type"):     # (parent: the oracle numbers the keypoints after the centre test)
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(got["desc"], want["desc"])
+    ctx.close()
