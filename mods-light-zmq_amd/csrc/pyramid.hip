@@ -13,6 +13,7 @@
 // column pass s = k[r]*T[y]; s = fma(k[r+j], T[y+j] + T[y-j], s) for j = 1..r.
 #include "common.hpp"
 #include "detmath.hpp"
+#include "device_util.hpp"
 #include <algorithm>
 #include <cmath>
 
@@ -603,6 +604,142 @@ __global__ __launch_bounds__(256) void resize_half_resp_kernel(const float *__re
 }
 
 
+// The tail of the pyramid in ONE launch: the octaves whose planes fit LDS (<= LDSP_CAP pixels: 120 x 68 and smaller for a 1080p
+// image) are built level by level by one 1024-thread workgroup per image - plane A (the current level), plane B (the row pass)
+// and the next octave's first plane N stay in LDS, only the results go to HBM.  As separate launches these octaves are ~6
+// launches each of 6-8 us for a few microseconds of work (18 launches for a 1080p batch).  Same arithmetic as the tiled
+// kernels: row pass left to right (centre first for ksize <= 5), column pass centre then symmetric pairs (below + above),
+// BORDER_REPLICATE, response stencil of hessian_response4_kernel, decimation of resize_half_kernel.
+constexpr int LDSP_CAP = 9216;
+struct LdsPyramidPlan {
+  int first, n_oct, n_levels, S;
+  int ntap[kMaxLevels];
+  BlurTaps taps[kMaxLevels];
+  float norm2[kMaxLevels];     // response norm of level l (l >= 1), squared as the kernels take it
+  float norm2_first;           // ... of a decimated first level
+};
+__device__ __forceinline__ float lds_response(const float *A, int w, int h, int x, int y, float norm2) {
+  if (!(x >= 1 && x < w - 1 && y >= 1 && y < h - 1)) return 0.f;
+  const float *r0 = A + (y - 1) * w + x, *r1 = r0 + w, *r2 = r1 + w;
+  const float v11 = r0[-1], v12 = r0[0], v13 = r0[1], v21 = r1[-1], v22 = r1[0], v23 = r1[1], v31 = r2[-1], v32 = r2[0], v33 = r2[1];
+  float Lxx = (v21 - 2 * v22 + v23);
+  float Lyy = (v12 - 2 * v22 + v32);
+  float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
+  return (Lxx * Lyy - Lxy * Lxy) * norm2;
+}
+template <int N>
+__device__ __forceinline__ float lds_row_taps(const float *pp, const float *t) {        // pp = &row[x - R], whole window inside the row
+  float s = t[0] * pp[0];
+#pragma unroll
+  for (int j = 1; j < N; j++) s = fmaf(t[j], pp[j], s);
+  return s;
+}
+__device__ __forceinline__ float lds_row_px(const float *row, int x, int w, int n, const float *t) {
+  const int R = n >> 1;
+  if (n > 5 && x >= R && x + R < w) {
+    const float *pp = row + x - R;
+    switch (n) {
+      case 7: return lds_row_taps<7>(pp, t);
+      case 9: return lds_row_taps<9>(pp, t);
+      case 11: return lds_row_taps<11>(pp, t);
+      case 13: return lds_row_taps<13>(pp, t);
+      case 15: return lds_row_taps<15>(pp, t);
+      case 17: return lds_row_taps<17>(pp, t);
+    }
+  }
+  float s;
+  if (n <= 5) {
+    s = row[x] * t[R];
+    for (int j = 1; j <= R; j++) { const int xa = x - j < 0 ? 0 : x - j, xb = x + j > w - 1 ? w - 1 : x + j; s = fmaf(row[xa] + row[xb], t[R + j], s); }
+  } else {
+    int x0 = x - R; x0 = x0 < 0 ? 0 : x0;
+    s = t[0] * row[x0];
+    for (int j = 1; j < n; j++) { int xx = x - R + j; xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx); s = fmaf(t[j], row[xx], s); }
+  }
+  return s;
+}
+template <int R>
+__device__ __forceinline__ float lds_col_taps(const float *pc, int w, const float *t) {   // pc = &B[y * w + x], rows y - R .. y + R inside
+  float s = t[R] * pc[0];
+#pragma unroll
+  for (int j = 1; j <= R; j++) s = fmaf(t[R + j], pc[j * w] + pc[-j * w], s);
+  return s;
+}
+__device__ __forceinline__ float lds_col_px(const float *B, int x, int y, int w, int h, int n, const float *t) {
+  const int R = n >> 1;
+  const float *pc = B + y * w + x;
+  if (y >= R && y + R < h) {
+    switch (R) {
+      case 1: return lds_col_taps<1>(pc, w, t);
+      case 2: return lds_col_taps<2>(pc, w, t);
+      case 3: return lds_col_taps<3>(pc, w, t);
+      case 4: return lds_col_taps<4>(pc, w, t);
+      case 5: return lds_col_taps<5>(pc, w, t);
+      case 6: return lds_col_taps<6>(pc, w, t);
+      case 7: return lds_col_taps<7>(pc, w, t);
+      case 8: return lds_col_taps<8>(pc, w, t);
+    }
+  }
+  float s = t[R] * pc[0];
+  for (int j = 1; j <= R; j++) {
+    const int ya = y + j > h - 1 ? h - 1 : y + j, yb = y - j < 0 ? 0 : y - j;
+    s = fmaf(t[R + j], B[ya * w + x] + B[yb * w + x], s);
+  }
+  return s;
+}
+__global__ __launch_bounds__(1024) void pyramid_lds_kernel(const PyramidDev *__restrict__ P, LdsPyramidPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *A = sm, *B = sm + LDSP_CAP, *N = B + LDSP_CAP;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  int w = P->oct[pl.first].w, h = P->oct[pl.first].h;
+  {
+    const float *src = as_global(P->oct[pl.first].blur[0]) + (size_t)w * h * b;
+    for (int p = tid; p < w * h; p += 1024) A[p] = src[p];
+  }
+  __syncthreads();
+  for (int oi = pl.first; oi < pl.n_oct; oi++) {
+    const OctaveDev &o = P->oct[oi];
+    const size_t plane = (size_t)w * h * b;
+    for (int l = 1; l < pl.n_levels; l++) {
+      const int n = pl.ntap[l];
+      const float *t = pl.taps[l].t;
+      // (one workgroup per image = one CU: the passes are bound by instruction issue, so the tap loops are instantiated for the
+      // kernel size - immediate LDS offsets, no address arithmetic or clamping per tap away from the plane's edge)
+      const int npx = w * h;
+      for (int p = tid; p < npx; p += 1024) {              // row pass A -> B
+        const int y = p / w, x = p - y * w;
+        B[p] = lds_row_px(A + y * w, x, w, n, t);
+      }
+      __syncthreads();
+      float *blur = as_global(o.blur[l]) + plane;
+      for (int p = tid; p < npx; p += 1024) {              // column pass B -> A (and the level's blurred plane)
+        const int y = p / w, x = p - y * w;
+        const float s = lds_col_px(B, x, y, w, h, n, t);
+        A[p] = s;
+        blur[p] = s;
+      }
+      __syncthreads();
+      float *resp = as_global(o.resp[l]) + plane;
+      for (int p = tid; p < w * h; p += 1024) { const int y = p / w, x = p - y * w; resp[p] = lds_response(A, w, h, x, y, pl.norm2[l]); }
+      if (l == pl.S && oi + 1 < pl.n_oct) {                // first level of the next octave: decimation + its response
+        const OctaveDev &nx = P->oct[oi + 1];
+        const int dw = nx.w, dh = nx.h;
+        for (int q = tid; q < dw * dh; q += 1024) { const int dy = q / dw, dx = q - dy * dw; N[q] = decimated_at(A, w, h, dx, dy); }
+        __syncthreads();
+        float *nb = as_global(nx.blur[0]) + (size_t)dw * dh * b, *nr = as_global(nx.resp[0]) + (size_t)dw * dh * b;
+        for (int q = tid; q < dw * dh; q += 1024) { const int dy = q / dw, dx = q - dy * dw; nb[q] = N[q]; nr[q] = lds_response(N, dw, dh, dx, dy, pl.norm2_first); }
+      }
+      __syncthreads();
+    }
+    if (oi + 1 < pl.n_oct) {
+      const int dw = P->oct[oi + 1].w, dh = P->oct[oi + 1].h;
+      for (int q = tid; q < dw * dh; q += 1024) A[q] = N[q];
+      w = dw; h = dh;
+      __syncthreads();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // DoG and Harris responses (ScaleSpaceDetector::dogResponse / iidogResponse / HarrisResponse, pyramid.cpp:165-194, 256-278).
 // Their own Gaussian blurs are wide (DoG passes sigma^2 of the level as the sigma: ksize up to 99 with the default
@@ -1012,7 +1149,16 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
   // for 8 % of the pixels - on a second stream next to the last level and the NMS of the large octaves: the small launches
   // slow down under the large ones (0.196 -> 0.332 ms) and the join waits for them: 1.436 vs 1.416 ms for the whole
   // scale space.  One stream.)
-  for (int oi = 0; oi < P.n_oct; oi++) {
+  // the octaves from `first_lds` on fit LDS and are built by pyramid_lds_kernel in one launch
+  int first_lds = P.n_oct;
+  static const bool no_lds = getenv("MODS_NO_LDS_PYRAMID") != nullptr;
+  if (!no_lds) {
+    bool taps_ok = P.n_levels <= kMaxLevels;
+    for (int l = 1; l < P.n_levels; l++) taps_ok = taps_ok && ntap[l] >= 3 && ntap[l] <= 17 && ctx->taps_host_n[l] == ntap[l];
+    if (taps_ok)
+      for (int oi = P.n_oct - 1; oi >= 1 && P.oct[oi].w * P.oct[oi].h <= LDSP_CAP; oi--) first_lds = oi;
+  }
+  for (int oi = 0; oi < first_lds; oi++) {
     OctaveDev &o = P.oct[oi];
     if (oi == 0 && !initial_blur)      // (the first level of a later octave gets its response from the decimation launch)
       if ((rc = launch_hessian_response(ctx, o.blur[0], o.resp[0], o.w, o.h, n_img, o.sigma[0] * o.sigma[0]))) return rc;
@@ -1024,6 +1170,26 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
         if ((rc = launch_resize_half_resp(ctx, o.blur[l], nx.blur[0], nx.resp[0], o.w, o.h, nx.w, nx.h, n_img, nx.sigma[0] * nx.sigma[0]))) return rc;
       }
     }
+  }
+  if (first_lds < P.n_oct) {
+    LdsPyramidPlan pl;
+    pl.first = first_lds; pl.n_oct = P.n_oct; pl.n_levels = P.n_levels; pl.S = S;
+    const OctaveDev &o = P.oct[first_lds];
+    for (int l = 0; l < kMaxLevels; l++) { pl.ntap[l] = 0; pl.norm2[l] = 0.f; for (int i = 0; i < 17; i++) pl.taps[l].t[i] = 0.f; }
+    for (int l = 1; l < P.n_levels; l++) {
+      pl.ntap[l] = ntap[l];
+      for (int i = 0; i < ntap[l]; i++) pl.taps[l].t[i] = ctx->taps_host[l][i];
+      const float sigma = o.sigma[l - 1] * sigmaStep;        // pyramid.cpp:455-458 (the same for every octave)
+      const float norm = sigma * sigma;
+      pl.norm2[l] = norm * norm;
+    }
+    { const float norm = o.sigma[0] * o.sigma[0]; pl.norm2_first = norm * norm; }
+    const size_t lds = sizeof(float) * (2 * LDSP_CAP + LDSP_CAP / 4 + 256);
+    static const hipError_t attr = hipFuncSetAttribute((const void *)pyramid_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MODS_HIP_CHECK(attr);
+    StageScope ts(ctx, MODS_STAGE_BLUR_SMALL, 0.0);
+    hipLaunchKernelGGL(pyramid_lds_kernel, dim3(n_img), dim3(1024), lds, ctx->stream, ctx->pyr_dev, pl);
+    MODS_HIP_CHECK(hipGetLastError());
   }
   return MODS_OK;
 }
