@@ -68,7 +68,9 @@ typedef struct mods_hessaff_params {
   double mserMaxArea;          /* max_area = 0.01 (0.05 in config_affori_classic.ini): largest region as a fraction of the image */
   double mserMinMargin;        /* min_margin = 10 (8 in the shipped .ini): the stability bound of FixedTh */
   int mserMinSize;             /* min_size = 30 pixels */
-  int pad_;
+  int affBmbrgMethod;          /* [HessianAffine] affBmbrgMethod (io_mods.cpp:193; AffineBaumbergMethod, affine.h:21-24): 0 = second moment
+                                * matrix, 1 = the Hessian form of the iteration (affine.cpp:92-128: 3x3 samples at s * 0.5, SVD of the
+                                * Hessian); HessianAffine / DoG / HarrisAffine */
 } mods_hessaff_params;
 enum { MODS_DET_FIXED_TH = 0, MODS_DET_RELATIVE_TH, MODS_DET_FIXED_REG_NUMBER, MODS_DET_RELATIVE_REG_NUMBER,
        MODS_DET_NOT_LESS_THAN_REGIONS };   /* detection_mode_t, detectors/structures.hpp:10-14 */

@@ -32,7 +32,7 @@ class HessAffParams(C.Structure):
                 ("mode", C.c_int), ("relativeThreshold", C.c_float), ("regionsNumber", C.c_int),
                 ("relativeRegionsNumber", C.c_float), ("detectorType", C.c_int), ("iiDoGMode", C.c_int),
                 ("sampleFromImage", C.c_int),
-                ("mserMaxArea", C.c_double), ("mserMinMargin", C.c_double), ("mserMinSize", C.c_int), ("pad_", C.c_int)]
+                ("mserMaxArea", C.c_double), ("mserMinMargin", C.c_double), ("mserMinSize", C.c_int), ("affBmbrgMethod", C.c_int)]
 
     @staticmethod
     def mser(mode=0, min_margin=8, max_area=0.05, min_size=30, reg_number=500, rel_threshold=-1.0, rel_reg_number=-1.0):

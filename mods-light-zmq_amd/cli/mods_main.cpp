@@ -125,7 +125,9 @@ int read_config(const std::string &config_fn, const std::string &iters_fn, int v
     return d;
   };
   p.det = read_det("HessianAffine", MODS_DET_HESSIAN);
-  if (ini.GetInteger("HessianAffine", "affBmbrgMethod", 0) != 0) std::cerr << "Warning: affBmbrgMethod != 0 (Hessian Baumberg) is not supported, SMM is used" << std::endl;
+  // only this section reads the key (io_mods.cpp:193); AffineBaumbergMethod, affine.h:21-24
+  p.det.affBmbrgMethod = (int)ini.GetInteger("HessianAffine", "affBmbrgMethod", 0);
+  if (p.det.affBmbrgMethod != 0 && p.det.affBmbrgMethod != 1) { std::cerr << "[HessianAffine] affBmbrgMethod must be 0 (SMM) or 1 (Hessian)" << std::endl; return 1; }
   // [DominantOrientation] :731-740 and [SIFTDescriptor] :423-436
   mods_describe_params &q = p.desc;
   q.ori_mrSize = ini.GetDouble("DominantOrientation", "mrSize", 3.0 * std::sqrt(3.0));

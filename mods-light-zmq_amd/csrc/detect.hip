@@ -37,6 +37,7 @@ struct DetectConst {
   int det_type;           // MODS_DET_HESSIAN / DOG / HARRIS
   const float *sfi_img;   // sampleFromImage: the batch's input images [n_img][sfi_h][sfi_w], else null
   int sfi_w, sfi_h;
+  float aff_meas_region;  // AffineShapeParams::affMeasRegion = 0.5 (affine.h:64; no key reads it)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -489,6 +490,145 @@ __global__ __launch_bounds__(256) void omap_reset_kernel(const PyramidDev *__res
 }
 
 // ---------------------------------------------------------------------------------------
+// The Hessian form of the iteration (affBmbrgMethod = 1, affine.cpp:92-128): nine bilinear samples at s * affMeasRegion, the 3x3
+// finite-difference Hessian of the warped neighbourhood, its SVD (OpenCV's one-sided Jacobi for fp32, restated in
+// oracle/detect.cpp:svd2x2_f32 - parity unpinned, see there) and Ap <- Au Ap Au.  A few hundred instructions per step:
+// one LANE per accepted point.  grid = (N, n_img) grid-stride, block 256.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void mul2x2_f32(const float a[4], const float b[4], float d[4]) {   // cv::gemm's 2x2 fp32 path
+  const float t0 = a[0] * b[0] + a[1] * b[2], t1 = a[0] * b[1] + a[1] * b[3];
+  const float t2 = a[2] * b[0] + a[3] * b[2], t3 = a[2] * b[1] + a[3] * b[3];
+  d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3;
+}
+__device__ bool svd2x2_f32(const float A[4], float d[2], float U[4], float Vt[4]) {   // false: a singular value <= FLT_MIN
+  const float eps = 1.1920929e-7f * 2;
+  const double minval = 1.17549435e-38;
+  float a0[2] = {A[0], A[2]}, a1[2] = {A[1], A[3]};       // rows of A^T
+  float v0[2] = {1.f, 0.f}, v1[2] = {0.f, 1.f};
+  double W0 = (double)a0[0] * a0[0] + (double)a0[1] * a0[1];
+  double W1 = (double)a1[0] * a1[0] + (double)a1[1] * a1[1];
+  for (int iter = 0; iter < 30; iter++) {
+    double p = (double)a0[0] * a1[0];
+    p += (double)a0[1] * a1[1];
+    if (fabs(p) <= eps * sqrt(W0 * W1)) break;
+    p *= 2;
+    const double beta = W0 - W1, gamma = hypot(p, beta);
+    float c, s;
+    if (beta < 0) {
+      const double delta = (gamma - beta) * 0.5;
+      s = (float)sqrt(delta / gamma);
+      c = (float)(p / (gamma * s * 2));
+    } else {
+      c = (float)sqrt((gamma + beta) / (gamma * 2));
+      s = (float)(p / (gamma * c * 2));
+    }
+    W0 = 0; W1 = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const float t0 = c * a0[q] + s * a1[q];
+      const float t1 = -s * a0[q] + c * a1[q];
+      a0[q] = t0; a1[q] = t1;
+      W0 += (double)t0 * t0; W1 += (double)t1 * t1;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const float t0 = c * v0[q] + s * v1[q];
+      const float t1 = -s * v0[q] + c * v1[q];
+      v0[q] = t0; v1[q] = t1;
+    }
+  }
+  W0 = sqrt((double)a0[0] * a0[0] + (double)a0[1] * a0[1]);
+  W1 = sqrt((double)a1[0] * a1[0] + (double)a1[1] * a1[1]);
+  if (W0 < W1) {
+    const double tw = W0; W0 = W1; W1 = tw;
+#pragma unroll
+    for (int q = 0; q < 2; q++) { float t = a0[q]; a0[q] = a1[q]; a1[q] = t; t = v0[q]; v0[q] = v1[q]; v1[q] = t; }
+  }
+  d[0] = (float)W0; d[1] = (float)W1;
+  if (W0 <= minval || W1 <= minval) return false;
+  const float s0 = (float)(1 / W0), s1 = (float)(1 / W1);
+  a0[0] *= s0; a0[1] *= s0; a1[0] *= s1; a1[1] *= s1;
+  U[0] = a0[0]; U[1] = a1[0]; U[2] = a0[1]; U[3] = a1[1];
+  Vt[0] = v0[0]; Vt[1] = v0[1]; Vt[2] = v1[0]; Vt[3] = v1[1];
+  return true;
+}
+__global__ __launch_bounds__(256) void baumberg_hessian_kernel(const PyramidDev *__restrict__ P, DetectConst k, CandDev *__restrict__ cand,
+                                                               const int *__restrict__ acc_list, const int *__restrict__ acc_count,
+                                                               unsigned long long *__restrict__ sort_keys, int *__restrict__ sort_idx,
+                                                               int *__restrict__ key_count) {
+  const int b = blockIdx.y;
+  const int n_acc = acc_count[b];
+  for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n_acc; slot += gridDim.x * 256) {
+    const int ci = acc_list[(size_t)b * k.max_cand + slot];
+    CandDev &cd = cand[(size_t)b * k.max_cand + ci];
+    const OctaveDev &o = P->oct[cd.octave];
+    const bool sfi = k.sfi_img != nullptr;
+    const int iw = sfi ? k.sfi_w : o.w, ih = sfi ? k.sfi_h : o.h;
+    const float *im = sfi ? k.sfi_img + (size_t)iw * ih * b : as_global(o.blur[cd.level - 1]) + (size_t)iw * ih * b;
+    const float pd = sfi ? 1.0f : cd.pixelDistance;
+    float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
+    float u[4] = {1.0f, 0.0f, 0.0f, 1.0f};
+    const float lx = cd.x / pd, ly = cd.y / pd;
+    const float aff_ratio = cd.s * k.aff_meas_region / pd;
+    bool converged = !k.do_baumberg;
+    for (int l = 0; l < k.max_iter && k.do_baumberg; l++) {
+      const float a11 = u[0] * aff_ratio, a12 = u[1] * aff_ratio, a21 = u[2] * aff_ratio, a22 = u[3] * aff_ratio;
+      const bool touch = check_borders(iw, ih, lx, ly, a11, a12, a21, a22, 3, 3);
+      float q[9];
+      float rx = lx - 1.0f * a12, ry = ly - 1.0f * a22;         // interpolate(), helpers.cpp:551-626: sequential fp32 coordinates
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        float WX = rx - 1.0f * a11, WY = ry - 1.0f * a21;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          q[j * 3 + i] = tap_combine(tap_load_bf(im, iw, ih, WX, WY, touch));
+          WX += a11; WY += a21;
+        }
+        rx += a12; ry += a22;
+      }
+      const float Dxx = (q[0] - 2.f * q[1] + q[2] + 2.f * q[3] - 4.f * q[4] + 2.f * q[5] + q[6] - 2.f * q[7] + q[8]);
+      const float Dyy = (q[0] + 2.f * q[1] + q[2] - 2.f * q[3] - 4.f * q[4] - 2.f * q[5] + q[6] + 2.f * q[7] + q[8]);
+      const float Dxy = (q[0] - q[2] - q[6] + q[8]);
+      const float Au0[4] = {Dxx, Dxy, Dxy, Dyy};
+      float d[2], U[4], Vt[4];
+      eigen_ratio_bef = eigen_ratio_act;
+      if (!svd2x2_f32(Au0, d, U, Vt)) break;
+      float l1 = d[0], l2 = d[1];
+      eigen_ratio_act = (float)(1.0 - fabsf(l2) / fabsf(l1));
+      const float det = sqrtf(fabsf(l1 * l2));
+      l2 = sqrtf(sqrtf(fabsf(l1) / det));
+      l1 = (float)(1. / l2);
+      const float D[4] = {l1, 0.f, 0.f, l2};
+      float UD[4], Au[4], T[4], Ap[4];
+      mul2x2_f32(U, D, UD);
+      mul2x2_f32(UD, Vt, Au);
+      mul2x2_f32(Au, u, T);
+      mul2x2_f32(T, Au, Ap);
+      u[0] = Ap[0]; u[1] = Ap[1]; u[2] = Ap[2]; u[3] = Ap[3];
+      // getEigenvalues, helpers.cpp:504-515
+      const float trace = u[0] + u[3];
+      const float delta1 = (trace * trace - 4 * (u[0] * u[3] - u[1] * u[2]));
+      if (delta1 < 0) break;
+      const float delta = sqrtf(delta1);
+      l1 = (trace + delta) / 2.0f;
+      l2 = (trace - delta) / 2.0f;
+      if ((l1 / l2 > 6) || (l2 / l1 > 6)) break;
+      if (eigen_ratio_act < k.conv_th && eigen_ratio_bef < k.conv_th) { converged = true; break; }
+    }
+    if (converged) {
+      cd.a11 = u[0]; cd.a12 = u[1]; cd.a21 = u[2]; cd.a22 = u[3];
+      cd.state = 3;
+      const unsigned int absbits = __float_as_uint(fabsf(cd.response));
+      const unsigned int order = ((unsigned int)cd.octave << 28) | ((unsigned int)cd.level << ORDER_POS_BITS) |
+                                 (unsigned int)(cd.r0 * iw + cd.c0);
+      const int sl2 = atomicAdd(&key_count[b], 1);
+      sort_keys[(size_t)b * k.max_cand + sl2] = ((unsigned long long)(~absbits) << 32) | order;
+      sort_idx[(size_t)b * k.max_cand + sl2] = ci;
+    } else cd.state = 4;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Baumberg iteration: one wave per accepted point.
 // ---------------------------------------------------------------------------------------
 // invSqrt, helpers.cpp:463-502 (double inside)
@@ -850,8 +990,10 @@ int detect_run(mods_ctx *ctx) {
   k.conv_th = par.convergenceThreshold;
   k.initial_sigma = par.initialSigma;
   k.do_baumberg = par.doBaumberg;
+  k.aff_meas_region = 0.5f;
   k.sfi_img = par.sampleFromImage ? ctx->last_img_dev : nullptr;
   k.sfi_w = ctx->last_w; k.sfi_h = ctx->last_h;
+  if (par.affBmbrgMethod != 0 && par.affBmbrgMethod != 1) { set_error("affBmbrgMethod %d: 0 (second moment matrix) or 1 (Hessian)", par.affBmbrgMethod); return MODS_E_ARG; }
   if (par.sampleFromImage && (!ctx->last_img_dev || ctx->last_stride != ctx->last_w)) { set_error("sampleFromImage needs the dense input image of the batch"); return MODS_E_ARG; }
   for (int oi = 0; oi < P.n_oct; oi++)
     if ((size_t)P.oct[oi].w * P.oct[oi].h >= (1u << ORDER_POS_BITS)) { set_error("octave too large for the order key"); return MODS_E_ARG; }
@@ -934,9 +1076,13 @@ int detect_run(mods_ctx *ctx) {
 #endif
     const size_t wp = (((size_t)par.smmWindowSize * par.smmWindowSize) + 3) & ~(size_t)3;
     const size_t lds = sizeof(float) * (wp + BAUMBERG_KP * (4 * wp + 4));
-    hipLaunchKernelGGL(baumberg_kernel<BAUMBERG_KP>, dim3(8192, n_img), dim3(64), lds, ctx->stream, ctx->pyr_dev, k, ctx->cand,
-                       ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->smm_mask_dev, ctx->sort_keys,
-                       ctx->sort_idx, key_count);
+    if (par.affBmbrgMethod == 1)
+      hipLaunchKernelGGL(baumberg_hessian_kernel, dim3(64, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, k, ctx->cand,
+                         ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->sort_keys, ctx->sort_idx, key_count);
+    else
+      hipLaunchKernelGGL(baumberg_kernel<BAUMBERG_KP>, dim3(8192, n_img), dim3(64), lds, ctx->stream, ctx->pyr_dev, k, ctx->cand,
+                         ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->smm_mask_dev, ctx->sort_keys,
+                         ctx->sort_idx, key_count);
     MODS_HIP_CHECK(hipGetLastError());
   }
   {

@@ -28,7 +28,7 @@ struct orc_hessaff_params {     // mirrors include/mods_hip.h: mods_hessaff_para
   int iiDoGMode;
   int sampleFromImage;
   double mserMaxArea, mserMinMargin;
-  int mserMinSize, pad;
+  int mserMinSize, affBmbrgMethod;
 };
 
 struct orc_candidate { int octave, level, r0, c0, r, c; float x, y, s, pixelDistance, response; int type; };
@@ -43,6 +43,7 @@ static HessAffParams cvt(const orc_hessaff_params *p) {
     q.mode = p->mode; q.rel_threshold = p->relativeThreshold; q.reg_number = p->regionsNumber; q.rel_reg_number = p->relativeRegionsNumber;
     q.detector_type = p->detectorType; q.ii_dog = p->iiDoGMode; q.sample_from_image = p->sampleFromImage;
     q.mser_max_area = p->mserMaxArea; q.mser_min_margin = p->mserMinMargin; q.mser_min_size = p->mserMinSize;
+    q.aff_bmbrg_method = p->affBmbrgMethod;
   }
   return q;
 }
@@ -106,6 +107,12 @@ void orc_resize_half(const float *src, int w, int h, float *dst) {
   Img a = wrap(src, w, h), b;
   resize_half(a, b);
   std::memcpy(dst, b.d.data(), sizeof(float) * (size_t)b.w * b.h);
+}
+// out = d0 d1 | U (4, row-major) | Vt (4); returns 1 when a singular value is <= FLT_MIN
+int orc_svd2x2(const float *A, float *out) {
+  bool deg = false;
+  svd2x2_f32(A, out, out + 2, out + 6, &deg);
+  return deg ? 1 : 0;
 }
 int orc_interpolate(const float *src, int w, int h, float ofsx, float ofsy, float a11, float a12, float a21,
                     float a22, int rw, int rh, float *dst) {

@@ -4,6 +4,7 @@
 #include "orc.h"
 #include "detmath.h"
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 
 namespace orc {
@@ -187,7 +188,119 @@ void find_candidates(const Pyramid &pyr, const HessAffParams &p, std::vector<Can
   }
 }
 
-// AffineShape::findAffineShape, SMM branch (affine.cpp:26-158).
+// ---- the Hessian form of the Baumberg iteration (affBmbrgMethod = 1, affine.cpp:92-128) ------------------------------------
+// PARITY UNPINNED beyond the reference's own lines: the step leans on cv::SVD::compute and on cv::Mat products of 2x2 float
+// matrices, i.e. on OpenCV (4.x, absent here), restated below from its published sources: modules/core/src/lapack.cpp
+// JacobiSVDImpl_<float> behind _SVDcompute (one-sided Jacobi on the rows of A^T, double accumulators, eps = 2 FLT_EPSILON,
+// singular values sorted descending, U = normalised rows) and the len == 2 fast path of cv::gemm (matmul: fp32 products and sums,
+// no accumulation in double).  A build of OpenCV that routes hal::SVD32f to LAPACK (sgesdd) may differ in the last bits and in
+// the signs of U / V; no shipped configuration sets the key.
+void svd2x2_f32(const float A[4], float d[2], float U[4], float Vt[4], bool *degenerate) {
+  const int m = 2, n = 2;
+  const float eps = FLT_EPSILON * 2;
+  const double minval = FLT_MIN;
+  float At[2][2] = {{A[0], A[2]}, {A[1], A[3]}};      // transpose(src, temp_a): row i = column i of A
+  float V[2][2] = {{1, 0}, {0, 1}};
+  double W[2];
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) { const float t = At[i][k]; sd += (double)t * t; }
+    W[i] = sd;
+  }
+  const int max_iter = 30;                              // std::max(m, 30)
+  for (int iter = 0; iter < max_iter; iter++) {
+    bool changed = false;
+    {                                                   // the one pair (i, j) = (0, 1)
+      float *Ai = At[0], *Aj = At[1];
+      double a = W[0], p = 0, b = W[1];
+      for (int k = 0; k < m; k++) p += (double)Ai[k] * Aj[k];
+      if (!(std::abs(p) <= eps * std::sqrt((double)a * b))) {
+        p *= 2;
+        const double beta = a - b, gamma = hypot((double)p, beta);
+        float c, s;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = (float)std::sqrt(delta / gamma);
+          c = (float)(p / (gamma * s * 2));
+        } else {
+          c = (float)std::sqrt((gamma + beta) / (gamma * 2));
+          s = (float)(p / (gamma * c * 2));
+        }
+        a = b = 0;
+        for (int k = 0; k < m; k++) {
+          const float t0 = c * Ai[k] + s * Aj[k];
+          const float t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0; Aj[k] = t1;
+          a += (double)t0 * t0; b += (double)t1 * t1;
+        }
+        W[0] = a; W[1] = b;
+        changed = true;
+        for (int k = 0; k < n; k++) {
+          const float t0 = c * V[0][k] + s * V[1][k];
+          const float t1 = -s * V[0][k] + c * V[1][k];
+          V[0][k] = t0; V[1][k] = t1;
+        }
+      }
+    }
+    if (!changed) break;
+  }
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) { const float t = At[i][k]; sd += (double)t * t; }
+    W[i] = std::sqrt(sd);
+  }
+  if (W[0] < W[1]) {
+    std::swap(W[0], W[1]);
+    for (int k = 0; k < m; k++) std::swap(At[0][k], At[1][k]);
+    for (int k = 0; k < n; k++) std::swap(V[0][k], V[1][k]);
+  }
+  d[0] = (float)W[0]; d[1] = (float)W[1];
+  // a singular value <= FLT_MIN: OpenCV builds the missing left vector from its random generator; findAffineShape then divides
+  // by det = 0 and carries non-finite shapes into the next interpolate() (undefined there).  Reported, and the caller drops
+  // the point.
+  *degenerate = W[0] <= minval || W[1] <= minval;
+  for (int i = 0; i < n; i++) {
+    const float s = (float)(W[i] > minval ? 1 / W[i] : 0.);
+    for (int k = 0; k < m; k++) At[i][k] *= s;
+  }
+  U[0] = At[0][0]; U[1] = At[1][0]; U[2] = At[0][1]; U[3] = At[1][1];      // transpose(temp_u, _u)
+  Vt[0] = V[0][0]; Vt[1] = V[0][1]; Vt[2] = V[1][0]; Vt[3] = V[1][1];
+}
+// cv::gemm, 2x2 fp32 operands (the len == 2 path): every product and sum rounded to fp32
+static void mul2x2_f32(const float a[4], const float b[4], float d[4]) {
+  const float t0 = a[0] * b[0] + a[1] * b[2], t1 = a[0] * b[1] + a[1] * b[3];
+  const float t2 = a[2] * b[0] + a[3] * b[2], t3 = a[2] * b[1] + a[3] * b[3];
+  d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3;
+}
+// one step of affine.cpp:92-128: updates u, returns the two singular values' ratio term; false = degenerate Hessian
+static bool hessian_shape_step(const Img &blur, float lx, float ly, float affRatio, float u[4], float *eigen_ratio_act) {
+  Img h3(3, 3);
+  interpolate(blur, lx, ly, u[0] * affRatio, u[1] * affRatio, u[2] * affRatio, u[3] * affRatio, h3);
+  const float *q = h3.d.data();
+  const float Dxx = (q[0] - 2.f * q[1] + q[2] + 2.f * q[3] - 4.f * q[4] + 2.f * q[5] + q[6] - 2.f * q[7] + q[8]);
+  const float Dyy = (q[0] + 2.f * q[1] + q[2] - 2.f * q[3] - 4.f * q[4] - 2.f * q[5] + q[6] + 2.f * q[7] + q[8]);
+  const float Dxy = (q[0] - q[2] - q[6] + q[8]);
+  const float Au0[4] = {Dxx, Dxy, Dxy, Dyy};
+  float d[2], U[4], Vt[4];
+  bool degenerate;
+  svd2x2_f32(Au0, d, U, Vt, &degenerate);
+  if (degenerate) return false;
+  float l1 = d[0], l2 = d[1];
+  *eigen_ratio_act = (float)(1.0 - std::abs(l2) / std::abs(l1));
+  const float det = std::sqrt(std::abs(l1 * l2));
+  l2 = std::sqrt(std::sqrt(std::abs(l1) / det));
+  l1 = (float)(1. / l2);
+  const float D[4] = {l1, 0, 0, l2};
+  float UD[4], Au[4], T[4], Ap[4];
+  mul2x2_f32(U, D, UD);
+  mul2x2_f32(UD, Vt, Au);        // Au = U * D * V (V is what SVD::compute returns as vt)
+  mul2x2_f32(Au, u, T);
+  mul2x2_f32(T, Au, Ap);         // Ap = Au * Ap * Au
+  u[0] = Ap[0]; u[1] = Ap[1]; u[2] = Ap[2]; u[3] = Ap[3];
+  return true;
+}
+
+// AffineShape::findAffineShape (affine.cpp:26-158): the SMM branch and, with p.aff_bmbrg_method = 1, the Hessian branch.
 bool find_affine_shape(const Img &blur, float x, float y, float s, float pixelDistance,
                        const HessAffParams &p, const Img &mask, float a_out[4], int *iters) {
   float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
@@ -202,6 +315,22 @@ bool find_affine_shape(const Img &blur, float x, float y, float s, float pixelDi
   }
   const int maskPixels = W * W;
   Img img(W, W), fx(W, W), fy(W, W);
+  if (p.aff_bmbrg_method == 1) {
+    const float affRatio = s * p.aff_meas_region / pixelDistance;
+    float u[4] = {u11, u12, u21, u22};
+    for (int l = 0; l < p.maxIterations; l++) {
+      eigen_ratio_bef = eigen_ratio_act;
+      if (!hessian_shape_step(blur, lx, ly, affRatio, u, &eigen_ratio_act)) break;
+      if (!get_eigenvalues(u[0], u[1], u[2], u[3], l1, l2)) break;
+      if ((l1 / l2 > 6) || (l2 / l1 > 6)) break;
+      if (eigen_ratio_act < p.convergenceThreshold && eigen_ratio_bef < p.convergenceThreshold) {
+        a_out[0] = u[0]; a_out[1] = u[1]; a_out[2] = u[2]; a_out[3] = u[3];
+        if (iters) *iters = l;
+        return true;
+      }
+    }
+    return false;
+  }
   for (int l = 0; l < p.maxIterations; l++) {
     float a = 0, b = 0, c = 0;
     interpolate(blur, lx, ly, u11 * ratio, u12 * ratio, u21 * ratio, u22 * ratio, img);

@@ -92,6 +92,9 @@ struct HessAffParams {          // PyramidParams + AffineShapeParams, detectors/
   double mser_max_area = 0.01;
   double mser_min_margin = 10;
   int mser_min_size = 30;
+  // AffineShapeParams::affBmbrgMethod / affMeasRegion (affine.h:21-24, 49-50, 63-64): 0 = SMM, 1 = Hessian form of the iteration
+  int aff_bmbrg_method = 0;
+  float aff_meas_region = 0.5f;
 };
 
 struct Candidate {              // one accepted pyramid keypoint before affine adaptation
@@ -115,6 +118,8 @@ struct Pyramid {
 void build_pyramid(const Img &image, const HessAffParams &p, Pyramid &pyr);
 void find_candidates(const Pyramid &pyr, const HessAffParams &p, std::vector<Candidate> &out,
                      std::vector<int> *nms_raw = nullptr);
+// cv::SVD::compute of a 2x2 fp32 matrix as OpenCV's Jacobi routine does it (detect.cpp; parity unpinned): A = U diag(d) Vt
+void svd2x2_f32(const float A[4], float d[2], float U[4], float Vt[4], bool *degenerate);
 bool find_affine_shape(const Img &blur, float x, float y, float s, float pixelDistance,
                        const HessAffParams &p, const Img &mask, float a[4], int *iters);
 // Full DetectAffineKeypoints + DetectAffineRegions (scale-space-detector.cpp:13-32,

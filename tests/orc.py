@@ -16,7 +16,7 @@ class HessAffParams(C.Structure):
                 ("mode", C.c_int), ("relativeThreshold", C.c_float), ("regionsNumber", C.c_int),
                 ("relativeRegionsNumber", C.c_float), ("detectorType", C.c_int), ("iiDoGMode", C.c_int),
                 ("sampleFromImage", C.c_int),
-                ("mserMaxArea", C.c_double), ("mserMinMargin", C.c_double), ("mserMinSize", C.c_int), ("pad", C.c_int)]
+                ("mserMaxArea", C.c_double), ("mserMinMargin", C.c_double), ("mserMinSize", C.c_int), ("affBmbrgMethod", C.c_int)]
 
     @staticmethod
     def mser(mode=0, min_margin=8, max_area=0.05, min_size=30, reg_number=500, rel_threshold=-1.0, rel_reg_number=-1.0):
@@ -207,6 +207,14 @@ def detect_hessian_affine(img, params=None, max_out=1 << 20):
     n = lib().orc_detect_hessian_affine(p, a.shape[1], a.shape[0], C.byref(params),
                                         out.ctypes.data_as(C.POINTER(AffKey)), max_out)
     return out[:n].copy()
+
+
+def svd2x2(a):
+    """(d[2], U[2, 2], Vt[2, 2], degenerate) of a 2x2 fp32 matrix, the restated cv::SVD::compute."""
+    a = np.ascontiguousarray(a, np.float32).reshape(4)
+    out = np.zeros(10, np.float32)
+    deg = lib().orc_svd2x2(a.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:2].copy(), out[2:6].reshape(2, 2).copy(), out[6:10].reshape(2, 2).copy(), bool(deg)
 
 
 def mser_regions(img, params=None, max_regions=1 << 16, max_runs=1 << 24):

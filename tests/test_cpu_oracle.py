@@ -162,3 +162,42 @@ def test_empty_and_tiny_inputs():
     assert len(orc.detect_hessian_affine(synth.texture(12, 12, seed=1))) == 0
     z = np.zeros(0, orc.REGION_DTYPE)
     assert len(orc.match_fginn(z, z)) == 0
+
+
+def test_svd2x2_restatement_is_an_svd():
+    """The Hessian form of the Baumberg iteration (affBmbrgMethod = 1, affine.cpp:92-128) leans on cv::SVD::compute of a 2x2 fp32
+    matrix; the oracle restates OpenCV's one-sided Jacobi routine (parity unpinned: OpenCV is absent).  Checked here as an SVD:
+    U diag(d) Vt reproduces the matrix, U and Vt are orthogonal, d is sorted and equals numpy's singular values to fp32."""
+    rng = np.random.default_rng(5)
+    for i in range(400):
+        a = rng.standard_normal((2, 2)).astype(np.float32) * np.float32(10.0 ** rng.integers(-3, 4))
+        if i % 2 == 0:
+            a[1, 0] = a[0, 1]                      # the iteration's matrices are symmetric (Dxx Dxy; Dxy Dyy)
+        d, U, Vt, deg = orc.svd2x2(a)
+        assert not deg
+        assert d[0] >= d[1] >= 0
+        sv = np.linalg.svd(a.astype(np.float64), compute_uv=False)
+        assert np.allclose(d, sv, rtol=2e-6, atol=1e-6 * sv[0])
+        assert np.allclose(U @ np.diag(d) @ Vt, a, rtol=0, atol=4e-6 * sv[0])
+        assert np.allclose(U @ U.T, np.eye(2), atol=4e-6) and np.allclose(Vt @ Vt.T, np.eye(2), atol=4e-6)
+    # diagonal input: no rotation, the values come out sorted with their axes swapped
+    d, U, Vt, deg = orc.svd2x2(np.array([[1.0, 0.0], [0.0, -3.0]], np.float32))
+    assert np.array_equal(d, np.array([3.0, 1.0], np.float32)) and not deg
+    assert np.allclose(U @ np.diag(d) @ Vt, [[1.0, 0.0], [0.0, -3.0]])
+    assert orc.svd2x2(np.zeros((2, 2), np.float32))[3]          # flat neighbourhood: reported degenerate
+    assert orc.svd2x2(np.array([[1.0, 1.0], [1.0, 1.0]], np.float32))[3]   # rank 1
+
+
+def test_hessian_baumberg_differs_from_smm_and_is_area_preserving():
+    """affBmbrgMethod = 1: the shapes differ from the second-moment iteration's, every update Au (U diag(1/l, l) Vt) has
+    determinant +-1 up to rounding, so the accumulated shape keeps |det| = 1; anisotropy stays below the reference's bound 6."""
+    img = synth.texture(320, 240, seed=4)
+    p0, p1 = orc.HessAffParams.default(), orc.HessAffParams.default()
+    p1.affBmbrgMethod = 1
+    k0, k1 = orc.detect_hessian_affine(img, p0), orc.detect_hessian_affine(img, p1)
+    assert len(k1) > 50 and (len(k0) != len(k1) or not np.array_equal(k0["a21"], k1["a21"]))
+    # AffineKeypoints leave the detector rectified (a12 = 0, det = 1): scale-space-detector.hpp:100-124
+    det = k1["a11"] * k1["a22"] - k1["a12"] * k1["a21"]
+    assert np.allclose(det, 1.0, atol=1e-4)
+    lam = np.array([np.linalg.svd(np.array([[r["a11"], r["a12"]], [r["a21"], r["a22"]]]), compute_uv=False) for r in k1])
+    assert (lam[:, 0] / lam[:, 1] < 6.0 * 1.001).all()

@@ -20,16 +20,16 @@ def _grey(fn):
     return orc.grey_of_rgb(np.asarray(Image.open(fn).convert("RGB")))     # (B + G + R) / 3.0 as OpenCV evaluates it
 
 
-def _run(tmp_path, iters, ver_type="0"):
+def _run(tmp_path, iters, ver_type="0", config=None):
     env = dict(os.environ, MODS_RANSAC_SEED="4242")
     args = [MODS, G1, G6, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", ver_type, "H.txt",
-            os.path.join(CFG, "classic.ini"), os.path.join(CFG, iters)]
+            config or os.path.join(CFG, "classic.ini"), os.path.join(CFG, iters)]
     p = subprocess.run(args, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()
     return p.stderr.decode()
 
 
-def _library_run(pkg, steps, use_f=0):
+def _library_run(pkg, steps, use_f=0, bmbrg=0):
     import torch
     a, b = _grey(G1), _grey(G6)
     h, w = a.shape
@@ -40,6 +40,7 @@ def _library_run(pkg, steps, use_f=0):
     torch.cuda.synchronize()
     par = pkg.PairParams.default()
     par.ransac.useF = use_f
+    par.det.affBmbrgMethod = bmbrg
     pkg.ransac_pin_seed(4242)
     res, m = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2, par, max_matches=1 << 20)
     regs = (rep1.fetch(), rep2.fetch())
@@ -73,6 +74,29 @@ def test_cli_one_view_matches_library_and_readme(pkg, tmp_path):
         assert np.array_equal(row[8:], r[0]["desc"].astype(float))
     assert "Done in 1 iterations" in err
     assert os.path.exists(tmp_path / "time.log")
+
+
+def test_cli_hessian_baumberg_key(pkg, tmp_path):
+    """[HessianAffine] affBmbrgMethod = 1 (io_mods.cpp:193) reaches the detector: same files as the library with the key set,
+    other regions than the second-moment iteration's (2665 / 3287 on this pair)."""
+    cfg = (tmp_path / "hb.ini")
+    text = open(os.path.join(CFG, "classic.ini")).read()
+    assert "[HessianAffine]" in text and "affBmbrgMethod" not in text
+    cfg.write_text(text.replace("[HessianAffine]", "[HessianAffine]\naffBmbrgMethod = 1", 1))
+    _run(tmp_path, "iters_one_view.ini", config=str(cfg))
+    res, m, regs = _library_run(pkg, [pkg.LadderStep.make((1,), 360.0)], bmbrg=1)
+    got = np.loadtxt(tmp_path / "m.txt").reshape(-1, 4)
+    assert len(got) == res.n_inliers > 15
+    assert np.allclose(got, m, rtol=1e-5, atol=1e-3)
+    assert (res.n_unoriented[0], res.n_unoriented[1]) != (2665, 3287)
+    for fn, r in (("k1.txt", regs[0]), ("k2.txt", regs[1])):
+        lines = (tmp_path / fn).read_text().splitlines()
+        assert lines[2] == "RootSIFT %d" % len(r)
+    (tmp_path / "bad.ini").write_text(text.replace("[HessianAffine]", "[HessianAffine]\naffBmbrgMethod = 3", 1))
+    p = subprocess.run([MODS, G1, G6, "o1.png", "o2.png", "k1.txt", "k2.txt", "m.txt", "log.txt", "0", "0", "H.txt",
+                        str(tmp_path / "bad.ini"), os.path.join(CFG, "iters_one_view.ini")], cwd=tmp_path, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0 and "affBmbrgMethod" in p.stderr.decode()
 
 
 def test_cli_ladder_and_epipolar(pkg, tmp_path):

@@ -187,6 +187,52 @@ def test_keypoint_selection_modes(pkg, mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,w,h,seed,sfi", [("HessianAffine", 640, 480, 11, 0), ("HessianAffine", 515, 389, 3, 1),
+                                               ("DoG", 400, 300, 5, 0), ("HarrisAffine", 400, 300, 6, 0)])
+def test_hessian_form_of_the_baumberg_iteration(pkg, name, w, h, seed, sfi):
+    """affBmbrgMethod = 1 (io_mods.cpp:193, affine.cpp:92-128): 3x3 samples at s * 0.5, SVD of the finite-difference Hessian,
+    Ap <- Au Ap Au - one lane per point (baumberg_hessian_kernel) against the oracle's restatement, bit for bit; with
+    sampleFromImage, and behind the DoG / Harris responses with doBaumberg switched on."""
+    import orc
+    img = synth.texture(w, h, seed=seed)
+    make = {"HessianAffine": "default", "DoG": "dog", "HarrisAffine": "harris"}[name]
+    par, opar = getattr(pkg.HessAffParams, make)(), getattr(orc.HessAffParams, make)()
+    for q in (par, opar):
+        q.affBmbrgMethod = 1; q.doBaumberg = 1; q.sampleFromImage = sfi; q.mode = 0
+    ctx = pkg.Context(0, w, h, 1)
+    got = ctx.detect_hessian_affine(img, par)
+    want = orc.detect_hessian_affine(img, opar)
+    par.affBmbrgMethod = 0
+    base = ctx.detect_hessian_affine(img, par)
+    assert len(want) > 100
+    _assert_keys_equal(got, want)
+    assert len(base) != len(got) or not np.array_equal(base["a21"], got["a21"])
+    par.affBmbrgMethod = 2
+    with pytest.raises(Exception, match="affBmbrgMethod"):
+        ctx.detect_hessian_affine(img, par)
+    ctx.close()
+
+
+def test_hessian_form_batch_and_describe(pkg):
+    """The same through the batched entry point the pipeline uses (two images per launch, orientation + RootSIFT behind it)."""
+    import orc
+    import torch
+    w, h = 480, 360
+    imgs = [synth.texture(w, h, seed=21), synth.texture(w, h, seed=22)]
+    par, opar = pkg.HessAffParams.default(), orc.HessAffParams.default()
+    par.affBmbrgMethod = 1; opar.affBmbrgMethod = 1
+    ctx = pkg.Context(0, w, h, 2)
+    t = torch.from_numpy(np.stack(imgs)).cuda()
+    nd, nr = ctx.detect_describe_dev(t.data_ptr(), 2, w, h, det=par)
+    for b in range(2):
+        want, ndet = orc.detect_describe(imgs[b], opar)
+        got = ctx.regions_fetch(b)
+        assert nd[b] == ndet and nr[b] == len(want) > 100
+        for f in ("x", "y", "s", "a11", "a12", "a21", "a22", "response", "sub_type", "desc"):
+            assert np.array_equal(got[f], want[f]), (b, f)
+    ctx.close()
+
+
 def test_sample_from_image(pkg):
     """[HessianAffine] sampleFromImage = 1 (io_mods.cpp:184): the Baumberg iteration samples the input image at pixel distance 1
     (scale-space-detector.hpp:47-55) instead of the blur level; keypoints equal the oracle's bit for bit and differ from the
