@@ -173,8 +173,12 @@ __device__ __forceinline__ void tile_store2(char *buf, const TileRegs2 &r) {
 // half of one copy with the lower half of the other, so both copies then hold both halves' values lane by lane (the shuffle
 // builtin goes through ds_bpermute: eight address instructions and an LDS round trip inside the exact path)
 __device__ __forceinline__ int max_halves(int x) {
+#ifdef MATCH_NO_PERMLANE
+  return max(x, __shfl_xor(x, 32));
+#else
   const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
   return max((int)r[0], (int)r[1]);
+#endif
 }
 __device__ __forceinline__ int med3_i32(int a, int b, int c) {
   int o;
@@ -188,7 +192,15 @@ __device__ unsigned long long g_match_stats[4];
 #define MATCH_XCH 16   // tiles between two exchanges of the shared bound (a power of two)
 #endif
 
-__global__ __launch_bounds__(NN1_THREADS) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
+// amdgpu_num_vgpr counts in pairs on gfx950 (the value is doubled for the unified register file): 62 = at most 124 VGPRs, i.e.
+// v124..v127 of the 128 allocated (4 waves per SIMD) stay untouched.  With all 128 in use - `ds_read_b128 v[124:127]` fed the MFMAs -
+// this kernel intermittently changed single results of kernels running next to it on OTHER streams (one keypoint's shape, one
+// descriptor per ~10^3 pairs under the six-worker pipeline; never with one stream); every build that left the top registers
+// unused, whatever else it changed, was clean.  tools/stress_match.py reproduces it, DESIGN.md "The matcher and its neighbours".
+#ifndef MATCH_NN1_VGPRS
+#define MATCH_NN1_VGPRS 62
+#endif
+__global__ __launch_bounds__(NN1_THREADS) __attribute__((amdgpu_num_vgpr(MATCH_NN1_VGPRS))) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                         const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
                                                         const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                         unsigned long long *__restrict__ best2, int *__restrict__ gthr) {
@@ -289,7 +301,9 @@ __global__ __launch_bounds__(NN1_THREADS) void match_nn1_kernel(MatchConst k, co
       for (int b = 0; b < QB; b++) {
         const int j = jbase + 32 * b;
         int nb = bk[b];
+#ifndef MATCH_NO_ATOMIC
         if (g == 0 && j < k.n_q) nb = max(nb, 1 - atomicMin(&gthr[j], 1 - nb));
+#endif
         nb = max_halves(nb);
         bk[b] = nb; alim[b] = (nb + 1) >> 1;
       }
@@ -331,7 +345,9 @@ __global__ __launch_bounds__(NN1_THREADS) void match_nn1_kernel(MatchConst k, co
     const unsigned long long lo2 = sec_b < o2 ? sec_b : o2;
     const unsigned long long m2 = hi < lo2 ? hi : lo2;
     if (g == 0 && j < k.n_q) {
+#ifndef MATCH_NO_ATOMIC
       atomicMin(&gthr[j], 1 - bk[b]);
+#endif
       unsigned long long *o = best2 + ((size_t)blockIdx.y * n_qpad + j) * 2;
       o[0] = m1; o[1] = m2;
     }
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(256) void match_gather_kernel(const int *__restrict
 
 // Pass 2: FGINN reductions.  Same tiling and the same two-speed epilogue as pass 1: a tile is examined exactly
 // only when one of its partial distances lies below max(D*, smallest distance >= D* found so far).
-__global__ __launch_bounds__(256) void match_fginn_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MATCH_NN1_VGPRS))) void match_fginn_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                           const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
                                                           const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                           const double2 *__restrict__ txy, const QueryMid *__restrict__ mid,
@@ -714,9 +730,10 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   int8_t *qd2 = (int8_t *)(mid2 + n);
   int *list2 = (int *)(qd2 + n * 128), *qcs = list2 + n, *count2 = qcs + n;
   int *gthr = count2 + 16;
-  hipLaunchKernelGGL(match_init_kernel, dim3((std::max(n_q, n_t) + 255) / 256), dim3(256), 0, ctx->stream, n_q, n_t, count_out, count2, qpar, tpar, gthr);
-  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
-  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
+  static const int dbg_mask = getenv("MODS_MATCH_MASK") ? atoi(getenv("MODS_MATCH_MASK")) : 63;   // DEBUG bisect
+  if (dbg_mask & 1) hipLaunchKernelGGL(match_init_kernel, dim3((std::max(n_q, n_t) + 255) / 256), dim3(256), 0, ctx->stream, n_q, n_t, count_out, count2, qpar, tpar, gthr);
+  if (dbg_mask & 1) hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
+  if (dbg_mask & 1) hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
   (void)best;
   // pass 1: top-2 keys per query and train split
   constexpr int QPB = 32 * NN1_WAVES * MATCH_QB1;      // queries per pass-1 workgroup
@@ -727,21 +744,21 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   splits1 = (n_tiles + k1.tiles_per_split - 1) / k1.tiles_per_split;
   const size_t n_qpad = (size_t)qblocks1 * QPB;
   if ((size_t)splits1 * n_qpad > ctx->m_best2_cap) { set_error("match: top-2 table too small"); return MODS_E_CAPACITY; }
-  hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks1, splits1), dim3(NN1_THREADS), 0, ctx->stream, k1, qd, qc, td, tc, tc2, tpar, best2, gthr);
-  hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best2, splits1, n_qpad, txy, (QueryMid *)ctx->m_mid,
+  if (dbg_mask & 2) hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks1, splits1), dim3(NN1_THREADS), 0, ctx->stream, k1, qd, qc, td, tc, tc2, tpar, best2, gthr);
+  if (dbg_mask & 4) hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best2, splits1, n_qpad, txy, (QueryMid *)ctx->m_mid,
                      key_ge, key_lt, n_lt, bad, list2, count2);
   // pass 2 on the undecided queries only (their number stays on the device: the grid covers the worst case, idle blocks exit)
-  hipLaunchKernelGGL(match_gather_kernel, dim3(std::min(1024, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, list2, count2, qd, qc,
+  if (dbg_mask & 4) hipLaunchKernelGGL(match_gather_kernel, dim3(std::min(1024, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, list2, count2, qd, qc,
                      (const QueryMid *)ctx->m_mid, qd2, qcs, mid2);
   {
     const int qblocks = (n_q + 128 * MATCH_QB - 1) / (128 * MATCH_QB);
-    hipLaunchKernelGGL(match_fginn_kernel, dim3(std::max(target_blocks, qblocks)), dim3(256), 0, ctx->stream, k, qd2, qcs, td, tc, tc2, tpar, txy,
+    if (dbg_mask & 8) hipLaunchKernelGGL(match_fginn_kernel, dim3(std::max(target_blocks, qblocks)), dim3(256), 0, ctx->stream, k, qd2, qcs, td, tc, tc2, tpar, txy,
                        (const QueryMid *)mid2, key_ge, key_lt, n_lt, bad, count2, list2);
   }
   const int eblocks = (n_q + 1023) / 1024;
   int *block_counts = (int *)(ctx->m_int + 2 * n);
-  hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
-  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, tent_out, count_out, ctx->max_cand);
+  if (dbg_mask & 16) hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
+  if (dbg_mask & 16) hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, tent_out, count_out, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }

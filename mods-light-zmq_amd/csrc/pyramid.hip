@@ -687,6 +687,9 @@ __device__ __forceinline__ float lds_col_px(const float *B, int x, int y, int w,
   }
   return s;
 }
+// p / w for p < 2^32 / w as one multiply-high (w = 1: the magic is 0 and p itself is returned)
+__device__ __forceinline__ unsigned lds_div_magic(int w) { return w > 1 ? 0xFFFFFFFFu / (unsigned)w + 1u : 0u; }
+__device__ __forceinline__ int lds_div(int p, unsigned magic) { return magic ? (int)__umulhi((unsigned)p, magic) : p; }
 __global__ __launch_bounds__(1024) void pyramid_lds_kernel(const PyramidDev *__restrict__ P, LdsPyramidPlan pl) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *A = sm, *B = sm + LDSP_CAP, *N = B + LDSP_CAP;
@@ -705,29 +708,32 @@ __global__ __launch_bounds__(1024) void pyramid_lds_kernel(const PyramidDev *__r
       const float *t = pl.taps[l].t;
       // (one workgroup per image = one CU: the passes are bound by instruction issue, so the tap loops are instantiated for the
       // kernel size - immediate LDS offsets, no address arithmetic or clamping per tap away from the plane's edge)
+      // (p / w as one multiply-high: exact for p < 2^32 / w, the planes here hold <= LDSP_CAP pixels)
       const int npx = w * h;
+      const unsigned inv_w = lds_div_magic(w);
       for (int p = tid; p < npx; p += 1024) {              // row pass A -> B
-        const int y = p / w, x = p - y * w;
+        const int y = lds_div(p, inv_w), x = p - y * w;
         B[p] = lds_row_px(A + y * w, x, w, n, t);
       }
       __syncthreads();
       float *blur = as_global(o.blur[l]) + plane;
       for (int p = tid; p < npx; p += 1024) {              // column pass B -> A (and the level's blurred plane)
-        const int y = p / w, x = p - y * w;
+        const int y = lds_div(p, inv_w), x = p - y * w;
         const float s = lds_col_px(B, x, y, w, h, n, t);
         A[p] = s;
         blur[p] = s;
       }
       __syncthreads();
       float *resp = as_global(o.resp[l]) + plane;
-      for (int p = tid; p < w * h; p += 1024) { const int y = p / w, x = p - y * w; resp[p] = lds_response(A, w, h, x, y, pl.norm2[l]); }
+      for (int p = tid; p < npx; p += 1024) { const int y = lds_div(p, inv_w), x = p - y * w; resp[p] = lds_response(A, w, h, x, y, pl.norm2[l]); }
       if (l == pl.S && oi + 1 < pl.n_oct) {                // first level of the next octave: decimation + its response
         const OctaveDev &nx = P->oct[oi + 1];
         const int dw = nx.w, dh = nx.h;
-        for (int q = tid; q < dw * dh; q += 1024) { const int dy = q / dw, dx = q - dy * dw; N[q] = decimated_at(A, w, h, dx, dy); }
+        const unsigned inv_dw = lds_div_magic(dw);
+        for (int q = tid; q < dw * dh; q += 1024) { const int dy = lds_div(q, inv_dw), dx = q - dy * dw; N[q] = decimated_at(A, w, h, dx, dy); }
         __syncthreads();
         float *nb = as_global(nx.blur[0]) + (size_t)dw * dh * b, *nr = as_global(nx.resp[0]) + (size_t)dw * dh * b;
-        for (int q = tid; q < dw * dh; q += 1024) { const int dy = q / dw, dx = q - dy * dw; nb[q] = N[q]; nr[q] = lds_response(N, dw, dh, dx, dy, pl.norm2_first); }
+        for (int q = tid; q < dw * dh; q += 1024) { const int dy = lds_div(q, inv_dw), dx = q - dy * dw; nb[q] = N[q]; nr[q] = lds_response(N, dw, dh, dx, dy, pl.norm2_first); }
       }
       __syncthreads();
     }

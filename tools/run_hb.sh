@@ -1,2 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r03b
-timeout 900 python -m pytest tests/test_gpu_cli.py tests/test_gpu_detect.py -x -q -m gpu -k "hessian_baumberg or hessian_form or one_view" 2>&1 | tail -25 > gpurun_out/r03b/hb.log
+(timeout 600 python -m pytest tests/test_gpu_pair.py -x -q -m gpu -k "disturb" 2>&1 | tail -5
+echo "== the same test against the build of before the fix (all 128 VGPRs in use)"
+MODS_LIB=$GRAFT_REPO_ROOT/mods-light-zmq_amd/_variants/libmodsgpu_base128.so timeout 600 python -m pytest tests/test_gpu_pair.py -x -q -m gpu -k "disturb" 2>&1 | tail -5
+python tools/bench_match.py 2>&1 | grep "C5\|C2") > gpurun_out/r03b/hb.log 2>&1
