@@ -17,7 +17,7 @@ pkg = ge.load_package()
 n_threads = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 redetect = 1
-aggressor = sys.argv[3] if len(sys.argv) > 3 else ""      # "", "detect", "match", "full": what the threads 1.. run (thread 0 = the victim)
+aggressor = sys.argv[3] if len(sys.argv) > 3 else ""      # "", "detect", "match", "full", "gemm", "stream", "poison1|2|3" [pattern]: what the threads 1.. run (thread 0 = the victim)
 stop = threading.Event()
 W, H = 1920, 1080
 pairs = [synth.pair(W, H, seed=2000 + i)[:2] for i in range(3)]
@@ -42,9 +42,22 @@ def aggress_torch(k):
             st.synchronize()
 
 
+def aggress_poison(k):
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libpoison.so"))
+    mode = int(aggressor[len("poison"):])              # 1 registers, 2 LDS, 3 both
+    pattern = int(sys.argv[4], 16) if len(sys.argv) > 4 else 0x7fc00000
+    while not stop.is_set():
+        rc = lib.poison_launch(mode, ctypes.c_uint(pattern), 1024, 1)
+        if rc:
+            print("poison_launch failed", rc); return
+
+
 def aggress(k):
     if aggressor in ("gemm", "stream"):
         return aggress_torch(k)
+    if aggressor.startswith("poison"):
+        return aggress_poison(k)
     ctx = pkg.Context(0, W, H, 2)
     ctx.detect_describe_dev(dev[0].data_ptr(), 2, W, H)
     n = 0
