@@ -1,6 +1,7 @@
 // Internal declarations of libmodsgpu (context, device buffers, launch helpers).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +21,17 @@ void set_error(const char *fmt, ...);
       return MODS_E_HIP;                                                                  \
     }                                                                                     \
   } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel AND device: a function's attributes live with the device's
+// code object, and a process may hold contexts on several GPUs (mods_multi, MODS_DEVICES).  `site` = a static per call site.
+struct DynLdsOnce { std::atomic<unsigned> done{0}; };
+inline hipError_t dyn_lds_once(DynLdsOnce &site, const void *fn, int bytes, int device) {
+  const unsigned bit = 1u << (device & 31);
+  if (site.done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) site.done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 constexpr int kMaxOctaves = 16;
 constexpr int kMaxLevels = 8;        // numberOfScales + 2 <= 8

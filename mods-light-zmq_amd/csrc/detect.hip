@@ -1092,8 +1092,8 @@ int detect_run(mods_ctx *ctx) {
     static const bool count_only = getenv("MODS_RANK_COUNT") != nullptr;   // the round-2 path for every image (A/B measurements)
     const int sort_max = count_only ? 0 : RANK_SORT_MAX;
     if (!count_only) {
-      static const hipError_t attr = hipFuncSetAttribute((const void *)rank_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      MODS_HIP_CHECK(attr);
+      static DynLdsOnce once;
+      MODS_HIP_CHECK(dyn_lds_once(once, (const void *)rank_sort_kernel, 160 * 1024, ctx->device));
       hipLaunchKernelGGL(rank_sort_kernel, dim3(n_img), dim3(1024), RANK_SORT_MAX * 10, ctx->stream, k, ctx->sort_keys, key_count, ctx->rank_dev);
     }
     hipLaunchKernelGGL(rank_count_kernel, dim3(64, 32, n_img), dim3(256), 0, ctx->stream, k, ctx->sort_keys, key_count, ctx->rank_dev, sort_max);

@@ -1162,7 +1162,11 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
     bool taps_ok = P.n_levels <= kMaxLevels;
     for (int l = 1; l < P.n_levels; l++) taps_ok = taps_ok && ntap[l] >= 3 && ntap[l] <= 17 && ctx->taps_host_n[l] == ntap[l];
     if (taps_ok)
-      for (int oi = P.n_oct - 1; oi >= 1 && P.oct[oi].w * P.oct[oi].h <= LDSP_CAP; oi--) first_lds = oi;
+      for (int oi = P.n_oct - 1; oi >= 1 && P.oct[oi].w * P.oct[oi].h <= LDSP_CAP; oi--) {
+        // (the decimated plane of an octave goes to the N plane: LDSP_CAP / 4 + 256 floats, short of it only for absurd aspect ratios)
+        if (oi + 1 < P.n_oct && P.oct[oi + 1].w * P.oct[oi + 1].h > LDSP_CAP / 4 + 256) break;
+        first_lds = oi;
+      }
   }
   for (int oi = 0; oi < first_lds; oi++) {
     OctaveDev &o = P.oct[oi];
@@ -1191,8 +1195,8 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
     }
     { const float norm = o.sigma[0] * o.sigma[0]; pl.norm2_first = norm * norm; }
     const size_t lds = sizeof(float) * (2 * LDSP_CAP + LDSP_CAP / 4 + 256);
-    static const hipError_t attr = hipFuncSetAttribute((const void *)pyramid_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    MODS_HIP_CHECK(attr);
+    static DynLdsOnce once;
+    MODS_HIP_CHECK(dyn_lds_once(once, (const void *)pyramid_lds_kernel, (int)lds, ctx->device));
     StageScope ts(ctx, MODS_STAGE_BLUR_SMALL, 0.0);
     hipLaunchKernelGGL(pyramid_lds_kernel, dim3(n_img), dim3(1024), lds, ctx->stream, ctx->pyr_dev, pl);
     MODS_HIP_CHECK(hipGetLastError());

@@ -1892,14 +1892,14 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   else if (run_sift) {
     static const bool first_form = getenv("MODS_SIFT_V1") != nullptr;   // the round-2 kernel (A/B measurements)
     if (first_form || n_img > 64) {
-      static const hipError_t attr = hipFuncSetAttribute((const void *)sift_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      MODS_HIP_CHECK(attr);
+      static DynLdsOnce once;
+      MODS_HIP_CHECK(dyn_lds_once(once, (const void *)sift_wave_kernel, 160 * 1024, ctx->device));
       hipLaunchKernelGGL(sift_wave_kernel, dim3(1024, n_img), dim3(256), sift_wave_lds_bytes(ps), ctx->stream, k, patches,
                          ctx->regions_dev, ctx->region_count, dmask, tab, (int)sift_wave_scratch_floats(ps));
     } else {
-      static const hipError_t attr16 = hipFuncSetAttribute((const void *)sift_wave2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      static const hipError_t attr18 = hipFuncSetAttribute((const void *)sift_wave2_kernel<SW_CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      MODS_HIP_CHECK(attr16); MODS_HIP_CHECK(attr18);
+      static DynLdsOnce once16, once18;
+      MODS_HIP_CHECK(dyn_lds_once(once16, (const void *)sift_wave2_kernel<16>, 160 * 1024, ctx->device));
+      MODS_HIP_CHECK(dyn_lds_once(once18, (const void *)sift_wave2_kernel<SW_CW>, 160 * 1024, ctx->device));
       // widest span of positive column weights of a spatial bin (siftdesc.cpp:22-71: step = 5 / (2 * (ps / 2)), bins x - 1 and x)
       int span = 0;
       {
