@@ -42,10 +42,15 @@ ths = [threading.Thread(target=aggress) for _ in range(n_aggr)]
 for t in ths: t.start()
 time.sleep(1.0)
 t0 = time.time()
-for i in range(launches):
-    rc = spin.spin_launch(4096, 3000, out)
+try:
+  for i in range(launches):
+    if os.environ.get("SPIN_LOADS"):
+        rc = spin.load_launch(8192, 4000, out)          # waves that keep loading known LDS / global words
+    else:
+        rc = spin.spin_launch(2048, int(os.environ.get("SPIN_ITERS", "300000")), out)
     assert rc == 0, rc
-stop.set()
+finally:
+  stop.set()
 for t in ths: t.join()
-print("%d aggressor contexts, %d victim waves: %d changed register values, %d changed LDS words, %.1f s"
+print("%d aggressor contexts, %d victim waves: %d wrong register / global values, %d wrong LDS words, %.1f s"
       % (n_aggr, out[2], out[0], out[1], time.time() - t0))

@@ -3,6 +3,7 @@
 // neighbours lose REGISTER or LDS contents - with no code of the library on the victim's side.
 //   hipcc --offload-arch=gfx950 -O2 -shared -fPIC tools/ubench/spin_victim.hip -o tools/ubench/libspin.so
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 __global__ __launch_bounds__(64) void spin_kernel(int iters, unsigned *__restrict__ counts) {
   __shared__ unsigned lds[4096];
@@ -20,8 +21,33 @@ __global__ __launch_bounds__(64) void spin_kernel(int iters, unsigned *__restric
   if (threadIdx.x == 0) atomicAdd(&counts[2], 1u);
 }
 
+// A wave that keeps LOADING: LDS words (b32 and b128 reads) and global words of known content, and counts the values that come back
+// wrong - the traffic the library's keypoint kernels have (gathers + LDS windows), without their arithmetic.
+__global__ __launch_bounds__(64) void load_kernel(int iters, const uint4 *__restrict__ gpat, int gwords, unsigned *__restrict__ counts) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = 0xa5000000u | i;
+  __syncthreads();
+  unsigned bad_lds = 0, bad_g = 0;
+  unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+  for (int it = 0; it < iters; it++) {
+    h = h * 1664525u + 1013904223u;
+    const unsigned i1 = (h >> 8) & 4095u, i4 = (h >> 12) & 4092u & ~3u, ig = (h >> 5) % (unsigned)gwords;
+    const unsigned a = ((volatile unsigned *)lds)[i1];
+    asm volatile("" ::: "memory");
+    const uint4 b = *(const uint4 *)(lds + i4);
+    const uint4 g = gpat[ig];
+    bad_lds += a != (0xa5000000u | i1);
+    bad_lds += (b.x != (0xa5000000u | i4)) + (b.y != (0xa5000000u | (i4 + 1))) + (b.z != (0xa5000000u | (i4 + 2))) + (b.w != (0xa5000000u | (i4 + 3)));
+    bad_g += (g.x != 4u * ig) + (g.y != 4u * ig + 1u) + (g.z != 4u * ig + 2u) + (g.w != 4u * ig + 3u);
+  }
+  if (bad_lds) atomicAdd(&counts[1], bad_lds);
+  if (bad_g) atomicAdd(&counts[0], bad_g);
+  if (threadIdx.x == 0) atomicAdd(&counts[2], 1u);
+}
+
 static hipStream_t g_stream;
 static unsigned *g_counts;
+extern "C" int load_launch(int blocks, int iters, unsigned *out3);
 extern "C" int spin_launch(int blocks, int iters, unsigned *out3) {
   if (!g_counts) {
     if (hipMalloc(&g_counts, 16) != hipSuccess) return 1;
@@ -29,6 +55,28 @@ extern "C" int spin_launch(int blocks, int iters, unsigned *out3) {
     if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
   }
   hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(64), 0, g_stream, iters, g_counts);
+  if (hipGetLastError() != hipSuccess) return 3;
+  if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
+  if (hipMemcpy(out3, g_counts, 12, hipMemcpyDeviceToHost) != hipSuccess) return 5;
+  return 0;
+}
+
+extern "C" int load_launch(int blocks, int iters, unsigned *out3) {
+  static uint4 *gpat = nullptr;
+  const int gwords = 1 << 20;       // 16 MB of uint4 whose content is its own word index
+  if (!g_counts) {
+    if (hipMalloc(&g_counts, 16) != hipSuccess) return 1;
+    if (hipMemset(g_counts, 0, 16) != hipSuccess) return 1;
+    if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
+  }
+  if (!gpat) {
+    if (hipMalloc(&gpat, (size_t)gwords * 16) != hipSuccess) return 1;
+    unsigned *h = (unsigned *)malloc((size_t)gwords * 16);
+    for (size_t i = 0; i < (size_t)gwords * 4; i++) h[i] = (unsigned)i;
+    if (hipMemcpy(gpat, h, (size_t)gwords * 16, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    free(h);
+  }
+  hipLaunchKernelGGL(load_kernel, dim3(blocks), dim3(64), 0, g_stream, iters, gpat, gwords, g_counts);
   if (hipGetLastError() != hipSuccess) return 3;
   if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
   if (hipMemcpy(out3, g_counts, 12, hipMemcpyDeviceToHost) != hipSuccess) return 5;
