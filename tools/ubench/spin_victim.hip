@@ -36,6 +36,11 @@ __global__ __launch_bounds__(64) void load_kernel(int iters, const uint4 *__rest
     asm volatile("" ::: "memory");
     const uint4 b = *(const uint4 *)(lds + i4);
     const uint4 g = gpat[ig];
+    // the keypoint kernels' gather: 8 bytes at 4-byte alignment (two horizontally adjacent pixels), any dword position
+    struct __attribute__((packed, aligned(4))) Pair { unsigned a, b; };
+    const unsigned iu = (h >> 3) % (unsigned)(4 * gwords - 2);
+    const Pair pr = *(const Pair *)((const unsigned *)gpat + iu);
+    bad_g += (pr.a != iu) + (pr.b != iu + 1u);
     bad_lds += a != (0xa5000000u | i1);
     bad_lds += (b.x != (0xa5000000u | i4)) + (b.y != (0xa5000000u | (i4 + 1))) + (b.z != (0xa5000000u | (i4 + 2))) + (b.w != (0xa5000000u | (i4 + 3)));
     bad_g += (g.x != 4u * ig) + (g.y != 4u * ig + 1u) + (g.z != 4u * ig + 2u) + (g.w != 4u * ig + 3u);
