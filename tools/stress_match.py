@@ -53,7 +53,19 @@ def aggress_poison(k):
             print("poison_launch failed", rc); return
 
 
+def aggress_top(k):
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libvgprtop.so"))
+    mode = int(aggressor[len("top"):])      # tools/ubench/vgpr_top.hip: 0 ds_read_b128 v[124:127], 1 control v[120:123], 5 ds_read -> MFMA srcA v[124:127]
+    while not stop.is_set():
+        rc = lib.top_launch(mode, 4096, 400)
+        if rc:
+            print("top_launch failed", rc); return
+
+
 def aggress(k):
+    if aggressor.startswith("top"):
+        return aggress_top(k)
     if aggressor in ("gemm", "stream"):
         return aggress_torch(k)
     if aggressor.startswith("poison"):

@@ -93,6 +93,28 @@ static int run(const char *what, hipStream_t sa, hipStream_t sb, unsigned *out, 
   return 0;
 }
 
+// aggressor launcher for tools/stress_match.py ("top<mode>" aggressors; build with -shared -fPIC -DVGPR_TOP_LIB)
+extern "C" int top_launch(int mode, int blocks, int iters) {
+  static hipStream_t st = nullptr;
+  static unsigned *sink = nullptr; static uint4 *src = nullptr;
+  if (!st) {
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return 1;
+    if (hipMalloc(&sink, 65536 * 4) != hipSuccess || hipMalloc(&src, 256 * 16) != hipSuccess) return 1;
+    if (hipMemset(src, 0x77, 256 * 16) != hipSuccess) return 1;
+  }
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(aggressor<0>, dim3(blocks), dim3(256), 0, st, sink, src, iters); break;
+    case 1: hipLaunchKernelGGL(aggressor<1>, dim3(blocks), dim3(256), 0, st, sink, src, iters); break;
+    case 2: hipLaunchKernelGGL(aggressor<2>, dim3(blocks), dim3(256), 0, st, sink, src, iters); break;
+    case 3: hipLaunchKernelGGL(aggressor<3>, dim3(blocks), dim3(256), 0, st, sink, src, iters); break;
+    case 4: hipLaunchKernelGGL(aggressor<4>, dim3(blocks), dim3(256), 0, st, sink, src, iters); break;
+    default: hipLaunchKernelGGL(aggressor<5>, dim3(blocks), dim3(256), 0, st, sink, src, iters); break;
+  }
+  if (hipGetLastError() != hipSuccess) return 2;
+  return hipStreamSynchronize(st) == hipSuccess ? 0 : 3;
+}
+
+#ifndef VGPR_TOP_LIB
 int main() {
   hipStream_t sa, sb;
   CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
@@ -111,3 +133,4 @@ int main() {
   if (run<5>("ds_read_b128 v[124:127] -> 2 x v_mfma srcA", sa, sb, out, sink, src, rounds)) return 1;
   return 0;
 }
+#endif
