@@ -13,9 +13,18 @@ import pipeline_oracle as po
 
 pkg = ge.load_package()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+partial = len(sys.argv) > 2 and sys.argv[2] == "partial"      # two motions per pair (bench.py --inlier-ratio): ~60 RANSAC samples per pair
 w, h = 1920, 1080
-n_pairs, n_sub = 6, 48
-oracle = [po.cached_pair(w, h, 2000 + i, 12345) for i in range(n_pairs)]
+n_pairs, n_sub = (3, 48) if partial else (6, 48)
+if partial:
+    import synth
+    oracle = []
+    for i in range(n_pairs):
+        a, b, Ht = synth.pair_partial(w, h, seed=2300 + i, frac=0.55)
+        a, b = np.round(a).clip(0, 255).astype(np.float32), np.round(b).clip(0, 255).astype(np.float32)   # the pipeline is fed 8-bit images
+        oracle.append((a, b, Ht, po.match_pair(a, b, seed_time=12345)))
+else:
+    oracle = [po.cached_pair(w, h, 2000 + i, 12345) for i in range(n_pairs)]
 pinned = []
 for a, b, _, _ in oracle:
     buf = pkg.PinnedBuffer((2, h, w), np.uint8)
