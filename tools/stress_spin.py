@@ -44,7 +44,9 @@ time.sleep(1.0)
 t0 = time.time()
 try:
   for i in range(launches):
-    if os.environ.get("SPIN_LOADS"):
+    if os.environ.get("SPIN_FP64"):
+        rc = spin.fp64_launch(8192, 400, out)           # waves that keep computing fp64 / fp32 chains (counts: fp64 in the first, fp32 in the second column)
+    elif os.environ.get("SPIN_LOADS"):
         rc = spin.load_launch(8192, 4000, out)          # waves that keep loading known LDS / global words
     else:
         rc = spin.spin_launch(2048, int(os.environ.get("SPIN_ITERS", "300000")), out)

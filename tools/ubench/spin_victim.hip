@@ -50,6 +50,34 @@ __global__ __launch_bounds__(64) void load_kernel(int iters, const uint4 *__rest
   if (threadIdx.x == 0) atomicAdd(&counts[2], 1u);
 }
 
+// A wave that keeps COMPUTING in double precision (fma, sqrt, division: what Baumberg's inverse square root, the photometric sums
+// and the exported frames use) and compares every round with its first one.
+__global__ __launch_bounds__(64) void fp64_kernel(int iters, double seed0, unsigned *__restrict__ counts) {
+  double seed = seed0 + 1e-3 * threadIdx.x + 1e-6 * (blockIdx.x & 1023);
+  double ref = 0;
+  float reff = 0;
+  unsigned bad = 0, badf = 0;
+  for (int it = 0; it < iters; it++) {
+    asm volatile("" : "+v"(seed));
+    double x = seed, acc = 0;
+    float xf = (float)seed, accf = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < 16; q++) {
+      x = fma(x, 1.0000001, 0.25);
+      const double r = 1.0 / sqrt(1.0 + x * x);
+      acc += r * x + (x - acc) / (2.0 + r);
+      xf = fmaf(xf, 1.0001f, 0.25f);
+      accf += sqrtf(1.0f + xf * xf) / (2.0f + xf);
+    }
+    if (it == 0) { ref = acc; reff = accf; }
+    bad += acc != ref;
+    badf += accf != reff;
+  }
+  if (bad) atomicAdd(&counts[0], bad);
+  if (badf) atomicAdd(&counts[1], badf);
+  if (threadIdx.x == 0) atomicAdd(&counts[2], 1u);
+}
+
 static hipStream_t g_stream;
 static unsigned *g_counts;
 extern "C" int load_launch(int blocks, int iters, unsigned *out3);
@@ -60,6 +88,19 @@ extern "C" int spin_launch(int blocks, int iters, unsigned *out3) {
     if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
   }
   hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(64), 0, g_stream, iters, g_counts);
+  if (hipGetLastError() != hipSuccess) return 3;
+  if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
+  if (hipMemcpy(out3, g_counts, 12, hipMemcpyDeviceToHost) != hipSuccess) return 5;
+  return 0;
+}
+
+extern "C" int fp64_launch(int blocks, int iters, unsigned *out3) {
+  if (!g_counts) {
+    if (hipMalloc(&g_counts, 16) != hipSuccess) return 1;
+    if (hipMemset(g_counts, 0, 16) != hipSuccess) return 1;
+    if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
+  }
+  hipLaunchKernelGGL(fp64_kernel, dim3(blocks), dim3(64), 0, g_stream, iters, 0.5, g_counts);
   if (hipGetLastError() != hipSuccess) return 3;
   if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
   if (hipMemcpy(out3, g_counts, 12, hipMemcpyDeviceToHost) != hipSuccess) return 5;
