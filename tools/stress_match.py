@@ -87,7 +87,39 @@ def aggress(k):
     ctx.close()
 
 
+def worker_detect(k):
+    """victim that runs the detector only (pyramid, NMS, localisation, Baumberg, export) and compares the keypoints"""
+    ctx = pkg.Context(0, W, H, 2)
+    ref = {}
+    par = pkg.HessAffParams.default()
+    if os.environ.get("VICTIM_NO_BAUMBERG"):
+        par.doBaumberg = 0
+    if os.environ.get("VICTIM_HESSIAN_BAUMBERG"):
+        par.affBmbrgMethod = 1
+    for it in range(reps):
+        p = (it + k) % len(dev)
+        keys = ctx.detect_hessian_affine_dev(dev[p].data_ptr(), 2, W, H, par, max_out=1 << 15)
+        if p not in ref:
+            ref[p] = keys
+            continue
+        msgs = []
+        for s in (0, 1):
+            if len(keys[s]) != len(ref[p][s]):
+                msgs.append("key count of image %d: %d vs %d" % (s, len(keys[s]), len(ref[p][s])))
+                continue
+            for f in ("x", "y", "s", "a11", "a21", "a22", "response"):
+                if not np.array_equal(keys[s][f], ref[p][s][f]):
+                    msgs.append("image %d key field %s differs at %s" % (s, f, np.nonzero(keys[s][f] != ref[p][s][f])[0][:4]))
+        if msgs:
+            with lock:
+                bad[0] += 1
+                print("thread %d iteration %d pair %d: %s" % (k, it, p, "; ".join(msgs)), flush=True)
+    ctx.close()
+
+
 def worker(k):
+    if os.environ.get("VICTIM") == "detect":
+        return worker_detect(k)
     ctx = pkg.Context(0, W, H, 2)
     ref = {}
     for it in range(reps):

@@ -26,13 +26,32 @@ stop = threading.Event()
 
 
 def aggress():
-    ctx = pkg.Context(0, W, H, 2)
+    if os.environ.get("AGGR_TOP"):        # synthetic aggressor: tools/ubench/vgpr_top.hip as a library, mode = AGGR_TOP
+        lib = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libvgprtop.so"))
+        while not stop.is_set():
+            if lib.top_launch(int(os.environ["AGGR_TOP"]), 4096, 400):
+                print("top_launch failed"); return
+        return
+    kind = os.environ.get("AGGR", "match")     # what the aggressor contexts run: match | pair | mser | view | dog
+    d = pkg.view_ctx_dims(W, H) if kind == "view" else (W, H)
+    ctx = pkg.Context(0, d[0], d[1], 2)
     ctx.detect_describe_dev(dev.data_ptr(), 2, W, H)
     while not stop.is_set():
         try:
-            ctx.match_dev(0, 1)
-        except Exception:
-            pass
+            if kind == "pair":        # detect + describe + match + duplicate filter + LO-RANSAC (GPU scoring kernels)
+                pkg.match_pair_dev(ctx, dev.data_ptr(), W, H, max_matches=1 << 16)
+            elif kind == "mser":
+                ctx.detect_describe_dev(dev.data_ptr(), 2, W, H, det=pkg.HessAffParams.mser())
+            elif kind == "dog":
+                ctx.detect_describe_dev(dev.data_ptr(), 2, W, H, det=pkg.HessAffParams.dog())
+                ctx.detect_describe_dev(dev.data_ptr(), 2, W, H, det=pkg.HessAffParams.harris())
+            elif kind == "view":
+                ctx.detect_describe_view_dev(dev.data_ptr(), W, H, 4.0, 0.6)
+            else:
+                ctx.match_dev(0, 1)
+        except Exception as e:
+            if kind != "match":
+                print("aggressor failed:", e); return
     ctx.close()
 
 
@@ -42,9 +61,19 @@ ths = [threading.Thread(target=aggress) for _ in range(n_aggr)]
 for t in ths: t.start()
 time.sleep(1.0)
 t0 = time.time()
+tot = [0, 0, 0]
 try:
   for i in range(launches):
-    if os.environ.get("SPIN_FP64"):
+    if os.environ.get("SPIN_PART"):
+        part = int(os.environ["SPIN_PART"])
+        rc = spin.part_launch(part, 2048, 300, out)
+        tot = [x + y for x, y in zip(tot, out)] if i else list(out)
+        out[0], out[1], out[2] = tot[0], tot[1], tot[2]
+    elif os.environ.get("SPIN_SVD"):
+        rc = spin.svd_launch(2048, 300, out)            # waves that repeat the detector's 2x2 fp64 Jacobi SVD
+    elif os.environ.get("SPIN_PK"):
+        rc = spin.pk_launch(8192, 2000, out)            # waves that keep running packed-fp32 chains
+    elif os.environ.get("SPIN_FP64"):
         rc = spin.fp64_launch(8192, 400, out)           # waves that keep computing fp64 / fp32 chains (counts: fp64 in the first, fp32 in the second column)
     elif os.environ.get("SPIN_LOADS"):
         rc = spin.load_launch(8192, 4000, out)          # waves that keep loading known LDS / global words

@@ -78,6 +78,131 @@ __global__ __launch_bounds__(64) void fp64_kernel(int iters, double seed0, unsig
   if (threadIdx.x == 0) atomicAdd(&counts[2], 1u);
 }
 
+// A wave that keeps running PACKED fp32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: what the compiler makes of the two
+// coordinate chains WX += a11, WY += a21 of the keypoint kernels) and compares every round with its first one.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64) void pk_kernel(int iters, float seed0, unsigned *__restrict__ counts) {
+  const float sd = seed0 + 1e-3f * threadIdx.x;
+  v2f ref = {0.f, 0.f};
+  unsigned bad = 0;
+  for (int it = 0; it < iters; it++) {
+    v2f x = {sd, sd * 0.5f}, a = {0.37f, 0.21f}, m = {1.0001f, 0.9999f};
+    asm volatile("" : "+v"(x), "+v"(a), "+v"(m));
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(a));
+      asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(m));
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(m), "v"(a));
+    }
+    if (it == 0) ref = x;
+    bad += (x.x != ref.x) + (x.y != ref.y);
+  }
+  if (bad) atomicAdd(&counts[0], bad);
+  if (threadIdx.x == 0) atomicAdd(&counts[2], 1u);
+}
+
+// The 2x2 Jacobi SVD of csrc/detect.hip (baumberg_hessian_kernel's fp64 part: products, hypot, sqrt, divisions, conversions) on
+// inputs that depend on the lane only, every round compared with the first one.  SVD_PART: 0 whole routine.
+__device__ bool svd2x2_f32(const float A[4], float d[2], float U[4], float Vt[4]) {   // false: a singular value <= FLT_MIN
+  const float eps = 1.1920929e-7f * 2;
+  const double minval = 1.17549435e-38;
+  float a0[2] = {A[0], A[2]}, a1[2] = {A[1], A[3]};       // rows of A^T
+  float v0[2] = {1.f, 0.f}, v1[2] = {0.f, 1.f};
+  double W0 = (double)a0[0] * a0[0] + (double)a0[1] * a0[1];
+  double W1 = (double)a1[0] * a1[0] + (double)a1[1] * a1[1];
+  for (int iter = 0; iter < 30; iter++) {
+    double p = (double)a0[0] * a1[0];
+    p += (double)a0[1] * a1[1];
+    if (fabs(p) <= eps * sqrt(W0 * W1)) break;
+    p *= 2;
+    const double beta = W0 - W1, gamma = hypot(p, beta);
+    float c, s;
+    if (beta < 0) {
+      const double delta = (gamma - beta) * 0.5;
+      s = (float)sqrt(delta / gamma);
+      c = (float)(p / (gamma * s * 2));
+    } else {
+      c = (float)sqrt((gamma + beta) / (gamma * 2));
+      s = (float)(p / (gamma * c * 2));
+    }
+    W0 = 0; W1 = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const float t0 = c * a0[q] + s * a1[q];
+      const float t1 = -s * a0[q] + c * a1[q];
+      a0[q] = t0; a1[q] = t1;
+      W0 += (double)t0 * t0; W1 += (double)t1 * t1;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const float t0 = c * v0[q] + s * v1[q];
+      const float t1 = -s * v0[q] + c * v1[q];
+      v0[q] = t0; v1[q] = t1;
+    }
+  }
+  W0 = sqrt((double)a0[0] * a0[0] + (double)a0[1] * a0[1]);
+  W1 = sqrt((double)a1[0] * a1[0] + (double)a1[1] * a1[1]);
+  if (W0 < W1) {
+    const double tw = W0; W0 = W1; W1 = tw;
+#pragma unroll
+    for (int q = 0; q < 2; q++) { float t = a0[q]; a0[q] = a1[q]; a1[q] = t; t = v0[q]; v0[q] = v1[q]; v1[q] = t; }
+  }
+  d[0] = (float)W0; d[1] = (float)W1;
+  if (W0 <= minval || W1 <= minval) return false;
+  const float s0 = (float)(1 / W0), s1 = (float)(1 / W1);
+  a0[0] *= s0; a0[1] *= s0; a1[0] *= s1; a1[1] *= s1;
+  U[0] = a0[0]; U[1] = a1[0]; U[2] = a0[1]; U[3] = a1[1];
+  Vt[0] = v0[0]; Vt[1] = v0[1]; Vt[2] = v1[0]; Vt[3] = v1[1];
+  return true;
+}
+
+__global__ __launch_bounds__(256) void svd_kernel(int iters, float seed0, unsigned *__restrict__ counts) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  float A[4] = {seed0 + 0.013f * (t & 1023), 0.3f + 0.001f * (t & 255), 0.3f + 0.001f * (t & 255), -1.7f + 0.007f * (t & 511)};
+  float rd[2] = {0, 0}, rU[4] = {0, 0, 0, 0}, rV[4] = {0, 0, 0, 0};
+  unsigned bad = 0;
+  for (int it = 0; it < iters; it++) {
+    asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]));
+    float d[2], U[4], Vt[4];
+    const bool ok = svd2x2_f32(A, d, U, Vt);
+    if (!ok) { d[0] = d[1] = 0; for (int q = 0; q < 4; q++) U[q] = Vt[q] = 0; }
+    if (it == 0) { rd[0] = d[0]; rd[1] = d[1]; for (int q = 0; q < 4; q++) { rU[q] = U[q]; rV[q] = Vt[q]; } }
+    unsigned b = (d[0] != rd[0]) + (d[1] != rd[1]);
+    for (int q = 0; q < 4; q++) b += (U[q] != rU[q]) + (Vt[q] != rV[q]);
+    bad += b != 0;
+  }
+  if (bad) atomicAdd(&counts[0], bad);
+  if (threadIdx.x == 0) atomicAdd(&counts[2], 1u);
+}
+
+// Parts of that routine on their own: 1 hypot, 2 float <-> double conversions around a product, 3 sqrt and division, 4 fma / add / mul
+// only, 5 comparisons and selects on doubles, 6 v_rcp_f64 / v_rsq_f64 alone (the hardware approximations)
+template <int PART>
+__global__ __launch_bounds__(256) void part_kernel(int iters, float seed0, unsigned *__restrict__ counts) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  float a = seed0 + 0.013f * (t & 1023), b = -1.7f + 0.007f * (t & 511);
+  double ref = 0;
+  unsigned bad = 0;
+  for (int it = 0; it < iters; it++) {
+    asm volatile("" : "+v"(a), "+v"(b));
+    double r = 0;
+#pragma unroll 4
+    for (int q = 0; q < 8; q++) {
+      const double x = (double)a + 0.125 * q, y = (double)b - 0.25 * q;
+      if (PART == 1) r += hypot(x, y);
+      else if (PART == 2) { const float f = (float)(x * y); r += (double)f * (double)(a + (float)q); }
+      else if (PART == 3) r += sqrt(x * x + 1.0) / (2.0 + y * y);
+      else if (PART == 4) r = fma(r, 1.0000001, x * y) + (x - y);
+      else if (PART == 5) r += (fabs(x) <= 1.5 * fabs(y)) ? (x < y ? x : y) : (x > -y ? 0.5 : y);
+      else { r += __builtin_amdgcn_rcp(x * x + 1.0) + __builtin_amdgcn_rsq(y * y + 2.0); }
+    }
+    if (it == 0) ref = r;
+    bad += r != ref;
+  }
+  if (bad) atomicAdd(&counts[0], bad);
+  if (threadIdx.x == 0) atomicAdd(&counts[2], 1u);
+}
+
 static hipStream_t g_stream;
 static unsigned *g_counts;
 extern "C" int load_launch(int blocks, int iters, unsigned *out3);
@@ -101,6 +226,52 @@ extern "C" int fp64_launch(int blocks, int iters, unsigned *out3) {
     if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
   }
   hipLaunchKernelGGL(fp64_kernel, dim3(blocks), dim3(64), 0, g_stream, iters, 0.5, g_counts);
+  if (hipGetLastError() != hipSuccess) return 3;
+  if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
+  if (hipMemcpy(out3, g_counts, 12, hipMemcpyDeviceToHost) != hipSuccess) return 5;
+  return 0;
+}
+
+extern "C" int pk_launch(int blocks, int iters, unsigned *out3) {
+  if (!g_counts) {
+    if (hipMalloc(&g_counts, 16) != hipSuccess) return 1;
+    if (hipMemset(g_counts, 0, 16) != hipSuccess) return 1;
+    if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
+  }
+  hipLaunchKernelGGL(pk_kernel, dim3(blocks), dim3(64), 0, g_stream, iters, 0.5f, g_counts);
+  if (hipGetLastError() != hipSuccess) return 3;
+  if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
+  if (hipMemcpy(out3, g_counts, 12, hipMemcpyDeviceToHost) != hipSuccess) return 5;
+  return 0;
+}
+
+extern "C" int svd_launch(int blocks, int iters, unsigned *out3) {
+  if (!g_counts) {
+    if (hipMalloc(&g_counts, 16) != hipSuccess) return 1;
+    if (hipMemset(g_counts, 0, 16) != hipSuccess) return 1;
+    if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
+  }
+  hipLaunchKernelGGL(svd_kernel, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts);
+  if (hipGetLastError() != hipSuccess) return 3;
+  if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
+  if (hipMemcpy(out3, g_counts, 12, hipMemcpyDeviceToHost) != hipSuccess) return 5;
+  return 0;
+}
+
+extern "C" int part_launch(int part, int blocks, int iters, unsigned *out3) {
+  if (!g_counts) {
+    if (hipMalloc(&g_counts, 16) != hipSuccess) return 1;
+    if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
+  }
+  if (hipMemset(g_counts, 0, 16) != hipSuccess) return 1;
+  switch (part) {
+    case 1: hipLaunchKernelGGL(part_kernel<1>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 2: hipLaunchKernelGGL(part_kernel<2>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 3: hipLaunchKernelGGL(part_kernel<3>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 4: hipLaunchKernelGGL(part_kernel<4>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 5: hipLaunchKernelGGL(part_kernel<5>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    default: hipLaunchKernelGGL(part_kernel<6>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+  }
   if (hipGetLastError() != hipSuccess) return 3;
   if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
   if (hipMemcpy(out3, g_counts, 12, hipMemcpyDeviceToHost) != hipSuccess) return 5;
