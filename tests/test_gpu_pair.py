@@ -1,4 +1,6 @@
 """-m gpu: the whole hot path on one pair vs the CPU oracle chain (identical counts, inlier set, H)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -393,3 +395,55 @@ def test_contexts_on_one_gpu_do_not_disturb_each_other(pkg):
         ctx.close()
     assert not errors, errors
     assert not differing, differing
+
+
+def test_fp64_work_of_other_waves_is_left_alone(pkg, tmp_path):
+    """The sharpest detector of the same disturbance: waves of NO library kernel that repeat the detector's 2x2 fp64 Jacobi SVD
+    on fixed inputs (tools/ubench/spin_victim.hip: svd_kernel) and compare every round with their first one.  Next to the pre-fix
+    match_nn1_kernel they returned 1.3 M wrong rounds in 2.5 s (profiles/r03_concurrency_stress.log); next to three contexts
+    running the shipped matcher it must be none."""
+    import ctypes
+    import shutil
+    import subprocess
+    import threading
+    import torch
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ubench", "spin_victim.hip")
+    so = str(tmp_path / "libspin.so")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", src, "-o", so],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    if p.returncode != 0:
+        pytest.skip("tools/ubench/spin_victim.hip did not compile here: " + p.stdout.decode()[-300:])
+    spin = ctypes.CDLL(so)
+    w, h = 1920, 1080
+    a, b = synth.pair(w, h, seed=2000)[:2]
+    dev = torch.from_numpy(np.stack([a, b]).astype(np.float32)).cuda()
+    torch.cuda.synchronize()
+    stop = threading.Event()
+    errors = []
+
+    def aggressor():
+        try:
+            ctx = pkg.Context(0, w, h, 2)
+            ctx.detect_describe_dev(dev.data_ptr(), 2, w, h)
+            while not stop.is_set():
+                ctx.match_dev(0, 1)
+            ctx.close()
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+
+    ths = [threading.Thread(target=aggressor) for _ in range(3)]
+    for t in ths:
+        t.start()
+    out = (ctypes.c_uint * 3)()
+    try:
+        for _ in range(1200):
+            assert spin.svd_launch(2048, 300, out) == 0
+    finally:
+        stop.set()
+        for t in ths:
+            t.join()
+    assert not errors, errors
+    assert out[2] == 1200 * 2048 and out[0] == 0, list(out)
