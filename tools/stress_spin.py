@@ -64,7 +64,11 @@ t0 = time.time()
 tot = [0, 0, 0]
 try:
   for i in range(launches):
-    if os.environ.get("SPIN_PART"):
+    if os.environ.get("SPIN_SVDVAR"):
+        rc = spin.svdvar_launch(int(os.environ["SPIN_SVDVAR"]), 2048, 300, out)
+        tot = [x + y for x, y in zip(tot, out)] if i else list(out)
+        out[0], out[1], out[2] = tot[0], tot[1], tot[2]
+    elif os.environ.get("SPIN_PART"):
         part = int(os.environ["SPIN_PART"])
         rc = spin.part_launch(part, 2048, 300, out)
         tot = [x + y for x, y in zip(tot, out)] if i else list(out)

@@ -156,6 +156,83 @@ __device__ bool svd2x2_f32(const float A[4], float d[2], float U[4], float Vt[4]
   return true;
 }
 
+template <int V> __device__ bool svd_var(const float A[4], float d[2], float U[4], float Vt[4]) {   // false: a singular value <= FLT_MIN
+  const float eps = 1.1920929e-7f * 2;
+  const double minval = 1.17549435e-38;
+  float a0[2] = {A[0], A[2]}, a1[2] = {A[1], A[3]};       // rows of A^T
+  float v0[2] = {1.f, 0.f}, v1[2] = {0.f, 1.f};
+  double W0 = (double)a0[0] * a0[0] + (double)a0[1] * a0[1];
+  double W1 = (double)a1[0] * a1[0] + (double)a1[1] * a1[1];
+  for (int iter = 0; iter < ((V & 256) ? 1 : (V & 15) == 3 ? 3 : 30); iter++) {
+    double p = (double)a0[0] * a1[0];
+    p += (double)a0[1] * a1[1];
+    if ((V & 15) != 3 && fabs(p) <= eps * sqrt(W0 * W1)) break;
+    p *= 2;
+    const double beta = W0 - W1, gamma = ((V & 15) == 1 || (V & 16)) ? sqrt(p * p + beta * beta) : hypot(p, beta);
+    float c, s;
+    if ((V & 64)) { c = 0.8f; s = 0.6f * (float)(p / (gamma + 1.0)); } else if ((V & 15) != 2 && beta < 0) {
+      const double delta = (gamma - beta) * 0.5;
+      s = (float)sqrt(delta / gamma);
+      c = (float)(p / (gamma * s * 2));
+    } else {
+      c = (float)sqrt((gamma + beta) / (gamma * 2));
+      s = (float)(p / (gamma * c * 2));
+    }
+    W0 = 0; W1 = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const float t0 = c * a0[q] + s * a1[q];
+      const float t1 = -s * a0[q] + c * a1[q];
+      a0[q] = t0; a1[q] = t1;
+      if (V & 128) { W0 = (double)((float)W0 + t0 * t0); W1 = (double)((float)W1 + t1 * t1); } else { W0 += (double)t0 * t0; W1 += (double)t1 * t1; }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (V & 32) continue;
+      const float t0 = c * v0[q] + s * v1[q];
+      const float t1 = -s * v0[q] + c * v1[q];
+      v0[q] = t0; v1[q] = t1;
+    }
+  }
+  if ((V & 15) == 4) { d[0] = (float)W0; d[1] = (float)W1; U[0] = a0[0]; U[1] = a1[0]; U[2] = a0[1]; U[3] = a1[1]; Vt[0] = v0[0]; Vt[1] = v0[1]; Vt[2] = v1[0]; Vt[3] = v1[1]; return true; }
+  W0 = sqrt((double)a0[0] * a0[0] + (double)a0[1] * a0[1]);
+  W1 = sqrt((double)a1[0] * a1[0] + (double)a1[1] * a1[1]);
+  if (W0 < W1) {
+    const double tw = W0; W0 = W1; W1 = tw;
+#pragma unroll
+    for (int q = 0; q < 2; q++) { float t = a0[q]; a0[q] = a1[q]; a1[q] = t; t = v0[q]; v0[q] = v1[q]; v1[q] = t; }
+  }
+  d[0] = (float)W0; d[1] = (float)W1;
+  if (W0 <= minval || W1 <= minval) return false;
+  const float s0 = (float)(1 / W0), s1 = (float)(1 / W1);
+  a0[0] *= s0; a0[1] *= s0; a1[0] *= s1; a1[1] *= s1;
+  U[0] = a0[0]; U[1] = a1[0]; U[2] = a0[1]; U[3] = a1[1];
+  Vt[0] = v0[0]; Vt[1] = v0[1]; Vt[2] = v1[0]; Vt[3] = v1[1];
+  return true;
+}
+
+// the same routine with one piece changed (which piece makes it vulnerable?): 1 sqrt(p^2 + beta^2) instead of hypot, 2 one branch of the
+// rotation only, 3 three sweeps without the convergence test, 4 without the final square roots / ordering / normalisation
+template <int V>
+__global__ __launch_bounds__(256) void svdvar_kernel(int iters, float seed0, unsigned *__restrict__ counts) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  float A[4] = {seed0 + 0.013f * (t & 1023), 0.3f + 0.001f * (t & 255), 0.3f + 0.001f * (t & 255), -1.7f + 0.007f * (t & 511)};
+  float rd[2] = {0, 0}, rU[4] = {0, 0, 0, 0}, rV[4] = {0, 0, 0, 0};
+  unsigned bad = 0;
+  for (int it = 0; it < iters; it++) {
+    asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]));
+    float d[2], U[4], Vt[4];
+    const bool ok = svd_var<V>(A, d, U, Vt);
+    if (!ok) { d[0] = d[1] = 0; for (int q = 0; q < 4; q++) U[q] = Vt[q] = 0; }
+    if (it == 0) { rd[0] = d[0]; rd[1] = d[1]; for (int q = 0; q < 4; q++) { rU[q] = U[q]; rV[q] = Vt[q]; } }
+    unsigned b = (d[0] != rd[0]) + (d[1] != rd[1]);
+    for (int q = 0; q < 4; q++) b += (U[q] != rU[q]) + (Vt[q] != rV[q]);
+    bad += b != 0;
+  }
+  if (bad) atomicAdd(&counts[0], bad);
+  if (threadIdx.x == 0) atomicAdd(&counts[2], 1u);
+}
+
 __global__ __launch_bounds__(256) void svd_kernel(int iters, float seed0, unsigned *__restrict__ counts) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   float A[4] = {seed0 + 0.013f * (t & 1023), 0.3f + 0.001f * (t & 255), 0.3f + 0.001f * (t & 255), -1.7f + 0.007f * (t & 511)};
@@ -194,7 +271,66 @@ __global__ __launch_bounds__(256) void part_kernel(int iters, float seed0, unsig
       else if (PART == 3) r += sqrt(x * x + 1.0) / (2.0 + y * y);
       else if (PART == 4) r = fma(r, 1.0000001, x * y) + (x - y);
       else if (PART == 5) r += (fabs(x) <= 1.5 * fabs(y)) ? (x < y ? x : y) : (x > -y ? 0.5 : y);
-      else { r += __builtin_amdgcn_rcp(x * x + 1.0) + __builtin_amdgcn_rsq(y * y + 2.0); }
+      else if (PART == 6) { r += __builtin_amdgcn_rcp(x * x + 1.0) + __builtin_amdgcn_rsq(y * y + 2.0); }
+      else { r += x * y; }
+    }
+    if (PART >= 14) {      // the rotation block of the SVD on its own: fp64 sqrt / division / conversion to float on both sides of a
+                           // data-dependent branch.  14: as in the routine after convergence (p = 0 exactly), 15: p small but not 0,
+                           // 16: the same arithmetic without the branch (one side), 17: zero numerators only: 0 / x in fp64
+      double acc = 0;
+#pragma unroll 2
+      for (int q = 0; q < 4; q++) {
+        double pp = PART == 14 ? 0.0 : (double)a * 1e-9 * (q + 1);
+        double beta = ((t + q) & 1) ? (double)b - 0.5 * q : -(double)b + 0.25 * q;
+        asm volatile("" : "+v"(pp), "+v"(beta));
+        if (PART == 17) { acc += (pp * 0.0) / (beta * beta + 2.0) + 0.0 / (beta + 3.0); continue; }
+        pp *= 2;
+        const double gamma = sqrt(pp * pp + beta * beta);
+        float c, sn;
+        if (PART != 16 && beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          sn = (float)sqrt(delta / gamma);
+          c = (float)(pp / (gamma * sn * 2));
+        } else {
+          c = (float)sqrt((gamma + beta) / (gamma * 2));
+          sn = (float)(pp / (gamma * c * 2));
+        }
+        acc += (double)c * 3.0 + (double)sn;
+      }
+      r += acc;
+    } else if (PART >= 10) {      // DENORMAL operands and results: 10 fp32 products / sums, 11 double -> float conversions into the denormal range,
+                           // 12 fp64 products in the denormal range, 13 float rotations (c * x + s * y) with a denormal s, as the SVD's later sweeps
+      float tiny = a * 1e-30f, acc = 0.f;
+      double dt = (double)a * 1e-300, dacc = 0.0;
+      asm volatile("" : "+v"(tiny), "+v"(dt));
+#pragma unroll 4
+      for (int q = 1; q <= 8; q++) {
+        if (PART == 10) { const float y = tiny * (1e-10f * q); acc += y * 3.0f + y; }
+        else if (PART == 11) { const float y = (float)((double)a * 1e-40 * q); acc += y; dacc += (double)y * 1e30; }
+        else if (PART == 12) { const double y = dt * (1e-12 * q); dacc += y * 3.0 + y; }
+        else { const float sn = tiny * 1e-9f * q, cs = 1.0f; const float t0 = cs * a + sn * b, t1 = -sn * a + cs * b; acc += t0 * 1e-3f + t1; dacc += (double)t0 * t0 + (double)t1 * t1; }
+      }
+      r += (double)acc * 1e38 + dacc * (PART == 12 ? 1e300 : 1.0);
+    } else if (PART == 9) {       // plain fp64 work under a lane-dependent trip count and a data-dependent exit: partial EXEC masks
+      const int n = 1 + (t & 15);
+      double z = (double)a;
+      for (int q = 0; q < n; q++) {
+        z = fma(z, 1.0000001, (double)b * 0.125) + sqrt(1.0 + z * z) / (2.0 + z * z);
+        if (z > 40.0 + (t & 3)) break;
+      }
+      r += z;
+    } else if (PART >= 7) {       // 7: the same plain fp64 work (fma, sqrt, division) on MANY live doubles: registers up to ~v60 carry fp64 operands
+      constexpr int N = PART == 7 ? 22 : (PART == 8 ? 10 : 2);
+      double v[N];
+#pragma unroll
+      for (int q = 0; q < N; q++) v[q] = (double)a * (1.0 + 0.01 * q) + (double)b;
+#pragma unroll
+      for (int rep = 0; rep < 3; rep++) {
+#pragma unroll
+        for (int q = 0; q < N; q++) v[q] = fma(v[q], 1.0000001, v[(q + 7) % N] * 0.125) + sqrt(1.0 + v[(q + 3) % N] * v[(q + 3) % N]) / (2.0 + v[(q + 5) % N] * v[(q + 5) % N]);
+      }
+#pragma unroll
+      for (int q = 0; q < N; q++) r += v[q];
     }
     if (it == 0) ref = r;
     bad += r != ref;
@@ -270,7 +406,43 @@ extern "C" int part_launch(int part, int blocks, int iters, unsigned *out3) {
     case 3: hipLaunchKernelGGL(part_kernel<3>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
     case 4: hipLaunchKernelGGL(part_kernel<4>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
     case 5: hipLaunchKernelGGL(part_kernel<5>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
-    default: hipLaunchKernelGGL(part_kernel<6>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 6: hipLaunchKernelGGL(part_kernel<6>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 7: hipLaunchKernelGGL(part_kernel<7>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 14: hipLaunchKernelGGL(part_kernel<14>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 15: hipLaunchKernelGGL(part_kernel<15>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 16: hipLaunchKernelGGL(part_kernel<16>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 17: hipLaunchKernelGGL(part_kernel<17>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 10: hipLaunchKernelGGL(part_kernel<10>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 11: hipLaunchKernelGGL(part_kernel<11>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 12: hipLaunchKernelGGL(part_kernel<12>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 13: hipLaunchKernelGGL(part_kernel<13>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 9: hipLaunchKernelGGL(part_kernel<9>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    default: hipLaunchKernelGGL(part_kernel<8>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+  }
+  if (hipGetLastError() != hipSuccess) return 3;
+  if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
+  if (hipMemcpy(out3, g_counts, 12, hipMemcpyDeviceToHost) != hipSuccess) return 5;
+  return 0;
+}
+
+extern "C" int svdvar_launch(int variant, int blocks, int iters, unsigned *out3) {
+  if (!g_counts) {
+    if (hipMalloc(&g_counts, 16) != hipSuccess) return 1;
+    if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
+  }
+  if (hipMemset(g_counts, 0, 16) != hipSuccess) return 1;
+  switch (variant) {
+    case 1: hipLaunchKernelGGL(svdvar_kernel<1>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 2: hipLaunchKernelGGL(svdvar_kernel<2>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 3: hipLaunchKernelGGL(svdvar_kernel<3>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 4: hipLaunchKernelGGL(svdvar_kernel<4>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 3 + 16: hipLaunchKernelGGL(svdvar_kernel<3 + 16>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 3 + 32: hipLaunchKernelGGL(svdvar_kernel<3 + 32>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 3 + 64: hipLaunchKernelGGL(svdvar_kernel<3 + 64>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 3 + 128: hipLaunchKernelGGL(svdvar_kernel<3 + 128>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 3 + 256: hipLaunchKernelGGL(svdvar_kernel<3 + 256>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    case 3 + 16 + 32 + 64: hipLaunchKernelGGL(svdvar_kernel<3 + 16 + 32 + 64>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
+    default: hipLaunchKernelGGL(svdvar_kernel<0>, dim3(blocks), dim3(256), 0, g_stream, iters, 0.5f, g_counts); break;
   }
   if (hipGetLastError() != hipSuccess) return 3;
   if (hipStreamSynchronize(g_stream) != hipSuccess) return 4;
