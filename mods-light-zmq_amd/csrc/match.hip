@@ -13,11 +13,14 @@
 //   reject  <=> some train t != i0 has d_t < D* and lies > contradDist from i0
 //   else accept the first train in (d, t) order with d_t >= D*, provided at most nn-2 trains
 //   (all consistent, all with d_t < D*) precede it.
-// Pass 1 finds (d0, i0); pass 2 accumulates {any inconsistent below D*, count below D*,
-// min key at/above D*, min key below D*} per query.
+// Pass 1 finds the two nearest trains (d0, i0), (d1, t1) of every query - a branch-free MFMA sweep that keeps the three best
+// half-tile maxima per query and train split, and an exact finish over the few half tiles that can hold them; most queries
+// are settled by those two keys (match_mid_kernel), the rest go through pass 2, which accumulates {any inconsistent below D*,
+// count below D*, min key at/above D*, min key below D*} per query.
 //
 // Distances are exact integers: descriptors are offset to int8 (v - 128), the contraction runs
-// on v_mfma_i32_32x32x32_i8 (i32 accumulate) and d = cq + ct - 2*dot with precombined norms.
+// on v_mfma_i32_32x32x32_i8 (i32 accumulate) and d = cq + ct - 2*dot with precombined norms (the same integers whether the dot
+// product comes from the matrix cores or from v_dot4 in the exact finish).
 // Trains are the MFMA rows (streamed), queries the columns (resident in registers), so every
 // lane reduces its 16 results per tile into per-query running values.
 #include "common.hpp"
@@ -35,6 +38,11 @@ struct MatchConst {
   int max_distance;       // >= 0: MatchFLANNDistance (Hamming) decisions in the emit stage; -1: FGINN
 };
 
+// Accumulator seed of a train row: acc = dot - floor(ct/2) + MATCH_BIAS.  dot lies in [-2^21, 2^21] and ct in [2^21, 2^22], so the
+// seeded accumulators of real rows lie in [1, 5*2^20 + 1] (23 bits, never negative); the rows past the end of the list inside the last
+// tile carry zero descriptors and the seed 0: their accumulators are exactly 0, below every real one.
+constexpr int MATCH_BIAS = (1 << 22) + 1;
+
 // Packs one region list for the matcher: int8 descriptors (v-128), c = sum v^2 - 256*sum(v-128),
 // centre coordinates.  grid = ceil(n/4), block = 256 (one wave per region).
 __global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__restrict__ reg, const int *__restrict__ count_ptr,
@@ -44,11 +52,11 @@ __global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__re
   int n = count_ptr ? *count_ptr : count_fixed;
   if (n > max_n) n = max_n;
   const int lane = threadIdx.x & 63;
-  // rows of the last tile beyond the list: a seed that can never be a tile maximum (stale or zero entries there
-  // must not shadow the valid rows; -2 * seed still fits an int)
-  if (blockIdx.x == 0 && threadIdx.x < 32) {
-    const int i = n + (int)threadIdx.x;
-    if (i < ((n + 31) & ~31)) c2neg[i] = -(1 << 25);
+  // rows of the last tile beyond the list: zero descriptor, zero seed (stale entries there must not shadow the valid rows)
+  if (blockIdx.x == 0) {
+    const int n32 = (n + 31) & ~31;
+    for (int e = threadIdx.x; e < (n32 - n) * 32; e += 256) ((int *)(desc + (size_t)n * 128))[e] = 0;
+    if (threadIdx.x < 32 && n + (int)threadIdx.x < n32) c2neg[n + threadIdx.x] = 0;
   }
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
     const uint8_t *d = reg[i].desc;
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__re
     if (lane == 0) {
       const int c = n2 - 256 * s1;
       cvec[i] = c;
-      c2neg[i] = -(c >> 1);       // accumulator seed of the distance tiles: acc = dot - floor(c/2)
+      c2neg[i] = MATCH_BIAS - (c >> 1);       // accumulator seed of the distance tiles: acc = dot - floor(c/2) + MATCH_BIAS
       if (c & 1) atomicOr(&parity[i >> 5], 1u << (i & 31));   // c & 1 of the 32 rows of a tile in one word (zeroed by the caller)
       xy[i] = make_double2(reg[i].x, reg[i].y);
     }
@@ -74,23 +82,25 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// Epilogue design.  A 32x32x128 tile costs 4 MFMAs (~128 clk of the matrix pipe) and leaves 16 results per
-// lane; building 64-bit (distance, index) keys for all of them costs several times that in VALU work.  So:
-//   - the accumulators are seeded with -floor(ct/2) of their train rows (the seed loads land directly in the
-//     C registers), which makes the MFMA result acc = dot - floor(ct/2) and the squared distance
-//     d = cq + (ct & 1) - 2*acc: the nearest trains of a tile are simply its LARGEST accumulators;
-//   - the fast path takes the maximum of the 16 accumulators (eight 3-input max) and compares -2*max with the
-//     lane's threshold on d - cq (pass 1: best distance so far; pass 2: max(D*, best distance >= D* so far));
-//     -2*acc <= d - cq, so a tile that cannot matter never passes, and only passing tiles take the exact path;
-//   - train tiles stream in index order, so after the first few hundred trains a lane passes with probability
-//     ~32/T per tile.
-// A wave keeps QB query blocks resident (QB x 4 B-operand registers): every A tile fetched from L1/L2 feeds
-// QB x 4 MFMAs.
+// Pass-1 design.  A 32x32x128 tile costs 4 MFMAs (~128 clk of the matrix pipe) and leaves 16 results per lane: the distances of
+// ONE query (the lane's column) to 16 of the tile's 32 trains (a "half tile": rows (r&3) + 8*(r>>2) + 4*(lane>>5)).  With the seeded
+// accumulators acc = dot - floor(ct/2) + MATCH_BIAS the squared distance is d = cq + (ct & 1) - 2*(acc - MATCH_BIAS): a larger
+// accumulator is a strictly nearer train (the parity term only orders equal accumulators).  Nothing exact happens inside the tile
+// loop: a lane keeps the THREE largest half-tile maxima it has seen, as packed 32-bit keys
+//     key = max16(acc) << 9 | (255 - tile index inside the train split) << 1 | (1 - half)
+// by v_max3 x 8, one v_lshl_or, v_med3 x 2 and v_max per query block and tile - no branch, no ballot, no exchange between waves or
+// workgroups.  The two nearest trains of a query then lie in half tiles whose maximum is at least the second largest maximum A
+// over all half tiles (two different half tiles hold an accumulator >= A, i.e. two trains strictly nearer than anything in a half
+// tile whose maximum is below A), so match_fix_kernel recomputes exactly the half tiles with maximum >= A - two of them unless
+// maxima tie - and a (query, split) stream whose THIRD key also reaches A may have dropped such a half tile: that query is
+// rescanned over all trains (the exact fallback; three half tiles of one stream tying with the runner-up needs repeated descriptors).
+// A wave keeps QB query blocks resident (QB x 4 B-operand registers): every A tile read from LDS feeds QB x 4 MFMAs.
 constexpr int MATCH_QB = 2;        // pass 2 (its exact path is taken per wave: fewer queries per wave, fewer exact tiles)
 #ifndef MATCH_QB_NN1
-#define MATCH_QB_NN1 2   // measured: 4 blocks per wave (16 MFMAs per tile) run slower, 0.67 vs 0.39 ms on 56 k x 40 k
+#define MATCH_QB_NN1 4   // measured (round 4, profiles/r04_match_variants.log): 2 blocks at 5 waves per SIMD 318 us, 3 blocks (spills) 349, 4 blocks at 3 waves 284
 #endif
-constexpr int MATCH_QB1 = MATCH_QB_NN1;   // pass 1: 16 MFMAs per train tile and wave
+constexpr int MATCH_QB1 = MATCH_QB_NN1;   // pass 1: 16 MFMAs per train tile and wave (half the LDS reads and tile fetches per MFMA of 2 blocks)
+constexpr int NN1_MAX_TPS = 256;          // tiles per train split: the tile index inside the split has 8 bits of the key
 
 __device__ __forceinline__ int acc_max16(const v16i &acc) {
   int m = max(max(acc[0], acc[1]), acc[2]);
@@ -128,230 +138,305 @@ __device__ __forceinline__ void tile_store(char *buf, const TileRegs &r) {
   *(v4i *)(buf + (threadIdx.x >> 3) * MT_ROW + (threadIdx.x & 7) * 16) = r.a;
   if (threadIdx.x < 32) ((int *)(buf + 32 * MT_ROW))[threadIdx.x] = r.s;
 }
-
-// Pass 1: the two smallest keys (d << 32 | t) per query and train split.  grid = (ceil(n_q/(128*QB)), splits), block 256.
-// The second key is what makes pass 2 rare: with (d1, t1) the smallest key over t != i0, a query whose d1 is >= D* has no
-// train below D* at all and its first train at or above D* IS (d1, t1) - see match_mid_kernel.
-// best2: [split][n_qpad][2], n_qpad = gridDim.x * 128 * QB (plain stores: every (split, query) has one owner).
-//
-// Exact path = branch-free register top-2 of packed 32-bit keys.  With acc = dot - floor(ct/2) the distance is
-// d = cq + (ct & 1) - 2*acc, so k = 2*acc - (ct & 1) = -(d - cq) orders the trains of a query (larger = nearer).  A lane
-// packs k4 = (k << 4) | (15 - r) (r = accumulator register = row order inside the lane) with ONE v_lshl_add_u32 per value:
-// k4 = (acc << 5) + C[row], C[row] = (-(ct & 1) << 4) | (15 - r(row)) comes with the tile through LDS.  The two largest
-// k4 of a lane are kept by v_med3_i32 + v_max_i32 per value (no compares, no exec masks, no LDS keys), and the tile
-// they came from by five selects per tile: values of one tile are distinct (distinct r), equal k4 of different tiles
-// keep the earlier tile = the lower train index, which is the (d, t) order.  |acc| < 2^23 (dot within +-2.1 M, ct/2 within
-// 2.1 M), rows past the end of the list carry the seed -2^25: their k4 lie below every real one and do not wrap.
-constexpr int MT2_BYTES = 32 * MT_ROW + 256;
-#ifndef MATCH_WG_WAVES
-#define MATCH_WG_WAVES 4   // waves of a pass-1 workgroup = the waves that wait for each other at the tile barrier
-#endif
-constexpr int NN1_WAVES = MATCH_WG_WAVES, NN1_THREADS = 64 * NN1_WAVES, NN1_LOADS = 256 / NN1_THREADS;   // 16-byte loads per thread and tile
-struct TileRegs2 { v4i a[NN1_LOADS]; int s; };
-__device__ __forceinline__ TileRegs2 tile_fetch2(const int8_t *__restrict__ tdesc, const int *__restrict__ tc2n, const int *__restrict__ tc, int tt) {
-  TileRegs2 r;
-#pragma unroll
-  for (int i = 0; i < NN1_LOADS; i++) r.a[i] = *(const v4i *)(tdesc + (size_t)tt * 4096 + (threadIdx.x + i * NN1_THREADS) * 16);
-  // threads 0..31: the seeds, 32..63: ct of the rows (turned into the key constants when the tile is stored: nothing
-  // waits for this load before the MFMAs)
-  r.s = threadIdx.x < 64 ? (threadIdx.x < 32 ? tc2n : tc - 32)[tt * 32 + threadIdx.x] : 0;
-  return r;
-}
-__device__ __forceinline__ void tile_store2(char *buf, const TileRegs2 &r) {
-#pragma unroll
-  for (int i = 0; i < NN1_LOADS; i++) {
-    const int t = threadIdx.x + i * NN1_THREADS;
-    *(v4i *)(buf + (t >> 3) * MT_ROW + (t & 7) * 16) = r.a[i];
-  }
-  if (threadIdx.x < 64) {
-    const int row = threadIdx.x & 31;
-    const int ck = (-(r.s & 1) * 16) | (15 - ((row & 3) + 4 * (row >> 3)));
-    ((int *)(buf + 32 * MT_ROW))[threadIdx.x] = threadIdx.x < 32 ? r.s : ck;
-  }
-}
 // max of a value over the two half-waves (lane l and lane l ^ 32) in one VALU instruction: v_permlane32_swap exchanges the upper
 // half of one copy with the lower half of the other, so both copies then hold both halves' values lane by lane (the shuffle
-// builtin goes through ds_bpermute: eight address instructions and an LDS round trip inside the exact path)
+// builtin goes through ds_bpermute: eight address instructions and an LDS round trip in every tile of pass 2)
 __device__ __forceinline__ int max_halves(int x) {
-#ifdef MATCH_NO_PERMLANE
-  return max(x, __shfl_xor(x, 32));
-#else
   const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
   return max((int)r[0], (int)r[1]);
-#endif
 }
-__device__ __forceinline__ int med3_i32(int a, int b, int c) {
-  int o;
-  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+__device__ __forceinline__ unsigned med3_u32(unsigned a, unsigned b, unsigned c) {
+  unsigned o;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
   return o;
 }
-#ifdef MATCH_STATS
-__device__ unsigned long long g_match_stats[4];
-#endif
-#ifndef MATCH_XCH
-#define MATCH_XCH 16   // tiles between two exchanges of the shared bound (a power of two)
-#endif
+// keeps (m1 >= m2 >= m3) the three largest keys seen
+__device__ __forceinline__ void top3_insert(unsigned &m1, unsigned &m2, unsigned &m3, unsigned x) {
+  m3 = med3_u32(m2, m3, x);
+  m2 = med3_u32(m1, m2, x);
+  m1 = max(m1, x);
+}
 
-// amdgpu_num_vgpr counts in pairs on gfx950 (the value is doubled for the unified register file): 62 = at most 124 VGPRs, i.e.
-// v124..v127 of the 128 allocated (4 waves per SIMD) stay untouched.  With all 128 in use - `ds_read_b128 v[124:127]` fed the MFMAs -
-// this kernel intermittently changed single results of kernels running next to it on OTHER streams (one keypoint's shape, one
-// descriptor per ~10^3 pairs under the six-worker pipeline; never with one stream); every build that left the top registers
-// unused, whatever else it changed, was clean.  tools/stress_match.py reproduces it, DESIGN.md "The matcher and its neighbours".
-#ifndef MATCH_NN1_VGPRS
-#define MATCH_NN1_VGPRS 62
+// Co-residency rule (DESIGN.md "The matcher and its neighbours").  A wave that issues independent MFMAs (several accumulator
+// chains) makes double-precision VALU results of OTHER waves on the same SIMD go wrong - waves of other streams and contexts
+// included; tools/ubench/mfma_aggr.hip reproduces it with nothing but MFMAs next to the fp64 victim of tools/ubench/spin_victim.hip
+// (10^5..10^9 wrong rounds per second, whatever the operand data; none with ONE dependent chain per wave, none when the MFMA kernel
+// allocates the whole register file of its SIMDs).  So the two matrix-core kernels of this file never share a SIMD with foreign
+// waves: a workgroup of either pass is four waves of 512 registers (one per SIMD, the whole file); the allocation is forced by touching the last register (nn1_own_simd / fginn_own_simd), and
+// tests/test_cpu_host.py::test_matrix_core_kernels_own_their_simds reads it back from the built library.
+__device__ __forceinline__ void own_simd_256() { asm volatile("v_mov_b32 v255, 0" ::: "v255"); }
+__device__ __forceinline__ void own_simd_512() { asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255"); }
+
+constexpr int NN1_WAVES = 4, NN1_THREADS = 64 * NN1_WAVES;
+// The four waves of a pass-1 workgroup - one per SIMD, each owning its SIMD - walk the same train tiles.  A tile (32 rows x 128 B)
+// and its 32 accumulator seeds go from global memory straight into LDS (global_load_lds: no staging registers, no ds_write),
+// NN1_PF tiles ahead of the MFMAs in a ring of NN1_PF + 1 images.
+// LDS image of a tile: the DMA writes a wave's 64 x 16 bytes linearly (8 rows), so rows are 128 bytes apart and the bank
+// conflicts of the operand reads (lane = row, same 16-byte column) are removed by a swizzle on the SOURCE side: the 16-byte
+// chunk c of row r sits at chunk position c ^ ((r >> 1) & 7); the 16 rows of a ds_read_b128 lane group then fall into 16
+// different 16-byte slots of the 256-byte bank row.
+// With one wave per SIMD nothing else hides a wave's own latencies, so the tile loop is software-pipelined inside the wave: the 16
+// MFMAs of tile i (4 query blocks x 4 K slices, into one of two accumulator sets) are interleaved with the epilogue of tile i - 1
+// on the other set (3 VALU instructions per MFMA), the LDS reads of tile i + 1's operands (a K slice's registers are refilled
+// once its four MFMAs have been issued) and the DMA of tile i + NN1_PF; one barrier per tile.
+#ifndef NN1_PF
+#define NN1_PF 3
 #endif
-__global__ __launch_bounds__(NN1_THREADS) __attribute__((amdgpu_num_vgpr(MATCH_NN1_VGPRS))) void match_nn1_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
-                                                        const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
-                                                        const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
-                                                        unsigned long long *__restrict__ best2, int *__restrict__ gthr) {
+constexpr int NN1_NBUF = NN1_PF + 1;
+constexpr int NN1_IMG = 4096 + 128;       // rows | seeds
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+__device__ __forceinline__ void nn1_dma_tile(const int8_t *__restrict__ tdesc, const int *__restrict__ tc2n, int tt, char *img, int w, int lane) {
+  const int r = 8 * w + (lane >> 3);
+  __builtin_amdgcn_global_load_lds((gptr_t)(tdesc + (size_t)tt * 4096 + r * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4)), (lptr_t)(img + w * 1024), 16, 0, 0);
+  if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(tc2n + tt * 32 + w * 8 + lane), (lptr_t)(img + 4096 + w * 32), 4, 0, 0);
+}
+struct Nn1State {          // what a wave carries through the tile loop besides the accumulators
+  v4i bq[MATCH_QB1][4];    // query operands (resident)
+  v4i a[4];                // train operands of the tile being multiplied (refilled slice by slice for the next one)
+  v16i seed;               // accumulator seeds of that tile
+  unsigned M1[MATCH_QB1], M2[MATCH_QB1], M3[MATCH_QB1];
+  int aoff[4];             // this lane's operand address inside an image: row lane & 31, chunk 2 * ks + g at its swizzled position
+  int soff;                // ... and of its first seed
+};
+// one epilogue slice: three of the twelve VALU instructions that fold block b's accumulators of the previous tile into its keys
+template <int PART>
+__device__ __forceinline__ void nn1_epi_slice(const v16i &acc, int &m, unsigned &M1, unsigned &M2, unsigned &M3, unsigned idc) {
+  if (PART == 0) { m = max(max(acc[0], acc[1]), acc[2]); m = max(max(m, acc[3]), acc[4]); m = max(max(m, acc[5]), acc[6]); }
+  if (PART == 1) { m = max(max(m, acc[7]), acc[8]); m = max(max(m, acc[9]), acc[10]); m = max(max(m, acc[11]), acc[12]); }
+  if (PART == 2) { m = max(max(m, acc[13]), acc[14]); m = max(m, acc[15]); const unsigned x = ((unsigned)m << 9) | idc; M3 = med3_u32(M2, M3, x); m = (int)x; }
+  if (PART == 3) { const unsigned x = (unsigned)m; M2 = med3_u32(M1, M2, x); M1 = max(M1, x); }
+}
+// Tile step of tile i (image RING = i mod 4):
+//   head   tile i + 1 has landed for everybody behind the barrier (a wave's two DMA instructions per tile complete in order: all but
+//          the NN1_PF - 2 youngest tiles), and the image of tile i - 1 - whose last readers passed the previous barrier - takes tile
+//          i + NN1_PF (GUARD: near the end of the split there is nothing left to fetch and the wait is for everything);
+//   body   multiplies tile i into accW while (EPI) folding tile i - 1 from accR, and refills the operand registers from the image
+//          of tile i + 1 (read whatever it holds after the last tile: unused).
+template <bool EPI, int RING, bool GUARD>
+__device__ __forceinline__ void nn1_step(Nn1State &st, v16i (&accW)[MATCH_QB1], const v16i (&accR)[MATCH_QB1], char *s_ring, const int8_t *__restrict__ tdesc,
+                                         const int *__restrict__ tc2n, int tile, int i, int n, int w, int lane, unsigned idc_prev) {
   constexpr int QB = MATCH_QB1;
-  constexpr int NONE = (int)0x80000000;
+  if (!GUARD || i - 1 + NN1_PF < n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * (NN1_PF - 2)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (!GUARD || i + NN1_PF < n) nn1_dma_tile(tdesc, tc2n, tile + NN1_PF, s_ring + ((RING + NN1_PF) % NN1_NBUF) * NN1_IMG, w, lane);
+  const char *nxt = s_ring + ((RING + 1) % NN1_NBUF) * NN1_IMG;
+  int m[QB];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+      accW[b] = ks == 0 ? __builtin_amdgcn_mfma_i32_32x32x32_i8(st.a[0], st.bq[b][0], st.seed, 0, 0, 0)
+                        : __builtin_amdgcn_mfma_i32_32x32x32_i8(st.a[ks], st.bq[b][ks], accW[b], 0, 0, 0);
+      if (EPI) {      // block ks of the previous tile, slice b
+        if (b == 0) nn1_epi_slice<0>(accR[ks], m[ks], st.M1[ks], st.M2[ks], st.M3[ks], idc_prev);
+        if (b == 1) nn1_epi_slice<1>(accR[ks], m[ks], st.M1[ks], st.M2[ks], st.M3[ks], idc_prev);
+        if (b == 2) nn1_epi_slice<2>(accR[ks], m[ks], st.M1[ks], st.M2[ks], st.M3[ks], idc_prev);
+        if (b == 3) nn1_epi_slice<3>(accR[ks], m[ks], st.M1[ks], st.M2[ks], st.M3[ks], idc_prev);
+      }
+    }
+    // the four MFMAs that read a[ks] (and, in round 0, the seeds) have been issued: refill for the next tile
+    st.a[ks] = *(const v4i *)(nxt + st.aoff[ks]);
+    if (ks == 0) st.seed = acc_seed((const int *)(nxt + 4096 + st.soff), 0, 0);
+  }
+  // the order above, pinned: per MFMA three VALU instructions of the epilogue; the LDS reads behind the rounds
+#define NN1_SGB_ROUND(NDS)                                                     \
+  _Pragma("unroll") for (int b = 0; b < QB; b++) {                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
+    if (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                \
+  }                                                                            \
+  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+  NN1_SGB_ROUND(5) NN1_SGB_ROUND(1) NN1_SGB_ROUND(1) NN1_SGB_ROUND(1)
+#undef NN1_SGB_ROUND
+}
+// Pass 1.  grid = qblocks * splits workgroups of 256 threads; best3: [split][n_qpad] (M1, M2, M3, 0), n_qpad = qblocks * 128 * QB
+// (plain 16-byte stores: every (split, query) has one owner).
+// Workgroup -> (query block, split): with a split count that is a multiple of 8, the workgroups that the dispatcher places on one
+// XCD (linear id mod 8) share that XCD's train splits (split mod 8 = XCD), so an XCD's L2 holds one eighth of the train list
+// instead of all of it; any other placement is only slower.
+__global__ __launch_bounds__(NN1_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_nn1_kernel(MatchConst k, int qblocks, int splits,
+                                                        const int8_t *__restrict__ qdesc, const int8_t *__restrict__ tdesc,
+                                                        const int *__restrict__ tc2n, uint4 *__restrict__ best3) {
+  constexpr int QB = MATCH_QB1;
+  static_assert(QB == 4 && NN1_NBUF == 4, "nn1_step is laid out for four query blocks and a ring of four images");
+  own_simd_512();
   const int lane = threadIdx.x & 63, g = lane >> 5;
-  const int jbase = (blockIdx.x * NN1_WAVES + (threadIdx.x >> 6)) * (32 * QB) + (lane & 31);
-  v4i bq[QB][4];
-  int M1[QB], M2[QB], T1[QB], T2[QB];   // two largest packed keys of this lane's rows and their tiles
-  int bk[QB], alim[QB];                 // bound on k = -(d - cq): only k >= bk can matter; acc >= alim <=> 2*acc >= bk
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int qb, sp;
+  if ((splits & 7) == 0) { const int x = blockIdx.x & 7, idx = blockIdx.x >> 3; sp = (idx / qblocks) * 8 + x; qb = idx % qblocks; }
+  else { sp = blockIdx.x / qblocks; qb = blockIdx.x % qblocks; }
+  const int n_tiles = (k.n_t + 31) / 32;
+  const int t0 = sp * k.tiles_per_split;
+  const int n = max(0, min(n_tiles, t0 + k.tiles_per_split) - t0);      // tiles of this workgroup
+  __shared__ __attribute__((aligned(16))) char s_ring[NN1_NBUF * NN1_IMG];
+#pragma unroll
+  for (int d = 0; d < NN1_PF; d++)
+    if (d < n) nn1_dma_tile(tdesc, tc2n, t0 + d, s_ring + d * NN1_IMG, w, lane);
+  const int jbase = (qb * NN1_WAVES + w) * (32 * QB) + (lane & 31);
+  Nn1State st;
 #pragma unroll
   for (int b = 0; b < QB; b++) {
     const int j = jbase + 32 * b;
     const int jc = j < k.n_q ? j : k.n_q - 1;
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) bq[b][ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
-    // gthr = (second smallest distance) - cq + 1 shared by the workgroups that scan other train ranges for the same queries
-    // (starts at 0x7f7f7f7f = no bound): the global second key is at most any split's second key, so trains above it
-    // cannot be among the two nearest.  d - cq < gthr  <=>  k >= 1 - gthr
-    bk[b] = 1 - __hip_atomic_load(&gthr[jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    alim[b] = (bk[b] + 1) >> 1;
-    M1[b] = NONE; M2[b] = NONE; T1[b] = 0; T2[b] = 0;
+    for (int ks = 0; ks < 4; ks++) st.bq[b][ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
+    st.M1[b] = 0u; st.M2[b] = 0u; st.M3[b] = 0u;
   }
-  const int n_tiles = (k.n_t + 31) / 32;
-  const int t0 = blockIdx.y * k.tiles_per_split;
-  const int t1 = min(n_tiles, t0 + k.tiles_per_split);
-  // The four waves of a workgroup walk the same train tiles: a tile (32 x 128 B), its 32 accumulator seeds and its 32 key
-  // constants are fetched from global memory once per workgroup (one 16-byte load per thread), handed over through LDS
-  // (double buffered, one barrier per tile) and read from there as MFMA operands; the next tile's loads are in flight
-  // during the MFMAs.
-#ifdef MATCH_STATS
-  unsigned int st_exact = 0, st_all = 0;
-#endif
-  // the 8 MFMAs of one tile (LDS image `cur`) into acc
-  auto mm = [&](const char *cur, v16i (&acc)[QB]) {
-    v4i a[4];
+  // the query operands are complete before the tile loop starts (otherwise the compiler's waits for them sit in front of the
+  // loop's MFMAs, where in every later iteration they would wait for the prefetch instead)
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(cur + (lane & 31) * MT_ROW + ks * 32 + g * 16);
-    acc[0] = acc_seed((const int *)(cur + 32 * MT_ROW), 0, g);
+  for (int b = 0; b < QB; b++)
 #pragma unroll
-    for (int b = 1; b < QB; b++) acc[b] = acc[0];
+    for (int ks = 0; ks < 4; ks++) asm volatile("" : "+v"(st.bq[b][ks]));
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++)
+  for (int ks = 0; ks < 4; ks++) st.aoff[ks] = (lane & 31) * 128 + (((2 * ks + g) ^ (((lane & 31) >> 1) & 7)) << 4);
+  st.soff = 16 * g;
 #pragma unroll
-      for (int b = 0; b < QB; b++) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], bq[b][ks], acc[b], 0, 0, 0);
-  };
-  // epilogue of tile tt (its LDS image `cur` still holds the key constants)
-  auto epi = [&](const char *cur, v16i (&acc)[QB], int tt) {
-    // key constants of this lane's 16 rows: read for every tile (they share the A operands' dead registers), so that the exact
-    // path does not start with an LDS round trip
-    int4 ck[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) ck[q] = ((const int4 *)(cur + 32 * MT_ROW + 128))[2 * q + g];
-#pragma unroll
-    for (int b = 0; b < QB; b++) {
-#ifdef MATCH_STATS
-      st_all++;
-#endif
-      // some train of this tile may be among the two nearest so far: a wave-level branch.  The 16 values of a lane are four
-      // groups of four rows (one accumulator quad each); a group is inserted only when some lane of the wave holds a value of
-      // that group at or above its bound - almost always ONE group of the four.  A lane inserts all four values of such a
-      // group (harmless for the lanes that did not pass: the insertion is exact whatever the bound).  Per entry ~30 VALU
-      // instructions instead of 63: the kernel issues about as many VALU cycles as MFMA cycles, so the count matters as much
-      // as the latency.
-      int gm[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) gm[q] = max(max(max(acc[b][4 * q + 0], acc[b][4 * q + 1]), acc[b][4 * q + 2]), acc[b][4 * q + 3]);
-      const int tmax = max(max(max(gm[0], gm[1]), gm[2]), gm[3]);
-      if (__any(tmax >= alim[b])) {
-#ifdef MATCH_STATS
-        st_exact++;
-#endif
-        const int m1o = M1[b], m2o = M2[b];
-        int m1 = m1o, m2 = m2o;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          if (!__any(gm[q] >= alim[b])) continue;
-          const int4 c = ck[q];   // rows 8q + 4g .. + 3
-          const int x0 = (acc[b][4 * q + 0] << 5) + c.x, x1 = (acc[b][4 * q + 1] << 5) + c.y;
-          const int x2 = (acc[b][4 * q + 2] << 5) + c.z, x3 = (acc[b][4 * q + 3] << 5) + c.w;
-          m2 = med3_i32(m1, m2, x0); m1 = max(m1, x0);
-          m2 = med3_i32(m1, m2, x1); m1 = max(m1, x1);
-          m2 = med3_i32(m1, m2, x2); m1 = max(m1, x2);
-          m2 = med3_i32(m1, m2, x3); m1 = max(m1, x3);
-        }
-        const bool c1 = m1 != m1o;
-        T2[b] = (c1 && m2 == m1o) ? T1[b] : (m2 == m2o ? T2[b] : tt);
-        T1[b] = c1 ? tt : T1[b];
-        M1[b] = m1; M2[b] = m2;
-        // the two half-waves hold the same 32 queries (different train rows): the second key of their union is at least the
-        // larger of their second keys; an equal distance at a lower index still counts, hence k >= bound
-        const int nb = max_halves(max(bk[b], m2 >> 4));
-        bk[b] = nb; alim[b] = (nb + 1) >> 1;
-      }
+  for (int ks = 0; ks < 4; ks++) st.a[ks] = *(const v4i *)(s_ring + st.aoff[ks]);
+  st.seed = acc_seed((const int *)(s_ring + 4096 + st.soff), 0, 0);
+  v16i accA[QB], accB[QB];            // even tiles go into accA, odd ones into accB
+  auto idc = [](int i) { return (unsigned)(NN1_MAX_TPS - 1 - i) << 1; };
+#define NN1_STEP(EPI, RING, GUARD, W, R, I) nn1_step<EPI, RING, GUARD>(st, W, R, s_ring, tdesc, tc2n, t0 + (I), (I), n, w, lane, idc((I) - 1))
+  if (n > 0) {
+    NN1_STEP(false, 0, true, accA, accB, 0);
+    int i = 1;
+    if (i < n) { NN1_STEP(true, 1, true, accB, accA, i); i++; }
+    if (i < n) { NN1_STEP(true, 2, true, accA, accB, i); i++; }
+    if (i < n) { NN1_STEP(true, 3, true, accB, accA, i); i++; }
+    // four tiles per iteration: image numbers and accumulator sets are compile-time constants, nothing is conditional
+    for (; i + 3 + NN1_PF < n; i += 4) {
+      NN1_STEP(true, 0, false, accA, accB, i);
+      NN1_STEP(true, 1, false, accB, accA, i + 1);
+      NN1_STEP(true, 2, false, accA, accB, i + 2);
+      NN1_STEP(true, 3, false, accB, accA, i + 3);
     }
-    if (((tt - t0) & (MATCH_XCH - 1)) == MATCH_XCH - 1) {   // publish / pick up the bound every MATCH_XCH tiles
-#pragma unroll
-      for (int b = 0; b < QB; b++) {
-        const int j = jbase + 32 * b;
-        int nb = bk[b];
-#ifndef MATCH_NO_ATOMIC
-        if (g == 0 && j < k.n_q) nb = max(nb, 1 - atomicMin(&gthr[j], 1 - nb));
-#endif
-        nb = max_halves(nb);
-        bk[b] = nb; alim[b] = (nb + 1) >> 1;
-      }
+    for (; i < n; i += 4) {
+      NN1_STEP(true, 0, true, accA, accB, i);
+      if (i + 1 < n) NN1_STEP(true, 1, true, accB, accA, i + 1);
+      if (i + 2 < n) NN1_STEP(true, 2, true, accA, accB, i + 2);
+      if (i + 3 < n) NN1_STEP(true, 3, true, accB, accA, i + 3);
     }
-  };
-  __shared__ __attribute__((aligned(16))) char s_tile[2 * MT2_BYTES];
-  TileRegs2 nxt;
-  if (t0 < t1) { nxt = tile_fetch2(tdesc, tc2n, tc, t0); tile_store2(s_tile, nxt); }
-  __syncthreads();
-  for (int tt = t0; tt < t1; tt++) {
-    const char *cur = s_tile + ((tt - t0) & 1) * MT2_BYTES;
-    if (tt + 1 < t1) nxt = tile_fetch2(tdesc, tc2n, tc, tt + 1);
-    v16i acc[QB];
-    mm(cur, acc);
-    epi(cur, acc, tt);
-    if (tt + 1 < t1) tile_store2(s_tile + (((tt - t0) & 1) ^ 1) * MT2_BYTES, nxt);
-    __syncthreads();
+    // the last tile's epilogue
+    const v16i (&accL)[QB] = (n & 1) ? accA : accB;
+#pragma unroll
+    for (int b = 0; b < QB; b++) top3_insert(st.M1[b], st.M2[b], st.M3[b], ((unsigned)acc_max16(accL[b]) << 9) | idc(n - 1));
   }
-#ifdef MATCH_STATS
-  if (lane == 0) { atomicAdd(&g_match_stats[0], (unsigned long long)st_all); atomicAdd(&g_match_stats[1], (unsigned long long)st_exact); }
-#endif
-  const size_t n_qpad = (size_t)gridDim.x * (32 * NN1_WAVES) * QB;
+#undef NN1_STEP
+  const size_t n_qpad = (size_t)qblocks * (32 * NN1_WAVES) * QB;
 #pragma unroll
   for (int b = 0; b < QB; b++) {
     const int j = jbase + 32 * b;
-    const int cqv = qc[j < k.n_q ? j : k.n_q - 1] - 4194304;
-    unsigned long long mine_b = ~0ull, sec_b = ~0ull;
-    {
-      const int r = 15 - (M1[b] & 15), t = T1[b] * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      if (M1[b] != NONE && t < k.n_t) mine_b = ((unsigned long long)(unsigned int)(cqv - (M1[b] >> 4)) << 32) | (unsigned int)t;
-    }
-    {
-      const int r = 15 - (M2[b] & 15), t = T2[b] * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      if (M2[b] != NONE && t < k.n_t) sec_b = ((unsigned long long)(unsigned int)(cqv - (M2[b] >> 4)) << 32) | (unsigned int)t;
-    }
-    const unsigned long long o1 = shfl_xor_u64(mine_b, 32), o2 = shfl_xor_u64(sec_b, 32);
-    const unsigned long long m1 = mine_b < o1 ? mine_b : o1;
-    const unsigned long long hi = mine_b < o1 ? o1 : mine_b;
-    const unsigned long long lo2 = sec_b < o2 ? sec_b : o2;
-    const unsigned long long m2 = hi < lo2 ? hi : lo2;
-    if (g == 0 && j < k.n_q) {
-#ifndef MATCH_NO_ATOMIC
-      atomicMin(&gthr[j], 1 - bk[b]);
-#endif
-      unsigned long long *o = best2 + ((size_t)blockIdx.y * n_qpad + j) * 2;
-      o[0] = m1; o[1] = m2;
+    // the two half-waves hold the same 32 queries (the two halves of every tile): the lower one merges both triples
+    unsigned m1 = st.M1[b] | (unsigned)(1 - g), m2 = st.M2[b] | (unsigned)(1 - g), m3 = st.M3[b] | (unsigned)(1 - g);
+    const unsigned o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32), o3 = __shfl_xor(m3, 32);
+    top3_insert(m1, m2, m3, o1); top3_insert(m1, m2, m3, o2); top3_insert(m1, m2, m3, o3);
+    if (g == 0 && j < k.n_q) best3[(size_t)sp * n_qpad + j] = make_uint4(m1, m2, m3, 0u);
+  }
+}
+
+// Exact finish of pass 1: one half-wave (32 lanes) per query.  grid = ceil(n_q/8), block 256.
+//   1. A = accumulator level of the second largest key over the (M1, M2) of all train splits (at least 1: rows past the end of the
+//      list have the level 0);
+//   2. candidates = every kept half tile at or above A; unsafe when some split's M3 is at or above A too (see above), or when the
+//      candidates do not fit the list;
+//   3. lane = one train row of a candidate (two candidates per round), exact d = cq + ct - 2*dot by v_dot4 over the packed
+//      descriptors, the two smallest keys (d << 32 | t) by a half-wave reduction; an unsafe query walks all trains instead.
+// best2: [n_q][2], the input of match_mid_kernel (one "split").
+constexpr int FIX_MAXC = 32;
+__device__ __forceinline__ int desc_dot(const int8_t *__restrict__ qrow, const int8_t *__restrict__ trow) {
+  int dot = 0;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int4 a = ((const int4 *)qrow)[e], b = ((const int4 *)trow)[e];
+    dot = __builtin_amdgcn_sdot4(a.x, b.x, dot, false); dot = __builtin_amdgcn_sdot4(a.y, b.y, dot, false);
+    dot = __builtin_amdgcn_sdot4(a.z, b.z, dot, false); dot = __builtin_amdgcn_sdot4(a.w, b.w, dot, false);
+  }
+  return dot;
+}
+__device__ __forceinline__ void top2_min_insert(unsigned long long &k1, unsigned long long &k2, unsigned long long key) {
+  const bool first = key < k1;
+  k2 = first ? k1 : (key < k2 ? key : k2);
+  k1 = first ? key : k1;
+}
+__global__ __launch_bounds__(256) void match_fix_kernel(MatchConst k, int splits, size_t n_qpad, const uint4 *__restrict__ best3,
+                                                        const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
+                                                        const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
+                                                        unsigned long long *__restrict__ best2) {
+  __shared__ int s_cand[8][FIX_MAXC];
+  const int lane = threadIdx.x & 63, hl = lane & 31, hw = threadIdx.x >> 5;
+  const int hshift = lane & 32;             // this half-wave's bits of a ballot
+  const int j = blockIdx.x * 8 + hw;
+  const bool live = j < k.n_q;
+  const int jc = live ? j : k.n_q - 1;
+  // 1. the two largest (M1, M2) keys over the splits
+  unsigned K1 = 0u, K2 = 0u;
+  for (int s = hl; s < splits; s += 32) {
+    const uint4 v = best3[(size_t)s * n_qpad + jc];
+    K2 = max(min(K1, v.x), max(K2, v.y));      // v.x >= v.y
+    K1 = max(K1, v.x);
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    const unsigned o1 = __shfl_xor(K1, off), o2 = __shfl_xor(K2, off);
+    K2 = max(min(K1, o1), max(K2, o2));
+    K1 = max(K1, o1);
+  }
+  const unsigned A = max(K2 >> 9, 1u);
+  // 2. candidate half tiles (tile << 1 | half) of this query
+  int nc = 0;
+  bool unsafe = false;
+  for (int s0 = 0; s0 < splits; s0 += 32) {
+    const int s = s0 + hl;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (s < splits) v = best3[(size_t)s * n_qpad + jc];
+    unsafe |= (v.z >> 9) >= A;
+    const unsigned key[2] = {v.x, v.y};
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const bool c = (key[e] >> 9) >= A;
+      const unsigned m = (unsigned)(__ballot(c) >> hshift);
+      const int slot = nc + __popc(m & ((1u << hl) - 1u));
+      if (c && slot < FIX_MAXC)
+        s_cand[hw][slot] = ((s * k.tiles_per_split + (NN1_MAX_TPS - 1 - (int)((key[e] >> 1) & 255u))) << 1) | (int)(1u - (key[e] & 1u));
+      nc += __popc(m);
     }
   }
+  unsafe = ((unsigned)(__ballot(unsafe) >> hshift) != 0u) || nc > FIX_MAXC;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // 3. exact distances
+  const int8_t *qrow = qdesc + (size_t)jc * 128;
+  const int cq = qc[jc] - 4194304;
+  unsigned long long k1 = ~0ull, k2 = ~0ull;
+  if (!unsafe) {
+    const int r = hl & 15;
+    for (int c0 = 0; c0 < nc; c0 += 2) {
+      const int ci = c0 + (hl >> 4);
+      if (ci < nc) {
+        const int cd = s_cand[hw][ci];
+        const int t = (cd >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (cd & 1);
+        if (t < k.n_t) {
+          const int d = cq + tc[t] - 2 * desc_dot(qrow, tdesc + (size_t)t * 128);
+          top2_min_insert(k1, k2, ((unsigned long long)(unsigned int)d << 32) | (unsigned int)t);
+        }
+      }
+    }
+  } else {
+    for (int t = hl; t < k.n_t; t += 32) {
+      const int d = cq + tc[t] - 2 * desc_dot(qrow, tdesc + (size_t)t * 128);
+      top2_min_insert(k1, k2, ((unsigned long long)(unsigned int)d << 32) | (unsigned int)t);
+    }
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    const unsigned long long o1 = shfl_xor_u64(k1, off), o2 = shfl_xor_u64(k2, off);
+    const unsigned long long hi = k1 < o1 ? o1 : k1, lo2 = k2 < o2 ? k2 : o2;
+    k1 = k1 < o1 ? k1 : o1;
+    k2 = hi < lo2 ? hi : lo2;
+  }
+  if (hl == 0 && live) { best2[(size_t)j * 2] = k1; best2[(size_t)j * 2 + 1] = k2; }
 }
 
 struct QueryMid {        // per query state between the passes
@@ -435,7 +520,7 @@ __global__ __launch_bounds__(256) void match_gather_kernel(const int *__restrict
 
 // Pass 2: FGINN reductions.  Same tiling and the same two-speed epilogue as pass 1: a tile is examined exactly
 // only when one of its partial distances lies below max(D*, smallest distance >= D* found so far).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MATCH_NN1_VGPRS))) void match_fginn_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_fginn_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                           const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
                                                           const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                           const double2 *__restrict__ txy, const QueryMid *__restrict__ mid,
@@ -443,6 +528,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MATCH_NN1_VGPRS
                                                           int *__restrict__ n_lt, int *__restrict__ bad,
                                                           const int *__restrict__ n_q_dev, const int *__restrict__ out_index) {
   constexpr int QB = MATCH_QB;
+  own_simd_512();
   // the query list of this pass is the compact list of match_mid_kernel: its length lives on the device, and results go to
   // the slots of the original queries
   // the grid is ONE row of workgroups: the few query blocks the compact list fills share it, each with as many train splits
@@ -467,7 +553,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MATCH_NN1_VGPRS
     const int jc = j < k.n_q ? j : k.n_q - 1;
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) bq[b][ks] = *(const v4i *)(qdesc + (size_t)jc * 128 + ks * 32 + g * 16);
-    cq[b] = qc[jc] - 4194304;
+    cq[b] = qc[jc] - 4194304 + 2 * MATCH_BIAS;   // d = cq + (ct & 1) - 2 * (seeded accumulator)
     const QueryMid m = mid[jc];
     i0[b] = m.i0; dstar[b] = m.dstar; x0[b] = m.x0; y0[b] = m.y0;
     thr[b] = 0x7fffffff;          // until a distance >= D* has been seen every tile is examined
@@ -657,26 +743,61 @@ __global__ __launch_bounds__(1024) void match_emit_kernel(MatchConst k, const Qu
 }
 
 // ---------------------------------------------------------------------------------------
-static int match_target_blocks() {
-  static const int v = getenv("MODS_MATCH_BLOCKS") ? std::max(1, atoi(getenv("MODS_MATCH_BLOCKS"))) : 2048;
-  return v;
-}
+constexpr int FGINN_BLOCKS = 1024;     // pass 2: one workgroup per CU at a time (it owns the register file), four rounds
 static size_t match_pad(const mods_ctx *ctx) { return ((size_t)ctx->max_cand + 127) & ~(size_t)63; }   // list stride, tile tail included
+
+// Train splits of pass 1.  A workgroup owns its compute unit (register allocation), so the launch runs in rounds of one workgroup
+// per CU and its time is rounds x (tiles per split + the workgroup's fixed cost: 128 KB of query operands, the first tiles'
+// latency, the final key merge - about six tiles' worth): the split count minimises that product, never more than NN1_MAX_TPS
+// tiles each.  MODS_MATCH_BLOCKS overrides the number of workgroups aimed at (development aid).
+struct Nn1Grid { int qblocks, splits, tiles_per_split; size_t n_qpad; };
+static Nn1Grid nn1_grid(int n_q, int n_t) {
+  constexpr int QPB = 32 * NN1_WAVES * MATCH_QB1;      // queries per pass-1 workgroup
+  constexpr int CUS = 256, FIXED = 6;
+  static const int forced = getenv("MODS_MATCH_BLOCKS") ? std::max(1, atoi(getenv("MODS_MATCH_BLOCKS"))) : 0;
+  Nn1Grid gr;
+  const int n_tiles = (n_t + 31) / 32;
+  gr.qblocks = (n_q + QPB - 1) / QPB;
+  const int smin = std::max(1, (n_tiles + NN1_MAX_TPS - 1) / NN1_MAX_TPS);
+  int splits = smin;
+  if (forced) splits = std::max(smin, std::min(n_tiles, forced / std::max(1, gr.qblocks)));
+  else {
+    long best = -1;
+    const int smax = std::max(smin, std::min(n_tiles, 4 * CUS / std::max(1, gr.qblocks) + 1));
+    for (int sc = smin; sc <= smax; sc++) {
+      const long rounds = ((long)gr.qblocks * sc + CUS - 1) / CUS, tps = (n_tiles + sc - 1) / sc;
+      const long cost = rounds * (tps + FIXED);
+      if (best < 0 || cost < best) { best = cost; splits = sc; }
+    }
+  }
+  gr.tiles_per_split = (n_tiles + splits - 1) / splits;
+  gr.splits = (n_tiles + gr.tiles_per_split - 1) / gr.tiles_per_split;
+  gr.n_qpad = (size_t)gr.qblocks * QPB;
+  return gr;
+}
 
 int match_ensure_buffers(mods_ctx *ctx) {
   if (ctx->m_desc) return MODS_OK;
   const size_t n = match_pad(ctx);
   MODS_HIP_CHECK(hipMalloc(&ctx->m_desc, 2 * n * 128));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_c, (4 * n + 2 * (n / 32 + 2)) * sizeof(int)));   // c of queries, trains; -floor(c/2) of both; parity words of both
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_c, (4 * n + 2 * (n / 32 + 2)) * sizeof(int)));   // c of queries, trains; seeds of both; parity words of both
   MODS_HIP_CHECK(hipMalloc(&ctx->m_regs, 2 * (size_t)ctx->max_cand * sizeof(mods_region)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_xy, 2 * n * sizeof(double2)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_u64, 3 * n * sizeof(unsigned long long)));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_int, (2 * n + n / 1024 + 2) * sizeof(int)));   // n_lt, bad, per-block counts of the compaction
   MODS_HIP_CHECK(hipMalloc(&ctx->m_mid, n * sizeof(QueryMid)));
-  // pass-1 top-2 table (one pair of keys per query and train split; splits * query blocks <= target blocks + query blocks) and
-  // the pass-2 subset: list | count | norms | descriptors | state
-  ctx->m_best2_cap = (size_t)match_target_blocks() * 128 * MATCH_QB1 + n + 128 * MATCH_QB1;
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_p2, ctx->m_best2_cap * 16 + n * (3 * sizeof(int) + 128 + sizeof(QueryMid)) + 128));
+  // pass-1 key table (one 16-byte triple per query and train split): the largest product splits * padded queries over the list
+  // sizes this context admits (the split count grows with the train list, so only the query count is scanned)
+  {
+    size_t cap = 0;
+    for (int nq = 1; nq < ctx->max_cand + 32 * NN1_WAVES * MATCH_QB1; nq += 32 * NN1_WAVES * MATCH_QB1) {
+      const Nn1Grid gr = nn1_grid(std::min(nq, ctx->max_cand), ctx->max_cand);
+      cap = std::max(cap, (size_t)gr.splits * gr.n_qpad);
+    }
+    ctx->m_best2_cap = cap;
+  }
+  // m_p2: key table | exact top-2 per query | pass-2 subset: state, descriptors, list, norms, count
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_p2, ctx->m_best2_cap * 16 + n * 16 + n * (3 * sizeof(int) + 128 + sizeof(QueryMid)) + 128));
   MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, tent_bytes(n) + 64));
   // the tentative count lives in pinned host memory: the emit kernel's single store lands there, the host reads it after a
   // stream synchronisation - no 4-byte copy launch per search
@@ -686,14 +807,12 @@ int match_ensure_buffers(mods_ctx *ctx) {
   return MODS_OK;
 }
 
-// One launch instead of four memsets per search: tentative counter, pass-2 list counter, the parity words the pack kernels OR
-// into, and the shared bounds of pass 1 (0x7f7f7f7f = none).  grid = ceil(max(n_q, n_t) / 256), block 256
+// One launch instead of three memsets per search: tentative counter, pass-2 list counter and the parity words the pack kernels
+// OR into.  grid = ceil(max(n_q, n_t) / 32 / 256) + 1, block 256
 __global__ __launch_bounds__(256) void match_init_kernel(int n_q, int n_t, int *__restrict__ m_count, int *__restrict__ count2,
-                                                         unsigned int *__restrict__ qpar, unsigned int *__restrict__ tpar,
-                                                         int *__restrict__ gthr) {
+                                                         unsigned int *__restrict__ qpar, unsigned int *__restrict__ tpar) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) { *m_count = 0; *count2 = 0; }
-  if (i < n_q) gthr[i] = 0x7f7f7f7f;
   if (i <= n_q / 32) qpar[i] = 0u;
   if (i <= n_t / 32) tpar[i] = 0u;
 }
@@ -707,6 +826,7 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   MatchConst k;
   k.n_q = n_q; k.n_t = n_t; k.nn = nn;
   k.max_distance = -1;
+  k.tiles_per_split = 0;
   k.sqminratio = ratio * ratio;
   k.contr_sq = contradDist * contradDist;
   if (!(k.sqminratio < 1.0)) { set_error("FGINN ratio >= 1 (all-neighbours mode) is not supported"); return MODS_E_ARG; }
@@ -719,46 +839,39 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   int *qc = ctx->m_c, *tc = ctx->m_c + n, *qc2 = ctx->m_c + 2 * n, *tc2 = ctx->m_c + 3 * n;
   unsigned int *qpar = (unsigned int *)(ctx->m_c + 4 * n), *tpar = qpar + n / 32 + 2;
   double2 *qxy = (double2 *)ctx->m_xy, *txy = (double2 *)ctx->m_xy + n;
-  unsigned long long *best = ctx->m_u64, *key_ge = ctx->m_u64 + n, *key_lt = ctx->m_u64 + 2 * n;
+  unsigned long long *key_ge = ctx->m_u64 + n, *key_lt = ctx->m_u64 + 2 * n;
   int *n_lt = ctx->m_int, *bad = ctx->m_int + n;
   StageScope ts(ctx, MODS_STAGE_MATCH);
-  const int n_tiles = (n_t + 31) / 32;
-  const int target_blocks = match_target_blocks();
   // carve of m_p2 (every part 16-byte aligned)
-  unsigned long long *best2 = (unsigned long long *)ctx->m_p2;
-  QueryMid *mid2 = (QueryMid *)(best2 + 2 * ctx->m_best2_cap);
+  uint4 *best3 = (uint4 *)ctx->m_p2;
+  unsigned long long *best2 = (unsigned long long *)(best3 + ctx->m_best2_cap);
+  QueryMid *mid2 = (QueryMid *)(best2 + 2 * n);
   int8_t *qd2 = (int8_t *)(mid2 + n);
   int *list2 = (int *)(qd2 + n * 128), *qcs = list2 + n, *count2 = qcs + n;
-  int *gthr = count2 + 16;
-  static const int dbg_mask = getenv("MODS_MATCH_MASK") ? atoi(getenv("MODS_MATCH_MASK")) : 63;   // DEBUG bisect
-  if (dbg_mask & 1) hipLaunchKernelGGL(match_init_kernel, dim3((std::max(n_q, n_t) + 255) / 256), dim3(256), 0, ctx->stream, n_q, n_t, count_out, count2, qpar, tpar, gthr);
-  if (dbg_mask & 1) hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
-  if (dbg_mask & 1) hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
-  (void)best;
-  // pass 1: top-2 keys per query and train split
-  constexpr int QPB = 32 * NN1_WAVES * MATCH_QB1;      // queries per pass-1 workgroup
-  const int qblocks1 = (n_q + QPB - 1) / QPB;
-  int splits1 = std::max(1, std::min(n_tiles, target_blocks * (4 / NN1_WAVES) / std::max(1, qblocks1)));
+  hipLaunchKernelGGL(match_init_kernel, dim3(std::max(n_q, n_t) / 32 / 256 + 1), dim3(256), 0, ctx->stream, n_q, n_t, count_out, count2, qpar, tpar);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
+  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
+  // pass 1: the three largest half-tile maxima per query and train split, then the exact two nearest trains per query
+  const Nn1Grid gr = nn1_grid(n_q, n_t);
   MatchConst k1 = k;
-  k1.tiles_per_split = (n_tiles + splits1 - 1) / splits1;
-  splits1 = (n_tiles + k1.tiles_per_split - 1) / k1.tiles_per_split;
-  const size_t n_qpad = (size_t)qblocks1 * QPB;
-  if ((size_t)splits1 * n_qpad > ctx->m_best2_cap) { set_error("match: top-2 table too small"); return MODS_E_CAPACITY; }
-  if (dbg_mask & 2) hipLaunchKernelGGL(match_nn1_kernel, dim3(qblocks1, splits1), dim3(NN1_THREADS), 0, ctx->stream, k1, qd, qc, td, tc, tc2, tpar, best2, gthr);
-  if (dbg_mask & 4) hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, best2, splits1, n_qpad, txy, (QueryMid *)ctx->m_mid,
-                     key_ge, key_lt, n_lt, bad, list2, count2);
+  k1.tiles_per_split = gr.tiles_per_split;
+  if ((size_t)gr.splits * gr.n_qpad > ctx->m_best2_cap) { set_error("match: pass-1 key table too small"); return MODS_E_CAPACITY; }
+  hipLaunchKernelGGL(match_nn1_kernel, dim3(gr.qblocks * gr.splits), dim3(NN1_THREADS), 0, ctx->stream, k1, gr.qblocks, gr.splits, qd, td, tc2, best3);
+  hipLaunchKernelGGL(match_fix_kernel, dim3((n_q + 7) / 8), dim3(256), 0, ctx->stream, k1, gr.splits, gr.n_qpad, (const uint4 *)best3, qd, qc, td, tc, best2);
+  hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, (const unsigned long long *)best2, 1, (size_t)n_q, txy,
+                     (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, list2, count2);
   // pass 2 on the undecided queries only (their number stays on the device: the grid covers the worst case, idle blocks exit)
-  if (dbg_mask & 4) hipLaunchKernelGGL(match_gather_kernel, dim3(std::min(1024, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, list2, count2, qd, qc,
+  hipLaunchKernelGGL(match_gather_kernel, dim3(std::min(1024, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, list2, count2, qd, qc,
                      (const QueryMid *)ctx->m_mid, qd2, qcs, mid2);
   {
     const int qblocks = (n_q + 128 * MATCH_QB - 1) / (128 * MATCH_QB);
-    if (dbg_mask & 8) hipLaunchKernelGGL(match_fginn_kernel, dim3(std::max(target_blocks, qblocks)), dim3(256), 0, ctx->stream, k, qd2, qcs, td, tc, tc2, tpar, txy,
+    hipLaunchKernelGGL(match_fginn_kernel, dim3(std::max(FGINN_BLOCKS, qblocks)), dim3(256), 0, ctx->stream, k, qd2, qcs, td, tc, tc2, tpar, txy,
                        (const QueryMid *)mid2, key_ge, key_lt, n_lt, bad, count2, list2);
   }
   const int eblocks = (n_q + 1023) / 1024;
   int *block_counts = (int *)(ctx->m_int + 2 * n);
-  if (dbg_mask & 16) hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
-  if (dbg_mask & 16) hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, tent_out, count_out, ctx->max_cand);
+  hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, tent_out, count_out, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }
@@ -837,12 +950,3 @@ int match_run_distance(mods_ctx *ctx, const mods_region *q_dev, int n_q, const m
 
 }  // namespace mods
 
-#ifdef MATCH_STATS
-// development aid: (query block, tile) pairs visited / taken through the exact path by match_nn1_kernel since the last call
-extern "C" void mods_debug_match_stats(unsigned long long out[2]) {
-  unsigned long long z[4] = {0, 0, 0, 0};
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mods::g_match_stats), 16);
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(mods::g_match_stats), z, 32);
-}
-#endif

@@ -152,38 +152,34 @@ def test_hmatrix_filter_matches_the_reference_error_functions(pkg, err_type, err
     assert pkg.hmatrix_filter(u6[:0], H, par)[1] == 0
 
 
-def test_matcher_kernels_leave_the_top_registers_unused():
-    """match_nn1_kernel / match_fginn_kernel run 4 waves per SIMD (a 128-VGPR allocation).  With all 128 registers in use
-    match_nn1_kernel disturbed kernels of OTHER contexts on the same GPU (round 3, DESIGN.md "The matcher and its neighbours",
-    tests/test_gpu_pair.py::test_contexts_on_one_gpu_do_not_disturb_each_other); both are capped at 124 (MATCH_NN1_VGPRS).  The
-    compiler's own resource report of csrc/match.hip, with the Makefile's flags, must say so - a later edit that lifts the cap or
-    drops the attribute fails here, on the CPU."""
-    import shutil
-    import subprocess
-    import tempfile
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc")
+def test_no_kernel_fills_its_register_allocation(pkg):
+    """Round 3 found that match_nn1_kernel, with all 128 VGPRs of its 4-waves-per-SIMD allocation in use, intermittently changed
+    fp64 results of kernels of OTHER contexts on the same GPU (DESIGN.md "The matcher and its neighbours"); every build that left
+    the top registers of the allocation untouched was clean.  The rule kept from it - no kernel, and certainly no matrix-core
+    kernel, uses the last registers of an allocation that fills the 512-entry file (64 x 8 waves, 128 x 4, 256 x 2) - is checked
+    here for EVERY kernel of the built libmodsgpu.so, from the code objects the library carries (tools/kernel_resources.py):
+    a later edit, a new kernel or a compiler update that reaches such a boundary fails on the CPU."""
+    import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = os.path.join(root, "mods-light-zmq_amd", "csrc", "match.hip")
-    mk = open(os.path.join(root, "mods-light-zmq_amd", "Makefile")).read()
-    assert "csrc/match.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form=1" in mk
-    with tempfile.TemporaryDirectory() as td:
-        p = subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                            "-fno-fast-math", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Rpass-analysis=kernel-resource-usage", "-c", src,
-                            "-o", os.path.join(td, "match.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    text = p.stdout.decode()
-    assert p.returncode == 0, text[-2000:]
-    seen = {}
-    name = None
-    for line in text.splitlines():
-        m = re.search(r"Function Name: (\S+)", line)
-        if m:
-            name = m.group(1)
-        m = re.search(r"\bVGPRs: (\d+)", line)
-        if m and name:
-            seen[name] = int(m.group(1))
-    for kernel in ("match_nn1_kernel", "match_fginn_kernel"):
-        hits = [v for k, v in seen.items() if kernel in k]
-        assert hits, (kernel, sorted(seen))
-        assert max(hits) <= 124, (kernel, hits)
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not os.path.exists(os.path.join(kr.LLVM, "llvm-objdump")):
+        pytest.skip("no llvm-objdump")
+    ks = kr.kernels(os.path.join(root, "mods-light-zmq_amd", "libmodsgpu.so"))
+    names = {k["name"] for k in ks}
+    for needed in ("match_nn1_kernel", "match_fginn_kernel", "gauss_blur_fast_kernel", "sift_wave2_kernel", "ransac_score_kernel"):
+        assert any(needed in n for n in names), (needed, len(names))
+    assert sum(1 for k in ks if k["mfma"]) >= 2                      # the two matcher passes are seen as matrix-core kernels
+    bad = []
+    for k in ks:
+        fills = k["alloc"] * k["waves"] == 512
+        # matrix-core kernels (the aggressor of round 3): the four top registers stay untouched, as in the build that was clean;
+        # every other kernel: not the last register (none was ever seen to disturb, this only keeps them off the exact boundary)
+        margin = 4 if k["mfma"] else 1
+        if fills and k["vgpr"] > k["alloc"] - margin:
+            bad.append((k["name"], k["vgpr"], k["alloc"], k["waves"], k["mfma"]))
+    assert not bad, bad
+    for k in ks:
+        if "match_nn1_kernel" in k["name"] or "match_fginn_kernel" in k["name"]:
+            assert k["scratch"] == 0, (k["name"], k["scratch"])

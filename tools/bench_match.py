@@ -38,6 +38,14 @@ def main():
         np.savez(os.path.join(ROOT, "gpurun_out", "match_fixture.npz"), q=q, t=t)
     d = np.load(CACHE)
     q, t = d["q"], d["t"]
+    # power experiments: the same lists with constant / uniformly random descriptors (the tentatives are meaningless)
+    if "--zero" in sys.argv:
+        q["desc"][:] = 0; t["desc"][:] = 0
+    if "--const128" in sys.argv:
+        q["desc"][:] = 128; t["desc"][:] = 128
+    if "--rand" in sys.argv:
+        rng = np.random.default_rng(1)
+        q["desc"][:] = rng.integers(0, 256, q["desc"].shape, dtype=np.uint8); t["desc"][:] = rng.integers(0, 256, t["desc"].shape, dtype=np.uint8)
     rq, rt = pkg.ImgRep(ctx, 1 << 17), pkg.ImgRep(ctx, 1 << 17)
     rq.append_host(q); rt.append_host(t)
     for name, (a, b) in (("C5", (rq, rt)),):

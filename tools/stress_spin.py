@@ -32,6 +32,12 @@ def aggress():
             if lib.top_launch(int(os.environ["AGGR_TOP"]), 4096, 400):
                 print("top_launch failed"); return
         return
+    if os.environ.get("AGGR_MFMA"):       # synthetic aggressor: tools/ubench/mfma_aggr.hip, nothing but MFMA streams (mode, data = AGGR_MFMA, AGGR_DATA)
+        lib = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libmfmaaggr.so"))
+        while not stop.is_set():
+            if lib.aggr_launch(int(os.environ["AGGR_MFMA"]), int(os.environ.get("AGGR_DATA", "1")), 1024, 2000):
+                print("aggr_launch failed"); return
+        return
     kind = os.environ.get("AGGR", "match")     # what the aggressor contexts run: match | pair | mser | view | dog
     d = pkg.view_ctx_dims(W, H) if kind == "view" else (W, H)
     ctx = pkg.Context(0, d[0], d[1], 2)
