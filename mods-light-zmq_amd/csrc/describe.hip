@@ -334,8 +334,7 @@ __global__ __launch_bounds__(1024) void compact_regions_kernel(DescConst k, cons
 // The same compaction with up to k.ori_cap oriented copies per keypoint (maxAngles > 1): keypoint i contributes the alive ones
 // of its ori_cap entries, in angle order, behind the copies of the keypoints before it (DetectOrientation pushes them in that
 // order, synth-detection.cpp:1095-1106).  grid = (1, n_img), block = 1024.
-// (capped at 60 registers: 64 in use would fill the 8-waves-per-SIMD allocation to the last register, tests/test_cpu_host.py)
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(30))) void compact_regions_multi_kernel(DescConst k, const mods_affkey *__restrict__ keys_all,
+__global__ __launch_bounds__(1024) void compact_regions_multi_kernel(DescConst k, const mods_affkey *__restrict__ keys_all,
                                                                      const int *__restrict__ key_count, const OriOut *__restrict__ ori_all,
                                                                      const OriOut *__restrict__ ori_multi_all, mods_region *__restrict__ reg_all,
                                                                      int *__restrict__ reg_count, int *__restrict__ inside_count) {

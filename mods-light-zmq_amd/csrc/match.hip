@@ -167,7 +167,10 @@ __device__ __forceinline__ void top3_insert(unsigned &m1, unsigned &m2, unsigned
 __device__ __forceinline__ void own_simd_256() { asm volatile("v_mov_b32 v255, 0" ::: "v255"); }
 __device__ __forceinline__ void own_simd_512() { asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255"); }
 
-constexpr int NN1_WAVES = 4, NN1_THREADS = 64 * NN1_WAVES;
+#ifndef NN1_NWAVES
+#define NN1_NWAVES 8    // measured: 4 waves of 512 registers (one per SIMD) 310 us, 8 waves of 256 (two per SIMD) 270 us at 60 156 x 47 177
+#endif
+constexpr int NN1_WAVES = NN1_NWAVES, NN1_THREADS = 64 * NN1_WAVES;
 // The four waves of a pass-1 workgroup - one per SIMD, each owning its SIMD - walk the same train tiles.  A tile (32 rows x 128 B)
 // and its 32 accumulator seeds go from global memory straight into LDS (global_load_lds: no staging registers, no ds_write),
 // NN1_PF tiles ahead of the MFMAs in a ring of NN1_PF + 1 images.
@@ -219,7 +222,7 @@ __device__ __forceinline__ void nn1_step(Nn1State &st, v16i (&accW)[MATCH_QB1], 
   constexpr int QB = MATCH_QB1;
   if (!GUARD || i - 1 + NN1_PF < n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * (NN1_PF - 2)) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  if (!GUARD || i + NN1_PF < n) nn1_dma_tile(tdesc, tc2n, tile + NN1_PF, s_ring + ((RING + NN1_PF) % NN1_NBUF) * NN1_IMG, w, lane);
+  if (w < 4 && (!GUARD || i + NN1_PF < n)) nn1_dma_tile(tdesc, tc2n, tile + NN1_PF, s_ring + ((RING + NN1_PF) % NN1_NBUF) * NN1_IMG, w, lane);
   const char *nxt = s_ring + ((RING + 1) % NN1_NBUF) * NN1_IMG;
   int m[QB];
 #pragma unroll
@@ -235,31 +238,33 @@ __device__ __forceinline__ void nn1_step(Nn1State &st, v16i (&accW)[MATCH_QB1], 
         if (b == 3) nn1_epi_slice<3>(accR[ks], m[ks], st.M1[ks], st.M2[ks], st.M3[ks], idc_prev);
       }
     }
-    // the four MFMAs that read a[ks] (and, in round 0, the seeds) have been issued: refill for the next tile
-    st.a[ks] = *(const v4i *)(nxt + st.aoff[ks]);
-    if (ks == 0) st.seed = acc_seed((const int *)(nxt + 4096 + st.soff), 0, 0);
   }
-  // the order above, pinned: per MFMA three VALU instructions of the epilogue; the LDS reads behind the rounds
-#define NN1_SGB_ROUND(NDS)                                                     \
-  _Pragma("unroll") for (int b = 0; b < QB; b++) {                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
-    if (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                \
-  }                                                                            \
-  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
-  NN1_SGB_ROUND(5) NN1_SGB_ROUND(1) NN1_SGB_ROUND(1) NN1_SGB_ROUND(1)
-#undef NN1_SGB_ROUND
+  // all MFMAs of the tile have been issued: refill the operand registers for the next one.  (Refills between the rounds would
+  // save nothing - the registers are not needed before the next step - and the compiler's wait for the LAST operand, which it
+  // writes as lgkmcnt(0), would then also wait for the reads issued just before it: ~100 exposed cycles per tile.)  Their latency
+  // runs under the tail of the matrix pipe, the barrier and the DMA issue of the next step.
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) st.a[ks] = *(const v4i *)(nxt + st.aoff[ks]);
+  st.seed = acc_seed((const int *)(nxt + 4096 + st.soff), 0, 0);
+  // the order above, pinned: per MFMA three VALU instructions of the epilogue, the LDS reads at the end
+#pragma unroll
+  for (int j = 0; j < 4 * QB; j++) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 }
 // Pass 1.  grid = qblocks * splits workgroups of 256 threads; best3: [split][n_qpad] (M1, M2, M3, 0), n_qpad = qblocks * 128 * QB
 // (plain 16-byte stores: every (split, query) has one owner).
 // Workgroup -> (query block, split): with a split count that is a multiple of 8, the workgroups that the dispatcher places on one
 // XCD (linear id mod 8) share that XCD's train splits (split mod 8 = XCD), so an XCD's L2 holds one eighth of the train list
 // instead of all of it; any other placement is only slower.
-__global__ __launch_bounds__(NN1_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_nn1_kernel(MatchConst k, int qblocks, int splits,
+__global__ __launch_bounds__(NN1_THREADS) __attribute__((amdgpu_waves_per_eu(NN1_WAVES / 4, NN1_WAVES / 4))) void match_nn1_kernel(MatchConst k, int qblocks, int splits,
                                                         const int8_t *__restrict__ qdesc, const int8_t *__restrict__ tdesc,
                                                         const int *__restrict__ tc2n, uint4 *__restrict__ best3) {
   constexpr int QB = MATCH_QB1;
   static_assert(QB == 4 && NN1_NBUF == 4, "nn1_step is laid out for four query blocks and a ring of four images");
-  own_simd_512();
+  if (NN1_WAVES == 4) own_simd_512(); else own_simd_256();
   const int lane = threadIdx.x & 63, g = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int qb, sp;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(NN1_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
   __shared__ __attribute__((aligned(16))) char s_ring[NN1_NBUF * NN1_IMG];
 #pragma unroll
   for (int d = 0; d < NN1_PF; d++)
-    if (d < n) nn1_dma_tile(tdesc, tc2n, t0 + d, s_ring + d * NN1_IMG, w, lane);
+    if (w < 4 && d < n) nn1_dma_tile(tdesc, tc2n, t0 + d, s_ring + d * NN1_IMG, w, lane);
   const int jbase = (qb * NN1_WAVES + w) * (32 * QB) + (lane & 31);
   Nn1State st;
 #pragma unroll

@@ -152,13 +152,14 @@ def test_hmatrix_filter_matches_the_reference_error_functions(pkg, err_type, err
     assert pkg.hmatrix_filter(u6[:0], H, par)[1] == 0
 
 
-def test_no_kernel_fills_its_register_allocation(pkg):
-    """Round 3 found that match_nn1_kernel, with all 128 VGPRs of its 4-waves-per-SIMD allocation in use, intermittently changed
-    fp64 results of kernels of OTHER contexts on the same GPU (DESIGN.md "The matcher and its neighbours"); every build that left
-    the top registers of the allocation untouched was clean.  The rule kept from it - no kernel, and certainly no matrix-core
-    kernel, uses the last registers of an allocation that fills the 512-entry file (64 x 8 waves, 128 x 4, 256 x 2) - is checked
-    here for EVERY kernel of the built libmodsgpu.so, from the code objects the library carries (tools/kernel_resources.py):
-    a later edit, a new kernel or a compiler update that reaches such a boundary fails on the CPU."""
+def test_matrix_core_kernels_own_their_simds(pkg):
+    """A wave that issues independent MFMA chains makes double-precision VALU results of OTHER waves on the same SIMD go wrong
+    (DESIGN.md "The matcher and its neighbours"; tools/ubench/mfma_aggr.hip next to tools/ubench/spin_victim.hip reproduces it
+    with nothing but MFMAs, and not at all when the MFMA waves allocate the whole register file of their SIMD).  So every kernel
+    of the built libmodsgpu.so that contains an MFMA instruction must leave no room for foreign waves: the waves of ONE workgroup
+    fill the 512-entry file of each SIMD (register allocation x waves of the workgroup per SIMD = 512).  Read from the code
+    objects the library carries (tools/kernel_resources.py): a new matrix-core kernel, an edit or a compiler update that breaks
+    the rule fails here, on the CPU."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
@@ -170,16 +171,10 @@ def test_no_kernel_fills_its_register_allocation(pkg):
     names = {k["name"] for k in ks}
     for needed in ("match_nn1_kernel", "match_fginn_kernel", "gauss_blur_fast_kernel", "sift_wave2_kernel", "ransac_score_kernel"):
         assert any(needed in n for n in names), (needed, len(names))
-    assert sum(1 for k in ks if k["mfma"]) >= 2                      # the two matcher passes are seen as matrix-core kernels
-    bad = []
-    for k in ks:
-        fills = k["alloc"] * k["waves"] == 512
-        # matrix-core kernels (the aggressor of round 3): the four top registers stay untouched, as in the build that was clean;
-        # every other kernel: not the last register (none was ever seen to disturb, this only keeps them off the exact boundary)
-        margin = 4 if k["mfma"] else 1
-        if fills and k["vgpr"] > k["alloc"] - margin:
-            bad.append((k["name"], k["vgpr"], k["alloc"], k["waves"], k["mfma"]))
-    assert not bad, bad
-    for k in ks:
-        if "match_nn1_kernel" in k["name"] or "match_fginn_kernel" in k["name"]:
-            assert k["scratch"] == 0, (k["name"], k["scratch"])
+    mfma = [k for k in ks if k["mfma"]]
+    assert sorted(n for k in mfma for n in ("match_nn1_kernel", "match_fginn_kernel") if n in k["name"]) == ["match_fginn_kernel", "match_nn1_kernel"]
+    for k in mfma:
+        waves_of_wg_per_simd = k["wg_size"] // 64 // 4
+        assert k["wg_size"] % 256 == 0 and waves_of_wg_per_simd >= 1, (k["name"], k["wg_size"])
+        assert k["alloc"] * waves_of_wg_per_simd == 512, (k["name"], k["vgpr"], k["alloc"], k["wg_size"])
+        assert k["scratch"] == 0, (k["name"], k["scratch"])

@@ -76,6 +76,26 @@ def test_match_ties_and_parity(gpu_ctx):
             _assert_tents_equal(got, want)
 
 
+def test_match_repeated_trains(gpu_ctx):
+    """Hundreds of identical train descriptors spread over many tiles: more than three half tiles of one train split tie at the
+    level of a query's runner-up, the case in which pass 1's three keys per split cannot name every candidate and the exact
+    finish rescans the query over all trains (match_fix_kernel's fallback).  Equal distances are ordered by the lower index."""
+    rng = np.random.default_rng(404)
+    nq, nt = 600, 6000
+    q, t = _rand_regions(nq, 31), _rand_regions(nt, 32)
+    base = q["desc"][0].copy()
+    rep = np.arange(7, nt, 9)                       # 666 copies of one descriptor, every ninth train
+    t["desc"][rep] = base
+    q["desc"][:40] = base                            # distance 0 to all of them
+    noisy = np.clip(base.astype(np.int16) + rng.integers(-2, 3, (60, 128)), 0, 255).astype(np.uint8)
+    q["desc"][40:100] = noisy                        # the same small distance to all of them
+    t["x"][rep] = t["x"][rep[0]]; t["y"][rep] = t["y"][rep[0]]          # ... at one place: consistent neighbours, deep walks
+    for ratio, nn in ((0.8, 50), (0.999, 50), (0.999, 1000)):
+        got, _ = gpu_ctx.match_fginn(q, t, ratio, 10.0, nn)
+        want = orc.match_fginn(q, t, ratio, 10.0, nn)
+        _assert_tents_equal(got, want)
+
+
 def test_match_large_lists(gpu_ctx, pkg):
     """Lists of the size of a view-synthesis bank (more than one query block per wave, many train splits)."""
     ctx = pkg.Context(0, 2048, 2048, 1)      # capacity 524288 regions

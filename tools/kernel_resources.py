@@ -6,9 +6,9 @@ the disassembly says which kernels issue MFMA instructions.
 
   python tools/kernel_resources.py [path/to/libmodsgpu.so]     prints one line per kernel
 
-Used by tests/test_cpu_host.py::test_no_mfma_kernel_fills_its_register_allocation (DESIGN.md "The matcher and its
-neighbours": a matrix-core kernel whose allocation x waves per SIMD is the whole 512-entry file disturbed other
-contexts' kernels in round 3)."""
+Used by tests/test_cpu_host.py::test_matrix_core_kernels_own_their_simds (DESIGN.md "The matcher and its neighbours":
+waves that issue independent MFMA chains disturb fp64 work of foreign waves on their SIMD, so the library's matrix-core
+kernels allocate whole SIMDs)."""
 import os
 import re
 import struct
@@ -70,7 +70,7 @@ def kernels(lib_path):
             vg, ag = int(get("vgpr_count")), int(get("agpr_count"))
             alloc, waves = waves_per_simd(vg)            # .vgpr_count is the unified count on gfx950 (AGPRs included)
             res.append(dict(name=name, vgpr=vg, agpr=ag, sgpr=int(get("sgpr_count")), lds=int(get("group_segment_fixed_size")),
-                            scratch=int(get("private_segment_fixed_size")), alloc=alloc, waves=waves, mfma=mfma.get(sym, mfma.get(name, 0))))
+                            scratch=int(get("private_segment_fixed_size")), wg_size=int(get("max_flat_workgroup_size")), alloc=alloc, waves=waves, mfma=mfma.get(sym, mfma.get(name, 0))))
     return res
 
 
@@ -90,5 +90,7 @@ if __name__ == "__main__":
     dn = demangle([k["name"] for k in ks])
     print("%-64s %5s %5s %6s %5s %7s %7s %5s" % ("kernel", "vgpr", "alloc", "waves", "sgpr", "lds", "scratch", "mfma"))
     for k, n in sorted(zip(ks, dn), key=lambda kn: kn[1]):
-        flag = "  <-- fills the register file" if k["alloc"] * k["waves"] == 512 and k["mfma"] else ""
+        flag = ""
+        if k["mfma"]:
+            flag = "  owns its SIMDs" if k["alloc"] * (k["wg_size"] // 256) == 512 else "  <-- MFMA kernel that shares its SIMDs"
         print("%-64s %5d %5d %6d %5d %7d %7d %5d%s" % (n.split("(")[0][-64:], k["vgpr"], k["alloc"], k["waves"], k["sgpr"], k["lds"], k["scratch"], k["mfma"], flag))
