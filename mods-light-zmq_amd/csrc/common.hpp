@@ -173,6 +173,7 @@ struct mods_ctx {
   void *mser = nullptr;              // MserState (mser.hip): buffers of the MSER detector, allocated on first use
   // the step loop spreads the views of a step over a few more contexts of the same GPU (imgrep.hip: run_view_jobs)
   std::vector<mods_ctx *> helpers;
+  std::atomic<bool> helpers_failed{false};   // a helper context could not be made (memory): reported once, not retried
   struct StageArena { mods_region *buf = nullptr; size_t cap = 0; };
   std::vector<StageArena> helper_stage;
   // timing

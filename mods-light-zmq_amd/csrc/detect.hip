@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void baumberg_hessian_kernel(const PyramidDev 
       cd.state = 3;
       const unsigned int absbits = __float_as_uint(fabsf(cd.response));
       const unsigned int order = ((unsigned int)cd.octave << 28) | ((unsigned int)cd.level << ORDER_POS_BITS) |
-                                 (unsigned int)(cd.r0 * iw + cd.c0);
+                                 (unsigned int)(cd.r0 * o.w + cd.c0);   // the octave's own width (iw may be the sampling image's: not unique there)
       const int sl2 = atomicAdd(&key_count[b], 1);
       sort_keys[(size_t)b * k.max_cand + sl2] = ((unsigned long long)(~absbits) << 32) | order;
       sort_idx[(size_t)b * k.max_cand + sl2] = ci;
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
         // sort key: |response| descending, then processing order (octave, level, r0, c0)
         const unsigned int absbits = __float_as_uint(fabsf(cd.response));
         const unsigned int order = ((unsigned int)cd.octave << 28) | ((unsigned int)cd.level << ORDER_POS_BITS) |
-                                   (unsigned int)(cd.r0 * iw + cd.c0);
+                                   (unsigned int)(cd.r0 * o.w + cd.c0);   // the octave's own width (iw may be the sampling image's: not unique there)
         const int sl2 = atomicAdd(&key_count[b], 1);
         sort_keys[(size_t)b * k.max_cand + sl2] = ((unsigned long long)(~absbits) << 32) | order;
         sort_idx[(size_t)b * k.max_cand + sl2] = ci;

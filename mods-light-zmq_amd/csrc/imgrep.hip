@@ -309,6 +309,9 @@ struct ViewJob {
 
 // MODS_LADDER_WORKERS contexts (default 4, 1 = the serial loop) on the GPU of `c`; worker 0 is `c` itself on the calling thread.
 // Every worker copies the regions of a finished view into its own staging arena, so the banks can be filled in job order.
+// Helper contexts cost device memory (each is a full max_w x max_h context with two image slots): one is made only while the
+// device has room for it several times over, a failed attempt is reported once on stderr and not repeated, and what the helpers'
+// stage timers measured is added to the caller's.
 static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
                          const mods_hessaff_params *dets, std::vector<ViewJob> &jobs) {
   static const int env_workers = getenv("MODS_LADDER_WORKERS") ? atoi(getenv("MODS_LADDER_WORKERS")) : 4;
@@ -341,6 +344,9 @@ static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, con
   // context takes to set up (a one-shot run with a handful of views is faster on the caller's context alone)
   if ((int)c->helpers.size() < n_workers - 1) c->helpers.resize(n_workers - 1, nullptr);
   if ((int)c->helper_stage.size() < n_workers) c->helper_stage.resize(n_workers);
+  // the banks were filled from the staging arenas by copies on c->stream (mods_imgrep_append_dev, asynchronous); the workers are
+  // about to overwrite the arenas on their own streams
+  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
   struct Placed { size_t off, off_half; };
   std::vector<Placed> placed(jobs.size());
   std::vector<int> owner(jobs.size(), 0);
@@ -348,12 +354,21 @@ static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, con
   auto work = [&](int k) {
     (void)hipSetDevice(c->device);
     if (k > 0 && !c->helpers[k - 1]) {
-      if ((int)units.size() - next.load() < 3 * (k + 1)) return;
+      if (c->helpers_failed || (int)units.size() - next.load() < 3 * (k + 1)) return;
+      // a context of this size takes roughly 100 bytes per pixel and image slot (pyramid pools, patch store, region lists):
+      // leave the device at least four such contexts of head room, other users of the GPU included
+      size_t free_b = 0, total_b = 0;
+      const size_t ctx_bytes = (size_t)c->max_w * c->max_h * 2 * 100;
       mods_ctx *h = nullptr;
-      if (mods_ctx_create_ex(c->device, c->max_w, c->max_h, 2, 1, &h)) return;      // the other workers take the units
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * ctx_bytes || mods_ctx_create_ex(c->device, c->max_w, c->max_h, 2, 1, &h)) {
+        if (!c->helpers_failed.exchange(true))
+          fprintf(stderr, "mods: view worker %d of the step loop not created (%.1f GB free on device %d): the remaining contexts take its views\n", k, free_b / 1e9, c->device);
+        return;                                                                        // the other workers take the units
+      }
       c->helpers[k - 1] = h;
     }
     mods_ctx *wk = k == 0 ? c : c->helpers[k - 1];
+    if (k > 0) wk->timing_mask = c->timing_mask;
     mods_ctx::StageArena &A = c->helper_stage[k];
     size_t used = 0;
     auto park = [&](int ji, int slot) {                         // regions of context slot `slot` -> this worker's arena
@@ -423,6 +438,15 @@ static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, con
   } catch (...) {}                       // fewer threads than asked for: the others (at least the caller) take the jobs
   work(0);
   for (auto &t : pool) t.join();
+  if (c->timing_mask)                                            // what the helpers' stage timers saw belongs to this call
+    for (mods_ctx *h : c->helpers) {
+      if (!h) continue;
+      for (int st = 0; st < MODS_STAGE_COUNT; st++) {
+        double ms = 0, by = 0; int n = 0;
+        if (mods_ctx_timing_read(h, st, &ms, &n, &by) == MODS_OK) { c->timers[st].total_ms += ms; c->timers[st].launches += n; c->timers[st].bytes += by; }
+      }
+      (void)mods_ctx_timing_reset(h);
+    }
   for (size_t i = 0; i < jobs.size(); i++) {
     ViewJob &j = jobs[i];
     if (j.rc) { set_error("%s", j.err.c_str()); return j.rc; }

@@ -278,7 +278,10 @@ struct MserOut { double response; int u, sub; };
 
 int mser_detect(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride, const mods_hessaff_params *par, double tilt,
                 double zoom) {
-  if (n_img <= 0 || n_img > c->batch) { set_error("bad image batch x%d (ctx batch %d)", n_img, c->batch); return MODS_E_ARG; }
+  if (w <= 0 || h <= 0 || n_img <= 0 || n_img > c->batch) { set_error("bad image batch %dx%d x%d (ctx batch %d)", w, h, n_img, c->batch); return MODS_E_ARG; }
+  // the context's per-image scratch planes (tmp_dev takes the packed copy of a strided input below, the describe stage reads a plane
+  // of this size) hold max_w * max_h pixels: the same check as pyramid_configure, which this detector does not go through
+  if ((size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("image %dx%d larger than the context (%dx%d)", w, h, c->max_w, c->max_h); return MODS_E_ARG; }
   if (par->mserMinSize < 1 || !(par->mserMaxArea > 0) || !(par->mserMinMargin >= 1)) {
     set_error("MSER: min_size >= 1, max_area > 0 and min_margin >= 1 are required (got %d, %g, %g)", par->mserMinSize, par->mserMaxArea, par->mserMinMargin);
     return MODS_E_ARG;

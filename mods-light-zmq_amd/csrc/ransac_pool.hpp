@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -66,6 +67,9 @@ class TaskPool {
     }
     while (in_work_.load(std::memory_order_acquire) > 0) cpu_relax();
     busy_.unlock();
+    // a task that threw (bad_alloc in a fit, say) was caught where it ran - on a detached worker an escaping exception would end
+    // the process, on the caller it would leave busy_ locked - and is rethrown here, after the pool is back in its idle state
+    if (failed_.exchange(false, std::memory_order_acq_rel)) { std::exception_ptr e = error_; error_ = nullptr; std::rethrow_exception(e); }
   }
 
  private:
@@ -85,7 +89,11 @@ class TaskPool {
     for (;;) {
       const int i = next_.fetch_add(1, std::memory_order_acq_rel);
       if (i >= n_) break;
-      (*fn_)(i);
+      try { (*fn_)(i); }
+      catch (...) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!failed_.load(std::memory_order_relaxed)) { error_ = std::current_exception(); failed_.store(true, std::memory_order_release); }
+      }
       done_.fetch_add(1, std::memory_order_acq_rel);
     }
   }
@@ -120,6 +128,8 @@ class TaskPool {
   std::condition_variable cv_;
   std::atomic<unsigned> gen_{0};
   std::atomic<int> next_{0}, done_{0}, in_work_{0};
+  std::atomic<bool> failed_{false};
+  std::exception_ptr error_;
   const std::function<void(int)> *fn_ = nullptr;
   int n_ = 0;
 };
