@@ -36,14 +36,16 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def pmc_blur_traffic():
-    """HBM bytes per launch of the dominant blur instantiation from the committed PMC passes (profiles/r02_pmc_blur_traffic.csv:
+    """HBM bytes per launch of the dominant blur instantiation from the newest committed PMC passes (profiles/rNN_pmc_blur_traffic.csv:
     FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc runs, 16 images per launch)."""
-    try:
-        for line in open(os.path.join(ROOT, "profiles", "r02_pmc_blur_traffic.csv")):
-            if line.startswith("# launches of gauss_blur_fast_kernel<R; 32; 2> only:"):
-                return int(line.split(":")[1].split()[0])
-    except OSError:
-        pass
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_blur_traffic.csv")), reverse=True):
+        try:
+            for line in open(path):
+                if line.startswith("# launches of gauss_blur_fast_kernel<R; 32; 2> only:"):
+                    return int(line.split(":")[1].split()[0])
+        except OSError:
+            pass
     return None
 
 
@@ -398,12 +400,17 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if pipe is not None:
+        pipe.cpu_seconds(reset=True)
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     results = run(args.steps * pps)
     torch.cuda.synchronize()
+    cpu_s = time.process_time() - cpu0          # every thread of this rank: submit loop, GPU workers, verify workers, RANSAC task pool
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    worker_cpu = pipe.cpu_seconds() if pipe is not None else (0.0, 0.0)
     timed = pipe if pipe is not None else ctx
     blur_ms, blur_n, blur_bytes = timed.timing_read("blur")
     small_ms, small_n, small_bytes = timed.timing_read("blur_small")
@@ -426,12 +433,22 @@ def main():
         for _ in range(2):
             bctx.detect_describe_dev(batch_t.data_ptr(), 2 * nb, W, H, params.det, params.desc)
         pyr_stages = ["blur", "blur_small", "response", "resize", "nms", "pyramid"]
+        bctx.pyramid_streams(1)           # per-launch scopes: every launch alone on the GPU
         bctx.timing_enable(pyr_stages); bctx.timing_reset()
         for _ in range(6):
             bctx.detect_describe_dev(batch_t.data_ptr(), 2 * nb, W, H, params.det, params.desc)
         i_ms, i_n, i_bytes = bctx.timing_read("blur")
         is_ms, is_n, is_bytes = bctx.timing_read("blur_small")
         pyr_ms = {st: bctx.timing_read(st)[0] / 6.0 for st in pyr_stages}
+        # the whole scale space as ONE scope, in a pass of its own: with the per-stage scopes on, every launch is bracketed by two
+        # more event records and the octaves' side stream is timed apart
+        pyr_ms["pyramid_with_stage_scopes"] = pyr_ms["pyramid"]
+        for n_streams, key in ((1, "pyramid_one_stream"), (2, "pyramid")):
+            bctx.pyramid_streams(n_streams)
+            bctx.timing_enable(["pyramid"]); bctx.timing_reset()
+            for _ in range(6):
+                bctx.detect_describe_dev(batch_t.data_ptr(), 2 * nb, W, H, params.det, params.desc)
+            pyr_ms[key] = bctx.timing_read("pyramid")[0] / 6.0
         bctx.timing_enable([])
         iso = (i_ms, i_n, i_bytes, is_ms, is_n, is_bytes)
         del reps
@@ -481,6 +498,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "host": host, "pairs_per_s_by_rank": rank_rates,
+            # what a pair costs the HOST (rank 0, timed steps): CPU seconds of the whole process per pair (every thread), and of the
+            # pipeline's own worker threads inside their stages; process_cpu_s_per_pair x pairs/s = busy cores per rank
+            "host_cpu": {"process_cpu_ms_per_pair": round(cpu_s / n_pairs * 1e3, 3), "gpu_workers_cpu_ms_per_pair": round(worker_cpu[0] / n_pairs * 1e3, 3),
+                         "verify_workers_cpu_ms_per_pair": round(worker_cpu[1] / n_pairs * 1e3, 3), "busy_cores": round(cpu_s / dt, 2)},
             "config": {"workload": "single 1920x1080 pair, HessianAffine+RootSIFT, 1 synth iteration (BASELINE configs[1])"
                                    + (" - VARIANT: second motion over %.0f %% of image 2 (--inlier-ratio)" % (100 * (1 - args.inlier_ratio)) if args.inlier_ratio > 0 else ""),
                        "pairs_per_step": pps, "image": "1920x1080",
@@ -501,6 +522,10 @@ def main():
             # planes use the 16-row instantiation and are launch-size bound: "all_blur_launches" is the figure over both
             "roofline": {"kernel": "gauss_blur_fast_kernel<R,32,2,true> (blur + Hessian response)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # `achieved` / `frac`: the launches of the TIMED steps, where the GPU workers' contexts share the GPU (a launch
+                         # then gets a fraction of the bandwidth: a contention figure); *_isolated: the same launches on one stream with
+                         # nothing else on the GPU (the kernel's own figure; details under "isolated")
+                         "achieved_isolated": round(gbs(i_bytes, i_ms), 2), "frac_isolated": round(gbs(i_bytes, i_ms) / HBM_PEAK_GBS, 4),
                          # `achieved` prices a launch by SURVEY 8d's UNFUSED model (blur 8 B/px + response 8 B/px = 16 B/px), as 8d asks;
                          # the fused kernel's own algorithmic bytes are 12 B/px (reads 4, writes 8): that figure is achieved_fused_model
                          "bytes_model": "SURVEY 8d unfused: 16 B/px per level",
@@ -525,8 +550,9 @@ def main():
         if iso is not None:
             # the scale space as a whole by SURVEY 8d's model (97 B/px over all octaves + 8 B/px initial blur = 284.77 MB per
             # 1080p image): the same isolated leg, HIP-event scopes per stage on one stream.  "kernels" adds up the launches'
-            # own scopes (blur of the large and of the small planes, response, decimation, NMS + compaction); "one_scope" is a
-            # single scope from the first blur launch to the end of the compaction, i.e. with the gaps between ~45 launches
+            # own scopes (blur of the large and of the small planes, response, decimation, NMS + compaction; the octaves from the third
+            # on run on a side stream, so these scopes overlap in time); "one_scope" is a single scope from the first blur launch to
+            # the end of the compaction, measured in a pass without the per-stage scopes
             n_images = 2 * nb
             sum_p = 0
             cw, ch = W, H
@@ -535,7 +561,7 @@ def main():
                 cw, ch = int(round(cw * 0.5)), int(round(ch * 0.5))     # Python rounds half to even, as cvRound does
             pyr_bytes = n_images * (97.0 * sum_p + 8.0 * W * H)
             k_ms = sum(pyr_ms[st] for st in ("blur", "blur_small", "response", "resize", "nms"))
-            out["roofline_pyramid"] = {"what": "scale space of a %d-image batch on one stream: every blur / response / decimation launch of every octave + NMS + "
+            out["roofline_pyramid"] = {"what": "scale space of a %d-image batch of one context: every blur / response / decimation launch of every octave + NMS + "
                                                "compaction (isolated leg)" % n_images,
                                        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "bytes_model": "SURVEY 8d: 97 B/px over all octaves + 8 B/px initial blur",
                                        "algorithmic_bytes": pyr_bytes, "stage_ms": {st: round(v, 4) for st, v in pyr_ms.items()},
@@ -543,7 +569,8 @@ def main():
                                        "large_planes_only": {"what": "blur (32-row tiles) + response + decimation + NMS: the four scopes round 2 was judged on",
                                                              "ms": round(k_ms - pyr_ms["blur_small"], 4),
                                                              "frac": round(gbs(pyr_bytes, k_ms - pyr_ms["blur_small"]) / HBM_PEAK_GBS, 4)},
-                                       "one_scope": {"ms": round(pyr_ms["pyramid"], 4), "achieved": round(gbs(pyr_bytes, pyr_ms["pyramid"]), 2),
+                                       "one_scope_one_stream": {"ms": round(pyr_ms["pyramid_one_stream"], 4), "frac": round(gbs(pyr_bytes, pyr_ms["pyramid_one_stream"]) / HBM_PEAK_GBS, 4)},
+                                       "one_scope": {"what": "as shipped: the octaves from the third on (and their NMS) on a side stream", "ms": round(pyr_ms["pyramid"], 4), "achieved": round(gbs(pyr_bytes, pyr_ms["pyramid"]), 2),
                                                      "frac": round(gbs(pyr_bytes, pyr_ms["pyramid"]) / HBM_PEAK_GBS, 4)}}
         if match_leg:
             nq, nt, mms, ntent = match_leg

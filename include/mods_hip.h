@@ -135,6 +135,10 @@ enum { MODS_STAGE_BLUR = 0, MODS_STAGE_RESPONSE, MODS_STAGE_RESIZE, MODS_STAGE_N
                                  * inside it, so the per-stage sums above overlap and add up to more than this) */
        MODS_STAGE_COUNT };
 int mods_ctx_timing_enable(mods_ctx *ctx, int stage_mask);
+/* Streams the Hessian scale space of a large batch is built on: 2 (default) = the octaves from the third on, and their non-maximum
+   suppression, run on a side stream next to the large octaves' last level and NMS; 1 = everything on the context's stream (what
+   per-launch timing wants).  The planes and the candidates are the same either way. */
+int mods_ctx_pyramid_streams(mods_ctx *ctx, int n);
 /* sums since the last reset; resolves pending events (synchronises the stream) */
 int mods_ctx_timing_read(mods_ctx *ctx, int stage, double *total_ms, int *launches, double *bytes);
 int mods_ctx_timing_reset(mods_ctx *ctx);
@@ -584,6 +588,9 @@ int mods_pipeline_capacity(const mods_pipeline *p);    /* pairs that may be in f
 /* HIP-event timing of the workers' contexts (sums over them); enable/read while nothing is in flight */
 int mods_pipeline_timing_enable(mods_pipeline *p, int stage_mask);
 int mods_pipeline_timing_read(mods_pipeline *p, int stage, double *total_ms, int *launches, double *bytes);
+/* CPU seconds the GPU workers' / the verify workers' own threads have spent inside their stages since the last reset (thread clocks;
+   the RANSAC task pool's helper threads are not in them).  What a pair costs the host: needed to size ranks per node. */
+int mods_pipeline_cpu_seconds(mods_pipeline *p, double *gpu_workers_s, double *verify_workers_s, int reset);
 int mods_pipeline_submit(mods_pipeline *p, const float *img_dev, long tag);
 /* the pair in HOST memory, [2][h][w] fp32 or 8-bit grey (what cv::imread hands to the ImageRepresentation constructor,
  * mods.cpp:111-121, 184-185): uploaded on the worker's stream (asynchronously when the memory is pinned, see

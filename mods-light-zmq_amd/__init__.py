@@ -175,6 +175,9 @@ class Context:
         _check(lib().mods_ctx_timing_read(self.h, STAGES.index(stage), C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
 
+    def pyramid_streams(self, n):
+        _check(lib().mods_ctx_pyramid_streams(self.h, int(n)))
+
     def timing_reset(self):
         _check(lib().mods_ctx_timing_reset(self.h))
 
@@ -880,6 +883,12 @@ class Pipeline:
         ms, n, by = C.c_double(), C.c_int(), C.c_double()
         _check(lib().mods_pipeline_timing_read(self.h, STAGES.index(stage), C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
+
+    def cpu_seconds(self, reset=False):
+        """(GPU workers, verify workers): CPU seconds their threads spent inside their stages since the last reset"""
+        g, v = C.c_double(), C.c_double()
+        _check(lib().mods_pipeline_cpu_seconds(self.h, C.byref(g), C.byref(v), 1 if reset else 0))
+        return g.value, v.value
 
     def close(self):
         if self.h:

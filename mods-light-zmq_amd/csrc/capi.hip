@@ -128,6 +128,9 @@ void mods_ctx_destroy(mods_ctx *c) {
   for (mods_ctx *h : c->helpers) if (h) mods_ctx_destroy(h);
   for (auto &a : c->helper_stage) (void)hipFree(a.buf);
   (void)hipSetDevice(c->device);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -136,6 +139,11 @@ int mods_ctx_sync(mods_ctx *c) { MODS_HIP_CHECK(hipStreamSynchronize(c->stream))
 void *mods_ctx_stream(mods_ctx *c) { return (void *)c->stream; }
 
 int mods_ctx_timing_enable(mods_ctx *c, int stage_mask) { c->timing_mask = stage_mask; return MODS_OK; }
+int mods_ctx_pyramid_streams(mods_ctx *c, int n) {
+  if (!c || n < 1 || n > 2) { set_error("pyramid streams: 1 or 2"); return MODS_E_ARG; }
+  c->pyr_streams = n;
+  return MODS_OK;
+}
 
 static int resolve_timers(mods_ctx *c) {
   MODS_HIP_CHECK(hipStreamSynchronize(c->stream));

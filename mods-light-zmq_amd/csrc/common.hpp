@@ -84,6 +84,13 @@ struct mods_ctx {
   int max_w = 0, max_h = 0, batch = 1;
   hipStream_t stream = nullptr;
   hipEvent_t pyr_scope_begin = nullptr;   // MODS_STAGE_PYRAMID: opened by pyramid_build, closed by detect_run after the compaction
+  // the octaves from the third on are built on a side stream next to the large octaves' last level and their NMS (pyramid_build
+  // forks, detect_run joins before the compaction)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool pyr_side = false;
+  int pyr_side_first = 0;                 // the first octave built on the side stream
+  int pyr_streams = 2;                    // mods_ctx_pyramid_streams: 1 keeps the whole scale space on ctx->stream
   // scale space
   mods::PyramidDev pyr;              // host copy of the descriptor table
   mods::PyramidDev *pyr_dev = nullptr;

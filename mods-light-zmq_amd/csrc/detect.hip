@@ -998,9 +998,11 @@ int detect_run(mods_ctx *ctx) {
   for (int oi = 0; oi < P.n_oct; oi++)
     if ((size_t)P.oct[oi].w * P.oct[oi].h >= (1u << ORDER_POS_BITS)) { set_error("octave too large for the order key"); return MODS_E_ARG; }
 
-  MODS_HIP_CHECK(hipMemsetAsync(ctx->cand_count, 0, sizeof(int) * 3 * ctx->batch, ctx->stream));   // cand/acc/key counts
+  // (with a forked pyramid these fills go to the side stream: off the longer chain, and joined before their first reader)
+  hipStream_t fill_stream = ctx->pyr_side ? ctx->stream2 : ctx->stream;
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->cand_count, 0, sizeof(int) * 3 * ctx->batch, fill_stream));   // cand/acc/key counts
   if (ctx->omap_dirty) {     // first use of the pool, or a call that did not reach omap_reset_kernel: fill it once
-    MODS_HIP_CHECK(hipMemsetAsync(ctx->omap_pool, 0xFF, ctx->omap_pool_elems * sizeof(unsigned int), ctx->stream));
+    MODS_HIP_CHECK(hipMemsetAsync(ctx->omap_pool, 0xFF, ctx->omap_pool_elems * sizeof(unsigned int), fill_stream));
   }
   ctx->omap_dirty = true;    // until this call has put the cells it claims back
   int *acc_count = ctx->cand_count + ctx->batch;
@@ -1045,8 +1047,33 @@ int detect_run(mods_ctx *ctx) {
       }
       narrow_pl.n = 0;
     }
-    if (wide_pl.n) hipLaunchKernelGGL(nms4_kernel, dim3(wide_pl.blk_begin[wide_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, wide_pl, k, mask);
-    if (narrow_pl.n) hipLaunchKernelGGL(nms_kernel, dim3(narrow_pl.blk_begin[narrow_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, narrow_pl, k, mask);
+    if (ctx->pyr_side) {
+      // the large octaves' planes are on this stream, the others' on the side stream (pyramid_build): each part's NMS follows its
+      // planes, the compaction waits for both
+      auto split = [&](const NmsPlan &pl, NmsPlan &first, NmsPlan &rest) {
+        first.n = rest.n = 0; first.blk_begin[0] = rest.blk_begin[0] = 0;
+        for (int e = 0; e < pl.n; e++) {
+          NmsPlan &d = pl.oi[e] < ctx->pyr_side_first ? first : rest;
+          const int i = d.n;
+          d.oi[i] = pl.oi[e]; d.nbx[i] = pl.nbx[e]; d.w[i] = pl.w[e]; d.h[i] = pl.h[e]; d.words[i] = pl.words[e]; d.wide[i] = pl.wide[e];
+          d.mask_off[i] = pl.mask_off[e];
+          d.blk_begin[i + 1] = d.blk_begin[i] + (pl.blk_begin[e + 1] - pl.blk_begin[e]);
+          d.n++;
+        }
+      };
+      NmsPlan w0, w1, n0, n1;
+      split(wide_pl, w0, w1); split(narrow_pl, n0, n1);
+      if (w0.n) hipLaunchKernelGGL(nms4_kernel, dim3(w0.blk_begin[w0.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, w0, k, mask);
+      if (n0.n) hipLaunchKernelGGL(nms_kernel, dim3(n0.blk_begin[n0.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, n0, k, mask);
+      if (w1.n) hipLaunchKernelGGL(nms4_kernel, dim3(w1.blk_begin[w1.n], 1, n_img), dim3(256), 0, ctx->stream2, ctx->pyr_dev, w1, k, mask);
+      if (n1.n) hipLaunchKernelGGL(nms_kernel, dim3(n1.blk_begin[n1.n], 1, n_img), dim3(256), 0, ctx->stream2, ctx->pyr_dev, n1, k, mask);
+      MODS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->stream2));
+      MODS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+      ctx->pyr_side = false;
+    } else {
+      if (wide_pl.n) hipLaunchKernelGGL(nms4_kernel, dim3(wide_pl.blk_begin[wide_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, wide_pl, k, mask);
+      if (narrow_pl.n) hipLaunchKernelGGL(nms_kernel, dim3(narrow_pl.blk_begin[narrow_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, narrow_pl, k, mask);
+    }
     if (comp_pl.n) hipLaunchKernelGGL(nms_compact_kernel, dim3(comp_pl.blk_begin[comp_pl.n], n_img), dim3(256), 0, ctx->stream, comp_pl, k, mask, ctx->cand,
                                       ctx->cand_count);
     MODS_HIP_CHECK(hipGetLastError());

@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <time.h>
 
 extern "C" int mods_ctx_create_ex(int device, int max_w, int max_h, int batch, int flags, mods_ctx **out);
 extern "C" int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
@@ -49,7 +50,11 @@ struct mods_pipeline {
   int ready = 0, warm_rc = MODS_OK;   // workers that finished their warm-up (mods_pipeline_create_ex waits for all of them)
   std::string warm_err;
   std::condition_variable cv_ready;
+  // CPU time the workers' own threads spent inside their stages (CLOCK_THREAD_CPUTIME_ID; the RANSAC task pool's helper threads,
+  // which the verify stage of a hard pair spreads its model fits over, are not in it: the process clock is)
+  std::atomic<long long> cpu_gpu_ns{0}, cpu_verify_ns{0};
 };
+static long long thread_cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; }
 
 using namespace mods;
 
@@ -86,7 +91,9 @@ static void gpu_worker(mods_pipeline *p, mods_ctx *ctx) {
     std::vector<std::vector<mods_tentative> *> tent(n);
     std::vector<std::vector<double> *> u6(n), laf(n);
     for (int i = 0; i < n; i++) { imgs[i] = js[i]->img; kinds[i] = js[i]->kind; res[i] = &js[i]->res; tent[i] = &js[i]->tent; u6[i] = &js[i]->u6; laf[i] = &js[i]->laf; }
+    const long long c0 = thread_cpu_ns();
     const int rc = mods_pairs_gpu_stage(ctx, imgs.data(), kinds.data(), n, p->w, p->h, &p->par, res.data(), tent.data(), u6.data(), laf.data());
+    p->cpu_gpu_ns.fetch_add(thread_cpu_ns() - c0, std::memory_order_relaxed);
     const std::string err = rc ? mods_last_error() : "";
     {
       std::lock_guard<std::mutex> lk(p->mu);
@@ -108,7 +115,9 @@ static void verify_worker(mods_pipeline *p) {
       j = p->q_verify.front(); p->q_verify.pop_front();
     }
     if (j->rc == MODS_OK) {
+      const long long c0 = thread_cpu_ns();
       j->rc = mods_pair_verify_stage(p->device, &p->par, &j->res, &j->tent, &j->u6, &j->laf, nullptr, 0);
+      p->cpu_verify_ns.fetch_add(thread_cpu_ns() - c0, std::memory_order_relaxed);
       if (j->rc) j->err = mods_last_error();
     }
     {
@@ -149,6 +158,15 @@ int mods_pipeline_timing_read(mods_pipeline *p, int stage, double *total_ms, int
   if (total_ms) *total_ms = ms;
   if (launches) *launches = n;
   if (bytes) *bytes = by;
+  return MODS_OK;
+}
+
+// CPU seconds the GPU workers / the verify workers have spent inside their stages since the last reset (reset != 0 clears them)
+int mods_pipeline_cpu_seconds(mods_pipeline *p, double *gpu_workers_s, double *verify_workers_s, int reset) {
+  if (!p) return MODS_E_ARG;
+  if (gpu_workers_s) *gpu_workers_s = p->cpu_gpu_ns.load() * 1e-9;
+  if (verify_workers_s) *verify_workers_s = p->cpu_verify_ns.load() * 1e-9;
+  if (reset) { p->cpu_gpu_ns.store(0); p->cpu_verify_ns.store(0); }
   return MODS_OK;
 }
 

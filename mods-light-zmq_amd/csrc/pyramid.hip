@@ -1151,10 +1151,16 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
   } else {
     MODS_HIP_CHECK(hipMemcpyAsync(P.oct[0].blur[0], src0, sizeof(float) * (size_t)w * h * n_img, hipMemcpyDeviceToDevice, ctx->stream));
   }
-  // (Tried in round 3: the octaves below ~3 Mpixel per batch - chains of ~30 launches of 6-10 us each, 0.2 ms per 16-image batch
-  // for 8 % of the pixels - on a second stream next to the last level and the NMS of the large octaves: the small launches
-  // slow down under the large ones (0.196 -> 0.332 ms) and the join waits for them: 1.436 vs 1.416 ms for the whole
-  // scale space.  One stream.)
+  // Octave k + 1 needs only level S of octave k.  With a batch of large planes the octaves from the third on (6 % of the pixels, but
+  // a serial chain of ~12 short launches and the one-workgroup-per-image LDS kernel: 0.25 ms of the 1.2 ms a 16-image 1080p batch
+  // takes) go to a side stream as soon as octaves 0 and 1 have produced their level S - those two octaves' levels up to S are issued
+  // first - next to the remaining levels of octaves 0 and 1 and their NMS (the bulk of both); detect_run launches the small
+  // octaves' NMS on the side stream too and joins before the compaction.  (Round 3 tried a fork with every octave's NMS after the
+  // join: the side chain then only had one blur launch to hide under, 1.436 against 1.416 ms; with octave 1 - all of it, or its
+  // last level and its NMS - on the side stream as well the side chain is the longer one: 1.05-1.06 against 0.99-1.01 ms.)  MODS_PYR_FORK=0 keeps one stream.
+  static const bool fork_on = !(getenv("MODS_PYR_FORK") && atoi(getenv("MODS_PYR_FORK")) == 0);
+  const bool fork = fork_on && ctx->pyr_streams >= 2 && P.n_oct >= 2 && S < P.n_levels - 1 && (size_t)w * h * n_img >= ((size_t)4 << 20);
+  ctx->pyr_side = false;
   // the octaves from `first_lds` on fit LDS and are built by pyramid_lds_kernel in one launch
   int first_lds = P.n_oct;
   static const bool no_lds = getenv("MODS_NO_LDS_PYRAMID") != nullptr;
@@ -1168,11 +1174,12 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
         first_lds = oi;
       }
   }
-  for (int oi = 0; oi < first_lds; oi++) {
+  hipStream_t main_stream = ctx->stream;
+  struct StreamRestore { mods_ctx *c; hipStream_t s; ~StreamRestore() { c->stream = s; } } restore{ctx, main_stream};
+  // levels [l0, l1) of octave oi on ctx->stream (+ the decimation into the next octave behind level S)
+  auto build_levels = [&](int oi, int l0, int l1) -> int {
     OctaveDev &o = P.oct[oi];
-    if (oi == 0 && !initial_blur)      // (the first level of a later octave gets its response from the decimation launch)
-      if ((rc = launch_hessian_response(ctx, o.blur[0], o.resp[0], o.w, o.h, n_img, o.sigma[0] * o.sigma[0]))) return rc;
-    for (int l = 1; l < P.n_levels; l++) {
+    for (int l = l0; l < l1; l++) {
       const float sigma = o.sigma[l - 1] * sigmaStep;   // pyramid.cpp:455-458
       if ((rc = blur_with_slot(ctx, o.blur[l - 1], o.blur[l], o.w, o.h, n_img, l, ntap[l], o.resp[l], sigma * sigma))) return rc;
       if (l == S && oi + 1 < P.n_oct) {
@@ -1180,7 +1187,31 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
         if ((rc = launch_resize_half_resp(ctx, o.blur[l], nx.blur[0], nx.resp[0], o.w, o.h, nx.w, nx.h, n_img, nx.sigma[0] * nx.sigma[0]))) return rc;
       }
     }
+    return MODS_OK;
+  };
+  if (!initial_blur && first_lds > 0)      // (the first level of a later octave gets its response from the decimation launch)
+    if ((rc = launch_hessian_response(ctx, P.oct[0].blur[0], P.oct[0].resp[0], P.oct[0].w, P.oct[0].h, n_img, P.oct[0].sigma[0] * P.oct[0].sigma[0]))) return rc;
+  // octaves [0, n_main) stay on this stream; with the fork their levels up to S (what the next octave needs) come first
+  const int n_main = fork ? std::min(2, first_lds) : first_lds;
+  ctx->pyr_side_first = n_main;
+  for (int oi = 0; oi < n_main; oi++)
+    if ((rc = build_levels(oi, 1, fork ? S + 1 : P.n_levels))) return rc;
+  if (fork && n_main < P.n_oct) {                                     // everything the later octaves need exists behind this event
+    if (!ctx->stream2) {
+      MODS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      MODS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      MODS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    MODS_HIP_CHECK(hipEventRecord(ctx->ev_fork, main_stream));
+    MODS_HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    ctx->pyr_side = true;
   }
+  if (fork)
+    for (int oi = 0; oi < n_main; oi++)
+      if ((rc = build_levels(oi, S + 1, P.n_levels))) return rc;
+  if (ctx->pyr_side) ctx->stream = ctx->stream2;                      // the launch helpers issue on ctx->stream
+  for (int oi = n_main; oi < first_lds; oi++)
+    if ((rc = build_levels(oi, 1, P.n_levels))) return rc;
   if (first_lds < P.n_oct) {
     LdsPyramidPlan pl;
     pl.first = first_lds; pl.n_oct = P.n_oct; pl.n_levels = P.n_levels; pl.S = S;

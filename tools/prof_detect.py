@@ -11,7 +11,7 @@ W, H, B = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 2
 imgs = np.stack([synth.texture(W, H, seed=100 + i) for i in range(B)])
 t = torch.from_numpy(imgs).cuda()
 ctx = pkg.Context(0, W, H, B)
-stages = ["blur", "blur_small", "response", "resize", "nms", "pyramid", "localize", "baumberg", "sort"]
+stages = os.environ.get("STAGES", "blur,blur_small,response,resize,nms,pyramid,localize,baumberg,sort").split(",")
 for it in range(3):
     ctx.detect_hessian_affine_dev(t.data_ptr(), B, W, H, fetch=False)
 ctx.sync()
