@@ -325,3 +325,95 @@ def test_ladder_with_ground_truth_verification(pkg, both):
     assert res.n_inliers == want["n_inliers"] == len(m) and np.array_equal(m, want["matches"])
     assert np.array_equal(np.array(res.H), Hgt.reshape(9))
     rep1.close(); rep2.close(); ctx.close()
+
+
+_LADDER_1080P = {}
+
+
+def _ladder_1080p_oracle():
+    """Both HessianAffine steps of iters_MODS.ini (11 + 20 views per image) on the benchmark's hard 1920x1080 pair through the CPU
+    oracle chain, kept for the session (about a minute of host time)."""
+    import pipeline_oracle as po
+    if "want" not in _LADDER_1080P:
+        a, b, Htrue = _hard_pair(1920, 1080, seed=3000)          # bench.py --config c3
+        steps_spec = [((1, 2, 4, 6, 8), 360.0), ((1, 2, 4, 6, 8), 120.0)]
+        # min_matches above anything reachable: the loop does not stop after the first step, every view of both steps is made
+        _LADDER_1080P.update(a=a, b=b, H=Htrue, steps=steps_spec, want=po.match_ladder(a, b, steps_spec, seed_time=31, min_matches=10 ** 6))
+    return _LADDER_1080P
+
+
+def test_ladder_1080p_concurrent_views_vs_oracle(pkg):
+    """BASELINE configs[2] at its own size: the step loop spreads the 62 views of the two HessianAffine steps over four contexts of
+    the GPU, the two images of a view through one chain of launches (run_view_jobs, csrc/imgrep.hip) - every region of both banks,
+    the tentatives, the RANSAC statistics and the inlier list must be the CPU oracle chain's.  Then the same ladder again and
+    again against its first result while two more contexts run the pair chain next to it (the workers' staging arenas, the side
+    streams of the scale space and the matcher's exclusive workgroups are all concurrency the parity tests at small sizes do not
+    reach)."""
+    import threading
+    import torch
+    import refdeg
+    if not refdeg.available():
+        pytest.skip("oracle/_ref not built")
+    L = _ladder_1080p_oracle()
+    a, b, want = L["a"], L["b"], L["want"]
+    w, h = 1920, 1080
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(0, d[0], d[1], 2)          # two image slots: paired views
+    rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
+    t = torch.from_numpy(np.stack([a, b])).cuda()
+    torch.cuda.synchronize()
+    steps = [pkg.LadderStep.make(tl, ph) for tl, ph in L["steps"]]
+
+    def run():
+        pkg.ransac_pin_seed(31)
+        return pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2, min_matches=10 ** 6, max_matches=200000)
+
+    res, m = run()
+    assert res.steps_done == want["steps_done"] == 2 and res.n_views == want["n_views"] == 62
+    assert list(res.n_described) == want["n_described"] == [len(rep1), len(rep2)]
+    first = (rep1.fetch(), rep2.fetch())
+    for got, exp in zip(first, want["regions"]):
+        for f in ("x", "y", "s", "a11", "a12", "a21", "a22"):
+            assert np.array_equal(got[f], exp[f]), f
+        assert np.array_equal(got["desc"], exp["desc"])
+    assert res.n_tentatives == want["n_tentatives"] and res.n_unique == want["n_unique"]
+    assert [res.ransac_samples, res.ransac_lo, res.ransac_rejects] == want["stats"]
+    assert res.n_inliers == want["n_inliers"] >= 15
+    assert np.array_equal(m, want["u6"][want["mask"]][:, [0, 1, 3, 4]])
+
+    # repeated under load
+    stop = threading.Event()
+    errors = []
+    pa, pb, _ = synth.pair(w, h, seed=2000)
+    tp = torch.from_numpy(np.stack([pa, pb]).astype(np.float32)).cuda()
+    torch.cuda.synchronize()
+
+    def neighbour():
+        try:
+            c2 = pkg.Context(0, w, h, 2)
+            while not stop.is_set():
+                pkg.match_pair_dev(c2, tp.data_ptr(), w, h, max_matches=1 << 16)
+            c2.close()
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+
+    ths = [threading.Thread(target=neighbour) for _ in range(2)]
+    for th in ths:
+        th.start()
+    differing = []
+    try:
+        for it in range(40):
+            r2, m2 = run()
+            regs = (rep1.fetch(), rep2.fetch())
+            same = (r2.n_tentatives, r2.n_unique, r2.n_inliers) == (res.n_tentatives, res.n_unique, res.n_inliers) and np.array_equal(m2, m)
+            for g0, g1 in zip(first, regs):
+                same = same and len(g0) == len(g1) and all(np.array_equal(g0[f], g1[f]) for f in g0.dtype.names if f != "pad")
+            if not same:
+                differing.append(it)
+    finally:
+        stop.set()
+        for th in ths:
+            th.join()
+    assert not errors, errors
+    assert not differing, differing
+    rep1.close(); rep2.close(); ctx.close()
