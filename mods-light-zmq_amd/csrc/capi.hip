@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <time.h>
+#include <sys/prctl.h>
 
 namespace mods {
 
@@ -16,6 +18,32 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+hipError_t stream_wait(hipStream_t s) {
+  const long ns = tl_wait_sleep_ns;
+  if (ns <= 0) return hipStreamSynchronize(s);
+  hipError_t e = hipStreamQuery(s);
+  if (e != hipErrorNotReady) return e;
+  for (int i = 0; i < tl_wait_spin_polls; i++)
+    if ((e = hipStreamQuery(s)) != hipErrorNotReady) break;
+  const timespec ts = {0, ns};
+  while (e == hipErrorNotReady) { nanosleep(&ts, nullptr); e = hipStreamQuery(s); }
+  // a "not ready" answer may have been left as the thread's last error: it is not one
+  const hipError_t last = hipGetLastError();
+  if (e == hipSuccess && last != hipSuccess && last != hipErrorNotReady) return last;
+  return e;
+}
+
+void wait_mode_for_worker(long default_sleep_ns) {
+  long ns = default_sleep_ns;
+  if (const char *m = getenv("MODS_SYNC")) {
+    if (!strncmp(m, "spin", 4)) ns = 0;
+    else if (!strncmp(m, "sleep", 5)) { if (m[5] == ':') ns = std::max(1l, atol(m + 6)) * 1000; }
+    else fprintf(stderr, "mods: MODS_SYNC=%s not understood (spin | sleep[:microseconds]); keeping the default\n", m);
+  }
+  tl_wait_sleep_ns = ns;
+  if (ns > 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);   // default slack 50 us: a 30 us sleep would take 80
 }
 
 StageScope::StageScope(mods_ctx *c, int s, double bytes) : ctx(c), stage(s) {
@@ -111,7 +139,7 @@ static int ctx_create_impl(int device, int max_w, int max_h, int batch, unsigned
 void mods_ctx_destroy(mods_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)mods::stream_wait(c->stream);
   for (auto &t : c->timers) {
     for (auto &p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &e : t.pool) (void)hipEventDestroy(e);
@@ -135,7 +163,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   delete c;
 }
 
-int mods_ctx_sync(mods_ctx *c) { MODS_HIP_CHECK(hipStreamSynchronize(c->stream)); return MODS_OK; }
+int mods_ctx_sync(mods_ctx *c) { MODS_HIP_CHECK(mods::stream_wait(c->stream)); return MODS_OK; }
 void *mods_ctx_stream(mods_ctx *c) { return (void *)c->stream; }
 
 int mods_ctx_timing_enable(mods_ctx *c, int stage_mask) { c->timing_mask = stage_mask; return MODS_OK; }
@@ -146,7 +174,7 @@ int mods_ctx_pyramid_streams(mods_ctx *c, int n) {
 }
 
 static int resolve_timers(mods_ctx *c) {
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   for (auto &t : c->timers) {
     for (auto &p : t.pending) {
       float ms = 0;
@@ -187,7 +215,7 @@ static int detect_common(mods_ctx *c, const float *img_dev, int n_img, int w, in
   int rc;
   if ((rc = detect_any(c, img_dev, n_img, w, h, stride, par, 1.0, 1.0))) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(c->host_counts, c->cand_count, sizeof(int) * 3 * c->batch, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   for (int b = 0; b < n_img; b++) {
     if (c->host_counts[b] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", c->host_counts[b], c->max_cand); return MODS_E_CAPACITY; }
     const int n = c->host_counts[2 * c->batch + b];
@@ -225,13 +253,13 @@ int mods_pyramid_plane(mods_ctx *c, int img, int o, int level, int kind, float *
   if (o < 0 || o >= c->pyr.n_oct || level < 0 || level >= c->pyr.n_levels || img < 0 || img >= c->last_n_img) return MODS_E_ARG;
   const OctaveDev &oc = c->pyr.oct[o];
   const float *p = (kind ? oc.resp[level] : oc.blur[level]) + (size_t)oc.w * oc.h * img;
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   MODS_HIP_CHECK(hipMemcpy(dst, p, sizeof(float) * (size_t)oc.w * oc.h, hipMemcpyDeviceToHost));
   return MODS_OK;
 }
 // accepted (post-dedup) localisation records of image `img`, in list (arbitrary) order
 int mods_pyramid_candidates(mods_ctx *c, int img, mods_candidate *out, int max_out, int *n_out) {
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   int count = 0;
   MODS_HIP_CHECK(hipMemcpy(&count, c->cand_count + img, sizeof(int), hipMemcpyDeviceToHost));
   int n = std::min(count, c->max_cand);
@@ -256,7 +284,7 @@ int mods_pyramid_candidates(mods_ctx *c, int img, mods_candidate *out, int max_o
 static int check_desc_err(mods_ctx *c) {
   int e = 0;
   MODS_HIP_CHECK(hipMemcpyAsync(&e, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   if (e) {
     MODS_HIP_CHECK(hipMemsetAsync(c->desc_err_dev, 0, sizeof(int), c->stream));
     set_error("measurement region larger than the descriptor scratch (P2 > 3*max(w,h) or > 4096 blur taps)");
@@ -283,7 +311,7 @@ int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w
   MODS_HIP_CHECK(hipMemcpyAsync(hc + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(hc + 4 * c->batch, c->inside_count, sizeof(int) * n_img, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(hc + 5 * c->batch, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   for (int b = 0; b < n_img; b++) {
     if (hc[b] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", hc[b], c->max_cand); return MODS_E_CAPACITY; }
     if (n_detected_host) n_detected_host[b] = hc[2 * c->batch + b];
@@ -326,7 +354,7 @@ int mods_patches_fetch(mods_ctx *c, int img, int ps, float *out, int max_regions
   if (!c || !out || !n_out || img < 0 || img >= c->batch || !c->desc_scratch) { set_error("patches_fetch: nothing described"); return MODS_E_ARG; }
   const int reg_cap = std::min(c->max_cand, 1 << 17);
   MODS_HIP_CHECK(hipSetDevice(c->device));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   int n = 0;
   MODS_HIP_CHECK(hipMemcpy(&n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
   if (n > reg_cap) n = reg_cap;
@@ -346,7 +374,7 @@ int mods_unoriented_count(mods_ctx *c, int img) {
 int mods_regions_fetch(mods_ctx *c, int img, mods_region *out, int max_out, int *n_out) {
   if (!c || img < 0 || img >= c->batch || !n_out) return MODS_E_ARG;
   MODS_HIP_CHECK(hipSetDevice(c->device));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   int n = 0;
   MODS_HIP_CHECK(hipMemcpy(&n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
   *n_out = n;
@@ -361,7 +389,7 @@ int mods_regions_fetch_half(mods_ctx *c, int img, mods_region *out, int max_out,
   if (!c || img < 0 || img >= c->batch || !n_out) return MODS_E_ARG;
   if (!c->have_half || !c->regions_half_dev) { set_error("no HalfRootSIFT descriptors: the last describe call did not ask for them"); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   int n = 0;
   MODS_HIP_CHECK(hipMemcpy(&n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
   *n_out = n;
@@ -385,7 +413,7 @@ int mods_orient_describe(mods_ctx *c, const float *img, int w, int h, int stride
                                   hipMemcpyHostToDevice, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(c->keys_dev, keys, sizeof(mods_affkey) * n_keys, hipMemcpyHostToDevice, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(c->cand_count + 2 * c->batch, &n_keys, sizeof(int), hipMemcpyHostToDevice, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));   // n_keys is a stack variable
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));   // n_keys is a stack variable
   int rc = describe_run(c, c->input_dev, 1, w, h, par);
   if (rc) return rc;
   if ((rc = mods_regions_fetch(c, 0, out, max_out, n_out))) return rc;
@@ -401,7 +429,7 @@ int mods_dominant_angle(mods_ctx *c, const float *patch, int ps, double th, floa
   if ((rc = launch_dominant_angle_test(c, c->input_dev, ps, th, c->tmp_dev))) return rc;
   float res[2];
   MODS_HIP_CHECK(hipMemcpyAsync(res, c->tmp_dev, sizeof(res), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   *found = res[0] != 0.f;
   *angle = res[1];
   return MODS_OK;
@@ -415,7 +443,7 @@ int mods_sift_patch(mods_ctx *c, const float *patch, int ps, int rootsift, doubl
   MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev, patch, sizeof(float) * ps * ps, hipMemcpyHostToDevice, c->stream));
   if ((rc = launch_sift_patch_test(c, c->input_dev, ps, rootsift, maxBinValue, (uint8_t *)c->tmp_dev))) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(out128, c->tmp_dev, 128, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 
@@ -427,7 +455,7 @@ int mods_match_copy_out(mods_ctx *c, int n, mods_tentative *tent, double *u6, do
   static thread_local std::vector<char> stage;
   stage.resize(tent_bytes((size_t)n));
   MODS_HIP_CHECK(hipMemcpyAsync(stage.data(), c->m_tent, stage.size(), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   if (tent) memcpy(tent, stage.data(), sizeof(mods_tentative) * n);
   if (u6) memcpy(u6, stage.data() + tent_u6_off((size_t)n), sizeof(double) * 6 * n);
   if (laf) memcpy(laf, stage.data() + tent_laf_off((size_t)n), sizeof(double) * 14 * n);
@@ -435,7 +463,7 @@ int mods_match_copy_out(mods_ctx *c, int n, mods_tentative *tent, double *u6, do
 }
 
 int mods_match_fetch_internal(mods_ctx *c, mods_tentative *out, double *u6_out, double *laf_out, int max_out, int *n_out) {
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   const int n = *(volatile int *)c->m_count;
   *n_out = n;
   if (n > max_out) { set_error("tentative output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
@@ -747,7 +775,7 @@ int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int str
   res->ms_detect_describe = t1 - t0;
   if ((rc = match_run(c, c->regions_dev, res->n_described[0], c->regions_dev + c->max_cand, res->n_described[1],
                       par->fginn_ratio, par->contradDist, par->nn))) return rc;
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   const int n = *(volatile int *)c->m_count;
   res->n_tentatives = n;
   if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
@@ -793,7 +821,7 @@ int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_pair_params
   if (rc) return rc;
   const int last = n_img - 1;
   if ((rc = match_run(c, c->regions_dev, nr[0], c->regions_dev + (size_t)last * c->max_cand, nr[last], par->fginn_ratio, par->contradDist, par->nn))) return rc;
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 
@@ -860,7 +888,7 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
     c->m_tent_out = nullptr; c->m_count_out = nullptr;
     if (rc) return rc;
   }
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   std::vector<size_t> off(n_pairs, (size_t)-1);
   size_t used = 0;
   for (int i = 0; i < n_pairs; i++) {
@@ -882,7 +910,7 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
       }
     }
   }
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   const double tm1 = now_ms();
   for (int i = 0; i < n_pairs; i++) {
     res[i]->ms_match = (tm1 - tm0) / n_pairs;
@@ -1029,7 +1057,7 @@ int mods_gauss_blur(mods_ctx *c, const float *src, int w, int h, float sigma, fl
   int rc = launch_gauss_blur(c, c->input_dev, c->tmp_dev, w, h, 1, sigma);
   if (rc) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(dst, c->tmp_dev, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 
@@ -1040,7 +1068,7 @@ int mods_hessian_response(mods_ctx *c, const float *src, int w, int h, float nor
   int rc = launch_hessian_response(c, c->input_dev, c->tmp_dev, w, h, 1, norm);
   if (rc) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(dst, c->tmp_dev, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 
@@ -1052,7 +1080,7 @@ int mods_resize_half(mods_ctx *c, const float *src, int w, int h, float *dst, in
   int rc = launch_resize_half(c, c->input_dev, c->tmp_dev, w, h, *dw, *dh, 1);
   if (rc) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(dst, c->tmp_dev, sizeof(float) * (size_t)(*dw) * (*dh), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 

@@ -33,6 +33,16 @@ inline hipError_t dyn_lds_once(DynLdsOnce &site, const void *fn, int bytes, int 
   return e;
 }
 
+// How the calling thread waits for a stream.  The runtime's hipStreamSynchronize spins on the completion signal: a pipeline
+// worker that waits 40 ms for its batch of pairs then burns a whole core, and eight ranks of a node need the cores for the
+// verification.  A thread that sets tl_wait_sleep_ns > 0 (the pipeline's workers do) polls hipStreamQuery instead: a short
+// run of back-to-back queries for work that is about to finish, then a nanosleep between queries.  No interrupt path of the
+// runtime is involved (hipDeviceScheduleBlockingSync hung on the test boxes).  Everything else keeps the runtime's wait.
+inline thread_local long tl_wait_sleep_ns = 0;
+inline thread_local int tl_wait_spin_polls = 8;
+hipError_t stream_wait(hipStream_t s);
+void wait_mode_for_worker(long default_sleep_ns);   // MODS_SYNC=spin|sleep[:us] decides for the pipeline's threads
+
 constexpr int kMaxOctaves = 16;
 constexpr int kMaxLevels = 8;        // numberOfScales + 2 <= 8
 constexpr int kMaxBlurRadius = 16;   // fused separable blur: ksize <= 33

@@ -470,7 +470,7 @@ int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
     circular_gauss_mask_host(par->desc_patchSize, 0.f, m2.data());                         // synth-detection.hpp:181, siftdesc.h:83
     SiftTab tab;
     build_sift_tab(par->desc_patchSize, &tab);
-    MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
     MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev, m1.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
     MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + 4096, m2.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
     MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + 8192, &tab, sizeof(SiftTab), hipMemcpyHostToDevice));
@@ -492,7 +492,7 @@ static int external_describe(mods_ctx *ctx, int n_img, const DescConst &k) {
   const int pp = k.desc_ps * k.desc_ps;
   std::vector<int> counts(n_img);
   MODS_HIP_CHECK(hipMemcpyAsync(counts.data(), ctx->region_count, sizeof(int) * n_img, hipMemcpyDeviceToHost, ctx->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
   std::vector<float> patches, out;
   std::vector<uint8_t> desc;
   for (int b = 0; b < n_img; b++) {
@@ -531,11 +531,11 @@ static int net_patches(mods_ctx *ctx, const float *img_dev, int n_img, DescConst
                                     hipMemcpyHostToDevice, ctx->stream));
   }
   MODS_HIP_CHECK(hipMemcpyAsync(ctx->region_count, counts.data(), sizeof(int) * n_img, hipMemcpyHostToDevice, ctx->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // (the host vectors above are pageable)
+  MODS_HIP_CHECK(mods::stream_wait(ctx->stream));   // (the host vectors above are pageable)
   k.desc_mr = mr; k.desc_ps = ps; k.patch_rule = 1; k.photo = 0;
   int rc = launch_extract_and_sift(ctx, img_dev, n_img, k, dmask, tab, false);
   if (rc) return rc;
-  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
   patches->assign(n_img, std::vector<float>());
   const size_t pp = (size_t)ps * ps;
   for (int b = 0; b < n_img; b++) {
@@ -549,7 +549,7 @@ static int net_patches(mods_ctx *ctx, const float *img_dev, int n_img, DescConst
 static int fetch_keys(mods_ctx *ctx, int n_img, const int *key_count, std::vector<std::vector<mods_affkey>> *keys) {
   std::vector<int> counts(n_img);
   MODS_HIP_CHECK(hipMemcpyAsync(counts.data(), key_count, sizeof(int) * n_img, hipMemcpyDeviceToHost, ctx->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
   keys->assign(n_img, std::vector<mods_affkey>());
   for (int b = 0; b < n_img; b++) {
     const int n = std::min(counts[b], ctx->max_cand);

@@ -121,7 +121,7 @@ int mods_imgrep_create(mods_ctx *c, int capacity, mods_imgrep **out) {
 void mods_imgrep_destroy(mods_imgrep *r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
-  (void)hipStreamSynchronize(r->stream);
+  (void)mods::stream_wait(r->stream);
   (void)hipFree(r->reg);
   delete r;
 }
@@ -165,7 +165,7 @@ int mods_imgrep_append_host(mods_imgrep *r, const mods_region *src, int n) {
   if (n == 0) return MODS_OK;
   MODS_HIP_CHECK(hipSetDevice(r->device));
   MODS_HIP_CHECK(hipMemcpyAsync(r->reg + r->n, src, sizeof(mods_region) * (size_t)n, hipMemcpyHostToDevice, r->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(r->stream));
+  MODS_HIP_CHECK(mods::stream_wait(r->stream));
   if (r->n > 0) hipLaunchKernelGGL(shift_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, r->stream, r->reg + r->n, n, r->n);
   MODS_HIP_CHECK(hipGetLastError());
   r->n += n;
@@ -176,7 +176,7 @@ int mods_imgrep_fetch(mods_imgrep *r, int begin, int count, mods_region *out) {
   if (count == 0) return MODS_OK;
   MODS_HIP_CHECK(hipSetDevice(r->device));
   MODS_HIP_CHECK(hipMemcpyAsync(out, r->reg + begin, sizeof(mods_region) * (size_t)count, hipMemcpyDeviceToHost, r->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(r->stream));
+  MODS_HIP_CHECK(mods::stream_wait(r->stream));
   return MODS_OK;
 }
 
@@ -235,7 +235,7 @@ static int match_into(mods_ctx *c, mods_imgrep *q, mods_imgrep *t, double ratio,
   if (distance > 0) rc = match_run_distance(c, q->reg, q->n, t->reg, t->n, distance);
   else rc = match_run(c, q->reg, q->n, t->reg, t->n, ratio, par->contradDist, par->nn);
   if (rc) return rc;
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   m = *(volatile int *)c->m_count;
   if (m > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
   out->t.resize(m); out->u6.resize((size_t)m * 6); out->laf.resize((size_t)m * 14);
@@ -346,7 +346,7 @@ static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, con
   if ((int)c->helper_stage.size() < n_workers) c->helper_stage.resize(n_workers);
   // the banks were filled from the staging arenas by copies on c->stream (mods_imgrep_append_dev, asynchronous); the workers are
   // about to overwrite the arenas on their own streams
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   struct Placed { size_t off, off_half; };
   std::vector<Placed> placed(jobs.size());
   std::vector<int> owner(jobs.size(), 0);
@@ -378,7 +378,7 @@ static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, con
         const size_t cap = std::max<size_t>(need + need / 2, 1 << 14);
         mods_region *nb = nullptr;
         if (hipMalloc(&nb, cap * sizeof(mods_region)) != hipSuccess) { j.rc = MODS_E_HIP; set_error("view staging: out of device memory"); return; }
-        (void)hipStreamSynchronize(wk->stream);                 // copies into the old arena may still be in flight
+        (void)mods::stream_wait(wk->stream);                 // copies into the old arena may still be in flight
         if (used) (void)hipMemcpy(nb, A.buf, used * sizeof(mods_region), hipMemcpyDeviceToDevice);
         (void)hipFree(A.buf);
         A.buf = nb; A.cap = cap;
@@ -430,7 +430,7 @@ static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, con
         owner[ji] = k;
       }
     }
-    (void)hipStreamSynchronize(wk->stream);
+    (void)mods::stream_wait(wk->stream);
   };
   std::vector<std::thread> pool;
   try {

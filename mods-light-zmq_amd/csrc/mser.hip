@@ -325,7 +325,7 @@ int mser_detect(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int 
   hipLaunchKernelGGL(mser_u8_kernel, dim3((unsigned)((npx + 255) / 256), n_img), dim3(256), 0, c->stream, img_dev, w, h, stride, S.img8);
   MODS_HIP_CHECK(hipGetLastError());
   MODS_HIP_CHECK(hipMemcpyAsync(S.h_img8, S.img8, npx * n_img, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
 
   // 2. growth of every (image, polarity) on host threads
   mser::GrowParams gp;
@@ -424,7 +424,7 @@ int mser_detect(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int 
   }
   const int n_keys = (int)out_u.size();
   MODS_HIP_CHECK(hipMemcpyAsync(key_count, n_out.data(), sizeof(int) * n_img, hipMemcpyHostToDevice, c->stream));
-  if (n_keys == 0 || n_u == 0) { MODS_HIP_CHECK(hipStreamSynchronize(c->stream)); return MODS_OK; }
+  if (n_keys == 0 || n_u == 0) { MODS_HIP_CHECK(mods::stream_wait(c->stream)); return MODS_OK; }
 
   // packed int table: ss_slot | ss_begin | u_slot | u_thresh | u_area | u_parent | job_ss_off | job_u_off | out_*[5]
   const size_t o_ss_slot = 0, o_ss_begin = o_ss_slot + n_ss, o_u_slot = o_ss_begin + n_ss + 1, o_u_thresh = o_u_slot + n_u,
@@ -462,7 +462,7 @@ int mser_detect(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int 
                      (unsigned long long *)nullptr, (size_t)0);
   MODS_HIP_CHECK(hipGetLastError());
   MODS_HIP_CHECK(hipMemcpyAsync(S.h_counters, S.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   const size_t n_runs = (size_t)S.h_counters[0];
   if (S.h_counters[1] != S.h_counters[0] || n_runs == 0 || n_runs >= (1ull << 32)) {
     set_error("MSER: %llu run starts, %llu run ends", S.h_counters[0], S.h_counters[1]);
@@ -500,7 +500,7 @@ int mser_detect(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int 
                      ot + 3 * (size_t)n_keys, ot + 4 * (size_t)n_keys, T.u_slot, T.u_thresh, w, S.ell, c->max_cand, c->keys_dev);
   MODS_HIP_CHECK(hipGetLastError());
   MODS_HIP_CHECK(hipMemcpyAsync(S.h_counters, S.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   if (S.h_counters[2]) { set_error("MSER: %llu regions whose runs disagree with the growth's area", S.h_counters[2]); return MODS_E_HIP; }
   return MODS_OK;
 }

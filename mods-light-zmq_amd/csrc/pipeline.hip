@@ -72,6 +72,7 @@ static void worker_ready(mods_pipeline *p, int rc) {
 
 static void gpu_worker(mods_pipeline *p, mods_ctx *ctx) {
   (void)hipSetDevice(p->device);
+  wait_mode_for_worker(50000);    // a batch takes tens of milliseconds: 50 us between looks
   // every pool a full batch needs (pyramid planes, candidate / region / matcher buffers, code objects) is allocated now: a
   // hipMalloc inside the running pipeline synchronises the whole device
   worker_ready(p, mods_ctx_warmup(ctx, 2 * p->pairs_per_batch, p->w, p->h, &p->par));
@@ -105,6 +106,7 @@ static void gpu_worker(mods_pipeline *p, mods_ctx *ctx) {
 
 static void verify_worker(mods_pipeline *p) {
   (void)hipSetDevice(p->device);
+  wait_mode_for_worker(20000);    // scoring launches are short but queue behind the other workers' kernels
   worker_ready(p, mods_ransac_warmup(p->device, 16384));   // this thread's scoring stream and workspace
   for (;;) {
     std::shared_ptr<Job> j;

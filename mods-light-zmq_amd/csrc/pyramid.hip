@@ -837,7 +837,7 @@ static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
   gauss_kernel_host(n, (double)sigma, taps);
   for (int i = 0; i < n; i++) ctx->taps_host[slot][i] = taps[i];
   ctx->taps_host_n[slot] = n;
-  MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // earlier launches may still read the slot
+  MODS_HIP_CHECK(mods::stream_wait(ctx->stream));   // earlier launches may still read the slot
   MODS_HIP_CHECK(hipMemcpy(ctx->gauss_taps_dev + slot * 64, taps, sizeof(float) * n, hipMemcpyHostToDevice));
   ctx->taps_sigma[slot] = sigma;
   return MODS_OK;
@@ -1066,7 +1066,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
       if (n > kAltTapStride - 1) { set_error("response blur too wide: sigma=%g ksize=%d", (double)sigma, n); return MODS_E_ARG; }
       std::vector<float> taps(n);
       gauss_kernel_host(n, (double)sigma, taps.data());
-      MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
       MODS_HIP_CHECK(hipMemcpy(ctx->alt_taps_dev + (size_t)l * kAltTapStride, taps.data(), sizeof(float) * n, hipMemcpyHostToDevice));
       ctx->alt_ntap[l] = n; ctx->alt_sigma[l] = sigma;
     }

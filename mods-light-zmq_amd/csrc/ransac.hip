@@ -215,14 +215,14 @@ static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, d
   hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
   RS_CHECK(hipGetLastError());
   RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * ws->hyp_cap + sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
-  RS_CHECK(hipStreamSynchronize(ws->stream));
+  RS_CHECK(mods::stream_wait(ws->stream));
   ws->launches += 2;
   return true;
 }
 
 bool ransac_fetch_row(RansacGpu *ws, int len, int k, double *dst) {
   RS_CHECK(hipMemcpyAsync(ws->row_host, ws->d_dev + (size_t)k * len, sizeof(double) * len, hipMemcpyDeviceToHost, ws->stream));
-  RS_CHECK(hipStreamSynchronize(ws->stream));
+  RS_CHECK(mods::stream_wait(ws->stream));
   memcpy(dst, ws->row_host, sizeof(double) * len);
   return true;
 }
@@ -289,7 +289,7 @@ int mods_ransac_warmup(int device, int len) {
   if (!ws) return MODS_E_NODEVICE;
   if (!ransac_ws_reserve(ws, len > 0 ? len : 1, 64)) return MODS_E_HIP;
   hipLaunchKernelGGL(ransac_gain_kernel, dim3(1), dim3(256), 0, ws->stream, ws->gain_dev, 0, 0, ws->hyp_cap, ws->J_dev);   // loads the code object
-  if (hipStreamSynchronize(ws->stream) != hipSuccess) { set_error("ransac warm-up failed"); return MODS_E_HIP; }
+  if (mods::stream_wait(ws->stream) != hipSuccess) { set_error("ransac warm-up failed"); return MODS_E_HIP; }
   return MODS_OK;
 }
 
@@ -549,7 +549,7 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
   const double t_up0 = rsprof_on() ? rs_now_us() : 0;
   if (!ransac_ws_reserve(ws, len, 64)) ransac_fail();
   if (hipMemcpyAsync(ws->u_dev, u, sizeof(double) * 6 * len, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
-      hipStreamSynchronize(ws->stream) != hipSuccess) { set_error("upload of the correspondences failed"); ransac_fail(); }
+      mods::stream_wait(ws->stream) != hipSuccess) { set_error("upload of the correspondences failed"); ransac_fail(); }
   if (rsprof_on()) g_rsprof.us[6] += rs_now_us() - t_up0;
 
   // sym check of a host-side model (LO results); the per-sample check comes from the GPU counts

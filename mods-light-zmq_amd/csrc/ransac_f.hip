@@ -101,7 +101,7 @@ static bool gpu_score_f(RansacGpu *ws, int len, int n, int err_type, int do_sym,
   hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
   RS_CHECK(hipGetLastError());
   RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * ws->hyp_cap + sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
-  RS_CHECK(hipStreamSynchronize(ws->stream));
+  RS_CHECK(mods::stream_wait(ws->stream));
   ws->launches += 2;
   return true;
 }
@@ -155,7 +155,7 @@ struct GpuEval : rs::PointEval {
     hipLaunchKernelGGL(ransac_eval_kernel, dim3((len + 255) / 256), dim3(256), 0, ws->stream, ws->u_dev, len, M, kind, d_dev, w_dev);
     const size_t n = (size_t)len * (w ? 2 : 1);
     if (hipMemcpyAsync(host, d_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ws->stream) != hipSuccess ||
-        hipStreamSynchronize(ws->stream) != hipSuccess) { set_error("error-function evaluation failed"); ransac_fail(); }
+        mods::stream_wait(ws->stream) != hipSuccess) { set_error("error-function evaluation failed"); ransac_fail(); }
     memcpy(d, host, sizeof(double) * len);
     if (w) memcpy(w, host + len, sizeof(double) * len);
     ws->launches++;
@@ -207,7 +207,7 @@ static bool gpu_upload_aux(RansacGpu *ws, const double *uN, unsigned n) {
     RS_CHECK(hipMalloc(&ws->aux_dev, ws->aux_cap * sizeof(double)));
   }
   RS_CHECK(hipMemcpyAsync(ws->aux_dev, uN, sizeof(double) * 6 * n, hipMemcpyHostToDevice, ws->stream));
-  RS_CHECK(hipStreamSynchronize(ws->stream));
+  RS_CHECK(mods::stream_wait(ws->stream));
   return true;
 }
 // counts k candidates (host array Fs, k x 9) over the n off-plane correspondences in aux_dev
@@ -226,7 +226,7 @@ static bool gpu_count_pairs(RansacGpu *ws, unsigned n, const double *Fs, int k, 
   hipLaunchKernelGGL(ransacf_count_kernel, dim3((n + 255) / 256, k), dim3(256), 0, ws->stream, ws->aux_dev, (int)n, ws->cand_dev, limit, ws->candc_dev);
   RS_CHECK(hipGetLastError());
   RS_CHECK(hipMemcpyAsync(ws->candc_host, ws->candc_dev, sizeof(int) * k, hipMemcpyDeviceToHost, ws->stream));
-  RS_CHECK(hipStreamSynchronize(ws->stream));
+  RS_CHECK(mods::stream_wait(ws->stream));
   for (int i = 0; i < k; i++) counts[i] = (unsigned)ws->candc_host[i];
   ws->launches += 1;
   return true;
@@ -493,7 +493,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
 
   if (!ransac_ws_reserve(ws, len, 96)) F_FATAL();
   if (hipMemcpyAsync(ws->u_dev, u, sizeof(double) * 6 * len, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
-      hipStreamSynchronize(ws->stream) != hipSuccess) { set_error("upload of the correspondences failed"); F_FATAL(); }
+      mods::stream_wait(ws->stream) != hipSuccess) { set_error("upload of the correspondences failed"); F_FATAL(); }
   // O(len) evaluations of one model (LO steps, degenerate branch): on the GPU for long lists, where a launch +
   // a row copy (~30 us) beats the host loop; the library's own error functions only
   rs::PointEval host_eval(u, len);

@@ -1837,7 +1837,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   const unsigned long long pool_elems = std::max<unsigned long long>(256ull << 20, (unsigned long long)n_img * area_units * (64ull << 20));
   const size_t need = patch_elems + book_elems + pool_elems;
   if (need > ctx->desc_scratch_elems) {
-    MODS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
     if (ctx->desc_scratch) MODS_HIP_CHECK(hipFree(ctx->desc_scratch));
     ctx->desc_scratch = nullptr;
     MODS_HIP_CHECK(hipMalloc(&ctx->desc_scratch, need * sizeof(float)));

@@ -246,7 +246,7 @@ int mods_warp_affine(mods_ctx *c, const float *src, int w, int h, const double *
   int rc = launch_warp_affine(c, c->input_dev, w, h, w, M, c->tmp_dev, dw, dh, dw, cval);
   if (rc) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(dst, c->tmp_dev, sizeof(float) * (size_t)dw * dh, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 
@@ -259,7 +259,7 @@ int mods_gauss_blur_xy(mods_ctx *c, const float *src, int w, int h, int kx, int 
   int rc = launch_blur_xy_reflect(c, c->input_dev, c->tmp_dev, c->view_dev, w, h, kx, ky, sx, sy);
   if (rc) return rc;
   MODS_HIP_CHECK(hipMemcpyAsync(dst, c->view_dev, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 
@@ -296,7 +296,7 @@ static int view_detect_describe(mods_ctx *c, const float *const *src_dev, int n_
   MODS_HIP_CHECK(hipMemcpyAsync(hc + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(hc + 4 * c->batch, c->inside_count, sizeof(int) * n_src, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(hc + 5 * c->batch, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   c->last_region_counts.assign(n_src, 0);
   c->last_inside_counts.assign(n_src, 0);
   for (int i = 0; i < n_src; i++) {
@@ -339,7 +339,7 @@ int mods_view_fetch(mods_ctx *c, const mods_view_geom *g, float *dst_host) {
   if (!c || !g || !dst_host || !c->view_dev) { set_error("view_fetch: no view"); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   MODS_HIP_CHECK(hipMemcpyAsync(dst_host, c->view_dev, sizeof(float) * (size_t)g->w_new * g->h_new, hipMemcpyDeviceToHost, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 
@@ -347,7 +347,7 @@ int mods_regions_copy_dev(mods_ctx *c, int img, mods_region *dst_dev, int n) {
   if (!c || !dst_dev || img < 0 || img >= c->batch || n < 0 || n > c->max_cand) { set_error("regions_copy_dev: bad arguments"); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   MODS_HIP_CHECK(hipMemcpyAsync(dst_dev, c->regions_dev + (size_t)img * c->max_cand, sizeof(mods_region) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 
@@ -357,7 +357,7 @@ int mods_regions_half_copy_dev(mods_ctx *c, int img, mods_region *dst_dev, int n
   if (!c->have_half || !c->regions_half_dev) { set_error("regions_half_copy_dev: no HalfRootSIFT descriptors in the context"); return MODS_E_ARG; }
   MODS_HIP_CHECK(hipSetDevice(c->device));
   MODS_HIP_CHECK(hipMemcpyAsync(dst_dev, c->regions_half_dev + (size_t)img * c->max_cand, sizeof(mods_region) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-  MODS_HIP_CHECK(hipStreamSynchronize(c->stream));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }
 
