@@ -98,6 +98,24 @@ def cpu_baseline(img1, img2, seed):
             "one_core": {"value": round(1.0 / t_one, 5), "cores": 1}}
 
 
+def thread_cpu_ns():
+    """CPU nanoseconds of every thread of this process, keyed name/tid (/proc/self/task/*/schedstat)."""
+    out = {}
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open("/proc/self/task/%s/comm" % tid) as f:
+                    name = f.read().strip()
+                with open("/proc/self/task/%s/schedstat" % tid) as f:
+                    ns = int(f.read().split()[0])
+            except (OSError, ValueError, IndexError):
+                continue
+            out[name + "/" + tid] = ns
+    except OSError:
+        pass
+    return out
+
+
 def host_share(torch, device, local_rank, local_world):
     """Cores of this rank: usable cores (affinity, cgroup quota) / ranks of the node, from the GPU's NUMA node when known.
     Pins the process (threads created later inherit the mask).  Returns the "host" object of the JSON line."""
@@ -403,6 +421,7 @@ def main():
     if pipe is not None:
         pipe.cpu_seconds(reset=True)
     cpu0 = time.process_time()
+    thr0 = thread_cpu_ns()
     t0 = time.perf_counter()
     results = run(args.steps * pps)
     torch.cuda.synchronize()
@@ -411,6 +430,14 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     worker_cpu = pipe.cpu_seconds() if pipe is not None else (0.0, 0.0)
+    thr1 = thread_cpu_ns()
+    per_tid = {k: thr1[k] - thr0.get(k, 0) for k in thr1}
+    by_name = {}
+    for k, v in per_tid.items():
+        nm = k.split("/")[0]
+        tot, cnt, top = by_name.get(nm, (0, 0, 0))
+        by_name[nm] = (tot + v, cnt + (1 if v > 0 else 0), max(top, v))
+    by_thread = sorted(by_name.items(), key=lambda kv: -kv[1][0])
     timed = pipe if pipe is not None else ctx
     blur_ms, blur_n, blur_bytes = timed.timing_read("blur")
     small_ms, small_n, small_bytes = timed.timing_read("blur_small")
@@ -501,7 +528,9 @@ def main():
             # what a pair costs the HOST (rank 0, timed steps): CPU seconds of the whole process per pair (every thread), and of the
             # pipeline's own worker threads inside their stages; process_cpu_s_per_pair x pairs/s = busy cores per rank
             "host_cpu": {"process_cpu_ms_per_pair": round(cpu_s / n_pairs * 1e3, 3), "gpu_workers_cpu_ms_per_pair": round(worker_cpu[0] / n_pairs * 1e3, 3),
-                         "verify_workers_cpu_ms_per_pair": round(worker_cpu[1] / n_pairs * 1e3, 3), "busy_cores": round(cpu_s / dt, 2)},
+                         "verify_workers_cpu_ms_per_pair": round(worker_cpu[1] / n_pairs * 1e3, 3), "busy_cores": round(cpu_s / dt, 2),
+                         "by_thread_name_ms_per_pair": {k: {"total": round(v[0] * 1e-6 / n_pairs, 3), "threads": v[1], "busiest": round(v[2] * 1e-6 / n_pairs, 3)}
+                                                        for k, v in by_thread[:6] if v[0] > 0}},
             "config": {"workload": "single 1920x1080 pair, HessianAffine+RootSIFT, 1 synth iteration (BASELINE configs[1])"
                                    + (" - VARIANT: second motion over %.0f %% of image 2 (--inlier-ratio)" % (100 * (1 - args.inlier_ratio)) if args.inlier_ratio > 0 else ""),
                        "pairs_per_step": pps, "image": "1920x1080",

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <thread>
 #include <time.h>
+#include <pthread.h>
 
 extern "C" int mods_ctx_create_ex(int device, int max_w, int max_h, int batch, int flags, mods_ctx **out);
 extern "C" int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
@@ -72,6 +73,7 @@ static void worker_ready(mods_pipeline *p, int rc) {
 
 static void gpu_worker(mods_pipeline *p, mods_ctx *ctx) {
   (void)hipSetDevice(p->device);
+  pthread_setname_np(pthread_self(), "mods-gpu");
   wait_mode_for_worker(50000);    // a batch takes tens of milliseconds: 50 us between looks
   // every pool a full batch needs (pyramid planes, candidate / region / matcher buffers, code objects) is allocated now: a
   // hipMalloc inside the running pipeline synchronises the whole device
@@ -106,6 +108,7 @@ static void gpu_worker(mods_pipeline *p, mods_ctx *ctx) {
 
 static void verify_worker(mods_pipeline *p) {
   (void)hipSetDevice(p->device);
+  pthread_setname_np(pthread_self(), "mods-verify");
   wait_mode_for_worker(20000);    // scoring launches are short but queue behind the other workers' kernels
   worker_ready(p, mods_ransac_warmup(p->device, 16384));   // this thread's scoring stream and workspace
   for (;;) {

@@ -7,6 +7,7 @@
 // process may use - affinity mask and cgroup quota - capped at 8; 1 = everything inline).  A caller that finds the pool
 // taken (several verification threads in a pipeline) runs its tasks inline: the pool never queues and never oversubscribes.
 #pragma once
+#include <pthread.h>
 #include <sched.h>
 
 #include <atomic>
@@ -98,6 +99,7 @@ class TaskPool {
     }
   }
   void loop() {
+    pthread_setname_np(pthread_self(), "mods-pool");
     unsigned seen = 0;
     for (;;) {
       // spin for a while (the tasks of one run are tens of microseconds to a millisecond, and runs follow each other closely),

@@ -5,7 +5,7 @@ OUT=$R/gpurun_out/${1:-quick}
 mkdir -p $OUT
 if [ -z "$SKIP_TESTS" ]; then (cd $R && timeout 900 python -m pytest tests/test_gpu_describe.py -x -q -m gpu 2>&1 | tail -5); fi
 rm -rf $OUT/dstats
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dstats -- python $R/tools/prof_describe.py > $OUT/run.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dstats -- python $R/tools/prof_describe.py > $OUT/run.log 2>&1
 cp $(find $OUT/dstats -name "*kernel_stats.csv" | head -1) $OUT/describe_leg_kernel_stats.csv
 rm -rf $OUT/dstats
 python3 - $OUT/describe_leg_kernel_stats.csv <<'PY'
