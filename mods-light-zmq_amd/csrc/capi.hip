@@ -809,9 +809,13 @@ int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_pair_params
   if (!c->u8_stage_dev) MODS_HIP_CHECK(hipMalloc(&c->u8_stage_dev, (size_t)c->max_w * c->max_h * c->batch + 16));
   if (!c->pin_arena) { MODS_HIP_CHECK(hipHostMalloc(&c->pin_arena, kPinArena)); c->pin_arena_cap = kPinArena; }
   std::vector<float> img((size_t)w * h);
+  // blobs every 14 px on top of blobs every 90 px: some ten thousand regions of both patch tiers on a 2-megapixel image; on larger
+  // images the lattice is stretched so that the count stays there (a 4096 x 4096 image at the 14-px period overflows the lists)
+  const float f = sqrtf(std::min(1.0f, 1920.f * 1080.f / ((float)w * (float)h)));
+  const float f1 = 0.22f * f, f2 = 0.035f * f;
   for (int y = 0; y < h; y++)
-    for (int x = 0; x < w; x++)   // blobs every 14 px on top of blobs every 90 px: a few thousand regions of both patch tiers
-      img[(size_t)y * w + x] = 128.f + 70.f * sinf(0.22f * x) * sinf(0.22f * y) + 50.f * sinf(0.035f * x + 1.f) * sinf(0.035f * y);
+    for (int x = 0; x < w; x++)
+      img[(size_t)y * w + x] = 128.f + 70.f * sinf(f1 * x) * sinf(f1 * y) + 50.f * sinf(f2 * x + 1.f) * sinf(f2 * y);
   const size_t plane = (size_t)w * h;
   MODS_HIP_CHECK(hipMemcpy(c->input_dev, img.data(), sizeof(float) * plane, hipMemcpyHostToDevice));
   for (int i = 1; i < n_img; i++)

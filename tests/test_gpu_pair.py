@@ -191,6 +191,57 @@ def test_pipeline_equals_serial(pkg, gpu_workers, verify_workers, ppb):
     pipe.close(); ctx.close()
 
 
+def test_pipeline_with_f_verification_equals_serial(pkg):
+    """The pair pipeline with DEGENSAC (useF): verification threads run the host-side LO fits and the degenerate branch of several
+    pairs at once (the task pool serves one caller, the others run their tasks inline) next to the GPU workers, and every
+    pair comes out as one mods_match_pair_dev call gives it (bench.py --config c5 runs this at 4096 x 4096)."""
+    import torch
+    w, h = 640, 480
+    scenes = [synth.pair_two_planes(w, h, seed=81 + i, blobs=2500)[:2] for i in range(2)] + [synth.pair(w, h, seed=90)[:2]]
+    dev = [torch.from_numpy(np.stack([a, b])).cuda() for a, b in scenes]
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    par.ransac.useF = 1
+    pkg.ransac_pin_seed(7)
+    ctx = pkg.Context(0, w, h, 2)
+    want = [pkg.match_pair_dev(ctx, d.data_ptr(), w, h, par)[0] for d in dev]
+    assert all(r.n_inliers >= 15 for r in want), [r.n_inliers for r in want]
+    pipe = pkg.Pipeline(0, w, h, par, 2, 4, 1)
+    order = [0, 1, 2, 2, 1, 0, 1, 2, 0]
+    for i, k in enumerate(order):
+        pipe.submit(dev[k].data_ptr(), i)
+    for i, k in enumerate(order):
+        res, tag = pipe.next()
+        assert tag == i
+        for f in ("n_tentatives", "n_unique", "n_inliers", "ransac_samples", "ransac_lo", "ransac_rejects"):
+            assert getattr(res, f) == getattr(want[k], f), (f, i)
+        assert list(res.H) == list(want[k].H)
+    pipe.close(); ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["spin", "sleep:200"])
+def test_pipeline_wait_modes(pkg, mode, monkeypatch):
+    """MODS_SYNC: the pipeline's threads wait for their streams by sleeping polls (default) or with the runtime's spinning
+    hipStreamSynchronize; the results are the same."""
+    import torch
+    w, h = 640, 480
+    pairs = [synth.pair(w, h, seed=40 + i) for i in range(3)]
+    dev = [torch.from_numpy(np.stack([a, b])).cuda() for a, b, _ in pairs]
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    pkg.ransac_pin_seed(7)
+    ctx = pkg.Context(0, w, h, 2)
+    want = [pkg.match_pair_dev(ctx, d.data_ptr(), w, h, par)[0] for d in dev]
+    monkeypatch.setenv("MODS_SYNC", mode)
+    pipe = pkg.Pipeline(0, w, h, par, 2, 2, 2)
+    for i in range(6):
+        pipe.submit(dev[i % 3].data_ptr(), i)
+    for i in range(6):
+        res, tag = pipe.next()
+        assert tag == i and res.n_inliers == want[i % 3].n_inliers and list(res.H) == list(want[i % 3].H)
+    pipe.close(); ctx.close()
+
+
 @pytest.mark.parametrize("ppb", [1, 4])
 def test_pipeline_host_input(pkg, ppb):
     """Pairs handed over in host memory (pinned fp32, pinned 8-bit grey, and pageable fp32) give what the same pairs give
