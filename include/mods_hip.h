@@ -299,8 +299,14 @@ int mods_match_dev(mods_ctx *ctx, int img_q, int img_t, double ratio, double con
 /* Replaces  void DuplicateFiltering(TentativeCorrespListExt &in, const double r, const int mode)
  * (matching.cpp:2615-2679).  Host-side, in place on (tent, u6); mode 0 = keep order (MODE_RANDOM),
  * 1 = best FGINN ratio first, 2 = best distance first (configuration.hpp:31-34); equal keys keep
- * list order.  Sequential greedy by definition; it is control logic, not a kernel. */
+ * list order. */
 int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, double r, int mode, int *n_out);
+/* The same filter on the context's GPU (csrc/dedup.hip: rank count for the order, brute-force near-predecessor lists, fixed-point
+ * resolution of the keep / drop rule; the pair entry points run it behind the search when [DuplicateFiltering] doBeforeRANSAC = 1).
+ * Host lists in and out as above, laf required; identical result.  *on_device (optional) = 0 when the list was handed to the
+ * host filter instead (a correspondence with more than 12 near predecessors, or more than 150 k correspondences). */
+int mods_duplicate_filter_gpu(mods_ctx *ctx, mods_tentative *tent, double *u6, double *laf, int n, double r, int mode, int *n_out,
+                              int *on_device);
 
 /* ---- B1: verification ---------------------------------------------------------------------------
  * The degensac C ABI itself is exported with the reference's exact signatures (degensac/exp_ranH.h:32-36,

@@ -409,6 +409,17 @@ def duplicate_filter(tent, u6, r=2.0, mode=1, laf=None):
     return tent[:n.value].copy(), u6[:n.value].copy()
 
 
+def duplicate_filter_gpu(ctx, tent, u6, laf, r=2.0, mode=1):
+    """DuplicateFiltering on the context's GPU (csrc/dedup.hip); returns (tent, u6, laf, on_device)."""
+    tent = np.ascontiguousarray(tent).copy()
+    u6 = np.ascontiguousarray(u6, np.float64).copy()
+    lf = np.ascontiguousarray(laf, np.float64).copy()
+    n, dev = C.c_int(), C.c_int()
+    _check(lib().mods_duplicate_filter_gpu(ctx.h, tent.ctypes.data_as(C.c_void_p), u6.ctypes.data_as(C.c_void_p),
+                                           lf.ctypes.data_as(C.c_void_p), len(tent), C.c_double(r), mode, C.byref(n), C.byref(dev)))
+    return tent[:n.value].copy(), u6[:n.value].copy(), lf[:n.value].copy(), bool(dev.value)
+
+
 # ---- verification (degensac C ABI + LORANSACFiltering) ---------------------------------------------
 class Score(C.Structure):
     _fields_ = [("I", C.c_uint), ("J", C.c_double)]

@@ -151,7 +151,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->ori_dev); (void)hipFree(c->ori_multi_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
-  (void)hipFree(c->m_p2); (void)hipFree(c->m_tent); (void)hipFree(c->m_tent_batch); (void)hipHostFree(c->m_count); (void)hipFree(c->m_regs);
+  (void)hipFree(c->m_p2); (void)hipFree(c->dd_buf); (void)hipFree(c->m_tent2); (void)hipFree(c->m_tent); (void)hipFree(c->m_tent_batch); (void)hipHostFree(c->m_count); (void)hipFree(c->m_regs);
   mser_release(c);
   for (mods_ctx *h : c->helpers) if (h) mods_ctx_destroy(h);
   for (auto &a : c->helper_stage) (void)hipFree(a.buf);
@@ -761,6 +761,45 @@ int mods_loransac_f(const double *u6, const double *laf, int n, const mods_ransa
 
 // ---- one pair end to end -------------------------------------------------------------------------------
 
+int mods_duplicate_filter_gpu(mods_ctx *c, mods_tentative *tent, double *u6, double *laf, int n, double r, int mode, int *n_out, int *on_device) {
+  if (!c || !n_out || (n > 0 && (!tent || !u6 || !laf))) { set_error("duplicate_filter_gpu: null argument"); return MODS_E_ARG; }
+  *n_out = n;
+  if (on_device) *on_device = 0;
+  if (r <= 0 || n <= 0) return MODS_OK;
+  if (n > c->max_cand || mode < 0 || mode > 3) return mods_duplicate_filter(tent, u6, laf, n, r, mode, n_out);
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = match_ensure_buffers(c))) return rc;
+  if (!c->m_tent2) MODS_HIP_CHECK(hipMalloc(&c->m_tent2, tent_bytes(((size_t)c->max_cand + 127) & ~(size_t)63) + 64));
+  std::vector<char> stage(tent_bytes((size_t)n));
+  memcpy(stage.data(), tent, sizeof(mods_tentative) * n);
+  memcpy(stage.data() + tent_u6_off(n), u6, sizeof(double) * 6 * n);
+  memcpy(stage.data() + tent_laf_off(n), laf, sizeof(double) * 14 * n);
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
+  MODS_HIP_CHECK(hipMemcpy(c->m_tent, stage.data(), stage.size(), hipMemcpyHostToDevice));
+  c->m_count[0] = n;
+  const DupJob job = {(const char *)c->m_tent, (char *)c->m_tent2, c->m_count, c->m_count + 64, c->m_count + 128};
+  if ((rc = dup_filter_dev(c, &job, 1, n, r, mode))) return rc;
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
+  if (((volatile int *)c->m_count)[128] != 0) return mods_duplicate_filter(tent, u6, laf, n, r, mode, n_out);
+  const int m = ((volatile int *)c->m_count)[64];
+  if (m > 0) {
+    MODS_HIP_CHECK(hipMemcpy(stage.data(), c->m_tent2, tent_bytes((size_t)m), hipMemcpyDeviceToHost));
+    memcpy(tent, stage.data(), sizeof(mods_tentative) * m);
+    memcpy(u6, stage.data() + tent_u6_off(m), sizeof(double) * 6 * m);
+    memcpy(laf, stage.data() + tent_laf_off(m), sizeof(double) * 14 * m);
+  }
+  *n_out = m;
+  if (on_device) *on_device = 1;
+  return MODS_OK;
+}
+
+// DuplicateFiltering ahead of RANSAC runs on the device, behind the search (dedup.hip); MODS_DEDUP=host keeps it on the verify thread
+static bool dedup_on_device(const mods_pair_params *par) {
+  static const bool host_only = [] { const char *e = getenv("MODS_DEDUP"); return e && !strcmp(e, "host"); }();
+  return !host_only && par->dup_before_ransac && par->dup_dist > 0 && par->dup_mode >= 0 && par->dup_mode <= 3;
+}
+
 // GPU half of a pair: detect + describe both images, match, bring the tentatives to the host.
 int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
                         mods_pair_result *res, std::vector<mods_tentative> *tent, std::vector<double> *u6, std::vector<double> *laf) {
@@ -775,12 +814,30 @@ int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int str
   res->ms_detect_describe = t1 - t0;
   if ((rc = match_run(c, c->regions_dev, res->n_described[0], c->regions_dev + c->max_cand, res->n_described[1],
                       par->fginn_ratio, par->contradDist, par->nn))) return rc;
+  const bool dedup = dedup_on_device(par);
+  if (dedup) {
+    if (!c->m_tent2) MODS_HIP_CHECK(hipMalloc(&c->m_tent2, tent_bytes(((size_t)c->max_cand + 127) & ~(size_t)63) + 64));
+    const DupJob job = {(const char *)c->m_tent, (char *)c->m_tent2, c->m_count, c->m_count + 64, c->m_count + 128};
+    if ((rc = dup_filter_dev(c, &job, 1, res->n_described[0], par->dup_dist, par->dup_mode))) return rc;
+  }
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
-  const int n = *(volatile int *)c->m_count;
+  int n = *(volatile int *)c->m_count;
   res->n_tentatives = n;
   if (n > c->max_cand) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
+  const bool filtered = dedup && ((volatile int *)c->m_count)[128] == 0;
+  if (filtered) n = ((volatile int *)c->m_count)[64];
   tent->resize(n); u6->resize((size_t)n * 6); laf->resize((size_t)n * 14);
-  if ((rc = mods_match_copy_out(c, n, tent->data(), u6->data(), laf->data()))) return rc;
+  if (filtered) {          // the kept correspondences in their sorted order; the verify stage sees n_unique == list length and does not filter again
+    res->n_unique = n;
+    if (n > 0) {
+      std::vector<char> stage(tent_bytes((size_t)n));
+      MODS_HIP_CHECK(hipMemcpyAsync(stage.data(), c->m_tent2, stage.size(), hipMemcpyDeviceToHost, c->stream));
+      MODS_HIP_CHECK(mods::stream_wait(c->stream));
+      memcpy(tent->data(), stage.data(), sizeof(mods_tentative) * n);
+      memcpy(u6->data(), stage.data() + tent_u6_off(n), sizeof(double) * 6 * n);
+      memcpy(laf->data(), stage.data() + tent_laf_off(n), sizeof(double) * 14 * n);
+    }
+  } else if ((rc = mods_match_copy_out(c, n, tent->data(), u6->data(), laf->data()))) return rc;
   res->ms_match = now_ms() - t1;
   return MODS_OK;
 }
@@ -873,11 +930,13 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
   std::vector<size_t> seg(n_pairs + 1, 0);
   for (int i = 0; i < n_pairs; i++) seg[i + 1] = seg[i] + ((tent_bytes((size_t)std::max(nr[2 * i], 1)) + 255) & ~(size_t)255);
   if ((rc = match_ensure_buffers(c))) return rc;
-  if (seg[n_pairs] > c->m_tent_batch_cap) {
+  const bool dedup = dedup_on_device(par);
+  // (the second half of the arena takes the filtered lists of the device duplicate filter)
+  if (2 * seg[n_pairs] > c->m_tent_batch_cap) {
     if (c->m_tent_batch) MODS_HIP_CHECK(hipFree(c->m_tent_batch));
     c->m_tent_batch = nullptr; c->m_tent_batch_cap = 0;
-    MODS_HIP_CHECK(hipMalloc(&c->m_tent_batch, seg[n_pairs] + seg[n_pairs] / 4));
-    c->m_tent_batch_cap = seg[n_pairs] + seg[n_pairs] / 4;
+    MODS_HIP_CHECK(hipMalloc(&c->m_tent_batch, 2 * seg[n_pairs] + seg[n_pairs] / 2));
+    c->m_tent_batch_cap = 2 * seg[n_pairs] + seg[n_pairs] / 2;
   }
   const double tm0 = now_ms();
   for (int i = 0; i < n_pairs; i++) {
@@ -892,22 +951,35 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
     c->m_tent_out = nullptr; c->m_count_out = nullptr;
     if (rc) return rc;
   }
+  if (dedup) {     // the lists of the whole batch through the device duplicate filter in one set of launches
+    std::vector<DupJob> jobs(n_pairs);
+    int grid_n = 1;
+    for (int i = 0; i < n_pairs; i++) {
+      jobs[i] = {c->m_tent_batch + seg[i], c->m_tent_batch + seg[n_pairs] + seg[i], c->m_count + 1 + i, c->m_count + 64 + 1 + i, c->m_count + 128 + 1 + i};
+      grid_n = std::max(grid_n, nr[2 * i]);
+    }
+    if ((rc = dup_filter_dev(c, jobs.data(), n_pairs, grid_n, par->dup_dist, par->dup_mode))) return rc;
+  }
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
   std::vector<size_t> off(n_pairs, (size_t)-1);
   size_t used = 0;
   for (int i = 0; i < n_pairs; i++) {
-    const int n = ((volatile int *)c->m_count)[1 + i];
+    int n = ((volatile int *)c->m_count)[1 + i];
     res[i]->n_tentatives = n;
     if (n > c->max_cand || n > nr[2 * i]) { set_error("tentative list overflow"); return MODS_E_CAPACITY; }
+    // filtered on the device: the kept correspondences come over, the verify stage sees n_unique == list length and does not filter again
+    const bool filtered = dedup && ((volatile int *)c->m_count)[128 + 1 + i] == 0;
+    const char *list = c->m_tent_batch + seg[i];
+    if (filtered) { n = ((volatile int *)c->m_count)[64 + 1 + i]; res[i]->n_unique = n; list = c->m_tent_batch + seg[n_pairs] + seg[i]; }
     tent[i]->resize(n); u6[i]->resize((size_t)n * 6); laf[i]->resize((size_t)n * 14);
     if (n > 0) {
       const size_t bytes = tent_bytes((size_t)n);
       if (used + bytes <= c->pin_arena_cap) {
-        MODS_HIP_CHECK(hipMemcpyAsync(c->pin_arena + used, c->m_tent_batch + seg[i], bytes, hipMemcpyDeviceToHost, c->stream));
+        MODS_HIP_CHECK(hipMemcpyAsync(c->pin_arena + used, list, bytes, hipMemcpyDeviceToHost, c->stream));
         off[i] = used; used += (bytes + 15) & ~(size_t)15;
       } else {      // a list that does not fit the arena: the direct (pageable, synchronous) path
         std::vector<char> stage(bytes);
-        MODS_HIP_CHECK(hipMemcpy(stage.data(), c->m_tent_batch + seg[i], bytes, hipMemcpyDeviceToHost));
+        MODS_HIP_CHECK(hipMemcpy(stage.data(), list, bytes, hipMemcpyDeviceToHost));
         memcpy(tent[i]->data(), stage.data(), sizeof(mods_tentative) * n);
         memcpy(u6[i]->data(), stage.data() + tent_u6_off(n), sizeof(double) * 6 * n);
         memcpy(laf[i]->data(), stage.data() + tent_laf_off(n), sizeof(double) * 14 * n);
@@ -1033,6 +1105,9 @@ int mods_verify_tentatives_ex(int device, const mods_pair_params *par, mods_tent
 int mods_pair_verify_stage(int device, const mods_pair_params *par, mods_pair_result *res, std::vector<mods_tentative> *tent,
                            std::vector<double> *u6, std::vector<double> *laf, double *matches_out, int max_matches) {
   int stats[3] = {0, 0, 0};
+  // a list the GPU stage has already filtered (DuplicateFiltering on the device, dedup.hip) arrives with n_unique = its length
+  mods_pair_params p2;
+  if (!tent->empty() && res->n_unique == (int)tent->size() && par->dup_before_ransac) { p2 = *par; p2.dup_dist = 0; par = &p2; }
   const int rc = mods_verify_tentatives(device, par, tent->data(), u6->data(), laf->data(), (int)tent->size(), &res->n_unique,
                                         &res->n_inliers, res->H, stats, &res->ms_duplicates, &res->ms_ransac);
   if (rc) return rc;

@@ -180,10 +180,13 @@ struct mods_ctx {
   // m_tent holds the n tentatives of the last search PACKED: mods_tentative[n] | (16-byte aligned) u6[n][6] = the correspondences
   // (x1 y1 1 x2 y2 1) | laf[n][14] = the frames (x y a11 a12 a21 a22 s) of both regions - one device-to-host copy of
   // tent_bytes(n) bytes brings all three (tent_u6_off / tent_laf_off give the parts)
-  int *m_count = nullptr;            // tentatives of the last search: PINNED HOST memory (64 ints) written by the emit kernel
+  int *m_count = nullptr;            // PINNED HOST memory (192 ints): [0] tentatives of the last search, [1..63] of pair i of a batch (emit kernel);
+                                     // [64 + i] / [128 + i] kept correspondences / status of the device duplicate filter (i = 0: the last search)
   mods_tentative *m_tent_out = nullptr; int *m_count_out = nullptr;   // set by a batch of pairs: where match_run leaves the packed list / its length
   char *m_tent_batch = nullptr; size_t m_tent_batch_cap = 0;          // the packed lists of a batch, one segment per pair
   mods_region *m_regs = nullptr;     // [2][max_cand] staging for host-side lists
+  void *dd_buf = nullptr; int dd_jobs = 0;   // duplicate filter on the device (dedup.hip): per list of a batch sorted coordinates, ranks, near lists
+  mods_tentative *m_tent2 = nullptr; // the filtered packed list of the last search (single-pair path)
   std::vector<mods_tentative> h_tent;  // host copies for the sequential stages
   std::vector<double> h_u6, h_laf;
   std::vector<unsigned char> h_mask;
@@ -231,6 +234,11 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
               double contradDist, int nn);
 int match_run_distance(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double threshold);   // MatchFLANNDistance, Hamming
 int match_ensure_buffers(mods_ctx *ctx);
+
+// dedup.hip
+constexpr int DUP_MAX_JOBS = 64;
+struct DupJob { const char *src; char *dst; const int *n_src; int *n_dst; int *status; };
+int dup_filter_dev(mods_ctx *c, const DupJob *jobs, int n_jobs, int grid_n, double r, int mode);
 
 // describe.hip
 int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par);

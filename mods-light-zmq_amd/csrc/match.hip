@@ -806,7 +806,7 @@ int match_ensure_buffers(mods_ctx *ctx) {
   MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, tent_bytes(n) + 64));
   // the tentative count lives in pinned host memory: the emit kernel's single store lands there, the host reads it after a
   // stream synchronisation - no 4-byte copy launch per search
-  MODS_HIP_CHECK(hipHostMalloc(&ctx->m_count, 64 * sizeof(int)));   // [0]: the last search; [i]: pair i of a batch (m_count_out)
+  MODS_HIP_CHECK(hipHostMalloc(&ctx->m_count, 192 * sizeof(int)));   // [0]: the last search; [i]: pair i of a batch (m_count_out)
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_desc, 0, 2 * n * 128, ctx->stream));
   MODS_HIP_CHECK(hipMemsetAsync(ctx->m_c, 0, 4 * n * sizeof(int), ctx->stream));
   return MODS_OK;

@@ -155,3 +155,57 @@ def test_distance_matcher_hamming(gpu_ctx, nq, nt, seed, threshold):
         assert np.array_equal(u6[:, 0], q["x"][want["q"]]) and np.array_equal(u6[:, 3], t["x"][want["t"]])
     if threshold >= 1024:
         assert len(want) == nq
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_duplicate_filter_on_the_device_equals_the_host_filter(gpu_ctx, pkg, mode):
+    """DuplicateFiltering as three launches (csrc/dedup.hip) against the sequential host form (mods_duplicate_filter, itself checked
+    against the oracle above): clusters of near-duplicates with chains (a drops b, so c - near b only - stays), equal sort keys,
+    points exactly at the distance, a list in reverse key order; every mode of whichCorrespondenceRemains."""
+    rng = np.random.default_rng(100 + mode)
+    for n, spread in ((1, 50.0), (700, 60.0), (6000, 900.0), (3000, 40.0)):
+        base = rng.uniform(0, spread, (n, 4))
+        k = n // 3                                          # a third of the list: copies of other entries, jittered around the radius
+        src = rng.integers(0, n, k)
+        base[n - k:] = base[src] + rng.choice([0.0, 0.7, 1.4, 1.99, 2.01], (k, 4)) * rng.choice([-1.0, 1.0], (k, 4)) * 0.7071
+        if n > 10:                                          # exactly on the circle in image 1 (3-4-5 triangle, r = 2)
+            base[5] = base[4] + np.array([1.2, 1.6, 0.0, 0.0])
+            base[7] = base[6] + np.array([1.2, 1.6, 1.2, 1.6])
+        tent = np.zeros(n, pkg.TENT_DTYPE)
+        tent["q"] = np.arange(n); tent["t"] = rng.permutation(n)
+        tent["ratio"] = np.round(rng.uniform(0.1, 0.8, n), 2)      # many equal keys: list order decides among them
+        tent["d1"] = np.round(rng.uniform(1000, 90000, n), -2).astype(np.float32)
+        u6 = np.ones((n, 6))
+        u6[:, 0:2] = base[:, 0:2]; u6[:, 3:5] = base[:, 2:4]
+        laf = rng.uniform(0.5, 3.0, (n, 14))
+        laf[:, 6] = np.round(laf[:, 6], 1)
+        if n == 3000:                                       # already sorted the wrong way round
+            o = np.argsort(-tent["ratio"], kind="stable")
+            tent, u6, laf = tent[o], u6[o], laf[o]
+        ht, hu, hl = pkg.duplicate_filter(tent, u6, 2.0, mode, laf=laf)
+        gt, gu, gl, on_dev = pkg.duplicate_filter_gpu(gpu_ctx, tent, u6, laf, 2.0, mode)
+        assert on_dev or n == 3000, (n, mode)               # (the 40 x 40 square packs more than 12 near predecessors: host hand-over)
+        assert len(gt) == len(ht) and 0 < len(ht) <= n
+        assert gt.tobytes() == ht.tobytes() and np.array_equal(gu, hu) and np.array_equal(gl, hl), (n, mode)
+
+
+@pytest.mark.gpu
+def test_pair_with_device_and_host_duplicate_filter(pkg, monkeypatch):
+    """mods_match_pair_dev with the filter behind the search on the device (default) and with doBeforeRANSAC = 0 (the filter runs on
+    the verified list, on the host): unique counts against the host filter applied to the same tentatives."""
+    import torch
+    w, h = 640, 480
+    a, b, _ = synth.pair(w, h, seed=21)
+    t = torch.from_numpy(np.stack([a, b])).cuda(); torch.cuda.synchronize()
+    ctx = pkg.Context(0, w, h, 2)
+    par = pkg.PairParams.default()
+    pkg.ransac_pin_seed(5)
+    res, _ = pkg.match_pair_dev(ctx, t.data_ptr(), w, h, par)
+    tent, u6 = ctx.match_dev(0, 1)                       # the regions of the pair are still in the context
+    ht, _ = pkg.duplicate_filter(tent, u6, par.dup_dist, par.dup_mode)
+    assert res.n_tentatives == len(tent) and res.n_unique == len(ht) and 0 < len(ht) < len(tent)
+    par.dup_before_ransac = 0
+    res2, _ = pkg.match_pair_dev(ctx, t.data_ptr(), w, h, par)
+    assert res2.n_tentatives == res.n_tentatives and res2.n_unique == res.n_tentatives and res2.n_inliers > 15
+    ctx.close()
