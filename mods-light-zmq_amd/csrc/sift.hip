@@ -438,11 +438,16 @@ struct BigLists {                     // device-resident bookkeeping, zeroed bef
   int sift_next, pad;               // next work unit of sift_wave2_kernel
 };
 // regions up to this size take the fused sample + row-pass kernel (S stays in LDS, no S slab); larger ones the phase kernels
-constexpr int BIG_FUSE_P2 = 256;
-__device__ __forceinline__ int big_fuse_rows(int P2) { return P2 <= 128 ? 64 : 32; }   // rows per fused item: rows * P2 floats <= 32 KB
+#ifndef BIG_FUSE_P2_MAX
+#define BIG_FUSE_P2_MAX 256
+#endif
+constexpr int BIG_FUSE_P2 = BIG_FUSE_P2_MAX;
+constexpr int BIG_FUSE_TAPS = 320;     // taps the fused kernel stages in LDS
+__device__ __forceinline__ int big_fuse_rows(int P2) { return P2 <= 128 ? 64 : (P2 <= 256 ? 32 : (P2 <= 512 ? 16 : 8)); }   // rows per fused item: rows * P2 floats <= 32 KB
+__device__ __forceinline__ bool big_is_fused(int P2, int n_tap) { return P2 <= BIG_FUSE_P2 && P2 <= 1024 && n_tap <= BIG_FUSE_TAPS; }
 
 __device__ __forceinline__ int big_hdr_floats(int n_tap, int ps) { return (n_tap + 3 * ps + 8 + 3) & ~3; }
-__device__ __forceinline__ unsigned long long big_s_floats(int P2, int P2r) { return P2 <= BIG_FUSE_P2 ? 0ull : (unsigned long long)P2 * P2r; }
+__device__ __forceinline__ unsigned long long big_s_floats(int P2, int P2r, int n_tap) { return big_is_fused(P2, n_tap) ? 0ull : (unsigned long long)P2 * P2r; }
 // a row-pass item covers `steps` groups of 4 column pairs
 __device__ __forceinline__ int big_rsteps(int n_tap) { const int v = BIG_RLOADS / (n_tap + 1); return v < 1 ? 1 : v; }
 
@@ -481,9 +486,9 @@ __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mo
   if (!have || g.P2 <= k.p2_hi) return;
   const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
   const int P2r = (g.P2 + 3) & ~3;
-  const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2, P2r) +
+  const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2, P2r, n_tap) +
                                    (unsigned long long)g.P2 * t_stride(k.desc_ps) + 3ull) & ~3ull;
-  const bool fused = g.P2 <= BIG_FUSE_P2;
+  const bool fused = big_is_fused(g.P2, n_tap);
   const int f_rows = big_fuse_rows(g.P2);
   const int f_chunks = fused ? (g.P2 + f_rows - 1) / f_rows : 0;
   const int s_chunks = fused ? 0 : (g.P2 + BIG_SROWS - 1) / BIG_SROWS;
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(256) void big_rowpass_kernel(DescConst k, const Big
     const float *tap = taps_in_lds ? (const float *)s_wtap[threadIdx.x >> 6] : (const float *)(pool + br.slab);
     const int *cidx = (const int *)(pool + br.slab + n_tap + ps);
     const float *St = pool + br.slab + big_hdr_floats(n_tap, ps);
-    float *T = (float *)St + big_s_floats(P2, P2r);
+    float *T = (float *)St + big_s_floats(P2, P2r, n_tap);
     for (int step = step0; step < step1; step++) {
       const int pi = step * 4 + pg;
       const bool live = y < P2 && pi < ps;
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
   // per-lane global loads with a full wait in front of every use - one L2 round trip per tap in the clamped branch
   // (round 3: 36 of the 66 thousand cycles of an item).  P2 <= BIG_FUSE_P2 = 256 and patch sizes >= 8 give at most
   // (int)(9 * 254 / 8 + 1) | 1 = 287 taps (57 with the 41-pixel patch of the .ini).
-  __shared__ float s_ftap[320];
+  __shared__ float s_ftap[BIG_FUSE_TAPS];
   if (*err_flag) return;
   const int ps = k.desc_ps, ps2 = t_stride(ps);   // (row stride of T)
   const int n_items = min(bl->n_fitems, max_items);
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
     const int P2 = br.P2, w = k.w, h = k.h;
     const int R = big_fuse_rows(P2), r0 = item.y;
     __syncthreads();   // the previous item's row pass is done with the tile
-    for (int i = tid; i < br.n_tap && i < 320; i += 256) s_ftap[i] = (pool + br.slab)[i];
+    for (int i = tid; i < br.n_tap && i < BIG_FUSE_TAPS; i += 256) s_ftap[i] = (pool + br.slab)[i];
     FPROF(0)
     // phase 1: the item's rows, tile by tile (device_util.hpp: sample_tiles), stored transposed St[col][R]
     sample_tiles_rows<true>(img, w, h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, P2, r0, min(P2, r0 + R), wv, 4,
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(256) void big_colres_kernel(DescConst k, const BigL
     const float *tap = pool + br.slab;
     const float *seq = tap + br.n_tap;
     const int *cidx = (const int *)(seq + ps);
-    const float *T = tap + big_hdr_floats(br.n_tap, ps) + big_s_floats(br.P2, br.P2r);
+    const float *T = tap + big_hdr_floats(br.n_tap, ps) + big_s_floats(br.P2, br.P2r, br.n_tap);
     const float c0 = (float)(br.P2 >> 1);
     const bool touch2 = check_borders(br.P2, br.P2, c0, c0, br.scale, 0.f, 0.f, br.scale, ps, ps);
     const int j = e / np, m = e - j * np;
