@@ -439,7 +439,7 @@ struct BigLists {                     // device-resident bookkeeping, zeroed bef
 };
 // regions up to this size take the fused sample + row-pass kernel (S stays in LDS, no S slab); larger ones the phase kernels
 #ifndef BIG_FUSE_P2_MAX
-#define BIG_FUSE_P2_MAX 256
+#define BIG_FUSE_P2_MAX 1024   // measured (round 4, profiles/r04_extract_variants.log): 256 -> 11.01, 512 -> 10.67, 1024 -> 10.43 ms per 16-image describe leg
 #endif
 constexpr int BIG_FUSE_P2 = BIG_FUSE_P2_MAX;
 constexpr int BIG_FUSE_TAPS = 320;     // taps the fused kernel stages in LDS

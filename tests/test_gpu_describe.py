@@ -86,6 +86,22 @@ def test_large_regions_tier_b(gpu_ctx):
     _assert_regions_equal(gpu_ctx.orient_describe(img, keys), want)
 
 
+def test_regions_above_the_fused_tier(pkg):
+    """Measurement regions of more than 1024 px (P2 > BIG_FUSE_P2: the sampled region lives in an HBM slab, wave-per-item sample and
+    row-pass kernels) next to ones just below the limit (the fused kernel with 8 rows per item)."""
+    w = h = 2400
+    img = synth.texture(w, h, seed=33)
+    keys = orc.detect_hessian_affine(img[:600, :600].copy())[:4].copy()
+    keys["x"] = 1200.0; keys["y"] = 1200.0
+    keys["s"] = np.array([90.0, 97.0, 99.0, 106.0])          # P2 = 939, 1013, 1033, 1105
+    regs = orc.regions_from_keys(keys)
+    want = orc.describe_rootsift(img, orc.filter_touch_boundary(orc.detect_orientation(img, regs), w, h))
+    assert len(want) == 4
+    ctx = pkg.Context(0, w, h, 1)
+    _assert_regions_equal(ctx.orient_describe(img, keys), want)
+    ctx.close()
+
+
 def test_describe_1080p_batch(gpu_ctx):
     import torch
     a = synth.texture(1920, 1080, seed=21)
