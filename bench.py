@@ -148,9 +148,14 @@ def host_share(torch, device, local_rank, local_world):
                 cand = near
         except (OSError, ValueError, AttributeError, RuntimeError):
             pass
-        # the ranks that share `cand` take consecutive slices of it
-        k = local_rank % max(1, len(cand) // per_rank)
-        mine = cand[k * per_rank:(k + 1) * per_rank] or cand[:per_rank]
+        if quota and quota < len(usable):
+            # the limit is a CPU-time quota, not a set of cores: a slice of per_rank named cores would queue a rank's dozen threads
+            # on two CPUs while 200 others idle; stay on the cores next to the GPU (or wherever the mask allows)
+            mine = cand
+        else:
+            # the ranks that share `cand` take consecutive slices of it
+            k = local_rank % max(1, len(cand) // per_rank)
+            mine = cand[k * per_rank:(k + 1) * per_rank] or cand[:per_rank]
         try:
             os.sched_setaffinity(0, mine)
             pinned = True
@@ -383,12 +388,15 @@ def main():
         args.input = "hbm"
     # host side of a rank: the cores this process may use (affinity mask, cgroup quota) are split between the ranks of the node,
     # each rank takes its share from the cores of its GPU's NUMA node when sysfs tells them (the pipeline's worker threads inherit
-    # the mask), and the worker counts shrink to what the share can run: 8 ranks x (6 + 8) threads on a box that exposes 8 cores
-    # would measure the host scheduler, not the GPUs
+    # the mask), and the number of verify threads follows the share
     host = host_share(torch, device, local_rank, local_world if world > 1 else 1)
     if world > 1 and not args.keep_workers:
-        args.gpu_workers = max(2, min(args.gpu_workers, host["cores_per_rank"] // 2))
-        args.verify_workers = max(2, min(args.verify_workers, host["cores_per_rank"] - args.gpu_workers))
+        # the pipeline's threads sleep while they wait (MODS_SYNC), so the GPU workers cost a tenth of a core each and stay; the
+        # verify threads do the host's real work (~2 ms of CPU per pair): two per core of the rank's share
+        cpr = host["cores_per_rank"]
+        if cpr < 2:
+            args.gpu_workers = min(args.gpu_workers, 3)
+        args.verify_workers = max(3, min(args.verify_workers, 2 * cpr))
 
     # synthetic inputs: seed = 1000*config + pair index (config 2 = the 1080p pair), distinct per rank.  The generator makes
     # 8-bit valued images ("uint8 then float32"), so the 8-bit and the fp32 form of a pair are the same image.

@@ -8,8 +8,15 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <algorithm>
+#include <chrono>
 #include <time.h>
 #include <pthread.h>
+#include <sched.h>
+#include <dirent.h>
+#include <unistd.h>
+#include <sys/syscall.h>
+#include <map>
 
 extern "C" int mods_ctx_create_ex(int device, int max_w, int max_h, int batch, int flags, mods_ctx **out);
 extern "C" int mods_pair_gpu_stage(mods_ctx *c, const float *img_dev, int w, int h, int stride, const mods_pair_params *par,
@@ -54,6 +61,9 @@ struct mods_pipeline {
   // CPU time the workers' own threads spent inside their stages (CLOCK_THREAD_CPUTIME_ID; the RANSAC task pool's helper threads,
   // which the verify stage of a hard pair spreads its model fits over, are not in it: the process clock is)
   std::atomic<long long> cpu_gpu_ns{0}, cpu_verify_ns{0};
+  std::vector<int> worker_tids;     // (under mu) kernel thread ids of the workers
+  std::thread watch;                // see runtime_thread_watch
+  std::condition_variable cv_watch;
 };
 static long long thread_cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; }
 
@@ -65,6 +75,7 @@ extern "C" int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_
 static void worker_ready(mods_pipeline *p, int rc) {
   {
     std::lock_guard<std::mutex> lk(p->mu);
+    p->worker_tids.push_back((int)syscall(SYS_gettid));
     if (rc && p->warm_rc == MODS_OK) { p->warm_rc = rc; p->warm_err = mods_last_error(); }
     p->ready++;
   }
@@ -130,6 +141,58 @@ static void verify_worker(mods_pipeline *p) {
       j->done = true;
     }
     p->cv_done.notify_all();
+  }
+}
+
+
+// The HIP runtime keeps one thread of its own per process that, once streams are busy, polls without pause: a whole core
+// (tools/who_spins.sh; 1.2 ms of CPU per pair at 800 pairs/s).  It is not one of ours and nothing the library calls quiets it,
+// but nothing in the pair path waits for it either (the workers look at their streams' completion signals themselves), so on a host
+// with few cores per GPU it is better off behind the threads that do the work.  MODS_RUNTIME_THREAD=idle[:delay in ms]: two seconds (or the delay) after the
+// pipeline starts, every thread of the process that is neither a pipeline worker nor the RANSAC pool and has used more than 80 % of
+// a core over 100 ms is moved to SCHED_IDLE (it runs when a core has nothing else to do), and the move is reported once on stderr.
+static std::map<int, long long> task_cpu_ns() {
+  std::map<int, long long> out;
+  if (DIR *d = opendir("/proc/self/task")) {
+    while (dirent *e = readdir(d)) {
+      const int tid = atoi(e->d_name);
+      if (tid <= 0) continue;
+      char path[64]; snprintf(path, sizeof(path), "/proc/self/task/%d/schedstat", tid);
+      if (FILE *f = fopen(path, "r")) { long long ns = 0; if (fscanf(f, "%lld", &ns) == 1) out[tid] = ns; fclose(f); }
+    }
+    closedir(d);
+  }
+  return out;
+}
+static void runtime_thread_watch(mods_pipeline *p) {
+  pthread_setname_np(pthread_self(), "mods-watch");
+  {
+    std::unique_lock<std::mutex> lk(p->mu);
+    int delay_ms = 2000;
+    if (const char *e = getenv("MODS_RUNTIME_THREAD")) if (const char *c = strchr(e, ':')) delay_ms = std::max(1, atoi(c + 1));
+    if (p->cv_watch.wait_for(lk, std::chrono::milliseconds(delay_ms), [&] { return p->stop; })) return;
+  }
+  const auto a = task_cpu_ns();
+  {
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->cv_watch.wait_for(lk, std::chrono::milliseconds(100), [&] { return p->stop; })) return;
+  }
+  const auto b = task_cpu_ns();
+  std::vector<int> ours;
+  { std::lock_guard<std::mutex> lk(p->mu); ours = p->worker_tids; }
+  const int self = (int)syscall(SYS_gettid);
+  for (const auto &kv : b) {
+    const int tid = kv.first;
+    const auto it = a.find(tid);
+    if (it == a.end() || kv.second - it->second < 80000000ll) continue;
+    if (tid == self || std::find(ours.begin(), ours.end(), tid) != ours.end()) continue;
+    char comm[32] = "?", path[64];
+    snprintf(path, sizeof(path), "/proc/self/task/%d/comm", tid);
+    if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%31s", comm) != 1) comm[0] = 0; fclose(f); }
+    if (!strncmp(comm, "mods-", 5)) continue;
+    sched_param sp; sp.sched_priority = 0;
+    if (sched_setscheduler(tid, SCHED_IDLE, &sp) == 0)
+      fprintf(stderr, "mods: thread %d (%s) of the HIP runtime was polling on a full core: moved to SCHED_IDLE (MODS_RUNTIME_THREAD=leave keeps it)\n", tid, comm);
   }
 }
 
@@ -202,6 +265,8 @@ int mods_pipeline_create_ex(int device, int w, int h, const mods_pair_params *pa
     set_error("pipeline warm-up: %s", err.c_str());
     return rc;
   }
+  if (const char *e = getenv("MODS_RUNTIME_THREAD"))
+    if (!strncmp(e, "idle", 4)) p->watch = std::thread(runtime_thread_watch, p.get());
   *out = p.release();
   return MODS_OK;
 }
@@ -261,7 +326,8 @@ void mods_pipeline_destroy(mods_pipeline *p) {
     std::lock_guard<std::mutex> lk(p->mu);
     p->stop = true;
   }
-  p->cv_gpu.notify_all(); p->cv_verify.notify_all();
+  p->cv_gpu.notify_all(); p->cv_verify.notify_all(); p->cv_watch.notify_all();
+  if (p->watch.joinable()) p->watch.join();
   for (auto &t : p->gpu_threads) t.join();
   for (auto &t : p->verify_threads) t.join();
   for (auto *c : p->ctxs) mods_ctx_destroy(c);

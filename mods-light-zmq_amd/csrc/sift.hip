@@ -443,7 +443,16 @@ struct BigLists {                     // device-resident bookkeeping, zeroed bef
 #endif
 constexpr int BIG_FUSE_P2 = BIG_FUSE_P2_MAX;
 constexpr int BIG_FUSE_TAPS = 320;     // taps the fused kernel stages in LDS
-__device__ __forceinline__ int big_fuse_rows(int P2) { return P2 <= 128 ? 64 : (P2 <= 256 ? 32 : (P2 <= 512 ? 16 : 8)); }   // rows per fused item: rows * P2 floats <= 32 KB
+#ifndef BIG_FUSE_KB
+#define BIG_FUSE_KB 32
+#endif
+// rows per fused item: the largest power of two (<= 64) with rows * P2 floats <= BIG_FUSE_KB KB (P2 <= 1024)
+__device__ __forceinline__ int big_fuse_rows(int P2) {
+  const int budget = BIG_FUSE_KB * 256;        // floats
+  int r = 64;
+  while (r > 4 && r * P2 > budget) r >>= 1;
+  return r;
+}
 __device__ __forceinline__ bool big_is_fused(int P2, int n_tap) { return P2 <= BIG_FUSE_P2 && P2 <= 1024 && n_tap <= BIG_FUSE_TAPS; }
 
 __device__ __forceinline__ int big_hdr_floats(int n_tap, int ps) { return (n_tap + 3 * ps + 8 + 3) & ~3; }
@@ -1883,7 +1892,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   }
   const size_t ldsH = sizeof(float) * (k.tap_cap + 4 * ps2) + 32;
   hipLaunchKernelGGL(big_setup_kernel, dim3(1024), dim3(256), ldsH, ctx->stream, k, bl, bregs, max_big, pool, ctx->desc_err_dev);
-  hipLaunchKernelGGL(big_fused_kernel, dim3(8192), dim3(256), 32 * 1024, ctx->stream, img_dev, k, bl, bregs, fitems, max_items,
+  hipLaunchKernelGGL(big_fused_kernel, dim3(8192), dim3(256), BIG_FUSE_KB * 1024, ctx->stream, img_dev, k, bl, bregs, fitems, max_items,
                      ctx->regions_dev, pool, ctx->desc_err_dev);
   hipLaunchKernelGGL(big_sample_kernel, dim3(4096), dim3(256), 0, ctx->stream, img_dev, k, bl, bregs, sitems, max_items,
                      ctx->regions_dev, pool, ctx->desc_err_dev);
