@@ -711,6 +711,7 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
       // replaying the reference's sequential fp32 additions (row steps, then column steps)
       if (active) {
         const bool touch = check_borders(iw, ih, lx, ly, a11, a12, a21, a22, W, W);
+        const bool all_inside = __all(!touch);      // over the lanes that are still iterating (one or two keypoints)
         // The lanes of a keypoint sample the window tile by tile (8 columns x G / 8 rows per step), lane = position inside
         // the tile: what a gather costs is the number of cache lines its 64 lanes touch (tools/ubench/gather.hip: 4 cycles
         // per line, 266 for 64 scattered lanes, 42 for an 8 x 8 pixel block), and a tile of neighbouring samples lies on a
@@ -728,19 +729,37 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
           float WY = ry - (float)half * a21;
 #pragma unroll
           for (int q = 0; q < 7; q++) { const bool m = q < tcol; const float nx = WX + a11, ny = WY + a21; WX = m ? nx : WX; WY = m ? ny : WY; }
-          // column tiles of the row in batches of three (the 19-wide window of the .ini is one batch): 6 loads in flight
-          for (int c0 = 0; c0 < W; c0 += 24) {
-            TapLoads t[3];
+          // column tiles of the row in batches of three (the 19-wide window of the .ini is one batch): 6 loads in flight.
+          // When no window of the wave's keypoints touches the image border (nearly always) the taps take the unchecked form
+          if (all_inside) {
+            for (int c0 = 0; c0 < W; c0 += 24) {
+              TapLoads t[3];
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
-              t[u] = tap_load_bf(im, iw, ih, WX, WY, touch);
+              for (int u = 0; u < 3; u++) {
+                t[u] = tap_load_inside(im, iw, WX, WY, row < W && c0 + 8 * u + tcol < W);
 #pragma unroll
-              for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
+                for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
+              }
+#pragma unroll
+              for (int u = 0; u < 3; u++) {
+                const int col = c0 + 8 * u + tcol;
+                if (row < W && col < W) s_img[row * W + col] = tap_combine_t<false>(t[u]);
+              }
             }
+          } else {
+            for (int c0 = 0; c0 < W; c0 += 24) {
+              TapLoads t[3];
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
-              const int col = c0 + 8 * u + tcol;
-              if (row < W && col < W) s_img[row * W + col] = tap_combine(t[u]);
+              for (int u = 0; u < 3; u++) {
+                t[u] = tap_load_bf(im, iw, ih, WX, WY, touch);
+#pragma unroll
+                for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
+              }
+#pragma unroll
+              for (int u = 0; u < 3; u++) {
+                const int col = c0 + 8 * u + tcol;
+                if (row < W && col < W) s_img[row * W + col] = tap_combine(t[u]);
+              }
             }
           }
 #pragma unroll

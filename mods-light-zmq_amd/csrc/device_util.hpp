@@ -117,6 +117,32 @@ __device__ __forceinline__ float tap_combine(const TapLoads &t) {
   return t.wy * (t.wx * (t.r11 - t.r10) + t.r10 - I1) + I1;
 }
 
+// A tap of a window that interpolateCheckBorders vouches for (`touch` false: the unchecked branch of interpolate(): (int) casts,
+// no border test, no clamp).  That covers the window's own samples only: a lane of a partly filled tile whose sample lies beyond
+// the window's edge (`inwin` false; its value is never stored) reads pixel 0 instead.  A third of the VALU work of the checked form
+// (tap_load_bf: two floors, four clamps, four compares - all half-rate instructions on gfx950 - go away).
+__device__ __forceinline__ TapLoads tap_load_inside(const float *__restrict__ im, int w, float WX, float WY, bool inwin) {
+  TapLoads t;
+  const int x = (int)WX, y = (int)WY;
+  t.valid = true;
+  t.wx = WX - (float)x;
+  t.wy = WY - (float)y;
+  const float *Row0 = im + (inwin ? (unsigned)(__mul24(y, w) + x) : 0u);
+  const PixPair p0 = *(const PixPair *)Row0, p1 = *(const PixPair *)(Row0 + w);
+  t.r00 = p0.a; t.r01 = p0.b; t.r10 = p1.a; t.r11 = p1.b;
+  return t;
+}
+template <bool TOUCH>
+__device__ __forceinline__ TapLoads tap_load_t(const float *__restrict__ im, int w, int h, float WX, float WY, bool inwin) {
+  if (TOUCH) return tap_load_bf(im, w, h, WX, WY, true);
+  return tap_load_inside(im, w, WX, WY, inwin);
+}
+template <bool TOUCH> __device__ __forceinline__ float tap_combine_t(const TapLoads &t) {
+  const float I1 = t.wx * (t.r01 - t.r00) + t.r00;
+  const float v = t.wy * (t.wx * (t.r11 - t.r10) + t.r10 - I1) + I1;
+  return (!TOUCH || t.valid) ? v : 0.f;
+}
+
 // interpolate(img, x, y, A) over an n x n window (helpers.cpp:551-626), tile by tile: the 64 lanes of a wave sit on an 8 x 8
 // block of neighbouring samples, wave `wv` of `nw` takes the tile rows wv, wv + nw, ...  A gather costs the memory pipeline
 // per cache line that its lanes touch (tools/ubench/gather.hip: ~4 cycles per line, 266 cycles when every lane has its own
@@ -124,11 +150,11 @@ __device__ __forceinline__ float tap_combine(const TapLoads &t) {
 // on about nine image rows.  The reference's coordinates are sequential fp32 sums (row starts: += a12 / a22 per row, then
 // += a11 / a21 per column): a lane walks its rows column by column, eight additions between two of its taps.
 // store(row, col, value) is called for every sample of the window.
-// The rows [row_begin, row_end) of the window are sampled (all columns).
-template <bool WIDE, class Store>
-__device__ __forceinline__ void sample_tiles_rows(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
-                                                  float a21, float a22, int n, int row_begin, int row_end, int wv, int nw, Store store) {
-  const bool touch = check_borders(w, h, fx, fy, a11, a12, a21, a22, n, n);
+// The rows [row_begin, row_end) of the window are sampled (all columns).  TOUCH = whether the window touches the image border
+// (interpolateCheckBorders): the same for every lane, so the two forms of the tap are two instantiations behind one scalar branch.
+template <bool WIDE, bool TOUCH, class Store>
+__device__ __forceinline__ void sample_tiles_rows_t(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
+                                                    float a21, float a22, int n, int row_begin, int row_end, int wv, int nw, Store store) {
   const int half = n / 2;
   const int lane = threadIdx.x & 63, tcol = lane & 7, trow = lane >> 3;
   float rx = fx - (float)half * a12;
@@ -147,44 +173,52 @@ __device__ __forceinline__ void sample_tiles_rows(const float *__restrict__ img,
       TapLoads t[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        t[u] = tap_load_bf(img, w, h, WX, WY, touch);
+        t[u] = tap_load_t<TOUCH>(img, w, h, WX, WY, row < row_end);
 #pragma unroll
         for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
       }
 #pragma unroll
       for (int u = 0; u < 8; u++)
-        if (row < row_end) store(row, c0 + 8 * u + tcol, tap_combine(t[u]));
+        if (row < row_end) store(row, c0 + 8 * u + tcol, tap_combine_t<TOUCH>(t[u]));
     }
     for (; c0 + 16 < n; c0 += 32) {              // four column tiles per batch while three or more remain (8 loads in flight)
       TapLoads t[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        t[u] = tap_load_bf(img, w, h, WX, WY, touch);
+        t[u] = tap_load_t<TOUCH>(img, w, h, WX, WY, row < row_end && c0 + 8 * u + tcol < n);
 #pragma unroll
         for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int col = c0 + 8 * u + tcol;
-        if (row < row_end && col < n) store(row, col, tap_combine(t[u]));
+        if (row < row_end && col < n) store(row, col, tap_combine_t<TOUCH>(t[u]));
       }
     }
     for (; c0 < n; c0 += 16) {
       TapLoads t[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        t[u] = tap_load_bf(img, w, h, WX, WY, touch);
+        t[u] = tap_load_t<TOUCH>(img, w, h, WX, WY, row < row_end && c0 + 8 * u + tcol < n);
 #pragma unroll
         for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
       }
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int col = c0 + 8 * u + tcol;
-        if (row < row_end && col < n) store(row, col, tap_combine(t[u]));
+        if (row < row_end && col < n) store(row, col, tap_combine_t<TOUCH>(t[u]));
       }
     }
     for (int q = nw * 8; q > 0; q--) { rx += a12; ry += a22; }
   }
+}
+template <bool WIDE, class Store>
+__device__ __forceinline__ void sample_tiles_rows(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
+                                                  float a21, float a22, int n, int row_begin, int row_end, int wv, int nw, Store store) {
+  // (every lane evaluates the same expression: the first lane's value makes the branch a scalar one)
+  const bool touch = __builtin_amdgcn_readfirstlane((int)check_borders(w, h, fx, fy, a11, a12, a21, a22, n, n)) != 0;
+  if (touch) sample_tiles_rows_t<WIDE, true>(img, w, h, fx, fy, a11, a12, a21, a22, n, row_begin, row_end, wv, nw, store);
+  else sample_tiles_rows_t<WIDE, false>(img, w, h, fx, fy, a11, a12, a21, a22, n, row_begin, row_end, wv, nw, store);
 }
 template <class Store>
 __device__ __forceinline__ void sample_tiles(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
