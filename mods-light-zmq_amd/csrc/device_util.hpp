@@ -159,7 +159,11 @@ __device__ __forceinline__ void sample_tiles_rows_t(const float *__restrict__ im
   const int lane = threadIdx.x & 63, tcol = lane & 7, trow = lane >> 3;
   float rx = fx - (float)half * a12;
   float ry = fy - (float)half * a22;
-  for (int q = row_begin + wv * 8 + trow; q > 0; q--) { rx += a12; ry += a22; }
+  // the row steps all lanes share as a scalar-counted loop, the lane's own 0..7 as selects (a loop with a per-lane trip count costs
+  // five vector instructions per step)
+  for (int q = __builtin_amdgcn_readfirstlane(row_begin + wv * 8); q > 0; q--) { rx += a12; ry += a22; }
+#pragma unroll
+  for (int q = 0; q < 7; q++) { const bool m = q < trow; const float nx = rx + a12, ny = ry + a22; rx = m ? nx : rx; ry = m ? ny : ry; }
   for (int r0 = row_begin + wv * 8; r0 < row_end; r0 += nw * 8) {
     const int row = r0 + trow;
     float WX = rx - (float)half * a11;
@@ -209,6 +213,7 @@ __device__ __forceinline__ void sample_tiles_rows_t(const float *__restrict__ im
         if (row < row_end && col < n) store(row, col, tap_combine_t<TOUCH>(t[u]));
       }
     }
+    if (r0 + nw * 8 >= row_end) break;          // (no walk behind the wave's last tile row)
     for (int q = nw * 8; q > 0; q--) { rx += a12; ry += a22; }
   }
 }

@@ -26,6 +26,9 @@
 namespace mods {
 
 constexpr int SMALL_CAP = 80;   // P2 limit of the LDS-resident extraction tier
+#ifndef ES_MINB
+#define ES_MINB 5                // workgroups of extract_small_kernel per CU the register budget is set for
+#endif
 
 // 8-byte aligned place at or behind p inside the (16-byte aligned) dynamic LDS block `base`, by pointer arithmetic: rounding the
 // address as an integer would make the result a FLAT pointer (its accesses wait on both counters)
@@ -363,7 +366,7 @@ __device__ __forceinline__ void col_resample(const float *T, int P2, int ps, int
 // extract, LDS tier: direct branch and P2 <= SMALL_CAP.  grid = (N, n_img), block = 256.
 // dynamic LDS: S cap*cap | T cap*2ps | cx,cy aliases S | seq 2ps | cidx 2ps | taps 32 | red 2 doubles
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 5) void extract_small_kernel(const float *__restrict__ img_all, DescConst k,
+__global__ __launch_bounds__(256, ES_MINB) void extract_small_kernel(const float *__restrict__ img_all, DescConst k,
                                                             const mods_region *__restrict__ reg_all, const int *__restrict__ items,
                                                             const int *__restrict__ n_items_dev, int items_cap,
                                                             float *__restrict__ patches) {
