@@ -478,10 +478,13 @@ __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mo
   RegionGeom g;
   g.P2 = 0;
   if (have) g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps, k.patch_rule);
-  // LDS tier: work lists of the two size classes (image << 17 | region), one atomic per wave and class
+  // LDS tier: work lists of the two size classes (image << 17 | region), one atomic per wave and class; a blur wider than the 32
+  // taps the LDS tier stages (patch sizes below ~24 only) sends a region to the HBM tier whatever its size
+  const int n_tap = have && g.P2 > 0 ? ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1 : 0;
+  const bool lds_tier = have && g.P2 <= k.p2_hi && n_tap <= 32;
   {
     const int lane = threadIdx.x & 63;
-    const int tier = !have || g.P2 > k.p2_hi ? -1 : (g.P2 <= t_lo ? 0 : 1);
+    const int tier = !lds_tier ? -1 : (g.P2 <= t_lo ? 0 : 1);
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       const unsigned long long m = __ballot(tier == t);
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mo
       }
     }
   }
-  if (!have || g.P2 <= k.p2_hi) return;
-  const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
+  const bool big = have && !lds_tier;
+  if (__ballot(big) == 0) return;
   const int P2r = (g.P2 + 3) & ~3;
   const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2, P2r, n_tap) +
                                    (unsigned long long)g.P2 * t_stride(k.desc_ps) + 3ull) & ~3ull;
@@ -506,11 +509,36 @@ __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mo
   const int s_chunks = fused ? 0 : (g.P2 + BIG_SROWS - 1) / BIG_SROWS;
   const int r_chunks = fused ? 0 : (g.P2 + BIG_RROWS - 1) / BIG_RROWS;
   const int steps = (k.desc_ps + 3) / 4, per = big_rsteps(n_tap), r_parts = (steps + per - 1) / per;
-  const int li = atomicAdd(&bl->n_regions, 1);
-  const unsigned long long off = atomicAdd(&bl->pool_used, need);
-  const int s0 = s_chunks ? atomicAdd(&bl->n_sitems, s_chunks) : 0;
-  const int r0 = r_chunks ? atomicAdd(&bl->n_ritems, r_chunks * r_parts) : 0;
-  const int f0 = f_chunks ? atomicAdd(&bl->n_fitems, f_chunks) : 0;
+  // one returning atomic per wave and counter (a lane's share = the exclusive prefix of its amount inside the wave): with one
+  // per region the ~1 500 large regions of an image queued on five addresses
+  int li, s0, r0, f0;
+  unsigned long long off;
+  {
+    const int lane = threadIdx.x & 63;
+    const int a_reg = big ? 1 : 0, a_s = big ? s_chunks : 0, a_r = big ? r_chunks * r_parts : 0, a_f = big ? f_chunks : 0;
+    const unsigned long long a_need = big ? need : 0ull;
+    int p_reg = a_reg, p_s = a_s, p_r = a_r, p_f = a_f;
+    unsigned long long p_need = a_need;
+    for (int d = 1; d < 64; d <<= 1) {      // inclusive scans over the wave
+      const int t_reg = __shfl_up(p_reg, d), t_s = __shfl_up(p_s, d), t_r = __shfl_up(p_r, d), t_f = __shfl_up(p_f, d);
+      const unsigned lo = __shfl_up((unsigned)p_need, d), hi = __shfl_up((unsigned)(p_need >> 32), d);
+      if (lane >= d) { p_reg += t_reg; p_s += t_s; p_r += t_r; p_f += t_f; p_need += ((unsigned long long)hi << 32) | lo; }
+    }
+    int b_reg = 0, b_s = 0, b_r = 0, b_f = 0;
+    unsigned long long b_need = 0;
+    if (lane == 63) {
+      b_reg = atomicAdd(&bl->n_regions, p_reg);
+      b_need = atomicAdd(&bl->pool_used, p_need);
+      if (p_s) b_s = atomicAdd(&bl->n_sitems, p_s);
+      if (p_r) b_r = atomicAdd(&bl->n_ritems, p_r);
+      if (p_f) b_f = atomicAdd(&bl->n_fitems, p_f);
+    }
+    b_reg = __shfl(b_reg, 63); b_s = __shfl(b_s, 63); b_r = __shfl(b_r, 63); b_f = __shfl(b_f, 63);
+    b_need = ((unsigned long long)__shfl((unsigned)(b_need >> 32), 63) << 32) | __shfl((unsigned)b_need, 63);
+    li = b_reg + p_reg - a_reg; s0 = b_s + p_s - a_s; r0 = b_r + p_r - a_r; f0 = b_f + p_f - a_f;
+    off = b_need + p_need - a_need;
+  }
+  if (!big) return;
   if (li >= max_regions || off + need > pool_elems || s0 + s_chunks > max_items || r0 + r_chunks * r_parts > max_items ||
       f0 + f_chunks > max_items || g.P2 >= 65536 || n_tap > k.tap_cap) {
     atomicExch(err_flag, 1);
