@@ -26,5 +26,19 @@ PY
 head -3 $OUT/threads.txt
 TID=$(head -1 $OUT/threads.txt | cut -d' ' -f1)
 echo "pid $PID busiest $TID"
+python3 - $PID $TID <<'PY'
+import sys, time
+pid, tid = sys.argv[1:3]
+def ticks():
+    f = open("/proc/%s/task/%s/stat" % (pid, tid)).read().rsplit(")", 1)[1].split()
+    return int(f[11]), int(f[12])          # utime, stime (clock ticks)
+u0, s0 = ticks(); time.sleep(2.0); u1, s1 = ticks()
+print("busiest thread over 2 s: user %d ticks, system %d ticks" % (u1 - u0, s1 - s0))
+for name in ("wchan", "syscall"):
+    try: print(name, open("/proc/%s/task/%s/%s" % (pid, tid, name)).read().strip())
+    except Exception as e: print(name, "?", e)
+try: print(open("/proc/%s/task/%s/stack" % (pid, tid)).read()[:600])
+except Exception as e: print("stack ?", e)
+PY
 kill $PID; sleep 1; kill -9 $PID 2>/dev/null
 tail -2 $OUT/bench.log | cut -c1-300
