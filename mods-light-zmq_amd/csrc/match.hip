@@ -76,6 +76,45 @@ __global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__re
   }
 }
 
+// Both lists of a search in ONE launch (blockIdx.y = list), which also does what match_init_kernel did: a wave packs 32
+// consecutive regions - one tile of the distance kernels - and WRITES the tile's parity word (the single-list kernel ORs bits into
+// words that a launch before it had to clear), block (0, 0) clears the two counters of the search.  Three dispatches fewer per search.
+// grid = (ceil(max(n_q, n_t) / 32 / 4), 2), block 256
+struct PackList { const mods_region *reg; int n; int8_t *desc; int *cvec; int *c2neg; unsigned int *parity; double2 *xy; };
+__global__ __launch_bounds__(256) void match_pack2_kernel(PackList lq, PackList lt, int max_n, int *__restrict__ m_count, int *__restrict__ count2) {
+  const PackList L = blockIdx.y == 0 ? lq : lt;
+  const int n = min(L.n, max_n);
+  const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { *m_count = 0; *count2 = 0; }
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile * 32 >= n) return;
+  unsigned int par = 0;
+  for (int r = 0; r < 32; r++) {
+    const int i = tile * 32 + r;
+    if (i < n) {
+      const uint8_t *d = L.reg[i].desc;
+      const int v0 = d[lane * 2], v1 = d[lane * 2 + 1];
+      L.desc[(size_t)i * 128 + lane * 2] = (int8_t)(v0 - 128);
+      L.desc[(size_t)i * 128 + lane * 2 + 1] = (int8_t)(v1 - 128);
+      int n2 = v0 * v0 + v1 * v1;
+      int s1 = (v0 - 128) + (v1 - 128);
+      for (int off = 32; off > 0; off >>= 1) { n2 += __shfl_xor(n2, off); s1 += __shfl_xor(s1, off); }
+      const int c = n2 - 256 * s1;
+      if (lane == 0) {
+        L.cvec[i] = c;
+        L.c2neg[i] = MATCH_BIAS - (c >> 1);       // accumulator seed of the distance tiles: acc = dot - floor(c/2) + MATCH_BIAS
+        L.xy[i] = make_double2(L.reg[i].x, L.reg[i].y);
+      }
+      par |= (unsigned int)(c & 1) << r;
+    } else {
+      // rows of the last tile beyond the list: zero descriptor, zero seed (stale entries there must not shadow the valid rows)
+      ((short *)(L.desc + (size_t)i * 128))[lane] = 0;
+      if (lane == 0) L.c2neg[i] = 0;
+    }
+  }
+  if (lane == 0) L.parity[tile] = par;
+}
+
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
   unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
   lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
@@ -853,9 +892,10 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   QueryMid *mid2 = (QueryMid *)(best2 + 2 * n);
   int8_t *qd2 = (int8_t *)(mid2 + n);
   int *list2 = (int *)(qd2 + n * 128), *qcs = list2 + n, *count2 = qcs + n;
-  hipLaunchKernelGGL(match_init_kernel, dim3(std::max(n_q, n_t) / 32 / 256 + 1), dim3(256), 0, ctx->stream, n_q, n_t, count_out, count2, qpar, tpar);
-  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
-  hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
+  {
+    const PackList lq = {q_dev, n_q, qd, qc, qc2, qpar, qxy}, lt = {t_dev, n_t, td, tc, tc2, tpar, txy};
+    hipLaunchKernelGGL(match_pack2_kernel, dim3((std::max(n_q, n_t) + 127) / 128, 2), dim3(256), 0, ctx->stream, lq, lt, ctx->max_cand, count_out, count2);
+  }
   // pass 1: the three largest half-tile maxima per query and train split, then the exact two nearest trains per query
   const Nn1Grid gr = nn1_grid(n_q, n_t);
   MatchConst k1 = k;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double *__restr
 // multiple of 64) columns, so every lane's column exists.
 constexpr int GAIN_ROWS = 128;
 __global__ void __launch_bounds__(256) ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride,
-                                                          double *__restrict__ J) {
+                                                          int *__restrict__ counts, double *__restrict__ J_out, int *__restrict__ counts_out) {
   __shared__ double s_rows[GAIN_ROWS][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
@@ -111,7 +111,13 @@ __global__ void __launch_bounds__(256) ransac_gain_kernel(const double *__restri
     __syncthreads();
   }
 #undef GAIN_FETCH
-  if (wv == 0 && k < n_hyp) J[k] = sum;
+  // J and the inlier counts of hypothesis k go straight to the host's (pinned, device-visible) result block, and the device counters
+  // are left at zero for the next batch: no copy and no fill launch per scoring round
+  if (wv == 0 && k < n_hyp) {
+    J_out[k] = sum;
+    counts_out[2 * k] = counts[2 * k]; counts_out[2 * k + 1] = counts[2 * k + 1];
+    counts[2 * k] = 0; counts[2 * k + 1] = 0;
+  }
 }
 
 RansacGpu::~RansacGpu() {
@@ -184,6 +190,7 @@ bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
     RS_CHECK(hipHostMalloc(&ws->J_host, 2 * sizeof(double) * n_hyp));
     ws->counts_dev = (int *)(ws->J_dev + n_hyp);
     ws->counts_host = (int *)(ws->J_host + n_hyp);
+    RS_CHECK(hipMemset(ws->J_dev, 0, 2 * sizeof(double) * n_hyp));
     ws->dg_cap = 0;
   }
   // hipFree / hipMalloc synchronise the whole device (20+ ms under a running pipeline): grow in powers of two from a
@@ -208,13 +215,13 @@ bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
 
 // scores hyp_host[0..n) over all correspondences; fills counts_host / J_host
 static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, double th, double th_check) {
+  // (the device counters are zero: ransac_ws_reserve clears them when it allocates, ransac_gain_kernel after it has read them)
   RS_CHECK(hipMemcpyAsync(ws->hyp_dev, ws->hyp_host, sizeof(HypDev) * n, hipMemcpyHostToDevice, ws->stream));
-  RS_CHECK(hipMemsetAsync(ws->counts_dev, 0, sizeof(int) * 2 * n, ws->stream));
   hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, (const HypDev *)ws->hyp_dev, err_type,
                      do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
-  hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
+  hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->counts_dev, ws->J_host,
+                     ws->counts_host);
   RS_CHECK(hipGetLastError());
-  RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * ws->hyp_cap + sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
   RS_CHECK(mods::stream_wait(ws->stream));
   ws->launches += 2;
   return true;
@@ -288,7 +295,7 @@ int mods_ransac_warmup(int device, int len) {
   RansacGpu *ws = ransac_gpu();
   if (!ws) return MODS_E_NODEVICE;
   if (!ransac_ws_reserve(ws, len > 0 ? len : 1, 64)) return MODS_E_HIP;
-  hipLaunchKernelGGL(ransac_gain_kernel, dim3(1), dim3(256), 0, ws->stream, ws->gain_dev, 0, 0, ws->hyp_cap, ws->J_dev);   // loads the code object
+  hipLaunchKernelGGL(ransac_gain_kernel, dim3(1), dim3(256), 0, ws->stream, ws->gain_dev, 0, 0, ws->hyp_cap, ws->counts_dev, ws->J_host, ws->counts_host);   // loads the code object
   if (mods::stream_wait(ws->stream) != hipSuccess) { set_error("ransac warm-up failed"); return MODS_E_HIP; }
   return MODS_OK;
 }

@@ -94,13 +94,13 @@ __global__ void __launch_bounds__(256) ransacf_count_kernel(const double *__rest
 }
 
 static bool gpu_score_f(RansacGpu *ws, int len, int n, int err_type, int do_sym, double th, double th_check) {
+  // (device counters: zero on entry, read out to the host's pinned result block and cleared again by ransac_gain_kernel; ransac.hip)
   RS_CHECK(hipMemcpyAsync(ws->hyp_dev, ws->hyp_host, sizeof(HypF) * n, hipMemcpyHostToDevice, ws->stream));
-  RS_CHECK(hipMemsetAsync(ws->counts_dev, 0, sizeof(int) * 2 * n, ws->stream));
   hipLaunchKernelGGL(ransacf_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, (const HypF *)ws->hyp_dev,
                      err_type, do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
-  hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->J_dev);
+  hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->counts_dev, ws->J_host,
+                     ws->counts_host);
   RS_CHECK(hipGetLastError());
-  RS_CHECK(hipMemcpyAsync(ws->J_host, ws->J_dev, sizeof(double) * ws->hyp_cap + sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ws->stream));
   RS_CHECK(mods::stream_wait(ws->stream));
   ws->launches += 2;
   return true;

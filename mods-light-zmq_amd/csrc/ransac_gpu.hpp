@@ -30,7 +30,8 @@ bool ransac_fetch_row(RansacGpu *ws, int len, int k, double *dst);
 long ransac_pinned_seed();                                // >= 0: pinned (mods_ransac_pin_seed / MODS_RANSAC_SEED)
 
 // lane k adds gain[i][k], i = 0..len-1, in correspondence order (the MSAC score is a sequential sum)
-__global__ void ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride, double *__restrict__ J);
+__global__ void ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride, int *__restrict__ counts,
+                                   double *__restrict__ J_out, int *__restrict__ counts_out);
 
 // A device failure inside the control loops unwinds to the extern "C" entry point (the reference's signatures have no
 // error channel): the entry point returns "no model" and raises the calling thread's failure flag, which
