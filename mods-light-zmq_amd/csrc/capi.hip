@@ -931,6 +931,7 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
   for (int i = 0; i < n_pairs; i++) seg[i + 1] = seg[i] + ((tent_bytes((size_t)std::max(nr[2 * i], 1)) + 255) & ~(size_t)255);
   if ((rc = match_ensure_buffers(c))) return rc;
   const bool dedup = dedup_on_device(par);
+  const bool direct = dedup && seg[n_pairs] <= c->pin_arena_cap;
   // (the second half of the arena takes the filtered lists of the device duplicate filter)
   if (2 * seg[n_pairs] > c->m_tent_batch_cap) {
     if (c->m_tent_batch) MODS_HIP_CHECK(hipFree(c->m_tent_batch));
@@ -952,17 +953,22 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
     if (rc) return rc;
   }
   if (dedup) {     // the lists of the whole batch through the device duplicate filter in one set of launches
+    // when the batch's lists fit the pinned arena (they do unless the images are very large) the filter's compaction writes the
+    // kept lists straight into it - host memory the device can address - at the segments' offsets: no copy launch per pair and one
+    // synchronisation per batch
     std::vector<DupJob> jobs(n_pairs);
     int grid_n = 1;
     for (int i = 0; i < n_pairs; i++) {
-      jobs[i] = {c->m_tent_batch + seg[i], c->m_tent_batch + seg[n_pairs] + seg[i], c->m_count + 1 + i, c->m_count + 64 + 1 + i, c->m_count + 128 + 1 + i};
+      char *dst = direct ? c->pin_arena + seg[i] : c->m_tent_batch + seg[n_pairs] + seg[i];
+      jobs[i] = {c->m_tent_batch + seg[i], dst, c->m_count + 1 + i, c->m_count + 64 + 1 + i, c->m_count + 128 + 1 + i};
       grid_n = std::max(grid_n, nr[2 * i]);
     }
     if ((rc = dup_filter_dev(c, jobs.data(), n_pairs, grid_n, par->dup_dist, par->dup_mode))) return rc;
   }
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
   std::vector<size_t> off(n_pairs, (size_t)-1);
-  size_t used = 0;
+  size_t used = direct ? seg[n_pairs] : 0;       // (lists that were not filtered on the device go behind the segments)
+  bool copies = false;
   for (int i = 0; i < n_pairs; i++) {
     int n = ((volatile int *)c->m_count)[1 + i];
     res[i]->n_tentatives = n;
@@ -974,9 +980,11 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
     tent[i]->resize(n); u6[i]->resize((size_t)n * 6); laf[i]->resize((size_t)n * 14);
     if (n > 0) {
       const size_t bytes = tent_bytes((size_t)n);
-      if (used + bytes <= c->pin_arena_cap) {
+      if (filtered && direct) off[i] = seg[i];          // already in the arena
+      else if (used + bytes <= c->pin_arena_cap) {
         MODS_HIP_CHECK(hipMemcpyAsync(c->pin_arena + used, list, bytes, hipMemcpyDeviceToHost, c->stream));
         off[i] = used; used += (bytes + 15) & ~(size_t)15;
+        copies = true;
       } else {      // a list that does not fit the arena: the direct (pageable, synchronous) path
         std::vector<char> stage(bytes);
         MODS_HIP_CHECK(hipMemcpy(stage.data(), list, bytes, hipMemcpyDeviceToHost));
@@ -986,7 +994,7 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
       }
     }
   }
-  MODS_HIP_CHECK(mods::stream_wait(c->stream));
+  if (copies) MODS_HIP_CHECK(mods::stream_wait(c->stream));
   const double tm1 = now_ms();
   for (int i = 0; i < n_pairs; i++) {
     res[i]->ms_match = (tm1 - tm0) / n_pairs;
