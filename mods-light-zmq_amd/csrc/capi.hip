@@ -881,6 +881,7 @@ int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_pair_params
   int rc = mods_detect_describe_dev(c, c->input_dev, n_img, w, h, w, &par->det, &par->desc, nd.data(), nr.data());
   if (rc) return rc;
   const int last = n_img - 1;
+  if ((rc = match_ensure_buffers(c, std::min(16, std::max(1, n_img / 2))))) return rc;     // the searches of a batch's pairs run as one group
   if ((rc = match_run(c, c->regions_dev, nr[0], c->regions_dev + (size_t)last * c->max_cand, nr[last], par->fginn_ratio, par->contradDist, par->nn))) return rc;
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
@@ -940,17 +941,25 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
     c->m_tent_batch_cap = 2 * seg[n_pairs] + seg[n_pairs] / 2;
   }
   const double tm0 = now_ms();
-  for (int i = 0; i < n_pairs; i++) {
-    mods_pair_result *r = res[i];
-    r->n_detected[0] = nd[2 * i]; r->n_detected[1] = nd[2 * i + 1];
-    r->n_described[0] = nr[2 * i]; r->n_described[1] = nr[2 * i + 1];
-    r->ms_detect_describe = (t1 - t0) / n_pairs;
-    c->m_tent_out = (mods_tentative *)(c->m_tent_batch + seg[i]);
-    c->m_count_out = c->m_count + 1 + i;
-    rc = match_run(c, c->regions_dev + (size_t)(2 * i) * c->max_cand, nr[2 * i], c->regions_dev + (size_t)(2 * i + 1) * c->max_cand,
-                   nr[2 * i + 1], par->fginn_ratio, par->contradDist, par->nn);
-    c->m_tent_out = nullptr; c->m_count_out = nullptr;
-    if (rc) return rc;
+  // the searches of the batch's pairs in grouped launches (csrc/match.hip: match_run_group), up to 16 pairs per set of launches
+  for (int i0 = 0; i0 < n_pairs; i0 += 16) {
+    const int g = std::min(16, n_pairs - i0);
+    const mods_region *qv[16], *tv[16];
+    int nq[16], nt[16];
+    mods_tentative *to[16];
+    int *co[16];
+    for (int e = 0; e < g; e++) {
+      const int i = i0 + e;
+      mods_pair_result *r = res[i];
+      r->n_detected[0] = nd[2 * i]; r->n_detected[1] = nd[2 * i + 1];
+      r->n_described[0] = nr[2 * i]; r->n_described[1] = nr[2 * i + 1];
+      r->ms_detect_describe = (t1 - t0) / n_pairs;
+      qv[e] = c->regions_dev + (size_t)(2 * i) * c->max_cand; nq[e] = nr[2 * i];
+      tv[e] = c->regions_dev + (size_t)(2 * i + 1) * c->max_cand; nt[e] = nr[2 * i + 1];
+      to[e] = (mods_tentative *)(c->m_tent_batch + seg[i]);
+      co[e] = c->m_count + 1 + i;
+    }
+    if ((rc = match_run_group(c, g, qv, nq, tv, nt, to, co, par->fginn_ratio, par->contradDist, par->nn))) return rc;
   }
   if (dedup) {     // the lists of the whole batch through the device duplicate filter in one set of launches
     // when the batch's lists fit the pinned arena (they do unless the images are very large) the filter's compaction writes the

@@ -176,6 +176,7 @@ struct mods_ctx {
   void *m_mid = nullptr;
   void *m_p2 = nullptr;              // pass-1 top-2 keys per train split, pass-2 query subset (see match.hip)
   size_t m_best2_cap = 0;            // entries (pairs of keys) in the top-2 table
+  int m_sets = 0;                    // searches the matcher's scratch buffers hold side by side (match_ensure_buffers)
   mods_tentative *m_tent = nullptr;
   // m_tent holds the n tentatives of the last search PACKED: mods_tentative[n] | (16-byte aligned) u6[n][6] = the correspondences
   // (x1 y1 1 x2 y2 1) | laf[n][14] = the frames (x y a11 a12 a21 a22 s) of both regions - one device-to-host copy of
@@ -233,7 +234,9 @@ void mser_release(mods_ctx *ctx);
 int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double ratio,
               double contradDist, int nn);
 int match_run_distance(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double threshold);   // MatchFLANNDistance, Hamming
-int match_ensure_buffers(mods_ctx *ctx);
+int match_ensure_buffers(mods_ctx *ctx, int n_sets = 1);
+int match_run_group(mods_ctx *ctx, int n_jobs, const mods_region *const *q_dev, const int *n_q, const mods_region *const *t_dev, const int *n_t,
+                    mods_tentative *const *tent_out, int *const *count_out, double ratio, double contradDist, int nn);   // <= 16 searches in one set of launches
 
 // dedup.hip
 constexpr int DUP_MAX_JOBS = 64;

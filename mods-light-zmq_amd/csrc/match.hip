@@ -24,6 +24,7 @@
 // Trains are the MFMA rows (streamed), queries the columns (resident in registers), so every
 // lane reduces its 16 results per tile into per-query running values.
 #include "common.hpp"
+#include <type_traits>
 
 namespace mods {
 
@@ -37,6 +38,28 @@ struct MatchConst {
   int tiles_per_split;
   int max_distance;       // >= 0: MatchFLANNDistance (Hamming) decisions in the emit stage; -1: FGINN
 };
+
+// The searches of one grouped launch: blockIdx.y (blockIdx.z in the pack kernel) = search.  Every scratch buffer of the context
+// exists once per search of a group ("set"): set j = set 0 + j * stride, so a kernel takes the pointers of set 0 and moves them.
+// The pairs of a pipeline batch are matched in ONE set of launches (a 10 k x 9 k search fills 40 of the 256 CUs on its own, and
+// every dispatch costs the host a completion interrupt); a single search is a group of one.
+constexpr int MATCH_MAX_JOBS = 16;
+struct MatchJobs {
+  int n_jobs;
+  int n_q[MATCH_MAX_JOBS], n_t[MATCH_MAX_JOBS];
+  int tps[MATCH_MAX_JOBS], qblocks[MATCH_MAX_JOBS], splits[MATCH_MAX_JOBS];     // pass-1 geometry (nn1_grid)
+  int eblocks[MATCH_MAX_JOBS];                                                   // blocks of the emit stage
+  const mods_region *q_reg[MATCH_MAX_JOBS], *t_reg[MATCH_MAX_JOBS];
+  mods_tentative *tent_out[MATCH_MAX_JOBS];
+  int *count_out[MATCH_MAX_JOBS];
+  size_t s_desc, s_p2;                       // set strides in bytes (m_desc, m_p2)
+  size_t s_c, s_xy, s_u64, s_int, s_mid;     // set strides in elements of the buffer's type (m_c, m_xy, m_u64, m_int, m_mid)
+};
+template <class T> __device__ __forceinline__ T *set_el(T *p, int job, size_t stride) { return p + (size_t)job * stride; }
+template <class T> __device__ __forceinline__ T *set_by(T *p, int job, size_t stride_bytes) {
+  typedef typename std::conditional<std::is_const<T>::value, const char, char>::type C;
+  return (T *)((C *)p + (size_t)job * stride_bytes);
+}
 
 // Accumulator seed of a train row: acc = dot - floor(ct/2) + MATCH_BIAS.  dot lies in [-2^21, 2^21] and ct in [2^21, 2^22], so the
 // seeded accumulators of real rows lie in [1, 5*2^20 + 1] (23 bits, never negative); the rows past the end of the list inside the last
@@ -79,13 +102,18 @@ __global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__re
 // Both lists of a search in ONE launch (blockIdx.y = list), which also does what match_init_kernel did: a wave packs 32
 // consecutive regions - one tile of the distance kernels - and WRITES the tile's parity word (the single-list kernel ORs bits into
 // words that a launch before it had to clear), block (0, 0) clears the two counters of the search.  Three dispatches fewer per search.
-// grid = (ceil(max(n_q, n_t) / 32 / 4), 2), block 256
+// grid = (ceil(max(n_q, n_t) / 32 / 4), 2, searches), block 256
 struct PackList { const mods_region *reg; int n; int8_t *desc; int *cvec; int *c2neg; unsigned int *parity; double2 *xy; };
-__global__ __launch_bounds__(256) void match_pack2_kernel(PackList lq, PackList lt, int max_n, int *__restrict__ m_count, int *__restrict__ count2) {
-  const PackList L = blockIdx.y == 0 ? lq : lt;
+__global__ __launch_bounds__(256) void match_pack2_kernel(MatchJobs J, PackList lq, PackList lt, int max_n, int *__restrict__ count2) {
+  const int job = blockIdx.z;
+  PackList L = blockIdx.y == 0 ? lq : lt;       // (reg and n of the lists come from the job table)
+  L.reg = blockIdx.y == 0 ? J.q_reg[job] : J.t_reg[job];
+  L.n = blockIdx.y == 0 ? J.n_q[job] : J.n_t[job];
+  L.desc = set_by(L.desc, job, J.s_desc); L.cvec = set_el(L.cvec, job, J.s_c); L.c2neg = set_el(L.c2neg, job, J.s_c);
+  L.parity = set_el(L.parity, job, J.s_c); L.xy = set_el(L.xy, job, J.s_xy);
   const int n = min(L.n, max_n);
   const int lane = threadIdx.x & 63;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { *m_count = 0; *count2 = 0; }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { *J.count_out[job] = 0; *set_by(count2, job, J.s_p2) = 0; }
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile * 32 >= n) return;
   unsigned int par = 0;
@@ -298,10 +326,15 @@ __device__ __forceinline__ void nn1_step(Nn1State &st, v16i (&accW)[MATCH_QB1], 
 // Workgroup -> (query block, split): with a split count that is a multiple of 8, the workgroups that the dispatcher places on one
 // XCD (linear id mod 8) share that XCD's train splits (split mod 8 = XCD), so an XCD's L2 holds one eighth of the train list
 // instead of all of it; any other placement is only slower.
-__global__ __launch_bounds__(NN1_THREADS) __attribute__((amdgpu_waves_per_eu(NN1_WAVES / 4, NN1_WAVES / 4))) void match_nn1_kernel(MatchConst k, int qblocks, int splits,
+__global__ __launch_bounds__(NN1_THREADS) __attribute__((amdgpu_waves_per_eu(NN1_WAVES / 4, NN1_WAVES / 4))) void match_nn1_kernel(MatchJobs J, MatchConst k,
                                                         const int8_t *__restrict__ qdesc, const int8_t *__restrict__ tdesc,
                                                         const int *__restrict__ tc2n, uint4 *__restrict__ best3) {
   constexpr int QB = MATCH_QB1;
+  const int job = blockIdx.y;
+  const int qblocks = J.qblocks[job], splits = J.splits[job];
+  if ((int)blockIdx.x >= qblocks * splits) return;        // (the grid is sized for the largest search of the group)
+  k.n_q = J.n_q[job]; k.n_t = J.n_t[job]; k.tiles_per_split = J.tps[job];
+  qdesc = set_by(qdesc, job, J.s_desc); tdesc = set_by(tdesc, job, J.s_desc); tc2n = set_el(tc2n, job, J.s_c); best3 = set_by(best3, job, J.s_p2);
   static_assert(QB == 4 && NN1_NBUF == 4, "nn1_step is laid out for four query blocks and a ring of four images");
   if (NN1_WAVES == 4) own_simd_512(); else own_simd_256();
   const int lane = threadIdx.x & 63, g = lane >> 5;
@@ -403,11 +436,18 @@ __device__ __forceinline__ void top2_min_insert(unsigned long long &k1, unsigned
   k2 = first ? k1 : (key < k2 ? key : k2);
   k1 = first ? key : k1;
 }
-__global__ __launch_bounds__(256) void match_fix_kernel(MatchConst k, int splits, size_t n_qpad, const uint4 *__restrict__ best3,
+__global__ __launch_bounds__(256) void match_fix_kernel(MatchJobs J, MatchConst k, const uint4 *__restrict__ best3,
                                                         const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                         const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
                                                         unsigned long long *__restrict__ best2) {
   __shared__ int s_cand[8][FIX_MAXC];
+  const int job = blockIdx.y;
+  k.n_q = J.n_q[job]; k.n_t = J.n_t[job]; k.tiles_per_split = J.tps[job];
+  if ((int)blockIdx.x * 8 >= k.n_q) return;
+  const int splits = J.splits[job];
+  const size_t n_qpad = (size_t)J.qblocks[job] * (32 * NN1_WAVES) * MATCH_QB1;
+  best3 = set_by(best3, job, J.s_p2); best2 = set_by(best2, job, J.s_p2);
+  qdesc = set_by(qdesc, job, J.s_desc); tdesc = set_by(tdesc, job, J.s_desc); qc = set_el(qc, job, J.s_c); tc = set_el(tc, job, J.s_c);
   const int lane = threadIdx.x & 63, hl = lane & 31, hw = threadIdx.x >> 5;
   const int hshift = lane & 32;             // this half-wave's bits of a ballot
   const int j = blockIdx.x * 8 + hw;
@@ -502,11 +542,17 @@ __device__ __forceinline__ bool ratio_ok(int d0, int d, double sqmin) {
 //   d1 <  D*, t1 far from i0       a contradicting neighbour below D*: bad, rejected whatever the other trains are
 //   d1 <  D*, t1 near i0           undecided: the query goes on the pass-2 list (descriptor, norm and state are copied to the
 //                                  compact arrays by match_gather_kernel)
-__global__ __launch_bounds__(256) void match_mid_kernel(MatchConst k, const unsigned long long *__restrict__ best2, int splits, size_t n_qpad,
+__global__ __launch_bounds__(256) void match_mid_kernel(MatchJobs J, MatchConst k, const unsigned long long *__restrict__ best2,
                                                         const double2 *__restrict__ txy, QueryMid *__restrict__ mid,
                                                         unsigned long long *__restrict__ key_ge, unsigned long long *__restrict__ key_lt,
                                                         int *__restrict__ n_lt, int *__restrict__ bad, int *__restrict__ list2,
                                                         int *__restrict__ count2) {
+  const int job = blockIdx.y;
+  k.n_q = J.n_q[job]; k.n_t = J.n_t[job];
+  const int splits = 1; const size_t n_qpad = (size_t)k.n_q;     // (the finish kernel leaves one exact pair of keys per query)
+  best2 = set_by(best2, job, J.s_p2); list2 = set_by(list2, job, J.s_p2); count2 = set_by(count2, job, J.s_p2);
+  txy = set_el(txy, job, J.s_xy); mid = set_el(mid, job, J.s_mid);
+  key_ge = set_el(key_ge, job, J.s_u64); key_lt = set_el(key_lt, job, J.s_u64); n_lt = set_el(n_lt, job, J.s_int); bad = set_el(bad, job, J.s_int);
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= k.n_q) return;
   unsigned long long m1 = ~0ull, m2 = ~0ull;
@@ -549,10 +595,14 @@ __global__ __launch_bounds__(256) void match_mid_kernel(MatchConst k, const unsi
 }
 
 // one wave per pass-2 query: descriptor row, norm and state into the compact arrays.  grid = ceil(n_q/4), block 256.
-__global__ __launch_bounds__(256) void match_gather_kernel(const int *__restrict__ list2, const int *__restrict__ count2,
+__global__ __launch_bounds__(256) void match_gather_kernel(MatchJobs J, const int *__restrict__ list2, const int *__restrict__ count2,
                                                            const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                            const QueryMid *__restrict__ mid, int8_t *__restrict__ qdesc2,
                                                            int *__restrict__ qc2, QueryMid *__restrict__ mid2) {
+  const int job = blockIdx.y;
+  list2 = set_by(list2, job, J.s_p2); count2 = set_by(count2, job, J.s_p2); qdesc2 = set_by(qdesc2, job, J.s_p2);
+  qc2 = set_by(qc2, job, J.s_p2); mid2 = set_by(mid2, job, J.s_p2);
+  qdesc = set_by(qdesc, job, J.s_desc); qc = set_el(qc, job, J.s_c); mid = set_el(mid, job, J.s_mid);
   const int n2 = *count2;
   const int lane = threadIdx.x & 63;
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n2; i += gridDim.x * 4) {
@@ -564,7 +614,7 @@ __global__ __launch_bounds__(256) void match_gather_kernel(const int *__restrict
 
 // Pass 2: FGINN reductions.  Same tiling and the same two-speed epilogue as pass 1: a tile is examined exactly
 // only when one of its partial distances lies below max(D*, smallest distance >= D* found so far).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_fginn_kernel(MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void match_fginn_kernel(MatchJobs J, MatchConst k, const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
                                                           const int8_t *__restrict__ tdesc, const int *__restrict__ tc,
                                                           const int *__restrict__ tc2n, const unsigned int *__restrict__ tpar,
                                                           const double2 *__restrict__ txy, const QueryMid *__restrict__ mid,
@@ -573,6 +623,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                           const int *__restrict__ n_q_dev, const int *__restrict__ out_index) {
   constexpr int QB = MATCH_QB;
   own_simd_512();
+  {
+    const int job = blockIdx.y;
+    k.n_t = J.n_t[job];
+    qdesc = set_by(qdesc, job, J.s_p2); qc = set_by(qc, job, J.s_p2); mid = set_by(mid, job, J.s_p2);
+    n_q_dev = set_by(n_q_dev, job, J.s_p2); out_index = set_by(out_index, job, J.s_p2);
+    tdesc = set_by(tdesc, job, J.s_desc); tc = set_el(tc, job, J.s_c); tc2n = set_el(tc2n, job, J.s_c); tpar = set_el(tpar, job, J.s_c);
+    txy = set_el(txy, job, J.s_xy);
+    key_ge = set_el(key_ge, job, J.s_u64); key_lt = set_el(key_lt, job, J.s_u64); n_lt = set_el(n_lt, job, J.s_int); bad = set_el(bad, job, J.s_int);
+  }
   // the query list of this pass is the compact list of match_mid_kernel: its length lives on the device, and results go to
   // the slots of the original queries
   // the grid is ONE row of workgroups: the few query blocks the compact list fills share it, each with as many train splits
@@ -724,30 +783,43 @@ __device__ __forceinline__ bool fginn_accept(const MatchConst &k, int j, const Q
   return true;
 }
 
-__global__ __launch_bounds__(1024) void match_emit_count_kernel(MatchConst k, const QueryMid *__restrict__ mid,
+__global__ __launch_bounds__(1024) void match_emit_count_kernel(MatchJobs J, MatchConst k, const QueryMid *__restrict__ mid,
                                                                 const unsigned long long *__restrict__ key_ge,
                                                                 const unsigned long long *__restrict__ key_lt, const int *__restrict__ n_lt,
                                                                 const int *__restrict__ bad, int *__restrict__ block_counts) {
+  const int job = blockIdx.y;
+  if ((int)blockIdx.x >= J.eblocks[job]) return;
+  k.n_q = J.n_q[job]; k.n_t = J.n_t[job];
+  mid = set_el(mid, job, J.s_mid); key_ge = set_el(key_ge, job, J.s_u64); key_lt = set_el(key_lt, job, J.s_u64);
+  n_lt = set_el(n_lt, job, J.s_int); bad = set_el(bad, job, J.s_int); block_counts = set_el(block_counts, job, J.s_int);
   mods_tentative tc;
   const bool emit = fginn_accept(k, blockIdx.x * 1024 + threadIdx.x, mid, key_ge, key_lt, n_lt, bad, &tc);
   const int c = __syncthreads_count(emit ? 1 : 0);
   if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
 }
 
-__global__ __launch_bounds__(1024) void match_emit_kernel(MatchConst k, const QueryMid *__restrict__ mid,
+__global__ __launch_bounds__(1024) void match_emit_kernel(MatchJobs J, MatchConst k, const QueryMid *__restrict__ mid,
                                                           const unsigned long long *__restrict__ key_ge,
                                                           const unsigned long long *__restrict__ key_lt, const int *__restrict__ n_lt,
                                                           const int *__restrict__ bad, const double2 *__restrict__ qxy,
-                                                          const double2 *__restrict__ txy, const mods_region *__restrict__ qreg,
-                                                          const mods_region *__restrict__ treg, const int *__restrict__ block_counts,
-                                                          mods_tentative *__restrict__ out, int *__restrict__ out_count, int max_out) {
+                                                          const double2 *__restrict__ txy, const int *__restrict__ block_counts, int max_out) {
   __shared__ int s_wave[16], s_wtot[16];
   __shared__ int s_base, s_total;
+  const int job = blockIdx.y;
+  const int n_blocks = J.eblocks[job];
+  if ((int)blockIdx.x >= n_blocks) return;
+  k.n_q = J.n_q[job]; k.n_t = J.n_t[job];
+  mid = set_el(mid, job, J.s_mid); key_ge = set_el(key_ge, job, J.s_u64); key_lt = set_el(key_lt, job, J.s_u64);
+  n_lt = set_el(n_lt, job, J.s_int); bad = set_el(bad, job, J.s_int); block_counts = set_el(block_counts, job, J.s_int);
+  qxy = set_el(qxy, job, J.s_xy); txy = set_el(txy, job, J.s_xy);
+  const mods_region *__restrict__ qreg = J.q_reg[job], *__restrict__ treg = J.t_reg[job];
+  mods_tentative *__restrict__ out = J.tent_out[job];
+  int *__restrict__ out_count = J.count_out[job];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // offset of this block = accepted queries of all earlier blocks; the total fixes the packed layout of the output
   // (tentatives | correspondences | frames, see common.hpp)
   int part = 0, tot = 0;
-  for (int q = tid; q < (int)gridDim.x; q += 1024) { const int c = block_counts[q]; tot += c; if (q < (int)blockIdx.x) part += c; }
+  for (int q = tid; q < n_blocks; q += 1024) { const int c = block_counts[q]; tot += c; if (q < (int)blockIdx.x) part += c; }
   for (int off = 32; off > 0; off >>= 1) { part += __shfl_xor(part, off); tot += __shfl_xor(tot, off); }
   if (lane == 0) { s_wave[wv] = part; s_wtot[wv] = tot; }
   __syncthreads();
@@ -779,7 +851,7 @@ __global__ __launch_bounds__(1024) void match_emit_kernel(MatchConst k, const Qu
       f[7] = r2.x; f[8] = r2.y; f[9] = r2.a11; f[10] = r2.a12; f[11] = r2.a21; f[12] = r2.a22; f[13] = r2.s;
     }
   }
-  if (blockIdx.x == gridDim.x - 1 && tid == 0) {   // total = offset of the last block + its own count
+  if ((int)blockIdx.x == n_blocks - 1 && tid == 0) {   // total = offset of the last block + its own count
     int t = base;
     for (int q = 0; q < 16; q++) t += s_wave[q];
     *out_count = t;
@@ -820,16 +892,31 @@ static Nn1Grid nn1_grid(int n_q, int n_t) {
   return gr;
 }
 
-int match_ensure_buffers(mods_ctx *ctx) {
-  if (ctx->m_desc) return MODS_OK;
+// set strides of the matcher's scratch buffers (MatchJobs)
+static void match_strides(const mods_ctx *ctx, MatchJobs *J) {
   const size_t n = match_pad(ctx);
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_desc, 2 * n * 128));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_c, (4 * n + 2 * (n / 32 + 2)) * sizeof(int)));   // c of queries, trains; seeds of both; parity words of both
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_regs, 2 * (size_t)ctx->max_cand * sizeof(mods_region)));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_xy, 2 * n * sizeof(double2)));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_u64, 3 * n * sizeof(unsigned long long)));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_int, (2 * n + n / 1024 + 2) * sizeof(int)));   // n_lt, bad, per-block counts of the compaction
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_mid, n * sizeof(QueryMid)));
+  J->s_desc = 2 * n * 128;
+  J->s_c = 4 * n + 2 * (n / 32 + 2);
+  J->s_xy = 2 * n;
+  J->s_u64 = 3 * n;
+  J->s_int = 2 * n + n / 1024 + 2;
+  J->s_mid = n;
+  J->s_p2 = (ctx->m_best2_cap * 16 + n * 16 + n * (3 * sizeof(int) + 128 + sizeof(QueryMid)) + 128 + 255) & ~(size_t)255;
+}
+
+// n_sets: searches a grouped launch may hold (the pairs of a pipeline batch); growing the sets reallocates, so the pipeline's warm-up
+// asks for what its batches need
+int match_ensure_buffers(mods_ctx *ctx, int n_sets) {
+  if (n_sets < 1) n_sets = 1;
+  if (n_sets > MATCH_MAX_JOBS) n_sets = MATCH_MAX_JOBS;
+  if (ctx->m_desc && ctx->m_sets >= n_sets) return MODS_OK;
+  const size_t n = match_pad(ctx);
+  if (ctx->m_desc) {        // more sets than before: the per-search scratch is reallocated (nothing in it outlives a search)
+    MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
+    MODS_HIP_CHECK(hipFree(ctx->m_desc)); MODS_HIP_CHECK(hipFree(ctx->m_c)); MODS_HIP_CHECK(hipFree(ctx->m_xy)); MODS_HIP_CHECK(hipFree(ctx->m_u64));
+    MODS_HIP_CHECK(hipFree(ctx->m_int)); MODS_HIP_CHECK(hipFree(ctx->m_mid)); MODS_HIP_CHECK(hipFree(ctx->m_p2));
+    ctx->m_desc = nullptr; ctx->m_c = nullptr; ctx->m_xy = nullptr; ctx->m_u64 = nullptr; ctx->m_int = nullptr; ctx->m_mid = nullptr; ctx->m_p2 = nullptr;
+  }
   // pass-1 key table (one 16-byte triple per query and train split): the largest product splits * padded queries over the list
   // sizes this context admits (the split count grows with the train list, so only the query count is scanned)
   {
@@ -840,14 +927,25 @@ int match_ensure_buffers(mods_ctx *ctx) {
     }
     ctx->m_best2_cap = cap;
   }
+  MatchJobs st;
+  match_strides(ctx, &st);
+  const size_t S = (size_t)n_sets;
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_desc, S * st.s_desc));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_c, S * st.s_c * sizeof(int)));   // c of queries, trains; seeds of both; parity words of both
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_xy, S * st.s_xy * sizeof(double2)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_u64, S * st.s_u64 * sizeof(unsigned long long)));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_int, S * st.s_int * sizeof(int)));   // n_lt, bad, per-block counts of the compaction
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_mid, S * st.s_mid * sizeof(QueryMid)));
   // m_p2: key table | exact top-2 per query | pass-2 subset: state, descriptors, list, norms, count
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_p2, ctx->m_best2_cap * 16 + n * 16 + n * (3 * sizeof(int) + 128 + sizeof(QueryMid)) + 128));
-  MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, tent_bytes(n) + 64));
+  MODS_HIP_CHECK(hipMalloc(&ctx->m_p2, S * st.s_p2));
+  if (!ctx->m_regs) MODS_HIP_CHECK(hipMalloc(&ctx->m_regs, 2 * (size_t)ctx->max_cand * sizeof(mods_region)));
+  if (!ctx->m_tent) MODS_HIP_CHECK(hipMalloc(&ctx->m_tent, tent_bytes(n) + 64));
   // the tentative count lives in pinned host memory: the emit kernel's single store lands there, the host reads it after a
   // stream synchronisation - no 4-byte copy launch per search
-  MODS_HIP_CHECK(hipHostMalloc(&ctx->m_count, 192 * sizeof(int)));   // [0]: the last search; [i]: pair i of a batch (m_count_out)
-  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_desc, 0, 2 * n * 128, ctx->stream));
-  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_c, 0, 4 * n * sizeof(int), ctx->stream));
+  if (!ctx->m_count) MODS_HIP_CHECK(hipHostMalloc(&ctx->m_count, 192 * sizeof(int)));   // [0]: the last search; [i]: pair i of a batch (m_count_out)
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_desc, 0, S * st.s_desc, ctx->stream));
+  MODS_HIP_CHECK(hipMemsetAsync(ctx->m_c, 0, S * st.s_c * sizeof(int), ctx->stream));
+  ctx->m_sets = n_sets;
   return MODS_OK;
 }
 
@@ -861,23 +959,41 @@ __global__ __launch_bounds__(256) void match_init_kernel(int n_q, int n_t, int *
   if (i <= n_t / 32) tpar[i] = 0u;
 }
 
-// queries / trains: device region lists with host-known sizes n_q, n_t.
-int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double ratio,
-              double contradDist, int nn) {
-  int rc = match_ensure_buffers(ctx);
+// n_jobs searches (queries / trains: device region lists with host-known sizes) in one set of launches; search j leaves its packed
+// list at tent_out[j] and its length at *count_out[j] (pinned host memory).
+int match_run_group(mods_ctx *ctx, int n_jobs, const mods_region *const *q_dev, const int *n_q, const mods_region *const *t_dev, const int *n_t,
+                    mods_tentative *const *tent_out, int *const *count_out, double ratio, double contradDist, int nn) {
+  if (n_jobs < 1 || n_jobs > MATCH_MAX_JOBS) { set_error("match: %d searches in a group", n_jobs); return MODS_E_ARG; }
+  int rc = match_ensure_buffers(ctx, n_jobs);
   if (rc) return rc;
-  if (n_q > ctx->max_cand || n_t > ctx->max_cand) { set_error("match: list larger than the context capacity"); return MODS_E_CAPACITY; }
   MatchConst k;
-  k.n_q = n_q; k.n_t = n_t; k.nn = nn;
+  k.n_q = 0; k.n_t = 0; k.nn = nn;
   k.max_distance = -1;
   k.tiles_per_split = 0;
   k.sqminratio = ratio * ratio;
   k.contr_sq = contradDist * contradDist;
   if (!(k.sqminratio < 1.0)) { set_error("FGINN ratio >= 1 (all-neighbours mode) is not supported"); return MODS_E_ARG; }
-  // where the packed list and its length go: the context's own buffer / counter, or what a batch of pairs set (capi.hip: match_pairs)
-  mods_tentative *tent_out = ctx->m_tent_out ? ctx->m_tent_out : ctx->m_tent;
-  int *count_out = ctx->m_count_out ? ctx->m_count_out : ctx->m_count;
-  if (n_q == 0 || n_t == 0) { MODS_HIP_CHECK(hipMemsetAsync(count_out, 0, sizeof(int), ctx->stream)); return MODS_OK; }
+  MatchJobs J;
+  memset(&J, 0, sizeof(J));
+  match_strides(ctx, &J);
+  J.n_jobs = n_jobs;
+  int max_q = 0, max_t = 0, max_nn1 = 0, max_eb = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    if (n_q[j] > ctx->max_cand || n_t[j] > ctx->max_cand) { set_error("match: list larger than the context capacity"); return MODS_E_CAPACITY; }
+    const bool empty = n_q[j] <= 0 || n_t[j] <= 0;      // an empty search: every kernel passes it by, the pack kernel leaves its count at 0
+    J.n_q[j] = empty ? 0 : n_q[j]; J.n_t[j] = empty ? 0 : n_t[j];
+    J.q_reg[j] = q_dev[j]; J.t_reg[j] = t_dev[j];
+    J.tent_out[j] = tent_out[j]; J.count_out[j] = count_out[j];
+    if (empty) continue;
+    // pass 1: the three largest half-tile maxima per query and train split, then the exact two nearest trains per query
+    const Nn1Grid gr = nn1_grid(n_q[j], n_t[j]);
+    if ((size_t)gr.splits * gr.n_qpad > ctx->m_best2_cap) { set_error("match: pass-1 key table too small"); return MODS_E_CAPACITY; }
+    J.tps[j] = gr.tiles_per_split; J.qblocks[j] = gr.qblocks; J.splits[j] = gr.splits;
+    J.eblocks[j] = (n_q[j] + 1023) / 1024;
+    max_q = std::max(max_q, n_q[j]); max_t = std::max(max_t, n_t[j]);
+    max_nn1 = std::max(max_nn1, gr.qblocks * gr.splits); max_eb = std::max(max_eb, J.eblocks[j]);
+  }
+  const unsigned G = (unsigned)n_jobs;
   const size_t n = match_pad(ctx);
   int8_t *qd = ctx->m_desc, *td = ctx->m_desc + n * 128;
   int *qc = ctx->m_c, *tc = ctx->m_c + n, *qc2 = ctx->m_c + 2 * n, *tc2 = ctx->m_c + 3 * n;
@@ -893,32 +1009,42 @@ int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_regio
   int8_t *qd2 = (int8_t *)(mid2 + n);
   int *list2 = (int *)(qd2 + n * 128), *qcs = list2 + n, *count2 = qcs + n;
   {
-    const PackList lq = {q_dev, n_q, qd, qc, qc2, qpar, qxy}, lt = {t_dev, n_t, td, tc, tc2, tpar, txy};
-    hipLaunchKernelGGL(match_pack2_kernel, dim3((std::max(n_q, n_t) + 127) / 128, 2), dim3(256), 0, ctx->stream, lq, lt, ctx->max_cand, count_out, count2);
+    const PackList lq = {nullptr, 0, qd, qc, qc2, qpar, qxy}, lt = {nullptr, 0, td, tc, tc2, tpar, txy};
+    hipLaunchKernelGGL(match_pack2_kernel, dim3((std::max(std::max(max_q, max_t), 1) + 127) / 128, 2, G), dim3(256), 0, ctx->stream, J, lq, lt, ctx->max_cand, count2);
   }
-  // pass 1: the three largest half-tile maxima per query and train split, then the exact two nearest trains per query
-  const Nn1Grid gr = nn1_grid(n_q, n_t);
-  MatchConst k1 = k;
-  k1.tiles_per_split = gr.tiles_per_split;
-  if ((size_t)gr.splits * gr.n_qpad > ctx->m_best2_cap) { set_error("match: pass-1 key table too small"); return MODS_E_CAPACITY; }
-  hipLaunchKernelGGL(match_nn1_kernel, dim3(gr.qblocks * gr.splits), dim3(NN1_THREADS), 0, ctx->stream, k1, gr.qblocks, gr.splits, qd, td, tc2, best3);
-  hipLaunchKernelGGL(match_fix_kernel, dim3((n_q + 7) / 8), dim3(256), 0, ctx->stream, k1, gr.splits, gr.n_qpad, (const uint4 *)best3, qd, qc, td, tc, best2);
-  hipLaunchKernelGGL(match_mid_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, (const unsigned long long *)best2, 1, (size_t)n_q, txy,
-                     (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, list2, count2);
-  // pass 2 on the undecided queries only (their number stays on the device: the grid covers the worst case, idle blocks exit)
-  hipLaunchKernelGGL(match_gather_kernel, dim3(std::min(1024, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, list2, count2, qd, qc,
-                     (const QueryMid *)ctx->m_mid, qd2, qcs, mid2);
-  {
-    const int qblocks = (n_q + 128 * MATCH_QB - 1) / (128 * MATCH_QB);
-    hipLaunchKernelGGL(match_fginn_kernel, dim3(std::max(FGINN_BLOCKS, qblocks)), dim3(256), 0, ctx->stream, k, qd2, qcs, td, tc, tc2, tpar, txy,
-                       (const QueryMid *)mid2, key_ge, key_lt, n_lt, bad, count2, list2);
+  if (max_q > 0) {
+    hipLaunchKernelGGL(match_nn1_kernel, dim3(max_nn1, G), dim3(NN1_THREADS), 0, ctx->stream, J, k, qd, td, tc2, best3);
+    hipLaunchKernelGGL(match_fix_kernel, dim3((max_q + 7) / 8, G), dim3(256), 0, ctx->stream, J, k, (const uint4 *)best3, qd, qc, td, tc, best2);
+    hipLaunchKernelGGL(match_mid_kernel, dim3((max_q + 255) / 256, G), dim3(256), 0, ctx->stream, J, k, (const unsigned long long *)best2, txy,
+                       (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, list2, count2);
+    // pass 2 on the undecided queries only (their number stays on the device: the grid covers the worst case, idle blocks exit)
+    hipLaunchKernelGGL(match_gather_kernel, dim3(std::min(1024, (max_q + 3) / 4), G), dim3(256), 0, ctx->stream, J, list2, count2, qd, qc,
+                       (const QueryMid *)ctx->m_mid, qd2, qcs, mid2);
+    {
+      const int qblocks = (max_q + 128 * MATCH_QB - 1) / (128 * MATCH_QB);
+      // (a group shares the chip: a single search gets the whole row of workgroups, the searches of a group their share of it)
+      const int row = std::max(std::max(FGINN_BLOCKS / n_jobs, 64), qblocks);
+      hipLaunchKernelGGL(match_fginn_kernel, dim3(row, G), dim3(256), 0, ctx->stream, J, k, qd2, qcs, td, tc, tc2, tpar, txy,
+                         (const QueryMid *)mid2, key_ge, key_lt, n_lt, bad, count2, list2);
+    }
+    int *block_counts = (int *)(ctx->m_int + 2 * n);
+    hipLaunchKernelGGL(match_emit_count_kernel, dim3(max_eb, G), dim3(1024), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
+    hipLaunchKernelGGL(match_emit_kernel, dim3(max_eb, G), dim3(1024), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy,
+                       block_counts, ctx->max_cand);
   }
-  const int eblocks = (n_q + 1023) / 1024;
-  int *block_counts = (int *)(ctx->m_int + 2 * n);
-  hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
-  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, tent_out, count_out, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
+}
+
+// queries / trains: device region lists with host-known sizes n_q, n_t.
+int match_run(mods_ctx *ctx, const mods_region *q_dev, int n_q, const mods_region *t_dev, int n_t, double ratio,
+              double contradDist, int nn) {
+  int rc = match_ensure_buffers(ctx);
+  if (rc) return rc;
+  // where the packed list and its length go: the context's own buffer / counter, or what a batch of pairs set (capi.hip: match_pairs)
+  mods_tentative *tent_out = ctx->m_tent_out ? ctx->m_tent_out : ctx->m_tent;
+  int *count_out = ctx->m_count_out ? ctx->m_count_out : ctx->m_count;
+  return match_run_group(ctx, 1, &q_dev, &n_q, &t_dev, &n_t, &tent_out, &count_out, ratio, contradDist, nn);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -987,8 +1113,13 @@ int match_run_distance(mods_ctx *ctx, const mods_region *q_dev, int n_q, const m
   hipLaunchKernelGGL(hamming_nn2_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, qd, td, (QueryMid *)ctx->m_mid, key_ge);
   const int eblocks = (n_q + 1023) / 1024;
   int *block_counts = (int *)(ctx->m_int + 2 * n);
-  hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
-  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, q_dev, t_dev, block_counts, ctx->m_tent, ctx->m_count, ctx->max_cand);
+  MatchJobs J;
+  memset(&J, 0, sizeof(J));
+  match_strides(ctx, &J);
+  J.n_jobs = 1; J.n_q[0] = n_q; J.n_t[0] = n_t; J.eblocks[0] = eblocks;
+  J.q_reg[0] = q_dev; J.t_reg[0] = t_dev; J.tent_out[0] = ctx->m_tent; J.count_out[0] = ctx->m_count;
+  hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, block_counts, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }
