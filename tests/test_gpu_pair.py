@@ -219,6 +219,35 @@ def test_pipeline_with_f_verification_equals_serial(pkg):
     pipe.close(); ctx.close()
 
 
+def test_grouped_search_with_an_empty_list(pkg):
+    """The searches of a batch's pairs run as one group of launches (match_run_group): pairs of different sizes side by side, one of
+    them with an image that has no regions at all (an empty search inside the group), against one call per pair."""
+    import torch
+    w, h = 640, 480
+    pairs = [synth.pair(w, h, seed=70 + i)[:2] for i in range(3)]
+    flat = np.full((h, w), 93.0, np.float32)
+    pairs.insert(1, (pairs[0][0], flat))          # nothing to detect in image 2
+    pairs.append((flat, pairs[2][1]))             # nothing to detect in image 1
+    dev = [torch.from_numpy(np.stack([a, b])).cuda() for a, b in pairs]
+    torch.cuda.synchronize()
+    par = pkg.PairParams.default()
+    pkg.ransac_pin_seed(7)
+    ctx = pkg.Context(0, w, h, 2)
+    want = [pkg.match_pair_dev(ctx, d.data_ptr(), w, h, par)[0] for d in dev]
+    assert want[1].n_tentatives == 0 and want[4].n_tentatives == 0 and want[0].n_inliers > 15
+    pipe = pkg.Pipeline(0, w, h, par, 1, 2, 5)
+    for rep in range(2):
+        for i, d in enumerate(dev):
+            pipe.submit(d.data_ptr(), i)
+        for i in range(len(dev)):
+            res, tag = pipe.next()
+            assert tag == i
+            for f in ("n_tentatives", "n_unique", "n_inliers", "ransac_samples"):
+                assert getattr(res, f) == getattr(want[i], f), (f, i, rep)
+            assert list(res.n_described) == list(want[i].n_described) and list(res.H) == list(want[i].H)
+    pipe.close(); ctx.close()
+
+
 @pytest.mark.parametrize("mode", ["spin", "sleep:200"])
 def test_pipeline_wait_modes(pkg, mode, monkeypatch):
     """MODS_SYNC: the pipeline's threads wait for their streams by sleeping polls (default) or with the runtime's spinning
