@@ -46,19 +46,30 @@ __device__ __forceinline__ float peak_angle(const float *s_hist, int b) {
   const float pp = (ha - hc) / (ha - 2.0f * hb + hc) / 2.0f;
   return 2.0f * PIf * (b + 0.5f + pp) / bins - PIf;
 }
-__device__ bool dominant_angle_wave(const float *s_patch, const float *__restrict__ orimask, int ps, double th,
+// The histogram is an ORDERED sum per bin (votes in raster order).  Round 3 let 36 lanes scan every vote (three vector instructions
+// per vote and keypoint: half of this kernel's instructions, and the kernel is VALU-issue bound); now every vote is filed into its
+// bin's list first and a lane adds its own bin's ~20 votes only:
+//   pass 1, per 64 raster-consecutive pixels: the lanes that vote for the same bin find each other (six ballots over the bits of
+//           the bin number), a lane's place in its bin's list = the bin's count so far + its rank among those lanes; the last lane of
+//           a group writes the new count (one writer per bin: no conflict, and the wave's LDS accesses execute in program order);
+//   then    the bins' list offsets (a prefix over 36 counts), the values scattered into the lists (the patch array is dead by then
+//           and holds them), and lane b adds list b front to back - the same additions in the same order as the scan made (the scan
+//           added +0.0f for every vote of another bin, which leaves a non-negative running sum unchanged).
+// s_key: one 16-bit word per pixel (bin | place << 6; bin 63 = no vote), s_cnt / s_off: 64 ints each behind the histogram.
+__device__ bool dominant_angle_wave(float *s_patch, const float *__restrict__ orimask, int ps, double th,
                                     float *s_val, unsigned char *s_bin, float *s_hist, float *angle_out, int half = 0,
                                     unsigned long long *peaks_out = nullptr) {
   const int lane = threadIdx.x;
   const int bins = 36;
   const float PIf = 3.14159265358979323846f;
   const int n = ps * (ps - 2);
-  // pixels that cast a vote are compacted in raster order (a pixel without a vote would add +0.0f to every bin: skipping it
-  // changes nothing); the list is padded to a multiple of 16 with bin 255 (no bin), the scan below takes 16 votes per step
-  int n_votes = 0;
+  unsigned short *s_key = (unsigned short *)s_bin;
+  int *s_cnt = (int *)(s_hist + 48), *s_off = s_cnt + 64;
+  s_cnt[lane] = 0;
+  __syncthreads();
   for (int p0 = 0; p0 < n; p0 += 64) {
     const int p = p0 + lane;
-    int bin = 255;
+    int bin = 63;
     float v = 0.f;
     if (p < n) {
       const int r = 1 + p / ps, c = p - (r - 1) * ps;
@@ -71,57 +82,41 @@ __device__ bool dominant_angle_wave(const float *s_patch, const float *__restric
       const float m = orimask[r * ps + c];
       const float mag = inner ? sqrtf(xgrad * xgrad + ygrad * ygrad) : 0.f;
       const int obin = as.zero ? (int)(bins * (0.f / PIf + 1.0f) / 2.0f) : tbin;
-      if (m > 0 && (double)mag > 1.0) {
+      if (m > 0 && (double)mag > 1.0 && obin < bins) {      // (bin 36 is write-only in the reference)
         bin = obin;
         v = mag * m;
       }
     }
-    const bool vote = bin != 255;
-    const unsigned long long vm = __ballot(vote);
-    if (vote) {
-      const int pos = n_votes + __popcll(vm & ((1ull << lane) - 1ull));
-      s_val[pos] = v;
-      s_bin[pos] = (unsigned char)bin;
+    // lanes with my bin
+    unsigned long long same = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit < 6; bit++) {
+      const bool set = (bin >> bit) & 1;
+      const unsigned long long bal = __ballot(set);
+      same &= set ? bal : ~bal;
     }
-    n_votes += __popcll(vm);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+    const bool last = ((same >> lane) >> 1) == 0ull;
+    const int before = s_cnt[bin];
+    if (p < n) { s_val[p] = v; s_key[p] = (unsigned short)(bin | ((before + rank) << 6)); }
+    if (last) s_cnt[bin] = before + rank + 1;
   }
-  const int n16 = (n_votes + 15) & ~15;
-  if (lane < n16 - n_votes) { s_val[n_votes + lane] = 0.f; s_bin[n_votes + lane] = 255; }
   __syncthreads();
-  // one lane per bin, votes in raster order (bin 36 is write-only in the reference).  Votes of other
-  // bins add +0.0f, which leaves the non-negative running sum unchanged, so the scan is branch-free
-  // and reads four votes per LDS access.
+  const int mine = lane < bins ? s_cnt[lane] : 0;
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+  s_off[lane] = incl - mine;
+  __syncthreads();
+  for (int p = lane; p < n; p += 64) {
+    const int key = s_key[p], b = key & 63;
+    if (b < bins) s_patch[s_off[b] + (key >> 6)] = s_val[p];
+  }
+  __syncthreads();
   if (lane < bins) {
     float acc = 0.f;
-    // per vote: compare its bin byte with the lane number, select the value or +0.0f, add - three vector instructions, written
-    // out because the compiler turns the select into a branch with a conditional LDS read per vote (the bin bytes are
-    // wave-uniform, so it unpacks them on the scalar unit: ~8 issued instructions and a taken branch per vote)
-    for (int p = 0; p < n16; p += 16) {   // 5 LDS reads (16 bins as bytes, 16 values), then the 16 votes in order
-      const uint4 bb = *(const uint4 *)(s_bin + p);
-      float4 v4[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) v4[u] = *(const float4 *)(s_val + p + 4 * u);
-      const unsigned int bw[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        float t;
-        asm volatile("v_cmp_eq_u32_sdwa vcc, %2, %7 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
-                     "v_cndmask_b32_e32 %1, 0, %3, vcc\n\t"
-                     "v_add_f32_e32 %0, %0, %1\n\t"
-                     "v_cmp_eq_u32_sdwa vcc, %2, %7 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-                     "v_cndmask_b32_e32 %1, 0, %4, vcc\n\t"
-                     "v_add_f32_e32 %0, %0, %1\n\t"
-                     "v_cmp_eq_u32_sdwa vcc, %2, %7 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
-                     "v_cndmask_b32_e32 %1, 0, %5, vcc\n\t"
-                     "v_add_f32_e32 %0, %0, %1\n\t"
-                     "v_cmp_eq_u32_sdwa vcc, %2, %7 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-                     "v_cndmask_b32_e32 %1, 0, %6, vcc\n\t"
-                     "v_add_f32_e32 %0, %0, %1"
-                     : "+v"(acc), "=&v"(t)
-                     : "v"(bw[u]), "v"(v4[u].x), "v"(v4[u].y), "v"(v4[u].z), "v"(v4[u].w), "v"(lane)
-                     : "vcc");
-      }
-    }
+    const float *list = s_patch + (incl - mine);
+    for (int i = 0; i < mine; i++) acc += list[i];
     s_hist[lane] = acc;
   }
   __syncthreads();
@@ -174,7 +169,7 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
   float *s_patch = smem;
   float *s_val = s_patch + ((pp2 + 3) & ~3);
   unsigned char *s_bin = (unsigned char *)(s_val + nv);
-  float *s_hist = (float *)(s_bin + nv);
+  float *s_hist = (float *)(s_bin + 2 * nv);
   const int lane = threadIdx.x;
   const int b = blockIdx.y;
   const float *img = img_all + (size_t)k.w * k.h * b;
@@ -419,7 +414,7 @@ __global__ __launch_bounds__(64) void dominant_angle_test_kernel(const float *__
   float *s_patch = smem;
   float *s_val = s_patch + ((ps * ps + 3) & ~3);
   unsigned char *s_bin = (unsigned char *)(s_val + nv);
-  float *s_hist = (float *)(s_bin + nv);
+  float *s_hist = (float *)(s_bin + 2 * nv);
   for (int p = threadIdx.x; p < ps * ps; p += 64) s_patch[p] = patch[p];
   __syncthreads();
   float ang = 0.f;
@@ -427,9 +422,9 @@ __global__ __launch_bounds__(64) void dominant_angle_test_kernel(const float *__
   if (threadIdx.x == 0) { out[0] = f ? 1.f : 0.f; out[1] = ang; }
 }
 
-static size_t orient_lds_bytes(int ps) {   // patch | vote values | vote bins (bytes) | histogram
+static size_t orient_lds_bytes(int ps) {   // patch | vote values | vote keys (16 bits) | histogram | list counts, offsets
   const size_t nv = ((size_t)ps * (ps - 2) + 15) & ~(size_t)15;
-  return sizeof(float) * ((((size_t)ps * ps + 3) & ~(size_t)3) + nv + 48) + nv;
+  return sizeof(float) * ((((size_t)ps * ps + 3) & ~(size_t)3) + nv + 48 + 128) + 2 * nv;   // (+ counts and offsets of the bins' lists)
 }
 
 // ---------------------------------------------------------------------------------------
