@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void match_pack_kernel(const mods_region *__re
 }
 
 // Both lists of a search in ONE launch (blockIdx.y = list), which also does what match_init_kernel did: a wave packs 32
-// consecutive regions - one tile of the distance kernels - and WRITES the tile's parity word (the single-list kernel ORs bits into
+// consecutive regions - one tile of the distance kernels, two lanes per region - and WRITES the tile's parity word (the single-list kernel ORs bits into
 // words that a launch before it had to clear), block (0, 0) clears the two counters of the search.  Three dispatches fewer per search.
 // grid = (ceil(max(n_q, n_t) / 32 / 4), 2, searches), block 256
 struct PackList { const mods_region *reg; int n; int8_t *desc; int *cvec; int *c2neg; unsigned int *parity; double2 *xy; };
@@ -116,31 +116,42 @@ __global__ __launch_bounds__(256) void match_pack2_kernel(MatchJobs J, PackList 
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { *J.count_out[job] = 0; *set_by(count2, job, J.s_p2) = 0; }
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile * 32 >= n) return;
-  unsigned int par = 0;
-  for (int r = 0; r < 32; r++) {
-    const int i = tile * 32 + r;
-    if (i < n) {
-      const uint8_t *d = L.reg[i].desc;
-      const int v0 = d[lane * 2], v1 = d[lane * 2 + 1];
-      L.desc[(size_t)i * 128 + lane * 2] = (int8_t)(v0 - 128);
-      L.desc[(size_t)i * 128 + lane * 2 + 1] = (int8_t)(v1 - 128);
-      int n2 = v0 * v0 + v1 * v1;
-      int s1 = (v0 - 128) + (v1 - 128);
-      for (int off = 32; off > 0; off >>= 1) { n2 += __shfl_xor(n2, off); s1 += __shfl_xor(s1, off); }
-      const int c = n2 - 256 * s1;
-      if (lane == 0) {
-        L.cvec[i] = c;
-        L.c2neg[i] = MATCH_BIAS - (c >> 1);       // accumulator seed of the distance tiles: acc = dot - floor(c/2) + MATCH_BIAS
-        L.xy[i] = make_double2(L.reg[i].x, L.reg[i].y);
-      }
-      par |= (unsigned int)(c & 1) << r;
-    } else {
-      // rows of the last tile beyond the list: zero descriptor, zero seed (stale entries there must not shadow the valid rows)
-      ((short *)(L.desc + (size_t)i * 128))[lane] = 0;
-      if (lane == 0) L.c2neg[i] = 0;
+  // two lanes per region (64 descriptor bytes each, four 16-byte loads), the 32 regions of the tile side by side: no loop over rows
+  const int i = tile * 32 + (lane >> 1), half = lane & 1;
+  unsigned int n2 = 0, sb = 0;
+  uint4 *dst = (uint4 *)(L.desc + (size_t)i * 128 + 64 * half);
+  if (i < n) {
+    const uint4 *src = (const uint4 *)(L.reg[i].desc + 64 * half);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint4 v = src[q];
+      n2 = __builtin_amdgcn_udot4(v.x, v.x, n2, false); n2 = __builtin_amdgcn_udot4(v.y, v.y, n2, false);
+      n2 = __builtin_amdgcn_udot4(v.z, v.z, n2, false); n2 = __builtin_amdgcn_udot4(v.w, v.w, n2, false);
+      sb = __builtin_amdgcn_udot4(v.x, 0x01010101u, sb, false); sb = __builtin_amdgcn_udot4(v.y, 0x01010101u, sb, false);
+      sb = __builtin_amdgcn_udot4(v.z, 0x01010101u, sb, false); sb = __builtin_amdgcn_udot4(v.w, 0x01010101u, sb, false);
+      dst[q] = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);   // v - 128 as int8
     }
+  } else {
+    // rows of the last tile beyond the list: zero descriptor, zero seed (stale entries there must not shadow the valid rows)
+#pragma unroll
+    for (int q = 0; q < 4; q++) dst[q] = make_uint4(0u, 0u, 0u, 0u);
+    if (half == 0) L.c2neg[i] = 0;
   }
-  if (lane == 0) L.parity[tile] = par;
+  n2 += __shfl_xor(n2, 1); sb += __shfl_xor(sb, 1);
+  const int c = (int)n2 - 256 * ((int)sb - 128 * 128);        // sum v^2 - 256 * sum (v - 128)
+  if (i < n && half == 0) {
+    L.cvec[i] = c;
+    L.c2neg[i] = MATCH_BIAS - (c >> 1);       // accumulator seed of the distance tiles: acc = dot - floor(c/2) + MATCH_BIAS
+    L.xy[i] = make_double2(L.reg[i].x, L.reg[i].y);
+  }
+  // parity word of the tile: bit r = c & 1 of row r (the even lanes' votes, squeezed together)
+  unsigned long long m = __ballot(i < n && half == 0 && (c & 1));
+  m = (m | (m >> 1)) & 0x3333333333333333ull;
+  m = (m | (m >> 2)) & 0x0f0f0f0f0f0f0f0full;
+  m = (m | (m >> 4)) & 0x00ff00ff00ff00ffull;
+  m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
+  m = (m | (m >> 16)) & 0x00000000ffffffffull;
+  if (lane == 0) L.parity[tile] = (unsigned int)m;
 }
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
@@ -859,7 +870,10 @@ __global__ __launch_bounds__(1024) void match_emit_kernel(MatchJobs J, MatchCons
 }
 
 // ---------------------------------------------------------------------------------------
-constexpr int FGINN_BLOCKS = 1024;     // pass 2: one workgroup per CU at a time (it owns the register file), four rounds
+#ifndef FGINN_BLOCKS_N
+#define FGINN_BLOCKS_N 256    // measured (round 4): 1024 / 512 / 256 workgroups: 78 / 60 / 47 us at 60 156 x 47 177, 19 / 19 / 15 us on a 1080p pair
+#endif
+constexpr int FGINN_BLOCKS = FGINN_BLOCKS_N;     // pass 2: one workgroup per CU (it owns the register file), one round
 static size_t match_pad(const mods_ctx *ctx) { return ((size_t)ctx->max_cand + 127) & ~(size_t)63; }   // list stride, tile tail included
 
 // Train splits of pass 1.  A workgroup owns its compute unit (register allocation), so the launch runs in rounds of one workgroup
