@@ -304,7 +304,9 @@ int mods_duplicate_filter(mods_tentative *tent, double *u6, double *laf, int n, 
 /* The same filter on the context's GPU (csrc/dedup.hip: rank count for the order, brute-force near-predecessor lists, fixed-point
  * resolution of the keep / drop rule; the pair entry points run it behind the search when [DuplicateFiltering] doBeforeRANSAC = 1).
  * Host lists in and out as above, laf required; identical result.  *on_device (optional) = 0 when the list was handed to the
- * host filter instead (a correspondence with more than 12 near predecessors, or more than 150 k correspondences). */
+ * host filter instead (a correspondence with more than 12 near predecessors, or more than 150 k correspondences).
+ * The call stages the list in the context's tentative buffer: it replaces the "last search" that mods_match_fetch_internal and
+ * the fetch entry points of the matcher read (run it after those, or search again). */
 int mods_duplicate_filter_gpu(mods_ctx *ctx, mods_tentative *tent, double *u6, double *laf, int n, double r, int mode, int *n_out,
                               int *on_device);
 

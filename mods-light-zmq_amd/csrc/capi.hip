@@ -704,7 +704,7 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
   if ((int)cur.size() < MIN_POINTS) cur.clear();
   for (int i : cur) mask[i] = 1;
   *n_inliers = (int)cur.size();
-  if (getenv("MODS_RANSAC_PROF")) fprintf(stderr, "loransac_h prof: whole %.0f us, checks after RANSAC %.0f us\n", 1e3 * (now_ms() - t_enter), 1e3 * (now_ms() - t_post0));
+  if (ransac_profile_on()) fprintf(stderr, "loransac_h prof: whole %.0f us, checks after RANSAC %.0f us\n", 1e3 * (now_ms() - t_enter), 1e3 * (now_ms() - t_post0));
   return MODS_OK;
 }
 
@@ -794,10 +794,9 @@ int mods_duplicate_filter_gpu(mods_ctx *c, mods_tentative *tent, double *u6, dou
   return MODS_OK;
 }
 
-// DuplicateFiltering ahead of RANSAC runs on the device, behind the search (dedup.hip); MODS_DEDUP=host keeps it on the verify thread
+// DuplicateFiltering ahead of RANSAC runs on the device, behind the search (dedup.hip)
 static bool dedup_on_device(const mods_pair_params *par) {
-  static const bool host_only = [] { const char *e = getenv("MODS_DEDUP"); return e && !strcmp(e, "host"); }();
-  return !host_only && par->dup_before_ransac && par->dup_dist > 0 && par->dup_mode >= 0 && par->dup_mode <= 3;
+  return par->dup_before_ransac && par->dup_dist > 0 && par->dup_mode >= 0 && par->dup_mode <= 3;
 }
 
 // GPU half of a pair: detect + describe both images, match, bring the tentatives to the host.
@@ -883,6 +882,18 @@ int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_pair_params
   const int last = n_img - 1;
   if ((rc = match_ensure_buffers(c, std::min(16, std::max(1, n_img / 2))))) return rc;     // the searches of a batch's pairs run as one group
   if ((rc = match_run(c, c->regions_dev, nr[0], c->regions_dev + (size_t)last * c->max_cand, nr[last], par->fginn_ratio, par->contradDist, par->nn))) return rc;
+  if (dedup_on_device(par)) {
+    // the duplicate filter's scratch for the lists of a whole batch and its kernels (a first hipMalloc inside the running pipeline
+    // would synchronise the device): the filter runs once over the warm-up search's list, repeated as every job of a batch
+    if (!c->m_tent2) MODS_HIP_CHECK(hipMalloc(&c->m_tent2, tent_bytes(((size_t)c->max_cand + 127) & ~(size_t)63) + 64));
+    const int n_jobs = std::min(DUP_MAX_JOBS, std::max(1, n_img / 2));
+    std::vector<DupJob> jobs(n_jobs, DupJob{(const char *)c->m_tent, (char *)c->m_tent2, c->m_count, c->m_count + 64, c->m_count + 128});
+    if ((rc = dup_filter_dev(c, jobs.data(), 1, nr[0], par->dup_dist, par->dup_mode))) return rc;     // kernels + the single-pair path
+    if (n_jobs > 1) {   // the allocation for a batch's jobs (every job of this call would write the same output: run none of them twice)
+      MODS_HIP_CHECK(mods::stream_wait(c->stream));
+      if ((rc = dup_filter_reserve(c, n_jobs))) return rc;
+    }
+  }
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
   return MODS_OK;
 }

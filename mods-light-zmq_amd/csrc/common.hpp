@@ -213,6 +213,7 @@ struct StageScope {                  // brackets launches of one stage with even
 // pyramid.hip
 int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff_params *par);
 int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride);
+int pyramid_join_side(mods_ctx *ctx);   // joins a forked pyramid's side stream into ctx->stream (no-op without a pending fork)
 int launch_gauss_blur(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, float sigma);
 int launch_hessian_response(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, float norm);
 int launch_resize_half(mods_ctx *ctx, const float *src, float *dst, int w, int h, int dw, int dh, int n_img);
@@ -242,6 +243,8 @@ int match_run_group(mods_ctx *ctx, int n_jobs, const mods_region *const *q_dev, 
 constexpr int DUP_MAX_JOBS = 64;
 struct DupJob { const char *src; char *dst; const int *n_src; int *n_dst; int *status; };
 int dup_filter_dev(mods_ctx *c, const DupJob *jobs, int n_jobs, int grid_n, double r, int mode);
+int dup_filter_reserve(mods_ctx *c, int n_jobs);
+bool ransac_profile_on();            // MODS_RANSAC_PROF: per-call breakdown of the verification on stderr (ransac.hip)
 
 // describe.hip
 int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par);

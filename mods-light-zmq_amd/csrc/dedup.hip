@@ -31,13 +31,14 @@ constexpr int DUP_MAX_N = 150 * 1024;  // one state byte per position in the LDS
 struct DupBatch {
   int n_jobs, max_n, mode;
   double r_sq;
-  char *scratch; size_t stride;        // per job: xy4[max_n] | rank[max_n] | near_cnt[max_n] | order[max_n] | near[max_n * DUP_K]
-  DupJob job[DUP_MAX_JOBS];
+  char *scratch; size_t stride;        // per job: xy4[max_n] | order[max_n] | near[max_n * DUP_K]
+  int *counters;                       // per job: rank[max_n] | near_cnt[max_n] - the only arrays that must start at zero, contiguous
+  DupJob job[DUP_MAX_JOBS];            // over the jobs so that ONE fill of 8 B per position clears them
 };
 __device__ __forceinline__ double4 *dj_xy4(const DupBatch &b, int j) { return (double4 *)(b.scratch + b.stride * j); }
-__device__ __forceinline__ int *dj_rank(const DupBatch &b, int j) { return (int *)(dj_xy4(b, j) + b.max_n); }
+__device__ __forceinline__ int *dj_rank(const DupBatch &b, int j) { return b.counters + (size_t)2 * b.max_n * j; }
 __device__ __forceinline__ int *dj_cnt(const DupBatch &b, int j) { return dj_rank(b, j) + b.max_n; }
-__device__ __forceinline__ int *dj_order(const DupBatch &b, int j) { return dj_cnt(b, j) + b.max_n; }
+__device__ __forceinline__ int *dj_order(const DupBatch &b, int j) { return (int *)(dj_xy4(b, j) + b.max_n); }
 __device__ __forceinline__ int *dj_near(const DupBatch &b, int j) { return dj_order(b, j) + b.max_n; }
 
 __device__ __forceinline__ double dup_key(const char *src, int n, int i, int mode) {
@@ -192,25 +193,36 @@ __global__ __launch_bounds__(1024) void dup_resolve_kernel(DupBatch b, int lds_n
 // (device-readable): the kept correspondences go to job[i].dst (room for the source list), their number to *n_dst and 0 / 1 (not
 // filtered: filter on the host) to *status - both in pinned host memory, valid after the stream has been synchronised.
 // grid_n: an upper bound of the list lengths known to the caller (sizes the launches; 0 = the context's capacity).
-int dup_filter_dev(mods_ctx *c, const DupJob *jobs, int n_jobs, int grid_n, double r, int mode) {
-  if (n_jobs < 1 || n_jobs > DUP_MAX_JOBS) { set_error("duplicate filter: %d lists", n_jobs); return MODS_E_ARG; }
+static size_t dup_job_stride(const mods_ctx *c) {
   const size_t n = (size_t)c->max_cand;
-  const size_t stride = (n * sizeof(double4) + n * sizeof(int) * (3 + DUP_K) + 255) & ~(size_t)255;
-  if (c->dd_jobs < n_jobs) {
-    if (c->dd_buf) { MODS_HIP_CHECK(mods::stream_wait(c->stream)); MODS_HIP_CHECK(hipFree(c->dd_buf)); c->dd_buf = nullptr; c->dd_jobs = 0; }
-    MODS_HIP_CHECK(hipMalloc(&c->dd_buf, stride * n_jobs));
-    c->dd_jobs = n_jobs;
-  }
+  return (n * sizeof(double4) + n * sizeof(int) * (1 + DUP_K) + 255) & ~(size_t)255;
+}
+// scratch for the lists of n_jobs pairs (mods_ctx_warmup calls this ahead of the pipeline: a hipMalloc synchronises the device)
+int dup_filter_reserve(mods_ctx *c, int n_jobs) {
+  if (n_jobs < 1 || n_jobs > DUP_MAX_JOBS) { set_error("duplicate filter: %d lists", n_jobs); return MODS_E_ARG; }
+  if (c->dd_jobs >= n_jobs) return MODS_OK;
+  if (c->dd_buf) { MODS_HIP_CHECK(mods::stream_wait(c->stream)); MODS_HIP_CHECK(hipFree(c->dd_buf)); c->dd_buf = nullptr; c->dd_jobs = 0; }
+  MODS_HIP_CHECK(hipMalloc(&c->dd_buf, (dup_job_stride(c) + 2 * (size_t)c->max_cand * sizeof(int)) * n_jobs));
+  c->dd_jobs = n_jobs;
+  return MODS_OK;
+}
+
+int dup_filter_dev(mods_ctx *c, const DupJob *jobs, int n_jobs, int grid_n, double r, int mode) {
+  { const int rrc = dup_filter_reserve(c, n_jobs); if (rrc) return rrc; }
+  const size_t n = (size_t)c->max_cand;
+  const size_t stride = dup_job_stride(c);
+  const size_t ctr_job = 2 * n * sizeof(int);
   DupBatch b;
   b.n_jobs = n_jobs; b.max_n = c->max_cand; b.mode = mode; b.r_sq = r * r;   // the packed layout of a source list is that of min(*n_src, max_cand) entries (match_emit_kernel)
   b.scratch = (char *)c->dd_buf; b.stride = stride;
+  b.counters = (int *)((char *)c->dd_buf + stride * c->dd_jobs);
   for (int i = 0; i < n_jobs; i++) b.job[i] = jobs[i];
   if (grid_n > c->max_cand || grid_n < 1) grid_n = c->max_cand;
   static DynLdsOnce once;
   MODS_HIP_CHECK(dyn_lds_once(once, (const void *)dup_resolve_kernel, DUP_MAX_N, c->device));
   const int tiles = (grid_n + 255) / 256;
-  // rank and near-count arrays start at zero (one fill over the scratch of the batch's jobs)
-  MODS_HIP_CHECK(hipMemsetAsync(c->dd_buf, 0, stride * n_jobs, c->stream));
+  // rank and near-count arrays start at zero: one fill over the counters of the batch's jobs (the last job's only up to grid_n)
+  MODS_HIP_CHECK(hipMemsetAsync(b.counters, 0, ctr_job * (n_jobs - 1) + (n + (size_t)grid_n) * sizeof(int), c->stream));
   if (mode >= 1 && mode <= 3) hipLaunchKernelGGL(dup_rank_kernel, dim3(tiles, tiles, n_jobs), dim3(256), 0, c->stream, b);
   hipLaunchKernelGGL(dup_scatter_kernel, dim3(tiles, 1, n_jobs), dim3(256), 0, c->stream, b);
   hipLaunchKernelGGL(dup_near_kernel, dim3(tiles, tiles, n_jobs), dim3(256), 0, c->stream, b);

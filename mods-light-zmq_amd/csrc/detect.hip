@@ -980,7 +980,14 @@ __global__ __launch_bounds__(256) void select_keys_kernel(int max_cand, const mo
 }
 
 // ---------------------------------------------------------------------------------------
+static int detect_run_stages(mods_ctx *ctx);
 int detect_run(mods_ctx *ctx) {
+  const int rc = detect_run_stages(ctx);
+  if (rc) (void)pyramid_join_side(ctx);   // an error exit ahead of the join: the side stream's launches must not outlive this call unjoined
+  return rc;
+}
+
+static int detect_run_stages(mods_ctx *ctx) {
   const PyramidDev &P = ctx->pyr;
   const mods_hessaff_params &par = ctx->par;
   const int n_img = ctx->last_n_img;
@@ -1086,9 +1093,7 @@ int detect_run(mods_ctx *ctx) {
       if (n0.n) hipLaunchKernelGGL(nms_kernel, dim3(n0.blk_begin[n0.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, n0, k, mask);
       if (w1.n) hipLaunchKernelGGL(nms4_kernel, dim3(w1.blk_begin[w1.n], 1, n_img), dim3(256), 0, ctx->stream2, ctx->pyr_dev, w1, k, mask);
       if (n1.n) hipLaunchKernelGGL(nms_kernel, dim3(n1.blk_begin[n1.n], 1, n_img), dim3(256), 0, ctx->stream2, ctx->pyr_dev, n1, k, mask);
-      MODS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->stream2));
-      MODS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-      ctx->pyr_side = false;
+      { const int jrc = pyramid_join_side(ctx); if (jrc) return jrc; }
     } else {
       if (wide_pl.n) hipLaunchKernelGGL(nms4_kernel, dim3(wide_pl.blk_begin[wide_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, wide_pl, k, mask);
       if (narrow_pl.n) hipLaunchKernelGGL(nms_kernel, dim3(narrow_pl.blk_begin[narrow_pl.n], 1, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, narrow_pl, k, mask);
@@ -1135,9 +1140,9 @@ int detect_run(mods_ctx *ctx) {
     StageScope ts(ctx, MODS_STAGE_SORT);
     // rank array: the raw-hit half of sort_idx's accept list is dead by now; use the dedicated buffer
     MODS_HIP_CHECK(hipMemsetAsync(ctx->rank_dev, 0, sizeof(int) * (size_t)ctx->max_cand * n_img, ctx->stream));
-    static const bool count_only = getenv("MODS_RANK_COUNT") != nullptr;   // the round-2 path for every image (A/B measurements)
-    const int sort_max = count_only ? 0 : RANK_SORT_MAX;
-    if (!count_only) {
+    // images of up to RANK_SORT_MAX keys are ranked by one workgroup out of LDS, larger ones by the O(n^2) count
+    const int sort_max = RANK_SORT_MAX;
+    {
       static DynLdsOnce once;
       MODS_HIP_CHECK(dyn_lds_once(once, (const void *)rank_sort_kernel, 160 * 1024, ctx->device));
       hipLaunchKernelGGL(rank_sort_kernel, dim3(n_img), dim3(1024), RANK_SORT_MAX * 10, ctx->stream, k, ctx->sort_keys, key_count, ctx->rank_dev);

@@ -55,28 +55,6 @@ __device__ __forceinline__ void wave_sync() {
 // and per instruction, so the four pixels of a bilinear tap are fetched with two loads
 struct __attribute__((packed, aligned(4))) PixPair { float a, b; };
 
-// One bilinear tap of interpolate(), helpers.cpp:551-626: `touch` selects the unchecked
-// (int-cast) branch or the per-pixel checked (floor, zero fill) branch.
-__device__ __forceinline__ float bilinear_tap(const float *__restrict__ im, int w, int h, float WX, float WY, bool touch) {
-  if (!touch) {
-    const int x = (int)WX, y = (int)WY;
-    const float wx = WX - (float)x;
-    const float *Row0 = im + (size_t)y * w + x;
-    const PixPair p0 = *(const PixPair *)Row0, p1 = *(const PixPair *)(Row0 + w);
-    const float I1 = wx * (p0.b - p0.a) + p0.a;
-    return (WY - y) * (wx * (p1.b - p1.a) + p1.a - I1) + I1;
-  }
-  const int x = (int)floorf(WX), y = (int)floorf(WY);
-  if (WX >= 0 && WY >= 0 && x < w - 1 && y < h - 1) {
-    const float wx = WX - x;
-    const float *Row0 = im + (size_t)y * w + x;
-    const PixPair p0 = *(const PixPair *)Row0, p1 = *(const PixPair *)(Row0 + w);
-    const float I1 = wx * (p0.b - p0.a) + p0.a;
-    return (WY - y) * (wx * (p1.b - p1.a) + p1.a - I1) + I1;
-  }
-  return 0.f;
-}
-
 // The four pixels of one bilinear tap, loaded without combining them (lets a caller issue the loads
 // of several taps before the first use).  valid = false: the tap is 0 (checked branch, outside).
 struct TapLoads { float r00, r01, r10, r11, wx, wy; bool valid; };
@@ -288,30 +266,6 @@ __device__ __forceinline__ float atan2_lut_ff_t(float y, float x, const double *
     if (absx > absy) return (float)((double)(-PIf) + L[(int)(255.f * absy / absx)]);
     if (x == 0.f) return 0.f;
     return (float)((double)(-PI_2f) - L[(int)(255.f * absx / absy)]);
-  }
-}
-
-__device__ __forceinline__ float atan2_lut_ff(float y, float x) {
-  const float PI_2f = 1.57079632679489661923f;
-  const float PIf = 3.14159265358979323846f;
-  if (x > 0.f) {
-    if (y > 0.f) {
-      if (x > y) return (float)g_atan_lut[(int)(255.f * y / x)];
-      return (float)((double)PI_2f - g_atan_lut[(int)(255 * x / y)]);
-    } else {
-      float absy = fabsf(y);
-      if (x > absy) return (float)(-g_atan_lut[(int)(255.f * absy / x)]);
-      return (float)((double)(-PI_2f) + g_atan_lut[(int)(255.f * x / absy)]);
-    }
-  } else if (y > 0.f) {
-    float absx = fabsf(x);
-    if (absx > y) return (float)((double)PIf - g_atan_lut[(int)(255.f * y / absx)]);
-    return (float)((double)PI_2f + g_atan_lut[(int)(255.f * absx / y)]);
-  } else {
-    float absx = fabsf(x), absy = fabsf(y);
-    if (absx > absy) return (float)((double)(-PIf) + g_atan_lut[(int)(255.f * absy / absx)]);
-    if (x == 0.f) return 0.f;
-    return (float)((double)(-PI_2f) - g_atan_lut[(int)(255.f * absx / absy)]);
   }
 }
 

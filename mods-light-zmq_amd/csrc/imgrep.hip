@@ -315,7 +315,6 @@ struct ViewJob {
 static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, const float *img2_dev, int w2, int h2,
                          const mods_hessaff_params *dets, std::vector<ViewJob> &jobs) {
   static const int env_workers = getenv("MODS_LADDER_WORKERS") ? atoi(getenv("MODS_LADDER_WORKERS")) : 4;
-  static const bool no_pairs = getenv("MODS_LADDER_NO_PAIRS") != nullptr;
   int n_workers = std::max(1, std::min(env_workers, 8));
   if (c->ext_fn || c->shape_fn || c->ori_fn) n_workers = 1;      // the daemons' hooks belong to one context
   if (jobs.empty()) return MODS_OK;
@@ -323,7 +322,7 @@ static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, con
   // (both images of a pair share their view schedule) and the contexts hold two images; otherwise one job per unit.
   struct Unit { int a, b; };                                     // job indices; b < 0: a single view
   std::vector<Unit> units;
-  const bool pair_ok = !no_pairs && w1 == w2 && h1 == h2 && !(c->ext_fn || c->shape_fn || c->ori_fn);
+  const bool pair_ok = w1 == w2 && h1 == h2 && !(c->ext_fn || c->shape_fn || c->ori_fn);
   {
     std::vector<char> used(jobs.size(), 0);
     for (size_t i = 0; i < jobs.size(); i++) {

@@ -879,19 +879,17 @@ static size_t match_pad(const mods_ctx *ctx) { return ((size_t)ctx->max_cand + 1
 // Train splits of pass 1.  A workgroup owns its compute unit (register allocation), so the launch runs in rounds of one workgroup
 // per CU and its time is rounds x (tiles per split + the workgroup's fixed cost: 128 KB of query operands, the first tiles'
 // latency, the final key merge - about six tiles' worth): the split count minimises that product, never more than NN1_MAX_TPS
-// tiles each.  MODS_MATCH_BLOCKS overrides the number of workgroups aimed at (development aid).
+// tiles each.
 struct Nn1Grid { int qblocks, splits, tiles_per_split; size_t n_qpad; };
 static Nn1Grid nn1_grid(int n_q, int n_t) {
   constexpr int QPB = 32 * NN1_WAVES * MATCH_QB1;      // queries per pass-1 workgroup
   constexpr int CUS = 256, FIXED = 6;
-  static const int forced = getenv("MODS_MATCH_BLOCKS") ? std::max(1, atoi(getenv("MODS_MATCH_BLOCKS"))) : 0;
   Nn1Grid gr;
   const int n_tiles = (n_t + 31) / 32;
   gr.qblocks = (n_q + QPB - 1) / QPB;
   const int smin = std::max(1, (n_tiles + NN1_MAX_TPS - 1) / NN1_MAX_TPS);
   int splits = smin;
-  if (forced) splits = std::max(smin, std::min(n_tiles, forced / std::max(1, gr.qblocks)));
-  else {
+  {
     long best = -1;
     const int smax = std::max(smin, std::min(n_tiles, 4 * CUS / std::max(1, gr.qblocks) + 1));
     for (int sc = smin; sc <= smax; sc++) {

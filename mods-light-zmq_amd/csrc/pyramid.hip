@@ -195,15 +195,10 @@ __device__ __forceinline__ void store_f4_nt(float *p, float x, float y, float z,
   asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(q) : "memory");
 }
 
-// STAGE = true: the input tile (ROWS x (FB_TW + 8*R4) pixels) is first brought into LDS with one coalesced, non-redundant
-// pass of 16-byte loads (all of a thread's loads in flight together), and the row pass takes its register windows from LDS.
-// Without it every thread loads its own window from global memory: adjacent threads' windows overlap, a workgroup issues
-// ~4.6x the tile's bytes as vector-memory instructions, and the PMC counters show the waves stalled at issue behind the
-// memory pipeline (profiles/r02_describe_pmc_digest.txt: stall 0.35-0.49 of the wave time).
 #ifndef BLUR_WAVES
 #define BLUR_WAVES 1
 #endif
-template <int R, int FB_TH, int OV, bool RESP, bool STAGE>
+template <int R, int FB_TH, int OV, bool RESP>
 __global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               BlurTaps taps, float *__restrict__ resp, float norm2) {
   constexpr int N = 2 * R + 1;
@@ -233,56 +228,12 @@ __global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const 
   src += plane * img;
   dst += plane * img;
   const int x0 = txi * SX, y0 = tyi * SY;
-  constexpr int IW4 = FB_TW / 4 + 2 * R4;     // float4s per staged input row
-  constexpr int IWP = 4 * IW4 + 4;            // its LDS pitch in floats
-  float *s_in = smem + ROWS * FB_TW;
-  if constexpr (STAGE) {
-    constexpr int NL = (ROWS * IW4 + 255) / 256;
-    const bool rows_aligned = (w & 3) == 0;
-    float4 q[NL];
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int e = tid + 256 * i;
-      q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < ROWS * IW4) {
-        const int ly = e / IW4, c4 = e - ly * IW4;
-        int gy = y0 - R + ly;
-        gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-        const float *row = src + (size_t)gy * w;
-        const int gx = x0 - 4 * R4 + 4 * c4;
-        if (rows_aligned && gx >= 0 && gx + 3 <= w - 1) q[i] = *(const float4 *)(row + gx);
-        else {   // BORDER_REPLICATE at the left / right edge (and planes whose rows are not 16-byte aligned)
-          const int g0 = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx), g1 = gx + 1 < 0 ? 0 : (gx + 1 > w - 1 ? w - 1 : gx + 1);
-          const int g2 = gx + 2 < 0 ? 0 : (gx + 2 > w - 1 ? w - 1 : gx + 2), g3 = gx + 3 < 0 ? 0 : (gx + 3 > w - 1 ? w - 1 : gx + 3);
-          q[i] = make_float4(row[g0], row[g1], row[g2], row[g3]);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int e = tid + 256 * i;
-      if (e < ROWS * IW4) {
-        const int ly = e / IW4, c4 = e - ly * IW4;
-        *(float4 *)(s_in + ly * IWP + 4 * c4) = q[i];
-      }
-    }
-    __syncthreads();
-  }
   // Row pass.  The memory pipeline takes about one clock per lane and load whatever the width, so the window of a thread is
   // kept wide: NO outputs from NV aligned float4 loads (1.25 loads per 4 outputs at OV = 1, R = 5..8; 0.75 at OV = 2).
   const int rc = tid % TPR;                   // output group within the row
   const int xg = x0 + NO * rc;
   const bool fast_x = ((w & 3) == 0) && (xg - 4 * R4 >= 0) && (xg + NO - 1 + 4 * R4 <= w - 1);   // aligned rows, whole window inside the row
   auto load_window = [&](int ly, float *win) {
-    if constexpr (STAGE) {
-      const float *row = s_in + ly * IWP + NO * rc;
-#pragma unroll
-      for (int v = 0; v < NV; v++) {
-        const float4 q = *(const float4 *)(row + 4 * v);
-        win[4 * v] = q.x; win[4 * v + 1] = q.y; win[4 * v + 2] = q.z; win[4 * v + 3] = q.w;
-      }
-      return;
-    }
     int gy = y0 - R + ly;
     gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
     const float *row = src + (size_t)gy * w;
@@ -828,6 +779,12 @@ __global__ __launch_bounds__(256) void harris_combine_kernel(const float *__rest
 // ---------------------------------------------------------------------------------------
 // Tap tables live in 16 device slots of 64 floats; a slot is re-uploaded (synchronously, so
 // the host buffer is never read late) only when its sigma changes: steady state = no copies.
+// both streams of the context drained: a tap slot may be read by launches of either
+static int wait_both_streams(mods_ctx *ctx) {
+  MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
+  if (ctx->stream2 && ctx->stream2 != ctx->stream) MODS_HIP_CHECK(mods::stream_wait(ctx->stream2));
+  return MODS_OK;
+}
 static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
   const int n = gauss_ksize(sigma);
   if (n / 2 > kMaxBlurRadius) { set_error("gaussian kernel too wide: sigma=%g ksize=%d", (double)sigma, n); return MODS_E_ARG; }
@@ -837,7 +794,7 @@ static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
   gauss_kernel_host(n, (double)sigma, taps);
   for (int i = 0; i < n; i++) ctx->taps_host[slot][i] = taps[i];
   ctx->taps_host_n[slot] = n;
-  MODS_HIP_CHECK(mods::stream_wait(ctx->stream));   // earlier launches may still read the slot
+  { const int wrc = wait_both_streams(ctx); if (wrc) return wrc; }   // earlier launches may still read the slot
   MODS_HIP_CHECK(hipMemcpy(ctx->gauss_taps_dev + slot * 64, taps, sizeof(float) * n, hipMemcpyHostToDevice));
   ctx->taps_sigma[slot] = sigma;
   return MODS_OK;
@@ -855,24 +812,19 @@ static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w,
     const size_t lds = sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * FB_TW;
     if (resp) {
       const int tilesB = blur_resp_tiles(w, FB_TW - 4, 4) * blur_resp_tiles(h, BLUR_TH_BIG - 2, 2) * n_img;
-      static const bool stage = getenv("MODS_BLUR_STAGE") != nullptr;   // measured neutral (0.739 vs 0.741 ms per 16-image batch): off
-      if (stage) {
-        const size_t lds_in = sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * (FB_TW + 8 * ((R + 3) / 4) + 4);
-        hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, true, true>), dim3(tilesB), dim3(256), lds + lds_in, ctx->stream, src, dst, w, h, taps, resp, norm2);
-      } else
-        hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, true, false>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, true>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
     } else {
       const int tilesB = ((w + FB_TW - 1) / FB_TW) * ((h + BLUR_TH_BIG - 1) / BLUR_TH_BIG) * n_img;
-      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, false, false>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, BLUR_TH_BIG, BLUR_OV_BIG, false>), dim3(tilesB), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
     }
   } else {                // small planes: short tiles, more workgroups, shorter per-thread row chains
     const size_t lds = sizeof(float) * (size_t)(16 + 2 * R) * FB_TW;
     if (resp) {
       const int tiles16 = blur_resp_tiles(w, FB_TW - 4, 4) * blur_resp_tiles(h, 16 - 2, 2) * n_img;
-      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, true, false>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, true>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, resp, norm2);
     } else {
       const int tiles16 = ((w + FB_TW - 1) / FB_TW) * ((h + 15) / 16) * n_img;
-      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, false, false>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
+      hipLaunchKernelGGL((gauss_blur_fast_kernel<R, 16, 1, false>), dim3(tiles16), dim3(256), lds, ctx->stream, src, dst, w, h, taps, nullptr, 0.f);
     }
   }
 }
@@ -1066,7 +1018,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
       if (n > kAltTapStride - 1) { set_error("response blur too wide: sigma=%g ksize=%d", (double)sigma, n); return MODS_E_ARG; }
       std::vector<float> taps(n);
       gauss_kernel_host(n, (double)sigma, taps.data());
-      MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
+      { const int wrc = wait_both_streams(ctx); if (wrc) return wrc; }
       MODS_HIP_CHECK(hipMemcpy(ctx->alt_taps_dev + (size_t)l * kAltTapStride, taps.data(), sizeof(float) * n, hipMemcpyHostToDevice));
       ctx->alt_ntap[l] = n; ctx->alt_sigma[l] = sigma;
     }
@@ -1087,7 +1039,27 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
 
 // detectPyramidKeypoints / detectOctaveKeypoints (pyramid.cpp:496-529, 428-494): every blur and
 // response plane of every octave, for the whole batch.  `img_dev`: [n_img][h][stride].
+// Joins the side stream of a forked pyramid into the main stream (no-op without a pending fork).  detect_run does this on
+// its way to the compaction; every error exit between the fork and that point, and a call that finds the flag still set,
+// come through here, so side-stream work never outlives the call that started it unjoined.
+int pyramid_join_side(mods_ctx *ctx) {
+  if (!ctx->pyr_side) return MODS_OK;
+  ctx->pyr_side = false;
+  MODS_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->stream2));
+  MODS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return MODS_OK;
+}
+
+static int pyramid_build_levels(mods_ctx *ctx, const float *img_dev, int stride);
 int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
+  int rc = pyramid_join_side(ctx);          // a previous call that failed behind its fork
+  if (rc) return rc;
+  rc = pyramid_build_levels(ctx, img_dev, stride);
+  if (rc) (void)pyramid_join_side(ctx);     // (the stream swap is undone by the build's own guard before this runs)
+  return rc;
+}
+
+static int pyramid_build_levels(mods_ctx *ctx, const float *img_dev, int stride) {
   ctx->last_img_dev = img_dev; ctx->last_stride = stride;
   ctx->pyr_scope_begin = nullptr;
   if ((ctx->timing_mask >> MODS_STAGE_PYRAMID) & 1) {
@@ -1157,14 +1129,13 @@ int pyramid_build(mods_ctx *ctx, const float *img_dev, int stride) {
   // first - next to the remaining levels of octaves 0 and 1 and their NMS (the bulk of both); detect_run launches the small
   // octaves' NMS on the side stream too and joins before the compaction.  (Round 3 tried a fork with every octave's NMS after the
   // join: the side chain then only had one blur launch to hide under, 1.436 against 1.416 ms; with octave 1 - all of it, or its
-  // last level and its NMS - on the side stream as well the side chain is the longer one: 1.05-1.06 against 0.99-1.01 ms.)  MODS_PYR_FORK=0 keeps one stream.
-  static const bool fork_on = !(getenv("MODS_PYR_FORK") && atoi(getenv("MODS_PYR_FORK")) == 0);
-  const bool fork = fork_on && ctx->pyr_streams >= 2 && P.n_oct >= 2 && S < P.n_levels - 1 && (size_t)w * h * n_img >= ((size_t)4 << 20);
+  // last level and its NMS - on the side stream as well the side chain is the longer one: 1.05-1.06 against 0.99-1.01 ms.)  mods_ctx_pyramid_streams(ctx, 1)
+  // keeps one stream.
+  const bool fork = ctx->pyr_streams >= 2 && P.n_oct >= 2 && S < P.n_levels - 1 && (size_t)w * h * n_img >= ((size_t)4 << 20);
   ctx->pyr_side = false;
   // the octaves from `first_lds` on fit LDS and are built by pyramid_lds_kernel in one launch
   int first_lds = P.n_oct;
-  static const bool no_lds = getenv("MODS_NO_LDS_PYRAMID") != nullptr;
-  if (!no_lds) {
+  {
     bool taps_ok = P.n_levels <= kMaxLevels;
     for (int l = 1; l < P.n_levels; l++) taps_ok = taps_ok && ntap[l] >= 3 && ntap[l] <= 17 && ctx->taps_host_n[l] == ntap[l];
     if (taps_ok)

@@ -130,7 +130,6 @@ RansacGpu::~RansacGpu() {
   (void)hipFree(u_dev); (void)hipFree(hyp_dev); (void)hipHostFree(hyp_host); (void)hipFree(d_dev); (void)hipFree(gain_dev);
   (void)hipFree(J_dev); (void)hipHostFree(J_host);   // (the counts live behind the J values in the same allocations)
   (void)hipHostFree(row_host); (void)hipFree(aux_dev);
-  (void)hipFree(ev_dev); (void)hipHostFree(ev_host);
   (void)hipFree(cand_dev); (void)hipHostFree(cand_host); (void)hipFree(candc_dev); (void)hipHostFree(candc_host);
   if (stream) (void)hipStreamDestroy(stream);
 }
@@ -162,7 +161,6 @@ RansacGpu *ransac_gpu() {
     // queue behind a describe batch of the pipeline's GPU workers (16-25 ms per call when they did)
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    if (getenv("MODS_RANSAC_PRIO")) prio_high = atoi(getenv("MODS_RANSAC_PRIO"));   // development aid
     if (hipStreamCreateWithPriority(&ws.stream, hipStreamNonBlocking, prio_high) != hipSuccess) { set_error("stream creation failed"); return nullptr; }
     ws.device = dev;
   }
@@ -191,6 +189,7 @@ bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
     ws->counts_dev = (int *)(ws->J_dev + n_hyp);
     ws->counts_host = (int *)(ws->J_host + n_hyp);
     RS_CHECK(hipMemset(ws->J_dev, 0, 2 * sizeof(double) * n_hyp));
+    ws->counts_dirty = false;
     ws->dg_cap = 0;
   }
   // hipFree / hipMalloc synchronise the whole device (20+ ms under a running pipeline): grow in powers of two from a
@@ -213,9 +212,18 @@ bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
   return true;
 }
 
+// The device counters are zero between scoring rounds: ransac_ws_reserve clears them when it allocates, ransac_gain_kernel
+// after it has read them.  A round that fails between its score and gain launches (or is abandoned) leaves counts behind; the
+// flag makes the next round of this workspace clear them first.
+bool ransac_counts_begin(RansacGpu *ws) {
+  if (ws->counts_dirty) RS_CHECK(hipMemsetAsync(ws->counts_dev, 0, 2 * sizeof(int) * (size_t)ws->hyp_cap, ws->stream));
+  ws->counts_dirty = true;      // until the gain kernel of this round has run and been waited for
+  return true;
+}
+
 // scores hyp_host[0..n) over all correspondences; fills counts_host / J_host
 static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, double th, double th_check) {
-  // (the device counters are zero: ransac_ws_reserve clears them when it allocates, ransac_gain_kernel after it has read them)
+  if (!ransac_counts_begin(ws)) return false;
   RS_CHECK(hipMemcpyAsync(ws->hyp_dev, ws->hyp_host, sizeof(HypDev) * n, hipMemcpyHostToDevice, ws->stream));
   hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, (const HypDev *)ws->hyp_dev, err_type,
                      do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
@@ -223,6 +231,7 @@ static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, d
                      ws->counts_host);
   RS_CHECK(hipGetLastError());
   RS_CHECK(mods::stream_wait(ws->stream));
+  ws->counts_dirty = false;
   ws->launches += 2;
   return true;
 }
@@ -311,7 +320,8 @@ namespace mods {
 // MODS_RANSAC_PROF=1: per-call breakdown of the verification on stderr (development aid)
 struct RsProf { double us[8]; };   // 0 hypotheses, 1 gpu_score, 2 fetch_row, 3 LO u2h, 4 LO error function, 5 LO, 6 upload, 7 whole call
 static thread_local RsProf g_rsprof;
-static int rsprof_on() { static const int on = getenv("MODS_RANSAC_PROF") ? 1 : 0; return on; }
+bool ransac_profile_on() { static const bool on = getenv("MODS_RANSAC_PROF") != nullptr; return on; }
+static int rsprof_on() { return ransac_profile_on() ? 1 : 0; }
 static inline double rs_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 struct RsTimer {
   int slot; double t0;

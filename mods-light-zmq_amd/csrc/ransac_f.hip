@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256) ransacf_count_kernel(const double *__rest
 
 static bool gpu_score_f(RansacGpu *ws, int len, int n, int err_type, int do_sym, double th, double th_check) {
   // (device counters: zero on entry, read out to the host's pinned result block and cleared again by ransac_gain_kernel; ransac.hip)
+  if (!ransac_counts_begin(ws)) return false;
   RS_CHECK(hipMemcpyAsync(ws->hyp_dev, ws->hyp_host, sizeof(HypF) * n, hipMemcpyHostToDevice, ws->stream));
   hipLaunchKernelGGL(ransacf_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, (const HypF *)ws->hyp_dev,
                      err_type, do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
@@ -102,76 +103,15 @@ static bool gpu_score_f(RansacGpu *ws, int len, int n, int err_type, int do_sym,
                      ws->counts_host);
   RS_CHECK(hipGetLastError());
   RS_CHECK(mods::stream_wait(ws->stream));
+  ws->counts_dirty = false;
   ws->launches += 2;
   return true;
 }
 
-// one model over all correspondences in u_dev -> d (and the LSQ weight w for the ex* variants).  grid = ceil(len/256)
-enum { EV_HDS = 0, EV_FDS = 1, EV_FDS_SYM = 2, EV_EXFDS = 3, EV_EXFDS_SYM = 4 };
-struct Model9 { double m[9]; };
-__global__ void __launch_bounds__(256) ransac_eval_kernel(const double *__restrict__ u, int len, Model9 M, int kind, double *__restrict__ d_out,
-                                                          double *__restrict__ w_out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= len) return;
-  double uu[6];
-#pragma unroll
-  for (int q = 0; q < 6; q++) uu[q] = u[(size_t)i * 6 + q];
-  double d, w = 0;
-  if (kind == EV_HDS) d = hds_dev(uu, M.m);
-  else if (kind == EV_FDS) d = fds_from(uu, M.m);
-  else if (kind == EV_EXFDS) { double ws; d = fds_from(uu, M.m, &ws); w = 1 / sqrt(ws); }
-  else {
-    const FTerms t = f_terms(uu, M.m);
-    if (kind == EV_FDS_SYM) d = t.r * t.r * (t.a + t.b) / (t.a * t.b);
-    else { w = (t.a * t.b) / (t.a + t.b); d = t.r * t.r / w; }
-  }
-  d_out[i] = d;
-  if (kind >= EV_EXFDS) w_out[i] = w;
-}
-
-// PointEval on the GPU: the correspondences are already in ws->u_dev; results come back through the pinned row buffer.
-// Rows live at the end of d_dev/gain_dev?  No: in their own small buffers, so that the candidate rows of the current
-// batch stay intact.
-struct GpuEval : rs::PointEval {
-  RansacGpu *ws;
-  double *d_dev = nullptr, *w_dev = nullptr, *host = nullptr;
-  GpuEval(RansacGpu *ws_, const double *u_, int len_) : rs::PointEval(u_, len_), ws(ws_) {
-    if ((size_t)len_ * 2 > ws->ev_cap) {          // persistent per-thread buffers, grown geometrically
-      (void)hipFree(ws->ev_dev); (void)hipHostFree(ws->ev_host);
-      ws->ev_dev = nullptr; ws->ev_host = nullptr;
-      ws->ev_cap = (size_t)len_ * 4;
-      if (hipMalloc(&ws->ev_dev, sizeof(double) * ws->ev_cap) != hipSuccess || hipHostMalloc(&ws->ev_host, sizeof(double) * ws->ev_cap) != hipSuccess) {
-        set_error("evaluation buffers: allocation failed");
-        ws->ev_cap = 0;
-        return;
-      }
-    }
-    d_dev = ws->ev_dev; w_dev = d_dev + len_; host = ws->ev_host;
-  }
-  bool ok() const { return d_dev != nullptr; }
-  void run(int kind, const double *model, double *d, double *w) {
-    Model9 M;
-    memcpy(M.m, model, sizeof(M.m));
-    hipLaunchKernelGGL(ransac_eval_kernel, dim3((len + 255) / 256), dim3(256), 0, ws->stream, ws->u_dev, len, M, kind, d_dev, w_dev);
-    const size_t n = (size_t)len * (w ? 2 : 1);
-    if (hipMemcpyAsync(host, d_dev, sizeof(double) * n, hipMemcpyDeviceToHost, ws->stream) != hipSuccess ||
-        mods::stream_wait(ws->stream) != hipSuccess) { set_error("error-function evaluation failed"); ransac_fail(); }
-    memcpy(d, host, sizeof(double) * len);
-    if (w) memcpy(w, host + len, sizeof(double) * len);
-    ws->launches++;
-  }
-  void hds(const double *H, double *out) override { run(EV_HDS, H, out, nullptr); }
-  void fds(const double *F, double *out) override { run(EV_FDS, F, out, nullptr); }
-  void fds_sym(const double *F, double *out) override { run(EV_FDS_SYM, F, out, nullptr); }
-  void exfds(const double *F, double *p, double *w) override { run(EV_EXFDS, F, p, w); }
-  void exfds_sym(const double *F, double *p, double *w) override { run(EV_EXFDS_SYM, F, p, w); }
-  bool concurrent() const override { return false; }   // one stream, one pair of staging buffers
-};
-
 // PointEval as host SIMD across correspondences (ransac_simd.hpp: the scalar code's operations in the scalar code's order, 4
-// or 8 correspondences per instruction).  One evaluation of 24 k correspondences takes ~25 us here against ~100 us for the
-// launch + copy + synchronise round trip of GpuEval, and the degenerate branch of a large planar pair makes over a thousand
-// of them (BASELINE configs[4]).
+// or 8 correspondences per instruction).  One evaluation of 24 k correspondences takes ~25 us here against ~100 us for a
+// launch + copy + synchronise round trip to the device (round 3's form, docs/history/r05_removed_paths.patch), and the
+// degenerate branch of a large planar pair makes over a thousand of them (BASELINE configs[4]).
 struct SimdEval : rs::PointEval {
   PointsSoA pts;
   SimdEval(const double *u_, int len_) : rs::PointEval(u_, len_) { pts.build(u_, len_); }
@@ -464,7 +404,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
   if (!EXFDS1) EXFDS1 = FDS1 == &FDsSym ? &exFDsSym : &exFDs;
   int err_type = FDS1 == &FDs ? FERR_SAMPSON : FDS1 == &FDsSym ? FERR_SYM : -1;   // -1: foreign error function, evaluated on the host
 
-  const bool prof = getenv("MODS_RANSAC_PROFILE") != nullptr;
+  const bool prof = ransac_profile_on();   // MODS_RANSAC_PROF
   const double t_begin = prof ? wall_ms() : 0;
   double t_innerh = 0, t_rfth = 0, t_lo = 0;
   const long pinned = ransac_pinned_seed();
@@ -494,16 +434,9 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
   if (!ransac_ws_reserve(ws, len, 96)) F_FATAL();
   if (hipMemcpyAsync(ws->u_dev, u, sizeof(double) * 6 * len, hipMemcpyHostToDevice, ws->stream) != hipSuccess ||
       mods::stream_wait(ws->stream) != hipSuccess) { set_error("upload of the correspondences failed"); F_FATAL(); }
-  // O(len) evaluations of one model (LO steps, degenerate branch): on the GPU for long lists, where a launch +
-  // a row copy (~30 us) beats the host loop; the library's own error functions only
-  rs::PointEval host_eval(u, len);
-  // evaluations of one model over all correspondences: host SIMD (MODS_F_EVAL=gpu: the device round trip, =scalar: the plain loops)
-  std::unique_ptr<GpuEval> gpu_eval;
-  std::unique_ptr<SimdEval> simd_eval;
-  static const char *eval_mode = getenv("MODS_F_EVAL");
-  if (eval_mode && !strcmp(eval_mode, "gpu")) { if (len >= 2048) { gpu_eval.reset(new GpuEval(ws, u, len)); if (!gpu_eval->ok()) F_FATAL(); } }
-  else if (!eval_mode || strcmp(eval_mode, "scalar")) simd_eval.reset(new SimdEval(u, len));
-  rs::PointEval *ev = gpu_eval ? (rs::PointEval *)gpu_eval.get() : simd_eval ? (rs::PointEval *)simd_eval.get() : &host_eval;
+  // O(len) evaluations of one model (LO steps, degenerate branch): host SIMD across the correspondences
+  SimdEval simd_eval(u, len);
+  rs::PointEval *ev = &simd_eval;
   auto eval_fds = [&](const double *Fm, double *dd) {
     if (FDS1 == &FDs) ev->fds(Fm, dd);
     else if (FDS1 == &FDsSym) ev->fds_sym(Fm, dd);

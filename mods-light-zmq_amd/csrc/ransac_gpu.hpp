@@ -14,11 +14,11 @@ struct RansacGpu {
   double *d_dev = nullptr; double *gain_dev = nullptr; size_t dg_cap = 0;
   int *counts_dev = nullptr; double *J_dev = nullptr;
   int *counts_host = nullptr; double *J_host = nullptr;
+  bool counts_dirty = false;                            // a scoring round did not complete: counts_dev is cleared before the next one
   double *row_host = nullptr; size_t row_cap = 0;
   double *aux_dev = nullptr; size_t aux_cap = 0;        // second point set (off-plane correspondences of rFtH)
   double *cand_dev = nullptr, *cand_host = nullptr;     // two-point candidates of rFtH (9 doubles each) and their counts
   int *candc_dev = nullptr, *candc_host = nullptr; int cand_cap = 0;
-  double *ev_dev = nullptr, *ev_host = nullptr; size_t ev_cap = 0;   // single-model evaluations over all points (d, w rows)
   double score_ms = 0; long launches = 0;
   ~RansacGpu();
 };
@@ -27,6 +27,7 @@ enum { HYP_SLOT_BYTES = 27 * 8 };   // largest hypothesis record (homography + i
 RansacGpu *ransac_gpu();                                  // nullptr + mods_last_error when no device
 bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp);
 bool ransac_fetch_row(RansacGpu *ws, int len, int k, double *dst);
+bool ransac_counts_begin(RansacGpu *ws);                 // start of a scoring round (clears counters a failed round left behind)
 long ransac_pinned_seed();                                // >= 0: pinned (mods_ransac_pin_seed / MODS_RANSAC_SEED)
 
 // lane k adds gain[i][k], i = 0..len-1, in correspondence order (the MSAC score is a sequential sum)

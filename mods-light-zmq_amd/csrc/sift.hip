@@ -1139,371 +1139,32 @@ __global__ __launch_bounds__(256, 5) void sift_kernel(DescConst k, const float *
 }
 
 // ---------------------------------------------------------------------------------------
-// SIFT, wave-per-8-regions form.  The ordered sums (photometric mean / variance, the histogram bins, the norms) are
+// SIFT, one WAVE per 8 regions.  The ordered sums (photometric mean / variance, the histogram bins, the norms) are
 // sequential chains whose cost on a SIMD is the same for 1 or 64 active lanes, so the lanes of a wave carry the chains of
 // 8 regions at once:
 //   photometric normalisation  lanes 0..7 = the 8 regions, masked values staged through LDS in 64-value chunks
-//   per pixel row r            64 lanes: normalised row r+1 -> ring; gradient / orientation of row r -> (mask*grad, o - bo0), bo0
-//                              lane (region, which of the two row bins of r, column bin) walks its <= 18 columns in order
-//                              and adds the two orientation contributions to the LDS accumulators with ds_add_f64
-//                              (LDS executes a wave's instructions in order, so every bin receives its terms in raster
-//                              order; lanes of one instruction never share a bin)
+//   per pixel row r            64 lanes: gradient / orientation of row r -> (mask*grad, o); lane (region, which of the two row
+//                              bins of r, column bin) walks its <= 18 columns in order and adds the two orientation
+//                              contributions to the LDS accumulators with ds_add_f64 (LDS executes a wave's instructions in
+//                              order, so every bin receives its terms in raster order; lanes of one instruction never share a bin)
 //   norms                      lanes 0..7 run the 128-term sums, all lanes scale / clip / quantise
-// No workgroup barrier: the 4 waves of a block only share read-only tables.
-// ---------------------------------------------------------------------------------------
-constexpr int SW_R = 8;          // regions per wave
-constexpr int SW_ACC = 130;      // accumulator stride in doubles (lanes 0..7 read bank-conflict free)
-constexpr int SW_G = 68;         // photometric chunk stride in floats
-constexpr int SW_CW = 18;        // pixel columns a spatial bin spans at most (patch sizes <= 45)
-
-static size_t sift_wave_scratch_floats(int ps) {   // per wave: ring 3 rows | pxrow (float2) + pad | borow + pad   (g aliases the ring)
-  const size_t row = (size_t)SW_R * ps;
-  size_t f = 3 * row + 2 * (row + SW_CW) + (row + SW_CW + 3) / 4 + 8;
-  const size_t g = (size_t)SW_R * SW_G;
-  if (f < g) f = g;
-  return (f + 3) & ~(size_t)3;
-}
-static size_t sift_wave_lds_bytes(int ps) {
-  const size_t ppa = ((size_t)ps * ps + 7) & ~(size_t)7;
-  return sizeof(float) * 2048 + sizeof(float) * (4 * ps + 4) + sizeof(unsigned short) * ppa +
-         4 * (sizeof(double) * SW_R * SW_ACC + sizeof(float) * (sift_wave_scratch_floats(ps) + 4 * SW_R)) + 64;
-}
-
-// grid = (N, n_img), block = 256 (4 independent waves): patches -> descriptors
-__global__ __launch_bounds__(256, 2) void sift_wave_kernel(DescConst k, const float *__restrict__ patches, mods_region *__restrict__ reg_all,
-                                                        const int *__restrict__ reg_count, const float *__restrict__ mask,
-                                                        const SiftTab *__restrict__ tab, int scratch_floats) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int ps = k.desc_ps, pp = ps * ps, ppa = (pp + 7) & ~7;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // block-shared, read-only after the setup (every part a multiple of 16 bytes; plain pointer arithmetic only, so
-  // that the compiler keeps treating these as LDS addresses)
-  float *s_ot = smem;   // [8][256]: the orientation coordinate o of computeSiftDescriptor per atan2LUTff (case, table index)
-  float *s_w = s_ot + 2048;
-  int *s_nmask = (int *)(s_w + 4 * ps);
-  unsigned short *s_midx = (unsigned short *)(s_nmask + 4);
-  // per wave
-  double *acc = (double *)(s_midx + ppa) + (size_t)wv * (SW_R * SW_ACC + (scratch_floats + 4 * SW_R) / 2);
-  float *scr = (float *)(acc + SW_R * SW_ACC);
-  float *s_mean = scr + scratch_floats, *s_fac = s_mean + SW_R;
-  int *s_flag = (int *)(s_fac + SW_R);
-  const int rowf = SW_R * ps;
-  float *ring = scr;                                 // [3][rowf]
-  float2 *pxrow = (float2 *)(scr + 3 * rowf);        // [rowf + SW_CW]
-  unsigned char *borow = (unsigned char *)(pxrow + rowf + SW_CW);
-  float *g = scr;                                    // photometric chunk [SW_R][SW_G], dead before the ring is filled
-
-  const double M_PI_DOUBLED = 6.28318530718;
-  sift_tables(tab, ps, s_w);
-  for (int oct = 0; oct < 8; oct++) {   // o = (float)(8.0f * ((double)ori + 2 pi) / 2 pi), siftdesc.cpp:181, for every value ori can take
-    const float ori = atan2_lut_case(oct, g_atan_lut[tid]);
-    s_ot[oct * 256 + tid] = (float)(8.0f * ((double)ori + M_PI_DOUBLED) / M_PI_DOUBLED);
-  }
-  if (tid < 64) {   // raster-ordered list of the masked pixels, one wave, ballot compaction
-    int c = 0;
-    for (int base = 0; base < pp; base += 64) {
-      const int p = base + tid;
-      const bool m = p < pp && mask[p] > 0;
-      const unsigned long long bm = __ballot(m);
-      if (m) s_midx[c + __popcll(bm & ((1ull << tid) - 1ull))] = (unsigned short)p;
-      c += __popcll(bm);
-    }
-    if (tid == 0) s_nmask[0] = c;
-  }
-  __syncthreads();
-  const int n_mask = s_nmask[0];
-  const int b = blockIdx.y;
-  mods_region *reg = reg_all + (size_t)b * k.max_reg;
-  int n = reg_count[b];
-  if (n > k.reg_cap) n = k.reg_cap;
-  const int groups = (n + SW_R - 1) / SW_R;
-  const float o_zero = (float)(8.0f * ((double)0.f + M_PI_DOUBLED) / M_PI_DOUBLED);
-
-  // histogram lane: region hr, row-bin selector hsel, column bin hbc; its column window and weights
-  const int hr = lane >> 3, hsel = (lane >> 2) & 1, hbc = lane & 3;
-  int clo = ps;
-  for (int i = ps - 1; i >= 0; i--) if (s_w[hbc * ps + i] > 0) clo = i;
-  float wcw[SW_CW];
-#pragma unroll
-  for (int q = 0; q < SW_CW; q++) wcw[q] = (clo + q < ps) ? s_w[hbc * ps + clo + q] : 0.f;
-
-#ifdef SIFT_PROF
-  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
-  int pn = 0;
-#define SPROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[i] += t_ - pl; pl = t_; }
-#else
-#define SPROF(i)
-#endif
-  for (int grp = blockIdx.x * 4 + wv; grp < groups; grp += gridDim.x * 4) {
-    const int ri0 = grp * SW_R;
-    SPROF(0)
-    // patch of region slot rr (slots past the end repeat the last region; their results are not stored)
-    auto patch_of = [&](int rr) { return patches + ((size_t)b * k.reg_cap + min(ri0 + rr, n - 1)) * pp; };
-    wave_sync();
-    for (int i = lane; i < SW_R * SW_ACC; i += 64) acc[i] = 0.0;
-    if (lane < SW_R) { s_flag[lane] = 0; s_mean[lane] = 0.f; s_fac[lane] = 0.f; }
-    // ---- photometricallyNormalize, helpers.cpp:666-715: mean, then deviation, both as sequential sums over the masked pixels
-    if (k.photo) {
-      float mean_l = 0.f;
-      for (int pass = 0; pass < 2; pass++) {
-        float sum = 0.f;
-        // the values of chunk q0 + 64 are in flight while lanes 0..7 add chunk q0
-        float v[SW_R];
-        {
-          const int idx = s_midx[min(lane, n_mask - 1)];
-#pragma unroll
-          for (int rr = 0; rr < SW_R; rr++) v[rr] = patch_of(rr)[idx];
-        }
-        for (int q0 = 0; q0 < n_mask; q0 += 64) {
-          const int cnt = min(64, n_mask - q0);
-          wave_sync();
-#pragma unroll
-          for (int rr = 0; rr < SW_R; rr++) {
-            float x = v[rr];
-            if (pass) { const float d = s_mean[rr] - x; x = d * d; }
-            g[rr * SW_G + lane] = x;
-          }
-          if (q0 + 64 < n_mask) {
-            const int idx = s_midx[min(q0 + 64 + lane, n_mask - 1)];
-#pragma unroll
-            for (int rr = 0; rr < SW_R; rr++) v[rr] = patch_of(rr)[idx];
-          }
-          wave_sync();
-          if (lane < SW_R) {
-            const float *gl = g + lane * SW_G;
-            int q = 0;
-            for (; q + 3 < cnt; q += 4) {
-              const float4 a = *(const float4 *)(gl + q);
-              sum += a.x; sum += a.y; sum += a.z; sum += a.w;
-            }
-            for (; q < cnt; q++) sum += gl[q];
-          }
-        }
-        if (lane < SW_R) {
-          if (pass == 0) { mean_l = sum / (float)n_mask; s_mean[lane] = mean_l; }
-          else {
-            const float var = sqrtf(sum / (float)n_mask);
-            if (!((double)var < 0.0001)) { s_flag[lane] = 1; s_fac[lane] = 50.0f / var; }
-          }
-        }
-        wave_sync();
-      }
-    }
-    wave_sync();
-    // normalised patch row -> ring slot; the row after next is fetched into registers while the current row is worked on
-    constexpr int RL = 6;                               // >= ceil(SW_R * ps / 64) for ps <= 48 (this kernel runs for ps <= 45)
-    float nxt[RL];
-    auto fetch_row = [&](int r) {
-#pragma unroll
-      for (int u = 0; u < RL; u++) {
-        const int e = lane + 64 * u;
-        if (e < rowf) { const int rr = e / ps; nxt[u] = patch_of(rr)[r * ps + e - rr * ps]; }
-      }
-    };
-    auto store_row = [&](int r) {
-      float *dst = ring + (r % 3) * rowf;
-#pragma unroll
-      for (int u = 0; u < RL; u++) {
-        const int e = lane + 64 * u;
-        if (e < rowf) {
-          const int rr = e / ps;
-          float v = nxt[u];
-          if (s_flag[rr]) {
-            v = 128 + s_fac[rr] * (v - s_mean[rr]);
-            if (v > 255) v = 255;
-            if (v < 0) v = 0;
-          }
-          dst[e] = v;
-        }
-      }
-    };
-    SPROF(1)
-    fetch_row(0); store_row(0);
-    if (ps > 1) { fetch_row(1); store_row(1); }
-    // ---- computeSiftDescriptor / samplePatch (siftdesc.cpp:73-131, 160-198), one pixel row at a time
-    for (int r = 0; r < ps; r++) {
-      if (r + 2 < ps) fetch_row(r + 2);
-      float mrow[RL];   // descriptor mask of this pixel row, per lane slot
-#pragma unroll
-      for (int u = 0; u < RL; u++) {
-        const int e = lane + 64 * u;
-        if (e < rowf) mrow[u] = mask[r * ps + e - (e / ps) * ps];
-      }
-      wave_sync();
-      SPROF(2)
-      {
-        // branch-free: the one-sided differences at the patch border are the same subtraction with one operand at the pixel
-        // itself; all loads of the row are issued before the first use
-        const float *R0 = ring + (r % 3) * rowf;
-        const float *Rdn = r == 0 ? R0 : ring + ((r + 2) % 3) * rowf;        // row r - 1 (row r at the top border)
-        const float *Rup = r == ps - 1 ? R0 : ring + ((r + 1) % 3) * rowf;   // row r + 1 (row r at the bottom border)
-        float xa[RL], xb[RL], ya[RL], yb[RL];
-#pragma unroll
-        for (int u = 0; u < RL; u++) {
-          const int e = lane + 64 * u;
-          if (e < rowf) {
-            const int c = e - (e / ps) * ps;
-            xa[u] = R0[e + (c < ps - 1 ? 1 : 0)];
-            xb[u] = R0[e - (c > 0 ? 1 : 0)];
-            ya[u] = Rup[e];
-            yb[u] = Rdn[e];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < RL; u++) {
-          const int e = lane + 64 * u;
-          if (e < rowf) {
-            const float xgrad = xa[u] - xb[u], ygrad = ya[u] - yb[u];
-            const float grad = sqrtf(xgrad * xgrad + ygrad * ygrad);
-            const AtanSel as = atan2_lut_sel(ygrad, xgrad);
-            const float ot = s_ot[as.oct * 256 + as.idx];
-            const float o = as.zero ? o_zero : ot;
-            const int bo0 = (int)o;
-            pxrow[e] = make_float2(mrow[u] * grad, o - bo0);
-            borow[e] = (unsigned char)(bo0 % 8);
-          }
-        }
-      }
-      wave_sync();
-      SPROF(3)
-      {
-        // the row's two spatial row bins (bin0 / bin1 and their weights; already multiplied by 8 = orientation bins)
-        const int rb = hsel ? tab->bin1[r] : tab->bin0[r];
-        const float wrr = hsel ? tab->w1[r] : tab->w0[r];
-        if (wrr > 0) {
-          double *abin = acc + hr * SW_ACC + rb * 4 + hbc * 8;
-          const float2 *px = pxrow + hr * ps + clo;
-          const unsigned char *bop = borow + hr * ps + clo;
-          float2 pv[SW_CW];
-          int bo[SW_CW];
-#pragma unroll
-          for (int q = 0; q < SW_CW; q++) { pv[q] = px[q]; bo[q] = bop[q]; }
-#pragma unroll
-          for (int q = 0; q < SW_CW; q++) {
-            const float val = wrr * (wcw[q] * pv[q].x);
-            if (val > 0) {
-              const float c0 = val * (1.0f - pv[q].y), c1 = val * pv[q].y;
-#ifdef SIFT_RMW
-              abin[bo[q]] += (double)c0;
-              abin[(bo[q] + 1) & 7] += (double)c1;
-#else
-              __hip_atomic_fetch_add(abin + bo[q], (double)c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-              __hip_atomic_fetch_add(abin + ((bo[q] + 1) & 7), (double)c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#endif
-            }
-          }
-        }
-      }
-      SPROF(4)
-      if (r + 2 < ps) store_row(r + 2);   // slot of row r - 1, which the gradients of row r have finished reading
-    }
-    wave_sync();
-    // ---- normalize / clip / renormalise (siftdesc.cpp:133-158, 199-210, 248-257) and the RootSIFT mapping
-    unsigned long long redo = ~0ull;   // bit 8 rr.. : region rr still takes part
-    for (int pass = 0; pass < 2; pass++) {
-      if (lane < SW_R && ((redo >> (8 * lane)) & 1)) {
-        const double *v = acc + lane * SW_ACC;
-        double len = 0.0;
-#pragma unroll 1
-        for (int i = 0; i < 128; i += 8) {
-          double x[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) x[q] = v[i + q];
-#pragma unroll
-          for (int q = 0; q < 8; q++) x[q] = x[q] * x[q];
-          len += x[0] + x[1] + x[2] + x[3];
-          len += x[4] + x[5] + x[6] + x[7];
-        }
-        len = sqrt(len);
-        ((double *)g)[lane] = 1.0 / len;     // the ring / chunk area is idle here
-      }
-      wave_sync();
-      bool changed = false;
-      {
-        const int rr = lane >> 3;
-        if ((redo >> (8 * rr)) & 1) {
-          const double inv = ((const double *)g)[rr];
-          double *v = acc + rr * SW_ACC;
-          for (int i = lane & 7; i < 128; i += 8) {
-            double x = v[i] * inv;
-            if (pass == 0 && x > k.max_bin) { x = k.max_bin; changed = true; }
-            v[i] = x;
-          }
-        }
-      }
-      const unsigned long long ch = __ballot(changed);
-      unsigned long long next = 0;
-      for (int rr = 0; rr < SW_R; rr++)
-        if ((ch >> (8 * rr)) & 0xffull) next |= 0xffull << (8 * rr);
-      redo = next;
-      wave_sync();
-      if (!redo) break;
-    }
-    if (k.root) {
-      if (lane < SW_R) {
-        const double *v = acc + lane * SW_ACC;
-        double sum = 0.;
-#pragma unroll 1
-        for (int i = 0; i < 128; i += 8) {
-          double x[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) x[q] = v[i + q];
-#pragma unroll
-          for (int q = 0; q < 8; q++) sum += fabs(x[q]);
-        }
-        ((double *)g)[lane] = sum;
-      }
-      wave_sync();
-    }
-    {
-      const int rr = lane >> 3;
-      if (ri0 + rr < n) {
-        const double *v = acc + rr * SW_ACC;
-        const double rs = k.root ? ((const double *)g)[rr] : 1.0;
-        uint32_t *out = (uint32_t *)reg[ri0 + rr].desc;
-        for (int w4 = lane & 7; w4 < 32; w4 += 8) {
-          uint32_t word = 0;
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const double x = v[4 * w4 + q];
-            const double y = k.root ? sqrt(x / rs) : x;
-            int bq = (int)(512.0 * y + 0.5);
-            bq = bq < 255 ? bq : 255;
-            bq = bq > 0 ? bq : 0;
-            word |= (uint32_t)bq << (8 * q);
-          }
-          out[w4] = word;
-        }
-      }
-    }
-    SPROF(5)
-#ifdef SIFT_PROF
-    pn++;
-#endif
-  }
-#ifdef SIFT_PROF
-  if (lane == 0 && blockIdx.y == 0 && (blockIdx.x % 64) == 3 && wv == 1)
-    printf("sift_wave prof: block %d groups %d cycles: other %llu photo %llu rowfetch+store %llu grad %llu hist %llu norm %llu\n", blockIdx.x, pn,
-           pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------
-// SIFT, wave-per-8-regions form, second generation (round 3).  Same arithmetic and the same lane roles as sift_wave_kernel;
-// what changed is everything around the arithmetic (profiles/r03_sift_*):
-//   * persistent waves: 2 workgroups of 6 waves per CU pull work units (8 regions of one image) from a device counter, so
-//     the tables are set up once per workgroup instead of once per 8 regions (the old grid spent 71 % of its workgroups on
-//     set-up alone) and the images of a batch balance;
+// Around the arithmetic (profiles/r03_sift_*; the round-2 form of this kernel is docs/history/r05_removed_paths.patch):
+//   * persistent waves: one workgroup of 12 waves per CU pulls work units (8 regions of one image) from a device counter, so
+//     the tables are set up once per workgroup and the images of a batch balance; no workgroup barrier after the set-up;
 //   * the histogram bins live at  bo * 128 + (g >> 2) * 64 + br * 16 + (g & 3) * 4 + bc  (doubles): the 32 lanes of a
 //     half-wave - 4 regions x 2 row bins x 4 column bins - always hit 32 different bank pairs whatever the orientation
 //     bins are, so ds_add_f64 runs at its conflict-free rate (10 instead of 23 cycles per wave instruction, tools/ubench);
 //   * the three pixel rows a gradient needs stay in registers (vertical neighbours = the lane's own values of the previous /
 //     next row, horizontal neighbours = one DPP move from the adjacent lane), the patch rows are fetched three rows ahead;
 //     photometric mean / factor sit in registers per pixel slot;
-//   * 11 KB of LDS per wave and <= 168 VGPRs: 12 waves per CU instead of 8.
+//   * 11 KB of LDS per wave and <= 168 VGPRs: 12 waves per CU.
 // LDS: o table 8 KB | row / column weights | work prefix | masked-pixel list || per wave: bins 8 KB | pixel row (x, o) + pad
 // (the photometric chunk aliases it) | mean, factor, flag.
 // ---------------------------------------------------------------------------------------
+constexpr int SW_R = 8;          // regions per wave
+constexpr int SW_G = 68;         // photometric chunk stride in floats
+constexpr int SW_CW = 18;        // pixel columns a spatial bin spans at most (patch sizes <= 45)
+constexpr int S2_MAX_IMG = 64;   // images of one launch (work prefix table in LDS)
 constexpr int S2_WAVES = 12;               // one workgroup per CU: 3 waves per SIMD (<= 168 VGPRs), 145 KB of LDS
 constexpr int S2_BINS = 1024;                 // doubles per wave
 __device__ __forceinline__ int s2_bin(int g, int br, int bc) { return (g >> 2) * 64 + br * 16 + (g & 3) * 4 + bc; }   // + bo * 128
@@ -1898,11 +1559,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   float *pool = ctx->desc_scratch + patch_elems + book_elems;
   MODS_HIP_CHECK(hipMemsetAsync(bl, 0, sizeof(BigLists), ctx->stream));
   k.tap_cap = 4096;
-  static const int small_cap = [] {   // P2 limit of the LDS tier (tuning knob, <= SMALL_CAP)
-    const char *e = getenv("MODS_SMALL_CAP");
-    const int v = e ? atoi(e) : SMALL_CAP;
-    return v < 0 ? 0 : (v > SMALL_CAP ? SMALL_CAP : v);
-  }();
+  const int small_cap = SMALL_CAP;   // P2 limit of the LDS tier
   k.p2_hi = small_cap;
   hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
                      ctx->region_count, bl, bregs, sitems, ritems, fitems, small_items, small_cap_items, std::min(small_cap, 48), max_big, max_items,
@@ -1930,42 +1587,40 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   hipLaunchKernelGGL(big_rowpass_kernel, dim3(4096), dim3(256), 0, ctx->stream, k, bl, bregs, ritems, max_items, pool,
                      ctx->desc_err_dev);
   hipLaunchKernelGGL(big_colres_kernel, dim3(4096), dim3(256), 0, ctx->stream, k, bl, bregs, max_big, pool, patches, ctx->desc_err_dev);
-  static const bool sift_block_form = getenv("MODS_SIFT_BLOCK") != nullptr;   // the block-per-region form (A/B measurements)
-  if (run_sift && (sift_block_form || ps > 45))
+  if (run_sift && ps > 45)   // the block-per-region form: patch sizes the wave form's register rows do not cover
     hipLaunchKernelGGL(sift_kernel, dim3(2048, n_img), dim3(256), sift_lds_bytes(ps), ctx->stream, k, patches, ctx->regions_dev,
                        ctx->region_count, dmask, tab);
   else if (run_sift) {
-    static const bool first_form = getenv("MODS_SIFT_V1") != nullptr;   // the round-2 kernel (A/B measurements)
-    if (first_form || n_img > 64) {
-      static DynLdsOnce once;
-      MODS_HIP_CHECK(dyn_lds_once(once, (const void *)sift_wave_kernel, 160 * 1024, ctx->device));
-      hipLaunchKernelGGL(sift_wave_kernel, dim3(1024, n_img), dim3(256), sift_wave_lds_bytes(ps), ctx->stream, k, patches,
-                         ctx->regions_dev, ctx->region_count, dmask, tab, (int)sift_wave_scratch_floats(ps));
-    } else {
-      static DynLdsOnce once16, once18;
-      MODS_HIP_CHECK(dyn_lds_once(once16, (const void *)sift_wave2_kernel<16>, 160 * 1024, ctx->device));
-      MODS_HIP_CHECK(dyn_lds_once(once18, (const void *)sift_wave2_kernel<SW_CW>, 160 * 1024, ctx->device));
-      // widest span of positive column weights of a spatial bin (siftdesc.cpp:22-71: step = 5 / (2 * (ps / 2)), bins x - 1 and x)
-      int span = 0;
-      {
-        const float step = 5.0f / (float)(2 * (ps >> 1));
-        for (int bc = 0; bc < 4; bc++) {
-          int lo = ps, hi = -1;
-          for (int i = 0; i < ps; i++) {
-            const float x = step * i; const int xi = (int)x; const float w1 = x - xi, w0 = 1.0f - w1;
-            const bool on = (xi - 1 == bc && w0 > 0) || (xi == bc && w1 > 0);
-            if (on) { lo = std::min(lo, i); hi = i; }
-          }
-          if (hi >= lo) span = std::max(span, hi - lo + 1);
+    static DynLdsOnce once16, once18;
+    MODS_HIP_CHECK(dyn_lds_once(once16, (const void *)sift_wave2_kernel<16>, 160 * 1024, ctx->device));
+    MODS_HIP_CHECK(dyn_lds_once(once18, (const void *)sift_wave2_kernel<SW_CW>, 160 * 1024, ctx->device));
+    // widest span of positive column weights of a spatial bin (siftdesc.cpp:22-71: step = 5 / (2 * (ps / 2)), bins x - 1 and x)
+    int span = 0;
+    {
+      const float step = 5.0f / (float)(2 * (ps >> 1));
+      for (int bc = 0; bc < 4; bc++) {
+        int lo = ps, hi = -1;
+        for (int i = 0; i < ps; i++) {
+          const float x = step * i; const int xi = (int)x; const float w1 = x - xi, w0 = 1.0f - w1;
+          const bool on = (xi - 1 == bc && w0 > 0) || (xi == bc && w1 > 0);
+          if (on) { lo = std::min(lo, i); hi = i; }
         }
+        if (hi >= lo) span = std::max(span, hi - lo + 1);
       }
-      // persistent: one workgroup of 12 waves per CU, work units pulled from bl->sift_next (zeroed with bl above)
+    }
+    // persistent: one workgroup of 12 waves per CU, work units pulled from bl->sift_next (zeroed with bl above; batches of
+    // more than S2_MAX_IMG images take one launch per S2_MAX_IMG images)
+    for (int b0 = 0; b0 < n_img; b0 += S2_MAX_IMG) {
+      const int nb = std::min(S2_MAX_IMG, n_img - b0);
+      if (b0) MODS_HIP_CHECK(hipMemsetAsync(&bl->sift_next, 0, sizeof(int), ctx->stream));
+      const float *pch = patches + (size_t)b0 * k.reg_cap * pp;
+      mods_region *regs = ctx->regions_dev + (size_t)b0 * k.max_reg;
       if (span <= 16)
-        hipLaunchKernelGGL(sift_wave2_kernel<16>, dim3(ctx->n_cu), dim3(64 * S2_WAVES), sift_wave2_lds_bytes(ps), ctx->stream, k, patches,
-                           ctx->regions_dev, ctx->region_count, dmask, tab, n_img, &bl->sift_next);
+        hipLaunchKernelGGL(sift_wave2_kernel<16>, dim3(ctx->n_cu), dim3(64 * S2_WAVES), sift_wave2_lds_bytes(ps), ctx->stream, k, pch,
+                           regs, ctx->region_count + b0, dmask, tab, nb, &bl->sift_next);
       else
-        hipLaunchKernelGGL(sift_wave2_kernel<SW_CW>, dim3(ctx->n_cu), dim3(64 * S2_WAVES), sift_wave2_lds_bytes(ps), ctx->stream, k, patches,
-                           ctx->regions_dev, ctx->region_count, dmask, tab, n_img, &bl->sift_next);
+        hipLaunchKernelGGL(sift_wave2_kernel<SW_CW>, dim3(ctx->n_cu), dim3(64 * S2_WAVES), sift_wave2_lds_bytes(ps), ctx->stream, k, pch,
+                           regs, ctx->region_count + b0, dmask, tab, nb, &bl->sift_next);
     }
   }
   MODS_HIP_CHECK(hipGetLastError());

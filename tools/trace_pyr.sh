@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rm -rf /tmp/tp; MODS_PYR_FORK=${FORK:-1} timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tp -- python $R/tools/prof_detect.py 16 > /tmp/tp.log 2>&1
+rm -rf /tmp/tp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tp -- python $R/tools/prof_detect.py 16 > /tmp/tp.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/tp/**/*kernel_trace.csv", recursive=True)[0]
