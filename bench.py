@@ -5,7 +5,7 @@ synthetic 1920x1080 pairs, HessianAffine + RootSIFT, one identity view per image
 
   python bench.py --gpus N --steps K --warmup W
 
-A step = one batch of --pairs-per-step (default 48) image pairs through the whole hot path, SURVEY.md 8d's boundary:
+A step = one batch of --pairs-per-step (default 256) image pairs through the whole hot path, SURVEY.md 8d's boundary:
 two decoded 8-bit grey images in (pinned) host memory -> upload -> detect, describe, match, duplicate filter, LO-RANSAC ->
 inlier set + H on the host (mods.cpp:184-383).  --input hbm keeps the images resident in HBM instead (fp32).  The reported
 value is pairs / second.  N > 1 is launched by torch.distributed.run, one rank per GPU; pairs are independent units, so every
@@ -81,12 +81,13 @@ def cpu_baseline(img1, img2, seed):
         orc.lib().orc_set_threads(1)
         return time.time() - t0, ninl
 
-    t_all, ninl = chain(ncpu, 1)          # OpenMP over rows / keypoints / queries inside every stage, all cores
+    t_all, ninl = chain(ncpu, 1)          # OpenMP over rows / keypoints / queries inside every stage, every usable core
+    fastest = None                        # a smaller team can be faster (fork / join cost of the short loops): reported beside it
     for n_try in (16, 8):
         if n_try < ncpu:
             t_try, _ = chain(n_try, 1)
-            if t_try < t_all:
-                t_all, ncpu = t_try, n_try
+            if t_try < t_all and (fastest is None or t_try < fastest[0]):
+                fastest = (t_try, n_try)
     t_ref, _ = chain(1, 2)                # the reference's structure: the two images as two tasks, the rest serial
     t_one, _ = chain(1, 1)
     return {"value": round(1.0 / t_all, 5), "unit": "pairs/s", "cores": ncpu, "kind": "port",
@@ -94,6 +95,7 @@ def cpu_baseline(img1, img2, seed):
                       "when oracle/_ref is present), %d inliers: %.1f s with OpenMP over rows / keypoints / queries on %d "
                       "cores, %.1f s in the reference's task structure (2 images side by side, mods.cpp:234-251), %.1f s on 1 core"
                       % (ninl, t_all, ncpu, t_ref, t_one),
+            "fastest_team": ({"value": round(1.0 / fastest[0], 5), "cores": fastest[1]} if fastest else None),
             "reference_task_structure": {"value": round(1.0 / t_ref, 5), "cores": 2},
             "one_core": {"value": round(1.0 / t_one, 5), "cores": 1}}
 
@@ -210,7 +212,7 @@ def other_configs(args):
             while pending:
                 res.append(pipe.next()[0]); pending -= 1
             return res
-        pps = max(1, args.pairs_per_step)
+        pps = max(1, args.pairs_per_step or 48)
         run(args.warmup * pps)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         res = run(args.steps * pps)
@@ -253,7 +255,7 @@ def other_configs(args):
             while pending:
                 res.append(pipe.next()[0]); pending -= 1
             return res
-        pps = max(1, min(args.pairs_per_step, 8))
+        pps = max(1, min(args.pairs_per_step or 8, 8))
         run(max(1, args.warmup) * pps)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pres = run(args.steps * pps)
@@ -283,53 +285,137 @@ def other_configs(args):
                              "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(ach / MFMA_I8_PEAK_TOPS, 4), "traffic": None,
                              "stage_ms": round(mms, 3)})
         ctx.close()
-    else:   # c3
-        w, h = 1920, 1080
-        a, b = _hard_pair(synth, np, w, h, 3000)
-        t = torch.from_numpy(np.stack([a, b])).cuda()
-        d = pkg.view_ctx_dims(w, h)
-        ctx = pkg.Context(0, d[0], d[1], 2)      # two image slots: a view of both images in one chain of launches
-        rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
-        steps = pkg.iters_mods_steps()
-        if args.ladder == "hessian":     # the two HessianAffine sections only (what rounds 1-3 measured)
-            def run_once():
-                return pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2)[0]
-            what = "iters_MODS.ini HessianAffine steps"
-        else:                            # the file as it is: [MSER0], [MSER1], [HessianAffine2], [HessianAffine3]
-            L = pkg.LadderStep.make
-            det_steps = [[None, None, steps[0], steps[1]],
-                         [L((1,), 360.0, scales=(1, 0.25, 0.125), init_sigma=0.8, fginn=0.85, half_orientation=1),
-                          L((1, 3, 6), 360.0, scales=(1, 0.25), init_sigma=0.8, fginn=0.8, half_orientation=1), None, None]]
-            dets = [pkg.HessAffParams.default(), pkg.HessAffParams.mser()]
-            repm1, repm2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
-
-            def run_once():
-                return pkg.match_ladder_dets_dev(ctx, t.data_ptr(), w, h, det_steps, dets, [rep1, repm1], [rep2, repm2])[0]
-            what = "iters_MODS.ini, all four steps (MSER, MSER, HessianAffine, HessianAffine)"
-        for _ in range(args.warmup):
-            run_once()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        res = [run_once() for _ in range(args.steps)]
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        r = res[-1]
-        out.update(value=round(args.steps / dt, 4), ms_per_step=round(dt / args.steps * 1e3, 3),
-                   config={"workload": what + " on one hard 1920x1080 pair (tilt 6), 1 GPU (BASELINE configs[2])",
-                           "view_workers": int(os.environ.get("MODS_LADDER_WORKERS", "4")),
-                           "steps_done": r.steps_done, "views": r.n_views, "regions": list(r.n_described), "tentatives": r.n_tentatives,
-                           "unique": r.n_unique, "inliers": r.n_inliers, "ransac_samples": r.ransac_samples,
-                           "stage_ms": {"synth_detect_describe": round(r.ms_detect_describe, 2), "match": round(r.ms_match, 2),
-                                        "duplicates": round(r.ms_duplicates, 2), "ransac": round(r.ms_ransac, 2)}})
-        rep1.close(); rep2.close(); ctx.close()
     print(json.dumps(out))
+
+
+def config_c3(args):
+    """BASELINE configs[2]: the view-synthesis ladder of iters_MODS.ini on ONE hard 1920x1080 pair.  --gpus 1: one context (the views
+    of a step side by side on its view workers).  --gpus N (launched by torch.distributed.run, one rank per GPU): the views of every
+    step sharded over the ranks largest first, ONE all-gather of the described regions per step over RCCL, the search split by query
+    rows, verification on rank 0 (mods-light-zmq_amd/shard.py); rank 0 then times the same ladder through the C++ form of
+    that decomposition (mods_match_ladder_multi: one process, one host thread + one communicator rank per device) while the other
+    ranks wait.  --min-matches (default: never reached) keeps the step loop from stopping early, so that every step of the file runs."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import synth
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    share = os.environ.get("MODS_BENCH_SHARE_GPU") == "1"
+    if world > 1:
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("MODS_BENCH_PG_TIMEOUT", "300")))
+        if share:
+            dist.init_process_group("gloo", timeout=pg_timeout)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
+    device = local_rank if (world > 1 and not share) else 0
+    torch.cuda.set_device(device)
+    pkg = ge.load_package()
+    if pkg.lib().mods_device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: libmodsgpu has no CPU path")
+    pkg.ransac_pin_seed(12345)
+    out = {"metric": "image_pairs_per_sec_end_to_end", "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    w, h = W, H
+    a, b = _hard_pair(synth, np, w, h, 3000)
+    t = torch.from_numpy(np.stack([a, b])).cuda(device)
+    d = pkg.view_ctx_dims(w, h)
+    ctx = pkg.Context(device, d[0], d[1], 2)      # two image slots: a view of both images in one chain of launches
+    steps = pkg.iters_mods_steps()
+    mm = args.min_matches
+    if world > 1:
+        import importlib
+        shard = importlib.import_module("mods_light_zmq_amd.shard")
+        what = "iters_MODS.ini HessianAffine steps, views sharded over %d ranks (one all-gather of the regions per step)" % world
+
+        def run_once():
+            return shard.match_ladder_distributed(pkg, ctx, t.data_ptr(), w, h, steps, dist, device, min_matches=mm, seed_time=12345)
+    elif args.ladder == "hessian":     # the two HessianAffine sections only
+        rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
+
+        def run_once():
+            return pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2, min_matches=mm)[0]
+        what = "iters_MODS.ini HessianAffine steps"
+    else:                              # the file as it is: [MSER0], [MSER1], [HessianAffine2], [HessianAffine3]
+        rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
+        L = pkg.LadderStep.make
+        det_steps = [[None, None, steps[0], steps[1]],
+                     [L((1,), 360.0, scales=(1, 0.25, 0.125), init_sigma=0.8, fginn=0.85, half_orientation=1),
+                      L((1, 3, 6), 360.0, scales=(1, 0.25), init_sigma=0.8, fginn=0.8, half_orientation=1), None, None]]
+        dets = [pkg.HessAffParams.default(), pkg.HessAffParams.mser()]
+        repm1, repm2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
+
+        def run_once():
+            return pkg.match_ladder_dets_dev(ctx, t.data_ptr(), w, h, det_steps, dets, [rep1, repm1], [rep2, repm2], min_matches=mm)[0]
+        what = "iters_MODS.ini, all four steps (MSER, MSER, HessianAffine, HessianAffine)"
+    for _ in range(args.warmup):
+        run_once()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = [run_once() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    r = res[-1]
+    get = (lambda k: r[k]) if isinstance(r, dict) else (lambda k: getattr(r, k))
+    cfg = {"workload": what + " on one hard 1920x1080 pair (tilt 6), BASELINE configs[2]", "min_matches": mm,
+           "view_workers": int(os.environ.get("MODS_LADDER_WORKERS", "4")),
+           "steps_done": get("steps_done"), "views": get("n_views"), "regions": list(get("n_described")), "tentatives": get("n_tentatives"),
+           "unique": get("n_unique"), "inliers": get("n_inliers"),
+           "parallelism": "views sharded, %d rank(s)" % world}
+    if not isinstance(r, dict):
+        cfg["ransac_samples"] = r.ransac_samples
+        cfg["stage_ms"] = {"synth_detect_describe": round(r.ms_detect_describe, 2), "match": round(r.ms_match, 2),
+                           "duplicates": round(r.ms_duplicates, 2), "ransac": round(r.ms_ransac, 2)}
+    if world > 1 and not share:
+        # the same decomposition as ONE process (C++ host: a thread and a communicator rank per device); rank 0 runs it, the others wait
+        multi = None
+        if rank == 0:
+            try:
+                mg = pkg.Multi(list(range(world)), w, h)
+                for _ in range(max(1, args.warmup)):
+                    mg.match_ladder(a, b, steps, min_matches=mm)
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    mr, _ = mg.match_ladder(a, b, steps, min_matches=mm)
+                dm = (time.perf_counter() - t1) / args.steps
+                multi = {"what": "mods_match_ladder_multi: one process, one host thread + one RCCL rank per device (images from host memory)",
+                         "ms_per_pair": round(dm * 1e3, 3), "value": round(1.0 / dm, 4), "uses_rccl": bool(mg.uses_rccl),
+                         "steps_done": mr.steps_done, "views": mr.n_views, "inliers": mr.n_inliers,
+                         "same_inliers_as_ranks": bool(mr.n_inliers == get("n_inliers"))}
+                mg.close()
+            except Exception as e:      # reported, not fatal: the ranks' figure above stands on its own
+                multi = {"error": str(e)[:200]}
+        dist.barrier()
+        cfg["in_process_multi"] = multi
+    out.update(value=round(args.steps / dt, 4), ms_per_step=round(dt / args.steps * 1e3, 3), config=cfg)
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=6, help="distinct synthetic pairs cycled through the steps")
-    ap.add_argument("--pairs-per-step", type=int, default=48, help="image pairs in the batch that one step processes")
+    ap.add_argument("--pairs-per-step", type=int, default=None,
+                    help="image pairs in the batch that one step processes (default 256 for the headline configuration: 20 steps are\n"
+                         "~5000 pairs = a timed region of several seconds; 48 for c4, 8 for c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gpu-workers", type=int, default=6, help="pipeline threads running detect/describe/match (one context each)")
     ap.add_argument("--verify-workers", type=int, default=8, help="pipeline threads running duplicate filter + LO-RANSAC")
@@ -343,6 +429,9 @@ def main():
                     help="--config c5: one plane (SURVEY 8d's generator: every sample is H-degenerate) or two planes with parallax")
     ap.add_argument("--ladder", default="full", choices=["full", "hessian"],
                     help="--config c3: the whole iters_MODS.ini (MSER steps 0-1, HessianAffine steps 2-3) or its HessianAffine steps only")
+    ap.add_argument("--min-matches", type=int, default=1 << 30,
+                    help="--config c3: [Iterations] minMatches of the step loop (default: never reached, every step of the ladder runs; "
+                         "15 = the reference's file, where the loop stops after the first step that verifies 15 matches)")
     ap.add_argument("--keep-workers", action="store_true", help="N > 1: do not shrink the worker counts to the rank's share of the host cores")
     ap.add_argument("--inlier-ratio", type=float, default=0.0,
                     help="0 (default): SURVEY 8d's pairs (one homography, ~94 %% of the tentatives are inliers: 3 RANSAC samples); "
@@ -352,6 +441,8 @@ def main():
                     help="BASELINE.json configs[]: c2 = the headline 1080p pair (default, what the driver runs); c3 = view-synthesis "
                          "ladder on a hard 1080p pair; c4 = 1-MP pairs (throughput); c5 = 4096x4096 pair with DEGENSAC F verification")
     args = ap.parse_args()
+    if args.config == "c3":
+        return config_c3(args)
     if args.config != "c2":
         return other_configs(args)
 
@@ -445,7 +536,7 @@ def main():
             out.append(pipe.next()[0]); pending -= 1
         return out
 
-    pps = max(1, args.pairs_per_step)
+    pps = max(1, args.pairs_per_step or 256)
     run(args.warmup * pps)
     # HIP events around every blur launch of the timed steps, on the streams the launches go to (the workers' streams)
     if pipe is not None:
@@ -528,17 +619,37 @@ def main():
                 k += 1
             nq, nt = len(rep_q), len(rep_t)
             pkg.match_reps(bctx, rep_q, rep_t)                      # warm-up
-            bctx.timing_enable(["match"]); bctx.timing_reset()
             reps_m = 5
+            bctx.timing_enable(["match"]); bctx.timing_reset()
             for _ in range(reps_m):
                 tent, _, _ = pkg.match_reps(bctx, rep_q, rep_t)
             m_ms, m_n, _ = bctx.timing_read("match")
+            # the matrix-core kernel alone (match_nn1_kernel), in a pass of its own so that its event pair is not inside the stage's figure
+            bctx.timing_enable(["match_nn1"]); bctx.timing_reset()
+            for _ in range(reps_m):
+                pkg.match_reps(bctx, rep_q, rep_t)
+            k_ms, k_n, _ = bctx.timing_read("match_nn1")
             bctx.timing_enable([])
-            match_leg = (nq, nt, m_ms / reps_m, len(tent))
+            match_leg = (nq, nt, m_ms / reps_m, len(tent), k_ms / max(k_n, 1), k_n // reps_m)
             rep_q.close(); rep_t.close()
         bctx.close()
         del batch_t
     last = step(0)
+    # BASELINE configs[1] is "Single 1920x1080 pair": the latency of ONE pair with nothing else in flight, two ways - one
+    # mods_match_pair_dev call (images fp32 in HBM, every stage on the caller's context, the runtime's own wait), and one pair through
+    # the pipeline from 8-bit images in pinned host memory (its threads sleep between looks at their streams: +0.05-0.1 ms per stage)
+    latency = None
+    if rank == 0:
+        import statistics
+        ts = []
+        for i in range(12):
+            t1 = time.perf_counter(); step(i); ts.append((time.perf_counter() - t1) * 1e3)
+        latency = {"one_call_hbm_f32": {"median": round(statistics.median(ts[2:]), 3), "min": round(min(ts[2:]), 3), "calls": len(ts) - 2}}
+        if pipe is not None:
+            tp = []
+            for i in range(12):
+                t1 = time.perf_counter(); submit(i); pipe.next(); tp.append((time.perf_counter() - t1) * 1e3)
+            latency["pipeline_one_in_flight_" + args.input] = {"median": round(statistics.median(tp[2:]), 3), "min": round(min(tp[2:]), 3), "calls": len(tp) - 2}
 
     rank_rates = [n_pairs / dt]
     if world > 1:
@@ -561,6 +672,7 @@ def main():
             "metric": "image_pairs_per_sec_end_to_end", "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "latency_ms_single_pair": latency,
             "host": host, "pairs_per_s_by_rank": rank_rates,
             # what a pair costs the HOST (rank 0, timed steps): CPU seconds of the whole process per pair (every thread), and of the
             # pipeline's own worker threads inside their stages; process_cpu_s_per_pair x pairs/s = busy cores per rank
@@ -586,26 +698,29 @@ def main():
             # 0-1 at this batching: 95 % of the pyramid's bytes), measured during the timed steps; algorithmic bytes by SURVEY 8d's
             # unfused model: 8 B/px for the blur + 8 B/px for the response of every level it produces.  The launches of the smaller
             # planes use the 16-row instantiation and are launch-size bound: "all_blur_launches" is the figure over both
-            "roofline": {"kernel": "gauss_blur_fast_kernel<R,32,2,true> (blur + Hessian response)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # `achieved` / `frac`: the launches of the TIMED steps, where the GPU workers' contexts share the GPU (a launch
-                         # then gets a fraction of the bandwidth: a contention figure); *_isolated: the same launches on one stream with
-                         # nothing else on the GPU (the kernel's own figure; details under "isolated")
-                         "achieved_isolated": round(gbs(i_bytes, i_ms), 2), "frac_isolated": round(gbs(i_bytes, i_ms) / HBM_PEAK_GBS, 4),
-                         # `achieved` prices a launch by SURVEY 8d's UNFUSED model (blur 8 B/px + response 8 B/px = 16 B/px), as 8d asks;
-                         # the fused kernel's own algorithmic bytes are 12 B/px (reads 4, writes 8): that figure is achieved_fused_model
+            "roofline": {"kernel": "gauss_blur_fast_kernel<R,32,2,true> (blur + Hessian response)", "bound": "hbm",
+                         # `achieved` / `frac`: the kernel's own figure - its launches for one batch on one stream with nothing else on the
+                         # GPU (HIP events, a separate leg right after the timed steps; details under "isolated").  *_in_pipeline: the
+                         # same launches DURING the timed steps, where six contexts share the GPU and a launch gets a fraction of the
+                         # bandwidth - a contention figure, not the kernel's
+                         "achieved": round(gbs(i_bytes, i_ms), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(i_bytes, i_ms) / HBM_PEAK_GBS, 4),
+                         "achieved_in_pipeline": round(achieved, 2), "frac_in_pipeline": round(achieved / HBM_PEAK_GBS, 4),
+                         # a launch is priced by SURVEY 8d's UNFUSED model (blur 8 B/px + response 8 B/px = 16 B/px), as 8d asks; the
+                         # fused kernel's own algorithmic bytes are 12 B/px (reads 4, writes 8): *_fused_model
                          "bytes_model": "SURVEY 8d unfused: 16 B/px per level",
-                         "achieved_fused_model": round(achieved * 0.75, 2), "frac_fused_model": round(achieved * 0.75 / HBM_PEAK_GBS, 4),
+                         "achieved_fused_model": round(gbs(i_bytes, i_ms) * 0.75, 2), "frac_fused_model": round(gbs(i_bytes, i_ms) * 0.75 / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
                          # note + WRITE_SIZE, mean over the blur launches of the default batching, 16 images per launch)
                          "traffic": pmc_blur_traffic() if (args.config == "c2" and pipe is not None and args.pairs_per_batch == 8 and args.inlier_ratio == 0) else None,
-                         "measured": "HIP events on the workers' streams during the timed steps",
-                         "launches": blur_n, "mean_launch_us": round(blur_ms / max(blur_n, 1) * 1e3, 3),
-                         "algorithmic_bytes_per_launch": round(blur_bytes / max(blur_n, 1), 1),
-                         "all_blur_launches": {"achieved": round(gbs(blur_bytes + small_bytes, blur_ms + small_ms), 2),
-                                               "frac": round(gbs(blur_bytes + small_bytes, blur_ms + small_ms) / HBM_PEAK_GBS, 4),
-                                               "launches": blur_n + small_n},
-                         "isolated": {"what": "the same launches on one stream, nothing else on the GPU (separate leg after the timed steps)",
+                         "measured": "HIP events around every launch, on the stream it is launched on",
+                         "launches": i_n, "mean_launch_us": round(i_ms / max(i_n, 1) * 1e3, 3),
+                         "algorithmic_bytes_per_launch": round(i_bytes / max(i_n, 1), 1),
+                         "in_pipeline": {"what": "the launches of the timed steps on the workers' streams (six contexts share the GPU)",
+                                         "launches": blur_n, "mean_launch_us": round(blur_ms / max(blur_n, 1) * 1e3, 3),
+                                         "all_blur_launches": {"achieved": round(gbs(blur_bytes + small_bytes, blur_ms + small_ms), 2),
+                                                               "frac": round(gbs(blur_bytes + small_bytes, blur_ms + small_ms) / HBM_PEAK_GBS, 4),
+                                                               "launches": blur_n + small_n}},
+                         "isolated": {"what": "one batch's launches on one stream, nothing else on the GPU (separate leg after the timed steps)",
                                       "achieved": round(gbs(i_bytes, i_ms), 2), "frac": round(gbs(i_bytes, i_ms) / HBM_PEAK_GBS, 4),
                                       "achieved_fused_model": round(gbs(i_bytes, i_ms) * 0.75, 2), "frac_fused_model": round(gbs(i_bytes, i_ms) * 0.75 / HBM_PEAK_GBS, 4),
                                       "launches": i_n, "mean_launch_us": round(i_ms / max(i_n, 1) * 1e3, 3),
@@ -639,12 +754,16 @@ def main():
                                        "one_scope": {"what": "as shipped: the octaves from the third on (and their NMS) on a side stream", "ms": round(pyr_ms["pyramid"], 4), "achieved": round(gbs(pyr_bytes, pyr_ms["pyramid"]), 2),
                                                      "frac": round(gbs(pyr_bytes, pyr_ms["pyramid"]) / HBM_PEAK_GBS, 4)}}
         if match_leg:
-            nq, nt, mms, ntent = match_leg
+            nq, nt, mms, ntent, kms, klaunches = match_leg
             ops = 2.0 * nq * nt * 128
             ach = ops / (mms * 1e-3) / 1e12
-            out["roofline_match"] = {"kernel": "match stage (pack + match_nn1_kernel + mid + match_fginn_kernel + emit; i8 MFMA)", "bound": "mfma",
+            kach = ops / (kms * klaunches * 1e-3) / 1e12 if kms else 0.0
+            out["roofline_match"] = {"kernel": "match stage (pack + match_nn1_kernel + fix + mid + match_fginn_kernel + emit; i8 MFMA)", "bound": "mfma",
                                      "achieved": round(ach, 2), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
                                      "frac": round(ach / MFMA_I8_PEAK_TOPS, 4), "traffic": None,
+                                     # the matrix-core kernel on its own (HIP events around match_nn1_kernel only): what the MFMA pipe does
+                                     "kernel_frac": round(kach / MFMA_I8_PEAK_TOPS, 4), "kernel_achieved": round(kach, 2),
+                                     "kernel_us": round(kms * 1e3, 2), "kernel_launches_per_search": klaunches,
                                      "queries": nq, "trains": nt, "ops": ops, "stage_ms": round(mms, 4), "tentatives": ntent,
                                      "measured": "HIP events around the match stage, BASELINE configs[4]-sized lists built from the "
                                                  "benchmark's regions (separate leg after the timed steps)"}

@@ -133,6 +133,7 @@ enum { MODS_STAGE_BLUR = 0, MODS_STAGE_RESPONSE, MODS_STAGE_RESIZE, MODS_STAGE_N
        MODS_STAGE_PYRAMID,      /* the whole scale space of a batch in ONE scope on the context's stream: every blur, response and
                                  * resize launch of every octave + NMS + compaction (the small octaves run on a second stream
                                  * inside it, so the per-stage sums above overlap and add up to more than this) */
+       MODS_STAGE_MATCH_NN1,    /* the matrix-core kernel of the search alone (match_nn1_kernel, i8 MFMA), inside MODS_STAGE_MATCH */
        MODS_STAGE_COUNT };
 int mods_ctx_timing_enable(mods_ctx *ctx, int stage_mask);
 /* Streams the Hessian scale space of a large batch is built on: 2 (default) = the octaves from the third on, and their non-maximum
@@ -230,6 +231,12 @@ int mods_regions_fetch(mods_ctx *ctx, int img, mods_region *out, int max_out, in
 
 /* parity-test building blocks: one 32x32 orientation patch / one 41x41 descriptor patch */
 int mods_dominant_angle(mods_ctx *ctx, const float *patch, int ps, double th, float *angle, int *found);
+/* Self-test of the square root the gradient passes use (csrc/device_util.hpp: fast_sqrtf = the compiler's correctly rounded
+ * expansion without its denormal rescue) against sqrtf over all 2^32 operands.  out5: {operands of its stated domain (+0, x >= 2^-96,
+ * +infinity, NaN) where it differs (must be 0), operands 0 < x < 2^-96 where it differs (allowed), non-negative operands where the
+ * everywhere-exact form differs (must be 0), operands visited (2^32), negative operands where either differs (outside both
+ * domains: the callers' operands are sums of squares)}. */
+int mods_selftest_fast_sqrt(mods_ctx *ctx, unsigned long long *out5);
 int mods_sift_patch(mods_ctx *ctx, const float *patch, int ps, int rootsift, double maxBinValue, uint8_t *out128);
 
 /* ---- view synthesis ---------------------------------------------------------------------------

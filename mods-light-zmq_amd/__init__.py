@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MODS_LIB") or os.path.join(PKG_DIR, "libmodsgpu.so")
 
 MODS_OK = 0
 STAGES = ["blur", "response", "resize", "nms", "localize", "baumberg", "sort", "orient", "describe", "match",
-          "ransac_score", "synth", "blur_small", "pyramid"]
+          "ransac_score", "synth", "blur_small", "pyramid", "match_nn1"]
 
 
 class ModsError(RuntimeError):
@@ -308,6 +308,13 @@ class Context:
         ang, found = C.c_float(), C.c_int()
         _check(lib().mods_dominant_angle(self.h, _fp(a), a.shape[0], C.c_double(th), C.byref(ang), C.byref(found)))
         return bool(found.value), ang.value
+
+    def selftest_fast_sqrt(self):
+        """(differs inside the stated domain, differs for 0 < x < 2^-96, everywhere-exact form differs on a non-negative operand,
+        operands visited, negative operands where either form differs)"""
+        out = (C.c_ulonglong * 5)()
+        _check(lib().mods_selftest_fast_sqrt(self.h, out))
+        return tuple(int(v) for v in out)
 
     def sift_patch(self, patch, rootsift=True, max_bin=0.2):
         a = np.ascontiguousarray(patch, np.float32)

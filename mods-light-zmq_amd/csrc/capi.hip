@@ -435,6 +435,12 @@ int mods_dominant_angle(mods_ctx *c, const float *patch, int ps, double th, floa
   return MODS_OK;
 }
 
+int mods_selftest_fast_sqrt(mods_ctx *c, unsigned long long *out5) {
+  if (!c || !out5) { set_error("selftest: null argument"); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  return launch_fast_sqrt_selftest(c, out5);
+}
+
 int mods_sift_patch(mods_ctx *c, const float *patch, int ps, int rootsift, double maxBinValue, uint8_t *out128) {
   mods_describe_params dp = {5.1962, c->desc_ori_ps ? c->desc_ori_ps : 32, 1, 0.8, 5.1962, ps, 1, rootsift, maxBinValue};
   MODS_HIP_CHECK(hipSetDevice(c->device));

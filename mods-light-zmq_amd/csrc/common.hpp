@@ -143,7 +143,7 @@ struct mods_ctx {
   int last_w = 0, last_h = 0, last_n_img = 0;
   const float *last_img_dev = nullptr; int last_stride = 0;   // the batch the pyramid was built from (sampleFromImage)
   // orientation + description
-  float *desc_tables_dev = nullptr;  // [orimask 64x64][desc mask 64x64][SiftTab]
+  float *desc_tables_dev = nullptr;  // [orimask 64x64][desc mask 64x64][orientation vote mask 64x64][SiftTab], offsets kTab*
   int *desc_err_dev = nullptr;
   int desc_ori_ps = 0, desc_ps = 0;
   void *ori_dev = nullptr;           // [batch][max_cand] OriOut
@@ -204,6 +204,9 @@ struct mods_ctx {
 
 namespace mods {
 
+// float offsets of the tables in mods_ctx::desc_tables_dev
+constexpr int kTabOriMask = 0, kTabDescMask = 4096, kTabVoteMask = 8192, kTabSift = 12288;
+
 struct StageScope {                  // brackets launches of one stage with events when enabled
   mods_ctx *ctx; int stage; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
   StageScope(mods_ctx *c, int s, double bytes = 0);
@@ -244,6 +247,7 @@ constexpr int DUP_MAX_JOBS = 64;
 struct DupJob { const char *src; char *dst; const int *n_src; int *n_dst; int *status; };
 int dup_filter_dev(mods_ctx *c, const DupJob *jobs, int n_jobs, int grid_n, double r, int mode);
 int dup_filter_reserve(mods_ctx *c, int n_jobs);
+int launch_fast_sqrt_selftest(mods_ctx *ctx, unsigned long long *out5_host);   // describe.hip
 bool ransac_profile_on();            // MODS_RANSAC_PROF: per-call breakdown of the verification on stderr (ransac.hip)
 
 // describe.hip

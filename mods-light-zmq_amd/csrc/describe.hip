@@ -47,16 +47,29 @@ __device__ __forceinline__ float peak_angle(const float *s_hist, int b) {
   return 2.0f * PIf * (b + 0.5f + pp) / bins - PIf;
 }
 // The histogram is an ORDERED sum per bin (votes in raster order).  Round 3 let 36 lanes scan every vote (three vector instructions
-// per vote and keypoint: half of this kernel's instructions, and the kernel is VALU-issue bound); now every vote is filed into its
-// bin's list first and a lane adds its own bin's ~20 votes only:
-//   pass 1, per 64 raster-consecutive pixels: the lanes that vote for the same bin find each other (six ballots over the bits of
-//           the bin number), a lane's place in its bin's list = the bin's count so far + its rank among those lanes; the last lane of
-//           a group writes the new count (one writer per bin: no conflict, and the wave's LDS accesses execute in program order);
+// per vote and keypoint: half of this kernel's instructions, and the kernel is VALU-issue bound); since round 4 every vote is filed
+// into its bin's list first and a lane adds its own bin's ~20 votes only:
+//   pass 1, per 64 raster-consecutive pixels: the lanes that vote for the same bin find each other, a lane's place in its bin's list
+//           = the bin's count so far + its rank among those lanes; the last lane of a group writes the new count (one writer per
+//           bin: no conflict, and the wave's LDS accesses execute in program order);
 //   then    the bins' list offsets (a prefix over 36 counts), the values scattered into the lists (the patch array is dead by then
 //           and holds them), and lane b adds list b front to back - the same additions in the same order as the scan made (the scan
 //           added +0.0f for every vote of another bin, which leaves a non-negative running sum unchanged).
-// s_key: one 16-bit word per pixel (bin | place << 6; bin 63 = no vote), s_cnt / s_off: 64 ints each behind the histogram.
-__device__ bool dominant_angle_wave(float *s_patch, const float *__restrict__ orimask, int ps, double th,
+// Round 5, by instruction count (tools/isa_stats.py: the loop over the pixels was 158 vector instructions per 64 pixels, half of the
+// kernel's):
+//   * "the lanes with my bin" comes out of LDS: every voting lane ORs its lane bit into its bin's 64-bit word (ds_or_b64; lanes of
+//     one instruction that share a word are serialised by the LDS, the words of a wave's next read are complete because a wave's
+//     LDS instructions execute in order), reads the word back and the group's last lane clears it - 3 LDS + 6 vector instructions
+//     in the place of six ballots folded into a per-lane 64-bit mask (54 vector instructions);
+//   * the pixel of vote p is patch index p + ps (row 1 + p / ps, column p % ps): no division; `votemask[p]` is the orientation mask
+//     of that pixel, 0 in the first and last column (describe_configure), so the column test and the clamped neighbour loads go too
+//     (a border column's gradient reads its in-row neighbours of the adjacent rows - finite values - and its vote is dropped);
+//   * the square root without the denormal rescue of the compiler's expansion (fast_sqrtf, device_util.hpp).
+// s_key: one word per pixel (bin | place << 6; bin 63 = no vote) - 16 bits while every place fits 10 bits (n <= 1024 votes: the
+// default 32 x 32 patch has 960), 32 bits for larger orientation patches (ori_key_bytes); s_cnt / s_off: 64 ints each behind the
+// histogram, then the 64 lane-set words.
+__host__ __device__ static inline int ori_key_bytes(int ps) { return ps * (ps - 2) > 1024 ? 4 : 2; }   // bytes of a vote's (bin, place) word
+__device__ bool dominant_angle_wave(float *s_patch, const float *__restrict__ votemask, int ps, double th,
                                     float *s_val, unsigned char *s_bin, float *s_hist, float *angle_out, int half = 0,
                                     unsigned long long *peaks_out = nullptr) {
   const int lane = threadIdx.x;
@@ -64,42 +77,49 @@ __device__ bool dominant_angle_wave(float *s_patch, const float *__restrict__ or
   const float PIf = 3.14159265358979323846f;
   const int n = ps * (ps - 2);
   unsigned short *s_key = (unsigned short *)s_bin;
+  unsigned int *s_key32 = (unsigned int *)s_bin;
+  const bool wide = n > 1024;             // a place can exceed 10 bits: 32-bit keys (uniform over the launch)
   int *s_cnt = (int *)(s_hist + 48), *s_off = s_cnt + 64;
+  unsigned long long *s_set = (unsigned long long *)(s_off + 64);
   s_cnt[lane] = 0;
+  s_set[lane] = 0ull;
   __syncthreads();
+  const unsigned long long lanebit = 1ull << lane;
+  const int zero_bin = (int)(bins * (0.f / PIf + 1.0f) / 2.0f);
   for (int p0 = 0; p0 < n; p0 += 64) {
     const int p = p0 + lane;
     int bin = 63;
     float v = 0.f;
-    if (p < n) {
-      const int r = 1 + p / ps, c = p - (r - 1) * ps;
-      // (border columns have no gradient: their loads are clamped into the row and the result is dropped)
-      const bool inner = c >= 1 && c < ps - 1;
-      const float xgrad = s_patch[r * ps + (c < ps - 1 ? c + 1 : c)] - s_patch[r * ps + (c >= 1 ? c - 1 : c)];
-      const float ygrad = s_patch[(r + 1) * ps + c] - s_patch[(r - 1) * ps + c];
+    const float m = p < n ? votemask[(unsigned)p] : 0.f;
+    if (m > 0) {
+      const float *c = s_patch + p + ps;                 // the pixel; m > 0 only in the columns 1 .. ps - 2
+      const float xgrad = c[1] - c[-1];
+      const float ygrad = c[ps] - c[-ps];
       const AtanSel as = atan2_lut_sel(ygrad, xgrad);
-      const int tbin = g_ori_bin[as.oct * 256 + as.idx];
-      const float m = orimask[r * ps + c];
-      const float mag = inner ? sqrtf(xgrad * xgrad + ygrad * ygrad) : 0.f;
-      const int obin = as.zero ? (int)(bins * (0.f / PIf + 1.0f) / 2.0f) : tbin;
-      if (m > 0 && (double)mag > 1.0 && obin < bins) {      // (bin 36 is write-only in the reference)
+      const int tbin = g_ori_bin[(unsigned)(as.oct * 256 + as.idx)];
+      const float mag = fast_sqrtf(xgrad * xgrad + ygrad * ygrad);
+      const int obin = as.zero ? zero_bin : tbin;
+      if ((double)mag > 1.0 && obin < bins) {      // (bin 36 is write-only in the reference)
         bin = obin;
         v = mag * m;
       }
     }
-    // lanes with my bin
-    unsigned long long same = ~0ull;
-#pragma unroll
-    for (int bit = 0; bit < 6; bit++) {
-      const bool set = (bin >> bit) & 1;
-      const unsigned long long bal = __ballot(set);
-      same &= set ? bal : ~bal;
-    }
+    // the lanes of this round that vote for my bin (lanes without a vote: nobody)
+    unsigned long long same = 0ull;
+    if (bin < bins) __hip_atomic_fetch_or(s_set + bin, lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    wave_sync();
+    if (bin < bins) same = s_set[bin];
     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
-    const bool last = ((same >> lane) >> 1) == 0ull;
+    const int group = __popcll(same);
+    const bool last = bin < bins && rank == group - 1;
     const int before = s_cnt[bin];
-    if (p < n) { s_val[p] = v; s_key[p] = (unsigned short)(bin | ((before + rank) << 6)); }
-    if (last) s_cnt[bin] = before + rank + 1;
+    if (p < n) {
+      s_val[p] = v;
+      const unsigned key = (unsigned)bin | ((unsigned)(before + rank) << 6);
+      if (wide) s_key32[p] = key; else s_key[p] = (unsigned short)key;
+    }
+    if (last) { s_cnt[bin] = before + group; s_set[bin] = 0ull; }
+    wave_sync();
   }
   __syncthreads();
   const int mine = lane < bins ? s_cnt[lane] : 0;
@@ -109,8 +129,9 @@ __device__ bool dominant_angle_wave(float *s_patch, const float *__restrict__ or
   s_off[lane] = incl - mine;
   __syncthreads();
   for (int p = lane; p < n; p += 64) {
-    const int key = s_key[p], b = key & 63;
-    if (b < bins) s_patch[s_off[b] + (key >> 6)] = s_val[p];
+    const unsigned key = wide ? s_key32[p] : (unsigned)s_key[p];
+    const int b = (int)(key & 63u);
+    if (b < bins) s_patch[s_off[b] + (int)(key >> 6)] = s_val[p];
   }
   __syncthreads();
   if (lane < bins) {
@@ -169,7 +190,7 @@ __global__ __launch_bounds__(64, ORIENT_WAVES) void orient_kernel(const float *_
   float *s_patch = smem;
   float *s_val = s_patch + ((pp2 + 3) & ~3);
   unsigned char *s_bin = (unsigned char *)(s_val + nv);
-  float *s_hist = (float *)(s_bin + 2 * nv);
+  float *s_hist = (float *)(s_bin + ori_key_bytes(ps) * nv);
   const int lane = threadIdx.x;
   const int b = blockIdx.y;
   const float *img = img_all + (size_t)k.w * k.h * b;
@@ -406,6 +427,41 @@ __global__ __launch_bounds__(256) void reproject_regions_kernel(DescConst k, mod
   }
 }
 
+// fast_sqrtf / fast_sqrtf_any (device_util.hpp) against the compiler's correctly rounded sqrtf over ALL 2^32 operands.
+// out[0]: operands in fast_sqrtf's domain (+0, x >= 2^-96, +infinity, NaN) where it differs from sqrtf (bit patterns; any two NaNs
+// count as equal), out[1]: operands 0 < x < 2^-96 where it differs (allowed), out[2]: NON-NEGATIVE operands (and NaN) where
+// fast_sqrtf_any differs, out[3]: operands visited, out[4]: negative operands where either differs (the callers' operands are sums
+// of squares; v_sqrt_f32 takes a negative denormal for -0 where sqrtf says NaN).  grid = 4096 x 256 threads, 4096 operands each.
+__global__ __launch_bounds__(256) void fast_sqrt_selftest_kernel(unsigned long long *out) {
+  const unsigned tid = blockIdx.x * 256u + threadIdx.x;
+  unsigned long long bad_dom = 0, bad_tiny = 0, bad_any = 0, bad_neg = 0, seen = 0;
+  for (unsigned i = 0; i < 4096u; i++) {
+    const unsigned bits = i * (4096u * 256u) + tid;       // consecutive lanes = consecutive operands
+    const float x = __uint_as_float(bits);
+    const float want = sqrtf(x), a = fast_sqrtf(x), b = fast_sqrtf_any(x);
+    const bool same_a = (__float_as_uint(a) == __float_as_uint(want)) || (a != a && want != want);
+    const bool same_b = (__float_as_uint(b) == __float_as_uint(want)) || (b != b && want != want);
+    const bool negative = (bits >> 31) != 0 && x == x;    // sign bit set, not a NaN
+    const bool tiny = x > 0.f && x < 0x1.0p-96f;
+    if (negative) { if (!same_a || !same_b) bad_neg++; }
+    else {
+      if (!same_a) { if (tiny) bad_tiny++; else bad_dom++; }
+      if (!same_b) bad_any++;
+    }
+    seen++;
+  }
+  atomicAdd(out + 0, bad_dom); atomicAdd(out + 1, bad_tiny); atomicAdd(out + 2, bad_any); atomicAdd(out + 3, seen); atomicAdd(out + 4, bad_neg);
+}
+int launch_fast_sqrt_selftest(mods_ctx *ctx, unsigned long long *out5_host) {
+  unsigned long long *dev = (unsigned long long *)ctx->tmp_dev;
+  MODS_HIP_CHECK(hipMemsetAsync(dev, 0, 5 * sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(fast_sqrt_selftest_kernel, dim3(4096), dim3(256), 0, ctx->stream, dev);
+  MODS_HIP_CHECK(hipGetLastError());
+  MODS_HIP_CHECK(hipMemcpyAsync(out5_host, dev, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
+  return MODS_OK;
+}
+
 // single-patch entry points for the parity tests
 __global__ __launch_bounds__(64) void dominant_angle_test_kernel(const float *__restrict__ patch, int ps, double th,
                                                                  const float *__restrict__ orimask, float *out) {
@@ -414,7 +470,7 @@ __global__ __launch_bounds__(64) void dominant_angle_test_kernel(const float *__
   float *s_patch = smem;
   float *s_val = s_patch + ((ps * ps + 3) & ~3);
   unsigned char *s_bin = (unsigned char *)(s_val + nv);
-  float *s_hist = (float *)(s_bin + 2 * nv);
+  float *s_hist = (float *)(s_bin + ori_key_bytes(ps) * nv);
   for (int p = threadIdx.x; p < ps * ps; p += 64) s_patch[p] = patch[p];
   __syncthreads();
   float ang = 0.f;
@@ -424,7 +480,7 @@ __global__ __launch_bounds__(64) void dominant_angle_test_kernel(const float *__
 
 static size_t orient_lds_bytes(int ps) {   // patch | vote values | vote keys (16 bits) | histogram | list counts, offsets
   const size_t nv = ((size_t)ps * (ps - 2) + 15) & ~(size_t)15;
-  return sizeof(float) * ((((size_t)ps * ps + 3) & ~(size_t)3) + nv + 48 + 128) + 2 * nv;   // (+ counts and offsets of the bins' lists)
+  return sizeof(float) * ((((size_t)ps * ps + 3) & ~(size_t)3) + nv + 48 + 128 + 128) + (size_t)ori_key_bytes(ps) * nv;   // (+ counts and offsets of the bins' lists, the lane-set words)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -455,7 +511,7 @@ int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
   if (par->ori_patchSize < 8 || par->ori_patchSize > 48 || par->desc_patchSize < 9 || par->desc_patchSize > 63 ||
       !(par->desc_patchSize & 1)) { set_error("unsupported patch sizes (ori %d, desc %d)", par->ori_patchSize, par->desc_patchSize); return MODS_E_ARG; }
   if (!ctx->desc_tables_dev) {
-    MODS_HIP_CHECK(hipMalloc(&ctx->desc_tables_dev, sizeof(float) * (64 * 64 * 2) + sizeof(SiftTab)));
+    MODS_HIP_CHECK(hipMalloc(&ctx->desc_tables_dev, sizeof(float) * kTabSift + sizeof(SiftTab)));
     MODS_HIP_CHECK(hipMalloc(&ctx->desc_err_dev, sizeof(int)));
     MODS_HIP_CHECK(hipMemsetAsync(ctx->desc_err_dev, 0, sizeof(int), ctx->stream));
   }
@@ -467,8 +523,16 @@ int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
     build_sift_tab(par->desc_patchSize, &tab);
     MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
     MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev, m1.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
-    MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + 4096, m2.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
-    MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + 8192, &tab, sizeof(SiftTab), hipMemcpyHostToDevice));
+    MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + kTabDescMask, m2.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
+    // the orientation mask as the vote loop of dominant_angle_wave reads it: entry p = the mask of pixel (1 + p / ps, p % ps), i.e.
+    // of patch index p + ps, and 0 in the first and the last column, where EstimateDominantAnglesFunctor computes no gradient
+    {
+      const int ps = par->ori_patchSize;
+      std::vector<float> vm((size_t)64 * 64, 0.f);
+      for (int p = 0; p < ps * (ps - 2); p++) { const int c = p % ps; vm[p] = (c >= 1 && c < ps - 1) ? m1[p + ps] : 0.f; }
+      MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + kTabVoteMask, vm.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
+    }
+    MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + kTabSift, &tab, sizeof(SiftTab), hipMemcpyHostToDevice));
     ctx->desc_ori_ps = par->ori_patchSize; ctx->desc_ps = par->desc_patchSize;
   }
   return MODS_OK;
@@ -729,8 +793,8 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
   if (external && par->fastExtraction) { set_error("FastPatchExtraction with an external descriptor is not supported"); return MODS_E_ARG; }
   if (external) { k.desc_mr = ctx->ext_mr; k.desc_ps = ctx->ext_ps; k.photo = 0; k.patch_rule = 1; }
   int *key_count = ctx->cand_count + 2 * ctx->batch;
-  const float *orimask = ctx->desc_tables_dev, *dmask = ctx->desc_tables_dev + 4096;
-  const SiftTab *tab = (const SiftTab *)(ctx->desc_tables_dev + 8192);
+  const float *orimask = ctx->desc_tables_dev + kTabVoteMask, *dmask = ctx->desc_tables_dev + kTabDescMask;
+  const SiftTab *tab = (const SiftTab *)(ctx->desc_tables_dev + kTabSift);
   // doExternalAffineAdaptation is set in the HessianAffine branch of the detector dispatch only (imagerepresentation.cpp:733-737):
   // the regions of DoG / HarrisAffine / MSER views keep their own frames
   if (ctx->shape_fn && ctx->par.detectorType == MODS_DET_HESSIAN && (rc = external_shape(ctx, img_dev, n_img, k, key_count, dmask, tab))) return rc;
@@ -782,7 +846,7 @@ int launch_dominant_angle_test(mods_ctx *ctx, const float *patch_dev, int ps, do
   const size_t lds = orient_lds_bytes(ps);
   hipLaunchKernelGGL(ori_bin_table_kernel, dim3(8), dim3(256), 0, ctx->stream);
   hipLaunchKernelGGL(dominant_angle_test_kernel, dim3(1), dim3(64), lds, ctx->stream, patch_dev, ps, th,
-                     ctx->desc_tables_dev, out_dev);
+                     ctx->desc_tables_dev + kTabVoteMask, out_dev);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }

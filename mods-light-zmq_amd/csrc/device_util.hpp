@@ -51,6 +51,31 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// sqrtf(x) without the denormal rescue.  hipcc expands a correctly rounded fp32 square root (the default,
+// -fhip-fp32-correctly-rounded-divide-sqrt) into: scale x by 2^32 when x < 2^-96, v_sqrt_f32 (1 ulp), one ulp down / up decided by
+// two FMA residuals, scale back, and a class test that passes zero and infinity through - 16 vector instructions, 8 of them half
+// rate.  This is the SAME sequence without the scaling and the class test (9 instructions): bit-identical to sqrtf for x = +0, every
+// x >= 2^-96, +infinity and NaN (the residual tests are false for NaN operands, so 0 stays 0 and infinity stays infinity); for
+// 0 < x < 2^-96 the result is some value below 2^-47.  The operand must not be negative (callers pass sums of squares): the
+// instruction reads a negative denormal as -0.  tests/test_gpu_describe.py::test_fast_sqrt_is_sqrtf runs all 2^32 operands against
+// sqrtf.  Use it where operands below 2^-96 cannot matter (gradient magnitudes that are compared with 1 before use);
+// fast_sqrtf_any is exact for every non-negative operand.
+__device__ __forceinline__ float fast_sqrtf(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+  const float vp = fmaf(-sd, s, x), vs = fmaf(-su, s, x);
+  s = vp <= 0.f ? sd : s;
+  s = vs > 0.f ? su : s;
+  return s;
+}
+// exact for every operand: the lanes of a wave take the compiler's full expansion together when one of them holds a positive
+// operand below 2^-96 (two more vector instructions and a scalar branch that is never taken on image data)
+__device__ __forceinline__ float fast_sqrtf_any(float x) {
+  const bool tiny = (unsigned)(__float_as_int(x) - 1) < (unsigned)(0x0f800000 - 1);     // 0 < x < 2^-96 (+0 wraps to 0xffffffff)
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0ull, 0)) return sqrtf(x);
+  return fast_sqrtf(x);
+}
+
 // two horizontally adjacent pixels by one 8-byte load (only 4-byte aligned): a gather costs the memory pipeline per lane
 // and per instruction, so the four pixels of a bilinear tap are fetched with two loads
 struct __attribute__((packed, aligned(4))) PixPair { float a, b; };

@@ -1025,7 +1025,10 @@ int match_run_group(mods_ctx *ctx, int n_jobs, const mods_region *const *q_dev, 
     hipLaunchKernelGGL(match_pack2_kernel, dim3((std::max(std::max(max_q, max_t), 1) + 127) / 128, 2, G), dim3(256), 0, ctx->stream, J, lq, lt, ctx->max_cand, count2);
   }
   if (max_q > 0) {
-    hipLaunchKernelGGL(match_nn1_kernel, dim3(max_nn1, G), dim3(NN1_THREADS), 0, ctx->stream, J, k, qd, td, tc2, best3);
+    {
+      StageScope ts1(ctx, MODS_STAGE_MATCH_NN1);
+      hipLaunchKernelGGL(match_nn1_kernel, dim3(max_nn1, G), dim3(NN1_THREADS), 0, ctx->stream, J, k, qd, td, tc2, best3);
+    }
     hipLaunchKernelGGL(match_fix_kernel, dim3((max_q + 7) / 8, G), dim3(256), 0, ctx->stream, J, k, (const uint4 *)best3, qd, qc, td, tc, best2);
     hipLaunchKernelGGL(match_mid_kernel, dim3((max_q + 255) / 256, G), dim3(256), 0, ctx->stream, J, k, (const unsigned long long *)best2, txy,
                        (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, list2, count2);

@@ -184,22 +184,35 @@ constexpr int FB_TW = 128;   // tile width; the tile height is a template parame
 // The `s_nop 1` belongs to the store: a VMEM store of more than 8 bytes reads its data registers late, and a VALU write to them
 // within the next 2 wait states corrupts the last dword(s) (the compiler inserts this wait for its own stores, it does not look
 // inside inline assembly; without it the .w of a float4 was occasionally the next iteration's value).
-__device__ __forceinline__ void store_f4(float *p, float x, float y, float z, float w) {
+// The address is a wave-uniform base (`base`: an SGPR pair) + the lane's BYTE offset in one VGPR (no 64-bit address arithmetic,
+// half the address registers).  NT = the streaming (non-temporal) form.
+template <bool NT>
+__device__ __forceinline__ void store_f4_at(float *base, unsigned byte_off, float x, float y, float z, float w) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   const v4f q = {x, y, z, w};
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(q) : "memory");
-}
-__device__ __forceinline__ void store_f4_nt(float *p, float x, float y, float z, float w) {   // streaming (non-temporal) form
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  const v4f q = {x, y, z, w};
-  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(q) : "memory");
+  if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(byte_off), "v"(q), "s"(base) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(q), "s"(base) : "memory");
 }
 
-#ifndef BLUR_WAVES
-#define BLUR_WAVES 1
+// Workgroups per CU the register allocation aims at (second launch bound).  The kernel overlaps its phases - window loads, row
+// pass, column pass out of LDS, stores - only across workgroups (barriers separate them inside one).  Round 5 (profiles/
+// r05_blur_variants.log): 32-bit offsets against the plane pointer instead of 64-bit addresses took 9-10 registers off every
+// instantiation (R = 7: 98 -> 88); holding the large radii to 80 registers (6 workgroups) makes the compiler spill and costs 35 %
+// (107 against 80 us), so they get the budget of 5.
+#ifndef BLUR_OCC_LO
+#define BLUR_OCC_LO 7    // R <= 4
+#endif
+#ifndef BLUR_OCC_HI
+#define BLUR_OCC_HI 5    // R >= 5
+#endif
+#ifndef BLUR_SWZ
+#define BLUR_SWZ 1
+#endif
+#ifndef BLUR_COLJ
+#define BLUR_COLJ 1
 #endif
 template <int R, int FB_TH, int OV, bool RESP>
-__global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+__global__ __launch_bounds__(256, (R <= 4 ? BLUR_OCC_LO : BLUR_OCC_HI)) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               BlurTaps taps, float *__restrict__ resp, float norm2) {
   constexpr int N = 2 * R + 1;
   constexpr int R4 = (R + 3) / 4;            // float4s on each side of the outputs
@@ -228,27 +241,47 @@ __global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const 
   src += plane * img;
   dst += plane * img;
   const int x0 = txi * SX, y0 = tyi * SY;
+  // LDS column swizzle (16-byte units of a strip row).  At OV = 2 a thread writes the units 2 rc and 2 rc + 1: the eight lanes that
+  // a ds_write_b128 services together would hit units 0, 2, .. 14 = only 4 of the 8 unit slots of the 32 banks a write sees (2-way
+  // conflict: a quarter of the kernel's LDS cycles in round 4's counters).  Unit f lives at f ^ ((f >> 3) & 1): lanes 0-3 then write
+  // the even slots and lanes 4-7 the odd ones, and every 16-lane group of the ds_read_b128 readers (units tc, tc + 1) still covers
+  // 16 different units.
+  auto swz = [](int f) { return (OV == 2 && BLUR_SWZ) ? (f ^ ((f >> 3) & 1)) : f; };
   // Row pass.  The memory pipeline takes about one clock per lane and load whatever the width, so the window of a thread is
   // kept wide: NO outputs from NV aligned float4 loads (1.25 loads per 4 outputs at OV = 1, R = 5..8; 0.75 at OV = 2).
   const int rc = tid % TPR;                   // output group within the row
   const int xg = x0 + NO * rc;
-  const bool fast_x = ((w & 3) == 0) && (xg - 4 * R4 >= 0) && (xg + NO - 1 + 4 * R4 <= w - 1);   // aligned rows, whole window inside the row
+  // Addresses are 32-bit byte offsets from the image's plane (uniform per workgroup: an SGPR pair), see blur_with_slot's size check.
+  // 16-byte global loads need dword alignment only, so rows of any width take them.
+  const bool fast_x = (xg - 4 * R4 >= 0) && (xg + NO - 1 + 4 * R4 <= w - 1);   // whole window inside the row
+  const char *srcb = (const char *)src;
   auto load_window = [&](int ly, float *win) {
     int gy = y0 - R + ly;
     gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-    const float *row = src + (size_t)gy * w;
+    const unsigned rowb = (unsigned)gy * (unsigned)w * 4u;
     if (fast_x) {
+      const unsigned b0 = rowb + (unsigned)(xg - 4 * R4) * 4u;
 #pragma unroll
       for (int v = 0; v < NV; v++) {
-        const float4 q = *(const float4 *)(row + xg - 4 * R4 + 4 * v);
+        const float4 q = *(const float4 *)(srcb + (b0 + 16u * v));
         win[4 * v] = q.x; win[4 * v + 1] = q.y; win[4 * v + 2] = q.z; win[4 * v + 3] = q.w;
       }
     } else {
+      // BORDER_REPLICATE.  Window float4s start at multiples of 4 pixels: one is wholly left of the row (column 0 four times),
+      // inside, or reaches sh = 1.. pixels past the last column w - 1: the float4 that ends at w - 1 is loaded instead and moved
+      // down by sh, its last pixel filling the rest.
 #pragma unroll
-      for (int e = 0; e < 4 * NV; e++) {
-        int gx = xg - 4 * R4 + e;
-        gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-        win[e] = row[gx];
+      for (int v = 0; v < NV; v++) {
+        const int gx = xg - 4 * R4 + 4 * v;
+        const int cx = gx < 0 ? 0 : (gx > w - 4 ? w - 4 : gx);
+        const float4 q = *(const float4 *)(srcb + (rowb + (unsigned)cx * 4u));
+        const int sh = gx - cx;     // < 0: left of the row; 0: inside; 1, 2, 3, >= 4: past the end
+        float4 o;
+        o.x = sh <= 0 ? q.x : (sh == 1 ? q.y : (sh == 2 ? q.z : q.w));
+        o.y = sh < 0 ? q.x : (sh == 0 ? q.y : (sh == 1 ? q.z : q.w));
+        o.z = sh < 0 ? q.x : (sh == 0 ? q.z : q.w);
+        o.w = sh < 0 ? q.x : q.w;
+        win[4 * v] = o.x; win[4 * v + 1] = o.y; win[4 * v + 2] = o.z; win[4 * v + 3] = o.w;
       }
     }
   };
@@ -270,9 +303,6 @@ __global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const 
 #pragma unroll
       for (int u = 0; u < NO; u++) {
         float s;
-#if defined(BLUR_DIAG) && (BLUR_DIAG & 4)
-        if (true) { s = wv[D + u + R]; } else
-#endif
         if constexpr (R <= 2) {   // ksize <= 5: cv::GaussianBlur's SymmRowSmallFilter, centre tap then the symmetric pairs
           s = wv[D + u + R] * taps.t[R];
 #pragma unroll
@@ -286,49 +316,83 @@ __global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const 
       }
 #pragma unroll
       for (int v = 0; v < OV; v++)
-        *(float4 *)(smem + ly * FB_TW + NO * rc + 4 * v) = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
+        *(float4 *)(smem + ly * FB_TW + 4 * swz(OV * rc + v)) = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
     }
     if (i + DEPTH < NI && ly + RPS * DEPTH < ROWS) load_window(ly + RPS * DEPTH, win[i % DEPTH]);
   }
   __syncthreads();
-  // Column pass.  A thread makes RPT vertically adjacent outputs of its 4 columns: the 2R + RPT strip rows it
-  // needs are read from LDS once into registers (instead of 2R + 1 reads per output).
+  // Column pass.  A thread makes RPT vertically adjacent outputs of its 4 columns.  The taps are walked OUTWARDS for all RPT
+  // outputs together: step j needs the strip rows R + j .. R + j + RPT - 1 ("up") and R - j .. R - j + RPT - 1 ("dn"), of which all
+  // but one each were the previous step's, so a step costs two 16-byte LDS reads and the thread holds 2 RPT + 2 strip rows at a
+  // time instead of all 2R + RPT (every output still gets: centre tap, then fma(tap j, row(+j) + row(-j), s), j = 1..R).
   const int tc = tid & 31;                    // 4-pixel column group
   const int x4 = x0 + 4 * tc;
+  const int tcs = swz(tc), tcs1 = swz(tc + 1 < 32 ? tc + 1 : tc);
   float4 bl[RESP ? FB_TH / 8 : 1];            // RESP: this thread's blurred outputs, for the response phase
 #pragma unroll
   for (int k = 0; k < (RESP ? FB_TH / 8 : 1); k++) bl[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (x4 < w) {
     constexpr int RPT = FB_TH / 8;
     const int lyb = (tid >> 5) * RPT;
+    const float *colp = smem + lyb * FB_TW + 4 * tcs;
+    float4 acc[RPT];
+#if BLUR_COLJ
+    float4 up[RPT], dn[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const float4 c = *(const float4 *)(colp + (k + R) * FB_TW);
+      acc[k] = make_float4(taps.t[R] * c.x, taps.t[R] * c.y, taps.t[R] * c.z, taps.t[R] * c.w);
+      up[k] = c; dn[k] = c;
+    }
+    // (the two reads of step j + 1 are issued ahead of step j's arithmetic; the scheduling barrier keeps the compiler from hoisting
+    // the reads of ALL steps to the top, which would bring the 2R + RPT rows back into registers)
+    float4 nu = *(const float4 *)(colp + (RPT + R) * FB_TW), nd = *(const float4 *)(colp + (R - 1) * FB_TW);
+#pragma unroll
+    for (int j = 1; j <= R; j++) {
+#pragma unroll
+      for (int k = 0; k + 1 < RPT; k++) up[k] = up[k + 1];
+      up[RPT - 1] = nu;
+#pragma unroll
+      for (int k = RPT - 1; k > 0; k--) dn[k] = dn[k - 1];
+      dn[0] = nd;
+      if (j < R) {
+        nu = *(const float4 *)(colp + (RPT + R + j) * FB_TW);
+        nd = *(const float4 *)(colp + (R - j - 1) * FB_TW);
+      }
+      const float t = taps.t[R + j];
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const float4 a = up[k], b = dn[k];
+        acc[k].x = fmaf(t, a.x + b.x, acc[k].x); acc[k].y = fmaf(t, a.y + b.y, acc[k].y);
+        acc[k].z = fmaf(t, a.z + b.z, acc[k].z); acc[k].w = fmaf(t, a.w + b.w, acc[k].w);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     float4 col[2 * R + RPT];
 #pragma unroll
-    for (int q = 0; q < 2 * R + RPT; q++) col[q] = *(const float4 *)(smem + (lyb + q) * FB_TW + 4 * tc);
+    for (int q = 0; q < 2 * R + RPT; q++) col[q] = *(const float4 *)(colp + q * FB_TW);
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const float4 c = col[k + R];
+      float4 s = make_float4(taps.t[R] * c.x, taps.t[R] * c.y, taps.t[R] * c.z, taps.t[R] * c.w);
+#pragma unroll
+      for (int j = 1; j <= R; j++) {
+        const float4 a = col[k + R + j], b = col[k + R - j];
+        const float t = taps.t[R + j];
+        s.x = fmaf(t, a.x + b.x, s.x); s.y = fmaf(t, a.y + b.y, s.y); s.z = fmaf(t, a.z + b.z, s.z); s.w = fmaf(t, a.w + b.w, s.w);
+      }
+      acc[k] = s;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       const int gy = y0 + lyb + k;
       if (gy < h) {
-        const float4 c = col[k + R];
-        float4 s = make_float4(taps.t[R] * c.x, taps.t[R] * c.y, taps.t[R] * c.z, taps.t[R] * c.w);
-#pragma unroll
-#if defined(BLUR_DIAG) && (BLUR_DIAG & 8)
-        for (int j = 1; j <= 0; j++) {
-#else
-        for (int j = 1; j <= R; j++) {
-#endif
-          const float4 a = col[k + R + j], b = col[k + R - j];
-          const float t = taps.t[R + j];
-          s.x = fmaf(t, a.x + b.x, s.x); s.y = fmaf(t, a.y + b.y, s.y); s.z = fmaf(t, a.z + b.z, s.z); s.w = fmaf(t, a.w + b.w, s.w);
-        }
-        float *d = dst + (size_t)gy * w + x4;
-#if defined(BLUR_DIAG) && (BLUR_DIAG & 1)
-        if (s.x == 123456.f)
-#endif
-#if defined(BLUR_NT) && (BLUR_NT & 2)
-        if (x4 + 3 < w) store_f4_nt(d, s.x, s.y, s.z, s.w);
-#else
-        if (x4 + 3 < w) store_f4(d, s.x, s.y, s.z, s.w);
-#endif
+        const float4 s = acc[k];
+        const unsigned db = ((unsigned)gy * (unsigned)w + (unsigned)x4) * 4u;
+        float *d = (float *)((char *)dst + db);
+        if (x4 + 3 < w) store_f4_at<false>(dst, db, s.x, s.y, s.z, s.w);
         else {
           d[0] = s.x;
           if (x4 + 1 < w) d[1] = s.y;
@@ -346,7 +410,7 @@ __global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const 
       constexpr int RPT = FB_TH / 8;
       const int lyb = (tid >> 5) * RPT;
 #pragma unroll
-      for (int k = 0; k < RPT; k++) *(float4 *)(smem + (lyb + k) * FB_TW + 4 * tc) = bl[k];
+      for (int k = 0; k < RPT; k++) *(float4 *)(smem + (lyb + k) * FB_TW + 4 * tcs) = bl[k];
     }
     __syncthreads();
     // Response phase: thread = 4 columns x RQ rows of the owned region; rows / columns of the image frame and pixels whose
@@ -361,8 +425,8 @@ __global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const 
       for (int q = 0; q < RQ + 2; q++) {
         const int ly = RQ * rg + q;                       // tile row of stencil row q (owned rows start at tile row 1)
         if (ly < FB_TH) {
-          const float4 a = *(const float4 *)(smem + ly * FB_TW + 4 * tc);
-          const float4 b = *(const float4 *)(smem + ly * FB_TW + 4 * tc + 4);   // tc < 31: inside the row (a 16-byte read: an
+          const float4 a = *(const float4 *)(smem + ly * FB_TW + 4 * tcs);
+          const float4 b = *(const float4 *)(smem + ly * FB_TW + 4 * tcs1);     // tc < 31: inside the row (a 16-byte read: an
           v[q][0] = a.x; v[q][1] = a.y; v[q][2] = a.z; v[q][3] = a.w; v[q][4] = b.x; v[q][5] = b.y;   // 8-byte one at this stride is a 2-way bank conflict)
         } else {
 #pragma unroll
@@ -390,15 +454,9 @@ __global__ __launch_bounds__(256, BLUR_WAVES) void gauss_blur_fast_kernel(const 
             }
             o[u] = out;
           }
-          float *d = resp + (size_t)y * w + xr;
-#if defined(BLUR_DIAG) && (BLUR_DIAG & 2)
-          if (o[0] == 123456.f)
-#endif
-#if !defined(BLUR_NT) || (BLUR_NT & 1)
-          if (xr + 3 < w) store_f4_nt(d, o[0], o[1], o[2], o[3]);
-#else
-          if (xr + 3 < w) store_f4(d, o[0], o[1], o[2], o[3]);
-#endif
+          const unsigned db = ((unsigned)y * (unsigned)w + (unsigned)xr) * 4u;
+          float *d = (float *)((char *)resp + db);
+          if (xr + 3 < w) store_f4_at<true>(resp, db, o[0], o[1], o[2], o[3]);
           else {
             if (xr < w) d[0] = o[0];
             if (xr + 1 < w) d[1] = o[1];
@@ -834,7 +892,7 @@ static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w,
 static int blur_with_slot(mods_ctx *ctx, const float *src, float *dst, int w, int h, int n_img, int slot, int n, float *resp = nullptr,
                           float norm = 0.f) {
   const int r = n / 2;
-  if (r >= 1 && r <= 8 && ctx->taps_host_n[slot] == n) {
+  if (r >= 1 && r <= 8 && ctx->taps_host_n[slot] == n && w >= 4 && (size_t)w * h < ((size_t)1 << 29)) {   // (16-byte row loads; 32-bit byte offsets inside a plane)
     BlurTaps taps;
     for (int i = 0; i < 17; i++) taps.t[i] = i < n ? ctx->taps_host[slot][i] : 0.f;
     // (the two tile instantiations are timed separately: launches of the small planes are launch-size bound)

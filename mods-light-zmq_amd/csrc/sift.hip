@@ -1323,15 +1323,13 @@ __global__ __launch_bounds__(64 * S2_WAVES, 3) void sift_wave2_kernel(DescConst 
     // of its region (flag off: factor 1, mean 0 never used - the raw value is selected)
     unsigned sbyte[RL], cbyte[RL];
     float sm[RL], sf[RL];
-    unsigned nflag = 0, has_left = 0, has_right = 0;
+    unsigned nflag = 0;
 #pragma unroll
     for (int u = 0; u < RL; u++) {
       sbyte[u] = ((unsigned)min(ri0 + s_rr[u], n - 1) * (unsigned)pp + (unsigned)s_c[u]) * 4u;
       cbyte[u] = (unsigned)s_c[u] * 4u;
       sm[u] = s_mean[s_rr[u]]; sf[u] = s_fac[s_rr[u]];
       nflag |= (s_flag[s_rr[u]] ? 1u : 0u) << u;
-      has_left |= (s_c[u] > 0 ? 1u : 0u) << u;
-      has_right |= (s_c[u] < ps - 1 ? 1u : 0u) << u;
     }
     auto fetch_row = [&](int r, float *dst) {
       const char *rowp = (const char *)(pbase + r * ps);           // uniform: scalar base + 32-bit lane offset
@@ -1365,8 +1363,12 @@ __global__ __launch_bounds__(64 * S2_WAVES, 3) void sift_wave2_kernel(DescConst 
 #pragma unroll 1
     for (int r = 0; r < ps; r++) {
       {
-        // branch-free: the one-sided differences at the patch border are the same subtraction with one operand at the pixel itself
-        const bool top = r == 0, bot = r == ps - 1;
+        // branch-free: the one-sided differences at the patch border are the same subtraction with one operand at the pixel itself.
+        // Vertically that needs nothing: the rows behind the last one are fetched clamped (np = the row itself at r = ps - 1) and
+        // nm starts as row 0.  Horizontally the column of a slot decides (cbyte = 4 * column: a compare + a select per side).
+        // The square root is the compiler's correctly rounded expansion without its rescue of operands below 2^-96 (fast_sqrtf_any,
+        // device_util.hpp: the full expansion when a lane holds such an operand - never on image data).
+        const unsigned last_col = 4u * (unsigned)(ps - 1);
 #pragma unroll
         for (int u = 0; u < RL; u++) {
           const int e = lane + 64 * u;
@@ -1374,12 +1376,10 @@ __global__ __launch_bounds__(64 * S2_WAVES, 3) void sift_wave2_kernel(DescConst 
           float right = lane_down1(n0[u]), left = lane_up1(n0[u]);
           if (u + 1 < RL) { const float nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n0[u + 1 < RL ? u + 1 : u]), 0)); right = lane == 63 ? nx : right; }
           if (u > 0) { const float pl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n0[u > 0 ? u - 1 : u]), 63)); left = lane == 0 ? pl : left; }
-          const float xa = ((has_right >> u) & 1) ? right : n0[u];
-          const float xb = ((has_left >> u) & 1) ? left : n0[u];
-          const float ya = bot ? n0[u] : np[u];
-          const float yb = top ? n0[u] : nm[u];
-          const float xgrad = xa - xb, ygrad = ya - yb;
-          const float grad = sqrtf(xgrad * xgrad + ygrad * ygrad);
+          const float xa = cbyte[u] < last_col ? right : n0[u];
+          const float xb = cbyte[u] > 0u ? left : n0[u];
+          const float xgrad = xa - xb, ygrad = np[u] - nm[u];
+          const float grad = fast_sqrtf_any(xgrad * xgrad + ygrad * ygrad);
           const AtanSel as = atan2_lut_sel(ygrad, xgrad);
           const float ot = s_ot[as.oct * 256 + as.idx];
           const float o = as.zero ? o_zero : ot;
@@ -1643,7 +1643,7 @@ int launch_half_sift(mods_ctx *ctx, int n_img, DescConst k, const float *dmask, 
 
 int launch_sift_patch_test(mods_ctx *ctx, const float *patch_dev, int ps, int root, double max_bin, uint8_t *out_dev) {
   hipLaunchKernelGGL(sift_patch_test_kernel, dim3(1), dim3(256), sift_lds_bytes(ps), ctx->stream, patch_dev, ps, root, max_bin,
-                     ctx->desc_tables_dev + 4096, (const SiftTab *)(ctx->desc_tables_dev + 8192), out_dev);
+                     ctx->desc_tables_dev + kTabDescMask, (const SiftTab *)(ctx->desc_tables_dev + kTabSift), out_dev);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }

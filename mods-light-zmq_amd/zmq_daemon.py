@@ -89,15 +89,41 @@ def build_model(name, weights=None, seed=0, device="cpu"):
         net.load_state_dict(ck["state_dict"] if "state_dict" in ck else ck)   # strict: the architecture has to be the checkpoint's
     net = net.eval().to(device)
 
+    on_gpu = str(device) != "cpu"
+    BUCKETS = (64, 512)                                           # batch shapes the GPU ever sees (512 = BATCH_SIZE of the reference servers)
+
+    def forward(chunk):
+        # On the GPU a chunk is padded with zero patches to one of two batch sizes: the convolution library then selects (and on
+        # first use tries) kernels for exactly two shapes, both at start-up (warm_up below) and never while a matcher's fp64 work
+        # shares the GPU - the first calls of a new shape are where foreign matrix-core kernels disturbed fp64 results
+        # (profiles/r05_foreign_mfma_first_calls.log) - and a patch's output does not depend on how
+        # many patches its request held.
+        n = len(chunk)
+        if on_gpu:
+            b = next(x for x in BUCKETS if n <= x)
+            if n < b:
+                chunk = np.concatenate([chunk, np.zeros((b - n,) + chunk.shape[1:], chunk.dtype)], axis=0)
+        return net(torch.from_numpy(chunk).to(device)).float().cpu().numpy()[:n]
+
     def run(p):
         outs = []
         with torch.no_grad():
-            for i in range(0, len(p), 512):                       # BATCH_SIZE of the reference servers
-                outs.append(net(torch.from_numpy(p[i:i + 512]).to(device)).float().cpu().numpy())
-        out = np.concatenate(outs, axis=0)
+            for i in range(0, len(p), 512):
+                outs.append(forward(p[i:i + 512]))
+        out = np.concatenate(outs, axis=0) if outs else np.zeros((0, 1), np.float32)
         if name == "hardnet":
             out = np.clip(210 * (out.astype(np.float64) + 0.45), 0, 255).astype(np.uint8).astype(np.float32)
         return out.astype(np.float32)
+
+    def warm_up(ps=32):
+        """Every batch shape once (twice: the second call runs the selected kernels), before the first request is served."""
+        if on_gpu:
+            with torch.no_grad():
+                for b in BUCKETS:
+                    for _ in range(2):
+                        forward(np.full((b, 1, ps, ps), 128.0, np.float32) + np.arange(ps, dtype=np.float32))
+            torch.cuda.synchronize()
+    run.warm_up = warm_up
     return run
 
 
@@ -152,6 +178,8 @@ def main():
         if not weights:
             raise SystemExit("zmq_daemon: %s holds no arrays named %s.*" % (args.weights, args.model))
     model = build_model(args.model, weights, args.seed, device or "cpu")
+    if hasattr(model, "warm_up"):
+        model.warm_up()
     print("zmq_daemon: %s on %s, serving %s" % (args.model, device or "cpu", endpoint), file=sys.stderr, flush=True)
     serve(endpoint, model, args.max_requests)
 

@@ -41,6 +41,36 @@ def test_dominant_angle_patches(gpu_ctx):
             assert np.float32(aw) == np.float32(ag)
 
 
+def test_fast_sqrt_is_sqrtf(gpu_ctx):
+    """The gradient magnitudes of the orientation and SIFT kernels come from fast_sqrtf (csrc/device_util.hpp): hipcc's correctly
+    rounded sqrtf without the rescaling of operands below 2^-96 and without the zero / infinity class test.  Exhaustive: every one of
+    the 2^32 float operands against sqrtf on the device - identical for +0, every x >= 2^-96, +infinity and NaN; the form the SIFT
+    kernel uses (the compiler's expansion whenever a lane of the wave holds a smaller positive operand) for every non-negative
+    operand.  Negative operands are outside both domains (the callers pass sums of squares): the 2^23 - 1 negative denormals
+    give -0 where sqrtf says NaN, and nothing else differs there."""
+    bad_domain, bad_tiny, bad_any, seen, bad_negative = gpu_ctx.selftest_fast_sqrt()
+    assert seen == 1 << 32
+    assert bad_domain == 0 and bad_any == 0, (bad_domain, bad_tiny, bad_any, bad_negative)
+    assert bad_negative <= (1 << 23) - 1
+
+
+@pytest.mark.parametrize("ps", [34, 41, 48])
+def test_dominant_angle_large_orientation_patches(gpu_ctx, ps):
+    """[DominantOrientation] patchSize above 32: ps*(ps-2) > 1024 votes, and on a ramp (or a straight edge) every vote goes to ONE
+    10-degree bin, so a vote's place in its bin's list passes 1023 - the list places are 32-bit words there."""
+    pats = _patches(12, ps, 21)
+    ramp = np.tile(np.arange(ps, dtype=np.float32) * 3, (ps, 1))
+    c, s = np.cos(0.35), np.sin(0.35)
+    yy, xx = np.mgrid[0:ps, 0:ps].astype(np.float32)
+    pats += [ramp, ramp.T.copy(), (2.5 * (c * xx + s * yy)).astype(np.float32), np.where(xx + yy > ps, 200.0, 20.0).astype(np.float32)]
+    for p in pats:
+        fw, aw = orc.dominant_angle(p)
+        fg, ag = gpu_ctx.dominant_angle(p)
+        assert fw == fg
+        if fw:
+            assert np.float32(aw) == np.float32(ag)
+
+
 @pytest.mark.parametrize("root", [True, False])
 def test_sift_patches(gpu_ctx, root):
     for p in _patches(40, 41, 9):

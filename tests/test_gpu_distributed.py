@@ -26,16 +26,23 @@ WORKER = textwrap.dedent('''
     import importlib.util
     spec = importlib.util.spec_from_file_location("shard", os.path.join(%r, "mods-light-zmq_amd", "shard.py"))
     shard = importlib.util.module_from_spec(spec); spec.loader.exec_module(shard)
-    dist.init_process_group("gloo")
+    backend = os.environ.get("MODS_TEST_BACKEND", "gloo")      # nccl (= RCCL): one GPU per rank
+    dev = int(os.environ["RANK"]) if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     w, h = 480, 360
     a, b, _ = _hard_pair(w, h, seed=21)
-    t = torch.from_numpy(np.stack([a, b])).cuda()
+    t = torch.from_numpy(np.stack([a, b])).cuda(dev)
     torch.cuda.synchronize()
     d = pkg.view_ctx_dims(w, h)
-    ctx = pkg.Context(0, d[0], d[1], 1)
+    ctx = pkg.Context(dev, d[0], d[1], 1)
+    pkg.lib().mods_ransac_set_device(dev)
     steps = [pkg.LadderStep.make(tl, ph) for tl, ph in (((1,), 360.0), ((1, 2, 4), 360.0), ((1, 2, 4), 120.0))]
-    got = shard.match_ladder_distributed(pkg, ctx, t.data_ptr(), w, h, steps, dist, "cuda:0", seed_time=31)
+    got = shard.match_ladder_distributed(pkg, ctx, t.data_ptr(), w, h, steps, dist, "cuda:" + str(dev), seed_time=31)
     if rank == 0:
         rep1, rep2 = pkg.ImgRep(ctx), pkg.ImgRep(ctx)
         pkg.ransac_pin_seed(31)
@@ -52,19 +59,47 @@ WORKER = textwrap.dedent('''
 ''') % (ROOT, ROOT, ROOT)
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_view_sharded_ladder(tmp_path, world):
+def _run_ranks(tmp_path, world, backend):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MODS_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
         assert "rank %d ok" % r in o
+
+
+def _need_gpus(pkg, n):
+    have = pkg.lib().mods_device_count()
+    if have < n:
+        pytest.skip("needs %d GPUs, this box has %d: RCCL between distinct devices is only exercised on a multi-GPU node "
+                    "(on one GPU the same decomposition runs with device 0 listed repeatedly / over gloo, see the tests beside this one)" % (n, have))
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_view_sharded_ladder(tmp_path, world):
+    _run_ranks(tmp_path, world, "gloo")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_view_sharded_ladder_over_rccl(pkg, tmp_path, world):
+    """The same ladder with one rank per GPU and the exchange as RCCL collectives on device buffers (backend nccl): identical to the
+    one-GPU result.  Runs only where `world` GPUs are visible."""
+    _need_gpus(pkg, world)
+    _run_ranks(tmp_path, world, "nccl")
+
+
+@pytest.mark.parametrize("n_dev", [2, 4, 8])
+def test_multi_gpu_ladder_in_cpp_on_distinct_devices(pkg, n_dev):
+    """mods_match_ladder_multi over n_dev DISTINCT devices: ncclCommInitAll + one grouped ncclAllGather per step (csrc/multi.hip),
+    the branch that a repeated device 0 bypasses.  Identical to the one-GPU ladder; runs only where n_dev GPUs are visible."""
+    _need_gpus(pkg, n_dev)
+    _check_multi_ladder(pkg, list(range(n_dev)), expect_rccl=True)
 
 
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
@@ -73,6 +108,10 @@ def test_multi_gpu_ladder_in_cpp(pkg, devices):
     per step - ncclAllGather on device buffers when the devices are distinct ([0]: a one-rank communicator), plain device
     copies when a device is listed more than once (the 2- and 3-way sharding exercised on this one-GPU box) - and the query
     rows split over the devices.  Identical to the one-GPU ladder."""
+    _check_multi_ladder(pkg, devices, expect_rccl=(len(devices) == 1))
+
+
+def _check_multi_ladder(pkg, devices, expect_rccl):
     import torch
     from test_gpu_views import _hard_pair
     w, h = 480, 360
@@ -87,7 +126,7 @@ def test_multi_gpu_ladder_in_cpp(pkg, devices):
     want, wm = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2, max_matches=100000)
     ra, rb = rep1.fetch(), rep2.fetch()
     multi = pkg.Multi(devices, w, h)
-    assert multi.uses_rccl == (len(devices) == 1)
+    assert multi.uses_rccl == expect_rccl
     pkg.ransac_pin_seed(31)
     got, gm = multi.match_ladder(a, b, steps, max_matches=100000)
     for f in ("steps_done", "n_views", "n_tentatives", "n_unique", "n_inliers", "ransac_samples", "ransac_lo", "ransac_rejects"):
