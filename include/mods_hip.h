@@ -136,6 +136,16 @@ enum { MODS_STAGE_BLUR = 0, MODS_STAGE_RESPONSE, MODS_STAGE_RESIZE, MODS_STAGE_N
        MODS_STAGE_MATCH_NN1,    /* the matrix-core kernel of the search alone (match_nn1_kernel, i8 MFMA), inside MODS_STAGE_MATCH */
        MODS_STAGE_COUNT };
 int mods_ctx_timing_enable(mods_ctx *ctx, int stage_mask);
+/* on != 0: mods_detect_describe_dev (and what is built on it: the pair entry points, the pipeline's workers) records the ~70
+   launches of a call into a hipGraph the second time it sees the same arguments (image pointer, sizes, parameters) and replays
+   it from then on - one submission and one completion for the host instead of one per launch.  The results are the same
+   launches' results.  Only calls whose scale space forks onto the context's side stream (images x batch of 4 megapixels or more,
+   pyramid streams = 2) are recorded; others stay eager (a linear recording faults on replay with the ROCm 7.0.2 runtime unless
+   DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is set before the runtime starts; csrc/capi.hip: dd_run).  Off by default for a context;
+   the pair pipeline switches it on for its workers' contexts.
+   mods_ctx_graph_replays: calls served by a replay so far. */
+int mods_ctx_graphs(mods_ctx *ctx, int on);
+long mods_ctx_graph_replays(const mods_ctx *ctx);
 /* Streams the Hessian scale space of a large batch is built on: 2 (default) = the octaves from the third on, and their non-maximum
    suppression, run on a side stream next to the large octaves' last level and NMS; 1 = everything on the context's stream (what
    per-launch timing wants).  The planes and the candidates are the same either way. */

@@ -139,9 +139,12 @@ def view_ctx_dims(w, h):
 
 
 class Context:
-    def __init__(self, device=0, max_w=1920, max_h=1080, batch=1):
+    def __init__(self, device=0, max_w=1920, max_h=1080, batch=1, nonblocking=False):
         self.h = C.c_void_p()
-        _check(lib().mods_ctx_create(device, max_w, max_h, batch, C.byref(self.h)))
+        if nonblocking:     # a stream without implicit ordering after the default stream (what the pipeline's workers use)
+            _check(lib().mods_ctx_create_ex(device, max_w, max_h, batch, 1, C.byref(self.h)))
+        else:
+            _check(lib().mods_ctx_create(device, max_w, max_h, batch, C.byref(self.h)))
         self.batch = batch
         self.device = device
 
@@ -174,6 +177,14 @@ class Context:
         ms, n, by = C.c_double(), C.c_int(), C.c_double()
         _check(lib().mods_ctx_timing_read(self.h, STAGES.index(stage), C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
+
+    def graphs(self, on=True):
+        """replay the launches of detect + describe as a hipGraph from the second call with the same arguments on"""
+        _check(lib().mods_ctx_graphs(self.h, 1 if on else 0))
+
+    def graph_replays(self):
+        lib().mods_ctx_graph_replays.restype = C.c_long
+        return int(lib().mods_ctx_graph_replays(self.h))
 
     def pyramid_streams(self, n):
         _check(lib().mods_ctx_pyramid_streams(self.h, int(n)))

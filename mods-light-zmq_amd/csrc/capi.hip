@@ -136,6 +136,11 @@ static int ctx_create_impl(int device, int max_w, int max_h, int batch, unsigned
   return MODS_OK;
 }
 
+static void dd_graph_drop(mods_ctx *c) {
+  for (auto &e : c->dd_cache) (void)hipGraphExecDestroy(e.second);
+  c->dd_cache.clear();
+}
+
 void mods_ctx_destroy(mods_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -156,6 +161,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   for (mods_ctx *h : c->helpers) if (h) mods_ctx_destroy(h);
   for (auto &a : c->helper_stage) (void)hipFree(a.buf);
   (void)hipSetDevice(c->device);
+  dd_graph_drop(c);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -293,13 +299,10 @@ static int check_desc_err(mods_ctx *c) {
   return MODS_OK;
 }
 
-int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride,
-                             const mods_hessaff_params *det, const mods_describe_params *desc, int *n_detected_host,
-                             int *n_regions_host) {
-  if (!c || !img_dev || !det || !desc) { set_error("detect_describe: null argument"); return MODS_E_ARG; }
-  if (w <= 0 || h <= 0 || (size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("detect_describe: image larger than the context"); return MODS_E_ARG; }
-  if (stride < w) { set_error("detect_describe: stride %d < width %d", stride, w); return MODS_E_ARG; }
-  MODS_HIP_CHECK(hipSetDevice(c->device));
+// The launches of one detect + describe call: scale space, NMS, localisation, Baumberg, order, orientation, extraction, SIFT and the
+// read-back of the batch's counters (pinned host words) - ~70 dispatches for a 1080p batch, no host round trip between them.
+static int dd_enqueue(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride, const mods_hessaff_params *det,
+                      const mods_describe_params *desc) {
   int rc;
   if ((rc = detect_any(c, img_dev, n_img, w, h, stride, det, 1.0, 1.0))) return rc;
   const float *planes = img_dev;
@@ -311,6 +314,101 @@ int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w
   MODS_HIP_CHECK(hipMemcpyAsync(hc + 3 * c->batch, c->region_count, sizeof(int) * c->batch, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(hc + 4 * c->batch, c->inside_count, sizeof(int) * n_img, hipMemcpyDeviceToHost, c->stream));
   MODS_HIP_CHECK(hipMemcpyAsync(hc + 5 * c->batch, c->desc_err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  return MODS_OK;
+}
+
+static unsigned long long fnv1a(const void *p, size_t n, unsigned long long h) {
+  const unsigned char *b = (const unsigned char *)p;
+  for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+// Replay instead of re-issue (mods_ctx_graphs).  A pipeline worker calls this with the same arguments batch after batch: every kernel
+// argument is either a pointer into the context's pools or a parameter, every data-dependent quantity lives on the device, so the
+// sequence of launches is the same each time.  The first call with a set of arguments runs eagerly (it may allocate pools, upload tap
+// tables, set kernel attributes); the second one is recorded with hipStreamBeginCapture (both streams of the forked pyramid end up in
+// the graph through their fork / join events) and launched; later ones are one hipGraphLaunch.  A recording that fails - a call in
+// the chain that cannot be captured - switches the context back to eager launches for good.  Off while stage timers are on (their
+// events belong to single launches), with external hooks (host round trips) and for the MSER detector (host threads).
+// Only recordings with TWO branches (the forked scale space of a large batch) are replayed.  A recording that is one linear chain
+// of launches faults on replay with this runtime (ROCm 7.0.2, HIP 7.0.51831: "illegal memory access" in the first replay, 12 of 12
+// linear configurations of tools/exp_graph.py, while all 16 - linear and forked - replay bit-identically with
+// DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, the switch for the runtime's replay of pre-built AQL packets, which linear kernel chains
+// take; profiles/r05_graph_replay_matrix*.log).  That switch is read when the runtime starts, out of a library's reach, so calls
+// whose scale space does not fork (small images, small batches, mods_ctx_pyramid_streams(1)) stay eager.
+static int dd_run(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride, const mods_hessaff_params *det,
+                  const mods_describe_params *desc) {
+  const bool can = c->dd_graphs && c->timing_mask == 0 && !c->ext_fn && !c->shape_fn && !c->ori_fn && det->detectorType != MODS_DET_MSER;
+  if (!can) return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
+  mods_ctx::DdKey key;
+  key.img = img_dev; key.n_img = n_img; key.w = w; key.h = h; key.stride = stride;
+  key.par_hash = fnv1a(desc, sizeof(*desc), fnv1a(det, sizeof(*det), 1469598103934665603ull)) ^ (unsigned long long)c->pyr_streams;
+  for (auto &e : c->dd_cache)
+    if (e.first == key) {
+      MODS_HIP_CHECK(hipGraphLaunch(e.second, c->stream));
+      c->dd_replays++;
+      return MODS_OK;
+    }
+  for (const auto &k2 : c->dd_linear)
+    if (k2 == key) return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
+  bool seen = false;
+  for (const auto &k2 : c->dd_seen) seen = seen || (k2 == key);
+  if (!seen) {                            // new arguments: one eager call first
+    if (c->dd_seen.size() >= 16) c->dd_seen.erase(c->dd_seen.begin());
+    c->dd_seen.push_back(key);
+    return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
+  }
+  hipStream_t s = c->stream;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    c->dd_graphs = false;
+    return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
+  }
+  const int rc = dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
+  hipGraph_t g = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(s, &g);
+  hipGraphExec_t ex = nullptr;
+  if (rc == MODS_OK && e_end == hipSuccess && g && !c->pyr_forked) {      // a linear recording: not replayed (above); nothing has run yet
+    (void)hipGraphDestroy(g);
+    if (c->dd_linear.size() >= 16) c->dd_linear.erase(c->dd_linear.begin());
+    c->dd_linear.push_back(key);
+    return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
+  }
+  if (rc == MODS_OK && e_end == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+    (void)hipGraphDestroy(g);
+    if (c->dd_cache.size() >= 8) { (void)hipGraphExecDestroy(c->dd_cache.front().second); c->dd_cache.erase(c->dd_cache.begin()); }
+    c->dd_cache.emplace_back(key, ex);
+    MODS_HIP_CHECK(hipGraphLaunch(ex, c->stream));
+    c->dd_replays++;
+    return MODS_OK;
+  }
+  // not capturable here (or the chain itself failed): nothing has run - clean up and issue the launches directly
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  c->pyr_side = false;                    // (a fork recorded into the dead capture)
+  c->dd_graphs = false;
+  c->omap_dirty = true;
+  return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
+}
+
+int mods_ctx_graphs(mods_ctx *c, int on) {
+  if (!c) return MODS_E_ARG;
+  c->dd_graphs = on != 0;
+  if (!on) { dd_graph_drop(c); c->dd_seen.clear(); c->dd_linear.clear(); }
+  return MODS_OK;
+}
+long mods_ctx_graph_replays(const mods_ctx *c) { return c ? c->dd_replays : 0; }
+
+int mods_detect_describe_dev(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride,
+                             const mods_hessaff_params *det, const mods_describe_params *desc, int *n_detected_host,
+                             int *n_regions_host) {
+  if (!c || !img_dev || !det || !desc) { set_error("detect_describe: null argument"); return MODS_E_ARG; }
+  if (w <= 0 || h <= 0 || (size_t)w * h > (size_t)c->max_w * c->max_h) { set_error("detect_describe: image larger than the context"); return MODS_E_ARG; }
+  if (stride < w) { set_error("detect_describe: stride %d < width %d", stride, w); return MODS_E_ARG; }
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = dd_run(c, img_dev, n_img, w, h, stride, det, desc))) return rc;
+  int *hc = c->host_counts;
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
   for (int b = 0; b < n_img; b++) {
     if (hc[b] > c->max_cand) { set_error("NMS hit list overflow: %d > %d", hc[b], c->max_cand); return MODS_E_CAPACITY; }

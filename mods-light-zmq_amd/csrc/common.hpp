@@ -104,6 +104,8 @@ struct mods_ctx {
   // scale space
   mods::PyramidDev pyr;              // host copy of the descriptor table
   mods::PyramidDev *pyr_dev = nullptr;
+  mods::PyramidDev pyr_dev_image;    // what pyr_dev holds (pyramid_configure uploads the table only when it changed)
+  bool pyr_dev_valid = false;
   float *plane_pool = nullptr;       // all blur/response planes
   size_t plane_pool_elems = 0;
   unsigned int *omap_pool = nullptr;
@@ -199,6 +201,15 @@ struct mods_ctx {
   std::vector<StageArena> helper_stage;
   // timing
   int timing_mask = 0;
+  // mods_ctx_graphs: the launches of a detect + describe call replayed as one hipGraph (capi.hip: mods_detect_describe_dev)
+  bool dd_graphs = false;
+  struct DdKey { const float *img = nullptr; int n_img = 0, w = 0, h = 0, stride = 0; unsigned long long par_hash = 0;
+                 bool operator==(const DdKey &o) const { return img == o.img && n_img == o.n_img && w == o.w && h == o.h && stride == o.stride && par_hash == o.par_hash; } };
+  std::vector<std::pair<DdKey, hipGraphExec_t>> dd_cache;   // recorded calls (a worker sees a few batch sizes), oldest first
+  std::vector<DdKey> dd_seen;                               // arguments that have run eagerly once
+  std::vector<DdKey> dd_linear;                             // arguments whose recording had no second branch: never replayed (see dd_run)
+  bool pyr_forked = false;                                  // the last pyramid_build put octaves on the side stream
+  long dd_replays = 0;
   mods::StageTimer timers[MODS_STAGE_COUNT];
 };
 

@@ -295,6 +295,9 @@ int mods_pipeline_create_ex(int device, int w, int h, const mods_pair_params *pa
     mods_ctx *c = nullptr;
     int rc = mods_ctx_create_ex(device, w, h, 2 * pairs_per_batch, 1, &c);   // non-blocking streams: the workers overlap on the GPU
     if (rc) { for (auto *q : p->ctxs) mods_ctx_destroy(q); return rc; }
+    // the workers call detect + describe with the same arguments batch after batch: replayed as a hipGraph (MODS_GRAPHS=0: eager launches)
+    static const bool graphs_on = !(getenv("MODS_GRAPHS") && atoi(getenv("MODS_GRAPHS")) == 0);
+    if (graphs_on) (void)mods_ctx_graphs(c, 1);
     p->ctxs.push_back(c);
   }
   for (int i = 0; i < gpu_workers; i++) p->gpu_threads.emplace_back(gpu_worker, p.get(), p->ctxs[i]);

@@ -211,6 +211,9 @@ __device__ __forceinline__ void store_f4_at(float *base, unsigned byte_off, floa
 #ifndef BLUR_COLJ
 #define BLUR_COLJ 1
 #endif
+#ifndef BLUR_COLJ_MIN_TH
+#define BLUR_COLJ_MIN_TH 32   // the outward column pass pays with 4 outputs per thread; the 16-row tiles (2 outputs) read their 2R + 2 rows up front
+#endif
 template <int R, int FB_TH, int OV, bool RESP>
 __global__ __launch_bounds__(256, (R <= 4 ? BLUR_OCC_LO : BLUR_OCC_HI)) void gauss_blur_fast_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
                                                               BlurTaps taps, float *__restrict__ resp, float norm2) {
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256, (R <= 4 ? BLUR_OCC_LO : BLUR_OCC_HI)) void gau
     const int lyb = (tid >> 5) * RPT;
     const float *colp = smem + lyb * FB_TW + 4 * tcs;
     float4 acc[RPT];
-#if BLUR_COLJ
+    if constexpr (BLUR_COLJ && FB_TH >= BLUR_COLJ_MIN_TH) {
     float4 up[RPT], dn[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256, (R <= 4 ? BLUR_OCC_LO : BLUR_OCC_HI)) void gau
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-#else
+    } else {
     float4 col[2 * R + RPT];
 #pragma unroll
     for (int q = 0; q < 2 * R + RPT; q++) col[q] = *(const float4 *)(colp + q * FB_TW);
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256, (R <= 4 ? BLUR_OCC_LO : BLUR_OCC_HI)) void gau
       }
       acc[k] = s;
     }
-#endif
+    }
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       const int gy = y0 + lyb + k;
@@ -1059,7 +1062,14 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
     for (int l = 0; l < n_levels; l++) { o.blur[l] = pp; pp += n; o.resp[l] = pp; pp += n; }
     o.omap = mp; mp += n;
   }
-  MODS_HIP_CHECK(hipMemcpyAsync(ctx->pyr_dev, &P, sizeof(PyramidDev), hipMemcpyHostToDevice, ctx->stream));
+  // the device copy of the table is refreshed only when the table changed (a batch of the same geometry leaves it alone: no
+  // host-to-device copy in the steady state of a worker, and none inside a recorded graph - mods_ctx_graphs)
+  if (!ctx->pyr_dev_valid || memcmp(&ctx->pyr_dev_image, &P, sizeof(PyramidDev)) != 0) {
+    ctx->pyr_dev_valid = false;
+    MODS_HIP_CHECK(hipMemcpyAsync(ctx->pyr_dev, &P, sizeof(PyramidDev), hipMemcpyHostToDevice, ctx->stream));   // (stream ordered behind the readers of the old table)
+    memcpy(&ctx->pyr_dev_image, &P, sizeof(PyramidDev));
+    ctx->pyr_dev_valid = true;
+  }
   if (par->detectorType != MODS_DET_HESSIAN) {
     if (!ctx->alt_taps_dev) MODS_HIP_CHECK(hipMalloc(&ctx->alt_taps_dev, sizeof(float) * kMaxLevels * kAltTapStride));
     const size_t need = (size_t)w * h * n_img;
@@ -1191,6 +1201,7 @@ static int pyramid_build_levels(mods_ctx *ctx, const float *img_dev, int stride)
   // keeps one stream.
   const bool fork = ctx->pyr_streams >= 2 && P.n_oct >= 2 && S < P.n_levels - 1 && (size_t)w * h * n_img >= ((size_t)4 << 20);
   ctx->pyr_side = false;
+  ctx->pyr_forked = false;
   // the octaves from `first_lds` on fit LDS and are built by pyramid_lds_kernel in one launch
   int first_lds = P.n_oct;
   {
@@ -1227,13 +1238,21 @@ static int pyramid_build_levels(mods_ctx *ctx, const float *img_dev, int stride)
     if ((rc = build_levels(oi, 1, fork ? S + 1 : P.n_levels))) return rc;
   if (fork && n_main < P.n_oct) {                                     // everything the later octaves need exists behind this event
     if (!ctx->stream2) {
-      MODS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      // the side chain is the scale space's critical path (every octave waits for the one before it; tools/trace_pyr.sh: its small
+      // launches took twice their own time next to the large octaves' NMS): it runs at the highest stream priority
+#ifndef PYR_SIDE_PRIO
+#define PYR_SIDE_PRIO 1
+#endif
+      int prio_low = 0, prio_high = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+      MODS_HIP_CHECK(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, PYR_SIDE_PRIO ? prio_high : prio_low));
       MODS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
       MODS_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
     MODS_HIP_CHECK(hipEventRecord(ctx->ev_fork, main_stream));
     MODS_HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     ctx->pyr_side = true;
+    ctx->pyr_forked = true;
   }
   if (fork)
     for (int oi = 0; oi < n_main; oi++)

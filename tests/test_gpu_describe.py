@@ -165,6 +165,40 @@ def test_batch16_1080p_vs_oracle(pkg):
     ctx.close()
 
 
+def test_graph_replay_equals_eager_launches(pkg):
+    """mods_ctx_graphs: from the second call with the same arguments on, the launches of detect + describe are recorded and replayed
+    as one hipGraph - regions identical to the eager calls', for different images in the same device buffer (what a pipeline worker
+    does batch after batch).  A batch whose scale space forks onto the side stream (16 x 720p: two branches in the graph) is
+    replayed; a call without the fork (2 images, or one pyramid stream) stays eager, because a linear recording faults on replay
+    with this runtime (csrc/capi.hip: dd_run; tools/exp_graph.py)."""
+    import torch
+    w, h = 1280, 720
+    for n_img, streams, replayed in ((16, 2, True), (2, 2, False), (16, 1, False)):
+        imgs = [np.stack([synth.texture(w, h, seed=500 + 7 * j + i) for i in range(n_img)]) for j in range(2)]
+        buf = torch.from_numpy(imgs[0]).cuda()
+        torch.cuda.synchronize()
+        eager = pkg.Context(0, w, h, n_img)
+        eager.pyramid_streams(streams)
+        want = []
+        for im in imgs:
+            buf.copy_(torch.from_numpy(im)); torch.cuda.synchronize()
+            eager.detect_describe_dev(buf.data_ptr(), n_img, w, h)
+            want.append([eager.regions_fetch(i) for i in range(n_img)])
+        eager.close()
+        ctx = pkg.Context(0, w, h, n_img, nonblocking=True)
+        ctx.pyramid_streams(streams)
+        ctx.graphs(True)
+        for rep in range(3):
+            for im, exp in zip(imgs, want):
+                buf.copy_(torch.from_numpy(im)); torch.cuda.synchronize()
+                ctx.detect_describe_dev(buf.data_ptr(), n_img, w, h)
+                for s in range(n_img):
+                    _assert_regions_equal(ctx.regions_fetch(s), exp[s])
+        # call 1 eager, call 2 records (and replays when the recording has two branches), 3.. replay
+        assert (ctx.graph_replays() >= 5) if replayed else (ctx.graph_replays() == 0), (n_img, streams, ctx.graph_replays())
+        ctx.close()
+
+
 def test_half_orientation_and_half_rootsift(pkg):
     """DetectOrientation in doHalfSIFT mode + HalfRootSIFT (64 values) for the same regions, as a step with
     Descriptors = RootSIFT,HalfRootSIFT asks for (imagerepresentation.cpp:725-731, 909-943, 970-979; siftdesc.cpp:401-436)."""
