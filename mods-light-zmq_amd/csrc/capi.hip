@@ -20,6 +20,9 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+// (Round 5 tried a wait without runtime calls - a one-thread kernel behind the stream's work stores a sequence number to a pinned
+// word of the waiting thread, which sleeps and reads that word: 836-843 against 858-866 pairs/s with the sleeping hipStreamQuery
+// polls below, the same process CPU per pair, the runtime's own thread as busy as before.  Dropped.)
 hipError_t stream_wait(hipStream_t s) {
   const long ns = tl_wait_sleep_ns;
   if (ns <= 0) return hipStreamSynchronize(s);
@@ -339,10 +342,18 @@ static unsigned long long fnv1a(const void *p, size_t n, unsigned long long h) {
 static int dd_run(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride, const mods_hessaff_params *det,
                   const mods_describe_params *desc) {
   const bool can = c->dd_graphs && c->timing_mask == 0 && !c->ext_fn && !c->shape_fn && !c->ori_fn && det->detectorType != MODS_DET_MSER;
-  if (!can) return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
+  if (!can) { c->dd_prev = mods_ctx::DdKey(); return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc); }
   mods_ctx::DdKey key;
   key.img = img_dev; key.n_img = n_img; key.w = w; key.h = h; key.stride = stride;
   key.par_hash = fnv1a(desc, sizeof(*desc), fnv1a(det, sizeof(*det), 1469598103934665603ull)) ^ (unsigned long long)c->pyr_streams;
+  // A recording is made, and replayed, only right behind a call with the SAME arguments: tables that live on the device and are
+  // refreshed from the host when the arguments change (the octave table, tap slots, masks) are then exactly what the recorded
+  // launches expect, and no such refresh can end up inside a recording.  A worker's steady state - full batches of one geometry -
+  // is a run of identical calls; a change of batch size or geometry costs one eager call.
+  if (c->dd_stale) { dd_graph_drop(c); c->dd_linear.clear(); c->dd_stale = false; }
+  const bool repeat = key == c->dd_prev;
+  c->dd_prev = key;
+  if (!repeat) return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
   for (auto &e : c->dd_cache)
     if (e.first == key) {
       MODS_HIP_CHECK(hipGraphLaunch(e.second, c->stream));
@@ -351,13 +362,6 @@ static int dd_run(mods_ctx *c, const float *img_dev, int n_img, int w, int h, in
     }
   for (const auto &k2 : c->dd_linear)
     if (k2 == key) return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
-  bool seen = false;
-  for (const auto &k2 : c->dd_seen) seen = seen || (k2 == key);
-  if (!seen) {                            // new arguments: one eager call first
-    if (c->dd_seen.size() >= 16) c->dd_seen.erase(c->dd_seen.begin());
-    c->dd_seen.push_back(key);
-    return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc);
-  }
   hipStream_t s = c->stream;
   if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
@@ -394,7 +398,8 @@ static int dd_run(mods_ctx *c, const float *img_dev, int n_img, int w, int h, in
 int mods_ctx_graphs(mods_ctx *c, int on) {
   if (!c) return MODS_E_ARG;
   c->dd_graphs = on != 0;
-  if (!on) { dd_graph_drop(c); c->dd_seen.clear(); c->dd_linear.clear(); }
+  if (!on) { dd_graph_drop(c); c->dd_linear.clear(); }
+  c->dd_prev = mods_ctx::DdKey();
   return MODS_OK;
 }
 long mods_ctx_graph_replays(const mods_ctx *c) { return c ? c->dd_replays : 0; }

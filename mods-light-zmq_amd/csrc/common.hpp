@@ -206,7 +206,8 @@ struct mods_ctx {
   struct DdKey { const float *img = nullptr; int n_img = 0, w = 0, h = 0, stride = 0; unsigned long long par_hash = 0;
                  bool operator==(const DdKey &o) const { return img == o.img && n_img == o.n_img && w == o.w && h == o.h && stride == o.stride && par_hash == o.par_hash; } };
   std::vector<std::pair<DdKey, hipGraphExec_t>> dd_cache;   // recorded calls (a worker sees a few batch sizes), oldest first
-  std::vector<DdKey> dd_seen;                               // arguments that have run eagerly once
+  bool dd_stale = false;                                    // a pool the recordings point into was reallocated: they are dropped
+  DdKey dd_prev;                                            // arguments of the context's previous detect + describe call
   std::vector<DdKey> dd_linear;                             // arguments whose recording had no second branch: never replayed (see dd_run)
   bool pyr_forked = false;                                  // the last pyramid_build put octaves on the side stream
   long dd_replays = 0;

@@ -1546,7 +1546,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
     MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
     if (ctx->desc_scratch) MODS_HIP_CHECK(hipFree(ctx->desc_scratch));
     ctx->desc_scratch = nullptr;
-    MODS_HIP_CHECK(hipMalloc(&ctx->desc_scratch, need * sizeof(float)));
+    { ctx->dd_stale = true; ctx->dd_prev = mods_ctx::DdKey(); } MODS_HIP_CHECK(hipMalloc(&ctx->desc_scratch, need * sizeof(float)));
     ctx->desc_scratch_elems = need;
   }
   float *patches = ctx->desc_scratch;

@@ -194,8 +194,9 @@ def test_graph_replay_equals_eager_launches(pkg):
                 ctx.detect_describe_dev(buf.data_ptr(), n_img, w, h)
                 for s in range(n_img):
                     _assert_regions_equal(ctx.regions_fetch(s), exp[s])
-        # call 1 eager, call 2 records (and replays when the recording has two branches), 3.. replay
-        assert (ctx.graph_replays() >= 5) if replayed else (ctx.graph_replays() == 0), (n_img, streams, ctx.graph_replays())
+        # calls 1-2 eager (the first one uploads tables: the second is the first plain repeat), call 3 records - and replays when the
+        # recording has two branches -, 4.. replay
+        assert (ctx.graph_replays() >= 3) if replayed else (ctx.graph_replays() == 0), (n_img, streams, ctx.graph_replays())
         ctx.close()
 
 
