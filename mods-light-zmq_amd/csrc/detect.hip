@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict_
   const int cl = c0 < 0 ? 0 : (c0 > w - 4 ? w - 4 : c0);              // lanes beside the row read a valid address (values unused)
   const bool lane_ok = lane >= 1 && lane <= 62;
 #ifndef NMS4_PREFETCH
-#define NMS4_PREFETCH 0
+#define NMS4_PREFETCH 1
 #endif
   // the rows of a level's own plane are requested while the level before it is worked on (round 5: the kernel is bound by the round
   // trips of a wave - own rows, then the candidates' neighbour planes, three levels in sequence -, not by bytes: 2.4 TB/s)
