@@ -221,10 +221,12 @@ __global__ __launch_bounds__(256) void nms4_kernel(const PyramidDev *__restrict_
   const int cl = c0 < 0 ? 0 : (c0 > w - 4 ? w - 4 : c0);              // lanes beside the row read a valid address (values unused)
   const bool lane_ok = lane >= 1 && lane <= 62;
 #ifndef NMS4_PREFETCH
-#define NMS4_PREFETCH 1
+#define NMS4_PREFETCH 0
 #endif
-  // the rows of a level's own plane are requested while the level before it is worked on (round 5: the kernel is bound by the round
-  // trips of a wave - own rows, then the candidates' neighbour planes, three levels in sequence -, not by bytes: 2.4 TB/s)
+  // NMS4_PREFETCH = 1: the rows of a level's own plane are requested while the level before it is worked on (the kernel is bound by
+  // the round trips of a wave - own rows, then the candidates' neighbour planes, three levels in sequence -, not by bytes: 2.4 TB/s).
+  // Round 5 measured it both ways: the NMS stage with per-launch scopes 0.338 -> 0.295 ms, the kernel under rocprofv3 119 -> 132 us
+  // per launch (162 registers: 3 waves per SIMD instead of 4), the whole scale space unchanged.  Left off.
   unsigned rowoff[NMS_ROWS + 2];
 #pragma unroll
   for (int rr = 0; rr < NMS_ROWS + 2; rr++) {
@@ -700,6 +702,7 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
   const int b = blockIdx.y;
   const int half = W / 2;
   for (int p = lane; p < WW; p += 64) s_mask[p] = mask[p];
+  const int g_r0 = sl / W, g_c0 = sl - g_r0 * W, g_dr = G / W, g_dc = G - g_dr * W;   // pixel walk of the gradient pass
   const int n_acc = acc_count[b];
 #ifdef BAUMBERG_PROF
   unsigned long long pt[5] = {0, 0, 0, 0, 0}, pl = __builtin_amdgcn_s_memtime();
@@ -793,9 +796,11 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
       BPROF(1)
       // computeGradient (helpers.cpp:779-797) and the three SMM products
       // (the one-sided differences at the window border are the same subtraction with one operand at the pixel itself)
-      if (active)
+      // (row and column of a lane's pixels advance by G / W and G % W with one carry: no division per pixel - the compiler's
+      // expansion of p / W was 16 of this loop's 58 vector instructions, and the loop a third of an iteration's)
+      if (active) {
+        int r = g_r0, c = g_c0;
         for (int p = sl; p < WW; p += G) {
-          const int r = p / W, c = p - r * W;
           const float xa = s_img[p + (c < W - 1 ? 1 : 0)], xb = s_img[p - (c > 0 ? 1 : 0)];
           const float ya = s_img[p + (r < W - 1 ? W : 0)], yb = s_img[p - (r > 0 ? W : 0)];
           const float xgrad = xa - xb, ygrad = ya - yb;
@@ -804,7 +809,10 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
           s_pa[p] = xgrad * xgrad * v;
           s_pb[p] = gxy * v;
           s_pc[p] = ygrad * ygrad * v;
+          r += g_dr; c += g_dc;
+          if (c >= W) { c -= W; r++; }
         }
+      }
       wave_sync();
       BPROF(2)
       // ordered accumulation (raster order, fp32): three lanes per keypoint, one sum each
