@@ -144,6 +144,26 @@ def test_describe_1080p_batch(gpu_ctx):
         _assert_regions_equal(gpu_ctx.regions_fetch(i), want)
 
 
+@pytest.mark.parametrize("w,h", [(1921, 1081), (1922, 1079), (1923, 1080)])
+def test_large_planes_with_unaligned_rows(pkg, w, h):
+    """Rows that are not a multiple of four pixels on planes large enough for the 32-row tiles of the fused blur + response kernel
+    (two images of ~1920 x 1080): its window loader takes 16-byte loads at any dword alignment, and a window float4 that reaches
+    past the last column is the row's last float4 shifted down with the last pixel repeated (csrc/pyramid.hip: load_window) - a path
+    that images with aligned rows, and single images of this size (16-row tiles), never take."""
+    import torch
+    import pipeline_oracle as po
+    imgs = [synth.texture(w, h, seed=900 + w + i) for i in range(2)]
+    want = po.pmap(orc.detect_describe, imgs)
+    ctx = pkg.Context(0, w, h, 2)
+    t = torch.from_numpy(np.stack(imgs)).cuda()
+    torch.cuda.synchronize()
+    nd, nr = ctx.detect_describe_dev(t.data_ptr(), 2, w, h)
+    for i, (exp, nd_exp) in enumerate(want):
+        assert nd[i] == nd_exp and nr[i] == len(exp), i
+        _assert_regions_equal(ctx.regions_fetch(i), exp)
+    ctx.close()
+
+
 def test_batch16_1080p_vs_oracle(pkg):
     """The batching of the benchmark's pipeline (pairs_per_batch = 8: 16 images of 1920 x 1080 per launch) against the
     oracle directly, image by image."""
