@@ -613,6 +613,7 @@ int mods_pipeline_capacity(const mods_pipeline *p);    /* pairs that may be in f
 /* HIP-event timing of the workers' contexts (sums over them); enable/read while nothing is in flight */
 int mods_pipeline_timing_enable(mods_pipeline *p, int stage_mask);
 int mods_pipeline_timing_read(mods_pipeline *p, int stage, double *total_ms, int *launches, double *bytes);
+long mods_pipeline_graph_replays(mods_pipeline *p);   /* batches whose detect + describe chain was a graph replay (mods_ctx_graphs) */
 /* CPU seconds the GPU workers' / the verify workers' own threads have spent inside their stages since the last reset (thread clocks;
    the RANSAC task pool's helper threads are not in them).  What a pair costs the host: needed to size ranks per node. */
 int mods_pipeline_cpu_seconds(mods_pipeline *p, double *gpu_workers_s, double *verify_workers_s, int reset);

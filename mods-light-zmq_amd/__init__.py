@@ -913,6 +913,10 @@ class Pipeline:
         _check(lib().mods_pipeline_timing_read(self.h, STAGES.index(stage), C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
 
+    def graph_replays(self):
+        lib().mods_pipeline_graph_replays.restype = C.c_long
+        return int(lib().mods_pipeline_graph_replays(self.h))
+
     def cpu_seconds(self, reset=False):
         """(GPU workers, verify workers): CPU seconds their threads spent inside their stages since the last reset"""
         g, v = C.c_double(), C.c_double()

@@ -274,6 +274,13 @@ int mods_pipeline_timing_read(mods_pipeline *p, int stage, double *total_ms, int
   return MODS_OK;
 }
 
+// detect + describe calls of the workers that were served by a graph replay so far (mods_ctx_graphs)
+long mods_pipeline_graph_replays(mods_pipeline *p) {
+  long n = 0;
+  if (p) for (auto *c : p->ctxs) n += mods_ctx_graph_replays(c);
+  return n;
+}
+
 // CPU seconds the GPU workers / the verify workers have spent inside their stages since the last reset (reset != 0 clears them)
 int mods_pipeline_cpu_seconds(mods_pipeline *p, double *gpu_workers_s, double *verify_workers_s, int reset) {
   if (!p) return MODS_E_ARG;
