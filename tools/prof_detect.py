@@ -11,6 +11,9 @@ W, H, B = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 2
 imgs = np.stack([synth.texture(W, H, seed=100 + i) for i in range(B)])
 t = torch.from_numpy(imgs).cuda()
 ctx = pkg.Context(0, W, H, B)
+# PYR_STREAMS=1: every launch of the scale space alone on the GPU (what bench.py's "isolated" events and the roofline of the blur kernel
+# are about); default 2 = as shipped, the small octaves on the side stream next to the large octaves' last level and NMS
+ctx.pyramid_streams(int(os.environ.get("PYR_STREAMS", "2")))
 stages = os.environ.get("STAGES", "blur,blur_small,response,resize,nms,pyramid,localize,baumberg,sort").split(",")
 for it in range(3):
     ctx.detect_hessian_affine_dev(t.data_ptr(), B, W, H, fetch=False)

@@ -13,8 +13,11 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 grep '^{"metric"' $OUT/stats.log > $OUT/bench_under_rocprof.json
 # the isolated leg alone (one stream, 16 images per launch): its blur durations are the ones bench.py's "isolated" events see
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -- python $R/tools/prof_detect.py 16 > $OUT/detect_leg.log 2>&1
+PYR_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -- python $R/tools/prof_detect.py 16 > $OUT/detect_leg.log 2>&1
 cp $(find $OUT/leg -name "*kernel_stats.csv" | head -1) $OUT/detect_leg_kernel_stats.csv
+# the same leg as shipped (small octaves on the prioritised side stream: launches of the two streams overlap)
+rm -rf $OUT/leg; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -- python $R/tools/prof_detect.py 16 > $OUT/detect_leg_two_streams.log 2>&1
+cp $(find $OUT/leg -name "*kernel_stats.csv" | head -1) $OUT/detect_leg_two_streams_kernel_stats.csv
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/tools/prof_detect.py 16 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/tools/prof_detect.py 16 > /dev/null 2>&1
 python3 $R/tools/pmc_blur.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/pmc_blur_traffic.csv
