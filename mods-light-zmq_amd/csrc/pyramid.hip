@@ -211,6 +211,9 @@ __device__ __forceinline__ void store_f4_at(float *base, unsigned byte_off, floa
 #ifndef BLUR_COLJ
 #define BLUR_COLJ 1
 #endif
+#ifndef BLUR_COLJ_MIN_R
+#define BLUR_COLJ_MIN_R 1
+#endif
 #ifndef BLUR_COLJ_MIN_TH
 #define BLUR_COLJ_MIN_TH 32   // the outward column pass pays with 4 outputs per thread; the 16-row tiles (2 outputs) read their 2R + 2 rows up front
 #endif
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256, (R <= 4 ? BLUR_OCC_LO : BLUR_OCC_HI)) void gau
     const int lyb = (tid >> 5) * RPT;
     const float *colp = smem + lyb * FB_TW + 4 * tcs;
     float4 acc[RPT];
-    if constexpr (BLUR_COLJ && FB_TH >= BLUR_COLJ_MIN_TH) {
+    if constexpr (BLUR_COLJ && FB_TH >= BLUR_COLJ_MIN_TH && R >= BLUR_COLJ_MIN_R) {
     float4 up[RPT], dn[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) {

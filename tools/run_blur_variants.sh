@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   if [[ "$v" == *=* ]]; then L=""; else L=$R/mods-light-zmq_amd/_variants/libmodsgpu_$v.so; fi
   rm -rf $OUT/leg
-  MODS_LIB=$L timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -- python $R/tools/prof_detect.py 16 > $OUT/leg_$v.log 2>&1
+  PYR_STREAMS=${PYR_STREAMS:-2} MODS_LIB=$L timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -- python $R/tools/prof_detect.py 16 > $OUT/leg_$v.log 2>&1
   echo "== $v" >> $OUT/variants.log
   grep -a "pyramid \|blur  \|nms " $OUT/leg_$v.log | head -4 >> $OUT/variants.log
   python3 - $(find $OUT/leg -name "*kernel_stats.csv" | head -1) >> $OUT/variants.log <<'PY'
