@@ -378,6 +378,16 @@ def config_c3(args):
         cfg["ransac_samples"] = r.ransac_samples
         cfg["stage_ms"] = {"synth_detect_describe": round(r.ms_detect_describe, 2), "match": round(r.ms_match, 2),
                            "duplicates": round(r.ms_duplicates, 2), "ransac": round(r.ms_ransac, 2)}
+    if world > 1 and rank == 0:
+        # the sharded result against the one-GPU ladder of the same pair (same pinned seed): identical banks, tentatives and inliers
+        rep1, rep2 = pkg.ImgRep(ctx, 1 << 20), pkg.ImgRep(ctx, 1 << 20)
+        pkg.ransac_pin_seed(12345)
+        one = pkg.match_ladder_dev(ctx, t.data_ptr(), w, h, steps, rep1, rep2, min_matches=mm)[0]
+        cfg["equals_one_gpu_ladder"] = bool(list(one.n_described) == list(get("n_described")) and one.n_tentatives == get("n_tentatives")
+                                            and one.n_unique == get("n_unique") and one.n_inliers == get("n_inliers"))
+        rep1.close(); rep2.close()
+    if world > 1:
+        dist.barrier()
     if world > 1 and not share:
         # the same decomposition as ONE process (C++ host: a thread and a communicator rank per device); rank 0 runs it, the others wait
         multi = None

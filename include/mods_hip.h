@@ -399,6 +399,12 @@ int mods_test_host_errfn(int type, const double *u6, int len, const double *H, i
 int mods_test_host_u2h(const double *u6, const int *inl, int n, int reference_form, double *H);
 int mods_test_host_cov(const double *u6, const int *inl, int n, int reference_form, double *Cv);
 int mods_test_host_inlidxs(const double *err, int len, double th, int lanes, int *inl, unsigned *I, double *J);
+/* mods_test_host_cov also takes reference_form 2 (the 30 folded sums in scalar code) and 100 + lanes (the sums through the SIMD
+ * table of that width).  The checks LORANSACFiltering runs behind the homography (H -> inv(H^T), NaiveHCheck, H_LAF_check;
+ * matching.cpp:745-805, 1014-1043, 250-308) over the correspondences with inl[i] != 0: lanes 0 = the scalar statement, 1 / 4 / 8 =
+ * lanes-wide; mask[n], H_out[9], returns the number of survivors (< 0: MODS_E_*). */
+int mods_test_host_hchecks(const double *u6, const double *laf14, int n, const unsigned char *inl, const double *Hloran,
+                           const mods_ransac_params *par, int lanes, unsigned char *mask, double *H_out);
 /* the same for the epipolar error functions of the F-matrix path: mode 0 FDs, 1 FDsSym, 2 exFDs, 3 exFDsSym (Ftools.c:94-209) */
 int mods_test_host_fds(int mode, const double *u6, int len, const double *F, int lanes, double *p, double *w);
 /* self-test hooks of the host-side pieces of the F-matrix path (no device needed; they let the CPU

@@ -2,6 +2,7 @@
 // detector entry points and introspection for the parity tests.
 #include "common.hpp"
 #include "detmath.hpp"
+#include "ransac_host.hpp"
 #include <cstdarg>
 #include <algorithm>
 #include <cmath>
@@ -156,7 +157,7 @@ void mods_ctx_destroy(mods_ctx *c) {
   (void)hipFree(c->tmp_dev); (void)hipFree(c->alt_taps_dev); (void)hipFree(c->alt_planes); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
   (void)hipHostFree(c->host_counts); (void)hipHostFree(c->pin_arena);
-  (void)hipFree(c->ori_dev); (void)hipFree(c->ori_multi_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev);
+  (void)hipFree(c->ori_dev); (void)hipFree(c->ori_multi_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev); (void)hipFree(c->blur_table_dev);
   (void)hipFree(c->desc_err_dev); (void)hipFree(c->desc_scratch);
   (void)hipFree(c->m_desc); (void)hipFree(c->m_c); (void)hipFree(c->m_xy); (void)hipFree(c->m_u64); (void)hipFree(c->m_int); (void)hipFree(c->m_mid);
   (void)hipFree(c->m_p2); (void)hipFree(c->dd_buf); (void)hipFree(c->m_tent2); (void)hipFree(c->m_tent); (void)hipFree(c->m_tent_batch); (void)hipHostFree(c->m_count); (void)hipFree(c->m_regs);
@@ -727,6 +728,108 @@ static bool invert3(const double *S, double *t) {
   return true;
 }
 
+// What LORANSACFiltering does with the model of the homography branch (matching.cpp:745-805): H -> row-major img1->img2 by inv(H^T),
+// NaiveHCheck (10 px, :1014-1043) over the RANSAC inliers, H_LAF_check (:250-308: HDsSymMax on the three frame points).  mask[i] = 1
+// for the correspondences that survive; returns their number.  ops = the host SIMD table (ransac_simd.hpp): both checks are the
+// symmetric transfer error of point pairs, evaluated lanes-wide over structure-of-arrays copies of the inliers (every lane does the
+// scalar code's operations in its order: the same bits); ops = nullptr runs the scalar statement (kept for the self-test).
+static int h_post_checks(const double *u6, const double *laf, int n, const unsigned char *inl2, const double *Hloran,
+                         const mods_ransac_params *par, const mods::rs::SimdOps *ops, unsigned char *mask, double *H_out) {
+  const int MIN_POINTS = 8;
+  // H: inv(Hloran^T); reading the column-major h as a row-major matrix is H^T, its transpose is h read column-wise
+  const double Ht[9] = {Hloran[0], Hloran[3], Hloran[6], Hloran[1], Hloran[4], Hloran[7], Hloran[2], Hloran[5], Hloran[8]};
+  double Hinv[9];
+  invert3(Ht, Hinv);
+  bool nonzero = false;
+  for (int i = 0; i < 9; i++) nonzero = nonzero || (Hinv[i] != 0.0);
+  if (!nonzero) return 0;
+  for (int i = 0; i < 9; i++) H_out[i] = Hinv[i];
+  std::vector<int> cur;
+  for (int i = 0; i < n; i++) if (inl2[i]) cur.push_back(i);
+  const double affineFerror = 3.0 * par->HLAFCoef * par->err_threshold;
+  const double err_sq = 10.0 * 10.0;
+  const double ks = 3.0;   // matching.cpp:171
+  double Hi[9];
+  invert3(Hinv, Hi);
+  if (ops) {
+    const int m = (int)cur.size();
+    if (m == 0) return 0;
+    const int m_pad = (m + mods::rs::SIMD_PAD - 1) / mods::rs::SIMD_PAD * mods::rs::SIMD_PAD;
+    std::vector<double> buf((size_t)7 * m_pad);
+    double *c0 = buf.data(), *c1 = c0 + m_pad, *c2 = c1 + m_pad, *c3 = c2 + m_pad, *e0 = c3 + m_pad, *e1 = e0 + m_pad, *e2 = e1 + m_pad;
+    const double *soa[5] = {c0, c1, c2, c3, c3};
+    for (int k = 0; k < m_pad; k++) {
+      const double *p = u6 + (size_t)cur[k < m ? k : m - 1] * 6;
+      c0[k] = p[0]; c1[k] = p[1]; c2[k] = p[3]; c3[k] = p[4];
+    }
+    ops->hsym_both_all(soa, m_pad, Hinv, Hi, e0, e1);
+    int ok = 0;
+    for (int k = 0; k < m; k++) if ((e0[k] <= err_sq) && (e1[k] <= err_sq)) ok++;
+    if (ok < MIN_POINTS) return 0;
+    if (affineFerror > 0 && laf) {
+      mods::rs::SymH sh;
+      mods::rs::sym_prepare(Hloran, &sh);
+      // the centre pair is the correspondence itself (u[0..1], u[3..4] = f[0..1], f[7..8]); then the two frame points
+      for (int k = 0; k < m_pad; k++) { const double *f = laf + (size_t)cur[k < m ? k : m - 1] * 14; c0[k] = f[0]; c1[k] = f[1]; c2[k] = f[7]; c3[k] = f[8]; }
+      ops->hsym_all(soa, m_pad, sh.H1, sh.Hinv, 1, e0);
+      for (int k = 0; k < m_pad; k++) {
+        const double *f = laf + (size_t)cur[k < m ? k : m - 1] * 14;
+        c0[k] = f[0] + ks * f[3] * f[6]; c1[k] = f[1] + ks * f[5] * f[6]; c2[k] = f[7] + ks * f[10] * f[13]; c3[k] = f[8] + ks * f[12] * f[13];
+      }
+      ops->hsym_all(soa, m_pad, sh.H1, sh.Hinv, 1, e1);
+      for (int k = 0; k < m_pad; k++) {
+        const double *f = laf + (size_t)cur[k < m ? k : m - 1] * 14;
+        c0[k] = f[0] + ks * f[2] * f[6]; c1[k] = f[1] + ks * f[4] * f[6]; c2[k] = f[7] + ks * f[9] * f[13]; c3[k] = f[8] + ks * f[11] * f[13];
+      }
+      ops->hsym_all(soa, m_pad, sh.H1, sh.Hinv, 1, e2);
+      int kept = 0;
+      for (int k = 0; k < m; k++) {
+        const double sumErr = std::sqrt(e0[k] + e1[k] + e2[k]);
+        if (!(sumErr > affineFerror)) cur[kept++] = cur[k];
+      }
+      cur.resize(kept);
+    }
+  } else {
+    // NaiveHCheck over the RANSAC inliers
+    {
+      int ok = 0;
+      for (int i : cur) {
+        const double *p = u6 + (size_t)i * 6;
+        const double *Hm = Hinv;
+        double xa = (Hm[0] * p[0] + Hm[1] * p[1] + Hm[2]) / (Hm[6] * p[0] + Hm[7] * p[1] + Hm[8]);
+        double ya = (Hm[3] * p[0] + Hm[4] * p[1] + Hm[5]) / (Hm[6] * p[0] + Hm[7] * p[1] + Hm[8]);
+        const double d1 = (p[3] - xa) * (p[3] - xa) + (p[4] - ya) * (p[4] - ya);
+        xa = (Hi[0] * p[3] + Hi[1] * p[4] + Hi[2]) / (Hi[6] * p[3] + Hi[7] * p[4] + Hi[8]);
+        ya = (Hi[3] * p[3] + Hi[4] * p[4] + Hi[5]) / (Hi[6] * p[3] + Hi[7] * p[4] + Hi[8]);
+        const double d2 = (p[0] - xa) * (p[0] - xa) + (p[1] - ya) * (p[1] - ya);
+        if ((d1 <= err_sq) && (d2 <= err_sq)) ok++;
+      }
+      if (ok < MIN_POINTS) cur.clear();
+    }
+    // H_LAF_check with HDsSymMax on the three frame points
+    if (affineFerror > 0 && laf) {
+      std::vector<int> good;
+      for (int i : cur) {
+        const double *f = laf + (size_t)i * 14;
+        double u[18], err[3];
+        u[0] = f[0]; u[1] = f[1]; u[2] = 1.0;
+        u[3] = f[7]; u[4] = f[8]; u[5] = 1.0;
+        u[6] = u[0] + ks * f[3] * f[6]; u[7] = u[1] + ks * f[5] * f[6]; u[8] = 1.0;
+        u[9] = u[3] + ks * f[10] * f[13]; u[10] = u[4] + ks * f[12] * f[13]; u[11] = 1.0;
+        u[12] = u[0] + ks * f[2] * f[6]; u[13] = u[1] + ks * f[4] * f[6]; u[14] = 1.0;
+        u[15] = u[3] + ks * f[9] * f[13]; u[16] = u[4] + ks * f[11] * f[13]; u[17] = 1.0;
+        HDsSymMax(nullptr, u, Hloran, err, 3);
+        const double sumErr = std::sqrt(err[0] + err[1] + err[2]);
+        if (!(sumErr > affineFerror)) good.push_back(i);
+      }
+      cur.swap(good);
+    }
+  }
+  if ((int)cur.size() < MIN_POINTS) cur.clear();
+  for (int i : cur) mask[i] = 1;
+  return (int)cur.size();
+}
+
 // LORANSACFiltering for the homography branch (useF = 0), matching.cpp:637-805: degensac LO-RANSAC,
 // H -> row-major img1->img2 by inv(H^T), NaiveHCheck (10 px, :1014-1043), H_LAF_check (:250-308).
 // mask[i] = 1 for the correspondences that survive every check.
@@ -746,9 +849,8 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
   if (n <= 20) max_samples = 1000;
   std::vector<double> u2(u6, u6 + (size_t)n * 6);
   std::vector<unsigned char> inl2(n);
-  std::vector<int> data_out((size_t)n * 18);
+  std::vector<int> data_out(18);   // (the reference sizes it 18 n, matching.cpp:700; three counters are written)
   double Hloran[9];
-  double *resids = nullptr;
   void (*f0)(const double *, const double *, const double *, double *, int);
   void (*f1)(const double *, const double *, const double *, double *, int, int *, int);
   void (*f2)(const double *, const double *, const double *, double *, int, int *, int);
@@ -756,65 +858,23 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
   else if (par->errorType == 1) { f0 = &HDsSymMax; f1 = &HDsiSymMax; f2 = &HDsSymidxMax; }
   else { f0 = &HDsSym; f1 = &HDsiSym; f2 = &HDsSymidx; }
   exp_ransacHcustom(u2.data(), n, par->err_threshold * par->err_threshold, par->confidence, max_samples, Hloran, inl2.data(), 4,
-                    data_out.data(), 1, 0, &resids, f0, f1, f2, par->doSymmCheck);
-  free(resids);
+                    data_out.data(), 1, 0, nullptr, f0, f1, f2, par->doSymmCheck);   // (no residual rows: nobody reads them here)
   if (mods::ransac_failed()) return MODS_E_HIP;   // device failure inside the control loop; mods_last_error() says which
   const double t_post0 = now_ms();
   if (stats3) { stats3[0] = data_out[0]; stats3[1] = data_out[1]; stats3[2] = data_out[2]; }
-  // H: inv(Hloran^T); reading the column-major h as a row-major matrix is H^T, its transpose is h read column-wise
-  const double Ht[9] = {Hloran[0], Hloran[3], Hloran[6], Hloran[1], Hloran[4], Hloran[7], Hloran[2], Hloran[5], Hloran[8]};
-  double Hinv[9];
-  invert3(Ht, Hinv);
-  bool nonzero = false;
-  for (int i = 0; i < 9; i++) nonzero = nonzero || (Hinv[i] != 0.0);
-  if (!nonzero) return MODS_OK;
-  for (int i = 0; i < 9; i++) H_out[i] = Hinv[i];
-  std::vector<int> cur;
-  for (int i = 0; i < n; i++) if (inl2[i]) cur.push_back(i);
-  // NaiveHCheck over the RANSAC inliers
-  {
-    const double err_sq = 10.0 * 10.0;
-    double Hi[9];
-    invert3(Hinv, Hi);
-    int ok = 0;
-    for (int i : cur) {
-      const double *p = u6 + (size_t)i * 6;
-      const double *Hm = Hinv;
-      double xa = (Hm[0] * p[0] + Hm[1] * p[1] + Hm[2]) / (Hm[6] * p[0] + Hm[7] * p[1] + Hm[8]);
-      double ya = (Hm[3] * p[0] + Hm[4] * p[1] + Hm[5]) / (Hm[6] * p[0] + Hm[7] * p[1] + Hm[8]);
-      const double d1 = (p[3] - xa) * (p[3] - xa) + (p[4] - ya) * (p[4] - ya);
-      xa = (Hi[0] * p[3] + Hi[1] * p[4] + Hi[2]) / (Hi[6] * p[3] + Hi[7] * p[4] + Hi[8]);
-      ya = (Hi[3] * p[3] + Hi[4] * p[4] + Hi[5]) / (Hi[6] * p[3] + Hi[7] * p[4] + Hi[8]);
-      const double d2 = (p[0] - xa) * (p[0] - xa) + (p[1] - ya) * (p[1] - ya);
-      if ((d1 <= err_sq) && (d2 <= err_sq)) ok++;
-    }
-    if (ok < MIN_POINTS) cur.clear();
-  }
-  // H_LAF_check with HDsSymMax on the three frame points
-  const double affineFerror = 3.0 * par->HLAFCoef * par->err_threshold;
-  if (affineFerror > 0 && laf) {
-    std::vector<int> good;
-    const double ks = 3.0;   // matching.cpp:171
-    for (int i : cur) {
-      const double *f = laf + (size_t)i * 14;
-      double u[18], err[3];
-      u[0] = f[0]; u[1] = f[1]; u[2] = 1.0;
-      u[3] = f[7]; u[4] = f[8]; u[5] = 1.0;
-      u[6] = u[0] + ks * f[3] * f[6]; u[7] = u[1] + ks * f[5] * f[6]; u[8] = 1.0;
-      u[9] = u[3] + ks * f[10] * f[13]; u[10] = u[4] + ks * f[12] * f[13]; u[11] = 1.0;
-      u[12] = u[0] + ks * f[2] * f[6]; u[13] = u[1] + ks * f[4] * f[6]; u[14] = 1.0;
-      u[15] = u[3] + ks * f[9] * f[13]; u[16] = u[4] + ks * f[11] * f[13]; u[17] = 1.0;
-      HDsSymMax(nullptr, u, Hloran, err, 3);
-      const double sumErr = std::sqrt(err[0] + err[1] + err[2]);
-      if (!(sumErr > affineFerror)) good.push_back(i);
-    }
-    cur.swap(good);
-  }
-  if ((int)cur.size() < MIN_POINTS) cur.clear();
-  for (int i : cur) mask[i] = 1;
-  *n_inliers = (int)cur.size();
+  *n_inliers = h_post_checks(u6, laf, n, inl2.data(), Hloran, par, mods::rs::simd_ops(), mask, H_out);
   if (ransac_profile_on()) fprintf(stderr, "loransac_h prof: whole %.0f us, checks after RANSAC %.0f us\n", 1e3 * (now_ms() - t_enter), 1e3 * (now_ms() - t_post0));
   return MODS_OK;
+}
+
+int mods_test_host_hchecks(const double *u6, const double *laf14, int n, const unsigned char *inl, const double *Hloran,
+                           const mods_ransac_params *par, int lanes, unsigned char *mask, double *H_out) {
+  if (!u6 || !inl || !Hloran || !par || !mask || !H_out || n < 0) return MODS_E_ARG;
+  const mods::rs::SimdOps *ops = lanes ? mods::rs::simd_ops_lanes(lanes) : nullptr;
+  if (lanes && !ops) return MODS_E_ARG;
+  for (int i = 0; i < 9; i++) H_out[i] = -1;
+  for (int i = 0; i < n; i++) mask[i] = 0;
+  return h_post_checks(u6, laf14, n, inl, Hloran, par, ops, mask, H_out);
 }
 
 // useF branch of LORANSACFiltering (matching.cpp:711-726, 804-816): DEGENSAC + F_LAF_check (:192-249)

@@ -157,6 +157,8 @@ struct mods_ctx {
   int *inside_count = nullptr;       // [batch] keypoints that pass the centre test (the reference's unoriented list)
   std::vector<int> last_inside_counts;
   float *desc_scratch = nullptr;
+  int blur_table_ps = 0;
+  float *blur_table_dev = nullptr;   // per-P2 taps / resampling sequence / source indices of the LDS extraction tier (sift.hip: blur_table_kernel)
   // external descriptor (e.g. a ZMQ daemon): when set, patches go to this function instead of the SIFT kernel
   mods_descriptor_fn ext_fn = nullptr;
   void *ext_user = nullptr;
@@ -260,6 +262,7 @@ struct DupJob { const char *src; char *dst; const int *n_src; int *n_dst; int *s
 int dup_filter_dev(mods_ctx *c, const DupJob *jobs, int n_jobs, int grid_n, double r, int mode);
 int dup_filter_reserve(mods_ctx *c, int n_jobs);
 int launch_fast_sqrt_selftest(mods_ctx *ctx, unsigned long long *out5_host);   // describe.hip
+int launch_blur_table(mods_ctx *ctx, int ps);   // sift.hip
 bool ransac_profile_on();            // MODS_RANSAC_PROF: per-call breakdown of the verification on stderr (ransac.hip)
 
 // describe.hip

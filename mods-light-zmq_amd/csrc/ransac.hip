@@ -390,7 +390,7 @@ static Score lo_iter(LoState &L, int *inliers, double th, double ths, int steps,
   lsq(S);
   for (int it = 0; it < steps; it++) {
     L.errfn(L.u, h, d, len);
-    memcpy(resids + (size_t)it * len, d, len * sizeof(double));
+    if (resids) memcpy(resids + (size_t)it * len, d, len * sizeof(double));
     Ss = inlidxs_v(L, d, th, inliers);
     const uint32_t hash = rs::super_fast_hash((const char *)inliers, (int)(Ss.I * sizeof(*inliers)));
     const int ret = L.ht->contains(hash, (int)Ss.I, iterID);
@@ -409,7 +409,7 @@ static Score lo_iter(LoState &L, int *inliers, double th, double ths, int steps,
     ths -= dth;
   }
   L.errfn(L.u, h, d, len);
-  memcpy(resids + (size_t)4 * len, d, len * sizeof(double));
+  if (resids) memcpy(resids + (size_t)4 * len, d, len * sizeof(double));
   S = inlidxs_v(L, d, th, inliers);
   if (rs::score_less(maxS, S)) {
     maxS = S;
@@ -427,7 +427,7 @@ static Score lo_inner(LoState &L, int *inliers, int ninl, double th, double *H, 
   double *d, h[9];
   std::vector<int> intbuff(len);
   if (ninl < 8) {
-    memset(resids, 0xFF, (size_t)(62 - 2) * len * sizeof(double));   // RESIDS_M - 2
+    if (resids) memset(resids, 0xFF, (size_t)(62 - 2) * len * sizeof(double));   // RESIDS_M - 2
     return maxS;
   }
   int ssiz = ninl / 2;
@@ -437,9 +437,9 @@ static Score lo_inner(LoState &L, int *inliers, int ninl, double th, double *H, 
     int *sample = rs::randsubset(*L.rng, inliers, ninl, ssiz);
     rs::u2h(L.u, sample, ssiz, h, L.buffer);
     L.errfn(L.u, h, L.errs[0], len);
-    memcpy(resids + (size_t)i * 6 * len, L.errs[0], len * sizeof(double));
+    if (resids) memcpy(resids + (size_t)i * 6 * len, L.errs[0], len * sizeof(double));
     L.errs[4] = L.errs[0];
-    S = lo_iter(L, intbuff.data(), th, 4 * th, 4, h, ++*iterID, resids + (size_t)i * 6 * len + len);
+    S = lo_iter(L, intbuff.data(), th, 4 * th, 4, h, ++*iterID, resids ? resids + (size_t)i * 6 * len + len : nullptr);
     if (rs::score_less(maxS, S)) {
       maxS = S;
       d = L.errs[2]; L.errs[2] = L.errs[0]; L.errs[0] = d;
@@ -489,16 +489,28 @@ int mods_test_host_u2h(const double *u6, const int *inl, int n, int reference_fo
   rs::u2h(u6, inl, n, H, buffer.data(), reference_form != 0);
   return MODS_OK;
 }
-// the 9 x 9 moment matrix alone (normu + lin_hgN + cov_mat, or cov_hgN)
+// the 9 x 9 moment matrix alone: reference_form 1 = normu + lin_hgN + cov_mat as written in the reference, 0 = the product's path
+// (the 30 folded sums through the host SIMD table), 2 = the folded sums in scalar code, 100 + lanes = the table of that
+// lane count (MODS_E_ARG when this CPU lacks it)
 int mods_test_host_cov(const double *u6, const int *inl, int n, int reference_form, double *Cv) {
   if (!u6 || !inl || !Cv || n < 1) return MODS_E_ARG;
   double A1[3], A2[3];
+  if (reference_form >= 100) {
+    const rs::SimdOps *ops = rs::simd_ops_lanes(reference_form - 100);
+    if (!ops) return MODS_E_ARG;
+    double sums[30];
+    rs::normu(u6, inl, n, A1, A2);
+    ops->cov_hg_all(u6, inl, n, A1, A2, sums);
+    rs::cov_hgN_unfold(sums, Cv);
+    return MODS_OK;
+  }
   rs::normu(u6, inl, n, A1, A2);
-  if (reference_form) {
+  if (reference_form == 0) { rs::cov_hgN(u6, inl, n, A1, A2, Cv); return MODS_OK; }
+  if (reference_form == 1) {
     std::vector<double> Z((size_t)18 * n);
     rs::lin_hgN(u6, Z.data(), inl, n, A1, A2);
     rs::cov_mat(Cv, Z.data(), 2 * n, 9);
-  } else rs::cov_hgN(u6, inl, n, A1, A2, Cv);
+  } else rs::cov_hgN_scalar(u6, inl, n, A1, A2, Cv);
   return MODS_OK;
 }
 // inlidxs (rtools.c:155-166): lanes 0 = scalar
@@ -550,7 +562,7 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
   for (int i = 0; i < len; i++) pool[i] = i;
   PointsSoA pts;
   pts.build(u, len);
-  std::vector<double> buffer((size_t)len * 18), err((size_t)pts.n_pad * 4), d_check(len);
+  std::vector<double> err((size_t)pts.n_pad * 4), d_check(len);   // (u2h's scratch matrix is for its reference form only: not used here)
   double *errs[5];
   for (int i = 0; i < 4; i++) errs[i] = err.data() + (size_t)i * pts.n_pad;
   errs[4] = errs[3];
@@ -561,7 +573,7 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
   const unsigned MIN_GOOD_SYM_PTS = 5;
   const double th_check = CHECK_COEF * th;
   ErrFn errfn = {err_type, custom, &pts};
-  LoState L = {u, len, th, {errs[0], errs[1], errs[2], errs[3], errs[4]}, buffer.data(), &rng, &ht, inlLimit, errfn, &pts};
+  LoState L = {u, len, th, {errs[0], errs[1], errs[2], errs[3], errs[4]}, nullptr, &rng, &ht, inlLimit, errfn, &pts};
 
   const double t_up0 = rsprof_on() ? rs_now_us() : 0;
   if (!ransac_ws_reserve(ws, len, 64)) ransac_fail();
@@ -581,38 +593,42 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
   auto run_lo = [&](bool *new_max) {
     RsTimer t_lo(5);
     iter_cnt++;
-    *resids = (double *)realloc(*resids, (size_t)iter_cnt * RESIDS_M * len * sizeof(double));
-    double *rbase = *resids + (size_t)RESIDS_M * (iter_cnt - 1) * len;
+    // the residual rows of every LO (exp_ranH.c:961-968: RESIDS_M rows of len doubles each) are kept for a caller that asks for them
+    double *rbase = nullptr;
+    if (resids) {
+      *resids = (double *)realloc(*resids, (size_t)iter_cnt * RESIDS_M * len * sizeof(double));
+      rbase = *resids + (size_t)RESIDS_M * (iter_cnt - 1) * len;
+    }
     double *d;
     switch (iter_type) {
       case 0: break;
       case 1:
         S = inlidxs_v(L, L.errs[4], 4 * th, inliers.data());
-        rs::u2h(u, inliers.data(), (int)S.I, h, buffer.data());
+        rs::u2h(u, inliers.data(), (int)S.I, h, nullptr);
         d = L.errs[0];
         errfn(u, h, d, len);
         S.I = 0; S.J = 0;
         for (int j = 0; j < len; j++) { if (d[j] <= th) S.I++; S.J += rs::trunc_quad(d[j], th); }
         break;
       case 2:
-        S = lo_iter(L, inliers.data(), th, 4 * th, 4, h, ++iterID, rbase + 2 * len);
+        S = lo_iter(L, inliers.data(), th, 4 * th, 4, h, ++iterID, rbase ? rbase + 2 * len : nullptr);
         break;
       case 3:
         d = L.errs[0];
         S = inlidxs_v(L, L.errs[4], 4 * th, inliers.data());
-        rs::u2h(u, inliers.data(), (int)S.I, h, buffer.data());
+        rs::u2h(u, inliers.data(), (int)S.I, h, nullptr);
         errfn(u, h, d, len);
         S = inlidxs_v(L, d, th, inliers.data());
         break;
       default: {
-        memcpy(rbase, L.errs[4], len * sizeof(double));
+        if (rbase) memcpy(rbase, L.errs[4], len * sizeof(double));
         d = L.errs[0];
         S = inlidxs_v(L, L.errs[4], 4 * th * 2, inliers.data());   // TC*th*MWM
-        rs::u2h(u, inliers.data(), (int)S.I, h, buffer.data());
+        rs::u2h(u, inliers.data(), (int)S.I, h, nullptr);
         errfn(u, h, d, len);
         S = inlidxs_v(L, d, th, inliers.data());
-        memcpy(rbase + len, d, len * sizeof(double));
-        S = lo_inner(L, inliers.data(), (int)S.I, th, h, 10, &iterID, rbase + 2 * len);
+        if (rbase) memcpy(rbase + len, d, len * sizeof(double));
+        S = lo_inner(L, inliers.data(), (int)S.I, th, h, 10, &iterID, rbase ? rbase + 2 * len : nullptr);
         break;
       }
     }
@@ -632,9 +648,12 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
   // ---- main loop, batched ---------------------------------------------------------------------------
   struct Sample { unsigned seed_before; int idx[4]; int valid; double h[9]; };
   std::vector<Sample> batch;
-  std::vector<double> Z((size_t)len * 18);
-  rs::lin_hg(u, Z.data(), pool.data(), len);
-  int batch_size = 64;
+  // (the reference samples rows of the 2len x 9 design matrix lin_hg made of all correspondences, exp_ranH.c:849, rtools.c:127-151;
+  // the two rows of a sampled correspondence are written from its coordinates instead - the same products, Htools.c:19-58 - so the
+  // 18 len doubles are neither filled nor read)
+  // batches: 8 samples first - a pair with many inliers stops after three to five -, then 64, 128, ... as before; the samples and
+  // their order do not depend on the batching
+  int batch_size = 8;
   bool bad_model = false;
   while (no_sam < max_sam) {
     int want = batch_size;
@@ -654,10 +673,14 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
         const int q = pool[s];
         pool[s] = pool[j];
         pool[j] = q;
-        for (int c = 0; c < 9; c++) {
-          M[(2 * i) * 9 + c] = Z[(size_t)c * 2 * len + 2 * q];
-          M[(2 * i + 1) * 9 + c] = Z[(size_t)c * 2 * len + 2 * q + 1];
-        }
+        const double *sq = u + 6 * (size_t)q;
+        double *r0 = M + (2 * i) * 9, *r1 = r0 + 9;
+        r0[0] = sq[3]; r0[3] = sq[4]; r0[6] = sq[5];
+        r0[1] = 0; r0[4] = 0; r0[7] = 0;
+        r0[2] = -sq[0] * sq[3]; r0[5] = -sq[0] * sq[4]; r0[8] = -sq[0] * sq[5];
+        r1[0] = 0; r1[3] = 0; r1[6] = 0;
+        r1[1] = sq[3]; r1[4] = sq[4]; r1[7] = sq[5];
+        r1[2] = -sq[1] * sq[3]; r1[5] = -sq[1] * sq[4]; r1[8] = -sq[1] * sq[5];
       }
       seed = (unsigned)rng.next();                  // seed = rand()
       for (int i = 0; i < 4; i++) sm.idx[i] = pool[len - 4 + i];
@@ -753,7 +776,7 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
       for (int i = 0; i < 5; i++) (void)rng.next();
       break;
     }
-    if (batch_size < 1024) batch_size *= 2;
+    batch_size = batch_size < 64 ? 64 : (batch_size < 1024 ? batch_size * 2 : batch_size);
   }
   // "If there were no LOs, do at least one NOW!", exp_ranH.c:1085-1197
   if (iter_cnt == 0 && iter_type != 0) {

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include "ransac_simd.hpp"
 
 namespace mods {
 namespace rs {
@@ -380,7 +381,28 @@ static inline void denormH(double *F, const double *A1, const double *A2) {
 //   sum b_j b_k (entries (3j,3k) and (3j+1,3k+1)),  sum b_j c_k,  sum b_j d_k,  sum (c_j c_k then d_j d_k),  or exactly +0.
 // Same additions in the same order per entry as the reference; 36 products per correspondence instead of 90, no 2len x 9
 // buffer.
+// sums: bb[6] | cd[6] | bc[9] | bd[9]
+static inline void cov_hgN_unfold(const double *sums, double *Cv) {
+  const double *bb = sums, *cd = sums + 6, *bc = sums + 12, *bd = sums + 21;
+  auto tri = [](int j, int k) { return j >= k ? j * (j + 1) / 2 + k : k * (k + 1) / 2 + j; };
+  for (int i = 0; i < 9; i++)
+    for (int q = 0; q <= i; q++) {
+      const int j = i / 3, al = i % 3, k = q / 3, be = q % 3;
+      double v;
+      if (al == 2 && be == 2) v = cd[tri(j, k)];
+      else if (al == 2) v = be == 0 ? bc[3 * k + j] : bd[3 * k + j];
+      else if (be == 2) v = al == 0 ? bc[3 * j + k] : bd[3 * j + k];
+      else v = al == be ? bb[tri(j, k)] : 0.0;
+      Cv[9 * i + q] = v; Cv[i + 9 * q] = v;
+    }
+}
+// through the host SIMD table (ransac_simd.inc: cov_hg_all - at 8 lanes the 30 sums run side by side in four vectors)
 static inline void cov_hgN(const double *u, const int *inl, int len, const double *A1, const double *A2, double *Cv) {
+  double sums[30];
+  simd_ops()->cov_hg_all(u, inl, len, A1, A2, sums);
+  cov_hgN_unfold(sums, Cv);
+}
+static inline void cov_hgN_scalar(const double *u, const int *inl, int len, const double *A1, const double *A2, double *Cv) {
   double bb[6] = {0, 0, 0, 0, 0, 0}, bc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, cd[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < len; i++) {
     const double *s = u + 6 * inl[i];

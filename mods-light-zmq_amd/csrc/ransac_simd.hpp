@@ -11,6 +11,10 @@ struct SimdOps {
   void (*fds_all)(const double *const *soa, int n_pad, const double *F, int mode, double *p, double *w);
   // the 45 ordered sums of the least-squares F's moment matrix (lower triangle, row-major); w may be null
   void (*cov_fm_all)(const double *u, const int *inl, const double *w, int len, const double *A1, const double *A2, double *acc45);
+  // homography LO step: the 30 ordered sums of the moment matrix, bb[6] | cd[6] | bc[9] | bd[9] (rs::cov_hgN)
+  void (*cov_hg_all)(const double *u, const int *inl, int len, const double *A1, const double *A2, double *sums30);
+  // d1 and d2 of hsym_point, not combined; soa = {x1, y1, x2, y2}
+  void (*hsym_both_all)(const double *const *soa, int n_pad, const double *H1, const double *Hinv, double *d1, double *d2);
 };
 const SimdOps *simd_ops();                 // widest table this CPU runs
 const SimdOps *simd_ops_lanes(int lanes);  // 1, 4 (AVX2) or 8 (AVX-512F); nullptr when the CPU lacks it

@@ -139,6 +139,40 @@ __device__ void blur_setup(int P2, float scale, int ps, int n_tap, float *s_tap,
   __syncthreads();
 }
 
+// Everything blur_setup makes is a function of (P2, ps): scale = (P2 - 2) / ps (region_geom), so the LDS tier reads it from a table
+// with one entry per P2, written by blur_setup itself (bit-identical by construction): round 5 measured the per-region set-up -
+// 41 sequential additions, a sequential tap sum, double-precision exponentials, three barriers - at 15 % of extract_small_kernel's
+// time (EXTRACT_PROF).  Entry layout (floats): taps [0, 32) | seq [32, 96) | cidx (ints) [96, 224).
+constexpr int BT_ENTRY = 256, BT_TAP = 0, BT_SEQ = 32, BT_CIDX = 96;
+__global__ __launch_bounds__(256) void blur_table_kernel(int ps, float *__restrict__ table) {
+  __shared__ float s_tap[32];
+  __shared__ float s_seq[64];
+  __shared__ int s_cidx[128];
+  __shared__ double s_red[2];
+  const int P2 = blockIdx.x;
+  if (P2 < 3) return;
+  const float scale = float(P2 - 2) / float(ps);              // region_geom: g.scale = float(P) / float(ps), P2 = P + 2
+  const int n_tap = ((int)(2.0 * 3.0 * (1.5f * scale) + 1.0)) | 1;
+  if (n_tap > 31) return;                                     // (not reached for P2 <= SMALL_CAP and the patch sizes this tier takes)
+  blur_setup(P2, scale, ps, n_tap, s_tap, s_seq, s_cidx, s_red);
+  float *e = table + (size_t)P2 * BT_ENTRY;
+  const int t = threadIdx.x;
+  if (t < 32) e[BT_TAP + t] = t < n_tap ? s_tap[t] : 0.f;
+  if (t >= 64 && t < 64 + ps) e[BT_SEQ + (t - 64)] = s_seq[t - 64];
+  if (t >= 128 && t < 128 + 2 * ps && t - 128 < 128) ((int *)e)[BT_CIDX + (t - 128)] = s_cidx[t - 128];
+}
+// (re)built on the context's stream when the patch size of the extraction changes: stream-ordered behind the launches that read the
+// previous table
+int launch_blur_table(mods_ctx *ctx, int ps) {
+  if (ctx->blur_table_ps == ps && ctx->blur_table_dev) return MODS_OK;
+  if (!ctx->blur_table_dev) MODS_HIP_CHECK(hipMalloc(&ctx->blur_table_dev, sizeof(float) * (SMALL_CAP + 1) * BT_ENTRY));
+  ctx->dd_prev = mods_ctx::DdKey();      // (device state changes: the next detect + describe call is not a repeat - capi.hip: dd_run)
+  hipLaunchKernelGGL(blur_table_kernel, dim3(SMALL_CAP + 1), dim3(256), 0, ctx->stream, ps, ctx->blur_table_dev);
+  MODS_HIP_CHECK(hipGetLastError());
+  ctx->blur_table_ps = ps;
+  return MODS_OK;
+}
+
 // row stride of the row-pass strip T (2 * ps columns, padded so that two adjacent column pairs are one aligned float4)
 __host__ __device__ __forceinline__ int t_stride(int ps) { return (2 * ps + 3) & ~3; }
 
@@ -369,7 +403,7 @@ __device__ __forceinline__ void col_resample(const float *T, int P2, int ps, int
 __global__ __launch_bounds__(256, ES_MINB) void extract_small_kernel(const float *__restrict__ img_all, DescConst k,
                                                             const mods_region *__restrict__ reg_all, const int *__restrict__ items,
                                                             const int *__restrict__ n_items_dev, int items_cap,
-                                                            float *__restrict__ patches) {
+                                                            float *__restrict__ patches, const float *__restrict__ blur_table) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ps = k.desc_ps, pp = ps * ps, ps2 = 2 * ps;
   const int cap = k.p2_hi > 4 ? k.p2_hi : 4;       // (the direct branch writes to the patch store, not to LDS)
@@ -400,7 +434,14 @@ __global__ __launch_bounds__(256, ES_MINB) void extract_small_kernel(const float
       sample_tiles(img, k.w, k.h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, g.P2, threadIdx.x >> 6, 4,
                    [&](int row, int col, float v) { s_S[col * stride + row] = v; });   // transposed: see row_pass_t
       PROF_MARK(1)
-      blur_setup(g.P2, g.scale, ps, n_tap, s_tap, s_seq, s_cidx, s_red);
+      if (blur_table && n_tap <= 31 && ps <= 63) {     // taps, resampling sequence and source indices of this P2 from the table
+        const float *e = blur_table + (size_t)g.P2 * BT_ENTRY;
+        const int t = threadIdx.x;
+        if (t < 32) s_tap[t] = e[BT_TAP + t];
+        if (t >= 64 && t < 64 + ps) s_seq[t - 64] = e[BT_SEQ + (t - 64)];
+        if (t >= 128 && t < 128 + 2 * ps && t - 128 < 128) s_cidx[t - 128] = ((const int *)e)[BT_CIDX + (t - 128)];
+        __syncthreads();
+      } else blur_setup(g.P2, g.scale, ps, n_tap, s_tap, s_seq, s_cidx, s_red);
       PROF_MARK(2)
       row_pass_t(s_S, s_T, g.P2, stride, ps, n_tap, s_tap, s_cidx);
       __syncthreads();
@@ -1558,6 +1599,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   int *small_items = (int *)(fitems + max_items);
   float *pool = ctx->desc_scratch + patch_elems + book_elems;
   MODS_HIP_CHECK(hipMemsetAsync(bl, 0, sizeof(BigLists), ctx->stream));
+  { const int trc = launch_blur_table(ctx, ps); if (trc) return trc; }
   k.tap_cap = 4096;
   const int small_cap = SMALL_CAP;   // P2 limit of the LDS tier
   k.p2_hi = small_cap;
@@ -1575,7 +1617,8 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
       const size_t capS = kt.p2_hi > 4 ? kt.p2_hi : 4;
       const size_t ldsS = sizeof(float) * (capS * ((capS + 3) & ~(size_t)3) + capS * t_stride(ps) + 2 * ps2 + 32) + 32;
       hipLaunchKernelGGL(extract_small_kernel, dim3(4096), dim3(256), ldsS, ctx->stream, img_dev, kt, ctx->regions_dev,
-                         small_items + (size_t)t * small_cap_items, &bl->n_small[t], small_cap_items, patches);
+                         small_items + (size_t)t * small_cap_items, &bl->n_small[t], small_cap_items, patches,
+                         (const float *)ctx->blur_table_dev);
     }
   }
   const size_t ldsH = sizeof(float) * (k.tap_cap + 4 * ps2) + 32;

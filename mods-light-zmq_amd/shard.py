@@ -134,10 +134,17 @@ def match_ladder_distributed(pkg, ctx, img_ptr, w, h, steps, dist, device, param
             areas.append(float(g.w_new * g.h_new))
         mine = largest_first_views(areas, world)[rank]
         local = {}
+        # a step whose descriptor list names a Half* descriptor runs the orientation of every view in doHalfSIFT mode
+        # (imagerepresentation.cpp:725-731; csrc/imgrep.hip does the same for the one-GPU ladder).  HalfRootSIFT LISTS
+        # (fginn_ratio_half > 0) are the C++ form's business (mods_match_ladder_groups_multi), not this harness's.
+        if step.fginn_ratio_half > 0:
+            raise ValueError("match_ladder_distributed: HalfRootSIFT lists are not supported by the Python harness")
+        desc = type(params.desc).from_buffer_copy(params.desc)
+        desc.ori_halfMode = 1 if step.half_orientation else 0
         for j in mine:
             im, (zoom, tilt, phi) = jobs[j]
             _, _, nr = ctx.detect_describe_view_dev(img_ptr + im * plane_bytes, w, h, tilt, phi, zoom, step.initSigma, step.doBlur,
-                                                    params.det, params.desc)
+                                                    params.det, desc)
             blk = torch.empty(nr * REGION_BYTES, dtype=torch.uint8, device=device)
             if nr:
                 ctx.regions_copy_dev(0, blk.data_ptr(), nr)

@@ -190,3 +190,66 @@ def test_moment_matrix_across_vector_lanes_bitexact(pkg, n, weighted):
         ran += 1
         assert np.array_equal(out.view(np.uint64), ref.view(np.uint64)), lanes
     assert ran >= 1
+
+
+@pytest.mark.parametrize("n", [5, 12, 13, 200, 5000])
+def test_moment_sums_at_every_lane_count(pkg, n):
+    """the 30 folded sums through the SIMD table (8 lanes: four vectors of running sums) = the scalar folded sums = lin_hgN + cov_mat"""
+    M = pkg.lib()
+    u, _ = _points(6000, 17)
+    g = np.random.default_rng(100 + n)
+    inl = np.ascontiguousarray(g.permutation(6000)[:n].astype(np.int32))
+    want = np.zeros(81)
+    assert M.mods_test_host_cov(P(u), P(inl), n, 1, P(want)) == 0
+    ran = 0
+    for form in (0, 2, 101, 104, 108):
+        got = np.full(81, -1.0)
+        if M.mods_test_host_cov(P(u), P(inl), n, form, P(got)) != 0:
+            assert form >= 100      # this CPU lacks the width
+            continue
+        ran += 1
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), form
+    assert ran >= 3
+
+
+def _frames(u, seed):
+    """14 doubles per correspondence as H_LAF_check reads them (matching.cpp:250-308): x, y, a11, a12, a21, a22, s per image"""
+    g = np.random.default_rng(seed)
+    n = len(u)
+    laf = np.zeros((n, 14))
+    for base, cols in ((0, (0, 1)), (7, (3, 4))):
+        laf[:, base:base + 2] = u[:, cols]
+        A = np.eye(2) + g.normal(0, 0.25, (n, 2, 2))
+        laf[:, base + 2:base + 6] = A.reshape(n, 4)
+        laf[:, base + 6] = g.uniform(1.5, 30.0, n)
+    return np.ascontiguousarray(laf)
+
+
+@pytest.mark.parametrize("n,outliers,coef", [(9, 0.0, 12.0), (40, 0.3, 12.0), (1003, 0.3, 12.0), (6001, 0.5, 3.0), (300, 0.3, 0.0), (64, 0.95, 12.0)])
+def test_checks_behind_the_homography_lanes_wide(pkg, n, outliers, coef):
+    """NaiveHCheck + H_LAF_check over structure-of-arrays copies of the inliers keep exactly the scalar statement's survivors"""
+    M = pkg.lib()
+    M.mods_test_host_hchecks.restype = C.c_int
+    u, h = _points(n, 31 + n, outliers=outliers)
+    laf = _frames(u, n)
+    err = np.zeros(n)
+    assert M.mods_test_host_errfn(0, P(u), n, P(h), 0, P(err)) == 0
+    inl = np.ascontiguousarray((err <= 16.0).astype(np.uint8))
+    par = pkg.RansacParams.default()
+    par.HLAFCoef = coef
+    want_mask, want_H = np.zeros(n, np.uint8), np.zeros(9)
+    want_n = M.mods_test_host_hchecks(P(u), P(laf), n, P(inl), P(h), C.byref(par), 0, P(want_mask), P(want_H))
+    assert want_n >= 0 and want_n == int(want_mask.sum())
+    if outliers < 0.9 and n >= 40:
+        assert 8 <= want_n <= int(inl.sum())
+        if 0 < coef < 12:
+            assert want_n < int(inl.sum())       # the frame check does reject something here
+    ran = 0
+    for lanes in LANES:
+        mask, H = np.full(n, 7, np.uint8), np.zeros(9)
+        got = M.mods_test_host_hchecks(P(u), P(laf), n, P(inl), P(h), C.byref(par), lanes, P(mask), P(H))
+        if got < 0:
+            continue
+        ran += 1
+        assert got == want_n and np.array_equal(mask, want_mask) and np.array_equal(H.view(np.uint64), want_H.view(np.uint64)), lanes
+    assert ran >= 1

@@ -41,7 +41,8 @@ WORKER = textwrap.dedent('''
     d = pkg.view_ctx_dims(w, h)
     ctx = pkg.Context(dev, d[0], d[1], 1)
     pkg.lib().mods_ransac_set_device(dev)
-    steps = [pkg.LadderStep.make(tl, ph) for tl, ph in (((1,), 360.0), ((1, 2, 4), 360.0), ((1, 2, 4), 120.0))]
+    # (the last two steps run the orientation in doHalfSIFT mode, as the HessianAffine steps of iters_MODS.ini do)
+    steps = [pkg.LadderStep.make(tl, ph, half_orientation=ho) for tl, ph, ho in (((1,), 360.0, 0), ((1, 2, 4), 360.0, 1), ((1, 2, 4), 120.0, 1))]
     got = shard.match_ladder_distributed(pkg, ctx, t.data_ptr(), w, h, steps, dist, "cuda:" + str(dev), seed_time=31)
     if rank == 0:
         rep1, rep2 = pkg.ImgRep(ctx), pkg.ImgRep(ctx)
