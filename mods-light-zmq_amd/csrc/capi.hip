@@ -834,10 +834,16 @@ static int h_post_checks(const double *u6, const double *laf, int n, const unsig
 // H -> row-major img1->img2 by inv(H^T), NaiveHCheck (10 px, :1014-1043), H_LAF_check (:250-308).
 // mask[i] = 1 for the correspondences that survive every check.
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// clock of the MODS_RANSAC_PROF lines: wall time, or the calling thread's CPU time with MODS_RANSAC_PROF=cpu (ransac.hip: rs_now_us)
+static double prof_ms() {
+  static const bool cpu = getenv("MODS_RANSAC_PROF") && !strcmp(getenv("MODS_RANSAC_PROF"), "cpu");
+  if (cpu) { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+  return now_ms();
+}
 
 int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransac_params *par, unsigned char *mask, double *H_out,
                     int *n_inliers, int *stats3) {
-  const double t_enter = now_ms();
+  const double t_enter = prof_ms();
   if (!par || !mask || !H_out || !n_inliers || (n > 0 && !u6)) { set_error("loransac_h: null argument"); return MODS_E_ARG; }
   *n_inliers = 0;
   for (int i = 0; i < 9; i++) H_out[i] = -1;   // TentativeCorrespListExt(): H[i] = -1 (matching.hpp:92-99)
@@ -860,10 +866,10 @@ int mods_loransac_h(const double *u6, const double *laf, int n, const mods_ransa
   exp_ransacHcustom(u2.data(), n, par->err_threshold * par->err_threshold, par->confidence, max_samples, Hloran, inl2.data(), 4,
                     data_out.data(), 1, 0, nullptr, f0, f1, f2, par->doSymmCheck);   // (no residual rows: nobody reads them here)
   if (mods::ransac_failed()) return MODS_E_HIP;   // device failure inside the control loop; mods_last_error() says which
-  const double t_post0 = now_ms();
+  const double t_post0 = prof_ms();
   if (stats3) { stats3[0] = data_out[0]; stats3[1] = data_out[1]; stats3[2] = data_out[2]; }
   *n_inliers = h_post_checks(u6, laf, n, inl2.data(), Hloran, par, mods::rs::simd_ops(), mask, H_out);
-  if (ransac_profile_on()) fprintf(stderr, "loransac_h prof: whole %.0f us, checks after RANSAC %.0f us\n", 1e3 * (now_ms() - t_enter), 1e3 * (now_ms() - t_post0));
+  if (ransac_profile_on()) fprintf(stderr, "loransac_h prof: whole %.0f us, checks after RANSAC %.0f us\n", 1e3 * (prof_ms() - t_enter), 1e3 * (prof_ms() - t_post0));
   return MODS_OK;
 }
 

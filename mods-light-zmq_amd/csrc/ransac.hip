@@ -322,7 +322,11 @@ struct RsProf { double us[8]; };   // 0 hypotheses, 1 gpu_score, 2 fetch_row, 3 
 static thread_local RsProf g_rsprof;
 bool ransac_profile_on() { static const bool on = getenv("MODS_RANSAC_PROF") != nullptr; return on; }
 static int rsprof_on() { return ransac_profile_on() ? 1 : 0; }
-static inline double rs_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+// MODS_RANSAC_PROF=cpu: the phases in the calling thread's CPU time (a sleeping wait costs none) instead of wall time
+static inline double rs_now_us() {
+  static const bool cpu = getenv("MODS_RANSAC_PROF") && !strcmp(getenv("MODS_RANSAC_PROF"), "cpu");
+  timespec ts; clock_gettime(cpu ? CLOCK_THREAD_CPUTIME_ID : CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
 struct RsTimer {
   int slot; double t0;
   explicit RsTimer(int s) : slot(s), t0(rsprof_on() ? rs_now_us() : 0) {}
@@ -358,10 +362,26 @@ static rs::Score inlidxs_v(const LoState &L, const double *err, double th, int *
   L.pts->ops->gains_all(err, L.pts->n_pad, th * 9 / 4, g);
   rs::Score s = {0, 0};
   const int len = L.len;
+  unsigned n = 0;
   for (int i = 0; i < len; ++i) {
     s.J += g[i];
-    if (err[i] <= th) { inl[s.I] = i; ++(s.I); }
+    inl[n] = i;                       // (written unconditionally, kept when the test holds: no branch on the data)
+    n += err[i] <= th ? 1u : 0u;
   }
+  s.I = n;
+  return s;
+}
+// the same where the caller reads the count and the list only (the wide-threshold sets the least-squares steps are fed with,
+// exp_ranH.c:650, 673, 1046, 1050): the sum - a serial chain of len additions behind len divisions - is not formed, J stays 0
+static rs::Score inlidxs_list(const LoState &L, const double *err, double th, int *inl) {
+  rs::Score s = {0, 0};
+  const int len = L.len;
+  unsigned n = 0;
+  for (int i = 0; i < len; ++i) {
+    inl[n] = i;
+    n += err[i] <= th ? 1u : 0u;
+  }
+  s.I = n;
   return s;
 }
 
@@ -386,7 +406,7 @@ static Score lo_iter(LoState &L, int *inliers, double th, double ths, int steps,
   };
   maxS = inlidxs_v(L, L.errs[4], th, inliers);
   if (maxS.I < 4) return S;
-  S = inlidxs_v(L, L.errs[4], th * 2, inliers);   // th*MWM, MWM = (9/4) = 2 (rtools.h:33)
+  S = inlidxs_list(L, L.errs[4], th * 2, inliers);   // th*MWM, MWM = (9/4) = 2 (rtools.h:33); only S.I and the list are read
   lsq(S);
   for (int it = 0; it < steps; it++) {
     L.errfn(L.u, h, d, len);
@@ -396,7 +416,7 @@ static Score lo_iter(LoState &L, int *inliers, double th, double ths, int steps,
     const int ret = L.ht->contains(hash, (int)Ss.I, iterID);
     if (ret != -1 && ret != iterID) { S.I = 0; S.J = 0; return S; }
     if (ret == -1) L.ht->insert(hash, (int)Ss.I, iterID);
-    S = inlidxs_v(L, d, ths * 2, inliers);
+    S = inlidxs_list(L, d, ths * 2, inliers);
     if (rs::score_less(maxS, Ss)) {
       maxS = Ss;
       L.errs[1] = L.errs[0];
@@ -623,10 +643,10 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
       default: {
         if (rbase) memcpy(rbase, L.errs[4], len * sizeof(double));
         d = L.errs[0];
-        S = inlidxs_v(L, L.errs[4], 4 * th * 2, inliers.data());   // TC*th*MWM
+        S = inlidxs_list(L, L.errs[4], 4 * th * 2, inliers.data());   // TC*th*MWM
         rs::u2h(u, inliers.data(), (int)S.I, h, nullptr);
         errfn(u, h, d, len);
-        S = inlidxs_v(L, d, th, inliers.data());
+        S = inlidxs_list(L, d, th, inliers.data());   // (lo_inner takes the count; what it returns replaces S)
         if (rbase) memcpy(rbase + len, d, len * sizeof(double));
         S = lo_inner(L, inliers.data(), (int)S.I, th, h, 10, &iterID, rbase ? rbase + 2 * len : nullptr);
         break;
