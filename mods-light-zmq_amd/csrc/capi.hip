@@ -836,8 +836,7 @@ static int h_post_checks(const double *u6, const double *laf, int n, const unsig
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // clock of the MODS_RANSAC_PROF lines: wall time, or the calling thread's CPU time with MODS_RANSAC_PROF=cpu (ransac.hip: rs_now_us)
 static double prof_ms() {
-  static const bool cpu = getenv("MODS_RANSAC_PROF") && !strcmp(getenv("MODS_RANSAC_PROF"), "cpu");
-  if (cpu) { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+  if (ransac_profile_mode() == 2) { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
   return now_ms();
 }
 

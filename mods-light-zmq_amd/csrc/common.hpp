@@ -263,7 +263,8 @@ int dup_filter_dev(mods_ctx *c, const DupJob *jobs, int n_jobs, int grid_n, doub
 int dup_filter_reserve(mods_ctx *c, int n_jobs);
 int launch_fast_sqrt_selftest(mods_ctx *ctx, unsigned long long *out5_host);   // describe.hip
 int launch_blur_table(mods_ctx *ctx, int ps);   // sift.hip
-bool ransac_profile_on();            // MODS_RANSAC_PROF: per-call breakdown of the verification on stderr (ransac.hip)
+bool ransac_profile_on();     // MODS_RANSAC_PROF: per-call breakdown of the verification on stderr (ransac.hip)
+int ransac_profile_mode();    // 0 off, 1 wall time, 2 the calling thread's CPU time (MODS_RANSAC_PROF=cpu)
 
 // describe.hip
 int describe_run(mods_ctx *ctx, const float *img_dev, int n_img, int w, int h, const mods_describe_params *par);

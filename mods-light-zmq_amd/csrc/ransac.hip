@@ -320,12 +320,12 @@ namespace mods {
 // MODS_RANSAC_PROF=1: per-call breakdown of the verification on stderr (development aid)
 struct RsProf { double us[8]; };   // 0 hypotheses, 1 gpu_score, 2 fetch_row, 3 LO u2h, 4 LO error function, 5 LO, 6 upload, 7 whole call
 static thread_local RsProf g_rsprof;
-bool ransac_profile_on() { static const bool on = getenv("MODS_RANSAC_PROF") != nullptr; return on; }
+// MODS_RANSAC_PROF: 0 = off, 1 = phase times on stderr in wall time, 2 ("cpu") = in the calling thread's CPU time (a sleeping wait costs none)
+int ransac_profile_mode() { static const int mode = [] { const char *e = getenv("MODS_RANSAC_PROF"); return !e ? 0 : (!strcmp(e, "cpu") ? 2 : 1); }(); return mode; }
+bool ransac_profile_on() { return ransac_profile_mode() != 0; }
 static int rsprof_on() { return ransac_profile_on() ? 1 : 0; }
-// MODS_RANSAC_PROF=cpu: the phases in the calling thread's CPU time (a sleeping wait costs none) instead of wall time
 static inline double rs_now_us() {
-  static const bool cpu = getenv("MODS_RANSAC_PROF") && !strcmp(getenv("MODS_RANSAC_PROF"), "cpu");
-  timespec ts; clock_gettime(cpu ? CLOCK_THREAD_CPUTIME_ID : CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+  timespec ts; clock_gettime(ransac_profile_mode() == 2 ? CLOCK_THREAD_CPUTIME_ID : CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 struct RsTimer {
   int slot; double t0;
