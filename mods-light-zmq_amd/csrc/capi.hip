@@ -39,6 +39,25 @@ hipError_t stream_wait(hipStream_t s) {
   return e;
 }
 
+hipError_t copy_wait(hipStream_t s, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  if (!bytes) return hipSuccess;
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+  return e != hipSuccess ? e : stream_wait(s);
+}
+hipError_t fill_wait(hipStream_t s, void *dst, int value, size_t bytes) {
+  if (!bytes) return hipSuccess;
+  const hipError_t e = hipMemsetAsync(dst, value, bytes, s);
+  return e != hipSuccess ? e : stream_wait(s);
+}
+hipStream_t thread_stream() {
+  struct PerThread { hipStream_t s[16] = {}; ~PerThread() { for (hipStream_t q : s) if (q) (void)hipStreamDestroy(q); } };
+  static thread_local PerThread t;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;     // (nullptr = the legacy stream: what the call used before)
+  if (!t.s[dev] && hipStreamCreateWithFlags(&t.s[dev], hipStreamNonBlocking) != hipSuccess) t.s[dev] = nullptr;
+  return t.s[dev];
+}
+
 void wait_mode_for_worker(long default_sleep_ns) {
   long ns = default_sleep_ns;
   if (const char *m = getenv("MODS_SYNC")) {
@@ -135,7 +154,7 @@ static int ctx_create_impl(int device, int max_w, int max_h, int batch, unsigned
   MODS_HIP_CHECK(hipMalloc(&c->regions_dev, sizeof(mods_region) * mc * batch));
   MODS_HIP_CHECK(hipMalloc(&c->region_count, sizeof(int) * 3 * batch));   // regions, then 2 tier counts per image
   MODS_HIP_CHECK(hipMalloc(&c->inside_count, sizeof(int) * batch));
-  MODS_HIP_CHECK(hipMemset(c->inside_count, 0, sizeof(int) * batch));
+  MODS_HIP_CHECK(mods::fill_wait(c->stream, c->inside_count, 0, sizeof(int) * batch));
   *out = c;
   return MODS_OK;
 }
@@ -232,7 +251,7 @@ static int detect_common(mods_ctx *c, const float *img_dev, int n_img, int w, in
     n_out_host[b] = n;
     if (out_host) {
       if (n > max_out) { set_error("keypoint output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
-      MODS_HIP_CHECK(hipMemcpy(out_host + (size_t)b * max_out, c->keys_dev + (size_t)b * c->max_cand, sizeof(mods_affkey) * n, hipMemcpyDeviceToHost));
+      MODS_HIP_CHECK(mods::copy_wait(c->stream, out_host + (size_t)b * max_out, c->keys_dev + (size_t)b * c->max_cand, sizeof(mods_affkey) * n, hipMemcpyDeviceToHost));
     }
   }
   return MODS_OK;
@@ -264,17 +283,17 @@ int mods_pyramid_plane(mods_ctx *c, int img, int o, int level, int kind, float *
   const OctaveDev &oc = c->pyr.oct[o];
   const float *p = (kind ? oc.resp[level] : oc.blur[level]) + (size_t)oc.w * oc.h * img;
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
-  MODS_HIP_CHECK(hipMemcpy(dst, p, sizeof(float) * (size_t)oc.w * oc.h, hipMemcpyDeviceToHost));
+  MODS_HIP_CHECK(mods::copy_wait(c->stream, dst, p, sizeof(float) * (size_t)oc.w * oc.h, hipMemcpyDeviceToHost));
   return MODS_OK;
 }
 // accepted (post-dedup) localisation records of image `img`, in list (arbitrary) order
 int mods_pyramid_candidates(mods_ctx *c, int img, mods_candidate *out, int max_out, int *n_out) {
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
   int count = 0;
-  MODS_HIP_CHECK(hipMemcpy(&count, c->cand_count + img, sizeof(int), hipMemcpyDeviceToHost));
+  MODS_HIP_CHECK(mods::copy_wait(c->stream, &count, c->cand_count + img, sizeof(int), hipMemcpyDeviceToHost));
   int n = std::min(count, c->max_cand);
   std::vector<CandDev> v(n);
-  MODS_HIP_CHECK(hipMemcpy(v.data(), c->cand + (size_t)img * c->max_cand, sizeof(CandDev) * n, hipMemcpyDeviceToHost));
+  MODS_HIP_CHECK(mods::copy_wait(c->stream, v.data(), c->cand + (size_t)img * c->max_cand, sizeof(CandDev) * n, hipMemcpyDeviceToHost));
   // state: 2 accepted (claimed its octaveMap cell), 3 Baumberg converged, 4 Baumberg rejected
   int m = 0;
   for (auto &cd : v) {
@@ -460,10 +479,10 @@ int mods_patches_fetch(mods_ctx *c, int img, int ps, float *out, int max_regions
   MODS_HIP_CHECK(hipSetDevice(c->device));
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
   int n = 0;
-  MODS_HIP_CHECK(hipMemcpy(&n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
+  MODS_HIP_CHECK(mods::copy_wait(c->stream, &n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
   if (n > reg_cap) n = reg_cap;
   if (n > max_regions) { set_error("patch output overflow: %d > %d", n, max_regions); return MODS_E_CAPACITY; }
-  MODS_HIP_CHECK(hipMemcpy(out, c->desc_scratch + (size_t)img * reg_cap * ps * ps, sizeof(float) * (size_t)n * ps * ps, hipMemcpyDeviceToHost));
+  MODS_HIP_CHECK(mods::copy_wait(c->stream, out, c->desc_scratch + (size_t)img * reg_cap * ps * ps, sizeof(float) * (size_t)n * ps * ps, hipMemcpyDeviceToHost));
   *n_out = n;
   return MODS_OK;
 }
@@ -480,11 +499,11 @@ int mods_regions_fetch(mods_ctx *c, int img, mods_region *out, int max_out, int 
   MODS_HIP_CHECK(hipSetDevice(c->device));
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
   int n = 0;
-  MODS_HIP_CHECK(hipMemcpy(&n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
+  MODS_HIP_CHECK(mods::copy_wait(c->stream, &n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
   *n_out = n;
   if (out) {
     if (n > max_out) { set_error("region output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
-    MODS_HIP_CHECK(hipMemcpy(out, c->regions_dev + (size_t)img * c->max_cand, sizeof(mods_region) * n, hipMemcpyDeviceToHost));
+    MODS_HIP_CHECK(mods::copy_wait(c->stream, out, c->regions_dev + (size_t)img * c->max_cand, sizeof(mods_region) * n, hipMemcpyDeviceToHost));
   }
   return MODS_OK;
 }
@@ -495,11 +514,11 @@ int mods_regions_fetch_half(mods_ctx *c, int img, mods_region *out, int max_out,
   MODS_HIP_CHECK(hipSetDevice(c->device));
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
   int n = 0;
-  MODS_HIP_CHECK(hipMemcpy(&n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
+  MODS_HIP_CHECK(mods::copy_wait(c->stream, &n, c->region_count + img, sizeof(int), hipMemcpyDeviceToHost));
   *n_out = n;
   if (out) {
     if (n > max_out) { set_error("region output overflow: %d > %d", n, max_out); return MODS_E_CAPACITY; }
-    MODS_HIP_CHECK(hipMemcpy(out, c->regions_half_dev + (size_t)img * c->max_cand, sizeof(mods_region) * n, hipMemcpyDeviceToHost));
+    MODS_HIP_CHECK(mods::copy_wait(c->stream, out, c->regions_half_dev + (size_t)img * c->max_cand, sizeof(mods_region) * n, hipMemcpyDeviceToHost));
   }
   return MODS_OK;
 }
@@ -950,7 +969,7 @@ int mods_duplicate_filter_gpu(mods_ctx *c, mods_tentative *tent, double *u6, dou
   memcpy(stage.data() + tent_u6_off(n), u6, sizeof(double) * 6 * n);
   memcpy(stage.data() + tent_laf_off(n), laf, sizeof(double) * 14 * n);
   MODS_HIP_CHECK(mods::stream_wait(c->stream));
-  MODS_HIP_CHECK(hipMemcpy(c->m_tent, stage.data(), stage.size(), hipMemcpyHostToDevice));
+  MODS_HIP_CHECK(mods::copy_wait(c->stream, c->m_tent, stage.data(), stage.size(), hipMemcpyHostToDevice));
   c->m_count[0] = n;
   const DupJob job = {(const char *)c->m_tent, (char *)c->m_tent2, c->m_count, c->m_count + 64, c->m_count + 128};
   if ((rc = dup_filter_dev(c, &job, 1, n, r, mode))) return rc;
@@ -958,7 +977,7 @@ int mods_duplicate_filter_gpu(mods_ctx *c, mods_tentative *tent, double *u6, dou
   if (((volatile int *)c->m_count)[128] != 0) return mods_duplicate_filter(tent, u6, laf, n, r, mode, n_out);
   const int m = ((volatile int *)c->m_count)[64];
   if (m > 0) {
-    MODS_HIP_CHECK(hipMemcpy(stage.data(), c->m_tent2, tent_bytes((size_t)m), hipMemcpyDeviceToHost));
+    MODS_HIP_CHECK(mods::copy_wait(c->stream, stage.data(), c->m_tent2, tent_bytes((size_t)m), hipMemcpyDeviceToHost));
     memcpy(tent, stage.data(), sizeof(mods_tentative) * m);
     memcpy(u6, stage.data() + tent_u6_off(m), sizeof(double) * 6 * m);
     memcpy(laf, stage.data() + tent_laf_off(m), sizeof(double) * 14 * m);
@@ -1047,7 +1066,7 @@ int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_pair_params
     for (int x = 0; x < w; x++)
       img[(size_t)y * w + x] = 128.f + 70.f * sinf(f1 * x) * sinf(f1 * y) + 50.f * sinf(f2 * x + 1.f) * sinf(f2 * y);
   const size_t plane = (size_t)w * h;
-  MODS_HIP_CHECK(hipMemcpy(c->input_dev, img.data(), sizeof(float) * plane, hipMemcpyHostToDevice));
+  MODS_HIP_CHECK(mods::copy_wait(c->stream, c->input_dev, img.data(), sizeof(float) * plane, hipMemcpyHostToDevice));
   for (int i = 1; i < n_img; i++)
     MODS_HIP_CHECK(hipMemcpyAsync(c->input_dev + plane * i, c->input_dev, sizeof(float) * plane, hipMemcpyDeviceToDevice, c->stream));
   std::vector<int> nd(n_img), nr(n_img);
@@ -1181,7 +1200,7 @@ int mods_pairs_gpu_stage(mods_ctx *c, const void *const *img, const int *kinds, 
         copies = true;
       } else {      // a list that does not fit the arena: the direct (pageable, synchronous) path
         std::vector<char> stage(bytes);
-        MODS_HIP_CHECK(hipMemcpy(stage.data(), list, bytes, hipMemcpyDeviceToHost));
+        MODS_HIP_CHECK(mods::copy_wait(c->stream, stage.data(), list, bytes, hipMemcpyDeviceToHost));
         memcpy(tent[i]->data(), stage.data(), sizeof(mods_tentative) * n);
         memcpy(u6[i]->data(), stage.data() + tent_u6_off(n), sizeof(double) * 6 * n);
         memcpy(laf[i]->data(), stage.data() + tent_laf_off(n), sizeof(double) * 14 * n);

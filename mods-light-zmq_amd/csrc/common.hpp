@@ -41,6 +41,12 @@ inline hipError_t dyn_lds_once(DynLdsOnce &site, const void *fn, int bytes, int 
 inline thread_local long tl_wait_sleep_ns = 0;
 inline thread_local int tl_wait_spin_polls = 8;
 hipError_t stream_wait(hipStream_t s);
+// hipMemcpy / hipMemset that wait, on a stream of the library instead of the legacy stream: an operation on the legacy stream waits
+// for every blocking stream of the process and is REFUSED (hipErrorStreamCaptureImplicit) while another thread records a stream
+// (mods_ctx_graphs: a pipeline worker recording its launch chain) - seen once as a failed workspace growth of a verify thread
+hipError_t copy_wait(hipStream_t s, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+hipError_t fill_wait(hipStream_t s, void *dst, int value, size_t bytes);
+hipStream_t thread_stream();   // a non-blocking stream of the calling thread on the current device (entry points without a context)
 void wait_mode_for_worker(long default_sleep_ns);   // MODS_SYNC=spin|sleep[:us] decides for the pipeline's threads
 
 constexpr int kMaxOctaves = 16;

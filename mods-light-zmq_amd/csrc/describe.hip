@@ -523,17 +523,17 @@ int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
     build_sift_tab(par->desc_patchSize, &tab);
     ctx->dd_prev = mods_ctx::DdKey();     // (device tables change: the next detect + describe call is not a repeat - capi.hip: dd_run)
     MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
-    MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev, m1.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
-    MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + kTabDescMask, m2.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
+    MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->desc_tables_dev, m1.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
+    MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->desc_tables_dev + kTabDescMask, m2.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
     // the orientation mask as the vote loop of dominant_angle_wave reads it: entry p = the mask of pixel (1 + p / ps, p % ps), i.e.
     // of patch index p + ps, and 0 in the first and the last column, where EstimateDominantAnglesFunctor computes no gradient
     {
       const int ps = par->ori_patchSize;
       std::vector<float> vm((size_t)64 * 64, 0.f);
       for (int p = 0; p < ps * (ps - 2); p++) { const int c = p % ps; vm[p] = (c >= 1 && c < ps - 1) ? m1[p + ps] : 0.f; }
-      MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + kTabVoteMask, vm.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
+      MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->desc_tables_dev + kTabVoteMask, vm.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
     }
-    MODS_HIP_CHECK(hipMemcpy(ctx->desc_tables_dev + kTabSift, &tab, sizeof(SiftTab), hipMemcpyHostToDevice));
+    MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->desc_tables_dev + kTabSift, &tab, sizeof(SiftTab), hipMemcpyHostToDevice));
     ctx->desc_ori_ps = par->ori_patchSize; ctx->desc_ps = par->desc_patchSize;
   }
   return MODS_OK;
@@ -559,7 +559,7 @@ static int external_describe(mods_ctx *ctx, int n_img, const DescConst &k) {
     const int n = std::min(counts[b], k.reg_cap);
     if (n <= 0) continue;
     patches.resize((size_t)n * pp); out.assign((size_t)n * 128, 0.f); desc.resize((size_t)n * 128);
-    MODS_HIP_CHECK(hipMemcpy(patches.data(), ctx->desc_scratch + (size_t)b * k.reg_cap * pp, sizeof(float) * patches.size(), hipMemcpyDeviceToHost));
+    MODS_HIP_CHECK(mods::copy_wait(ctx->stream, patches.data(), ctx->desc_scratch + (size_t)b * k.reg_cap * pp, sizeof(float) * patches.size(), hipMemcpyDeviceToHost));
     int dim = 0;
     const int rc = ctx->ext_fn(ctx->ext_user, patches.data(), n, k.desc_ps, out.data(), out.size(), &dim);
     if (rc || dim != 128) { set_error("external descriptor failed (rc %d, %d values per patch; 128 expected)", rc, dim); return MODS_E_ARG; }
@@ -601,7 +601,7 @@ static int net_patches(mods_ctx *ctx, const float *img_dev, int n_img, DescConst
   for (int b = 0; b < n_img; b++) {
     (*patches)[b].resize(pp * counts[b]);
     if (counts[b])
-      MODS_HIP_CHECK(hipMemcpy((*patches)[b].data(), ctx->desc_scratch + (size_t)b * k.reg_cap * pp, sizeof(float) * pp * counts[b], hipMemcpyDeviceToHost));
+      MODS_HIP_CHECK(mods::copy_wait(ctx->stream, (*patches)[b].data(), ctx->desc_scratch + (size_t)b * k.reg_cap * pp, sizeof(float) * pp * counts[b], hipMemcpyDeviceToHost));
   }
   return MODS_OK;
 }
@@ -614,7 +614,7 @@ static int fetch_keys(mods_ctx *ctx, int n_img, const int *key_count, std::vecto
   for (int b = 0; b < n_img; b++) {
     const int n = std::min(counts[b], ctx->max_cand);
     (*keys)[b].resize(n);
-    if (n) MODS_HIP_CHECK(hipMemcpy((*keys)[b].data(), ctx->keys_dev + (size_t)b * ctx->max_cand, sizeof(mods_affkey) * n, hipMemcpyDeviceToHost));
+    if (n) MODS_HIP_CHECK(mods::copy_wait(ctx->stream, (*keys)[b].data(), ctx->keys_dev + (size_t)b * ctx->max_cand, sizeof(mods_affkey) * n, hipMemcpyDeviceToHost));
   }
   return MODS_OK;
 }
@@ -670,9 +670,9 @@ static int external_shape(mods_ctx *ctx, const float *img_dev, int n_img, const 
       }
     }
     counts[b] = (int)kept.size();
-    if (counts[b]) MODS_HIP_CHECK(hipMemcpy(ctx->keys_dev + (size_t)b * ctx->max_cand, kept.data(), sizeof(mods_affkey) * counts[b], hipMemcpyHostToDevice));
+    if (counts[b]) MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->keys_dev + (size_t)b * ctx->max_cand, kept.data(), sizeof(mods_affkey) * counts[b], hipMemcpyHostToDevice));
   }
-  MODS_HIP_CHECK(hipMemcpy(key_count, counts.data(), sizeof(int) * n_img, hipMemcpyHostToDevice));
+  MODS_HIP_CHECK(mods::copy_wait(ctx->stream, key_count, counts.data(), sizeof(int) * n_img, hipMemcpyHostToDevice));
   return MODS_OK;
 }
 
@@ -737,10 +737,10 @@ static int external_orientation(mods_ctx *ctx, const float *img_dev, int n_img, 
     }
     counts[b] = (int)kept.size();
     if (counts[b] > k.reg_cap) counts[b] = k.reg_cap;
-    if (counts[b]) MODS_HIP_CHECK(hipMemcpy(ctx->regions_dev + (size_t)b * ctx->max_cand, kept.data(), sizeof(mods_region) * counts[b], hipMemcpyHostToDevice));
+    if (counts[b]) MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->regions_dev + (size_t)b * ctx->max_cand, kept.data(), sizeof(mods_region) * counts[b], hipMemcpyHostToDevice));
   }
-  MODS_HIP_CHECK(hipMemcpy(ctx->region_count, counts.data(), sizeof(int) * n_img, hipMemcpyHostToDevice));
-  MODS_HIP_CHECK(hipMemcpy(ctx->inside_count, inside.data(), sizeof(int) * n_img, hipMemcpyHostToDevice));
+  MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->region_count, counts.data(), sizeof(int) * n_img, hipMemcpyHostToDevice));
+  MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->inside_count, inside.data(), sizeof(int) * n_img, hipMemcpyHostToDevice));
   return MODS_OK;
 }
 

@@ -57,8 +57,8 @@ int mods_host_alloc(size_t bytes, void **out) { if (!out) return MODS_E_ARG; MOD
 int mods_host_free(void *p) { MODS_HIP_CHECK(hipHostFree(p)); return MODS_OK; }
 int mods_dev_alloc(size_t bytes, void **out) { if (!out) return MODS_E_ARG; MODS_HIP_CHECK(hipMalloc(out, bytes ? bytes : 4)); return MODS_OK; }
 int mods_dev_free(void *p) { MODS_HIP_CHECK(hipFree(p)); return MODS_OK; }
-int mods_dev_upload(void *dst_dev, const void *src_host, size_t bytes) { MODS_HIP_CHECK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return MODS_OK; }
-int mods_dev_download(void *dst_host, const void *src_dev, size_t bytes) { MODS_HIP_CHECK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return MODS_OK; }
+int mods_dev_upload(void *dst_dev, const void *src_host, size_t bytes) { MODS_HIP_CHECK(mods::copy_wait(mods::thread_stream(), dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return MODS_OK; }
+int mods_dev_download(void *dst_host, const void *src_dev, size_t bytes) { MODS_HIP_CHECK(mods::copy_wait(mods::thread_stream(), dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return MODS_OK; }
 
 // ---- view schedule -------------------------------------------------------------------------------------
 // SetVSPars for one detector: the (zoom, tilt, phi) triples of a step that no earlier step has produced.
@@ -378,7 +378,7 @@ static int run_view_jobs(mods_ctx *c, const float *img1_dev, int w1, int h1, con
         mods_region *nb = nullptr;
         if (hipMalloc(&nb, cap * sizeof(mods_region)) != hipSuccess) { j.rc = MODS_E_HIP; set_error("view staging: out of device memory"); return; }
         (void)mods::stream_wait(wk->stream);                 // copies into the old arena may still be in flight
-        if (used) (void)hipMemcpy(nb, A.buf, used * sizeof(mods_region), hipMemcpyDeviceToDevice);
+        if (used) (void)mods::copy_wait(wk->stream, nb, A.buf, used * sizeof(mods_region), hipMemcpyDeviceToDevice);
         (void)hipFree(A.buf);
         A.buf = nb; A.cap = cap;
       }

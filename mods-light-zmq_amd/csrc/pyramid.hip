@@ -860,7 +860,7 @@ static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
   ctx->taps_host_n[slot] = n;
   { const int wrc = wait_both_streams(ctx); if (wrc) return wrc; }   // earlier launches may still read the slot
   ctx->dd_prev = mods_ctx::DdKey();
-  MODS_HIP_CHECK(hipMemcpy(ctx->gauss_taps_dev + slot * 64, taps, sizeof(float) * n, hipMemcpyHostToDevice));
+  MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->gauss_taps_dev + slot * 64, taps, sizeof(float) * n, hipMemcpyHostToDevice));
   ctx->taps_sigma[slot] = sigma;
   return MODS_OK;
 }
@@ -1093,7 +1093,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
       gauss_kernel_host(n, (double)sigma, taps.data());
       { const int wrc = wait_both_streams(ctx); if (wrc) return wrc; }
       ctx->dd_prev = mods_ctx::DdKey();
-      MODS_HIP_CHECK(hipMemcpy(ctx->alt_taps_dev + (size_t)l * kAltTapStride, taps.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+      MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->alt_taps_dev + (size_t)l * kAltTapStride, taps.data(), sizeof(float) * n, hipMemcpyHostToDevice));
       ctx->alt_ntap[l] = n; ctx->alt_sigma[l] = sigma;
     }
   }
@@ -1106,7 +1106,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
     std::vector<float> m((size_t)par->smmWindowSize * par->smmWindowSize);
     gauss_mask_host(par->smmWindowSize, m.data());
     ctx->dd_prev = mods_ctx::DdKey();
-    MODS_HIP_CHECK(hipMemcpy(ctx->smm_mask_dev, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
+    MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->smm_mask_dev, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
     ctx->smm_mask_size = par->smmWindowSize;
   }
   return MODS_OK;

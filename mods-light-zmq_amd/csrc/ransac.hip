@@ -188,7 +188,10 @@ bool ransac_ws_reserve(RansacGpu *ws, int len, int n_hyp) {
     RS_CHECK(hipHostMalloc(&ws->J_host, 2 * sizeof(double) * n_hyp));
     ws->counts_dev = (int *)(ws->J_dev + n_hyp);
     ws->counts_host = (int *)(ws->J_host + n_hyp);
-    RS_CHECK(hipMemset(ws->J_dev, 0, 2 * sizeof(double) * n_hyp));
+    // on the workspace's own stream: a memset on the legacy stream is refused while ANY blocking stream of the process is being
+    // captured (another thread recording a context's launch chain), and it would wait for every blocking stream besides
+    RS_CHECK(hipMemsetAsync(ws->J_dev, 0, 2 * sizeof(double) * n_hyp, ws->stream));
+    RS_CHECK(mods::stream_wait(ws->stream));
     ws->counts_dirty = false;
     ws->dg_cap = 0;
   }
@@ -333,16 +336,65 @@ struct RsTimer {
   ~RsTimer() { if (rsprof_on()) g_rsprof.us[slot] += rs_now_us() - t0; }
 };
 
+// The LO step of one call fits and scores the same inlier lists over and over: its ten inner samples (exp_ranH.c:741-793) mostly lead
+// to the same wide-threshold sets, and the reference's own hash table only ends an iteration once the NARROW set repeats - 9 to 12 of
+// the 14 full least-squares fits of a 1080p pair (and the error passes behind them) repeat an earlier one of the same call.  A fit is
+// a function of (u, list), an error vector of (u, H): both are kept per call and looked up by exact comparison (list / the nine
+// doubles bit by bit), so a hit returns the bits the computation would return.  Fits with a random subset (inlLimit) draw from the
+// generator and are never looked up; a caller's own error function is never cached.
+struct LoMemo {
+  struct Fit { int n; std::vector<int> list; double h[9]; };
+  struct Err { double h[9]; std::vector<double> d; };
+  static constexpr size_t kFits = 12, kErrs = 8;
+  std::vector<Fit> fits;
+  std::vector<Err> errs;
+  size_t fit_next = 0, err_next = 0;
+  const double *find_fit(const int *list, int n) const {
+    for (const Fit &f : fits)
+      if (f.n == n && !memcmp(f.list.data(), list, sizeof(int) * (size_t)n)) return f.h;
+    return nullptr;
+  }
+  void add_fit(const int *list, int n, const double *h) {
+    if (fits.size() < kFits) fits.emplace_back();
+    Fit &f = fits[fit_next % fits.size()];
+    fit_next = (fit_next + 1) % kFits;
+    f.n = n; f.list.assign(list, list + n); memcpy(f.h, h, sizeof(f.h));
+  }
+  const double *find_err(const double *h) const {
+    for (const Err &e : errs)
+      if (!memcmp(e.h, h, sizeof(e.h))) return e.d.data();
+    return nullptr;
+  }
+  void add_err(const double *h, const double *d, int n) {
+    if (errs.size() < kErrs) errs.emplace_back();
+    Err &e = errs[err_next % errs.size()];
+    err_next = (err_next + 1) % kErrs;
+    memcpy(e.h, h, sizeof(e.h)); e.d.assign(d, d + n);
+  }
+};
+
 struct ErrFn {   // host-side error function of the run (LO path); d has room for n_pad values
-  int type; HDsPtr custom; const PointsSoA *pts;
+  int type; HDsPtr custom; const PointsSoA *pts; LoMemo *memo;
   void operator()(const double *u, const double *H, double *d, int len) const {
     RsTimer t_(4);
     if (custom) { custom(nullptr, u, H, d, len); return; }
-    if (type == ERR_SAMPSON) { pts->ops->hds_all(pts->col, pts->n_pad, H, d); return; }
-    rs::SymH s; rs::sym_prepare(H, &s);
-    pts->ops->hsym_all(pts->col, pts->n_pad, s.H1, s.Hinv, type == ERR_SYMSUM ? 0 : 1, d);
+    if (memo)
+      if (const double *known = memo->find_err(H)) { memcpy(d, known, sizeof(double) * (size_t)pts->n_pad); return; }
+    if (type == ERR_SAMPSON) pts->ops->hds_all(pts->col, pts->n_pad, H, d);
+    else {
+      rs::SymH s; rs::sym_prepare(H, &s);
+      pts->ops->hsym_all(pts->col, pts->n_pad, s.H1, s.Hinv, type == ERR_SYMSUM ? 0 : 1, d);
+    }
+    if (memo) memo->add_err(H, d, pts->n_pad);
   }
 };
+// u2h of a whole list (no random subset) through the call's memo
+static void u2h_memo(LoMemo *memo, const double *u, const int *list, int n, double *h) {
+  if (memo && n >= 32)
+    if (const double *known = memo->find_fit(list, n)) { memcpy(h, known, 9 * sizeof(double)); return; }
+  rs::u2h(u, list, n, h, nullptr);
+  if (memo && n >= 32) memo->add_fit(list, n, h);
+}
 
 struct LoState {
   const double *u; int len; double th;
@@ -353,6 +405,7 @@ struct LoState {
   unsigned inlLimit;
   ErrFn errfn;
   PointsSoA *pts;
+  LoMemo *memo;
 };
 
 // inlidxs, rtools.c:155-166: the gains are computed lanes-wide, the MSAC sum and the index list stay sequential
@@ -398,7 +451,7 @@ static Score lo_iter(LoState &L, int *inliers, double th, double ths, int steps,
     if (detached > L.inlLimit) detached = L.inlLimit;
     if (detached < 4) detached = 4;
     RsTimer t_(3);
-    if (detached >= Sc.I) rs::u2h(L.u, inliers, (int)Sc.I, h, L.buffer);
+    if (detached >= Sc.I) u2h_memo(L.memo, L.u, inliers, (int)Sc.I, h);
     else {
       int *sub = rs::randsubset(*L.rng, inliers, (int)Sc.I, (int)detached);
       rs::u2h(L.u, sub, (int)detached, h, L.buffer);
@@ -592,8 +645,9 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
   const double CHECK_COEF = 9.0;
   const unsigned MIN_GOOD_SYM_PTS = 5;
   const double th_check = CHECK_COEF * th;
-  ErrFn errfn = {err_type, custom, &pts};
-  LoState L = {u, len, th, {errs[0], errs[1], errs[2], errs[3], errs[4]}, nullptr, &rng, &ht, inlLimit, errfn, &pts};
+  LoMemo memo;
+  ErrFn errfn = {err_type, custom, &pts, &memo};
+  LoState L = {u, len, th, {errs[0], errs[1], errs[2], errs[3], errs[4]}, nullptr, &rng, &ht, inlLimit, errfn, &pts, &memo};
 
   const double t_up0 = rsprof_on() ? rs_now_us() : 0;
   if (!ransac_ws_reserve(ws, len, 64)) ransac_fail();
@@ -624,7 +678,7 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
       case 0: break;
       case 1:
         S = inlidxs_v(L, L.errs[4], 4 * th, inliers.data());
-        rs::u2h(u, inliers.data(), (int)S.I, h, nullptr);
+        u2h_memo(&memo, u, inliers.data(), (int)S.I, h);
         d = L.errs[0];
         errfn(u, h, d, len);
         S.I = 0; S.J = 0;
@@ -636,7 +690,7 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
       case 3:
         d = L.errs[0];
         S = inlidxs_v(L, L.errs[4], 4 * th, inliers.data());
-        rs::u2h(u, inliers.data(), (int)S.I, h, nullptr);
+        u2h_memo(&memo, u, inliers.data(), (int)S.I, h);
         errfn(u, h, d, len);
         S = inlidxs_v(L, d, th, inliers.data());
         break;
@@ -644,7 +698,7 @@ static Score ransac_h_run(double *u, int len, double th, double conf, int max_sa
         if (rbase) memcpy(rbase, L.errs[4], len * sizeof(double));
         d = L.errs[0];
         S = inlidxs_list(L, L.errs[4], 4 * th * 2, inliers.data());   // TC*th*MWM
-        rs::u2h(u, inliers.data(), (int)S.I, h, nullptr);
+        u2h_memo(&memo, u, inliers.data(), (int)S.I, h);
         errfn(u, h, d, len);
         S = inlidxs_list(L, d, th, inliers.data());   // (lo_inner takes the count; what it returns replaces S)
         if (rbase) memcpy(rbase + len, d, len * sizeof(double));
