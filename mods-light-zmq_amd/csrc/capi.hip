@@ -31,8 +31,17 @@ hipError_t stream_wait(hipStream_t s) {
   if (e != hipErrorNotReady) return e;
   for (int i = 0; i < tl_wait_spin_polls; i++)
     if ((e = hipStreamQuery(s)) != hipErrorNotReady) break;
-  const timespec ts = {0, ns};
-  while (e == hipErrorNotReady) { nanosleep(&ts, nullptr); e = hipStreamQuery(s); }
+  // every poll is a runtime call and a wake-up of this thread (~4 us of CPU): the sleep grows by half per poll up to its bound, so a
+  // batch's 10 ms cost a GPU worker ~45 polls instead of 200 and a scoring round a verify thread ~6 instead of 25 (process CPU per
+  // pair 2.35 -> ~2.0 ms at the same rate, profiles/r05_wait_interval_sweep.log); the wait overshoots by at most a third of itself
+  long cur = ns;
+  const long cap = std::max(ns, tl_wait_sleep_max_ns);
+  while (e == hipErrorNotReady) {
+    const timespec ts = {0, cur};
+    nanosleep(&ts, nullptr);
+    e = hipStreamQuery(s);
+    cur = std::min(cap, cur + cur / 2);
+  }
   // a "not ready" answer may have been left as the thread's last error: it is not one
   const hipError_t last = hipGetLastError();
   if (e == hipSuccess && last != hipSuccess && last != hipErrorNotReady) return last;
@@ -59,13 +68,14 @@ hipStream_t thread_stream() {
 }
 
 void wait_mode_for_worker(long default_sleep_ns) {
-  long ns = default_sleep_ns;
+  long ns = default_sleep_ns, cap = 250000;
   if (const char *m = getenv("MODS_SYNC")) {
     if (!strncmp(m, "spin", 4)) ns = 0;
-    else if (!strncmp(m, "sleep", 5)) { if (m[5] == ':') ns = std::max(1l, atol(m + 6)) * 1000; }
+    else if (!strncmp(m, "sleep", 5)) { if (m[5] == ':') { ns = std::max(1l, atol(m + 6)) * 1000; cap = ns; } }   // a given interval is kept as it is
     else fprintf(stderr, "mods: MODS_SYNC=%s not understood (spin | sleep[:microseconds]); keeping the default\n", m);
   }
   tl_wait_sleep_ns = ns;
+  tl_wait_sleep_max_ns = cap;
   if (ns > 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);   // default slack 50 us: a 30 us sleep would take 80
 }
 

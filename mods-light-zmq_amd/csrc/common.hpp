@@ -39,6 +39,7 @@ inline hipError_t dyn_lds_once(DynLdsOnce &site, const void *fn, int bytes, int 
 // run of back-to-back queries for work that is about to finish, then a nanosleep between queries.  No interrupt path of the
 // runtime is involved (hipDeviceScheduleBlockingSync hung on the test boxes).  Everything else keeps the runtime's wait.
 inline thread_local long tl_wait_sleep_ns = 0;
+inline thread_local long tl_wait_sleep_max_ns = 0;   // the sleep between two polls grows by half per poll up to this (a long wait costs few polls, a short one stays sharp)
 inline thread_local int tl_wait_spin_polls = 8;
 hipError_t stream_wait(hipStream_t s);
 // hipMemcpy / hipMemset that wait, on a stream of the library instead of the legacy stream: an operation on the legacy stream waits
