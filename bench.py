@@ -705,7 +705,7 @@ def main():
                                  "hbm": "fp32 images resident in HBM"}[args.input],
                        "output": "inlier set + H on the host",
                        "overlap": "serial" if pipe is None else "%d gpu workers x %d pairs per batch + %d verify workers" % (args.gpu_workers, args.pairs_per_batch, args.verify_workers), "matcher": "linear (exact), FGINN 0.8",
-                       "detect_describe_batches_replayed_as_graph": replays,
+                       "streams_per_gpu_worker": int(os.environ.get("MODS_PIPELINE_STREAMS", "1")), "detect_describe_batches_replayed_as_graph": replays,
                        "verification": "LO-RANSAC homography, Sampson, th 4 px", "parallelism": "pairs sharded, %d rank(s)" % world,
                        "keypoints_per_image": list(last.n_described), "tentatives": last.n_tentatives,
                        "inliers_last_pair": last.n_inliers, "mean_inliers": round(inl / n_pairs, 1),

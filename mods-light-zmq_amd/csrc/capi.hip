@@ -21,16 +21,31 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-// (Round 5 tried a wait without runtime calls - a one-thread kernel behind the stream's work stores a sequence number to a pinned
-// word of the waiting thread, which sleeps and reads that word: 836-843 against 858-866 pairs/s with the sleeping hipStreamQuery
-// polls below, the same process CPU per pair, the runtime's own thread as busy as before.  Dropped.)
+// How a pipeline thread waits for a stream.  hipStreamQuery on a stream that is not done makes the runtime put a marker behind the
+// stream's work and has the runtime's OWN thread spin until that marker completes: tools/ubench/rt_thread_probe.hip - a 5 ms kernel
+// polled with hipStreamQuery every 50 us keeps that thread at 98.5 % of a core for the whole 5 ms, the same kernel behind a recorded
+// event polled with hipEventQuery at 0.0 % (a word in pinned memory written by a kernel: 0.0 % as well).  That spinning was the "one
+// core per process" of rounds 4 and 5 (1.1 ms per pair at 900 pairs/s).  So: record an event of the calling thread behind the work
+// and poll THAT, sleeping in between.
+// (A first attempt this round - a one-thread kernel that stores a sequence number to pinned memory - showed no gain only because
+// other waits of the process still used hipStreamQuery; one pending query-marker is enough to keep the runtime's thread spinning.)
+static hipEvent_t thread_event() {
+  struct PerThread { hipEvent_t e[16] = {}; ~PerThread() { for (hipEvent_t q : e) if (q) (void)hipEventDestroy(q); } };
+  static thread_local PerThread t;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!t.e[dev] && hipEventCreateWithFlags(&t.e[dev], hipEventDisableTiming) != hipSuccess) t.e[dev] = nullptr;
+  return t.e[dev];
+}
 hipError_t stream_wait(hipStream_t s) {
   const long ns = tl_wait_sleep_ns;
   if (ns <= 0) return hipStreamSynchronize(s);
-  hipError_t e = hipStreamQuery(s);
-  if (e != hipErrorNotReady) return e;
-  for (int i = 0; i < tl_wait_spin_polls; i++)
-    if ((e = hipStreamQuery(s)) != hipErrorNotReady) break;
+  hipEvent_t ev = thread_event();
+  if (!ev) return hipStreamSynchronize(s);
+  hipError_t e = hipEventRecord(ev, s);
+  if (e != hipSuccess) return e;
+  e = hipEventQuery(ev);
+  for (int i = 0; i < tl_wait_spin_polls && e == hipErrorNotReady; i++) e = hipEventQuery(ev);
   // every poll is a runtime call and a wake-up of this thread (~4 us of CPU): the sleep grows by half per poll up to its bound, so a
   // batch's 10 ms cost a GPU worker ~45 polls instead of 200 and a scoring round a verify thread ~6 instead of 25 (process CPU per
   // pair 2.35 -> ~2.0 ms at the same rate, profiles/r05_wait_interval_sweep.log); the wait overshoots by at most a third of itself
@@ -39,7 +54,7 @@ hipError_t stream_wait(hipStream_t s) {
   while (e == hipErrorNotReady) {
     const timespec ts = {0, cur};
     nanosleep(&ts, nullptr);
-    e = hipStreamQuery(s);
+    e = hipEventQuery(ev);
     cur = std::min(cap, cur + cur / 2);
   }
   // a "not ready" answer may have been left as the thread's last error: it is not one

@@ -302,9 +302,17 @@ int mods_pipeline_create_ex(int device, int w, int h, const mods_pair_params *pa
     mods_ctx *c = nullptr;
     int rc = mods_ctx_create_ex(device, w, h, 2 * pairs_per_batch, 1, &c);   // non-blocking streams: the workers overlap on the GPU
     if (rc) { for (auto *q : p->ctxs) mods_ctx_destroy(q); return rc; }
-    // the workers call detect + describe with the same arguments batch after batch: replayed as a hipGraph (MODS_GRAPHS=0: eager launches)
-    static const bool graphs_on = !(getenv("MODS_GRAPHS") && atoi(getenv("MODS_GRAPHS")) == 0);
-    if (graphs_on) (void)mods_ctx_graphs(c, 1);
+    // One stream per worker, eager launches.  A worker's own side stream (the small octaves of the scale space, pyramid.hip) and the
+    // replay of its launch chain as a hipGraph (capi.hip: dd_run) both put a dependency between two streams in front of the runtime,
+    // and this runtime resolves such a dependency on its own thread, SPINNING until the awaited work is done (tools/ubench/
+    // rt_thread_probe.hip: a fork / join over two streams keeps that thread at 66 % of a core for its duration, the same chain as a
+    // graph launch at 98 %, one stream at 0.3 %): with six workers that thread never slept - the "one core per process" of rounds 4
+    // and 5.  Six workers overlap on the GPU anyway, so the side stream buys the pipeline nothing: 895-906 pairs/s at 0.95 ms of
+    // process CPU per pair on one stream against 841-862 at 2.0 ms with side stream + replay on the same box
+    // (profiles/r05_pipeline_streams_ab.log).  MODS_PIPELINE_STREAMS=2 restores side stream + replay.
+    static const int streams_env = getenv("MODS_PIPELINE_STREAMS") ? atoi(getenv("MODS_PIPELINE_STREAMS")) : 1;
+    if (streams_env >= 2) (void)mods_ctx_graphs(c, 1);
+    else (void)mods_ctx_pyramid_streams(c, 1);
     p->ctxs.push_back(c);
   }
   for (int i = 0; i < gpu_workers; i++) p->gpu_threads.emplace_back(gpu_worker, p.get(), p->ctxs[i]);

@@ -639,3 +639,57 @@ def test_the_fp64_victim_still_detects_a_shared_simd(tmp_path):
     assert got[49] == 0, got
     if got[41] == 0:
         pytest.skip("this GPU no longer shows the MFMA / fp64 interaction: %r" % (got,))
+
+
+_SIDE_STREAM_PIPELINE = r'''
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, torch
+import __graft_entry__ as ge
+import synth
+pkg = ge.load_package()
+w, h = 640, 480
+pairs = [synth.pair(w, h, seed=40 + i) for i in range(3)]
+dev = [torch.from_numpy(np.stack([a, b])).cuda() for a, b, _ in pairs]
+torch.cuda.synchronize()
+par = pkg.PairParams.default()
+pkg.ransac_pin_seed(7)
+ctx = pkg.Context(0, w, h, 2)
+want = [pkg.match_pair_dev(ctx, d.data_ptr(), w, h, par)[0] for d in dev]
+pipe = pkg.Pipeline(0, w, h, par, 2, 4, 8)
+order = [i %% 3 for i in range(96)]
+got, pending = [], 0
+for i, k in enumerate(order):
+    if pending >= pipe.capacity - 1:
+        got.append(pipe.next()); pending -= 1
+    pipe.submit(dev[k].data_ptr(), i); pending += 1
+while pending:
+    got.append(pipe.next()); pending -= 1
+bad = 0
+for i, k in enumerate(order):
+    res, tag = got[i]
+    exp = want[k]
+    ok = tag == i and all(getattr(res, f) == getattr(exp, f) for f in ("n_tentatives", "n_unique", "n_inliers", "ransac_samples", "ransac_lo"))
+    ok = ok and list(res.n_described) == list(exp.n_described) and list(res.H) == list(exp.H)
+    bad += 0 if ok else 1
+print("RESULT bad=%%d replays=%%d" %% (bad, pipe.graph_replays()))
+pipe.close(); ctx.close()
+'''
+
+
+def test_pipeline_with_side_stream_and_graph_replay():
+    """MODS_PIPELINE_STREAMS=2 (read once per process, hence a process of its own): the workers' contexts fork the small octaves onto
+    their side stream and replay their launch chain as a hipGraph - the configuration the pipeline ran in until the runtime's spinning
+    thread was traced to exactly these two - and every pair still comes out as one mods_match_pair_dev call gives it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MODS_PIPELINE_STREAMS="2")
+    out = subprocess.run([sys.executable, "-c", _SIDE_STREAM_PIPELINE % {"root": root, "tests": os.path.join(root, "tests")}], env=env,
+                         capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    bad, replays = (int(t.split("=")[1]) for t in line[0].split()[1:])
+    assert bad == 0
+    assert replays >= 1
