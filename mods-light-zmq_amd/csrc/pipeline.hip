@@ -63,11 +63,6 @@ struct mods_pipeline {
   // CPU time the workers' own threads spent inside their stages (CLOCK_THREAD_CPUTIME_ID; the RANSAC task pool's helper threads,
   // which the verify stage of a hard pair spreads its model fits over, are not in it: the process clock is)
   std::atomic<long long> cpu_gpu_ns{0}, cpu_verify_ns{0};
-  std::vector<int> worker_tids;     // (under mu) kernel thread ids of the workers
-  std::thread watch;                // see runtime_thread_watch
-  std::set<int> api_tids;           // (under mu) threads that called create / submit / next: never rescheduled
-  std::vector<std::tuple<int, int, int>> moved;   // (under mu) (tid, previous policy, previous priority) of threads the watch moved to SCHED_IDLE
-  std::condition_variable cv_watch;
 };
 static long long thread_cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; }
 
@@ -76,17 +71,9 @@ using namespace mods;
 extern "C" int mods_ransac_warmup(int device, int len);
 extern "C" int mods_ctx_warmup(mods_ctx *c, int n_img, int w, int h, const mods_pair_params *par);
 
-// (p->mu held) the calling thread is the application's: the watch never touches it
-static void note_caller(mods_pipeline *p) {
-  static thread_local int tid = 0;
-  if (!tid) tid = (int)syscall(SYS_gettid);
-  p->api_tids.insert(tid);
-}
-
 static void worker_ready(mods_pipeline *p, int rc) {
   {
     std::lock_guard<std::mutex> lk(p->mu);
-    p->worker_tids.push_back((int)syscall(SYS_gettid));
     if (rc && p->warm_rc == MODS_OK) { p->warm_rc = rc; p->warm_err = mods_last_error(); }
     p->ready++;
   }
@@ -156,90 +143,10 @@ static void verify_worker(mods_pipeline *p) {
 }
 
 
-// The HIP runtime keeps one thread of its own per process that is woken by every dispatch completion once streams are busy: close
-// to a whole core (tools/who_spins.sh; 1.2 ms of CPU per pair at 800 pairs/s, 72 % of it system time).  It is not one of ours and
-// nothing the library calls quiets it, but nothing in the pair path waits for it either (the workers look at their streams'
-// completion signals themselves), so on a host with few cores per GPU it is better off behind the threads that do the work.
-// MODS_RUNTIME_THREAD=idle[:delay in ms]: two seconds (or the delay) after the pipeline starts, a thread is moved to SCHED_IDLE (it
-// runs when a core has nothing else to do) if ALL of this holds, and the move is reported once on stderr and undone by
-// mods_pipeline_destroy:
-//   * it used more than 80 % of a core over 100 ms;
-//   * it is not a pipeline worker, not a "mods-" thread (RANSAC pool, view workers), not the process's main thread, and has never
-//     called into this pipeline (create / submit / next): the application's own busy threads - an image decoder, a numpy pool, the
-//     thread that feeds the pipeline - are left alone whatever they do;
-//   * it was seen, in at least one of eight looks 10 ms apart, inside an ioctl on /dev/kfd - where the runtime's event thread
-//     sleeps between completions (/proc/self/task/<tid>/syscall); a thread that computes or polls in user space is never there.
-static std::map<int, long long> task_cpu_ns() {
-  std::map<int, long long> out;
-  if (DIR *d = opendir("/proc/self/task")) {
-    while (dirent *e = readdir(d)) {
-      const int tid = atoi(e->d_name);
-      if (tid <= 0) continue;
-      char path[64]; snprintf(path, sizeof(path), "/proc/self/task/%d/schedstat", tid);
-      if (FILE *f = fopen(path, "r")) { long long ns = 0; if (fscanf(f, "%lld", &ns) == 1) out[tid] = ns; fclose(f); }
-    }
-    closedir(d);
-  }
-  return out;
-}
-// is thread `tid` blocked in ioctl(fd, ...) with fd = /dev/kfd right now?
-static bool in_kfd_ioctl(int tid) {
-  char path[64], line[256];
-  snprintf(path, sizeof(path), "/proc/self/task/%d/syscall", tid);
-  FILE *f = fopen(path, "r");
-  if (!f) return false;
-  const bool got = fgets(line, sizeof(line), f) != nullptr;
-  fclose(f);
-  long nr = -1; unsigned long long fd = ~0ull;
-  if (!got || sscanf(line, "%ld %llx", &nr, &fd) != 2 || nr != SYS_ioctl) return false;
-  char link[64], target[128];
-  snprintf(link, sizeof(link), "/proc/self/fd/%llu", fd);
-  const ssize_t n = readlink(link, target, sizeof(target) - 1);
-  if (n <= 0) return false;
-  target[n] = 0;
-  return !strcmp(target, "/dev/kfd");
-}
-static void runtime_thread_watch(mods_pipeline *p) {
-  pthread_setname_np(pthread_self(), "mods-watch");
-  {
-    std::unique_lock<std::mutex> lk(p->mu);
-    int delay_ms = 2000;
-    if (const char *e = getenv("MODS_RUNTIME_THREAD")) if (const char *c = strchr(e, ':')) delay_ms = std::max(1, atoi(c + 1));
-    if (p->cv_watch.wait_for(lk, std::chrono::milliseconds(delay_ms), [&] { return p->stop; })) return;
-  }
-  const auto a = task_cpu_ns();
-  std::map<int, int> kfd_looks;
-  for (int look = 0; look < 10; look++) {
-    if (look >= 1 && look <= 8) for (const auto &kv : a) if (in_kfd_ioctl(kv.first)) kfd_looks[kv.first]++;
-    std::unique_lock<std::mutex> lk(p->mu);
-    if (p->cv_watch.wait_for(lk, std::chrono::milliseconds(10), [&] { return p->stop; })) return;
-  }
-  const auto b = task_cpu_ns();
-  std::vector<int> ours;
-  std::set<int> callers;
-  { std::lock_guard<std::mutex> lk(p->mu); ours = p->worker_tids; callers = p->api_tids; }
-  const int self = (int)syscall(SYS_gettid), main_tid = (int)getpid();
-  for (const auto &kv : b) {
-    const int tid = kv.first;
-    const auto it = a.find(tid);
-    if (it == a.end() || kv.second - it->second < 80000000ll) continue;
-    if (tid == self || tid == main_tid || callers.count(tid) || std::find(ours.begin(), ours.end(), tid) != ours.end()) continue;
-    if (!kfd_looks.count(tid)) continue;          // never seen waiting in the driver: not the runtime's event thread
-    char comm[32] = "?", path[64];
-    snprintf(path, sizeof(path), "/proc/self/task/%d/comm", tid);
-    if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%31s", comm) != 1) comm[0] = 0; fclose(f); }
-    if (!strncmp(comm, "mods-", 5)) continue;
-    const int old_policy = sched_getscheduler(tid);
-    sched_param old_sp; old_sp.sched_priority = 0;
-    (void)sched_getparam(tid, &old_sp);
-    sched_param sp; sp.sched_priority = 0;
-    if (old_policy >= 0 && old_policy != SCHED_IDLE && sched_setscheduler(tid, SCHED_IDLE, &sp) == 0) {
-      { std::lock_guard<std::mutex> lk(p->mu); p->moved.emplace_back(tid, old_policy, old_sp.sched_priority); }
-      fprintf(stderr, "mods: thread %d (%s), the HIP runtime's completion thread (busy on a full core, waits in /dev/kfd), moved to SCHED_IDLE until "
-                      "the pipeline is destroyed (MODS_RUNTIME_THREAD=leave keeps it)\n", tid, comm);
-    }
-  }
-}
+// (Rounds 4 and 5 carried a watch here that moved the HIP runtime's busy thread to SCHED_IDLE on request, MODS_RUNTIME_THREAD=idle.
+// The thread was busy because it SPINS while a hipStreamQuery marker, a dependency between two streams or a graph launch is pending
+// (tools/ubench/rt_thread_probe.hip); the pipeline no longer hands it any of the three - see stream_wait in capi.hip and the
+// workers' contexts below - so the watch is gone: docs/history/r05_removed_paths.patch.)
 
 extern "C" {
 
@@ -328,9 +235,6 @@ int mods_pipeline_create_ex(int device, int w, int h, const mods_pair_params *pa
     set_error("pipeline warm-up: %s", err.c_str());
     return rc;
   }
-  { std::lock_guard<std::mutex> lk(p->mu); note_caller(p.get()); }
-  if (const char *e = getenv("MODS_RUNTIME_THREAD"))
-    if (!strncmp(e, "idle", 4)) p->watch = std::thread(runtime_thread_watch, p.get());
   *out = p.release();
   return MODS_OK;
 }
@@ -343,7 +247,6 @@ static int submit_any(mods_pipeline *p, const void *img, int kind, long tag) {
   j->tag = tag; j->img = img; j->kind = kind;
   {
     std::unique_lock<std::mutex> lk(p->mu);
-    note_caller(p);
     p->cv_space.wait(lk, [&] { return (int)p->q_order.size() < p->max_in_flight; });
     p->q_gpu.push_back(j);
     p->q_order.push_back(j);
@@ -365,7 +268,6 @@ int mods_pipeline_next_matches(mods_pipeline *p, mods_pair_result *res, long *ta
   std::shared_ptr<Job> j;
   {
     std::unique_lock<std::mutex> lk(p->mu);
-    note_caller(p);
     if (p->q_order.empty()) { set_error("pipeline: nothing in flight"); return MODS_E_ARG; }
     j = p->q_order.front();
     p->cv_done.wait(lk, [&] { return j->done; });
@@ -392,12 +294,7 @@ void mods_pipeline_destroy(mods_pipeline *p) {
     std::lock_guard<std::mutex> lk(p->mu);
     p->stop = true;
   }
-  p->cv_gpu.notify_all(); p->cv_verify.notify_all(); p->cv_watch.notify_all();
-  if (p->watch.joinable()) p->watch.join();
-  for (const auto &m : p->moved) {      // give the rescheduled threads their policy back
-    sched_param sp; sp.sched_priority = std::get<2>(m);
-    (void)sched_setscheduler(std::get<0>(m), std::get<1>(m), &sp);
-  }
+  p->cv_gpu.notify_all(); p->cv_verify.notify_all();
   for (auto &t : p->gpu_threads) t.join();
   for (auto &t : p->verify_threads) t.join();
   for (auto *c : p->ctxs) mods_ctx_destroy(c);
