@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <mutex>
+#include <vector>
 #include <time.h>
 #include <sys/prctl.h>
 
@@ -29,13 +31,31 @@ void set_error(const char *fmt, ...) {
 // and poll THAT, sleeping in between.
 // (A first attempt this round - a one-thread kernel that stores a sequence number to pinned memory - showed no gain only because
 // other waits of the process still used hipStreamQuery; one pending query-marker is enough to keep the runtime's thread spinning.)
+// Events / streams a thread borrows for as long as it lives: handed back to a process-wide list when the thread ends (no runtime call
+// in a thread's exit path - the runtime may be shutting down by then -, and a pipeline that is created and destroyed again and again
+// reuses the same few objects)
+template <class T> struct HandlePool {
+  std::mutex mu;
+  std::vector<T> free_[16];
+  T take(int dev, T (*make)()) {
+    { std::lock_guard<std::mutex> lk(mu); if (!free_[dev].empty()) { T h = free_[dev].back(); free_[dev].pop_back(); return h; } }
+    return make();
+  }
+  void give(int dev, T h) { std::lock_guard<std::mutex> lk(mu); free_[dev].push_back(h); }
+};
+template <class T> struct Borrowed {
+  HandlePool<T> *pool; T h[16] = {};
+  explicit Borrowed(HandlePool<T> *p) : pool(p) {}
+  ~Borrowed() { for (int d = 0; d < 16; d++) if (h[d]) pool->give(d, h[d]); }
+};
+static HandlePool<hipEvent_t> *event_pool() { static HandlePool<hipEvent_t> *p = new HandlePool<hipEvent_t>(); return p; }     // (never destroyed: threads may outlive statics)
+static HandlePool<hipStream_t> *stream_pool() { static HandlePool<hipStream_t> *p = new HandlePool<hipStream_t>(); return p; }
 static hipEvent_t thread_event() {
-  struct PerThread { hipEvent_t e[16] = {}; ~PerThread() { for (hipEvent_t q : e) if (q) (void)hipEventDestroy(q); } };
-  static thread_local PerThread t;
+  static thread_local Borrowed<hipEvent_t> t(event_pool());
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!t.e[dev] && hipEventCreateWithFlags(&t.e[dev], hipEventDisableTiming) != hipSuccess) t.e[dev] = nullptr;
-  return t.e[dev];
+  if (!t.h[dev]) t.h[dev] = t.pool->take(dev, +[]() -> hipEvent_t { hipEvent_t e = nullptr; return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? e : nullptr; });
+  return t.h[dev];
 }
 hipError_t stream_wait(hipStream_t s) {
   const long ns = tl_wait_sleep_ns;
@@ -74,12 +94,11 @@ hipError_t fill_wait(hipStream_t s, void *dst, int value, size_t bytes) {
   return e != hipSuccess ? e : stream_wait(s);
 }
 hipStream_t thread_stream() {
-  struct PerThread { hipStream_t s[16] = {}; ~PerThread() { for (hipStream_t q : s) if (q) (void)hipStreamDestroy(q); } };
-  static thread_local PerThread t;
+  static thread_local Borrowed<hipStream_t> t(stream_pool());
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;     // (nullptr = the legacy stream: what the call used before)
-  if (!t.s[dev] && hipStreamCreateWithFlags(&t.s[dev], hipStreamNonBlocking) != hipSuccess) t.s[dev] = nullptr;
-  return t.s[dev];
+  if (!t.h[dev]) t.h[dev] = t.pool->take(dev, +[]() -> hipStream_t { hipStream_t q = nullptr; return hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess ? q : nullptr; });
+  return t.h[dev];
 }
 
 void wait_mode_for_worker(long default_sleep_ns) {

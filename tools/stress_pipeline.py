@@ -33,6 +33,7 @@ for a, b, _, _ in oracle:
 par = pkg.PairParams.default()
 pkg.ransac_pin_seed(12345)
 bad = 0
+if os.environ.get("STRESS_VERBOSE"): print("oracle ready", flush=True)
 t0 = time.time()
 for rep in range(reps):
     pipe = pkg.Pipeline(0, w, h, par, 6, 8, 8)
@@ -62,4 +63,5 @@ for rep in range(reps):
             else:
                 print("  shapes", m.shape, exp_m.shape)
     pipe.close()
+    if os.environ.get("STRESS_VERBOSE"): print("rep %d done at %.1f s" % (rep, time.time() - t0), flush=True)
 print("%d repetitions, %d differing results, %.1f s" % (reps, bad, time.time() - t0))
