@@ -141,8 +141,10 @@ int mods_ctx_timing_enable(mods_ctx *ctx, int stage_mask);
    it from then on - one submission and one completion for the host instead of one per launch.  The results are the same
    launches' results.  Only calls whose scale space forks onto the context's side stream (images x batch of 4 megapixels or more,
    pyramid streams = 2) are recorded; others stay eager (a linear recording faults on replay with the ROCm 7.0.2 runtime unless
-   DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is set before the runtime starts; csrc/capi.hip: dd_run).  Off by default for a context;
-   the pair pipeline switches it on for its workers' contexts.
+   DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is set before the runtime starts; csrc/capi.hip: dd_run).  Off by default for a context.
+   The pair pipeline used it for its workers' contexts during round 5 and does so only with MODS_PIPELINE_STREAMS=2 now: with this
+   runtime a graph launch with branches - like the side stream itself - keeps the HIP runtime's own thread spinning for its
+   duration (tools/ubench/rt_thread_probe.hip), a core per process that the pipeline's one-stream workers do not cost.
    mods_ctx_graph_replays: calls served by a replay so far. */
 int mods_ctx_graphs(mods_ctx *ctx, int on);
 long mods_ctx_graph_replays(const mods_ctx *ctx);
@@ -607,7 +609,11 @@ int mods_dev_download(void *dst_host, const void *src_dev, size_t bytes);
  * Throughput form of the same path: `gpu_workers` threads (one context each) run detect/describe/match
  * while `verify_workers` threads run duplicate filtering + LO-RANSAC of earlier pairs (mods.cpp overlaps
  * its two images with OpenMP tasks, mods.cpp:234-251; here the overlap is across pairs).  Results are
- * returned in submission order and are identical to mods_match_pair_dev's. */
+ * returned in submission order and are identical to mods_match_pair_dev's.
+ * Host cost: ~1.0 ms of process CPU per 1080p pair: the pipeline's threads wait on recorded events with sleeping
+ * polls (MODS_SYNC=spin | sleep:<us> changes that), and its workers' contexts keep ONE stream and eager launches
+ * (MODS_PIPELINE_STREAMS=2: side stream for the small octaves + hipGraph replay per worker - same results, same rate, one more
+ * busy core: the runtime's own thread spins while a dependency between two streams is pending). */
 typedef struct mods_pipeline mods_pipeline;
 int mods_pipeline_create(int device, int w, int h, const mods_pair_params *par, int gpu_workers, int verify_workers,
                          mods_pipeline **out);
