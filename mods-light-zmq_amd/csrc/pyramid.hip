@@ -871,7 +871,9 @@ static void launch_fast_blur(mods_ctx *ctx, const float *src, float *dst, int w,
 #ifndef BLUR_OV_BIG
 #define BLUR_OV_BIG 2   // float4 output groups per thread and strip row on the large planes
 #endif
+#ifndef BLUR_TH_BIG
 #define BLUR_TH_BIG 32   // measured on 1080p pairs: 32-row tiles (4 workgroups per CU, phases of different tiles overlap) beat 64-row tiles by ~15 %
+#endif
   const int tiles64 = ((w + FB_TW - 1) / FB_TW) * ((h + 63) / 64) * n_img;
   if (tiles64 >= 384) {   // at least ~1.5 tiles per CU: large planes: 32-row tiles
     const size_t lds = sizeof(float) * (size_t)(BLUR_TH_BIG + 2 * R) * FB_TW;

@@ -12,7 +12,7 @@ for v in "$@"; do
   python3 - $(find $OUT/leg -name "*kernel_stats.csv" | head -1) >> $OUT/variants.log <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if "gauss_blur_fast_kernel" in r["Name"] and ", 32, 2, true" in r["Name"]:
+    if "gauss_blur_fast_kernel" in r["Name"] and ", 2, true" in r["Name"]:
         print("   %-52s calls %4s avg %7.1f us" % (r["Name"].split("(")[0][-52:], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
