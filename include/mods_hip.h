@@ -396,7 +396,8 @@ void mods_test_glibc_rand(unsigned seed, int n, int *out);
 /* self-test hooks of the fast host forms of the homography LO step (no device needed): the error functions at a given
  * SIMD width (lanes 0 = the scalar HDs / HDsSym / HDsSymMax, 1 / 4 / 8 = vector forms; MODS_E_ARG when the CPU lacks the
  * width), u2h and its moment matrix with the design matrix written out (reference_form 1: lin_hgN + cov_mat,
- * Htools.c:60-132, utools.c:172-185) or folded into 30 ordered sums (0), and inlidxs (rtools.c:155-166). */
+ * Htools.c:60-132, utools.c:172-185) or folded into 30 ordered sums (0), and inlidxs (rtools.c:155-166; lanes < 0: the list-only
+ * form of the wide-threshold sets - count and list, J = 0). */
 int mods_test_host_errfn(int type, const double *u6, int len, const double *H, int lanes, double *out);
 int mods_test_host_u2h(const double *u6, const int *inl, int n, int reference_form, double *H);
 int mods_test_host_cov(const double *u6, const int *inl, int n, int reference_form, double *Cv);

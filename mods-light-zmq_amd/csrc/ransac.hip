@@ -591,7 +591,11 @@ int mods_test_host_inlidxs(const double *err, int len, double th, int lanes, int
   if (!err || !inl || !I || !J || len < 1) return MODS_E_ARG;
   rs::Score s;
   if (lanes == 0) s = rs::inlidxs(err, len, th, inl);
-  else {
+  else if (lanes < 0) {     // the list-only form (count and list; J stays 0)
+    LoState L = {};
+    L.len = len;
+    s = inlidxs_list(L, err, th, inl);
+  } else {
     PointsSoA pts;
     pts.ops = rs::simd_ops_lanes(lanes);
     if (!pts.ops) return MODS_E_ARG;

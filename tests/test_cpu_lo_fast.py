@@ -101,6 +101,10 @@ def test_inlidxs_gain_pass_bitexact(pkg, th):
             continue
         assert I.value == I0.value and np.float64(J.value).view(np.uint64) == np.float64(J0.value).view(np.uint64)
         assert np.array_equal(inl[:I.value], want_inl[:I0.value])
+    # the list-only form the wide-threshold sets use: the same count and list, no sum
+    inl, I, J = np.zeros(n, np.int32), C.c_uint(), C.c_double(-1.0)
+    assert M.mods_test_host_inlidxs(P(err), n, C.c_double(th), -1, P(inl), C.byref(I), C.byref(J)) == 0
+    assert I.value == I0.value and J.value == 0.0 and np.array_equal(inl[:I.value], want_inl[:I0.value])
     if refdeg.available():
         R = refdeg.lib()
         R.inlidxs.restype = refdeg.Score
