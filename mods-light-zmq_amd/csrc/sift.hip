@@ -26,6 +26,12 @@
 namespace mods {
 
 constexpr int SMALL_CAP = 80;   // P2 limit of the LDS-resident extraction tier
+#ifndef EXTRACT_T_LO
+#define EXTRACT_T_LO 48     // size classes of the LDS tier: P2 <= 48, <= 64, <= SMALL_CAP
+#endif
+#ifndef EXTRACT_T_MID
+#define EXTRACT_T_MID 64
+#endif
 #ifndef ES_MINB
 #define ES_MINB 5                // workgroups of extract_small_kernel per CU the register budget is set for
 #endif
@@ -478,8 +484,8 @@ struct BigRegion { int img, ri, P2, n_tap; unsigned long long slab; float scale;
 struct BigLists {                     // device-resident bookkeeping, zeroed before every batch
   int n_regions, n_sitems, n_ritems, n_fitems;
   unsigned long long pool_used;
-  int n_small[2];                   // regions of the two LDS tiers (P2 <= t_lo, t_lo < P2 <= p2_hi), over all images
-  int sift_next, pad;               // next work unit of sift_wave2_kernel
+  int n_small[3];                   // regions of the three LDS tiers (P2 <= t_lo, <= t_mid, <= p2_hi), over all images
+  int sift_next;                    // next work unit of sift_wave2_kernel
 };
 // regions up to this size take the fused sample + row-pass kernel (S stays in LDS, no S slab); larger ones the phase kernels
 #ifndef BIG_FUSE_P2_MAX
@@ -508,7 +514,7 @@ __device__ __forceinline__ int big_rsteps(int n_tap) { const int v = BIG_RLOADS 
 __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mods_region *__restrict__ reg_all,
                                                            const int *__restrict__ reg_count, BigLists *__restrict__ bl,
                                                            BigRegion *__restrict__ regions, int2 *__restrict__ sitems,
-                                                           int2 *__restrict__ ritems, int2 *__restrict__ fitems, int *__restrict__ small_items, int small_cap_items, int t_lo,
+                                                           int2 *__restrict__ ritems, int2 *__restrict__ fitems, int *__restrict__ small_items, int small_cap_items, int t_lo, int t_mid,
                                                            int max_regions, int max_items,
                                                            unsigned long long pool_elems, int *__restrict__ err_flag) {
   const int b = blockIdx.y;
@@ -525,9 +531,9 @@ __global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mo
   const bool lds_tier = have && g.P2 <= k.p2_hi && n_tap <= 32;
   {
     const int lane = threadIdx.x & 63;
-    const int tier = !lds_tier ? -1 : (g.P2 <= t_lo ? 0 : 1);
+    const int tier = !lds_tier ? -1 : (g.P2 <= t_lo ? 0 : (g.P2 <= t_mid ? 1 : 2));
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < 3; t++) {
       const unsigned long long m = __ballot(tier == t);
       if (m == 0) continue;
       int base = 0;
@@ -1577,7 +1583,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   const size_t patch_elems = (size_t)n_img * k.reg_cap * pp;
   const int max_big = 1 << 17, max_items = 1 << 20;
   const int small_cap_items = n_img * k.reg_cap;
-  const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + 3 * sizeof(int2) * max_items + 2 * sizeof(int) * (size_t)small_cap_items + 15) / 4;
+  const size_t book_elems = (sizeof(BigLists) + sizeof(BigRegion) * max_big + 3 * sizeof(int2) * max_items + 3 * sizeof(int) * (size_t)small_cap_items + 15) / 4;
   // slab pool: ~25 M floats per 1080p image in practice (row-pass strips, S only above 256 px); 64 M per image of the batch
   // and per 2 Mpx of image area, at least 1 GiB
   const unsigned long long area_units = std::max<unsigned long long>(1, ((unsigned long long)k.w * k.h + (1ull << 21) - 1) >> 21);
@@ -1604,14 +1610,15 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   const int small_cap = SMALL_CAP;   // P2 limit of the LDS tier
   k.p2_hi = small_cap;
   hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
-                     ctx->region_count, bl, bregs, sitems, ritems, fitems, small_items, small_cap_items, std::min(small_cap, 48), max_big, max_items,
+                     ctx->region_count, bl, bregs, sitems, ritems, fitems, small_items, small_cap_items, std::min(small_cap, EXTRACT_T_LO), std::min(small_cap, EXTRACT_T_MID), max_big, max_items,
                      pool_elems, ctx->desc_err_dev);
-  // LDS tier in two launches over the work lists of big_classify_kernel (P2 <= 48 takes half the LDS of the 80 class: twice
-  // the workgroups per CU); the HBM tier takes P2 > small_cap
+  // LDS tier in three launches over the work lists of big_classify_kernel: a workgroup's LDS follows the largest window of its class
+  // (26 / 39 / 53 KB for the 41-pixel patch: 6 / 4 / 3 workgroups per CU), and the 48 < P2 <= 80 regions of a 1080p image are as
+  // much sampling work as the 6 800 smaller ones; the HBM tier takes P2 > small_cap
   {
-    const int tiers[3] = {-1, small_cap < 48 ? small_cap : 48, small_cap};
-    for (int t = 0; t < 2; t++) {
-      if (t == 1 && tiers[2] <= tiers[1]) continue;
+    const int tiers[4] = {-1, std::min(small_cap, EXTRACT_T_LO), std::min(small_cap, EXTRACT_T_MID), small_cap};
+    for (int t = 0; t < 3; t++) {
+      if (tiers[t + 1] <= tiers[t]) continue;
       DescConst kt = k;
       kt.p2_lo = tiers[t]; kt.p2_hi = tiers[t + 1];
       const size_t capS = kt.p2_hi > 4 ? kt.p2_hi : 4;
