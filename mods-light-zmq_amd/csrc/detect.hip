@@ -924,6 +924,9 @@ __global__ __launch_bounds__(256) void rank_count_kernel(DetectConst k, const un
 // counting kernel, which returns at once for the others.  10 k keys: 105 barrier-separated passes of 8 compare-exchanges per
 // thread ~ 60 us per image against 310 us of counting for a batch (round 3).
 constexpr int RANK_SORT_MAX = 16384;
+#ifndef RANK_COUNT_MAX_IMG
+#define RANK_COUNT_MAX_IMG 4      // calls with up to this many images rank by counting (latency), larger batches by sorting (throughput)
+#endif
 __global__ __launch_bounds__(1024) void rank_sort_kernel(DetectConst k, const unsigned long long *__restrict__ sort_keys,
                                                          const int *__restrict__ key_count, int *__restrict__ rank) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
@@ -1171,9 +1174,12 @@ static int detect_run_stages(mods_ctx *ctx) {
     StageScope ts(ctx, MODS_STAGE_SORT);
     // rank array: the raw-hit half of sort_idx's accept list is dead by now; use the dedicated buffer
     MODS_HIP_CHECK(hipMemsetAsync(ctx->rank_dev, 0, sizeof(int) * (size_t)ctx->max_cand * n_img, ctx->stream));
-    // images of up to RANK_SORT_MAX keys are ranked by one workgroup out of LDS, larger ones by the O(n^2) count
-    const int sort_max = RANK_SORT_MAX;
-    {
+    // images of up to RANK_SORT_MAX keys are ranked by one workgroup out of LDS, larger ones by the O(n^2) count.  The sort is the
+    // cheaper one for the GPU (one CU per image for ~0.2 ms: 105 barrier-separated passes) and the slower one for the caller: a call
+    // with a few images - one pair, a view of the ladder - has the GPU to itself, where the count over 4 096 workgroups takes a few
+    // microseconds; both give the same ranks (the keys are unique)
+    const int sort_max = n_img <= RANK_COUNT_MAX_IMG ? 0 : RANK_SORT_MAX;
+    if (sort_max > 0) {
       static DynLdsOnce once;
       MODS_HIP_CHECK(dyn_lds_once(once, (const void *)rank_sort_kernel, 160 * 1024, ctx->device));
       hipLaunchKernelGGL(rank_sort_kernel, dim3(n_img), dim3(1024), RANK_SORT_MAX * 10, ctx->stream, k, ctx->sort_keys, key_count, ctx->rank_dev);
