@@ -72,52 +72,68 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const double *__restr
   }
 }
 
-// grid = ceil(n_hyp/64), block 256: lane k of wave 0 sums gain[i][k] for i = 0..len-1 in order.  The sum is a serial
+// grid = ceil(n_hyp / COLS), block 256: lane k of wave 0 sums gain[i][k] for i = 0..len-1 in order.  The sum is a serial
 // chain, so one wave adds; what it would wait for is the memory latency of 8 bytes per row, so all four waves fetch the
-// next GAIN_ROWS rows into registers while wave 0 adds the current ones out of LDS.  The gain matrix has hyp_cap (a
-// multiple of 64) columns, so every lane's column exists.
-constexpr int GAIN_ROWS = 128;
-__global__ void __launch_bounds__(256) ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride,
-                                                          int *__restrict__ counts, double *__restrict__ J_out, int *__restrict__ counts_out) {
-  __shared__ double s_rows[GAIN_ROWS][64];
+// next ROWS rows into registers while wave 0 adds the current ones out of LDS.  The gain matrix has hyp_cap (a multiple of 64)
+// columns, so every lane's column exists.  COLS = 64, ROWS = 128 for a full batch; the first batch of a call has 8 hypotheses:
+// 16 columns wide the same LDS holds 384 rows, a third of the chunks and of the exposed fetch latencies (114 -> ~50 us for 6 000
+// correspondences, on the path of a single pair's latency).
+template <int COLS, int ROWS>
+__device__ __forceinline__ void gain_sums(const double *__restrict__ gain, int len, int n_hyp, int kstride, int *__restrict__ counts,
+                                          double *__restrict__ J_out, int *__restrict__ counts_out, double *s_rows) {
+  constexpr int RG = 256 / COLS;            // row groups of a fetch step
+  constexpr int PER = ROWS / RG;
+  const int col = threadIdx.x % COLS, rsub = threadIdx.x / COLS;
+  const int kf = blockIdx.x * COLS + col;   // column this thread fetches
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + lane;
-  constexpr int PER = GAIN_ROWS / 4;
+  const int k = blockIdx.x * COLS + lane;   // column lane `lane` of wave 0 sums (lane < COLS)
   double v[PER];
   double sum = 0;
 #define GAIN_FETCH(c0)                                                                  \
   _Pragma("unroll") for (int j = 0; j < PER; j++) {                                     \
-    const int row = (c0) + wv + 4 * j;                                                  \
-    v[j] = row < len ? gain[(size_t)row * kstride + k] : 0.0;                           \
+    const int row = (c0) + rsub + RG * j;                                               \
+    v[j] = row < len ? gain[(size_t)row * kstride + kf] : 0.0;                          \
   }
   GAIN_FETCH(0)
-  for (int c0 = 0; c0 < len; c0 += GAIN_ROWS) {
+  for (int c0 = 0; c0 < len; c0 += ROWS) {
 #pragma unroll
-    for (int j = 0; j < PER; j++) s_rows[wv + 4 * j][lane] = v[j];
+    for (int j = 0; j < PER; j++) s_rows[(rsub + RG * j) * COLS + col] = v[j];
     __syncthreads();
-    if (c0 + GAIN_ROWS < len) { GAIN_FETCH(c0 + GAIN_ROWS) }
-    if (wv == 0) {
-      const int rows = min(GAIN_ROWS, len - c0);
+    if (c0 + ROWS < len) { GAIN_FETCH(c0 + ROWS) }
+    if (wv == 0 && lane < COLS) {
+      const int rows = min(ROWS, len - c0);
       int r = 0;
       for (; r + 15 < rows; r += 16) {
         double t[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) t[q] = s_rows[r + q][lane];
+        for (int q = 0; q < 16; q++) t[q] = s_rows[(r + q) * COLS + lane];
 #pragma unroll
         for (int q = 0; q < 16; q++) sum += t[q];
       }
-      for (; r < rows; r++) sum += s_rows[r][lane];
+      for (; r < rows; r++) sum += s_rows[r * COLS + lane];
     }
     __syncthreads();
   }
 #undef GAIN_FETCH
   // J and the inlier counts of hypothesis k go straight to the host's (pinned, device-visible) result block, and the device counters
   // are left at zero for the next batch: no copy and no fill launch per scoring round
-  if (wv == 0 && k < n_hyp) {
+  if (wv == 0 && lane < COLS && k < n_hyp) {
     J_out[k] = sum;
     counts_out[2 * k] = counts[2 * k]; counts_out[2 * k + 1] = counts[2 * k + 1];
     counts[2 * k] = 0; counts[2 * k + 1] = 0;
   }
+}
+constexpr int GAIN_ROWS = 128;
+__global__ void __launch_bounds__(256) ransac_gain_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride,
+                                                          int *__restrict__ counts, double *__restrict__ J_out, int *__restrict__ counts_out) {
+  __shared__ double s_rows[GAIN_ROWS * 64];
+  gain_sums<64, GAIN_ROWS>(gain, len, n_hyp, kstride, counts, J_out, counts_out, s_rows);
+}
+constexpr int GAIN_FEW = 16, GAIN_FEW_ROWS = 384;      // up to 16 hypotheses: 16 columns x 384 rows in the same 48 KB
+__global__ void __launch_bounds__(256) ransac_gain_few_kernel(const double *__restrict__ gain, int len, int n_hyp, int kstride,
+                                                              int *__restrict__ counts, double *__restrict__ J_out, int *__restrict__ counts_out) {
+  __shared__ double s_rows[GAIN_FEW_ROWS * GAIN_FEW];
+  gain_sums<GAIN_FEW, GAIN_FEW_ROWS>(gain, len, n_hyp, kstride, counts, J_out, counts_out, s_rows);
 }
 
 RansacGpu::~RansacGpu() {
@@ -230,7 +246,9 @@ static bool gpu_score(RansacGpu *ws, int len, int n, int err_type, int do_sym, d
   RS_CHECK(hipMemcpyAsync(ws->hyp_dev, ws->hyp_host, sizeof(HypDev) * n, hipMemcpyHostToDevice, ws->stream));
   hipLaunchKernelGGL(ransac_score_kernel, dim3((len + 255) / 256, n), dim3(256), 0, ws->stream, ws->u_dev, len, (const HypDev *)ws->hyp_dev, err_type,
                      do_sym, th, th_check, ws->d_dev, ws->gain_dev, ws->hyp_cap, ws->counts_dev);
-  hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->counts_dev, ws->J_host,
+  if (n <= GAIN_FEW) hipLaunchKernelGGL(ransac_gain_few_kernel, dim3(1), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->counts_dev, ws->J_host,
+                     ws->counts_host);
+  else hipLaunchKernelGGL(ransac_gain_kernel, dim3((n + 63) / 64), dim3(256), 0, ws->stream, ws->gain_dev, len, n, ws->hyp_cap, ws->counts_dev, ws->J_host,
                      ws->counts_host);
   RS_CHECK(hipGetLastError());
   RS_CHECK(mods::stream_wait(ws->stream));
