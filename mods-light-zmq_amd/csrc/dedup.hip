@@ -150,19 +150,9 @@ __global__ __launch_bounds__(1024) void dup_resolve_kernel(DupBatch b, int lds_n
     }
     if (!__syncthreads_or(changed)) break;
   }
-  // total first (it fixes the packed layout), then the compaction in sorted order
-  int mine = 0;
-  for (int p = tid; p < n; p += 1024) mine += s_state[p] == 1 ? 1 : 0;
-  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-  if (lane == 0) s_wave[wv] = mine;
-  __syncthreads();
-  int total = 0;
-  for (int q = 0; q < 16; q++) total += s_wave[q];
-  __syncthreads();
-  const mods_tentative *st = (const mods_tentative *)src;
-  const double *su = (const double *)(src + tent_u6_off((size_t)n)), *sl = (const double *)(src + tent_laf_off((size_t)n));
-  mods_tentative *dt = (mods_tentative *)dst;
-  double *du = (double *)(dst + tent_u6_off((size_t)total)), *dl = (double *)(dst + tent_laf_off((size_t)total));
+  // the kept positions' places in the packed output (sorted order), left in the near-count array - dead by now - for
+  // dup_copy_kernel: one workgroup moving 200 bytes per kept correspondence was most of this kernel's time
+  int *slot_of = dj_cnt(b, blockIdx.x);
   if (tid == 0) s_base = 0;
   __syncthreads();
   for (int p0 = 0; p0 < n; p0 += 1024) {
@@ -173,20 +163,35 @@ __global__ __launch_bounds__(1024) void dup_resolve_kernel(DupBatch b, int lds_n
     __syncthreads();
     int off = s_base;
     for (int q = 0; q < wv; q++) off += s_wave[q];
-    if (keep) {
-      const int slot = off + __popcll(mm & ((1ull << lane) - 1ull));
-      const int i = order[p];
-      dt[slot] = st[i];
-#pragma unroll
-      for (int q = 0; q < 6; q++) du[(size_t)slot * 6 + q] = su[(size_t)i * 6 + q];
-#pragma unroll
-      for (int q = 0; q < 14; q++) dl[(size_t)slot * 14 + q] = sl[(size_t)i * 14 + q];
-    }
+    if (p < n) slot_of[p] = keep ? off + __popcll(mm & ((1ull << lane) - 1ull)) : -1;
     __syncthreads();
     if (tid == 0) { int t = s_base; for (int q = 0; q < 16; q++) t += s_wave[q]; s_base = t; }
     __syncthreads();
   }
+  const int total = s_base;
   if (tid == 0) { *n_dst = total; *status = 0; }
+}
+
+// grid = (tiles of 256 positions, jobs): the kept correspondences of a resolved list move to their places in the packed output
+__global__ __launch_bounds__(256) void dup_copy_kernel(DupBatch b) {
+  const DupJob &J = b.job[blockIdx.y];
+  if (*J.status != 0) return;
+  const int n = *J.n_src, total = *J.n_dst;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int slot = dj_cnt(b, blockIdx.y)[p];
+  if (slot < 0) return;
+  const int i = dj_order(b, blockIdx.y)[p];
+  const char *src = J.src; char *dst = J.dst;
+  const mods_tentative *st = (const mods_tentative *)src;
+  const double *su = (const double *)(src + tent_u6_off((size_t)n)), *sl = (const double *)(src + tent_laf_off((size_t)n));
+  mods_tentative *dt = (mods_tentative *)dst;
+  double *du = (double *)(dst + tent_u6_off((size_t)total)), *dl = (double *)(dst + tent_laf_off((size_t)total));
+  dt[slot] = st[i];
+#pragma unroll
+  for (int q = 0; q < 6; q++) du[(size_t)slot * 6 + q] = su[(size_t)i * 6 + q];
+#pragma unroll
+  for (int q = 0; q < 14; q++) dl[(size_t)slot * 14 + q] = sl[(size_t)i * 14 + q];
 }
 
 // Queues the filter behind the searches that leave their packed lists at job[i].src and the lengths at *job[i].n_src
@@ -228,6 +233,7 @@ int dup_filter_dev(mods_ctx *c, const DupJob *jobs, int n_jobs, int grid_n, doub
   hipLaunchKernelGGL(dup_near_kernel, dim3(tiles, tiles, n_jobs), dim3(256), 0, c->stream, b);
   const int lds = (int)std::min((size_t)DUP_MAX_N, ((size_t)grid_n + 63) & ~(size_t)63);
   hipLaunchKernelGGL(dup_resolve_kernel, dim3(n_jobs), dim3(1024), (size_t)lds, c->stream, b, lds);
+  hipLaunchKernelGGL(dup_copy_kernel, dim3(tiles, n_jobs), dim3(256), 0, c->stream, b);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }
