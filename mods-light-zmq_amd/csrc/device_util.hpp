@@ -155,69 +155,73 @@ template <bool TOUCH> __device__ __forceinline__ float tap_combine_t(const TapLo
 // store(row, col, value) is called for every sample of the window.
 // The rows [row_begin, row_end) of the window are sampled (all columns).  TOUCH = whether the window touches the image border
 // (interpolateCheckBorders): the same for every lane, so the two forms of the tap are two instantiations behind one scalar branch.
+#ifndef SAMPLE_TC
+#define SAMPLE_TC 8          // columns of a sampling tile (64 / SAMPLE_TC rows): a lane adds SAMPLE_TC column steps between two of its taps
+#endif
 template <bool WIDE, bool TOUCH, class Store>
 __device__ __forceinline__ void sample_tiles_rows_t(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
                                                     float a21, float a22, int n, int row_begin, int row_end, int wv, int nw, Store store) {
+  constexpr int TC = SAMPLE_TC, TR = 64 / TC;
   const int half = n / 2;
-  const int lane = threadIdx.x & 63, tcol = lane & 7, trow = lane >> 3;
+  const int lane = threadIdx.x & 63, tcol = lane & (TC - 1), trow = lane / TC;
   float rx = fx - (float)half * a12;
   float ry = fy - (float)half * a22;
-  // the row steps all lanes share as a scalar-counted loop, the lane's own 0..7 as selects (a loop with a per-lane trip count costs
+  // the row steps all lanes share as a scalar-counted loop, the lane's own 0..TR-1 as selects (a loop with a per-lane trip count costs
   // five vector instructions per step)
-  for (int q = __builtin_amdgcn_readfirstlane(row_begin + wv * 8); q > 0; q--) { rx += a12; ry += a22; }
+  for (int q = __builtin_amdgcn_readfirstlane(row_begin + wv * TR); q > 0; q--) { rx += a12; ry += a22; }
 #pragma unroll
-  for (int q = 0; q < 7; q++) { const bool m = q < trow; const float nx = rx + a12, ny = ry + a22; rx = m ? nx : rx; ry = m ? ny : ry; }
-  for (int r0 = row_begin + wv * 8; r0 < row_end; r0 += nw * 8) {
+  for (int q = 0; q < TR - 1; q++) { const bool m = q < trow; const float nx = rx + a12, ny = ry + a22; rx = m ? nx : rx; ry = m ? ny : ry; }
+  for (int r0 = row_begin + wv * TR; r0 < row_end; r0 += nw * TR) {
     const int row = r0 + trow;
     float WX = rx - (float)half * a11;
     float WY = ry - (float)half * a21;
 #pragma unroll
-    for (int q = 0; q < 7; q++) { const bool m = q < tcol; const float nx = WX + a11, ny = WY + a21; WX = m ? nx : WX; WY = m ? ny : WY; }
+    for (int q = 0; q < TC - 1; q++) { const bool m = q < tcol; const float nx = WX + a11, ny = WY + a21; WX = m ? nx : WX; WY = m ? ny : WY; }
     // column tiles in batches: eight per batch while at least eight remain (wide windows only), four while three or more
     // remain, then two: a wave waits for every batch, so the number of batches per row of tiles is what its time follows
     int c0 = 0;
-    for (; WIDE && c0 + 64 <= n; c0 += 64) {
+    for (; WIDE && c0 + 8 * TC <= n; c0 += 8 * TC) {
       TapLoads t[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         t[u] = tap_load_t<TOUCH>(img, w, h, WX, WY, row < row_end);
 #pragma unroll
-        for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
+        for (int q = 0; q < TC; q++) { WX += a11; WY += a21; }
       }
 #pragma unroll
       for (int u = 0; u < 8; u++)
-        if (row < row_end) store(row, c0 + 8 * u + tcol, tap_combine_t<TOUCH>(t[u]));
+        if (row < row_end) store(row, c0 + TC * u + tcol, tap_combine_t<TOUCH>(t[u]));
     }
-    for (; c0 + 16 < n; c0 += 32) {              // four column tiles per batch while three or more remain (8 loads in flight)
+    for (; c0 + 2 * TC < n; c0 += 4 * TC) {              // four column tiles per batch while three or more remain (8 loads in flight)
       TapLoads t[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        t[u] = tap_load_t<TOUCH>(img, w, h, WX, WY, row < row_end && c0 + 8 * u + tcol < n);
+        t[u] = tap_load_t<TOUCH>(img, w, h, WX, WY, row < row_end && c0 + TC * u + tcol < n);
 #pragma unroll
-        for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
+        for (int q = 0; q < TC; q++) { WX += a11; WY += a21; }
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int col = c0 + 8 * u + tcol;
+        const int col = c0 + TC * u + tcol;
         if (row < row_end && col < n) store(row, col, tap_combine_t<TOUCH>(t[u]));
       }
     }
-    for (; c0 < n; c0 += 16) {
+    for (; c0 < n; c0 += 2 * TC) {
       TapLoads t[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        t[u] = tap_load_t<TOUCH>(img, w, h, WX, WY, row < row_end && c0 + 8 * u + tcol < n);
+        t[u] = tap_load_t<TOUCH>(img, w, h, WX, WY, row < row_end && c0 + TC * u + tcol < n);
 #pragma unroll
-        for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
+        for (int q = 0; q < TC; q++) { WX += a11; WY += a21; }
       }
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        const int col = c0 + 8 * u + tcol;
+        const int col = c0 + TC * u + tcol;
         if (row < row_end && col < n) store(row, col, tap_combine_t<TOUCH>(t[u]));
       }
     }
-    if (r0 + nw * 8 >= row_end) break;          // (no walk behind the wave's last tile row)
-    for (int q = nw * 8; q > 0; q--) { rx += a12; ry += a22; }
+    if (r0 + nw * TR >= row_end) break;          // (no walk behind the wave's last tile row)
+    for (int q = nw * TR; q > 0; q--) { rx += a12; ry += a22; }
   }
 }
 template <bool WIDE, class Store>

@@ -9,11 +9,11 @@
 // Two kernels per batch:
 //   extract : one workgroup per region -> the ps x ps patch (before photometric normalisation),
 //             written to HBM.  The reference samples a P2 x P2 region (P2 = 2*ceil(s*mrSize)+3), blurs
-//             all of it and resamples 41 x 41 points on an axis-aligned grid.  Only the blurred values
-//             at the <= 2ps grid rows x 2ps grid columns are ever read, so the row pass runs on every row
-//             but only the needed columns and the column pass only on the needed (row, column) pairs -
-//             each value computed exactly as the full blur would.  Regions with P2 <= 80 keep the
-//             sampled region and the row-pass strip in LDS; larger ones use an HBM slab per workgroup.
+//             all of it and resamples 41 x 41 points on an axis-aligned grid.  Windows with P2 <= 80 (fewer
+//             columns than the 2 ps grid lines) are blurred in full inside LDS (extract_small_kernel).  Of a
+//             larger window only the blurred values at the <= 2ps grid rows x 2ps grid columns are ever read,
+//             so its row pass runs on every row but only the needed columns and its column pass only on the
+//             needed (row, column) pairs - each value computed exactly as the full blur would (big_* kernels).
 //   sift    : one workgroup per region: photometric normalisation, gradients, 4x4x8 histogram,
 //             normalisation, quantisation.
 // Every floating-point accumulation the reference performs sequentially keeps its order: sample
@@ -64,49 +64,6 @@ __device__ __forceinline__ RegionGeom region_geom(const mods_region &r, double d
   g.scale = float(P) / float(ps);
   g.P2 = ((double)g.scale > 0.4) ? P + 2 : 0;
   return g;
-}
-
-// interpolate(img, x, y, A) -> dst (n x n, row-major), helpers.cpp:551-626.  All 256 threads take a
-// contiguous run of samples in raster order; the running coordinates of a run are rebuilt by
-// replaying the reference's fp32 additions (row steps, then column steps) up to its first sample.
-__device__ void sample_region(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12, float a21,
-                              float a22, int n, float *dst) {
-  const bool touch = check_borders(w, h, fx, fy, a11, a12, a21, a22, n, n);
-  const int half = n / 2;
-  const int total = n * n;
-  const int L = (total + 255) / 256;
-  int idx = threadIdx.x * L;
-  if (idx >= total) return;
-  int row = idx / n, col = idx - row * n;
-  float rx = fx - (float)half * a12;
-  float ry = fy - (float)half * a22;
-  for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
-  float WX = rx - (float)half * a11;
-  float WY = ry - (float)half * a21;
-  for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
-  const int end = min(total, idx + L);
-  // four taps per step: coordinates first (sequential fp32 additions), then 16 loads, then the lerps
-  while (idx < end) {
-    TapLoads t[4];
-    int cnt = 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (idx + u < end) {
-        t[u] = tap_load(img, w, h, WX, WY, touch);
-        cnt++;
-        if (++col == n) {
-          col = 0;
-          rx += a12; ry += a22;
-          WX = rx - (float)half * a11;
-          WY = ry - (float)half * a21;
-        } else { WX += a11; WY += a21; }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (u < cnt) dst[idx + u] = tap_combine(t[u]);
-    idx += cnt;
-  }
 }
 
 // Gaussian taps for sigma (getGaussianKernel CV_32F) into s_tap; resampling sequence X_i (= Y_i) of
@@ -181,122 +138,6 @@ int launch_blur_table(mods_ctx *ctx, int ps) {
 
 // row stride of the row-pass strip T (2 * ps columns, padded so that two adjacent column pairs are one aligned float4)
 __host__ __device__ __forceinline__ int t_stride(int ps) { return (2 * ps + 3) & ~3; }
-
-// interpolate() as sample_region, stored transposed: dst[col * stride + row] (stride = n rounded up to 4)
-__device__ void sample_region_t(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12, float a21,
-                                float a22, int n, int stride, float *dst) {
-  const bool touch = check_borders(w, h, fx, fy, a11, a12, a21, a22, n, n);
-  const int half = n / 2;
-  const int total = n * n;
-  const int L = (total + 255) / 256;
-  int idx = threadIdx.x * L;
-  if (idx >= total) return;
-  int row = idx / n, col = idx - row * n;
-  float rx = fx - (float)half * a12;
-  float ry = fy - (float)half * a22;
-  for (int q = 0; q < row; q++) { rx += a12; ry += a22; }
-  float WX = rx - (float)half * a11;
-  float WY = ry - (float)half * a21;
-  for (int q = 0; q < col; q++) { WX += a11; WY += a21; }
-  const int end = min(total, idx + L);
-  while (idx < end) {
-    TapLoads t[8];
-    int at[8];
-    int cnt = 0;
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      if (idx + u < end) {
-        t[u] = tap_load(img, w, h, WX, WY, touch);
-        at[u] = col * stride + row;
-        cnt++;
-        if (++col == n) {
-          col = 0; row++;
-          rx += a12; ry += a22;
-          WX = rx - (float)half * a11;
-          WY = ry - (float)half * a21;
-        } else { WX += a11; WY += a21; }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (u < cnt) dst[at[u]] = tap_combine(t[u]);
-    idx += cnt;
-  }
-}
-
-// row pass of the separable blur at the needed columns from a transposed tile St[col][stride]:
-//   T[y][q] = sum_j tap[j] * S[y][clamp(cidx[q] - r + j)], taps left to right, fused multiply-adds (the contract of
-//   pyramid.hip: cv::GaussianBlur as an FMA build of OpenCV evaluates it); 5 taps: centre, then symmetric pairs.
-// A thread owns four consecutive rows (one float4 per tap) of one column pair (x0, x1): x1 = x0 + 1, whose window is the
-// window of x0 shifted by one sample (also after clamping), or x1 = x0 for a grid line clamped at the edge.
-__device__ __forceinline__ void row_pass_t(const float *St, float *T, int P2, int stride, int ps, int n_tap, const float *s_tap,
-                                           const int *s_cidx) {
-  const int r_tap = n_tap >> 1, nq = stride >> 2, ps2 = t_stride(ps);
-  for (int e = threadIdx.x; e < nq * ps; e += 256) {
-    const int pi = e / nq, y = 4 * (e - pi * nq);
-    const int x0 = s_cidx[2 * pi], x1 = s_cidx[2 * pi + 1];
-    const float *p = St + y;
-    if (n_tap == 5) {   // cv::GaussianBlur's row filter for ksize <= 5 (SymmRowSmallFilter): centre tap, then the symmetric pairs
-      float4 v[6];
-#pragma unroll
-      for (int u = 0; u < 6; u++) {
-        int xb = x0 - 2 + u; xb = xb < 0 ? 0 : (xb > P2 - 1 ? P2 - 1 : xb);
-        v[u] = *(const float4 *)(p + xb * stride);
-      }
-      const float k0 = s_tap[2], k1 = s_tap[3], k2 = s_tap[4];
-      float4 a0 = make_float4(v[2].x * k0, v[2].y * k0, v[2].z * k0, v[2].w * k0);
-      float4 a1 = make_float4(v[3].x * k0, v[3].y * k0, v[3].z * k0, v[3].w * k0);
-      a0.x = fmaf(v[1].x + v[3].x, k1, a0.x); a0.y = fmaf(v[1].y + v[3].y, k1, a0.y); a0.z = fmaf(v[1].z + v[3].z, k1, a0.z); a0.w = fmaf(v[1].w + v[3].w, k1, a0.w);
-      a1.x = fmaf(v[2].x + v[4].x, k1, a1.x); a1.y = fmaf(v[2].y + v[4].y, k1, a1.y); a1.z = fmaf(v[2].z + v[4].z, k1, a1.z); a1.w = fmaf(v[2].w + v[4].w, k1, a1.w);
-      a0.x = fmaf(v[0].x + v[4].x, k2, a0.x); a0.y = fmaf(v[0].y + v[4].y, k2, a0.y); a0.z = fmaf(v[0].z + v[4].z, k2, a0.z); a0.w = fmaf(v[0].w + v[4].w, k2, a0.w);
-      a1.x = fmaf(v[1].x + v[5].x, k2, a1.x); a1.y = fmaf(v[1].y + v[5].y, k2, a1.y); a1.z = fmaf(v[1].z + v[5].z, k2, a1.z); a1.w = fmaf(v[1].w + v[5].w, k2, a1.w);
-      if (x1 == x0) a1 = a0;
-      float *o = T + y * ps2 + 2 * pi;
-      *(float2 *)o = make_float2(a0.x, a1.x);
-      if (y + 1 < P2) *(float2 *)(o + ps2) = make_float2(a0.y, a1.y);
-      if (y + 2 < P2) *(float2 *)(o + 2 * ps2) = make_float2(a0.z, a1.z);
-      if (y + 3 < P2) *(float2 *)(o + 3 * ps2) = make_float2(a0.w, a1.w);
-      continue;
-    }
-    int xa = x0 - r_tap; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
-    float4 prev = *(const float4 *)(p + xa * stride);
-    float t = s_tap[0];
-    float4 s0 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
-    xa = x0 - r_tap + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
-    prev = *(const float4 *)(p + xa * stride);
-    float4 s1 = make_float4(t * prev.x, t * prev.y, t * prev.z, t * prev.w);
-    int j = 1;
-    for (; j + 3 < n_tap; j += 4) {
-      float4 c[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        xa = x0 - r_tap + j + u + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
-        c[u] = *(const float4 *)(p + xa * stride);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        t = s_tap[j + u];
-        s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
-        s1.x = fmaf(t, c[u].x, s1.x); s1.y = fmaf(t, c[u].y, s1.y); s1.z = fmaf(t, c[u].z, s1.z); s1.w = fmaf(t, c[u].w, s1.w);
-        prev = c[u];
-      }
-    }
-    for (; j < n_tap; j++) {
-      xa = x0 - r_tap + j + 1; xa = xa < 0 ? 0 : (xa > P2 - 1 ? P2 - 1 : xa);
-      const float4 c = *(const float4 *)(p + xa * stride);
-      t = s_tap[j];
-      s0.x = fmaf(t, prev.x, s0.x); s0.y = fmaf(t, prev.y, s0.y); s0.z = fmaf(t, prev.z, s0.z); s0.w = fmaf(t, prev.w, s0.w);
-      s1.x = fmaf(t, c.x, s1.x); s1.y = fmaf(t, c.y, s1.y); s1.z = fmaf(t, c.z, s1.z); s1.w = fmaf(t, c.w, s1.w);
-      prev = c;
-    }
-    if (x1 == x0) s1 = s0;
-    float *o = T + y * ps2 + 2 * pi;
-    *(float2 *)o = make_float2(s0.x, s1.x);
-    if (y + 1 < P2) *(float2 *)(o + ps2) = make_float2(s0.y, s1.y);
-    if (y + 2 < P2) *(float2 *)(o + 2 * ps2) = make_float2(s0.z, s1.z);
-    if (y + 3 < P2) *(float2 *)(o + 3 * ps2) = make_float2(s0.w, s1.w);
-  }
-}
 
 // column pass value at (needed row y, strip column q): centre tap first, symmetric pairs
 __device__ __forceinline__ float col_value(const float *T, int P2, int ps2, int y, int q, int r_tap, const float *s_tap) {
@@ -388,23 +229,120 @@ __device__ __forceinline__ void col_resample_pair(const float *T, int ts, int P2
   }
 }
 
-__device__ __forceinline__ void col_resample(const float *T, int P2, int ps, int n_tap, float scale, const float *s_tap,
-                                             const float *s_seq, const int *s_cidx, float *patch_out) {
+// ---- the LDS tier's blur as a FULL separable blur of the window (P2 < 2 ps: fewer blurred values than the 4 per output pixel) ----
+// A window of the LDS tier has P2 <= 80 < 2 * 41 columns, so the "needed columns" of the strip form are all of them, several times
+// over (82 strip columns for 19..80 window columns), and its column pass makes four blurred values per OUTPUT pixel where the
+// window has only P2 * P2 of them (P2 = 30: 900 against 6 724).  Here every blurred value is made once - each by the same
+// operations in the same order as the strip form (and as cv::GaussianBlur: row pass left to right, 5 taps centre then pairs;
+// column pass centre then symmetric pairs, REPLICATE borders) - and the 41 x 41 resampling reads the blurred window.
+// column stride of the transposed window S: a multiple of 4 whose quarter is odd - the float4 reads of the row pass (lanes on
+// consecutive columns) and the tile-wise writes of the sampler (8 columns x 8 rows per wave) then spread over all banks
+__host__ __device__ __forceinline__ int odd4(int n) { const int q = (n + 3) >> 2; return 4 * (q | 1); }
+// e / d for 0 <= e < 2^16, 0 < d <= 256 without the integer division's expansion (rcp = 1.f / d): (e + 0.5) / d is at least
+// 0.5 / d away from an integer, far more than the product's rounding error
+__device__ __forceinline__ int small_div(int e, float rcp) { return (int)(((float)e + 0.5f) * rcp); }
+
+// row pass, all columns: T[y][x] (row-major, row stride ts) from the transposed window St[x][y] (column stride st)
+__device__ __forceinline__ void row_pass_full(const float *St, float *T, int P2, int st, int ts, int n_tap, const float *s_tap) {
+  const int r_tap = n_tap >> 1, nq = (P2 + 3) >> 2;
+  const float rcp = 1.0f / (float)P2;
+  for (int e = threadIdx.x; e < nq * P2; e += 256) {
+    const int yq = small_div(e, rcp), x = e - yq * P2, y = 4 * yq;
+    const float *p = St + y;
+    float4 s;
+    if (n_tap == 5) {   // SymmRowSmallFilter: centre tap, then the symmetric pairs
+      float4 v[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        int xb = x - 2 + u; xb = xb < 0 ? 0 : (xb > P2 - 1 ? P2 - 1 : xb);
+        v[u] = *(const float4 *)(p + xb * st);
+      }
+      const float k0 = s_tap[2], k1 = s_tap[3], k2 = s_tap[4];
+      s = make_float4(v[2].x * k0, v[2].y * k0, v[2].z * k0, v[2].w * k0);
+      s.x = fmaf(v[1].x + v[3].x, k1, s.x); s.y = fmaf(v[1].y + v[3].y, k1, s.y); s.z = fmaf(v[1].z + v[3].z, k1, s.z); s.w = fmaf(v[1].w + v[3].w, k1, s.w);
+      s.x = fmaf(v[0].x + v[4].x, k2, s.x); s.y = fmaf(v[0].y + v[4].y, k2, s.y); s.z = fmaf(v[0].z + v[4].z, k2, s.z); s.w = fmaf(v[0].w + v[4].w, k2, s.w);
+    } else {
+      int xa = x - r_tap; xa = xa < 0 ? 0 : xa;
+      float4 c = *(const float4 *)(p + xa * st);
+      float t = s_tap[0];
+      s = make_float4(t * c.x, t * c.y, t * c.z, t * c.w);
+      int j = 1;
+      for (; j + 1 < n_tap; j += 2) {
+        int xb = x - r_tap + j; xb = xb < 0 ? 0 : (xb > P2 - 1 ? P2 - 1 : xb);
+        int xc = x - r_tap + j + 1; xc = xc < 0 ? 0 : (xc > P2 - 1 ? P2 - 1 : xc);
+        const float4 c0 = *(const float4 *)(p + xb * st), c1 = *(const float4 *)(p + xc * st);
+        t = s_tap[j];
+        s.x = fmaf(t, c0.x, s.x); s.y = fmaf(t, c0.y, s.y); s.z = fmaf(t, c0.z, s.z); s.w = fmaf(t, c0.w, s.w);
+        t = s_tap[j + 1];
+        s.x = fmaf(t, c1.x, s.x); s.y = fmaf(t, c1.y, s.y); s.z = fmaf(t, c1.z, s.z); s.w = fmaf(t, c1.w, s.w);
+      }
+      for (; j < n_tap; j++) {
+        int xb = x - r_tap + j; xb = xb < 0 ? 0 : (xb > P2 - 1 ? P2 - 1 : xb);
+        c = *(const float4 *)(p + xb * st);
+        t = s_tap[j];
+        s.x = fmaf(t, c.x, s.x); s.y = fmaf(t, c.y, s.y); s.z = fmaf(t, c.z, s.z); s.w = fmaf(t, c.w, s.w);
+      }
+    }
+    float *o = T + y * ts + x;
+    o[0] = s.x;
+    if (y + 1 < P2) o[ts] = s.y;
+    if (y + 2 < P2) o[2 * ts] = s.z;
+    if (y + 3 < P2) o[3 * ts] = s.w;
+  }
+}
+// column pass, all rows: B[y][x] from T[y][x], four adjacent columns per item (centre tap, then the symmetric pairs)
+__device__ __forceinline__ void col_pass_full(const float *T, float *B, int P2, int ts, int n_tap, const float *s_tap) {
+  const int r_tap = n_tap >> 1, nx = ts >> 2;
+  const float rcp = 1.0f / (float)nx;
+  for (int e = threadIdx.x; e < nx * P2; e += 256) {
+    const int y = small_div(e, rcp), xq = e - y * nx;
+    const float *c = T + 4 * xq;
+    const float4 m = *(const float4 *)(c + y * ts);
+    const float tc = s_tap[r_tap];
+    float4 s = make_float4(tc * m.x, tc * m.y, tc * m.z, tc * m.w);
+    int j = 1;
+    for (; j + 1 <= r_tap; j += 2) {
+      const int yu0 = min(y + j, P2 - 1), yd0 = max(y - j, 0), yu1 = min(y + j + 1, P2 - 1), yd1 = max(y - j - 1, 0);
+      const float4 u0 = *(const float4 *)(c + yu0 * ts), d0 = *(const float4 *)(c + yd0 * ts);
+      const float4 u1 = *(const float4 *)(c + yu1 * ts), d1 = *(const float4 *)(c + yd1 * ts);
+      float t = s_tap[r_tap + j];
+      s.x = fmaf(t, u0.x + d0.x, s.x); s.y = fmaf(t, u0.y + d0.y, s.y); s.z = fmaf(t, u0.z + d0.z, s.z); s.w = fmaf(t, u0.w + d0.w, s.w);
+      t = s_tap[r_tap + j + 1];
+      s.x = fmaf(t, u1.x + d1.x, s.x); s.y = fmaf(t, u1.y + d1.y, s.y); s.z = fmaf(t, u1.z + d1.z, s.z); s.w = fmaf(t, u1.w + d1.w, s.w);
+    }
+    for (; j <= r_tap; j++) {
+      const int yu = min(y + j, P2 - 1), yd = max(y - j, 0);
+      const float4 u = *(const float4 *)(c + yu * ts), d = *(const float4 *)(c + yd * ts);
+      const float t = s_tap[r_tap + j];
+      s.x = fmaf(t, u.x + d.x, s.x); s.y = fmaf(t, u.y + d.y, s.y); s.z = fmaf(t, u.z + d.z, s.z); s.w = fmaf(t, u.w + d.w, s.w);
+    }
+    *(float4 *)(B + y * ts + 4 * xq) = s;
+  }
+}
+// interpolate(smoothed, c0, c0, scale, 0, 0, scale) -> ps x ps from the blurred window B (the arithmetic of col_resample_pair)
+__device__ __forceinline__ void resample_full(const float *B, int P2, int ts, int ps, float scale, const float *s_seq, const int *s_cidx,
+                                              float *__restrict__ out) {
   const float c0 = (float)(P2 >> 1);
   const bool touch2 = check_borders(P2, P2, c0, c0, scale, 0.f, 0.f, scale, ps, ps);
-  const int np = (ps + 1) >> 1, ts = t_stride(ps);
-  for (int e = threadIdx.x; e < ps * np; e += 256) {
-    const int j = e / np, m = e - j * np;
-    float v0, v1;
-    col_resample_pair(T, ts, P2, ps, n_tap >> 1, touch2, s_tap, s_seq, s_cidx, j, m, &v0, &v1);
-    patch_out[j * ps + 2 * m] = v0;
-    if (2 * m + 1 < ps) patch_out[j * ps + 2 * m + 1] = v1;
+  const float rcp = 1.0f / (float)ps;
+  for (int e = threadIdx.x; e < ps * ps; e += 256) {
+    const int j = small_div(e, rcp), i = e - j * ps;
+    const float WY = s_seq[j], WX = s_seq[i];
+    const int2 yy = *(const int2 *)(s_cidx + 2 * j), xx = *(const int2 *)(s_cidx + 2 * i);
+    const int y = touch2 ? (int)floorf(WY) : (int)WY, x = touch2 ? (int)floorf(WX) : (int)WX;
+    const float *b0 = B + yy.x * ts, *b1 = B + yy.y * ts;
+    const float r00 = b0[xx.x], r01 = b0[xx.y], r10 = b1[xx.x], r11 = b1[xx.y];
+    const float wx = WX - (float)x;
+    const float I1 = wx * (r01 - r00) + r00;
+    const float v = (WY - y) * (wx * (r11 - r10) + r10 - I1) + I1;
+    const bool ok = !touch2 || (WY >= 0 && y < P2 - 1 && WX >= 0 && x < P2 - 1);
+    out[e] = ok ? v : 0.f;
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // extract, LDS tier: direct branch and P2 <= SMALL_CAP.  grid = (N, n_img), block = 256.
-// dynamic LDS: S cap*cap | T cap*2ps | cx,cy aliases S | seq 2ps | cidx 2ps | taps 32 | red 2 doubles
+// dynamic LDS: S cap*odd4(cap) (transposed window, then the blurred window) | T cap*cap4 (row pass) | seq 2ps | cidx 2ps | taps 32 | red 2 doubles
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, ES_MINB) void extract_small_kernel(const float *__restrict__ img_all, DescConst k,
                                                             const mods_region *__restrict__ reg_all, const int *__restrict__ items,
@@ -414,8 +352,8 @@ __global__ __launch_bounds__(256, ES_MINB) void extract_small_kernel(const float
   const int ps = k.desc_ps, pp = ps * ps, ps2 = 2 * ps;
   const int cap = k.p2_hi > 4 ? k.p2_hi : 4;       // (the direct branch writes to the patch store, not to LDS)
   float *s_S = smem;
-  float *s_T = s_S + cap * ((cap + 3) & ~3);
-  float *s_seq = s_T + cap * t_stride(ps);
+  float *s_T = s_S + cap * odd4(cap);
+  float *s_seq = s_T + cap * ((cap + 3) & ~3);
   int *s_cidx = (int *)(s_seq + ps2);
   float *s_tap = (float *)(s_cidx + ps2);
   double *s_red = lds_doubles(smem, s_tap + 32);
@@ -436,9 +374,9 @@ __global__ __launch_bounds__(256, ES_MINB) void extract_small_kernel(const float
     PROF_MARK(0)
     if (g.P2 > 0) {
       const int n_tap = ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1;
-      const int stride = (g.P2 + 3) & ~3;
+      const int stride = odd4(g.P2);
       sample_tiles(img, k.w, k.h, g.fx, g.fy, g.f11, g.f12, g.f21, g.f22, g.P2, threadIdx.x >> 6, 4,
-                   [&](int row, int col, float v) { s_S[col * stride + row] = v; });   // transposed: see row_pass_t
+                   [&](int row, int col, float v) { s_S[col * stride + row] = v; });   // transposed: see row_pass_full
       PROF_MARK(1)
       if (blur_table && n_tap <= 31 && ps <= 63) {     // taps, resampling sequence and source indices of this P2 from the table
         const float *e = blur_table + (size_t)g.P2 * BT_ENTRY;
@@ -449,10 +387,13 @@ __global__ __launch_bounds__(256, ES_MINB) void extract_small_kernel(const float
         __syncthreads();
       } else blur_setup(g.P2, g.scale, ps, n_tap, s_tap, s_seq, s_cidx, s_red);
       PROF_MARK(2)
-      row_pass_t(s_S, s_T, g.P2, stride, ps, n_tap, s_tap, s_cidx);
+      const int ts = (g.P2 + 3) & ~3;
+      row_pass_full(s_S, s_T, g.P2, stride, ts, n_tap, s_tap);
       __syncthreads();
       PROF_MARK(3)
-      col_resample(s_T, g.P2, ps, n_tap, g.scale, s_tap, s_seq, s_cidx, out);
+      col_pass_full(s_T, s_S, g.P2, ts, n_tap, s_tap);        // the blurred window takes the sampled one's place
+      __syncthreads();
+      resample_full(s_S, g.P2, ts, ps, g.scale, s_seq, s_cidx, out);
       PROF_MARK(4)
 #ifdef EXTRACT_PROF
       pn++;
@@ -909,7 +850,10 @@ __global__ __launch_bounds__(256) void big_fused_kernel(const float *__restrict_
 #endif
 }
 
-// wave per 64 pairs of adjacent output pixels of a region: column pass + resampling -> patch
+// wave per 64 pairs of adjacent output pixels of a region: column pass + resampling -> patch.  (Round 6 measured this kernel at 0.87 of
+// the texture addresser and 27 % of the vector ALU - every strip value is fetched ~9 times through the vector cache - and built the
+// obvious remedy, the strip of a region staged once in LDS by a workgroup per region: 0.607 against 0.550 ms per batch, three
+// workgroups of 53 KB per CU load, then compute, and hide less than 24 independent waves do; left as it is.)
 __global__ __launch_bounds__(256) void big_colres_kernel(DescConst k, const BigLists *__restrict__ bl, const BigRegion *__restrict__ regions,
                                                          int max_regions, const float *__restrict__ pool, float *__restrict__ patches,
                                                          const int *__restrict__ err_flag) {
@@ -1613,7 +1557,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
                      ctx->region_count, bl, bregs, sitems, ritems, fitems, small_items, small_cap_items, std::min(small_cap, EXTRACT_T_LO), std::min(small_cap, EXTRACT_T_MID), max_big, max_items,
                      pool_elems, ctx->desc_err_dev);
   // LDS tier in three launches over the work lists of big_classify_kernel: a workgroup's LDS follows the largest window of its class
-  // (26 / 39 / 53 KB for the 41-pixel patch: 6 / 4 / 3 workgroups per CU), and the 48 < P2 <= 80 regions of a 1080p image are as
+  // (20 / 34 / 53 KB: 8 / 4 / 3 workgroups per CU by LDS), and the 48 < P2 <= 80 regions of a 1080p image are as
   // much sampling work as the 6 800 smaller ones; the HBM tier takes P2 > small_cap
   {
     const int tiers[4] = {-1, std::min(small_cap, EXTRACT_T_LO), std::min(small_cap, EXTRACT_T_MID), small_cap};
@@ -1622,7 +1566,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
       DescConst kt = k;
       kt.p2_lo = tiers[t]; kt.p2_hi = tiers[t + 1];
       const size_t capS = kt.p2_hi > 4 ? kt.p2_hi : 4;
-      const size_t ldsS = sizeof(float) * (capS * ((capS + 3) & ~(size_t)3) + capS * t_stride(ps) + 2 * ps2 + 32) + 32;
+      const size_t ldsS = sizeof(float) * (capS * odd4((int)capS) + capS * ((capS + 3) & ~(size_t)3) + 2 * ps2 + 32) + 32;
       hipLaunchKernelGGL(extract_small_kernel, dim3(4096), dim3(256), ldsS, ctx->stream, img_dev, kt, ctx->regions_dev,
                          small_items + (size_t)t * small_cap_items, &bl->n_small[t], small_cap_items, patches,
                          (const float *)ctx->blur_table_dev);
