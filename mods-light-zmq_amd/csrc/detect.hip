@@ -945,186 +945,6 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
 #endif
 }
 
-// The same iteration with NW waves per workgroup (KP keypoints per wave, as above) and the ordered sums of ALL the workgroup's
-// keypoints carried by one wave: a 361-term chain costs its SIMD the same issue slots for 6 active lanes or for 3 * KP * NW,
-// and the chains were 450 of an iteration's ~800 vector instructions.  Sampling, gradients and the update stay inside the
-// keypoint's own wave (wave_sync); two workgroup barriers per iteration hand the product arrays to wave 0 and the sums back.
-// Whether anybody still iterates is read from flags that every keypoint leaves before the first barrier, so the loop needs no
-// third one.  A keypoint's arithmetic is the single-wave kernel's, operation for operation.
-// dynamic LDS: mask WP | NW * KP x (img, pa, pb, pc: 4 WP | 4 sums) | NW * KP flags
-template <int KP, int NW>
-__global__ __launch_bounds__(64 * NW) void baumberg_wg_kernel(const PyramidDev *__restrict__ P, DetectConst k,
-                                                      CandDev *__restrict__ cand, const int *__restrict__ acc_list,
-                                                      const int *__restrict__ acc_count, const float *__restrict__ mask,
-                                                      unsigned long long *__restrict__ sort_keys, int *__restrict__ sort_idx,
-                                                      int *__restrict__ key_count) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int G = 64 / KP;                                  // lanes per keypoint
-  constexpr int NK = KP * NW;                                 // keypoints per workgroup
-  static_assert(3 * NK <= 64, "one wave carries every chain of the workgroup");
-  const int W = k.smm, WW = W * W, WP = (WW + 3) & ~3, KS = 4 * WP + 4;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sl = lane % G;
-  const int sub = wave * KP + lane / G;                       // the keypoint's place in the workgroup
-  float *s_mask = smem;
-  float *s_img = smem + WP + sub * KS, *s_pa = s_img + WP, *s_pb = s_pa + WP, *s_pc = s_pb + WP, *s_sum = s_pc + WP;
-  int *s_flag = (int *)(smem + WP + NK * KS);
-  const int b = blockIdx.y;
-  const int half = W / 2;
-  for (int p = lane; p < WW; p += 64) s_mask[p] = mask[p];    // (every wave writes the same values: its own wave_sync covers its reads)
-  const int g_r0 = sl / W, g_c0 = sl - g_r0 * W, g_dr = G / W, g_dc = G - g_dr * W;
-  const int n_acc = acc_count[b];
-  // the chain this lane of wave 0 runs: keypoint ck, product array cw
-  const int ck = lane / 3, cw = lane - 3 * ck;
-  const float *c_arr = smem + WP + (ck < NK ? ck : 0) * KS + (1 + cw) * WP;
-  for (int slot0 = blockIdx.x * NK; slot0 < n_acc; slot0 += gridDim.x * NK) {
-    const int slot = slot0 + sub;
-    const bool have = slot < n_acc;
-    const int ci = acc_list[(size_t)b * k.max_cand + (have ? slot : slot0)];
-    CandDev &cd = cand[(size_t)b * k.max_cand + ci];
-    const OctaveDev &o = P->oct[cd.octave];
-    const bool sfi = k.sfi_img != nullptr;
-    const int iw = sfi ? k.sfi_w : o.w, ih = sfi ? k.sfi_h : o.h;
-    const float *im = sfi ? k.sfi_img + (size_t)iw * ih * b : as_global(o.blur[cd.level - 1]) + (size_t)iw * ih * b;
-    const float pd = sfi ? 1.0f : cd.pixelDistance;
-    float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
-    float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
-    const float lx = cd.x / pd, ly = cd.y / pd;
-    const float ratio = cd.s / (k.initial_sigma * pd);
-    bool converged = false;
-    bool active = have && k.do_baumberg;
-    if (!k.do_baumberg) converged = true;
-    for (int l = 0; l < k.max_iter; l++) {
-      const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
-      if (active) {
-        const bool touch = check_borders(iw, ih, lx, ly, a11, a12, a21, a22, W, W);
-        const bool all_inside = __all(!touch);
-        constexpr int TH = G / 8;
-        const int tcol = sl & 7, trow = sl >> 3;
-        float rx = lx - (float)half * a12;
-        float ry = ly - (float)half * a22;
-#pragma unroll
-        for (int q = 0; q < TH - 1; q++) { const bool m = q < trow; const float nx = rx + a12, ny = ry + a22; rx = m ? nx : rx; ry = m ? ny : ry; }
-        for (int r0 = 0; r0 < W; r0 += TH) {
-          const int row = r0 + trow;
-          float WX = rx - (float)half * a11;
-          float WY = ry - (float)half * a21;
-#pragma unroll
-          for (int q = 0; q < 7; q++) { const bool m = q < tcol; const float nx = WX + a11, ny = WY + a21; WX = m ? nx : WX; WY = m ? ny : WY; }
-          if (all_inside) {
-            for (int c0 = 0; c0 < W; c0 += 24) {
-              TapLoads t[3];
-#pragma unroll
-              for (int u = 0; u < 3; u++) {
-                t[u] = tap_load_inside(im, iw, WX, WY, row < W && c0 + 8 * u + tcol < W);
-#pragma unroll
-                for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
-              }
-#pragma unroll
-              for (int u = 0; u < 3; u++) {
-                const int col = c0 + 8 * u + tcol;
-                if (row < W && col < W) s_img[row * W + col] = tap_combine_t<false>(t[u]);
-              }
-            }
-          } else {
-            for (int c0 = 0; c0 < W; c0 += 24) {
-              TapLoads t[3];
-#pragma unroll
-              for (int u = 0; u < 3; u++) {
-                t[u] = tap_load_bf(im, iw, ih, WX, WY, touch);
-#pragma unroll
-                for (int q = 0; q < 8; q++) { WX += a11; WY += a21; }
-              }
-#pragma unroll
-              for (int u = 0; u < 3; u++) {
-                const int col = c0 + 8 * u + tcol;
-                if (row < W && col < W) s_img[row * W + col] = tap_combine(t[u]);
-              }
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < TH; q++) { rx += a12; ry += a22; }
-        }
-      }
-      wave_sync();
-      if (active) {
-        int r = g_r0, c = g_c0;
-        for (int p = sl; p < WW; p += G) {
-          const float xa = s_img[p + (c < W - 1 ? 1 : 0)], xb = s_img[p - (c > 0 ? 1 : 0)];
-          const float ya = s_img[p + (r < W - 1 ? W : 0)], yb = s_img[p - (r > 0 ? W : 0)];
-          const float xgrad = xa - xb, ygrad = ya - yb;
-          const float v = s_mask[p];
-          const float gxy = xgrad * ygrad;
-          s_pa[p] = xgrad * xgrad * v;
-          s_pb[p] = gxy * v;
-          s_pc[p] = ygrad * ygrad * v;
-          r += g_dr; c += g_dc;
-          if (c >= W) { c -= W; r++; }
-        }
-      }
-      if (sl == 0) s_flag[sub] = active ? 1 : 0;
-      __syncthreads();
-      // (the flags stay as they are until every wave has passed the second barrier: all waves read the same answer)
-      if (!__any(lane < NK && s_flag[lane < NK ? lane : 0] != 0)) break;
-      if (wave == 0 && ck < NK && s_flag[ck] != 0) {
-        float acc = 0;
-        int i = 0;
-        for (; i + 31 < WW; i += 32) {
-          float4 v[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) v[u] = *(const float4 *)(c_arr + i + 4 * u);
-#pragma unroll
-          for (int u = 0; u < 8; u++) { acc += v[u].x; acc += v[u].y; acc += v[u].z; acc += v[u].w; }
-        }
-        for (; i + 3 < WW; i += 4) {
-          const float4 v4 = *(const float4 *)(c_arr + i);
-          acc += v4.x; acc += v4.y; acc += v4.z; acc += v4.w;
-        }
-        for (; i < WW; i++) acc += c_arr[i];
-        smem[WP + ck * KS + 4 * WP + cw] = acc;
-      }
-      __syncthreads();
-      if (active) {
-        float a = s_sum[0], bq = s_sum[1], c = s_sum[2];
-        a /= WW; bq /= WW; c /= WW;
-        inv_sqrt(a, bq, c, l1, l2);
-        if ((a != a) || (bq != bq) || (c != c)) active = false;
-        else {
-          eigen_ratio_bef = eigen_ratio_act;
-          eigen_ratio_act = (float)(1.0 - l2 / l1);
-          const float u11t = u11, u12t = u12;
-          u11 = a * u11t + bq * u21;
-          u12 = a * u12t + bq * u22;
-          u21 = bq * u11t + c * u21;
-          u22 = bq * u12t + c * u22;
-          const float trace = u11 + u22;
-          const float delta1 = (trace * trace - 4 * (u11 * u22 - u12 * u21));
-          if (delta1 < 0) active = false;
-          else {
-            const float delta = sqrtf(delta1);
-            l1 = (trace + delta) / 2.0f;
-            l2 = (trace - delta) / 2.0f;
-            if ((l1 / l2 > 6) || (l2 / l1 > 6)) active = false;
-            else if (eigen_ratio_act < k.conv_th && eigen_ratio_bef < k.conv_th) { converged = true; active = false; }
-          }
-        }
-      }
-    }
-    if (have && sl == 0) {
-      if (converged) {
-        cd.a11 = u11; cd.a12 = u12; cd.a21 = u21; cd.a22 = u22;
-        cd.state = 3;
-        const unsigned int absbits = __float_as_uint(fabsf(cd.response));
-        const unsigned int order = ((unsigned int)cd.octave << 28) | ((unsigned int)cd.level << ORDER_POS_BITS) |
-                                   (unsigned int)(cd.r0 * o.w + cd.c0);
-        const int sl2 = atomicAdd(&key_count[b], 1);
-        sort_keys[(size_t)b * k.max_cand + sl2] = ((unsigned long long)(~absbits) << 32) | order;
-        sort_idx[(size_t)b * k.max_cand + sl2] = ci;
-      } else cd.state = 4;
-    }
-    __syncthreads();     // the next keypoints' first flags are written behind every wave's last read of this round's
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // Rank sort + export.  Keys are unique, so rank = #{j : key_j < key_i}.
 // rank_count_kernel: grid = (blocks over i, splits over j, n_img): partial counts added atomically.
@@ -1397,32 +1217,15 @@ static int detect_run_stages(mods_ctx *ctx) {
 #ifndef BAUMBERG_KP
 #define BAUMBERG_KP 2
 #endif
-#ifndef BAUMBERG_NW
-#define BAUMBERG_NW 1
-#endif
     const size_t wp = (((size_t)par.smmWindowSize * par.smmWindowSize) + 3) & ~(size_t)3;
-#ifndef BAUMBERG_LDS_PAD
-#define BAUMBERG_LDS_PAD 0
-#endif
-    const size_t lds = sizeof(float) * (wp + BAUMBERG_KP * (4 * wp + 4)) + BAUMBERG_LDS_PAD;
+    const size_t lds = sizeof(float) * (wp + BAUMBERG_KP * (4 * wp + 4));
     if (par.affBmbrgMethod == 1)
       hipLaunchKernelGGL(baumberg_hessian_kernel, dim3(64, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, k, ctx->cand,
                          ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->sort_keys, ctx->sort_idx, key_count);
-#if BAUMBERG_NW > 1
-    else {
-      const size_t lds_wg = sizeof(float) * (wp + BAUMBERG_KP * BAUMBERG_NW * (4 * wp + 4) + BAUMBERG_KP * BAUMBERG_NW);
-      static DynLdsOnce once_wg;
-      MODS_HIP_CHECK(dyn_lds_once(once_wg, (const void *)baumberg_wg_kernel<BAUMBERG_KP, BAUMBERG_NW>, 160 * 1024, ctx->device));
-      hipLaunchKernelGGL((baumberg_wg_kernel<BAUMBERG_KP, BAUMBERG_NW>), dim3(8192 / BAUMBERG_NW, n_img), dim3(64 * BAUMBERG_NW), lds_wg, ctx->stream,
-                         ctx->pyr_dev, k, ctx->cand, ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->smm_mask_dev,
-                         ctx->sort_keys, ctx->sort_idx, key_count);
-    }
-#else
     else
       hipLaunchKernelGGL(baumberg_kernel<BAUMBERG_KP>, dim3(8192, n_img), dim3(64), lds, ctx->stream, ctx->pyr_dev, k, ctx->cand,
                          ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->smm_mask_dev, ctx->sort_keys,
                          ctx->sort_idx, key_count);
-#endif
     MODS_HIP_CHECK(hipGetLastError());
   }
   {

@@ -155,13 +155,12 @@ template <bool TOUCH> __device__ __forceinline__ float tap_combine_t(const TapLo
 // store(row, col, value) is called for every sample of the window.
 // The rows [row_begin, row_end) of the window are sampled (all columns).  TOUCH = whether the window touches the image border
 // (interpolateCheckBorders): the same for every lane, so the two forms of the tap are two instantiations behind one scalar branch.
-#ifndef SAMPLE_TC
-#define SAMPLE_TC 8          // columns of a sampling tile (64 / SAMPLE_TC rows): a lane adds SAMPLE_TC column steps between two of its taps
-#endif
 template <bool WIDE, bool TOUCH, class Store>
 __device__ __forceinline__ void sample_tiles_rows_t(const float *__restrict__ img, int w, int h, float fx, float fy, float a11, float a12,
                                                     float a21, float a22, int n, int row_begin, int row_end, int wv, int nw, Store store) {
-  constexpr int TC = SAMPLE_TC, TR = 64 / TC;
+  // tile = TC columns x TR rows of neighbouring samples (round 6 measured 4 x 16 tiles - half the column steps between a lane's taps,
+  // twice the image rows per gather: no change in any kernel, profiles/r06_describe_experiments.log)
+  constexpr int TC = 8, TR = 64 / TC;
   const int half = n / 2;
   const int lane = threadIdx.x & 63, tcol = lane & (TC - 1), trow = lane / TC;
   float rx = fx - (float)half * a12;
