@@ -451,94 +451,114 @@ __device__ __forceinline__ unsigned long long big_s_floats(int P2, int P2r, int 
 // a row-pass item covers `steps` groups of 4 column pairs
 __device__ __forceinline__ int big_rsteps(int n_tap) { const int v = BIG_RLOADS / (n_tap + 1); return v < 1 ? 1 : v; }
 
-// grid = (ceil(reg_cap/256), n_img), block 256: reserve slabs, emit the work items
-__global__ __launch_bounds__(256) void big_classify_kernel(DescConst k, const mods_region *__restrict__ reg_all,
+// grid = (CLASSIFY_BLOCKS, n_img), block 1024, grid-stride over the image's regions: reserve slabs, emit the work items.
+// One returning atomic per WORKGROUP and counter: the amounts of a workgroup's regions are scanned inside each wave, the waves'
+// totals meet in LDS, eight threads reserve the workgroup's ranges and every region takes its share.  (Until round 6 every wave
+// with a region queued up to eight returning atomics on the same eight words of BigLists - ~20 000 per 16-image batch, serialised
+// in the L2 at ~12 ns each - and the grid had a workgroup per 256 slots of the region CAPACITY: 0.17 ms per batch for a kernel
+// that moves 2 MB.)
+constexpr int CLASSIFY_BLOCKS = 16;
+__global__ __launch_bounds__(1024) void big_classify_kernel(DescConst k, const mods_region *__restrict__ reg_all,
                                                            const int *__restrict__ reg_count, BigLists *__restrict__ bl,
                                                            BigRegion *__restrict__ regions, int2 *__restrict__ sitems,
                                                            int2 *__restrict__ ritems, int2 *__restrict__ fitems, int *__restrict__ small_items, int small_cap_items, int t_lo, int t_mid,
                                                            int max_regions, int max_items,
                                                            unsigned long long pool_elems, int *__restrict__ err_flag) {
+  __shared__ int s_w[16][8];                       // per wave: totals of the seven integer amounts, then their bases
+  __shared__ unsigned long long s_need[16];
   const int b = blockIdx.y;
   int n = reg_count[b];
   if (n > k.reg_cap) n = k.reg_cap;
-  const int ri = blockIdx.x * 256 + threadIdx.x;
-  const bool have = ri < n;
-  RegionGeom g;
-  g.P2 = 0;
-  if (have) g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps, k.patch_rule);
-  // LDS tier: work lists of the two size classes (image << 17 | region), one atomic per wave and class; a blur wider than the 32
-  // taps the LDS tier stages (patch sizes below ~24 only) sends a region to the HBM tier whatever its size
-  const int n_tap = have && g.P2 > 0 ? ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1 : 0;
-  const bool lds_tier = have && g.P2 <= k.p2_hi && n_tap <= 32;
-  {
-    const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int ri0 = blockIdx.x * 1024; ri0 < n; ri0 += gridDim.x * 1024) {
+    const int ri = ri0 + threadIdx.x;
+    const bool have = ri < n;
+    RegionGeom g;
+    g.P2 = 0;
+    if (have) g = region_geom(reg_all[(size_t)b * k.max_reg + ri], k.desc_mr, k.desc_ps, k.patch_rule);
+    // LDS tier: work lists of the three size classes (image << 17 | region); a blur wider than the 32 taps the LDS tier stages
+    // (patch sizes below ~24 only) sends a region to the HBM tier whatever its size
+    const int n_tap = have && g.P2 > 0 ? ((int)(2.0 * 3.0 * (1.5f * g.scale) + 1.0)) | 1 : 0;
+    const bool lds_tier = have && g.P2 <= k.p2_hi && n_tap <= 32;
     const int tier = !lds_tier ? -1 : (g.P2 <= t_lo ? 0 : (g.P2 <= t_mid ? 1 : 2));
+    const bool big = have && !lds_tier;
+    const int P2r = (g.P2 + 3) & ~3;
+    const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2, P2r, n_tap) +
+                                     (unsigned long long)g.P2 * t_stride(k.desc_ps) + 3ull) & ~3ull;
+    const bool fused = big_is_fused(g.P2, n_tap);
+    const int f_rows = big_fuse_rows(g.P2);
+    const int f_chunks = fused ? (g.P2 + f_rows - 1) / f_rows : 0;
+    const int s_chunks = fused ? 0 : (g.P2 + BIG_SROWS - 1) / BIG_SROWS;
+    const int r_chunks = fused ? 0 : (g.P2 + BIG_RROWS - 1) / BIG_RROWS;
+    const int steps = (k.desc_ps + 3) / 4, per = big_rsteps(n_tap), r_parts = (steps + per - 1) / per;
+    // amounts: [0..2] one slot of a small list, [3] a region, [4] sample items, [5] row-pass items, [6] fused items; + pool floats
+    int a[7] = {tier == 0, tier == 1, tier == 2, big ? 1 : 0, big ? s_chunks : 0, big ? r_chunks * r_parts : 0, big ? f_chunks : 0};
+    const unsigned long long a_need = big ? need : 0ull;
+    int p[7];
+    // the three list slots by ballots, the four item amounts and the pool share by inclusive scans over the wave
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-      const unsigned long long m = __ballot(tier == t);
-      if (m == 0) continue;
-      int base = 0;
-      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&bl->n_small[t], __popcll(m));
-      base = __shfl(base, __ffsll((long long)m) - 1);
-      if (tier == t) {
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < small_cap_items) small_items[(size_t)t * small_cap_items + pos] = (b << 17) | ri;
+      const unsigned long long m = __ballot(a[t] != 0);
+      p[t] = __popcll(m & ((2ull << lane) - 1ull));
+    }
+#pragma unroll
+    for (int t = 3; t < 7; t++) p[t] = a[t];
+    unsigned long long p_need = a_need;
+    for (int d = 1; d < 64; d <<= 1) {
+      int u[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) u[t] = __shfl_up(p[3 + t], d);
+      const unsigned lo = __shfl_up((unsigned)p_need, d), hi = __shfl_up((unsigned)(p_need >> 32), d);
+      if (lane >= d) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) p[3 + t] += u[t];
+        p_need += ((unsigned long long)hi << 32) | lo;
       }
     }
-  }
-  const bool big = have && !lds_tier;
-  if (__ballot(big) == 0) return;
-  const int P2r = (g.P2 + 3) & ~3;
-  const unsigned long long need = ((unsigned long long)big_hdr_floats(n_tap, k.desc_ps) + big_s_floats(g.P2, P2r, n_tap) +
-                                   (unsigned long long)g.P2 * t_stride(k.desc_ps) + 3ull) & ~3ull;
-  const bool fused = big_is_fused(g.P2, n_tap);
-  const int f_rows = big_fuse_rows(g.P2);
-  const int f_chunks = fused ? (g.P2 + f_rows - 1) / f_rows : 0;
-  const int s_chunks = fused ? 0 : (g.P2 + BIG_SROWS - 1) / BIG_SROWS;
-  const int r_chunks = fused ? 0 : (g.P2 + BIG_RROWS - 1) / BIG_RROWS;
-  const int steps = (k.desc_ps + 3) / 4, per = big_rsteps(n_tap), r_parts = (steps + per - 1) / per;
-  // one returning atomic per wave and counter (a lane's share = the exclusive prefix of its amount inside the wave): with one
-  // per region the ~1 500 large regions of an image queued on five addresses
-  int li, s0, r0, f0;
-  unsigned long long off;
-  {
-    const int lane = threadIdx.x & 63;
-    const int a_reg = big ? 1 : 0, a_s = big ? s_chunks : 0, a_r = big ? r_chunks * r_parts : 0, a_f = big ? f_chunks : 0;
-    const unsigned long long a_need = big ? need : 0ull;
-    int p_reg = a_reg, p_s = a_s, p_r = a_r, p_f = a_f;
-    unsigned long long p_need = a_need;
-    for (int d = 1; d < 64; d <<= 1) {      // inclusive scans over the wave
-      const int t_reg = __shfl_up(p_reg, d), t_s = __shfl_up(p_s, d), t_r = __shfl_up(p_r, d), t_f = __shfl_up(p_f, d);
-      const unsigned lo = __shfl_up((unsigned)p_need, d), hi = __shfl_up((unsigned)(p_need >> 32), d);
-      if (lane >= d) { p_reg += t_reg; p_s += t_s; p_r += t_r; p_f += t_f; p_need += ((unsigned long long)hi << 32) | lo; }
-    }
-    int b_reg = 0, b_s = 0, b_r = 0, b_f = 0;
-    unsigned long long b_need = 0;
     if (lane == 63) {
-      b_reg = atomicAdd(&bl->n_regions, p_reg);
-      b_need = atomicAdd(&bl->pool_used, p_need);
-      if (p_s) b_s = atomicAdd(&bl->n_sitems, p_s);
-      if (p_r) b_r = atomicAdd(&bl->n_ritems, p_r);
-      if (p_f) b_f = atomicAdd(&bl->n_fitems, p_f);
+#pragma unroll
+      for (int t = 0; t < 7; t++) s_w[wv][t] = p[t];
+      s_need[wv] = p_need;
     }
-    b_reg = __shfl(b_reg, 63); b_s = __shfl(b_s, 63); b_r = __shfl(b_r, 63); b_f = __shfl(b_f, 63);
-    b_need = ((unsigned long long)__shfl((unsigned)(b_need >> 32), 63) << 32) | __shfl((unsigned)b_need, 63);
-    li = b_reg + p_reg - a_reg; s0 = b_s + p_s - a_s; r0 = b_r + p_r - a_r; f0 = b_f + p_f - a_f;
-    off = b_need + p_need - a_need;
+    __syncthreads();
+    if (threadIdx.x < 8) {             // thread t: counter t of the workgroup (7 = the pool)
+      const int t = threadIdx.x;
+      if (t < 7) {
+        int tot = 0;
+        for (int q = 0; q < 16; q++) tot += s_w[q][t];
+        int *ctr = t < 3 ? &bl->n_small[t] : (t == 3 ? &bl->n_regions : (t == 4 ? &bl->n_sitems : (t == 5 ? &bl->n_ritems : &bl->n_fitems)));
+        int base = tot ? atomicAdd(ctr, tot) : 0;
+        for (int q = 0; q < 16; q++) { const int c = s_w[q][t]; s_w[q][t] = base; base += c; }
+      } else {
+        unsigned long long tot = 0;
+        for (int q = 0; q < 16; q++) tot += s_need[q];
+        unsigned long long base = tot ? atomicAdd(&bl->pool_used, tot) : 0ull;
+        for (int q = 0; q < 16; q++) { const unsigned long long c = s_need[q]; s_need[q] = base; base += c; }
+      }
+    }
+    __syncthreads();
+    if (tier >= 0) {
+      const int pos = s_w[wv][tier] + p[tier] - 1;
+      if (pos < small_cap_items) small_items[(size_t)tier * small_cap_items + pos] = (b << 17) | ri;
+    }
+    if (big) {
+      const int li = s_w[wv][3] + p[3] - a[3], s0 = s_w[wv][4] + p[4] - a[4], r0 = s_w[wv][5] + p[5] - a[5], f0 = s_w[wv][6] + p[6] - a[6];
+      const unsigned long long off = s_need[wv] + p_need - a_need;
+      if (li >= max_regions || off + need > pool_elems || s0 + s_chunks > max_items || r0 + r_chunks * r_parts > max_items ||
+          f0 + f_chunks > max_items || g.P2 >= 65536 || n_tap > k.tap_cap) {
+        atomicExch(err_flag, 1);
+      } else {
+        BigRegion br;
+        br.img = b; br.ri = ri; br.P2 = g.P2; br.n_tap = n_tap; br.slab = off; br.scale = g.scale; br.P2r = P2r;
+        regions[li] = br;
+        for (int c = 0; c < f_chunks; c++) fitems[f0 + c] = make_int2(li, c * f_rows);
+        for (int c = 0; c < s_chunks; c++) sitems[s0 + c] = make_int2(li, c * BIG_SROWS);
+        for (int c = 0; c < r_chunks; c++)
+          for (int q = 0; q < r_parts; q++) ritems[r0 + c * r_parts + q] = make_int2(li, c * BIG_RROWS | (q * per << 16));
+      }
+    }
+    __syncthreads();                   // s_w / s_need are rewritten by the next round
   }
-  if (!big) return;
-  if (li >= max_regions || off + need > pool_elems || s0 + s_chunks > max_items || r0 + r_chunks * r_parts > max_items ||
-      f0 + f_chunks > max_items || g.P2 >= 65536 || n_tap > k.tap_cap) {
-    atomicExch(err_flag, 1);
-    return;
-  }
-  BigRegion br;
-  br.img = b; br.ri = ri; br.P2 = g.P2; br.n_tap = n_tap; br.slab = off; br.scale = g.scale; br.P2r = P2r;
-  regions[li] = br;
-  for (int c = 0; c < f_chunks; c++) fitems[f0 + c] = make_int2(li, c * f_rows);
-  for (int c = 0; c < s_chunks; c++) sitems[s0 + c] = make_int2(li, c * BIG_SROWS);
-  for (int c = 0; c < r_chunks; c++)
-    for (int q = 0; q < r_parts; q++) ritems[r0 + c * r_parts + q] = make_int2(li, c * BIG_RROWS | (q * per << 16));
 }
 
 // grid-stride over the big regions, block 256: taps / resampling sequence into the slab header
@@ -1553,7 +1573,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   k.tap_cap = 4096;
   const int small_cap = SMALL_CAP;   // P2 limit of the LDS tier
   k.p2_hi = small_cap;
-  hipLaunchKernelGGL(big_classify_kernel, dim3((k.reg_cap + 255) / 256, n_img), dim3(256), 0, ctx->stream, k, ctx->regions_dev,
+  hipLaunchKernelGGL(big_classify_kernel, dim3(CLASSIFY_BLOCKS, n_img), dim3(1024), 0, ctx->stream, k, ctx->regions_dev,
                      ctx->region_count, bl, bregs, sitems, ritems, fitems, small_items, small_cap_items, std::min(small_cap, EXTRACT_T_LO), std::min(small_cap, EXTRACT_T_MID), max_big, max_items,
                      pool_elems, ctx->desc_err_dev);
   // LDS tier in three launches over the work lists of big_classify_kernel: a workgroup's LDS follows the largest window of its class
