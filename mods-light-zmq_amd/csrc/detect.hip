@@ -733,7 +733,7 @@ __device__ __forceinline__ void baumberg_sample_piped(const float *__restrict__ 
 // Most of an iteration is work that costs the SIMD the same for one lane or for sixty-four (three 361-term ordered sums, the
 // double-precision inverse square root of the 2x2 moment matrix), so several keypoints share the wave; a keypoint that has
 // converged or failed idles until the others of its wave are done.
-// dynamic LDS: mask WP | KP x (img, pa, pb, pc: 4 WP | 4 sums)
+// dynamic LDS: mask WP | KP x (img, pa, pb[, pc]: 3 or 4 WP | 4 sums)
 #ifndef BAUMBERG_WAVES
 #define BAUMBERG_WAVES 4
 #endif
@@ -748,7 +748,12 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
   const int W = k.smm, WW = W * W, WP = (WW + 3) & ~3;
   const int lane = threadIdx.x, sub = lane / G, sl = lane % G;
   float *s_mask = smem;
-  float *s_img = smem + WP + sub * (4 * WP + 4), *s_pa = s_img + WP, *s_pb = s_pa + WP, *s_pc = s_pb + WP, *s_sum = s_pc + WP;
+  // a keypoint's third product array takes the place of its window once the gradient pass has read it (64 / KP >= W: see there):
+  // 3 instead of 4 arrays per keypoint, 16 instead of 13 waves per CU by LDS - the kernel follows its occupancy (round 6:
+  // 13 / 10 / 8 waves per CU = 1.47 / 1.67 / 1.97 ms per batch, profiles/r06_describe_experiments.log)
+  const bool alias_pc = G >= W;
+  const int KS = (alias_pc ? 3 : 4) * WP + 4;
+  float *s_img = smem + WP + sub * KS, *s_pa = s_img + WP, *s_pb = s_pa + WP, *s_pc = alias_pc ? s_img : s_pb + WP, *s_sum = s_img + KS - 4;
   const int b = blockIdx.y;
   const int half = W / 2;
   for (int p = lane; p < WW; p += 64) s_mask[p] = mask[p];
@@ -856,8 +861,13 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
       // (the one-sided differences at the window border are the same subtraction with one operand at the pixel itself)
       // (row and column of a lane's pixels advance by G / W and G % W with one carry: no division per pixel - the compiler's
       // expansion of p / W was 16 of this loop's 58 vector instructions, and the loop a third of an iteration's)
+      // The third product of a pixel is stored one round late, over the window itself: round j reads window values from G j - W
+      // on, the store of round j - 1 covers [G (j - 1), G j) and is issued behind round j's reads (LDS executes a wave's
+      // instructions in order), and no later round reads below G j when G >= W.
       if (active) {
         int r = g_r0, c = g_c0;
+        float pend = 0.f;
+        int pend_at = -1;
         for (int p = sl; p < WW; p += G) {
           const float xa = s_img[p + (c < W - 1 ? 1 : 0)], xb = s_img[p - (c > 0 ? 1 : 0)];
           const float ya = s_img[p + (r < W - 1 ? W : 0)], yb = s_img[p - (r > 0 ? W : 0)];
@@ -866,10 +876,15 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
           const float gxy = xgrad * ygrad;
           s_pa[p] = xgrad * xgrad * v;
           s_pb[p] = gxy * v;
-          s_pc[p] = ygrad * ygrad * v;
+          if (alias_pc) {
+            if (pend_at >= 0) s_pc[pend_at] = pend;
+            pend = ygrad * ygrad * v; pend_at = p;
+          } else s_pc[p] = ygrad * ygrad * v;
           r += g_dr; c += g_dc;
           if (c >= W) { c -= W; r++; }
         }
+        // the last round's products (a lane whose loop ended a round early holds a pixel of the round before): every read is done
+        if (alias_pc && pend_at >= 0) s_pc[pend_at] = pend;
       }
       wave_sync();
       BPROF(2)
@@ -1218,7 +1233,8 @@ static int detect_run_stages(mods_ctx *ctx) {
 #define BAUMBERG_KP 2
 #endif
     const size_t wp = (((size_t)par.smmWindowSize * par.smmWindowSize) + 3) & ~(size_t)3;
-    const size_t lds = sizeof(float) * (wp + BAUMBERG_KP * (4 * wp + 4));
+    // (three arrays per keypoint when the third product can take the window's place: baumberg_kernel, alias_pc)
+    const size_t lds = sizeof(float) * (wp + BAUMBERG_KP * ((64 / BAUMBERG_KP >= par.smmWindowSize ? 3 : 4) * wp + 4));
     if (par.affBmbrgMethod == 1)
       hipLaunchKernelGGL(baumberg_hessian_kernel, dim3(64, n_img), dim3(256), 0, ctx->stream, ctx->pyr_dev, k, ctx->cand,
                          ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->sort_keys, ctx->sort_idx, key_count);
