@@ -134,6 +134,8 @@ enum { MODS_STAGE_BLUR = 0, MODS_STAGE_RESPONSE, MODS_STAGE_RESIZE, MODS_STAGE_N
                                  * resize launch of every octave + NMS + compaction (the small octaves run on a second stream
                                  * inside it, so the per-stage sums above overlap and add up to more than this) */
        MODS_STAGE_MATCH_NN1,    /* the matrix-core kernel of the search alone (match_nn1_kernel, i8 MFMA), inside MODS_STAGE_MATCH */
+       MODS_STAGE_EXTRACT,      /* measurement-region extraction alone (classify .. column pass + resampling), inside MODS_STAGE_DESCRIBE */
+       MODS_STAGE_SIFT,         /* the SIFT kernels alone, inside MODS_STAGE_DESCRIBE */
        MODS_STAGE_COUNT };
 int mods_ctx_timing_enable(mods_ctx *ctx, int stage_mask);
 /* on != 0: mods_detect_describe_dev (and what is built on it: the pair entry points, the pipeline's workers) records the ~70
@@ -238,6 +240,10 @@ int mods_ctx_set_external_descriptor(mods_ctx *ctx, mods_descriptor_fn fn, void 
 int mods_ctx_set_external_shape(mods_ctx *ctx, mods_descriptor_fn fn, void *user, double mrSize, int patchSize);
 int mods_ctx_set_external_orientation(mods_ctx *ctx, mods_descriptor_fn fn, void *user, double mrSize, int patchSize);
 int mods_patches_fetch(mods_ctx *ctx, int img, int ps, float *out, int max_regions, int *n_out);   /* patches of the last describe call */
+/* Baumberg work counters of image slot img (bench.py's per-keypoint figures): keypoints that entered the affine-shape iteration and
+ * iterations run since mods_baumberg_stats_enable(ctx, 1); one iteration = smmWindowSize^2 bilinear taps (affine.cpp:26-158). */
+int mods_baumberg_stats_enable(mods_ctx *ctx, int on);
+int mods_baumberg_stats(mods_ctx *ctx, int img, unsigned long long *keypoints, unsigned long long *iterations);
 int mods_unoriented_count(mods_ctx *ctx, int img);   /* |"None" region list| of slot img after the last describe call */
 int mods_regions_fetch(mods_ctx *ctx, int img, mods_region *out, int max_out, int *n_out);
 
@@ -603,6 +609,11 @@ int mods_host_alloc(size_t bytes, void **out);     /* pinned host memory */
 int mods_host_free(void *p);
 int mods_dev_alloc(size_t bytes, void **out);
 int mods_dev_free(void *p);
+/* Both copies are complete when the call returns.  They run on a NON-BLOCKING stream of the calling thread on the device the buffer
+ * lives on: they are ordered after nothing else - not after work in flight on a context's stream, on the legacy stream or on an
+ * application's own streams.  A buffer that some stream is still writing (or reading, for an upload) has to be waited for first
+ * (mods_ctx_sync, or the application's own synchronisation); every entry point of this library that produces a buffer has returned
+ * only after its work was complete, unless its comment says otherwise. */
 int mods_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
 int mods_dev_download(void *dst_host, const void *src_dev, size_t bytes);
 

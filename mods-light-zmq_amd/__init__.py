@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MODS_LIB") or os.path.join(PKG_DIR, "libmodsgpu.so")
 
 MODS_OK = 0
 STAGES = ["blur", "response", "resize", "nms", "localize", "baumberg", "sort", "orient", "describe", "match",
-          "ransac_score", "synth", "blur_small", "pyramid", "match_nn1"]
+          "ransac_score", "synth", "blur_small", "pyramid", "match_nn1", "extract", "sift"]
 
 
 class ModsError(RuntimeError):
@@ -177,6 +177,15 @@ class Context:
         ms, n, by = C.c_double(), C.c_int(), C.c_double()
         _check(lib().mods_ctx_timing_read(self.h, STAGES.index(stage), C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
+
+    def baumberg_stats_enable(self, on=True):
+        """count the keypoints that enter the Baumberg iteration and the iterations they run (mods_baumberg_stats)"""
+        _check(lib().mods_baumberg_stats_enable(self.h, 1 if on else 0))
+
+    def baumberg_stats(self, img):
+        kp, it = C.c_ulonglong(), C.c_ulonglong()
+        _check(lib().mods_baumberg_stats(self.h, img, C.byref(kp), C.byref(it)))
+        return kp.value, it.value
 
     def graphs(self, on=True):
         """replay the launches of detect + describe as a hipGraph from the second call with the same arguments on"""

@@ -50,20 +50,30 @@ template <class T> struct Borrowed {
 };
 static HandlePool<hipEvent_t> *event_pool() { static HandlePool<hipEvent_t> *p = new HandlePool<hipEvent_t>(); return p; }     // (never destroyed: threads may outlive statics)
 static HandlePool<hipStream_t> *stream_pool() { static HandlePool<hipStream_t> *p = new HandlePool<hipStream_t>(); return p; }
-static hipEvent_t thread_event() {
+// the thread's event on the device that OWNS stream s (an event can only be recorded on a stream of its own device, and a polling
+// thread may wait for a stream of another device than its current one: the plane getters, the multi-device helpers); the event is
+// created with that device current, and the caller's device is put back
+static hipEvent_t thread_event(hipStream_t s) {
   static thread_local Borrowed<hipEvent_t> t(event_pool());
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!t.h[dev]) t.h[dev] = t.pool->take(dev, +[]() -> hipEvent_t { hipEvent_t e = nullptr; return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? e : nullptr; });
+  int cur = 0, dev = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+  dev = cur;
+  if (s && hipStreamGetDevice(s, &dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (dev < 0 || dev >= 16) return nullptr;
+  if (!t.h[dev]) {
+    if (dev != cur && hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    t.h[dev] = t.pool->take(dev, +[]() -> hipEvent_t { hipEvent_t e = nullptr; return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? e : nullptr; });
+    if (dev != cur) (void)hipSetDevice(cur);
+  }
   return t.h[dev];
 }
 hipError_t stream_wait(hipStream_t s) {
   const long ns = tl_wait_sleep_ns;
   if (ns <= 0) return hipStreamSynchronize(s);
-  hipEvent_t ev = thread_event();
+  hipEvent_t ev = thread_event(s);
   if (!ev) return hipStreamSynchronize(s);
   hipError_t e = hipEventRecord(ev, s);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess) { (void)hipGetLastError(); return hipStreamSynchronize(s); }   // (the runtime's own wait works from any current device)
   e = hipEventQuery(ev);
   for (int i = 0; i < tl_wait_spin_polls && e == hipErrorNotReady; i++) e = hipEventQuery(ev);
   // every poll is a runtime call and a wake-up of this thread (~4 us of CPU): the sleep grows by half per poll up to its bound, so a
@@ -83,22 +93,43 @@ hipError_t stream_wait(hipStream_t s) {
   return e;
 }
 
+// (a blocking copy / fill inside a stream capture would be recorded as a node and then waited for - which a capture forbids: refused
+// here, so that no upload can end up inside a recorded detect + describe graph)
+static bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
 hipError_t copy_wait(hipStream_t s, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
   if (!bytes) return hipSuccess;
+  if (capturing(s)) return hipErrorStreamCaptureUnsupported;
   const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
   return e != hipSuccess ? e : stream_wait(s);
 }
 hipError_t fill_wait(hipStream_t s, void *dst, int value, size_t bytes) {
   if (!bytes) return hipSuccess;
+  if (capturing(s)) return hipErrorStreamCaptureUnsupported;
   const hipError_t e = hipMemsetAsync(dst, value, bytes, s);
   return e != hipSuccess ? e : stream_wait(s);
 }
-hipStream_t thread_stream() {
+hipStream_t thread_stream(int dev) {
   static thread_local Borrowed<hipStream_t> t(stream_pool());
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;     // (nullptr = the legacy stream: what the call used before)
-  if (!t.h[dev]) t.h[dev] = t.pool->take(dev, +[]() -> hipStream_t { hipStream_t q = nullptr; return hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess ? q : nullptr; });
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return nullptr;                             // (nullptr = the legacy stream: what the call used before)
+  if (dev < 0) dev = cur;
+  if (dev >= 16) return nullptr;
+  if (!t.h[dev]) {
+    if (dev != cur && hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    t.h[dev] = t.pool->take(dev, +[]() -> hipStream_t { hipStream_t q = nullptr; return hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess ? q : nullptr; });
+    if (dev != cur) (void)hipSetDevice(cur);
+  }
   return t.h[dev];
+}
+// the device a device pointer lives on (-1: not a device pointer the runtime knows - the calling thread's current device then)
+int device_of_pointer(const void *p) {
+  hipPointerAttribute_t a;
+  if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return a.type == hipMemoryTypeDevice ? a.device : -1;
 }
 
 void wait_mode_for_worker(long default_sleep_ns) {
@@ -217,7 +248,7 @@ void mods_ctx_destroy(mods_ctx *c) {
     for (auto &e : t.pool) (void)hipEventDestroy(e);
   }
   (void)hipFree(c->pyr_dev); (void)hipFree(c->plane_pool); (void)hipFree(c->omap_pool); (void)hipFree(c->input_dev); (void)hipFree(c->u8_stage_dev);
-  (void)hipFree(c->tmp_dev); (void)hipFree(c->alt_taps_dev); (void)hipFree(c->alt_planes); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); (void)hipFree(c->cand);
+  (void)hipFree(c->tmp_dev); (void)hipFree(c->alt_taps_dev); (void)hipFree(c->alt_planes); (void)hipFree(c->view_dev); (void)hipFree(c->gauss_taps_dev); (void)hipFree(c->smm_mask_dev); if (c->baum_stats_dev) (void)hipFree(c->baum_stats_dev); (void)hipFree(c->cand);
   (void)hipFree(c->cand_count); (void)hipFree(c->keys_dev); (void)hipFree(c->sort_keys); (void)hipFree(c->sort_idx); (void)hipFree(c->rank_dev); (void)hipFree(c->nms_mask);
   (void)hipHostFree(c->host_counts); (void)hipHostFree(c->pin_arena);
   (void)hipFree(c->ori_dev); (void)hipFree(c->ori_multi_dev); (void)hipFree(c->regions_dev); (void)hipFree(c->regions_half_dev); (void)hipFree(c->region_count); (void)hipFree(c->inside_count); (void)hipFree(c->desc_tables_dev); (void)hipFree(c->blur_table_dev);
@@ -406,10 +437,11 @@ static unsigned long long fnv1a(const void *p, size_t n, unsigned long long h) {
 static int dd_run(mods_ctx *c, const float *img_dev, int n_img, int w, int h, int stride, const mods_hessaff_params *det,
                   const mods_describe_params *desc) {
   const bool can = c->dd_graphs && c->timing_mask == 0 && !c->ext_fn && !c->shape_fn && !c->ori_fn && det->detectorType != MODS_DET_MSER;
-  if (!can) { c->dd_prev = mods_ctx::DdKey(); return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc); }
+  if (!can) { mods::dev_state_changed(c); return dd_enqueue(c, img_dev, n_img, w, h, stride, det, desc); }
   mods_ctx::DdKey key;
   key.img = img_dev; key.n_img = n_img; key.w = w; key.h = h; key.stride = stride;
   key.par_hash = fnv1a(desc, sizeof(*desc), fnv1a(det, sizeof(*det), 1469598103934665603ull)) ^ (unsigned long long)c->pyr_streams;
+  key.epoch = c->dev_state_epoch;
   // A recording is made, and replayed, only right behind a call with the SAME arguments: tables that live on the device and are
   // refreshed from the host when the arguments change (the octave table, tap slots, masks) are then exactly what the recorded
   // launches expect, and no such refresh can end up inside a recording.  A worker's steady state - full batches of one geometry -
@@ -463,7 +495,7 @@ int mods_ctx_graphs(mods_ctx *c, int on) {
   if (!c) return MODS_E_ARG;
   c->dd_graphs = on != 0;
   if (!on) { dd_graph_drop(c); c->dd_linear.clear(); }
-  c->dd_prev = mods_ctx::DdKey();
+  mods::dev_state_changed(c);
   return MODS_OK;
 }
 long mods_ctx_graph_replays(const mods_ctx *c) { return c ? c->dd_replays : 0; }
@@ -533,6 +565,32 @@ int mods_patches_fetch(mods_ctx *c, int img, int ps, float *out, int max_regions
 
 // size of the reference's unoriented ("None") region list of image slot img after the last describe call:
 // detections whose centre, in the original frame, lies inside the image (imagerepresentation.cpp:867, 939)
+// Baumberg work of image slot img, accumulated since mods_baumberg_stats_enable(ctx, 1): keypoints that entered the iteration and
+// iterations run (each = one smmWindowSize^2 window of bilinear taps, affine.cpp:26-158).  Off by default: two atomics per keypoint.
+int mods_baumberg_stats_enable(mods_ctx *c, int on) {
+  if (!c) return MODS_E_ARG;
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
+  if (c->baum_stats_dev) { (void)hipFree(c->baum_stats_dev); c->baum_stats_dev = nullptr; }
+  if (on) {
+    MODS_HIP_CHECK(hipMalloc(&c->baum_stats_dev, sizeof(unsigned long long) * 2 * 64 * (size_t)c->batch));
+    MODS_HIP_CHECK(hipMemset(c->baum_stats_dev, 0, sizeof(unsigned long long) * 2 * 64 * (size_t)c->batch));
+  }
+  mods::dev_pool_reallocated(c);         // (a recorded detect + describe graph holds the old pointer)
+  return MODS_OK;
+}
+int mods_baumberg_stats(mods_ctx *c, int img, unsigned long long *keypoints, unsigned long long *iterations) {
+  if (!c || img < 0 || img >= c->batch || !c->baum_stats_dev) return MODS_E_ARG;
+  MODS_HIP_CHECK(hipSetDevice(c->device));
+  MODS_HIP_CHECK(mods::stream_wait(c->stream));
+  unsigned long long v[2 * 64], kp = 0, it = 0;   // 64 slots per image (the kernel spreads its adds)
+  MODS_HIP_CHECK(hipMemcpy(v, c->baum_stats_dev + 2 * 64 * (size_t)img, sizeof(v), hipMemcpyDeviceToHost));
+  for (int q = 0; q < 64; q++) { kp += v[2 * q]; it += v[2 * q + 1]; }
+  if (keypoints) *keypoints = kp;
+  if (iterations) *iterations = it;
+  return MODS_OK;
+}
+
 int mods_unoriented_count(mods_ctx *c, int img) {
   if (!c || img < 0 || img >= (int)c->last_inside_counts.size()) return 0;
   return c->last_inside_counts[img];

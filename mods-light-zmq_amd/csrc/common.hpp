@@ -47,7 +47,8 @@ hipError_t stream_wait(hipStream_t s);
 // (mods_ctx_graphs: a pipeline worker recording its launch chain) - seen once as a failed workspace growth of a verify thread
 hipError_t copy_wait(hipStream_t s, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 hipError_t fill_wait(hipStream_t s, void *dst, int value, size_t bytes);
-hipStream_t thread_stream();   // a non-blocking stream of the calling thread on the current device (entry points without a context)
+hipStream_t thread_stream(int dev = -1);   // a non-blocking stream of the calling thread on device `dev` (-1: the current one; entry points without a context)
+int device_of_pointer(const void *p);      // the device a device pointer lives on, -1 when the runtime does not know it as one
 void wait_mode_for_worker(long default_sleep_ns);   // MODS_SYNC=spin|sleep[:us] decides for the pipeline's threads
 
 constexpr int kMaxOctaves = 16;
@@ -131,6 +132,7 @@ struct mods_ctx {
   float taps_host[16][2 * mods::kMaxBlurRadius + 1] = {{0}};
   int taps_host_n[16] = {0};
   float *smm_mask_dev = nullptr;     // computeGaussMask(smmWindowSize)
+  unsigned long long *baum_stats_dev = nullptr;   // per image slot: {keypoints that entered the Baumberg iteration, iterations run} (mods_baumberg_stats)
   int smm_mask_size = 0;
   // candidates
   int max_cand = 0;                  // per image
@@ -212,8 +214,11 @@ struct mods_ctx {
   int timing_mask = 0;
   // mods_ctx_graphs: the launches of a detect + describe call replayed as one hipGraph (capi.hip: mods_detect_describe_dev)
   bool dd_graphs = false;
-  struct DdKey { const float *img = nullptr; int n_img = 0, w = 0, h = 0, stride = 0; unsigned long long par_hash = 0;
-                 bool operator==(const DdKey &o) const { return img == o.img && n_img == o.n_img && w == o.w && h == o.h && stride == o.stride && par_hash == o.par_hash; } };
+  // `epoch` = dev_state_epoch when the call was made: every host-side change of device tables or pools bumps that counter
+  // (mods::dev_state_changed / dev_pool_reallocated), so a call behind such a change is never taken for a repeat of the one before it
+  struct DdKey { const float *img = nullptr; int n_img = 0, w = 0, h = 0, stride = 0; unsigned long long par_hash = 0, epoch = ~0ull;
+                 bool operator==(const DdKey &o) const { return img == o.img && n_img == o.n_img && w == o.w && h == o.h && stride == o.stride && par_hash == o.par_hash && epoch == o.epoch; } };
+  unsigned long long dev_state_epoch = 0;
   std::vector<std::pair<DdKey, hipGraphExec_t>> dd_cache;   // recorded calls (a worker sees a few batch sizes), oldest first
   bool dd_stale = false;                                    // a pool the recordings point into was reallocated: they are dropped
   DdKey dd_prev;                                            // arguments of the context's previous detect + describe call
@@ -228,6 +233,10 @@ namespace mods {
 // float offsets of the tables in mods_ctx::desc_tables_dev
 constexpr int kTabOriMask = 0, kTabDescMask = 4096, kTabVoteMask = 8192, kTabSift = 12288;
 
+// A hipGraph replay of a detect + describe call is valid only while the device tables and pools it was recorded against are
+// untouched: every upload, setter and (re)allocation that changes them from the host goes through one of these two
+inline void dev_state_changed(mods_ctx *c) { c->dev_state_epoch++; }                          // tables / parameters refreshed from the host
+inline void dev_pool_reallocated(mods_ctx *c) { c->dev_state_epoch++; c->dd_stale = true; }   // a pool moved: recordings are dropped
 struct StageScope {                  // brackets launches of one stage with events when enabled
   mods_ctx *ctx; int stage; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
   StageScope(mods_ctx *c, int s, double bytes = 0);

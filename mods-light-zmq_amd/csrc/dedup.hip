@@ -115,13 +115,13 @@ __global__ __launch_bounds__(1024) void dup_resolve_kernel(DupBatch b, int lds_n
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const DupJob &J = b.job[blockIdx.x];
-  const char *src = J.src; char *dst = J.dst;
-  int *n_dst = J.n_dst, *status = J.status;
-  const int *order = dj_order(b, blockIdx.x), *near = dj_near(b, blockIdx.x), *near_cnt = dj_cnt(b, blockIdx.x);
+  int *n_dst = J.n_dst, *status = J.status;          // pinned host memory: the caller's copy
+  int *res = dj_rank(b, blockIdx.x);                 // {kept, status} for dup_copy_kernel, in the (dead) rank array: device memory
+  const int *near = dj_near(b, blockIdx.x), *near_cnt = dj_cnt(b, blockIdx.x);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = *J.n_src;
   if (n > b.max_n || n > lds_n) {                    // (uniform)
-    if (tid == 0) { *status = 1; *n_dst = 0; }
+    if (tid == 0) { *status = 1; *n_dst = 0; res[0] = 0; res[1] = 1; }
     return;
   }
   int over = 0;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(1024) void dup_resolve_kernel(DupBatch b, int lds_n
     s_state[p] = c == 0 ? 1 : 0;
   }
   if (__syncthreads_or(over)) {
-    if (tid == 0) { *status = 1; *n_dst = 0; }
+    if (tid == 0) { *status = 1; *n_dst = 0; res[0] = 0; res[1] = 1; }
     return;
   }
   for (;;) {
@@ -169,14 +169,15 @@ __global__ __launch_bounds__(1024) void dup_resolve_kernel(DupBatch b, int lds_n
     __syncthreads();
   }
   const int total = s_base;
-  if (tid == 0) { *n_dst = total; *status = 0; }
+  if (tid == 0) { *n_dst = total; *status = 0; res[0] = total; res[1] = 0; }
 }
 
 // grid = (tiles of 256 positions, jobs): the kept correspondences of a resolved list move to their places in the packed output
 __global__ __launch_bounds__(256) void dup_copy_kernel(DupBatch b) {
   const DupJob &J = b.job[blockIdx.y];
-  if (*J.status != 0) return;
-  const int n = *J.n_src, total = *J.n_dst;
+  const int *res = dj_rank(b, blockIdx.y);           // left by dup_resolve_kernel in device memory (a read of the caller's pinned words
+  if (res[1] != 0) return;                           //  would be a PCIe round trip per wave)
+  const int n = *J.n_src, total = res[0];
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   const int slot = dj_cnt(b, blockIdx.y)[p];
@@ -226,8 +227,9 @@ int dup_filter_dev(mods_ctx *c, const DupJob *jobs, int n_jobs, int grid_n, doub
   static DynLdsOnce once;
   MODS_HIP_CHECK(dyn_lds_once(once, (const void *)dup_resolve_kernel, DUP_MAX_N, c->device));
   const int tiles = (grid_n + 255) / 256;
-  // rank and near-count arrays start at zero: one fill over the counters of the batch's jobs (the last job's only up to grid_n)
-  MODS_HIP_CHECK(hipMemsetAsync(b.counters, 0, ctr_job * (n_jobs - 1) + (n + (size_t)grid_n) * sizeof(int), c->stream));
+  // rank and near-count arrays start at zero: one fill over the counters of the batch's jobs, whole (a list longer than the caller's
+  // grid_n bound - which the resolve kernel hands to the host - must not meet the previous call's place numbers either)
+  MODS_HIP_CHECK(hipMemsetAsync(b.counters, 0, ctr_job * n_jobs, c->stream));
   if (mode >= 1 && mode <= 3) hipLaunchKernelGGL(dup_rank_kernel, dim3(tiles, tiles, n_jobs), dim3(256), 0, c->stream, b);
   hipLaunchKernelGGL(dup_scatter_kernel, dim3(tiles, 1, n_jobs), dim3(256), 0, c->stream, b);
   hipLaunchKernelGGL(dup_near_kernel, dim3(tiles, tiles, n_jobs), dim3(256), 0, c->stream, b);

@@ -521,7 +521,7 @@ int describe_configure(mods_ctx *ctx, const mods_describe_params *par) {
     circular_gauss_mask_host(par->desc_patchSize, 0.f, m2.data());                         // synth-detection.hpp:181, siftdesc.h:83
     SiftTab tab;
     build_sift_tab(par->desc_patchSize, &tab);
-    ctx->dd_prev = mods_ctx::DdKey();     // (device tables change: the next detect + describe call is not a repeat - capi.hip: dd_run)
+    mods::dev_state_changed(ctx);     // (device tables change: the next detect + describe call is not a repeat - capi.hip: dd_run)
     MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
     MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->desc_tables_dev, m1.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
     MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->desc_tables_dev + kTabDescMask, m2.data(), sizeof(float) * 4096, hipMemcpyHostToDevice));
@@ -810,7 +810,7 @@ int describe_run_view(mods_ctx *ctx, const float *img_dev, int n_img, int w, int
       if (need > ctx->ori_multi_bytes) {
         if (ctx->ori_multi_dev) MODS_HIP_CHECK(hipFree(ctx->ori_multi_dev));
         ctx->ori_multi_dev = nullptr; ctx->ori_multi_bytes = 0;
-        { ctx->dd_stale = true; ctx->dd_prev = mods_ctx::DdKey(); } MODS_HIP_CHECK(hipMalloc(&ctx->ori_multi_dev, need));
+        mods::dev_pool_reallocated(ctx); MODS_HIP_CHECK(hipMalloc(&ctx->ori_multi_dev, need));
         ctx->ori_multi_bytes = need;
       }
     }

@@ -742,7 +742,7 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
                                                       CandDev *__restrict__ cand, const int *__restrict__ acc_list,
                                                       const int *__restrict__ acc_count, const float *__restrict__ mask,
                                                       unsigned long long *__restrict__ sort_keys, int *__restrict__ sort_idx,
-                                                      int *__restrict__ key_count) {
+                                                      int *__restrict__ key_count, unsigned long long *__restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int G = 64 / KP;                                  // lanes per keypoint
   const int W = k.smm, WW = W * W, WP = (WW + 3) & ~3;
@@ -784,7 +784,9 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
     bool converged = false;
     bool active = have && k.do_baumberg;       // still iterating (uniform within the keypoint's lanes)
     if (!k.do_baumberg) converged = true;
+    int n_iter = 0;
     for (int l = 0; l < k.max_iter && __any(active); l++) {
+      n_iter += active ? 1 : 0;
       const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
       wave_sync();   // previous iteration's readers are done with the tiles
       BPROF(0)
@@ -940,6 +942,11 @@ __global__ __launch_bounds__(64, BAUMBERG_WAVES) void baumberg_kernel(const Pyra
       }
     }
     if (have && sl == 0) {
+      // (bench.py's per-keypoint figures; off unless mods_baumberg_stats_enable)
+      if (stats && n_iter) {                     // 64 slots per image: the adds of a launch's 8192 workgroups do not queue on one word
+        unsigned long long *st = stats + 2 * ((size_t)b * 64 + (blockIdx.x & 63));
+        atomicAdd(&st[0], 1ull); atomicAdd(&st[1], (unsigned long long)n_iter);
+      }
       if (converged) {
         cd.a11 = u11; cd.a12 = u12; cd.a21 = u21; cd.a22 = u22;
         cd.state = 3;
@@ -1241,7 +1248,7 @@ static int detect_run_stages(mods_ctx *ctx) {
     else
       hipLaunchKernelGGL(baumberg_kernel<BAUMBERG_KP>, dim3(8192, n_img), dim3(64), lds, ctx->stream, ctx->pyr_dev, k, ctx->cand,
                          ctx->sort_idx + (size_t)ctx->batch * ctx->max_cand, acc_count, ctx->smm_mask_dev, ctx->sort_keys,
-                         ctx->sort_idx, key_count);
+                         ctx->sort_idx, key_count, ctx->baum_stats_dev);
     MODS_HIP_CHECK(hipGetLastError());
   }
   {

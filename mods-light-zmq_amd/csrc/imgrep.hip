@@ -57,8 +57,9 @@ int mods_host_alloc(size_t bytes, void **out) { if (!out) return MODS_E_ARG; MOD
 int mods_host_free(void *p) { MODS_HIP_CHECK(hipHostFree(p)); return MODS_OK; }
 int mods_dev_alloc(size_t bytes, void **out) { if (!out) return MODS_E_ARG; MODS_HIP_CHECK(hipMalloc(out, bytes ? bytes : 4)); return MODS_OK; }
 int mods_dev_free(void *p) { MODS_HIP_CHECK(hipFree(p)); return MODS_OK; }
-int mods_dev_upload(void *dst_dev, const void *src_host, size_t bytes) { MODS_HIP_CHECK(mods::copy_wait(mods::thread_stream(), dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return MODS_OK; }
-int mods_dev_download(void *dst_host, const void *src_dev, size_t bytes) { MODS_HIP_CHECK(mods::copy_wait(mods::thread_stream(), dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return MODS_OK; }
+// (the copy runs on a stream of the device the buffer lives on; ordering contract: include/mods_hip.h)
+int mods_dev_upload(void *dst_dev, const void *src_host, size_t bytes) { MODS_HIP_CHECK(mods::copy_wait(mods::thread_stream(mods::device_of_pointer(dst_dev)), dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return MODS_OK; }
+int mods_dev_download(void *dst_host, const void *src_dev, size_t bytes) { MODS_HIP_CHECK(mods::copy_wait(mods::thread_stream(mods::device_of_pointer(src_dev)), dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return MODS_OK; }
 
 // ---- view schedule -------------------------------------------------------------------------------------
 // SetVSPars for one detector: the (zoom, tilt, phi) triples of a step that no earlier step has produced.

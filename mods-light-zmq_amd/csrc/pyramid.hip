@@ -859,7 +859,7 @@ static int upload_taps(mods_ctx *ctx, int slot, float sigma, int *n_out) {
   for (int i = 0; i < n; i++) ctx->taps_host[slot][i] = taps[i];
   ctx->taps_host_n[slot] = n;
   { const int wrc = wait_both_streams(ctx); if (wrc) return wrc; }   // earlier launches may still read the slot
-  ctx->dd_prev = mods_ctx::DdKey();
+  mods::dev_state_changed(ctx);
   MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->gauss_taps_dev + slot * 64, taps, sizeof(float) * n, hipMemcpyHostToDevice));
   ctx->taps_sigma[slot] = sigma;
   return MODS_OK;
@@ -1050,13 +1050,13 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
   if (plane_elems > ctx->plane_pool_elems) {
     if (ctx->plane_pool) MODS_HIP_CHECK(hipFree(ctx->plane_pool));
     ctx->plane_pool = nullptr;
-    { ctx->dd_stale = true; ctx->dd_prev = mods_ctx::DdKey(); } MODS_HIP_CHECK(hipMalloc(&ctx->plane_pool, plane_elems * sizeof(float)));
+    mods::dev_pool_reallocated(ctx); MODS_HIP_CHECK(hipMalloc(&ctx->plane_pool, plane_elems * sizeof(float)));
     ctx->plane_pool_elems = plane_elems;
   }
   if (omap_elems > ctx->omap_pool_elems) {
     if (ctx->omap_pool) MODS_HIP_CHECK(hipFree(ctx->omap_pool));
     ctx->omap_pool = nullptr;
-    { ctx->dd_stale = true; ctx->dd_prev = mods_ctx::DdKey(); } MODS_HIP_CHECK(hipMalloc(&ctx->omap_pool, omap_elems * sizeof(unsigned int)));
+    mods::dev_pool_reallocated(ctx); MODS_HIP_CHECK(hipMalloc(&ctx->omap_pool, omap_elems * sizeof(unsigned int)));
     ctx->omap_pool_elems = omap_elems;
     ctx->omap_dirty = true;
   }
@@ -1072,7 +1072,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
   // host-to-device copy in the steady state of a worker, and none inside a recorded graph - mods_ctx_graphs)
   if (!ctx->pyr_dev_valid || memcmp(&ctx->pyr_dev_image, &P, sizeof(PyramidDev)) != 0) {
     ctx->pyr_dev_valid = false;
-    ctx->dd_prev = mods_ctx::DdKey();     // (device state changed from the host: the next call is not a repeat - capi.hip: dd_run)
+    mods::dev_state_changed(ctx);     // (device state changed from the host: the next call is not a repeat - capi.hip: dd_run)
     MODS_HIP_CHECK(hipMemcpyAsync(ctx->pyr_dev, &P, sizeof(PyramidDev), hipMemcpyHostToDevice, ctx->stream));   // (stream ordered behind the readers of the old table)
     memcpy(&ctx->pyr_dev_image, &P, sizeof(PyramidDev));
     ctx->pyr_dev_valid = true;
@@ -1083,7 +1083,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
     if (need > ctx->alt_plane_elems) {
       if (ctx->alt_planes) MODS_HIP_CHECK(hipFree(ctx->alt_planes));
       ctx->alt_planes = nullptr; ctx->alt_plane_elems = 0;
-      { ctx->dd_stale = true; ctx->dd_prev = mods_ctx::DdKey(); } MODS_HIP_CHECK(hipMalloc(&ctx->alt_planes, 4 * need * sizeof(float)));
+      mods::dev_pool_reallocated(ctx); MODS_HIP_CHECK(hipMalloc(&ctx->alt_planes, 4 * need * sizeof(float)));
       ctx->alt_plane_elems = need;
     }
     for (int l = 0; l < n_levels; l++) {
@@ -1094,7 +1094,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
       std::vector<float> taps(n);
       gauss_kernel_host(n, (double)sigma, taps.data());
       { const int wrc = wait_both_streams(ctx); if (wrc) return wrc; }
-      ctx->dd_prev = mods_ctx::DdKey();
+      mods::dev_state_changed(ctx);
       MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->alt_taps_dev + (size_t)l * kAltTapStride, taps.data(), sizeof(float) * n, hipMemcpyHostToDevice));
       ctx->alt_ntap[l] = n; ctx->alt_sigma[l] = sigma;
     }
@@ -1107,7 +1107,7 @@ int pyramid_configure(mods_ctx *ctx, int w, int h, int n_img, const mods_hessaff
     if (par->smmWindowSize < 3 || par->smmWindowSize > 31 || !(par->smmWindowSize & 1)) { set_error("smmWindowSize %d unsupported", par->smmWindowSize); return MODS_E_ARG; }
     std::vector<float> m((size_t)par->smmWindowSize * par->smmWindowSize);
     gauss_mask_host(par->smmWindowSize, m.data());
-    ctx->dd_prev = mods_ctx::DdKey();
+    mods::dev_state_changed(ctx);
     MODS_HIP_CHECK(mods::copy_wait(ctx->stream, ctx->smm_mask_dev, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
     ctx->smm_mask_size = par->smmWindowSize;
   }

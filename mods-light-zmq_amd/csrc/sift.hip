@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void blur_table_kernel(int ps, float *__restri
 int launch_blur_table(mods_ctx *ctx, int ps) {
   if (ctx->blur_table_ps == ps && ctx->blur_table_dev) return MODS_OK;
   if (!ctx->blur_table_dev) MODS_HIP_CHECK(hipMalloc(&ctx->blur_table_dev, sizeof(float) * (SMALL_CAP + 1) * BT_ENTRY));
-  ctx->dd_prev = mods_ctx::DdKey();      // (device state changes: the next detect + describe call is not a repeat - capi.hip: dd_run)
+  mods::dev_state_changed(ctx);      // (device state changes: the next detect + describe call is not a repeat - capi.hip: dd_run)
   hipLaunchKernelGGL(blur_table_kernel, dim3(SMALL_CAP + 1), dim3(256), 0, ctx->stream, ps, ctx->blur_table_dev);
   MODS_HIP_CHECK(hipGetLastError());
   ctx->blur_table_ps = ps;
@@ -1557,7 +1557,7 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
     MODS_HIP_CHECK(mods::stream_wait(ctx->stream));
     if (ctx->desc_scratch) MODS_HIP_CHECK(hipFree(ctx->desc_scratch));
     ctx->desc_scratch = nullptr;
-    { ctx->dd_stale = true; ctx->dd_prev = mods_ctx::DdKey(); } MODS_HIP_CHECK(hipMalloc(&ctx->desc_scratch, need * sizeof(float)));
+    mods::dev_pool_reallocated(ctx); MODS_HIP_CHECK(hipMalloc(&ctx->desc_scratch, need * sizeof(float)));
     ctx->desc_scratch_elems = need;
   }
   float *patches = ctx->desc_scratch;
@@ -1570,6 +1570,8 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   float *pool = ctx->desc_scratch + patch_elems + book_elems;
   MODS_HIP_CHECK(hipMemsetAsync(bl, 0, sizeof(BigLists), ctx->stream));
   { const int trc = launch_blur_table(ctx, ps); if (trc) return trc; }
+  {
+  StageScope ts_extract(ctx, MODS_STAGE_EXTRACT);
   k.tap_cap = 4096;
   const int small_cap = SMALL_CAP;   // P2 limit of the LDS tier
   k.p2_hi = small_cap;
@@ -1601,6 +1603,8 @@ int launch_extract_and_sift(mods_ctx *ctx, const float *img_dev, int n_img, Desc
   hipLaunchKernelGGL(big_rowpass_kernel, dim3(4096), dim3(256), 0, ctx->stream, k, bl, bregs, ritems, max_items, pool,
                      ctx->desc_err_dev);
   hipLaunchKernelGGL(big_colres_kernel, dim3(4096), dim3(256), 0, ctx->stream, k, bl, bregs, max_big, pool, patches, ctx->desc_err_dev);
+  }
+  StageScope ts_sift(ctx, MODS_STAGE_SIFT);
   if (run_sift && ps > 45)   // the block-per-region form: patch sizes the wave form's register rows do not cover
     hipLaunchKernelGGL(sift_kernel, dim3(2048, n_img), dim3(256), sift_lds_bytes(ps), ctx->stream, k, patches, ctx->regions_dev,
                        ctx->region_count, dmask, tab);
