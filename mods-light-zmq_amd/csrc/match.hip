@@ -552,16 +552,20 @@ __device__ __forceinline__ bool ratio_ok(int d0, int d, double sqmin) {
 //                                  key_ge = (d1, t1), n_lt = 0 (what pass 2 would have found)
 //   d1 <  D*, t1 far from i0       a contradicting neighbour below D*: bad, rejected whatever the other trains are
 //   d1 <  D*, t1 near i0           undecided: the query goes on the pass-2 list (descriptor, norm and state are copied to the
-//                                  compact arrays by match_gather_kernel)
+//                                  compact arrays)
 __global__ __launch_bounds__(256) void match_mid_kernel(MatchJobs J, MatchConst k, const unsigned long long *__restrict__ best2,
                                                         const double2 *__restrict__ txy, QueryMid *__restrict__ mid,
                                                         unsigned long long *__restrict__ key_ge, unsigned long long *__restrict__ key_lt,
                                                         int *__restrict__ n_lt, int *__restrict__ bad, int *__restrict__ list2,
-                                                        int *__restrict__ count2) {
+                                                        int *__restrict__ count2, const int8_t *__restrict__ qdesc,
+                                                        const int *__restrict__ qc, int8_t *__restrict__ qdesc2, int *__restrict__ qc2,
+                                                        QueryMid *__restrict__ mid2) {
   const int job = blockIdx.y;
   k.n_q = J.n_q[job]; k.n_t = J.n_t[job];
   const int splits = 1; const size_t n_qpad = (size_t)k.n_q;     // (the finish kernel leaves one exact pair of keys per query)
   best2 = set_by(best2, job, J.s_p2); list2 = set_by(list2, job, J.s_p2); count2 = set_by(count2, job, J.s_p2);
+  qdesc2 = set_by(qdesc2, job, J.s_p2); qc2 = set_by(qc2, job, J.s_p2); mid2 = set_by(mid2, job, J.s_p2);
+  qdesc = set_by(qdesc, job, J.s_desc); qc = set_el(qc, job, J.s_c);
   txy = set_el(txy, job, J.s_xy); mid = set_el(mid, job, J.s_mid);
   key_ge = set_el(key_ge, job, J.s_u64); key_lt = set_el(key_lt, job, J.s_u64); n_lt = set_el(n_lt, job, J.s_int); bad = set_el(bad, job, J.s_int);
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -599,28 +603,23 @@ __global__ __launch_bounds__(256) void match_mid_kernel(MatchJobs J, MatchConst 
       const double2 q = txy[(unsigned int)m2];
       const double dx = m.x0 - q.x, dy = m.y0 - q.y;
       if (dx * dx + dy * dy > k.contr_sq) isbad = 1;
-      else list2[atomicAdd(count2, 1)] = j;
+      else {
+        // undecided: the query goes on the pass-2 list, and this thread leaves its descriptor row, norm and state in the compact
+        // arrays (a few % of the queries: eight 16-byte copies each; a launch of its own for this was 5 us + a boundary, round 6)
+        const int i = atomicAdd(count2, 1);
+        list2[i] = j;
+        const uint4 *src = (const uint4 *)(qdesc + (size_t)j * 128);
+        uint4 *dst = (uint4 *)(qdesc2 + (size_t)i * 128);
+        uint4 row[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) row[q] = src[q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = row[q];
+        qc2[i] = qc[j]; mid2[i] = m;
+      }
     }
   }
   key_ge[j] = kg; key_lt[j] = ~0ull; n_lt[j] = 0; bad[j] = isbad;
-}
-
-// one wave per pass-2 query: descriptor row, norm and state into the compact arrays.  grid = ceil(n_q/4), block 256.
-__global__ __launch_bounds__(256) void match_gather_kernel(MatchJobs J, const int *__restrict__ list2, const int *__restrict__ count2,
-                                                           const int8_t *__restrict__ qdesc, const int *__restrict__ qc,
-                                                           const QueryMid *__restrict__ mid, int8_t *__restrict__ qdesc2,
-                                                           int *__restrict__ qc2, QueryMid *__restrict__ mid2) {
-  const int job = blockIdx.y;
-  list2 = set_by(list2, job, J.s_p2); count2 = set_by(count2, job, J.s_p2); qdesc2 = set_by(qdesc2, job, J.s_p2);
-  qc2 = set_by(qc2, job, J.s_p2); mid2 = set_by(mid2, job, J.s_p2);
-  qdesc = set_by(qdesc, job, J.s_desc); qc = set_el(qc, job, J.s_c); mid = set_el(mid, job, J.s_mid);
-  const int n2 = *count2;
-  const int lane = threadIdx.x & 63;
-  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n2; i += gridDim.x * 4) {
-    const int j = list2[i];
-    ((short *)(qdesc2 + (size_t)i * 128))[lane] = ((const short *)(qdesc + (size_t)j * 128))[lane];
-    if (lane == 0) { qc2[i] = qc[j]; mid2[i] = mid[j]; }
-  }
 }
 
 // Pass 2: FGINN reductions.  Same tiling and the same two-speed epilogue as pass 1: a tile is examined exactly
@@ -765,7 +764,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
-// Decision + order-preserving compaction into the tentative list, in two launches over ceil(n_q/1024) blocks:
+// Decision + order-preserving compaction into the tentative list, in two launches over ceil(n_q / EMIT_T) blocks (EMIT_T = 256
+// since round 6: at 1024 queries per block a 60 000-query search kept 59 CUs busy with chains of dependent loads - 24 + 5 us):
 // the first counts the accepted queries of every block, the second adds up the counts of the blocks before it
 // and writes its own tentatives at that offset (query order is the output order of the reference's loop).
 __device__ __forceinline__ bool fginn_accept(const MatchConst &k, int j, const QueryMid *__restrict__ mid,
@@ -794,7 +794,8 @@ __device__ __forceinline__ bool fginn_accept(const MatchConst &k, int j, const Q
   return true;
 }
 
-__global__ __launch_bounds__(1024) void match_emit_count_kernel(MatchJobs J, MatchConst k, const QueryMid *__restrict__ mid,
+constexpr int EMIT_T = 256;        // queries (= threads) per block of the emit stage
+__global__ __launch_bounds__(EMIT_T) void match_emit_count_kernel(MatchJobs J, MatchConst k, const QueryMid *__restrict__ mid,
                                                                 const unsigned long long *__restrict__ key_ge,
                                                                 const unsigned long long *__restrict__ key_lt, const int *__restrict__ n_lt,
                                                                 const int *__restrict__ bad, int *__restrict__ block_counts) {
@@ -804,12 +805,12 @@ __global__ __launch_bounds__(1024) void match_emit_count_kernel(MatchJobs J, Mat
   mid = set_el(mid, job, J.s_mid); key_ge = set_el(key_ge, job, J.s_u64); key_lt = set_el(key_lt, job, J.s_u64);
   n_lt = set_el(n_lt, job, J.s_int); bad = set_el(bad, job, J.s_int); block_counts = set_el(block_counts, job, J.s_int);
   mods_tentative tc;
-  const bool emit = fginn_accept(k, blockIdx.x * 1024 + threadIdx.x, mid, key_ge, key_lt, n_lt, bad, &tc);
+  const bool emit = fginn_accept(k, blockIdx.x * EMIT_T + threadIdx.x, mid, key_ge, key_lt, n_lt, bad, &tc);
   const int c = __syncthreads_count(emit ? 1 : 0);
   if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
 }
 
-__global__ __launch_bounds__(1024) void match_emit_kernel(MatchJobs J, MatchConst k, const QueryMid *__restrict__ mid,
+__global__ __launch_bounds__(EMIT_T) void match_emit_kernel(MatchJobs J, MatchConst k, const QueryMid *__restrict__ mid,
                                                           const unsigned long long *__restrict__ key_ge,
                                                           const unsigned long long *__restrict__ key_lt, const int *__restrict__ n_lt,
                                                           const int *__restrict__ bad, const double2 *__restrict__ qxy,
@@ -830,18 +831,18 @@ __global__ __launch_bounds__(1024) void match_emit_kernel(MatchJobs J, MatchCons
   // offset of this block = accepted queries of all earlier blocks; the total fixes the packed layout of the output
   // (tentatives | correspondences | frames, see common.hpp)
   int part = 0, tot = 0;
-  for (int q = tid; q < n_blocks; q += 1024) { const int c = block_counts[q]; tot += c; if (q < (int)blockIdx.x) part += c; }
+  for (int q = tid; q < n_blocks; q += EMIT_T) { const int c = block_counts[q]; tot += c; if (q < (int)blockIdx.x) part += c; }
   for (int off = 32; off > 0; off >>= 1) { part += __shfl_xor(part, off); tot += __shfl_xor(tot, off); }
   if (lane == 0) { s_wave[wv] = part; s_wtot[wv] = tot; }
   __syncthreads();
-  if (tid == 0) { int t = 0, u = 0; for (int q = 0; q < 16; q++) { t += s_wave[q]; u += s_wtot[q]; } s_base = t; s_total = u; }
+  if (tid == 0) { int t = 0, u = 0; for (int q = 0; q < EMIT_T / 64; q++) { t += s_wave[q]; u += s_wtot[q]; } s_base = t; s_total = u; }
   __syncthreads();
   const int base = s_base;
   const size_t n_out = (size_t)min(s_total, max_out);
   double *u6 = (double *)((char *)out + tent_u6_off(n_out)), *laf = (double *)((char *)out + tent_laf_off(n_out));
   __syncthreads();
   mods_tentative tc;
-  const bool emit = fginn_accept(k, blockIdx.x * 1024 + tid, mid, key_ge, key_lt, n_lt, bad, &tc);
+  const bool emit = fginn_accept(k, blockIdx.x * EMIT_T + tid, mid, key_ge, key_lt, n_lt, bad, &tc);
   const unsigned long long mm = __ballot(emit);
   if (lane == 0) s_wave[wv] = __popcll(mm);
   __syncthreads();
@@ -864,7 +865,7 @@ __global__ __launch_bounds__(1024) void match_emit_kernel(MatchJobs J, MatchCons
   }
   if ((int)blockIdx.x == n_blocks - 1 && tid == 0) {   // total = offset of the last block + its own count
     int t = base;
-    for (int q = 0; q < 16; q++) t += s_wave[q];
+    for (int q = 0; q < EMIT_T / 64; q++) t += s_wave[q];
     *out_count = t;
   }
 }
@@ -911,7 +912,7 @@ static void match_strides(const mods_ctx *ctx, MatchJobs *J) {
   J->s_c = 4 * n + 2 * (n / 32 + 2);
   J->s_xy = 2 * n;
   J->s_u64 = 3 * n;
-  J->s_int = 2 * n + n / 1024 + 2;
+  J->s_int = 2 * n + n / 256 + 2;         // n_lt | bad | the emit stage's block counts (EMIT_T = 256 queries per block)
   J->s_mid = n;
   J->s_p2 = (ctx->m_best2_cap * 16 + n * 16 + n * (3 * sizeof(int) + 128 + sizeof(QueryMid)) + 128 + 255) & ~(size_t)255;
 }
@@ -1001,7 +1002,7 @@ int match_run_group(mods_ctx *ctx, int n_jobs, const mods_region *const *q_dev, 
     const Nn1Grid gr = nn1_grid(n_q[j], n_t[j]);
     if ((size_t)gr.splits * gr.n_qpad > ctx->m_best2_cap) { set_error("match: pass-1 key table too small"); return MODS_E_CAPACITY; }
     J.tps[j] = gr.tiles_per_split; J.qblocks[j] = gr.qblocks; J.splits[j] = gr.splits;
-    J.eblocks[j] = (n_q[j] + 1023) / 1024;
+    J.eblocks[j] = (n_q[j] + EMIT_T - 1) / EMIT_T;
     max_q = std::max(max_q, n_q[j]); max_t = std::max(max_t, n_t[j]);
     max_nn1 = std::max(max_nn1, gr.qblocks * gr.splits); max_eb = std::max(max_eb, J.eblocks[j]);
   }
@@ -1031,10 +1032,8 @@ int match_run_group(mods_ctx *ctx, int n_jobs, const mods_region *const *q_dev, 
     }
     hipLaunchKernelGGL(match_fix_kernel, dim3((max_q + 7) / 8, G), dim3(256), 0, ctx->stream, J, k, (const uint4 *)best3, qd, qc, td, tc, best2);
     hipLaunchKernelGGL(match_mid_kernel, dim3((max_q + 255) / 256, G), dim3(256), 0, ctx->stream, J, k, (const unsigned long long *)best2, txy,
-                       (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, list2, count2);
+                       (QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, list2, count2, qd, qc, qd2, qcs, mid2);
     // pass 2 on the undecided queries only (their number stays on the device: the grid covers the worst case, idle blocks exit)
-    hipLaunchKernelGGL(match_gather_kernel, dim3(std::min(1024, (max_q + 3) / 4), G), dim3(256), 0, ctx->stream, J, list2, count2, qd, qc,
-                       (const QueryMid *)ctx->m_mid, qd2, qcs, mid2);
     {
       const int qblocks = (max_q + 128 * MATCH_QB - 1) / (128 * MATCH_QB);
       // (a group shares the chip: a single search gets the whole row of workgroups, the searches of a group their share of it)
@@ -1043,8 +1042,8 @@ int match_run_group(mods_ctx *ctx, int n_jobs, const mods_region *const *q_dev, 
                          (const QueryMid *)mid2, key_ge, key_lt, n_lt, bad, count2, list2);
     }
     int *block_counts = (int *)(ctx->m_int + 2 * n);
-    hipLaunchKernelGGL(match_emit_count_kernel, dim3(max_eb, G), dim3(1024), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
-    hipLaunchKernelGGL(match_emit_kernel, dim3(max_eb, G), dim3(1024), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy,
+    hipLaunchKernelGGL(match_emit_count_kernel, dim3(max_eb, G), dim3(EMIT_T), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
+    hipLaunchKernelGGL(match_emit_kernel, dim3(max_eb, G), dim3(EMIT_T), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy,
                        block_counts, ctx->max_cand);
   }
   MODS_HIP_CHECK(hipGetLastError());
@@ -1126,15 +1125,15 @@ int match_run_distance(mods_ctx *ctx, const mods_region *q_dev, int n_q, const m
   hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_q + 3) / 4)), dim3(256), 0, ctx->stream, q_dev, (const int *)nullptr, n_q, qd, qc, qc2, qpar, qxy, ctx->max_cand);
   hipLaunchKernelGGL(match_pack_kernel, dim3(std::min(2048, (n_t + 3) / 4)), dim3(256), 0, ctx->stream, t_dev, (const int *)nullptr, n_t, td, tc, tc2, tpar, txy, ctx->max_cand);
   hipLaunchKernelGGL(hamming_nn2_kernel, dim3((n_q + 255) / 256), dim3(256), 0, ctx->stream, k, qd, td, (QueryMid *)ctx->m_mid, key_ge);
-  const int eblocks = (n_q + 1023) / 1024;
+  const int eblocks = (n_q + EMIT_T - 1) / EMIT_T;
   int *block_counts = (int *)(ctx->m_int + 2 * n);
   MatchJobs J;
   memset(&J, 0, sizeof(J));
   match_strides(ctx, &J);
   J.n_jobs = 1; J.n_q[0] = n_q; J.n_t[0] = n_t; J.eblocks[0] = eblocks;
   J.q_reg[0] = q_dev; J.t_reg[0] = t_dev; J.tent_out[0] = ctx->m_tent; J.count_out[0] = ctx->m_count;
-  hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
-  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(1024), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, block_counts, ctx->max_cand);
+  hipLaunchKernelGGL(match_emit_count_kernel, dim3(eblocks), dim3(EMIT_T), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, block_counts);
+  hipLaunchKernelGGL(match_emit_kernel, dim3(eblocks), dim3(EMIT_T), 0, ctx->stream, J, k, (const QueryMid *)ctx->m_mid, key_ge, key_lt, n_lt, bad, qxy, txy, block_counts, ctx->max_cand);
   MODS_HIP_CHECK(hipGetLastError());
   return MODS_OK;
 }
