@@ -697,17 +697,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
   // (pass 2 takes the exact path on most tiles at these list sizes: its waves drift apart, a barrier per tile costs more than
   // the shared fetch saves, so every wave fetches its own operands)
+  // round 6: the operands and seeds of tile tt + 1 are requested before tile tt is multiplied and examined (a wave fetched them at
+  // the top of every step and waited a full round trip per tile: ~1 us x 29 tiles per workgroup at 60 156 x 47 177); the rows of
+  // the step behind the split's last tile are read clamped and not used
+  v4i an[4];
+  v16i seedn;
+  {
+    const int8_t *arow = tdesc + (size_t)(t0 * 32 + (lane & 31)) * 128 + g * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) an[ks] = *(const v4i *)(arow + ks * 32);
+    seedn = acc_seed(tc2n, t0 * 32, g);
+  }
   for (int tt = t0; tt < t1; tt++) {
     const int tbase = tt * 32;
-    const int8_t *arow = tdesc + (size_t)(tbase + (lane & 31)) * 128 + g * 16;
     v4i a[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) a[ks] = *(const v4i *)(arow + ks * 32);
+    for (int ks = 0; ks < 4; ks++) a[ks] = an[ks];
     const unsigned int par = tpar[tt];   // wave-uniform: ct & 1 of the 32 train rows
     v16i acc[QB];
-    acc[0] = acc_seed(tc2n, tbase, g);
+    acc[0] = seedn;
 #pragma unroll
     for (int b = 1; b < QB; b++) acc[b] = acc[0];
+    {
+      const int tn = tt + 1 < t1 ? tt + 1 : tt;
+      const int8_t *arow = tdesc + (size_t)(tn * 32 + (lane & 31)) * 128 + g * 16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) an[ks] = *(const v4i *)(arow + ks * 32);
+      seedn = acc_seed(tc2n, tn * 32, g);
+    }
 #endif
 #pragma unroll
     for (int ks = 0; ks < 4; ks++)
