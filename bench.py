@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 def pmc_blur_traffic():
     """HBM bytes per launch of the dominant blur instantiation from the newest committed PMC passes (profiles/rNN_pmc_blur_traffic.csv:
-    FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc runs, 16 images per launch)."""
+    FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, separate rocprofv3 --pmc runs, at the default batching: 32 images per launch)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_blur_traffic.csv")), reverse=True):
         try:
@@ -435,9 +435,9 @@ def main():
                     help="image pairs in the batch that one step processes (default 256 for the headline configuration: 20 steps are\n"
                          "~5000 pairs = a timed region of several seconds; 48 for c4, 8 for c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gpu-workers", type=int, default=6, help="pipeline threads running detect/describe/match (one context each)")
+    ap.add_argument("--gpu-workers", type=int, default=4, help="pipeline threads running detect/describe/match (one context each; round 6, tools/sweep_pipeline.sh: 4 x 16 pairs per batch 994 pairs/s, 6 x 8 928)")
     ap.add_argument("--verify-workers", type=int, default=8, help="pipeline threads running duplicate filter + LO-RANSAC")
-    ap.add_argument("--pairs-per-batch", type=int, default=8, help="pairs a GPU worker pushes through detect/describe as one batch of launches")
+    ap.add_argument("--pairs-per-batch", type=int, default=16, help="pairs a GPU worker pushes through detect/describe as one batch of launches (at most 16: one grouped match launch)")
     ap.add_argument("--serial", action="store_true", help="no cross-pair overlap: one mods_match_pair_dev call per step (images in HBM)")
     ap.add_argument("--input", default="host_u8", choices=["host_u8", "host_f32", "hbm"],
                     help="where a pair lives when its step starts: 8-bit grey in pinned host memory (default: the boundary of the "
@@ -772,7 +772,7 @@ def main():
             return by / (ms * 1e-3) / 1e9 if ms else 0.0
         achieved = gbs(blur_bytes, blur_ms)
         i_ms, i_n, i_bytes, is_ms, is_n, is_bytes = iso
-        traffic = pmc_blur_traffic() if (args.config == "c2" and pipe is not None and args.pairs_per_batch == 8 and args.inlier_ratio == 0) else None
+        traffic = pmc_blur_traffic() if (args.config == "c2" and pipe is not None and args.pairs_per_batch == 16 and args.inlier_ratio == 0) else None
         out = {
             "metric": "image_pairs_per_sec_end_to_end", "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -816,7 +816,7 @@ def main():
                          "bytes_model": "SURVEY 8d unfused: 16 B/px per level",
                          "achieved_fused_model": round(gbs(i_bytes, i_ms) * 0.75, 2), "frac_fused_model": round(gbs(i_bytes, i_ms) * 0.75 / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
-                         # note + WRITE_SIZE, mean over the blur launches of the default batching, 16 images per launch)
+                         # note + WRITE_SIZE, mean over the blur launches of the default batching, 32 images per launch)
                          "traffic": traffic,
                          # what the counters say the kernel moves per second against the 8 TB/s peak (traffic / mean launch time):
                          # the kernel's REAL HBM rate, beside the model figure above

@@ -322,12 +322,12 @@ def _check_against_oracle(res, m, want, Htrue):
 
 @pytest.mark.skipif(not refdeg.available(), reason="oracle/_ref not built")
 def test_bench_pipeline_path_vs_oracle(pkg):
-    """bench.py's own code path (BASELINE configs[1]): Pipeline(6 GPU workers x 8 pairs per batch + 8 verify workers) fed with the
-    benchmark's six 1920 x 1080 pairs as 8-bit images in pinned host memory, 48 submissions = one bench step; every result -
+    """bench.py's own code path (BASELINE configs[1]): Pipeline(4 GPU workers x 16 pairs per batch + 8 verify workers) fed with the
+    benchmark's six 1920 x 1080 pairs as 8-bit images in pinned host memory, 64 submissions = a batch per worker; every result -
     counts, RANSAC statistics, the inlier list and H - against the CPU oracle chain of its pair (mods.cpp:202-383)."""
     import pipeline_oracle as po
     w, h = 1920, 1080
-    n_pairs, n_sub = 6, 48
+    n_pairs, n_sub = 6, 64
     oracle = [po.cached_pair(w, h, 2000 + i, 12345) for i in range(n_pairs)]
     pinned = []
     for a, b, _, _ in oracle:
@@ -336,7 +336,7 @@ def test_bench_pipeline_path_vs_oracle(pkg):
         pinned.append(buf)
     par = pkg.PairParams.default()
     pkg.ransac_pin_seed(12345)
-    pipe = pkg.Pipeline(0, w, h, par, 6, 8, 8)
+    pipe = pkg.Pipeline(0, w, h, par, 4, 8, 16)
     got, pending = [], 0
     for i in range(n_sub):
         if pending >= pipe.capacity - 1:

@@ -1,8 +1,8 @@
 # Runs on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh r02'): the bench line, the rocprofv3 kernel statistics of the same
-# command, the isolated detector leg (one stream, 16 images per launch), the two PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+# command, the isolated detector leg (one stream, 32 images per launch = the bench's batching since round 6), the two PMC passes (FETCH_SIZE / WRITE_SIZE, separate
 # runs, --kernel-trace only) for the HBM traffic of the fused blur + response kernel at the bench's batching, the matcher
 # micro-benchmark (kernel statistics + SQ counters), and SQ counters of the describe-stage kernels.  Outputs: gpurun_out/<tag>/.
-TAG=${1:-r03}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -12,14 +12,14 @@ grep '^{"metric"' $OUT/bench.log > $OUT/bench.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 grep '^{"metric"' $OUT/stats.log > $OUT/bench_under_rocprof.json
-# the isolated leg alone (one stream, 16 images per launch): its blur durations are the ones bench.py's "isolated" events see
-PYR_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -- python $R/tools/prof_detect.py 16 > $OUT/detect_leg.log 2>&1
+# the isolated leg alone (one stream, 32 images per launch): its blur durations are the ones bench.py's "isolated" events see
+PYR_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -- python $R/tools/prof_detect.py 32 > $OUT/detect_leg.log 2>&1
 cp $(find $OUT/leg -name "*kernel_stats.csv" | head -1) $OUT/detect_leg_kernel_stats.csv
 # the same leg as shipped (small octaves on the prioritised side stream: launches of the two streams overlap)
-rm -rf $OUT/leg; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -- python $R/tools/prof_detect.py 16 > $OUT/detect_leg_two_streams.log 2>&1
+rm -rf $OUT/leg; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -- python $R/tools/prof_detect.py 32 > $OUT/detect_leg_two_streams.log 2>&1
 cp $(find $OUT/leg -name "*kernel_stats.csv" | head -1) $OUT/detect_leg_two_streams_kernel_stats.csv
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/tools/prof_detect.py 16 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/tools/prof_detect.py 16 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/tools/prof_detect.py 32 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/tools/prof_detect.py 32 > /dev/null 2>&1
 python3 $R/tools/pmc_blur.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/pmc_blur_traffic.csv
 # matcher: BASELINE configs[4]-sized lists (tools/_cache/match_fixture.npz travels with the snapshot when it exists)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mstats -- python $R/tools/bench_match.py > $OUT/match.log 2>&1
