@@ -151,6 +151,42 @@ def test_small_and_odd_sizes_end_to_end(pkg, w, h):
     ctx.close()
 
 
+@pytest.mark.parametrize("smm", [9, 19, 23, 27, 31])
+def test_baumberg_window_sizes(pkg, smm):
+    """[HessianAffine] smmWindowSize other than the .ini's 19: baumberg_kernel keeps three product arrays per keypoint (the third
+    over the window itself) while a keypoint's 32 lanes cover a window row (W <= 32: all of these), samples windows of up to 24
+    columns with the next tile row's taps in flight and wider ones tile row by tile row (27, 31): the shapes are the oracle's."""
+    import orc
+    import synth
+    img = synth.texture(640, 480, seed=77)
+    gp, op = pkg.HessAffParams.default(), orc.HessAffParams.default()
+    gp.smmWindowSize = smm; op.smmWindowSize = smm
+    ctx = pkg.Context(0, 640, 480, 1)
+    got, want = ctx.detect_hessian_affine(img, params=gp), orc.detect_hessian_affine(img, params=op)
+    assert len(got) == len(want) and len(got) > 200
+    for f in ("x", "y", "s", "a11", "a12", "a21", "a22", "response"):
+        assert np.array_equal(got[f], want[f]), f
+    ctx.close()
+
+
+def test_baumberg_work_counters(pkg):
+    """mods_baumberg_stats: keypoints that entered the iteration = the points the pyramid accepted, 1 .. max_iter iterations each."""
+    import synth
+    img = synth.texture(640, 480, seed=78)
+    ctx = pkg.Context(0, 640, 480, 1)
+    ctx.baumberg_stats_enable(True)
+    keys = ctx.detect_hessian_affine(img)
+    kp, it = ctx.baumberg_stats(0)
+    assert kp >= len(keys) > 200 and kp <= it <= 16 * kp
+    keys2 = ctx.detect_hessian_affine(img)
+    kp2, it2 = ctx.baumberg_stats(0)
+    assert (kp2, it2) == (2 * kp, 2 * it) and np.array_equal(keys2["a11"], keys["a11"])
+    ctx.baumberg_stats_enable(False)
+    with pytest.raises(pkg.ModsError):
+        ctx.baumberg_stats(0)
+    ctx.close()
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3, 4])
 def test_keypoint_selection_modes(pkg, mode):
     """[HessianAffine] mode = RelativeTh / FixedRegNumber / RelativeRegNumber / NotLessThanRegions
