@@ -74,23 +74,52 @@ __global__ void __launch_bounds__(256) ransacf_score_kernel(const double *__rest
   }
 }
 
-// plane-and-parallax candidates: counts[k] = #{i < n : FDs(uN_i, F_k) < limit}.  grid = (ceil(n/256), k)
-__global__ void __launch_bounds__(256) ransacf_count_kernel(const double *__restrict__ uN, int n, const double *__restrict__ Fs, double limit,
-                                                            int *__restrict__ counts) {
+// plane-and-parallax candidates: counts[k] = #{i < n : FDs(uN_i, F_k) < limit}, one workgroup per candidate (grid = k), with the candidates made on
+// the device (round 6; until then the host made k x 9 matrices and uploaded them): a candidate is F = ([e]x H^T)^T with e through the two parallax
+// lines of off-plane correspondences p0, p1 (rFtH, DegUtils.c:254-444) - ~80 fp64 operations that the host spent 30 us per block of
+// 2048 on, and nine doubles per candidate to upload.  Here a block gets the two indices and thread 0 makes F with the host code's
+// operations in the host code's order (rs::rFtH's `candidate`: crossprod x 3, the norm's sqrt and three divisions, skew_sym, the 3 x 3
+// product with its zero terms, the transpose; no contraction on either side), so the counts are the host candidates' counts.
+// us: per off-plane correspondence (x, y, 1 of image 1 | H^T-side point of image 2), as rFtH builds it; Ht: H transposed.
+struct RfthHt { double v[9]; };
+__global__ void __launch_bounds__(256) ransacf_count_pairs_kernel(const double *__restrict__ uN, const double *__restrict__ us, int n,
+                                                                  const unsigned int *__restrict__ pairs, RfthHt Ht, double limit,
+                                                                  int *__restrict__ counts) {
   __shared__ double F[9];
-  const int k = blockIdx.y;
-  if (threadIdx.x < 9) F[threadIdx.x] = Fs[(size_t)k * 9 + threadIdx.x];
+  __shared__ int s_c[4];
+  const int k = blockIdx.x;
+  if (threadIdx.x == 0) {
+    const double *a0 = us + 6 * (size_t)pairs[2 * k], *a1 = us + 6 * (size_t)pairs[2 * k + 1];
+    double c1[3], c2[3], ec[3], sk[9], prod[9];
+    c1[0] = a0[1] * a0[5] - a0[2] * a0[4]; c1[1] = a0[2] * a0[3] - a0[0] * a0[5]; c1[2] = a0[0] * a0[4] - a0[1] * a0[3];
+    c2[0] = a1[1] * a1[5] - a1[2] * a1[4]; c2[1] = a1[2] * a1[3] - a1[0] * a1[5]; c2[2] = a1[0] * a1[4] - a1[1] * a1[3];
+    ec[0] = c1[1] * c2[2] - c1[2] * c2[1]; ec[1] = c1[2] * c2[0] - c1[0] * c2[2]; ec[2] = c1[0] * c2[1] - c1[1] * c2[0];
+    const double ecNorm = sqrt(ec[0] * ec[0] + ec[1] * ec[1] + ec[2] * ec[2]);
+    ec[0] = ec[0] / ecNorm; ec[1] = ec[1] / ecNorm; ec[2] = ec[2] / ecNorm;
+    sk[0] = 0; sk[1] = -ec[2]; sk[2] = ec[1];
+    sk[3] = ec[2]; sk[4] = 0; sk[5] = -ec[0];
+    sk[6] = -ec[1]; sk[7] = ec[0]; sk[8] = 0;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double sacc = 0.;
+        for (int q = 0; q < 3; q++) sacc += sk[3 * i + q] * Ht.v[3 * q + j];
+        prod[3 * i + j] = sacc;
+      }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) F[3 * i + j] = prod[3 * j + i];
+  }
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  bool in = false;
-  if (i < n) {
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
     double uu[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) uu[q] = uN[(size_t)i * 6 + q];
-    in = fds_from(uu, F) < limit;
+    c += fds_from(uu, F) < limit ? 1 : 0;
   }
-  const unsigned long long m = __ballot(in);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[k], __popcll(m));
+  for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[k] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
 }
 
 static bool gpu_score_f(RansacGpu *ws, int len, int n, int err_type, int do_sym, double th, double th_check) {
@@ -139,36 +168,52 @@ struct SimdEval : rs::PointEval {
   bool concurrent() const override { return true; }
 };
 
-// off-plane set of rFtH -> aux_dev
-static bool gpu_upload_aux(RansacGpu *ws, const double *uN, unsigned n) {
-  if ((size_t)n * 6 > ws->aux_cap) {
+// off-plane set of rFtH (uN) and its plane-transferred form (us, may be null) -> aux_dev: uN in the first half of the buffer, us behind it
+static bool gpu_upload_aux(RansacGpu *ws, const double *uN, const double *us, unsigned n) {
+  if ((size_t)n * 12 > ws->aux_cap) {
     if (ws->aux_dev) RS_CHECK(hipFree(ws->aux_dev));
-    ws->aux_cap = (size_t)n * 6 * 2;
+    ws->aux_cap = (size_t)n * 12 * 2;
     RS_CHECK(hipMalloc(&ws->aux_dev, ws->aux_cap * sizeof(double)));
   }
   RS_CHECK(hipMemcpyAsync(ws->aux_dev, uN, sizeof(double) * 6 * n, hipMemcpyHostToDevice, ws->stream));
+  if (us) RS_CHECK(hipMemcpyAsync(ws->aux_dev + (size_t)6 * n, us, sizeof(double) * 6 * n, hipMemcpyHostToDevice, ws->stream));
   RS_CHECK(mods::stream_wait(ws->stream));
   return true;
 }
-// counts k candidates (host array Fs, k x 9) over the n off-plane correspondences in aux_dev
-static bool gpu_count_pairs(RansacGpu *ws, unsigned n, const double *Fs, int k, double limit, unsigned *counts) {
+// Count of k candidates given as index pairs into the off-plane set (pairs: 2 k unsigned; us sits behind uN in aux_dev), in two
+// calls with a buffer slot (0 / 1) between them: begin queues upload, count and copy back on the workspace's stream and records the
+// slot's event; end waits for that event only - the other slot's block may be in flight behind it.
+static bool gpu_count_pairs_begin(RansacGpu *ws, int slot, unsigned n, const unsigned *pairs, int k, const double *Ht, double limit) {
   if (k > ws->cand_cap) {
-    if (ws->cand_dev) { RS_CHECK(hipFree(ws->cand_dev)); RS_CHECK(hipHostFree(ws->cand_host)); RS_CHECK(hipFree(ws->candc_dev)); RS_CHECK(hipHostFree(ws->candc_host)); }
-    ws->cand_cap = k;
-    RS_CHECK(hipMalloc(&ws->cand_dev, sizeof(double) * 9 * k));
-    RS_CHECK(hipHostMalloc(&ws->cand_host, sizeof(double) * 9 * k));
-    RS_CHECK(hipMalloc(&ws->candc_dev, sizeof(int) * k));
-    RS_CHECK(hipHostMalloc(&ws->candc_host, sizeof(int) * k));
+    RS_CHECK(hipStreamSynchronize(ws->stream));                            // (no slot is in flight when the first block of a call is the largest)
+    if (ws->cand_host) { RS_CHECK(hipHostFree(ws->cand_host)); RS_CHECK(hipHostFree(ws->candc_host)); }
+    const int cap = k > 2048 ? k : 2048;                                   // rFtH's block size: never grown with a slot in flight
+    ws->cand_cap = cap;
+    // both in pinned host memory the kernel addresses itself (16 KB of index pairs in, 8 KB of counts out per block): a block of
+    // candidates is ONE launch and one event, no copies to queue - the calls, not the work, were the cost of a block here
+    RS_CHECK(hipHostMalloc(&ws->cand_host, sizeof(unsigned) * 2 * 2 * cap, hipHostMallocMapped));
+    RS_CHECK(hipHostMalloc(&ws->candc_host, sizeof(int) * 2 * cap, hipHostMallocMapped));
+    RS_CHECK(hipHostGetDevicePointer((void **)&ws->cand_dev, ws->cand_host, 0));
+    RS_CHECK(hipHostGetDevicePointer((void **)&ws->candc_dev, ws->candc_host, 0));
   }
-  memcpy(ws->cand_host, Fs, sizeof(double) * 9 * k);
-  RS_CHECK(hipMemcpyAsync(ws->cand_dev, ws->cand_host, sizeof(double) * 9 * k, hipMemcpyHostToDevice, ws->stream));
-  RS_CHECK(hipMemsetAsync(ws->candc_dev, 0, sizeof(int) * k, ws->stream));
-  hipLaunchKernelGGL(ransacf_count_kernel, dim3((n + 255) / 256, k), dim3(256), 0, ws->stream, ws->aux_dev, (int)n, ws->cand_dev, limit, ws->candc_dev);
+  if (!ws->cand_ev[slot]) RS_CHECK(hipEventCreateWithFlags(&ws->cand_ev[slot], hipEventDisableTiming));
+  memcpy(ws->cand_host + (size_t)slot * 2 * ws->cand_cap, pairs, sizeof(unsigned) * 2 * k);
+  RfthHt ht;
+  for (int i = 0; i < 9; i++) ht.v[i] = Ht[i];
+  hipLaunchKernelGGL(ransacf_count_pairs_kernel, dim3(k), dim3(256), 0, ws->stream, ws->aux_dev, ws->aux_dev + (size_t)6 * n, (int)n,
+                     (const unsigned int *)(ws->cand_dev + (size_t)slot * 2 * ws->cand_cap), ht, limit, ws->candc_dev + (size_t)slot * ws->cand_cap);
   RS_CHECK(hipGetLastError());
-  RS_CHECK(hipMemcpyAsync(ws->candc_host, ws->candc_dev, sizeof(int) * k, hipMemcpyDeviceToHost, ws->stream));
-  RS_CHECK(mods::stream_wait(ws->stream));
-  for (int i = 0; i < k; i++) counts[i] = (unsigned)ws->candc_host[i];
+  RS_CHECK(hipEventRecord(ws->cand_ev[slot], ws->stream));
   ws->launches += 1;
+  return true;
+}
+static bool gpu_count_pairs_end(RansacGpu *ws, int slot, int k, unsigned *counts) {
+  hipError_t e = hipEventQuery(ws->cand_ev[slot]);                         // tens of microseconds: polled, no sleep
+  while (e == hipErrorNotReady) e = hipEventQuery(ws->cand_ev[slot]);
+  (void)hipGetLastError();                                                 // ("not ready" is not an error to leave behind)
+  RS_CHECK(e);
+  const int *ch = ws->candc_host + (size_t)slot * ws->cand_cap;
+  for (int i = 0; i < k; i++) counts[i] = (unsigned)ch[i];
   return true;
 }
 
@@ -451,9 +496,13 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
 
   // plane-and-parallax search with its two-point candidates counted on the GPU
   unsigned aux_n = 0;
-  auto upload_offplane = [&](const double *uN, unsigned n) { aux_n = n; if (!gpu_upload_aux(ws, uN, n)) F_FATAL(); };
-  rs::PairCounter count_pairs = [&](const double *Fs, int k, unsigned *counts) {
-    if (!gpu_count_pairs(ws, aux_n, Fs, k, th * 2, counts)) F_FATAL();
+  auto upload_offplane = [&](const double *uN, const double *us, unsigned n) { aux_n = n; if (!gpu_upload_aux(ws, uN, us, n)) F_FATAL(); };
+  rs::PairCounter count_pairs;
+  count_pairs.begin = [&](int slot, const unsigned *pairs, int k, const double *Ht) {
+    if (!gpu_count_pairs_begin(ws, slot, aux_n, pairs, k, Ht, th * 2)) F_FATAL();
+  };
+  count_pairs.end = [&](int slot, int k, unsigned *counts) {
+    if (!gpu_count_pairs_end(ws, slot, k, counts)) F_FATAL();
   };
 
   // LO block of the main loop, exp_ranF.c:1032-1070 (__LSQ_BEFORE_LO__); `source` = errs[4] in the loop,
@@ -678,7 +727,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
   }
   data_out[0] = no_sam;
   data_out[1] = iter_cnt;
-  if (prof) { fprintf(stderr, "[mods ransacF] rFtH: candidates %.2f ms, counting %.2f ms, %.0f blocks, %.0f off-plane; innerFH %.0f calls (+%.0f run ahead and dropped) in %.0f rounds %.2f ms on %d threads, %.0f fits in u2Fit %.2f thread-ms\n", rs::g_rfth_prof[0], rs::g_rfth_prof[1], rs::g_rfth_prof[2], rs::g_rfth_prof[3], rs::g_rfth_prof[6], rs::g_rfth_prof[8], rs::g_rfth_prof[9], rs::g_rfth_prof[4], rs::TaskPool::get().threads(), rs::g_rfth_prof[7], rs::g_rfth_prof[5]); for (double &x : rs::g_rfth_prof) x = 0; }
+  if (prof) { fprintf(stderr, "[mods ransacF] rFtH: candidates %.2f ms, counting %.2f ms, %.0f blocks, %.0f off-plane; innerFH %.0f calls (+%.0f run ahead and dropped) in %.0f rounds %.2f ms on %d threads, %.0f fits in u2Fit %.2f thread-ms; set-up %.2f ms, triggers %.2f ms, folding %.2f ms, count launches %.2f ms, innerFH stages %.2f + %.2f ms\n", rs::g_rfth_prof[0], rs::g_rfth_prof[1], rs::g_rfth_prof[2], rs::g_rfth_prof[3], rs::g_rfth_prof[6], rs::g_rfth_prof[8], rs::g_rfth_prof[9], rs::g_rfth_prof[4], rs::TaskPool::get().threads(), rs::g_rfth_prof[7], rs::g_rfth_prof[5], rs::g_rfth_prof[10], rs::g_rfth_prof[11], rs::g_rfth_prof[12], rs::g_rfth_prof[13], rs::g_rfth_prof[14], rs::g_rfth_prof[15]); for (double &x : rs::g_rfth_prof) x = 0; }
   if (prof) fprintf(stderr, "[mods ransacF] len %d samples %d lo %d degen %d | total %.2f ms: innerH %.2f rFtH %.2f LO %.2f\n", len, no_sam, iter_cnt,
                     degen_cnt, wall_ms() - t_begin, t_innerh, t_rfth, t_lo);
   if (Ih) *Ih = Ihmax;

@@ -836,7 +836,7 @@ static inline unsigned innerH(double *H, const double *u, unsigned len, double t
 // development aid (MODS_RANSAC_PROFILE): [0] rFtH candidate loops ms, [1] counting calls ms, [2] blocks, [3] off-plane points,
 // [4] innerFH ms, [5] least-squares fits inside u2Fit ms, [6] innerFH calls, [7] u2Fit fits, [8] inner estimations that were run
 // ahead and dropped (their trigger lay beyond the budget an earlier one set), [9] rounds of triggers
-static thread_local double g_rfth_prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static thread_local double g_rfth_prof[16] = {0};   // [10] set-up before the search, [11] trigger handling (drawing the inner samples), [12] folding, [13] launching the counts, [14] / [15] the sample-evaluation and refinement stages of innerFH
 static inline double rfth_prof_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 // ---- plane-and-parallax search ----------------------------------------------------------------------------
@@ -989,13 +989,17 @@ static inline void run_innerFH_jobs(InnerFHJob *const *jobs, int n, bool paralle
   std::vector<std::pair<int, int>> work;
   for (int j = 0; j < n; j++)
     for (int r = 0; r < jobs[j]->n_eval(); r++) work.push_back({j, r});
+  const double t0_ = rfth_prof_now();
   for_each((int)work.size(), [&](int i) { jobs[work[i].first]->eval(work[i].second); });
+  const double t1_ = rfth_prof_now();
+  g_rfth_prof[14] += t1_ - t0_;
   work.clear();
   for (int j = 0; j < n; j++) {
     jobs[j]->mark();
     for (int t = 0; t < jobs[j]->n_refine(); t++) work.push_back({j, t});
   }
   for_each((int)work.size(), [&](int i) { jobs[work[i].first]->refine(work[i].second); });
+  g_rfth_prof[15] += rfth_prof_now() - t1_;
 }
 static inline void innerFH(GlibcRand &rng, const double *uH, unsigned lenH, const double *uO, unsigned lenO, PointEval &ev,
                            double th, unsigned repCount, unsigned sam_sizH, unsigned sam_sizO, double *F, unsigned char *inl,
@@ -1009,20 +1013,31 @@ static inline void innerFH(GlibcRand &rng, const double *uH, unsigned lenH, cons
 
 // Counts, for k candidate matrices (k x 9), the off-plane correspondences with FDs < limit.
 // Supplied by the caller so that the GPU can do it; a null function means "count on the host".
-typedef std::function<void(const double *Fs, int k, unsigned *counts)> PairCounter;
+// by_matrix: the candidates as k x 9 matrices made on the host; by_index (preferred when set): as k index pairs (p0, p1) into the
+// off-plane set, the matrix F = ([e]x H^T)^T made where the count runs (Ht = H transposed; `candidate` below is its definition).
+// begin / end (both or neither): the count of a block of index pairs as two calls with a buffer slot 0 / 1 between them, so that the
+// next block can be drawn (and its count started) while this one is counted.
+struct PairCounter {
+  std::function<void(const double *Fs, int k, unsigned *counts)> by_matrix;
+  std::function<void(const unsigned *pairs, int k, const double *Ht, unsigned *counts)> by_index;
+  std::function<void(int slot, const unsigned *pairs, int k, const double *Ht)> begin;
+  std::function<void(int slot, int k, unsigned *counts)> end;
+  explicit operator bool() const { return (bool)by_matrix || (bool)by_index || (bool)begin; }
+};
 
 // rFtH, DegUtils.c:233-444: F from the plane homography H plus two off-plane correspondences.
 // hinl marks the on-plane correspondences; returns the best inlier count (3 when nothing was found,
 // 0 when there is not enough data) and writes F only on improvement.
 // `upload_offplane(uN, n)` is called once with the off-plane set before `count` is used.
 static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char *hinl, double th, const double *H, unsigned len, double *F,
-                            const std::function<void(const double *uN, unsigned n)> &upload_offplane, const PairCounter &count,
+                            const std::function<void(const double *uN, const double *us, unsigned n)> &upload_offplane, const PairCounter &count,
                             PointEval *ev_in = nullptr) {
   PointEval host_ev(u, (int)len);
   PointEval &ev = ev_in ? *ev_in : host_ev;
   const unsigned MAX_SAM = 10000;
   const double conf = .999;
   const unsigned sam_sizH = 6, sam_sizO = 4;
+  const double t_setup = rfth_prof_now();
   std::vector<unsigned char> nhinl(len), inl(len);
   unsigned nN = 0, nH = 0;
   {
@@ -1052,8 +1067,9 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
   for (unsigned i = 0; i < nN; ++i) ptr[i] = i;
   unsigned max_i = 3, m_i = sam_sizO, max_sam = MAX_SAM;
   if (nN < 4 || nH < 6) return 0;
-  if (upload_offplane) upload_offplane(uN.data(), nN);
+  if (upload_offplane) upload_offplane(uN.data(), us.data(), nN);
   g_rfth_prof[3] = nN;
+  g_rfth_prof[10] += rfth_prof_now() - t_setup;
 
   double Ht[9];
   mat3_tr(Ht, H);
@@ -1080,7 +1096,8 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
   // blocks; at a trigger the block is rewound to that sample and the tail is redrawn
   const unsigned BLOCK = count ? 2048 : 1;
   std::vector<double> Fs((size_t)9 * BLOCK);
-  std::vector<unsigned> cnt(BLOCK);
+  std::vector<unsigned> cnt(BLOCK), pairs((size_t)2 * BLOCK);
+  const bool by_index = (bool)count.by_index;
   // Between two inner estimations the loop only draws and counts, and what an inner estimation hands back to it is max_sam (the
   // budget, which can only shrink) - the generator leaves innerFH in a state that does not depend on its result (150 draws),
   // and m_i is set from the candidate's own count.  So the search runs AHEAD of the estimations, on the budget it knows: it
@@ -1099,27 +1116,74 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
     return max_i;
   };
   const bool parallel = ev.concurrent();
+  // With a begin / end counter the blocks are produced ONE AHEAD: while the device counts block A, the host draws block B from the
+  // state behind A (as if A held no trigger) and starts its count; a trigger in A throws B away (its count is drained, not read).
+  const bool async = (bool)count.begin && (bool)count.end;
+  struct Blk { GlibcRand rng0, rng1; std::vector<unsigned> ptr0, ptr1; unsigned nb = 0; int slot = 0; };
+  Blk blk[2];
+  std::vector<unsigned> pairs2[2];
+  if (async) { pairs2[0].resize((size_t)2 * BLOCK); pairs2[1].resize((size_t)2 * BLOCK); }
+  std::vector<unsigned> cnt_unused(async ? BLOCK : 0);
+  int pending[2] = {0, 0};                                     // blocks whose count has begun and not ended, per slot
+  auto issue = [&](const GlibcRand &r0, const std::vector<unsigned> &p0, unsigned no_sam, int slot) {
+    Blk &b = blk[slot];
+    b.slot = slot; b.rng0 = r0; b.ptr0 = p0;
+    b.nb = 2 * max_sam - no_sam;
+    if (b.nb > BLOCK) b.nb = BLOCK;
+    b.rng1 = r0; b.ptr1 = p0;
+    const double t0_ = rfth_prof_now();
+    for (unsigned s = 0; s < b.nb; s++) { draw(b.rng1, b.ptr1); pairs2[slot][2 * s] = b.ptr1[0]; pairs2[slot][2 * s + 1] = b.ptr1[1]; }
+    g_rfth_prof[0] += rfth_prof_now() - t0_; g_rfth_prof[2] += 1;
+    const double t1_ = rfth_prof_now();
+    count.begin(slot, pairs2[slot].data(), (int)b.nb, Ht);
+    g_rfth_prof[13] += rfth_prof_now() - t1_;
+    pending[slot] = 1;
+  };
+  auto drain = [&]() {                                         // counts nobody will read: waited for, so that their buffers are free
+    for (int q = 0; q < 2; q++) if (pending[q]) { count.end(q, (int)blk[q].nb, cnt_unused.data()); pending[q] = 0; }
+  };
   while (done.no_sam < 2 * max_sam) {
     LoopState w = done;
     std::vector<std::unique_ptr<Trigger>> trig_list;
+    int cur = 0;
+    bool have_cur = false;
     while (trig_list.size() < MAX_JOBS && w.no_sam < 2 * max_sam) {
       unsigned nb = 2 * max_sam - w.no_sam;
       if (nb > BLOCK) nb = BLOCK;
-      const GlibcRand rng0 = w.rng;
-      const std::vector<unsigned> ptr0 = w.ptr;
+      GlibcRand rng0 = w.rng;
+      std::vector<unsigned> ptr0 = w.ptr;
       const double tq0 = rfth_prof_now();
+      if (async) {
+        if (!have_cur) issue(w.rng, w.ptr, w.no_sam, cur);
+        Blk &A = blk[cur];
+        nb = A.nb; rng0 = A.rng0; ptr0 = A.ptr0;
+        bool have_next = false;
+        if (w.no_sam + A.nb < 2 * max_sam) { issue(A.rng1, A.ptr1, w.no_sam + A.nb, cur ^ 1); have_next = true; }
+        const double tq1 = rfth_prof_now();
+        count.end(cur, (int)nb, cnt.data()); pending[cur] = 0;
+        g_rfth_prof[1] += rfth_prof_now() - tq1;
+        w.rng = A.rng1; w.ptr = A.ptr1;                        // the state behind the block (what the synchronous loop holds here)
+        unsigned trig0 = nb;
+        for (unsigned s = 0; s < nb; s++)
+          if (cnt[s] > w.m_i) { trig0 = s; break; }
+        if (trig0 == nb) { w.no_sam += nb; cur ^= 1; have_cur = have_next; continue; }
+        drain(); have_cur = false;                             // the block drawn ahead starts behind a sample that is not the last one now
+      } else {
       for (unsigned s = 0; s < nb; s++) {
         draw(w.rng, w.ptr);
-        candidate(w.ptr[0], w.ptr[1], &Fs[9 * s]);
+        if (by_index) { pairs[2 * s] = w.ptr[0]; pairs[2 * s + 1] = w.ptr[1]; }
+        else candidate(w.ptr[0], w.ptr[1], &Fs[9 * s]);
       }
       const double tq1 = rfth_prof_now();
       g_rfth_prof[0] += tq1 - tq0; g_rfth_prof[2] += 1;
-      if (count) { count(Fs.data(), (int)nb, cnt.data()); g_rfth_prof[1] += rfth_prof_now() - tq1; }
+      if (by_index) { count.by_index(pairs.data(), (int)nb, Ht, cnt.data()); g_rfth_prof[1] += rfth_prof_now() - tq1; }
+      else if (count.by_matrix) { count.by_matrix(Fs.data(), (int)nb, cnt.data()); g_rfth_prof[1] += rfth_prof_now() - tq1; }
       else {
         FDs_all(uN.data(), Fs.data(), Ds.data(), (int)nN);
         unsigned c = 0;
         for (unsigned i = 0; i < nN; ++i) if (Ds[i] < th * 2) ++c;
         cnt[0] = c;
+      }
       }
       unsigned trig = nb;
       for (unsigned s = 0; s < nb; s++)
@@ -1130,6 +1194,7 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
         w.rng = rng0; w.ptr = ptr0;
         for (unsigned s = 0; s <= trig; s++) draw(w.rng, w.ptr);
       }
+      const double t_trig = rfth_prof_now();
       w.no_sam += trig;          // loop variable value while sample `trig` is processed
       double aFt[9];
       candidate(w.ptr[0], w.ptr[1], aFt);
@@ -1145,7 +1210,9 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
       w.no_sam += 1;             // ++no_sam of the for statement
       t->after = w;
       trig_list.push_back(std::move(t));
+      g_rfth_prof[11] += rfth_prof_now() - t_trig;
     }
+    drain();                                   // (a block drawn ahead of the last trigger or of the budget's end)
     if (trig_list.empty()) return leave();     // the budget ran out without another trigger
     {
       const double t_ = rfth_prof_now();
@@ -1155,6 +1222,8 @@ static inline unsigned rFtH(GlibcRand &rng, const double *u, const unsigned char
       g_rfth_prof[4] += rfth_prof_now() - t_;
     }
     g_rfth_prof[9] += 1;
+    const double t_fold = rfth_prof_now();
+    struct FoldTime { double t0; ~FoldTime() { g_rfth_prof[12] += rfth_prof_now() - t0; } } fold_time{t_fold};
     for (size_t ti = 0; ti < trig_list.size(); ti++) {
       auto &t = trig_list[ti];
       if (!(t->no_sam_at < 2 * max_sam)) { g_rfth_prof[8] += (double)(trig_list.size() - ti); return leave(); }   // an earlier result had ended the loop before this sample

@@ -17,8 +17,11 @@ struct RansacGpu {
   bool counts_dirty = false;                            // a scoring round did not complete: counts_dev is cleared before the next one
   double *row_host = nullptr; size_t row_cap = 0;
   double *aux_dev = nullptr; size_t aux_cap = 0;        // second point set (off-plane correspondences of rFtH)
-  double *cand_dev = nullptr, *cand_host = nullptr;     // two-point candidates of rFtH (9 doubles each) and their counts
+  // two-point candidates of rFtH as index pairs and their counts: two slots of cand_cap candidates each (a block is counted while
+  // the next one is drawn), an event per slot behind its count's copy back
+  unsigned int *cand_dev = nullptr, *cand_host = nullptr;
   int *candc_dev = nullptr, *candc_host = nullptr; int cand_cap = 0;
+  hipEvent_t cand_ev[2] = {nullptr, nullptr};
   double score_ms = 0; long launches = 0;
   ~RansacGpu();
 };
