@@ -146,7 +146,7 @@ RansacGpu::~RansacGpu() {
   (void)hipFree(u_dev); (void)hipFree(hyp_dev); (void)hipHostFree(hyp_host); (void)hipFree(d_dev); (void)hipFree(gain_dev);
   (void)hipFree(J_dev); (void)hipHostFree(J_host);   // (the counts live behind the J values in the same allocations)
   (void)hipHostFree(row_host); (void)hipFree(aux_dev);
-  (void)hipHostFree(cand_host); (void)hipHostFree(candc_host);   // (cand_dev / candc_dev are their device addresses)
+  (void)hipHostFree(cand_host); (void)hipHostFree(candc_host); (void)hipHostFree(cntf_host); (void)hipHostFree(cntc_host);   // (cand_dev / candc_dev are their device addresses)
   for (int q = 0; q < 2; q++) if (cand_ev[q]) (void)hipEventDestroy(cand_ev[q]);
   if (stream) (void)hipStreamDestroy(stream);
 }

@@ -122,6 +122,30 @@ __global__ void __launch_bounds__(256) ransacf_count_pairs_kernel(const double *
   if (threadIdx.x == 0) counts[k] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
 }
 
+// counts[k * COUNT_PARTS + part] = #{i in the part : FDs(u_i, F_k) < limit} over ALL correspondences of the run, for the k models of
+// innerFH's samples at once (DegUtils.c:476-584 evaluates them one after the other): grid = (k, COUNT_PARTS); Fs and counts are
+// mapped host memory (a few KB each way), the parts are added on the host.
+constexpr int COUNT_PARTS = 4;
+__global__ void __launch_bounds__(256) ransacf_count_models_kernel(const double *__restrict__ u, int len, const double *__restrict__ Fs, double limit,
+                                                                   int *__restrict__ counts) {
+  __shared__ double F[9];
+  __shared__ int s_c[4];
+  const int k = blockIdx.x;
+  if (threadIdx.x < 9) F[threadIdx.x] = Fs[(size_t)k * 9 + threadIdx.x];
+  __syncthreads();
+  int c = 0;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < len; i += 256 * COUNT_PARTS) {
+    double uu[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) uu[q] = u[(size_t)i * 6 + q];
+    c += fds_from(uu, F) < limit ? 1 : 0;
+  }
+  for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[k * COUNT_PARTS + blockIdx.y] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+
 static bool gpu_score_f(RansacGpu *ws, int len, int n, int err_type, int do_sym, double th, double th_check) {
   // (device counters: zero on entry, read out to the host's pinned result block and cleared again by ransac_gain_kernel; ransac.hip)
   if (!ransac_counts_begin(ws)) return false;
@@ -204,6 +228,30 @@ static bool gpu_count_pairs_begin(RansacGpu *ws, int slot, unsigned n, const uns
                      (const unsigned int *)(ws->cand_dev + (size_t)slot * 2 * ws->cand_cap), ht, limit, ws->candc_dev + (size_t)slot * ws->cand_cap);
   RS_CHECK(hipGetLastError());
   RS_CHECK(hipEventRecord(ws->cand_ev[slot], ws->stream));
+  ws->launches += 1;
+  return true;
+}
+// the models of one round of innerFH samples counted over the run's correspondences (ws->u_dev), see ransacf_count_models_kernel
+static bool gpu_count_models(RansacGpu *ws, int len, const double *Fs, int k, double limit, unsigned *counts) {
+  if (k > ws->cntf_cap) {
+    if (ws->cntf_host) { RS_CHECK(hipHostFree(ws->cntf_host)); RS_CHECK(hipHostFree(ws->cntc_host)); }
+    const int cap = k > 256 ? k : 256;
+    ws->cntf_cap = cap;
+    RS_CHECK(hipHostMalloc(&ws->cntf_host, sizeof(double) * 9 * cap, hipHostMallocMapped));
+    RS_CHECK(hipHostMalloc(&ws->cntc_host, sizeof(int) * COUNT_PARTS * cap, hipHostMallocMapped));
+    RS_CHECK(hipHostGetDevicePointer((void **)&ws->cntf_dev, ws->cntf_host, 0));
+    RS_CHECK(hipHostGetDevicePointer((void **)&ws->cntc_dev, ws->cntc_host, 0));
+  }
+  memcpy(ws->cntf_host, Fs, sizeof(double) * 9 * k);
+  hipLaunchKernelGGL(ransacf_count_models_kernel, dim3(k, COUNT_PARTS), dim3(256), 0, ws->stream, (const double *)ws->u_dev, len, (const double *)ws->cntf_dev,
+                     limit, ws->cntc_dev);
+  RS_CHECK(hipGetLastError());
+  RS_CHECK(mods::stream_wait(ws->stream));
+  for (int j = 0; j < k; j++) {
+    int c = 0;
+    for (int q = 0; q < COUNT_PARTS; q++) c += ws->cntc_host[j * COUNT_PARTS + q];
+    counts[j] = (unsigned)c;
+  }
   ws->launches += 1;
   return true;
 }
@@ -482,6 +530,9 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
   // O(len) evaluations of one model (LO steps, degenerate branch): host SIMD across the correspondences
   SimdEval simd_eval(u, len);
   rs::PointEval *ev = &simd_eval;
+  simd_eval.count_fds = [&](const double *Fs, int k, double limit, unsigned *counts) {
+    if (!gpu_count_models(ws, len, Fs, k, limit, counts)) F_FATAL();
+  };
   auto eval_fds = [&](const double *Fm, double *dd) {
     if (FDS1 == &FDs) ev->fds(Fm, dd);
     else if (FDS1 == &FDsSym) ev->fds_sym(Fm, dd);

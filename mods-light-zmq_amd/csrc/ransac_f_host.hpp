@@ -562,6 +562,10 @@ struct PointEval {
   virtual void exfds(const double *F, double *p, double *w) { exFDs_all(u, F, p, w, len); }
   virtual void exfds_sym(const double *F, double *p, double *w) { exFDsSym_all(u, F, p, w, len); }
   virtual bool concurrent() const { return true; }   // may several threads evaluate through this object at once?
+  // optional: counts[j] = #{i : FDs(u_i, F_j) < th} for k matrices (k x 9) in one go - set by a caller that can count many models
+  // at once cheaper than one evaluation each (ransac_f.hip: one launch over the resident correspondences); called from the thread
+  // that owns the run only.  Unset: every model is evaluated through fds().
+  std::function<void(const double *Fs, int k, double th, unsigned *counts)> count_fds;
 };
 
 // Hdetect, DegUtils.c:93-156: homography compatible with F through three correspondences
@@ -929,23 +933,29 @@ struct InnerFHJob {
     }
   }
   int n_eval() const { return (int)reps.size(); }
-  void eval(int r) {
+  // eval(r) = fit(r) + mask(r); with the counts of all samples made elsewhere (PointEval::count_fds) a repetition's mask is only made
+  // when it is refined - fold() reads the mask of a repetition only if its count beat every earlier one's, which is mark()'s rule
+  void fit(int r) {
     Rep &R = reps[r];
-    static thread_local std::vector<double> Ds;   // (see u2Fit)
-    if (Ds.size() < len) Ds.resize(len);
     std::vector<double> buffer((size_t)9 * ns + 96);
     std::vector<int> allInl(ns);
     for (unsigned i = 0; i < ns; ++i) allInl[i] = (int)i;
     u2f(R.usam.data(), allInl.data(), (int)ns, R.aF, buffer.data());
+  }
+  void mask(int r) {
+    Rep &R = reps[r];
+    static thread_local std::vector<double> Ds;   // (see u2Fit)
+    if (Ds.size() < len) Ds.resize(len);
     ev->fds(R.aF, Ds.data());
     R.v.resize(len);
     unsigned no_i = 0;
     for (unsigned i = 0; i < len; ++i) {
-      if (Ds[i] < th) { R.v[i] = 1; ++no_i; }
-      else R.v[i] = 0;
+      const unsigned char in = Ds[i] < th ? 1 : 0;
+      R.v[i] = in; no_i += in;
     }
     R.no_i = no_i;
   }
+  void eval(int r) { fit(r); mask(r); }
   void mark() {
     unsigned max_s = 0;
     todo.clear();
@@ -955,6 +965,7 @@ struct InnerFHJob {
   int n_refine() const { return (int)todo.size(); }
   void refine(int t) {
     Rep &R = reps[todo[t]];
+    if (R.v.empty()) mask(todo[t]);                 // (counted elsewhere: same count, now with the mask)
     R.v2 = R.v;
     std::memcpy(R.aF2, R.aF, sizeof(R.aF));
     R.no_2 = u2Fit(*ev, R.aF2, R.v2.data(), th, th * 3, 4, want_prof ? R.prof : nullptr);
@@ -990,7 +1001,18 @@ static inline void run_innerFH_jobs(InnerFHJob *const *jobs, int n, bool paralle
   for (int j = 0; j < n; j++)
     for (int r = 0; r < jobs[j]->n_eval(); r++) work.push_back({j, r});
   const double t0_ = rfth_prof_now();
-  for_each((int)work.size(), [&](int i) { jobs[work[i].first]->eval(work[i].second); });
+  PointEval *ev0 = n ? jobs[0]->ev : nullptr;
+  bool counted_elsewhere = ev0 && (bool)ev0->count_fds;
+  for (int j = 1; j < n && counted_elsewhere; j++) counted_elsewhere = jobs[j]->ev == ev0 && jobs[j]->th == jobs[0]->th;
+  if (counted_elsewhere) {
+    for_each((int)work.size(), [&](int i) { jobs[work[i].first]->fit(work[i].second); });
+    std::vector<double> Fs((size_t)9 * work.size());
+    std::vector<unsigned> cnt(work.size());
+    for (size_t i = 0; i < work.size(); i++) std::memcpy(&Fs[9 * i], jobs[work[i].first]->reps[work[i].second].aF, 9 * sizeof(double));
+    ev0->count_fds(Fs.data(), (int)work.size(), jobs[0]->th, cnt.data());
+    for (size_t i = 0; i < work.size(); i++) jobs[work[i].first]->reps[work[i].second].no_i = cnt[i];
+  } else
+    for_each((int)work.size(), [&](int i) { jobs[work[i].first]->eval(work[i].second); });
   const double t1_ = rfth_prof_now();
   g_rfth_prof[14] += t1_ - t0_;
   work.clear();

@@ -22,6 +22,9 @@ struct RansacGpu {
   unsigned int *cand_dev = nullptr, *cand_host = nullptr;
   int *candc_dev = nullptr, *candc_host = nullptr; int cand_cap = 0;
   hipEvent_t cand_ev[2] = {nullptr, nullptr};
+  // models counted over all correspondences in one launch (innerFH's samples): k x 9 doubles in, k x COUNT_PARTS partial counts out,
+  // both in mapped host memory
+  double *cntf_host = nullptr, *cntf_dev = nullptr; int *cntc_host = nullptr, *cntc_dev = nullptr; int cntf_cap = 0;
   double score_ms = 0; long launches = 0;
   ~RansacGpu();
 };
