@@ -499,7 +499,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
 
   const bool prof = ransac_profile_on();   // MODS_RANSAC_PROF
   const double t_begin = prof ? wall_ms() : 0;
-  double t_innerh = 0, t_rfth = 0, t_lo = 0;
+  double t_innerh = 0, t_rfth = 0, t_lo = 0, t_gen = 0, t_score = 0, t_setup = 0;
   const long pinned = ransac_pinned_seed();
   rs::GlibcRand rng, gen;
   rng.seed((unsigned)(pinned >= 0 ? (time_t)pinned : time(NULL)));   // srand(time(NULL)), exp_ranF.c:832
@@ -586,7 +586,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
     int slot[3];       // scored slot, -1 = rejected by the orientation constraint
   };
   std::vector<Sample> batch;
-  int batch_size = 32;
+  int batch_size = 8;            // (the first round trip is the latency of an easy pair: 24 candidates instead of 96; doubles per batch up to 512)
   int tag[4] = {-1, -1, -1, -1};   // per error buffer: batch slot of the candidate last evaluated into it (-1: content is on the host)
   bool rng_live = true;          // does `rng` hold the generator state the reference has at this point?
   unsigned live_seed = 0;
@@ -597,6 +597,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
     rng_live = true;
   };
 
+  if (prof) t_setup = wall_ms() - t_begin;
   while (no_sam < max_sam) {
     int want = batch_size;
     if (want > max_sam - no_sam) want = max_sam - no_sam;
@@ -604,6 +605,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
     if (!ransac_ws_reserve(ws, len, 3 * want)) F_FATAL();
     HypF *hyp_host = (HypF *)ws->hyp_host;
     int n_hyp = 0;
+    const double tg0 = prof ? wall_ms() : 0;
     for (int b = 0; b < want; b++) {
       Sample &sm = batch[b];
       sm.seed_before = seed;
@@ -636,6 +638,8 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
         sm.slot[i] = n_hyp++;
       }
     }
+    const double tg1 = prof ? wall_ms() : 0;
+    t_gen += tg1 - tg0;
     std::vector<double> host_d;
     if (n_hyp > 0) {
       if (err_type < 0) {
@@ -650,6 +654,7 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
         }
       } else if (!gpu_score_f(ws, len, n_hyp, err_type, doSymCheck, th, th_check)) F_FATAL();
     }
+    if (prof) t_score += wall_ms() - tg1;
     std::vector<int> cnt(ws->counts_host, ws->counts_host + 2 * n_hyp);
     std::vector<double> Jv(ws->J_host, ws->J_host + n_hyp);
     auto fetch_row = [&](int slot, double *dst) {
@@ -779,8 +784,8 @@ static int ransac_f_run(double *u, int len, double th, double conf, int max_sam,
   data_out[0] = no_sam;
   data_out[1] = iter_cnt;
   if (prof) { fprintf(stderr, "[mods ransacF] rFtH: candidates %.2f ms, counting %.2f ms, %.0f blocks, %.0f off-plane; innerFH %.0f calls (+%.0f run ahead and dropped) in %.0f rounds %.2f ms on %d threads, %.0f fits in u2Fit %.2f thread-ms; set-up %.2f ms, triggers %.2f ms, folding %.2f ms, count launches %.2f ms, innerFH stages %.2f + %.2f ms\n", rs::g_rfth_prof[0], rs::g_rfth_prof[1], rs::g_rfth_prof[2], rs::g_rfth_prof[3], rs::g_rfth_prof[6], rs::g_rfth_prof[8], rs::g_rfth_prof[9], rs::g_rfth_prof[4], rs::TaskPool::get().threads(), rs::g_rfth_prof[7], rs::g_rfth_prof[5], rs::g_rfth_prof[10], rs::g_rfth_prof[11], rs::g_rfth_prof[12], rs::g_rfth_prof[13], rs::g_rfth_prof[14], rs::g_rfth_prof[15]); for (double &x : rs::g_rfth_prof) x = 0; }
-  if (prof) fprintf(stderr, "[mods ransacF] len %d samples %d lo %d degen %d | total %.2f ms: innerH %.2f rFtH %.2f LO %.2f\n", len, no_sam, iter_cnt,
-                    degen_cnt, wall_ms() - t_begin, t_innerh, t_rfth, t_lo);
+  if (prof) fprintf(stderr, "[mods ransacF] len %d samples %d lo %d degen %d | total %.2f ms: set-up %.2f samples %.2f scoring %.2f innerH %.2f rFtH %.2f LO %.2f\n", len, no_sam, iter_cnt,
+                    degen_cnt, wall_ms() - t_begin, t_setup, t_gen, t_score, t_innerh, t_rfth, t_lo);
   if (Ih) *Ih = Ihmax;
   return (int)maxS.I;
 }

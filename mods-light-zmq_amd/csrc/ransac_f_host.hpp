@@ -884,19 +884,27 @@ static inline unsigned u2Fit(PointEval &ev, double *F, unsigned char *inl, doubl
 // dual_sample, DegUtils.c:587-626: sA correspondences of uA and sB of uB (shuffles with repetition of
 // positions, as the reference does)
 static inline void dual_sample(GlibcRand &rng, const double *uA, unsigned lenA, unsigned sA, const double *uB, unsigned lenB, unsigned sB, double *usam) {
-  std::vector<unsigned> ptrA(lenA), ptrB(lenB);
-  for (unsigned i = 0; i < lenA; ++i) ptrA[i] = i;
-  for (unsigned i = 0; i < lenB; ++i) ptrB[i] = i;
-  for (unsigned pos = 0; pos < sA; ++pos) {
-    const unsigned idx = (unsigned)rng.next() % lenA;
-    const unsigned t = ptrA[pos]; ptrA[pos] = ptrA[idx]; ptrA[idx] = t;
-  }
-  for (unsigned pos = 0; pos < sB; ++pos) {
-    const unsigned idx = (unsigned)rng.next() % lenB;
-    const unsigned t = ptrB[pos]; ptrB[pos] = ptrB[idx]; ptrB[idx] = t;
-  }
-  for (unsigned i = 0; i < sA; ++i) std::memcpy(usam + 6 * i, uA + 6 * ptrA[i], 6 * sizeof(double));
-  for (unsigned i = 0; i < sB; ++i) std::memcpy(usam + 6 * (i + sA), uB + 6 * ptrB[i], 6 * sizeof(double));
+  // the reference starts every call from two identity permutations of lenA and lenB entries and swaps sA + sB positions in them:
+  // the identity lives across calls per thread (a call of innerFH makes 15 samples out of ~22 000 on-plane correspondences - 1.4 MB
+  // of index writes for 150 swaps), and only the touched entries are put back
+  static thread_local std::vector<unsigned> ident;
+  const unsigned need = lenA > lenB ? lenA : lenB;
+  if (ident.size() < need) { const size_t old_n = ident.size(); ident.resize(need); for (size_t i = old_n; i < need; ++i) ident[i] = (unsigned)i; }
+  unsigned *ptr = ident.data();
+  unsigned touched[64];
+  auto draw_from = [&](const double *src, unsigned len, unsigned n, double *dst) {
+    unsigned nt = 0;
+    for (unsigned pos = 0; pos < n; ++pos) {
+      const unsigned idx = (unsigned)rng.next() % len;
+      const unsigned t = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = t;
+      if (nt + 2 <= 64) { touched[nt++] = pos; touched[nt++] = idx; }
+    }
+    for (unsigned i = 0; i < n; ++i) std::memcpy(dst + 6 * i, src + 6 * ptr[i], 6 * sizeof(double));
+    if (n <= 32) for (unsigned i = 0; i < nt; ++i) ptr[touched[i]] = touched[i];
+    else for (unsigned i = 0; i < len; ++i) ptr[i] = i;
+  };
+  draw_from(uA, lenA, sA, usam);
+  draw_from(uB, lenB, sB, usam + 6 * sA);
 }
 
 // innerFH, DegUtils.c:476-584: F from sam_sizH on-plane + sam_sizO off-plane correspondences, repCount times.

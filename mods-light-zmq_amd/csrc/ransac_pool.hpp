@@ -4,10 +4,11 @@
 // would have produced - only sooner.  The reference runs all of it on one core (DegUtils.c:233-584).
 //
 // One pool per process, started on first use: MODS_RANSAC_THREADS threads in total with the caller (default: the cores this
-// process may use - affinity mask and cgroup quota - capped at 24; 1 = everything inline).  Round 6, 4096 x 4096 planar pair, 23 545
+// process may use - affinity mask and cgroup quota - capped at 16; 1 = everything inline).  Round 6, 4096 x 4096 planar pair, 23 545
 // correspondences (profiles/r06_degensac_pool.log): the degenerate branch's 105 sample evaluations and ~20 refinements per round of
 // triggers are throughput work - 8 / 12 / 16 threads: innerFH 13.0 / 8.9 / 6.8 ms, the whole call 25.0 / 19.8 / 17.3 ms; with the samples' counts made on the device the ~20 refinements of a
-// round are what is left, one wave on 24 threads: 16 / 24 threads: innerFH 5.2 / 4.1 ms, the whole call 12.7 / 12.2 ms.  A caller that finds the pool
+// round are what is left: 16 / 24 threads: innerFH 5.2 / 4.1-5.5 ms, the whole call 12.0-12.7 / 11.2-13.8 ms over four leases - no
+// gain that repeats, so the cap stays at 16.  A caller that finds the pool
 // taken (several verification threads in a pipeline) runs its tasks inline: the pool never queues and never oversubscribes.
 #pragma once
 #include <pthread.h>
@@ -80,7 +81,7 @@ class TaskPool {
   TaskPool() {
     const char *e = getenv("MODS_RANSAC_THREADS");
     int n = e ? atoi(e) : usable_cores();
-    if (!e && n > 24) n = 24;
+    if (!e && n > 16) n = 16;
     n_threads_ = n < 1 ? 1 : n;
   }
   static void cpu_relax() { __builtin_ia32_pause(); }
