@@ -215,8 +215,9 @@ static bool gpu_count_pairs_begin(RansacGpu *ws, int slot, unsigned n, const uns
     ws->cand_cap = cap;
     // both in pinned host memory the kernel addresses itself (16 KB of index pairs in, 8 KB of counts out per block): a block of
     // candidates is ONE launch and one event, no copies to queue - the calls, not the work, were the cost of a block here
-    RS_CHECK(hipHostMalloc(&ws->cand_host, sizeof(unsigned) * 2 * 2 * cap, hipHostMallocMapped));
-    RS_CHECK(hipHostMalloc(&ws->candc_host, sizeof(int) * 2 * cap, hipHostMallocMapped));
+    // (coherent: what the kernel writes is in host memory when its event has completed, whatever HIP_HOST_COHERENT says)
+    RS_CHECK(hipHostMalloc(&ws->cand_host, sizeof(unsigned) * 2 * 2 * cap, hipHostMallocMapped | hipHostMallocCoherent));
+    RS_CHECK(hipHostMalloc(&ws->candc_host, sizeof(int) * 2 * cap, hipHostMallocMapped | hipHostMallocCoherent));
     RS_CHECK(hipHostGetDevicePointer((void **)&ws->cand_dev, ws->cand_host, 0));
     RS_CHECK(hipHostGetDevicePointer((void **)&ws->candc_dev, ws->candc_host, 0));
   }
@@ -237,8 +238,8 @@ static bool gpu_count_models(RansacGpu *ws, int len, const double *Fs, int k, do
     if (ws->cntf_host) { RS_CHECK(hipHostFree(ws->cntf_host)); RS_CHECK(hipHostFree(ws->cntc_host)); }
     const int cap = k > 256 ? k : 256;
     ws->cntf_cap = cap;
-    RS_CHECK(hipHostMalloc(&ws->cntf_host, sizeof(double) * 9 * cap, hipHostMallocMapped));
-    RS_CHECK(hipHostMalloc(&ws->cntc_host, sizeof(int) * COUNT_PARTS * cap, hipHostMallocMapped));
+    RS_CHECK(hipHostMalloc(&ws->cntf_host, sizeof(double) * 9 * cap, hipHostMallocMapped | hipHostMallocCoherent));
+    RS_CHECK(hipHostMalloc(&ws->cntc_host, sizeof(int) * COUNT_PARTS * cap, hipHostMallocMapped | hipHostMallocCoherent));
     RS_CHECK(hipHostGetDevicePointer((void **)&ws->cntf_dev, ws->cntf_host, 0));
     RS_CHECK(hipHostGetDevicePointer((void **)&ws->cntc_dev, ws->cntc_host, 0));
   }
