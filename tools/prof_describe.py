@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Detect + orient + describe of one batch of 16 synthetic 1080p images (the pipeline's batching), a few repetitions on one
-stream: the workload of the describe-stage profiles (tools/refresh_profiles.sh)."""
+"""Detect + orient + describe of one batch of 16 synthetic 1080p images (the unit of rounds 2-5; `prof_describe.py 32` = the launch size
+of the round-6 pipeline), a few repetitions on one stream: the workload of the describe-stage profiles (tools/refresh_profiles.sh)."""
 import os
 import sys
 
@@ -12,7 +12,7 @@ import __graft_entry__ as ge
 import synth
 
 pkg = ge.load_package()
-W, H, B = 1920, 1080, 16
+W, H, B = 1920, 1080, (int(sys.argv[1]) if len(sys.argv) > 1 else 16)
 imgs = []
 for i in range(B // 2):
     a, b, _ = synth.pair(W, H, seed=2000 + (i % 2))
